@@ -1,0 +1,153 @@
+/*
+ * naf_hip.h — C ABI of libnaf_hip.so: the MI355X (gfx950) NAF learn()/replay hot path.
+ *
+ * The reference (JavierMtz5/robotic_manipulator_rloa) is pure Python and has NO FFI/plugin
+ * interface; its hot path is a chain of stock torch ops. Each entry point below replaces one such
+ * chain, cited as file:line relative to the reference checkout. The Python host
+ * (robotic_manipulator_rloa_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - Every data pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()),
+ *     f32 unless stated otherwise. Nothing is allocated after naf_replay_create().
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Every call only enqueues
+ *     work on `stream` and returns; no call synchronises, so all of them are HIP-graph capturable.
+ *   - Return value: 0 = NAF_OK, <0 = argument/state error (NAF_ERR_*), >0 = hipError_t.
+ *   - A = action size, 1 <= A <= 8.  T = A(A+1)/2.  "heads row" = [mu_pre(A) | l_pre(T) | V(1)],
+ *     row stride ldh >= A+T+1 floats; l_pre is the row-major lower triangle
+ *     (0,0),(1,0),(1,1),(2,0)... exactly as torch.tril_indices orders it
+ *     (naf_components/naf_neural_network.py:98-100).
+ *   - "transition row" = [state(S) | action(A) | reward | next_state(S) | done | 0-pad], padded to
+ *     naf_replay_row_floats(S,A) floats (64 for A<=8: 256 B = two 128-B lines), the layout of both the
+ *     HBM ring and of gathered minibatches.
+ */
+#ifndef NAF_HIP_H
+#define NAF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAF_OK 0
+#define NAF_ERR_ARG (-1)
+#define NAF_ERR_STATE (-2)
+
+/* P = L (*) L^T elementwise — what the reference computes (naf_neural_network.py:104) */
+#define NAF_P_HADAMARD 0
+/* P = L @ L^T — textbook NAF (Gu et al. 2016) */
+#define NAF_P_MATMUL 1
+
+/* stored action is truncated toward zero on gather: the reference's `.long()` (utils/replay_buffer.py:60) */
+#define NAF_ACTION_TRUNC_INT 0
+#define NAF_ACTION_FLOAT 1
+
+typedef struct naf_replay naf_replay_t;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int naf_hip_abi_version(void);
+/* "gfx950" — the only architecture this library carries code objects for */
+const char* naf_hip_arch(void);
+
+/* ---- replay buffer: HBM ring of transition rows ------------------------------------------ */
+/* replaces ReplayBuffer.__init__ (utils/replay_buffer.py:16-30): deque(maxlen=buffer_size) */
+int naf_replay_row_floats(int S, int A);
+/* `rows` : capacity * row_floats f32 (caller-owned device memory)
+ * `meta` : 8 x uint64 device words {head, size, total_added, sample_counter, 0,0,0, bad_index_count},
+ *          zero-initialised by the caller. */
+int naf_replay_create(uint64_t capacity, int S, int A, float* rows, uint64_t* meta, naf_replay_t** out);
+int naf_replay_destroy(naf_replay_t* h);
+/* replaces ReplayBuffer.add (replay_buffer.py:32-45) for n transitions at once: FIFO append with
+ * eviction of the oldest when full. `src_rows`: n packed transition rows on the device. n <= capacity. */
+int naf_replay_add_batch(naf_replay_t* h, const float* src_rows, int n, void* stream);
+/* replaces `random.sample(self.memory, k)` (replay_buffer.py:55): n_batches independent minibatches of
+ * B deque positions (0 = oldest), uniform over the current size, without replacement inside a
+ * minibatch when `without_replacement` != 0 (and size >= B). Philox4x32-10 keyed by `seed`; stream position
+ * = *counter_dev + counter_off + minibatch (counter_dev may be NULL). idx: n_batches*B int32. */
+int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const uint64_t* counter_dev, uint64_t counter_off,
+                              int32_t* idx, int B, int n_batches, int without_replacement, void* stream);
+/* replaces the np.stack/vstack + from_numpy + .to(device) chain (replay_buffer.py:57-65):
+ * out_rows[n][row_floats] = ring[deque position idx[i]], actions truncated when action_mode == TRUNC_INT. */
+int naf_replay_gather_rows(naf_replay_t* h, const int32_t* idx, float* out_rows, int n, int action_mode,
+                           void* stream);
+/* same, to the reference's five separate tensors (states[n,S], actions[n,A], rewards[n], next_states[n,S],
+ * dones[n]) — the ReplayBuffer.sample() return contract (replay_buffer.py:67). */
+int naf_replay_gather_soa(naf_replay_t* h, const int32_t* idx, float* s, float* u, float* r, float* s2,
+                          float* d, int n, int action_mode, void* stream);
+/* *p += inc on the device (1 thread): advances sampler / noise stream counters inside a graph */
+int naf_counter_add(uint64_t* p, uint64_t inc, void* stream);
+
+/* ---- NAF head ------------------------------------------------------------------------------ */
+/* replaces naf_neural_network.py:81-115 after the three head Linears: tanh(mu), tanh(l), tril scatter,
+ * exp on the diagonal, P, Q = V - 1/2 d^T P d with d = u - mu.  u rows: u + i*ldu. q: B floats. */
+int naf_head_fwd(const float* heads_pre, int ldh, const float* u, int ldu, float* q, float* mu_out /*nullable, B*A*/,
+                 int B, int A, int p_mode, void* stream);
+/* autograd of the above (implicit in loss.backward(), naf_algorithm.py:208): given dq[B] = dLoss/dQ,
+ * d_heads[B][ldh] = dLoss/d(heads_pre) (pad columns written as 0). */
+int naf_head_bwd(const float* heads_pre, int ldh, const float* u, int ldu, const float* dq, float* d_heads,
+                 int B, int A, int p_mode, void* stream);
+/* fused learn() middle (naf_algorithm.py:199-208): y = r + gamma * v_next; Q as above;
+ * loss = mean((Q - y)^2); d_heads = dLoss/d(heads_pre).  r: r[i*ldr], v_next: v_next[i*ldv].
+ * loss_partials[ceil(B/32)]: per-workgroup sums of (Q-y)^2 / B, summed by the reader in index order
+ * (bitwise reproducible). q_out nullable. */
+int naf_head_fwd_bwd_mse(const float* heads_pre, int ldh, const float* u, int ldu, const float* r, int ldr,
+                         const float* v_next, int ldv, float gamma, float* q_out, float* d_heads,
+                         float* loss_partials, int B, int A, int p_mode, void* stream);
+/* replaces MultivariateNormal(mu, inverse(P)).sample() + clamp (naf_neural_network.py:119-121) for E
+ * states: action = clamp(mu + noise_scale * P^{-1/2} z, -1, 1), z ~ N(0, I) from Philox
+ * (seed, *counter_dev + counter_off, sample, lane). action_out: E x A. */
+int naf_act_noise(const float* heads_pre, int ldh, float* action_out, uint64_t seed, const uint64_t* counter_dev,
+                  uint64_t counter_off, float noise_scale, int E, int A, int p_mode, void* stream);
+
+/* ---- BatchNorm1d + ReLU around the trunk GEMMs ---------------------------------------------- */
+/* replaces `torch.relu(self.bnK(linear(x)))` minus the GEMM (naf_neural_network.py:76-78) in TRAINING mode
+ * for `nets` networks in one launch (net n uses pointer + n*stride): z = g + bias; batch mean / biased var;
+ * y = gamma*(z-mean)*invstd + beta; out = max(y,0); running stats updated with momentum and the unbiased
+ * variance (torch BatchNorm1d defaults, naf_neural_network.py:42,46). save_mean/save_invstd: [nets][H]. */
+int naf_bn_relu_fwd_train(const float* g, int64_t g_net_stride, int ldg, const float* bias, const float* gamma,
+                          const float* beta, int64_t param_net_stride, float* running_mean, float* running_var,
+                          int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo, float* save_mean,
+                          float* save_invstd, int B, int H, int nets, float momentum, float eps, void* stream);
+/* eval mode (NAFAgent.act, naf_algorithm.py:170-173): running statistics, no update */
+int naf_bn_relu_fwd_eval(const float* g, int ldg, const float* bias, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, float* out, int ldo, int B, int H,
+                         float eps, void* stream);
+/* backward of bn+relu in training mode: given d_out (grad w.r.t. the ReLU output), the forward's g/bias,
+ * out (ReLU mask), saved mean/invstd: d_z[B][ldd], d_gamma[H], d_beta[H], d_bias[H] (= column sums of d_z). */
+int naf_bn_relu_bwd(const float* d_out, int ld_dout, const float* g, int ldg, const float* bias, const float* out,
+                    int ldo, const float* gamma, const float* save_mean, const float* save_invstd, float* d_z,
+                    int ldd, float* d_gamma, float* d_beta, float* d_bias, int B, int H, void* stream);
+
+/* ---- clip + Adam + Polyak over one flat parameter buffer -------------------------------------- */
+/* first half of clip_grad_norm_(params, 1) (naf_algorithm.py:209): partials[i] = sum of g^2 over chunk i of
+ * NAF_NORM_CHUNK floats; n_partials = ceil(n / NAF_NORM_CHUNK). If step_dev != NULL also does *step_dev += 1
+ * (the optimizer step count the following naf_adam_polyak_fused reads). */
+#define NAF_NORM_CHUNK 4096
+int naf_grad_norm_partials(const float* g, size_t n, float* partials, int32_t* step_dev, void* stream);
+/* second half of clip_grad_norm_ + Adam.step() (naf_algorithm.py:209-210) + soft_update (:217-226) in one
+ * pass over {theta, g, m, v, theta_target}: 36 B/param. grad = g * inv_world * clip, clip =
+ * min(1, max_norm / (inv_world*sqrt(sum partials) + 1e-6)); Adam with torch defaults' formulas and bias
+ * correction at t = *step_dev; theta_target = tau*theta_new + one_minus_tau*theta_target.
+ * theta_target may be NULL (no Polyak). */
+int naf_adam_polyak_fused(float* theta, const float* g, float* m, float* v, float* theta_target,
+                          const float* partials, int n_partials, float max_norm, float lr, float beta1, float beta2,
+                          float eps, float tau, float one_minus_tau, const int32_t* step_dev, float inv_world, size_t n,
+                          void* stream);
+/* NAFAgent.soft_update (naf_algorithm.py:217-226): target = tau*main + one_minus_tau*target, 12 B/param */
+int naf_polyak_update(float* target, const float* main, float tau, float one_minus_tau, size_t n, void* stream);
+
+/* ---- synthetic manipulator environment (stand-in for the PyBullet Environment) ---------------- */
+/* One step of E independent kinematic-chain arms on the device, emitting transition rows
+ * (environment/environment.py:431-485 state layout / reward constants); see csrc/synth_env.hip. */
+int naf_synth_env_step(float* env_state, const float* actions, float* out_rows, float* obs_next, int E, int A,
+                       uint64_t seed, const uint64_t* counter_dev, int max_frames, void* stream);
+int naf_synth_env_reset(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t counter, void* stream);
+int naf_synth_env_state_floats(int A);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAF_HIP_H */

@@ -1,0 +1,144 @@
+"""ctypes binding of libnaf_hip.so (include/naf_hip.h) — the only way the package reaches the HIP kernels.
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the caller gets a
+NafHipError. The library is built in-tree by `build_library()` (hipcc --offload-arch=gfx950), which
+__graft_entry__.build() calls; hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from typing import Optional
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
+SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "optim.hip", "synth_env.hip"]
+HEADERS = ["common.h", os.path.join("..", "..", "include", "naf_hip.h")]
+
+P_HADAMARD, P_MATMUL = 0, 1
+ACTION_TRUNC_INT, ACTION_FLOAT = 0, 1
+NORM_CHUNK = 4096
+
+
+class NafHipError(RuntimeError):
+    pass
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip into csrc/libnaf_hip.so for gfx950. Returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise NafHipError("hipcc not found: cannot build libnaf_hip.so")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-variable", "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise NafHipError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+_vp, _i, _f, _u64, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t, C.c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/naf_hip.h one to one
+_PROTOS = {
+    "naf_hip_abi_version": [],
+    "naf_hip_arch": [],
+    "naf_replay_row_floats": [_i, _i],
+    "naf_replay_create": [_u64, _i, _i, _vp, _vp, C.POINTER(_vp)],
+    "naf_replay_destroy": [_vp],
+    "naf_replay_add_batch": [_vp, _vp, _i, _vp],
+    "naf_replay_sample_indices": [_vp, _u64, _vp, _u64, _vp, _i, _i, _i, _vp],
+    "naf_replay_gather_rows": [_vp, _vp, _vp, _i, _i, _vp],
+    "naf_replay_gather_soa": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_counter_add": [_vp, _u64, _vp],
+    "naf_head_fwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "naf_head_bwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "naf_head_fwd_bwd_mse": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "naf_act_noise": [_vp, _i, _vp, _u64, _vp, _u64, _f, _i, _i, _i, _vp],
+    "naf_bn_relu_fwd_train": [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i,
+                              _f, _f, _vp],
+    "naf_bn_relu_fwd_eval": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "naf_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
+    "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
+    "naf_polyak_update": [_vp, _vp, _f, _f, _sz, _vp],
+    "naf_synth_env_step": [_vp, _vp, _vp, _vp, _i, _i, _u64, _vp, _i, _vp],
+    "naf_synth_env_reset": [_vp, _vp, _i, _i, _u64, _u64, _vp],
+    "naf_synth_env_state_floats": [_i],
+}
+_RESTYPES = {"naf_hip_arch": C.c_char_p}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def load(allow_build: bool = True) -> C.CDLL:
+    """Load libnaf_hip.so. `import torch` must already have happened in the process when tensors are going to be
+    passed, so the library binds to the same HIP runtime torch loaded (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _stale() and allow_build:
+        try:
+            build_library()
+        except NafHipError:
+            if not os.path.exists(LIB_PATH):
+                raise
+    if not os.path.exists(LIB_PATH):
+        raise NafHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                          "This package has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first)
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.naf_hip_abi_version() != 1:
+        raise NafHipError("libnaf_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code == 0:
+        return
+    if code < 0:
+        raise NafHipError(f"{what}: argument/state error {code}")
+    raise NafHipError(f"{what}: hipError_t {code}")
+
+
+def require_gpu() -> None:
+    import torch
+    if not torch.cuda.is_available():
+        raise NafHipError("no MI355X visible (torch.cuda.is_available() is False): the NAF hot path runs only on "
+                          "the GPU through libnaf_hip.so — there is no CPU fallback")
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    return t.data_ptr() if t is not None else None

@@ -1,0 +1,205 @@
+// BatchNorm1d (+ Linear bias, + ReLU) around the trunk GEMMs, gfx950. Replaces
+// `torch.relu(self.bnK(self.linear(x)))` minus the GEMM itself (naf_neural_network.py:76-78) in training
+// mode (batch statistics, running-stat update: the reference never puts either net in eval() inside
+// learn(), naf_algorithm.py:194-202), its autograd, and the eval-mode form used by act() (:170-173).
+//
+// Tile: a workgroup owns 32 feature columns x ALL B rows, so batch statistics never leave the workgroup
+// (no atomics, no second launch, fixed summation order). 32 x 32 threads: lane tx = column, ty = row
+// phase; a wave covers two rows x 32 columns = two 128-B lines per load instruction. Each thread keeps its
+// rows in registers (RPT = ceil(B/32) values), so the matrix is read once. The matrices here are
+// <= 2 MB and L2-resident between the producing GEMM and this kernel; the kernel is latency-bound, the
+// design goal is one pass and one launch for both networks.
+#include "common.h"
+#include "../../include/naf_hip.h"
+
+#define BN_TX 32
+#define BN_TY 32
+
+__device__ static inline float bn_col_reduce(float part, float (*red)[BN_TX + 1], int tx, int ty) {
+    __syncthreads();  // previous use of `red` is over
+    red[ty][tx] = part;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_TY; ++k) s += red[k][tx];
+    return s;
+}
+
+template <int RPT>
+__global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
+    const float* __restrict__ g, int64_t g_net_stride, int ldg, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int64_t param_net_stride,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out,
+    int64_t out_net_stride, int ldo, float* __restrict__ save_mean, float* __restrict__ save_invstd, int B, int H,
+    float momentum, float eps) {
+    __shared__ float red[BN_TY][BN_TX + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = blockIdx.x * BN_TX + tx;
+    const int net = blockIdx.y;
+    const bool col_on = col < H;
+    const float* gz = g + net * g_net_stride;
+    float* oz = out + net * out_net_stride;
+    const int64_t po = net * param_net_stride;
+    const float b = (bias && col_on) ? bias[po + col] : 0.f;
+
+    float x[RPT];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        x[k] = (col_on && row < B) ? gz[(int64_t)row * ldg + col] + b : 0.f;
+        sum += x[k];
+    }
+    const float mean = bn_col_reduce(sum, red, tx, ty) / (float)B;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        float dlt = (row < B) ? x[k] - mean : 0.f;
+        ss += dlt * dlt;
+    }
+    const float var = bn_col_reduce(ss, red, tx, ty) / (float)B;  // biased: what normalises
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float gm = col_on ? gamma[po + col] : 0.f;
+    const float bt = col_on ? beta[po + col] : 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        if (col_on && row < B) {
+            float y = (x[k] - mean) * invstd * gm + bt;
+            oz[(int64_t)row * ldo + col] = y > 0.f ? y : 0.f;
+        }
+    }
+    if (ty == 0 && col_on) {
+        const int64_t so = net * stat_net_stride + col;
+        const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+        running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
+        running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+        save_mean[(int64_t)net * H + col] = mean;
+        save_invstd[(int64_t)net * H + col] = invstd;
+    }
+}
+
+template <int RPT>
+__global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
+    const float* __restrict__ d_out, int ld_dout, const float* __restrict__ g, int ldg, const float* __restrict__ bias,
+    const float* __restrict__ out, int ldo, const float* __restrict__ gamma, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, float* __restrict__ d_z, int ldd, float* __restrict__ d_gamma,
+    float* __restrict__ d_beta, float* __restrict__ d_bias, int B, int H) {
+    __shared__ float red[BN_TY][BN_TX + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = blockIdx.x * BN_TX + tx;
+    const bool col_on = col < H;
+    const float b = (bias && col_on) ? bias[col] : 0.f;
+    const float mean = col_on ? save_mean[col] : 0.f;
+    const float invstd = col_on ? save_invstd[col] : 0.f;
+    const float gm = col_on ? gamma[col] : 0.f;
+
+    float xh[RPT], dy[RPT];
+    float s_dy = 0.f, s_dyxh = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        bool on = col_on && row < B;
+        float z = on ? g[(int64_t)row * ldg + col] + b : 0.f;
+        float o = on ? out[(int64_t)row * ldo + col] : 0.f;
+        float dd = on ? d_out[(int64_t)row * ld_dout + col] : 0.f;
+        xh[k] = on ? (z - mean) * invstd : 0.f;
+        dy[k] = o > 0.f ? dd : 0.f;  // ReLU mask from the forward's own output
+        s_dy += dy[k];
+        s_dyxh += dy[k] * xh[k];
+    }
+    const float dbeta = bn_col_reduce(s_dy, red, tx, ty);
+    const float dgamma = bn_col_reduce(s_dyxh, red, tx, ty);
+    const float invB = 1.0f / (float)B;
+    const float k1 = gm * invstd;
+    float s_dz = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        if (col_on && row < B) {
+            float dz = k1 * (dy[k] - dbeta * invB - xh[k] * (dgamma * invB));
+            d_z[(int64_t)row * ldd + col] = dz;
+            s_dz += dz;
+        }
+    }
+    const float dbias = bn_col_reduce(s_dz, red, tx, ty);  // Linear bias under a train-mode BN: ~0 up to rounding
+    if (ty == 0 && col_on) {
+        d_gamma[col] = dgamma;
+        d_beta[col] = dbeta;
+        if (d_bias) d_bias[col] = dbias;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_fwd_eval_kernel(const float* __restrict__ g, int ldg,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ running_mean,
+                                                               const float* __restrict__ running_var,
+                                                               float* __restrict__ out, int ldo, int B, int H, float eps) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)B * H;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        int row = (int)(e / H), col = (int)(e - (int64_t)row * H);
+        float z = g[(int64_t)row * ldg + col] + (bias ? bias[col] : 0.f);
+        float invstd = 1.0f / sqrtf(running_var[col] + eps);
+        float y = (z - running_mean[col]) * invstd * gamma[col] + beta[col];
+        out[(int64_t)row * ldo + col] = y > 0.f ? y : 0.f;
+    }
+}
+
+#define BN_DISPATCH(KERNEL, ...)                                                       \
+    do {                                                                               \
+        int rpt = (B + BN_TY - 1) / BN_TY;                                             \
+        if (rpt <= 2) KERNEL<2><<<grid, block, 0, st>>>(__VA_ARGS__);                  \
+        else if (rpt <= 4) KERNEL<4><<<grid, block, 0, st>>>(__VA_ARGS__);             \
+        else if (rpt <= 8) KERNEL<8><<<grid, block, 0, st>>>(__VA_ARGS__);             \
+        else if (rpt <= 16) KERNEL<16><<<grid, block, 0, st>>>(__VA_ARGS__);           \
+        else if (rpt <= 32) KERNEL<32><<<grid, block, 0, st>>>(__VA_ARGS__);           \
+        else KERNEL<64><<<grid, block, 0, st>>>(__VA_ARGS__);                          \
+    } while (0)
+
+#define BN_MAX_B (BN_TY * 64)
+
+extern "C" int naf_bn_relu_fwd_train(const float* g, int64_t g_net_stride, int ldg, const float* bias,
+                                     const float* gamma, const float* beta, int64_t param_net_stride,
+                                     float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
+                                     int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, int B, int H,
+                                     int nets, float momentum, float eps, void* stream) {
+    if (!g || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd) return NAF_ERR_ARG;
+    if (B <= 0 || B > BN_MAX_B || H <= 0 || nets <= 0 || ldg < H || ldo < H) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H + BN_TX - 1) / BN_TX, nets), block(BN_TX, BN_TY);
+    BN_DISPATCH(bn_relu_fwd_train_kernel, g, g_net_stride, ldg, bias, gamma, beta, param_net_stride, running_mean,
+                running_var, stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, B, H, momentum, eps);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bn_relu_bwd(const float* d_out, int ld_dout, const float* g, int ldg, const float* bias,
+                               const float* out, int ldo, const float* gamma, const float* save_mean,
+                               const float* save_invstd, float* d_z, int ldd, float* d_gamma, float* d_beta,
+                               float* d_bias, int B, int H, void* stream) {
+    if (!d_out || !g || !out || !gamma || !save_mean || !save_invstd || !d_z || !d_gamma || !d_beta) return NAF_ERR_ARG;
+    if (B <= 0 || B > BN_MAX_B || H <= 0 || ld_dout < H || ldg < H || ldo < H || ldd < H) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H + BN_TX - 1) / BN_TX, 1), block(BN_TX, BN_TY);
+    BN_DISPATCH(bn_relu_bwd_kernel, d_out, ld_dout, g, ldg, bias, out, ldo, gamma, save_mean, save_invstd, d_z, ldd,
+                d_gamma, d_beta, d_bias, B, H);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bn_relu_fwd_eval(const float* g, int ldg, const float* bias, const float* gamma, const float* beta,
+                                    const float* running_mean, const float* running_var, float* out, int ldo, int B,
+                                    int H, float eps, void* stream) {
+    if (!g || !gamma || !beta || !running_mean || !running_var || !out) return NAF_ERR_ARG;
+    if (B <= 0 || H <= 0 || ldg < H || ldo < H) return NAF_ERR_ARG;
+    int64_t total = (int64_t)B * H;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    bn_relu_fwd_eval_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g, ldg, bias, gamma, beta, running_mean,
+                                                                      running_var, out, ldo, B, H, eps);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}

@@ -1,0 +1,52 @@
+// Shared host/device helpers for the NAF hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NAF_OK 0
+#define NAF_ERR_ARG (-1)       // bad argument (null pointer, out-of-range size, unsupported A)
+#define NAF_ERR_STATE (-2)     // bad handle / state
+// positive return values are hipError_t codes
+
+#define NAF_MAX_A 8            // one sample per 8-lane group: A <= 8
+#define NAF_WAVE 64
+
+#define NAF_CHECK_LAUNCH()                                    \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+static inline int naf_round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter-based: used by the replay sampler and by the
+// exploration noise. The numpy restatement in oracle/naf_oracle.py must produce the same words.
+// ---------------------------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t v[4];
+};
+
+__host__ __device__ static inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                        uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 out;
+    out.v[0] = c0; out.v[1] = c1; out.v[2] = c2; out.v[3] = c3;
+    return out;
+}
+
+// uniform in (0,1) from the top 24 bits of a 32-bit word (exactly representable in f32)
+__host__ __device__ static inline float naf_u01(uint32_t x) {
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}

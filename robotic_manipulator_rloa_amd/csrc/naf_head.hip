@@ -1,0 +1,327 @@
+// NAF head for gfx950: tanh(mu), tanh(l), tril unpack, exp on the diagonal, P, the quadratic advantage,
+// Q, the MSE/TD epilogue and the whole backward, fused. Replaces naf_neural_network.py:81-115 (+ its
+// autograd) and naf_algorithm.py:199-208 of the reference.
+//
+// Mapping: one sample per 8-lane group (A <= 8), lane i owns row i of L; 8 samples per 64-lane wave, 32 per
+// 256-thread workgroup. The heads rows of a workgroup are one contiguous 32*ldh*4-byte span: staged into LDS
+// with 16-B/lane loads, and d_heads leaves the same way. The A x A contraction is per sample — not a GEMM,
+// so no MFMA: row reductions are 8-lane xor shuffles, column accesses of L go through a padded LDS tile.
+#include "common.h"
+#include "../../include/naf_hip.h"
+
+#define HEAD_SPB 32          // samples per workgroup
+#define HEAD_THREADS 256
+#define HEAD_MAX_LDH 48      // A=8: 8+36+1 = 45 -> 48
+#define LT_STRIDE 9          // 8x8 L tile padded to 9 columns: column reads hit distinct banks
+
+__device__ static inline float group8_sum(float x) {
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 4);
+    return x;
+}
+
+// MODE: 0 = forward only (q, optional mu); 1 = backward given dq; 2 = fused TD target + MSE + backward
+template <int PMODE, int MODE>
+__global__ __launch_bounds__(HEAD_THREADS) void naf_head_kernel(const float* __restrict__ heads, int ldh,
+                                                                const float* __restrict__ u, int ldu,
+                                                                const float* __restrict__ r, int ldr,
+                                                                const float* __restrict__ v_next, int ldv,
+                                                                const float* __restrict__ dq_in, float gamma,
+                                                                float* __restrict__ q_out, float* __restrict__ mu_out,
+                                                                float* __restrict__ d_heads,
+                                                                float* __restrict__ loss_partials, int B, int A) {
+    __shared__ __attribute__((aligned(16))) float sh_in[HEAD_SPB * HEAD_MAX_LDH];
+    __shared__ __attribute__((aligned(16))) float sh_out[MODE == 0 ? 4 : HEAD_SPB * HEAD_MAX_LDH];
+    __shared__ float sh_L[PMODE == NAF_P_MATMUL ? HEAD_SPB * 8 * LT_STRIDE : 1];
+    __shared__ float sh_red[HEAD_THREADS / 64];
+
+    const int T = A * (A + 1) / 2;
+    const int tid = threadIdx.x;
+    const int s_loc = tid >> 3;   // sample within the workgroup
+    const int i = tid & 7;        // row of L owned by this lane
+    const int64_t s0 = (int64_t)blockIdx.x * HEAD_SPB;
+    const int ns = (B - s0) < HEAD_SPB ? (int)(B - s0) : HEAD_SPB;
+    const int64_t s = s0 + s_loc;
+    const bool live = s_loc < ns;
+    const bool row_on = live && i < A;
+
+    // ---- stage this workgroup's heads rows (contiguous span) ------------------------------------
+    {
+        const float4* src = (const float4*)(heads + s0 * ldh);
+        const int n4 = ns * ldh / 4;  // ldh % 4 == 0 (checked on the host)
+        for (int k = tid; k < n4; k += HEAD_THREADS) ((float4*)sh_in)[k] = src[k];
+        if (MODE != 0) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = tid; k < n4; k += HEAD_THREADS) ((float4*)sh_out)[k] = z;
+        }
+    }
+    __syncthreads();
+
+    const float* hrow = sh_in + s_loc * ldh;
+    float mu = 0.f, d = 0.f, Vv = 0.f;
+    float t_row[8], L_row[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { t_row[j] = 0.f; L_row[j] = 0.f; }
+    if (row_on) {
+        mu = tanhf(hrow[i]);
+        d = u[s * ldu + i] - mu;
+        const int rbase = A + i * (i + 1) / 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j <= i) {
+                float t = tanhf(hrow[rbase + j]);
+                t_row[j] = t;
+                L_row[j] = (j == i) ? expf(t) : t;
+            }
+        }
+    }
+    if (live) Vv = hrow[A + T];
+
+    // ---- quadratic form ---------------------------------------------------------------------------
+    float quad_part = 0.f;
+    float w = 0.f;  // matmul mode: w_i = (L^T d)_i, lane i holds component i
+    float Pii = 0.f;
+    if (PMODE == NAF_P_HADAMARD) {
+        // P = L (*) L^T = diag(L_ii^2): off-diagonal entries of L multiply structural zeros of L^T
+        float Lii = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j == i) Lii = L_row[j];
+        Pii = Lii * Lii;
+        quad_part = Pii * d * d;
+    } else {
+        float* Lt = sh_L + s_loc * 8 * LT_STRIDE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Lt[i * LT_STRIDE + j] = L_row[j];
+        __syncthreads();  // reached by every lane: no early exit above
+        const int gb = (tid & 63) & ~7;  // first lane of this sample's group inside the wave
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float dk = __shfl(d, gb + k);
+            if (k >= i) w += Lt[k * LT_STRIDE + i] * dk;  // column i of L
+        }
+        quad_part = w * w;
+    }
+    const float quad = group8_sum(quad_part);
+    const float Q = Vv - 0.5f * quad;
+
+    if (MODE == 0) {
+        if (live && i == 0) q_out[s] = Q;
+        if (mu_out && row_on) mu_out[s * A + i] = mu;
+        return;
+    }
+
+    // ---- dLoss/dQ ---------------------------------------------------------------------------------
+    float dq = 0.f;
+    float sq_err = 0.f;
+    if (MODE == 1) {
+        if (live) dq = dq_in[s];
+    } else {
+        // lane 0 of the group fetches r and V'(s'); the group shares them by shuffle (uniform control flow)
+        float y = 0.f;
+        if (live && i == 0) y = r[s * ldr] + gamma * v_next[s * ldv];
+        y = __shfl(y, (tid & 63) & ~7);
+        if (live) {
+            float e = Q - y;
+            dq = 2.0f * e / (float)B;
+            if (i == 0) {
+                sq_err = e * e / (float)B;
+                if (q_out) q_out[s] = Q;
+            }
+        }
+    }
+
+    // ---- backward ---------------------------------------------------------------------------------
+    float* orow = sh_out + s_loc * ldh;
+    if (PMODE == NAF_P_HADAMARD) {
+        if (row_on) {
+            // dQ/dmu_i = P_ii d_i ; dQ/dl_ii = -P_ii d_i^2 (through L_ii = exp(t)); off-diagonals: exactly 0
+            float tii = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j == i) tii = t_row[j];
+            orow[i] = dq * (Pii * d) * (1.0f - mu * mu);
+            orow[A + i * (i + 1) / 2 + i] = dq * (-(Pii * d * d)) * (1.0f - tii * tii);
+        }
+    } else {
+        const int gb = (tid & 63) & ~7;
+        float Lw = 0.f;
+        float wj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            wj[j] = __shfl(w, gb + j);
+            Lw += L_row[j] * wj[j];  // L_row[j] = 0 for j > i
+        }
+        if (row_on) {
+            // dQ/dmu = L w ; dQ/dL_ij = -d_i w_j (j <= i); diagonal chains through exp
+            orow[i] = dq * Lw * (1.0f - mu * mu);
+            const int rbase = A + i * (i + 1) / 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j <= i) {
+                    float dL = -d * wj[j];
+                    float dt = (j == i) ? dL * L_row[j] : dL;
+                    orow[rbase + j] = dq * dt * (1.0f - t_row[j] * t_row[j]);
+                }
+            }
+        }
+    }
+    if (live && i == 0) orow[A + T] = dq;  // dQ/dV = 1
+
+    if (MODE == 2) {
+        // workgroup sum of squared TD errors, fixed order -> bitwise reproducible
+        float x = sq_err;
+        x += __shfl_xor(x, 8);
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        if ((tid & 63) == 0) sh_red[tid >> 6] = x;
+    }
+    __syncthreads();
+    if (MODE == 2 && tid == 0 && loss_partials) {
+        float x = 0.f;
+        for (int k = 0; k < HEAD_THREADS / 64; ++k) x += sh_red[k];
+        loss_partials[blockIdx.x] = x;
+    }
+    {
+        float4* dst = (float4*)(d_heads + s0 * ldh);
+        const int n4 = ns * ldh / 4;
+        for (int k = tid; k < n4; k += HEAD_THREADS) dst[k] = ((const float4*)sh_out)[k];
+    }
+}
+
+static int head_args_ok(const float* heads, int ldh, const float* u, int ldu, int B, int A, int p_mode) {
+    if (!heads || !u || B <= 0 || A <= 0 || A > NAF_MAX_A) return 0;
+    if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return 0;
+    if (ldh < A + A * (A + 1) / 2 + 1 || ldh > HEAD_MAX_LDH || (ldh & 3) != 0) return 0;
+    if (((uintptr_t)heads & 15) != 0 || ldu < A) return 0;
+    return 1;
+}
+
+#define HEAD_LAUNCH(PM, MD, ...)                                                                       \
+    do {                                                                                               \
+        if ((PM) == NAF_P_HADAMARD)                                                                    \
+            naf_head_kernel<NAF_P_HADAMARD, MD><<<blocks, HEAD_THREADS, 0, st>>>(__VA_ARGS__);         \
+        else                                                                                           \
+            naf_head_kernel<NAF_P_MATMUL, MD><<<blocks, HEAD_THREADS, 0, st>>>(__VA_ARGS__);           \
+    } while (0)
+
+extern "C" int naf_head_fwd(const float* heads_pre, int ldh, const float* u, int ldu, float* q, float* mu_out, int B,
+                            int A, int p_mode, void* stream) {
+    if (!head_args_ok(heads_pre, ldh, u, ldu, B, A, p_mode) || !q) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (B + HEAD_SPB - 1) / HEAD_SPB;
+    HEAD_LAUNCH(p_mode, 0, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, nullptr, 0.f, q, mu_out, nullptr, nullptr, B, A);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_head_bwd(const float* heads_pre, int ldh, const float* u, int ldu, const float* dq, float* d_heads,
+                            int B, int A, int p_mode, void* stream) {
+    if (!head_args_ok(heads_pre, ldh, u, ldu, B, A, p_mode) || !dq || !d_heads || ((uintptr_t)d_heads & 15) != 0)
+        return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (B + HEAD_SPB - 1) / HEAD_SPB;
+    HEAD_LAUNCH(p_mode, 1, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, dq, 0.f, nullptr, nullptr, d_heads, nullptr, B, A);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_head_fwd_bwd_mse(const float* heads_pre, int ldh, const float* u, int ldu, const float* r, int ldr,
+                                    const float* v_next, int ldv, float gamma, float* q_out, float* d_heads,
+                                    float* loss_partials, int B, int A, int p_mode, void* stream) {
+    if (!head_args_ok(heads_pre, ldh, u, ldu, B, A, p_mode) || !r || !v_next || !d_heads ||
+        ((uintptr_t)d_heads & 15) != 0 || ldr < 1 || ldv < 1)
+        return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (B + HEAD_SPB - 1) / HEAD_SPB;
+    HEAD_LAUNCH(p_mode, 2, heads_pre, ldh, u, ldu, r, ldr, v_next, ldv, nullptr, gamma, q_out, nullptr, d_heads,
+                loss_partials, B, A);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exploration noise: action = clamp(mu + noise_scale * P^{-1/2} z). Hadamard: P = diag(L_ii^2) so the
+// covariance inverse(P) is diag(exp(-2 tanh l_ii)); matmul: cov = (L L^T)^-1 = L^-T L^-1, sample x solves
+// L^T x = z by back substitution over the 8-lane group.
+// ------------------------------------------------------------------------------------------------
+template <int PMODE>
+__global__ __launch_bounds__(HEAD_THREADS) void naf_act_noise_kernel(const float* __restrict__ heads, int ldh,
+                                                                     float* __restrict__ action_out, uint64_t seed,
+                                                                     const uint64_t* __restrict__ counter_dev,
+                                                                     uint64_t counter_off, float noise_scale, int E,
+                                                                     int A) {
+    __shared__ float sh_L[PMODE == NAF_P_MATMUL ? HEAD_SPB * 8 * LT_STRIDE : 1];
+    const int tid = threadIdx.x;
+    const int s_loc = tid >> 3;
+    const int i = tid & 7;
+    const int64_t s = (int64_t)blockIdx.x * HEAD_SPB + s_loc;
+    const bool live = s < E;
+    const bool row_on = live && i < A;
+    const uint64_t ctr = (counter_dev ? *counter_dev : 0ull) + counter_off;
+    const float* hrow = heads + s * ldh;
+
+    float mu = 0.f, z = 0.f;
+    float L_row[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) L_row[j] = 0.f;
+    if (row_on) {
+        mu = tanhf(hrow[i]);
+        const int rbase = A + i * (i + 1) / 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j <= i) {
+                float t = tanhf(hrow[rbase + j]);
+                L_row[j] = (j == i) ? expf(t) : t;
+            }
+        }
+        Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)s, (uint32_t)i, (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+        float u1 = naf_u01(p.v[0]), u2 = naf_u01(p.v[1]);
+        z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
+    float x = 0.f;
+    if (PMODE == NAF_P_HADAMARD) {
+        float Lii = 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j == i) Lii = row_on ? L_row[j] : 1.f;
+        x = z / Lii;
+    } else {
+        float* Lt = sh_L + s_loc * 8 * LT_STRIDE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Lt[i * LT_STRIDE + j] = L_row[j];
+        __syncthreads();
+        const int gb = (tid & 63) & ~7;
+        // solve L^T x = z: x_j = (z_j - sum_{k>j} L_kj x_k) / L_jj, j = A-1 .. 0 (lane j owns x_j)
+        float acc = z;
+        for (int k = 7; k >= 0; --k) {
+            float Lkk = Lt[k * LT_STRIDE + k];
+            float xk_mine = (k < A) ? acc / (Lkk == 0.f ? 1.f : Lkk) : 0.f;
+            float xk = __shfl(xk_mine, gb + k);  // lane k's value is the finished x_k
+            if (i == k) x = xk;
+            if (i < k) acc -= Lt[k * LT_STRIDE + i] * xk;
+        }
+    }
+    if (row_on) {
+        float a = mu + noise_scale * x;
+        a = fminf(1.0f, fmaxf(-1.0f, a));
+        action_out[s * A + i] = a;
+    }
+}
+
+extern "C" int naf_act_noise(const float* heads_pre, int ldh, float* action_out, uint64_t seed,
+                             const uint64_t* counter_dev, uint64_t counter_off, float noise_scale, int E, int A,
+                             int p_mode, void* stream) {
+    if (!heads_pre || !action_out || E <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
+    if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
+    if (ldh < A + A * (A + 1) / 2 + 1) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (E + HEAD_SPB - 1) / HEAD_SPB;
+    if (p_mode == NAF_P_HADAMARD)
+        naf_act_noise_kernel<NAF_P_HADAMARD><<<blocks, HEAD_THREADS, 0, st>>>(heads_pre, ldh, action_out, seed, counter_dev,
+                                                                             counter_off, noise_scale, E, A);
+    else
+        naf_act_noise_kernel<NAF_P_MATMUL><<<blocks, HEAD_THREADS, 0, st>>>(heads_pre, ldh, action_out, seed, counter_dev,
+                                                                           counter_off, noise_scale, E, A);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}

@@ -1,0 +1,319 @@
+"""Flat-buffer NAF learner: the MI355X implementation of NAFAgent.learn() + soft_update
+(reference naf_components/naf_algorithm.py:180-226) and of NAF.forward's training pass
+(naf_components/naf_neural_network.py:76-115).
+
+Design:
+  * all learner state lives in a few flat f32 HBM allocations: theta2[2, P] (row 0 = main net, row 1 = target
+    net), grad[P], adam m[P], v[P]; parameters of the nn.Module facades are views into them.
+  * the dense GEMMs stay on PyTorch-ROCm (torch.bmm / torch.mm with out=, hipBLASLt underneath); main and
+    target forward share every launch (batch-2 bmm, 2-net BN kernel).
+  * everything else is libnaf_hip.so: bias+BatchNorm+ReLU fwd/bwd, the fused NAF head (fwd + TD target + MSE +
+    bwd), grad-norm partials, clip+Adam+Polyak in one pass.
+  * the three head Linears are one GEMM against Wh[NHP, H+8]: column H of Wh is the bias and the activation
+    buffer carries a constant-1 column there, so bias add and bias gradient ride inside the GEMMs.
+  * no host sync anywhere: step count, clip factor, replay size and sampler counters live on the device, so a
+    chunk of U updates (sample -> gather -> U x learn) is captured once as a HIP graph and replayed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
+MAX_GRAD_NORM = 1.0
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass(frozen=True)
+class Segment:
+    offset: int
+    shape: Tuple[int, ...]
+
+    @property
+    def numel(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+class NetLayout:
+    """Where each parameter of one NAF network sits inside its flat buffer (units: floats).
+    Segments start on 64-float (256-B) boundaries; the gaps and the pad rows/columns of Wh hold zeros, receive
+    zero gradients and therefore stay zero under Adam."""
+
+    def __init__(self, state_size: int, action_size: int, layer_size: int):
+        if not (1 <= action_size <= 8):
+            raise ValueError("action_size must be in 1..8 (one sample per 8-lane group in the head kernel)")
+        self.S, self.A, self.H = state_size, action_size, layer_size
+        self.T = action_size * (action_size + 1) // 2
+        self.NH = self.A + self.T + 1                  # [mu | l | V]
+        self.NHP = _round_up(self.NH, 8)               # heads row stride (ldh)
+        self.HP = layer_size + 8                       # activations: H features | 1.0 | 7 zeros
+        self.seg: Dict[str, Segment] = {}
+        off = 0
+        for name, shape in (("W1", (self.H, self.S)), ("b1", (self.H,)), ("g1", (self.H,)), ("be1", (self.H,)),
+                            ("W2", (self.H, self.H)), ("b2", (self.H,)), ("g2", (self.H,)), ("be2", (self.H,)),
+                            ("Wh", (self.NHP, self.HP))):
+            self.seg[name] = Segment(off, shape)
+            off = _round_up(off + self.seg[name].numel, 64)
+        self.P = off
+        self.row_floats = _lib.load().naf_replay_row_floats(self.S, self.A)
+        # offsets inside a transition row
+        self.off_u = self.S
+        self.off_r = self.S + self.A
+        self.off_s2 = self.S + self.A + 1
+        self.off_d = 2 * self.S + self.A + 1
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        s = self.seg[name]
+        return flat[s.offset:s.offset + s.numel].view(*s.shape)
+
+    def n_ref_params(self) -> int:
+        """Number of parameters of the reference module (79,644 at S=21, A=6, H=256)."""
+        return self.H * self.S + self.H * self.H + 6 * self.H + self.NH * (self.H + 1)
+
+    # ---- mapping to the reference's state_dict keys (naf_neural_network.py:37-54) -------------------------
+    def param_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        A, T, H = self.A, self.T, self.H
+        Wh = self.view(flat, "Wh")
+        return {
+            "input_layer.weight": self.view(flat, "W1"), "input_layer.bias": self.view(flat, "b1"),
+            "bn1.weight": self.view(flat, "g1"), "bn1.bias": self.view(flat, "be1"),
+            "hidden_layer.weight": self.view(flat, "W2"), "hidden_layer.bias": self.view(flat, "b2"),
+            "bn2.weight": self.view(flat, "g2"), "bn2.bias": self.view(flat, "be2"),
+            "action_values.weight": Wh[0:A, 0:H], "action_values.bias": Wh[0:A, H],
+            "value.weight": Wh[A + T:A + T + 1, 0:H], "value.bias": Wh[A + T:A + T + 1, H],
+            "matrix_entries.weight": Wh[A:A + T, 0:H], "matrix_entries.bias": Wh[A:A + T, H],
+        }
+
+
+PARAM_ORDER = ["input_layer.weight", "input_layer.bias", "bn1.weight", "bn1.bias", "hidden_layer.weight",
+               "hidden_layer.bias", "bn2.weight", "bn2.bias", "action_values.weight", "action_values.bias",
+               "value.weight", "value.bias", "matrix_entries.weight", "matrix_entries.bias"]
+
+
+class Learner:
+    """Owns the flat learner state of one agent (main + target) and enqueues learn() updates on the current
+    stream. Everything is asynchronous; nothing here calls .item()/.cpu()."""
+
+    def __init__(self, state_size: int, action_size: int, layer_size: int, batch_size: int, learning_rate: float,
+                 tau: float, gamma: float, device: torch.device, p_mode: int = _lib.P_HADAMARD,
+                 world_size: int = 1, process_group=None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        self.lay = NetLayout(state_size, action_size, layer_size)
+        self.B = int(batch_size)
+        self.lr, self.tau, self.gamma = float(learning_rate), float(tau), float(gamma)
+        self.p_mode = int(p_mode)
+        self.world_size = int(world_size)
+        self.pg = process_group
+        lay, B, dev = self.lay, self.B, self.dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        P, H, HP, NHP = lay.P, lay.H, lay.HP, lay.NHP
+
+        # ---- persistent state --------------------------------------------------------------------------
+        self.theta2 = torch.zeros(2, P, **f32)             # [main; target]
+        self.grad = torch.zeros(P, **f32)
+        self.adam_m = torch.zeros(P, **f32)
+        self.adam_v = torch.zeros(P, **f32)
+        # BN running statistics [net][rm1, rv1, rm2, rv2][H]; not in theta: soft_update copies parameters() only
+        self.bn_stats = torch.zeros(2, 4, H, **f32)
+        self.bn_stats[:, 1].fill_(1.0)
+        self.bn_stats[:, 3].fill_(1.0)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # optimizer steps taken
+        self.n_partials = (P + _lib.NORM_CHUNK - 1) // _lib.NORM_CHUNK
+        self.partials = torch.zeros(self.n_partials, **f32)
+        self.n_loss_wg = (B + 31) // 32
+
+        # ---- work buffers for one minibatch ------------------------------------------------------------
+        self.G1 = torch.empty(2, B, H, **f32)
+        self.A1 = torch.empty(2, B, H, **f32)
+        self.G2 = torch.empty(2, B, H, **f32)
+        self.A2 = torch.zeros(2, B, HP, **f32)
+        self.A2[:, :, H] = 1.0                               # the constant-1 column that carries the head biases
+        self.Gh = torch.empty(2, B, NHP, **f32)
+        self.dH = torch.zeros(B, NHP, **f32)
+        self.dA2 = torch.empty(B, HP, **f32)
+        self.dZ2 = torch.empty(B, H, **f32)
+        self.dA1 = torch.empty(B, H, **f32)
+        self.dZ1 = torch.empty(B, H, **f32)
+        self.save_mean = torch.empty(2, 2, H, **f32)         # [layer][net][H]
+        self.save_invstd = torch.empty(2, 2, H, **f32)
+        self.q_out = torch.empty(B, **f32)
+
+        # ---- GEMM operand views (built once: no per-call tensor construction on the hot path) -------------
+        seg = lay.seg
+        t2 = self.theta2
+        self.W1T2 = t2[:, seg["W1"].offset:seg["W1"].offset + seg["W1"].numel].view(2, H, lay.S).transpose(1, 2)
+        self.W2T2 = t2[:, seg["W2"].offset:seg["W2"].offset + seg["W2"].numel].view(2, H, H).transpose(1, 2)
+        self.WhT2 = t2[:, seg["Wh"].offset:seg["Wh"].offset + seg["Wh"].numel].view(2, NHP, HP).transpose(1, 2)
+        self.W2_main = lay.view(t2[0], "W2")
+        self.Wh_main = lay.view(t2[0], "Wh")
+        self.gW1 = lay.view(self.grad, "W1")
+        self.gW2 = lay.view(self.grad, "W2")
+        self.gWh = lay.view(self.grad, "Wh")
+        self._f = self.lib  # shorthand
+
+    # ---- parameters in / out ----------------------------------------------------------------------------
+    def main_views(self) -> Dict[str, torch.Tensor]:
+        return self.lay.param_views(self.theta2[0])
+
+    def target_views(self) -> Dict[str, torch.Tensor]:
+        return self.lay.param_views(self.theta2[1])
+
+    def bn_views(self, net: int) -> Dict[str, torch.Tensor]:
+        s = self.bn_stats[net]
+        return {"bn1.running_mean": s[0], "bn1.running_var": s[1], "bn2.running_mean": s[2], "bn2.running_var": s[3]}
+
+    def load_params(self, net: int, sd: Dict[str, torch.Tensor]) -> None:
+        views = self.lay.param_views(self.theta2[net])
+        with torch.no_grad():
+            for k, v in views.items():
+                v.copy_(torch.as_tensor(sd[k]).to(self.dev, torch.float32).reshape(v.shape))
+            for k, v in self.bn_views(net).items():
+                if k in sd:
+                    v.copy_(torch.as_tensor(sd[k]).to(self.dev, torch.float32))
+
+    def reset_optimizer(self) -> None:
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.step_dev.zero_()
+
+    # ---- one learn() on the current stream --------------------------------------------------------------
+    def _x2(self, rows: torch.Tensor) -> torch.Tensor:
+        """[2, B, S] view of a [B, row_floats] minibatch: net 0 reads `state`, net 1 reads `next_state`."""
+        lay = self.lay
+        return rows.as_strided((2, self.B, lay.S), (lay.off_s2, lay.row_floats, 1), rows.storage_offset())
+
+    def forward_train(self, rows: torch.Tensor) -> None:
+        """Both networks' training-mode forward up to the heads pre-activations (Gh). Main net sees `state`,
+        target net sees `next_state` (naf_algorithm.py:194-202); both use batch statistics and both update their
+        running statistics (the reference never calls .eval() on the target)."""
+        lay, B, st = self.lay, self.B, stream_ptr()
+        seg, P, H = lay.seg, lay.P, lay.H
+        t2p = self.theta2.data_ptr()
+        bnp = self.bn_stats.data_ptr()
+        torch.bmm(self._x2(rows), self.W1T2, out=self.G1)
+        check(self._f.naf_bn_relu_fwd_train(
+            ptr(self.G1), B * H, H, t2p + 4 * seg["b1"].offset, t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P,
+            bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]),
+            B, H, 2, BN_MOMENTUM, BN_EPS, st), "bn_relu_fwd_train(1)")
+        torch.bmm(self.A1, self.W2T2, out=self.G2)
+        check(self._f.naf_bn_relu_fwd_train(
+            ptr(self.G2), B * H, H, t2p + 4 * seg["b2"].offset, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P,
+            bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2), B * lay.HP, lay.HP, ptr(self.save_mean[1]),
+            ptr(self.save_invstd[1]), B, H, 2, BN_MOMENTUM, BN_EPS, st), "bn_relu_fwd_train(2)")
+        torch.bmm(self.A2, self.WhT2, out=self.Gh)
+
+    def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None) -> None:
+        """Enqueue one full NAFAgent.learn() (naf_algorithm.py:180-215) + soft_update (:217-226) on the minibatch
+        `rows` [B, row_floats] (actions already truncated by the gather if the reference's `.long()` is mimicked).
+        loss_partials: optional [ceil(B/32)] f32 receiving the per-workgroup parts of the MSE loss."""
+        lay, B, st = self.lay, self.B, stream_ptr()
+        seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
+        f = self._f
+        t2p, gp = self.theta2.data_ptr(), self.grad.data_ptr()
+        rp = rows.data_ptr()
+        self.forward_train(rows)
+        # y = r + gamma * V'(s') ; Q ; loss ; d loss / d heads_pre — one launch
+        check(f.naf_head_fwd_bwd_mse(
+            ptr(self.Gh[0]), NHP, rp + 4 * lay.off_u, lay.row_floats, rp + 4 * lay.off_r, lay.row_floats,
+            self.Gh[1].data_ptr() + 4 * (lay.A + lay.T), NHP, self.gamma, ptr(self.q_out), ptr(self.dH),
+            ptr(loss_partials) if loss_partials is not None else None, B, lay.A, self.p_mode, st), "head_fwd_bwd_mse")
+        # heads GEMM backward: weight+bias gradient in one GEMM thanks to the ones column
+        torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
+        torch.mm(self.dH, self.Wh_main, out=self.dA2)
+        check(f.naf_bn_relu_bwd(
+            ptr(self.dA2), HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset, ptr(self.A2[0]), HP,
+            t2p + 4 * seg["g2"].offset, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.dZ2), H,
+            gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
+        torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
+        torch.mm(self.dZ2, self.W2_main, out=self.dA1)
+        check(f.naf_bn_relu_bwd(
+            ptr(self.dA1), H, ptr(self.G1[0]), H, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
+            t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.dZ1), H,
+            gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, B, H, st), "bn_relu_bwd(1)")
+        torch.mm(self.dZ1.t(), self._x2(rows)[0], out=self.gW1)
+        if self.world_size > 1:
+            # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
+            # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
+            torch.distributed.all_reduce(self.grad, group=self.pg)
+        self.optimizer_step()
+
+    def optimizer_step(self) -> None:
+        """clip_grad_norm_(params, 1) + Adam.step() + soft_update on the flat buffers: 2 launches."""
+        st, P = stream_ptr(), self.lay.P
+        f = self._f
+        check(f.naf_grad_norm_partials(ptr(self.grad), P, ptr(self.partials), ptr(self.step_dev), st), "grad_norm")
+        check(f.naf_adam_polyak_fused(
+            ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]),
+            ptr(self.partials), self.n_partials, MAX_GRAD_NORM, self.lr, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau,
+            float(1.0 - self.tau), ptr(self.step_dev), 1.0 / self.world_size, P, st), "adam_polyak")
+
+    def soft_update(self) -> None:
+        """Standalone NAFAgent.soft_update(main, target) (naf_algorithm.py:217-226) over the flat buffers."""
+        check(self._f.naf_polyak_update(ptr(self.theta2[1]), ptr(self.theta2[0]), self.tau, float(1.0 - self.tau),
+                                        self.lay.P, stream_ptr()), "polyak")
+
+
+class ActPath:
+    """Eval-mode policy forward for E states at once (NAFAgent.act, naf_algorithm.py:158-178): running-stat BN
+    (main net only), mu = tanh, exploration noise clamp(mu + P^-1/2 z) — noise is drawn on EVERY call exactly as
+    the reference's forward does (naf_neural_network.py:119-121), unless noise_scale = 0."""
+
+    def __init__(self, learner: Learner, n_states: int, seed: int):
+        self.L = learner
+        lay, dev = learner.lay, learner.dev
+        self.E = int(n_states)
+        f32 = dict(dtype=torch.float32, device=dev)
+        E, H, HP, NHP = self.E, lay.H, lay.HP, lay.NHP
+        self.obs = torch.zeros(E, lay.S, **f32)
+        self.G1 = torch.empty(E, H, **f32)
+        self.A1 = torch.empty(E, H, **f32)
+        self.G2 = torch.empty(E, H, **f32)
+        self.A2 = torch.zeros(E, HP, **f32)
+        self.A2[:, H] = 1.0
+        self.Gh = torch.empty(E, NHP, **f32)
+        self.actions = torch.zeros(E, lay.A, **f32)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)   # noise stream position (uint64 on device)
+        self.W1T = learner.W1T2[0]
+        self.W2T = learner.W2T2[0]
+        self.WhT = learner.WhT2[0]
+
+    def heads(self) -> None:
+        L, lay, E, st = self.L, self.L.lay, self.E, stream_ptr()
+        seg, H = lay.seg, lay.H
+        t2p, bnp = L.theta2.data_ptr(), L.bn_stats.data_ptr()
+        f = L.lib
+        torch.mm(self.obs, self.W1T, out=self.G1)
+        check(f.naf_bn_relu_fwd_eval(ptr(self.G1), H, t2p + 4 * seg["b1"].offset, t2p + 4 * seg["g1"].offset,
+                                     t2p + 4 * seg["be1"].offset, bnp, bnp + 4 * H, ptr(self.A1), H, E, H, BN_EPS, st),
+              "bn_relu_fwd_eval(1)")
+        torch.mm(self.A1, self.W2T, out=self.G2)
+        check(f.naf_bn_relu_fwd_eval(ptr(self.G2), H, t2p + 4 * seg["b2"].offset, t2p + 4 * seg["g2"].offset,
+                                     t2p + 4 * seg["be2"].offset, bnp + 8 * H, bnp + 12 * H, ptr(self.A2), lay.HP, E, H,
+                                     BN_EPS, st), "bn_relu_fwd_eval(2)")
+        torch.mm(self.A2, self.WhT, out=self.Gh)
+
+    def act(self, noise_scale: float = 1.0) -> torch.Tensor:
+        """obs (already in self.obs) -> self.actions; advances the noise counter on the device."""
+        L, lay, st = self.L, self.L.lay, stream_ptr()
+        self.heads()
+        check(L.lib.naf_act_noise(ptr(self.Gh), lay.NHP, ptr(self.actions), self.seed, ptr(self.counter), 0,
+                                  float(noise_scale), self.E, lay.A, L.p_mode, st), "act_noise")
+        check(L.lib.naf_counter_add(ptr(self.counter), 1, st), "counter_add")
+        return self.actions

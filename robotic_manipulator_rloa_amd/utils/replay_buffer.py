@@ -1,0 +1,152 @@
+"""ReplayBuffer with the reference's interface (utils/replay_buffer.py:14-75) backed by an HBM ring of 256-byte
+transition rows and the libnaf_hip.so sample/gather kernels. Differences that are deliberate and documented
+(DESIGN.md): sampling is drawn on the device from Philox4x32-10 instead of Python's Mersenne Twister (same
+distribution: uniform, without replacement inside a minibatch), and rows are float32 at insertion.
+"""
+from __future__ import annotations
+
+import random
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream_ptr
+
+_STAGE_ROWS = 1024
+
+
+class ReplayBuffer:
+
+    def __init__(self, buffer_size: int, batch_size: int, device, seed: int, state_size: Optional[int] = None,
+                 action_size: Optional[int] = None, action_mode: int = _lib.ACTION_TRUNC_INT,
+                 without_replacement: bool = True):
+        """
+        Args mirror the reference (replay_buffer.py:16-30). state_size/action_size may be given up front; otherwise
+        the HBM ring is allocated at the first add() from the shapes of that transition.
+        action_mode: ACTION_TRUNC_INT reproduces the reference's `.long()` cast of sampled actions (:60).
+        """
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.buffer_size = int(buffer_size)
+        self.batch_size = int(batch_size)
+        self.seed = int(seed)
+        self.action_mode = int(action_mode)
+        self.without_replacement = bool(without_replacement)
+        random.seed(seed)   # the reference seeds Python's GLOBAL RNG here (:30); Environment.reset draws from it
+        self._handle = None
+        self._total_added = 0      # host mirror of the device counters (adds are host-initiated: always known)
+        self._pending = 0
+        self.S = self.A = None
+        if state_size is not None and action_size is not None:
+            self._allocate(int(state_size), int(action_size))
+
+    # ---- storage ------------------------------------------------------------------------------------------
+    def _allocate(self, S: int, A: int) -> None:
+        self.S, self.A = S, A
+        self.row_floats = self.lib.naf_replay_row_floats(S, A)
+        self.rows = torch.zeros(self.buffer_size, self.row_floats, dtype=torch.float32, device=self.device)
+        self.meta = torch.zeros(8, dtype=torch.int64, device=self.device)
+        h = _lib.C.c_void_p()
+        check(self.lib.naf_replay_create(self.buffer_size, S, A, ptr(self.rows), ptr(self.meta), _lib.C.byref(h)),
+              "naf_replay_create")
+        self._handle = h
+        self._stage_host = torch.zeros(_STAGE_ROWS, self.row_floats, dtype=torch.float32).pin_memory()
+        self._stage_np = self._stage_host.numpy()
+        self._stage_dev = torch.zeros(_STAGE_ROWS, self.row_floats, dtype=torch.float32, device=self.device)
+        self._idx = torch.zeros(self.batch_size, dtype=torch.int32, device=self.device)
+        self._sample_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self.lib.naf_replay_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if self._handle is None:
+            raise _lib.NafHipError("ReplayBuffer storage is not allocated yet (no transition added)")
+        return self._handle
+
+    # ---- add ------------------------------------------------------------------------------------------------
+    def add(self, state, action, reward: float, next_state, done: int) -> None:
+        """Append one experience (replay_buffer.py:32-45). Staged in pinned host memory; reaches the HBM ring at the
+        next flush() (sample() and the agent's update path flush first), so FIFO order and eviction are exact."""
+        if self._handle is None:
+            self._allocate(int(np.asarray(state).shape[-1]), int(np.asarray(action).shape[-1]))
+        S, A = self.S, self.A
+        row = self._stage_np[self._pending]
+        row[:S] = state[0] if isinstance(state, tuple) else state     # same tuple guard as replay_buffer.py:58
+        row[S:S + A] = action
+        row[S + A] = reward
+        row[S + A + 1:2 * S + A + 1] = next_state
+        row[2 * S + A + 1] = done
+        self._pending += 1
+        self._total_added += 1
+        if self._pending == _STAGE_ROWS:
+            self.flush()
+
+    def flush(self) -> None:
+        n = self._pending
+        if n == 0:
+            return
+        self._stage_dev[:n].copy_(self._stage_host[:n], non_blocking=True)
+        self.add_rows_device(self._stage_dev, n, _count=False)
+        # the pinned staging buffer is rewritten by the next add(): wait for the H2D copy (one event per flush)
+        torch.cuda.current_stream().synchronize()
+        self._pending = 0
+
+    def add_rows_device(self, rows_dev: torch.Tensor, n: int, _count: bool = True) -> None:
+        """Append n packed transition rows that already live on the device (vector-env path)."""
+        if self._handle is None:
+            raise _lib.NafHipError("allocate the ReplayBuffer with state_size/action_size before add_rows_device")
+        if n > self.buffer_size:
+            raise ValueError("cannot add more rows than the buffer holds in one call")
+        check(self.lib.naf_replay_add_batch(self.handle, ptr(rows_dev), int(n), stream_ptr()), "naf_replay_add_batch")
+        if _count:
+            self._total_added += int(n)
+
+    # ---- sample -----------------------------------------------------------------------------------------------
+    def sample_indices(self, idx_out: torch.Tensor, n_batches: int = 1) -> None:
+        check(self.lib.naf_replay_sample_indices(self.handle, self.seed, ptr(self._sample_ctr), 0, ptr(idx_out),
+                                                 self.batch_size, int(n_batches), int(self.without_replacement),
+                                                 stream_ptr()), "naf_replay_sample_indices")
+        check(self.lib.naf_counter_add(ptr(self._sample_ctr), int(n_batches), stream_ptr()), "naf_counter_add")
+
+    def gather_rows(self, idx: torch.Tensor, out_rows: torch.Tensor, n: int) -> None:
+        check(self.lib.naf_replay_gather_rows(self.handle, ptr(idx), ptr(out_rows), int(n), self.action_mode,
+                                              stream_ptr()), "naf_replay_gather_rows")
+
+    def sample(self, idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
+        """(states, actions, rewards, next_states, dones) with the reference's shapes and dtypes
+        (replay_buffer.py:47-67): f32 (B,S), int64 (B,A) truncated, f32 (B,1), f32 (B,S), f32 (B,1).
+        idx: optional int32 deque positions (0 = oldest) to take instead of drawing."""
+        self.flush()
+        B, dev = self.batch_size, self.device
+        if idx is None:
+            self.sample_indices(self._idx, 1)
+            idx = self._idx
+        else:
+            idx = idx.to(dev, torch.int32).contiguous()
+            B = idx.numel()
+        s = torch.empty(B, self.S, dtype=torch.float32, device=dev)
+        u = torch.empty(B, self.A, dtype=torch.float32, device=dev)
+        r = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        s2 = torch.empty(B, self.S, dtype=torch.float32, device=dev)
+        d = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        check(self.lib.naf_replay_gather_soa(self.handle, ptr(idx), ptr(s), ptr(u), ptr(r), ptr(s2), ptr(d), B,
+                                             self.action_mode, stream_ptr()), "naf_replay_gather_soa")
+        actions = u.long() if self.action_mode == _lib.ACTION_TRUNC_INT else u
+        return s, actions, r, s2, d
+
+    def bad_index_count(self) -> int:
+        return int(self.meta[7].item())
+
+    def __len__(self) -> int:
+        """Current number of stored experiences (replay_buffer.py:69-75), pending staged rows included."""
+        return min(self._total_added, self.buffer_size)

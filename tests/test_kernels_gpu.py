@@ -1,0 +1,384 @@
+"""GPU parity tests proper: every entry point of libnaf_hip.so (through the C ABI, via ctypes) against the
+numpy oracle and the golden vectors generated from the unmodified reference. Bit-exact for byte/index work
+(replay add/gather/sample, Polyak), tolerance stated per test for floating point."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_group
+from oracle import naf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from robotic_manipulator_rloa_amd import _lib
+    _lib.require_gpu()
+    return _lib.load(allow_build=False)
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x)).to("cuda", dtype)
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def heads_rows(mu_pre, l_pre, V, ldh):
+    B, A = mu_pre.shape
+    T = l_pre.shape[1]
+    h = np.zeros((B, ldh), np.float32)
+    h[:, :A], h[:, A:A + T], h[:, A + T] = mu_pre, l_pre, np.asarray(V).reshape(-1)
+    return h
+
+
+# ------------------------------------------------------------------------------------------------------------
+# replay
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,A", [(21, 6), (23, 7), (19, 5)])
+def test_replay_add_gather_fifo_and_trunc(lib, S, A):
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    from robotic_manipulator_rloa_amd import _lib
+    from synth_data import make_transitions
+    cap = 1000
+    buf = ReplayBuffer(cap, 64, "cuda", 0, state_size=S, action_size=A)
+    rf = buf.row_floats
+    assert rf == 64
+    st_, ac, rw, ns, dn = make_transitions(2600, S, A, seed=3)
+    rows = O.pack_rows(st_, ac, rw, ns, dn, rf)
+    batches = [rows[0:1], rows[1:65], rows[65:700], rows[700:1300], rows[1300:2300], rows[2300:2600]]  # ragged, wraps
+    for b in batches:
+        buf.add_rows_device(dev(b), b.shape[0])
+        torch.cuda.synchronize()
+    assert len(buf) == cap
+    meta = buf.meta.cpu().numpy()
+    assert meta[1] == cap and meta[2] == 2600 and meta[0] == 2600 % cap
+    expect = O.ring_after_adds(cap, batches)              # deque order: oldest first
+    idx = torch.arange(cap, dtype=torch.int32, device="cuda")
+    out = torch.empty(cap, rf, device="cuda")
+    buf.action_mode = _lib.ACTION_FLOAT
+    buf.gather_rows(idx, out, cap)
+    np.testing.assert_array_equal(out.cpu().numpy(), expect)          # byte-exact row copy, FIFO eviction
+    buf.action_mode = _lib.ACTION_TRUNC_INT
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(cap).astype(np.int32)).cuda()
+    buf.gather_rows(perm, out, cap)
+    exp_t = expect[perm.cpu().numpy()].copy()
+    exp_t[:, S:S + A] = np.trunc(exp_t[:, S:S + A])                    # the reference's .long() (replay_buffer.py:60)
+    np.testing.assert_array_equal(out.cpu().numpy(), exp_t)
+    # bulk path (4 rows in flight per lane) on a big index list with repeats
+    big = torch.from_numpy(np.random.default_rng(1).integers(0, cap, 70000).astype(np.int32)).cuda()
+    outb = torch.empty(70000, rf, device="cuda")
+    buf.gather_rows(big, outb, 70000)
+    np.testing.assert_array_equal(outb.cpu().numpy(), exp_t_full(expect, big.cpu().numpy(), S, A))
+    assert buf.bad_index_count() == 0
+    # out-of-range positions are counted, not silently used
+    bad = torch.tensor([0, cap, -1, 5], dtype=torch.int32, device="cuda")
+    buf.gather_rows(bad, out, 4)
+    assert buf.bad_index_count() == 2
+
+
+def exp_t_full(expect, idx, S, A):
+    e = expect[idx].copy()
+    e[:, S:S + A] = np.trunc(e[:, S:S + A])
+    return e
+
+
+def test_replay_sample_api_contract_matches_reference_golden(lib):
+    """ReplayBuffer.add/sample through the host API against G4 (the reference's own sample() output for the
+    same deque positions)."""
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    from synth_data import make_transitions
+    g = np.load(os.path.join(GOLDEN, "g4_replay.npz"))
+    S, A, cap, B = [int(x) for x in g["dims"]]
+    st_, ac, rw, ns, dn = make_transitions(500, S, A, seed=11)
+    buf = ReplayBuffer(cap, B, torch.device("cuda"), 0)
+    for i in range(500):
+        s = st_[i].astype(np.float64).copy()
+        s[0] = float(i)
+        buf.add(s, ac[i], float(rw[i]), ns[i].astype(np.float64), int(dn[i]))
+    assert len(buf) == cap
+    pos = torch.from_numpy(g["positions_from_range"][0].astype(np.int32))
+    s, a, r, s2, d = buf.sample(idx=pos)
+    assert [str(t.dtype) for t in (s, a, r, s2, d)] == list(g["dtypes"])
+    assert [tuple(t.shape) for t in (s, a, r, s2, d)] == [(B, S), (B, A), (B, 1), (B, S), (B, 1)]
+    np.testing.assert_array_equal(s.cpu().numpy(), g["s"])
+    np.testing.assert_array_equal(a.cpu().numpy(), g["a"])
+    np.testing.assert_array_equal(r.cpu().numpy(), g["r"])
+    np.testing.assert_array_equal(s2.cpu().numpy(), g["s2"])
+    np.testing.assert_array_equal(d.cpu().numpy(), g["d"])
+    # free-running sample(): right shapes, in range, no duplicates
+    s, a, r, s2, d = buf.sample()
+    ids = s[:, 0].cpu().numpy()
+    assert len(set(ids.tolist())) == B and ids.min() >= 200 and ids.max() <= 499
+
+
+@pytest.mark.parametrize("size,B,nb", [(1000, 256, 8), (257, 256, 3), (300, 64, 5), (100000, 2048, 2), (5000, 1024, 2)])
+def test_replay_sampler_bit_exact_vs_oracle(lib, size, B, nb):
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    buf = ReplayBuffer(size, B, "cuda", 0x1234ABCD5678, state_size=21, action_size=6)
+    buf.add_rows_device(torch.zeros(size, 64, device="cuda"), size)
+    idx = torch.zeros(nb, B, dtype=torch.int32, device="cuda")
+    buf._sample_ctr.fill_(7)
+    buf.sample_indices(idx, nb)
+    got = idx.cpu().numpy()
+    exp = O.replay_sample_indices(0x1234ABCD5678, 7, size, B, nb, True)
+    np.testing.assert_array_equal(got, exp)
+    for b in range(nb):
+        assert len(set(got[b].tolist())) == B
+    assert int(buf._sample_ctr.item()) == 7 + nb
+    # with replacement: plain draws
+    buf.without_replacement = False
+    buf.sample_indices(idx, nb)
+    np.testing.assert_array_equal(idx.cpu().numpy(), O.replay_sample_indices(0x1234ABCD5678, 7 + nb, size, B, nb, False))
+
+
+def test_replay_sampler_uniformity(lib):
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    size, B, nb = 4096, 256, 4000
+    buf = ReplayBuffer(size, B, "cuda", 99, state_size=21, action_size=6)
+    buf.add_rows_device(torch.zeros(size, 64, device="cuda"), size)
+    idx = torch.zeros(nb, B, dtype=torch.int32, device="cuda")
+    buf.sample_indices(idx, nb)
+    counts = np.bincount(idx.cpu().numpy().ravel(), minlength=size).astype(np.float64)
+    expected = nb * B / size
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert abs(chi2 - size) < 6 * np.sqrt(2 * size)      # chi-square with ~size dof
+
+
+# ------------------------------------------------------------------------------------------------------------
+# NAF head
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("A", [5, 6, 7])
+@pytest.mark.parametrize("B", [2, 256])
+@pytest.mark.parametrize("tag", ["rand", "wide"])
+def test_head_vs_reference_golden(lib, A, B, tag):
+    """Hadamard mode against the reference's own forward/autograd outputs (G2). rtol 2e-5 forward (f32 tanh/exp
+    differ by an ulp or two between libm and the device), 2e-4 backward."""
+    g = load_group(np.load(os.path.join(GOLDEN, "g2_head.npz")), f"A{A}_B{B}_{tag}")
+    T = A * (A + 1) // 2
+    ldh = (A + T + 1 + 7) // 8 * 8
+    h = dev(heads_rows(g["mu_pre"], g["l_pre"], g["V"], ldh))
+    u = dev(g["u_trunc"])
+    q = torch.empty(B, device="cuda")
+    mu = torch.empty(B, A, device="cuda")
+    assert lib.naf_head_fwd(h.data_ptr(), ldh, u.data_ptr(), A, q.data_ptr(), mu.data_ptr(), B, A, 0, st()) == 0
+    np.testing.assert_allclose(q.cpu().numpy(), g["q"].ravel(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(mu.cpu().numpy(), np.tanh(g["mu_pre"]), rtol=1e-5, atol=1e-6)
+    dq = dev(g["dq"].ravel())
+    dh = torch.full((B, ldh), 7.0, device="cuda")
+    assert lib.naf_head_bwd(h.data_ptr(), ldh, u.data_ptr(), A, dq.data_ptr(), dh.data_ptr(), B, A, 0, st()) == 0
+    dh = dh.cpu().numpy()
+    np.testing.assert_allclose(dh[:, :A], g["d_mu_pre"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dh[:, A:A + T], g["d_l_pre"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dh[:, A + T], g["d_V"].ravel(), rtol=1e-6)
+    assert (dh[:, A + T + 1:] == 0).all()                              # pad columns are written as zeros
+    # off-diagonal l entries get EXACTLY zero gradient under the reference's Hadamard P
+    diag = [k * (k + 3) // 2 for k in range(A)]
+    off = [k for k in range(T) if k not in diag]
+    assert (dh[:, A:A + T][:, off] == 0).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("A,B", [(6, 256), (7, 2048), (3, 33), (8, 100), (1, 5)])
+def test_head_both_modes_vs_oracle_f64(lib, mode, A, B):
+    rng = np.random.default_rng(10 * A + B + mode)
+    T = A * (A + 1) // 2
+    ldh = (A + T + 1 + 7) // 8 * 8
+    mu_pre, l_pre, V = rng.standard_normal((B, A)), rng.standard_normal((B, T)), rng.standard_normal(B)
+    u = np.trunc(rng.uniform(-1.5, 1.5, (B, A)))
+    r, vn = rng.standard_normal(B), rng.standard_normal(B)
+    gamma = 0.99
+    f = O.head_forward(mu_pre, l_pre, V, u, mode)
+    y = r + gamma * vn
+    dq = 2 * (f["Q"] - y) / B
+    d_mu, d_l, d_V = O.head_backward(mu_pre, l_pre, u, dq, mode)
+    h = dev(heads_rows(mu_pre, l_pre, V, ldh))
+    ud, rd, vnd = dev(u), dev(r), dev(vn)
+    q = torch.empty(B, device="cuda")
+    dh = torch.empty(B, ldh, device="cuda")
+    nwg = (B + 31) // 32
+    lp = torch.zeros(nwg, device="cuda")
+    assert lib.naf_head_fwd_bwd_mse(h.data_ptr(), ldh, ud.data_ptr(), A, rd.data_ptr(), 1, vnd.data_ptr(), 1, gamma,
+                                    q.data_ptr(), dh.data_ptr(), lp.data_ptr(), B, A, mode, st()) == 0
+    np.testing.assert_allclose(q.cpu().numpy(), f["Q"], rtol=3e-5, atol=3e-5)
+    dhn = dh.cpu().numpy()
+    scale = np.abs(dq).max() * 10
+    np.testing.assert_allclose(dhn[:, :A], d_mu, rtol=3e-4, atol=1e-6 * scale + 1e-7)
+    np.testing.assert_allclose(dhn[:, A:A + T], d_l, rtol=3e-4, atol=1e-6 * scale + 1e-7)
+    np.testing.assert_allclose(dhn[:, A + T], d_V, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(lp.sum().item(), ((f["Q"] - y) ** 2).mean(), rtol=1e-4)
+    # run-to-run bitwise reproducible
+    dh2 = torch.empty_like(dh)
+    lp2 = torch.zeros_like(lp)
+    lib.naf_head_fwd_bwd_mse(h.data_ptr(), ldh, ud.data_ptr(), A, rd.data_ptr(), 1, vnd.data_ptr(), 1, gamma,
+                             q.data_ptr(), dh2.data_ptr(), lp2.data_ptr(), B, A, mode, st())
+    assert torch.equal(dh, dh2) and torch.equal(lp, lp2)
+
+
+def test_head_argument_errors(lib):
+    h = torch.zeros(4, 32, device="cuda")
+    u = torch.zeros(4, 6, device="cuda")
+    q = torch.zeros(4, device="cuda")
+    assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 9, 0, st()) == -1   # A > 8
+    assert lib.naf_head_fwd(h.data_ptr(), 24, u.data_ptr(), 6, q.data_ptr(), None, 4, 6, 0, st()) == -1   # ldh too small
+    assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 6, 2, st()) == -1   # bad mode
+    assert lib.naf_head_fwd(None, 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 6, 0, st()) == -1
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_act_noise_distribution(lib, mode):
+    """clamp(mu + P^-1/2 z): first two moments against the analytic covariance inverse(P) (what the reference's
+    MultivariateNormal(mu, inverse(P)) samples from, naf_neural_network.py:119), and z bit-stream against the
+    oracle's Philox restatement."""
+    A, E = 6, 64
+    T = A * (A + 1) // 2
+    rng = np.random.default_rng(5)
+    mu_pre, l_pre = 0.1 * rng.standard_normal((E, A)), rng.standard_normal((E, T))
+    h = dev(heads_rows(mu_pre, l_pre, np.zeros(E), 32))
+    n_draws = 4000
+    acts = torch.empty(n_draws, E, A, device="cuda")
+    ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for k in range(n_draws):
+        assert lib.naf_act_noise(h.data_ptr(), 32, acts[k].data_ptr(), 42, ctr.data_ptr(), k, 0.05, E, A, mode, st()) == 0
+    a = acts.cpu().numpy().astype(np.float64)
+    f = O.head_forward(mu_pre, l_pre, np.zeros(E), np.zeros((E, A)), mode)
+    cov = np.linalg.inv(f["P"]) * 0.05 ** 2                      # noise_scale^2 * inverse(P); small so the clamp is idle
+    np.testing.assert_allclose(a.mean(0), f["mu"], atol=5 * np.sqrt(np.einsum("eii->ei", cov).max() / n_draws))
+    emp = np.einsum("kei,kej->eij", a - a.mean(0), a - a.mean(0)) / (n_draws - 1)
+    np.testing.assert_allclose(emp, cov, rtol=0.25, atol=0.12 * np.abs(cov).max())
+    # Hadamard: exact stream check for draw 0
+    if mode == 0:
+        z = O.normal_from_philox(42, 0, np.arange(E)[:, None], np.arange(A)[None, :])
+        sigma = O.noise_std_hadamard(l_pre, A)
+        np.testing.assert_allclose(a[0], np.clip(f["mu"] + 0.05 * sigma * z, -1, 1), rtol=1e-4, atol=2e-6)
+    # noise_scale = 1 and big sigma: the clamp holds
+    lib.naf_act_noise(h.data_ptr(), 32, acts[0].data_ptr(), 1, None, 0, 50.0, E, A, mode, st())
+    assert acts[0].abs().max().item() <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BatchNorm + ReLU
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H", [(256, 256), (2, 256), (64, 256), (2048, 256), (33, 40), (1024, 64)])
+def test_bn_relu_train_fwd_bwd_vs_oracle(lib, B, H):
+    rng = np.random.default_rng(B + H)
+    nets = 2
+    g = rng.standard_normal((nets, B, H)) * 2 + 0.5
+    bias, gamma, beta = rng.standard_normal((nets, H)), rng.uniform(0.5, 1.5, (nets, H)), rng.standard_normal((nets, H))
+    rm, rv = rng.standard_normal((nets, H)), rng.uniform(0.5, 2, (nets, H))
+    P = 3 * H + 16   # fake flat layout: [bias | gamma | beta | pad] per net
+    flat = np.zeros((nets, P), np.float32)
+    flat[:, :H], flat[:, H:2 * H], flat[:, 2 * H:3 * H] = bias, gamma, beta
+    flat_d, g_d = dev(flat), dev(g)
+    stats = dev(np.stack([rm, rv], 1))                                 # [nets][2][H]
+    ldo = H + 8
+    out = torch.zeros(nets, B, ldo, device="cuda")
+    sm, si = torch.empty(nets, H, device="cuda"), torch.empty(nets, H, device="cuda")
+    fp = flat_d.data_ptr()
+    assert lib.naf_bn_relu_fwd_train(g_d.data_ptr(), B * H, H, fp, fp + 4 * H, fp + 8 * H, P, stats.data_ptr(),
+                                     stats.data_ptr() + 4 * H, 2 * H, out.data_ptr(), B * ldo, ldo, sm.data_ptr(),
+                                     si.data_ptr(), B, H, nets, 0.1, 1e-5, st()) == 0
+    outn, statn = out.cpu().numpy(), stats.cpu().numpy()
+    tol = 5e-5 if B > 2 else 2e-3     # a batch of 2 amplifies rounding (x - mean)/sqrt(var+eps) with var ~ eps
+    caches = []
+    for n in range(nets):
+        z = (g[n] + bias[n])
+        y, cache, nrm, nrv = O.bn_train_forward(z, gamma[n], beta[n], rm[n], rv[n])
+        caches.append((z, cache))
+        np.testing.assert_allclose(outn[n, :, :H], np.maximum(y, 0), rtol=tol, atol=tol)
+        assert (outn[n, :, H:] == 0).all()                             # columns beyond H are never touched
+        np.testing.assert_allclose(statn[n, 0], nrm, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(statn[n, 1], nrv, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sm[n].cpu().numpy(), cache["mean"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(si[n].cpu().numpy(), cache["invstd"], rtol=1e-4)
+    # backward for net 0
+    d_out = rng.standard_normal((B, ldo))
+    z, cache = caches[0]
+    dy = d_out[:, :H] * (outn[0, :, :H] > 0)
+    dz, dgam, dbet = O.bn_train_backward(dy, {"xhat": (z - sm[0].cpu().numpy().astype(np.float64)) * si[0].cpu().numpy(),
+                                              "invstd": si[0].cpu().numpy().astype(np.float64)}, gamma[0])
+    dzd = torch.empty(B, H, device="cuda")
+    dg, db, dbias = (torch.empty(H, device="cuda") for _ in range(3))
+    d_out_d = dev(d_out)
+    assert lib.naf_bn_relu_bwd(d_out_d.data_ptr(), ldo, g_d.data_ptr(), H, fp, out.data_ptr(), ldo, fp + 4 * H,
+                               sm.data_ptr(), si.data_ptr(), dzd.data_ptr(), H, dg.data_ptr(), db.data_ptr(),
+                               dbias.data_ptr(), B, H, st()) == 0
+    s = max(1.0, np.abs(dz).max())
+    np.testing.assert_allclose(dzd.cpu().numpy(), dz, rtol=1e-3, atol=2e-5 * s)
+    np.testing.assert_allclose(dg.cpu().numpy(), dgam, rtol=1e-3, atol=1e-4 * np.abs(dgam).max())
+    np.testing.assert_allclose(db.cpu().numpy(), dbet, rtol=1e-3, atol=1e-4 * np.abs(dbet).max())
+    np.testing.assert_allclose(dbias.cpu().numpy(), 0, atol=1e-3 * s)   # bias under train-mode BN: gradient ~ 0
+
+
+def test_bn_relu_eval_vs_oracle(lib):
+    rng = np.random.default_rng(0)
+    B, H = 64, 256
+    g, bias = rng.standard_normal((B, H)), rng.standard_normal(H)
+    gamma, beta, rm, rv = rng.uniform(.5, 1.5, H), rng.standard_normal(H), rng.standard_normal(H), rng.uniform(.5, 2, H)
+    out = torch.zeros(B, H + 8, device="cuda")
+    t = [dev(x) for x in (g, bias, gamma, beta, rm, rv)]
+    assert lib.naf_bn_relu_fwd_eval(t[0].data_ptr(), H, t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(),
+                                    t[5].data_ptr(), out.data_ptr(), H + 8, B, H, 1e-5, st()) == 0
+    exp = np.maximum(O.bn_eval_forward(g + bias, gamma, beta, rm, rv), 0)
+    np.testing.assert_allclose(out.cpu().numpy()[:, :H], exp, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# optimizer
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [83264, 4096, 5000, 1023])
+def test_polyak_bit_exact(lib, n):
+    rng = np.random.default_rng(n)
+    main, tgt = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    tau = 1e-3
+    md, td = dev(main), dev(tgt)
+    assert lib.naf_polyak_update(td.data_ptr(), md.data_ptr(), tau, float(1.0 - tau), n, st()) == 0
+    exp = O.polyak(tgt, main, tau)      # f32: fl(fl(tau*main) + fl((1-tau)*target)), exactly the reference's expression
+    np.testing.assert_array_equal(td.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("n,gscale,world", [(83264, 1.0, 1), (83264, 1e-3, 1), (5000, 30.0, 1), (83264, 1.0, 8)])
+def test_clip_adam_polyak_vs_oracle(lib, n, gscale, world):
+    """5 consecutive optimizer steps. Tolerance: 2e-6 absolute on parameters (step size is lr = 1e-3, f32)."""
+    rng = np.random.default_rng(1)
+    th = rng.standard_normal(n).astype(np.float32) * 0.05
+    tg = th.copy()
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    thd, tgd, md, vd = dev(th), dev(tg), dev(m), dev(v)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nparts = (n + 4095) // 4096
+    parts = torch.zeros(nparts, device="cuda")
+    lr, tau = 1e-3, 1e-3
+    for t in range(1, 6):
+        g = (rng.standard_normal(n) * gscale).astype(np.float32)
+        g[rng.random(n) < 0.3] = 0.0          # exact zeros: padding and Hadamard-dead weights
+        gd = dev(g)
+        assert lib.naf_grad_norm_partials(gd.data_ptr(), n, parts.data_ptr(), step.data_ptr(), st()) == 0
+        assert lib.naf_adam_polyak_fused(thd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), tgd.data_ptr(),
+                                         parts.data_ptr(), nparts, 1.0, lr, 0.9, 0.999, 1e-8, tau, float(1 - tau),
+                                         step.data_ptr(), 1.0 / world, n, st()) == 0
+        gavg = (g.astype(np.float64) / world)
+        grads, total = O.clip_grad_norm({"g": gavg.astype(np.float32)}, 1.0)
+        np.testing.assert_allclose(np.sqrt(parts.sum().item()) / world, total, rtol=1e-5)
+        th, m, v = O.adam_step(th, grads["g"], m, v, t, lr)
+        tg = O.polyak(tg, th, tau)
+        assert int(step.item()) == t
+        np.testing.assert_allclose(thd.cpu().numpy(), th, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(md.cpu().numpy(), m, rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(tgd.cpu().numpy(), tg, rtol=0, atol=1e-6)
+        zero = g == 0
+        if t == 1:
+            assert (thd.cpu().numpy()[zero] == th[zero]).all()        # zero gradient + zero moments: no movement
+
+
+def test_symbols_exported(lib):
+    from robotic_manipulator_rloa_amd import _lib
+    for name in _lib.EXPORTED_SYMBOLS:
+        assert hasattr(lib, name)
+    assert lib.naf_hip_arch() == b"gfx950"

@@ -1,0 +1,189 @@
+"""CPU: pins oracle/naf_oracle.py against the golden vectors generated from the unmodified reference
+(tests/golden/make_golden.py). If these fail the oracle may not be used as a checker."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_group
+from oracle import naf_oracle as O
+
+
+def assert_adam_stepped_close(actual, desired, lr, msg=""):
+    """Parameters after an Adam step: the first step is lr*g/(|g|+eps), so an element whose gradient is within
+    rounding noise of 0 (|g| <~ 1e-7) may legitimately land anywhere within +-lr. Require: every element within
+    one full step, and all but 0.1 % of them within 2 % of a step."""
+    err = np.abs(np.asarray(actual, np.float64) - np.asarray(desired, np.float64))
+    assert err.max() <= 2.02 * lr, f"{msg}: max err {err.max()}"
+    frac_bad = (err > 0.02 * lr).mean()
+    assert frac_bad <= 1e-3, f"{msg}: {frac_bad:.2e} of elements off by more than 2% of a step"
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def test_g1_reference_known_answer():
+    """The reference's only numeric test (tests/.../test_naf_neural_network.py:53-67): BN over a batch of 2
+    amplifies rounding, torch-version drift alone is 4.5e-6 relative -> rtol 2e-5."""
+    g = _npz("g1_known_answer.npz")
+    sd = load_group(g, "sd")
+    for dtype, rtol in ((np.float32, 2e-5), (np.float64, 2e-5)):
+        p = O.cast_params(sd, dtype)
+        out, _ = O.net_forward_train(p, g["states"], g["actions"].astype(np.float32))
+        np.testing.assert_allclose(out["Q"], g["q"].ravel(), rtol=rtol)
+        np.testing.assert_allclose(out["V"], g["v"].ravel(), rtol=rtol, atol=2e-6)
+        np.testing.assert_allclose(out["Q"], g["q_test_literal"].ravel(), rtol=2e-5)
+        np.testing.assert_allclose(out["V"], g["v_test_literal"].ravel(), rtol=5e-5)
+    p64 = O.cast_params(sd, np.float64)
+    out64, _ = O.net_forward_train(p64, g["states"], g["actions"].astype(np.float64))
+    np.testing.assert_allclose(out64["Q"], g["q_f64"].ravel(), rtol=1e-9)
+
+
+@pytest.mark.parametrize("A", [5, 6, 7])
+@pytest.mark.parametrize("B", [2, 256])
+@pytest.mark.parametrize("tag", ["rand", "wide"])
+def test_g2_head_forward_backward(A, B, tag):
+    g = load_group(_npz("g2_head.npz"), f"A{A}_B{B}_{tag}")
+    mu_pre, l_pre, V = g["mu_pre"].astype(np.float64), g["l_pre"].astype(np.float64), g["V"].astype(np.float64)
+    u = g["u_trunc"].astype(np.float64)
+    f = O.head_forward(mu_pre, l_pre, V, u, O.P_HADAMARD)
+    np.testing.assert_allclose(f["Q"], g["q"].ravel(), rtol=2e-5, atol=2e-5)
+    d_mu, d_l, d_V = O.head_backward(mu_pre, l_pre, u, g["dq"].ravel(), O.P_HADAMARD)
+    np.testing.assert_allclose(d_mu, g["d_mu_pre"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(d_l, g["d_l_pre"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(d_V, g["d_V"].ravel(), rtol=1e-6)
+    # the 'true NAF' mode must NOT agree with the reference (Q1): guards against silently fixing it
+    fm = O.head_forward(mu_pre, l_pre, V, u, O.P_MATMUL)
+    if B == 256:
+        assert np.abs(fm["Q"] - g["q"].ravel()).max() > 1e-3
+
+
+def test_head_backward_matches_finite_differences_both_modes():
+    rng = np.random.default_rng(0)
+    A, B = 6, 8
+    T = A * (A + 1) // 2
+    mu_pre, l_pre = rng.standard_normal((B, A)), rng.standard_normal((B, T))
+    u = rng.uniform(-1, 1, (B, A))
+    dq = rng.standard_normal(B)
+    for mode in (O.P_HADAMARD, O.P_MATMUL):
+        d_mu, d_l, _ = O.head_backward(mu_pre, l_pre, u, dq, mode)
+        eps = 1e-6
+        for (arr, grad) in ((mu_pre, d_mu), (l_pre, d_l)):
+            for (b, k) in ((0, 0), (3, 2), (7, arr.shape[1] - 1)):
+                hi, lo = arr.copy(), arr.copy()
+                hi[b, k] += eps
+                lo[b, k] -= eps
+                args_hi = (hi, l_pre) if arr is mu_pre else (mu_pre, hi)
+                args_lo = (lo, l_pre) if arr is mu_pre else (mu_pre, lo)
+                qh = O.head_forward(*args_hi, np.zeros(B), u, mode)["Q"]
+                ql = O.head_forward(*args_lo, np.zeros(B), u, mode)["Q"]
+                fd = ((qh - ql) * dq).sum() / (2 * eps)
+                assert abs(fd - grad[b, k]) < 1e-6 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize("tag", ["kuka", "panda"])
+def test_g3_full_learn_step(tag):
+    g = _npz("g3_learn.npz")
+    from synth_data import make_transitions
+    S, A, B = [int(x) for x in g[f"{tag}/dims"]]
+    st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
+    for dtype, tol in ((np.float64, 1.0), (np.float32, 4.0)):
+        L = O.LearnerOracle(load_group(g, f"{tag}/main0"), dtype=dtype, target_state_dict=load_group(g, f"{tag}/target0"))
+        losses = []
+        for k in range(5):
+            sl = slice(k * B, (k + 1) * B)
+            losses.append(L.learn(st[sl], ac[sl], rw[sl], ns[sl], dn[sl]))
+            if k == 0:
+                np.testing.assert_allclose(L.last["Q"], g[f"{tag}/q1"].ravel(), rtol=2e-4 * tol, atol=2e-4 * tol)
+                np.testing.assert_allclose(L.last["y"], g[f"{tag}/y1"].ravel(), rtol=1e-5 * tol, atol=1e-5 * tol)
+                gr = load_group(g, f"{tag}/grads1")
+                np.testing.assert_allclose(L.last["grad_norm"], float(g[f"{tag}/grad_norm1"]), rtol=1e-4 * tol)
+                scale = L.last["grad_norm"]
+                for name in O.PARAM_ORDER:
+                    if name in ("input_layer.bias", "hidden_layer.bias"):
+                        continue  # exactly-zero-in-theory gradients (bias under train-mode BN): rounding noise only
+                    np.testing.assert_allclose(L.last["grads"][name], gr[name], rtol=2e-3 * tol, atol=2e-6 * scale * tol,
+                                               err_msg=name)
+                for grp, state in (("main1", L.main), ("target1", L.target)):
+                    ref = load_group(g, f"{tag}/{grp}")
+                    for name, val in ref.items():
+                        if "num_batches" in name:
+                            assert int(state[name]) == int(val)
+                        elif name in ("input_layer.bias", "hidden_layer.bias"):
+                            # Adam normalises their rounding-noise gradient (|g| ~ 1e-9 ~ eps) into steps anywhere in
+                            # [-lr, lr]: un-pinnable by construction, and cancelled by the train-mode BN that follows
+                            np.testing.assert_allclose(state[name], val, atol=1.01e-3)
+                        elif "running" in name:
+                            np.testing.assert_allclose(state[name], val, rtol=1e-4, atol=2e-5 * tol, err_msg=f"{grp}/{name}")
+                        else:
+                            assert_adam_stepped_close(state[name], val, lr=1e-3, msg=f"{grp}/{name}")
+                for name in O.PARAM_ORDER:
+                    if name in ("input_layer.bias", "hidden_layer.bias"):
+                        continue
+                    np.testing.assert_allclose(L.m[name], g[f"{tag}/adam_m1/{name}"], rtol=2e-3 * tol, atol=1e-7 * tol)
+        np.testing.assert_allclose(losses, g[f"{tag}/losses5"], rtol=2e-3 * tol)
+
+
+def test_g4_replay_contract_and_fifo():
+    g = _npz("g4_replay.npz")
+    from synth_data import make_transitions
+    S, A, cap, B = [int(x) for x in g["dims"]]
+    st, ac, rw, ns, dn = make_transitions(500, S, A, seed=11)
+    buf = O.ReplayOracle(cap, B, 0)
+    for i in range(500):
+        s = st[i].astype(np.float64).copy()
+        s[0] = float(i)
+        buf.add(s, ac[i], float(rw[i]), ns[i].astype(np.float64), int(dn[i]))
+    assert len(buf) == cap
+    rows = buf.rows()
+    np.testing.assert_array_equal(rows[:, 0], g["ids_in_order"])       # FIFO eviction keeps the newest `cap`
+    # random.sample(deque) == positions from random.sample(range(len)) with the same RNG state
+    import random
+    random.seed(0)
+    for k in range(3):
+        pos = buf.sample_positions_reference()
+        np.testing.assert_array_equal(pos, g["positions_from_range"][k])
+        np.testing.assert_array_equal(rows[pos, 0], g["sampled_ids"][k])
+        if k == 0:
+            s, a, r, s2, d = buf.take(pos)
+            np.testing.assert_array_equal(s, g["s"])
+            np.testing.assert_array_equal(a, g["a"])                     # int64, truncated toward zero (Q2)
+            assert a.dtype == np.int64 and set(np.unique(a)) <= {-1, 0, 1}
+            np.testing.assert_array_equal(r, g["r"])
+            np.testing.assert_array_equal(s2, g["s2"])
+            np.testing.assert_array_equal(d, g["d"])
+    assert list(g["dtypes"]) == ["torch.float32", "torch.int64", "torch.float32", "torch.float32", "torch.float32"]
+
+
+def test_g6_act_eval_mode():
+    g = _npz("g6_act.npz")
+    for name in ("kuka", "xarm6"):
+        sd = load_group(g, f"{name}/sd")
+        out = O.net_forward_eval(O.cast_params(sd, np.float32), g[f"{name}/x"])
+        np.testing.assert_allclose(out["mu"], g[f"{name}/mu"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out["l_pre"], g[f"{name}/l_pre"], rtol=1e-4, atol=1e-5)
+        # distribution of the reference's noisy actions (256 draws per state): clamp(N(mu, sigma^2))
+        sigma = O.noise_std_hadamard(out["l_pre"], 6)
+        assert sigma.min() >= np.exp(-1) - 1e-6 and sigma.max() <= np.e + 1e-6
+        unclamped = np.abs(out["mu"]) + 3 * sigma < 1.0                   # entries where the clamp never bites
+        if unclamped.any():
+            np.testing.assert_allclose(g[f"{name}/act_std"][unclamped], sigma[unclamped], rtol=0.25)
+
+
+def test_sampler_restatement_properties():
+    idx = O.replay_sample_indices(seed=1234, counter=5, size=1000, B=256, n_batches=4)
+    assert idx.shape == (4, 256) and idx.min() >= 0 and idx.max() < 1000
+    for b in range(4):
+        assert len(set(idx[b].tolist())) == 256                          # without replacement inside a minibatch
+    # tiny population: forces many redraw rounds
+    idx = O.replay_sample_indices(seed=7, counter=0, size=257, B=256, n_batches=2)
+    for b in range(2):
+        assert len(set(idx[b].tolist())) == 256
+    again = O.replay_sample_indices(seed=7, counter=0, size=257, B=256, n_batches=2)
+    np.testing.assert_array_equal(idx, again)
+    # philox known-answer (Random123 kat_vectors: philox4x32-10, all-zero and all-ones inputs)
+    v = O.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(x) for x in v] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    v = O.philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
+    assert [int(x) for x in v] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
