@@ -1,0 +1,156 @@
+"""HIP-graph engines around the Learner: the steady-state loop of NAFAgent.step()/run()
+(reference naf_components/naf_algorithm.py:129-156, :228-270) with zero host<->device synchronisation.
+
+  TrainChunk     : [sample U minibatches] -> [gather U*B rows, one launch] -> U x learn()  as ONE graph.
+  DeviceEnvLoop  : E synthetic arms stepped on the device: act (eval-mode policy + noise) -> env step ->
+                   append E transitions to the HBM ring, as ONE graph; followed by a TrainChunk with
+                   U = E * num_updates / update_freq so the reference's update-to-data ratio is kept.
+
+Graph capture goes through torch.cuda.CUDAGraph (= hipGraph on ROCm): the ctypes kernel launches use the
+stream torch reports as current, which inside the capture context is the capturing stream.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .learner import ActPath, Learner
+from .utils.replay_buffer import ReplayBuffer
+
+
+class _StateSnapshot:
+    """Warm-up before capture must not leave a trace: save/restore every piece of mutable learner state."""
+
+    def __init__(self, learner: Learner, replay: Optional[ReplayBuffer], extra=()):
+        self.pairs = [(t, t.clone()) for t in (learner.theta2, learner.grad, learner.adam_m, learner.adam_v,
+                                               learner.bn_stats, learner.step_dev, learner.partials)]
+        if replay is not None and replay._handle is not None:
+            self.pairs += [(t, t.clone()) for t in (replay.meta, replay._sample_ctr)]
+        self.pairs += [(t, t.clone()) for t in extra]
+
+    def restore(self) -> None:
+        for live, saved in self.pairs:
+            live.copy_(saved)
+
+
+def _capture(body, snapshot: _StateSnapshot, warmup: int = 2, after_warmup=None) -> torch.cuda.CUDAGraph:
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):        # lets hipBLASLt pick kernels / allocate workspaces outside the capture
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    snapshot.restore()
+    if after_warmup is not None:
+        after_warmup()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    snapshot.restore()                 # capture does not execute, but keep the contract explicit
+    torch.cuda.synchronize()
+    return g
+
+
+class TrainChunk:
+    """U consecutive learn() updates on U freshly sampled minibatches."""
+
+    def __init__(self, learner: Learner, replay: ReplayBuffer, n_updates: int, teacher_forced: bool = False,
+                 use_graph: bool = True):
+        self.L, self.replay, self.U = learner, replay, int(n_updates)
+        self.teacher_forced = teacher_forced
+        B, dev = learner.B, learner.dev
+        if replay.batch_size != B:
+            raise ValueError("ReplayBuffer.batch_size must equal the learner's batch size")
+        self.idx = torch.zeros(self.U, B, dtype=torch.int32, device=dev)
+        self.batch = torch.zeros(self.U, B, learner.lay.row_floats, dtype=torch.float32, device=dev)
+        self.loss_parts = torch.zeros(self.U, learner.n_loss_wg, dtype=torch.float32, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.use_graph = use_graph
+
+    def _body(self) -> None:
+        if not self.teacher_forced:
+            self.replay.sample_indices(self.idx, self.U)
+        self.replay.gather_rows(self.idx, self.batch, self.U * self.L.B)
+        for k in range(self.U):
+            self.L.learn_rows(self.batch[k], self.loss_parts[k])
+
+    def capture(self) -> None:
+        self.replay.flush()
+        self.graph = _capture(self._body, _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts)))
+
+    def run(self) -> None:
+        """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first."""
+        if self.use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self._body()
+
+    def losses(self) -> torch.Tensor:
+        """[U] MSE losses of the last run (device tensor; summing the per-workgroup parts in index order)."""
+        return self.loss_parts.sum(dim=1)
+
+
+class DeviceEnvLoop:
+    """E synthetic manipulator envs living on the GPU (csrc/synth_env.hip) driven by the agent's policy."""
+
+    def __init__(self, learner: Learner, replay: ReplayBuffer, n_envs: int, seed: int, max_frames: int = 400,
+                 noise_scale: float = 1.0, use_graph: bool = True):
+        self.L, self.replay, self.E = learner, replay, int(n_envs)
+        lay, dev = learner.lay, learner.dev
+        self.lib = learner.lib
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.max_frames = int(max_frames)
+        self.noise_scale = float(noise_scale)
+        self.actor = ActPath(learner, self.E, seed=self.seed ^ 0xA5A5A5A5)
+        nst = self.lib.naf_synth_env_state_floats(lay.A)
+        self.env_state = torch.zeros(self.E, nst, dtype=torch.float32, device=dev)
+        self.rows = torch.zeros(self.E, lay.row_floats, dtype=torch.float32, device=dev)
+        self.step_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.use_graph = use_graph
+        self.env_steps = 0
+        self.reset()
+
+    def reset(self) -> None:
+        check(self.lib.naf_synth_env_reset(ptr(self.env_state), ptr(self.actor.obs), self.E, self.L.lay.A, self.seed, 0,
+                                           stream_ptr()), "synth_env_reset")
+
+    def _body(self) -> None:
+        st = stream_ptr()
+        self.actor.act(self.noise_scale)                                     # NAFAgent.act for E states
+        check(self.lib.naf_synth_env_step(ptr(self.env_state), ptr(self.actor.actions), ptr(self.rows),
+                                          ptr(self.actor.obs), self.E, self.L.lay.A, self.seed, ptr(self.step_ctr),
+                                          self.max_frames, st), "synth_env_step")   # environment.step
+        check(self.lib.naf_counter_add(ptr(self.step_ctr), 1, st), "counter_add")
+        check(self.lib.naf_replay_add_batch(self.replay.handle, ptr(self.rows), self.E, st), "replay_add_batch")
+
+    def capture(self) -> None:
+        warmup = 2
+        snap = _StateSnapshot(self.L, self.replay, (self.env_state, self.rows, self.step_ctr, self.actor.obs,
+                                                    self.actor.counter, self.actor.actions))
+        # the warm-up appends rows to the ring: {head,size} come back with the snapshot, the ring slots it wrote
+        # (possibly live rows of a full ring) are saved and put back here
+        head = int(self.replay.meta[0].item())
+        pos = (head + torch.arange(warmup * self.E, device=self.L.dev)) % self.replay.buffer_size
+        saved = self.replay.rows[pos].clone()
+
+        def put_back():
+            self.replay.rows[pos] = saved
+        self.graph = _capture(self._body, snap, warmup=warmup, after_warmup=put_back)
+
+    def step(self) -> None:
+        """One vector step: E env transitions appended to the replay ring (asynchronous)."""
+        if self.use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self._body()
+        self.replay._total_added += self.E
+        self.env_steps += self.E

@@ -96,7 +96,9 @@ class ReplayBuffer:
         if n == 0:
             return
         self._stage_dev[:n].copy_(self._stage_host[:n], non_blocking=True)
-        self.add_rows_device(self._stage_dev, n, _count=False)
+        for lo in range(0, n, self.buffer_size):      # a ring smaller than the staging area: append in ring-sized pieces
+            k = min(self.buffer_size, n - lo)
+            self.add_rows_device(self._stage_dev[lo:lo + k], k, _count=False)
         # the pinned staging buffer is rewritten by the next add(): wait for the H2D copy (one event per flush)
         torch.cuda.current_stream().synchronize()
         self._pending = 0

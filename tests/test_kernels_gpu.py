@@ -248,9 +248,12 @@ def test_act_noise_distribution(lib, mode):
     a = acts.cpu().numpy().astype(np.float64)
     f = O.head_forward(mu_pre, l_pre, np.zeros(E), np.zeros((E, A)), mode)
     cov = np.linalg.inv(f["P"]) * 0.05 ** 2                      # noise_scale^2 * inverse(P); small so the clamp is idle
-    np.testing.assert_allclose(a.mean(0), f["mu"], atol=5 * np.sqrt(np.einsum("eii->ei", cov).max() / n_draws))
+    sd = np.sqrt(np.einsum("eii->ei", cov))
+    free = (np.abs(f["mu"]) + 4.5 * sd < 1.0).all(axis=1)          # states where the +-1 clamp never bites
+    assert free.sum() >= E // 2
+    np.testing.assert_allclose(a.mean(0)[free], f["mu"][free], atol=5 * sd[free].max() / np.sqrt(n_draws))
     emp = np.einsum("kei,kej->eij", a - a.mean(0), a - a.mean(0)) / (n_draws - 1)
-    np.testing.assert_allclose(emp, cov, rtol=0.25, atol=0.12 * np.abs(cov).max())
+    np.testing.assert_allclose(emp[free], cov[free], rtol=0.25, atol=0.12 * np.abs(cov[free]).max())
     # Hadamard: exact stream check for draw 0
     if mode == 0:
         z = O.normal_from_philox(42, 0, np.arange(E)[:, None], np.arange(A)[None, :])
@@ -369,8 +372,8 @@ def test_clip_adam_polyak_vs_oracle(lib, n, gscale, world):
         tg = O.polyak(tg, th, tau)
         assert int(step.item()) == t
         np.testing.assert_allclose(thd.cpu().numpy(), th, rtol=0, atol=2e-6)
-        np.testing.assert_allclose(md.cpu().numpy(), m, rtol=1e-5, atol=1e-9)
-        np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(md.cpu().numpy(), m, rtol=5e-5, atol=1e-9)      # clip factor from an f32 norm
+        np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-4, atol=1e-12)
         np.testing.assert_allclose(tgd.cpu().numpy(), tg, rtol=0, atol=1e-6)
         zero = g == 0
         if t == 1:
