@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s + learn() updates/s of the NAF hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): KUKA IIWA 6-DoF shapes (S=21, A=6, H=256), 64 envs per GPU, batch 256,
+HBM replay of 1e6 transitions (pre-filled, so the ring is full and evicting), HIP NAF head, Hadamard P and
+truncated actions = the reference's semantics. One "step" = one vector-env step of the per-timestep hot path
+(reference naf_algorithm.py:249-261 for 64 envs): act(64 states) -> env step -> 64 transitions appended ->
+64 x (sample 256 + learn()), i.e. the reference's update-to-data ratio (update_freq = num_updates = 1).
+The simulator is the on-device synthetic stand-in (PyBullet is not installable here) — labelled in `data`.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, gradients all-reduced over RCCL each update)
+
+Prints ONE JSON line (rank 0). `value` = env-steps/s summed over all ranks (= learn() updates/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def synth_rows(n, S, A, row_floats, seed, device):
+    """Transition rows of the BASELINE value ranges, generated on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rows = torch.zeros(n, row_floats, device=device)
+    chunk = 1 << 18
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        s = torch.randn(m, S, generator=g, device=device).clamp_(-3.1416, 3.1416)
+        s2 = (s + 0.05 * torch.randn(m, S, generator=g, device=device)).clamp_(-3.1416, 3.1416)
+        a = torch.rand(m, A, generator=g, device=device) * 2 - 1
+        sat = torch.rand(m, A, generator=g, device=device) < 0.10
+        a = torch.where(sat, torch.sign(a), a)
+        r = -1.5 * torch.rand(m, generator=g, device=device)
+        ev = torch.rand(m, generator=g, device=device)
+        r = torch.where(ev < 0.0025, torch.full_like(r, 250.0), r)
+        r = torch.where((ev >= 0.0025) & (ev < 0.005), torch.full_like(r, -1000.0), r)
+        blk = rows[lo:lo + m]
+        blk[:, :S], blk[:, S:S + A], blk[:, S + A] = s, a, r
+        blk[:, S + A + 1:2 * S + A + 1], blk[:, 2 * S + A + 1] = s2, (ev < 0.005).float()
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--buffer", type=int, default=1_000_000)
+    ap.add_argument("--p-mode", choices=["hadamard", "matmul"], default="hadamard")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.engine import DeviceEnvLoop, TrainChunk
+    from robotic_manipulator_rloa_amd.learner import Learner
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+
+    S, A, H, B, E, N = 21, 6, 256, args.batch, args.envs, args.buffer
+    p_mode = _lib.P_HADAMARD if args.p_mode == "hadamard" else _lib.P_MATMUL
+    L = Learner(S, A, H, B, 1e-3, 1e-3, 0.99, dev, p_mode=p_mode, world_size=world)
+    sd = reference_init_state_dict(S, A, H, seed=0)          # same seed on every rank: replicas start identical
+    L.load_params(0, sd)
+    L.load_params(1, sd)
+    if world > 1:
+        dist.broadcast(L.theta2, src=0)
+    replay = ReplayBuffer(N, B, dev, seed=1000 + rank, state_size=S, action_size=A)
+    rows = synth_rows(N, S, A, replay.row_floats, seed=77 + rank, device=dev)
+    replay.add_rows_device(rows, N)
+    del rows
+    loop = DeviceEnvLoop(L, replay, E, seed=31 + rank, max_frames=400, use_graph=not args.no_graph)
+    U = E   # update_freq = num_updates = 1: one learn() per env transition (naf_algorithm.py:147-156)
+    chunk = TrainChunk(L, replay, U, use_graph=not args.no_graph, gather_outside_graph=True)
+    graph_note = "hipGraph"
+    try:
+        if not args.no_graph:
+            loop.capture()
+            chunk.capture()
+    except Exception as e:  # e.g. a collective that cannot be captured: run the same launches eagerly
+        if rank == 0:
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        loop.use_graph = chunk.use_graph = False
+        graph_note = "eager"
+
+    def one_step():
+        loop.step()
+        chunk.run()
+
+    for _ in range(args.warmup):
+        one_step()
+    # ---- timed region: exactly K steps between barrier + synchronize on both sides -------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        chunk.gather_events = ev[k]
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    chunk.gather_events = None
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    gather_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    finite = bool(torch.isfinite(L.theta2).all().item())
+    bad = replay.bad_index_count()
+    env_steps = args.steps * E * world
+    updates = args.steps * U * world
+    value = env_steps / elapsed
+
+    out = {
+        "metric": "env-steps/s (= learn() updates/s at update_freq=1,num_updates=1), KUKA 6-DoF NAF batch=256",
+        "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (on-device kinematic stand-in env; replay pre-filled "
+        "with synthetic transitions; random-init weights, seed 0)",
+        "config": {"workload": f"configs[1]: KUKA 6-DoF shapes S=21 A=6 H=256, {E} envs/GPU, batch {B}, HBM replay {N}, "
+                               f"HIP NAF head ({args.p_mode} P), {U} learn() per vector step",
+                   "launch": graph_note, "parallelism": f"dp{world}" if world > 1 else "single"},
+        "updates_per_s": round(updates / elapsed, 1),
+        "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": int(L.step_dev.item())},
+    }
+    # ---- roofline of the replay gather (the kernel north_star names), measured live with events -----------
+    rows_per_launch = U * B
+    alg_bytes = rows_per_launch * (4 * (2 * S + A + 2) * 2 + 4)       # 400 B/row read+written + 4 B index
+    out["roofline"] = {"kernel": "replay_gather_rows_kernel", "bound": "hbm",
+                       "achieved": round(alg_bytes / (gather_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                       "frac": round(alg_bytes / (gather_ms * 1e-3) / 8e12, 4), "traffic": None,
+                       "rows_per_launch": rows_per_launch, "alg_bytes_per_launch": alg_bytes,
+                       "avg_launch_ms": round(gather_ms, 5),
+                       "note": "event-bracketed single launch inside the timed loop (includes ~event overhead); "
+                               "kernel-only duration: profiles/"}
+    if rank == 0 and world == 1:
+        out["roofline_bulk"] = bulk_gather(replay, dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.torch_cpu_port import time_baseline
+        cb = time_baseline(S, A, H, B, N, budget_s=args.cpu_budget)
+        out["cpu_baseline"] = {"value": round(cb["steps_per_s"], 2), "unit": "env-steps/s", "cores": cb["threads"],
+                               "kind": "port",
+                               "sample": f"oracle/torch_cpu_port.py (reference op order incl. deque+random.sample "
+                                         f"sampler), act+add+sample+learn for {cb['n_steps']} timesteps, B={B}, "
+                                         f"deque filled to N={N}; learn()-only {cb['learn_updates_per_s']:.1f} "
+                                         f"updates/s over {cb['n_learn']} calls; host has {cb['host_cpus']} cpus",
+                               "learn_only_updates_per_s": round(cb["learn_updates_per_s"], 2)}
+        out["speedup_vs_cpu_port"] = round(value / cb["steps_per_s"], 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bulk_gather(replay, dev, n_rows=1 << 22, reps=20):
+    """The same gather kernel on a launch big enough to be bandwidth- instead of latency-bound: 4 Mi uniformly
+    random rows (1.07 GB of row traffic per launch) out of the 1e6-row (256 MB) ring."""
+    idx = torch.randint(0, len(replay), (n_rows,), device=dev, dtype=torch.int32)
+    out = torch.empty(n_rows, replay.row_floats, device=dev)
+    for _ in range(3):
+        replay.gather_rows(idx, out, n_rows)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        replay.gather_rows(idx, out, n_rows)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    alg = n_rows * (4 * (2 * replay.S + replay.A + 2) * 2 + 4)
+    phys = n_rows * (replay.row_floats * 4 * 2 + 4)
+    return {"kernel": "replay_gather_rows_kernel", "rows_per_launch": n_rows, "avg_launch_ms": round(ms, 4),
+            "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 8e12, 4),
+            "physical_GBps": round(phys / (ms * 1e-3) / 1e9, 1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -59,9 +59,13 @@ class TrainChunk:
     """U consecutive learn() updates on U freshly sampled minibatches."""
 
     def __init__(self, learner: Learner, replay: ReplayBuffer, n_updates: int, teacher_forced: bool = False,
-                 use_graph: bool = True):
+                 use_graph: bool = True, gather_outside_graph: bool = False):
+        """gather_outside_graph: launch sample+gather eagerly in front of the graph of U updates, so the caller can
+        bracket the gather launch with events (bench.py's live roofline measurement)."""
         self.L, self.replay, self.U = learner, replay, int(n_updates)
         self.teacher_forced = teacher_forced
+        self.gather_outside_graph = gather_outside_graph
+        self.gather_events = None          # optional (start, end) torch.cuda.Event pair recorded around the gather
         B, dev = learner.B, learner.dev
         if replay.batch_size != B:
             raise ValueError("ReplayBuffer.batch_size must equal the learner's batch size")
@@ -71,22 +75,40 @@ class TrainChunk:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph
 
-    def _body(self) -> None:
+    def _sample_gather(self) -> None:
         if not self.teacher_forced:
             self.replay.sample_indices(self.idx, self.U)
+        ev = self.gather_events
+        if ev is not None:
+            ev[0].record()
         self.replay.gather_rows(self.idx, self.batch, self.U * self.L.B)
+        if ev is not None:
+            ev[1].record()
+
+    def _updates(self) -> None:
         for k in range(self.U):
             self.L.learn_rows(self.batch[k], self.loss_parts[k])
 
+    def _body(self) -> None:
+        self._sample_gather()
+        self._updates()
+
     def capture(self) -> None:
         self.replay.flush()
-        self.graph = _capture(self._body, _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts)))
+        snap = _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts))
+        if self.gather_outside_graph:
+            self._sample_gather()          # the updates need a valid batch to warm up on
+            self.graph = _capture(self._updates, snap)
+        else:
+            self.graph = _capture(self._body, snap)
 
     def run(self) -> None:
         """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first."""
         if self.use_graph:
             if self.graph is None:
                 self.capture()
+            if self.gather_outside_graph:
+                self._sample_gather()
             self.graph.replay()
         else:
             self._body()

@@ -17,6 +17,7 @@ Design:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -29,6 +30,35 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
 MAX_GRAD_NORM = 1.0
+
+
+_BLAS_CONFIGURED = False
+TUNING_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
+
+
+def configure_blas() -> str:
+    """Pick the GEMM kernels PyTorch-ROCm will use for the (tiny) trunk GEMMs.
+    Measured on MI355X (benchmarks/gemm_probe.py, B=256): hipBLASLt's default heuristic runs the 256x256x256 f32
+    GEMMs as ONE 256x256 macro-tile on one CU (63 us each, 239 us for the 8 GEMMs of an update); rocBLAS takes
+    42 us for the 8; with the shipped TunableOp results (best rocBLAS/hipBLASLt solution per shape) 26 us.
+    Env: NAF_BLAS_DEFAULT=1 leaves torch's BLAS settings untouched; NAF_BLAS_TUNING_FILE overrides the results file
+    ('none' disables it)."""
+    global _BLAS_CONFIGURED
+    if _BLAS_CONFIGURED or os.environ.get("NAF_BLAS_DEFAULT") == "1":
+        _BLAS_CONFIGURED = True
+        return "default"
+    _BLAS_CONFIGURED = True
+    torch.backends.cuda.preferred_blas_library("cublas")           # = rocBLAS on ROCm
+    path = os.environ.get("NAF_BLAS_TUNING_FILE", TUNING_FILE)
+    if path != "none" and os.path.exists(path):
+        try:
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(False)                # look up only: never tune inside a training run
+            torch.cuda.tunable.read_file(path)
+            return "rocblas+tunableop"
+        except Exception:                                          # results from another library build: ignore them
+            torch.cuda.tunable.enable(False)
+    return "rocblas"
 
 
 def _round_up(x: int, m: int) -> int:
@@ -113,6 +143,7 @@ class Learner:
                  world_size: int = 1, process_group=None):
         _lib.require_gpu()
         self.lib = _lib.load()
+        self.blas = configure_blas()
         self.dev = torch.device(device)
         self.lay = NetLayout(state_size, action_size, layer_size)
         self.B = int(batch_size)

@@ -1,0 +1,202 @@
+"""NAF network with the reference's interface (naf_components/naf_neural_network.py:8-123) whose parameters are
+views into a flat HBM buffer and whose forward runs on libnaf_hip.so kernels + PyTorch-ROCm GEMMs.
+
+    NAF(state_size, action_size, layer_size, seed, device)
+    forward(input_, action=None) -> (noisy clamped action (B,A), Q (B,1) | None, V (B,1))
+
+Same state_dict keys/shapes, same parameters() order, same seed -> bit-identical initial weights (the
+constructor consumes torch's global CPU RNG exactly as the reference's does).
+Reference quirks kept on purpose: P = L * L^T elementwise (p_mode='hadamard', the default;
+'matmul' gives textbook NAF), integer actions are accepted and promoted, every forward draws exploration noise.
+forward() does not build an autograd graph: training goes through NAFAgent.learn(), whose backward is fused
+into the HIP kernels.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Any, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .._lib import check, ptr, stream_ptr
+from ..learner import BN_EPS, BN_MOMENTUM, NetLayout, PARAM_ORDER
+
+_P_MODES = {"hadamard": _lib.P_HADAMARD, "matmul": _lib.P_MATMUL, 0: 0, 1: 1}
+
+
+def reference_init_state_dict(state_size: int, action_size: int, layer_size: int, seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """CPU state_dict with exactly the weights the reference constructor produces for `seed`: it calls
+    torch.manual_seed(seed) and then builds Linear/BatchNorm1d layers in this order
+    (naf_neural_network.py:33-54), so doing the same with stock torch modules reproduces the draws."""
+    torch.manual_seed(seed)
+    T = int(action_size * (action_size + 1) / 2)
+    mods = OrderedDict([
+        ("input_layer", nn.Linear(state_size, layer_size)), ("bn1", nn.BatchNorm1d(layer_size)),
+        ("hidden_layer", nn.Linear(layer_size, layer_size)), ("bn2", nn.BatchNorm1d(layer_size)),
+        ("action_values", nn.Linear(layer_size, action_size)), ("value", nn.Linear(layer_size, 1)),
+        ("matrix_entries", nn.Linear(layer_size, T))])
+    sd = OrderedDict()
+    for name, m in mods.items():
+        for k, v in m.state_dict().items():
+            sd[f"{name}.{k}"] = v.detach().clone()
+    return sd
+
+
+class NAF(nn.Module):
+
+    def __init__(self, state_size: int, action_size: int, layer_size: int, seed: int, device, *,
+                 p_mode="hadamard", _flat: Optional[torch.Tensor] = None, _bn: Optional[torch.Tensor] = None,
+                 _init: bool = True) -> None:
+        """
+        Args (reference order, naf_neural_network.py:10): state_size, action_size, layer_size, seed, device.
+        p_mode: 'hadamard' (reference parity) or 'matmul'.
+        _flat/_bn: storage handed in by NAFAgent so main and target share one [2,P] allocation.
+        """
+        super().__init__()
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.seed = torch.manual_seed(seed)          # same global side effect as the reference (:33)
+        self.state_size, self.action_size, self.layer_size = state_size, action_size, layer_size
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NafHipError("NAF runs on the MI355X only (device must be cuda:N); there is no CPU path")
+        self.p_mode = _P_MODES[p_mode]
+        self.layout = NetLayout(state_size, action_size, layer_size)
+        lay = self.layout
+        self.flat = _flat if _flat is not None else torch.zeros(lay.P, dtype=torch.float32, device=self.device)
+        self.bn_stats = _bn if _bn is not None else torch.zeros(4, layer_size, dtype=torch.float32, device=self.device)
+        if _bn is None:
+            self.bn_stats[1].fill_(1.0)
+            self.bn_stats[3].fill_(1.0)
+        T = lay.T
+        # nn.Module facade: stock layers (meta-device, nothing allocated) whose tensors are re-pointed at the flat buffer
+        with torch.device("meta"):
+            self.input_layer = nn.Linear(state_size, layer_size)
+            self.bn1 = nn.BatchNorm1d(layer_size)
+            self.hidden_layer = nn.Linear(layer_size, layer_size)
+            self.bn2 = nn.BatchNorm1d(layer_size)
+            self.action_values = nn.Linear(layer_size, action_size)
+            self.value = nn.Linear(layer_size, 1)
+            self.matrix_entries = nn.Linear(layer_size, T)
+        views = lay.param_views(self.flat)
+        for name in PARAM_ORDER:
+            mod, attr = name.split(".")
+            setattr(getattr(self, mod), attr, nn.Parameter(views[name], requires_grad=False))
+        self.bn1.running_mean, self.bn1.running_var = self.bn_stats[0], self.bn_stats[1]
+        self.bn2.running_mean, self.bn2.running_var = self.bn_stats[2], self.bn_stats[3]
+        self.bn1.num_batches_tracked = torch.zeros((), dtype=torch.long, device=self.device)
+        self.bn2.num_batches_tracked = torch.zeros((), dtype=torch.long, device=self.device)
+        self._tracked_base = 0            # batches tracked at load time
+        self._tracked_eager = 0           # train-mode forwards through this facade
+        self._tracked_hook = None         # NAFAgent: learn() count living on the device
+        self._noise_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._noise_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
+        if _init:
+            self.load_state_dict(reference_init_state_dict(state_size, action_size, layer_size, seed))
+
+    # ---- nn.Module plumbing ------------------------------------------------------------------------------------
+    def to(self, *args, **kwargs):
+        dev = args[0] if args else kwargs.get("device")
+        if dev is None or torch.device(dev) == self.device or (torch.device(dev).type == "cuda" and torch.device(dev).index is None):
+            return self
+        raise _lib.NafHipError(f"NAF parameters live in one flat HBM buffer on {self.device}; cannot move to {dev}")
+
+    def _tracked(self) -> int:
+        extra = int(self._tracked_hook()) if self._tracked_hook is not None else 0
+        return self._tracked_base + self._tracked_eager + extra
+
+    def state_dict(self, *args, **kwargs):
+        """Reference key set and order; tensors are contiguous clones (safe to torch.save: no flat-buffer aliasing)."""
+        views = self.layout.param_views(self.flat)
+        n = torch.tensor(self._tracked(), dtype=torch.long, device=self.device)
+        sd = OrderedDict()
+        for mod in ("input_layer", "bn1", "hidden_layer", "bn2", "action_values", "value", "matrix_entries"):
+            sd[f"{mod}.weight"] = views[f"{mod}.weight"].detach().clone().contiguous()
+            sd[f"{mod}.bias"] = views[f"{mod}.bias"].detach().clone().contiguous()
+            if mod.startswith("bn"):
+                k = 0 if mod == "bn1" else 2
+                sd[f"{mod}.running_mean"] = self.bn_stats[k].clone()
+                sd[f"{mod}.running_var"] = self.bn_stats[k + 1].clone()
+                sd[f"{mod}.num_batches_tracked"] = n.clone()
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        views = self.layout.param_views(self.flat)
+        missing = [k for k in PARAM_ORDER if k not in state_dict]
+        if missing and strict:
+            raise RuntimeError(f"Error(s) in loading state_dict for NAF: missing keys {missing}")
+        with torch.no_grad():
+            for k, v in views.items():
+                if k in state_dict:
+                    src = torch.as_tensor(state_dict[k])
+                    if tuple(src.shape) != tuple(v.shape):
+                        raise RuntimeError(f"size mismatch for {k}: {tuple(src.shape)} vs {tuple(v.shape)}")
+                    v.copy_(src.to(self.device, torch.float32))
+            for i, k in enumerate(("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var")):
+                if k in state_dict:
+                    self.bn_stats[i].copy_(torch.as_tensor(state_dict[k]).to(self.device, torch.float32))
+        if "bn1.num_batches_tracked" in state_dict:
+            self._tracked_base = int(torch.as_tensor(state_dict["bn1.num_batches_tracked"]).item())
+            self._tracked_eager = 0
+            if self._tracked_hook is not None:
+                self._tracked_base -= int(self._tracked_hook())
+        return torch.nn.modules.module._IncompatibleKeys(missing, [])
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def heads(self, input_: torch.Tensor) -> torch.Tensor:
+        """Trunk + merged heads GEMM: returns heads_pre [B, NHP] = [mu_pre | l_pre | V | 0-pad] (bias included)."""
+        lay, lib, st = self.layout, self.lib, stream_ptr()
+        seg, H, HP = lay.seg, lay.H, lay.HP
+        x = input_.to(self.device, torch.float32)
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        B = x.shape[0]
+        fp, bp = self.flat.data_ptr(), self.bn_stats.data_ptr()
+        f32 = dict(dtype=torch.float32, device=self.device)
+        a2 = torch.zeros(B, HP, **f32)
+        a2[:, H] = 1.0
+        a1 = torch.empty(B, H, **f32)
+        g1 = torch.mm(x, lay.view(self.flat, "W1").t())
+        g2 = torch.empty(B, H, **f32)
+        if self.training:
+            sm, si = torch.empty(H, **f32), torch.empty(H, **f32)
+            check(lib.naf_bn_relu_fwd_train(ptr(g1), 0, H, fp + 4 * seg["b1"].offset, fp + 4 * seg["g1"].offset,
+                                            fp + 4 * seg["be1"].offset, 0, bp, bp + 4 * H, 0, ptr(a1), 0, H, ptr(sm), ptr(si),
+                                            B, H, 1, BN_MOMENTUM, BN_EPS, st), "bn_relu_fwd_train")
+            torch.mm(a1, lay.view(self.flat, "W2").t(), out=g2)
+            check(lib.naf_bn_relu_fwd_train(ptr(g2), 0, H, fp + 4 * seg["b2"].offset, fp + 4 * seg["g2"].offset,
+                                            fp + 4 * seg["be2"].offset, 0, bp + 8 * H, bp + 12 * H, 0, ptr(a2), 0, HP, ptr(sm),
+                                            ptr(si), B, H, 1, BN_MOMENTUM, BN_EPS, st), "bn_relu_fwd_train")
+            self._tracked_eager += 1
+        else:
+            check(lib.naf_bn_relu_fwd_eval(ptr(g1), H, fp + 4 * seg["b1"].offset, fp + 4 * seg["g1"].offset,
+                                           fp + 4 * seg["be1"].offset, bp, bp + 4 * H, ptr(a1), H, B, H, BN_EPS, st), "bn_eval")
+            torch.mm(a1, lay.view(self.flat, "W2").t(), out=g2)
+            check(lib.naf_bn_relu_fwd_eval(ptr(g2), H, fp + 4 * seg["b2"].offset, fp + 4 * seg["g2"].offset,
+                                           fp + 4 * seg["be2"].offset, bp + 8 * H, bp + 12 * H, ptr(a2), HP, B, H, BN_EPS, st),
+                  "bn_eval")
+        return torch.mm(a2, lay.view(self.flat, "Wh").t())
+
+    @torch.no_grad()
+    def forward(self, input_: torch.Tensor, action: Optional[torch.Tensor] = None,
+                noise_scale: float = 1.0) -> Tuple[torch.Tensor, Optional[Any], Any]:
+        """(noisy action, Q | None, V), as naf_neural_network.py:56-123. `action` may be int64 (what the reference's
+        ReplayBuffer.sample() yields) or float."""
+        lay, lib, st = self.layout, self.lib, stream_ptr()
+        gh = self.heads(input_)
+        B = gh.shape[0]
+        V = gh[:, lay.A + lay.T].clone().unsqueeze(-1)
+        Q = None
+        if action is not None:
+            u = action.to(self.device, torch.float32).contiguous().view(B, lay.A)
+            q = torch.empty(B, dtype=torch.float32, device=self.device)
+            check(lib.naf_head_fwd(ptr(gh), lay.NHP, ptr(u), lay.A, ptr(q), None, B, lay.A, self.p_mode, st), "naf_head_fwd")
+            Q = q.unsqueeze(-1)
+        noisy = torch.empty(B, lay.A, dtype=torch.float32, device=self.device)
+        check(lib.naf_act_noise(ptr(gh), lay.NHP, ptr(noisy), self._noise_seed, ptr(self._noise_counter), 0,
+                                float(noise_scale), B, lay.A, self.p_mode, st), "naf_act_noise")
+        check(lib.naf_counter_add(ptr(self._noise_counter), 1, st), "naf_counter_add")
+        return noisy, Q, V

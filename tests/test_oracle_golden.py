@@ -187,3 +187,26 @@ def test_sampler_restatement_properties():
     assert [int(x) for x in v] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     v = O.philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
     assert [int(x) for x in v] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+
+
+def test_torch_port_matches_reference_golden():
+    """oracle/torch_cpu_port.py (the timed cpu_baseline) reproduces the unmodified reference's learn() losses and
+    its seed-0 initialisation (G3)."""
+    import torch
+    from oracle.torch_cpu_port import TorchCpuAgent, init_state_dict
+    from synth_data import make_transitions
+    g = _npz("g3_learn.npz")
+    S, A, B = [int(x) for x in g["kuka/dims"]]
+    sd = init_state_dict(S, A, 256, 0)
+    ref0 = load_group(g, "kuka/main0")
+    for k in ("input_layer.weight", "hidden_layer.bias", "matrix_entries.weight", "value.bias"):
+        np.testing.assert_array_equal(sd[k].numpy(), ref0[k])             # same RNG consumption order as the reference
+    agent = TorchCpuAgent(S, A, 256, B, 1000, seed=0)
+    st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
+    for k in range(5):
+        sl = slice(k * B, (k + 1) * B)
+        agent.learn((torch.from_numpy(st[sl]), torch.from_numpy(ac[sl]).long(), torch.from_numpy(rw[sl, None]),
+                     torch.from_numpy(ns[sl]), torch.from_numpy(dn[sl, None])))
+    np.testing.assert_allclose(agent.losses, g["kuka/losses5"], rtol=1e-5)
+    ref5 = load_group(g, "kuka/main5")
+    np.testing.assert_allclose(agent.main.p["hidden_layer.weight"].detach().numpy(), ref5["hidden_layer.weight"], atol=1e-6)
