@@ -25,6 +25,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
+from .parallel import all_reduce_flat_grad
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -278,10 +279,10 @@ class Learner:
             t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.dZ1), H,
             gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, B, H, st), "bn_relu_bwd(1)")
         torch.mm(self.dZ1.t(), self._x2(rows)[0], out=self.gW1)
-        if self.world_size > 1:
+        if self.world_size > 1 or os.environ.get("NAF_FORCE_ALLREDUCE") == "1":
             # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
-            torch.distributed.all_reduce(self.grad, group=self.pg)
+            all_reduce_flat_grad(self.grad, self.pg)
         self.optimizer_step()
 
     def optimizer_step(self) -> None:

@@ -1,0 +1,274 @@
+"""NAFAgent with the reference's interface (naf_components/naf_algorithm.py:23-292), running its per-timestep
+hot path — act / step (add, gate, sample, learn) / soft_update — on the MI355X through the flat-buffer Learner,
+the HBM ReplayBuffer and captured HIP graphs.
+
+Kept from the reference, on purpose: learning starts when len(memory) > batch_size (strict, :150);
+the update gate is (t+1) % update_freq == 0 (:147-148); `dones` is stored and sampled but never used in the target
+(:199); both networks run BatchNorm in training mode inside learn() and only parameters() are soft-updated; act()
+returns a NOISY action even at test time; sampled actions are truncated toward zero (`.long()`), unless
+action_mode='float'. Files written by run(): checkpoints/{episode}/weights.p, scores.txt, model.p — same names,
+same JSON, same state_dict keys, so they interchange with the reference.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import time
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..engine import DeviceEnvLoop, TrainChunk
+from ..learner import ActPath, Learner
+from ..utils.exceptions import MissingWeightsFile
+from ..utils.logger import get_global_logger
+from ..utils.replay_buffer import ReplayBuffer
+from .naf_neural_network import NAF, _P_MODES
+
+logger = get_global_logger()
+
+_ACTION_MODES = {"trunc_int": _lib.ACTION_TRUNC_INT, "float": _lib.ACTION_FLOAT, 0: 0, 1: 1}
+
+
+class FlatAdam:
+    """What `agent.optimizer` is here: Adam's state lives in two flat buffers next to the parameters and is stepped
+    by naf_adam_polyak_fused; this object only exposes it (torch.optim.Adam defaults, naf_algorithm.py:83)."""
+
+    def __init__(self, learner: Learner):
+        self._L = learner
+        self.defaults = {"lr": learner.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0}
+        self.param_groups = [dict(self.defaults, params=list(range(14)))]
+
+    def zero_grad(self, set_to_none: bool = True) -> None:   # every gradient segment is overwritten by each backward
+        return None
+
+    def state_dict(self) -> dict:
+        L = self._L
+        return {"step": int(L.step_dev.item()), "exp_avg": L.adam_m.clone(), "exp_avg_sq": L.adam_v.clone(),
+                "param_groups": self.param_groups}
+
+
+class NAFAgent:
+
+    MODEL_PATH = 'model.p'
+
+    def __init__(self, environment, state_size: int, action_size: int, layer_size: int, batch_size: int,
+                 buffer_size: int, learning_rate: float, tau: float, gamma: float, update_freq: int, num_updates: int,
+                 checkpoint_frequency: int, device, seed: int, *, p_mode="hadamard", action_mode="trunc_int",
+                 data_parallel: Optional[bool] = None, use_graph: bool = True) -> None:
+        """Positional arguments as the reference (naf_algorithm.py:27-41). Keyword-only extras default to the
+        reference's behaviour. data_parallel=None: all-reduce gradients iff torch.distributed is initialised with
+        more than one rank."""
+        os.makedirs('checkpoints/', exist_ok=True)
+        _lib.require_gpu()
+        self.environment = environment
+        self.state_size, self.action_size, self.layer_size = state_size, action_size, layer_size
+        self.buffer_size, self.learning_rate = buffer_size, learning_rate
+        random.seed(seed)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NafHipError(f"NAFAgent needs the MI355X (got device={device}); there is no CPU fallback")
+        self.tau, self.gamma = tau, gamma
+        self.update_freq, self.num_updates = update_freq, num_updates
+        self.batch_size, self.checkpoint_frequency = batch_size, checkpoint_frequency
+        self.seed = seed
+
+        import torch.distributed as dist
+        world, pg = 1, None
+        if data_parallel or (data_parallel is None and dist.is_available() and dist.is_initialized()):
+            world = dist.get_world_size()
+        self.world_size = world
+        self.rank = dist.get_rank() if world > 1 else 0
+
+        self.learner = Learner(state_size, action_size, layer_size, batch_size, learning_rate, tau, gamma, self.device,
+                               p_mode=_P_MODES[p_mode], world_size=world, process_group=pg)
+        L = self.learner
+        # both constructors draw from torch's global RNG exactly as the reference's do (:79-80): identical nets
+        self.qnetwork_main = NAF(state_size, action_size, layer_size, seed, self.device, p_mode=p_mode,
+                                 _flat=L.theta2[0], _bn=L.bn_stats[0])
+        self.qnetwork_target = NAF(state_size, action_size, layer_size, seed, self.device, p_mode=p_mode,
+                                   _flat=L.theta2[1], _bn=L.bn_stats[1])
+        self.qnetwork_main._tracked_hook = lambda: int(L.step_dev.item())
+        self.qnetwork_target._tracked_hook = lambda: int(L.step_dev.item())
+        if world > 1:
+            dist.broadcast(L.theta2, src=0)
+        self.optimizer = FlatAdam(L)
+        # per-rank sampler stream; rank 0 uses the user's seed
+        self.memory = ReplayBuffer(buffer_size, batch_size, self.device, seed + 7919 * self.rank, state_size=state_size,
+                                   action_size=action_size, action_mode=_ACTION_MODES[action_mode])
+        if self.rank:
+            random.seed(seed)  # ReplayBuffer re-seeded Python's RNG with the rank offset; keep the reference's value
+        self.update_t_step = 0
+        self.use_graph = use_graph
+        self._chunk: Optional[TrainChunk] = None
+        self._actor1: Optional[ActPath] = None
+        self._act_graph = None
+        self._obs_pinned = torch.zeros(1, state_size, dtype=torch.float32).pin_memory()
+        self._act_pinned = torch.zeros(1, action_size, dtype=torch.float32).pin_memory()
+        self._learn_rows = torch.zeros(batch_size, L.lay.row_floats, dtype=torch.float32, device=self.device)
+        self._learn_loss = torch.zeros(L.n_loss_wg, dtype=torch.float32, device=self.device)
+
+    # ---- pretrained weights (naf_algorithm.py:91-127) ----------------------------------------------------------
+    def _load_weights(self, path: str) -> None:
+        sd = torch.load(path, map_location="cpu")
+        self.qnetwork_main.load_state_dict(sd)
+        self.qnetwork_target.load_state_dict(sd)
+
+    def initialize_pretrained_agent_from_episode(self, episode: int) -> None:
+        path = f'checkpoints/{episode}/weights.p'
+        if not os.path.isfile(path):
+            raise MissingWeightsFile
+        self._load_weights(path)
+        logger.info(f'Loaded weights from trained naf_components on episode {episode}')
+
+    def initialize_pretrained_agent_from_weights_file(self, weights_path: str) -> None:
+        if not os.path.isfile(weights_path):
+            raise MissingWeightsFile
+        self._load_weights(weights_path)
+        logger.info('Loaded pre-trained weights for the NN')
+
+    # ---- per-timestep path ---------------------------------------------------------------------------------------
+    def step(self, state, action, reward: float, next_state, done: int) -> None:
+        """Store the experience and, every update_freq steps once len(memory) > batch_size, run num_updates
+        (sample + learn) (naf_algorithm.py:129-156). The updates are one captured graph:
+        sample num_updates minibatches -> one gather -> num_updates x learn."""
+        self.memory.add(state, action, reward, next_state, done)
+        self.update_t_step = (self.update_t_step + 1) % self.update_freq
+        if self.update_t_step == 0 and len(self.memory) > self.batch_size:
+            self.memory.flush()
+            if self._chunk is None:
+                self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=self.use_graph)
+            self._chunk.run()
+
+    def act(self, state) -> np.ndarray:
+        """Noisy clamped action for one state, main net in eval mode (naf_algorithm.py:158-178)."""
+        if self._actor1 is None:
+            self._actor1 = ActPath(self.learner, 1, seed=(self.seed * 2654435761 + 12345 + self.rank) & 0xFFFFFFFFFFFFFFFF)
+            if self.use_graph:
+                a = self._actor1
+                saved = (a.counter.clone(),)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    a.act()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    a.act()
+                a.counter.copy_(saved[0])
+                self._act_graph = g
+        a = self._actor1
+        self._obs_pinned[0].copy_(torch.from_numpy(np.asarray(state, dtype=np.float32)))
+        a.obs.copy_(self._obs_pinned, non_blocking=True)
+        if self._act_graph is not None:
+            self._act_graph.replay()
+        else:
+            a.act()
+        self._act_pinned.copy_(a.actions, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self._act_pinned.numpy().squeeze().copy()
+
+    def learn(self, experiences: Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]) -> None:
+        """One update from an explicit (states, actions, rewards, next_states, dones) tuple
+        (naf_algorithm.py:180-215). actions may be int64 (the reference's sample() contract) or float."""
+        states, actions, rewards, next_states, dones = experiences
+        L, lay, B = self.learner, self.learner.lay, self.batch_size
+        if states.shape[0] != B:
+            raise ValueError(f"learn() expects minibatches of batch_size={B} rows, got {states.shape[0]}")
+        r = self._learn_rows
+        S, A = lay.S, lay.A
+        r[:, :S] = states.to(self.device, torch.float32)
+        r[:, S:S + A] = actions.to(self.device, torch.float32)
+        r[:, S + A] = rewards.to(self.device, torch.float32).view(B)
+        r[:, S + A + 1:2 * S + A + 1] = next_states.to(self.device, torch.float32)
+        r[:, 2 * S + A + 1] = dones.to(self.device, torch.float32).view(B)
+        L.learn_rows(r, self._learn_loss)
+
+    def last_loss(self) -> float:
+        """MSE loss of the most recent update (host sync). The reference computes it and drops it (:215)."""
+        if self._chunk is not None:
+            return float(self._chunk.losses()[-1].item())
+        return float(self._learn_loss.sum().item())
+
+    def soft_update(self, main_nn, target_nn) -> None:
+        """theta_target = tau*theta_main + (1 - tau)*theta_target over parameters() (naf_algorithm.py:217-226)."""
+        if main_nn is self.qnetwork_main and target_nn is self.qnetwork_target:
+            self.learner.soft_update()
+            return
+        lib, st = self.learner.lib, torch.cuda.current_stream().cuda_stream
+        for tp, mp in zip(target_nn.parameters(), main_nn.parameters()):
+            if tp.is_contiguous() and mp.is_contiguous() and tp.data_ptr() % 16 == 0 and mp.data_ptr() % 16 == 0:
+                _lib.check(lib.naf_polyak_update(tp.data_ptr(), mp.data_ptr(), self.tau, float(1.0 - self.tau), tp.numel(), st),
+                           "naf_polyak_update")
+            else:   # strided views of a foreign flat buffer
+                tp.data.copy_(self.tau * mp.data + (1. - self.tau) * tp.data)
+
+    # ---- training loop with a host-side environment (naf_algorithm.py:228-292) ---------------------------------
+    def run(self, frames: int = 1000, episodes: int = 1000, verbose: bool = True) -> Dict[int, Tuple[float, int]]:
+        logger.info('Training started')
+        scores = {episode: (0, 0) for episode in range(1, episodes + 1)}
+        for episode in range(episodes):
+            logger.info(f'Running Episode {episode + 1}')
+            start = time.time()
+            state = self.environment.reset(verbose)
+            score, mean = 0, list()
+            frame = 0
+            for frame in range(1, frames + 1):
+                if verbose:
+                    logger.info(f'Running frame {frame} in episode {episode + 1}')
+                action = self.act(state)
+                next_state, reward, done = self.environment.step(action)
+                self.step(state, action, reward, next_state, done)
+                state = next_state
+                score += reward
+                mean.append(reward)
+                if verbose:
+                    logger.info(f'Reward: {reward}  -  Cumulative reward: {score}\n')
+                if done:
+                    break
+            scores[episode + 1] = (score, frame)
+            logger.info(f'Reward:                             {score}')
+            logger.info(f'Number of frames:                   {frame}')
+            logger.info(f'Mean of rewards on this episode:    {sum(mean) / frames}')
+            logger.info(f'Time taken for this episode:        {round(time.time() - start, 3)} secs\n')
+            if (episode + 1) % self.checkpoint_frequency == 0 and self.rank == 0:
+                os.makedirs(f'checkpoints/{episode + 1}/', exist_ok=True)
+                torch.save(self._cpu_state_dict(), f'checkpoints/{episode + 1}/weights.p')
+                with open(f'checkpoints/{episode + 1}/scores.txt', 'w') as f:
+                    f.write(json.dumps(scores))
+        if self.rank == 0:
+            torch.save(self._cpu_state_dict(), self.MODEL_PATH)
+            logger.info(f'Model has been successfully saved in {self.MODEL_PATH}')
+        return scores
+
+    def _cpu_state_dict(self):
+        return type(self.qnetwork_main.state_dict())((k, v.cpu()) for k, v in self.qnetwork_main.state_dict().items())
+
+    # ---- training loop with E on-device synthetic envs (the many-env path of BASELINE configs[1..4]) -----------
+    def run_vectorized(self, vector_steps: int, n_envs: int = 64, max_frames: int = 400, noise_scale: float = 1.0) -> dict:
+        """E synthetic arms on the GPU feed the HBM replay ring; each vector step is followed by
+        E * num_updates / update_freq learn() calls, i.e. the reference's update-to-data ratio. Returns counters;
+        everything stays on the device (no host sync per step)."""
+        E = int(n_envs)
+        if (E * self.num_updates) % self.update_freq != 0:
+            raise ValueError("n_envs * num_updates must be a multiple of update_freq")
+        U = E * self.num_updates // self.update_freq
+        loop = DeviceEnvLoop(self.learner, self.memory, E, seed=self.seed + 104729 * self.rank, max_frames=max_frames,
+                             noise_scale=noise_scale, use_graph=self.use_graph)
+        chunk = TrainChunk(self.learner, self.memory, U, use_graph=self.use_graph)
+        self.memory.flush()
+        t0 = time.time()
+        updates = 0
+        for _ in range(vector_steps):
+            loop.step()
+            if len(self.memory) > self.batch_size:
+                chunk.run()
+                updates += U
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        return {"env_steps": vector_steps * E, "updates": updates, "seconds": dt,
+                "env_steps_per_s": vector_steps * E / dt, "last_loss": float(chunk.losses()[-1].item()) if updates else None}

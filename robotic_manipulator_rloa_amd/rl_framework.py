@@ -1,0 +1,362 @@
+"""ManipulatorFramework: the user-facing object of the reference (rl_framework.py:47-699) re-hosted on the
+MI355X hot path. Same method names, argument meaning, validation rules and exceptions; no compute happens
+here — everything numeric goes through NAFAgent -> libnaf_hip.so.
+
+Differences, all opt-in or forced by the image:
+  * initialize_environment() needs PyBullet (absent from this image): it raises InvalidManipulatorFile with an
+    explanatory message if `pybullet` cannot be imported; initialize_synthetic_environment() builds the
+    kinematic stand-in (environment/synthetic.py) so the rest of the API works everywhere.
+  * the demos take `interactive=False` to skip the reference's input() prompts (rl_framework.py:525,535) and
+    `environment='synthetic'` to run without PyBullet.
+  * p_mode / action_mode / use_graph can be passed to initialize_naf_agent(); defaults = reference semantics.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from dataclasses import dataclass, fields
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from .environment.synthetic import SyntheticEnvironment
+from .naf_components.naf_algorithm import NAFAgent
+from .utils.exceptions import (ConfigurationIncomplete, EnvironmentNotInitialized, InvalidHyperParameter,
+                               InvalidManipulatorFile, InvalidNAFAgentParameter, NAFAgentNotInitialized)
+from .utils.logger import Logger, get_global_logger
+
+logger = get_global_logger()
+Logger.set_logger_setup()
+
+
+@dataclass
+class HyperParameters:
+    """Defaults of the reference (rl_framework.py:33-44)."""
+    buffer_size: int = 100000
+    batch_size: int = 128
+    gamma: float = 0.99
+    tau: float = 0.001
+    learning_rate: float = 0.001
+    update_freq: int = 1
+    num_updates: int = 1
+
+
+def _positive_int(v) -> bool:
+    return isinstance(v, int) and v > 0
+
+
+# accepted spellings -> (field, validity predicate, error text) — the reference's table (rl_framework.py:179-230),
+# including its copy-pasted message for num_update
+_HYPERPARAMETER_RULES = (
+    (r'^(buffer_size|buffersize|BUFFER_SIZE|BUFFERSIZE)$', 'buffer_size', _positive_int,
+     'Buffer Size is not an int or has a value lower than 0'),
+    (r'^(batch_size|batchsize|BATCH_SIZE|BATCHSIZE)$', 'batch_size', _positive_int,
+     'Batch Size is not an int or has a value lower than 0'),
+    (r'^(gamma|GAMMA)$', 'gamma', lambda v: isinstance(v, (int, float)) and 0 < v < 1,
+     'Gamma is not a float or its value is out of range (0, 1)'),
+    (r'^(tau|TAU)$', 'tau', lambda v: isinstance(v, (int, float)) and 0 <= v <= 1,
+     'Tau is not a float or its value is out of range [0, 1]'),
+    (r'^(learning_rate|learningrate|LEARNING_RATE|LEARNINGRATE)$', 'learning_rate',
+     lambda v: isinstance(v, (int, float)) and v > 0, 'Learning Rate is not a float or has a value lower than 0'),
+    (r'^(update_freq|updatefreq|UPDATE_FREQ|UPDATEFREQ)$', 'update_freq', _positive_int,
+     'Update Frequency is not an int or has a value lower than 0'),
+    (r'^(num_update|numupdate|NUMUPDATE|NUM_UPDATE)$', 'num_updates', _positive_int,
+     'Buffer Size is not an int or has a value lower than 0'),
+)
+
+_DEMO_ENVS = {   # presets of run_demo_training / run_demo_testing (rl_framework.py:547-555, :571-580, :642-649, :669-678)
+    'kuka': dict(manipulator_file='kuka_iiwa/kuka_with_gripper2.sdf', endeffector_index=13,
+                 fixed_joints=[6, 7, 8, 9, 10, 11, 12, 13], involved_joints=[0, 1, 2, 3, 4, 5],
+                 target_position=[0.4, 0.85, 0.71], obstacle_position=[0.45, 0.55, 0.55],
+                 initial_joint_positions=[0.9, 0.45, 0, 0, 0, 0]),
+    'xarm6': dict(manipulator_file='xarm/xarm6_with_gripper.urdf', endeffector_index=12,
+                  fixed_joints=[0, 7, 8, 9, 10, 11, 12, 13], involved_joints=[1, 2, 3, 4, 5, 6],
+                  target_position=[0.3, 0.47, 0.61], obstacle_position=[0.25, 0.27, 0.5],
+                  initial_joint_positions=[0., 1., 0., -2.3, 0., 0., 0.]),
+}
+
+
+class ManipulatorFramework:
+
+    def __init__(self) -> None:
+        self.env = None
+        self.naf_agent: Optional[NAFAgent] = None
+        self._hyperparameters: Optional[HyperParameters] = None
+        self._initialize_hyperparameters()
+        logger.info('The Framework has been initialized with the default hyperparameters configuration')
+
+    def _initialize_hyperparameters(self) -> None:
+        self._hyperparameters = HyperParameters()
+
+    # ---- logging / info ------------------------------------------------------------------------------------------
+    @staticmethod
+    def set_log_level(log_level: int) -> None:
+        names = {10: 'DEBUG', 20: 'INFO', 30: 'WARNING', 40: 'ERROR', 50: 'CRITICAL'}
+        if log_level in names:
+            logger.setLevel(log_level)
+            logger.info(f'Log Level has been set to {log_level} ({names[log_level]})')
+        else:
+            logger.error(f'The Log level provided is invalid, so the previous Log Level is maintained ({logger.level}))')
+            logger.error('Valid values: 10 (DEBUG), 20 (INFO), 30 (WARNING), 40 (ERROR), 50 (CRITICAL)')
+
+    @staticmethod
+    def get_required_hyperparameters() -> None:
+        if logger.level > 10:
+            logger.error('get_required_hyperparameters() only shows information for DEBUG log level. '
+                         'Try running this method after setting the log level to DEBUG by calling '
+                         'set_log_level(10) class method')
+            return
+        logger.debug('Required Hyperparameters:')
+        for f in fields(HyperParameters):
+            logger.debug('{:<25} default {}'.format(f.name, f.default))
+
+    @staticmethod
+    def plot_training_rewards(episode: int, mean_range: int = 50) -> None:
+        """Mean reward per block of `mean_range` episodes from checkpoints/{episode}/scores.txt (rl_framework.py:124-157)."""
+        try:
+            with open(f'checkpoints/{episode}/scores.txt', 'r') as f:
+                scores = json.loads(f.read())
+        except FileNotFoundError as err:
+            logger.error(f'File "scores.txt" located in checkpoints/{episode}/ folder was not found')
+            raise err
+        rewards = [result[0] for result in scores.values()]
+        means = [sum(rewards[i:i + mean_range]) / mean_range for i in range(0, len(rewards) - mean_range + 1, mean_range)]
+        import matplotlib.pyplot as plt   # optional dependency, only needed for this plot
+        plt.plot(range(len(means)), means)
+        plt.show()
+
+    # ---- hyper-parameters ---------------------------------------------------------------------------------------
+    def set_hyperparameter(self, hyperparameter: str, value: Union[float, int]) -> None:
+        for pattern, field, valid, error in _HYPERPARAMETER_RULES:
+            if re.match(pattern, hyperparameter):
+                if not valid(value):
+                    raise InvalidHyperParameter(error)
+                setattr(self._hyperparameters, field, value)
+                logger.info(f'Hyperparameter {hyperparameter} has been set to {value}')
+                return
+        raise InvalidHyperParameter(
+            'The hyperparameter name passed as parameter is not valid. Valid hyperparameters are: '
+            '["buffer_size", "batch_size", "gamma", "tau", "learning_rate", "update_freq", "num_update"]')
+
+    # ---- pretrained weights -------------------------------------------------------------------------------------
+    def _require_env_and_agent(self) -> None:
+        if not self.env:
+            raise EnvironmentNotInitialized
+        if not self.naf_agent:
+            raise NAFAgentNotInitialized
+
+    def load_pretrained_parameters_from_weights_file(self, parameters_file_path: str) -> None:
+        self._require_env_and_agent()
+        self.naf_agent.initialize_pretrained_agent_from_weights_file(parameters_file_path)
+
+    def load_pretrained_parameters_from_episode(self, episode: int) -> None:
+        self._require_env_and_agent()
+        self.naf_agent.initialize_pretrained_agent_from_episode(episode)
+
+    # ---- configuration dumps ------------------------------------------------------------------------------------
+    def get_environment_configuration(self) -> None:
+        if not self.env:
+            logger.error("Environment is not initialized yet, can't show configuration")
+            return
+        logger.info('Environment Configuration:')
+        for label, attr in (('Manipulator File', 'manipulator_file'), ('End Effector index', 'endeffector_index'),
+                            ('List of fixed Joints', 'fixed_joints'), ('List of Joints involved in training', 'involved_joints'),
+                            ('Position of the Target', 'target_pos'), ('Position of the Obstacle', 'obstacle_pos'),
+                            ('Initial position of joints', 'initial_joint_positions'),
+                            ('Initial variation range of joints', 'initial_positions_variation_range'),
+                            ('Max Force to be applied on joints', 'max_force'), ('Visualize mode', 'visualize')):
+            logger.info('* {:<38} {}'.format(label + ':', getattr(self.env, attr, 'n/a')))
+        logger.info(f'* Instance of the Environment:         {self.env}')
+
+    def get_nafagent_configuration(self) -> None:
+        if not self.naf_agent:
+            logger.error("NAFAgent is not initialized yet, can't show configuration")
+            return
+        logger.info('NAFAgent Configuration:')
+        for label, attr in (('Environment Instance', 'environment'), ('State Size', 'state_size'),
+                            ('Action Size', 'action_size'), ('Size of layers of the Neural Network', 'layer_size'),
+                            ('Batch Size', 'batch_size'), ('Buffer Size', 'buffer_size'), ('Learning Rate', 'learning_rate'),
+                            ('Tau', 'tau'), ('Gamma', 'gamma'), ('Update Frequency', 'update_freq'),
+                            ('Number of Updates', 'num_updates'), ('Checkpoint frequency', 'checkpoint_frequency'),
+                            ('Device', 'device')):
+            logger.info('* {:<40} {}'.format(label + ':', getattr(self.naf_agent, attr)))
+
+    # ---- evaluation -----------------------------------------------------------------------------------------------
+    def test_trained_model(self, n_episodes: int, frames: int) -> dict:
+        """n_episodes test episodes of at most `frames` steps; success iff done with reward == 250
+        (rl_framework.py:319-367). Also returns the summary it logs."""
+        if not self.naf_agent or not self.env:
+            raise ConfigurationIncomplete
+        results, num_collisions = [], 0
+        for ep in range(n_episodes):
+            state = self.env.reset()
+            for frame in range(frames):
+                action = self.naf_agent.act(state)
+                state, reward, done = self.env.step(action)
+                if done:
+                    results.append((reward == 250, frame))
+                    num_collisions += int(reward != 250)
+                    break
+                if frame == frames - 1:
+                    results.append((False, frame))
+            logger.info('Test Episode number {ep} completed\n'.format(ep=ep + 1))
+        logger.info('RESULTS OF THE TEST:')
+        for i, (ok, frame) in enumerate(results):
+            logger.info(f'Results of Iteration {i + 1}: COMPLETED: {ok}. FRAMES: {frame}')
+        wins = [f for ok, f in results if ok]
+        summary = {'successes': len(wins), 'episodes': len(results), 'collisions': num_collisions,
+                   'mean_frames_to_success': float(np.mean(wins)) if wins else float('nan')}
+        logger.info(f'Number of successful executions: {len(wins)}/{len(results)}  '
+                    f'({100.0 * len(wins) / max(1, len(results))}%)')
+        logger.info(f'Average number of frames required to complete an episode: {summary["mean_frames_to_success"]}')
+        logger.info(f'Number of episodes terminated because of collisions: {num_collisions}')
+        return summary
+
+    # ---- environment ------------------------------------------------------------------------------------------------
+    def initialize_environment(self, manipulator_file: str, endeffector_index: int, fixed_joints: List[int],
+                               involved_joints: List[int], target_position: List[float], obstacle_position: List[float],
+                               initial_joint_positions: List[float] = None,
+                               initial_positions_variation_range: List[float] = None, max_force: float = 200.,
+                               visualize: bool = True) -> None:
+        """PyBullet environment (rl_framework.py:369-417). The simulator is third-party and not part of this build."""
+        try:
+            from .environment.environment import Environment, EnvironmentConfiguration
+        except ImportError as e:
+            raise InvalidManipulatorFile(
+                f'PyBullet is not importable here ({e}); use initialize_synthetic_environment() for the built-in '
+                f'kinematic stand-in, or install pybullet to load {manipulator_file}') from e
+        config = EnvironmentConfiguration(
+            endeffector_index=endeffector_index, fixed_joints=fixed_joints, involved_joints=involved_joints,
+            target_position=target_position, obstacle_position=obstacle_position,
+            initial_joint_positions=initial_joint_positions,
+            initial_positions_variation_range=initial_positions_variation_range, max_force=max_force, visualize=visualize)
+        self.env = Environment(manipulator_file=manipulator_file, environment_config=config)
+        logger.info('Pybullet Environment successfully initialized')
+
+    def initialize_synthetic_environment(self, n_joints: int = 6, target_position: List[float] = None,
+                                         obstacle_position: List[float] = None, initial_joint_positions: List[float] = None,
+                                         initial_positions_variation_range: List[float] = None) -> None:
+        self.env = SyntheticEnvironment(n_joints, target_position, obstacle_position, initial_joint_positions,
+                                        initial_positions_variation_range)
+        logger.info('Synthetic (kinematic stand-in) Environment successfully initialized')
+
+    def delete_environment(self) -> None:
+        if not self.env:
+            logger.error('No existing instance of Environment found')
+            return
+        close = getattr(self.env, 'close', None)
+        if close:
+            close()
+        self.env = None
+        logger.info('Environment instance has been successfully removed')
+
+    # ---- agent --------------------------------------------------------------------------------------------------------
+    def initialize_naf_agent(self, checkpoint_frequency: int = 500, seed: int = 0, **agent_options) -> None:
+        """rl_framework.py:431-465: same guards, same NAFAgent keyword arguments (layer_size is 256, :452).
+        The device is cuda:0 — this build has no CPU path, so a missing GPU is an error, not a silent fallback."""
+        if not self.env:
+            raise EnvironmentNotInitialized
+        if not isinstance(checkpoint_frequency, int) or not isinstance(seed, int):
+            raise InvalidNAFAgentParameter('Checkpoint Frequency or Seed received is not an integer')
+        hp = self._hyperparameters
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        device = torch.device(f'cuda:{local_rank}')
+        self.naf_agent = NAFAgent(environment=self.env,
+                                  state_size=self.env.observation_space.shape[0],
+                                  action_size=self.env.action_space.shape[0],
+                                  layer_size=256,
+                                  batch_size=hp.batch_size, buffer_size=hp.buffer_size, learning_rate=hp.learning_rate,
+                                  tau=hp.tau, gamma=hp.gamma, update_freq=hp.update_freq, num_updates=hp.num_updates,
+                                  checkpoint_frequency=checkpoint_frequency, device=device, seed=seed, **agent_options)
+        logger.info('NAF Agent successfully initialized')
+
+    def delete_naf_agent(self) -> None:
+        if not self.naf_agent:
+            logger.error('No existing instance of NAFAgent found')
+            return
+        self.naf_agent = None
+        logger.info('NAFAgent instance has been successfully removed')
+
+    # ---- training ---------------------------------------------------------------------------------------------------
+    def run_training(self, episodes: int, frames: Optional[int] = 500, verbose: bool = True):
+        if not self.naf_agent or not self.env:
+            raise ConfigurationIncomplete
+        return self.naf_agent.run(frames, episodes, verbose)
+
+    def run_vectorized_training(self, vector_steps: int, n_envs: int = 64, max_frames: int = 400) -> dict:
+        """Many-env training on the device-resident synthetic arms (BASELINE configs[1..4] shape); see
+        NAFAgent.run_vectorized."""
+        if not self.naf_agent or not self.env:
+            raise ConfigurationIncomplete
+        return self.naf_agent.run_vectorized(vector_steps, n_envs=n_envs, max_frames=max_frames)
+
+    # ---- demos --------------------------------------------------------------------------------------------------------
+    def _clear_for_demo(self, interactive: bool) -> bool:
+        for what, present, delete in (('Environment', self.env, self.delete_environment),
+                                      ('NAFAgent', self.naf_agent, self.delete_naf_agent)):
+            if present:
+                if interactive and input(f'{what} instance found. Overwrite? [Y/n] ').lower() != 'y':
+                    logger.info(f'Demo could not run due to the presence of a user-configured {what} instance')
+                    return False
+                delete()
+        return True
+
+    def _demo_environment(self, robot: str, environment: str, variation, visualize: bool) -> None:
+        preset = dict(_DEMO_ENVS[robot])
+        if environment == 'synthetic':
+            self.initialize_synthetic_environment(len(preset['involved_joints']), preset['target_position'],
+                                                  preset['obstacle_position'], preset['initial_joint_positions'][:6], variation)
+        else:
+            import pybullet_data
+            preset['manipulator_file'] = os.path.join(pybullet_data.getDataPath(), preset['manipulator_file'])
+            self.initialize_environment(initial_positions_variation_range=variation, visualize=visualize, **preset)
+
+    def run_demo_training(self, demo_type: str, verbose: bool = False, interactive: bool = True,
+                          environment: str = 'pybullet', episodes: int = 20, frames: int = 400) -> None:
+        """'kuka_training' / 'xarm6_training': preset env + default agent, 20 episodes x 400 frames
+        (rl_framework.py:503-598)."""
+        old_level = logger.level
+        logger.setLevel(10)
+        try:
+            if demo_type not in ('kuka_training', 'xarm6_training'):
+                logger.error('Incorrect demo type!')
+                return
+            if not self._clear_for_demo(interactive):
+                return
+            robot = demo_type.split('_')[0]
+            variation = [0, 0, 0, 0, 0, 0] if robot == 'kuka' else [0, 0, 0, 0.3, 1, 1, 1]
+            self._demo_environment(robot, environment, variation, visualize=True)
+            self.initialize_naf_agent()
+            self.run_training(episodes, frames, verbose=verbose)
+            self.delete_environment()
+            self.delete_naf_agent()
+        finally:
+            logger.setLevel(old_level)
+
+    def run_demo_testing(self, demo_type: str, interactive: bool = True, environment: str = 'pybullet',
+                         weights_file: Optional[str] = None, episodes: int = 50, frames: int = 750) -> Optional[dict]:
+        """'kuka_testing' / 'xarm6_testing': preset env, pretrained weights, 50 x 750-frame test episodes
+        (rl_framework.py:600-699). The reference ships demo weights inside its package; pass their path as
+        `weights_file` (reference-format .p files load unchanged)."""
+        old_level = logger.level
+        logger.setLevel(10)
+        try:
+            if demo_type not in ('kuka_testing', 'xarm6_testing'):
+                logger.error('Incorrect demo type!')
+                return None
+            if not self._clear_for_demo(interactive):
+                return None
+            robot = demo_type.split('_')[0]
+            variation = [0, 0, .5, .5, .5, .5] if robot == 'kuka' else [0, 0, 0, 0.3, 1, 1, 1]
+            self._demo_environment(robot, environment, variation, visualize=(robot != 'kuka'))
+            self.initialize_naf_agent()
+            if weights_file is not None:
+                self.load_pretrained_parameters_from_weights_file(weights_file)
+            out = self.test_trained_model(episodes, frames)
+            self.delete_environment()
+            self.delete_naf_agent()
+            return out
+        finally:
+            logger.setLevel(old_level)

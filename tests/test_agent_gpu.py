@@ -1,0 +1,265 @@
+"""GPU: the drop-in boundary — NAF / NAFAgent / ReplayBuffer / ManipulatorFramework with the reference's
+signatures — against the reference's own known-answer test (G1), its act() statistics with the shipped demo
+weights (G6), its step() gating trace (G4) and its checkpoint file formats."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_group
+from oracle import naf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture()
+def scratch_cwd(tmp_path):
+    old = os.getcwd()
+    os.chdir(tmp_path)
+    yield tmp_path
+    os.chdir(old)
+
+
+def test_naf_forward_reference_known_answer_g1():
+    """The reference's tests/.../test_naf_neural_network.py:53-67, same constructor call and inputs; the literals
+    there are pinned to rtol 2e-5 (they drift 4.5e-6 across torch versions on the reference itself)."""
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import NAF
+    g = np.load(os.path.join(GOLDEN, "g1_known_answer.npz"))
+    net = NAF(10, 5, 256, 0, DEV)
+    sd = net.state_dict()
+    ref = load_group(g, "sd")
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+        np.testing.assert_array_equal(sd[k].cpu().numpy(), ref[k], err_msg=k)      # same seed -> same weights, bit for bit
+    assert [tuple(p.shape) for p in net.parameters()] == [tuple(ref[k].shape) for k in O.PARAM_ORDER]
+    states = torch.arange(20).reshape(2, 10).float()
+    actions = torch.tensor([[0, 1, 2, 3, 4], [10, 11, 12, 13, 14]]).long()
+    a, q, v = net(states.to(DEV), actions.to(DEV))
+    assert a.shape == (2, 5) and q.shape == (2, 1) and v.shape == (2, 1) and a.abs().max() <= 1
+    np.testing.assert_allclose(q.cpu().numpy(), g["q_test_literal"], rtol=2e-5)
+    np.testing.assert_allclose(v.cpu().numpy(), g["v_test_literal"], rtol=5e-5)
+    np.testing.assert_allclose(q.cpu().numpy(), g["q_f64"], rtol=2e-5)
+    _, q_none, _ = net(states.to(DEV))
+    assert q_none is None
+    assert int(net.state_dict()["bn1.num_batches_tracked"]) == 2                   # two train-mode forwards
+    # 'matmul' (textbook NAF) must differ: nobody silently "fixed" the reference's Hadamard P
+    net2 = NAF(10, 5, 256, 0, DEV, p_mode="matmul")
+    _, q2, _ = net2(states.to(DEV), actions.to(DEV))
+    assert (q2 - q).abs().max() > 1.0
+
+
+def test_act_eval_mode_with_reference_demo_weights_g6(scratch_cwd):
+    """Reference-format weight files load unchanged; act() = eval-mode mu + N(0, inverse(P)) noise, clamped."""
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    g = np.load(os.path.join(GOLDEN, "g6_act.npz"))
+    sd = {k: torch.from_numpy(v) for k, v in load_group(g, "kuka/sd").items()}
+    torch.save(sd, "weights_kuka.p")
+    agent = NAFAgent(object(), 21, 6, 256, 64, 1000, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+    agent.initialize_pretrained_agent_from_weights_file("weights_kuka.p")
+    assert int(agent.qnetwork_main.state_dict()["bn1.num_batches_tracked"]) == int(sd["bn1.num_batches_tracked"])
+    x = g["kuka/x"]
+    agent.qnetwork_main.eval()
+    gh = agent.qnetwork_main.heads(torch.from_numpy(x).to(DEV)).cpu().numpy()
+    agent.qnetwork_main.train()
+    np.testing.assert_allclose(np.tanh(gh[:, :6]), g["kuka/mu"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gh[:, 6:27], g["kuka/l_pre"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gh[:, 27], g["kuka/V"].ravel(), rtol=1e-4, atol=1e-4)
+    draws = np.stack([agent.act(x[0]) for _ in range(600)])
+    assert draws.shape == (600, 6) and draws.dtype == np.float32 and np.abs(draws).max() <= 1.0
+    sigma = O.noise_std_hadamard(g["kuka/l_pre"][:1], 6)[0]
+    mu = g["kuka/mu"][0]
+    free = np.abs(mu) + 3.5 * sigma < 1.0
+    if free.any():
+        np.testing.assert_allclose(draws.mean(0)[free], mu[free], atol=5 * sigma[free].max() / np.sqrt(600))
+        np.testing.assert_allclose(draws.std(0)[free], sigma[free], rtol=0.15)
+    # against the reference's own sampled statistics (256 draws/state there)
+    np.testing.assert_allclose(draws.mean(0), g["kuka/act_mean"][0], atol=0.2)
+    with pytest.raises(Exception):
+        agent.initialize_pretrained_agent_from_weights_file("missing.p")
+
+
+def test_step_gating_trace_matches_reference_g4(scratch_cwd):
+    """Which timesteps fire learn(), for update_freq/num_updates combinations: the reference's trace
+    (naf_algorithm.py:144-156: strict len > batch_size, (t+1) % update_freq == 0)."""
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    from synth_data import make_transitions
+    gate = np.load(os.path.join(GOLDEN, "g4_gating.npz"))
+    st, ac, rw, ns, dn = make_transitions(500, 21, 6, seed=11)
+    for key in gate.files:
+        uf, nu = [int(x[2:]) for x in key.split("_")]
+        agent = NAFAgent(object(), 21, 6, 256, 8, 1000, 1e-3, 1e-3, 0.99, uf, nu, 500, DEV, 0)
+        fired, prev = [], 0
+        for t in range(40):
+            agent.step(st[t].astype(np.float64), ac[t], float(rw[t]), st[t + 1].astype(np.float64), 0)
+            now = int(agent.learner.step_dev.item())
+            fired.append(now - prev)
+            prev = now
+        np.testing.assert_array_equal(fired, gate[key], err_msg=key)
+        assert len(agent.memory) == 40 and torch.isfinite(agent.learner.theta2).all()
+
+
+def test_learn_api_with_reference_sample_tuple():
+    """NAFAgent.learn((states, actions int64, rewards, next_states, dones)) == the reference's losses (G3)."""
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    from synth_data import make_transitions
+    g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
+    S, A, B = 21, 6, 256
+    st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
+    agent = NAFAgent(object(), S, A, 256, B, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+    losses = []
+    for k in range(5):
+        sl = slice(k * B, (k + 1) * B)
+        agent.learn((torch.from_numpy(st[sl]), torch.from_numpy(ac[sl]).long(), torch.from_numpy(rw[sl, None]),
+                     torch.from_numpy(ns[sl]), torch.from_numpy(dn[sl, None])))
+        losses.append(agent.last_loss())
+    np.testing.assert_allclose(losses, g["kuka/losses5"], rtol=5e-3)
+    assert agent.optimizer.state_dict()["step"] == 5
+    with pytest.raises(ValueError):
+        agent.learn((torch.zeros(3, S), torch.zeros(3, A), torch.zeros(3, 1), torch.zeros(3, S), torch.zeros(3, 1)))
+
+
+def test_soft_update_api():
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    agent = NAFAgent(object(), 21, 6, 256, 8, 100, 1e-3, 0.25, 0.99, 1, 1, 500, DEV, 0)
+    with torch.no_grad():
+        agent.learner.theta2[0].add_(1.0)
+    main0 = {k: v.cpu().numpy() for k, v in agent.qnetwork_main.state_dict().items()}
+    tgt0 = {k: v.cpu().numpy() for k, v in agent.qnetwork_target.state_dict().items()}
+    agent.soft_update(agent.qnetwork_main, agent.qnetwork_target)
+    tgt1 = agent.qnetwork_target.state_dict()
+    for k in O.PARAM_ORDER:
+        np.testing.assert_array_equal(tgt1[k].cpu().numpy(), O.polyak(tgt0[k], main0[k], 0.25), err_msg=k)   # bit-exact
+    np.testing.assert_array_equal(tgt1["bn1.running_mean"].cpu().numpy(), tgt0["bn1.running_mean"])          # buffers untouched
+    # foreign modules (e.g. a user's torch nets) go through the same kernel per tensor
+    a, b = torch.nn.Linear(16, 16).to(DEV), torch.nn.Linear(16, 16).to(DEV)
+    wa, wb = a.weight.detach().cpu().numpy().copy(), b.weight.detach().cpu().numpy().copy()
+    agent.soft_update(a, b)
+    np.testing.assert_array_equal(b.weight.detach().cpu().numpy(), O.polyak(wb, wa, 0.25))
+
+
+def test_run_writes_reference_format_checkpoints(scratch_cwd):
+    """NAFAgent.run with a host env: scores dict, checkpoints/{ep}/weights.p + scores.txt, model.p
+    (naf_algorithm.py:273-289; pinned by the reference's tests/.../test_naf_algorithm.py:316-328)."""
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    from oracle.torch_cpu_port import Net
+    env = SyntheticEnvironment(6)
+    agent = NAFAgent(env, 21, 6, 256, 16, 1000, 1e-3, 1e-3, 0.99, 1, 1, 2, DEV, 0)
+    assert os.path.isdir("checkpoints")
+    scores = agent.run(frames=15, episodes=4, verbose=False)
+    assert set(scores.keys()) == {1, 2, 3, 4} and all(len(v) == 2 for v in scores.values())
+    assert scores[4][1] == 15 and scores[1][0] < 0
+    assert int(agent.learner.step_dev.item()) == 60 - 16                           # learning starts when len > batch_size
+    for ep in (2, 4):
+        assert os.path.isfile(f"checkpoints/{ep}/weights.p") and os.path.isfile(f"checkpoints/{ep}/scores.txt")
+    saved_scores = json.loads(open("checkpoints/4/scores.txt").read())
+    assert saved_scores["4"] == [scores[4][0], scores[4][1]]
+    sd = torch.load("model.p", map_location="cpu")
+    g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
+    ref = load_group(g, "kuka/main0")
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape) and sd[k].device.type == "cpu"
+    assert int(sd["bn1.num_batches_tracked"]) == 44
+    Net(sd, 6)                                                                      # loads into a reference-layout net
+    agent2 = NAFAgent(env, 21, 6, 256, 16, 1000, 1e-3, 1e-3, 0.99, 1, 1, 2, DEV, 1)
+    agent2.initialize_pretrained_agent_from_episode(4)
+    for k, v in agent2.qnetwork_target.state_dict().items():
+        np.testing.assert_array_equal(v.cpu().numpy(), torch.load("checkpoints/4/weights.p")[k].numpy(), err_msg=k)
+
+
+def test_framework_end_to_end_synthetic(scratch_cwd):
+    from robotic_manipulator_rloa_amd import ManipulatorFramework
+    f = ManipulatorFramework()
+    f.set_hyperparameter("batch_size", 64)          # BASELINE configs[0]: demo training at batch 64
+    f.set_hyperparameter("buffer_size", 5000)
+    f.run_demo_training("kuka_training", interactive=False, environment="synthetic", episodes=2, frames=40)
+    assert f.env is None and f.naf_agent is None and os.path.isfile("model.p")
+    f.initialize_synthetic_environment(6)
+    f.initialize_naf_agent(checkpoint_frequency=1, seed=3)
+    f.load_pretrained_parameters_from_weights_file("model.p")
+    out = f.test_trained_model(2, 10)
+    assert out["episodes"] == 2
+    stats = f.run_vectorized_training(vector_steps=6, n_envs=32, max_frames=50)
+    assert stats["env_steps"] == 192 and stats["updates"] == 32 * 4 and np.isfinite(stats["last_loss"])
+    f.get_nafagent_configuration()
+    f.get_environment_configuration()
+    f.delete_naf_agent()
+    f.delete_environment()
+
+
+_DP1 = r'''
+import os, sys
+sys.path.insert(0, os.environ["NAF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NAF_ROOT"], "tests")); sys.path.insert(0, os.path.join(os.environ["NAF_ROOT"], "tests", "golden"))
+import numpy as np, torch, torch.distributed as dist
+from robotic_manipulator_rloa_amd import parallel
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from test_learner_gpu import _kuka_learner_and_replay
+from robotic_manipulator_rloa_amd.engine import TrainChunk
+res = []
+for force in ("0", "1"):
+    os.environ["NAF_FORCE_ALLREDUCE"] = force
+    L, buf = _kuka_learner_and_replay(5000, 256, seed_data=5)
+    chunk = TrainChunk(L, buf, 4)
+    chunk.capture()                        # with force=1 the RCCL all-reduce is a node of the captured graph
+    for _ in range(3):
+        chunk.run()
+    torch.cuda.synchronize()
+    res.append(L.theta2.clone())
+assert torch.equal(res[0], res[1])
+dist.destroy_process_group()
+print("RCCL_CAPTURE_OK")
+'''
+
+
+def test_rccl_allreduce_inside_captured_graph_world1(tmp_path):
+    """The N > 1 launch structure on the one GPU available here: an RCCL all-reduce of the flat gradient captured
+    inside the learn() graph (world_size 1, so the sum is the identity and the result must be bit-identical)."""
+    script = tmp_path / "dp1.py"
+    script.write_text(_DP1)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, NAF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_CAPTURE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_device_env_kernel_matches_numpy_environment():
+    """csrc/synth_env.hip against its numpy twin (environment/synthetic.py) on the same actions."""
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
+    lib = _lib.load()
+    E, A, S = 8, 6, 21
+    nst = lib.naf_synth_env_state_floats(A)
+    st = torch.zeros(E, nst, device=DEV)
+    obs = torch.zeros(E, S, device=DEV)
+    rows = torch.zeros(E, 64, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 5, 0, stream) == 0
+    envs = [SyntheticEnvironment(A) for _ in range(E)]
+    q0 = st[:, :A].cpu().numpy()
+    for e, env in enumerate(envs):
+        env.reset(False)
+        env.q = q0[e].copy()                       # same randomised start as the device env
+        np.testing.assert_allclose(obs[e].cpu().numpy(), env.get_state(), atol=2e-6)
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        act = rng.uniform(-1, 1, (E, A)).astype(np.float32)
+        a_d = torch.from_numpy(act).to(DEV)
+        assert lib.naf_synth_env_step(st.data_ptr(), a_d.data_ptr(), rows.data_ptr(), obs.data_ptr(), E, A, 5, None, 0, stream) == 0
+        r = rows.cpu().numpy()
+        for e, env in enumerate(envs):
+            s_before = env.get_state()
+            s2, rew, done = env.step(act[e])
+            np.testing.assert_allclose(r[e, :S], s_before, atol=3e-6)
+            np.testing.assert_array_equal(r[e, S:S + A], act[e])
+            np.testing.assert_allclose(r[e, S + A + 1:2 * S + A + 1], s2, atol=3e-6)
+            np.testing.assert_allclose(r[e, S + A], rew, rtol=1e-4, atol=1e-5)
+            assert r[e, 2 * S + A + 1] == done
+            assert (r[e, 2 * S + A + 2:] == 0).all()

@@ -1,0 +1,251 @@
+"""CPU (`-m "not gpu"`): host logic, the C-ABI library's exported symbols, loud failure without a GPU, and the
+world_size-2 data-parallel path over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_group
+from oracle import naf_oracle as O
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """Every function include/naf_hip.h declares must be exported by the built .so (no compute calls here)."""
+    from robotic_manipulator_rloa_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "naf_hip.h")).read()
+    declared = set(re.findall(r"\b(naf_[a-z0-9_]+)\s*\(", header))
+    declared -= {"naf_replay_t"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/naf_hip.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.naf_hip_arch() == b"gfx950" and lib.naf_hip_abi_version() == 1
+    assert lib.naf_replay_row_floats(21, 6) == 64 and lib.naf_replay_row_floats(23, 7) == 64
+    assert lib.naf_replay_row_floats(5, 1) == 32 and lib.naf_replay_row_floats(0, 6) == -1
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from robotic_manipulator_rloa_amd import _lib, ManipulatorFramework
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import NAF
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    with pytest.raises(_lib.NafHipError):
+        NAF(10, 5, 256, 0, torch.device("cpu"))
+    with pytest.raises(_lib.NafHipError):
+        ReplayBuffer(100, 8, "cpu", 0)
+    with pytest.raises(_lib.NafHipError):
+        NAFAgent(object(), 21, 6, 256, 8, 100, 1e-3, 1e-3, 0.99, 1, 1, 500, torch.device("cpu"), 0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "robotic_manipulator_rloa_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_reference_init_bit_exact_and_layout_roundtrip():
+    from robotic_manipulator_rloa_amd.learner import NetLayout, PARAM_ORDER
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
+    for tag, (S, A) in (("kuka", (21, 6)), ("panda", (23, 7))):
+        sd = reference_init_state_dict(S, A, 256, 0)
+        for k, v in sd.items():
+            np.testing.assert_array_equal(v.numpy(), g[f"{tag}/main0/{k}"], err_msg=k)   # same draws as the reference ctor
+        lay = NetLayout(S, A, 256)
+        assert lay.n_ref_params() == sum(v.numel() for k, v in sd.items() if k in PARAM_ORDER)
+        flat = torch.zeros(lay.P)
+        views = lay.param_views(flat)
+        for k in PARAM_ORDER:
+            views[k].copy_(sd[k].reshape(views[k].shape))
+        used = torch.zeros(lay.P, dtype=torch.bool)
+        probe = lay.param_views(torch.arange(lay.P, dtype=torch.float32))
+        total = 0
+        for k in PARAM_ORDER:
+            ids = probe[k].reshape(-1).long()
+            assert not used[ids].any(), f"{k} overlaps another parameter"
+            used[ids] = True
+            total += ids.numel()
+            np.testing.assert_array_equal(views[k].reshape(sd[k].shape).numpy(), sd[k].numpy())
+        assert total == lay.n_ref_params() and (flat[~used] == 0).all()
+        assert lay.P % 64 == 0 and lay.NHP % 8 == 0 and all(s.offset % 64 == 0 for s in lay.seg.values())
+    assert NetLayout(21, 6, 256).n_ref_params() == 79644 and NetLayout(23, 7, 256).n_ref_params() == 82212
+    with pytest.raises(ValueError):
+        NetLayout(27, 9, 256)
+
+
+def test_hyperparameter_rules_match_reference_contract():
+    """Aliases, ranges and messages of set_hyperparameter (reference rl_framework.py:159-230; its tests :124-204)."""
+    from robotic_manipulator_rloa_amd import ManipulatorFramework
+    from robotic_manipulator_rloa_amd.utils.exceptions import InvalidHyperParameter
+    f = ManipulatorFramework()
+    hp = f._hyperparameters
+    assert (hp.buffer_size, hp.batch_size, hp.gamma, hp.tau, hp.learning_rate, hp.update_freq, hp.num_updates) == \
+        (100000, 128, 0.99, 0.001, 0.001, 1, 1)
+    ok = {"buffer_size": ("buffer_size", 5), "buffersize": ("buffer_size", 6), "BUFFER_SIZE": ("buffer_size", 7),
+          "BUFFERSIZE": ("buffer_size", 8), "batch_size": ("batch_size", 64), "BATCHSIZE": ("batch_size", 32),
+          "gamma": ("gamma", 0.5), "GAMMA": ("gamma", 0.9), "tau": ("tau", 0), "TAU": ("tau", 1),
+          "learning_rate": ("learning_rate", 0.1), "LEARNINGRATE": ("learning_rate", 2), "update_freq": ("update_freq", 4),
+          "UPDATEFREQ": ("update_freq", 2), "num_update": ("num_updates", 3), "NUMUPDATE": ("num_updates", 2),
+          "NUM_UPDATE": ("num_updates", 5)}
+    for name, (field, value) in ok.items():
+        f.set_hyperparameter(name, value)
+        assert getattr(f._hyperparameters, field) == value
+    bad = [("buffer_size", 0), ("buffer_size", 1.5), ("batch_size", -1), ("gamma", 0), ("gamma", 1), ("gamma", "x"),
+           ("tau", -0.1), ("tau", 1.1), ("learning_rate", 0), ("update_freq", 0), ("update_freq", 2.0), ("num_update", 0),
+           ("Buffer_Size", 5), ("num_updates", 2), ("lr", 0.1)]
+    for name, value in bad:
+        with pytest.raises(InvalidHyperParameter):
+            f.set_hyperparameter(name, value)
+    with pytest.raises(InvalidHyperParameter, match="Gamma is not a float or its value is out of range"):
+        f.set_hyperparameter("gamma", 2)
+
+
+def test_framework_guards_and_exception_messages():
+    from robotic_manipulator_rloa_amd import ManipulatorFramework
+    from robotic_manipulator_rloa_amd.utils import exceptions as E
+    f = ManipulatorFramework()
+    with pytest.raises(E.EnvironmentNotInitialized):
+        f.initialize_naf_agent()
+    with pytest.raises(E.ConfigurationIncomplete):
+        f.run_training(1, 1)
+    with pytest.raises(E.ConfigurationIncomplete):
+        f.test_trained_model(1, 1)
+    with pytest.raises(E.EnvironmentNotInitialized):
+        f.load_pretrained_parameters_from_weights_file("x.p")
+    f.initialize_synthetic_environment()
+    with pytest.raises(E.NAFAgentNotInitialized):
+        f.load_pretrained_parameters_from_episode(3)
+    with pytest.raises(E.InvalidNAFAgentParameter, match="Checkpoint Frequency or Seed received is not an integer"):
+        f.initialize_naf_agent(checkpoint_frequency=1.5)
+    with pytest.raises(E.InvalidManipulatorFile):       # pybullet is not installed in this image
+        f.initialize_environment("kuka.sdf", 13, [6], [0, 1, 2, 3, 4, 5], [0, 0, 0], [1, 1, 1])
+    # messages and str() format of the reference's exception types
+    assert str(E.MissingWeightsFile()) == "MissingWeightsFile: The weight file provided does not exist"
+    assert str(E.InvalidHyperParameter("boom")) == "InvalidHyperParameter: boom"
+    assert E.ConfigurationIncomplete().message.startswith("The configuration for the training is incomplete.")
+    assert issubclass(E.InvalidEnvironmentParameter, E.FrameworkException) and issubclass(E.FrameworkException, Exception)
+    assert E.EnvironmentNotInitialized().set_message("m").message == "m"
+    f.delete_environment()
+    assert f.env is None
+
+
+def test_synthetic_environment_protocol_and_rewards():
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment, forward_kinematics
+    env = SyntheticEnvironment(6)
+    s = env.reset(False)
+    assert s.shape == (21,) and s.dtype == np.float64 and env.observation_space.shape == (21,) and env.action_space.shape == (6,)
+    np.testing.assert_allclose(s[:6], [0.9, 0.45, 0, 0, 0, 0], atol=1e-7)
+    np.testing.assert_array_equal(s[6:12], 0)
+    np.testing.assert_allclose(s[15:18], [0.4, 0.85, 0.71], atol=1e-7)
+    np.testing.assert_allclose(s[18:21], [0.45, 0.55, 0.55], atol=1e-7)
+    a = np.array([1, -1, 0.5, 0, 0, 0], np.float32)
+    s2, r, d = env.step(a)
+    np.testing.assert_allclose(s2[:6], s[:6] + a / 240.0, atol=1e-6)
+    np.testing.assert_allclose(s2[6:12], a)
+    dist = np.linalg.norm(s2[12:15] - s2[15:18])
+    assert d == 0 and abs(r + (dist - 0.05)) < 1e-5
+    # chain of zero angles points straight up: ee = (0, 0, sum of the first 6 links)
+    ee, hit = forward_kinematics(np.zeros(6, np.float32), np.array([5, 5, 5], np.float32))
+    np.testing.assert_allclose(ee, [0, 0, 0.34 + 0.02 + 0.40 + 0.02 + 0.40 + 0.13], atol=1e-6)
+    # terminal events
+    env2 = SyntheticEnvironment(6, target_position=list(ee))
+    env2.q = np.zeros(6, np.float32)
+    _, r, d = env2.step(np.zeros(6, np.float32))
+    assert (r, d) == (250, 1)
+    env3 = SyntheticEnvironment(6, obstacle_position=[0, 0, 0.35])
+    env3.q = np.zeros(6, np.float32)
+    _, r, d = env3.step(np.zeros(6, np.float32))
+    assert (r, d) == (-1000, 1)
+
+
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["NAF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NAF_ROOT"], "tests", "golden"))
+import numpy as np, torch, torch.distributed as dist
+from oracle import naf_oracle as O
+from robotic_manipulator_rloa_amd.learner import NetLayout, PARAM_ORDER
+from robotic_manipulator_rloa_amd import parallel
+from synth_data import make_transitions
+rank, local_rank, world = parallel.init_distributed("gloo")
+assert world == 2 and dist.get_backend() == "gloo"
+S, A, B = 21, 6, 32
+g = np.load(os.path.join(os.environ["NAF_ROOT"], "tests", "golden", "g3_learn.npz"))
+sd = {k[len("kuka/main0/"):]: g[k] for k in g.files if k.startswith("kuka/main0/")}
+lay = NetLayout(S, A, 256)
+# replicas start identical; rank 1 deliberately perturbs, then the broadcast repairs it
+theta2 = torch.zeros(2, lay.P)
+for net in range(2):
+    for k, v in lay.param_views(theta2[net]).items():
+        v.copy_(torch.from_numpy(sd[k]).reshape(v.shape))
+if rank == 1:
+    theta2 += 1.0
+parallel.broadcast_parameters(theta2)
+ref = torch.zeros(2, lay.P)
+for net in range(2):
+    for k, v in lay.param_views(ref[net]).items():
+        v.copy_(torch.from_numpy(sd[k]).reshape(v.shape))
+assert torch.equal(theta2, ref)
+# each rank: its own shard of transitions (independent units, no data-path collective) -> local gradient
+st, ac, rw, ns, dn = make_transitions(2 * B, S, A, seed=5 + 0)
+sl = slice(rank * B, (rank + 1) * B)
+L = O.LearnerOracle(sd, dtype=np.float32)
+u = np.trunc(ac[sl]).astype(np.float32)
+tf, _ = O.net_forward_train(L.target, ns[sl])
+y = rw[sl] + np.float32(0.99) * tf["V"]
+mf, _ = O.net_forward_train(L.main, st[sl], u)
+dQ = (2.0 * (mf["Q"] - y) / B).astype(np.float32)
+grads = O.net_backward(L.main, mf, u, dQ)
+flat = torch.zeros(lay.P)
+for k, v in lay.param_views(flat).items():
+    v.copy_(torch.from_numpy(grads[k]).reshape(v.shape))
+local = flat.clone()
+parallel.all_reduce_flat_grad(flat)                 # the one exchange per update
+gathered = [torch.zeros(lay.P) for _ in range(world)]
+dist.all_gather(gathered, local)
+assert torch.allclose(flat, gathered[0] + gathered[1], rtol=0, atol=0)
+# identical optimizer step on every rank from the summed gradient with inv_world folded into the clip
+avg = {k: (v.numpy().reshape(sd[k].shape) / world).astype(np.float32) for k, v in lay.param_views(flat).items()}
+clipped, norm = O.clip_grad_norm(avg, 1.0)
+new = {k: O.adam_step(L.main[k], clipped[k], L.m[k], L.v[k], 1, 1e-3)[0] for k in PARAM_ORDER}
+chk = torch.tensor([float(sum(np.abs(v).sum() for v in new.values())), norm], dtype=torch.float64)
+both = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(both, chk)
+assert torch.equal(both[0], both[1]), both        # replicas stay in lock-step
+assert parallel.rank_seed(0, 0) == 0 and parallel.rank_seed(0, 1) != parallel.rank_seed(0, 0)
+assert [parallel.units_per_rank(130, 4, r) for r in range(4)] == [33, 33, 32, 32]
+dist.barrier(); dist.destroy_process_group()
+print("DP_OK", rank)
+'''
+
+
+def test_data_parallel_world2_gloo(tmp_path):
+    """N > 1 path on CPU: 2 ranks over gloo — parameter broadcast, per-rank shards, ONE sum all-reduce of the flat
+    gradient laid out by NetLayout, identical clip+Adam on both ranks."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, NAF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DP_OK 0" in r.stdout and "DP_OK 1" in r.stdout
+
+
+def test_bench_cli_contract_is_parseable():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in src
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
+                '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
+        assert key in src
