@@ -192,6 +192,11 @@ class Learner:
         self.W1T2 = t2[:, seg["W1"].offset:seg["W1"].offset + seg["W1"].numel].view(2, H, lay.S).transpose(1, 2)
         self.W2T2 = t2[:, seg["W2"].offset:seg["W2"].offset + seg["W2"].numel].view(2, H, H).transpose(1, 2)
         self.WhT2 = t2[:, seg["Wh"].offset:seg["Wh"].offset + seg["Wh"].numel].view(2, NHP, HP).transpose(1, 2)
+        # weight-gradient GEMMs are off the critical path (nothing reads them before the grad norm): they run on a
+        # second stream / a forked branch of the captured graph, beside the dA -> bn_bwd chain
+        self._side = torch.cuda.Stream(device=dev)
+        self._ev_fork = [torch.cuda.Event() for _ in range(2)]
+        self.fork_weight_grads = os.environ.get("NAF_FORK") == "1"   # measured: a forked hipGraph is SLOWER (8.0k vs 12.7k updates/s)
         self.W2_main = lay.view(t2[0], "W2")
         self.Wh_main = lay.view(t2[0], "Wh")
         self.gW1 = lay.view(self.grad, "W1")
@@ -266,19 +271,35 @@ class Learner:
             self.Gh[1].data_ptr() + 4 * (lay.A + lay.T), NHP, self.gamma, ptr(self.q_out), ptr(self.dH),
             ptr(loss_partials) if loss_partials is not None else None, B, lay.A, self.p_mode, st), "head_fwd_bwd_mse")
         # heads GEMM backward: weight+bias gradient in one GEMM thanks to the ones column
-        torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
+        fork = self.fork_weight_grads
+        main = torch.cuda.current_stream()
+        if fork:
+            self._ev_fork[0].record(main)
+            self._side.wait_event(self._ev_fork[0])
+            with torch.cuda.stream(self._side):
+                torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
+        else:
+            torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
         torch.mm(self.dH, self.Wh_main, out=self.dA2)
         check(f.naf_bn_relu_bwd(
             ptr(self.dA2), HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset, ptr(self.A2[0]), HP,
             t2p + 4 * seg["g2"].offset, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.dZ2), H,
             gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
-        torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
+        if fork:
+            self._ev_fork[1].record(main)
+            self._side.wait_event(self._ev_fork[1])
+            with torch.cuda.stream(self._side):
+                torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
+        else:
+            torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
         torch.mm(self.dZ2, self.W2_main, out=self.dA1)
         check(f.naf_bn_relu_bwd(
             ptr(self.dA1), H, ptr(self.G1[0]), H, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
             t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.dZ1), H,
             gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, B, H, st), "bn_relu_bwd(1)")
         torch.mm(self.dZ1.t(), self._x2(rows)[0], out=self.gW1)
+        if fork:
+            main.wait_stream(self._side)               # join: every gradient segment is complete
         if self.world_size > 1 or os.environ.get("NAF_FORCE_ALLREDUCE") == "1":
             # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
