@@ -18,9 +18,10 @@
  *     row stride ldh >= A+T+1 floats; l_pre is the row-major lower triangle
  *     (0,0),(1,0),(1,1),(2,0)... exactly as torch.tril_indices orders it
  *     (naf_components/naf_neural_network.py:98-100).
- *   - "transition row" = [state(S) | action(A) | reward | next_state(S) | done | 0-pad], padded to
- *     naf_replay_row_floats(S,A) floats (64 for A<=8: 256 B = two 128-B lines), the layout of both the
- *     HBM ring and of gathered minibatches.
+ *   - "transition row" = [state(S) | action(A) | reward | 0-pad | next_state(S) | done | 0-pad]: next_state starts
+ *     at naf_replay_row_off_next_state(S,A) = round_up(S+A+1, 4) floats (16-byte aligned, = 28 at S=21/A=6, 32 at
+ *     S=23/A=7), done follows it; rows are padded to naf_replay_row_floats(S,A) floats (64 for A<=8: 256 B = two
+ *     128-B lines). This is the layout of both the HBM ring and of gathered minibatches.
  */
 #ifndef NAF_HIP_H
 #define NAF_HIP_H
@@ -55,6 +56,7 @@ const char* naf_hip_arch(void);
 /* ---- replay buffer: HBM ring of transition rows ------------------------------------------ */
 /* replaces ReplayBuffer.__init__ (utils/replay_buffer.py:16-30): deque(maxlen=buffer_size) */
 int naf_replay_row_floats(int S, int A);
+int naf_replay_row_off_next_state(int S, int A);
 /* `rows` : capacity * row_floats f32 (caller-owned device memory)
  * `meta` : 8 x uint64 device words {head, size, total_added, sample_counter, 0,0,0, bad_index_count},
  *          zero-initialised by the caller. */
@@ -120,6 +122,36 @@ int naf_bn_relu_fwd_eval(const float* g, int ldg, const float* bias, const float
 int naf_bn_relu_bwd(const float* d_out, int ld_dout, const float* g, int ldg, const float* bias, const float* out,
                     int ldo, const float* gamma, const float* save_mean, const float* save_invstd, float* d_z,
                     int ldd, float* d_gamma, float* d_beta, float* d_bias, int B, int H, void* stream);
+
+/* ---- trunk layers with their small GEMMs folded in (csrc/fused_layers.hip) --------------------------------- */
+/* Linear(K <= 32) + BatchNorm1d(train) + ReLU for `nets` networks in one launch: replaces
+ * `torch.relu(self.bn1(self.input_layer(input_)))` INCLUDING the GEMM (naf_neural_network.py:76).
+ * x rows (x + net*x_net_stride + row*ldx) must be 16-B aligned with ldx % 4 == 0 and at least 24 (K <= 24) or 32
+ * readable floats per row; W is row-major [H][K] (torch Linear.weight), net n at + n*param_net_stride like bias/
+ * gamma/beta. */
+int naf_linear_bn_relu_fwd_train(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+                                 const float* gamma, const float* beta, int64_t param_net_stride, float* running_mean,
+                                 float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
+                                 float* save_mean, float* save_invstd, int B, int H, int nets, float momentum, float eps,
+                                 void* stream);
+/* backward of the above for one network: d_gamma, d_beta, d_bias and d_W[H][K] = dZ^T X (dZ never leaves registers) */
+int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
+                          const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
+                          const float* save_invstd, float* d_gamma, float* d_beta, float* d_bias, float* d_W, int B, int H,
+                          void* stream);
+/* d_out = d_heads[B][ldh] @ Wh[ldh][ldw] computed on the fly (ldh in {16,32,48}, pad columns zero), then the
+ * ReLU/BN backward of naf_bn_relu_bwd: replaces the dA2 GEMM + bn_relu_bwd pair */
+int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const float* Wh, int ldw, const float* g, int ldg,
+                              const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
+                              const float* save_invstd, float* d_z, int ldd, float* d_gamma, float* d_beta, float* d_bias,
+                              int B, int H, void* stream);
+/* heads_pre = a2[net 0] @ Wh[net 0]^T on f32 MFMA tiles (K % 16 == 0, NHP in {16,32,48}), V'(s') = a2[net 1] . Wh[net 1]
+ * row A+T, then exactly naf_head_fwd_bwd_mse: replaces the three head Linears of both networks
+ * (naf_neural_network.py:81-87) + the head + the TD/MSE epilogue. heads_out (nullable): [B][NHP]. */
+int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int lda, int K, const float* Wh,
+                                    int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu, const float* r, int ldr,
+                                    float gamma, float* heads_out, float* q_out, float* d_heads, float* loss_partials, int B,
+                                    int A, int p_mode, void* stream);
 
 /* ---- clip + Adam + Polyak over one flat parameter buffer -------------------------------------- */
 /* first half of clip_grad_norm_(params, 1) (naf_algorithm.py:209): partials[i] = sum of g^2 over chunk i of

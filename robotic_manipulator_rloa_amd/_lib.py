@@ -14,8 +14,8 @@ from typing import Optional
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
-SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "optim.hip", "synth_env.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "naf_hip.h")]
+SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "optim.hip", "synth_env.hip"]
+HEADERS = ["common.h", "head_body.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
 ACTION_TRUNC_INT, ACTION_FLOAT = 0, 1
@@ -64,6 +64,7 @@ _PROTOS = {
     "naf_hip_abi_version": [],
     "naf_hip_arch": [],
     "naf_replay_row_floats": [_i, _i],
+    "naf_replay_row_off_next_state": [_i, _i],
     "naf_replay_create": [_u64, _i, _i, _vp, _vp, C.POINTER(_vp)],
     "naf_replay_destroy": [_vp],
     "naf_replay_add_batch": [_vp, _vp, _i, _vp],
@@ -79,6 +80,12 @@ _PROTOS = {
                               _f, _f, _vp],
     "naf_bn_relu_fwd_eval": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "naf_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_linear_bn_relu_fwd_train": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp,
+                                     _i, _i, _i, _f, _f, _vp],
+    "naf_bn_relu_bwd_wgrad": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_heads_bwd_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_heads_gemm_head_fwd_bwd_mse": [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i,
+                                        _i, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
     "naf_polyak_update": [_vp, _vp, _f, _f, _sz, _vp],

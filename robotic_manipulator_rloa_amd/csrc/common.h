@@ -17,7 +17,12 @@
         if (e__ != hipSuccess) return (int)e__;               \
     } while (0)
 
-static inline int naf_round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ static inline int naf_round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// transition row layout: [state(S) | action(A) | reward | 0-pad to a multiple of 4 floats | next_state(S) | done | 0-pad]
+// next_state starts on a 16-byte boundary so both observations of a row can be read as float4
+__host__ __device__ static inline int naf_row_off_s2(int S, int A) { return naf_round_up(S + A + 1, 4); }
+__host__ __device__ static inline int naf_row_off_done(int S, int A) { return naf_row_off_s2(S, A) + S; }
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based: used by the replay sampler and by the

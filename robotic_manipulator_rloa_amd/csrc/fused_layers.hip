@@ -1,0 +1,485 @@
+// Trunk layers with their SMALL GEMMs folded into the BatchNorm/head kernels (gfx950). The learn() update is
+// launch-latency bound (each dependent launch costs ~1.5 us of boundary + its own latency), so every GEMM whose
+// reduction or output dimension is tiny (K = state size 21, N = heads 32) is computed inside the kernel that
+// consumes or produces it, on the tile that kernel already owns:
+//   naf_linear_bn_relu_fwd_train : X[B,K<=32] @ W^T + b -> BatchNorm(train) -> ReLU          (replaces bmm + bn_relu_fwd)
+//   naf_bn_relu_bwd_wgrad        : ReLU/BN backward of that layer + dW = dZ^T X, no dZ round trip (replaces bn_bwd + mm)
+//   naf_heads_bwd_bn_relu_bwd    : dA = dHeads @ Wh (K = 32..48) -> ReLU/BN backward -> dZ     (replaces mm + bn_bwd)
+//   naf_heads_gemm_head_fwd_bwd_mse : heads = A2 @ Wh^T on f32 MFMA tiles written to LDS, V'(s') GEMV for the target
+//                                  net, then the whole NAF head fwd + TD/MSE + bwd               (replaces bmm + head)
+// Reference lines replaced: naf_neural_network.py:76,81-115 (forward), their autograd, naf_algorithm.py:199-208.
+// Tile ownership as in bn_relu.hip: a workgroup owns 32 feature columns x ALL batch rows (32 x 32 threads).
+#include "head_body.h"
+
+#define BN_TX 32
+#define BN_TY 32
+#define MAX_K4 8    // small-K layers: K <= 32 (8 float4 per input row)
+
+__device__ static inline float col_reduce(float part, float (*red)[BN_TX + 1], int tx, int ty) {
+    __syncthreads();
+    red[ty][tx] = part;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_TY; ++k) s += red[k][tx];
+    return s;
+}
+
+// z[row] = b + sum_k x[row][k] * w[k], k ascending; x rows are 16-B aligned, read as K4 float4 (columns >= K hit
+// zero weights). All 32 lanes of a row-phase read the same addresses: one broadcast transaction per load.
+template <int K4>
+__device__ static inline float small_k_dot(const float* __restrict__ xrow, const float* w, float b) {
+    float z = b;
+#pragma unroll
+    for (int q = 0; q < K4; ++q) {
+        const float4 v = ((const float4*)xrow)[q];
+        z += v.x * w[4 * q + 0];
+        z += v.y * w[4 * q + 1];
+        z += v.z * w[4 * q + 2];
+        z += v.w * w[4 * q + 3];
+    }
+    return z;
+}
+
+// stage this workgroup's 32 x K weight tile (contiguous 32*K floats of a row-major [H][K] matrix) and return the
+// calling thread's column in registers, zero-padded to 4*K4
+template <int K4>
+__device__ static inline void load_w_column(const float* __restrict__ Wn, int col0, int H, int K, float (*sW)[4 * MAX_K4 + 1],
+                                            int tid, int tx, float* w) {
+    for (int e = tid; e < BN_TX * 4 * K4; e += BN_TX * BN_TY) {
+        int c = e / (4 * K4), k = e - c * (4 * K4);
+        sW[c][k] = (k < K && col0 + c < H) ? Wn[(int64_t)(col0 + c) * K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4 * K4; ++k) w[k] = sW[tx][k];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// F1: Linear(K small) + BatchNorm1d(train) + ReLU for `nets` networks
+// ------------------------------------------------------------------------------------------------------------
+template <int RPT, int K4>
+__global__ __launch_bounds__(BN_TX* BN_TY) void linear_bn_relu_fwd_train_kernel(
+    const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+    int64_t param_net_stride, float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride,
+    float* __restrict__ out, int64_t out_net_stride, int ldo, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd, int B, int H, float momentum, float eps) {
+    __shared__ float red[BN_TY][BN_TX + 1];
+    __shared__ float sW[BN_TX][4 * MAX_K4 + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * BN_TX + tx;
+    const int col0 = blockIdx.x * BN_TX, col = col0 + tx, net = blockIdx.y;
+    const bool col_on = col < H;
+    const int64_t po = net * param_net_stride;
+    const float* xn = x + net * x_net_stride;
+    float* oz = out + net * out_net_stride;
+    float w[4 * K4];
+    load_w_column<K4>(W + po, col0, H, K, sW, tid, tx, w);
+    const float b = col_on ? bias[po + col] : 0.f;
+
+    float z[RPT];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        z[k] = (row < B) ? small_k_dot<K4>(xn + (int64_t)row * ldx, w, b) : 0.f;
+        sum += z[k];
+    }
+    const float mean = col_reduce(sum, red, tx, ty) / (float)B;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        float dlt = (row < B) ? z[k] - mean : 0.f;
+        ss += dlt * dlt;
+    }
+    const float var = col_reduce(ss, red, tx, ty) / (float)B;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float gm = col_on ? gamma[po + col] : 0.f;
+    const float bt = col_on ? beta[po + col] : 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        if (col_on && row < B) {
+            float y = (z[k] - mean) * invstd * gm + bt;
+            oz[(int64_t)row * ldo + col] = y > 0.f ? y : 0.f;
+        }
+    }
+    if (ty == 0 && col_on) {
+        const int64_t so = net * stat_net_stride + col;
+        const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+        running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
+        running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+        save_mean[(int64_t)net * H + col] = mean;
+        save_invstd[(int64_t)net * H + col] = invstd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// B1: backward of F1 for one network: d_gamma, d_beta, d_bias and dW[H][K] = dZ^T X. dZ never leaves registers;
+// z is recomputed from X and W exactly as the forward computed it.
+// ------------------------------------------------------------------------------------------------------------
+template <int RPT, int K4>
+__global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_wgrad_kernel(
+    const float* __restrict__ d_out, int ld_dout, const float* __restrict__ x, int ldx, int K,
+    const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ out, int ldo,
+    const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+    float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_W, int B,
+    int H) {
+    __shared__ float red[BN_TY][BN_TX + 1];
+    __shared__ float sW[BN_TX][4 * MAX_K4 + 1];
+    __shared__ float sG[BN_TY / 2][BN_TX][4 * MAX_K4 + 1];   // per-wave partial dW tiles
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * BN_TX + tx;
+    const int col0 = blockIdx.x * BN_TX, col = col0 + tx;
+    const bool col_on = col < H;
+    float w[4 * K4];
+    load_w_column<K4>(W, col0, H, K, sW, tid, tx, w);
+    const float b = col_on ? bias[col] : 0.f;
+    const float mean = col_on ? save_mean[col] : 0.f;
+    const float invstd = col_on ? save_invstd[col] : 0.f;
+    const float gm = col_on ? gamma[col] : 0.f;
+
+    float xh[RPT], dy[RPT];
+    float s_dy = 0.f, s_dyxh = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        bool on = col_on && row < B;
+        float z = on ? small_k_dot<K4>(x + (int64_t)row * ldx, w, b) : 0.f;
+        float o = on ? out[(int64_t)row * ldo + col] : 0.f;
+        float dd = on ? d_out[(int64_t)row * ld_dout + col] : 0.f;
+        xh[k] = on ? (z - mean) * invstd : 0.f;
+        dy[k] = o > 0.f ? dd : 0.f;
+        s_dy += dy[k];
+        s_dyxh += dy[k] * xh[k];
+    }
+    const float dbeta = col_reduce(s_dy, red, tx, ty);
+    const float dgamma = col_reduce(s_dyxh, red, tx, ty);
+    const float invB = 1.0f / (float)B;
+    const float k1 = gm * invstd;
+    float acc[4 * K4];
+#pragma unroll
+    for (int k = 0; k < 4 * K4; ++k) acc[k] = 0.f;
+    float s_dz = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        if (row < B) {
+            float dz = col_on ? k1 * (dy[k] - dbeta * invB - xh[k] * (dgamma * invB)) : 0.f;
+            s_dz += dz;
+            const float4* xr = (const float4*)(x + (int64_t)row * ldx);
+#pragma unroll
+            for (int q = 0; q < K4; ++q) {
+                const float4 v = xr[q];
+                acc[4 * q + 0] += dz * v.x;
+                acc[4 * q + 1] += dz * v.y;
+                acc[4 * q + 2] += dz * v.z;
+                acc[4 * q + 3] += dz * v.w;
+            }
+        }
+    }
+    const float dbias = col_reduce(s_dz, red, tx, ty);
+    // dW tile: lanes l and l+32 of a wave hold the same column (row phases 2w, 2w+1): fold them, then 16 wave tiles
+    const int wv = ty >> 1;
+#pragma unroll
+    for (int k = 0; k < 4 * K4; ++k) {
+        float v = acc[k] + __shfl_xor(acc[k], 32);
+        if ((ty & 1) == 0) sG[wv][tx][k] = v;
+    }
+    __syncthreads();
+    // thread (tx, ty) finishes dW[col][k = ty] (K <= 32 = BN_TY)
+    if (ty < K && col_on) {
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < BN_TY / 2; ++v) s += sG[v][tx][ty];
+        d_W[(int64_t)col * K + ty] = s;
+    }
+    if (ty == 0 && col_on) {
+        d_gamma[col] = dgamma;
+        d_beta[col] = dbeta;
+        if (d_bias) d_bias[col] = dbias;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// B2: d_out = d_heads @ Wh (reduction over the NH <= 48 heads outputs) computed on the fly, then ReLU/BN backward.
+// ------------------------------------------------------------------------------------------------------------
+template <int RPT, int NH4>
+__global__ __launch_bounds__(BN_TX* BN_TY) void heads_bwd_bn_relu_bwd_kernel(
+    const float* __restrict__ d_heads, int ldh, const float* __restrict__ Wh, int ldw, const float* __restrict__ g,
+    int ldg, const float* __restrict__ bias, const float* __restrict__ out, int ldo, const float* __restrict__ gamma,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* __restrict__ d_z, int ldd,
+    float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, int B, int H) {
+    __shared__ float red[BN_TY][BN_TX + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = blockIdx.x * BN_TX + tx;
+    const bool col_on = col < H;
+    float w[4 * NH4];   // column `col` of Wh: Wh[j][col], coalesced across tx
+#pragma unroll
+    for (int j = 0; j < 4 * NH4; ++j) w[j] = col_on ? Wh[(int64_t)j * ldw + col] : 0.f;
+    const float b = (bias && col_on) ? bias[col] : 0.f;
+    const float mean = col_on ? save_mean[col] : 0.f;
+    const float invstd = col_on ? save_invstd[col] : 0.f;
+    const float gm = col_on ? gamma[col] : 0.f;
+
+    float xh[RPT], dy[RPT];
+    float s_dy = 0.f, s_dyxh = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        bool on = col_on && row < B;
+        float dd = 0.f;
+        if (row < B) {
+            const float4* dh = (const float4*)(d_heads + (int64_t)row * ldh);   // broadcast across the 32 columns
+#pragma unroll
+            for (int q = 0; q < NH4; ++q) {
+                const float4 v = dh[q];
+                dd += v.x * w[4 * q + 0];
+                dd += v.y * w[4 * q + 1];
+                dd += v.z * w[4 * q + 2];
+                dd += v.w * w[4 * q + 3];
+            }
+        }
+        float z = on ? g[(int64_t)row * ldg + col] + b : 0.f;
+        float o = on ? out[(int64_t)row * ldo + col] : 0.f;
+        xh[k] = on ? (z - mean) * invstd : 0.f;
+        dy[k] = o > 0.f ? dd : 0.f;
+        s_dy += dy[k];
+        s_dyxh += dy[k] * xh[k];
+    }
+    const float dbeta = col_reduce(s_dy, red, tx, ty);
+    const float dgamma = col_reduce(s_dyxh, red, tx, ty);
+    const float invB = 1.0f / (float)B;
+    const float k1 = gm * invstd;
+    float s_dz = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * BN_TY;
+        if (col_on && row < B) {
+            float dz = k1 * (dy[k] - dbeta * invB - xh[k] * (dgamma * invB));
+            d_z[(int64_t)row * ldd + col] = dz;
+            s_dz += dz;
+        }
+    }
+    const float dbias = col_reduce(s_dz, red, tx, ty);
+    if (ty == 0 && col_on) {
+        d_gamma[col] = dgamma;
+        d_beta[col] = dbeta;
+        if (d_bias) d_bias[col] = dbias;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// F3: heads GEMM on f32 MFMA + NAF head. Workgroup = 256 threads = 4 waves = 32 samples.
+// Each wave produces 16(samples) x 16(outputs) tiles with v_mfma_f32_16x16x4_f32 straight from global memory:
+// lane (r = l & 15, g = l >> 4) loads ONE float4 of row r at k = 16 j + 4 g for A and for B, and feeds components
+// x,y,z,w to four MFMAs — over the four lane groups the 16 k's of macro-step j are each used once (the order
+// of summation over k is a permutation of ascending, identical for A and B). Two accumulators hide the 40-cycle
+// dependent-accumulate latency. Tiles land in the LDS heads rows the head math reads.
+// ------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define KSTEPS 17   // K = 272 = layer_size 256 + 16: the framework's fixed hidden width (rl_framework.py:452)
+
+template <int PMODE>
+__global__ __launch_bounds__(HEAD_THREADS) void heads_gemm_head_kernel(
+    const float* __restrict__ a2, int64_t a2_net_stride, int lda, int K, const float* __restrict__ Wh,
+    int64_t wh_net_stride, int ldw, int NHP, const float* __restrict__ u, int ldu, const float* __restrict__ r, int ldr,
+    float gamma, float* __restrict__ heads_out, float* __restrict__ q_out, float* __restrict__ d_heads,
+    float* __restrict__ loss_partials, int B, int A) {
+    __shared__ __attribute__((aligned(16))) float sh_in[HEAD_SPB * HEAD_MAX_LDH];
+    __shared__ __attribute__((aligned(16))) float sh_out[HEAD_SPB * HEAD_MAX_LDH];
+    __shared__ float sh_L[PMODE == NAF_P_MATMUL ? HEAD_SPB * 8 * LT_STRIDE : 1];
+    __shared__ float sh_red[HEAD_THREADS / 64];
+    __shared__ float sh_vnext[HEAD_SPB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t s0 = (int64_t)blockIdx.x * HEAD_SPB;
+    const int ns = (B - s0) < HEAD_SPB ? (int)(B - s0) : HEAD_SPB;
+    const int T = A * (A + 1) / 2;
+
+    for (int k = tid; k < HEAD_SPB * NHP / 4; k += HEAD_THREADS) ((float4*)sh_out)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- heads = A2[main] @ Wh[main]^T : 2 x (NHP/16) tiles of 16 x 16 over the 4 waves -----------------------
+    const int tiles_n = NHP >> 4;
+    const int rr = lane & 15, gg = lane >> 4;
+    for (int t = wave; t < 2 * tiles_n; t += 4) {
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+        int srow = tm * 16 + rr;                       // sample row (within the workgroup) this lane loads for A
+        if (srow >= ns) srow = ns - 1;                 // clamp: rows beyond the batch are computed but never used
+        const float* ap = a2 + (s0 + srow) * (int64_t)lda + 4 * gg;
+        const float* bp = Wh + (int64_t)(tn * 16 + rr) * ldw + 4 * gg;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (K == 16 * KSTEPS) {
+            // one wave per SIMD and nothing else resident: spend registers, not latency — issue every operand load of
+            // the tile (2 x KSTEPS float4 per lane) before the first MFMA
+            float4 av[KSTEPS], bv[KSTEPS];
+#pragma unroll
+            for (int j = 0; j < KSTEPS; ++j) {
+                av[j] = *(const float4*)(ap + 16 * j);
+                bv[j] = *(const float4*)(bp + 16 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < KSTEPS; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
+            }
+        } else {
+            for (int k0 = 0; k0 < K; k0 += 16) {
+                const float4 av = *(const float4*)(ap + k0);
+                const float4 bv = *(const float4*)(bp + k0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+            }
+        }
+        // C/D map: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int srow_o = tm * 16 + 4 * gg + e;
+            sh_in[srow_o * NHP + tn * 16 + rr] = acc0[e] + acc1[e];
+        }
+    }
+    // ---- V'(s') of the target net: one 8-lane group per sample, k strided by 8 float4 --------------------------
+    {
+        const int s_loc = tid >> 3, i = tid & 7;
+        const float* ap = a2 + a2_net_stride + (s0 + (s_loc < ns ? s_loc : ns - 1)) * (int64_t)lda;
+        const float* wp = Wh + wh_net_stride + (int64_t)(A + T) * ldw;
+        float p = 0.f;
+#pragma unroll 9
+        for (int k0 = 4 * i; k0 < K; k0 += 32) {
+            const float4 av = *(const float4*)(ap + k0);
+            const float4 wv = *(const float4*)(wp + k0);
+            p += av.x * wv.x + av.y * wv.y + av.z * wv.z + av.w * wv.w;
+        }
+        p = group8_sum(p);
+        if (i == 0) sh_vnext[s_loc] = p;
+    }
+    __syncthreads();
+    if (heads_out) {
+        for (int k = tid; k < ns * NHP / 4; k += HEAD_THREADS) ((float4*)(heads_out + s0 * NHP))[k] = ((const float4*)sh_in)[k];
+    }
+    naf_head_body<PMODE, 2>(sh_in, sh_out, sh_L, sh_red, NHP, u, ldu, r, ldr, sh_vnext - s0, 1, nullptr, gamma, q_out, nullptr,
+                            loss_partials, B, A, s0, ns);
+    {
+        float4* dst = (float4*)(d_heads + s0 * NHP);
+        const int n4 = ns * NHP / 4;
+        for (int k = tid; k < n4; k += HEAD_THREADS) dst[k] = ((const float4*)sh_out)[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+#define RPT_DISPATCH(KERNEL, KK, ...)                                                      \
+    do {                                                                                   \
+        int rpt = (B + BN_TY - 1) / BN_TY;                                                 \
+        if (rpt <= 2) KERNEL<2, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                  \
+        else if (rpt <= 4) KERNEL<4, KK><<<grid, block, 0, st>>>(__VA_ARGS__);             \
+        else if (rpt <= 8) KERNEL<8, KK><<<grid, block, 0, st>>>(__VA_ARGS__);             \
+        else if (rpt <= 16) KERNEL<16, KK><<<grid, block, 0, st>>>(__VA_ARGS__);           \
+        else if (rpt <= 32) KERNEL<32, KK><<<grid, block, 0, st>>>(__VA_ARGS__);           \
+        else KERNEL<64, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                          \
+    } while (0)
+
+#define K4_DISPATCH(KERNEL, k4, ...)                                                        \
+    do {                                                                                    \
+        if ((k4) <= 6) RPT_DISPATCH(KERNEL, 6, __VA_ARGS__);                                \
+        else RPT_DISPATCH(KERNEL, 8, __VA_ARGS__);                                          \
+    } while (0)
+
+#define FUSED_MAX_B (BN_TY * 64)
+
+extern "C" int naf_linear_bn_relu_fwd_train(const float* x, int64_t x_net_stride, int ldx, int K, const float* W,
+                                            const float* bias, const float* gamma, const float* beta,
+                                            int64_t param_net_stride, float* running_mean, float* running_var,
+                                            int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
+                                            float* save_mean, float* save_invstd, int B, int H, int nets, float momentum,
+                                            float eps, void* stream) {
+    if (!x || !W || !bias || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd)
+        return NAF_ERR_ARG;
+    if (B <= 0 || B > FUSED_MAX_B || H <= 0 || nets <= 0 || K <= 0 || K > 4 * MAX_K4 || ldo < H) return NAF_ERR_ARG;
+    const int k4 = (K + 3) / 4;
+    // rows are read as float4: 16-B aligned rows, and a row must own 4*k4' floats (k4' = 6 or 8 as dispatched)
+    const int k4d = k4 <= 6 ? 6 : 8;
+    if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d || (x_net_stride & 3) != 0) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H + BN_TX - 1) / BN_TX, nets), block(BN_TX, BN_TY);
+    K4_DISPATCH(linear_bn_relu_fwd_train_kernel, k4, x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride,
+                running_mean, running_var, stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, B, H,
+                momentum, eps);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
+                                     const float* bias, const float* out, int ldo, const float* gamma,
+                                     const float* save_mean, const float* save_invstd, float* d_gamma, float* d_beta,
+                                     float* d_bias, float* d_W, int B, int H, void* stream) {
+    if (!d_out || !x || !W || !bias || !out || !gamma || !save_mean || !save_invstd || !d_gamma || !d_beta || !d_W)
+        return NAF_ERR_ARG;
+    if (B <= 0 || B > FUSED_MAX_B || H <= 0 || K <= 0 || K > 4 * MAX_K4 || ld_dout < H || ldo < H) return NAF_ERR_ARG;
+    const int k4 = (K + 3) / 4;
+    const int k4d = k4 <= 6 ? 6 : 8;
+    if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H + BN_TX - 1) / BN_TX, 1), block(BN_TX, BN_TY);
+    K4_DISPATCH(bn_relu_bwd_wgrad_kernel, k4, d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, save_invstd,
+                d_gamma, d_beta, d_bias, d_W, B, H);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const float* Wh, int ldw, const float* g, int ldg,
+                                         const float* bias, const float* out, int ldo, const float* gamma,
+                                         const float* save_mean, const float* save_invstd, float* d_z, int ldd,
+                                         float* d_gamma, float* d_beta, float* d_bias, int B, int H, void* stream) {
+    if (!d_heads || !Wh || !g || !out || !gamma || !save_mean || !save_invstd || !d_z || !d_gamma || !d_beta)
+        return NAF_ERR_ARG;
+    if (B <= 0 || B > FUSED_MAX_B || H <= 0 || ldw < H || ldg < H || ldo < H || ldd < H) return NAF_ERR_ARG;
+    if (ldh != 16 && ldh != 32 && ldh != 48) return NAF_ERR_ARG;     // every heads column (pads are zeros) is reduced
+    if (((uintptr_t)d_heads & 15) != 0) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H + BN_TX - 1) / BN_TX, 1), block(BN_TX, BN_TY);
+    if (ldh == 16)
+        RPT_DISPATCH(heads_bwd_bn_relu_bwd_kernel, 4, d_heads, ldh, Wh, ldw, g, ldg, bias, out, ldo, gamma, save_mean,
+                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, B, H);
+    else if (ldh == 32)
+        RPT_DISPATCH(heads_bwd_bn_relu_bwd_kernel, 8, d_heads, ldh, Wh, ldw, g, ldg, bias, out, ldo, gamma, save_mean,
+                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, B, H);
+    else
+        RPT_DISPATCH(heads_bwd_bn_relu_bwd_kernel, 12, d_heads, ldh, Wh, ldw, g, ldg, bias, out, ldo, gamma, save_mean,
+                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, B, H);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int lda, int K, const float* Wh,
+                                               int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu,
+                                               const float* r, int ldr, float gamma, float* heads_out, float* q_out,
+                                               float* d_heads, float* loss_partials, int B, int A, int p_mode,
+                                               void* stream) {
+    if (!a2 || !Wh || !u || !r || !d_heads || B <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
+    if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
+    if ((NHP != 16 && NHP != 32 && NHP != 48) || NHP < A + A * (A + 1) / 2 + 1) return NAF_ERR_ARG;
+    if (K <= 0 || (K & 15) != 0 || lda < K || ldw < K || (lda & 3) != 0 || (ldw & 3) != 0 || ldu < A || ldr < 1)
+        return NAF_ERR_ARG;
+    if ((((uintptr_t)a2 | (uintptr_t)Wh | (uintptr_t)d_heads | (uintptr_t)heads_out) & 15) != 0 ||
+        (a2_net_stride & 3) != 0 || (wh_net_stride & 3) != 0)
+        return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (B + HEAD_SPB - 1) / HEAD_SPB;
+    if (p_mode == NAF_P_HADAMARD)
+        heads_gemm_head_kernel<NAF_P_HADAMARD><<<blocks, HEAD_THREADS, 0, st>>>(a2, a2_net_stride, lda, K, Wh, wh_net_stride,
+                                                                               ldw, NHP, u, ldu, r, ldr, gamma, heads_out,
+                                                                               q_out, d_heads, loss_partials, B, A);
+    else
+        heads_gemm_head_kernel<NAF_P_MATMUL><<<blocks, HEAD_THREADS, 0, st>>>(a2, a2_net_stride, lda, K, Wh, wh_net_stride,
+                                                                             ldw, NHP, u, ldu, r, ldr, gamma, heads_out, q_out,
+                                                                             d_heads, loss_partials, B, A);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}

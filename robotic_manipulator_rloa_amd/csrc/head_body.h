@@ -1,0 +1,161 @@
+// NAF head math shared by naf_head.hip (heads rows staged from memory) and fused_layers.hip (heads rows produced
+// in LDS by an MFMA GEMM). One sample per 8-lane group, lane i owns row i of L. See naf_head.hip for the mapping.
+#pragma once
+#include "common.h"
+#include "../../include/naf_hip.h"
+
+#define HEAD_SPB 32          // samples per workgroup
+#define HEAD_THREADS 256
+#define HEAD_MAX_LDH 48      // A=8: 8+36+1 = 45 -> 48
+#define LT_STRIDE 9          // 8x8 L tile padded to 9 columns: column reads hit distinct banks
+
+__device__ static inline float group8_sum(float x) {
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 4);
+    return x;
+}
+
+// sh_in : HEAD_SPB heads rows (stride ldh) already in LDS and visible (caller synchronised)
+// sh_out: HEAD_SPB x ldh floats, zero-filled by the caller when MODE != 0; receives d_heads rows
+// sh_L  : HEAD_SPB*8*LT_STRIDE floats (matmul mode only); sh_red: HEAD_THREADS/64 floats
+// Ends with a __syncthreads() when MODE != 0, after which sh_out is complete. MODE 0 returns early per lane.
+// MODE: 0 = forward only (q, optional mu); 1 = backward given dq; 2 = fused TD target + MSE + backward
+template <int PMODE, int MODE>
+__device__ static inline void naf_head_body(const float* sh_in, float* sh_out, float* sh_L, float* sh_red, int ldh,
+                                            const float* __restrict__ u, int ldu, const float* __restrict__ r, int ldr,
+                                            const float* __restrict__ v_next, int ldv, const float* __restrict__ dq_in,
+                                            float gamma, float* __restrict__ q_out, float* __restrict__ mu_out,
+                                            float* __restrict__ loss_partials, int B, int A, int64_t s0, int ns) {
+    const int T = A * (A + 1) / 2;
+    const int tid = threadIdx.x;
+    const int s_loc = tid >> 3;   // sample within the workgroup
+    const int i = tid & 7;        // row of L owned by this lane
+    const int64_t s = s0 + s_loc;
+    const bool live = s_loc < ns;
+    const bool row_on = live && i < A;
+
+    const float* hrow = sh_in + s_loc * ldh;
+    float mu = 0.f, d = 0.f, Vv = 0.f;
+    float t_row[8], L_row[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { t_row[j] = 0.f; L_row[j] = 0.f; }
+    if (row_on) {
+        mu = tanhf(hrow[i]);
+        d = u[s * ldu + i] - mu;
+        const int rbase = A + i * (i + 1) / 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j <= i) {
+                float t = tanhf(hrow[rbase + j]);
+                t_row[j] = t;
+                L_row[j] = (j == i) ? expf(t) : t;
+            }
+        }
+    }
+    if (live) Vv = hrow[A + T];
+
+    // ---- quadratic form ---------------------------------------------------------------------------
+    float quad_part = 0.f;
+    float w = 0.f;  // matmul mode: w_i = (L^T d)_i, lane i holds component i
+    float Pii = 0.f;
+    if (PMODE == NAF_P_HADAMARD) {
+        // P = L (*) L^T = diag(L_ii^2): off-diagonal entries of L multiply structural zeros of L^T
+        float Lii = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j == i) Lii = L_row[j];
+        Pii = Lii * Lii;
+        quad_part = Pii * d * d;
+    } else {
+        float* Lt = sh_L + s_loc * 8 * LT_STRIDE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Lt[i * LT_STRIDE + j] = L_row[j];
+        __syncthreads();  // reached by every lane: no early exit above
+        const int gb = (tid & 63) & ~7;  // first lane of this sample's group inside the wave
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float dk = __shfl(d, gb + k);
+            if (k >= i) w += Lt[k * LT_STRIDE + i] * dk;  // column i of L
+        }
+        quad_part = w * w;
+    }
+    const float quad = group8_sum(quad_part);
+    const float Q = Vv - 0.5f * quad;
+
+    if (MODE == 0) {
+        if (live && i == 0) q_out[s] = Q;
+        if (mu_out && row_on) mu_out[s * A + i] = mu;
+        return;
+    }
+
+    // ---- dLoss/dQ ---------------------------------------------------------------------------------
+    float dq = 0.f;
+    float sq_err = 0.f;
+    if (MODE == 1) {
+        if (live) dq = dq_in[s];
+    } else {
+        // lane 0 of the group fetches r and V'(s'); the group shares them by shuffle (uniform control flow)
+        float y = 0.f;
+        if (live && i == 0) y = r[s * ldr] + gamma * v_next[s * ldv];
+        y = __shfl(y, (tid & 63) & ~7);
+        if (live) {
+            float e = Q - y;
+            dq = 2.0f * e / (float)B;
+            if (i == 0) {
+                sq_err = e * e / (float)B;
+                if (q_out) q_out[s] = Q;
+            }
+        }
+    }
+
+    // ---- backward ---------------------------------------------------------------------------------
+    float* orow = sh_out + s_loc * ldh;
+    if (PMODE == NAF_P_HADAMARD) {
+        if (row_on) {
+            // dQ/dmu_i = P_ii d_i ; dQ/dl_ii = -P_ii d_i^2 (through L_ii = exp(t)); off-diagonals: exactly 0
+            float tii = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j == i) tii = t_row[j];
+            orow[i] = dq * (Pii * d) * (1.0f - mu * mu);
+            orow[A + i * (i + 1) / 2 + i] = dq * (-(Pii * d * d)) * (1.0f - tii * tii);
+        }
+    } else {
+        const int gb = (tid & 63) & ~7;
+        float Lw = 0.f;
+        float wj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            wj[j] = __shfl(w, gb + j);
+            Lw += L_row[j] * wj[j];  // L_row[j] = 0 for j > i
+        }
+        if (row_on) {
+            // dQ/dmu = L w ; dQ/dL_ij = -d_i w_j (j <= i); diagonal chains through exp
+            orow[i] = dq * Lw * (1.0f - mu * mu);
+            const int rbase = A + i * (i + 1) / 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j <= i) {
+                    float dL = -d * wj[j];
+                    float dt = (j == i) ? dL * L_row[j] : dL;
+                    orow[rbase + j] = dq * dt * (1.0f - t_row[j] * t_row[j]);
+                }
+            }
+        }
+    }
+    if (live && i == 0) orow[A + T] = dq;  // dQ/dV = 1
+
+    if (MODE == 2) {
+        // workgroup sum of squared TD errors, fixed order -> bitwise reproducible
+        float x = sq_err;
+        x += __shfl_xor(x, 8);
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        if ((tid & 63) == 0) sh_red[tid >> 6] = x;
+    }
+    __syncthreads();
+    if (MODE == 2 && tid == 0 && loss_partials) {
+        float x = 0.f;
+        for (int k = 0; k < HEAD_THREADS / 64; ++k) x += sh_red[k];
+        loss_partials[blockIdx.x] = x;
+    }
+}

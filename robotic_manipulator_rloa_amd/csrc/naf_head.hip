@@ -6,20 +6,7 @@
 // 256-thread workgroup. The heads rows of a workgroup are one contiguous 32*ldh*4-byte span: staged into LDS
 // with 16-B/lane loads, and d_heads leaves the same way. The A x A contraction is per sample — not a GEMM,
 // so no MFMA: row reductions are 8-lane xor shuffles, column accesses of L go through a padded LDS tile.
-#include "common.h"
-#include "../../include/naf_hip.h"
-
-#define HEAD_SPB 32          // samples per workgroup
-#define HEAD_THREADS 256
-#define HEAD_MAX_LDH 48      // A=8: 8+36+1 = 45 -> 48
-#define LT_STRIDE 9          // 8x8 L tile padded to 9 columns: column reads hit distinct banks
-
-__device__ static inline float group8_sum(float x) {
-    x += __shfl_xor(x, 1);
-    x += __shfl_xor(x, 2);
-    x += __shfl_xor(x, 4);
-    return x;
-}
+#include "head_body.h"
 
 // MODE: 0 = forward only (q, optional mu); 1 = backward given dq; 2 = fused TD target + MSE + backward
 template <int PMODE, int MODE>
@@ -35,16 +22,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void naf_head_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float sh_out[MODE == 0 ? 4 : HEAD_SPB * HEAD_MAX_LDH];
     __shared__ float sh_L[PMODE == NAF_P_MATMUL ? HEAD_SPB * 8 * LT_STRIDE : 1];
     __shared__ float sh_red[HEAD_THREADS / 64];
-
-    const int T = A * (A + 1) / 2;
     const int tid = threadIdx.x;
-    const int s_loc = tid >> 3;   // sample within the workgroup
-    const int i = tid & 7;        // row of L owned by this lane
     const int64_t s0 = (int64_t)blockIdx.x * HEAD_SPB;
     const int ns = (B - s0) < HEAD_SPB ? (int)(B - s0) : HEAD_SPB;
-    const int64_t s = s0 + s_loc;
-    const bool live = s_loc < ns;
-    const bool row_on = live && i < A;
 
     // ---- stage this workgroup's heads rows (contiguous span) ------------------------------------
     {
@@ -57,130 +37,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void naf_head_kernel(const float* __r
         }
     }
     __syncthreads();
-
-    const float* hrow = sh_in + s_loc * ldh;
-    float mu = 0.f, d = 0.f, Vv = 0.f;
-    float t_row[8], L_row[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { t_row[j] = 0.f; L_row[j] = 0.f; }
-    if (row_on) {
-        mu = tanhf(hrow[i]);
-        d = u[s * ldu + i] - mu;
-        const int rbase = A + i * (i + 1) / 2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j <= i) {
-                float t = tanhf(hrow[rbase + j]);
-                t_row[j] = t;
-                L_row[j] = (j == i) ? expf(t) : t;
-            }
-        }
-    }
-    if (live) Vv = hrow[A + T];
-
-    // ---- quadratic form ---------------------------------------------------------------------------
-    float quad_part = 0.f;
-    float w = 0.f;  // matmul mode: w_i = (L^T d)_i, lane i holds component i
-    float Pii = 0.f;
-    if (PMODE == NAF_P_HADAMARD) {
-        // P = L (*) L^T = diag(L_ii^2): off-diagonal entries of L multiply structural zeros of L^T
-        float Lii = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (j == i) Lii = L_row[j];
-        Pii = Lii * Lii;
-        quad_part = Pii * d * d;
-    } else {
-        float* Lt = sh_L + s_loc * 8 * LT_STRIDE;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Lt[i * LT_STRIDE + j] = L_row[j];
-        __syncthreads();  // reached by every lane: no early exit above
-        const int gb = (tid & 63) & ~7;  // first lane of this sample's group inside the wave
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float dk = __shfl(d, gb + k);
-            if (k >= i) w += Lt[k * LT_STRIDE + i] * dk;  // column i of L
-        }
-        quad_part = w * w;
-    }
-    const float quad = group8_sum(quad_part);
-    const float Q = Vv - 0.5f * quad;
-
-    if (MODE == 0) {
-        if (live && i == 0) q_out[s] = Q;
-        if (mu_out && row_on) mu_out[s * A + i] = mu;
-        return;
-    }
-
-    // ---- dLoss/dQ ---------------------------------------------------------------------------------
-    float dq = 0.f;
-    float sq_err = 0.f;
-    if (MODE == 1) {
-        if (live) dq = dq_in[s];
-    } else {
-        // lane 0 of the group fetches r and V'(s'); the group shares them by shuffle (uniform control flow)
-        float y = 0.f;
-        if (live && i == 0) y = r[s * ldr] + gamma * v_next[s * ldv];
-        y = __shfl(y, (tid & 63) & ~7);
-        if (live) {
-            float e = Q - y;
-            dq = 2.0f * e / (float)B;
-            if (i == 0) {
-                sq_err = e * e / (float)B;
-                if (q_out) q_out[s] = Q;
-            }
-        }
-    }
-
-    // ---- backward ---------------------------------------------------------------------------------
-    float* orow = sh_out + s_loc * ldh;
-    if (PMODE == NAF_P_HADAMARD) {
-        if (row_on) {
-            // dQ/dmu_i = P_ii d_i ; dQ/dl_ii = -P_ii d_i^2 (through L_ii = exp(t)); off-diagonals: exactly 0
-            float tii = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (j == i) tii = t_row[j];
-            orow[i] = dq * (Pii * d) * (1.0f - mu * mu);
-            orow[A + i * (i + 1) / 2 + i] = dq * (-(Pii * d * d)) * (1.0f - tii * tii);
-        }
-    } else {
-        const int gb = (tid & 63) & ~7;
-        float Lw = 0.f;
-        float wj[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            wj[j] = __shfl(w, gb + j);
-            Lw += L_row[j] * wj[j];  // L_row[j] = 0 for j > i
-        }
-        if (row_on) {
-            // dQ/dmu = L w ; dQ/dL_ij = -d_i w_j (j <= i); diagonal chains through exp
-            orow[i] = dq * Lw * (1.0f - mu * mu);
-            const int rbase = A + i * (i + 1) / 2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j <= i) {
-                    float dL = -d * wj[j];
-                    float dt = (j == i) ? dL * L_row[j] : dL;
-                    orow[rbase + j] = dq * dt * (1.0f - t_row[j] * t_row[j]);
-                }
-            }
-        }
-    }
-    if (live && i == 0) orow[A + T] = dq;  // dQ/dV = 1
-
-    if (MODE == 2) {
-        // workgroup sum of squared TD errors, fixed order -> bitwise reproducible
-        float x = sq_err;
-        x += __shfl_xor(x, 8);
-        x += __shfl_xor(x, 16);
-        x += __shfl_xor(x, 32);
-        if ((tid & 63) == 0) sh_red[tid >> 6] = x;
-    }
-    __syncthreads();
-    if (MODE == 2 && tid == 0 && loss_partials) {
-        float x = 0.f;
-        for (int k = 0; k < HEAD_THREADS / 64; ++k) x += sh_red[k];
-        loss_partials[blockIdx.x] = x;
-    }
+    naf_head_body<PMODE, MODE>(sh_in, sh_out, sh_L, sh_red, ldh, u, ldu, r, ldr, v_next, ldv, dq_in, gamma, q_out, mu_out,
+                               loss_partials, B, A, s0, ns);
+    if (MODE == 0) return;
     {
         float4* dst = (float4*)(d_heads + s0 * ldh);
         const int n4 = ns * ldh / 4;

@@ -20,10 +20,15 @@ enum { META_HEAD = 0, META_SIZE = 1, META_TOTAL = 2, META_SAMPLE_CTR = 3, META_B
 extern "C" int naf_replay_row_floats(int S, int A) {
     if (S <= 0 || A <= 0) return NAF_ERR_ARG;
     // whole 128-B lines, and a power-of-two number of float4 per row so a row maps onto 2^k lanes
-    int need = 2 * S + A + 2;
+    int need = naf_row_off_done(S, A) + 1;
     int rf = 32;
     while (rf < need) rf *= 2;
     return rf;
+}
+
+extern "C" int naf_replay_row_off_next_state(int S, int A) {
+    if (S <= 0 || A <= 0) return NAF_ERR_ARG;
+    return naf_row_off_s2(S, A);
 }
 
 extern "C" int naf_replay_create(uint64_t capacity, int S, int A, float* rows, uint64_t* meta, naf_replay_t** out) {
@@ -308,7 +313,8 @@ __global__ __launch_bounds__(256) void replay_gather_soa_kernel(const float* __r
     const uint64_t head = meta[META_HEAD];
     const uint64_t size = meta[META_SIZE];
     const uint64_t base = head + cap - size;
-    const int used = 2 * S + A + 2;
+    const int off_s2 = naf_row_off_s2(S, A), off_d = naf_row_off_done(S, A);
+    const int used = off_d + 1;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < (int64_t)n * used;
          g += (int64_t)gridDim.x * blockDim.x) {
         int64_t row = g / used;
@@ -323,7 +329,8 @@ __global__ __launch_bounds__(256) void replay_gather_soa_kernel(const float* __r
         if (c < S) s[row * S + c] = v;
         else if (c < S + A) u[row * A + (c - S)] = trunc ? truncf(v) : v;
         else if (c == S + A) r[row] = v;
-        else if (c < 2 * S + A + 1) s2[row * S + (c - S - A - 1)] = v;
+        else if (c < off_s2) continue;                       // alignment pad
+        else if (c < off_d) s2[row * S + (c - off_s2)] = v;
         else d[row] = v;
     }
 }
@@ -334,7 +341,7 @@ extern "C" int naf_replay_gather_soa(naf_replay_t* h, const int32_t* idx, float*
     if (!idx || !s || !u || !r || !s2 || !d || n < 0) return NAF_ERR_ARG;
     if (action_mode != NAF_ACTION_TRUNC_INT && action_mode != NAF_ACTION_FLOAT) return NAF_ERR_ARG;
     if (n == 0) return NAF_OK;
-    int used = 2 * h->S + h->A + 2;
+    int used = naf_row_off_done(h->S, h->A) + 1;
     int64_t total = (int64_t)n * used;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;

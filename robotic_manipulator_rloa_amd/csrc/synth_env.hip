@@ -109,10 +109,12 @@ __global__ void synth_env_step_kernel(float* env_state, const float* __restrict_
     const bool reached = dist < 0.05f;
     float reward = reached ? 250.f : (hit ? -1000.f : -(dist - 0.05f));
     float done = (reached || hit) ? 1.f : 0.f;
+    const int off_s2 = naf_row_off_s2(S, A), off_d = naf_row_off_done(S, A);
     row[S + A] = reward;
-    write_obs(row + S + A + 1, st, a, ee, st + 8, st + 11, A);
-    row[2 * S + A + 1] = done;
-    for (int k = 2 * S + A + 2; k < row_floats; ++k) row[k] = 0.f;
+    for (int k = S + A + 1; k < off_s2; ++k) row[k] = 0.f;
+    write_obs(row + off_s2, st, a, ee, st + 8, st + 11, A);
+    row[off_d] = done;
+    for (int k = off_d + 1; k < row_floats; ++k) row[k] = 0.f;
 
     st[22] += 1.f;
     if (done != 0.f || (max_frames > 0 && st[22] >= (float)max_frames)) {
@@ -123,7 +125,7 @@ __global__ void synth_env_step_kernel(float* env_state, const float* __restrict_
         fk_chain(st, A, ee, st + 11, 0.06f, &hit);
         write_obs(ob, st, qd0, ee, st + 8, st + 11, A);
     } else {
-        for (int k = 0; k < S; ++k) ob[k] = row[S + A + 1 + k];
+        for (int k = 0; k < S; ++k) ob[k] = row[off_s2 + k];
     }
 }
 

@@ -90,8 +90,8 @@ class NetLayout:
         self.S, self.A, self.H = state_size, action_size, layer_size
         self.T = action_size * (action_size + 1) // 2
         self.NH = self.A + self.T + 1                  # [mu | l | V]
-        self.NHP = _round_up(self.NH, 8)               # heads row stride (ldh)
-        self.HP = layer_size + 8                       # activations: H features | 1.0 | 7 zeros
+        self.NHP = _round_up(self.NH, 16)              # heads row stride (ldh): whole 16-wide MFMA tiles
+        self.HP = layer_size + 16                      # activations: H features | 1.0 | 15 zeros (K % 16 == 0)
         self.seg: Dict[str, Segment] = {}
         off = 0
         for name, shape in (("W1", (self.H, self.S)), ("b1", (self.H,)), ("g1", (self.H,)), ("be1", (self.H,)),
@@ -104,8 +104,8 @@ class NetLayout:
         # offsets inside a transition row
         self.off_u = self.S
         self.off_r = self.S + self.A
-        self.off_s2 = self.S + self.A + 1
-        self.off_d = 2 * self.S + self.A + 1
+        self.off_s2 = _lib.load().naf_replay_row_off_next_state(self.S, self.A)   # 16-B aligned
+        self.off_d = self.off_s2 + self.S
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         s = self.seg[name]
@@ -152,6 +152,12 @@ class Learner:
         self.p_mode = int(p_mode)
         self.world_size = int(world_size)
         self.pg = process_group
+        # NAF_FUSED=1: small GEMMs (K = state size, N = heads) folded into the BN / head kernels
+        # (csrc/fused_layers.hip): 16 -> 11 launches per update. Parity-green but, as measured on MI355X
+        # (benchmarks/kernel_probe.py), each fused kernel is still slower than the pair it replaces (its broadcast
+        # operand loads serialise in the vector-memory pipe), 11.0k vs 12.7k updates/s: off by default until the
+        # MFMA-tiled versions land.
+        self.fused = os.environ.get("NAF_FUSED") == "1" and self.lay.S <= 32
         lay, B, dev = self.lay, self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
         P, H, HP, NHP = lay.P, lay.H, lay.HP, lay.NHP
@@ -235,25 +241,34 @@ class Learner:
         lay = self.lay
         return rows.as_strided((2, self.B, lay.S), (lay.off_s2, lay.row_floats, 1), rows.storage_offset())
 
-    def forward_train(self, rows: torch.Tensor) -> None:
-        """Both networks' training-mode forward up to the heads pre-activations (Gh). Main net sees `state`,
-        target net sees `next_state` (naf_algorithm.py:194-202); both use batch statistics and both update their
-        running statistics (the reference never calls .eval() on the target)."""
+    def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True) -> None:
+        """Both networks' training-mode forward up to the second hidden activation A2 (and, with heads_gemm, the
+        heads pre-activations Gh). Main net sees `state`, target net sees `next_state` (naf_algorithm.py:194-202);
+        both use batch statistics and both update their running statistics (the reference never calls .eval() on the
+        target)."""
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H = lay.seg, lay.P, lay.H
         t2p = self.theta2.data_ptr()
         bnp = self.bn_stats.data_ptr()
-        torch.bmm(self._x2(rows), self.W1T2, out=self.G1)
-        check(self._f.naf_bn_relu_fwd_train(
-            ptr(self.G1), B * H, H, t2p + 4 * seg["b1"].offset, t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P,
-            bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]),
-            B, H, 2, BN_MOMENTUM, BN_EPS, st), "bn_relu_fwd_train(1)")
+        if self.fused:
+            # layer 1 (K = state size): GEMM + bias + BN + ReLU of both nets in one launch, straight off the rows
+            check(self._f.naf_linear_bn_relu_fwd_train(
+                rows.data_ptr(), lay.off_s2, lay.row_floats, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H,
+                ptr(self.save_mean[0]), ptr(self.save_invstd[0]), B, H, 2, BN_MOMENTUM, BN_EPS, st), "linear_bn_relu_fwd_train")
+        else:
+            torch.bmm(self._x2(rows), self.W1T2, out=self.G1)
+            check(self._f.naf_bn_relu_fwd_train(
+                ptr(self.G1), B * H, H, t2p + 4 * seg["b1"].offset, t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P,
+                bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]),
+                B, H, 2, BN_MOMENTUM, BN_EPS, st), "bn_relu_fwd_train(1)")
         torch.bmm(self.A1, self.W2T2, out=self.G2)
         check(self._f.naf_bn_relu_fwd_train(
             ptr(self.G2), B * H, H, t2p + 4 * seg["b2"].offset, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P,
             bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2), B * lay.HP, lay.HP, ptr(self.save_mean[1]),
             ptr(self.save_invstd[1]), B, H, 2, BN_MOMENTUM, BN_EPS, st), "bn_relu_fwd_train(2)")
-        torch.bmm(self.A2, self.WhT2, out=self.Gh)
+        if heads_gemm:
+            torch.bmm(self.A2, self.WhT2, out=self.Gh)
 
     def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None) -> None:
         """Enqueue one full NAFAgent.learn() (naf_algorithm.py:180-215) + soft_update (:217-226) on the minibatch
@@ -264,12 +279,21 @@ class Learner:
         f = self._f
         t2p, gp = self.theta2.data_ptr(), self.grad.data_ptr()
         rp = rows.data_ptr()
-        self.forward_train(rows)
-        # y = r + gamma * V'(s') ; Q ; loss ; d loss / d heads_pre — one launch
-        check(f.naf_head_fwd_bwd_mse(
-            ptr(self.Gh[0]), NHP, rp + 4 * lay.off_u, lay.row_floats, rp + 4 * lay.off_r, lay.row_floats,
-            self.Gh[1].data_ptr() + 4 * (lay.A + lay.T), NHP, self.gamma, ptr(self.q_out), ptr(self.dH),
-            ptr(loss_partials) if loss_partials is not None else None, B, lay.A, self.p_mode, st), "head_fwd_bwd_mse")
+        lp = ptr(loss_partials) if loss_partials is not None else None
+        if self.fused:
+            self.forward_train(rows, heads_gemm=False)
+            # heads GEMM (MFMA) + V'(s') + y = r + gamma V' ; Q ; loss ; d loss / d heads_pre — one launch
+            check(f.naf_heads_gemm_head_fwd_bwd_mse(
+                ptr(self.A2), B * HP, HP, HP, t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, lay.row_floats,
+                rp + 4 * lay.off_r, lay.row_floats, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
+                st), "heads_gemm_head_fwd_bwd_mse")
+        else:
+            self.forward_train(rows)
+            # y = r + gamma * V'(s') ; Q ; loss ; d loss / d heads_pre — one launch
+            check(f.naf_head_fwd_bwd_mse(
+                ptr(self.Gh[0]), NHP, rp + 4 * lay.off_u, lay.row_floats, rp + 4 * lay.off_r, lay.row_floats,
+                self.Gh[1].data_ptr() + 4 * (lay.A + lay.T), NHP, self.gamma, ptr(self.q_out), ptr(self.dH), lp, B, lay.A,
+                self.p_mode, st), "head_fwd_bwd_mse")
         # heads GEMM backward: weight+bias gradient in one GEMM thanks to the ones column
         fork = self.fork_weight_grads
         main = torch.cuda.current_stream()
@@ -280,11 +304,19 @@ class Learner:
                 torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
         else:
             torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
-        torch.mm(self.dH, self.Wh_main, out=self.dA2)
-        check(f.naf_bn_relu_bwd(
-            ptr(self.dA2), HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset, ptr(self.A2[0]), HP,
-            t2p + 4 * seg["g2"].offset, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.dZ2), H,
-            gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
+        if self.fused:
+            # dA2 = dH @ Wh (K = NHP) folded into the ReLU/BN backward of layer 2
+            check(f.naf_heads_bwd_bn_relu_bwd(
+                ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset,
+                ptr(self.A2[0]), HP, t2p + 4 * seg["g2"].offset, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]),
+                ptr(self.dZ2), H, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st),
+                "heads_bwd_bn_relu_bwd")
+        else:
+            torch.mm(self.dH, self.Wh_main, out=self.dA2)
+            check(f.naf_bn_relu_bwd(
+                ptr(self.dA2), HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset, ptr(self.A2[0]), HP,
+                t2p + 4 * seg["g2"].offset, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.dZ2), H,
+                gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
         if fork:
             self._ev_fork[1].record(main)
             self._side.wait_event(self._ev_fork[1])
@@ -293,11 +325,19 @@ class Learner:
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
         torch.mm(self.dZ2, self.W2_main, out=self.dA1)
-        check(f.naf_bn_relu_bwd(
-            ptr(self.dA1), H, ptr(self.G1[0]), H, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
-            t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.dZ1), H,
-            gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, B, H, st), "bn_relu_bwd(1)")
-        torch.mm(self.dZ1.t(), self._x2(rows)[0], out=self.gW1)
+        if self.fused:
+            # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written)
+            check(f.naf_bn_relu_bwd_wgrad(
+                ptr(self.dA1), H, rp, lay.row_floats, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                ptr(self.A1[0]), H, t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]),
+                gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, gp + 4 * seg["W1"].offset,
+                B, H, st), "bn_relu_bwd_wgrad")
+        else:
+            check(f.naf_bn_relu_bwd(
+                ptr(self.dA1), H, ptr(self.G1[0]), H, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
+                t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.dZ1), H,
+                gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, B, H, st), "bn_relu_bwd(1)")
+            torch.mm(self.dZ1.t(), self._x2(rows)[0], out=self.gW1)
         if fork:
             main.wait_stream(self._side)               # join: every gradient segment is complete
         if self.world_size > 1 or os.environ.get("NAF_FORCE_ALLREDUCE") == "1":

@@ -184,8 +184,8 @@ class NAFAgent:
         r[:, :S] = states.to(self.device, torch.float32)
         r[:, S:S + A] = actions.to(self.device, torch.float32)
         r[:, S + A] = rewards.to(self.device, torch.float32).view(B)
-        r[:, S + A + 1:2 * S + A + 1] = next_states.to(self.device, torch.float32)
-        r[:, 2 * S + A + 1] = dones.to(self.device, torch.float32).view(B)
+        r[:, lay.off_s2:lay.off_s2 + S] = next_states.to(self.device, torch.float32)
+        r[:, lay.off_d] = dones.to(self.device, torch.float32).view(B)
         L.learn_rows(r, self._learn_loss)
 
     def last_loss(self) -> float:

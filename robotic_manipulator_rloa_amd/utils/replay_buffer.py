@@ -47,6 +47,7 @@ class ReplayBuffer:
     def _allocate(self, S: int, A: int) -> None:
         self.S, self.A = S, A
         self.row_floats = self.lib.naf_replay_row_floats(S, A)
+        self.off_s2 = self.lib.naf_replay_row_off_next_state(S, A)
         self.rows = torch.zeros(self.buffer_size, self.row_floats, dtype=torch.float32, device=self.device)
         self.meta = torch.zeros(8, dtype=torch.int64, device=self.device)
         h = _lib.C.c_void_p()
@@ -84,8 +85,8 @@ class ReplayBuffer:
         row[:S] = state[0] if isinstance(state, tuple) else state     # same tuple guard as replay_buffer.py:58
         row[S:S + A] = action
         row[S + A] = reward
-        row[S + A + 1:2 * S + A + 1] = next_state
-        row[2 * S + A + 1] = done
+        row[self.off_s2:self.off_s2 + S] = next_state
+        row[self.off_s2 + S] = done
         self._pending += 1
         self._total_added += 1
         if self._pending == _STAGE_ROWS:

@@ -259,7 +259,8 @@ def test_device_env_kernel_matches_numpy_environment():
             s2, rew, done = env.step(act[e])
             np.testing.assert_allclose(r[e, :S], s_before, atol=3e-6)
             np.testing.assert_array_equal(r[e, S:S + A], act[e])
-            np.testing.assert_allclose(r[e, S + A + 1:2 * S + A + 1], s2, atol=3e-6)
-            np.testing.assert_allclose(r[e, S + A], rew, rtol=1e-4, atol=1e-5)
-            assert r[e, 2 * S + A + 1] == done
-            assert (r[e, 2 * S + A + 2:] == 0).all()
+            _, off_r, off_s2, off_d = O.row_offsets(S, A)
+            np.testing.assert_allclose(r[e, off_s2:off_s2 + S], s2, atol=3e-6)
+            np.testing.assert_allclose(r[e, off_r], rew, rtol=1e-4, atol=1e-5)
+            assert r[e, off_d] == done
+            assert (r[e, off_d + 1:] == 0).all() and (r[e, off_r + 1:off_s2] == 0).all()

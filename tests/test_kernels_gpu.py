@@ -385,3 +385,131 @@ def test_symbols_exported(lib):
     for name in _lib.EXPORTED_SYMBOLS:
         assert hasattr(lib, name)
     assert lib.naf_hip_arch() == b"gfx950"
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fused small-GEMM layers (csrc/fused_layers.hip)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,K,H", [(256, 21, 256), (64, 23, 256), (2, 10, 256), (2048, 23, 256), (100, 32, 40), (33, 5, 70)])
+def test_linear_bn_relu_fused_fwd_and_wgrad_vs_oracle(lib, B, K, H):
+    rng = np.random.default_rng(B + K)
+    nets, ldx, xoff = 2, 64, 28 if K <= 24 else 32
+    rows = rng.standard_normal((B, ldx)) * 3.0                  # columns beyond K hold other (finite) row fields
+    W = rng.standard_normal((nets, H, K)) / np.sqrt(K)
+    bias, gamma, beta = rng.standard_normal((nets, H)), rng.uniform(0.5, 1.5, (nets, H)), rng.standard_normal((nets, H))
+    rm, rv = rng.standard_normal((nets, H)), rng.uniform(0.5, 2, (nets, H))
+    P = H * K + 3 * H + 8
+    flat = np.zeros((nets, P), np.float32)
+    flat[:, :H * K], flat[:, H * K:H * K + H] = W.reshape(nets, -1), bias
+    flat[:, H * K + H:H * K + 2 * H], flat[:, H * K + 2 * H:H * K + 3 * H] = gamma, beta
+    fd, xd = dev(flat), dev(rows)
+    stats = dev(np.stack([rm, rv], 1))
+    out = torch.zeros(nets, B, H, device="cuda")
+    sm, si = torch.empty(nets, H, device="cuda"), torch.empty(nets, H, device="cuda")
+    fp = fd.data_ptr()
+    assert lib.naf_linear_bn_relu_fwd_train(xd.data_ptr(), xoff, ldx, K, fp, fp + 4 * H * K, fp + 4 * (H * K + H),
+                                            fp + 4 * (H * K + 2 * H), P, stats.data_ptr(), stats.data_ptr() + 4 * H, 2 * H,
+                                            out.data_ptr(), B * H, H, sm.data_ptr(), si.data_ptr(), B, H, nets, 0.1, 1e-5,
+                                            st()) == 0
+    tol = 5e-5 if B > 2 else 2e-3
+    caches = []
+    for n in range(nets):
+        x = rows[:, n * xoff:n * xoff + K]
+        z = x @ W[n].T + bias[n]
+        y, cache, nrm, nrv = O.bn_train_forward(z, gamma[n], beta[n], rm[n], rv[n])
+        caches.append((x, z, cache))
+        np.testing.assert_allclose(out[n].cpu().numpy(), np.maximum(y, 0), rtol=tol, atol=tol)
+        np.testing.assert_allclose(stats[n, 0].cpu().numpy(), nrm, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(stats[n, 1].cpu().numpy(), nrv, rtol=1e-4, atol=1e-6)
+    # backward + weight gradient of net 0
+    x, z, cache = caches[0]
+    d_out = rng.standard_normal((B, H))
+    mean, invstd = sm[0].cpu().numpy().astype(np.float64), si[0].cpu().numpy().astype(np.float64)
+    dy = d_out * (out[0].cpu().numpy() > 0)
+    dz, dgam, dbet = O.bn_train_backward(dy, {"xhat": (z - mean) * invstd, "invstd": invstd}, gamma[0])
+    dg, db, dbias = (torch.empty(H, device="cuda") for _ in range(3))
+    dW = torch.full((H, K), 9.0, device="cuda")
+    dod = dev(d_out)
+    assert lib.naf_bn_relu_bwd_wgrad(dod.data_ptr(), H, xd.data_ptr(), ldx, K, fp, fp + 4 * H * K, out.data_ptr(), H,
+                                     fp + 4 * (H * K + H), sm.data_ptr(), si.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                     dbias.data_ptr(), dW.data_ptr(), B, H, st()) == 0
+    gW = dz.T @ x
+    s = max(1.0, np.abs(gW).max())
+    np.testing.assert_allclose(dW.cpu().numpy(), gW, rtol=2e-3, atol=3e-5 * s)
+    np.testing.assert_allclose(dg.cpu().numpy(), dgam, rtol=1e-3, atol=1e-4 * np.abs(dgam).max())
+    np.testing.assert_allclose(db.cpu().numpy(), dbet, rtol=1e-3, atol=1e-4 * np.abs(dbet).max())
+    np.testing.assert_allclose(dbias.cpu().numpy(), 0, atol=1e-3 * max(1.0, np.abs(dz).max()))
+    # alignment contract
+    assert lib.naf_linear_bn_relu_fwd_train(xd.data_ptr() + 4, xoff, ldx, K, fp, fp, fp, fp, P, stats.data_ptr(), stats.data_ptr(),
+                                            0, out.data_ptr(), 0, H, sm.data_ptr(), si.data_ptr(), B, H, 1, 0.1, 1e-5, st()) == -1
+
+
+@pytest.mark.parametrize("B,NHP,H", [(256, 32, 256), (64, 48, 256), (2048, 48, 256), (33, 16, 70)])
+def test_heads_bwd_bn_relu_bwd_fused_vs_oracle(lib, B, NHP, H):
+    rng = np.random.default_rng(B + NHP)
+    ldw = H + 16
+    dH = rng.standard_normal((B, NHP))
+    Wh = rng.standard_normal((NHP, ldw)) * 0.1
+    g, bias = rng.standard_normal((B, H)) * 2, rng.standard_normal(H)
+    gamma = rng.uniform(0.5, 1.5, H)
+    z = g + bias
+    y, cache, _, _ = O.bn_train_forward(z, gamma, rng.standard_normal(H), np.zeros(H), np.ones(H))
+    outp = np.maximum(y, 0)
+    d_out = dH @ Wh[:, :H]
+    dz, dgam, dbet = O.bn_train_backward(d_out * (outp > 0), cache, gamma)
+    t = {k: dev(v) for k, v in dict(dH=dH, Wh=Wh, g=g, bias=bias, out=outp, gamma=gamma, mean=cache["mean"], inv=cache["invstd"]).items()}
+    dzd = torch.empty(B, H, device="cuda")
+    dg, db, dbias = (torch.empty(H, device="cuda") for _ in range(3))
+    assert lib.naf_heads_bwd_bn_relu_bwd(t["dH"].data_ptr(), NHP, t["Wh"].data_ptr(), ldw, t["g"].data_ptr(), H,
+                                         t["bias"].data_ptr(), t["out"].data_ptr(), H, t["gamma"].data_ptr(), t["mean"].data_ptr(),
+                                         t["inv"].data_ptr(), dzd.data_ptr(), H, dg.data_ptr(), db.data_ptr(), dbias.data_ptr(),
+                                         B, H, st()) == 0
+    s = max(1.0, np.abs(dz).max())
+    np.testing.assert_allclose(dzd.cpu().numpy(), dz, rtol=1e-3, atol=3e-5 * s)
+    np.testing.assert_allclose(dg.cpu().numpy(), dgam, rtol=1e-3, atol=1e-4 * np.abs(dgam).max())
+    np.testing.assert_allclose(db.cpu().numpy(), dbet, rtol=1e-3, atol=1e-4 * np.abs(dbet).max())
+    assert lib.naf_heads_bwd_bn_relu_bwd(t["dH"].data_ptr(), 40, t["Wh"].data_ptr(), ldw, t["g"].data_ptr(), H, None,
+                                         t["out"].data_ptr(), H, t["gamma"].data_ptr(), t["mean"].data_ptr(), t["inv"].data_ptr(),
+                                         dzd.data_ptr(), H, dg.data_ptr(), db.data_ptr(), None, B, H, st()) == -1
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("B,A", [(256, 6), (2048, 7), (37, 3), (64, 8)])
+def test_heads_gemm_head_mfma_fused_vs_oracle(lib, mode, B, A):
+    """MFMA heads GEMM + target V' GEMV + head fwd/TD/MSE/bwd in one launch, against float64 numpy."""
+    rng = np.random.default_rng(B + A + mode)
+    T = A * (A + 1) // 2
+    NH = A + T + 1
+    NHP = (NH + 15) // 16 * 16
+    H, K = 256, 272
+    a2 = np.zeros((2, B, K))
+    a2[:, :, :H] = np.maximum(rng.standard_normal((2, B, H)), 0)
+    a2[:, :, H] = 1.0
+    Wh = np.zeros((2, NHP, K))
+    Wh[:, :NH, :H + 1] = rng.standard_normal((2, NH, H + 1)) / 16.0
+    u = np.trunc(rng.uniform(-1.5, 1.5, (B, A)))
+    r = rng.standard_normal(B)
+    gamma = 0.99
+    heads = a2[0] @ Wh[0].T
+    vnext = a2[1] @ Wh[1][A + T]
+    f = O.head_forward(heads[:, :A], heads[:, A:A + T], heads[:, A + T], u, mode)
+    y = r + gamma * vnext
+    dq = 2 * (f["Q"] - y) / B
+    d_mu, d_l, d_V = O.head_backward(heads[:, :A], heads[:, A:A + T], u, dq, mode)
+    a2d, Whd, ud, rd = dev(a2), dev(Wh), dev(u), dev(r)
+    ho = torch.empty(B, NHP, device="cuda")
+    q = torch.empty(B, device="cuda")
+    dh = torch.empty(B, NHP, device="cuda")
+    lp = torch.zeros((B + 31) // 32, device="cuda")
+    assert lib.naf_heads_gemm_head_fwd_bwd_mse(a2d.data_ptr(), B * K, K, K, Whd.data_ptr(), NHP * K, K, NHP, ud.data_ptr(), A,
+                                               rd.data_ptr(), 1, gamma, ho.data_ptr(), q.data_ptr(), dh.data_ptr(), lp.data_ptr(),
+                                               B, A, mode, st()) == 0
+    np.testing.assert_allclose(ho.cpu().numpy(), heads, rtol=1e-4, atol=2e-5)              # the MFMA GEMM itself
+    np.testing.assert_allclose(q.cpu().numpy(), f["Q"], rtol=2e-4, atol=2e-4)
+    dhn = dh.cpu().numpy()
+    scale = np.abs(dq).max() * 10
+    np.testing.assert_allclose(dhn[:, :A], d_mu, rtol=2e-3, atol=1e-5 * scale + 1e-7)
+    np.testing.assert_allclose(dhn[:, A:A + T], d_l, rtol=2e-3, atol=1e-5 * scale + 1e-7)
+    np.testing.assert_allclose(dhn[:, A + T], d_V, rtol=1e-3, atol=1e-5 * scale)
+    assert (dhn[:, NH:] == 0).all()
+    np.testing.assert_allclose(lp.sum().item(), ((f["Q"] - y) ** 2).mean(), rtol=5e-4)

@@ -32,8 +32,12 @@ def current_sd(L, net):
     return sd
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("tag", ["kuka", "panda"])
-def test_learn_vs_reference_golden_g3(tag):
+def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
+    """fused=1: the small-GEMM-folded kernels of csrc/fused_layers.hip (MFMA heads GEMM etc.) replace 5 of the torch
+    GEMMs; both paths must match the reference."""
+    monkeypatch.setenv("NAF_FUSED", fused)
     from synth_data import make_transitions
     g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
     S, A, B = [int(x) for x in g[f"{tag}/dims"]]
@@ -79,9 +83,11 @@ def test_learn_vs_reference_golden_g3(tag):
     assert (L.grad[mask] == 0).all() and (L.theta2[0][mask] == 0).all() and (L.adam_v[mask] == 0).all()
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64)])
-def test_learn_vs_oracle_both_modes(p_mode, S, A, B):
+def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
+    monkeypatch.setenv("NAF_FUSED", fused)
     """20 updates against the f32 numpy oracle (Hadamard = reference semantics; matmul = textbook NAF)."""
     from synth_data import make_transitions
     g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
@@ -211,7 +217,7 @@ def test_device_env_loop_fills_replay_and_trains():
     assert torch.equal(theta0, L.theta2)                                    # acting does not touch the weights
     assert len(buf) == 160 and int(buf.meta[1].item()) == 160 and int(buf.meta[2].item()) == 160
     rows = buf.rows[:160].cpu().numpy()
-    s, a, r, s2, d = rows[:, :S], rows[:, S:S + A], rows[:, S + A], rows[:, S + A + 1:2 * S + A + 1], rows[:, 2 * S + A + 1]
+    s, a, r, s2, d = O.unpack_rows(rows, S, A)
     assert np.abs(a).max() <= 1.0 and np.isfinite(rows).all()
     np.testing.assert_allclose(s2[:, :A], s[:, :A] + a / 240.0, atol=1e-6)      # velocity control for one 1/240 s tick
     np.testing.assert_allclose(s2[:, A:2 * A], a, atol=0)                        # joint velocities = commanded
@@ -221,7 +227,7 @@ def test_device_env_loop_fills_replay_and_trains():
     np.testing.assert_allclose(r[plain], -(dist[plain] - 0.05), atol=1e-5)      # environment.py:366-371
     # consecutive transitions of env 0 chain: s2 of step t is s of step t+1 (no episode end within 10 frames)
     e0 = rows[0::E]
-    np.testing.assert_array_equal(e0[1:, :S], e0[:-1, S + A + 1:2 * S + A + 1])
+    np.testing.assert_array_equal(e0[1:, :S], O.unpack_rows(e0[:-1], S, A)[3])
     chunk = TrainChunk(L, buf, E)
     chunk.run()
     torch.cuda.synchronize()
