@@ -46,3 +46,8 @@ tests["gather 64xB rows"] = lambda: buf.gather_rows(idx, out, 64*B)
 L.step_dev.fill_(1)
 for k, f in tests.items():
     print(f"{k:28s} {timeit(f):8.2f} us")
+names = {0: "32x32", 1: "32x16", 2: "32x8", 3: "16x16", 4: "16x32", 5: "64x8", 6: "64x16", 7: "16x64", 8: "8x32", 9: "8x64", 10: "8x128", 11: "4x64"}
+for cfg, nm in names.items():
+    lib.naf_debug_set(0, cfg)
+    print(f"bn tile {nm:6s} fwd {timeit(tests['bn_relu_fwd_train x2nets']):6.2f} us   bwd {timeit(tests['bn_relu_bwd']):6.2f} us")
+lib.naf_debug_set(0, 0)

@@ -52,6 +52,8 @@ typedef struct naf_replay naf_replay_t;
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
+/* development knob (tile-shape selection for A/B timing, benchmarks/kernel_probe.py); not part of the data path */
+int naf_debug_set(int key, int value);
 
 /* ---- replay buffer: HBM ring of transition rows ------------------------------------------ */
 /* replaces ReplayBuffer.__init__ (utils/replay_buffer.py:16-30): deque(maxlen=buffer_size) */

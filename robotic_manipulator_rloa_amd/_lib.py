@@ -63,6 +63,7 @@ _vp, _i, _f, _u64, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_s
 _PROTOS = {
     "naf_hip_abi_version": [],
     "naf_hip_arch": [],
+    "naf_debug_set": [_i, _i],
     "naf_replay_row_floats": [_i, _i],
     "naf_replay_row_off_next_state": [_i, _i],
     "naf_replay_create": [_u64, _i, _i, _vp, _vp, C.POINTER(_vp)],

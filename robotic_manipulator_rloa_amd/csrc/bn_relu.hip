@@ -12,27 +12,58 @@
 #include "common.h"
 #include "../../include/naf_hip.h"
 
-#define BN_TX 32
-#define BN_TY 32
+// tile shape: TX feature columns x TY row phases per workgroup (TX*TY threads, TX <= 64, TX*TY % 64 == 0).
+// Column sums: lanes of a wave that share a column (lane = phase*TX + tx) fold by xor shuffles, the TX*TY/64 wave
+// results meet in LDS. Fixed order -> bitwise reproducible.
+template <int BN_TX, int BN_TY>
+__device__ static inline void bn_col_reduce2(float pa, float pb, float (*red)[BN_TX + 1], float (*red2)[BN_TX + 1], int tx,
+                                             int ty, float* oa, float* ob) {
+    constexpr int NW = BN_TX * BN_TY / 64;
+#pragma unroll
+    for (int o = BN_TX; o < 64; o <<= 1) {
+        pa += __shfl_xor(pa, o);
+        pb += __shfl_xor(pb, o);
+    }
+    const int tid = ty * BN_TX + tx;
+    __syncthreads();  // previous use of red/red2 is over
+    if ((tid & 63) < BN_TX) {
+        red[tid >> 6][tx] = pa;
+        red2[tid >> 6][tx] = pb;
+    }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        sa += red[k][tx];
+        sb += red2[k][tx];
+    }
+    *oa = sa;
+    *ob = sb;
+}
 
+template <int BN_TX, int BN_TY>
 __device__ static inline float bn_col_reduce(float part, float (*red)[BN_TX + 1], int tx, int ty) {
-    __syncthreads();  // previous use of `red` is over
-    red[ty][tx] = part;
+    constexpr int NW = BN_TX * BN_TY / 64;
+#pragma unroll
+    for (int o = BN_TX; o < 64; o <<= 1) part += __shfl_xor(part, o);
+    const int tid = ty * BN_TX + tx;
+    __syncthreads();
+    if ((tid & 63) < BN_TX) red[tid >> 6][tx] = part;
     __syncthreads();
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < BN_TY; ++k) s += red[k][tx];
+    for (int k = 0; k < NW; ++k) s += red[k][tx];
     return s;
 }
 
-template <int RPT>
+template <int RPT, int BN_TX, int BN_TY>
 __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
     const float* __restrict__ g, int64_t g_net_stride, int ldg, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, int64_t param_net_stride,
     float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out,
     int64_t out_net_stride, int ldo, float* __restrict__ save_mean, float* __restrict__ save_invstd, int B, int H,
     float momentum, float eps) {
-    __shared__ float red[BN_TY][BN_TX + 1];
+    __shared__ float red[BN_TX * BN_TY / 64][BN_TX + 1];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int col = blockIdx.x * BN_TX + tx;
     const int net = blockIdx.y;
@@ -41,6 +72,12 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
     float* oz = out + net * out_net_stride;
     const int64_t po = net * param_net_stride;
     const float b = (bias && col_on) ? bias[po + col] : 0.f;
+    // every per-column scalar is requested up front: its latency hides under the matrix loads below
+    const float gm = col_on ? gamma[po + col] : 0.f;
+    const float bt = col_on ? beta[po + col] : 0.f;
+    const int64_t so = net * stat_net_stride + col;
+    const float rm_old = (ty == 0 && col_on) ? running_mean[so] : 0.f;
+    const float rv_old = (ty == 0 && col_on) ? running_var[so] : 0.f;
 
     float x[RPT];
     float sum = 0.f;
@@ -50,7 +87,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
         x[k] = (col_on && row < B) ? gz[(int64_t)row * ldg + col] + b : 0.f;
         sum += x[k];
     }
-    const float mean = bn_col_reduce(sum, red, tx, ty) / (float)B;
+    const float mean = bn_col_reduce<BN_TX, BN_TY>(sum, red, tx, ty) / (float)B;
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -58,10 +95,8 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
         float dlt = (row < B) ? x[k] - mean : 0.f;
         ss += dlt * dlt;
     }
-    const float var = bn_col_reduce(ss, red, tx, ty) / (float)B;  // biased: what normalises
+    const float var = bn_col_reduce<BN_TX, BN_TY>(ss, red, tx, ty) / (float)B;  // biased: what normalises
     const float invstd = 1.0f / sqrtf(var + eps);
-    const float gm = col_on ? gamma[po + col] : 0.f;
-    const float bt = col_on ? beta[po + col] : 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         int row = ty + k * BN_TY;
@@ -71,22 +106,22 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
         }
     }
     if (ty == 0 && col_on) {
-        const int64_t so = net * stat_net_stride + col;
         const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-        running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
-        running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+        running_mean[so] = (1.0f - momentum) * rm_old + momentum * mean;
+        running_var[so] = (1.0f - momentum) * rv_old + momentum * unbiased;
         save_mean[(int64_t)net * H + col] = mean;
         save_invstd[(int64_t)net * H + col] = invstd;
     }
 }
 
-template <int RPT>
+template <int RPT, int BN_TX, int BN_TY>
 __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
     const float* __restrict__ d_out, int ld_dout, const float* __restrict__ g, int ldg, const float* __restrict__ bias,
     const float* __restrict__ out, int ldo, const float* __restrict__ gamma, const float* __restrict__ save_mean,
     const float* __restrict__ save_invstd, float* __restrict__ d_z, int ldd, float* __restrict__ d_gamma,
     float* __restrict__ d_beta, float* __restrict__ d_bias, int B, int H) {
-    __shared__ float red[BN_TY][BN_TX + 1];
+    __shared__ float red[BN_TX * BN_TY / 64][BN_TX + 1];
+    __shared__ float red2[BN_TX * BN_TY / 64][BN_TX + 1];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int col = blockIdx.x * BN_TX + tx;
     const bool col_on = col < H;
@@ -109,8 +144,8 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
         s_dy += dy[k];
         s_dyxh += dy[k] * xh[k];
     }
-    const float dbeta = bn_col_reduce(s_dy, red, tx, ty);
-    const float dgamma = bn_col_reduce(s_dyxh, red, tx, ty);
+    float dbeta, dgamma;
+    bn_col_reduce2<BN_TX, BN_TY>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
     const float invB = 1.0f / (float)B;
     const float k1 = gm * invstd;
     float s_dz = 0.f;
@@ -123,7 +158,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
             s_dz += dz;
         }
     }
-    const float dbias = bn_col_reduce(s_dz, red, tx, ty);  // Linear bias under a train-mode BN: ~0 up to rounding
+    const float dbias = bn_col_reduce<BN_TX, BN_TY>(s_dz, red, tx, ty);  // Linear bias under a train-mode BN: ~0 up to rounding
     if (ty == 0 && col_on) {
         d_gamma[col] = dgamma;
         d_beta[col] = dbeta;
@@ -148,18 +183,45 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_eval_kernel(const float* __re
     }
 }
 
-#define BN_DISPATCH(KERNEL, ...)                                                       \
-    do {                                                                               \
-        int rpt = (B + BN_TY - 1) / BN_TY;                                             \
-        if (rpt <= 2) KERNEL<2><<<grid, block, 0, st>>>(__VA_ARGS__);                  \
-        else if (rpt <= 4) KERNEL<4><<<grid, block, 0, st>>>(__VA_ARGS__);             \
-        else if (rpt <= 8) KERNEL<8><<<grid, block, 0, st>>>(__VA_ARGS__);             \
-        else if (rpt <= 16) KERNEL<16><<<grid, block, 0, st>>>(__VA_ARGS__);           \
-        else if (rpt <= 32) KERNEL<32><<<grid, block, 0, st>>>(__VA_ARGS__);           \
-        else KERNEL<64><<<grid, block, 0, st>>>(__VA_ARGS__);                          \
+// Tile shapes to choose from (dev knob naf_debug_set(0, id); the default was picked with benchmarks/kernel_probe.py)
+static int g_bn_tile = 9;   // 8 columns x 64 row phases: fwd 3.3 us / bwd 3.7 us per launch at B=256 (32x32: 4.5 / 5.6)
+extern "C" int naf_debug_set(int key, int value) {
+    if (key == 0) g_bn_tile = value;
+    return NAF_OK;
+}
+
+#define BN_LAUNCH_RPT(KERNEL, TXv, TYv, ...)                                                               \
+    do {                                                                                                   \
+        dim3 grid((H + TXv - 1) / TXv, nets_), block(TXv, TYv);                                            \
+        int rpt = (B + TYv - 1) / TYv;                                                                     \
+        if (rpt <= 2) KERNEL<2, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                            \
+        else if (rpt <= 4) KERNEL<4, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                       \
+        else if (rpt <= 8) KERNEL<8, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                       \
+        else if (rpt <= 16) KERNEL<16, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                     \
+        else if (rpt <= 32) KERNEL<32, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                     \
+        else if (rpt <= 64) KERNEL<64, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                     \
+        else return NAF_ERR_ARG;                                                                           \
     } while (0)
 
-#define BN_MAX_B (BN_TY * 64)
+#define BN_DISPATCH(KERNEL, ...)                                                                           \
+    do {                                                                                                   \
+        switch (g_bn_tile) {                                                                               \
+            case 1: BN_LAUNCH_RPT(KERNEL, 32, 16, __VA_ARGS__); break;                                     \
+            case 2: BN_LAUNCH_RPT(KERNEL, 32, 8, __VA_ARGS__); break;                                      \
+            case 3: BN_LAUNCH_RPT(KERNEL, 16, 16, __VA_ARGS__); break;                                     \
+            case 4: BN_LAUNCH_RPT(KERNEL, 16, 32, __VA_ARGS__); break;                                     \
+            case 5: BN_LAUNCH_RPT(KERNEL, 64, 8, __VA_ARGS__); break;                                      \
+            case 6: BN_LAUNCH_RPT(KERNEL, 64, 16, __VA_ARGS__); break;                                     \
+            case 7: BN_LAUNCH_RPT(KERNEL, 16, 64, __VA_ARGS__); break;                                     \
+            case 8: BN_LAUNCH_RPT(KERNEL, 8, 32, __VA_ARGS__); break;                                      \
+            case 9: BN_LAUNCH_RPT(KERNEL, 8, 64, __VA_ARGS__); break;                                      \
+            case 10: BN_LAUNCH_RPT(KERNEL, 8, 128, __VA_ARGS__); break;                                    \
+            case 11: BN_LAUNCH_RPT(KERNEL, 4, 64, __VA_ARGS__); break;                                     \
+            default: BN_LAUNCH_RPT(KERNEL, 32, 32, __VA_ARGS__); break;                                    \
+        }                                                                                                  \
+    } while (0)
+
+#define BN_MAX_B (64 * 64)   // default tile: 64 row phases x up to 64 rows per thread
 
 extern "C" int naf_bn_relu_fwd_train(const float* g, int64_t g_net_stride, int ldg, const float* bias,
                                      const float* gamma, const float* beta, int64_t param_net_stride,
@@ -169,7 +231,7 @@ extern "C" int naf_bn_relu_fwd_train(const float* g, int64_t g_net_stride, int l
     if (!g || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd) return NAF_ERR_ARG;
     if (B <= 0 || B > BN_MAX_B || H <= 0 || nets <= 0 || ldg < H || ldo < H) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((H + BN_TX - 1) / BN_TX, nets), block(BN_TX, BN_TY);
+    const int nets_ = nets;
     BN_DISPATCH(bn_relu_fwd_train_kernel, g, g_net_stride, ldg, bias, gamma, beta, param_net_stride, running_mean,
                 running_var, stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, B, H, momentum, eps);
     NAF_CHECK_LAUNCH();
@@ -183,7 +245,7 @@ extern "C" int naf_bn_relu_bwd(const float* d_out, int ld_dout, const float* g, 
     if (!d_out || !g || !out || !gamma || !save_mean || !save_invstd || !d_z || !d_gamma || !d_beta) return NAF_ERR_ARG;
     if (B <= 0 || B > BN_MAX_B || H <= 0 || ld_dout < H || ldg < H || ldo < H || ldd < H) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((H + BN_TX - 1) / BN_TX, 1), block(BN_TX, BN_TY);
+    const int nets_ = 1;
     BN_DISPATCH(bn_relu_bwd_kernel, d_out, ld_dout, g, ldg, bias, out, ldo, gamma, save_mean, save_invstd, d_z, ldd,
                 d_gamma, d_beta, d_bias, B, H);
     NAF_CHECK_LAUNCH();

@@ -16,6 +16,7 @@
 __global__ __launch_bounds__(OPT_THREADS) void grad_norm_partials_kernel(const float* __restrict__ g, size_t n,
                                                                          float* __restrict__ partials,
                                                                          int32_t* step_dev) {
+    // (the optimizer step count is advanced here, one launch ahead of its only reader)
     __shared__ float red[OPT_THREADS / 64];
     const size_t base = (size_t)blockIdx.x * NAF_NORM_CHUNK;
     float acc = 0.f;
@@ -55,6 +56,17 @@ extern "C" int naf_grad_norm_partials(const float* g, size_t n, float* partials,
     return NAF_OK;
 }
 
+// b^t for integer t >= 0 by square-and-multiply in double: ~2 log2(t) multiplies instead of the libm pow() call
+__device__ static inline double ipow(double b, int t) {
+    double r = 1.0;
+    while (t > 0) {
+        if (t & 1) r *= b;
+        b *= b;
+        t >>= 1;
+    }
+    return r;
+}
+
 struct AdamScalars {
     float clip_scale;   // inv_world * min(1, max_norm / (total_norm + 1e-6))
     float step_size;    // lr / (1 - beta1^t)
@@ -80,6 +92,18 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
                                                                   const int32_t* __restrict__ step_dev, float inv_world,
                                                                   size_t n) {
     __shared__ AdamScalars sh;
+    const size_t n4 = n / 4;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // first trip's operands are requested BEFORE the scalar prologue: the 21-partial sum, the sqrt and the two
+    // double-precision powers of thread 0 then run under the latency of these loads instead of in front of it
+    float4 th0 = make_float4(0.f, 0.f, 0.f, 0.f), gr0 = th0, mm0 = th0, vv0 = th0, tg0 = th0;
+    if (i0 < n4) {
+        th0 = ((float4*)theta)[i0];
+        gr0 = ((const float4*)g)[i0];
+        mm0 = ((float4*)m)[i0];
+        vv0 = ((float4*)v)[i0];
+        if (target) tg0 = ((float4*)target)[i0];
+    }
     if (threadIdx.x == 0) {
         // every workgroup re-derives the same scalars from the same partials in the same order
         float s = 0.f;
@@ -88,22 +112,25 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
         float clip = max_norm / (total_norm + 1e-6f);
         clip = clip > 1.0f ? 1.0f : clip;
         const int t = *step_dev;
-        const double bc1 = 1.0 - pow((double)beta1, (double)t);
-        const double bc2 = 1.0 - pow((double)beta2, (double)t);
+        const double bc1 = 1.0 - ipow((double)beta1, t);
+        const double bc2 = 1.0 - ipow((double)beta2, t);
         sh.clip_scale = clip * inv_world;
         sh.step_size = (float)((double)lr / bc1);
         sh.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     }
     __syncthreads();
     const AdamScalars sc = sh;
-    const size_t n4 = n / 4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 th = ((float4*)theta)[i];
-        const float4 gr = ((const float4*)g)[i];
-        float4 mm = ((float4*)m)[i];
-        float4 vv = ((float4*)v)[i];
-        float4 tg = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (target) tg = ((float4*)target)[i];
+    for (size_t i = i0; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 th, gr, mm, vv, tg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i == i0) {
+            th = th0; gr = gr0; mm = mm0; vv = vv0; tg = tg0;
+        } else {
+            th = ((float4*)theta)[i];
+            gr = ((const float4*)g)[i];
+            mm = ((float4*)m)[i];
+            vv = ((float4*)v)[i];
+            if (target) tg = ((float4*)target)[i];
+        }
         adam_one(th.x, gr.x, mm.x, vv.x, target ? &tg.x : nullptr, sc, beta1, beta2, eps, tau, one_minus_tau);
         adam_one(th.y, gr.y, mm.y, vv.y, target ? &tg.y : nullptr, sc, beta1, beta2, eps, tau, one_minus_tau);
         adam_one(th.z, gr.z, mm.z, vv.z, target ? &tg.z : nullptr, sc, beta1, beta2, eps, tau, one_minus_tau);
