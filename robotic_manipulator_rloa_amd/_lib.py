@@ -15,7 +15,7 @@ from typing import Optional
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
 SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "optim.hip", "synth_env.hip"]
-HEADERS = ["common.h", "head_body.h", os.path.join("..", "..", "include", "naf_hip.h")]
+HEADERS = ["common.h", "head_body.h", "bn_tile.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
 ACTION_TRUNC_INT, ACTION_FLOAT = 0, 1

@@ -1,0 +1,48 @@
+// Column-ownership tile shared by bn_relu.hip and fused_layers.hip.
+#pragma once
+#include "common.h"
+
+// tile shape: TX feature columns x TY row phases per workgroup (TX*TY threads, TX <= 64, TX*TY % 64 == 0).
+// Column sums: lanes of a wave that share a column (lane = phase*TX + tx) fold by xor shuffles, the TX*TY/64 wave
+// results meet in LDS. Fixed order -> bitwise reproducible.
+template <int BN_TX, int BN_TY>
+__device__ static inline void bn_col_reduce2(float pa, float pb, float (*red)[BN_TX + 1], float (*red2)[BN_TX + 1], int tx,
+                                             int ty, float* oa, float* ob) {
+    constexpr int NW = BN_TX * BN_TY / 64;
+#pragma unroll
+    for (int o = BN_TX; o < 64; o <<= 1) {
+        pa += __shfl_xor(pa, o);
+        pb += __shfl_xor(pb, o);
+    }
+    const int tid = ty * BN_TX + tx;
+    __syncthreads();  // previous use of red/red2 is over
+    if ((tid & 63) < BN_TX) {
+        red[tid >> 6][tx] = pa;
+        red2[tid >> 6][tx] = pb;
+    }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        sa += red[k][tx];
+        sb += red2[k][tx];
+    }
+    *oa = sa;
+    *ob = sb;
+}
+
+template <int BN_TX, int BN_TY>
+__device__ static inline float bn_col_reduce(float part, float (*red)[BN_TX + 1], int tx, int ty) {
+    constexpr int NW = BN_TX * BN_TY / 64;
+#pragma unroll
+    for (int o = BN_TX; o < 64; o <<= 1) part += __shfl_xor(part, o);
+    const int tid = ty * BN_TX + tx;
+    __syncthreads();
+    if ((tid & 63) < BN_TX) red[tid >> 6][tx] = part;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) s += red[k][tx];
+    return s;
+}
+

@@ -10,43 +10,41 @@
 // Reference lines replaced: naf_neural_network.py:76,81-115 (forward), their autograd, naf_algorithm.py:199-208.
 // Tile ownership as in bn_relu.hip: a workgroup owns 32 feature columns x ALL batch rows (32 x 32 threads).
 #include "head_body.h"
+#include "bn_tile.h"
 
-#define BN_TX 32
-#define BN_TY 32
+// tile of the column-ownership kernels: 8 feature columns x 64 row phases (512 threads), RPT = ceil(B/64) rows per
+// thread. A wave = 8 row phases x 8 columns, so a broadcast row load (all 8 column lanes read the same 16 B of an
+// input row) still covers 8 distinct rows per instruction.
+#define FT_TX 8
+#define FT_TY 64
+#define FT_THREADS (FT_TX * FT_TY)
+#define FT_NW (FT_THREADS / 64)
 #define MAX_K4 8    // small-K layers: K <= 32 (8 float4 per input row)
 
-__device__ static inline float col_reduce(float part, float (*red)[BN_TX + 1], int tx, int ty) {
-    __syncthreads();
-    red[ty][tx] = part;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < BN_TY; ++k) s += red[k][tx];
-    return s;
-}
-
 // z[row] = b + sum_k x[row][k] * w[k], k ascending; x rows are 16-B aligned, read as K4 float4 (columns >= K hit
-// zero weights). All 32 lanes of a row-phase read the same addresses: one broadcast transaction per load.
+// zero weights)
 template <int K4>
 __device__ static inline float small_k_dot(const float* __restrict__ xrow, const float* w, float b) {
+    float4 v[K4];
+#pragma unroll
+    for (int q = 0; q < K4; ++q) v[q] = ((const float4*)xrow)[q];
     float z = b;
 #pragma unroll
     for (int q = 0; q < K4; ++q) {
-        const float4 v = ((const float4*)xrow)[q];
-        z += v.x * w[4 * q + 0];
-        z += v.y * w[4 * q + 1];
-        z += v.z * w[4 * q + 2];
-        z += v.w * w[4 * q + 3];
+        z += v[q].x * w[4 * q + 0];
+        z += v[q].y * w[4 * q + 1];
+        z += v[q].z * w[4 * q + 2];
+        z += v[q].w * w[4 * q + 3];
     }
     return z;
 }
 
-// stage this workgroup's 32 x K weight tile (contiguous 32*K floats of a row-major [H][K] matrix) and return the
+// stage this workgroup's TX x K weight tile (contiguous TX*K floats of a row-major [H][K] matrix) and return the
 // calling thread's column in registers, zero-padded to 4*K4
 template <int K4>
 __device__ static inline void load_w_column(const float* __restrict__ Wn, int col0, int H, int K, float (*sW)[4 * MAX_K4 + 1],
                                             int tid, int tx, float* w) {
-    for (int e = tid; e < BN_TX * 4 * K4; e += BN_TX * BN_TY) {
+    for (int e = tid; e < FT_TX * 4 * K4; e += FT_THREADS) {
         int c = e / (4 * K4), k = e - c * (4 * K4);
         sW[c][k] = (k < K && col0 + c < H) ? Wn[(int64_t)(col0 + c) * K + k] : 0.f;
     }
@@ -59,57 +57,59 @@ __device__ static inline void load_w_column(const float* __restrict__ Wn, int co
 // F1: Linear(K small) + BatchNorm1d(train) + ReLU for `nets` networks
 // ------------------------------------------------------------------------------------------------------------
 template <int RPT, int K4>
-__global__ __launch_bounds__(BN_TX* BN_TY) void linear_bn_relu_fwd_train_kernel(
+__global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
     const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
     int64_t param_net_stride, float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride,
     float* __restrict__ out, int64_t out_net_stride, int ldo, float* __restrict__ save_mean,
     float* __restrict__ save_invstd, int B, int H, float momentum, float eps) {
-    __shared__ float red[BN_TY][BN_TX + 1];
-    __shared__ float sW[BN_TX][4 * MAX_K4 + 1];
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * BN_TX + tx;
-    const int col0 = blockIdx.x * BN_TX, col = col0 + tx, net = blockIdx.y;
+    __shared__ float red[FT_NW][FT_TX + 1];
+    __shared__ float sW[FT_TX][4 * MAX_K4 + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
+    const int col0 = blockIdx.x * FT_TX, col = col0 + tx, net = blockIdx.y;
     const bool col_on = col < H;
     const int64_t po = net * param_net_stride;
     const float* xn = x + net * x_net_stride;
     float* oz = out + net * out_net_stride;
+    const float b = col_on ? bias[po + col] : 0.f;
+    const float gm = col_on ? gamma[po + col] : 0.f;
+    const float bt = col_on ? beta[po + col] : 0.f;
+    const int64_t so = net * stat_net_stride + col;
+    const float rm_old = (ty == 0 && col_on) ? running_mean[so] : 0.f;
+    const float rv_old = (ty == 0 && col_on) ? running_var[so] : 0.f;
     float w[4 * K4];
     load_w_column<K4>(W + po, col0, H, K, sW, tid, tx, w);
-    const float b = col_on ? bias[po + col] : 0.f;
 
     float z[RPT];
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * BN_TY;
+        int row = ty + k * FT_TY;
         z[k] = (row < B) ? small_k_dot<K4>(xn + (int64_t)row * ldx, w, b) : 0.f;
         sum += z[k];
     }
-    const float mean = col_reduce(sum, red, tx, ty) / (float)B;
+    const float mean = bn_col_reduce<FT_TX, FT_TY>(sum, red, tx, ty) / (float)B;
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * BN_TY;
+        int row = ty + k * FT_TY;
         float dlt = (row < B) ? z[k] - mean : 0.f;
         ss += dlt * dlt;
     }
-    const float var = col_reduce(ss, red, tx, ty) / (float)B;
+    const float var = bn_col_reduce<FT_TX, FT_TY>(ss, red, tx, ty) / (float)B;
     const float invstd = 1.0f / sqrtf(var + eps);
-    const float gm = col_on ? gamma[po + col] : 0.f;
-    const float bt = col_on ? beta[po + col] : 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * BN_TY;
+        int row = ty + k * FT_TY;
         if (col_on && row < B) {
             float y = (z[k] - mean) * invstd * gm + bt;
             oz[(int64_t)row * ldo + col] = y > 0.f ? y : 0.f;
         }
     }
     if (ty == 0 && col_on) {
-        const int64_t so = net * stat_net_stride + col;
         const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-        running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
-        running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+        running_mean[so] = (1.0f - momentum) * rm_old + momentum * mean;
+        running_var[so] = (1.0f - momentum) * rv_old + momentum * unbiased;
         save_mean[(int64_t)net * H + col] = mean;
         save_invstd[(int64_t)net * H + col] = invstd;
     }
@@ -120,32 +120,42 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void linear_bn_relu_fwd_train_kernel(
 // z is recomputed from X and W exactly as the forward computed it.
 // ------------------------------------------------------------------------------------------------------------
 template <int RPT, int K4>
-__global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_wgrad_kernel(
+__global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     const float* __restrict__ d_out, int ld_dout, const float* __restrict__ x, int ldx, int K,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ out, int ldo,
     const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
     float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_W, int B,
     int H) {
-    __shared__ float red[BN_TY][BN_TX + 1];
-    __shared__ float sW[BN_TX][4 * MAX_K4 + 1];
-    __shared__ float sG[BN_TY / 2][BN_TX][4 * MAX_K4 + 1];   // per-wave partial dW tiles
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * BN_TX + tx;
-    const int col0 = blockIdx.x * BN_TX, col = col0 + tx;
+    __shared__ float red[FT_NW][FT_TX + 1];
+    __shared__ float red2[FT_NW][FT_TX + 1];
+    __shared__ float sW[FT_TX][4 * MAX_K4 + 1];
+    __shared__ float sG[FT_NW][FT_TX][4 * MAX_K4 + 1];   // per-wave partial dW tiles
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
+    const int col0 = blockIdx.x * FT_TX, col = col0 + tx;
     const bool col_on = col < H;
-    float w[4 * K4];
-    load_w_column<K4>(W, col0, H, K, sW, tid, tx, w);
     const float b = col_on ? bias[col] : 0.f;
     const float mean = col_on ? save_mean[col] : 0.f;
     const float invstd = col_on ? save_invstd[col] : 0.f;
     const float gm = col_on ? gamma[col] : 0.f;
+    float w[4 * K4];
+    load_w_column<K4>(W, col0, H, K, sW, tid, tx, w);
 
     float xh[RPT], dy[RPT];
+    float4 xv[RPT][K4];
     float s_dy = 0.f, s_dyxh = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * BN_TY;
+        int row = ty + k * FT_TY;
         bool on = col_on && row < B;
-        float z = on ? small_k_dot<K4>(x + (int64_t)row * ldx, w, b) : 0.f;
+        float z = b;
+#pragma unroll
+        for (int q = 0; q < K4; ++q) {
+            xv[k][q] = (row < B) ? ((const float4*)(x + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            z += xv[k][q].x * w[4 * q + 0];
+            z += xv[k][q].y * w[4 * q + 1];
+            z += xv[k][q].z * w[4 * q + 2];
+            z += xv[k][q].w * w[4 * q + 3];
+        }
         float o = on ? out[(int64_t)row * ldo + col] : 0.f;
         float dd = on ? d_out[(int64_t)row * ld_dout + col] : 0.f;
         xh[k] = on ? (z - mean) * invstd : 0.f;
@@ -153,8 +163,8 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_wgrad_kernel(
         s_dy += dy[k];
         s_dyxh += dy[k] * xh[k];
     }
-    const float dbeta = col_reduce(s_dy, red, tx, ty);
-    const float dgamma = col_reduce(s_dyxh, red, tx, ty);
+    float dbeta, dgamma;
+    bn_col_reduce2<FT_TX, FT_TY>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
     const float invB = 1.0f / (float)B;
     const float k1 = gm * invstd;
     float acc[4 * K4];
@@ -163,36 +173,35 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_wgrad_kernel(
     float s_dz = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * BN_TY;
-        if (row < B) {
-            float dz = col_on ? k1 * (dy[k] - dbeta * invB - xh[k] * (dgamma * invB)) : 0.f;
-            s_dz += dz;
-            const float4* xr = (const float4*)(x + (int64_t)row * ldx);
+        int row = ty + k * FT_TY;
+        float dz = (col_on && row < B) ? k1 * (dy[k] - dbeta * invB - xh[k] * (dgamma * invB)) : 0.f;
+        s_dz += dz;
 #pragma unroll
-            for (int q = 0; q < K4; ++q) {
-                const float4 v = xr[q];
-                acc[4 * q + 0] += dz * v.x;
-                acc[4 * q + 1] += dz * v.y;
-                acc[4 * q + 2] += dz * v.z;
-                acc[4 * q + 3] += dz * v.w;
-            }
+        for (int q = 0; q < K4; ++q) {
+            acc[4 * q + 0] += dz * xv[k][q].x;
+            acc[4 * q + 1] += dz * xv[k][q].y;
+            acc[4 * q + 2] += dz * xv[k][q].z;
+            acc[4 * q + 3] += dz * xv[k][q].w;
         }
     }
-    const float dbias = col_reduce(s_dz, red, tx, ty);
-    // dW tile: lanes l and l+32 of a wave hold the same column (row phases 2w, 2w+1): fold them, then 16 wave tiles
-    const int wv = ty >> 1;
+    const float dbias = bn_col_reduce<FT_TX, FT_TY>(s_dz, red, tx, ty);
+    // dW tile: fold the 8 row phases of a wave by xor shuffles, then the wave partials through LDS
 #pragma unroll
     for (int k = 0; k < 4 * K4; ++k) {
-        float v = acc[k] + __shfl_xor(acc[k], 32);
-        if ((ty & 1) == 0) sG[wv][tx][k] = v;
+        float v = acc[k];
+#pragma unroll
+        for (int o = FT_TX; o < 64; o <<= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) < FT_TX) sG[tid >> 6][tx][k] = v;
     }
     __syncthreads();
-    // thread (tx, ty) finishes dW[col][k = ty] (K <= 32 = BN_TY)
-    if (ty < K && col_on) {
-        float s = 0.f;
+    for (int e = tid; e < FT_TX * K; e += FT_THREADS) {
+        int c = e / K, k = e - c * K;
+        if (col0 + c < H) {
+            float s = 0.f;
 #pragma unroll
-        for (int v = 0; v < BN_TY / 2; ++v) s += sG[v][tx][ty];
-        d_W[(int64_t)col * K + ty] = s;
+            for (int v = 0; v < FT_NW; ++v) s += sG[v][c][k];
+            d_W[(int64_t)(col0 + c) * K + k] = s;
+        }
     }
     if (ty == 0 && col_on) {
         d_gamma[col] = dgamma;
@@ -205,39 +214,49 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_wgrad_kernel(
 // B2: d_out = d_heads @ Wh (reduction over the NH <= 48 heads outputs) computed on the fly, then ReLU/BN backward.
 // ------------------------------------------------------------------------------------------------------------
 template <int RPT, int NH4>
-__global__ __launch_bounds__(BN_TX* BN_TY) void heads_bwd_bn_relu_bwd_kernel(
+__global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     const float* __restrict__ d_heads, int ldh, const float* __restrict__ Wh, int ldw, const float* __restrict__ g,
     int ldg, const float* __restrict__ bias, const float* __restrict__ out, int ldo, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* __restrict__ d_z, int ldd,
     float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, int B, int H) {
-    __shared__ float red[BN_TY][BN_TX + 1];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * BN_TX + tx;
+    __shared__ float red[FT_NW][FT_TX + 1];
+    __shared__ float red2[FT_NW][FT_TX + 1];
+    __shared__ float sWh[4 * NH4][FT_TX + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
+    const int col0 = blockIdx.x * FT_TX, col = col0 + tx;
     const bool col_on = col < H;
-    float w[4 * NH4];   // column `col` of Wh: Wh[j][col], coalesced across tx
-#pragma unroll
-    for (int j = 0; j < 4 * NH4; ++j) w[j] = col_on ? Wh[(int64_t)j * ldw + col] : 0.f;
     const float b = (bias && col_on) ? bias[col] : 0.f;
     const float mean = col_on ? save_mean[col] : 0.f;
     const float invstd = col_on ? save_invstd[col] : 0.f;
     const float gm = col_on ? gamma[col] : 0.f;
+    // Wh[:, col0 .. col0+TX): 4*NH4 x TX tile, one element per thread
+    for (int e = tid; e < 4 * NH4 * FT_TX; e += FT_THREADS) {
+        int j = e / FT_TX, c = e - j * FT_TX;
+        sWh[j][c] = (col0 + c < H) ? Wh[(int64_t)j * ldw + col0 + c] : 0.f;
+    }
+    __syncthreads();
+    float w[4 * NH4];
+#pragma unroll
+    for (int j = 0; j < 4 * NH4; ++j) w[j] = sWh[j][tx];
 
     float xh[RPT], dy[RPT];
     float s_dy = 0.f, s_dyxh = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * BN_TY;
+        int row = ty + k * FT_TY;
         bool on = col_on && row < B;
         float dd = 0.f;
         if (row < B) {
-            const float4* dh = (const float4*)(d_heads + (int64_t)row * ldh);   // broadcast across the 32 columns
+            const float4* dh = (const float4*)(d_heads + (int64_t)row * ldh);   // the 8 column lanes share these loads
+            float4 v[NH4];
+#pragma unroll
+            for (int q = 0; q < NH4; ++q) v[q] = dh[q];
 #pragma unroll
             for (int q = 0; q < NH4; ++q) {
-                const float4 v = dh[q];
-                dd += v.x * w[4 * q + 0];
-                dd += v.y * w[4 * q + 1];
-                dd += v.z * w[4 * q + 2];
-                dd += v.w * w[4 * q + 3];
+                dd += v[q].x * w[4 * q + 0];
+                dd += v[q].y * w[4 * q + 1];
+                dd += v[q].z * w[4 * q + 2];
+                dd += v[q].w * w[4 * q + 3];
             }
         }
         float z = on ? g[(int64_t)row * ldg + col] + b : 0.f;
@@ -247,21 +266,21 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void heads_bwd_bn_relu_bwd_kernel(
         s_dy += dy[k];
         s_dyxh += dy[k] * xh[k];
     }
-    const float dbeta = col_reduce(s_dy, red, tx, ty);
-    const float dgamma = col_reduce(s_dyxh, red, tx, ty);
+    float dbeta, dgamma;
+    bn_col_reduce2<FT_TX, FT_TY>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
     const float invB = 1.0f / (float)B;
     const float k1 = gm * invstd;
     float s_dz = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * BN_TY;
+        int row = ty + k * FT_TY;
         if (col_on && row < B) {
             float dz = k1 * (dy[k] - dbeta * invB - xh[k] * (dgamma * invB));
             d_z[(int64_t)row * ldd + col] = dz;
             s_dz += dz;
         }
     }
-    const float dbias = col_reduce(s_dz, red, tx, ty);
+    const float dbias = bn_col_reduce<FT_TX, FT_TY>(s_dz, red, tx, ty);
     if (ty == 0 && col_on) {
         d_gamma[col] = dgamma;
         d_beta[col] = dbeta;
@@ -299,6 +318,11 @@ __global__ __launch_bounds__(HEAD_THREADS) void heads_gemm_head_kernel(
     const int T = A * (A + 1) / 2;
 
     for (int k = tid; k < HEAD_SPB * NHP / 4; k += HEAD_THREADS) ((float4*)sh_out)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-sample scalars: requested before anything else
+    const int hs_loc = tid >> 3, hi = tid & 7;
+    const bool hlive = hs_loc < ns;
+    const float u_val = (hlive && hi < A) ? u[(s0 + hs_loc) * ldu + hi] : 0.f;
+    const float r_val = (hlive && hi == 0) ? r[(s0 + hs_loc) * ldr] : 0.f;
 
     // ---- heads = A2[main] @ Wh[main]^T : 2 x (NHP/16) tiles of 16 x 16 over the 4 waves -----------------------
     const int tiles_n = NHP >> 4;
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void heads_gemm_head_kernel(
     if (heads_out) {
         for (int k = tid; k < ns * NHP / 4; k += HEAD_THREADS) ((float4*)(heads_out + s0 * NHP))[k] = ((const float4*)sh_in)[k];
     }
-    naf_head_body<PMODE, 2>(sh_in, sh_out, sh_L, sh_red, NHP, u, ldu, r, ldr, sh_vnext - s0, 1, nullptr, gamma, q_out, nullptr,
+    naf_head_body<PMODE, 2>(sh_in, sh_out, sh_L, sh_red, NHP, u_val, r_val, sh_vnext[hs_loc], 0.f, gamma, q_out, nullptr,
                             loss_partials, B, A, s0, ns);
     {
         float4* dst = (float4*)(d_heads + s0 * NHP);
@@ -376,13 +400,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void heads_gemm_head_kernel(
 // ------------------------------------------------------------------------------------------------------------
 #define RPT_DISPATCH(KERNEL, KK, ...)                                                      \
     do {                                                                                   \
-        int rpt = (B + BN_TY - 1) / BN_TY;                                                 \
-        if (rpt <= 2) KERNEL<2, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                  \
+        int rpt = (B + FT_TY - 1) / FT_TY;                                                 \
+        if (rpt <= 1) KERNEL<1, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                  \
+        else if (rpt <= 2) KERNEL<2, KK><<<grid, block, 0, st>>>(__VA_ARGS__);             \
         else if (rpt <= 4) KERNEL<4, KK><<<grid, block, 0, st>>>(__VA_ARGS__);             \
         else if (rpt <= 8) KERNEL<8, KK><<<grid, block, 0, st>>>(__VA_ARGS__);             \
         else if (rpt <= 16) KERNEL<16, KK><<<grid, block, 0, st>>>(__VA_ARGS__);           \
-        else if (rpt <= 32) KERNEL<32, KK><<<grid, block, 0, st>>>(__VA_ARGS__);           \
-        else KERNEL<64, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                          \
+        else KERNEL<32, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                          \
     } while (0)
 
 #define K4_DISPATCH(KERNEL, k4, ...)                                                        \
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void heads_gemm_head_kernel(
         else RPT_DISPATCH(KERNEL, 8, __VA_ARGS__);                                          \
     } while (0)
 
-#define FUSED_MAX_B (BN_TY * 64)
+#define FUSED_MAX_B (FT_TY * 32)
 
 extern "C" int naf_linear_bn_relu_fwd_train(const float* x, int64_t x_net_stride, int ldx, int K, const float* W,
                                             const float* bias, const float* gamma, const float* beta,
@@ -407,7 +431,7 @@ extern "C" int naf_linear_bn_relu_fwd_train(const float* x, int64_t x_net_stride
     const int k4d = k4 <= 6 ? 6 : 8;
     if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d || (x_net_stride & 3) != 0) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((H + BN_TX - 1) / BN_TX, nets), block(BN_TX, BN_TY);
+    dim3 grid((H + FT_TX - 1) / FT_TX, nets), block(FT_TX, FT_TY);
     K4_DISPATCH(linear_bn_relu_fwd_train_kernel, k4, x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride,
                 running_mean, running_var, stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, B, H,
                 momentum, eps);
@@ -426,7 +450,7 @@ extern "C" int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const floa
     const int k4d = k4 <= 6 ? 6 : 8;
     if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((H + BN_TX - 1) / BN_TX, 1), block(BN_TX, BN_TY);
+    dim3 grid((H + FT_TX - 1) / FT_TX, 1), block(FT_TX, FT_TY);
     K4_DISPATCH(bn_relu_bwd_wgrad_kernel, k4, d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, save_invstd,
                 d_gamma, d_beta, d_bias, d_W, B, H);
     NAF_CHECK_LAUNCH();
@@ -443,7 +467,7 @@ extern "C" int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const fl
     if (ldh != 16 && ldh != 32 && ldh != 48) return NAF_ERR_ARG;     // every heads column (pads are zeros) is reduced
     if (((uintptr_t)d_heads & 15) != 0) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((H + BN_TX - 1) / BN_TX, 1), block(BN_TX, BN_TY);
+    dim3 grid((H + FT_TX - 1) / FT_TX, 1), block(FT_TX, FT_TY);
     if (ldh == 16)
         RPT_DISPATCH(heads_bwd_bn_relu_bwd_kernel, 4, d_heads, ldh, Wh, ldw, g, ldg, bias, out, ldo, gamma, save_mean,
                      save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, B, H);

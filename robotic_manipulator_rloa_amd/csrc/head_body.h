@@ -21,11 +21,13 @@ __device__ static inline float group8_sum(float x) {
 // sh_L  : HEAD_SPB*8*LT_STRIDE floats (matmul mode only); sh_red: HEAD_THREADS/64 floats
 // Ends with a __syncthreads() when MODE != 0, after which sh_out is complete. MODE 0 returns early per lane.
 // MODE: 0 = forward only (q, optional mu); 1 = backward given dq; 2 = fused TD target + MSE + backward
+// u_val: this lane's action component (lane i of the sample's 8-lane group, 0 beyond A); r_val / vnext_val / dq_val:
+// the sample's reward, V'(s') and dLoss/dQ, needed on lane 0 of the group only. The caller fetches them BEFORE the
+// barrier that publishes sh_in, so their latency overlaps the staging instead of following it.
 template <int PMODE, int MODE>
 __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, float* sh_L, float* sh_red, int ldh,
-                                            const float* __restrict__ u, int ldu, const float* __restrict__ r, int ldr,
-                                            const float* __restrict__ v_next, int ldv, const float* __restrict__ dq_in,
-                                            float gamma, float* __restrict__ q_out, float* __restrict__ mu_out,
+                                            float u_val, float r_val, float vnext_val, float dq_val, float gamma,
+                                            float* __restrict__ q_out, float* __restrict__ mu_out,
                                             float* __restrict__ loss_partials, int B, int A, int64_t s0, int ns) {
     const int T = A * (A + 1) / 2;
     const int tid = threadIdx.x;
@@ -42,7 +44,7 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     for (int j = 0; j < 8; ++j) { t_row[j] = 0.f; L_row[j] = 0.f; }
     if (row_on) {
         mu = tanhf(hrow[i]);
-        d = u[s * ldu + i] - mu;
+        d = u_val - mu;
         const int rbase = A + i * (i + 1) / 2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -92,11 +94,11 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     float dq = 0.f;
     float sq_err = 0.f;
     if (MODE == 1) {
-        if (live) dq = dq_in[s];
+        if (live) dq = __shfl(dq_val, (tid & 63) & ~7);
     } else {
         // lane 0 of the group fetches r and V'(s'); the group shares them by shuffle (uniform control flow)
         float y = 0.f;
-        if (live && i == 0) y = r[s * ldr] + gamma * v_next[s * ldv];
+        if (live && i == 0) y = r_val + gamma * vnext_val;
         y = __shfl(y, (tid & 63) & ~7);
         if (live) {
             float e = Q - y;

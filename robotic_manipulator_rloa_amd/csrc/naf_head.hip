@@ -26,6 +26,16 @@ __global__ __launch_bounds__(HEAD_THREADS) void naf_head_kernel(const float* __r
     const int64_t s0 = (int64_t)blockIdx.x * HEAD_SPB;
     const int ns = (B - s0) < HEAD_SPB ? (int)(B - s0) : HEAD_SPB;
 
+    // per-sample scalars first: their loads fly while the heads rows are staged
+    const int s_loc_ = tid >> 3, i_ = tid & 7;
+    const bool live_ = s_loc_ < ns;
+    const int64_t s_ = s0 + s_loc_;
+    const float u_val = (live_ && i_ < A) ? u[s_ * ldu + i_] : 0.f;
+    float r_val = 0.f, vnext_val = 0.f, dq_val = 0.f;
+    if (live_ && i_ == 0) {
+        if (MODE == 2) { r_val = r[s_ * ldr]; vnext_val = v_next[s_ * ldv]; }
+        if (MODE == 1) dq_val = dq_in[s_];
+    }
     // ---- stage this workgroup's heads rows (contiguous span) ------------------------------------
     {
         const float4* src = (const float4*)(heads + s0 * ldh);
@@ -37,7 +47,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void naf_head_kernel(const float* __r
         }
     }
     __syncthreads();
-    naf_head_body<PMODE, MODE>(sh_in, sh_out, sh_L, sh_red, ldh, u, ldu, r, ldr, v_next, ldv, dq_in, gamma, q_out, mu_out,
+    naf_head_body<PMODE, MODE>(sh_in, sh_out, sh_L, sh_red, ldh, u_val, r_val, vnext_val, dq_val, gamma, q_out, mu_out,
                                loss_partials, B, A, s0, ns);
     if (MODE == 0) return;
     {

@@ -152,12 +152,18 @@ class Learner:
         self.p_mode = int(p_mode)
         self.world_size = int(world_size)
         self.pg = process_group
-        # NAF_FUSED=1: small GEMMs (K = state size, N = heads) folded into the BN / head kernels
-        # (csrc/fused_layers.hip): 16 -> 11 launches per update. Parity-green but, as measured on MI355X
-        # (benchmarks/kernel_probe.py), each fused kernel is still slower than the pair it replaces (its broadcast
-        # operand loads serialise in the vector-memory pipe), 11.0k vs 12.7k updates/s: off by default until the
-        # MFMA-tiled versions land.
-        self.fused = os.environ.get("NAF_FUSED") == "1" and self.lay.S <= 32
+        # Small GEMMs (K = state size 21, N = heads 32) folded into the BN / head kernels (csrc/fused_layers.hip).
+        # Measured per launch at B=256 (benchmarks/kernel_probe.py) and in the bench (updates/s):
+        #   l1 = layer 1 forward (4.5 us vs bmm 3.0 + bn 3.4) and backward incl. dW1 (7.5 vs 3.7 + 3.7); the pair goes
+        #        together because the fused forward does not materialise the pre-BN GEMM output the unfused backward reads
+        #   b2 = dA2 = dH @ Wh folded into layer 2's BN backward (5.5 vs mm 2.7 + bn_bwd 3.7)
+        #   f3 = MFMA heads GEMM + head in one launch (8.1 vs 3.2 + 4.1: slower, off)
+        # none 14.99k, l1+b2 16.26k, all 15.78k updates/s.  NAF_FUSE = comma list out of {l1,b2,f3}, "all" or "none".
+        spec = os.environ.get("NAF_FUSE", "l1,b2").lower()
+        names = {"l1", "b2", "f3"}
+        self.fuse = set(names) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
+        if self.lay.S > 32:
+            self.fuse -= {"l1"}
         lay, B, dev = self.lay, self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
         P, H, HP, NHP = lay.P, lay.H, lay.HP, lay.NHP
@@ -250,7 +256,7 @@ class Learner:
         seg, P, H = lay.seg, lay.P, lay.H
         t2p = self.theta2.data_ptr()
         bnp = self.bn_stats.data_ptr()
-        if self.fused:
+        if "l1" in self.fuse:
             # layer 1 (K = state size): GEMM + bias + BN + ReLU of both nets in one launch, straight off the rows
             check(self._f.naf_linear_bn_relu_fwd_train(
                 rows.data_ptr(), lay.off_s2, lay.row_floats, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
@@ -280,7 +286,7 @@ class Learner:
         t2p, gp = self.theta2.data_ptr(), self.grad.data_ptr()
         rp = rows.data_ptr()
         lp = ptr(loss_partials) if loss_partials is not None else None
-        if self.fused:
+        if "f3" in self.fuse:
             self.forward_train(rows, heads_gemm=False)
             # heads GEMM (MFMA) + V'(s') + y = r + gamma V' ; Q ; loss ; d loss / d heads_pre — one launch
             check(f.naf_heads_gemm_head_fwd_bwd_mse(
@@ -304,7 +310,7 @@ class Learner:
                 torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
         else:
             torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
-        if self.fused:
+        if "b2" in self.fuse:
             # dA2 = dH @ Wh (K = NHP) folded into the ReLU/BN backward of layer 2
             check(f.naf_heads_bwd_bn_relu_bwd(
                 ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset,
@@ -325,7 +331,7 @@ class Learner:
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
         torch.mm(self.dZ2, self.W2_main, out=self.dA1)
-        if self.fused:
+        if "l1" in self.fuse:
             # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written)
             check(f.naf_bn_relu_bwd_wgrad(
                 ptr(self.dA1), H, rp, lay.row_floats, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,

@@ -32,12 +32,12 @@ def current_sd(L, net):
     return sd
 
 
-@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("fused", ["none", "l1,b2", "all"])
 @pytest.mark.parametrize("tag", ["kuka", "panda"])
 def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
-    """fused=1: the small-GEMM-folded kernels of csrc/fused_layers.hip (MFMA heads GEMM etc.) replace 5 of the torch
-    GEMMs; both paths must match the reference."""
-    monkeypatch.setenv("NAF_FUSED", fused)
+    """NAF_FUSE selects which small GEMMs are folded into the BN / head kernels (csrc/fused_layers.hip; "all" includes
+    the MFMA heads GEMM): every combination must match the reference."""
+    monkeypatch.setenv("NAF_FUSE", fused)
     from synth_data import make_transitions
     g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
     S, A, B = [int(x) for x in g[f"{tag}/dims"]]
@@ -83,11 +83,11 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     assert (L.grad[mask] == 0).all() and (L.theta2[0][mask] == 0).all() and (L.adam_v[mask] == 0).all()
 
 
-@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("fused", ["none", "all"])
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64)])
 def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
-    monkeypatch.setenv("NAF_FUSED", fused)
+    monkeypatch.setenv("NAF_FUSE", fused)
     """20 updates against the f32 numpy oracle (Hadamard = reference semantics; matmul = textbook NAF)."""
     from synth_data import make_transitions
     g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
