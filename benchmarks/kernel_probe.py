@@ -38,6 +38,16 @@ tests["F1 linear_bn_relu_fwd x2"] = lambda: lib.naf_linear_bn_relu_fwd_train(row
 tests["B1 bn_relu_bwd_wgrad"] = lambda: lib.naf_bn_relu_bwd_wgrad(ptr(L.dA1), H, rows.data_ptr(), 64, lay.S, t2p+4*seg["W1"].offset, t2p+4*seg["b1"].offset, ptr(L.A1[0]), H, t2p+4*seg["g1"].offset, ptr(L.save_mean[0,0]), ptr(L.save_invstd[0,0]), gp+4*seg["g1"].offset, gp+4*seg["be1"].offset, gp+4*seg["b1"].offset, gp+4*seg["W1"].offset, B, H, stream_ptr())
 tests["B2 heads_bwd_bn_relu_bwd"] = lambda: lib.naf_heads_bwd_bn_relu_bwd(ptr(L.dH), NHP, t2p+4*seg["Wh"].offset, HP, ptr(L.G2[0]), H, t2p+4*seg["b2"].offset, ptr(L.A2[0]), HP, t2p+4*seg["g2"].offset, ptr(L.save_mean[1,0]), ptr(L.save_invstd[1,0]), ptr(L.dZ2), H, gp+4*seg["g2"].offset, gp+4*seg["be2"].offset, gp+4*seg["b2"].offset, B, H, stream_ptr())
 tests["F3 heads_gemm_head"] = lambda: lib.naf_heads_gemm_head_fwd_bwd_mse(ptr(L.A2), B*HP, HP, HP, t2p+4*seg["Wh"].offset, P, HP, NHP, rows.data_ptr()+4*lay.off_u, 64, rows.data_ptr()+4*lay.off_r, 64, 0.99, None, ptr(L.q_out), ptr(L.dH), None, B, lay.A, 0, stream_ptr())
+D = _lib.GemmDesc
+bun = L._bundle
+one = lambda i: (D * 1)(bun[i])
+tests["GB bundle dWh+dW2+dA1"] = lambda: lib.naf_gemm_bundle(bun, 3, stream_ptr())
+tests["GB dWh only (kmaj,kmaj)"] = lambda a=one(0): lib.naf_gemm_bundle(a, 1, stream_ptr())
+tests["GB dW2 only (kmaj,kmaj)"] = lambda a=one(1): lib.naf_gemm_bundle(a, 1, stream_ptr())
+tests["GB dA1 only (kcont,kmaj)"] = lambda a=one(2): lib.naf_gemm_bundle(a, 1, stream_ptr())
+tests["torch mm dW2"] = lambda: torch.mm(L.dZ2.t(), L.A1[0], out=L.gW2)
+tests["torch mm dA1"] = lambda: torch.mm(L.dZ2, L.W2_main, out=L.dA1)
+tests["torch mm dWh"] = lambda: torch.mm(L.dH.t(), L.A2[0], out=L.gWh)
 buf = ReplayBuffer(1_000_000, B, "cuda", 0, state_size=21, action_size=6)
 buf.add_rows_device(torch.randn(1_000_000, 64, device="cuda"), 1_000_000)
 idx = torch.randint(0, 1_000_000, (64, B), device="cuda", dtype=torch.int32); out = torch.empty(64*B, 64, device="cuda")

@@ -155,6 +155,20 @@ int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int 
                                     float gamma, float* heads_out, float* q_out, float* d_heads, float* loss_partials, int B,
                                     int A, int p_mode, void* stream);
 
+/* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
+/* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is
+ * [N][K] row-major (b_kmajor = 0; i.e. C = A B^T like torch Linear) or [K][N] (b_kmajor = 1). M, N, K multiples of 16.
+ * Replaces the dW2 / dA1 / dWh GEMMs of the backward pass (autograd of naf_neural_network.py:76-87) with one grid of
+ * f32-MFMA 16x16 tiles. */
+#define NAF_GEMM_BUNDLE_MAX 4
+typedef struct naf_gemm_desc {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor;
+} naf_gemm_desc_t;
+int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
+
 /* ---- clip + Adam + Polyak over one flat parameter buffer -------------------------------------- */
 /* first half of clip_grad_norm_(params, 1) (naf_algorithm.py:209): partials[i] = sum of g^2 over chunk i of
  * NAF_NORM_CHUNK floats; n_partials = ceil(n / NAF_NORM_CHUNK). If step_dev != NULL also does *step_dev += 1

@@ -14,7 +14,7 @@ from typing import Optional
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
-SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "optim.hip", "synth_env.hip"]
+SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "gemm_bundle.hip", "optim.hip", "synth_env.hip"]
 HEADERS = ["common.h", "head_body.h", "bn_tile.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
@@ -87,6 +87,7 @@ _PROTOS = {
     "naf_heads_bwd_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "naf_heads_gemm_head_fwd_bwd_mse": [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i,
                                         _i, _i, _vp],
+    "naf_gemm_bundle": [_vp, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
     "naf_polyak_update": [_vp, _vp, _f, _f, _sz, _vp],
@@ -96,6 +97,12 @@ _PROTOS = {
 }
 _RESTYPES = {"naf_hip_arch": C.c_char_p}
 EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+class GemmDesc(C.Structure):
+    """naf_gemm_desc_t (include/naf_hip.h)"""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int)]
 
 
 def load(allow_build: bool = True) -> C.CDLL:

@@ -159,11 +159,16 @@ class Learner:
         #   b2 = dA2 = dH @ Wh folded into layer 2's BN backward (5.5 vs mm 2.7 + bn_bwd 3.7)
         #   f3 = MFMA heads GEMM + head in one launch (8.1 vs 3.2 + 4.1: slower, off)
         # none 14.99k, l1+b2 16.26k, all 15.78k updates/s.  NAF_FUSE = comma list out of {l1,b2,f3}, "all" or "none".
+        #   gb = dWh, dW2, dA1 as ONE grid of f32-MFMA 16x16 tiles fed straight from L2 (csrc/gemm_bundle.hip) instead of
+        #        three rocBLAS launches: 10.2 us vs 3.8 + 3.2 + 3.8 — per-lane 4-byte fragment loads saturate the vector
+        #        memory pipe (256 load instructions per lane per tile); needs LDS-staged dwordx4 loads to win: off
         spec = os.environ.get("NAF_FUSE", "l1,b2").lower()
-        names = {"l1", "b2", "f3"}
+        names = {"l1", "b2", "f3", "gb"}
         self.fuse = set(names) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if self.lay.S > 32:
             self.fuse -= {"l1"}
+        if self.B % 16 != 0:
+            self.fuse -= {"gb"}
         lay, B, dev = self.lay, self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
         P, H, HP, NHP = lay.P, lay.H, lay.HP, lay.NHP
@@ -204,17 +209,20 @@ class Learner:
         self.W1T2 = t2[:, seg["W1"].offset:seg["W1"].offset + seg["W1"].numel].view(2, H, lay.S).transpose(1, 2)
         self.W2T2 = t2[:, seg["W2"].offset:seg["W2"].offset + seg["W2"].numel].view(2, H, H).transpose(1, 2)
         self.WhT2 = t2[:, seg["Wh"].offset:seg["Wh"].offset + seg["Wh"].numel].view(2, NHP, HP).transpose(1, 2)
-        # weight-gradient GEMMs are off the critical path (nothing reads them before the grad norm): they run on a
-        # second stream / a forked branch of the captured graph, beside the dA -> bn_bwd chain
-        self._side = torch.cuda.Stream(device=dev)
-        self._ev_fork = [torch.cuda.Event() for _ in range(2)]
-        self.fork_weight_grads = os.environ.get("NAF_FORK") == "1"   # measured: a forked hipGraph is SLOWER (8.0k vs 12.7k updates/s)
+        # (running the weight-gradient GEMMs on a forked branch of the captured graph was measured SLOWER — 8.0k vs
+        # 12.7k updates/s: hipGraph cross-stream edges cost more than the serial launches they hide — so the update is
+        # one linear chain of launches)
         self.W2_main = lay.view(t2[0], "W2")
         self.Wh_main = lay.view(t2[0], "Wh")
         self.gW1 = lay.view(self.grad, "W1")
         self.gW2 = lay.view(self.grad, "W2")
         self.gWh = lay.view(self.grad, "Wh")
         self._f = self.lib  # shorthand
+        D = _lib.GemmDesc
+        self._bundle = (D * 3)(
+            D(ptr(self.dH), ptr(self.A2[0]), ptr(self.gWh), NHP, HP, B, NHP, HP, HP, 1, 1),                 # dWh
+            D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.gW2), H, H, B, H, H, H, 1, 1),                         # dW2
+            D(ptr(self.dZ2), ptr(self.W2_main), ptr(self.dA1), B, H, H, H, H, H, 0, 1))                       # dA1
 
     # ---- parameters in / out ----------------------------------------------------------------------------
     def main_views(self) -> Dict[str, torch.Tensor]:
@@ -301,14 +309,8 @@ class Learner:
                 self.Gh[1].data_ptr() + 4 * (lay.A + lay.T), NHP, self.gamma, ptr(self.q_out), ptr(self.dH), lp, B, lay.A,
                 self.p_mode, st), "head_fwd_bwd_mse")
         # heads GEMM backward: weight+bias gradient in one GEMM thanks to the ones column
-        fork = self.fork_weight_grads
-        main = torch.cuda.current_stream()
-        if fork:
-            self._ev_fork[0].record(main)
-            self._side.wait_event(self._ev_fork[0])
-            with torch.cuda.stream(self._side):
-                torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
-        else:
+        gb = "gb" in self.fuse
+        if not gb:
             torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
         if "b2" in self.fuse:
             # dA2 = dH @ Wh (K = NHP) folded into the ReLU/BN backward of layer 2
@@ -323,14 +325,12 @@ class Learner:
                 ptr(self.dA2), HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset, ptr(self.A2[0]), HP,
                 t2p + 4 * seg["g2"].offset, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.dZ2), H,
                 gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
-        if fork:
-            self._ev_fork[1].record(main)
-            self._side.wait_event(self._ev_fork[1])
-            with torch.cuda.stream(self._side):
-                torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
+        if gb:
+            # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles
+            check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
-        torch.mm(self.dZ2, self.W2_main, out=self.dA1)
+            torch.mm(self.dZ2, self.W2_main, out=self.dA1)
         if "l1" in self.fuse:
             # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written)
             check(f.naf_bn_relu_bwd_wgrad(
@@ -344,8 +344,6 @@ class Learner:
                 t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.dZ1), H,
                 gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, B, H, st), "bn_relu_bwd(1)")
             torch.mm(self.dZ1.t(), self._x2(rows)[0], out=self.gW1)
-        if fork:
-            main.wait_stream(self._side)               # join: every gradient segment is complete
         if self.world_size > 1 or os.environ.get("NAF_FORCE_ALLREDUCE") == "1":
             # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
