@@ -249,3 +249,76 @@ def test_bench_cli_contract_is_parseable():
     for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
                 '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
         assert key in src
+
+
+def test_pybullet_environment_adapter_with_fake_simulator(monkeypatch):
+    """environment/environment.py (the PyBullet adapter) driven through a kinematic test double of `pybullet`
+    (tests/fake_pybullet.py): validation messages, load errors, reset/step protocol, reward / terminal logic; and it
+    must agree with the built-in synthetic environment, which models the same chain."""
+    import importlib
+    import fake_pybullet
+    pb, pbd = fake_pybullet.make_modules(n_joints=6)
+    monkeypatch.setitem(sys.modules, "pybullet", pb)
+    monkeypatch.setitem(sys.modules, "pybullet_data", pbd)
+    for m in ("robotic_manipulator_rloa_amd.utils.collision_detector", "robotic_manipulator_rloa_amd.environment.environment"):
+        sys.modules.pop(m, None)
+    envmod = importlib.import_module("robotic_manipulator_rloa_amd.environment.environment")
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
+    from robotic_manipulator_rloa_amd.utils.exceptions import InvalidEnvironmentParameter, InvalidManipulatorFile
+    C = envmod.EnvironmentConfiguration
+    good = dict(endeffector_index=5, fixed_joints=[], involved_joints=[0, 1, 2, 3, 4, 5], target_position=[0.4, 0.85, 0.71],
+                obstacle_position=[0.45, 0.55, 0.55], initial_joint_positions=[0.9, 0.45, 0, 0, 0, 0],
+                initial_positions_variation_range=None, max_force=200., visualize=False)
+    for key, bad, msg in (("endeffector_index", 1.5, "End Effector index received is not an integer"),
+                          ("fixed_joints", (1, 2), "Fixed Joints received is not a list"),
+                          ("involved_joints", [0, "a"], "An item inside the Involved Joints list is not an integer"),
+                          ("target_position", "x", "Target Position received is not a list"),
+                          ("obstacle_position", [0, None, 1], "An item inside the Obstacle Position list is not a float"),
+                          ("initial_joint_positions", 3, "Initial Joint Positions received is not a list"),
+                          ("initial_positions_variation_range", ["a"], "An item inside the Initial Positions Variation Range list is not a float"),
+                          ("max_force", "strong", "Maximum Force value received is not a float"),
+                          ("visualize", 1, "Visualize value received is not a boolean")):
+        with pytest.raises(InvalidEnvironmentParameter, match=msg):
+            C(**dict(good, **{key: bad}))
+    cfg = C(**good)
+    with pytest.raises(InvalidManipulatorFile, match="neither .sdf nor .urdf"):
+        envmod.Environment("arm.obj", cfg)
+    with pytest.raises(InvalidManipulatorFile):
+        envmod.Environment("broken.urdf", cfg)
+    with pytest.raises(InvalidManipulatorFile, match="not a string"):
+        envmod.Environment(5, cfg)
+    env = envmod.Environment("kuka_iiwa/model.sdf", cfg)
+    assert ("connect", pb.DIRECT) in pb._state["calls"]
+    twin = SyntheticEnvironment(6)
+    s, t = env.reset(False), twin.reset(False)
+    assert s.shape == (21,) and env.observation_space.shape == (21,) and env.action_space.shape == (6,)
+    np.testing.assert_allclose(s, t, atol=1e-6)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        a = rng.uniform(-1, 1, 6).astype(np.float32)
+        (s2, r, d), (t2, tr, td) = env.step(a), twin.step(a)
+        np.testing.assert_allclose(s2, t2, atol=2e-6)
+        assert d == td == 0 and abs(r - tr) < 1e-5
+    assert env.is_terminal_state() == 0 and env.get_reward() < 0
+    # target reached / obstacle hit
+    pb._state["q"][:] = 0
+    top = [0.0, 0.0, float(0.34 + 0.02 + 0.40 + 0.02 + 0.40 + 0.13)]
+    env2 = envmod.Environment("arm.urdf", C(**dict(good, target_position=top, initial_joint_positions=None)))
+    env2.reset(False)
+    _, r, d = env2.step(np.zeros(6, np.float32))
+    assert (r, d) == (250, 1) and env2.get_reward() == 250 and env2.is_terminal_state() == 1
+    env3 = envmod.Environment("arm.urdf", C(**dict(good, obstacle_position=[0.0, 0.0, 0.35], initial_joint_positions=None)))
+    env3.reset(False)
+    _, r, d = env3.step(np.zeros(6, np.float32))
+    assert (r, d) == (-1000, 1)
+    assert set(env3.get_manipulator_collisions_with_itself().keys()) == {f"joint_{j}" for j in range(6)}
+    env3.close()
+    assert ("disconnect", 7) in pb._state["calls"]
+    # the framework facade builds it when pybullet is importable
+    from robotic_manipulator_rloa_amd import ManipulatorFramework
+    f = ManipulatorFramework()
+    f.initialize_environment("arm.urdf", 5, [], [0, 1, 2, 3, 4, 5], [0.4, 0.85, 0.71], [0.45, 0.55, 0.55], visualize=False)
+    assert isinstance(f.env, envmod.Environment)
+    f.delete_environment()
+    for m in ("robotic_manipulator_rloa_amd.utils.collision_detector", "robotic_manipulator_rloa_amd.environment.environment"):
+        sys.modules.pop(m, None)
