@@ -77,6 +77,15 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
     const int64_t so = net * stat_net_stride + col;
     const float rm_old = (ty == 0 && col_on) ? running_mean[so] : 0.f;
     const float rv_old = (ty == 0 && col_on) ? running_var[so] : 0.f;
+    // input rows first (their loads fly while the weight tile is staged through LDS), weights second
+    float4 xv[RPT][K4];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * FT_TY;
+#pragma unroll
+        for (int q = 0; q < K4; ++q)
+            xv[k][q] = (row < B) ? ((const float4*)(xn + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float w[4 * K4];
     load_w_column<K4>(W + po, col0, H, K, sW, tid, tx, w);
 
@@ -85,7 +94,15 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         int row = ty + k * FT_TY;
-        z[k] = (row < B) ? small_k_dot<K4>(xn + (int64_t)row * ldx, w, b) : 0.f;
+        float acc = b;
+#pragma unroll
+        for (int q = 0; q < K4; ++q) {
+            acc += xv[k][q].x * w[4 * q + 0];
+            acc += xv[k][q].y * w[4 * q + 1];
+            acc += xv[k][q].z * w[4 * q + 2];
+            acc += xv[k][q].w * w[4 * q + 3];
+        }
+        z[k] = (row < B) ? acc : 0.f;
         sum += z[k];
     }
     const float mean = bn_col_reduce<FT_TX, FT_TY>(sum, red, tx, ty) / (float)B;
@@ -137,11 +154,22 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     const float mean = col_on ? save_mean[col] : 0.f;
     const float invstd = col_on ? save_invstd[col] : 0.f;
     const float gm = col_on ? gamma[col] : 0.f;
+    float xh[RPT], dy[RPT];
+    float4 xv[RPT][K4];
+    float ov[RPT], ddv[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {      // every matrix operand is requested before the weight-tile barrier
+        int row = ty + k * FT_TY;
+        bool on = col_on && row < B;
+#pragma unroll
+        for (int q = 0; q < K4; ++q)
+            xv[k][q] = (row < B) ? ((const float4*)(x + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ov[k] = on ? out[(int64_t)row * ldo + col] : 0.f;
+        ddv[k] = on ? d_out[(int64_t)row * ld_dout + col] : 0.f;
+    }
     float w[4 * K4];
     load_w_column<K4>(W, col0, H, K, sW, tid, tx, w);
 
-    float xh[RPT], dy[RPT];
-    float4 xv[RPT][K4];
     float s_dy = 0.f, s_dyxh = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -150,16 +178,13 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
         float z = b;
 #pragma unroll
         for (int q = 0; q < K4; ++q) {
-            xv[k][q] = (row < B) ? ((const float4*)(x + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
             z += xv[k][q].x * w[4 * q + 0];
             z += xv[k][q].y * w[4 * q + 1];
             z += xv[k][q].z * w[4 * q + 2];
             z += xv[k][q].w * w[4 * q + 3];
         }
-        float o = on ? out[(int64_t)row * ldo + col] : 0.f;
-        float dd = on ? d_out[(int64_t)row * ld_dout + col] : 0.f;
         xh[k] = on ? (z - mean) * invstd : 0.f;
-        dy[k] = o > 0.f ? dd : 0.f;
+        dy[k] = ov[k] > 0.f ? ddv[k] : 0.f;
         s_dy += dy[k];
         s_dyxh += dy[k] * xh[k];
     }
@@ -229,6 +254,19 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     const float mean = col_on ? save_mean[col] : 0.f;
     const float invstd = col_on ? save_invstd[col] : 0.f;
     const float gm = col_on ? gamma[col] : 0.f;
+    // every matrix operand is requested before the weight-tile barrier
+    float4 dhv[RPT][NH4];
+    float zv[RPT], ov[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * FT_TY;
+        bool on = col_on && row < B;
+#pragma unroll
+        for (int q = 0; q < NH4; ++q)
+            dhv[k][q] = (row < B) ? ((const float4*)(d_heads + (int64_t)row * ldh))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        zv[k] = on ? g[(int64_t)row * ldg + col] + b : 0.f;
+        ov[k] = on ? out[(int64_t)row * ldo + col] : 0.f;
+    }
     // Wh[:, col0 .. col0+TX): 4*NH4 x TX tile, one element per thread
     for (int e = tid; e < 4 * NH4 * FT_TX; e += FT_THREADS) {
         int j = e / FT_TX, c = e - j * FT_TX;
@@ -246,23 +284,15 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
         int row = ty + k * FT_TY;
         bool on = col_on && row < B;
         float dd = 0.f;
-        if (row < B) {
-            const float4* dh = (const float4*)(d_heads + (int64_t)row * ldh);   // the 8 column lanes share these loads
-            float4 v[NH4];
 #pragma unroll
-            for (int q = 0; q < NH4; ++q) v[q] = dh[q];
-#pragma unroll
-            for (int q = 0; q < NH4; ++q) {
-                dd += v[q].x * w[4 * q + 0];
-                dd += v[q].y * w[4 * q + 1];
-                dd += v[q].z * w[4 * q + 2];
-                dd += v[q].w * w[4 * q + 3];
-            }
+        for (int q = 0; q < NH4; ++q) {
+            dd += dhv[k][q].x * w[4 * q + 0];
+            dd += dhv[k][q].y * w[4 * q + 1];
+            dd += dhv[k][q].z * w[4 * q + 2];
+            dd += dhv[k][q].w * w[4 * q + 3];
         }
-        float z = on ? g[(int64_t)row * ldg + col] + b : 0.f;
-        float o = on ? out[(int64_t)row * ldo + col] : 0.f;
-        xh[k] = on ? (z - mean) * invstd : 0.f;
-        dy[k] = o > 0.f ? dd : 0.f;
+        xh[k] = on ? (zv[k] - mean) * invstd : 0.f;
+        dy[k] = ov[k] > 0.f ? dd : 0.f;
         s_dy += dy[k];
         s_dyxh += dy[k] * xh[k];
     }

@@ -4,13 +4,7 @@
 // boundaries (~3.3 us each, all latency); as one grid of 16x16 output tiles (546 tiles at B=256) they fill half the
 // chip once.
 //
-// One wave per 16x16 output tile, operands straight from L2 (every operand here was just written by the previous
-// kernel and is < 300 KB: no LDS staging, no reuse to exploit beyond L2). Lane (r = l & 15, g = l >> 4), macro-step j
-// (16 k's), component c: k = 16 j + 4 g + c for BOTH operands, so the four MFMAs of a macro-step use each k once:
-//   operand stored k-contiguous ([rows][K], e.g. dZ2 as A of dZ2 @ W2): one float4 per lane per macro-step
-//   operand stored k-major     ([K][rows], e.g. dZ2 as A of dZ2^T @ A1): four 4-byte loads, 64 B contiguous per
-//                                                                         16-lane group
-// C/D map: col = l & 15, row = 4 (l >> 4) + reg. Summation order over k is fixed -> bitwise reproducible.
+// C/D map of the MFMA: col = l & 15, row = 4 (l >> 4) + reg. Summation order over k is fixed -> bitwise reproducible.
 #include "common.h"
 #include "../../include/naf_hip.h"
 
@@ -27,74 +21,92 @@ struct GemmBundle {
     int n, total_tiles;
 };
 
-template <bool KMAJOR>
-__device__ static inline void load_frag(const float* __restrict__ p, int ld, int r0, int r, int g, int k0, float* f) {
-    if (KMAJOR) {   // element (row = r0 + r, k) at p[k * ld + r0 + r]
-        const float* q = p + (int64_t)(k0 + 4 * g) * ld + r0 + r;
-        f[0] = q[0];
-        f[1] = q[ld];
-        f[2] = q[2 * (int64_t)ld];
-        f[3] = q[3 * (int64_t)ld];
-    } else {        // element (row, k) at p[row * ld + k]
-        const float4 v = *(const float4*)(p + (int64_t)(r0 + r) * ld + k0 + 4 * g);
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-    }
-}
+// ---- LDS-staged form -----------------------------------------------------------------------------------------------
+// Workgroup = 256 threads = 4 waves = one 32 x 32 output block (2 x 2 MFMA tiles, one per wave). A K-chunk of 256 of
+// both operand panels (32 rows x 256 k each) is staged into LDS as [row][k] with 16-byte global loads — for a k-major
+// operand the float4 covers 4 consecutive ROWS of one k and is scattered as 4 ds_write_b32 (the transpose happens on
+// the way in) — then every wave reads its fragments as ds_read_b128: lane (r, g) takes k = 16 j + 4 g .. +3 of row r
+// for BOTH operands, so the four MFMAs of macro-step j use each k once. One L2 round trip per 256 k instead of one per
+// fragment (the register-fed form of this kernel issued 256 4-byte loads per lane per tile and ran 10.2 us).
+#define GB_KC 256                 // k per staged chunk
+#define GB_LD (GB_KC + 4)         // LDS row stride (floats): 16-B aligned rows, b128 reads of 16 rows spread over banks
 
-// STEPS macro-steps (16 k's each) with EVERY operand fragment requested before the first MFMA: a tile's K loop is a
-// dependent chain (load -> MFMA), and with one L2 round trip per macro-step it cost 8.4 us per tile at K = 256;
-// with the loads of 16 macro-steps in flight together it is one round trip + 64 MFMAs. Registers are free here
-// (one tile per wave, nothing else resident).
-template <bool AK, bool BK, int STEPS>
-__device__ static inline void gemm_chunk(const GemmDesc& D, int m0, int n0, int r, int g, int k0, f32x4& acc0, f32x4& acc1) {
-    float a[STEPS][4], b[STEPS][4];
-#pragma unroll
-    for (int j = 0; j < STEPS; ++j) {
-        load_frag<AK>(D.A, D.lda, m0, r, g, k0 + 16 * j, a[j]);
-        load_frag<BK>(D.B, D.ldb, n0, r, g, k0 + 16 * j, b[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < STEPS; ++j) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], b[j][1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], b[j][2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
+template <bool KMAJOR>
+__device__ static inline void stage_panel(float* __restrict__ sm, const float* __restrict__ p, int ld, int row0, int rows_total,
+                                          int k0, int kc, int tid) {
+    if (KMAJOR) {
+        // global element (row, k) at p[k * ld + row]: thread -> (k = e / 8, 4 rows = 4 * (e % 8)) ; 32 rows = 8 float4
+        for (int e = tid; e < kc * 8; e += 256) {
+            const int k = e >> 3, r4 = (e & 7) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r4 < rows_total) v = *(const float4*)(p + (int64_t)(k0 + k) * ld + row0 + r4);
+            sm[(r4 + 0) * GB_LD + k] = v.x;
+            sm[(r4 + 1) * GB_LD + k] = v.y;
+            sm[(r4 + 2) * GB_LD + k] = v.z;
+            sm[(r4 + 3) * GB_LD + k] = v.w;
+        }
+    } else {
+        // global element (row, k) at p[row * ld + k]: thread -> (row = e / (kc/4), 4 k's)
+        const int k4n = kc >> 2;
+        for (int e = tid; e < 32 * k4n; e += 256) {
+            const int row = e / k4n, k4 = (e - row * k4n) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + row < rows_total) v = *(const float4*)(p + (int64_t)(row0 + row) * ld + k0 + k4);
+            *(float4*)(sm + row * GB_LD + k4) = v;
+        }
     }
 }
 
 template <bool AK, bool BK>
-__device__ static inline void gemm_tile(const GemmDesc& D, int tm, int tn, int lane) {
+__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, float* sA, float* sB) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;              // this wave's 16 x 16 tile inside the 32 x 32 block
+    const int m0 = bm * 32, n0 = bn * 32;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int m0 = tm * 16, n0 = tn * 16;
-    int k0 = 0;
-    for (; D.K - k0 >= 256; k0 += 256) gemm_chunk<AK, BK, 16>(D, m0, n0, r, g, k0, acc0, acc1);
-    if (D.K - k0 >= 128) { gemm_chunk<AK, BK, 8>(D, m0, n0, r, g, k0, acc0, acc1); k0 += 128; }
-    if (D.K - k0 >= 64) { gemm_chunk<AK, BK, 4>(D, m0, n0, r, g, k0, acc0, acc1); k0 += 64; }
-    if (D.K - k0 >= 32) { gemm_chunk<AK, BK, 2>(D, m0, n0, r, g, k0, acc0, acc1); k0 += 32; }
-    if (D.K - k0 >= 16) { gemm_chunk<AK, BK, 1>(D, m0, n0, r, g, k0, acc0, acc1); k0 += 16; }
-    float* c = D.C + (int64_t)(m0 + 4 * g) * D.ldc + n0 + r;
+    for (int k0 = 0; k0 < D.K; k0 += GB_KC) {
+        const int kc = (D.K - k0) < GB_KC ? (D.K - k0) : GB_KC;
+        if (k0) __syncthreads();                          // previous chunk fully consumed
+        stage_panel<AK>(sA, D.A, D.lda, m0, D.M, k0, kc, tid);
+        stage_panel<BK>(sB, D.B, D.ldb, n0, D.N, k0, kc, tid);
+        __syncthreads();
+        const float* ap = sA + (wm * 16 + r) * GB_LD + 4 * g;
+        const float* bp = sB + (wn * 16 + r) * GB_LD + 4 * g;
+#pragma unroll 4
+        for (int kk = 0; kk < kc; kk += 16) {
+            const float4 a = *(const float4*)(ap + kk);
+            const float4 b = *(const float4*)(bp + kk);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
+        }
+    }
+    const int cm = m0 + wm * 16 + 4 * g, cn = n0 + wn * 16 + r;
+    if (cn < D.N) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) c[(int64_t)e * D.ldc] = acc0[e] + acc1[e];
+        for (int e = 0; e < 4; ++e)
+            if (cm + e < D.M) D.C[(int64_t)(cm + e) * D.ldc + cn] = acc0[e] + acc1[e];
+    }
 }
 
 __global__ __launch_bounds__(256) void gemm_bundle_kernel(const GemmBundle bundle) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);   // one 16x16 tile per wave
-    if (t >= bundle.total_tiles) return;
+    __shared__ __attribute__((aligned(16))) float sA[32 * GB_LD];
+    __shared__ __attribute__((aligned(16))) float sB[32 * GB_LD];
+    const int t = blockIdx.x;                             // one 32 x 32 block per workgroup
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < NAF_GEMM_BUNDLE_MAX; ++i)
         if (i < bundle.n && t >= bundle.d[i].tile0) gi = i;
     const GemmDesc& D = bundle.d[gi];
     const int lt = t - D.tile0;
-    const int tm = lt / D.tiles_n, tn = lt - tm * D.tiles_n;
+    const int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;
     if (D.a_kmajor) {
-        if (D.b_kmajor) gemm_tile<true, true>(D, tm, tn, lane);
-        else gemm_tile<true, false>(D, tm, tn, lane);
+        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, sA, sB);
+        else gemm_block<true, false>(D, bm, bn, sA, sB);
     } else {
-        if (D.b_kmajor) gemm_tile<false, true>(D, tm, tn, lane);
-        else gemm_tile<false, false>(D, tm, tn, lane);
+        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, sA, sB);
+        else gemm_block<false, false>(D, bm, bn, sA, sB);
     }
 }
 
@@ -108,20 +120,19 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (!s.A || !s.B || !s.C || s.M <= 0 || s.N <= 0 || s.K <= 0) return NAF_ERR_ARG;
         if ((s.M & 15) || (s.N & 15) || (s.K & 15)) return NAF_ERR_ARG;            // whole 16x16x16 steps only
         if (s.lda < (s.a_kmajor ? s.M : s.K) || s.ldb < (s.b_kmajor ? s.N : s.K) || s.ldc < s.N) return NAF_ERR_ARG;
-        if (!s.a_kmajor && ((((uintptr_t)s.A) & 15) || (s.lda & 3))) return NAF_ERR_ARG;   // float4 fragments
-        if (!s.b_kmajor && ((((uintptr_t)s.B) & 15) || (s.ldb & 3))) return NAF_ERR_ARG;
+        if ((((uintptr_t)s.A) & 15) || (s.lda & 3) || (((uintptr_t)s.B) & 15) || (s.ldb & 3)) return NAF_ERR_ARG;   // float4 staging
         GemmDesc& d = b.d[i];
         d.A = s.A; d.B = s.B; d.C = s.C;
         d.M = s.M; d.N = s.N; d.K = s.K;
         d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc;
         d.a_kmajor = s.a_kmajor; d.b_kmajor = s.b_kmajor;
         d.tile0 = tiles;
-        d.tiles_n = s.N / 16;
-        tiles += (s.M / 16) * (s.N / 16);
+        d.tiles_n = (s.N + 31) / 32;
+        tiles += ((s.M + 31) / 32) * d.tiles_n;
     }
     for (int i = n; i < NAF_GEMM_BUNDLE_MAX; ++i) b.d[i] = b.d[0];
     b.total_tiles = tiles;
-    gemm_bundle_kernel<<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(b);
+    gemm_bundle_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(b);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

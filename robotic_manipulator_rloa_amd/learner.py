@@ -158,11 +158,12 @@ class Learner:
         #        together because the fused forward does not materialise the pre-BN GEMM output the unfused backward reads
         #   b2 = dA2 = dH @ Wh folded into layer 2's BN backward (5.5 vs mm 2.7 + bn_bwd 3.7)
         #   f3 = MFMA heads GEMM + head in one launch (8.1 vs 3.2 + 4.1: slower, off)
-        # none 14.99k, l1+b2 16.26k, all 15.78k updates/s.  NAF_FUSE = comma list out of {l1,b2,f3}, "all" or "none".
-        #   gb = dWh, dW2, dA1 as ONE grid of f32-MFMA 16x16 tiles fed straight from L2 (csrc/gemm_bundle.hip) instead of
-        #        three rocBLAS launches: 10.2 us vs 3.8 + 3.2 + 3.8 — per-lane 4-byte fragment loads saturate the vector
-        #        memory pipe (256 load instructions per lane per tile); needs LDS-staged dwordx4 loads to win: off
-        spec = os.environ.get("NAF_FUSE", "l1,b2").lower()
+        # NAF_FUSE = comma list out of {l1,b2,gb,f3}, "all" or "none".
+        #   gb = dWh, dW2, dA1 as ONE grid of LDS-staged f32-MFMA 32x32 blocks (csrc/gemm_bundle.hip) instead of three
+        #        rocBLAS launches: 6.2 us vs 3.8 + 3.2 + 3.8 (a first version fed the MFMA fragments straight from L2 with
+        #        4-byte loads and took 10.2 us: 256 load instructions per lane per tile saturate the vector memory pipe)
+        # none 14.99k, l1+b2 16.33k, l1+b2+gb 17.24k updates/s
+        spec = os.environ.get("NAF_FUSE", "l1,b2,gb").lower()
         names = {"l1", "b2", "f3", "gb"}
         self.fuse = set(names) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if self.lay.S > 32:
