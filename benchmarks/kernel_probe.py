@@ -35,8 +35,8 @@ tests = {
 }
 HPv = HP
 tests["F1 linear_bn_relu_fwd x2"] = lambda: lib.naf_linear_bn_relu_fwd_train(rows.data_ptr(), lay.off_s2, 64, lay.S, t2p+4*seg["W1"].offset, t2p+4*seg["b1"].offset, t2p+4*seg["g1"].offset, t2p+4*seg["be1"].offset, P, bnp, bnp+4*H, 4*H, ptr(L.A1), B*H, H, ptr(L.save_mean[0]), ptr(L.save_invstd[0]), B, H, 2, 0.1, 1e-5, stream_ptr())
-tests["B1 bn_relu_bwd_wgrad"] = lambda: lib.naf_bn_relu_bwd_wgrad(ptr(L.dA1), H, rows.data_ptr(), 64, lay.S, t2p+4*seg["W1"].offset, t2p+4*seg["b1"].offset, ptr(L.A1[0]), H, t2p+4*seg["g1"].offset, ptr(L.save_mean[0,0]), ptr(L.save_invstd[0,0]), gp+4*seg["g1"].offset, gp+4*seg["be1"].offset, gp+4*seg["b1"].offset, gp+4*seg["W1"].offset, B, H, stream_ptr())
-tests["B2 heads_bwd_bn_relu_bwd"] = lambda: lib.naf_heads_bwd_bn_relu_bwd(ptr(L.dH), NHP, t2p+4*seg["Wh"].offset, HP, ptr(L.G2[0]), H, t2p+4*seg["b2"].offset, ptr(L.A2[0]), HP, t2p+4*seg["g2"].offset, ptr(L.save_mean[1,0]), ptr(L.save_invstd[1,0]), ptr(L.dZ2), H, gp+4*seg["g2"].offset, gp+4*seg["be2"].offset, gp+4*seg["b2"].offset, B, H, stream_ptr())
+tests["B1 bn_relu_bwd_wgrad"] = lambda: lib.naf_bn_relu_bwd_wgrad(ptr(L.dA1), H, rows.data_ptr(), 64, lay.S, t2p+4*seg["W1"].offset, t2p+4*seg["b1"].offset, ptr(L.A1[0]), H, t2p+4*seg["g1"].offset, ptr(L.save_mean[0,0]), ptr(L.save_invstd[0,0]), gp+4*seg["g1"].offset, gp+4*seg["be1"].offset, gp+4*seg["b1"].offset, gp+4*seg["W1"].offset, None, None, B, H, stream_ptr())
+tests["B2 heads_bwd_bn_relu_bwd"] = lambda: lib.naf_heads_bwd_bn_relu_bwd(ptr(L.dH), NHP, t2p+4*seg["Wh"].offset, HP, ptr(L.G2[0]), H, t2p+4*seg["b2"].offset, ptr(L.A2[0]), HP, t2p+4*seg["g2"].offset, ptr(L.save_mean[1,0]), ptr(L.save_invstd[1,0]), ptr(L.dZ2), H, gp+4*seg["g2"].offset, gp+4*seg["be2"].offset, gp+4*seg["b2"].offset, None, B, H, stream_ptr())
 tests["F3 heads_gemm_head"] = lambda: lib.naf_heads_gemm_head_fwd_bwd_mse(ptr(L.A2), B*HP, HP, HP, t2p+4*seg["Wh"].offset, P, HP, NHP, rows.data_ptr()+4*lay.off_u, 64, rows.data_ptr()+4*lay.off_r, 64, 0.99, None, ptr(L.q_out), ptr(L.dH), None, B, lay.A, 0, stream_ptr())
 D = _lib.GemmDesc
 bun = L._bundle

@@ -137,16 +137,19 @@ int naf_linear_bn_relu_fwd_train(const float* x, int64_t x_net_stride, int ldx, 
                                  float* save_mean, float* save_invstd, int B, int H, int nets, float momentum, float eps,
                                  void* stream);
 /* backward of the above for one network: d_gamma, d_beta, d_bias and d_W[H][K] = dZ^T X (dZ never leaves registers) */
+/* sumsq_partials (nullable): [ceil(H/8)] per-workgroup sums of squares of every gradient this launch writes — the
+ * first half of clip_grad_norm_ folded in (see naf_adam_polyak_fused); step_dev (nullable): *step_dev += 1, as
+ * naf_grad_norm_partials does. */
 int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
                           const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
-                          const float* save_invstd, float* d_gamma, float* d_beta, float* d_bias, float* d_W, int B, int H,
-                          void* stream);
+                          const float* save_invstd, float* d_gamma, float* d_beta, float* d_bias, float* d_W,
+                          float* sumsq_partials, int32_t* step_dev, int B, int H, void* stream);
 /* d_out = d_heads[B][ldh] @ Wh[ldh][ldw] computed on the fly (ldh in {16,32,48}, pad columns zero), then the
  * ReLU/BN backward of naf_bn_relu_bwd: replaces the dA2 GEMM + bn_relu_bwd pair */
 int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const float* Wh, int ldw, const float* g, int ldg,
                               const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
                               const float* save_invstd, float* d_z, int ldd, float* d_gamma, float* d_beta, float* d_bias,
-                              int B, int H, void* stream);
+                              float* sumsq_partials /* nullable, [ceil(H/8)] */, int B, int H, void* stream);
 /* heads_pre = a2[net 0] @ Wh[net 0]^T on f32 MFMA tiles (K % 16 == 0, NHP in {16,32,48}), V'(s') = a2[net 1] . Wh[net 1]
  * row A+T, then exactly naf_head_fwd_bwd_mse: replaces the three head Linears of both networks
  * (naf_neural_network.py:81-87) + the head + the TD/MSE epilogue. heads_out (nullable): [B][NHP]. */
@@ -165,6 +168,7 @@ typedef struct naf_gemm_desc {
     const float* A;
     const float* B;
     float* C;
+    float* sumsq; /* nullable: [ceil(M/32)*ceil(N/32)] per-block sums of C^2 (gradient-norm partials) */
     int M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor;
 } naf_gemm_desc_t;
 int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);

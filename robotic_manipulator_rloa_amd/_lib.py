@@ -83,8 +83,9 @@ _PROTOS = {
     "naf_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "naf_linear_bn_relu_fwd_train": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp,
                                      _i, _i, _i, _f, _f, _vp],
-    "naf_bn_relu_bwd_wgrad": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "naf_heads_bwd_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_bn_relu_bwd_wgrad": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_heads_bwd_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i,
+                                  _vp],
     "naf_heads_gemm_head_fwd_bwd_mse": [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i,
                                         _i, _i, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],
@@ -101,7 +102,7 @@ EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 class GemmDesc(C.Structure):
     """naf_gemm_desc_t (include/naf_hip.h)"""
-    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("sumsq", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int)]
 
 

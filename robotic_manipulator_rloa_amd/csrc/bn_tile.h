@@ -46,3 +46,20 @@ __device__ static inline float bn_col_reduce(float part, float (*red)[BN_TX + 1]
     return s;
 }
 
+
+// Sum of one float per thread over a whole workgroup of NT threads (NT % 64 == 0), result valid in thread 0.
+// Fixed order (xor shuffles inside a wave, then the wave results in index order) -> bitwise reproducible.
+template <int NT>
+__device__ static inline float block_sum_to_thread0(float v, float* sh /* >= NT/64 floats */, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) s += sh[k];
+    }
+    return s;
+}

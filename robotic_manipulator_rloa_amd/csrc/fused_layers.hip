@@ -141,12 +141,13 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     const float* __restrict__ d_out, int ld_dout, const float* __restrict__ x, int ldx, int K,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ out, int ldo,
     const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-    float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_W, int B,
-    int H) {
+    float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_W,
+    float* __restrict__ sumsq_partials, int32_t* step_dev, int B, int H) {
     __shared__ float red[FT_NW][FT_TX + 1];
     __shared__ float red2[FT_NW][FT_TX + 1];
     __shared__ float sW[FT_TX][4 * MAX_K4 + 1];
     __shared__ float sG[FT_NW][FT_TX][4 * MAX_K4 + 1];   // per-wave partial dW tiles
+    __shared__ float sQ[FT_NW];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
     const int col0 = blockIdx.x * FT_TX, col = col0 + tx;
     const bool col_on = col < H;
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
         if ((tid & 63) < FT_TX) sG[tid >> 6][tx][k] = v;
     }
     __syncthreads();
+    float sq = 0.f;   // this thread's share of sum(grad^2) over everything the workgroup writes
     for (int e = tid; e < FT_TX * K; e += FT_THREADS) {
         int c = e / K, k = e - c * K;
         if (col0 + c < H) {
@@ -226,12 +228,21 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
 #pragma unroll
             for (int v = 0; v < FT_NW; ++v) s += sG[v][c][k];
             d_W[(int64_t)(col0 + c) * K + k] = s;
+            sq += s * s;
         }
     }
     if (ty == 0 && col_on) {
         d_gamma[col] = dgamma;
         d_beta[col] = dbeta;
         if (d_bias) d_bias[col] = dbias;
+        sq += dgamma * dgamma + dbeta * dbeta + (d_bias ? dbias * dbias : 0.f);
+    }
+    if (sumsq_partials) {   // first half of clip_grad_norm_ folded in: no separate pass over these gradients
+        const float tot = block_sum_to_thread0<FT_THREADS>(sq, sQ, tid);
+        if (tid == 0) {
+            sumsq_partials[blockIdx.x] = tot;
+            if (blockIdx.x == 0 && step_dev) *step_dev += 1;   // read by the NEXT launch (Adam) only
+        }
     }
 }
 
@@ -243,10 +254,12 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     const float* __restrict__ d_heads, int ldh, const float* __restrict__ Wh, int ldw, const float* __restrict__ g,
     int ldg, const float* __restrict__ bias, const float* __restrict__ out, int ldo, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* __restrict__ d_z, int ldd,
-    float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, int B, int H) {
+    float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias,
+    float* __restrict__ sumsq_partials, int B, int H) {
     __shared__ float red[FT_NW][FT_TX + 1];
     __shared__ float red2[FT_NW][FT_TX + 1];
     __shared__ float sWh[4 * NH4][FT_TX + 1];
+    __shared__ float sQ[FT_NW];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
     const int col0 = blockIdx.x * FT_TX, col = col0 + tx;
     const bool col_on = col < H;
@@ -311,10 +324,16 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
         }
     }
     const float dbias = bn_col_reduce<FT_TX, FT_TY>(s_dz, red, tx, ty);
+    float sq = 0.f;
     if (ty == 0 && col_on) {
         d_gamma[col] = dgamma;
         d_beta[col] = dbeta;
         if (d_bias) d_bias[col] = dbias;
+        sq = dgamma * dgamma + dbeta * dbeta + (d_bias ? dbias * dbias : 0.f);
+    }
+    if (sumsq_partials) {
+        const float tot = block_sum_to_thread0<FT_THREADS>(sq, sQ, ty * FT_TX + tx);
+        if (ty == 0 && tx == 0) sumsq_partials[blockIdx.x] = tot;
     }
 }
 
@@ -472,7 +491,8 @@ extern "C" int naf_linear_bn_relu_fwd_train(const float* x, int64_t x_net_stride
 extern "C" int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
                                      const float* bias, const float* out, int ldo, const float* gamma,
                                      const float* save_mean, const float* save_invstd, float* d_gamma, float* d_beta,
-                                     float* d_bias, float* d_W, int B, int H, void* stream) {
+                                     float* d_bias, float* d_W, float* sumsq_partials, int32_t* step_dev, int B, int H,
+                                     void* stream) {
     if (!d_out || !x || !W || !bias || !out || !gamma || !save_mean || !save_invstd || !d_gamma || !d_beta || !d_W)
         return NAF_ERR_ARG;
     if (B <= 0 || B > FUSED_MAX_B || H <= 0 || K <= 0 || K > 4 * MAX_K4 || ld_dout < H || ldo < H) return NAF_ERR_ARG;
@@ -482,7 +502,7 @@ extern "C" int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const floa
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((H + FT_TX - 1) / FT_TX, 1), block(FT_TX, FT_TY);
     K4_DISPATCH(bn_relu_bwd_wgrad_kernel, k4, d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, save_invstd,
-                d_gamma, d_beta, d_bias, d_W, B, H);
+                d_gamma, d_beta, d_bias, d_W, sumsq_partials, step_dev, B, H);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -490,7 +510,8 @@ extern "C" int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const floa
 extern "C" int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const float* Wh, int ldw, const float* g, int ldg,
                                          const float* bias, const float* out, int ldo, const float* gamma,
                                          const float* save_mean, const float* save_invstd, float* d_z, int ldd,
-                                         float* d_gamma, float* d_beta, float* d_bias, int B, int H, void* stream) {
+                                         float* d_gamma, float* d_beta, float* d_bias, float* sumsq_partials, int B, int H,
+                                         void* stream) {
     if (!d_heads || !Wh || !g || !out || !gamma || !save_mean || !save_invstd || !d_z || !d_gamma || !d_beta)
         return NAF_ERR_ARG;
     if (B <= 0 || B > FUSED_MAX_B || H <= 0 || ldw < H || ldg < H || ldo < H || ldd < H) return NAF_ERR_ARG;
@@ -500,13 +521,13 @@ extern "C" int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const fl
     dim3 grid((H + FT_TX - 1) / FT_TX, 1), block(FT_TX, FT_TY);
     if (ldh == 16)
         RPT_DISPATCH(heads_bwd_bn_relu_bwd_kernel, 4, d_heads, ldh, Wh, ldw, g, ldg, bias, out, ldo, gamma, save_mean,
-                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, B, H);
+                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, sumsq_partials, B, H);
     else if (ldh == 32)
         RPT_DISPATCH(heads_bwd_bn_relu_bwd_kernel, 8, d_heads, ldh, Wh, ldw, g, ldg, bias, out, ldo, gamma, save_mean,
-                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, B, H);
+                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, sumsq_partials, B, H);
     else
         RPT_DISPATCH(heads_bwd_bn_relu_bwd_kernel, 12, d_heads, ldh, Wh, ldw, g, ldg, bias, out, ldo, gamma, save_mean,
-                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, B, H);
+                     save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, sumsq_partials, B, H);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

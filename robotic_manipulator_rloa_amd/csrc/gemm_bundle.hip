@@ -14,6 +14,7 @@ struct GemmDesc {
     const float* A;   // a_kmajor ? [K][M] (ld = lda) : [M][K]
     const float* B;   // b_kmajor ? [K][N] (ld = ldb) : [N][K]
     float* C;         // [M][N], ld = ldc
+    float* sumsq;     // nullable: sumsq[block] = sum of C^2 over the block (grad-norm partial)
     int M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, tile0, tiles_n;
 };
 struct GemmBundle {
@@ -58,7 +59,7 @@ __device__ static inline void stage_panel(float* __restrict__ sm, const float* _
 }
 
 template <bool AK, bool BK>
-__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, float* sA, float* sB) {
+__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, float* sA, float* sB, float* sQ) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;              // this wave's 16 x 16 tile inside the 32 x 32 block
@@ -83,16 +84,30 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
         }
     }
     const int cm = m0 + wm * 16 + 4 * g, cn = n0 + wn * 16 + r;
+    float sq = 0.f;
     if (cn < D.N) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (cm + e < D.M) D.C[(int64_t)(cm + e) * D.ldc + cn] = acc0[e] + acc1[e];
+            if (cm + e < D.M) {
+                const float v = acc0[e] + acc1[e];
+                D.C[(int64_t)(cm + e) * D.ldc + cn] = v;
+                sq += v * v;
+            }
+    }
+    if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 waves)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        __syncthreads();
+        if (lane == 0) sQ[wave] = sq;
+        __syncthreads();
+        if (tid == 0) D.sumsq[bm * D.tiles_n + bn] = sQ[0] + sQ[1] + sQ[2] + sQ[3];
     }
 }
 
 __global__ __launch_bounds__(256) void gemm_bundle_kernel(const GemmBundle bundle) {
     __shared__ __attribute__((aligned(16))) float sA[32 * GB_LD];
     __shared__ __attribute__((aligned(16))) float sB[32 * GB_LD];
+    __shared__ float sQ[4];
     const int t = blockIdx.x;                             // one 32 x 32 block per workgroup
     int gi = 0;
 #pragma unroll
@@ -102,11 +117,11 @@ __global__ __launch_bounds__(256) void gemm_bundle_kernel(const GemmBundle bundl
     const int lt = t - D.tile0;
     const int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;
     if (D.a_kmajor) {
-        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, sA, sB);
-        else gemm_block<true, false>(D, bm, bn, sA, sB);
+        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, sA, sB, sQ);
+        else gemm_block<true, false>(D, bm, bn, sA, sB, sQ);
     } else {
-        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, sA, sB);
-        else gemm_block<false, false>(D, bm, bn, sA, sB);
+        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, sA, sB, sQ);
+        else gemm_block<false, false>(D, bm, bn, sA, sB, sQ);
     }
 }
 
@@ -122,7 +137,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (s.lda < (s.a_kmajor ? s.M : s.K) || s.ldb < (s.b_kmajor ? s.N : s.K) || s.ldc < s.N) return NAF_ERR_ARG;
         if ((((uintptr_t)s.A) & 15) || (s.lda & 3) || (((uintptr_t)s.B) & 15) || (s.ldb & 3)) return NAF_ERR_ARG;   // float4 staging
         GemmDesc& d = b.d[i];
-        d.A = s.A; d.B = s.B; d.C = s.C;
+        d.A = s.A; d.B = s.B; d.C = s.C; d.sumsq = s.sumsq;
         d.M = s.M; d.N = s.N; d.K = s.K;
         d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc;
         d.a_kmajor = s.a_kmajor; d.b_kmajor = s.b_kmajor;

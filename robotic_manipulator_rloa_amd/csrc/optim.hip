@@ -104,19 +104,24 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
         vv0 = ((float4*)v)[i0];
         if (target) tg0 = ((float4*)target)[i0];
     }
-    if (threadIdx.x == 0) {
-        // every workgroup re-derives the same scalars from the same partials in the same order
+    if (threadIdx.x < 64) {
+        // every workgroup re-derives the same scalars from the same partials in the same order: the first wave takes
+        // the partials 64 at a time (all loads in flight together), folds them with xor shuffles
         float s = 0.f;
-        for (int k = 0; k < n_partials; ++k) s += partials[k];
-        const float total_norm = sqrtf(s) * inv_world;
-        float clip = max_norm / (total_norm + 1e-6f);
-        clip = clip > 1.0f ? 1.0f : clip;
-        const int t = *step_dev;
-        const double bc1 = 1.0 - ipow((double)beta1, t);
-        const double bc2 = 1.0 - ipow((double)beta2, t);
-        sh.clip_scale = clip * inv_world;
-        sh.step_size = (float)((double)lr / bc1);
-        sh.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+        for (int k = threadIdx.x; k < n_partials; k += 64) s += partials[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (threadIdx.x == 0) {
+            const float total_norm = sqrtf(s) * inv_world;
+            float clip = max_norm / (total_norm + 1e-6f);
+            clip = clip > 1.0f ? 1.0f : clip;
+            const int t = *step_dev;
+            const double bc1 = 1.0 - ipow((double)beta1, t);
+            const double bc2 = 1.0 - ipow((double)beta2, t);
+            sh.clip_scale = clip * inv_world;
+            sh.step_size = (float)((double)lr / bc1);
+            sh.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+        }
     }
     __syncthreads();
     const AdamScalars sc = sh;

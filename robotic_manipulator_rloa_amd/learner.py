@@ -170,6 +170,11 @@ class Learner:
             self.fuse -= {"l1"}
         if self.B % 16 != 0:
             self.fuse -= {"gb"}
+        # with l1 + b2 + gb every gradient element is produced by one of our own kernels, which then also emit its
+        # sum-of-squares partial: the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken
+        # on the all-reduced gradient).
+        self.fold_norm = {"l1", "b2", "gb"} <= self.fuse and self.world_size == 1 and \
+            os.environ.get("NAF_FORCE_ALLREDUCE") != "1" and os.environ.get("NAF_NO_FOLD_NORM") != "1"
         lay, B, dev = self.lay, self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
         P, H, HP, NHP = lay.P, lay.H, lay.HP, lay.NHP
@@ -184,8 +189,14 @@ class Learner:
         self.bn_stats[:, 1].fill_(1.0)
         self.bn_stats[:, 3].fill_(1.0)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # optimizer steps taken
-        self.n_partials = (P + _lib.NORM_CHUNK - 1) // _lib.NORM_CHUNK
-        self.partials = torch.zeros(self.n_partials, **f32)
+        ft_blocks = (H + 7) // 8                                           # workgroups of the 8-column tile kernels
+        gb_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32) + ((H + 31) // 32) ** 2   # dWh + dW2 blocks of the bundle
+        self.n_partials_norm = (P + _lib.NORM_CHUNK - 1) // _lib.NORM_CHUNK
+        self.n_partials_fold = gb_blocks + 2 * ft_blocks
+        self.n_partials = self.n_partials_fold if self.fold_norm else self.n_partials_norm
+        self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm), **f32)
+        self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
+        self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
         self.n_loss_wg = (B + 31) // 32
 
         # ---- work buffers for one minibatch ------------------------------------------------------------
@@ -220,10 +231,13 @@ class Learner:
         self.gWh = lay.view(self.grad, "Wh")
         self._f = self.lib  # shorthand
         D = _lib.GemmDesc
+        pp = self.partials.data_ptr()
+        sq_wh = pp if self.fold_norm else None
+        sq_w2 = pp + 4 * self._gb_wh_blocks if self.fold_norm else None
         self._bundle = (D * 3)(
-            D(ptr(self.dH), ptr(self.A2[0]), ptr(self.gWh), NHP, HP, B, NHP, HP, HP, 1, 1),                 # dWh
-            D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.gW2), H, H, B, H, H, H, 1, 1),                         # dW2
-            D(ptr(self.dZ2), ptr(self.W2_main), ptr(self.dA1), B, H, H, H, H, H, 0, 1))                       # dA1
+            D(ptr(self.dH), ptr(self.A2[0]), ptr(self.gWh), sq_wh, NHP, HP, B, NHP, HP, HP, 1, 1),          # dWh
+            D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.gW2), sq_w2, H, H, B, H, H, H, 1, 1),                  # dW2
+            D(ptr(self.dZ2), ptr(self.W2_main), ptr(self.dA1), None, B, H, H, H, H, H, 0, 1))                 # dA1
 
     # ---- parameters in / out ----------------------------------------------------------------------------
     def main_views(self) -> Dict[str, torch.Tensor]:
@@ -318,7 +332,8 @@ class Learner:
             check(f.naf_heads_bwd_bn_relu_bwd(
                 ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset,
                 ptr(self.A2[0]), HP, t2p + 4 * seg["g2"].offset, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]),
-                ptr(self.dZ2), H, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st),
+                ptr(self.dZ2), H, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset,
+                self.partials.data_ptr() + 4 * (self._gb_blocks + self._ft_blocks) if self.fold_norm else None, B, H, st),
                 "heads_bwd_bn_relu_bwd")
         else:
             torch.mm(self.dH, self.Wh_main, out=self.dA2)
@@ -338,7 +353,8 @@ class Learner:
                 ptr(self.dA1), H, rp, lay.row_floats, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                 ptr(self.A1[0]), H, t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, gp + 4 * seg["W1"].offset,
-                B, H, st), "bn_relu_bwd_wgrad")
+                self.partials.data_ptr() + 4 * self._gb_blocks if self.fold_norm else None,
+                ptr(self.step_dev) if self.fold_norm else None, B, H, st), "bn_relu_bwd_wgrad")
         else:
             check(f.naf_bn_relu_bwd(
                 ptr(self.dA1), H, ptr(self.G1[0]), H, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
@@ -355,7 +371,8 @@ class Learner:
         """clip_grad_norm_(params, 1) + Adam.step() + soft_update on the flat buffers: 2 launches."""
         st, P = stream_ptr(), self.lay.P
         f = self._f
-        check(f.naf_grad_norm_partials(ptr(self.grad), P, ptr(self.partials), ptr(self.step_dev), st), "grad_norm")
+        if not self.fold_norm:
+            check(f.naf_grad_norm_partials(ptr(self.grad), P, ptr(self.partials), ptr(self.step_dev), st), "grad_norm")
         check(f.naf_adam_polyak_fused(
             ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]),
             ptr(self.partials), self.n_partials, MAX_GRAD_NORM, self.lr, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau,

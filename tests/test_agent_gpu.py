@@ -205,6 +205,7 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 from test_learner_gpu import _kuka_learner_and_replay
 from robotic_manipulator_rloa_amd.engine import TrainChunk
 res = []
+os.environ["NAF_NO_FOLD_NORM"] = "1"      # both runs take the gradient norm with the same (post-all-reduce) kernel
 for force in ("0", "1"):
     os.environ["NAF_FORCE_ALLREDUCE"] = force
     L, buf = _kuka_learner_and_replay(5000, 256, seed_data=5)

@@ -430,9 +430,15 @@ def test_linear_bn_relu_fused_fwd_and_wgrad_vs_oracle(lib, B, K, H):
     dg, db, dbias = (torch.empty(H, device="cuda") for _ in range(3))
     dW = torch.full((H, K), 9.0, device="cuda")
     dod = dev(d_out)
+    nblk = (H + 7) // 8
+    sq = torch.zeros(nblk, device="cuda")
+    stepc = torch.zeros(1, dtype=torch.int32, device="cuda")
     assert lib.naf_bn_relu_bwd_wgrad(dod.data_ptr(), H, xd.data_ptr(), ldx, K, fp, fp + 4 * H * K, out.data_ptr(), H,
                                      fp + 4 * (H * K + H), sm.data_ptr(), si.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                     dbias.data_ptr(), dW.data_ptr(), B, H, st()) == 0
+                                     dbias.data_ptr(), dW.data_ptr(), sq.data_ptr(), stepc.data_ptr(), B, H, st()) == 0
+    total = (dW.double() ** 2).sum() + (dg.double() ** 2).sum() + (db.double() ** 2).sum() + (dbias.double() ** 2).sum()
+    np.testing.assert_allclose(sq.double().sum().item(), total.item(), rtol=1e-5)      # folded grad-norm partials
+    assert int(stepc.item()) == 1
     gW = dz.T @ x
     s = max(1.0, np.abs(gW).max())
     np.testing.assert_allclose(dW.cpu().numpy(), gW, rtol=2e-3, atol=3e-5 * s)
@@ -460,17 +466,20 @@ def test_heads_bwd_bn_relu_bwd_fused_vs_oracle(lib, B, NHP, H):
     t = {k: dev(v) for k, v in dict(dH=dH, Wh=Wh, g=g, bias=bias, out=outp, gamma=gamma, mean=cache["mean"], inv=cache["invstd"]).items()}
     dzd = torch.empty(B, H, device="cuda")
     dg, db, dbias = (torch.empty(H, device="cuda") for _ in range(3))
+    sq = torch.zeros((H + 7) // 8, device="cuda")
     assert lib.naf_heads_bwd_bn_relu_bwd(t["dH"].data_ptr(), NHP, t["Wh"].data_ptr(), ldw, t["g"].data_ptr(), H,
                                          t["bias"].data_ptr(), t["out"].data_ptr(), H, t["gamma"].data_ptr(), t["mean"].data_ptr(),
                                          t["inv"].data_ptr(), dzd.data_ptr(), H, dg.data_ptr(), db.data_ptr(), dbias.data_ptr(),
-                                         B, H, st()) == 0
+                                         sq.data_ptr(), B, H, st()) == 0
+    total = (dg.double() ** 2).sum() + (db.double() ** 2).sum() + (dbias.double() ** 2).sum()
+    np.testing.assert_allclose(sq.double().sum().item(), total.item(), rtol=1e-5)
     s = max(1.0, np.abs(dz).max())
     np.testing.assert_allclose(dzd.cpu().numpy(), dz, rtol=1e-3, atol=3e-5 * s)
     np.testing.assert_allclose(dg.cpu().numpy(), dgam, rtol=1e-3, atol=1e-4 * np.abs(dgam).max())
     np.testing.assert_allclose(db.cpu().numpy(), dbet, rtol=1e-3, atol=1e-4 * np.abs(dbet).max())
     assert lib.naf_heads_bwd_bn_relu_bwd(t["dH"].data_ptr(), 40, t["Wh"].data_ptr(), ldw, t["g"].data_ptr(), H, None,
                                          t["out"].data_ptr(), H, t["gamma"].data_ptr(), t["mean"].data_ptr(), t["inv"].data_ptr(),
-                                         dzd.data_ptr(), H, dg.data_ptr(), db.data_ptr(), None, B, H, st()) == -1
+                                         dzd.data_ptr(), H, dg.data_ptr(), db.data_ptr(), None, None, B, H, st()) == -1
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -522,7 +531,7 @@ def test_gemm_bundle_mfma_vs_numpy(lib, ak, bk):
     from robotic_manipulator_rloa_amd import _lib
     rng = np.random.default_rng(10 * ak + bk)
     shapes = [(32, 272, 256), (256, 256, 64), (48, 16, 272)]
-    descs, keep, expect = [], [], []
+    descs, keep, expect, sums = [], [], [], []
     for (M, N, K) in shapes:
         A = rng.standard_normal((M, K))
         Bm = rng.standard_normal((N, K))
@@ -535,8 +544,10 @@ def test_gemm_bundle_mfma_vs_numpy(lib, ak, bk):
         else: b_store[:, :K] = Bm
         ad, bd = dev(a_store), dev(b_store)
         cd = torch.full((M, ldc), -7.0, device="cuda")
+        sqd = torch.zeros(((M + 31) // 32) * ((N + 31) // 32), device="cuda")
         keep += [ad, bd, cd]
-        descs.append(_lib.GemmDesc(ad.data_ptr(), bd.data_ptr(), cd.data_ptr(), M, N, K, lda, ldb, ldc, ak, bk))
+        sums.append(sqd)
+        descs.append(_lib.GemmDesc(ad.data_ptr(), bd.data_ptr(), cd.data_ptr(), sqd.data_ptr(), M, N, K, lda, ldb, ldc, ak, bk))
         expect.append(A @ Bm.T)
     arr = (_lib.GemmDesc * 3)(*descs)
     assert lib.naf_gemm_bundle(arr, 3, st()) == 0
@@ -544,5 +555,6 @@ def test_gemm_bundle_mfma_vs_numpy(lib, ak, bk):
         got = keep[3 * i + 2].cpu().numpy()
         np.testing.assert_allclose(got[:, :N], expect[i], rtol=1e-4, atol=1e-4 * np.sqrt(K))
         assert (got[:, N:] == -7.0).all()
-    bad = (_lib.GemmDesc * 1)(_lib.GemmDesc(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), 30, 272, 256, 300, 300, 300, ak, bk))
+        np.testing.assert_allclose(sums[i].double().sum().item(), (expect[i] ** 2).sum(), rtol=1e-4)   # per-block sum of C^2
+    bad = (_lib.GemmDesc * 1)(_lib.GemmDesc(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), None, 30, 272, 256, 300, 300, 300, ak, bk))
     assert lib.naf_gemm_bundle(bad, 1, st()) == -1            # M not a multiple of 16
