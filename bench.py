@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--buffer", type=int, default=1_000_000)
     ap.add_argument("--p-mode", choices=["hadamard", "matmul"], default="hadamard")
+    ap.add_argument("--robot", choices=["kuka", "xarm6", "panda"], default="kuka",
+                    help="shapes only: kuka/xarm6 S=21 A=6, panda S=23 A=7 (BASELINE configs[3], [4])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -80,7 +82,8 @@ def main():
     from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
 
-    S, A, H, B, E, N = 21, 6, 256, args.batch, args.envs, args.buffer
+    S, A = (23, 7) if args.robot == "panda" else (21, 6)
+    H, B, E, N = 256, args.batch, args.envs, args.buffer
     p_mode = _lib.P_HADAMARD if args.p_mode == "hadamard" else _lib.P_MATMUL
     L = Learner(S, A, H, B, 1e-3, 1e-3, 0.99, dev, p_mode=p_mode, world_size=world)
     sd = reference_init_state_dict(S, A, H, seed=0)          # same seed on every rank: replicas start identical
@@ -146,7 +149,8 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (on-device kinematic stand-in env; replay pre-filled "
         "with synthetic transitions; random-init weights, seed 0)",
-        "config": {"workload": f"configs[1]: KUKA 6-DoF shapes S=21 A=6 H=256, {E} envs/GPU, batch {B}, HBM replay {N}, "
+        "config": {"workload": f"{'configs[1]: ' if (args.robot, B, N, E) == ('kuka', 256, 1000000, 64) else ''}{args.robot} shapes "
+                               f"S={S} A={A} H=256, {E} envs/GPU, batch {B}, HBM replay {N}, "
                                f"HIP NAF head ({args.p_mode} P), {U} learn() per vector step",
                    "launch": graph_note, "parallelism": f"dp{world}" if world > 1 else "single"},
         "updates_per_s": round(updates / elapsed, 1),

@@ -163,7 +163,10 @@ class Learner:
         #        rocBLAS launches: 6.2 us vs 3.8 + 3.2 + 3.8 (a first version fed the MFMA fragments straight from L2 with
         #        4-byte loads and took 10.2 us: 256 load instructions per lane per tile saturate the vector memory pipe)
         # none 14.99k, l1+b2 16.33k, l1+b2+gb 17.24k updates/s
-        spec = os.environ.get("NAF_FUSE", "l1,b2,gb").lower()
+        # The folded kernels keep their operand rows in registers (ceil(B/64) rows per thread): they win up to B = 512
+        # and spill beyond (B=1024: 3.8k vs 9.0k updates/s unfused; B=2048: 1.3k vs 5.6k), where rocBLAS also beats the
+        # bundle (longer K) — so large batches default to the unfused chain.
+        spec = os.environ.get("NAF_FUSE", "l1,b2,gb" if self.B <= 512 else "none").lower()
         names = {"l1", "b2", "f3", "gb"}
         self.fuse = set(names) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if self.lay.S > 32:
