@@ -60,4 +60,4 @@ names = {0: "32x32", 1: "32x16", 2: "32x8", 3: "16x16", 4: "16x32", 5: "64x8", 6
 for cfg, nm in names.items():
     lib.naf_debug_set(0, cfg)
     print(f"bn tile {nm:6s} fwd {timeit(tests['bn_relu_fwd_train x2nets']):6.2f} us   bwd {timeit(tests['bn_relu_bwd']):6.2f} us")
-lib.naf_debug_set(0, 0)
+lib.naf_debug_set(0, -1)

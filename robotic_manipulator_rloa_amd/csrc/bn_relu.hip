@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_eval_kernel(const float* __re
 }
 
 // Tile shapes to choose from (dev knob naf_debug_set(0, id); the default was picked with benchmarks/kernel_probe.py)
-static int g_bn_tile = 9;   // 8 columns x 64 row phases: fwd 3.3 us / bwd 3.7 us per launch at B=256 (32x32: 4.5 / 5.6)
+static int g_bn_tile = -1;  // -1 = by batch size: 8 columns x 64 row phases up to B = 512 (fwd 3.3 us / bwd 3.7 us per launch
+                            // at B=256; 32x32: 4.5 / 5.6), 8 x 128 beyond (B=2048: 8.3 / 10.1 us vs 10.7 / 15.4 for 8 x 64)
 extern "C" int naf_debug_set(int key, int value) {
     if (key == 0) g_bn_tile = value;
     return NAF_OK;
@@ -161,7 +162,7 @@ extern "C" int naf_debug_set(int key, int value) {
 
 #define BN_DISPATCH(KERNEL, ...)                                                                           \
     do {                                                                                                   \
-        switch (g_bn_tile) {                                                                               \
+        switch (g_bn_tile >= 0 ? g_bn_tile : (B <= 512 ? 9 : 10)) {                                        \
             case 1: BN_LAUNCH_RPT(KERNEL, 32, 16, __VA_ARGS__); break;                                     \
             case 2: BN_LAUNCH_RPT(KERNEL, 32, 8, __VA_ARGS__); break;                                      \
             case 3: BN_LAUNCH_RPT(KERNEL, 16, 16, __VA_ARGS__); break;                                     \
@@ -177,7 +178,7 @@ extern "C" int naf_debug_set(int key, int value) {
         }                                                                                                  \
     } while (0)
 
-#define BN_MAX_B (64 * 64)   // default tile: 64 row phases x up to 64 rows per thread
+#define BN_MAX_B (64 * 128)  // 128 row phases x up to 64 rows per thread
 
 extern "C" int naf_bn_relu_fwd_train(const float* g, int64_t g_net_stride, int ldg, const float* bias,
                                      const float* gamma, const float* beta, int64_t param_net_stride,
