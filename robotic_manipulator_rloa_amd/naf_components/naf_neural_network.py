@@ -8,8 +8,10 @@ Same state_dict keys/shapes, same parameters() order, same seed -> bit-identical
 constructor consumes torch's global CPU RNG exactly as the reference's does).
 Reference quirks kept on purpose (SURVEY.md §0): P = L * L^T elementwise (p_mode='hadamard', the default;
 'matmul' gives textbook NAF), integer actions are accepted and promoted, every forward draws exploration noise.
-forward() does not build an autograd graph: training goes through NAFAgent.learn(), whose backward is fused
-into the HIP kernels.
+forward() is differentiable (like the reference's): when gradients are enabled and the parameters require them, the
+BatchNorm+ReLU and head kernels are wrapped in torch.autograd.Function (backward = the same HIP kernels learn() uses)
+and the Linears run as torch matmuls, so `Q.sum().backward()` fills `.grad` of the 14 parameters. NAFAgent.learn()
+does not go through this path: its backward is fused into the flat-buffer kernels.
 """
 from __future__ import annotations
 
@@ -42,6 +44,59 @@ def reference_init_state_dict(state_size: int, action_size: int, layer_size: int
         for k, v in m.state_dict().items():
             sd[f"{name}.{k}"] = v.detach().clone()
     return sd
+
+
+class _BnReluTrain(torch.autograd.Function):
+    """relu(batch_norm(g + bias)) in training mode for one network through naf_bn_relu_fwd_train / naf_bn_relu_bwd."""
+
+    @staticmethod
+    def forward(ctx, g, bias, gamma, beta, running_mean, running_var, lib):
+        g = g.contiguous()
+        B, H = g.shape
+        out = torch.empty_like(g)
+        sm, si = torch.empty(H, device=g.device), torch.empty(H, device=g.device)
+        bias_c, gamma_c, beta_c = bias.contiguous(), gamma.contiguous(), beta.contiguous()
+        check(lib.naf_bn_relu_fwd_train(ptr(g), 0, H, ptr(bias_c), ptr(gamma_c), ptr(beta_c), 0, ptr(running_mean),
+                                        ptr(running_var), 0, ptr(out), 0, H, ptr(sm), ptr(si), B, H, 1, BN_MOMENTUM, BN_EPS,
+                                        stream_ptr()), "bn_relu_fwd_train")
+        ctx.save_for_backward(g, bias_c, gamma_c, out, sm, si)
+        ctx.lib = lib
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        g, bias, gamma, out, sm, si = ctx.saved_tensors
+        B, H = g.shape
+        d_out = d_out.contiguous()
+        dz = torch.empty_like(g)
+        dg, db, dbias = (torch.empty(H, device=g.device) for _ in range(3))
+        check(ctx.lib.naf_bn_relu_bwd(ptr(d_out), H, ptr(g), H, ptr(bias), ptr(out), H, ptr(gamma), ptr(sm), ptr(si), ptr(dz), H,
+                                      ptr(dg), ptr(db), ptr(dbias), B, H, stream_ptr()), "bn_relu_bwd")
+        return dz, dbias, dg, db, None, None, None
+
+
+class _NafHead(torch.autograd.Function):
+    """Q from heads_pre = [mu_pre | l_pre | V | pad] and the action, through naf_head_fwd / naf_head_bwd."""
+
+    @staticmethod
+    def forward(ctx, heads, u, A, p_mode, lib):
+        heads = heads.contiguous()
+        B, ldh = heads.shape
+        q = torch.empty(B, device=heads.device)
+        check(lib.naf_head_fwd(ptr(heads), ldh, ptr(u), A, ptr(q), None, B, A, p_mode, stream_ptr()), "naf_head_fwd")
+        ctx.save_for_backward(heads, u)
+        ctx.meta = (A, p_mode, lib)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        heads, u = ctx.saved_tensors
+        A, p_mode, lib = ctx.meta
+        B, ldh = heads.shape
+        dq = dq.contiguous()
+        dh = torch.empty_like(heads)
+        check(lib.naf_head_bwd(ptr(heads), ldh, ptr(u), A, ptr(dq), ptr(dh), B, A, p_mode, stream_ptr()), "naf_head_bwd")
+        return dh, None, None, None, None
 
 
 class NAF(nn.Module):
@@ -83,7 +138,7 @@ class NAF(nn.Module):
         views = lay.param_views(self.flat)
         for name in PARAM_ORDER:
             mod, attr = name.split(".")
-            setattr(getattr(self, mod), attr, nn.Parameter(views[name], requires_grad=False))
+            setattr(getattr(self, mod), attr, nn.Parameter(views[name], requires_grad=True))
         self.bn1.running_mean, self.bn1.running_var = self.bn_stats[0], self.bn_stats[1]
         self.bn2.running_mean, self.bn2.running_var = self.bn_stats[2], self.bn_stats[3]
         self.bn1.num_batches_tracked = torch.zeros((), dtype=torch.long, device=self.device)
@@ -180,11 +235,50 @@ class NAF(nn.Module):
                   "bn_eval")
         return torch.mm(a2, lay.view(self.flat, "Wh").t())
 
-    @torch.no_grad()
+    def _heads_autograd(self, input_: torch.Tensor) -> torch.Tensor:
+        """Differentiable heads_pre [B, NHP] (training mode only): torch matmuls + the BN kernels as autograd Functions."""
+        lay = self.layout
+        x = input_.to(self.device, torch.float32)
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        h = _BnReluTrain.apply(x @ self.input_layer.weight.t(), self.input_layer.bias, self.bn1.weight, self.bn1.bias,
+                               self.bn_stats[0], self.bn_stats[1], self.lib)
+        h = _BnReluTrain.apply(h @ self.hidden_layer.weight.t(), self.hidden_layer.bias, self.bn2.weight, self.bn2.bias,
+                               self.bn_stats[2], self.bn_stats[3], self.lib)
+        self._tracked_eager += 1
+        mu_pre = h @ self.action_values.weight.t() + self.action_values.bias
+        l_pre = h @ self.matrix_entries.weight.t() + self.matrix_entries.bias
+        v = h @ self.value.weight.t() + self.value.bias
+        pad = x.new_zeros(x.shape[0], lay.NHP - lay.NH)
+        return torch.cat([mu_pre, l_pre, v, pad], dim=1)
+
     def forward(self, input_: torch.Tensor, action: Optional[torch.Tensor] = None,
                 noise_scale: float = 1.0) -> Tuple[torch.Tensor, Optional[Any], Any]:
         """(noisy action, Q | None, V), as naf_neural_network.py:56-123. `action` may be int64 (what the reference's
-        ReplayBuffer.sample() yields) or float."""
+        ReplayBuffer.sample() yields) or float. Q and V carry an autograd graph when gradients are enabled in training
+        mode; the noisy action never does (the reference samples it without reparameterisation too)."""
+        lay, lib, st = self.layout, self.lib, stream_ptr()
+        want_grad = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
+        if want_grad:
+            gh = self._heads_autograd(input_)
+            B = gh.shape[0]
+            V = gh[:, lay.A + lay.T].unsqueeze(-1)
+            Q = None
+            if action is not None:
+                u = action.to(self.device, torch.float32).contiguous().view(B, lay.A)
+                Q = _NafHead.apply(gh, u, lay.A, self.p_mode, lib).unsqueeze(-1)
+            with torch.no_grad():
+                ghd = gh.detach().contiguous()
+                noisy = torch.empty(B, lay.A, dtype=torch.float32, device=self.device)
+                check(lib.naf_act_noise(ptr(ghd), lay.NHP, ptr(noisy), self._noise_seed, ptr(self._noise_counter), 0,
+                                        float(noise_scale), B, lay.A, self.p_mode, st), "naf_act_noise")
+                check(lib.naf_counter_add(ptr(self._noise_counter), 1, st), "naf_counter_add")
+            return noisy, Q, V
+        with torch.no_grad():
+            return self._forward_nograd(input_, action, noise_scale)
+
+    @torch.no_grad()
+    def _forward_nograd(self, input_, action, noise_scale):
         lay, lib, st = self.layout, self.lib, stream_ptr()
         gh = self.heads(input_)
         B = gh.shape[0]

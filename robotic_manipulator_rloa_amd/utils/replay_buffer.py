@@ -131,6 +131,9 @@ class ReplayBuffer:
         idx: optional int32 deque positions (0 = oldest) to take instead of drawing."""
         self.flush()
         B, dev = self.batch_size, self.device
+        if idx is None and len(self) < B:
+            # random.sample(deque, k) of the reference raises exactly this (replay_buffer.py:55)
+            raise ValueError("Sample larger than population or is negative")
         if idx is None:
             self.sample_indices(self._idx, 1)
             idx = self._idx
