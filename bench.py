@@ -135,7 +135,15 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    gather_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    gather_bracket_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    # what an EMPTY event bracket reads on this stream: the part of every bracket that is not the kernel
+    cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(256)]
+    for a, b in cal:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    event_overhead_ms = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
+    gather_ms = max(gather_bracket_ms - event_overhead_ms, 1e-6)
 
     finite = bool(torch.isfinite(L.theta2).all().item())
     bad = replay.bad_index_count()
@@ -163,9 +171,12 @@ def main():
                        "achieved": round(alg_bytes / (gather_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                        "frac": round(alg_bytes / (gather_ms * 1e-3) / 8e12, 4), "traffic": None,
                        "rows_per_launch": rows_per_launch, "alg_bytes_per_launch": alg_bytes,
-                       "avg_launch_ms": round(gather_ms, 5),
-                       "note": "event-bracketed single launch inside the timed loop (includes ~event overhead); "
-                               "kernel-only duration: profiles/"}
+                       "avg_launch_ms": round(gather_ms, 5), "avg_event_bracket_ms": round(gather_bracket_ms, 5),
+                       "empty_event_bracket_ms": round(event_overhead_ms, 5),
+                       "note": "one launch per vector step inside the timed loop, bracketed by HIP events on its stream; "
+                               "avg_launch_ms = bracket - empty bracket; rocprofv3 --kernel-trace average of the same "
+                               "command: profiles/r01_bench_kernel_stats.csv (replay_gather_rows_kernel<1>)"}
+    out["roofline"]["traffic"] = pmc_traffic(rows_per_launch)
     if rank == 0 and world == 1:
         out["roofline_bulk"] = bulk_gather(replay, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -191,6 +202,19 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(rows_per_launch):
+    """HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/gather_traffic.json (FETCH_SIZE doubled
+    per the gfx950 correction + WRITE_SIZE); None when no pass was recorded for this launch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "gather_traffic.json")) as f:
+            for rec in json.load(f)["launches"]:
+                if rec["rows_per_launch"] == rows_per_launch:
+                    return int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def bulk_gather(replay, dev, n_rows=1 << 22, reps=20):
     """The same gather kernel on a launch big enough to be bandwidth- instead of latency-bound: 4 Mi uniformly
     random rows (1.07 GB of row traffic per launch) out of the 1e6-row (256 MB) ring."""
@@ -208,6 +232,7 @@ def bulk_gather(replay, dev, n_rows=1 << 22, reps=20):
     alg = n_rows * (4 * (2 * replay.S + replay.A + 2) * 2 + 4)
     phys = n_rows * (replay.row_floats * 4 * 2 + 4)
     return {"kernel": "replay_gather_rows_kernel", "rows_per_launch": n_rows, "avg_launch_ms": round(ms, 4),
+            "traffic": pmc_traffic(n_rows), "alg_bytes_per_launch": alg,
             "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 8e12, 4),
             "physical_GBps": round(phys / (ms * 1e-3) / 1e9, 1)}
 
