@@ -95,8 +95,9 @@ int naf_head_bwd(const float* heads_pre, int ldh, const float* u, int ldu, const
                  int B, int A, int p_mode, void* stream);
 /* fused learn() middle (naf_algorithm.py:199-208): y = r + gamma * v_next; Q as above;
  * loss = mean((Q - y)^2); d_heads = dLoss/d(heads_pre).  r: r[i*ldr], v_next: v_next[i*ldv].
- * loss_partials[ceil(B/32)]: per-workgroup sums of (Q-y)^2 / B, summed by the reader in index order
+ * loss_partials[ceil(B/NAF_HEAD_SPB)]: per-workgroup sums of (Q-y)^2 / B, summed by the reader in index order
  * (bitwise reproducible). q_out nullable. */
+#define NAF_HEAD_SPB 8
 int naf_head_fwd_bwd_mse(const float* heads_pre, int ldh, const float* u, int ldu, const float* r, int ldr,
                          const float* v_next, int ldv, float gamma, float* q_out, float* d_heads,
                          float* loss_partials, int B, int A, int p_mode, void* stream);
@@ -152,7 +153,8 @@ int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const float* Wh, in
                               float* sumsq_partials /* nullable, [ceil(H/8)] */, int B, int H, void* stream);
 /* heads_pre = a2[net 0] @ Wh[net 0]^T on f32 MFMA tiles (K % 16 == 0, NHP in {16,32,48}), V'(s') = a2[net 1] . Wh[net 1]
  * row A+T, then exactly naf_head_fwd_bwd_mse: replaces the three head Linears of both networks
- * (naf_neural_network.py:81-87) + the head + the TD/MSE epilogue. heads_out (nullable): [B][NHP]. */
+ * (naf_neural_network.py:81-87) + the head + the TD/MSE epilogue. heads_out (nullable): [B][NHP]. This kernel works on
+ * 32 samples per workgroup: loss_partials has ceil(B/32) entries here. */
 int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int lda, int K, const float* Wh,
                                     int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu, const float* r, int ldr,
                                     float gamma, float* heads_out, float* q_out, float* d_heads, float* loss_partials, int B,

@@ -2,15 +2,15 @@
 // Q, the MSE/TD epilogue and the whole backward, fused. Replaces naf_neural_network.py:81-115 (+ its
 // autograd) and naf_algorithm.py:199-208 of the reference.
 //
-// Mapping: one sample per 8-lane group (A <= 8), lane i owns row i of L; 8 samples per 64-lane wave, 32 per
-// 256-thread workgroup. The heads rows of a workgroup are one contiguous 32*ldh*4-byte span: staged into LDS
+// Mapping: one sample per 8-lane group (A <= 8), lane i owns row i of L; 8 samples per 64-lane wave = one
+// workgroup (NH_SPB). The heads rows of a workgroup are one contiguous 32*ldh*4-byte span: staged into LDS
 // with 16-B/lane loads, and d_heads leaves the same way. The A x A contraction is per sample — not a GEMM,
 // so no MFMA: row reductions are 8-lane xor shuffles, column accesses of L go through a padded LDS tile.
 #include "head_body.h"
 
 // MODE: 0 = forward only (q, optional mu); 1 = backward given dq; 2 = fused TD target + MSE + backward
 template <int PMODE, int MODE>
-__global__ __launch_bounds__(HEAD_THREADS) void naf_head_kernel(const float* __restrict__ heads, int ldh,
+__global__ __launch_bounds__(NH_THREADS) void naf_head_kernel(const float* __restrict__ heads, int ldh,
                                                                 const float* __restrict__ u, int ldu,
                                                                 const float* __restrict__ r, int ldr,
                                                                 const float* __restrict__ v_next, int ldv,
@@ -18,13 +18,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void naf_head_kernel(const float* __r
                                                                 float* __restrict__ q_out, float* __restrict__ mu_out,
                                                                 float* __restrict__ d_heads,
                                                                 float* __restrict__ loss_partials, int B, int A) {
-    __shared__ __attribute__((aligned(16))) float sh_in[HEAD_SPB * HEAD_MAX_LDH];
-    __shared__ __attribute__((aligned(16))) float sh_out[MODE == 0 ? 4 : HEAD_SPB * HEAD_MAX_LDH];
-    __shared__ float sh_L[PMODE == NAF_P_MATMUL ? HEAD_SPB * 8 * LT_STRIDE : 1];
-    __shared__ float sh_red[HEAD_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) float sh_in[NH_SPB * HEAD_MAX_LDH];
+    __shared__ __attribute__((aligned(16))) float sh_out[MODE == 0 ? 4 : NH_SPB * HEAD_MAX_LDH];
+    __shared__ float sh_L[PMODE == NAF_P_MATMUL ? NH_SPB * 8 * LT_STRIDE : 1];
+    __shared__ float sh_red[NH_THREADS / 64];
     const int tid = threadIdx.x;
-    const int64_t s0 = (int64_t)blockIdx.x * HEAD_SPB;
-    const int ns = (B - s0) < HEAD_SPB ? (int)(B - s0) : HEAD_SPB;
+    const int64_t s0 = (int64_t)blockIdx.x * NH_SPB;
+    const int ns = (B - s0) < NH_SPB ? (int)(B - s0) : NH_SPB;
 
     // per-sample scalars first: their loads fly while the heads rows are staged
     const int s_loc_ = tid >> 3, i_ = tid & 7;
@@ -40,20 +40,20 @@ __global__ __launch_bounds__(HEAD_THREADS) void naf_head_kernel(const float* __r
     {
         const float4* src = (const float4*)(heads + s0 * ldh);
         const int n4 = ns * ldh / 4;  // ldh % 4 == 0 (checked on the host)
-        for (int k = tid; k < n4; k += HEAD_THREADS) ((float4*)sh_in)[k] = src[k];
+        for (int k = tid; k < n4; k += NH_THREADS) ((float4*)sh_in)[k] = src[k];
         if (MODE != 0) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = tid; k < n4; k += HEAD_THREADS) ((float4*)sh_out)[k] = z;
+            for (int k = tid; k < n4; k += NH_THREADS) ((float4*)sh_out)[k] = z;
         }
     }
     __syncthreads();
-    naf_head_body<PMODE, MODE>(sh_in, sh_out, sh_L, sh_red, ldh, u_val, r_val, vnext_val, dq_val, gamma, q_out, mu_out,
+    naf_head_body<PMODE, MODE, NH_THREADS>(sh_in, sh_out, sh_L, sh_red, ldh, u_val, r_val, vnext_val, dq_val, gamma, q_out, mu_out,
                                loss_partials, B, A, s0, ns);
     if (MODE == 0) return;
     {
         float4* dst = (float4*)(d_heads + s0 * ldh);
         const int n4 = ns * ldh / 4;
-        for (int k = tid; k < n4; k += HEAD_THREADS) dst[k] = ((const float4*)sh_out)[k];
+        for (int k = tid; k < n4; k += NH_THREADS) dst[k] = ((const float4*)sh_out)[k];
     }
 }
 
@@ -68,16 +68,16 @@ static int head_args_ok(const float* heads, int ldh, const float* u, int ldu, in
 #define HEAD_LAUNCH(PM, MD, ...)                                                                       \
     do {                                                                                               \
         if ((PM) == NAF_P_HADAMARD)                                                                    \
-            naf_head_kernel<NAF_P_HADAMARD, MD><<<blocks, HEAD_THREADS, 0, st>>>(__VA_ARGS__);         \
+            naf_head_kernel<NAF_P_HADAMARD, MD><<<blocks, NH_THREADS, 0, st>>>(__VA_ARGS__);         \
         else                                                                                           \
-            naf_head_kernel<NAF_P_MATMUL, MD><<<blocks, HEAD_THREADS, 0, st>>>(__VA_ARGS__);           \
+            naf_head_kernel<NAF_P_MATMUL, MD><<<blocks, NH_THREADS, 0, st>>>(__VA_ARGS__);           \
     } while (0)
 
 extern "C" int naf_head_fwd(const float* heads_pre, int ldh, const float* u, int ldu, float* q, float* mu_out, int B,
                             int A, int p_mode, void* stream) {
     if (!head_args_ok(heads_pre, ldh, u, ldu, B, A, p_mode) || !q) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int blocks = (B + HEAD_SPB - 1) / HEAD_SPB;
+    int blocks = (B + NH_SPB - 1) / NH_SPB;
     HEAD_LAUNCH(p_mode, 0, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, nullptr, 0.f, q, mu_out, nullptr, nullptr, B, A);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
@@ -88,7 +88,7 @@ extern "C" int naf_head_bwd(const float* heads_pre, int ldh, const float* u, int
     if (!head_args_ok(heads_pre, ldh, u, ldu, B, A, p_mode) || !dq || !d_heads || ((uintptr_t)d_heads & 15) != 0)
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int blocks = (B + HEAD_SPB - 1) / HEAD_SPB;
+    int blocks = (B + NH_SPB - 1) / NH_SPB;
     HEAD_LAUNCH(p_mode, 1, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, dq, 0.f, nullptr, nullptr, d_heads, nullptr, B, A);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
@@ -101,7 +101,7 @@ extern "C" int naf_head_fwd_bwd_mse(const float* heads_pre, int ldh, const float
         ((uintptr_t)d_heads & 15) != 0 || ldr < 1 || ldv < 1)
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int blocks = (B + HEAD_SPB - 1) / HEAD_SPB;
+    int blocks = (B + NH_SPB - 1) / NH_SPB;
     HEAD_LAUNCH(p_mode, 2, heads_pre, ldh, u, ldu, r, ldr, v_next, ldv, nullptr, gamma, q_out, nullptr, d_heads,
                 loss_partials, B, A);
     NAF_CHECK_LAUNCH();

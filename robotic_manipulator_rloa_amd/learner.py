@@ -200,7 +200,7 @@ class Learner:
         self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm), **f32)
         self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
         self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
-        self.n_loss_wg = (B + 31) // 32
+        self.n_loss_wg = (B + 7) // 8                  # loss partials per update (NAF_HEAD_SPB samples per workgroup)
 
         # ---- work buffers for one minibatch ------------------------------------------------------------
         self.G1 = torch.empty(2, B, H, **f32)

@@ -201,7 +201,7 @@ def test_head_both_modes_vs_oracle_f64(lib, mode, A, B):
     ud, rd, vnd = dev(u), dev(r), dev(vn)
     q = torch.empty(B, device="cuda")
     dh = torch.empty(B, ldh, device="cuda")
-    nwg = (B + 31) // 32
+    nwg = (B + 7) // 8
     lp = torch.zeros(nwg, device="cuda")
     assert lib.naf_head_fwd_bwd_mse(h.data_ptr(), ldh, ud.data_ptr(), A, rd.data_ptr(), 1, vnd.data_ptr(), 1, gamma,
                                     q.data_ptr(), dh.data_ptr(), lp.data_ptr(), B, A, mode, st()) == 0
