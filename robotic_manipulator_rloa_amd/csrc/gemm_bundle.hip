@@ -24,30 +24,31 @@ struct GemmBundle {
 
 // ---- LDS-staged form -----------------------------------------------------------------------------------------------
 // Workgroup = 256 threads = 4 waves = one 32 x 32 output block (2 x 2 MFMA tiles, one per wave). A K-chunk of 256 of
-// both operand panels (32 rows x 256 k each) is staged into LDS as [row][k] with 16-byte global loads — for a k-major
-// operand the float4 covers 4 consecutive ROWS of one k and is scattered as 4 ds_write_b32 (the transpose happens on
-// the way in) — then every wave reads its fragments as ds_read_b128: lane (r, g) takes k = 16 j + 4 g .. +3 of row r
-// for BOTH operands, so the four MFMAs of macro-step j use each k once. One L2 round trip per 256 k instead of one per
+// both operand panels (32 rows x 256 k each) is staged into LDS with 16-byte global loads and 16-byte LDS stores, then
+// every wave reads its fragments: lane (r, g) takes k = 16 j + 4 g .. +3 of row r for BOTH operands, so the four MFMAs
+// of macro-step j use each k once. One L2 round trip per 256 k instead of one per
 // fragment (the register-fed form of this kernel issued 256 4-byte loads per lane per tile and ran 10.2 us).
 #define GB_KC 256                 // k per staged chunk
-#define GB_LD (GB_KC + 4)         // LDS row stride (floats): 16-B aligned rows, b128 reads of 16 rows spread over banks
+#define GB_LD (GB_KC + 4)         // [row][k] panels: 16-B aligned rows, b128 fragment reads spread over the banks
+#define GB_LDK 36                 // [k][row] panels (k-major operands keep their memory layout): 32 rows + 4 pad
+#define GB_PANEL (GB_KC * GB_LDK) // floats per panel buffer (>= 32 * GB_LD)
 
+// Stage a 32-row x kc panel with 16-byte loads AND 16-byte LDS stores, in the operand's own memory order:
+//   k-contiguous operand -> LDS [row][k] (stride GB_LD), fragments read as one ds_read_b128 per macro-step
+//   k-major operand      -> LDS [k][row] (stride GB_LDK), fragments read as four ds_read_b32 (bank = 4k + row: the two
+//                           16-lane groups a b32 read serves per cycle never collide)
+// (the first version transposed k-major panels while staging: 4 ds_write_b32 per float4 with a 4-way bank conflict)
 template <bool KMAJOR>
 __device__ static inline void stage_panel(float* __restrict__ sm, const float* __restrict__ p, int ld, int row0, int rows_total,
                                           int k0, int kc, int tid) {
     if (KMAJOR) {
-        // global element (row, k) at p[k * ld + row]: thread -> (k = e / 8, 4 rows = 4 * (e % 8)) ; 32 rows = 8 float4
         for (int e = tid; e < kc * 8; e += 256) {
             const int k = e >> 3, r4 = (e & 7) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + r4 < rows_total) v = *(const float4*)(p + (int64_t)(k0 + k) * ld + row0 + r4);
-            sm[(r4 + 0) * GB_LD + k] = v.x;
-            sm[(r4 + 1) * GB_LD + k] = v.y;
-            sm[(r4 + 2) * GB_LD + k] = v.z;
-            sm[(r4 + 3) * GB_LD + k] = v.w;
+            *(float4*)(sm + k * GB_LDK + r4) = v;
         }
     } else {
-        // global element (row, k) at p[row * ld + k]: thread -> (row = e / (kc/4), 4 k's)
         const int k4n = kc >> 2;
         for (int e = tid; e < 32 * k4n; e += 256) {
             const int row = e / k4n, k4 = (e - row * k4n) * 4;
@@ -56,6 +57,16 @@ __device__ static inline void stage_panel(float* __restrict__ sm, const float* _
             *(float4*)(sm + row * GB_LD + k4) = v;
         }
     }
+}
+
+// fragment of macro-step kk for lane (r, g): elements k = kk + 4 g + c, c = 0..3, of panel row `row`
+template <bool KMAJOR>
+__device__ static inline float4 read_frag(const float* __restrict__ sm, int row, int g, int kk) {
+    if (KMAJOR) {
+        const float* q = sm + (kk + 4 * g) * GB_LDK + row;
+        return make_float4(q[0], q[GB_LDK], q[2 * GB_LDK], q[3 * GB_LDK]);
+    }
+    return *(const float4*)(sm + row * GB_LD + kk + 4 * g);
 }
 
 template <bool AK, bool BK>
@@ -71,12 +82,10 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
         stage_panel<AK>(sA, D.A, D.lda, m0, D.M, k0, kc, tid);
         stage_panel<BK>(sB, D.B, D.ldb, n0, D.N, k0, kc, tid);
         __syncthreads();
-        const float* ap = sA + (wm * 16 + r) * GB_LD + 4 * g;
-        const float* bp = sB + (wn * 16 + r) * GB_LD + 4 * g;
 #pragma unroll 4
         for (int kk = 0; kk < kc; kk += 16) {
-            const float4 a = *(const float4*)(ap + kk);
-            const float4 b = *(const float4*)(bp + kk);
+            const float4 a = read_frag<AK>(sA, wm * 16 + r, g, kk);
+            const float4 b = read_frag<BK>(sB, wn * 16 + r, g, kk);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
@@ -105,8 +114,8 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
 }
 
 __global__ __launch_bounds__(256) void gemm_bundle_kernel(const GemmBundle bundle) {
-    __shared__ __attribute__((aligned(16))) float sA[32 * GB_LD];
-    __shared__ __attribute__((aligned(16))) float sB[32 * GB_LD];
+    __shared__ __attribute__((aligned(16))) float sA[GB_PANEL];
+    __shared__ __attribute__((aligned(16))) float sB[GB_PANEL];
     __shared__ float sQ[4];
     const int t = blockIdx.x;                             // one 32 x 32 block per workgroup
     int gi = 0;
