@@ -558,3 +558,42 @@ def test_gemm_bundle_mfma_vs_numpy(lib, ak, bk):
         np.testing.assert_allclose(sums[i].double().sum().item(), (expect[i] ** 2).sum(), rtol=1e-4)   # per-block sum of C^2
     bad = (_lib.GemmDesc * 1)(_lib.GemmDesc(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), None, 30, 272, 256, 300, 300, 300, ak, bk))
     assert lib.naf_gemm_bundle(bad, 1, st()) == -1            # M not a multiple of 16
+
+
+def test_replay_edge_cases(lib):
+    """Boundary behaviour the reference has by construction: population == batch (random.sample returns a permutation),
+    host add() beyond the pinned staging size, n = 0 appends, sample() on a too-small buffer."""
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    from synth_data import make_transitions
+    S, A = 21, 6
+    # population == batch: every stored transition exactly once
+    buf = ReplayBuffer(64, 64, "cuda", 5, state_size=S, action_size=A)
+    buf.add_rows_device(torch.arange(64 * 64, device="cuda", dtype=torch.float32).view(64, 64), 64)
+    idx = torch.zeros(3, 64, dtype=torch.int32, device="cuda")
+    buf.sample_indices(idx, 3)
+    for b in range(3):
+        assert sorted(idx[b].cpu().tolist()) == list(range(64))
+    np.testing.assert_array_equal(idx.cpu().numpy(), O.replay_sample_indices(5, 0, 64, 64, 3, True))
+    # n = 0 is a no-op
+    buf.add_rows_device(torch.zeros(1, 64, device="cuda"), 0)
+    assert len(buf) == 64 and int(buf.meta[2].item()) == 64
+    # host add(): 2500 transitions through a 1024-row staging area into a 2000-row ring
+    st_, ac, rw, ns, dn = make_transitions(2500, S, A, seed=1)
+    hb = ReplayBuffer(2000, 32, "cuda", 0)
+    with pytest.raises(ValueError):
+        hb.add(st_[0], ac[0], float(rw[0]), ns[0], int(dn[0]))
+        hb.sample()                                                   # 1 < batch_size: same error class as random.sample
+    for i in range(1, 2500):
+        hb.add(st_[i], ac[i], float(rw[i]), ns[i], int(dn[i]))
+    assert len(hb) == 2000
+    hb.flush()
+    expect = O.pack_rows(st_, ac, rw, ns, dn, 64)[-2000:]
+    out = torch.empty(2000, 64, device="cuda")
+    hb.action_mode = 1
+    hb.gather_rows(torch.arange(2000, dtype=torch.int32, device="cuda"), out, 2000)
+    np.testing.assert_array_equal(out.cpu().numpy(), expect)          # FIFO: the newest 2000, oldest first
+    s, a, r, s2, d = hb.sample()
+    assert s.shape == (32, S) and a.dtype == torch.float32           # action_mode FLOAT keeps the continuous action
+    # handle misuse is reported, not executed
+    assert lib.naf_replay_add_batch(None, out.data_ptr(), 1, st()) == -2
+    assert lib.naf_replay_add_batch(hb.handle, out.data_ptr(), 2001, st()) == -1
