@@ -106,7 +106,7 @@ def test_step_gating_trace_matches_reference_g4(scratch_cwd):
         assert len(agent.memory) == 40 and torch.isfinite(agent.learner.theta2).all()
 
 
-def test_learn_api_with_reference_sample_tuple():
+def test_learn_api_with_reference_sample_tuple(scratch_cwd):
     """NAFAgent.learn((states, actions int64, rewards, next_states, dones)) == the reference's losses (G3)."""
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
     from synth_data import make_transitions
@@ -126,7 +126,7 @@ def test_learn_api_with_reference_sample_tuple():
         agent.learn((torch.zeros(3, S), torch.zeros(3, A), torch.zeros(3, 1), torch.zeros(3, S), torch.zeros(3, 1)))
 
 
-def test_soft_update_api():
+def test_soft_update_api(scratch_cwd):
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
     agent = NAFAgent(object(), 21, 6, 256, 8, 100, 1e-3, 0.25, 0.99, 1, 1, 500, DEV, 0)
     with torch.no_grad():
