@@ -62,15 +62,15 @@ class NAFAgent:
         """Positional arguments as the reference (naf_algorithm.py:27-41). Keyword-only extras default to the
         reference's behaviour. data_parallel=None: all-reduce gradients iff torch.distributed is initialised with
         more than one rank."""
-        os.makedirs('checkpoints/', exist_ok=True)
-        _lib.require_gpu()
+        _lib.require_gpu()                               # fail before touching the file system
+        if torch.device(device).type != "cuda":
+            raise _lib.NafHipError(f"NAFAgent needs the MI355X (got device={device}); there is no CPU fallback")
+        os.makedirs('checkpoints/', exist_ok=True)       # as the reference does at construction (:61)
         self.environment = environment
         self.state_size, self.action_size, self.layer_size = state_size, action_size, layer_size
         self.buffer_size, self.learning_rate = buffer_size, learning_rate
         random.seed(seed)
         self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.NafHipError(f"NAFAgent needs the MI355X (got device={device}); there is no CPU fallback")
         self.tau, self.gamma = tau, gamma
         self.update_freq, self.num_updates = update_freq, num_updates
         self.batch_size, self.checkpoint_frequency = batch_size, checkpoint_frequency
