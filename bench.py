@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--p-mode", choices=["hadamard", "matmul"], default="hadamard")
     ap.add_argument("--robot", choices=["kuka", "xarm6", "panda"], default="kuka",
                     help="shapes only: kuka/xarm6 S=21 A=6, panda S=23 A=7 (BASELINE configs[3], [4])")
+    ap.add_argument("--obstacle-jitter", type=float, default=0.0, help="per-env obstacle randomisation (configs[3])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -95,7 +96,8 @@ def main():
     rows = synth_rows(N, S, A, replay.row_floats, replay.off_s2, seed=77 + rank, device=dev)
     replay.add_rows_device(rows, N)
     del rows
-    loop = DeviceEnvLoop(L, replay, E, seed=31 + rank, max_frames=400, use_graph=not args.no_graph)
+    loop = DeviceEnvLoop(L, replay, E, seed=31 + rank, max_frames=400, use_graph=not args.no_graph, robot=args.robot,
+                         obstacle_jitter=args.obstacle_jitter)
     U = E   # update_freq = num_updates = 1: one learn() per env transition (naf_algorithm.py:147-156)
     chunk = TrainChunk(L, replay, U, use_graph=not args.no_graph, gather_outside_graph=True)
     graph_note = "hipGraph"

@@ -198,7 +198,11 @@ int naf_polyak_update(float* target, const float* main, float tau, float one_min
  * (environment/environment.py:431-485 state layout / reward constants); see csrc/synth_env.hip. */
 int naf_synth_env_step(float* env_state, const float* actions, float* out_rows, float* obs_next, int E, int A,
                        uint64_t seed, const uint64_t* counter_dev, int max_frames, void* stream);
-int naf_synth_env_reset(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t counter, void* stream);
+/* preset_host (nullable, HOST pointer, 15 floats): [initial joint positions(8) | target xyz | obstacle xyz |
+ * obstacle_jitter]; NULL = the reference's KUKA demo preset. obstacle_jitter > 0: per-env obstacle position, uniform in
+ * a cube of that half-width around the preset (seeded by (seed, env)). */
+int naf_synth_env_reset(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t counter,
+                        const float* preset_host, void* stream);
 int naf_synth_env_state_floats(int A);
 
 #ifdef __cplusplus

@@ -93,7 +93,7 @@ _PROTOS = {
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
     "naf_polyak_update": [_vp, _vp, _f, _f, _sz, _vp],
     "naf_synth_env_step": [_vp, _vp, _vp, _vp, _i, _i, _u64, _vp, _i, _vp],
-    "naf_synth_env_reset": [_vp, _vp, _i, _i, _u64, _u64, _vp],
+    "naf_synth_env_reset": [_vp, _vp, _i, _i, _u64, _u64, _vp, _vp],
     "naf_synth_env_state_floats": [_i],
 }
 _RESTYPES = {"naf_hip_arch": C.c_char_p}

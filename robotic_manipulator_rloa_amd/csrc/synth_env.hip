@@ -67,14 +67,24 @@ __device__ static inline void env_reset_one(float* st, int e, int A, uint64_t se
     st[22] = 0.f;
 }
 
-__global__ void synth_env_reset_kernel(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t ctr) {
+// preset: [init_q(8) | target(3) | obstacle(3) | obstacle_jitter] — the demo presets of the reference
+// (rl_framework.py:547-555 KUKA, :571-580 xArm6) or the caller's own; obstacle_jitter > 0 gives every env its own
+// obstacle position, uniform in a cube of that half-width around the preset (BASELINE configs[3])
+struct EnvPreset {
+    float v[15];
+};
+
+__global__ void synth_env_reset_kernel(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t ctr,
+                                       const EnvPreset preset) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     float* st = env_state + (int64_t)e * ENV_STATE_FLOATS;
-    const float init_q[8] = {0.9f, 0.45f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // rl_framework.py:553 demo preset
-    const float target[3] = {0.4f, 0.85f, 0.71f}, obstacle[3] = {0.45f, 0.55f, 0.55f};  // :551-552
-    for (int k = 0; k < 8; ++k) st[14 + k] = init_q[k];
-    for (int k = 0; k < 3; ++k) { st[8 + k] = target[k]; st[11 + k] = obstacle[k]; }
+    for (int k = 0; k < 8; ++k) st[14 + k] = preset.v[k];
+    for (int k = 0; k < 3; ++k) { st[8 + k] = preset.v[8 + k]; st[11 + k] = preset.v[11 + k]; }
+    if (preset.v[14] > 0.f) {
+        Philox4 p = philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)e, 0x4f425354u, 0x9E3779B9u, 0x243F6A88u);
+        for (int k = 0; k < 3; ++k) st[11 + k] += (naf_u01(p.v[k]) * 2.f - 1.f) * preset.v[14];
+    }
     st[23] = 0.f;
     env_reset_one(st, e, A, seed, ctr);
     float qd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ee[3];
@@ -132,9 +142,13 @@ __global__ void synth_env_step_kernel(float* env_state, const float* __restrict_
 extern "C" int naf_synth_env_state_floats(int A) { return (A > 0 && A <= NAF_MAX_A) ? ENV_STATE_FLOATS : NAF_ERR_ARG; }
 
 extern "C" int naf_synth_env_reset(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t counter,
-                                   void* stream) {
+                                   const float* preset_host, void* stream) {
     if (!env_state || !obs || E <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
-    synth_env_reset_kernel<<<(E + 63) / 64, 64, 0, (hipStream_t)stream>>>(env_state, obs, E, A, seed, counter);
+    // default: the reference's KUKA demo preset (rl_framework.py:551-553), no obstacle jitter
+    EnvPreset p = {{0.9f, 0.45f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.4f, 0.85f, 0.71f, 0.45f, 0.55f, 0.55f, 0.f}};
+    if (preset_host)
+        for (int k = 0; k < 15; ++k) p.v[k] = preset_host[k];
+    synth_env_reset_kernel<<<(E + 63) / 64, 64, 0, (hipStream_t)stream>>>(env_state, obs, E, A, seed, counter, p);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -121,8 +121,16 @@ class TrainChunk:
 class DeviceEnvLoop:
     """E synthetic manipulator envs living on the GPU (csrc/synth_env.hip) driven by the agent's policy."""
 
+    # [initial joint positions(8) | target | obstacle]: the reference's demo presets (rl_framework.py:547-555, :571-580);
+    # 'panda' has no reference preset (BASELINE configs[4] names only the URDF): a reachable target/obstacle pair
+    PRESETS = {
+        "kuka": [0.9, 0.45, 0, 0, 0, 0, 0, 0, 0.4, 0.85, 0.71, 0.45, 0.55, 0.55],
+        "xarm6": [0.0, 1.0, 0.0, -2.3, 0.0, 0.0, 0.0, 0, 0.3, 0.47, 0.61, 0.25, 0.27, 0.5],
+        "panda": [0.0, -0.6, 0.0, -2.0, 0.0, 1.6, 0.8, 0, 0.45, 0.3, 0.6, 0.35, 0.2, 0.45],
+    }
+
     def __init__(self, learner: Learner, replay: ReplayBuffer, n_envs: int, seed: int, max_frames: int = 400,
-                 noise_scale: float = 1.0, use_graph: bool = True):
+                 noise_scale: float = 1.0, use_graph: bool = True, robot: str = "kuka", obstacle_jitter: float = 0.0):
         self.L, self.replay, self.E = learner, replay, int(n_envs)
         lay, dev = learner.lay, learner.dev
         self.lib = learner.lib
@@ -137,11 +145,13 @@ class DeviceEnvLoop:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph
         self.env_steps = 0
+        import ctypes
+        self._preset = (ctypes.c_float * 15)(*(self.PRESETS[robot] + [float(obstacle_jitter)]))
         self.reset()
 
     def reset(self) -> None:
         check(self.lib.naf_synth_env_reset(ptr(self.env_state), ptr(self.actor.obs), self.E, self.L.lay.A, self.seed, 0,
-                                           stream_ptr()), "synth_env_reset")
+                                           self._preset, stream_ptr()), "synth_env_reset")
 
     def _body(self) -> None:
         st = stream_ptr()

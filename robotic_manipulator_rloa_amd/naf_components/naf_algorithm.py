@@ -249,7 +249,8 @@ class NAFAgent:
         return type(self.qnetwork_main.state_dict())((k, v.cpu()) for k, v in self.qnetwork_main.state_dict().items())
 
     # ---- training loop with E on-device synthetic envs (the many-env path of BASELINE configs[1..4]) -----------
-    def run_vectorized(self, vector_steps: int, n_envs: int = 64, max_frames: int = 400, noise_scale: float = 1.0) -> dict:
+    def run_vectorized(self, vector_steps: int, n_envs: int = 64, max_frames: int = 400, noise_scale: float = 1.0,
+                       robot: str = "kuka", obstacle_jitter: float = 0.0) -> dict:
         """E synthetic arms on the GPU feed the HBM replay ring; each vector step is followed by
         E * num_updates / update_freq learn() calls, i.e. the reference's update-to-data ratio. Returns counters;
         everything stays on the device (no host sync per step)."""
@@ -258,7 +259,7 @@ class NAFAgent:
             raise ValueError("n_envs * num_updates must be a multiple of update_freq")
         U = E * self.num_updates // self.update_freq
         loop = DeviceEnvLoop(self.learner, self.memory, E, seed=self.seed + 104729 * self.rank, max_frames=max_frames,
-                             noise_scale=noise_scale, use_graph=self.use_graph)
+                             noise_scale=noise_scale, use_graph=self.use_graph, robot=robot, obstacle_jitter=obstacle_jitter)
         chunk = TrainChunk(self.learner, self.memory, U, use_graph=self.use_graph)
         self.memory.flush()
         t0 = time.time()

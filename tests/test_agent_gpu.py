@@ -244,7 +244,7 @@ def test_device_env_kernel_matches_numpy_environment():
     obs = torch.zeros(E, S, device=DEV)
     rows = torch.zeros(E, 64, device=DEV)
     stream = torch.cuda.current_stream().cuda_stream
-    assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 5, 0, stream) == 0
+    assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 5, 0, None, stream) == 0
     envs = [SyntheticEnvironment(A) for _ in range(E)]
     q0 = st[:, :A].cpu().numpy()
     for e, env in enumerate(envs):
@@ -301,3 +301,28 @@ def test_naf_forward_is_differentiable_like_the_reference():
     with torch.no_grad():
         _, q2, _ = net(torch.from_numpy(st).to(DEV), u.to(DEV))
     assert not q2.requires_grad
+
+
+def test_device_env_presets_and_per_env_obstacles():
+    """BASELINE configs[3]: per-env randomised obstacle positions (seeded by (seed, env)); xArm6 / Panda presets."""
+    import ctypes
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.engine import DeviceEnvLoop
+    lib = _lib.load()
+    E, A, S = 16, 6, 21
+    nst = lib.naf_synth_env_state_floats(A)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for rep in range(2):
+        st = torch.zeros(E, nst, device=DEV)
+        obs = torch.zeros(E, S, device=DEV)
+        preset = (ctypes.c_float * 15)(*(DeviceEnvLoop.PRESETS["xarm6"] + [0.1]))
+        assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 77, 0, preset, stream) == 0
+        outs.append(obs.cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])                               # deterministic in (seed, env)
+    o = outs[0]
+    np.testing.assert_allclose(o[:, 15:18], np.tile([0.3, 0.47, 0.61], (E, 1)), atol=1e-6)     # shared target
+    obst = o[:, 18:21]
+    assert np.abs(obst - np.array([0.25, 0.27, 0.5])).max() <= 0.1 + 1e-6 and len({tuple(x) for x in obst.round(5)}) == E
+    np.testing.assert_allclose(o[:, 1], 1.0, atol=0.1 + 1e-6)                        # xArm6 initial joints (+-0.1 variation)
+    np.testing.assert_allclose(o[:, 3], -2.3, atol=0.1 + 1e-6)
