@@ -322,3 +322,39 @@ def test_pybullet_environment_adapter_with_fake_simulator(monkeypatch):
     f.delete_environment()
     for m in ("robotic_manipulator_rloa_amd.utils.collision_detector", "robotic_manipulator_rloa_amd.environment.environment"):
         sys.modules.pop(m, None)
+
+
+def test_framework_misc_api_contract(tmp_path, monkeypatch):
+    """Small pieces of the ManipulatorFramework surface the reference's tests pin (tests/.../test_rl_framework.py):
+    log-level setter, plot_training_rewards' missing-file error and its block means, delete_* on empty state."""
+    import json
+    import logging
+    from robotic_manipulator_rloa_amd import ManipulatorFramework
+    from robotic_manipulator_rloa_amd.utils.logger import get_global_logger
+    monkeypatch.chdir(tmp_path)
+    f = ManipulatorFramework()
+    f.set_log_level(10)
+    assert get_global_logger().level == 10
+    f.get_required_hyperparameters()
+    f.set_log_level(15)                                    # invalid: level unchanged
+    assert get_global_logger().level == 10
+    f.set_log_level(20)
+    with pytest.raises(FileNotFoundError):
+        f.plot_training_rewards(7)
+    os.makedirs("checkpoints/4")
+    with open("checkpoints/4/scores.txt", "w") as fh:
+        fh.write(json.dumps({str(i): (float(i), 10) for i in range(1, 9)}))
+    import types
+    shown = {}
+    fake_plt = types.ModuleType("matplotlib.pyplot")
+    fake_plt.plot = lambda x, y: shown.update(x=list(x), y=list(y))
+    fake_plt.show = lambda: None
+    monkeypatch.setitem(sys.modules, "matplotlib", types.ModuleType("matplotlib"))
+    monkeypatch.setitem(sys.modules, "matplotlib.pyplot", fake_plt)
+    f.plot_training_rewards(4, mean_range=4)
+    assert shown["y"] == [2.5, 6.5] and shown["x"] == [0, 1]   # means of episodes 1-4 and 5-8
+    f.delete_environment()
+    f.delete_naf_agent()
+    f.get_environment_configuration()
+    f.get_nafagent_configuration()
+    assert f.env is None and f.naf_agent is None
