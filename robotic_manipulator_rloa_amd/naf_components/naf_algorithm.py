@@ -273,3 +273,61 @@ class NAFAgent:
         dt = time.time() - t0
         return {"env_steps": vector_steps * E, "updates": updates, "seconds": dt,
                 "env_steps_per_s": vector_steps * E / dt, "last_loss": float(chunk.losses()[-1].item()) if updates else None}
+
+    # ---- training loop with E host environments in worker processes (PyBullet or any env with the reference protocol) --
+    def run_host_vectorized(self, vec_env, vector_steps: int, async_policy: bool = False, noise_scale: float = 1.0) -> dict:
+        """vec_env: environment.vector_env.HostVectorEnv with E envs. Per vector step: batched act() on the GPU for the E
+        current states -> workers step their envs -> E transitions packed into pinned memory -> one H2D copy -> HBM
+        replay ring -> E * num_updates / update_freq learn() calls (the reference's update-to-data ratio).
+        async_policy=False keeps the reference's ordering (the policy of step t has seen every update of step t-1);
+        async_policy=True enqueues the learn() chunk of step t-1 behind act(t), so the GPU learns while the workers
+        simulate (the policy then lags by one vector step: "asynchronous many-env training")."""
+        E = vec_env.E
+        if (E * self.num_updates) % self.update_freq != 0:
+            raise ValueError("n_envs * num_updates must be a multiple of update_freq")
+        U = E * self.num_updates // self.update_freq
+        L, lay = self.learner, self.learner.lay
+        actor = ActPath(L, E, seed=(self.seed * 40503 + 7 + self.rank) & 0xFFFFFFFFFFFFFFFF)
+        chunk = TrainChunk(L, self.memory, U, use_graph=self.use_graph)
+        obs_pin = torch.zeros(E, lay.S, dtype=torch.float32).pin_memory()
+        act_pin = torch.zeros(E, lay.A, dtype=torch.float32).pin_memory()
+        rows_pin = torch.zeros(E, lay.row_floats, dtype=torch.float32).pin_memory()
+        rows_dev = torch.zeros(E, lay.row_floats, dtype=torch.float32, device=self.device)
+        rows_np, obs_np = rows_pin.numpy(), obs_pin.numpy()
+        self.memory.flush()
+        obs = vec_env.reset()
+        t0 = time.time()
+        updates, reward_sum, pending_learn = 0, 0.0, False
+        stream = torch.cuda.current_stream()
+        for _ in range(vector_steps):
+            obs_np[...] = obs
+            actor.obs.copy_(obs_pin, non_blocking=True)
+            actor.act(noise_scale)
+            act_pin.copy_(actor.actions, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            if async_policy and pending_learn:
+                chunk.run()                                   # learns on step t-1's data while the workers simulate step t
+                updates += U
+                pending_learn = False
+            ev.synchronize()
+            _, _, rewards, _, _, obs = vec_env.step(act_pin.numpy())
+            reward_sum += float(rewards.sum())
+            vec_env.pack_rows(rows_np, lay.off_s2)
+            rows_dev.copy_(rows_pin, non_blocking=True)
+            self.memory.add_rows_device(rows_dev, E)
+            if len(self.memory) > self.batch_size:
+                if async_policy:
+                    pending_learn = True
+                else:
+                    chunk.run()
+                    updates += U
+            stream.synchronize()                              # rows_pin / obs_pin are rewritten next iteration
+        if pending_learn:
+            chunk.run()
+            updates += U
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        return {"env_steps": vector_steps * E, "updates": updates, "seconds": dt, "env_steps_per_s": vector_steps * E / dt,
+                "mean_reward": reward_sum / (vector_steps * E), "episodes_finished": vec_env.episodes_finished,
+                "last_loss": float(chunk.losses()[-1].item()) if updates else None}

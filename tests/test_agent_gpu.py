@@ -326,3 +326,33 @@ def test_device_env_presets_and_per_env_obstacles():
     assert np.abs(obst - np.array([0.25, 0.27, 0.5])).max() <= 0.1 + 1e-6 and len({tuple(x) for x in obst.round(5)}) == E
     np.testing.assert_allclose(o[:, 1], 1.0, atol=0.1 + 1e-6)                        # xArm6 initial joints (+-0.1 variation)
     np.testing.assert_allclose(o[:, 3], -2.3, atol=0.1 + 1e-6)
+
+
+def _make_env6():
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
+    return SyntheticEnvironment(6, initial_positions_variation_range=[0.1] * 6)
+
+
+@pytest.mark.parametrize("async_policy", [False, True])
+def test_host_vector_env_training_end_to_end(scratch_cwd, async_policy):
+    """E environments in worker processes feed the HBM replay ring through pinned staging; batched act on the GPU;
+    E learn() per vector step once len(memory) > batch_size."""
+    from robotic_manipulator_rloa_amd.environment.vector_env import HostVectorEnv
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    E = 8
+    vec = HostVectorEnv(_make_env6, E, 21, 6, envs_per_worker=4, max_frames=20, seed=1)
+    try:
+        agent = NAFAgent(None, 21, 6, 256, 32, 1000, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+        out = agent.run_host_vectorized(vec, vector_steps=12, async_policy=async_policy)
+        assert out["env_steps"] == 96 and len(agent.memory) == 96 and int(agent.memory.meta[1].item()) == 96
+        # learning starts at the first vector step that leaves len(memory) > 32, i.e. after step 5 (40 rows): 8 steps x 8
+        assert out["updates"] == 64 and int(agent.learner.step_dev.item()) == 64
+        assert out["episodes_finished"] == 0 and np.isfinite(out["last_loss"]) and out["mean_reward"] < 0
+        rows = agent.memory.rows[:96].cpu().numpy()
+        s, a, r, s2, d = O.unpack_rows(rows, 21, 6)
+        np.testing.assert_allclose(s2[:, :6], s[:, :6] + a / 240.0, atol=1e-6)      # the worker envs' transitions, intact
+        assert np.abs(a).max() <= 1.0 and (d == 0).all()
+        e0 = rows[0::E]
+        np.testing.assert_array_equal(e0[1:, :21], O.unpack_rows(e0[:-1], 21, 6)[3])   # env 0's states chain step to step
+    finally:
+        vec.close()

@@ -358,3 +358,51 @@ def test_framework_misc_api_contract(tmp_path, monkeypatch):
     f.get_environment_configuration()
     f.get_nafagent_configuration()
     assert f.env is None and f.naf_agent is None
+
+
+def _make_synth_env():
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
+    return SyntheticEnvironment(6, initial_positions_variation_range=[0.1] * 6)
+
+
+def test_host_vector_env_workers_match_serial_envs():
+    """HostVectorEnv (worker processes + shared memory) against the same envs stepped serially in this process: same
+    transitions, per-env auto-reset on the frame budget, row packing in the HBM layout."""
+    import random
+    from robotic_manipulator_rloa_amd.environment.vector_env import HostVectorEnv
+    E, S, A = 6, 21, 6
+    vec = HostVectorEnv(_make_synth_env, E, S, A, envs_per_worker=2, max_frames=5, seed=3)
+    try:
+        obs = vec.reset().copy()
+        # serial twin: worker w seeds Python's RNG with seed + first env index, then resets its envs in order
+        twins = []
+        for first in range(0, E, 2):
+            random.seed(3 + first)
+            envs = [_make_synth_env() for _ in range(2)]
+            states = [e.reset(False) for e in envs]
+            twins.append((first, envs, states))
+        for first, envs, states in twins:
+            for j in range(2):
+                np.testing.assert_allclose(obs[first + j], states[j], atol=1e-12)
+        rng = np.random.default_rng(0)
+        cur = obs.copy()
+        for t in range(7):
+            actions = rng.uniform(-1, 1, (E, A)).astype(np.float32)
+            st, ac, rw, ns, dn, nxt = vec.step(actions)
+            np.testing.assert_array_equal(st, cur)
+            np.testing.assert_array_equal(ac, actions)
+            # the env's own dynamics (velocity control for one tick)
+            np.testing.assert_allclose(ns[:, :A], st[:, :A] + actions / 240.0, atol=1e-6)
+            rows = np.zeros((E, 64), np.float32)
+            vec.pack_rows(rows, 28)
+            exp = O.pack_rows(st.astype(np.float32), ac, rw.astype(np.float32), ns.astype(np.float32), dn.astype(np.float32), 64)
+            np.testing.assert_array_equal(rows, exp)
+            if t == 4:                                       # frame budget of 5 reached: every env was reset
+                assert vec.arr["episode_end"].sum() == E and vec.episodes_finished == E
+                assert not np.allclose(nxt, ns)               # next observation = reset state, stored next_state = true one
+            elif t < 4:
+                np.testing.assert_array_equal(nxt, ns)
+            cur = nxt.copy()
+    finally:
+        vec.close()
+    assert all(not p.is_alive() for p in vec._procs)
