@@ -54,9 +54,13 @@ class ReplayBuffer:
         check(self.lib.naf_replay_create(self.buffer_size, S, A, ptr(self.rows), ptr(self.meta), _lib.C.byref(h)),
               "naf_replay_create")
         self._handle = h
-        self._stage_host = torch.zeros(_STAGE_ROWS, self.row_floats, dtype=torch.float32).pin_memory()
-        self._stage_np = self._stage_host.numpy()
-        self._stage_dev = torch.zeros(_STAGE_ROWS, self.row_floats, dtype=torch.float32, device=self.device)
+        # two pinned staging areas used alternately: the H2D copy of one is in flight while add() fills the other, so a
+        # flush does not have to wait for its own copy (one event wait, normally already satisfied, before reuse)
+        self._stage_hosts = [torch.zeros(_STAGE_ROWS, self.row_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._stage_events = [torch.cuda.Event(), torch.cuda.Event()]
+        self._stage_devs = [torch.zeros(_STAGE_ROWS, self.row_floats, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._stage_cur = 0
+        self._stage_np = self._stage_hosts[0].numpy()
         self._idx = torch.zeros(self.batch_size, dtype=torch.int32, device=self.device)
         self._sample_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
 
@@ -96,12 +100,17 @@ class ReplayBuffer:
         n = self._pending
         if n == 0:
             return
-        self._stage_dev[:n].copy_(self._stage_host[:n], non_blocking=True)
+        cur = self._stage_cur
+        host, dev = self._stage_hosts[cur], self._stage_devs[cur]
+        dev[:n].copy_(host[:n], non_blocking=True)
         for lo in range(0, n, self.buffer_size):      # a ring smaller than the staging area: append in ring-sized pieces
             k = min(self.buffer_size, n - lo)
-            self.add_rows_device(self._stage_dev[lo:lo + k], k, _count=False)
-        # the pinned staging buffer is rewritten by the next add(): wait for the H2D copy (one event per flush)
-        torch.cuda.current_stream().synchronize()
+            self.add_rows_device(dev[lo:lo + k], k, _count=False)
+        self._stage_events[cur].record()
+        # switch to the other staging area; its previous copy (two flushes ago) has long completed
+        self._stage_cur = cur ^ 1
+        self._stage_events[self._stage_cur].synchronize()
+        self._stage_np = self._stage_hosts[self._stage_cur].numpy()
         self._pending = 0
 
     def add_rows_device(self, rows_dev: torch.Tensor, n: int, _count: bool = True) -> None:
