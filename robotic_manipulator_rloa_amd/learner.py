@@ -5,10 +5,11 @@
 Design:
   * all learner state lives in a few flat f32 HBM allocations: theta2[2, P] (row 0 = main net, row 1 = target
     net), grad[P], adam m[P], v[P]; parameters of the nn.Module facades are views into them.
-  * the dense GEMMs stay on PyTorch-ROCm (torch.bmm / torch.mm with out=, hipBLASLt underneath); main and
-    target forward share every launch (batch-2 bmm, 2-net BN kernel).
-  * everything else is libnaf_hip.so: bias+BatchNorm+ReLU fwd/bwd, the fused NAF head (fwd + TD target + MSE +
-    bwd), grad-norm partials, clip+Adam+Polyak in one pass.
+  * the big trunk GEMMs stay on PyTorch-ROCm (torch.bmm / torch.mm with out=; rocBLAS kernels picked by the shipped
+    TunableOp results); main and target forward share every launch (batch-2 bmm, 2-net BN kernel).
+  * everything else is libnaf_hip.so: bias+BatchNorm+ReLU fwd/bwd (with the K=21 and N=32 GEMMs folded in), the
+    fused NAF head (fwd + TD target + MSE + bwd), the backward GEMM bundle on f32 MFMA, grad-norm partials,
+    clip+Adam+Polyak in one pass.
   * the three head Linears are one GEMM against Wh[NHP, H+8]: column H of Wh is the bias and the activation
     buffer carries a constant-1 column there, so bias add and bias gradient ride inside the GEMMs.
   * no host sync anywhere: step count, clip factor, replay size and sampler counters live on the device, so a
@@ -16,7 +17,6 @@ Design:
 """
 from __future__ import annotations
 
-import ctypes as C
 import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -152,17 +152,16 @@ class Learner:
         self.p_mode = int(p_mode)
         self.world_size = int(world_size)
         self.pg = process_group
-        # Small GEMMs (K = state size 21, N = heads 32) folded into the BN / head kernels (csrc/fused_layers.hip).
-        # Measured per launch at B=256 (benchmarks/kernel_probe.py) and in the bench (updates/s):
-        #   l1 = layer 1 forward (4.5 us vs bmm 3.0 + bn 3.4) and backward incl. dW1 (7.5 vs 3.7 + 3.7); the pair goes
-        #        together because the fused forward does not materialise the pre-BN GEMM output the unfused backward reads
-        #   b2 = dA2 = dH @ Wh folded into layer 2's BN backward (5.5 vs mm 2.7 + bn_bwd 3.7)
-        #   f3 = MFMA heads GEMM + head in one launch (8.1 vs 3.2 + 4.1: slower, off)
-        # NAF_FUSE = comma list out of {l1,b2,gb,f3}, "all" or "none".
+        # Which GEMMs are folded into our own kernels (NAF_FUSE = comma list out of {l1,b2,gb,f3}, "all" or "none").
+        # Per-launch costs at B=256 from benchmarks/kernel_probe.py, updates/s from bench.py:
+        #   l1 = layer 1 (K = state size): GEMM + BN + ReLU forward in one launch (4.5 us vs bmm 3.0 + bn 3.4) and BN
+        #        backward + dW1 in one (7.3 vs 3.7 + 3.7); they go together because the fused forward does not
+        #        materialise the pre-BN GEMM output the unfused backward reads
+        #   b2 = dA2 = dH @ Wh (K = 32 heads) folded into layer 2's BN backward (5.0 vs mm 2.7 + bn_bwd 3.7)
         #   gb = dWh, dW2, dA1 as ONE grid of LDS-staged f32-MFMA 32x32 blocks (csrc/gemm_bundle.hip) instead of three
-        #        rocBLAS launches: 6.2 us vs 3.8 + 3.2 + 3.8 (a first version fed the MFMA fragments straight from L2 with
-        #        4-byte loads and took 10.2 us: 256 load instructions per lane per tile saturate the vector memory pipe)
-        # none 14.99k, l1+b2 16.33k, l1+b2+gb 17.24k updates/s
+        #        rocBLAS launches (6.2 vs 3.8 + 3.2 + 3.8)
+        #   f3 = MFMA heads GEMM + head in one launch (8.1 vs 3.2 + 3.6: slower, off)
+        # none 15.0k -> l1,b2 16.3k -> l1,b2,gb 18.0k updates/s (18.7k with the grad norm folded in, below).
         # The folded kernels keep their operand rows in registers (ceil(B/64) rows per thread): they win up to B = 512
         # and spill beyond (B=1024: 3.8k vs 9.0k updates/s unfused; B=2048: 1.3k vs 5.6k), where rocBLAS also beats the
         # bundle (longer K) — so large batches default to the unfused chain.
