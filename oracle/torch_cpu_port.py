@@ -163,11 +163,12 @@ def time_baseline(S=21, A=6, H=256, B=256, N=1_000_000, fill=None, budget_s=15.0
     rng = np.random.default_rng(seed)
     agent = TorchCpuAgent(S, A, H, B, N, seed=seed)
     fill = N if fill is None else fill
-    st = rng.standard_normal((4096, S))
-    ac = rng.uniform(-1, 1, (4096, A)).astype(np.float32)
+    # every stored transition owns its arrays (views of two big blocks), as in a real run where each env state is a
+    # fresh ndarray: deque + random.sample then see the same pointer-chasing the reference does
+    st = rng.standard_normal((fill + 4097, S))
+    ac = rng.uniform(-1, 1, (fill + 4097, A)).astype(np.float32)
     for i in range(fill):
-        k = i & 4095
-        agent.memory.append((st[k], ac[k], -0.5, st[(k + 1) & 4095], 0))
+        agent.memory.append((st[i], ac[i], -0.5, st[i + 1], 0))
     # learn() only
     ex = agent.sample()
     for _ in range(3):
@@ -178,11 +179,11 @@ def time_baseline(S=21, A=6, H=256, B=256, N=1_000_000, fill=None, budget_s=15.0
         n_learn += 1
     t_learn = (time.perf_counter() - t0) / n_learn
     # full timestep
-    s = st[0]
+    s = st[fill]
     t0, n_step = time.perf_counter(), 0
     while time.perf_counter() - t0 < budget_s * 0.7:
         a = agent.act(s)
-        s2 = st[(n_step + 1) & 4095]
+        s2 = st[fill + ((n_step + 1) & 4095)]
         agent.step(s, a, -0.5, s2, 0)
         s = s2
         n_step += 1
