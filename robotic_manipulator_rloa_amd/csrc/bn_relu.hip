@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_eval_kernel(const float* __re
 // Tile shapes to choose from (dev knob naf_debug_set(0, id); the default was picked with benchmarks/kernel_probe.py)
 static int g_bn_tile = -1;  // -1 = by batch size: 8 columns x 64 row phases up to B = 512 (fwd 3.3 us / bwd 3.7 us per launch
                             // at B=256; 32x32: 4.5 / 5.6), 8 x 128 beyond (B=2048: 8.3 / 10.1 us vs 10.7 / 15.4 for 8 x 64)
+extern int g_gather_nt;   // replay.hip
 extern "C" int naf_debug_set(int key, int value) {
     if (key == 0) g_bn_tile = value;
+    if (key == 1) g_gather_nt = value;
     return NAF_OK;
 }
 

@@ -226,7 +226,9 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
 // several index->row dependent loads are in flight per lane. Algorithmic traffic: 4*(2S+A+2) B read +
 // the same written per row (400 B at S=21/A=6); physical: 2 x row_floats*4 B.
 // ------------------------------------------------------------------------------------------------
-template <int RPT>
+typedef float nt_f4 __attribute__((ext_vector_type(4)));   // native vector type the nontemporal builtins accept
+
+template <int RPT, int NT /* bit 0: nontemporal loads, bit 1: nontemporal stores */>
 __global__ __launch_bounds__(256) void replay_gather_rows_kernel(const float4* __restrict__ ring,
                                                                  uint64_t* __restrict__ meta,
                                                                  const int32_t* __restrict__ idx,
@@ -256,7 +258,15 @@ __global__ __launch_bounds__(256) void replay_gather_rows_kernel(const float4* _
     float4 v[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-        if (ok[k]) v[k] = ring[(pos[k] << rf4_shift) + c];
+        if (ok[k]) {
+            // bulk launches (RPT > 1) stream: every ring row is touched once, nothing is re-read by this kernel
+            if (NT & 1) {
+                const nt_f4 t = __builtin_nontemporal_load((const nt_f4*)&ring[(pos[k] << rf4_shift) + c]);
+                v[k] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                v[k] = ring[(pos[k] << rf4_shift) + c];
+            }
+        }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         if (!ok[k]) continue;
@@ -269,9 +279,17 @@ __global__ __launch_bounds__(256) void replay_gather_rows_kernel(const float4* _
             if (f0 + 3 >= trunc_lo && f0 + 3 < trunc_hi) v[k].w = truncf(v[k].w);
         }
         int64_t r = row0 + (int64_t)k * lanes_per_block_rows;
-        out[(r << rf4_shift) + c] = v[k];
+        if (NT & 2) {
+            nt_f4 t = {v[k].x, v[k].y, v[k].z, v[k].w};
+            __builtin_nontemporal_store(t, (nt_f4*)&out[(r << rf4_shift) + c]);
+        } else {
+            out[(r << rf4_shift) + c] = v[k];        // minibatch-sized launches: the learner reads these rows next
+        }
     }
 }
+
+// bulk launches: cache policy of the streamed rows (bit 0 nontemporal loads, bit 1 nontemporal stores)
+int g_gather_nt = -1;   // -1 = default (nontemporal stores on bulk launches)
 
 extern "C" int naf_replay_gather_rows(naf_replay_t* h, const int32_t* idx, float* out_rows, int n, int action_mode,
                                       void* stream) {
@@ -288,13 +306,25 @@ extern "C" int naf_replay_gather_rows(naf_replay_t* h, const int32_t* idx, float
     // small launches: 1 row per lane-group so that every CU gets a workgroup; bulk launches: 4 rows in flight
     if ((int64_t)n <= 256 * 8 * rows_per_pass) {
         int blocks = (n + rows_per_pass - 1) / rows_per_pass;
-        replay_gather_rows_kernel<1><<<blocks, 256, 0, st>>>((const float4*)h->rows, h->meta, idx, (float4*)out_rows, n,
+        replay_gather_rows_kernel<1, 0><<<blocks, 256, 0, st>>>((const float4*)h->rows, h->meta, idx, (float4*)out_rows, n,
                                                              h->capacity, sh, lo, hi);
     } else {
         int per_block = rows_per_pass * 4;
         int blocks = (n + per_block - 1) / per_block;
-        replay_gather_rows_kernel<4><<<blocks, 256, 0, st>>>((const float4*)h->rows, h->meta, idx, (float4*)out_rows, n,
-                                                             h->capacity, sh, lo, hi);
+#define GATHER_BULK(NTV)                                                                                              \
+    replay_gather_rows_kernel<4, NTV><<<blocks, 256, 0, st>>>((const float4*)h->rows, h->meta, idx, (float4*)out_rows, n, \
+                                                              h->capacity, sh, lo, hi)
+        // The gathered rows are written once and not re-read by this kernel: nontemporal STORES keep them from evicting
+        // ring lines (measured, 4 Mi rows per launch, interleaved A/B: 977 MiB ring 0.393 -> 0.340 ms, 244 MiB ring
+        // 0.346 -> 0.300 ms). Nontemporal LOADS of the ring do not help (0.388 ms) and cost 10 % on a ring that fits the
+        // 256 MiB Infinity Cache, so loads stay temporal. naf_debug_set(1, mode) overrides for A/B timing.
+        int nt = g_gather_nt < 0 ? 2 : g_gather_nt;
+        switch (nt) {
+            case 1: GATHER_BULK(1); break;
+            case 2: GATHER_BULK(2); break;
+            case 3: GATHER_BULK(3); break;
+            default: GATHER_BULK(0); break;
+        }
     }
     NAF_CHECK_LAUNCH();
     return NAF_OK;
