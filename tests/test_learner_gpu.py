@@ -85,7 +85,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
 
 @pytest.mark.parametrize("fused", ["none", "all"])
 @pytest.mark.parametrize("p_mode", [0, 1])
-@pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64)])
+@pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32)])
 def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
     monkeypatch.setenv("NAF_FUSE", fused)
     """20 updates against the f32 numpy oracle (Hadamard = reference semantics; matmul = textbook NAF)."""
