@@ -225,7 +225,7 @@ assert torch.equal(both[0], both[1]), both        # replicas stay in lock-step
 assert parallel.rank_seed(0, 0) == 0 and parallel.rank_seed(0, 1) != parallel.rank_seed(0, 0)
 assert [parallel.units_per_rank(130, 4, r) for r in range(4)] == [33, 33, 32, 32]
 dist.barrier(); dist.destroy_process_group()
-print("DP_OK", rank)
+os.write(1, f"DP_OK_{rank};".encode())      # one atomic write per rank: the two ranks share stdout
 '''
 
 
@@ -239,7 +239,7 @@ def test_data_parallel_world2_gloo(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "DP_OK 0" in r.stdout and "DP_OK 1" in r.stdout
+    assert "DP_OK_0;" in r.stdout and "DP_OK_1;" in r.stdout, r.stdout[-2000:]
 
 
 def test_bench_cli_contract_is_parseable():
