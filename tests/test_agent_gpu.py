@@ -201,7 +201,7 @@ import os, sys
 sys.path.insert(0, os.environ["NAF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NAF_ROOT"], "tests")); sys.path.insert(0, os.path.join(os.environ["NAF_ROOT"], "tests", "golden"))
 import numpy as np, torch, torch.distributed as dist
 from robotic_manipulator_rloa_amd import parallel
-os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["NAF_TEST_PORT"])
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 from test_learner_gpu import _kuka_learner_and_replay
@@ -226,9 +226,14 @@ print("RCCL_CAPTURE_OK")
 def test_rccl_allreduce_inside_captured_graph_world1(tmp_path):
     """The N > 1 launch structure on the one GPU available here: an RCCL all-reduce of the flat gradient captured
     inside the learn() graph (world_size 1, so the sum is the identity and the result must be bit-identical)."""
+    import socket
     script = tmp_path / "dp1.py"
     script.write_text(_DP1)
-    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, NAF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    r = subprocess.run([sys.executable, str(script)],
+                       env=dict(os.environ, NAF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", NAF_TEST_PORT=port),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_CAPTURE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 

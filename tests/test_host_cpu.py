@@ -232,11 +232,15 @@ os.write(1, f"DP_OK_{rank};".encode())      # one atomic write per rank: the two
 def test_data_parallel_world2_gloo(tmp_path):
     """N > 1 path on CPU: 2 ranks over gloo — parameter broadcast, per-rank shards, ONE sum all-reduce of the flat
     gradient laid out by NetLayout, identical clip+Adam on both ranks."""
+    import socket
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
-    env = dict(os.environ, NAF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="2")
+    with socket.socket() as sock:                      # a port nobody is using right now
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, NAF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DP_OK_0;" in r.stdout and "DP_OK_1;" in r.stdout, r.stdout[-2000:]
