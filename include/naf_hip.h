@@ -162,9 +162,10 @@ int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int 
 
 /* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
 /* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is
- * [N][K] row-major (b_kmajor = 0; i.e. C = A B^T like torch Linear) or [K][N] (b_kmajor = 1). M, N, K multiples of 16.
+ * [N][K] row-major (b_kmajor = 0; i.e. C = A B^T like torch Linear) or [K][N] (b_kmajor = 1). M, N, K multiples of 16;
+ * A and B 16-byte aligned with lda, ldb multiples of 4 (panels are staged into LDS with 16-byte loads).
  * Replaces the dW2 / dA1 / dWh GEMMs of the backward pass (autograd of naf_neural_network.py:76-87) with one grid of
- * f32-MFMA 16x16 tiles. */
+ * 32 x 32 output blocks computed on v_mfma_f32_16x16x4_f32. `descs` is a HOST array (copied into the launch). */
 #define NAF_GEMM_BUNDLE_MAX 4
 typedef struct naf_gemm_desc {
     const float* A;
@@ -182,7 +183,8 @@ int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
 #define NAF_NORM_CHUNK 4096
 int naf_grad_norm_partials(const float* g, size_t n, float* partials, int32_t* step_dev, void* stream);
 /* second half of clip_grad_norm_ + Adam.step() (naf_algorithm.py:209-210) + soft_update (:217-226) in one
- * pass over {theta, g, m, v, theta_target}: 36 B/param. grad = g * inv_world * clip, clip =
+ * pass over {theta, g, m, v, theta_target}: 36 B/param. `partials`: sums of squares covering every gradient element once
+ * (from naf_grad_norm_partials, or the sumsq outputs of the gradient-producing kernels). grad = g * inv_world * clip, clip =
  * min(1, max_norm / (inv_world*sqrt(sum partials) + 1e-6)); Adam with torch defaults' formulas and bias
  * correction at t = *step_dev; theta_target = tau*theta_new + one_minus_tau*theta_target.
  * theta_target may be NULL (no Polyak). */
