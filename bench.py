@@ -162,10 +162,15 @@ def main():
         "config": {"workload": f"{'configs[1]: ' if (args.robot, B, N, E) == ('kuka', 256, 1000000, 64) else ''}{args.robot} shapes "
                                f"S={S} A={A} H=256, {E} envs/GPU, batch {B}, HBM replay {N}, "
                                f"HIP NAF head ({args.p_mode} P), {U} learn() per vector step",
-                   "launch": graph_note, "parallelism": f"dp{world}" if world > 1 else "single"},
+                   "launch": graph_note, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "grad_exchange": ("none" if world == 1 else
+                                     "one-shot peer-memory all-reduce over xGMI (csrc/xgmi_reduce.hip)" if L.xgmi is not None
+                                     else "RCCL all-reduce")},
         "updates_per_s": round(updates / elapsed, 1),
         "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": int(L.step_dev.item())},
     }
+    if L.xgmi is not None:
+        out["sanity"]["xgmi_allreduces"], out["sanity"]["xgmi_timed_out_waits"] = L.xgmi.status()
     # ---- roofline of the replay gather (the kernel north_star names), measured live with events -----------
     rows_per_launch = U * B
     alg_bytes = rows_per_launch * (4 * (2 * S + A + 2) * 2 + 4)       # 400 B/row read+written + 4 B index

@@ -207,6 +207,31 @@ int naf_synth_env_reset(float* env_state, float* obs, int E, int A, uint64_t see
                         const float* preset_host, void* stream);
 int naf_synth_env_state_floats(int A);
 
+/* ---- one-shot gradient all-reduce over peer-mapped memory (no reference counterpart) ----------
+ * The data-parallel exchange that follows loss.backward() (naf_algorithm.py:207-210 on every rank): sum of the flat
+ * gradient over the W <= 8 GPUs of one node, each rank pushing its gradient into a receive slot on every peer over
+ * xGMI and summing the W contributions in rank order (bit-identical on all ranks). See csrc/xgmi_reduce.hip.
+ *   create  : allocates this rank's receive slab (uncached device memory) for n_floats-long gradients (n_floats % 4
+ *             == 0); timeout_s bounds every wait on a peer (a time-out is counted, the kernel then proceeds)
+ *   export  : writes the slab's 64-byte hipIpc handle; the host exchanges the W handles (torch.distributed)
+ *   connect : all_handle_bytes = W x 64 bytes in rank order; maps every peer slab (hipIpcOpenMemHandle)
+ *   allreduce_sum : two launches on `stream`: grad_out[i] = sum over ranks of grad_in[i] (in place allowed);
+ *             sumsq_partials (nullable) receives ceil(n_floats / naf_xgmi_chunk_floats()) partial sums of
+ *             grad_out^2 for naf_adam_polyak_fused; step_dev (nullable) is advanced by one. Capturable.
+ *   status  : blocking read of the epoch (all-reduces done) and of the number of timed-out waits (must stay 0). */
+#define NAF_XGMI_MAX_WORLD 8
+#define NAF_XGMI_HANDLE_BYTES 64
+int naf_xgmi_chunk_floats(void);
+int naf_xgmi_create(int rank, int world, size_t n_floats, double timeout_s, void** handle);
+int naf_xgmi_set_timeout(void* handle, double timeout_s); /* for launches enqueued (or captured) after this call */
+int naf_xgmi_mem_kind(void* handle); /* 2 = uncached, 1 = fine-grained */
+int naf_xgmi_export(void* handle, void* out_handle_bytes);
+int naf_xgmi_connect(void* handle, const void* all_handle_bytes);
+int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
+                           int32_t* step_dev, void* stream);
+int naf_xgmi_status(void* handle, uint64_t* epoch, uint64_t* timeouts);
+int naf_xgmi_destroy(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

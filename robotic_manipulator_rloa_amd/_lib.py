@@ -14,7 +14,8 @@ from typing import Optional
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
-SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "gemm_bundle.hip", "optim.hip", "synth_env.hip"]
+SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "gemm_bundle.hip", "optim.hip", "synth_env.hip",
+           "xgmi_reduce.hip"]
 HEADERS = ["common.h", "head_body.h", "bn_tile.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
@@ -95,6 +96,15 @@ _PROTOS = {
     "naf_synth_env_step": [_vp, _vp, _vp, _vp, _i, _i, _u64, _vp, _i, _vp],
     "naf_synth_env_reset": [_vp, _vp, _i, _i, _u64, _u64, _vp, _vp],
     "naf_synth_env_state_floats": [_i],
+    "naf_xgmi_chunk_floats": [],
+    "naf_xgmi_create": [_i, _i, _sz, C.c_double, C.POINTER(_vp)],
+    "naf_xgmi_set_timeout": [_vp, C.c_double],
+    "naf_xgmi_mem_kind": [_vp],
+    "naf_xgmi_export": [_vp, _vp],
+    "naf_xgmi_connect": [_vp, _vp],
+    "naf_xgmi_allreduce_sum": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "naf_xgmi_status": [_vp, C.POINTER(_u64), C.POINTER(_u64)],
+    "naf_xgmi_destroy": [_vp],
 }
 _RESTYPES = {"naf_hip_arch": C.c_char_p}
 EXPORTED_SYMBOLS = tuple(_PROTOS)

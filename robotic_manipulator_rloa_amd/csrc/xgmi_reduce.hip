@@ -1,0 +1,264 @@
+// One-shot sum all-reduce of the flat gradient between the GPUs of one node, over peer-mapped (hipIpc) memory:
+// the data-parallel exchange of SURVEY.md §8e without a ring. Every rank PUSHES its 4*P-byte gradient straight into a
+// receive slot on each of its W-1 peers (7 xGMI links in parallel at W = 8), raises one epoch flag per peer, waits for
+// its own W-1 flags and then sums the W contributions in RANK ORDER, so every replica computes bit-identical sums.
+// The reducing kernel also emits the sum-of-squares partials clip_grad_norm_ needs (the separate norm launch of the
+// RCCL path disappears) and advances the optimizer step count.
+//
+//   launch 1  xgmi_push_kernel    grid (chunks, W-1): 16-B stores into peer memory -> system-scope release fence ->
+//                                 arrival counter; the LAST workgroup publishes the epoch flag on every peer
+//   launch 2  xgmi_reduce_kernel  grid (chunks): wave 0 polls the W-1 local flags (bounded by wall clock: a missing
+//                                 peer ends in a recorded time-out, never in a hang) -> system-scope acquire ->
+//                                 rank-ordered sum -> gradient + sumsq partial
+//
+// Receive slots and flags live in device memory allocated UNCACHED (hipDeviceMallocUncached: not kept in any L2, so a
+// line written by a remote GPU is what the next local load returns); slots are double-buffered by epoch parity. A peer
+// can never be two epochs ahead: its push of epoch e+2 is stream-ordered behind its reduce of e+1, which waited for
+// this rank's push of e+1, which is stream-ordered behind this rank's reduce of e.
+// Nothing here allocates or synchronises after naf_xgmi_connect; both launches are plain kernel launches and can be
+// captured into a hipGraph (the epoch lives on the device).
+#include <string.h>
+#include "common.h"
+#include "../../include/naf_hip.h"
+
+#define XG_THREADS 256
+#define XG_CHUNK (XG_THREADS * 4)          // floats per workgroup: one float4 per thread
+#define XG_FLAG_STRIDE 128                 // bytes: one flag per line
+#define XG_TICKS_PER_S 100000000ll         // wall_clock64() runs at 100 MHz
+
+typedef float xg_f4 __attribute__((ext_vector_type(4)));
+
+struct XgPeers {
+    char* base[NAF_XGMI_MAX_WORLD];        // slab of every rank as mapped into THIS process (base[rank] = local)
+};
+
+struct XgmiComm {
+    int rank, world, mem_kind;
+    size_t n, n_pad, data_off, slab_bytes;
+    char* local;
+    XgPeers peers;
+    bool opened[NAF_XGMI_MAX_WORLD];
+    uint64_t* ctrl;                        // device, ordinary memory: [0] epoch [1] arrivals [2] time-outs [3] spare
+    long long timeout_ticks;
+};
+
+__device__ static inline float* xg_slot(char* base, size_t data_off, size_t n_pad, int world, uint64_t epoch, int sender) {
+    return (float*)(base + data_off) + ((size_t)(epoch & 1) * world + sender) * n_pad;
+}
+
+__global__ __launch_bounds__(XG_THREADS) void xgmi_push_kernel(XgPeers peers, const float* __restrict__ grad, size_t n,
+                                                               size_t n_pad, size_t data_off, int rank, int world,
+                                                               uint64_t* __restrict__ ctrl) {
+    const uint64_t e = ctrl[0] + 1;        // nobody writes ctrl[0] before every workgroup has arrived below
+    const int peer = (int)blockIdx.y + ((int)blockIdx.y >= rank ? 1 : 0);
+    const size_t i = (size_t)blockIdx.x * XG_CHUNK + (size_t)threadIdx.x * 4;
+    if (i < n) {                           // n is a multiple of 4 (checked on the host)
+        const xg_f4 v = *(const xg_f4*)(grad + i);
+        float* dst = xg_slot(peers.base[peer], data_off, n_pad, world, e, rank);
+        *(xg_f4*)(dst + i) = v;
+    }
+    __threadfence_system();                // every wave: its stores have reached the peer before it arrives
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+        const unsigned long long old = atomicAdd((unsigned long long*)&ctrl[1], 1ull);
+        last = (old == total - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x < world && (int)threadIdx.x != rank) {
+        uint64_t* flag = (uint64_t*)(peers.base[threadIdx.x] + (size_t)rank * XG_FLAG_STRIDE);
+        __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (last && threadIdx.x == 0) {
+        ctrl[1] = 0;
+        ctrl[0] = e;
+    }
+}
+
+template <int world>
+__global__ __launch_bounds__(XG_THREADS) void xgmi_reduce_kernel(XgPeers peers, const float* __restrict__ grad_in,
+                                                                 float* __restrict__ grad_out, size_t n, size_t n_pad,
+                                                                 size_t data_off, int rank,
+                                                                 uint64_t* __restrict__ ctrl,
+                                                                 float* __restrict__ sumsq_partials, int32_t* step_dev,
+                                                                 long long timeout_ticks) {
+    __shared__ float red[XG_THREADS / 64];
+    const uint64_t e = ctrl[0];            // published by the push launch in front of this one
+    const size_t i = (size_t)blockIdx.x * XG_CHUNK + (size_t)threadIdx.x * 4;
+    // own contribution requested before the wait: it does not depend on any peer
+    xg_f4 mine = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) mine = *(const xg_f4*)(grad_in + i);
+    if (threadIdx.x < world && (int)threadIdx.x != rank) {
+        const uint64_t* flag = (const uint64_t*)(peers.base[rank] + (size_t)threadIdx.x * XG_FLAG_STRIDE);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+            if (wall_clock64() - t0 > timeout_ticks) {       // the exit every wave reaches: peer missing or dead
+                atomicAdd((unsigned long long*)&ctrl[2], 1ull);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");            // system scope: drop anything this CU still holds
+    float ss = 0.f;
+    if (i < n) {
+        // all W-1 peer contributions in flight together (the slot of the own rank is never written: its address is
+        // read like the others and the value replaced, which keeps the loop free of divergent addressing)
+        const float* slot0 = xg_slot(peers.base[rank], data_off, n_pad, world, e, 0) + i;
+        xg_f4 v[world];
+#pragma unroll
+        for (int s = 0; s < world; ++s) v[s] = *(const xg_f4*)(slot0 + (size_t)s * n_pad);
+        xg_f4 acc = (rank == 0) ? mine : v[0];
+#pragma unroll
+        for (int s = 1; s < world; ++s) acc = acc + (s == rank ? mine : v[s]);
+        *(xg_f4*)(grad_out + i) = acc;
+        ss = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < XG_THREADS / 64; ++k) s += red[k];
+        if (sumsq_partials) sumsq_partials[blockIdx.x] = s;
+        if (blockIdx.x == 0 && step_dev) *step_dev += 1;
+    }
+}
+
+static inline XgmiComm* xg_comm(void* h) { return (XgmiComm*)h; }
+
+extern "C" int naf_xgmi_chunk_floats(void) { return XG_CHUNK; }
+
+extern "C" int naf_xgmi_create(int rank, int world, size_t n_floats, double timeout_s, void** handle) {
+    if (!handle || world < 2 || world > NAF_XGMI_MAX_WORLD || rank < 0 || rank >= world || n_floats == 0 ||
+        (n_floats & 3) != 0 || !(timeout_s > 0.0))
+        return NAF_ERR_ARG;
+    XgmiComm* c = new XgmiComm();
+    c->rank = rank;
+    c->world = world;
+    c->n = n_floats;
+    c->n_pad = (n_floats + XG_CHUNK - 1) / XG_CHUNK * XG_CHUNK;
+    c->data_off = ((size_t)world * XG_FLAG_STRIDE + 4095) / 4096 * 4096;
+    c->slab_bytes = c->data_off + (size_t)2 * world * c->n_pad * sizeof(float);
+    c->timeout_ticks = (long long)(timeout_s * (double)XG_TICKS_PER_S);
+    for (int p = 0; p < NAF_XGMI_MAX_WORLD; ++p) {
+        c->peers.base[p] = nullptr;
+        c->opened[p] = false;
+    }
+    void* p = nullptr;
+    c->mem_kind = 2;
+    hipError_t e = hipExtMallocWithFlags(&p, c->slab_bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c->mem_kind = 1;
+        e = hipExtMallocWithFlags(&p, c->slab_bytes, hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return (int)e;
+    }
+    c->local = (char*)p;
+    c->peers.base[rank] = c->local;
+    e = hipMalloc((void**)&c->ctrl, 64);
+    if (e == hipSuccess) e = hipMemset(c->ctrl, 0, 64);
+    if (e == hipSuccess) e = hipMemset(c->local, 0, c->slab_bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(c->local);
+        if (c->ctrl) (void)hipFree(c->ctrl);
+        delete c;
+        return (int)e;
+    }
+    *handle = c;
+    return NAF_OK;
+}
+
+extern "C" int naf_xgmi_set_timeout(void* handle, double timeout_s) {
+    if (!handle || !(timeout_s > 0.0)) return NAF_ERR_ARG;
+    xg_comm(handle)->timeout_ticks = (long long)(timeout_s * (double)XG_TICKS_PER_S);
+    return NAF_OK;
+}
+
+extern "C" int naf_xgmi_mem_kind(void* handle) { return handle ? xg_comm(handle)->mem_kind : NAF_ERR_STATE; }
+
+extern "C" int naf_xgmi_export(void* handle, void* out_handle_bytes) {
+    if (!handle || !out_handle_bytes) return NAF_ERR_ARG;
+    static_assert(sizeof(hipIpcMemHandle_t) == NAF_XGMI_HANDLE_BYTES, "ipc handle size");
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, xg_comm(handle)->local);
+    if (e != hipSuccess) return (int)e;
+    memcpy(out_handle_bytes, &h, sizeof(h));
+    return NAF_OK;
+}
+
+extern "C" int naf_xgmi_connect(void* handle, const void* all_handle_bytes) {
+    if (!handle || !all_handle_bytes) return NAF_ERR_ARG;
+    XgmiComm* c = xg_comm(handle);
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank || c->opened[p]) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)all_handle_bytes + (size_t)p * NAF_XGMI_HANDLE_BYTES, sizeof(h));
+        void* mapped = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return (int)e;
+        c->peers.base[p] = (char*)mapped;
+        c->opened[p] = true;
+    }
+    return NAF_OK;
+}
+
+extern "C" int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
+                                      int32_t* step_dev, void* stream) {
+    if (!handle || !grad_in || !grad_out) return NAF_ERR_ARG;
+    XgmiComm* c = xg_comm(handle);
+    if ((((uintptr_t)grad_in | (uintptr_t)grad_out) & 15) != 0) return NAF_ERR_ARG;
+    for (int p = 0; p < c->world; ++p)
+        if (!c->peers.base[p]) return NAF_ERR_STATE;           // naf_xgmi_connect has not mapped every peer
+    const unsigned chunks = (unsigned)(c->n_pad / XG_CHUNK);
+    xgmi_push_kernel<<<dim3(chunks, c->world - 1), XG_THREADS, 0, (hipStream_t)stream>>>(
+        c->peers, grad_in, c->n, c->n_pad, c->data_off, c->rank, c->world, c->ctrl);
+    NAF_CHECK_LAUNCH();
+#define XG_REDUCE(W)                                                                                              \
+    case W:                                                                                                       \
+        xgmi_reduce_kernel<W><<<chunks, XG_THREADS, 0, (hipStream_t)stream>>>(                                    \
+            c->peers, grad_in, grad_out, c->n, c->n_pad, c->data_off, c->rank, c->ctrl, sumsq_partials, step_dev, \
+            c->timeout_ticks);                                                                                    \
+        break;
+    switch (c->world) {
+        XG_REDUCE(2) XG_REDUCE(3) XG_REDUCE(4) XG_REDUCE(5) XG_REDUCE(6) XG_REDUCE(7) XG_REDUCE(8)
+        default: return NAF_ERR_STATE;
+    }
+#undef XG_REDUCE
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_xgmi_status(void* handle, uint64_t* epoch, uint64_t* timeouts) {
+    if (!handle) return NAF_ERR_ARG;
+    uint64_t host[4];
+    hipError_t e = hipMemcpy(host, xg_comm(handle)->ctrl, sizeof(host), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    if (epoch) *epoch = host[0];
+    if (timeouts) *timeouts = host[2];
+    return NAF_OK;
+}
+
+extern "C" int naf_xgmi_destroy(void* handle) {
+    if (!handle) return NAF_ERR_ARG;
+    XgmiComm* c = xg_comm(handle);
+    (void)hipDeviceSynchronize();
+    for (int p = 0; p < c->world; ++p)
+        if (c->opened[p]) (void)hipIpcCloseMemHandle(c->peers.base[p]);
+    // The receive slab is deliberately NOT handed back to the allocator (<= 5.3 MB per communicator, released with the
+    // process). Measured with 4 ranks sharing one MI355X: once the slab had been freed AND every peer had closed its
+    // mapping, the recycled pages served a later allocation stale data now and then (a learner built afterwards in the
+    // same process took a different update in ~1 of 2 runs); keeping either the slab or the mappings alive: 30 of 30
+    // runs bit-identical. Peers wrote these pages through their own (importer-side) mappings.
+    (void)hipFree(c->ctrl);
+    delete c;
+    return NAF_OK;
+}

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .parallel import all_reduce_flat_grad
+from .parallel import XgmiAllReduce, all_reduce_flat_grad
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -196,7 +196,15 @@ class Learner:
         self.n_partials_norm = (P + _lib.NORM_CHUNK - 1) // _lib.NORM_CHUNK
         self.n_partials_fold = gb_blocks + 2 * ft_blocks
         self.n_partials = self.n_partials_fold if self.fold_norm else self.n_partials_norm
-        self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm), **f32)
+        # data parallel inside one node: the one-shot peer-memory all-reduce (csrc/xgmi_reduce.hip) replaces the RCCL
+        # ring + the grad-norm launch when every rank could map every peer and the exact self-test passed on all of
+        # them; otherwise (or with NAF_XGMI=0) the RCCL all-reduce below stays. try_create is collective.
+        self.xgmi = None
+        if self.world_size > 1 and os.environ.get("NAF_XGMI", "1") != "0":
+            self.xgmi = XgmiAllReduce.try_create(P, dev, self.pg)
+            if self.xgmi is not None:
+                self.n_partials = self.xgmi.n_partials
+        self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm, self.n_partials), **f32)
         self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
         self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
         self.n_loss_wg = (B + 7) // 8                  # loss partials per update (NAF_HEAD_SPB samples per workgroup)
@@ -366,19 +374,27 @@ class Learner:
         if self.world_size > 1 or os.environ.get("NAF_FORCE_ALLREDUCE") == "1":
             # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
+            if self.xgmi is not None:
+                # push + rank-ordered reduce; the reduce launch leaves the sum-of-squares partials and the step count
+                self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev)
+                self.optimizer_step(norm_ready=True)
+                return
             all_reduce_flat_grad(self.grad, self.pg)
-        self.optimizer_step()
+        self.optimizer_step(norm_ready=self.fold_norm)
 
-    def optimizer_step(self) -> None:
-        """clip_grad_norm_(params, 1) + Adam.step() + soft_update on the flat buffers: 2 launches."""
+    def optimizer_step(self, norm_ready: Optional[bool] = None) -> None:
+        """clip_grad_norm_(params, 1) + Adam.step() + soft_update on the flat buffers: 2 launches (1 when the
+        producers of the gradient already left its sum-of-squares partials)."""
         st, P = stream_ptr(), self.lay.P
         f = self._f
-        if not self.fold_norm:
+        if norm_ready is None:
+            norm_ready = self.fold_norm
+        if not norm_ready:
             check(f.naf_grad_norm_partials(ptr(self.grad), P, ptr(self.partials), ptr(self.step_dev), st), "grad_norm")
         check(f.naf_adam_polyak_fused(
             ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]),
-            ptr(self.partials), self.n_partials, MAX_GRAD_NORM, self.lr, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau,
-            float(1.0 - self.tau), ptr(self.step_dev), 1.0 / self.world_size, P, st), "adam_polyak")
+            ptr(self.partials), self.n_partials if norm_ready else self.n_partials_norm, MAX_GRAD_NORM, self.lr,
+            ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau, float(1.0 - self.tau), ptr(self.step_dev), 1.0 / self.world_size, P, st), "adam_polyak")
 
     def soft_update(self) -> None:
         """Standalone NAFAgent.soft_update(main, target) (naf_algorithm.py:217-226) over the flat buffers."""

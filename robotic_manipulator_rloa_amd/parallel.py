@@ -58,3 +58,122 @@ def units_per_rank(total_envs: int, world: int, rank: int) -> int:
     """Weak scaling keeps envs/GPU fixed; for a fixed global env count the remainder goes to the low ranks."""
     base, rem = divmod(int(total_envs), int(world))
     return base + (1 if rank < rem else 0)
+
+
+def _agree(ok: bool, device: torch.device, group=None) -> bool:
+    """True only when EVERY rank passes ok=True (MIN all-reduce on the backend's own device type)."""
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item() == 1)
+
+
+class XgmiAllReduce:
+    """One-shot sum all-reduce of the flat gradient over peer-mapped device memory (csrc/xgmi_reduce.hip):
+    every rank pushes its gradient into a slot on each peer over xGMI and sums the W contributions in rank order.
+    Two capturable launches, no host involvement per call; the reduce launch also emits the grad-norm partials.
+
+    `XgmiAllReduce.try_create` is collective: either every rank of the group gets a verified communicator, or every
+    rank gets None (and the caller stays on the RCCL all-reduce). Verification = `self_test`: exact integer-valued
+    patterns through the very same kernels, any mismatch or timed-out wait on any rank disables the path everywhere.
+    """
+
+    def __init__(self, handle, lib, n_floats: int, rank: int, world: int, device: torch.device, group):
+        self.handle, self.lib, self.n, self.rank, self.world = handle, lib, int(n_floats), rank, world
+        self.device, self.group = device, group
+        self.chunk = lib.naf_xgmi_chunk_floats()
+        self.n_partials = (self.n + self.chunk - 1) // self.chunk
+        self.mem_kind = {2: "uncached", 1: "fine-grained"}.get(lib.naf_xgmi_mem_kind(handle), "?")
+
+    @classmethod
+    def try_create(cls, n_floats: int, device: torch.device, group=None, timeout_s: float = 30.0,
+                   test_rounds: int = 48, test_timeout_s: float = 3.0) -> Optional["XgmiAllReduce"]:
+        import ctypes as C
+        from . import _lib
+        if not dist.is_initialized() or dist.get_world_size(group) < 2:
+            return None
+        lib = _lib.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        handle, blob, why = C.c_void_p(), None, ""
+        if world <= 8 and n_floats % 4 == 0:
+            with torch.cuda.device(device):
+                rc = lib.naf_xgmi_create(rank, world, n_floats, float(test_timeout_s), C.byref(handle))
+                if rc == 0:
+                    buf = C.create_string_buffer(64)
+                    rc = lib.naf_xgmi_export(handle, buf)
+                    blob = bytes(buf.raw) if rc == 0 else None
+                why = "" if rc == 0 else f"create/export rc={rc}"
+        blobs = [None] * world
+        dist.all_gather_object(blobs, blob, group=group)       # also orders every rank's slab memset before any push
+        ok = all(b is not None for b in blobs)
+        if ok:
+            with torch.cuda.device(device):
+                rc = lib.naf_xgmi_connect(handle, b"".join(blobs))
+            ok, why = rc == 0, (why or (f"connect rc={rc}" if rc else ""))
+        ok = _agree(ok, device, group)
+        comm = cls(handle, lib, n_floats, rank, world, device, group) if handle.value else None
+        if ok:
+            ok = _agree(comm.self_test(test_rounds), device, group)
+            why = why or ("" if ok else "self-test mismatch or time-out")
+            lib.naf_xgmi_set_timeout(handle, float(timeout_s))
+        if not ok:
+            if rank == 0:
+                import sys
+                print(f"[xgmi] one-shot all-reduce disabled ({why or 'a peer failed'}); using RCCL", file=sys.stderr)
+            if comm is not None:
+                comm.close()
+            return None
+        return comm
+
+    def all_reduce(self, grad_in: torch.Tensor, grad_out: torch.Tensor, partials: Optional[torch.Tensor] = None,
+                   step_dev: Optional[torch.Tensor] = None) -> None:
+        """grad_out = sum over ranks of grad_in on the current stream (in place allowed)."""
+        from ._lib import check, ptr, stream_ptr
+        if grad_in.numel() != self.n or grad_out.numel() != self.n or grad_in.dtype != torch.float32 or \
+                grad_out.dtype != torch.float32 or not grad_in.is_contiguous() or not grad_out.is_contiguous():
+            raise ValueError("xgmi all_reduce: gradients must be contiguous f32 of the communicator's length")
+        if partials is not None and partials.numel() < self.n_partials:
+            raise ValueError("xgmi all_reduce: partials too short")
+        check(self.lib.naf_xgmi_allreduce_sum(self.handle, ptr(grad_in), ptr(grad_out), ptr(partials), ptr(step_dev),
+                                              stream_ptr()), "xgmi_allreduce")
+
+    def status(self) -> tuple:
+        """(all-reduces done, timed-out waits) — blocking."""
+        import ctypes as C
+        e, t = C.c_uint64(), C.c_uint64()
+        self.lib.naf_xgmi_status(self.handle, C.byref(e), C.byref(t))
+        return int(e.value), int(t.value)
+
+    def self_test(self, rounds: int = 48) -> bool:
+        """Exact check of this rank's results: rank r contributes (r+1) * ((i + 3*round) % 61), whose sum over ranks is
+        an integer below 2^24 (exact in f32 whatever the order)."""
+        i = torch.arange(self.n, device=self.device, dtype=torch.int64)
+        out = torch.empty(self.n, device=self.device, dtype=torch.float32)
+        part = torch.zeros(self.n_partials, device=self.device, dtype=torch.float32)
+        bad = torch.zeros((), device=self.device, dtype=torch.int64)
+        tri = self.world * (self.world + 1) // 2
+        for k in range(rounds):
+            if k in (1, 8):     # a broken mapping shows in the first round: do not sit through the others' time-outs
+                torch.cuda.synchronize(self.device)
+                if self.status()[1] or int(bad.item()):
+                    return False
+            base = ((i + 3 * k) % 61).to(torch.float32)
+            g = base * float(self.rank + 1)
+            if k % 2:
+                self.all_reduce(g, g, part)          # in place
+                got = g
+            else:
+                self.all_reduce(g, out, part)
+                got = out
+            want = base * float(tri)
+            bad += (got != want).sum()
+            ss = (want.double() ** 2).sum()
+            bad += ((part.double().sum() - ss).abs() > 1e-4 * ss).long()
+        torch.cuda.synchronize(self.device)
+        done, timeouts = self.status()
+        return int(bad.item()) == 0 and timeouts == 0 and done >= rounds
+
+    def close(self) -> None:
+        if self.handle is not None and self.handle.value:
+            self.lib.naf_xgmi_destroy(self.handle)
+        self.handle = None

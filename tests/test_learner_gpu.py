@@ -139,12 +139,12 @@ def test_learn_bitwise_reproducible_run_to_run():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-def _kuka_learner_and_replay(n_rows, B=256, seed_data=2024, **data_kw):
+def _kuka_learner_and_replay(n_rows, B=256, seed_data=2024, learner_kw=None, **data_kw):
     from synth_data import make_transitions
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
     S, A = 21, 6
-    L = make_learner(S, A, B, load_group(g, "kuka/main0"), load_group(g, "kuka/target0"))
+    L = make_learner(S, A, B, load_group(g, "kuka/main0"), load_group(g, "kuka/target0"), **(learner_kw or {}))
     st, ac, rw, ns, dn = make_transitions(n_rows, S, A, seed=seed_data, **data_kw)
     buf = ReplayBuffer(n_rows, B, "cuda", 0, state_size=S, action_size=A)
     buf.add_rows_device(torch.from_numpy(O.pack_rows(st, ac, rw, ns, dn, 64)).cuda(), n_rows)

@@ -1,0 +1,180 @@
+"""Worker of tests/test_agent_gpu.py::test_xgmi_oneshot_allreduce_* — W processes (torch.distributed.run, gloo as the
+control plane) that ALL use cuda:0: the only way to run the peer-memory all-reduce (csrc/xgmi_reduce.hip) with more than
+one rank on a 1-GPU box. hipIpc mappings between processes, the epoch/flag protocol, double buffering, graph capture
+and the Learner integration are exactly the multi-GPU code path; only the wire (xGMI) is replaced by local HBM.
+
+Prints XGMI_OK_<rank>; per rank on success.
+"""
+import os
+import sys
+import time
+
+ROOT = os.environ.get("NAF_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from robotic_manipulator_rloa_amd import parallel  # noqa: E402
+
+
+def rank_input(rank, k, n, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 * k + rank)
+    return torch.randn(n, generator=g, device=dev)
+
+
+def expected_sum(k, n, world, dev):
+    acc = rank_input(0, k, n, dev)
+    for r in range(1, world):
+        acc = acc + rank_input(r, k, n, dev)          # same order and rounding as the kernel's rank-ordered sum
+    return acc
+
+
+def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    n = 81152                                          # the flat parameter count at S=21/A=6 (NetLayout.P)
+    comm = parallel.XgmiAllReduce.try_create(n, dev)
+    assert comm is not None, "xgmi communicator was not created / did not pass its self-test"
+    base_epoch = comm.status()[0]
+
+    # ---- 1. random data, eager launches, alternating in-place / out-of-place -------------------------------------
+    out = torch.empty(n, device=dev)
+    part = torch.zeros(comm.n_partials, device=dev)
+    rounds = 120
+    for k in range(rounds):
+        g = rank_input(rank, k, n, dev)
+        want = expected_sum(k, n, world, dev)
+        if k % 3 == 0:
+            comm.all_reduce(g, g, part)
+            got = g
+        else:
+            comm.all_reduce(g, out, part)
+            got = out
+        assert torch.equal(got, want), f"round {k}: {(got != want).sum().item()} elements differ"
+        ss = (want.double() ** 2).sum()
+        assert abs(part.double().sum().item() - ss.item()) < 1e-5 * ss.item()
+    epoch, timeouts = comm.status()
+    assert timeouts == 0 and epoch == base_epoch + rounds, (epoch, timeouts)
+
+    # ---- 2. inside a captured graph: the epoch advances on the device, no host involvement ------------------------
+    g_in = rank_input(rank, 7777, n, dev)
+    want = expected_sum(7777, n, world, dev)
+    outs = [torch.empty(n, device=dev) for _ in range(4)]
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for o in outs:
+            comm.all_reduce(g_in, o, part, step)       # warm-up on the capture stream (4 epochs)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for o in outs:
+            comm.all_reduce(g_in, o, part, step)
+    replays = 40
+    for _ in range(replays):
+        for o in outs:
+            o.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, want)
+    epoch2, timeouts = comm.status()
+    assert timeouts == 0 and epoch2 == epoch + 4 + 4 * replays, (epoch, epoch2, timeouts)
+    assert int(step.item()) == 4 + 4 * replays
+    # latency of one all-reduce, graph replay, all ranks on ONE GPU (protocol cost; the wire is local HBM here)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        graph.replay()
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / (50 * 4) * 1e6
+
+    # ---- 3. Learner integration: W lock-step replicas, each with its own minibatches ------------------------------
+    from robotic_manipulator_rloa_amd.engine import TrainChunk
+    from robotic_manipulator_rloa_amd import learner as learner_mod
+    from test_learner_gpu import _kuka_learner_and_replay
+
+    def host_staged_all_reduce(grad, group=None):      # gloo reference for the exchange (eager, through the host)
+        t = grad.detach().cpu()
+        dist.all_reduce(t, group=group)
+        grad.copy_(t)
+        return grad
+
+    learner_mod.all_reduce_flat_grad = host_staged_all_reduce
+    res = {}
+    for mode in ("1", "0"):                            # one-shot peer-memory path, then the gloo reference
+        os.environ["NAF_XGMI"] = mode
+        L, buf = _kuka_learner_and_replay(5000, 256, seed_data=5 + rank, learner_kw={"world_size": world})
+        assert (L.xgmi is not None) == (mode == "1")
+        if mode == "1":
+            # (a) the exchange as learn_rows() issues it, eagerly: what leaves it must be the rank-ordered sum of what
+            #     every rank put in, bit for bit
+            seen = []
+            real = L.xgmi.all_reduce
+
+            def spy(grad_in, grad_out, partials=None, step_dev=None):
+                before = grad_in.clone()
+                real(grad_in, grad_out, partials, step_dev)
+                seen.append((before, grad_out.clone(), partials[:L.xgmi.n_partials].clone()))
+
+            L.xgmi.all_reduce = spy
+            state = [t.clone() for t in (L.theta2, L.adam_m, L.adam_v, L.bn_stats, L.step_dev)]
+            rows = buf.rows[:2 * 256].view(2, 256, -1)
+            for k in range(2):
+                L.learn_rows(rows[k])
+            torch.cuda.synchronize()
+            L.xgmi.all_reduce = real
+            for before, after, parts in seen:
+                mine = before.cpu()
+                allg = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allg, mine)
+                want = allg[0].clone()
+                for other in allg[1:]:
+                    want = want + other
+                assert torch.equal(after.cpu(), want)
+                ss = (want.double() ** 2).sum().item()
+                assert abs(parts.double().sum().item() - ss) < 1e-5 * ss
+            for t, saved in zip((L.theta2, L.adam_m, L.adam_v, L.bn_stats, L.step_dev), state):
+                t.copy_(saved)
+        # (b) 12 updates (captured graph for the one-shot path), replicas must stay bit-identical
+        chunk = TrainChunk(L, buf, 4, use_graph=(mode == "1"))
+        if mode == "1":
+            chunk.capture()
+        for _ in range(3):
+            chunk.run()
+        torch.cuda.synchronize()
+        if L.xgmi is not None:
+            assert L.xgmi.status()[1] == 0
+        theta = L.theta2.detach().cpu()
+        everyone = [torch.zeros_like(theta) for _ in range(world)]
+        dist.all_gather(everyone, theta)
+        for other in everyone:
+            assert torch.equal(other, everyone[0]), f"replicas diverged (NAF_XGMI={mode})"
+        assert torch.isfinite(theta).all() and int(L.step_dev.item()) == 12
+        res[mode] = theta
+        if L.xgmi is not None:
+            dist.barrier()
+            L.xgmi.close()
+    # (c) same updates through either exchange. Not necessarily bit-equal: the norm partials are chunked differently,
+    # and the biases in front of a train-mode BatchNorm have rounding-noise gradients that Adam turns into +-lr steps
+    d = (res["1"] - res["0"]).abs()
+    assert d.max().item() <= 12 * 1.01e-3 and (d > 1e-5).float().mean().item() < 0.01, (d.max(), (d > 1e-5).float().mean())
+
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+    os.write(1, f"XGMI_OK_{rank};us_per_allreduce={us:.1f};mem={comm.mem_kind};".encode())
+
+
+if __name__ == "__main__":
+    main()
