@@ -70,12 +70,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NAF_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo as the control plane — the N > 1 code path of this file on
+    # a 1-GPU box (RCCL refuses two ranks on one device). Never a measurement; the JSON line says so.
+    rehearsal = os.environ.get("NAF_BENCH_REHEARSAL") == "1" and world > 1
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from robotic_manipulator_rloa_amd import _lib
     from robotic_manipulator_rloa_amd.engine import DeviceEnvLoop, TrainChunk
@@ -91,7 +98,12 @@ def main():
     L.load_params(0, sd)
     L.load_params(1, sd)
     if world > 1:
-        dist.broadcast(L.theta2, src=0)
+        if rehearsal:
+            host = L.theta2.cpu()
+            dist.broadcast(host, src=0)
+            L.theta2.copy_(host)
+        else:
+            dist.broadcast(L.theta2, src=0)
     replay = ReplayBuffer(N, B, dev, seed=1000 + rank, state_size=S, action_size=A)
     rows = synth_rows(N, S, A, replay.row_floats, replay.off_s2, seed=77 + rank, device=dev)
     replay.add_rows_device(rows, N)
@@ -133,7 +145,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     chunk.gather_events = None
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -162,7 +174,8 @@ def main():
         "config": {"workload": f"{'configs[1]: ' if (args.robot, B, N, E) == ('kuka', 256, 1000000, 64) else ''}{args.robot} shapes "
                                f"S={S} A={A} H=256, {E} envs/GPU, batch {B}, HBM replay {N}, "
                                f"HIP NAF head ({args.p_mode} P), {U} learn() per vector step",
-                   "launch": graph_note, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "launch": graph_note + (" [REHEARSAL: all ranks share cuda:0, not a measurement]" if rehearsal else ""),
+                   "parallelism": f"dp{world}" if world > 1 else "single",
                    "grad_exchange": ("none" if world == 1 else
                                      "one-shot peer-memory all-reduce over xGMI (csrc/xgmi_reduce.hip)" if L.xgmi is not None
                                      else "RCCL all-reduce")},

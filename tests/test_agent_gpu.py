@@ -380,3 +380,29 @@ def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
     for k in range(world):
         assert f"XGMI_OK_{k};" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py's N > 1 code path (torch.distributed.run launch, rank-0-only JSON line, barrier-bracketed timing, MAX
+    over ranks, whole-job aggregate, gradient exchange inside the captured graphs) with both ranks on cuda:0
+    (NAF_BENCH_REHEARSAL=1: gloo control plane, the peer-memory all-reduce as the exchange)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, NAF_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=port, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--buffer", "100000"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2" and "one-shot" in out["config"]["grad_exchange"]
+    assert out["sanity"]["params_finite"] and out["sanity"]["xgmi_timed_out_waits"] == 0
+    assert out["sanity"]["optimizer_steps"] == (6 + 2) * 64       # warm-up inside capture leaves no trace
+    assert abs(out["value"] - 2 * 64 * 6 / (out["ms_per_step"] * 6e-3)) < 1e-3 * out["value"]
+    assert "cpu_baseline" not in out                               # timed at N = 1 only
