@@ -101,6 +101,14 @@ int naf_head_bwd(const float* heads_pre, int ldh, const float* u, int ldu, const
 int naf_head_fwd_bwd_mse(const float* heads_pre, int ldh, const float* u, int ldu, const float* r, int ldr,
                          const float* v_next, int ldv, float gamma, float* q_out, float* d_heads,
                          float* loss_partials, int B, int A, int p_mode, void* stream);
+/* the same, fed by the split-K partial heads of naf_bn_relu_fwd_heads_partial: heads_partial[n_slabs][B][ldh] (main
+ * net; slabs slab_stride >= B*ldh floats apart — keep it off a power of two, the n_slabs pieces of one row are read
+ * together and would otherwise share an L2 channel and set
+ * net) and vnext_partial[n_slabs][B] (target net's V column) are summed in slab order while being staged; n_slabs in {16, 32}. */
+int naf_head_fwd_bwd_mse_splitk(const float* heads_partial, int64_t slab_stride, const float* vnext_partial, int n_slabs,
+                                int ldh,
+                                const float* u, int ldu, const float* r, int ldr, float gamma, float* q_out,
+                                float* d_heads, float* loss_partials, int B, int A, int p_mode, void* stream);
 /* replaces MultivariateNormal(mu, inverse(P)).sample() + clamp (naf_neural_network.py:119-121) for E
  * states: action = clamp(mu + noise_scale * P^{-1/2} z, -1, 1), z ~ N(0, I) from Philox
  * (seed, *counter_dev + counter_off, sample, lane). action_out: E x A. */
@@ -151,6 +159,18 @@ int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const float* Wh, in
                               const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
                               const float* save_invstd, float* d_z, int ldd, float* d_gamma, float* d_beta, float* d_bias,
                               float* sumsq_partials /* nullable, [ceil(H/8)] */, int B, int H, void* stream);
+/* layer 2 of BOTH nets (net 0 = main, net 1 = target; pointer + net*stride): bias + BatchNorm1d(train) + ReLU exactly
+ * as naf_bn_relu_fwd_train, plus the heads Linears (naf_neural_network.py:81-87) split over K: workgroup w owns 8
+ * feature columns and writes heads_partial[w][row][NHP] = A2[row][8w..8w+8) . Wh[:, 8w..8w+8)^T (+ column H of Wh, the
+ * bias, in w = 0) for the main net (slab w starts at heads_partial + w*slab_stride floats), vnext_partial[w][row] = the
+ * same for head column v_col of the target net.
+ * n_slabs = H/8. H % 8 == 0, B <= 512, NHP in {16,32,48}. */
+int naf_bn_relu_fwd_heads_partial(const float* g, int64_t g_net_stride, int ldg, const float* bias, const float* gamma,
+                                  const float* beta, int64_t param_net_stride, float* running_mean, float* running_var,
+                                  int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo, float* save_mean,
+                                  float* save_invstd, const float* Wh, int64_t wh_net_stride, int ldw, int NHP, int v_col,
+                                  float* heads_partial, int64_t slab_stride, float* vnext_partial, int B, int H,
+                                  float momentum, float eps, void* stream);
 /* heads_pre = a2[net 0] @ Wh[net 0]^T on f32 MFMA tiles (K % 16 == 0, NHP in {16,32,48}), V'(s') = a2[net 1] . Wh[net 1]
  * row A+T, then exactly naf_head_fwd_bwd_mse: replaces the three head Linears of both networks
  * (naf_neural_network.py:81-87) + the head + the TD/MSE epilogue. heads_out (nullable): [B][NHP]. This kernel works on

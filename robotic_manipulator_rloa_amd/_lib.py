@@ -77,6 +77,7 @@ _PROTOS = {
     "naf_head_fwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "naf_head_bwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "naf_head_fwd_bwd_mse": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "naf_head_fwd_bwd_mse_splitk": [_vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "naf_act_noise": [_vp, _i, _vp, _u64, _vp, _u64, _f, _i, _i, _i, _vp],
     "naf_bn_relu_fwd_train": [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i,
                               _f, _f, _vp],
@@ -87,6 +88,8 @@ _PROTOS = {
     "naf_bn_relu_bwd_wgrad": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "naf_heads_bwd_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i,
                                   _vp],
+    "naf_bn_relu_fwd_heads_partial": [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
+                                      _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
     "naf_heads_gemm_head_fwd_bwd_mse": [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i,
                                         _i, _i, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],

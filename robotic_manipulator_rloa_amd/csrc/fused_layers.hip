@@ -338,6 +338,126 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// S3: bias + BatchNorm1d(train) + ReLU of layer 2 for `nets` networks, and — while the tile is still on chip — this
+// workgroup's share of the heads GEMM: heads_partial[w][row][h] = sum over the 8 columns c owned by workgroup w of
+// A2[row][c] * Wh[h][c] (+ the head bias in workgroup 0). The heads GEMM is thereby split over K = H/8 workgroups;
+// the NAF head kernel that follows adds the H/8 slabs in index order while it stages its rows (fixed order: bitwise
+// reproducible), so the separate heads GEMM launch disappears. Net 0 (main) produces all NHP head columns; net 1
+// (target) only the V column, the one thing learn() reads from the target (naf_algorithm.py:199-201).
+// ------------------------------------------------------------------------------------------------------------
+template <int RPT, int NH4>
+__global__ __launch_bounds__(FT_THREADS) void bn_relu_fwd_heads_partial_kernel(
+    const float* __restrict__ g, int64_t g_net_stride, int ldg, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int64_t param_net_stride,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out,
+    int64_t out_net_stride, int ldo, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    const float* __restrict__ Wh, int64_t wh_net_stride, int ldw, int v_col, float* __restrict__ heads_partial,
+    int64_t slab_stride, float* __restrict__ vnext_partial, int B, int H, float momentum, float eps) {
+    constexpr int NHP = 4 * NH4;
+    __shared__ float red[FT_NW][FT_TX + 1];
+    __shared__ __attribute__((aligned(16))) float sA[RPT * FT_TY][FT_TX];     // this tile's activations, row-major
+    // Wh[:, col0 .. col0+8) grouped by 4 heads: [head group][4 heads x 8 columns], rows 36 floats apart so the 8
+    // head groups a wave reads at once start in 8 different bank quads
+    __shared__ __attribute__((aligned(16))) float sW[NH4][4 * FT_TX + 4];
+    __shared__ float sBias[NHP];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
+    const int col0 = blockIdx.x * FT_TX, col = col0 + tx;
+    const int net = blockIdx.y;
+    const bool col_on = col < H;
+    const float* gz = g + net * g_net_stride;
+    float* oz = out + net * out_net_stride;
+    const int64_t po = net * param_net_stride;
+    const float b = (bias && col_on) ? bias[po + col] : 0.f;
+    const float gm = col_on ? gamma[po + col] : 0.f;
+    const float bt = col_on ? beta[po + col] : 0.f;
+    const int64_t so = net * stat_net_stride + col;
+    const float rm_old = (ty == 0 && col_on) ? running_mean[so] : 0.f;
+    const float rv_old = (ty == 0 && col_on) ? running_var[so] : 0.f;
+    // head-weight tile and bias column: requested with the matrix rows, used after the statistics
+    const float* Whn = Wh + net * wh_net_stride;
+    float wreg = 0.f, breg = 0.f;
+    if (tid < NHP * FT_TX) {
+        const int h = tid / FT_TX, c = tid - h * FT_TX;
+        wreg = (col0 + c < H) ? Whn[(int64_t)h * ldw + col0 + c] : 0.f;
+    } else if (tid < NHP * FT_TX + NHP && blockIdx.x == 0) {
+        breg = Whn[(int64_t)(tid - NHP * FT_TX) * ldw + H];                     // bias = column H (the ones column of A2)
+    }
+
+    float x[RPT];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * FT_TY;
+        x[k] = (col_on && row < B) ? gz[(int64_t)row * ldg + col] + b : 0.f;
+        sum += x[k];
+    }
+    const float mean = bn_col_reduce<FT_TX, FT_TY>(sum, red, tx, ty) / (float)B;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * FT_TY;
+        float dlt = (row < B) ? x[k] - mean : 0.f;
+        ss += dlt * dlt;
+    }
+    const float var = bn_col_reduce<FT_TX, FT_TY>(ss, red, tx, ty) / (float)B;
+    const float invstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        int row = ty + k * FT_TY;
+        float y = 0.f;
+        if (col_on && row < B) {
+            y = (x[k] - mean) * invstd * gm + bt;
+            y = y > 0.f ? y : 0.f;
+            oz[(int64_t)row * ldo + col] = y;
+        }
+        sA[row][tx] = y;
+    }
+    if (tid < NHP * FT_TX) sW[tid / (4 * FT_TX)][tid % (4 * FT_TX)] = wreg;
+    else if (tid < NHP * FT_TX + NHP) sBias[tid - NHP * FT_TX] = breg;        // zeros outside workgroup 0
+    if (ty == 0 && col_on) {
+        const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+        running_mean[so] = (1.0f - momentum) * rm_old + momentum * mean;
+        running_var[so] = (1.0f - momentum) * rv_old + momentum * unbiased;
+        save_mean[(int64_t)net * H + col] = mean;
+        save_invstd[(int64_t)net * H + col] = invstd;
+    }
+    __syncthreads();
+    if (net == 0) {
+        // item = (row, group of 4 heads); consecutive threads take consecutive head groups of one row
+        float* dst = heads_partial + (int64_t)blockIdx.x * slab_stride;
+        constexpr int ITEMS = (RPT * FT_TY * NH4 + FT_THREADS - 1) / FT_THREADS;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = tid + it * FT_THREADS;
+            if (item >= B * NH4) break;
+            const int row = item / NH4, hq = item - row * NH4;
+            const float4 a0 = ((const float4*)sA[row])[0], a1 = ((const float4*)sA[row])[1];
+            float4 acc;
+            float* ap = (float*)&acc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 w0 = ((const float4*)sW[hq])[2 * i], w1 = ((const float4*)sW[hq])[2 * i + 1];
+                float t = sBias[4 * hq + i];
+                t += a0.x * w0.x; t += a0.y * w0.y; t += a0.z * w0.z; t += a0.w * w0.w;
+                t += a1.x * w1.x; t += a1.y * w1.y; t += a1.z * w1.z; t += a1.w * w1.w;
+                ap[i] = t;
+            }
+            ((float4*)(dst + (int64_t)row * NHP))[hq] = acc;
+        }
+    } else {
+        float* dst = vnext_partial + (int64_t)blockIdx.x * B;
+        for (int row = tid; row < B; row += FT_THREADS) {
+            const float4 a0 = ((const float4*)sA[row])[0], a1 = ((const float4*)sA[row])[1];
+            const float4 w0 = ((const float4*)sW[v_col >> 2])[2 * (v_col & 3)], w1 = ((const float4*)sW[v_col >> 2])[2 * (v_col & 3) + 1];
+            float t = sBias[v_col];
+            t += a0.x * w0.x; t += a0.y * w0.y; t += a0.z * w0.z; t += a0.w * w0.w;
+            t += a1.x * w1.x; t += a1.y * w1.y; t += a1.z * w1.z; t += a1.w * w1.w;
+            dst[row] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // F3: heads GEMM on f32 MFMA + NAF head. Workgroup = 256 threads = 4 waves = 32 samples.
 // Each wave produces 16(samples) x 16(outputs) tiles with v_mfma_f32_16x16x4_f32 straight from global memory:
 // lane (r = l & 15, g = l >> 4) loads ONE float4 of row r at k = 16 j + 4 g for A and for B, and feeds components
@@ -528,6 +648,44 @@ extern "C" int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const fl
     else
         RPT_DISPATCH(heads_bwd_bn_relu_bwd_kernel, 12, d_heads, ldh, Wh, ldw, g, ldg, bias, out, ldo, gamma, save_mean,
                      save_invstd, d_z, ldd, d_gamma, d_beta, d_bias, sumsq_partials, B, H);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bn_relu_fwd_heads_partial(const float* g, int64_t g_net_stride, int ldg, const float* bias,
+                                             const float* gamma, const float* beta, int64_t param_net_stride,
+                                             float* running_mean, float* running_var, int64_t stat_net_stride,
+                                             float* out, int64_t out_net_stride, int ldo, float* save_mean,
+                                             float* save_invstd, const float* Wh, int64_t wh_net_stride, int ldw,
+                                             int NHP, int v_col, float* heads_partial, int64_t slab_stride,
+                                             float* vnext_partial, int B, int H, float momentum, float eps,
+                                             void* stream) {
+    if (!g || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd || !Wh ||
+        !heads_partial || !vnext_partial)
+        return NAF_ERR_ARG;
+    if (B <= 0 || B > 8 * FT_TY || H <= 0 || (H % FT_TX) != 0 || ldg < H || ldo < H || ldw <= H) return NAF_ERR_ARG;
+    if ((NHP != 16 && NHP != 32 && NHP != 48) || v_col < 0 || v_col >= NHP) return NAF_ERR_ARG;
+    if (((uintptr_t)heads_partial & 15) != 0 || (slab_stride & 3) != 0 || slab_stride < (int64_t)B * NHP) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(H / FT_TX, 2), block(FT_TX, FT_TY);
+#define S3_DISPATCH(NH4v)                                                                                       \
+    do {                                                                                                        \
+        int rpt = (B + FT_TY - 1) / FT_TY;                                                                      \
+        if (rpt <= 1) bn_relu_fwd_heads_partial_kernel<1, NH4v><<<grid, block, 0, st>>>(S3_ARGS);               \
+        else if (rpt <= 2) bn_relu_fwd_heads_partial_kernel<2, NH4v><<<grid, block, 0, st>>>(S3_ARGS);          \
+        else if (rpt <= 4) bn_relu_fwd_heads_partial_kernel<4, NH4v><<<grid, block, 0, st>>>(S3_ARGS);          \
+        else bn_relu_fwd_heads_partial_kernel<8, NH4v><<<grid, block, 0, st>>>(S3_ARGS);                        \
+    } while (0)
+#define S3_ARGS                                                                                                  \
+    g, g_net_stride, ldg, bias, gamma, beta, param_net_stride, running_mean, running_var, stat_net_stride, out, \
+        out_net_stride, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, v_col, heads_partial, slab_stride,          \
+        vnext_partial, B, H,                                                                                            \
+        momentum, eps
+    if (NHP == 16) S3_DISPATCH(4);
+    else if (NHP == 32) S3_DISPATCH(8);
+    else S3_DISPATCH(12);
+#undef S3_ARGS
+#undef S3_DISPATCH
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -9,7 +9,7 @@
 #include "head_body.h"
 
 // MODE: 0 = forward only (q, optional mu); 1 = backward given dq; 2 = fused TD target + MSE + backward
-template <int PMODE, int MODE>
+template <int PMODE, int MODE, int NSLAB = 0>
 __global__ __launch_bounds__(NH_THREADS) void naf_head_kernel(const float* __restrict__ heads, int ldh,
                                                                 const float* __restrict__ u, int ldu,
                                                                 const float* __restrict__ r, int ldr,
@@ -17,7 +17,14 @@ __global__ __launch_bounds__(NH_THREADS) void naf_head_kernel(const float* __res
                                                                 const float* __restrict__ dq_in, float gamma,
                                                                 float* __restrict__ q_out, float* __restrict__ mu_out,
                                                                 float* __restrict__ d_heads,
-                                                                float* __restrict__ loss_partials, int B, int A) {
+                                                                float* __restrict__ loss_partials, int B, int A,
+                                                                int n_slabs, int64_t slab_stride,
+                                                                int64_t vn_slab_stride) {
+    // NSLAB > 0: `heads` (and `v_next`) are split-K partial results, NSLAB slabs slab_stride (vn_slab_stride) floats
+    // apart, produced by naf_bn_relu_fwd_heads_partial; they are added in index order while being staged. NSLAB is a
+    // compile-time constant on purpose: one wave runs this kernel, so its length in INSTRUCTIONS is its run time, and
+    // run-time slab counts (clamped indices, predicated adds) cost 3.4 us per launch against 0.6 us for the loads
+    constexpr bool SPLITK = NSLAB > 0;
     __shared__ __attribute__((aligned(16))) float sh_in[NH_SPB * HEAD_MAX_LDH];
     __shared__ __attribute__((aligned(16))) float sh_out[MODE == 0 ? 4 : NH_SPB * HEAD_MAX_LDH];
     __shared__ float sh_L[PMODE == NAF_P_MATMUL ? NH_SPB * 8 * LT_STRIDE : 1];
@@ -33,14 +40,41 @@ __global__ __launch_bounds__(NH_THREADS) void naf_head_kernel(const float* __res
     const float u_val = (live_ && i_ < A) ? u[s_ * ldu + i_] : 0.f;
     float r_val = 0.f, vnext_val = 0.f, dq_val = 0.f;
     if (live_ && i_ == 0) {
-        if (MODE == 2) { r_val = r[s_ * ldr]; vnext_val = v_next[s_ * ldv]; }
+        if (MODE == 2) {
+            r_val = r[s_ * ldr];
+            if (!SPLITK) vnext_val = v_next[s_ * ldv];
+        }
         if (MODE == 1) dq_val = dq_in[s_];
     }
     // ---- stage this workgroup's heads rows (contiguous span) ------------------------------------
     {
         const float4* src = (const float4*)(heads + s0 * ldh);
         const int n4 = ns * ldh / 4;  // ldh % 4 == 0 (checked on the host)
-        for (int k = tid; k < n4; k += NH_THREADS) ((float4*)sh_in)[k] = src[k];
+        if (!SPLITK) {
+            for (int k = tid; k < n4; k += NH_THREADS) ((float4*)sh_in)[k] = src[k];
+        } else {
+            // split-K input: every slab piece this thread needs — its float4 of the heads rows and its sample's partial
+            // V'(s') — is requested before the first use, then added in slab order
+            const int64_t sv = (live_ ? s_ : s0) * ldv;
+            constexpr int NS = SPLITK ? NSLAB : 1;
+            for (int k0 = 0; k0 < n4; k0 += NH_THREADS) {
+                const int k = (k0 + tid < n4) ? k0 + tid : 0;
+                float4 p[NS];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) p[j] = ((const float4*)(heads + s0 * ldh + j * slab_stride))[k];
+                float4 acc = p[0];
+#pragma unroll
+                for (int j = 1; j < NS; ++j) { acc.x += p[j].x; acc.y += p[j].y; acc.z += p[j].z; acc.w += p[j].w; }
+                if (k0 + tid < n4) ((float4*)sh_in)[k0 + tid] = acc;
+            }
+            float pv[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) pv[j] = v_next[sv + j * vn_slab_stride];
+            float v = pv[0];
+#pragma unroll
+            for (int j = 1; j < NS; ++j) v += pv[j];
+            if (MODE == 2 && live_ && i_ == 0) vnext_val = v;
+        }
         if (MODE != 0) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int k = tid; k < n4; k += NH_THREADS) ((float4*)sh_out)[k] = z;
@@ -78,7 +112,8 @@ extern "C" int naf_head_fwd(const float* heads_pre, int ldh, const float* u, int
     if (!head_args_ok(heads_pre, ldh, u, ldu, B, A, p_mode) || !q) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     int blocks = (B + NH_SPB - 1) / NH_SPB;
-    HEAD_LAUNCH(p_mode, 0, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, nullptr, 0.f, q, mu_out, nullptr, nullptr, B, A);
+    HEAD_LAUNCH(p_mode, 0, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, nullptr, 0.f, q, mu_out, nullptr, nullptr, B, A,
+                1, 0, 0);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -89,7 +124,8 @@ extern "C" int naf_head_bwd(const float* heads_pre, int ldh, const float* u, int
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     int blocks = (B + NH_SPB - 1) / NH_SPB;
-    HEAD_LAUNCH(p_mode, 1, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, dq, 0.f, nullptr, nullptr, d_heads, nullptr, B, A);
+    HEAD_LAUNCH(p_mode, 1, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, dq, 0.f, nullptr, nullptr, d_heads, nullptr, B, A,
+                1, 0, 0);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -103,7 +139,34 @@ extern "C" int naf_head_fwd_bwd_mse(const float* heads_pre, int ldh, const float
     hipStream_t st = (hipStream_t)stream;
     int blocks = (B + NH_SPB - 1) / NH_SPB;
     HEAD_LAUNCH(p_mode, 2, heads_pre, ldh, u, ldu, r, ldr, v_next, ldv, nullptr, gamma, q_out, nullptr, d_heads,
-                loss_partials, B, A);
+                loss_partials, B, A, 1, 0, 0);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_head_fwd_bwd_mse_splitk(const float* heads_partial, int64_t slab_stride, const float* vnext_partial,
+                                           int n_slabs, int ldh,
+                                           const float* u, int ldu, const float* r, int ldr, float gamma, float* q_out,
+                                           float* d_heads, float* loss_partials, int B, int A, int p_mode,
+                                           void* stream) {
+    if (!head_args_ok(heads_partial, ldh, u, ldu, B, A, p_mode) || !r || !vnext_partial || !d_heads ||
+        ((uintptr_t)d_heads & 15) != 0 || ldr < 1 || (n_slabs != 32 && n_slabs != 16) || (slab_stride & 3) != 0 ||
+        slab_stride < (int64_t)B * ldh)
+        return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (B + NH_SPB - 1) / NH_SPB;
+#define HEAD_SPLITK(PM, NS)                                                                                       \
+    naf_head_kernel<PM, 2, NS><<<blocks, NH_THREADS, 0, st>>>(heads_partial, ldh, u, ldu, r, ldr, vnext_partial, 1,    \
+                                                               nullptr, gamma, q_out, nullptr, d_heads, loss_partials, \
+                                                               B, A, n_slabs, slab_stride, (int64_t)B)
+    if (p_mode == NAF_P_HADAMARD) {
+        if (n_slabs == 32) HEAD_SPLITK(NAF_P_HADAMARD, 32);
+        else HEAD_SPLITK(NAF_P_HADAMARD, 16);
+    } else {
+        if (n_slabs == 32) HEAD_SPLITK(NAF_P_MATMUL, 32);
+        else HEAD_SPLITK(NAF_P_MATMUL, 16);
+    }
+#undef HEAD_SPLITK
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -152,7 +152,7 @@ class Learner:
         self.p_mode = int(p_mode)
         self.world_size = int(world_size)
         self.pg = process_group
-        # Which GEMMs are folded into our own kernels (NAF_FUSE = comma list out of {l1,b2,gb,f3}, "all" or "none").
+        # Which GEMMs are folded into our own kernels (NAF_FUSE = comma list out of {l1,b2,gb,s3,f3}, "all" or "none").
         # Per-launch costs at B=256 from benchmarks/kernel_probe.py, updates/s from bench.py:
         #   l1 = layer 1 (K = state size): GEMM + BN + ReLU forward in one launch (4.5 us vs bmm 3.0 + bn 3.4) and BN
         #        backward + dW1 in one (7.3 vs 3.7 + 3.7); they go together because the fused forward does not
@@ -161,17 +161,21 @@ class Learner:
         #   gb = dWh, dW2, dA1 as ONE grid of LDS-staged f32-MFMA 32x32 blocks (csrc/gemm_bundle.hip) instead of three
         #        rocBLAS launches (6.2 vs 3.8 + 3.2 + 3.8)
         #   f3 = MFMA heads GEMM + head in one launch (8.1 vs 3.2 + 3.6: slower, off)
-        # none 15.0k -> l1,b2 16.3k -> l1,b2,gb 18.0k updates/s (18.7k with the grad norm folded in, below).
+        #   s3 = heads GEMM split over K inside layer 2's BN kernel (each 8-column workgroup writes its [B, NHP] partial
+        #        slab; the head kernel adds the 32 slabs while staging): 4.4 + 4.4 vs bn 3.4 + bmm 4.1 + head 3.2
+        # none 15.0k -> l1,b2 16.3k -> l1,b2,gb 18.0k updates/s (18.7k with the grad norm folded in, below) -> +s3 19.5k.
         # The folded kernels keep their operand rows in registers (ceil(B/64) rows per thread): they win up to B = 512
         # and spill beyond (B=1024: 3.8k vs 9.0k updates/s unfused; B=2048: 1.3k vs 5.6k), where rocBLAS also beats the
         # bundle (longer K) — so large batches default to the unfused chain.
-        spec = os.environ.get("NAF_FUSE", "l1,b2,gb" if self.B <= 512 else "none").lower()
-        names = {"l1", "b2", "f3", "gb"}
+        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else "none").lower()
+        names = {"l1", "b2", "f3", "gb", "s3"}
         self.fuse = set(names) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if self.lay.S > 32:
             self.fuse -= {"l1"}
         if self.B % 16 != 0:
             self.fuse -= {"gb"}
+        if self.B > 512 or self.lay.H not in (128, 256) or "f3" in self.fuse:
+            self.fuse -= {"s3"}
         # with l1 + b2 + gb every gradient element is produced by one of our own kernels, which then also emit its
         # sum-of-squares partial: the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken
         # on the all-reduced gradient).
@@ -224,6 +228,14 @@ class Learner:
         self.save_mean = torch.empty(2, 2, H, **f32)         # [layer][net][H]
         self.save_invstd = torch.empty(2, 2, H, **f32)
         self.q_out = torch.empty(B, **f32)
+        if "s3" in self.fuse:
+            # split-K heads: one [B, NHP] slab per 8-column workgroup of layer 2's BN kernel (+ the target's V column)
+            # slabs 256 B further apart than their size: the H/8 pieces of one row, read together by the head kernel,
+            # then sit in different L2 channels instead of one (32-KB stride: 6.6 us per head launch, padded: see DESIGN)
+            self.n_slabs = H // 8
+            self.slab_stride = B * NHP + 64
+            self.heads_partial = torch.zeros(self.n_slabs * self.slab_stride, **f32)
+            self.vnext_partial = torch.zeros(self.n_slabs, B, **f32)
 
         # ---- GEMM operand views (built once: no per-call tensor construction on the hot path) -------------
         seg = lay.seg
@@ -302,6 +314,15 @@ class Learner:
                 bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]),
                 B, H, 2, BN_MOMENTUM, BN_EPS, st), "bn_relu_fwd_train(1)")
         torch.bmm(self.A1, self.W2T2, out=self.G2)
+        if heads_gemm and "s3" in self.fuse:
+            # layer-2 BN + ReLU and, on the same tile, this workgroup's K-slice of the heads GEMM (no heads launch)
+            check(self._f.naf_bn_relu_fwd_heads_partial(
+                ptr(self.G2), B * H, H, t2p + 4 * seg["b2"].offset, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset,
+                P, bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2), B * lay.HP, lay.HP, ptr(self.save_mean[1]),
+                ptr(self.save_invstd[1]), t2p + 4 * seg["Wh"].offset, P, lay.HP, lay.NHP, lay.A + lay.T,
+                ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), B, H, BN_MOMENTUM, BN_EPS, st),
+                "bn_relu_fwd_heads_partial")
+            return
         check(self._f.naf_bn_relu_fwd_train(
             ptr(self.G2), B * H, H, t2p + 4 * seg["b2"].offset, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P,
             bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2), B * lay.HP, lay.HP, ptr(self.save_mean[1]),
@@ -326,6 +347,14 @@ class Learner:
                 ptr(self.A2), B * HP, HP, HP, t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, lay.row_floats,
                 rp + 4 * lay.off_r, lay.row_floats, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "heads_gemm_head_fwd_bwd_mse")
+        elif "s3" in self.fuse:
+            self.forward_train(rows)
+            # the head adds the H/8 split-K slabs while staging its rows, then as below
+            check(f.naf_head_fwd_bwd_mse_splitk(
+                ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), self.n_slabs, NHP, rp + 4 * lay.off_u,
+                lay.row_floats,
+                rp + 4 * lay.off_r, lay.row_floats, self.gamma, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
+                st), "head_fwd_bwd_mse_splitk")
         else:
             self.forward_train(rows)
             # y = r + gamma * V'(s') ; Q ; loss ; d loss / d heads_pre — one launch

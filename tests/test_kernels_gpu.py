@@ -597,3 +597,74 @@ def test_replay_edge_cases(lib):
     # handle misuse is reported, not executed
     assert lib.naf_replay_add_batch(None, out.data_ptr(), 1, st()) == -2
     assert lib.naf_replay_add_batch(hb.handle, out.data_ptr(), 2001, st()) == -1
+
+
+@pytest.mark.parametrize("B,A,H", [(256, 6, 256), (512, 7, 256), (100, 8, 128), (64, 1, 128)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bn_relu_fwd_heads_partial_and_splitk_head(lib, B, A, H, mode):
+    """S3: layer-2 BN+ReLU with the heads GEMM split over K inside it, and the head kernel that adds the slabs.
+    BN outputs and statistics must equal naf_bn_relu_fwd_train bit for bit (same tile, same arithmetic); the summed
+    slabs must equal A2 @ Wh^T (+ bias) to f32 rounding; Q / d_heads / loss must match the unsplit head on that sum."""
+    rng = np.random.default_rng(B + A + H)
+    T = A * (A + 1) // 2
+    NH, NHP, HP = A + T + 1, (A + T + 1 + 15) // 16 * 16, H + 16
+    g = dev(rng.standard_normal((2, B, H)) * 2)
+    bias, gamma, beta = (dev(rng.standard_normal((2, H))) for _ in range(3))
+    Wh = np.zeros((2, NHP, HP))
+    Wh[:, :NH, :H + 1] = rng.standard_normal((2, NH, H + 1)) / 8.0
+    Wh = dev(Wh)
+    outs = []
+    for which in range(2):
+        rm, rv = torch.zeros(2, H, device="cuda"), torch.ones(2, H, device="cuda")
+        out = torch.zeros(2, B, HP, device="cuda")
+        out[:, :, H] = 1.0
+        sm, si = torch.empty(2, H, device="cuda"), torch.empty(2, H, device="cuda")
+        if which == 0:
+            assert lib.naf_bn_relu_fwd_train(g.data_ptr(), B * H, H, bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H,
+                                             rm.data_ptr(), rv.data_ptr(), H, out.data_ptr(), B * HP, HP, sm.data_ptr(),
+                                             si.data_ptr(), B, H, 2, 0.1, 1e-5, st()) == 0
+        else:
+            hp = torch.full((H // 8, B * NHP + 64), 7.0, device="cuda")        # slabs padded by 64 floats
+            vp = torch.full((H // 8, B), 7.0, device="cuda")
+            assert lib.naf_bn_relu_fwd_heads_partial(
+                g.data_ptr(), B * H, H, bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H, rm.data_ptr(), rv.data_ptr(),
+                H, out.data_ptr(), B * HP, HP, sm.data_ptr(), si.data_ptr(), Wh.data_ptr(), NHP * HP, HP, NHP, A + T,
+                hp.data_ptr(), B * NHP + 64, vp.data_ptr(), B, H, 0.1, 1e-5, st()) == 0
+        torch.cuda.synchronize()
+        outs.append((out, rm, rv, sm, si))
+    for a, b in zip(outs[0], outs[1]):     # same tile and arithmetic; the compiler may contract an fma differently
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    assert (hp[:, B * NHP:] == 7.0).all()                                # nothing written into the padding
+    slab_stride, hp = B * NHP + 64, hp[:, :B * NHP].reshape(H // 8, B, NHP)
+    hp_flat = torch.zeros(H // 8, slab_stride, device="cuda")
+    hp_flat[:, :B * NHP] = hp.reshape(H // 8, -1)
+    A2 = outs[1][0]
+    want = (A2.double() @ Wh.double().transpose(1, 2))                   # [2, B, NHP] incl. the ones column = bias
+    np.testing.assert_allclose(hp.double().sum(0).cpu().numpy(), want[0].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(vp.double().sum(0).cpu().numpy(), want[1, :, A + T].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # the head on the slabs == the head on their (index-ordered f32) sum
+    heads = hp[0].clone()
+    vn = vp[0].clone()
+    for w in range(1, H // 8):
+        heads += hp[w]
+        vn += vp[w]
+    u = dev(np.trunc(rng.uniform(-1.5, 1.5, (B, A))))
+    r = dev(rng.uniform(-1.5, 0, B))
+    res = []
+    for split in (False, True):
+        q, dH = torch.empty(B, device="cuda"), torch.empty(B, NHP, device="cuda")
+        lp = torch.zeros((B + 7) // 8, device="cuda")
+        if split:
+            assert lib.naf_head_fwd_bwd_mse_splitk(hp_flat.data_ptr(), slab_stride, vp.data_ptr(), H // 8, NHP, u.data_ptr(), A, r.data_ptr(), 1,
+                                                   0.99, q.data_ptr(), dH.data_ptr(), lp.data_ptr(), B, A, mode, st()) == 0
+        else:
+            assert lib.naf_head_fwd_bwd_mse(heads.data_ptr(), NHP, u.data_ptr(), A, r.data_ptr(), 1, vn.data_ptr(), 1, 0.99,
+                                            q.data_ptr(), dH.data_ptr(), lp.data_ptr(), B, A, mode, st()) == 0
+        torch.cuda.synchronize()
+        res.append((q, dH, lp))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert lib.naf_bn_relu_fwd_heads_partial(
+        g.data_ptr(), B * H, H, bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H, rm.data_ptr(), rv.data_ptr(), H,
+        out.data_ptr(), B * HP, HP, sm.data_ptr(), si.data_ptr(), Wh.data_ptr(), NHP * HP, HP, 40, A + T, hp_flat.data_ptr(),
+        slab_stride, vp.data_ptr(), B, H, 0.1, 1e-5, st()) == -1

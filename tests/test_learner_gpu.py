@@ -32,7 +32,7 @@ def current_sd(L, net):
     return sd
 
 
-@pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "all"])
+@pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "s3", "l1,b2,gb,s3", "all"])
 @pytest.mark.parametrize("tag", ["kuka", "panda"])
 def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     """NAF_FUSE selects which small GEMMs are folded into the BN / head kernels (csrc/fused_layers.hip; "all" includes
