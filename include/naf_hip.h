@@ -153,12 +153,14 @@ int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const float* x, int l
                           const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
                           const float* save_invstd, float* d_gamma, float* d_beta, float* d_bias, float* d_W,
                           float* sumsq_partials, int32_t* step_dev, int B, int H, void* stream);
+/* feature columns per workgroup of the three kernels above and below (= entries per H in their sumsq_partials) */
+int naf_fused_tile_cols(void);
 /* d_out = d_heads[B][ldh] @ Wh[ldh][ldw] computed on the fly (ldh in {16,32,48}, pad columns zero), then the
  * ReLU/BN backward of naf_bn_relu_bwd: replaces the dA2 GEMM + bn_relu_bwd pair */
 int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const float* Wh, int ldw, const float* g, int ldg,
                               const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
                               const float* save_invstd, float* d_z, int ldd, float* d_gamma, float* d_beta, float* d_bias,
-                              float* sumsq_partials /* nullable, [ceil(H/8)] */, int B, int H, void* stream);
+                              float* sumsq_partials /* nullable, [ceil(H / naf_fused_tile_cols())] */, int B, int H, void* stream);
 /* layer 2 of BOTH nets (net 0 = main, net 1 = target; pointer + net*stride): bias + BatchNorm1d(train) + ReLU exactly
  * as naf_bn_relu_fwd_train, plus the heads Linears (naf_neural_network.py:81-87) split over K: workgroup w owns 8
  * feature columns and writes heads_partial[w][row][NHP] = A2[row][8w..8w+8) . Wh[:, 8w..8w+8)^T (+ column H of Wh, the

@@ -47,6 +47,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         raise NafHipError("hipcc not found: cannot build libnaf_hip.so")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-variable", "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    if os.environ.get("NAF_BUILD_DEFINES"):          # tile-shape experiments (benchmarks/): e.g. "-DFT_TX=4"
+        cmd[1:1] = os.environ["NAF_BUILD_DEFINES"].split()
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -86,6 +88,7 @@ _PROTOS = {
     "naf_linear_bn_relu_fwd_train": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp,
                                      _i, _i, _i, _f, _f, _vp],
     "naf_bn_relu_bwd_wgrad": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_fused_tile_cols": [],
     "naf_heads_bwd_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i,
                                   _vp],
     "naf_bn_relu_fwd_heads_partial": [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,

@@ -15,7 +15,9 @@
 // tile of the column-ownership kernels: 8 feature columns x 64 row phases (512 threads), RPT = ceil(B/64) rows per
 // thread. A wave = 8 row phases x 8 columns, so a broadcast row load (all 8 column lanes read the same 16 B of an
 // input row) still covers 8 distinct rows per instruction.
+#ifndef FT_TX
 #define FT_TX 8
+#endif
 #define FT_TY 64
 #define FT_THREADS (FT_TX * FT_TY)
 #define FT_NW (FT_THREADS / 64)
@@ -345,8 +347,12 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
 // reproducible), so the separate heads GEMM launch disappears. Net 0 (main) produces all NHP head columns; net 1
 // (target) only the V column, the one thing learn() reads from the target (naf_algorithm.py:199-201).
 // ------------------------------------------------------------------------------------------------------------
+#define S3_TX 8
+#define S3_TY 64
+#define S3_THREADS (S3_TX * S3_TY)
+#define S3_NW (S3_THREADS / 64)
 template <int RPT, int NH4>
-__global__ __launch_bounds__(FT_THREADS) void bn_relu_fwd_heads_partial_kernel(
+__global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
     const float* __restrict__ g, int64_t g_net_stride, int ldg, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, int64_t param_net_stride,
     float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out,
@@ -354,14 +360,14 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_fwd_heads_partial_kernel(
     const float* __restrict__ Wh, int64_t wh_net_stride, int ldw, int v_col, float* __restrict__ heads_partial,
     int64_t slab_stride, float* __restrict__ vnext_partial, int B, int H, float momentum, float eps) {
     constexpr int NHP = 4 * NH4;
-    __shared__ float red[FT_NW][FT_TX + 1];
-    __shared__ __attribute__((aligned(16))) float sA[RPT * FT_TY][FT_TX];     // this tile's activations, row-major
+    __shared__ float red[S3_NW][S3_TX + 1];
+    __shared__ __attribute__((aligned(16))) float sA[RPT * S3_TY][S3_TX];     // this tile's activations, row-major
     // Wh[:, col0 .. col0+8) grouped by 4 heads: [head group][4 heads x 8 columns], rows 36 floats apart so the 8
     // head groups a wave reads at once start in 8 different bank quads
-    __shared__ __attribute__((aligned(16))) float sW[NH4][4 * FT_TX + 4];
+    __shared__ __attribute__((aligned(16))) float sW[NH4][4 * S3_TX + 4];
     __shared__ float sBias[NHP];
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
-    const int col0 = blockIdx.x * FT_TX, col = col0 + tx;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * S3_TX + tx;
+    const int col0 = blockIdx.x * S3_TX, col = col0 + tx;
     const int net = blockIdx.y;
     const bool col_on = col < H;
     const float* gz = g + net * g_net_stride;
@@ -376,34 +382,34 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_fwd_heads_partial_kernel(
     // head-weight tile and bias column: requested with the matrix rows, used after the statistics
     const float* Whn = Wh + net * wh_net_stride;
     float wreg = 0.f, breg = 0.f;
-    if (tid < NHP * FT_TX) {
-        const int h = tid / FT_TX, c = tid - h * FT_TX;
+    if (tid < NHP * S3_TX) {
+        const int h = tid / S3_TX, c = tid - h * S3_TX;
         wreg = (col0 + c < H) ? Whn[(int64_t)h * ldw + col0 + c] : 0.f;
-    } else if (tid < NHP * FT_TX + NHP && blockIdx.x == 0) {
-        breg = Whn[(int64_t)(tid - NHP * FT_TX) * ldw + H];                     // bias = column H (the ones column of A2)
+    } else if (tid < NHP * S3_TX + NHP && blockIdx.x == 0) {
+        breg = Whn[(int64_t)(tid - NHP * S3_TX) * ldw + H];                     // bias = column H (the ones column of A2)
     }
 
     float x[RPT];
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * FT_TY;
+        int row = ty + k * S3_TY;
         x[k] = (col_on && row < B) ? gz[(int64_t)row * ldg + col] + b : 0.f;
         sum += x[k];
     }
-    const float mean = bn_col_reduce<FT_TX, FT_TY>(sum, red, tx, ty) / (float)B;
+    const float mean = bn_col_reduce<S3_TX, S3_TY>(sum, red, tx, ty) / (float)B;
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * FT_TY;
+        int row = ty + k * S3_TY;
         float dlt = (row < B) ? x[k] - mean : 0.f;
         ss += dlt * dlt;
     }
-    const float var = bn_col_reduce<FT_TX, FT_TY>(ss, red, tx, ty) / (float)B;
+    const float var = bn_col_reduce<S3_TX, S3_TY>(ss, red, tx, ty) / (float)B;
     const float invstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * FT_TY;
+        int row = ty + k * S3_TY;
         float y = 0.f;
         if (col_on && row < B) {
             y = (x[k] - mean) * invstd * gm + bt;
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_fwd_heads_partial_kernel(
         }
         sA[row][tx] = y;
     }
-    if (tid < NHP * FT_TX) sW[tid / (4 * FT_TX)][tid % (4 * FT_TX)] = wreg;
-    else if (tid < NHP * FT_TX + NHP) sBias[tid - NHP * FT_TX] = breg;        // zeros outside workgroup 0
+    if (tid < NHP * S3_TX) sW[tid / (4 * S3_TX)][tid % (4 * S3_TX)] = wreg;
+    else if (tid < NHP * S3_TX + NHP) sBias[tid - NHP * S3_TX] = breg;        // zeros outside workgroup 0
     if (ty == 0 && col_on) {
         const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
         running_mean[so] = (1.0f - momentum) * rm_old + momentum * mean;
@@ -425,10 +431,10 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_fwd_heads_partial_kernel(
     if (net == 0) {
         // item = (row, group of 4 heads); consecutive threads take consecutive head groups of one row
         float* dst = heads_partial + (int64_t)blockIdx.x * slab_stride;
-        constexpr int ITEMS = (RPT * FT_TY * NH4 + FT_THREADS - 1) / FT_THREADS;
+        constexpr int ITEMS = (RPT * S3_TY * NH4 + S3_THREADS - 1) / S3_THREADS;
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            const int item = tid + it * FT_THREADS;
+            const int item = tid + it * S3_THREADS;
             if (item >= B * NH4) break;
             const int row = item / NH4, hq = item - row * NH4;
             const float4 a0 = ((const float4*)sA[row])[0], a1 = ((const float4*)sA[row])[1];
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_fwd_heads_partial_kernel(
         }
     } else {
         float* dst = vnext_partial + (int64_t)blockIdx.x * B;
-        for (int row = tid; row < B; row += FT_THREADS) {
+        for (int row = tid; row < B; row += S3_THREADS) {
             const float4 a0 = ((const float4*)sA[row])[0], a1 = ((const float4*)sA[row])[1];
             const float4 w0 = ((const float4*)sW[v_col >> 2])[2 * (v_col & 3)], w1 = ((const float4*)sW[v_col >> 2])[2 * (v_col & 3) + 1];
             float t = sBias[v_col];
@@ -663,14 +669,14 @@ extern "C" int naf_bn_relu_fwd_heads_partial(const float* g, int64_t g_net_strid
     if (!g || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd || !Wh ||
         !heads_partial || !vnext_partial)
         return NAF_ERR_ARG;
-    if (B <= 0 || B > 8 * FT_TY || H <= 0 || (H % FT_TX) != 0 || ldg < H || ldo < H || ldw <= H) return NAF_ERR_ARG;
+    if (B <= 0 || B > 8 * S3_TY || H <= 0 || (H % S3_TX) != 0 || ldg < H || ldo < H || ldw <= H) return NAF_ERR_ARG;
     if ((NHP != 16 && NHP != 32 && NHP != 48) || v_col < 0 || v_col >= NHP) return NAF_ERR_ARG;
     if (((uintptr_t)heads_partial & 15) != 0 || (slab_stride & 3) != 0 || slab_stride < (int64_t)B * NHP) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(H / FT_TX, 2), block(FT_TX, FT_TY);
+    dim3 grid(H / S3_TX, 2), block(S3_TX, S3_TY);
 #define S3_DISPATCH(NH4v)                                                                                       \
     do {                                                                                                        \
-        int rpt = (B + FT_TY - 1) / FT_TY;                                                                      \
+        int rpt = (B + S3_TY - 1) / S3_TY;                                                                      \
         if (rpt <= 1) bn_relu_fwd_heads_partial_kernel<1, NH4v><<<grid, block, 0, st>>>(S3_ARGS);               \
         else if (rpt <= 2) bn_relu_fwd_heads_partial_kernel<2, NH4v><<<grid, block, 0, st>>>(S3_ARGS);          \
         else if (rpt <= 4) bn_relu_fwd_heads_partial_kernel<4, NH4v><<<grid, block, 0, st>>>(S3_ARGS);          \
@@ -689,6 +695,8 @@ extern "C" int naf_bn_relu_fwd_heads_partial(const float* g, int64_t g_net_strid
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
+
+extern "C" int naf_fused_tile_cols(void) { return FT_TX; }
 
 extern "C" int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int lda, int K, const float* Wh,
                                                int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu,

@@ -195,7 +195,8 @@ class Learner:
         self.bn_stats[:, 1].fill_(1.0)
         self.bn_stats[:, 3].fill_(1.0)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # optimizer steps taken
-        ft_blocks = (H + 7) // 8                                           # workgroups of the 8-column tile kernels
+        ft_tx = self.lib.naf_fused_tile_cols()
+        ft_blocks = (H + ft_tx - 1) // ft_tx                               # workgroups of the column-tile kernels
         gb_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32) + ((H + 31) // 32) ** 2   # dWh + dW2 blocks of the bundle
         self.n_partials_norm = (P + _lib.NORM_CHUNK - 1) // _lib.NORM_CHUNK
         self.n_partials_fold = gb_blocks + 2 * ft_blocks
