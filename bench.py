@@ -195,7 +195,7 @@ def main():
                        "empty_event_bracket_ms": round(event_overhead_ms, 5),
                        "note": "one launch per vector step inside the timed loop, bracketed by HIP events on its stream; "
                                "avg_launch_ms = bracket - empty bracket; rocprofv3 --kernel-trace average of the same "
-                               "command: profiles/r01_bench_kernel_stats.csv (replay_gather_rows_kernel<1>)"}
+                               "command: profiles/r01_bench_kernel_stats.csv (replay_gather_rows_kernel<1, 0>)"}
     out["roofline"]["traffic"] = pmc_traffic(rows_per_launch)
     if rank == 0 and world == 1:
         out["roofline_bulk"] = bulk_gather(replay, dev)
