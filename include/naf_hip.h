@@ -237,7 +237,7 @@ int naf_synth_env_state_floats(int A);
  *             == 0); timeout_s bounds every wait on a peer (a time-out is counted, the kernel then proceeds)
  *   export  : writes the slab's 64-byte hipIpc handle; the host exchanges the W handles (torch.distributed)
  *   connect : all_handle_bytes = W x 64 bytes in rank order; maps every peer slab (hipIpcOpenMemHandle)
- *   allreduce_sum : two launches on `stream`: grad_out[i] = sum over ranks of grad_in[i] (in place allowed);
+ *   allreduce_sum : one launch on `stream`: grad_out[i] = sum over ranks of grad_in[i] (in place allowed);
  *             sumsq_partials (nullable) receives ceil(n_floats / naf_xgmi_chunk_floats()) partial sums of
  *             grad_out^2 for naf_adam_polyak_fused; step_dev (nullable) is advanced by one. Capturable.
  *   status  : blocking read of the epoch (all-reduces done) and of the number of timed-out waits (must stay 0). */

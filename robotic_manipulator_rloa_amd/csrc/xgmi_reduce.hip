@@ -5,18 +5,17 @@
 // The reducing kernel also emits the sum-of-squares partials clip_grad_norm_ needs (the separate norm launch of the
 // RCCL path disappears) and advances the optimizer step count.
 //
-//   launch 1  xgmi_push_kernel    grid (chunks, W-1): 16-B stores into peer memory -> system-scope release fence ->
-//                                 arrival counter; the LAST workgroup publishes the epoch flag on every peer
-//   launch 2  xgmi_reduce_kernel  grid (chunks): wave 0 polls the W-1 local flags (bounded by wall clock: a missing
-//                                 peer ends in a recorded time-out, never in a hang) -> system-scope acquire ->
-//                                 rank-ordered sum -> gradient + sumsq partial
+//   ONE launch, xgmi_allreduce_kernel, grid (chunks): every workgroup pushes its 4-KB chunk (16-B stores into each
+//   peer's memory) -> system-scope release fence -> arrival counter, the LAST workgroup to arrive publishes the epoch flag
+//   on every peer -> wave 0 polls the W-1 local flags (bounded by wall clock: a missing peer ends in a recorded time-out,
+//   never in a hang) -> system-scope acquire -> rank-ordered sum of the chunk -> gradient + sumsq partial
 //
 // Receive slots and flags live in device memory allocated UNCACHED (hipDeviceMallocUncached: not kept in any L2, so a
 // line written by a remote GPU is what the next local load returns); slots are double-buffered by epoch parity. A peer
-// can never be two epochs ahead: its push of epoch e+2 is stream-ordered behind its reduce of e+1, which waited for
-// this rank's push of e+1, which is stream-ordered behind this rank's reduce of e.
-// Nothing here allocates or synchronises after naf_xgmi_connect; both launches are plain kernel launches and can be
-// captured into a hipGraph (the epoch lives on the device).
+// can never be two epochs ahead: its launch of epoch e+2 is stream-ordered behind its launch of e+1, whose every
+// workgroup waited for this rank's flag of e+1, raised only after this rank's launch of e had finished.
+// Nothing here allocates or synchronises after naf_xgmi_connect; the launch is a plain kernel launch and can be captured
+// into a hipGraph (the epoch lives on the device).
 #include <string.h>
 #include "common.h"
 #include "../../include/naf_hip.h"
@@ -46,49 +45,44 @@ __device__ static inline float* xg_slot(char* base, size_t data_off, size_t n_pa
     return (float*)(base + data_off) + ((size_t)(epoch & 1) * world + sender) * n_pad;
 }
 
-__global__ __launch_bounds__(XG_THREADS) void xgmi_push_kernel(XgPeers peers, const float* __restrict__ grad, size_t n,
-                                                               size_t n_pad, size_t data_off, int rank, int world,
-                                                               uint64_t* __restrict__ ctrl) {
-    const uint64_t e = ctrl[0] + 1;        // nobody writes ctrl[0] before every workgroup has arrived below
-    const int peer = (int)blockIdx.y + ((int)blockIdx.y >= rank ? 1 : 0);
-    const size_t i = (size_t)blockIdx.x * XG_CHUNK + (size_t)threadIdx.x * 4;
-    if (i < n) {                           // n is a multiple of 4 (checked on the host)
-        const xg_f4 v = *(const xg_f4*)(grad + i);
-        float* dst = xg_slot(peers.base[peer], data_off, n_pad, world, e, rank);
-        *(xg_f4*)(dst + i) = v;
-    }
-    __threadfence_system();                // every wave: its stores have reached the peer before it arrives
-    __syncthreads();
-    __shared__ int last;
-    if (threadIdx.x == 0) {
-        const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
-        const unsigned long long old = atomicAdd((unsigned long long*)&ctrl[1], 1ull);
-        last = (old == total - 1);
-    }
-    __syncthreads();
-    if (last && threadIdx.x < world && (int)threadIdx.x != rank) {
-        uint64_t* flag = (uint64_t*)(peers.base[threadIdx.x] + (size_t)rank * XG_FLAG_STRIDE);
-        __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (last && threadIdx.x == 0) {
-        ctrl[1] = 0;
-        ctrl[0] = e;
-    }
-}
-
+// One launch per all-reduce. No workgroup waits for another workgroup of its own launch (the last one to ARRIVE raises
+// the flags; nobody polls the arrival counter), so the only waits are on the peers' flags, which depend on nothing but the
+// peers' own pushes: no circular wait whatever the residency of the grid.
 template <int world>
-__global__ __launch_bounds__(XG_THREADS) void xgmi_reduce_kernel(XgPeers peers, const float* __restrict__ grad_in,
-                                                                 float* __restrict__ grad_out, size_t n, size_t n_pad,
-                                                                 size_t data_off, int rank,
-                                                                 uint64_t* __restrict__ ctrl,
-                                                                 float* __restrict__ sumsq_partials, int32_t* step_dev,
-                                                                 long long timeout_ticks) {
+__global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peers, const float* __restrict__ grad_in,
+                                                                    float* __restrict__ grad_out, size_t n, size_t n_pad,
+                                                                    size_t data_off, int rank,
+                                                                    uint64_t* __restrict__ ctrl,
+                                                                    float* __restrict__ sumsq_partials, int32_t* step_dev,
+                                                                    long long timeout_ticks) {
     __shared__ float red[XG_THREADS / 64];
-    const uint64_t e = ctrl[0];            // published by the push launch in front of this one
+    __shared__ int last;
+    const uint64_t e = ctrl[0] + 1;        // nobody writes ctrl[0] before every workgroup has arrived below
     const size_t i = (size_t)blockIdx.x * XG_CHUNK + (size_t)threadIdx.x * 4;
-    // own contribution requested before the wait: it does not depend on any peer
+    const bool on = i < n;                 // n is a multiple of 4 (checked on the host)
+    // ---- push: this workgroup's chunk of the local gradient into the slot `rank` of every peer ---------------------
     xg_f4 mine = {0.f, 0.f, 0.f, 0.f};
-    if (i < n) mine = *(const xg_f4*)(grad_in + i);
+    if (on) {
+        mine = *(const xg_f4*)(grad_in + i);
+#pragma unroll
+        for (int p = 0; p < world; ++p)
+            if (p != rank) *(xg_f4*)(xg_slot(peers.base[p], data_off, n_pad, world, e, rank) + i) = mine;
+    }
+    __threadfence_system();                // every wave: its stores have reached the peers before it arrives
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd((unsigned long long*)&ctrl[1], 1ull) == (unsigned long long)gridDim.x - 1);
+    __syncthreads();
+    if (last) {
+        if (threadIdx.x < world && (int)threadIdx.x != rank) {
+            uint64_t* flag = (uint64_t*)(peers.base[threadIdx.x] + (size_t)rank * XG_FLAG_STRIDE);
+            __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (threadIdx.x == 0) {
+            ctrl[1] = 0;
+            ctrl[0] = e;
+        }
+    }
+    // ---- wait for the W-1 peers' flags (bounded), then the rank-ordered sum of this chunk ------------------------------
     if (threadIdx.x < world && (int)threadIdx.x != rank) {
         const uint64_t* flag = (const uint64_t*)(peers.base[rank] + (size_t)threadIdx.x * XG_FLAG_STRIDE);
         const long long t0 = wall_clock64();
@@ -103,7 +97,7 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_reduce_kernel(XgPeers peers, 
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");            // system scope: drop anything this CU still holds
     float ss = 0.f;
-    if (i < n) {
+    if (on) {
         // all W-1 peer contributions in flight together (the slot of the own rank is never written: its address is
         // read like the others and the value replaced, which keeps the loop free of divergent addressing)
         const float* slot0 = xg_slot(peers.base[rank], data_off, n_pad, world, e, 0) + i;
@@ -219,14 +213,11 @@ extern "C" int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float*
     for (int p = 0; p < c->world; ++p)
         if (!c->peers.base[p]) return NAF_ERR_STATE;           // naf_xgmi_connect has not mapped every peer
     const unsigned chunks = (unsigned)(c->n_pad / XG_CHUNK);
-    xgmi_push_kernel<<<dim3(chunks, c->world - 1), XG_THREADS, 0, (hipStream_t)stream>>>(
-        c->peers, grad_in, c->n, c->n_pad, c->data_off, c->rank, c->world, c->ctrl);
-    NAF_CHECK_LAUNCH();
-#define XG_REDUCE(W)                                                                                              \
-    case W:                                                                                                       \
-        xgmi_reduce_kernel<W><<<chunks, XG_THREADS, 0, (hipStream_t)stream>>>(                                    \
-            c->peers, grad_in, grad_out, c->n, c->n_pad, c->data_off, c->rank, c->ctrl, sumsq_partials, step_dev, \
-            c->timeout_ticks);                                                                                    \
+#define XG_REDUCE(W)                                                                                                 \
+    case W:                                                                                                          \
+        xgmi_allreduce_kernel<W><<<chunks, XG_THREADS, 0, (hipStream_t)stream>>>(                                    \
+            c->peers, grad_in, grad_out, c->n, c->n_pad, c->data_off, c->rank, c->ctrl, sumsq_partials, step_dev,    \
+            c->timeout_ticks);                                                                                       \
         break;
     switch (c->world) {
         XG_REDUCE(2) XG_REDUCE(3) XG_REDUCE(4) XG_REDUCE(5) XG_REDUCE(6) XG_REDUCE(7) XG_REDUCE(8)

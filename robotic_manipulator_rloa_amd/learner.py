@@ -405,7 +405,7 @@ class Learner:
             # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
             if self.xgmi is not None:
-                # push + rank-ordered reduce; the reduce launch leaves the sum-of-squares partials and the step count
+                # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
                 self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev)
                 self.optimizer_step(norm_ready=True)
                 return

@@ -71,7 +71,7 @@ def _agree(ok: bool, device: torch.device, group=None) -> bool:
 class XgmiAllReduce:
     """One-shot sum all-reduce of the flat gradient over peer-mapped device memory (csrc/xgmi_reduce.hip):
     every rank pushes its gradient into a slot on each peer over xGMI and sums the W contributions in rank order.
-    Two capturable launches, no host involvement per call; the reduce launch also emits the grad-norm partials.
+    One capturable launch, no host involvement per call; it also emits the grad-norm partials.
 
     `XgmiAllReduce.try_create` is collective: either every rank of the group gets a verified communicator, or every
     rank gets None (and the caller stays on the RCCL all-reduce). Verification = `self_test`: exact integer-valued
