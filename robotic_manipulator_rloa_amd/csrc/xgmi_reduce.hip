@@ -192,6 +192,16 @@ extern "C" int naf_xgmi_export(void* handle, void* out_handle_bytes) {
 extern "C" int naf_xgmi_connect(void* handle, const void* all_handle_bytes) {
     if (!handle || !all_handle_bytes) return NAF_ERR_ARG;
     XgmiComm* c = xg_comm(handle);
+    // peers may sit on any other device of the node: make them reachable before mapping (errors such as "already
+    // enabled" are not failures; hipIpcOpenMemHandle below is what decides)
+    int cur = 0, ndev = 0;
+    if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&ndev) == hipSuccess) {
+        for (int d = 0; d < ndev; ++d) {
+            int can = 0;
+            if (d != cur && hipDeviceCanAccessPeer(&can, cur, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0);
+        }
+        (void)hipGetLastError();
+    }
     for (int p = 0; p < c->world; ++p) {
         if (p == c->rank || c->opened[p]) continue;
         hipIpcMemHandle_t h;
