@@ -21,7 +21,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
     float momentum, float eps) {
     __shared__ float red[BN_TX * BN_TY / 64][BN_TX + 1];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * BN_TX + tx;
+    const int col = naf_xcd_tile(blockIdx.x, gridDim.x) * BN_TX + tx;
     const int net = blockIdx.y;
     const bool col_on = col < H;
     const float* gz = g + net * g_net_stride;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
     __shared__ float red[BN_TX * BN_TY / 64][BN_TX + 1];
     __shared__ float red2[BN_TX * BN_TY / 64][BN_TX + 1];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * BN_TX + tx;
+    const int col = naf_xcd_tile(blockIdx.x, gridDim.x) * BN_TX + tx;
     const bool col_on = col < H;
     const float b = (bias && col_on) ? bias[col] : 0.f;
     const float mean = col_on ? save_mean[col] : 0.f;

@@ -2,6 +2,14 @@
 #pragma once
 #include "common.h"
 
+// Which column tile a workgroup owns. Workgroups are dealt round-robin over the 8 XCDs (XCD = blockIdx.x % 8; for the
+// two-net grids too, their x extent being a multiple of 8), and an 8-column f32 tile is a quarter of a 128-B line: with
+// tile = blockIdx.x the four tiles sharing every line of the activation matrices sit on four different XCDs, and each
+// of those L2s pulls the whole line over the fabric — for data the previous kernel has only just written (the dominant
+// cost of an update, benchmarks/chain_probe.py). Dealing CONTIGUOUS runs of tiles to an XCD lets one L2 fetch a line
+// once for all its tiles. Placement is speed only: results do not depend on it.
+__device__ static inline int naf_xcd_tile(int b, int n) { return (n & 7) == 0 ? (b & 7) * (n >> 3) + (b >> 3) : b; }
+
 // tile shape: TX feature columns x TY row phases per workgroup (TX*TY threads, TX <= 64, TX*TY % 64 == 0).
 // Column sums: lanes of a wave that share a column (lane = phase*TX + tx) fold by xor shuffles, the TX*TY/64 wave
 // results meet in LDS. Fixed order -> bitwise reproducible.

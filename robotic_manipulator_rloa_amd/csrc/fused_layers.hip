@@ -68,7 +68,8 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
     __shared__ float red[FT_NW][FT_TX + 1];
     __shared__ float sW[FT_TX][4 * MAX_K4 + 1];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
-    const int col0 = blockIdx.x * FT_TX, col = col0 + tx, net = blockIdx.y;
+    const int bx = naf_xcd_tile(blockIdx.x, gridDim.x);
+    const int col0 = bx * FT_TX, col = col0 + tx, net = blockIdx.y;
     const bool col_on = col < H;
     const int64_t po = net * param_net_stride;
     const float* xn = x + net * x_net_stride;
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     __shared__ float sG[FT_NW][FT_TX][4 * MAX_K4 + 1];   // per-wave partial dW tiles
     __shared__ float sQ[FT_NW];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
-    const int col0 = blockIdx.x * FT_TX, col = col0 + tx;
+    const int bx = naf_xcd_tile(blockIdx.x, gridDim.x);
+    const int col0 = bx * FT_TX, col = col0 + tx;
     const bool col_on = col < H;
     const float b = col_on ? bias[col] : 0.f;
     const float mean = col_on ? save_mean[col] : 0.f;
@@ -242,8 +244,8 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     if (sumsq_partials) {   // first half of clip_grad_norm_ folded in: no separate pass over these gradients
         const float tot = block_sum_to_thread0<FT_THREADS>(sq, sQ, tid);
         if (tid == 0) {
-            sumsq_partials[blockIdx.x] = tot;
-            if (blockIdx.x == 0 && step_dev) *step_dev += 1;   // read by the NEXT launch (Adam) only
+            sumsq_partials[bx] = tot;
+            if (bx == 0 && step_dev) *step_dev += 1;   // read by the NEXT launch (Adam) only
         }
     }
 }
@@ -263,7 +265,8 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     __shared__ float sWh[4 * NH4][FT_TX + 1];
     __shared__ float sQ[FT_NW];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
-    const int col0 = blockIdx.x * FT_TX, col = col0 + tx;
+    const int bx = naf_xcd_tile(blockIdx.x, gridDim.x);
+    const int col0 = bx * FT_TX, col = col0 + tx;
     const bool col_on = col < H;
     const float b = (bias && col_on) ? bias[col] : 0.f;
     const float mean = col_on ? save_mean[col] : 0.f;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     }
     if (sumsq_partials) {
         const float tot = block_sum_to_thread0<FT_THREADS>(sq, sQ, ty * FT_TX + tx);
-        if (ty == 0 && tx == 0) sumsq_partials[blockIdx.x] = tot;
+        if (ty == 0 && tx == 0) sumsq_partials[bx] = tot;
     }
 }
 
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
     __shared__ __attribute__((aligned(16))) float sW[NH4][4 * S3_TX + 4];
     __shared__ float sBias[NHP];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * S3_TX + tx;
-    const int col0 = blockIdx.x * S3_TX, col = col0 + tx;
+    const int bx = naf_xcd_tile(blockIdx.x, gridDim.x);
+    const int col0 = bx * S3_TX, col = col0 + tx;
     const int net = blockIdx.y;
     const bool col_on = col < H;
     const float* gz = g + net * g_net_stride;
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
     if (tid < NHP * S3_TX) {
         const int h = tid / S3_TX, c = tid - h * S3_TX;
         wreg = (col0 + c < H) ? Whn[(int64_t)h * ldw + col0 + c] : 0.f;
-    } else if (tid < NHP * S3_TX + NHP && blockIdx.x == 0) {
+    } else if (tid < NHP * S3_TX + NHP && bx == 0) {
         breg = Whn[(int64_t)(tid - NHP * S3_TX) * ldw + H];                     // bias = column H (the ones column of A2)
     }
 
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
     __syncthreads();
     if (net == 0) {
         // item = (row, group of 4 heads); consecutive threads take consecutive head groups of one row
-        float* dst = heads_partial + (int64_t)blockIdx.x * slab_stride;
+        float* dst = heads_partial + (int64_t)bx * slab_stride;
         constexpr int ITEMS = (RPT * S3_TY * NH4 + S3_THREADS - 1) / S3_THREADS;
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
             ((float4*)(dst + (int64_t)row * NHP))[hq] = acc;
         }
     } else {
-        float* dst = vnext_partial + (int64_t)blockIdx.x * B;
+        float* dst = vnext_partial + (int64_t)bx * B;
         for (int row = tid; row < B; row += S3_THREADS) {
             const float4 a0 = ((const float4*)sA[row])[0], a1 = ((const float4*)sA[row])[1];
             const float4 w0 = ((const float4*)sW[v_col >> 2])[2 * (v_col & 3)], w1 = ((const float4*)sW[v_col >> 2])[2 * (v_col & 3) + 1];
