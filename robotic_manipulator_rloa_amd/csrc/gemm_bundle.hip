@@ -38,23 +38,45 @@ struct GemmBundle {
 //   k-major operand      -> LDS [k][row] (stride GB_LDK), fragments read as four ds_read_b32 (bank = 4k + row: the two
 //                           16-lane groups a b32 read serves per cycle never collide)
 // (the first version transposed k-major panels while staging: 4 ds_write_b32 per float4 with a 4-way bank conflict)
+// A panel is 32 rows x kc k = kc * 8 float4, GB_KC * 8 / 256 = 8 per thread. ALL of a thread's loads — of both panels —
+// are issued before the first LDS store: as a load -> store loop (one load in flight per thread) the staging was 16
+// serial memory round trips per block, ~200 cycles each on L2 hits but 545+ on data the previous kernel had just
+// written (Infinity Cache): the whole fresh-data penalty of this kernel (benchmarks/chain_probe.py: 1.8 of its 8.5 us).
+#define GB_PT (GB_KC * 8 / 256)   // float4 per thread per panel
 template <bool KMAJOR>
-__device__ static inline void stage_panel(float* __restrict__ sm, const float* __restrict__ p, int ld, int row0, int rows_total,
-                                          int k0, int kc, int tid) {
-    if (KMAJOR) {
-        for (int e = tid; e < kc * 8; e += 256) {
-            const int k = e >> 3, r4 = (e & 7) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r4 < rows_total) v = *(const float4*)(p + (int64_t)(k0 + k) * ld + row0 + r4);
-            *(float4*)(sm + k * GB_LDK + r4) = v;
+__device__ static inline void load_panel(float4 (&v)[GB_PT], const float* __restrict__ p, int ld, int row0,
+                                         int rows_total, int k0, int kc, int tid) {
+#pragma unroll
+    for (int i = 0; i < GB_PT; ++i) {
+        const int e = tid + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < kc * 8) {
+            if (KMAJOR) {
+                const int k = e >> 3, r4 = (e & 7) * 4;
+                if (row0 + r4 < rows_total) v[i] = *(const float4*)(p + (int64_t)(k0 + k) * ld + row0 + r4);
+            } else {
+                const int k4n = kc >> 2;
+                const int row = e / k4n, k4 = (e - row * k4n) * 4;
+                if (row0 + row < rows_total) v[i] = *(const float4*)(p + (int64_t)(row0 + row) * ld + k0 + k4);
+            }
         }
-    } else {
-        const int k4n = kc >> 2;
-        for (int e = tid; e < 32 * k4n; e += 256) {
-            const int row = e / k4n, k4 = (e - row * k4n) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + row < rows_total) v = *(const float4*)(p + (int64_t)(row0 + row) * ld + k0 + k4);
-            *(float4*)(sm + row * GB_LD + k4) = v;
+    }
+}
+
+template <bool KMAJOR>
+__device__ static inline void store_panel(float* __restrict__ sm, const float4 (&v)[GB_PT], int kc, int tid) {
+#pragma unroll
+    for (int i = 0; i < GB_PT; ++i) {
+        const int e = tid + 256 * i;
+        if (e < kc * 8) {
+            if (KMAJOR) {
+                const int k = e >> 3, r4 = (e & 7) * 4;
+                *(float4*)(sm + k * GB_LDK + r4) = v[i];
+            } else {
+                const int k4n = kc >> 2;
+                const int row = e / k4n, k4 = (e - row * k4n) * 4;
+                *(float4*)(sm + row * GB_LD + k4) = v[i];
+            }
         }
     }
 }
@@ -79,8 +101,11 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
     for (int k0 = 0; k0 < D.K; k0 += GB_KC) {
         const int kc = (D.K - k0) < GB_KC ? (D.K - k0) : GB_KC;
         if (k0) __syncthreads();                          // previous chunk fully consumed
-        stage_panel<AK>(sA, D.A, D.lda, m0, D.M, k0, kc, tid);
-        stage_panel<BK>(sB, D.B, D.ldb, n0, D.N, k0, kc, tid);
+        float4 va[GB_PT], vb[GB_PT];
+        load_panel<AK>(va, D.A, D.lda, m0, D.M, k0, kc, tid);
+        load_panel<BK>(vb, D.B, D.ldb, n0, D.N, k0, kc, tid);
+        store_panel<AK>(sA, va, kc, tid);
+        store_panel<BK>(sB, vb, kc, tid);
         __syncthreads();
 #pragma unroll 4
         for (int kk = 0; kk < kc; kk += 16) {
