@@ -87,7 +87,7 @@ class XgmiAllReduce:
 
     @classmethod
     def try_create(cls, n_floats: int, device: torch.device, group=None, timeout_s: float = 30.0,
-                   test_rounds: int = 48, test_timeout_s: float = 3.0) -> Optional["XgmiAllReduce"]:
+                   test_rounds: int = 128, test_timeout_s: float = 3.0) -> Optional["XgmiAllReduce"]:
         import ctypes as C
         from . import _lib
         if not dist.is_initialized() or dist.get_world_size(group) < 2:
@@ -144,7 +144,7 @@ class XgmiAllReduce:
         self.lib.naf_xgmi_status(self.handle, C.byref(e), C.byref(t))
         return int(e.value), int(t.value)
 
-    def self_test(self, rounds: int = 48) -> bool:
+    def self_test(self, rounds: int = 128) -> bool:
         """Exact check of this rank's results: rank r contributes (r+1) * ((i + 3*round) % 61), whose sum over ranks is
         an integer below 2^24 (exact in f32 whatever the order)."""
         i = torch.arange(self.n, device=self.device, dtype=torch.int64)
