@@ -26,6 +26,16 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
     const bool col_on = col < H;
     const float* gz = g + net * g_net_stride;
     float* oz = out + net * out_net_stride;
+    float x[RPT];
+    float sum = 0.f;
+    // unconditional loads (clamped at the edges, masked afterwards): `on ? load + b : 0` made the compiler branch around
+    // every row's load and wait at each merge — RPT serial round trips instead of one
+    const int colc = col_on ? col : H - 1;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int row = ty + k * BN_TY;
+        x[k] = gz[(int64_t)(row < B ? row : B - 1) * ldg + colc];
+    }
     const int64_t po = net * param_net_stride;
     const float b = (bias && col_on) ? bias[po + col] : 0.f;
     // every per-column scalar is requested up front: its latency hides under the matrix loads below
@@ -35,12 +45,9 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
     const float rm_old = (ty == 0 && col_on) ? running_mean[so] : 0.f;
     const float rv_old = (ty == 0 && col_on) ? running_var[so] : 0.f;
 
-    float x[RPT];
-    float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * BN_TY;
-        x[k] = (col_on && row < B) ? gz[(int64_t)row * ldg + col] + b : 0.f;
+        x[k] = (col_on && (ty + k * BN_TY) < B) ? x[k] + b : 0.f;
         sum += x[k];
     }
     const float mean = bn_col_reduce<BN_TX, BN_TY>(sum, red, tx, ty) / (float)B;
@@ -88,13 +95,23 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
 
     float xh[RPT], dy[RPT];
     float s_dy = 0.f, s_dyxh = 0.f;
+    float zl[RPT], ol[RPT], dl[RPT];
+    const int colc = col_on ? col : H - 1;       // unconditional loads first (see the forward kernel)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int row = ty + k * BN_TY;
+        const int64_t rowc = row < B ? row : B - 1;
+        zl[k] = g[rowc * ldg + colc];
+        ol[k] = out[rowc * ldo + colc];
+        dl[k] = d_out[rowc * ld_dout + colc];
+    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         int row = ty + k * BN_TY;
         bool on = col_on && row < B;
-        float z = on ? g[(int64_t)row * ldg + col] + b : 0.f;
-        float o = on ? out[(int64_t)row * ldo + col] : 0.f;
-        float dd = on ? d_out[(int64_t)row * ld_dout + col] : 0.f;
+        float z = on ? zl[k] + b : 0.f;
+        float o = on ? ol[k] : 0.f;
+        float dd = on ? dl[k] : 0.f;
         xh[k] = on ? (z - mean) * invstd : 0.f;
         dy[k] = o > 0.f ? dd : 0.f;  // ReLU mask from the forward's own output
         s_dy += dy[k];

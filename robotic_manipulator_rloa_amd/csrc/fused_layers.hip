@@ -162,15 +162,28 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     float xh[RPT], dy[RPT];
     float4 xv[RPT][K4];
     float ov[RPT], ddv[RPT];
+    // Every matrix operand is requested before the weight-tile barrier, UNCONDITIONALLY: rows/columns beyond the edge
+    // are clamped to the last valid one and masked after the loads. With `on ? load : 0` the compiler branched around
+    // each row's loads and waited (vmcnt 0) at every merge: RPT serial round trips instead of one.
+    const int colc = col_on ? col : H - 1;
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {      // every matrix operand is requested before the weight-tile barrier
-        int row = ty + k * FT_TY;
-        bool on = col_on && row < B;
+    for (int k = 0; k < RPT; ++k) {
+        const int row = ty + k * FT_TY;
+        const int rowc = row < B ? row : B - 1;
 #pragma unroll
-        for (int q = 0; q < K4; ++q)
-            xv[k][q] = (row < B) ? ((const float4*)(x + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        ov[k] = on ? out[(int64_t)row * ldo + col] : 0.f;
-        ddv[k] = on ? d_out[(int64_t)row * ld_dout + col] : 0.f;
+        for (int q = 0; q < K4; ++q) xv[k][q] = ((const float4*)(x + (int64_t)rowc * ldx))[q];
+        ov[k] = out[(int64_t)rowc * ldo + colc];
+        ddv[k] = d_out[(int64_t)rowc * ld_dout + colc];
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const bool on = col_on && (ty + k * FT_TY) < B;
+        if (!((ty + k * FT_TY) < B)) {
+#pragma unroll
+            for (int q = 0; q < K4; ++q) xv[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        ov[k] = on ? ov[k] : 0.f;
+        ddv[k] = on ? ddv[k] : 0.f;
     }
     float w[4 * K4];
     load_w_column<K4>(W, col0, H, K, sW, tid, tx, w);
@@ -275,15 +288,25 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     // every matrix operand is requested before the weight-tile barrier
     float4 dhv[RPT][NH4];
     float zv[RPT], ov[RPT];
+    const int colc = col_on ? col : H - 1;       // unconditional loads, clamped at the edges, masked afterwards (see B1)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * FT_TY;
-        bool on = col_on && row < B;
+        const int row = ty + k * FT_TY;
+        const int rowc = row < B ? row : B - 1;
 #pragma unroll
-        for (int q = 0; q < NH4; ++q)
-            dhv[k][q] = (row < B) ? ((const float4*)(d_heads + (int64_t)row * ldh))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        zv[k] = on ? g[(int64_t)row * ldg + col] + b : 0.f;
-        ov[k] = on ? out[(int64_t)row * ldo + col] : 0.f;
+        for (int q = 0; q < NH4; ++q) dhv[k][q] = ((const float4*)(d_heads + (int64_t)rowc * ldh))[q];
+        zv[k] = g[(int64_t)rowc * ldg + colc];
+        ov[k] = out[(int64_t)rowc * ldo + colc];
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const bool rin = (ty + k * FT_TY) < B, on = col_on && rin;
+        if (!rin) {
+#pragma unroll
+            for (int q = 0; q < NH4; ++q) dhv[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        zv[k] = on ? zv[k] + b : 0.f;
+        ov[k] = on ? ov[k] : 0.f;
     }
     // Wh[:, col0 .. col0+TX): 4*NH4 x TX tile, one element per thread
     for (int e = tid; e < 4 * NH4 * FT_TX; e += FT_THREADS) {
@@ -376,6 +399,14 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
     const bool col_on = col < H;
     const float* gz = g + net * g_net_stride;
     float* oz = out + net * out_net_stride;
+    float x[RPT];
+    float sum = 0.f;
+    const int colc = col_on ? col : H - 1;       // unconditional loads, clamped at the edges, masked afterwards (see B1)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int row = ty + k * S3_TY;
+        x[k] = gz[(int64_t)(row < B ? row : B - 1) * ldg + colc];
+    }
     const int64_t po = net * param_net_stride;
     const float b = (bias && col_on) ? bias[po + col] : 0.f;
     const float gm = col_on ? gamma[po + col] : 0.f;
@@ -393,12 +424,9 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
         breg = Whn[(int64_t)(tid - NHP * S3_TX) * ldw + H];                     // bias = column H (the ones column of A2)
     }
 
-    float x[RPT];
-    float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * S3_TY;
-        x[k] = (col_on && row < B) ? gz[(int64_t)row * ldg + col] + b : 0.f;
+        x[k] = (col_on && (ty + k * S3_TY) < B) ? x[k] + b : 0.f;
         sum += x[k];
     }
     const float mean = bn_col_reduce<S3_TX, S3_TY>(sum, red, tx, ty) / (float)B;
