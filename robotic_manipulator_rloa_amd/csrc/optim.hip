@@ -94,28 +94,35 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
     __shared__ AdamScalars sh;
     const size_t n4 = n / 4;
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // first trip's operands are requested BEFORE the scalar prologue: the 21-partial sum, the sqrt and the two
-    // double-precision powers of thread 0 then run under the latency of these loads instead of in front of it
-    float4 th0 = make_float4(0.f, 0.f, 0.f, 0.f), gr0 = th0, mm0 = th0, vv0 = th0, tg0 = th0;
-    if (i0 < n4) {
-        th0 = ((float4*)theta)[i0];
-        gr0 = ((const float4*)g)[i0];
-        mm0 = ((float4*)m)[i0];
-        vv0 = ((float4*)v)[i0];
-        if (target) tg0 = ((float4*)target)[i0];
+    // first trip's operands AND the norm partials are requested up front, branch-free (indices clamped, results masked
+    // later): the partial sum, the sqrt and the two double-precision powers of thread 0 then run under the latency of
+    // these loads instead of in front of it. (With the loads inside `if`s the compiler waited for the operand loads at
+    // the merge before it even issued the partials' loads: two serial round trips.)
+    const size_t i0c = i0 < n4 ? i0 : (n4 ? n4 - 1 : 0);
+    float4 th0 = ((float4*)theta)[i0c];
+    float4 gr0 = ((const float4*)g)[i0c];
+    float4 mm0 = ((float4*)m)[i0c];
+    float4 vv0 = ((float4*)v)[i0c];
+    float4 tg0 = ((float4*)(target ? target : theta))[i0c];
+    const int t = *step_dev;                 // (uniform: a scalar load, in flight with the rest)
+    float pr[NAF_MAX_NORM_PARTIALS / 64];
+#pragma unroll
+    for (int j = 0; j < NAF_MAX_NORM_PARTIALS / 64; ++j) {
+        const int k = (int)(threadIdx.x & 63) + 64 * j;
+        pr[j] = partials[k < n_partials ? k : 0];
     }
     if (threadIdx.x < 64) {
         // every workgroup re-derives the same scalars from the same partials in the same order: the first wave takes
-        // the partials 64 at a time (all loads in flight together), folds them with xor shuffles
+        // the partials 64 at a time, folds them with xor shuffles
         float s = 0.f;
-        for (int k = threadIdx.x; k < n_partials; k += 64) s += partials[k];
+#pragma unroll
+        for (int j = 0; j < NAF_MAX_NORM_PARTIALS / 64; ++j) s += ((int)threadIdx.x + 64 * j < n_partials) ? pr[j] : 0.f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (threadIdx.x == 0) {
             const float total_norm = sqrtf(s) * inv_world;
             float clip = max_norm / (total_norm + 1e-6f);
             clip = clip > 1.0f ? 1.0f : clip;
-            const int t = *step_dev;
             const double bc1 = 1.0 - ipow((double)beta1, t);
             const double bc2 = 1.0 - ipow((double)beta2, t);
             sh.clip_scale = clip * inv_world;
@@ -160,7 +167,9 @@ extern "C" int naf_adam_polyak_fused(float* theta, const float* g, float* m, flo
                                      const float* partials, int n_partials, float max_norm, float lr, float beta1,
                                      float beta2, float eps, float tau, float one_minus_tau, const int32_t* step_dev,
                                      float inv_world, size_t n, void* stream) {
-    if (!theta || !g || !m || !v || !partials || !step_dev || n == 0 || n_partials <= 0) return NAF_ERR_ARG;
+    if (!theta || !g || !m || !v || !partials || !step_dev || n < 4 || n_partials <= 0 ||
+        n_partials > NAF_MAX_NORM_PARTIALS)
+        return NAF_ERR_ARG;
     if ((((uintptr_t)theta | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)theta_target) & 15) != 0)
         return NAF_ERR_ARG;
     size_t n4 = (n + 3) / 4;
