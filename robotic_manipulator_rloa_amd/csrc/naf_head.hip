@@ -57,19 +57,22 @@ __global__ __launch_bounds__(NH_THREADS) void naf_head_kernel(const float* __res
             // V'(s') — is requested before the first use, then added in slab order
             const int64_t sv = (live_ ? s_ : s0) * ldv;
             constexpr int NS = SPLITK ? NSLAB : 1;
+            // V'(s') pieces first, then the rows' pieces; the scheduling barrier keeps every load in front of the first
+            // add (left alone, the scheduler kept ~12 loads in flight to save registers: 3 round trips instead of 1)
+            float pv[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) pv[j] = v_next[sv + j * vn_slab_stride];
             for (int k0 = 0; k0 < n4; k0 += NH_THREADS) {
                 const int k = (k0 + tid < n4) ? k0 + tid : 0;
                 float4 p[NS];
 #pragma unroll
                 for (int j = 0; j < NS; ++j) p[j] = ((const float4*)(heads + s0 * ldh + j * slab_stride))[k];
+                __builtin_amdgcn_sched_barrier(0);
                 float4 acc = p[0];
 #pragma unroll
                 for (int j = 1; j < NS; ++j) { acc.x += p[j].x; acc.y += p[j].y; acc.z += p[j].z; acc.w += p[j].w; }
                 if (k0 + tid < n4) ((float4*)sh_in)[k0 + tid] = acc;
             }
-            float pv[NS];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) pv[j] = v_next[sv + j * vn_slab_stride];
             float v = pv[0];
 #pragma unroll
             for (int j = 1; j < NS; ++j) v += pv[j];
