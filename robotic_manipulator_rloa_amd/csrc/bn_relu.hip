@@ -20,6 +20,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
     int64_t out_net_stride, int ldo, float* __restrict__ save_mean, float* __restrict__ save_invstd, int B, int H,
     float momentum, float eps) {
     __shared__ float red[BN_TX * BN_TY / 64][BN_TX + 1];
+    __shared__ float redv[BN_TX * BN_TY / 64][BN_TX + 1];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int col = naf_xcd_tile(blockIdx.x, gridDim.x) * BN_TX + tx;
     const int net = blockIdx.y;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
         x[k] = (col_on && (ty + k * BN_TY) < B) ? x[k] + b : 0.f;
         sum += x[k];
     }
-    const float mean = bn_col_reduce<BN_TX, BN_TY>(sum, red, tx, ty) / (float)B;
+    const float mean = bn_col_reduce<BN_TX, BN_TY, true>(sum, red, tx, ty) / (float)B;
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_kernel(
         float dlt = (row < B) ? x[k] - mean : 0.f;
         ss += dlt * dlt;
     }
-    const float var = bn_col_reduce<BN_TX, BN_TY>(ss, red, tx, ty) / (float)B;  // biased: what normalises
+    const float var = bn_col_reduce<BN_TX, BN_TY, true>(ss, redv, tx, ty) / (float)B;  // biased: what normalises
     const float invstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
     float* __restrict__ d_beta, float* __restrict__ d_bias, int B, int H) {
     __shared__ float red[BN_TX * BN_TY / 64][BN_TX + 1];
     __shared__ float red2[BN_TX * BN_TY / 64][BN_TX + 1];
+    __shared__ float red3[BN_TX * BN_TY / 64][BN_TX + 1];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int col = naf_xcd_tile(blockIdx.x, gridDim.x) * BN_TX + tx;
     const bool col_on = col < H;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
         s_dyxh += dy[k] * xh[k];
     }
     float dbeta, dgamma;
-    bn_col_reduce2<BN_TX, BN_TY>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
+    bn_col_reduce2<BN_TX, BN_TY, true>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
     const float invB = 1.0f / (float)B;
     const float k1 = gm * invstd;
     float s_dz = 0.f;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
             s_dz += dz;
         }
     }
-    const float dbias = bn_col_reduce<BN_TX, BN_TY>(s_dz, red, tx, ty);  // Linear bias under a train-mode BN: ~0 up to rounding
+    const float dbias = bn_col_reduce<BN_TX, BN_TY, true>(s_dz, red3, tx, ty);  // Linear bias under a train-mode BN: ~0 up to rounding
     if (ty == 0 && col_on) {
         d_gamma[col] = dgamma;
         d_beta[col] = dbeta;

@@ -13,7 +13,10 @@ __device__ static inline int naf_xcd_tile(int b, int n) { return (n & 7) == 0 ? 
 // tile shape: TX feature columns x TY row phases per workgroup (TX*TY threads, TX <= 64, TX*TY % 64 == 0).
 // Column sums: lanes of a wave that share a column (lane = phase*TX + tx) fold by xor shuffles, the TX*TY/64 wave
 // results meet in LDS. Fixed order -> bitwise reproducible.
-template <int BN_TX, int BN_TY>
+// FRESH = the LDS array(s) passed in have not been touched by this workgroup before: the leading barrier ("the previous
+// use is over") is skipped. Every reduction of a kernel gets its own array for exactly that reason — these kernels are
+// chains of short barrier-separated phases, and a barrier costs about as much as the phase it guards.
+template <int BN_TX, int BN_TY, bool FRESH = false>
 __device__ static inline void bn_col_reduce2(float pa, float pb, float (*red)[BN_TX + 1], float (*red2)[BN_TX + 1], int tx,
                                              int ty, float* oa, float* ob) {
     constexpr int NW = BN_TX * BN_TY / 64;
@@ -23,7 +26,7 @@ __device__ static inline void bn_col_reduce2(float pa, float pb, float (*red)[BN
         pb += __shfl_xor(pb, o);
     }
     const int tid = ty * BN_TX + tx;
-    __syncthreads();  // previous use of red/red2 is over
+    if (!FRESH) __syncthreads();  // previous use of red/red2 is over
     if ((tid & 63) < BN_TX) {
         red[tid >> 6][tx] = pa;
         red2[tid >> 6][tx] = pb;
@@ -39,13 +42,13 @@ __device__ static inline void bn_col_reduce2(float pa, float pb, float (*red)[BN
     *ob = sb;
 }
 
-template <int BN_TX, int BN_TY>
+template <int BN_TX, int BN_TY, bool FRESH = false>
 __device__ static inline float bn_col_reduce(float part, float (*red)[BN_TX + 1], int tx, int ty) {
     constexpr int NW = BN_TX * BN_TY / 64;
 #pragma unroll
     for (int o = BN_TX; o < 64; o <<= 1) part += __shfl_xor(part, o);
     const int tid = ty * BN_TX + tx;
-    __syncthreads();
+    if (!FRESH) __syncthreads();
     if ((tid & 63) < BN_TX) red[tid >> 6][tx] = part;
     __syncthreads();
     float s = 0.f;
@@ -57,11 +60,11 @@ __device__ static inline float bn_col_reduce(float part, float (*red)[BN_TX + 1]
 
 // Sum of one float per thread over a whole workgroup of NT threads (NT % 64 == 0), result valid in thread 0.
 // Fixed order (xor shuffles inside a wave, then the wave results in index order) -> bitwise reproducible.
-template <int NT>
+template <int NT, bool FRESH = false>
 __device__ static inline float block_sum_to_thread0(float v, float* sh /* >= NT/64 floats */, int tid) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
+    if (!FRESH) __syncthreads();
     if ((tid & 63) == 0) sh[tid >> 6] = v;
     __syncthreads();
     float s = 0.f;

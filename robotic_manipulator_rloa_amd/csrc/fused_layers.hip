@@ -66,6 +66,7 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
     float* __restrict__ out, int64_t out_net_stride, int ldo, float* __restrict__ save_mean,
     float* __restrict__ save_invstd, int B, int H, float momentum, float eps) {
     __shared__ float red[FT_NW][FT_TX + 1];
+    __shared__ float redv[FT_NW][FT_TX + 1];
     __shared__ float sW[FT_TX][4 * MAX_K4 + 1];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
     const int bx = naf_xcd_tile(blockIdx.x, gridDim.x);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
         z[k] = (row < B) ? acc : 0.f;
         sum += z[k];
     }
-    const float mean = bn_col_reduce<FT_TX, FT_TY>(sum, red, tx, ty) / (float)B;
+    const float mean = bn_col_reduce<FT_TX, FT_TY, true>(sum, red, tx, ty) / (float)B;
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
         float dlt = (row < B) ? z[k] - mean : 0.f;
         ss += dlt * dlt;
     }
-    const float var = bn_col_reduce<FT_TX, FT_TY>(ss, red, tx, ty) / (float)B;
+    const float var = bn_col_reduce<FT_TX, FT_TY, true>(ss, redv, tx, ty) / (float)B;
     const float invstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     float* __restrict__ sumsq_partials, int32_t* step_dev, int B, int H) {
     __shared__ float red[FT_NW][FT_TX + 1];
     __shared__ float red2[FT_NW][FT_TX + 1];
+    __shared__ float red3[FT_NW][FT_TX + 1];
     __shared__ float sW[FT_TX][4 * MAX_K4 + 1];
     __shared__ float sG[FT_NW][FT_TX][4 * MAX_K4 + 1];   // per-wave partial dW tiles
     __shared__ float sQ[FT_NW];
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
         s_dyxh += dy[k] * xh[k];
     }
     float dbeta, dgamma;
-    bn_col_reduce2<FT_TX, FT_TY>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
+    bn_col_reduce2<FT_TX, FT_TY, true>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
     const float invB = 1.0f / (float)B;
     const float k1 = gm * invstd;
     float acc[4 * K4];
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
             acc[4 * q + 3] += dz * xv[k][q].w;
         }
     }
-    const float dbias = bn_col_reduce<FT_TX, FT_TY>(s_dz, red, tx, ty);
+    const float dbias = bn_col_reduce<FT_TX, FT_TY, true>(s_dz, red3, tx, ty);
     // dW tile: fold the 8 row phases of a wave by xor shuffles, then the wave partials through LDS
 #pragma unroll
     for (int k = 0; k < 4 * K4; ++k) {
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
         sq += dgamma * dgamma + dbeta * dbeta + (d_bias ? dbias * dbias : 0.f);
     }
     if (sumsq_partials) {   // first half of clip_grad_norm_ folded in: no separate pass over these gradients
-        const float tot = block_sum_to_thread0<FT_THREADS>(sq, sQ, tid);
+        const float tot = block_sum_to_thread0<FT_THREADS, true>(sq, sQ, tid);
         if (tid == 0) {
             sumsq_partials[bx] = tot;
             if (bx == 0 && step_dev) *step_dev += 1;   // read by the NEXT launch (Adam) only
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     float* __restrict__ sumsq_partials, int B, int H) {
     __shared__ float red[FT_NW][FT_TX + 1];
     __shared__ float red2[FT_NW][FT_TX + 1];
+    __shared__ float red3[FT_NW][FT_TX + 1];
     __shared__ float sWh[4 * NH4][FT_TX + 1];
     __shared__ float sQ[FT_NW];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
         s_dyxh += dy[k] * xh[k];
     }
     float dbeta, dgamma;
-    bn_col_reduce2<FT_TX, FT_TY>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
+    bn_col_reduce2<FT_TX, FT_TY, true>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
     const float invB = 1.0f / (float)B;
     const float k1 = gm * invstd;
     float s_dz = 0.f;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
             s_dz += dz;
         }
     }
-    const float dbias = bn_col_reduce<FT_TX, FT_TY>(s_dz, red, tx, ty);
+    const float dbias = bn_col_reduce<FT_TX, FT_TY, true>(s_dz, red3, tx, ty);
     float sq = 0.f;
     if (ty == 0 && col_on) {
         d_gamma[col] = dgamma;
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
         sq = dgamma * dgamma + dbeta * dbeta + (d_bias ? dbias * dbias : 0.f);
     }
     if (sumsq_partials) {
-        const float tot = block_sum_to_thread0<FT_THREADS>(sq, sQ, ty * FT_TX + tx);
+        const float tot = block_sum_to_thread0<FT_THREADS, true>(sq, sQ, ty * FT_TX + tx);
         if (ty == 0 && tx == 0) sumsq_partials[bx] = tot;
     }
 }
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
     int64_t slab_stride, float* __restrict__ vnext_partial, int B, int H, float momentum, float eps) {
     constexpr int NHP = 4 * NH4;
     __shared__ float red[S3_NW][S3_TX + 1];
+    __shared__ float redv[S3_NW][S3_TX + 1];
     __shared__ __attribute__((aligned(16))) float sA[RPT * S3_TY][S3_TX];     // this tile's activations, row-major
     // Wh[:, col0 .. col0+8) grouped by 4 heads: [head group][4 heads x 8 columns], rows 36 floats apart so the 8
     // head groups a wave reads at once start in 8 different bank quads
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
         x[k] = (col_on && (ty + k * S3_TY) < B) ? x[k] + b : 0.f;
         sum += x[k];
     }
-    const float mean = bn_col_reduce<S3_TX, S3_TY>(sum, red, tx, ty) / (float)B;
+    const float mean = bn_col_reduce<S3_TX, S3_TY, true>(sum, red, tx, ty) / (float)B;
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
         float dlt = (row < B) ? x[k] - mean : 0.f;
         ss += dlt * dlt;
     }
-    const float var = bn_col_reduce<S3_TX, S3_TY>(ss, red, tx, ty) / (float)B;
+    const float var = bn_col_reduce<S3_TX, S3_TY, true>(ss, redv, tx, ty) / (float)B;
     const float invstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
