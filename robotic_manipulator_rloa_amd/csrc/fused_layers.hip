@@ -230,13 +230,34 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
         }
     }
     const float dbias = bn_col_reduce<FT_TX, FT_TY, true>(s_dz, red3, tx, ty);
-    // dW tile: fold the 8 row phases of a wave by xor shuffles, then the wave partials through LDS
+    // dW tile: fold the 64 / FT_TX row phases of a wave, then the wave partials through LDS. The fold is a
+    // recursive-halving exchange: at each xor level a lane keeps one half of its values and sends the other, so the
+    // 4*K4 values cost 4*K4 * (1/2 + 1/4 + 1/8) cross-lane moves instead of 4*K4 * 3 (the plain xor-shuffle fold of
+    // all 24 values was 2.0 of this kernel's 7.2 us), and every lane ends up owning 4*K4/8 finished sums.
+    static_assert(FT_TX == 8 && (4 * K4) % 8 == 0, "recursive halving below assumes 8 row phases per wave");
+    {
+        constexpr int N0 = 4 * K4, N1 = N0 / 2, N2 = N0 / 4, N3 = N0 / 8;
+        const int lane = tid & 63;
+        const bool b1 = lane & 8, b2 = lane & 16, b3 = lane & 32;
+        float a1[N1], a2[N2], a3[N3];
 #pragma unroll
-    for (int k = 0; k < 4 * K4; ++k) {
-        float v = acc[k];
+        for (int i = 0; i < N1; ++i) {
+            const float send = b1 ? acc[i] : acc[N1 + i], keep = b1 ? acc[N1 + i] : acc[i];
+            a1[i] = keep + __shfl_xor(send, 8);
+        }
 #pragma unroll
-        for (int o = FT_TX; o < 64; o <<= 1) v += __shfl_xor(v, o);
-        if ((tid & 63) < FT_TX) sG[tid >> 6][tx][k] = v;
+        for (int i = 0; i < N2; ++i) {
+            const float send = b2 ? a1[i] : a1[N2 + i], keep = b2 ? a1[N2 + i] : a1[i];
+            a2[i] = keep + __shfl_xor(send, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < N3; ++i) {
+            const float send = b3 ? a2[i] : a2[N3 + i], keep = b3 ? a2[N3 + i] : a2[i];
+            a3[i] = keep + __shfl_xor(send, 32);
+        }
+        const int kbase = (b1 ? N1 : 0) + (b2 ? N2 : 0) + (b3 ? N3 : 0);
+#pragma unroll
+        for (int i = 0; i < N3; ++i) sG[tid >> 6][tx][kbase + i] = a3[i];
     }
     __syncthreads();
     float sq = 0.f;   // this thread's share of sum(grad^2) over everything the workgroup writes
