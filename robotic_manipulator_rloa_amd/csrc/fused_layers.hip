@@ -55,6 +55,32 @@ __device__ static inline void load_w_column(const float* __restrict__ Wn, int co
     for (int k = 0; k < 4 * K4; ++k) w[k] = sW[tx][k];
 }
 
+// Rows that all FT_TX column lanes of a wave need (the layer input X, the heads gradient dH) go through LDS once per
+// workgroup: read straight from memory by every thread they were 8x redundant register fills — one wave-instruction per
+// 8 distinct rows — and the texture path, not the ALUs, set these kernels' pace (F1 4.2 us with the loads, 3.0 without;
+// B2 4.8 / 3.2: benchmarks/kernel_probe.py with the loads stubbed out). Cooperative, coalesced, branch-free (clamped)
+// loads; rows beyond B become zeros. Row stride 4*V4 + 4 floats: the 8 rows a wave reads at once start in 8 different
+// bank quads. Used up to RPT = 8 (B <= 512); larger tiles keep the direct loads (LDS budget).
+#define FT_STAGE_MAX_RPT 8
+template <int V4, int ROWS>
+__device__ static inline void stage_rows(float* __restrict__ sm, const float* __restrict__ src, int ld, int B, int tid) {
+    constexpr int TOTAL = ROWS * V4, PER = (TOTAL + FT_THREADS - 1) / FT_THREADS, STRIDE = 4 * V4 + 4;
+    float4 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + FT_THREADS * i;
+        const int row = e / V4, q = e - row * V4;
+        const int rowc = row < B ? row : B - 1;
+        v[i] = ((const float4*)(src + (int64_t)rowc * ld))[q];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + FT_THREADS * i;
+        const int row = e / V4, q = e - row * V4;
+        if (e < TOTAL) *(float4*)(sm + row * STRIDE + 4 * q) = row < B ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // F1: Linear(K small) + BatchNorm1d(train) + ReLU for `nets` networks
 // ------------------------------------------------------------------------------------------------------------
@@ -82,16 +108,28 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
     const float rm_old = (ty == 0 && col_on) ? running_mean[so] : 0.f;
     const float rv_old = (ty == 0 && col_on) ? running_var[so] : 0.f;
     // input rows first (their loads fly while the weight tile is staged through LDS), weights second
+    constexpr bool STAGE = RPT <= FT_STAGE_MAX_RPT;
+    __shared__ __attribute__((aligned(16))) float sX[STAGE ? RPT * FT_TY * (4 * K4 + 4) : 4];
     float4 xv[RPT][K4];
+    if (STAGE) {
+        stage_rows<K4, RPT * FT_TY>(sX, xn, ldx, B, tid);
+    } else {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        int row = ty + k * FT_TY;
+        for (int k = 0; k < RPT; ++k) {
+            int row = ty + k * FT_TY;
 #pragma unroll
-        for (int q = 0; q < K4; ++q)
-            xv[k][q] = (row < B) ? ((const float4*)(xn + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < K4; ++q)
+                xv[k][q] = (row < B) ? ((const float4*)(xn + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     float w[4 * K4];
-    load_w_column<K4>(W + po, col0, H, K, sW, tid, tx, w);
+    load_w_column<K4>(W + po, col0, H, K, sW, tid, tx, w);     // (its barrier also publishes sX)
+    if (STAGE) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+#pragma unroll
+            for (int q = 0; q < K4; ++q) xv[k][q] = *(const float4*)(sX + (ty + k * FT_TY) * (4 * K4 + 4) + 4 * q);
+    }
 
     float z[RPT];
     float sum = 0.f;
@@ -168,19 +206,24 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     // are clamped to the last valid one and masked after the loads. With `on ? load : 0` the compiler branched around
     // each row's loads and waited (vmcnt 0) at every merge: RPT serial round trips instead of one.
     const int colc = col_on ? col : H - 1;
+    constexpr bool STAGE = RPT <= FT_STAGE_MAX_RPT;
+    __shared__ __attribute__((aligned(16))) float sX[STAGE ? RPT * FT_TY * (4 * K4 + 4) : 4];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int row = ty + k * FT_TY;
         const int rowc = row < B ? row : B - 1;
-#pragma unroll
-        for (int q = 0; q < K4; ++q) xv[k][q] = ((const float4*)(x + (int64_t)rowc * ldx))[q];
         ov[k] = out[(int64_t)rowc * ldo + colc];
         ddv[k] = d_out[(int64_t)rowc * ld_dout + colc];
+        if (!STAGE) {
+#pragma unroll
+            for (int q = 0; q < K4; ++q) xv[k][q] = ((const float4*)(x + (int64_t)rowc * ldx))[q];
+        }
     }
+    if (STAGE) stage_rows<K4, RPT * FT_TY>(sX, x, ldx, B, tid);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const bool on = col_on && (ty + k * FT_TY) < B;
-        if (!((ty + k * FT_TY) < B)) {
+        if (!STAGE && !((ty + k * FT_TY) < B)) {
 #pragma unroll
             for (int q = 0; q < K4; ++q) xv[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -188,7 +231,13 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
         ddv[k] = on ? ddv[k] : 0.f;
     }
     float w[4 * K4];
-    load_w_column<K4>(W, col0, H, K, sW, tid, tx, w);
+    load_w_column<K4>(W, col0, H, K, sW, tid, tx, w);          // (its barrier also publishes sX)
+    if (STAGE) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+#pragma unroll
+            for (int q = 0; q < K4; ++q) xv[k][q] = *(const float4*)(sX + (ty + k * FT_TY) * (4 * K4 + 4) + 4 * q);
+    }
 
     float s_dy = 0.f, s_dyxh = 0.f;
 #pragma unroll
@@ -313,19 +362,24 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     float4 dhv[RPT][NH4];
     float zv[RPT], ov[RPT];
     const int colc = col_on ? col : H - 1;       // unconditional loads, clamped at the edges, masked afterwards (see B1)
+    constexpr bool STAGE = RPT <= FT_STAGE_MAX_RPT;
+    __shared__ __attribute__((aligned(16))) float sDH[STAGE ? RPT * FT_TY * (4 * NH4 + 4) : 4];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int row = ty + k * FT_TY;
         const int rowc = row < B ? row : B - 1;
-#pragma unroll
-        for (int q = 0; q < NH4; ++q) dhv[k][q] = ((const float4*)(d_heads + (int64_t)rowc * ldh))[q];
         zv[k] = g[(int64_t)rowc * ldg + colc];
         ov[k] = out[(int64_t)rowc * ldo + colc];
+        if (!STAGE) {
+#pragma unroll
+            for (int q = 0; q < NH4; ++q) dhv[k][q] = ((const float4*)(d_heads + (int64_t)rowc * ldh))[q];
+        }
     }
+    if (STAGE) stage_rows<NH4, RPT * FT_TY>(sDH, d_heads, ldh, B, tid);     // published by the weight-tile barrier below
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const bool rin = (ty + k * FT_TY) < B, on = col_on && rin;
-        if (!rin) {
+        if (!STAGE && !rin) {
 #pragma unroll
             for (int q = 0; q < NH4; ++q) dhv[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -341,6 +395,12 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     float w[4 * NH4];
 #pragma unroll
     for (int j = 0; j < 4 * NH4; ++j) w[j] = sWh[j][tx];
+    if (STAGE) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+#pragma unroll
+            for (int q = 0; q < NH4; ++q) dhv[k][q] = *(const float4*)(sDH + (ty + k * FT_TY) * (4 * NH4 + 4) + 4 * q);
+    }
 
     float xh[RPT], dy[RPT];
     float s_dy = 0.f, s_dyxh = 0.f;
