@@ -44,16 +44,24 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     float t_row[8], L_row[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { t_row[j] = 0.f; L_row[j] = 0.f; }
+    float tii = 0.f, Lii = 0.f;   // Hadamard mode: the diagonal entry of this lane's row is all P = L (*) L^T keeps
     if (row_on) {
         mu = tanhf(hrow[i]);
         d = u_val - mu;
         const int rbase = A + i * (i + 1) / 2;
+        if (PMODE == NAF_P_HADAMARD) {
+            // one tanh per lane instead of eight: the wave executes every j of the loop below whatever its mask, and the
+            // kernel is one wave whose run time is its instruction count
+            tii = tanhf(hrow[rbase + i]);
+            Lii = expf(tii);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j <= i) {
-                float t = tanhf(hrow[rbase + j]);
-                t_row[j] = t;
-                L_row[j] = (j == i) ? expf(t) : t;
+            for (int j = 0; j < 8; ++j) {
+                if (j <= i) {
+                    float t = tanhf(hrow[rbase + j]);
+                    t_row[j] = t;
+                    L_row[j] = (j == i) ? expf(t) : t;
+                }
             }
         }
     }
@@ -65,9 +73,6 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     float Pii = 0.f;
     if (PMODE == NAF_P_HADAMARD) {
         // P = L (*) L^T = diag(L_ii^2): off-diagonal entries of L multiply structural zeros of L^T
-        float Lii = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (j == i) Lii = L_row[j];
         Pii = Lii * Lii;
         quad_part = Pii * d * d;
     } else {
@@ -117,9 +122,6 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     if (PMODE == NAF_P_HADAMARD) {
         if (row_on) {
             // dQ/dmu_i = P_ii d_i ; dQ/dl_ii = -P_ii d_i^2 (through L_ii = exp(t)); off-diagonals: exactly 0
-            float tii = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (j == i) tii = t_row[j];
             orow[i] = dq * (Pii * d) * (1.0f - mu * mu);
             orow[A + i * (i + 1) / 2 + i] = dq * (-(Pii * d * d)) * (1.0f - tii * tii);
         }
