@@ -43,38 +43,41 @@ struct GemmBundle {
 // serial memory round trips per block, ~200 cycles each on L2 hits but 545+ on data the previous kernel had just
 // written (Infinity Cache): the whole fresh-data penalty of this kernel (benchmarks/chain_probe.py: 1.8 of its 8.5 us).
 #define GB_PT (GB_KC * 8 / 256)   // float4 per thread per panel
-template <bool KMAJOR>
+// FULL = the chunk is a whole GB_KC (every call but the tail of a K that is not a multiple of 256): row / k indices are
+// shifts; the general form divides by a run-time k4n once per element — ~20 integer instructions, 32 times per thread,
+// in a kernel whose waves run ~1,100 instructions in all.
+template <bool KMAJOR, bool FULL>
 __device__ static inline void load_panel(float4 (&v)[GB_PT], const float* __restrict__ p, int ld, int row0,
                                          int rows_total, int k0, int kc, int tid) {
 #pragma unroll
     for (int i = 0; i < GB_PT; ++i) {
         const int e = tid + 256 * i;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < kc * 8) {
+        if (FULL || e < kc * 8) {
             if (KMAJOR) {
                 const int k = e >> 3, r4 = (e & 7) * 4;
                 if (row0 + r4 < rows_total) v[i] = *(const float4*)(p + (int64_t)(k0 + k) * ld + row0 + r4);
             } else {
-                const int k4n = kc >> 2;
-                const int row = e / k4n, k4 = (e - row * k4n) * 4;
+                const int k4n = FULL ? GB_KC / 4 : kc >> 2;
+                const int row = FULL ? e / (GB_KC / 4) : e / k4n, k4 = (e - row * k4n) * 4;
                 if (row0 + row < rows_total) v[i] = *(const float4*)(p + (int64_t)(row0 + row) * ld + k0 + k4);
             }
         }
     }
 }
 
-template <bool KMAJOR>
+template <bool KMAJOR, bool FULL>
 __device__ static inline void store_panel(float* __restrict__ sm, const float4 (&v)[GB_PT], int kc, int tid) {
 #pragma unroll
     for (int i = 0; i < GB_PT; ++i) {
         const int e = tid + 256 * i;
-        if (e < kc * 8) {
+        if (FULL || e < kc * 8) {
             if (KMAJOR) {
                 const int k = e >> 3, r4 = (e & 7) * 4;
                 *(float4*)(sm + k * GB_LDK + r4) = v[i];
             } else {
-                const int k4n = kc >> 2;
-                const int row = e / k4n, k4 = (e - row * k4n) * 4;
+                const int k4n = FULL ? GB_KC / 4 : kc >> 2;
+                const int row = FULL ? e / (GB_KC / 4) : e / k4n, k4 = (e - row * k4n) * 4;
                 *(float4*)(sm + row * GB_LD + k4) = v[i];
             }
         }
@@ -102,10 +105,17 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
         const int kc = (D.K - k0) < GB_KC ? (D.K - k0) : GB_KC;
         if (k0) __syncthreads();                          // previous chunk fully consumed
         float4 va[GB_PT], vb[GB_PT];
-        load_panel<AK>(va, D.A, D.lda, m0, D.M, k0, kc, tid);
-        load_panel<BK>(vb, D.B, D.ldb, n0, D.N, k0, kc, tid);
-        store_panel<AK>(sA, va, kc, tid);
-        store_panel<BK>(sB, vb, kc, tid);
+        if (kc == GB_KC) {
+            load_panel<AK, true>(va, D.A, D.lda, m0, D.M, k0, kc, tid);
+            load_panel<BK, true>(vb, D.B, D.ldb, n0, D.N, k0, kc, tid);
+            store_panel<AK, true>(sA, va, kc, tid);
+            store_panel<BK, true>(sB, vb, kc, tid);
+        } else {
+            load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k0, kc, tid);
+            load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k0, kc, tid);
+            store_panel<AK, false>(sA, va, kc, tid);
+            store_panel<BK, false>(sB, vb, kc, tid);
+        }
         __syncthreads();
 #pragma unroll 4
         for (int kk = 0; kk < kc; kk += 16) {
