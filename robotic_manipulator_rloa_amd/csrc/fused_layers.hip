@@ -310,9 +310,9 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     }
     __syncthreads();
     float sq = 0.f;   // this thread's share of sum(grad^2) over everything the workgroup writes
-    for (int e = tid; e < FT_TX * K; e += FT_THREADS) {
-        int c = e / K, k = e - c * K;
-        if (col0 + c < H) {
+    for (int e = tid; e < FT_TX * 4 * K4; e += FT_THREADS) {   // (c, k) over the padded tile: no run-time division
+        int c = e / (4 * K4), k = e - c * (4 * K4);
+        if (k < K && col0 + c < H) {
             float s = 0.f;
 #pragma unroll
             for (int v = 0; v < FT_NW; ++v) s += sG[v][c][k];
