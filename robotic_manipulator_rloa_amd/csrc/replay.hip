@@ -154,7 +154,7 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(const uint64_t* __r
                                                              const uint64_t* __restrict__ counter_dev,
                                                              uint64_t counter_off, int32_t* __restrict__ idx, int B,
                                                              int without_replacement) {
-    extern __shared__ int vals[];  // 4*B ints: B sampled values, or the whole population in the dense regime
+    extern __shared__ __attribute__((aligned(16))) int vals[];  // 4*B ints: B sampled values, or the whole population in the dense regime
     const uint64_t size = meta[META_SIZE];
     const uint64_t ctr = (counter_dev ? *counter_dev : 0ull) + counter_off + (uint64_t)blockIdx.x;
     int32_t* out = idx + (int64_t)blockIdx.x * B;
@@ -190,9 +190,18 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(const uint64_t* __r
         for (int round = 0; round < NAF_SAMPLE_MAX_ROUNDS; ++round) {
             int dupmask = 0;
             for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) {
-                int mine = vals[t];
+                // "some earlier element holds the same value": four candidates per LDS read, eight reads in flight (the
+                // one-int-per-iteration form was a chain of ~B/2 dependent LDS round trips: 20 us per launch at B = 256)
+                const int mine = vals[t];
+                const int4* v4 = (const int4*)vals;
                 bool dup = false;
-                for (int j = 0; j < t; ++j) dup |= (vals[j] == mine);
+#pragma unroll 8
+                for (int j4 = 0; 4 * j4 < t; ++j4) {
+                    const int4 q = v4[j4];
+                    const int j = 4 * j4;
+                    dup |= (q.x == mine) | ((q.y == mine) & (j + 1 < t)) | ((q.z == mine) & (j + 2 < t)) |
+                           ((q.w == mine) & (j + 3 < t));
+                }
                 if (dup) dupmask |= (1 << k);
             }
             int any = __syncthreads_or(dupmask);  // also orders the reads above before the writes below
