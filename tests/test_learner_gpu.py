@@ -83,9 +83,10 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     assert (L.grad[mask] == 0).all() and (L.theta2[0][mask] == 0).all() and (L.adam_v[mask] == 0).all()
 
 
-@pytest.mark.parametrize("fused", ["none", "all"])
+@pytest.mark.parametrize("fused", ["none", "all", "l1,b2,gb,s3"])
 @pytest.mark.parametrize("p_mode", [0, 1])
-@pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32)])
+@pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32),
+                                   (21, 6, 512), (32, 8, 512)])
 def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
     monkeypatch.setenv("NAF_FUSE", fused)
     """20 updates against the f32 numpy oracle (Hadamard = reference semantics; matmul = textbook NAF)."""
