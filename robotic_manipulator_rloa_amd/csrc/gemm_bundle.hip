@@ -23,7 +23,7 @@ struct GemmBundle {
 };
 
 // ---- LDS-staged form -----------------------------------------------------------------------------------------------
-// Workgroup = 256 threads = 4 waves = one 32 x 32 output block (2 x 2 MFMA tiles, one per wave). A K-chunk of 256 of
+// Workgroup = 512 threads = 8 waves = one 32 x 32 output block (2 x 2 MFMA tiles, two waves per tile: K halves). A K-chunk of 256 of
 // both operand panels (32 rows x 256 k each) is staged into LDS with 16-byte global loads and 16-byte LDS stores, then
 // every wave reads its fragments: lane (r, g) takes k = 16 j + 4 g .. +3 of row r for BOTH operands, so the four MFMAs
 // of macro-step j use each k once. One L2 round trip per 256 k instead of one per
@@ -42,7 +42,8 @@ struct GemmBundle {
 // are issued before the first LDS store: as a load -> store loop (one load in flight per thread) the staging was 16
 // serial memory round trips per block, ~200 cycles each on L2 hits but 545+ on data the previous kernel had just
 // written (Infinity Cache): the whole fresh-data penalty of this kernel (benchmarks/chain_probe.py: 1.8 of its 8.5 us).
-#define GB_PT (GB_KC * 8 / 256)   // float4 per thread per panel
+#define GB_THREADS 512
+#define GB_PT (GB_KC * 8 / GB_THREADS)   // float4 per thread per panel
 // FULL = the chunk is a whole GB_KC (every call but the tail of a K that is not a multiple of 256): row / k indices are
 // shifts; the general form divides by a run-time k4n once per element — ~20 integer instructions, 32 times per thread,
 // in a kernel whose waves run ~1,100 instructions in all.
@@ -51,7 +52,7 @@ __device__ static inline void load_panel(float4 (&v)[GB_PT], const float* __rest
                                          int rows_total, int k0, int kc, int tid) {
 #pragma unroll
     for (int i = 0; i < GB_PT; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + GB_THREADS * i;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (FULL || e < kc * 8) {
             if (KMAJOR) {
@@ -70,7 +71,7 @@ template <bool KMAJOR, bool FULL>
 __device__ static inline void store_panel(float* __restrict__ sm, const float4 (&v)[GB_PT], int kc, int tid) {
 #pragma unroll
     for (int i = 0; i < GB_PT; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + GB_THREADS * i;
         if (FULL || e < kc * 8) {
             if (KMAJOR) {
                 const int k = e >> 3, r4 = (e & 7) * 4;
@@ -95,10 +96,14 @@ __device__ static inline float4 read_frag(const float* __restrict__ sm, int row,
 }
 
 template <bool AK, bool BK>
-__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, float* sA, float* sB, float* sQ) {
+__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, float* sA, float* sB, float* sQ, float* sC) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;              // this wave's 16 x 16 tile inside the 32 x 32 block
+    // 8 waves: two per 16 x 16 tile of the 32 x 32 block, each taking one half of the K chunk — the per-wave chain of
+    // dependent MFMAs (the longest single piece of this kernel: 1.5 of its 5.0 us with 64 of them) is halved; the two
+    // halves meet through LDS, lower half first (fixed order)
+    const int tile = wave & 3, kh = wave >> 2;
+    const int wm = tile >> 1, wn = tile & 1;
     const int m0 = bm * 32, n0 = bn * 32;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < D.K; k0 += GB_KC) {
@@ -117,8 +122,10 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
             store_panel<BK, false>(sB, vb, kc, tid);
         }
         __syncthreads();
+        const int steps = kc >> 4, first = (steps + 1) >> 1;          // macro-steps of 16 k: [0, first) and [first, steps)
+        const int kbeg = (kh ? first : 0) << 4, kend = (kh ? steps : first) << 4;
 #pragma unroll 4
-        for (int kk = 0; kk < kc; kk += 16) {
+        for (int kk = kbeg; kk < kend; kk += 16) {
             const float4 a = read_frag<AK>(sA, wm * 16 + r, g, kk);
             const float4 b = read_frag<BK>(sB, wn * 16 + r, g, kk);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
@@ -127,31 +134,37 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
         }
     }
-    const int cm = m0 + wm * 16 + 4 * g, cn = n0 + wn * 16 + r;
+    f32x4 acc = acc0 + acc1;
+    if (kh) *(f32x4*)(sC + (tile * 64 + lane) * 4) = acc;
+    __syncthreads();
     float sq = 0.f;
-    if (cn < D.N) {
+    if (!kh) {
+        acc = acc + *(const f32x4*)(sC + (tile * 64 + lane) * 4);
+        const int cm = m0 + wm * 16 + 4 * g, cn = n0 + wn * 16 + r;
+        if (cn < D.N) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (cm + e < D.M) {
-                const float v = acc0[e] + acc1[e];
-                D.C[(int64_t)(cm + e) * D.ldc + cn] = v;
-                sq += v * v;
-            }
+            for (int e = 0; e < 4; ++e)
+                if (cm + e < D.M) {
+                    const float v = acc[e];
+                    D.C[(int64_t)(cm + e) * D.ldc + cn] = v;
+                    sq += v * v;
+                }
+        }
     }
-    if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 waves)
+    if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 tiles)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-        __syncthreads();
-        if (lane == 0) sQ[wave] = sq;
+        if (!kh && lane == 0) sQ[tile] = sq;                  // sQ is touched nowhere else: no barrier in front
         __syncthreads();
         if (tid == 0) D.sumsq[bm * D.tiles_n + bn] = sQ[0] + sQ[1] + sQ[2] + sQ[3];
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_bundle_kernel(const GemmBundle bundle) {
+__global__ __launch_bounds__(GB_THREADS) void gemm_bundle_kernel(const GemmBundle bundle) {
     __shared__ __attribute__((aligned(16))) float sA[GB_PANEL];
     __shared__ __attribute__((aligned(16))) float sB[GB_PANEL];
     __shared__ float sQ[4];
+    __shared__ __attribute__((aligned(16))) float sC[4 * 64 * 4];
     const int t = blockIdx.x;                             // one 32 x 32 block per workgroup
     int gi = 0;
 #pragma unroll
@@ -161,11 +174,11 @@ __global__ __launch_bounds__(256) void gemm_bundle_kernel(const GemmBundle bundl
     const int lt = t - D.tile0;
     const int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;
     if (D.a_kmajor) {
-        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, sA, sB, sQ);
-        else gemm_block<true, false>(D, bm, bn, sA, sB, sQ);
+        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, sA, sB, sQ, sC);
+        else gemm_block<true, false>(D, bm, bn, sA, sB, sQ, sC);
     } else {
-        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, sA, sB, sQ);
-        else gemm_block<false, false>(D, bm, bn, sA, sB, sQ);
+        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, sA, sB, sQ, sC);
+        else gemm_block<false, false>(D, bm, bn, sA, sB, sQ, sC);
     }
 }
 
@@ -191,7 +204,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     }
     for (int i = n; i < NAF_GEMM_BUNDLE_MAX; ++i) b.d[i] = b.d[0];
     b.total_tiles = tiles;
-    gemm_bundle_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(b);
+    gemm_bundle_kernel<<<tiles, GB_THREADS, 0, (hipStream_t)stream>>>(b);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
