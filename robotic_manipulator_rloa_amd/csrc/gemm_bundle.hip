@@ -42,7 +42,10 @@ struct GemmBundle {
 // are issued before the first LDS store: as a load -> store loop (one load in flight per thread) the staging was 16
 // serial memory round trips per block, ~200 cycles each on L2 hits but 545+ on data the previous kernel had just
 // written (Infinity Cache): the whole fresh-data penalty of this kernel (benchmarks/chain_probe.py: 1.8 of its 8.5 us).
+#ifndef GB_THREADS
 #define GB_THREADS 512
+#endif
+#define GB_KSPLIT (GB_THREADS / 256)   // waves per 16 x 16 tile: each takes 1/GB_KSPLIT of the K chunk
 #define GB_PT (GB_KC * 8 / GB_THREADS)   // float4 per thread per panel
 // FULL = the chunk is a whole GB_KC (every call but the tail of a K that is not a multiple of 256): row / k indices are
 // shifts; the general form divides by a run-time k4n once per element — ~20 integer instructions, 32 times per thread,
@@ -122,8 +125,8 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
             store_panel<BK, false>(sB, vb, kc, tid);
         }
         __syncthreads();
-        const int steps = kc >> 4, first = (steps + 1) >> 1;          // macro-steps of 16 k: [0, first) and [first, steps)
-        const int kbeg = (kh ? first : 0) << 4, kend = (kh ? steps : first) << 4;
+        const int steps = kc >> 4;                                    // macro-steps of 16 k, dealt in contiguous runs
+        const int kbeg = (steps * kh / GB_KSPLIT) << 4, kend = (steps * (kh + 1) / GB_KSPLIT) << 4;
 #pragma unroll 4
         for (int kk = kbeg; kk < kend; kk += 16) {
             const float4 a = read_frag<AK>(sA, wm * 16 + r, g, kk);
@@ -135,11 +138,12 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
         }
     }
     f32x4 acc = acc0 + acc1;
-    if (kh) *(f32x4*)(sC + (tile * 64 + lane) * 4) = acc;
+    if (kh) *(f32x4*)(sC + (((kh - 1) * 4 + tile) * 64 + lane) * 4) = acc;
     __syncthreads();
     float sq = 0.f;
     if (!kh) {
-        acc = acc + *(const f32x4*)(sC + (tile * 64 + lane) * 4);
+#pragma unroll
+        for (int h = 1; h < GB_KSPLIT; ++h) acc = acc + *(const f32x4*)(sC + (((h - 1) * 4 + tile) * 64 + lane) * 4);
         const int cm = m0 + wm * 16 + 4 * g, cn = n0 + wn * 16 + r;
         if (cn < D.N) {
 #pragma unroll
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bundle_kernel(const GemmBundl
     __shared__ __attribute__((aligned(16))) float sA[GB_PANEL];
     __shared__ __attribute__((aligned(16))) float sB[GB_PANEL];
     __shared__ float sQ[4];
-    __shared__ __attribute__((aligned(16))) float sC[4 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float sC[(GB_KSPLIT - 1) * 4 * 64 * 4];
     const int t = blockIdx.x;                             // one 32 x 32 block per workgroup
     int gi = 0;
 #pragma unroll
