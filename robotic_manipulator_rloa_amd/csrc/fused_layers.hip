@@ -19,6 +19,7 @@
 #define FT_TX 8
 #endif
 #define FT_TY 64
+typedef float ft_f2 __attribute__((ext_vector_type(2)));
 #define FT_THREADS (FT_TX * FT_TY)
 #define FT_NW (FT_THREADS / 64)
 #define MAX_K4 8    // small-K layers: K <= 32 (8 float4 per input row)
@@ -136,14 +137,13 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         int row = ty + k * FT_TY;
-        float acc = b;
+        ft_f2 acc2 = {b, 0.f};                         // even / odd k partial sums: packed FMAs (see B2)
 #pragma unroll
         for (int q = 0; q < K4; ++q) {
-            acc += xv[k][q].x * w[4 * q + 0];
-            acc += xv[k][q].y * w[4 * q + 1];
-            acc += xv[k][q].z * w[4 * q + 2];
-            acc += xv[k][q].w * w[4 * q + 3];
+            acc2 = __builtin_elementwise_fma((ft_f2){xv[k][q].x, xv[k][q].y}, (ft_f2){w[4 * q + 0], w[4 * q + 1]}, acc2);
+            acc2 = __builtin_elementwise_fma((ft_f2){xv[k][q].z, xv[k][q].w}, (ft_f2){w[4 * q + 2], w[4 * q + 3]}, acc2);
         }
+        const float acc = acc2.x + acc2.y;
         z[k] = (row < B) ? acc : 0.f;
         sum += z[k];
     }
@@ -244,14 +244,13 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     for (int k = 0; k < RPT; ++k) {
         int row = ty + k * FT_TY;
         bool on = col_on && row < B;
-        float z = b;
+        ft_f2 z2 = {b, 0.f};                           // exactly the forward's arithmetic (F1): same z bit for bit
 #pragma unroll
         for (int q = 0; q < K4; ++q) {
-            z += xv[k][q].x * w[4 * q + 0];
-            z += xv[k][q].y * w[4 * q + 1];
-            z += xv[k][q].z * w[4 * q + 2];
-            z += xv[k][q].w * w[4 * q + 3];
+            z2 = __builtin_elementwise_fma((ft_f2){xv[k][q].x, xv[k][q].y}, (ft_f2){w[4 * q + 0], w[4 * q + 1]}, z2);
+            z2 = __builtin_elementwise_fma((ft_f2){xv[k][q].z, xv[k][q].w}, (ft_f2){w[4 * q + 2], w[4 * q + 3]}, z2);
         }
+        const float z = z2.x + z2.y;
         xh[k] = on ? (z - mean) * invstd : 0.f;
         dy[k] = ov[k] > 0.f ? ddv[k] : 0.f;
         s_dy += dy[k];
@@ -261,21 +260,20 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     bn_col_reduce2<FT_TX, FT_TY, true>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
     const float invB = 1.0f / (float)B;
     const float k1 = gm * invstd;
-    float acc[4 * K4];
+    ft_f2 accp[2 * K4];                                // dW partials, two k per register pair (packed FMAs)
 #pragma unroll
-    for (int k = 0; k < 4 * K4; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 2 * K4; ++k) accp[k] = (ft_f2){0.f, 0.f};
     float s_dz = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         int row = ty + k * FT_TY;
         float dz = (col_on && row < B) ? k1 * (dy[k] - dbeta * invB - xh[k] * (dgamma * invB)) : 0.f;
         s_dz += dz;
+        const ft_f2 dz2 = {dz, dz};
 #pragma unroll
         for (int q = 0; q < K4; ++q) {
-            acc[4 * q + 0] += dz * xv[k][q].x;
-            acc[4 * q + 1] += dz * xv[k][q].y;
-            acc[4 * q + 2] += dz * xv[k][q].z;
-            acc[4 * q + 3] += dz * xv[k][q].w;
+            accp[2 * q + 0] = __builtin_elementwise_fma(dz2, (ft_f2){xv[k][q].x, xv[k][q].y}, accp[2 * q + 0]);
+            accp[2 * q + 1] = __builtin_elementwise_fma(dz2, (ft_f2){xv[k][q].z, xv[k][q].w}, accp[2 * q + 1]);
         }
     }
     const float dbias = bn_col_reduce<FT_TX, FT_TY, true>(s_dz, red3, tx, ty);
@@ -288,6 +286,9 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
         constexpr int N0 = 4 * K4, N1 = N0 / 2, N2 = N0 / 4, N3 = N0 / 8;
         const int lane = tid & 63;
         const bool b1 = lane & 8, b2 = lane & 16, b3 = lane & 32;
+        float acc[N0];
+#pragma unroll
+        for (int i = 0; i < N0 / 2; ++i) { acc[2 * i] = accp[i].x; acc[2 * i + 1] = accp[i].y; }
         float a1[N1], a2[N2], a3[N3];
 #pragma unroll
         for (int i = 0; i < N1; ++i) {
@@ -408,14 +409,15 @@ __global__ __launch_bounds__(FT_THREADS) void heads_bwd_bn_relu_bwd_kernel(
     for (int k = 0; k < RPT; ++k) {
         int row = ty + k * FT_TY;
         bool on = col_on && row < B;
-        float dd = 0.f;
+        // two interleaved partial sums (even / odd heads) so the 4*NH4 multiply-adds issue as 2*NH4 packed ones
+        // (v_pk_fma_f32: two f32 FMAs per instruction); fixed order
+        ft_f2 dd2 = {0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < NH4; ++q) {
-            dd += dhv[k][q].x * w[4 * q + 0];
-            dd += dhv[k][q].y * w[4 * q + 1];
-            dd += dhv[k][q].z * w[4 * q + 2];
-            dd += dhv[k][q].w * w[4 * q + 3];
+            dd2 = __builtin_elementwise_fma((ft_f2){dhv[k][q].x, dhv[k][q].y}, (ft_f2){w[4 * q + 0], w[4 * q + 1]}, dd2);
+            dd2 = __builtin_elementwise_fma((ft_f2){dhv[k][q].z, dhv[k][q].w}, (ft_f2){w[4 * q + 2], w[4 * q + 3]}, dd2);
         }
+        const float dd = dd2.x + dd2.y;
         xh[k] = on ? (zv[k] - mean) * invstd : 0.f;
         dy[k] = ov[k] > 0.f ? dd : 0.f;
         s_dy += dy[k];
