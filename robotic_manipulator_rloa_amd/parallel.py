@@ -87,7 +87,7 @@ class XgmiAllReduce:
 
     @classmethod
     def try_create(cls, n_floats: int, device: torch.device, group=None, timeout_s: float = 30.0,
-                   test_rounds: int = 128, test_timeout_s: float = 3.0) -> Optional["XgmiAllReduce"]:
+                   test_rounds: int = 128, test_timeout_s: float = 10.0) -> Optional["XgmiAllReduce"]:
         import ctypes as C
         from . import _lib
         if not dist.is_initialized() or dist.get_world_size(group) < 2:
@@ -110,6 +110,12 @@ class XgmiAllReduce:
             with torch.cuda.device(device):
                 rc = lib.naf_xgmi_connect(handle, b"".join(blobs))
             ok, why = rc == 0, (why or (f"connect rc={rc}" if rc else ""))
+        # load the library's code object and warm the launch path BEFORE the barrier below, so that the ranks enter the
+        # self-test together (its waits are bounded by test_timeout_s)
+        with torch.cuda.device(device):
+            warm = torch.zeros(1, dtype=torch.int64, device=device)
+            lib.naf_counter_add(warm.data_ptr(), 0, torch.cuda.current_stream(device).cuda_stream)
+            torch.cuda.synchronize(device)
         ok = _agree(ok, device, group)
         comm = cls(handle, lib, n_floats, rank, world, device, group) if handle.value else None
         if ok:
