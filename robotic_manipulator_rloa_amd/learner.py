@@ -165,9 +165,9 @@ class Learner:
         #        slab; the head kernel adds the 32 slabs while staging): 4.4 + 4.4 vs bn 3.4 + bmm 4.1 + head 3.2
         # none 15.0k -> l1,b2 16.3k -> l1,b2,gb 18.0k updates/s (18.7k with the grad norm folded in, below) -> +s3 19.5k.
         # The folded kernels keep their operand rows in registers (ceil(B/64) rows per thread): they win up to B = 512
-        # and spill beyond (B=1024: 3.8k vs 9.0k updates/s unfused; B=2048: 1.3k vs 5.6k), where rocBLAS also beats the
-        # bundle (longer K) — so large batches default to the unfused chain.
-        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else "none").lower()
+        # and spill beyond (B=1024: 5.1k vs 11.7k updates/s unfused; B=2048: 2.0k vs 8.2k) — so large batches keep the
+        # unfused BN / head chain and take only the GEMM bundle (B=1024: 12.7k, B=2048: 8.8k).
+        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else "gb").lower()
         names = {"l1", "b2", "f3", "gb", "s3"}
         self.fuse = set(names) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if self.lay.S > 32:
