@@ -115,6 +115,19 @@ int naf_head_fwd_bwd_mse_splitk(const float* heads_partial, int64_t slab_stride,
 int naf_act_noise(const float* heads_pre, int ldh, float* action_out, uint64_t seed, const uint64_t* counter_dev,
                   uint64_t counter_off, float noise_scale, int E, int A, int p_mode, void* stream);
 
+/* NAFAgent.act() for E states in ONE launch (naf_algorithm.py:158-178 with naf_neural_network.py:76-87,119-121):
+ * eval-mode forward of the main net (Linear -> BatchNorm with running statistics -> ReLU, twice; the NH = A+T+1 head
+ * rows of Wh[.][ldw], whose column H is the bias) for obs[E][ldobs], then naf_act_noise's mu / noise / clamp with the
+ * same Philox stream (seed, *counter_dev, state, lane). *counter_dev is advanced by one when the launch is over (by
+ * the last workgroup to finish: `ticket` is a zero-initialised uint32 the library uses for that). H must be 256,
+ * S <= 32. heads_out (nullable): [E][ldh] pre-activations. One workgroup per state. */
+int naf_policy_act(const float* obs, int ldobs, int S, const float* W1, const float* b1, const float* g1, const float* be1,
+                   const float* W2, const float* b2, const float* g2, const float* be2, const float* Wh, int ldw, int NH,
+                   const float* running_mean1, const float* running_var1, const float* running_mean2,
+                   const float* running_var2, float eps, int H, float* heads_out, int ldh, float* action_out,
+                   uint64_t seed, uint64_t* counter_dev, uint32_t* ticket, float noise_scale, int E, int A, int p_mode,
+                   void* stream);
+
 /* ---- BatchNorm1d + ReLU around the trunk GEMMs ---------------------------------------------- */
 /* replaces `torch.relu(self.bnK(linear(x)))` minus the GEMM (naf_neural_network.py:76-78) in TRAINING mode
  * for `nets` networks in one launch (net n uses pointer + n*stride): z = g + bias; batch mean / biased var;

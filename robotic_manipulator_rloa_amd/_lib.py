@@ -15,7 +15,7 @@ from typing import Optional
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
 SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "gemm_bundle.hip", "optim.hip", "synth_env.hip",
-           "xgmi_reduce.hip"]
+           "xgmi_reduce.hip", "policy_act.hip"]
 HEADERS = ["common.h", "head_body.h", "bn_tile.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
@@ -102,6 +102,8 @@ _PROTOS = {
     "naf_synth_env_step": [_vp, _vp, _vp, _vp, _i, _i, _u64, _vp, _i, _vp],
     "naf_synth_env_reset": [_vp, _vp, _i, _i, _u64, _u64, _vp, _vp],
     "naf_synth_env_state_floats": [_i],
+    "naf_policy_act": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i,
+                       _vp, _u64, _vp, _vp, _f, _i, _i, _i, _vp],
     "naf_xgmi_chunk_floats": [],
     "naf_xgmi_create": [_i, _i, _sz, C.c_double, C.POINTER(_vp)],
     "naf_xgmi_set_timeout": [_vp, C.c_double],

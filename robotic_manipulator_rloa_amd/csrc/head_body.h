@@ -165,3 +165,65 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
         loss_partials[blockIdx.x] = x;
     }
 }
+
+// Exploration noise for ONE sample per 8-lane group (lane i = tid & 7 owns component i): action = clamp(mu +
+// noise_scale * P^{-1/2} z, -1, 1), z ~ N(0, I) from Philox keyed by (ctr, sample, lane, seed). Hadamard: P = diag(L_ii^2),
+// so the covariance inverse(P) is diag(exp(-2 tanh l_ii)); matmul: cov = (L L^T)^-1 = L^-T L^-1, x solves L^T x = z by
+// back substitution over the group. hrow: the sample's heads row (global or LDS); Lt: 8 * LT_STRIDE floats of LDS
+// (matmul mode). Contains a __syncthreads() in matmul mode: call it from every thread of the workgroup (live = false
+// for lanes without a sample).
+template <int PMODE>
+__device__ static inline void naf_act_noise_body(const float* hrow, float* Lt, float* __restrict__ action_out,
+                                                 uint64_t seed, uint64_t ctr, float noise_scale, int64_t s, bool live,
+                                                 int A, int tid) {
+    const int i = tid & 7;
+    const bool row_on = live && i < A;
+    float mu = 0.f, z = 0.f, Lii = 1.f;
+    float L_row[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) L_row[j] = 0.f;
+    if (row_on) {
+        mu = tanhf(hrow[i]);
+        const int rbase = A + i * (i + 1) / 2;
+        if (PMODE == NAF_P_HADAMARD) {
+            Lii = expf(tanhf(hrow[rbase + i]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j <= i) {
+                    float t = tanhf(hrow[rbase + j]);
+                    L_row[j] = (j == i) ? expf(t) : t;
+                }
+            }
+        }
+        Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)s, (uint32_t)i, (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+        float u1 = naf_u01(p.v[0]), u2 = naf_u01(p.v[1]);
+        z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
+    float x = 0.f;
+    if (PMODE == NAF_P_HADAMARD) {
+        x = z / Lii;
+    } else {
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Lt[i * LT_STRIDE + j] = L_row[j];
+        }
+        __syncthreads();
+        const int gb = (tid & 63) & ~7;
+        // solve L^T x = z: x_j = (z_j - sum_{k>j} L_kj x_k) / L_jj, j = A-1 .. 0 (lane j owns x_j)
+        float acc = z;
+        for (int k = 7; k >= 0; --k) {
+            float Lkk = Lt[k * LT_STRIDE + k];
+            float xk_mine = (k < A) ? acc / (Lkk == 0.f ? 1.f : Lkk) : 0.f;
+            float xk = __shfl(xk_mine, gb + k);  // lane k's value is the finished x_k
+            if (i == k) x = xk;
+            if (i < k) acc -= Lt[k * LT_STRIDE + i] * xk;
+        }
+    }
+    if (row_on) {
+        float a = mu + noise_scale * x;
+        a = fminf(1.0f, fmaxf(-1.0f, a));
+        action_out[s * A + i] = a;
+    }
+}

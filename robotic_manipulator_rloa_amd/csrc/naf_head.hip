@@ -187,60 +187,10 @@ __global__ __launch_bounds__(HEAD_THREADS) void naf_act_noise_kernel(const float
                                                                      int A) {
     __shared__ float sh_L[PMODE == NAF_P_MATMUL ? HEAD_SPB * 8 * LT_STRIDE : 1];
     const int tid = threadIdx.x;
-    const int s_loc = tid >> 3;
-    const int i = tid & 7;
-    const int64_t s = (int64_t)blockIdx.x * HEAD_SPB + s_loc;
-    const bool live = s < E;
-    const bool row_on = live && i < A;
+    const int64_t s = (int64_t)blockIdx.x * HEAD_SPB + (tid >> 3);
     const uint64_t ctr = (counter_dev ? *counter_dev : 0ull) + counter_off;
-    const float* hrow = heads + s * ldh;
-
-    float mu = 0.f, z = 0.f;
-    float L_row[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) L_row[j] = 0.f;
-    if (row_on) {
-        mu = tanhf(hrow[i]);
-        const int rbase = A + i * (i + 1) / 2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j <= i) {
-                float t = tanhf(hrow[rbase + j]);
-                L_row[j] = (j == i) ? expf(t) : t;
-            }
-        }
-        Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)s, (uint32_t)i, (uint32_t)seed,
-                                  (uint32_t)(seed >> 32));
-        float u1 = naf_u01(p.v[0]), u2 = naf_u01(p.v[1]);
-        z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-    }
-    float x = 0.f;
-    if (PMODE == NAF_P_HADAMARD) {
-        float Lii = 1.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (j == i) Lii = row_on ? L_row[j] : 1.f;
-        x = z / Lii;
-    } else {
-        float* Lt = sh_L + s_loc * 8 * LT_STRIDE;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Lt[i * LT_STRIDE + j] = L_row[j];
-        __syncthreads();
-        const int gb = (tid & 63) & ~7;
-        // solve L^T x = z: x_j = (z_j - sum_{k>j} L_kj x_k) / L_jj, j = A-1 .. 0 (lane j owns x_j)
-        float acc = z;
-        for (int k = 7; k >= 0; --k) {
-            float Lkk = Lt[k * LT_STRIDE + k];
-            float xk_mine = (k < A) ? acc / (Lkk == 0.f ? 1.f : Lkk) : 0.f;
-            float xk = __shfl(xk_mine, gb + k);  // lane k's value is the finished x_k
-            if (i == k) x = xk;
-            if (i < k) acc -= Lt[k * LT_STRIDE + i] * xk;
-        }
-    }
-    if (row_on) {
-        float a = mu + noise_scale * x;
-        a = fminf(1.0f, fmaxf(-1.0f, a));
-        action_out[s * A + i] = a;
-    }
+    naf_act_noise_body<PMODE>(heads + s * ldh, sh_L + (tid >> 3) * 8 * LT_STRIDE, action_out, seed, ctr, noise_scale, s,
+                              s < E, A, tid);
 }
 
 extern "C" int naf_act_noise(const float* heads_pre, int ldh, float* action_out, uint64_t seed,

@@ -453,6 +453,10 @@ class ActPath:
         self.actions = torch.zeros(E, lay.A, **f32)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)   # noise stream position (uint64 on device)
+        # one launch for the whole act() (csrc/policy_act.hip) when the shapes are the framework's (H = 256, S <= 32);
+        # NAF_ACT_FUSED=0 keeps the seven-launch path (3 GEMMs, 2 BN kernels, noise, counter)
+        self.fused = lay.H == 256 and lay.S <= 32 and os.environ.get("NAF_ACT_FUSED", "1") != "0"
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.W1T = learner.W1T2[0]
         self.W2T = learner.W2T2[0]
         self.WhT = learner.WhT2[0]
@@ -475,6 +479,16 @@ class ActPath:
     def act(self, noise_scale: float = 1.0) -> torch.Tensor:
         """obs (already in self.obs) -> self.actions; advances the noise counter on the device."""
         L, lay, st = self.L, self.L.lay, stream_ptr()
+        if self.fused:
+            seg, H = lay.seg, lay.H
+            t2p, bnp = L.theta2.data_ptr(), L.bn_stats.data_ptr()
+            off = lambda name: t2p + 4 * seg[name].offset          # noqa: E731
+            check(L.lib.naf_policy_act(
+                ptr(self.obs), lay.S, lay.S, off("W1"), off("b1"), off("g1"), off("be1"), off("W2"), off("b2"), off("g2"),
+                off("be2"), off("Wh"), lay.HP, lay.NH, bnp, bnp + 4 * H, bnp + 8 * H, bnp + 12 * H, BN_EPS, H, ptr(self.Gh),
+                lay.NHP, ptr(self.actions), self.seed, ptr(self.counter), ptr(self._ticket), float(noise_scale), self.E,
+                lay.A, L.p_mode, st), "policy_act")
+            return self.actions
         self.heads()
         check(L.lib.naf_act_noise(ptr(self.Gh), lay.NHP, ptr(self.actions), self.seed, ptr(self.counter), 0,
                                   float(noise_scale), self.E, lay.A, L.p_mode, st), "act_noise")

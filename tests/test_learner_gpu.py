@@ -233,3 +233,47 @@ def test_device_env_loop_fills_replay_and_trains():
     chunk.run()
     torch.cuda.synchronize()
     assert not torch.equal(theta0, L.theta2) and torch.isfinite(L.theta2).all() and buf.bad_index_count() == 0
+
+
+@pytest.mark.parametrize("p_mode", [0, 1])
+@pytest.mark.parametrize("S,A,E", [(21, 6, 1), (21, 6, 64), (23, 7, 5), (32, 8, 33), (11, 1, 300)])
+def test_policy_act_one_launch_matches_seven_launch_path(S, A, E, p_mode, monkeypatch):
+    """csrc/policy_act.hip (act() for E states in one launch) against the GEMM + BN-eval + noise chain it replaces:
+    same heads pre-activations to f32 rounding, same noise stream (same Philox keys), counter advanced by one per call."""
+    from robotic_manipulator_rloa_amd.learner import ActPath
+    torch.manual_seed(S + A + E)
+    g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
+    import torch.nn as nn
+    T = A * (A + 1) // 2
+    lin = {"input_layer": nn.Linear(S, 256), "hidden_layer": nn.Linear(256, 256), "action_values": nn.Linear(256, A),
+           "value": nn.Linear(256, 1), "matrix_entries": nn.Linear(256, T)}
+    sd = {}
+    for k, l in lin.items():
+        sd[f"{k}.weight"], sd[f"{k}.bias"] = l.weight.detach().numpy(), l.bias.detach().numpy()
+    rng = np.random.default_rng(5)
+    for b in ("bn1", "bn2"):
+        sd[f"{b}.weight"], sd[f"{b}.bias"] = rng.uniform(0.5, 1.5, 256).astype(np.float32), rng.normal(0, 0.2, 256).astype(np.float32)
+        sd[f"{b}.running_mean"] = rng.normal(0, 0.3, 256).astype(np.float32)
+        sd[f"{b}.running_var"] = rng.uniform(0.5, 2.0, 256).astype(np.float32)
+    L = make_learner(S, A, 64, sd, sd, p_mode=p_mode)
+    obs = torch.randn(E, S, device="cuda")
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("NAF_ACT_FUSED", fused)
+        act = ActPath(L, E, seed=1234)
+        assert act.fused == (fused == "1")
+        act.obs.copy_(obs)
+        a1 = act.act(1.0).clone()
+        h1 = act.Gh[:, :L.lay.NH].clone()
+        a2 = act.act(1.0).clone()          # second call: the counter moved, fresh noise
+        a0 = act.act(0.0).clone()          # noise off: tanh(mu)
+        torch.cuda.synchronize()
+        assert int(act.counter.item()) == 3 and int(act._ticket.item()) == 0
+        outs.append((h1, a1, a2, a0))
+    (h_ref, a1_ref, a2_ref, a0_ref), (h, a1, a2, a0) = outs
+    scale = max(1.0, float(h_ref.abs().max()))
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
+    np.testing.assert_allclose(a0.cpu().numpy(), a0_ref.cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(a1.cpu().numpy(), a1_ref.cpu().numpy(), atol=2e-4)      # same z, sigma from nearly equal heads
+    np.testing.assert_allclose(a2.cpu().numpy(), a2_ref.cpu().numpy(), atol=2e-4)
+    assert not torch.equal(a1, a2)
