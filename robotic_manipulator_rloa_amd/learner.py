@@ -437,7 +437,10 @@ class ActPath:
     (main net only), mu = tanh, exploration noise clamp(mu + P^-1/2 z) — noise is drawn on EVERY call exactly as
     the reference's forward does (naf_neural_network.py:119-121), unless noise_scale = 0."""
 
-    def __init__(self, learner: Learner, n_states: int, seed: int):
+    def __init__(self, learner: Learner, n_states: int, seed: int, host_io: bool = False):
+        """host_io: `obs` and `actions` live in pinned HOST memory that the one-launch kernel reads and writes directly
+        (84 B in, 24 B out per state): the per-call H2D / D2H copies of NAFAgent.act() disappear, the caller fills
+        `obs_np`, enqueues act(), synchronises the stream and reads `actions_np`. Only with the fused kernel."""
         self.L = learner
         lay, dev = learner.lay, learner.dev
         self.E = int(n_states)
@@ -457,6 +460,11 @@ class ActPath:
         # NAF_ACT_FUSED=0 keeps the seven-launch path (3 GEMMs, 2 BN kernels, noise, counter)
         self.fused = lay.H == 256 and lay.S <= 32 and os.environ.get("NAF_ACT_FUSED", "1") != "0"
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.host_io = bool(host_io) and self.fused
+        if self.host_io:
+            self.obs = torch.zeros(E, lay.S, dtype=torch.float32).pin_memory()
+            self.actions = torch.zeros(E, lay.A, dtype=torch.float32).pin_memory()
+            self.obs_np, self.actions_np = self.obs.numpy(), self.actions.numpy()
         self.W1T = learner.W1T2[0]
         self.W2T = learner.W2T2[0]
         self.WhT = learner.WhT2[0]

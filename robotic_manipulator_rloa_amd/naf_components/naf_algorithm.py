@@ -146,8 +146,9 @@ class NAFAgent:
     def act(self, state) -> np.ndarray:
         """Noisy clamped action for one state, main net in eval mode (naf_algorithm.py:158-178)."""
         if self._actor1 is None:
-            self._actor1 = ActPath(self.learner, 1, seed=(self.seed * 2654435761 + 12345 + self.rank) & 0xFFFFFFFFFFFFFFFF)
-            if self.use_graph:
+            self._actor1 = ActPath(self.learner, 1, seed=(self.seed * 2654435761 + 12345 + self.rank) & 0xFFFFFFFFFFFFFFFF,
+                                   host_io=True)
+            if self.use_graph and not self._actor1.fused:      # one launch needs no graph around it
                 a = self._actor1
                 saved = (a.counter.clone(),)
                 side = torch.cuda.Stream()
@@ -162,6 +163,15 @@ class NAFAgent:
                 a.counter.copy_(saved[0])
                 self._act_graph = g
         a = self._actor1
+        if a.host_io:
+            # the kernel reads the state from, and writes the action to, pinned host memory: no copies to enqueue
+            a.obs_np[0] = state
+            if self._act_graph is not None:
+                self._act_graph.replay()
+            else:
+                a.act()
+            torch.cuda.current_stream().synchronize()
+            return a.actions_np[0].copy().squeeze()
         self._obs_pinned[0].copy_(torch.from_numpy(np.asarray(state, dtype=np.float32)))
         a.obs.copy_(self._obs_pinned, non_blocking=True)
         if self._act_graph is not None:
