@@ -14,6 +14,7 @@ import torch
 from .. import _lib
 from .._lib import check, ptr, stream_ptr
 
+_DIRECT_ROWS = 16      # up to this many staged rows are read by the append kernel from pinned host memory
 _STAGE_ROWS = 1024
 
 
@@ -102,10 +103,14 @@ class ReplayBuffer:
             return
         cur = self._stage_cur
         host, dev = self._stage_hosts[cur], self._stage_devs[cur]
-        dev[:n].copy_(host[:n], non_blocking=True)
+        if n <= _DIRECT_ROWS:
+            src = host                 # pinned and device-mapped: the append kernel reads the few rows straight from it
+        else:
+            dev[:n].copy_(host[:n], non_blocking=True)
+            src = dev
         for lo in range(0, n, self.buffer_size):      # a ring smaller than the staging area: append in ring-sized pieces
             k = min(self.buffer_size, n - lo)
-            self.add_rows_device(dev[lo:lo + k], k, _count=False)
+            self.add_rows_device(src[lo:lo + k], k, _count=False)
         self._stage_events[cur].record()
         # switch to the other staging area; its previous copy (two flushes ago) has long completed
         self._stage_cur = cur ^ 1
