@@ -193,13 +193,25 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(const uint64_t* __r
                 // "some earlier element holds the same value": four candidates per LDS read, eight reads in flight (the
                 // one-int-per-iteration form was a chain of ~B/2 dependent LDS round trips: 20 us per launch at B = 256)
                 const int mine = vals[t];
+                // The scan is VALU-bound (B candidates per element). Wave-uniform trip counts keep the loops unrolled
+                // into independent LDS reads (with a per-lane bound they ran as one dependent read per iteration):
+                // candidates below the wave's first element need no position mask, only the wave's own 64 positions do.
+                // (A sort-based variant, bitonic in LDS, measured slower: 8.9 vs 7.1 us at B = 256.)
+                const int wave_first = t & ~63;                   // uniform inside a wave
                 const int4* v4 = (const int4*)vals;
                 bool dup = false;
+                const int full4 = wave_first >> 2;
 #pragma unroll 8
-                for (int j4 = 0; 4 * j4 < t; ++j4) {
+                for (int j4 = 0; j4 < full4; ++j4) {
+                    const int4 q = v4[j4];
+                    dup |= (q.x == mine) | (q.y == mine) | (q.z == mine) | (q.w == mine);
+                }
+                const int end4 = (wave_first + 64 < B ? wave_first + 64 : B + 3) >> 2;
+#pragma unroll 8
+                for (int j4 = full4; j4 < end4; ++j4) {
                     const int4 q = v4[j4];
                     const int j = 4 * j4;
-                    dup |= (q.x == mine) | ((q.y == mine) & (j + 1 < t)) | ((q.z == mine) & (j + 2 < t)) |
+                    dup |= ((q.x == mine) & (j + 0 < t)) | ((q.y == mine) & (j + 1 < t)) | ((q.z == mine) & (j + 2 < t)) |
                            ((q.w == mine) & (j + 3 < t));
                 }
                 if (dup) dupmask |= (1 << k);
