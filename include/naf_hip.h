@@ -48,6 +48,17 @@ extern "C" {
 
 typedef struct naf_replay naf_replay_t;
 
+#define NAF_XGMI_MAX_WORLD 8
+#define NAF_XGMI_HANDLE_BYTES 64
+/* what a kernel outside xgmi_reduce.hip needs to push part of the gradient early (naf_bn_relu_bwd_wgrad_push; the
+ * one-shot gradient all-reduce is described with the naf_xgmi_* entry points below) */
+typedef struct {
+    void* peer_base[NAF_XGMI_MAX_WORLD]; /* every rank's slab as mapped in this process */
+    uint64_t* ctrl;
+    uint64_t data_off, n_pad;
+    int rank, world;
+} naf_xgmi_push_t;
+
 /* ---- library ------------------------------------------------------------------------------ */
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
@@ -166,6 +177,13 @@ int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const float* x, int l
                           const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
                           const float* save_invstd, float* d_gamma, float* d_beta, float* d_bias, float* d_W,
                           float* sumsq_partials, int32_t* step_dev, int B, int H, void* stream);
+/* naf_bn_relu_bwd_wgrad with, in the same launch, extra workgroups that push grad[push_lo, push_hi) — gradient segments
+ * finished by EARLIER launches — to the data-parallel peers (NULL push = exactly naf_bn_relu_bwd_wgrad). */
+int naf_bn_relu_bwd_wgrad_push(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
+                               const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
+                               const float* save_invstd, float* d_gamma, float* d_beta, float* d_bias, float* d_W,
+                               float* sumsq_partials, int32_t* step_dev, int B, int H, const naf_xgmi_push_t* push,
+                               const float* grad, size_t push_lo, size_t push_hi, void* stream);
 /* feature columns per workgroup of the three kernels above and below (= entries per H in their sumsq_partials) */
 int naf_fused_tile_cols(void);
 /* d_out = d_heads[B][ldh] @ Wh[ldh][ldw] computed on the fly (ldh in {16,32,48}, pad columns zero), then the
@@ -255,8 +273,6 @@ int naf_synth_env_state_floats(int A);
  *             sumsq_partials (nullable) receives ceil(n_floats / naf_xgmi_chunk_floats()) partial sums of
  *             grad_out^2 for naf_adam_polyak_fused; step_dev (nullable) is advanced by one. Capturable.
  *   status  : blocking read of the epoch (all-reduces done) and of the number of timed-out waits (must stay 0). */
-#define NAF_XGMI_MAX_WORLD 8
-#define NAF_XGMI_HANDLE_BYTES 64
 int naf_xgmi_chunk_floats(void);
 int naf_xgmi_create(int rank, int world, size_t n_floats, double timeout_s, void** handle);
 int naf_xgmi_set_timeout(void* handle, double timeout_s); /* for launches enqueued (or captured) after this call */
@@ -265,6 +281,13 @@ int naf_xgmi_export(void* handle, void* out_handle_bytes);
 int naf_xgmi_connect(void* handle, const void* all_handle_bytes);
 int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
                            int32_t* step_dev, void* stream);
+/* Early push: grad[lo, hi) (multiples of 4, hi <= n_floats) goes to the peers ahead of the all-reduce proper, either from
+ * a launch of its own (push_early: used by the self-test) or from extra workgroups of naf_bn_relu_bwd_wgrad_push. The
+ * all-reduce that follows must then be naf_xgmi_allreduce_sum_from with the same `lo`: it pushes only [0, lo). */
+int naf_xgmi_push_desc(void* handle, naf_xgmi_push_t* out);
+int naf_xgmi_push_early(void* handle, const float* grad_in, size_t lo, size_t hi, void* stream);
+int naf_xgmi_allreduce_sum_from(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
+                                int32_t* step_dev, size_t pushed_lo, void* stream);
 int naf_xgmi_status(void* handle, uint64_t* epoch, uint64_t* timeouts);
 int naf_xgmi_destroy(void* handle);
 

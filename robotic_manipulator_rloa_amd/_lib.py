@@ -16,7 +16,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
 SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "gemm_bundle.hip", "optim.hip", "synth_env.hip",
            "xgmi_reduce.hip", "policy_act.hip"]
-HEADERS = ["common.h", "head_body.h", "bn_tile.h", os.path.join("..", "..", "include", "naf_hip.h")]
+HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
 ACTION_TRUNC_INT, ACTION_FLOAT = 0, 1
@@ -88,6 +88,8 @@ _PROTOS = {
     "naf_linear_bn_relu_fwd_train": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp,
                                      _i, _i, _i, _f, _f, _vp],
     "naf_bn_relu_bwd_wgrad": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_bn_relu_bwd_wgrad_push": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                   _vp, _vp, _sz, _sz, _vp],
     "naf_fused_tile_cols": [],
     "naf_heads_bwd_bn_relu_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i,
                                   _vp],
@@ -111,11 +113,20 @@ _PROTOS = {
     "naf_xgmi_export": [_vp, _vp],
     "naf_xgmi_connect": [_vp, _vp],
     "naf_xgmi_allreduce_sum": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "naf_xgmi_push_desc": [_vp, _vp],
+    "naf_xgmi_push_early": [_vp, _vp, _sz, _sz, _vp],
+    "naf_xgmi_allreduce_sum_from": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "naf_xgmi_status": [_vp, C.POINTER(_u64), C.POINTER(_u64)],
     "naf_xgmi_destroy": [_vp],
 }
 _RESTYPES = {"naf_hip_arch": C.c_char_p}
 EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+class XgmiPushDesc(C.Structure):
+    """naf_xgmi_push_t (include/naf_hip.h)"""
+    _fields_ = [("peer_base", C.c_void_p * 8), ("ctrl", C.c_void_p), ("data_off", C.c_uint64), ("n_pad", C.c_uint64),
+                ("rank", C.c_int), ("world", C.c_int)]
 
 
 class GemmDesc(C.Structure):

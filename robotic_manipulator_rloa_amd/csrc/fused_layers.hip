@@ -9,8 +9,10 @@
 //                                  net, then the whole NAF head fwd + TD/MSE + bwd               (replaces bmm + head)
 // Reference lines replaced: naf_neural_network.py:76,81-115 (forward), their autograd, naf_algorithm.py:199-208.
 // Tile ownership as in bn_relu.hip: a workgroup owns 32 feature columns x ALL batch rows (32 x 32 threads).
+#include <string.h>
 #include "head_body.h"
 #include "bn_tile.h"
+#include "xgmi_dev.h"
 
 // tile of the column-ownership kernels: 8 feature columns x 64 row phases (512 threads), RPT = ceil(B/64) rows per
 // thread. A wave = 8 row phases x 8 columns, so a broadcast row load (all 8 column lanes read the same 16 B of an
@@ -178,13 +180,28 @@ __global__ __launch_bounds__(FT_THREADS) void linear_bn_relu_fwd_train_kernel(
 // B1: backward of F1 for one network: d_gamma, d_beta, d_bias and dW[H][K] = dZ^T X. dZ never leaves registers;
 // z is recomputed from X and W exactly as the forward computed it.
 // ------------------------------------------------------------------------------------------------------------
+struct B1Push {            // data-parallel runs: extra workgroups of this launch push finished gradient segments
+    naf_xgmi_push_t d;
+    const float* grad;
+    size_t lo, hi;
+    int n_tiles;           // workgroups [0, n_tiles) are the column tiles, the rest push; 0 = no pushing
+};
+
 template <int RPT, int K4>
 __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     const float* __restrict__ d_out, int ld_dout, const float* __restrict__ x, int ldx, int K,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ out, int ldo,
     const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
     float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_W,
-    float* __restrict__ sumsq_partials, int32_t* step_dev, int B, int H) {
+    float* __restrict__ sumsq_partials, int32_t* step_dev, int B, int H, const B1Push push) {
+    if (push.n_tiles && (int)blockIdx.x >= push.n_tiles) {
+        // the gradient of everything but layer 1 is final (written by earlier launches): it travels to the peers while
+        // the column tiles of this launch work, instead of after them
+        xg_push_range<NAF_XGMI_MAX_WORLD>(push.d, push.grad, push.lo, push.hi, (int)blockIdx.x - push.n_tiles, FT_THREADS,
+                                          threadIdx.y * FT_TX + threadIdx.x);
+        return;
+    }
+    const int n_tiles = push.n_tiles ? push.n_tiles : (int)gridDim.x;
     __shared__ float red[FT_NW][FT_TX + 1];
     __shared__ float red2[FT_NW][FT_TX + 1];
     __shared__ float red3[FT_NW][FT_TX + 1];
@@ -192,7 +209,7 @@ __global__ __launch_bounds__(FT_THREADS) void bn_relu_bwd_wgrad_kernel(
     __shared__ float sG[FT_NW][FT_TX][4 * MAX_K4 + 1];   // per-wave partial dW tiles
     __shared__ float sQ[FT_NW];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FT_TX + tx;
-    const int bx = naf_xcd_tile(blockIdx.x, gridDim.x);
+    const int bx = naf_xcd_tile(blockIdx.x, n_tiles);
     const int col0 = bx * FT_TX, col = col0 + tx;
     const bool col_on = col < H;
     const float b = col_on ? bias[col] : 0.f;
@@ -733,11 +750,12 @@ extern "C" int naf_linear_bn_relu_fwd_train(const float* x, int64_t x_net_stride
     return NAF_OK;
 }
 
-extern "C" int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
-                                     const float* bias, const float* out, int ldo, const float* gamma,
-                                     const float* save_mean, const float* save_invstd, float* d_gamma, float* d_beta,
-                                     float* d_bias, float* d_W, float* sumsq_partials, int32_t* step_dev, int B, int H,
-                                     void* stream) {
+extern "C" int naf_bn_relu_bwd_wgrad_push(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
+                                          const float* bias, const float* out, int ldo, const float* gamma,
+                                          const float* save_mean, const float* save_invstd, float* d_gamma, float* d_beta,
+                                          float* d_bias, float* d_W, float* sumsq_partials, int32_t* step_dev, int B, int H,
+                                          const naf_xgmi_push_t* push, const float* grad, size_t push_lo, size_t push_hi,
+                                          void* stream) {
     if (!d_out || !x || !W || !bias || !out || !gamma || !save_mean || !save_invstd || !d_gamma || !d_beta || !d_W)
         return NAF_ERR_ARG;
     if (B <= 0 || B > FUSED_MAX_B || H <= 0 || K <= 0 || K > 4 * MAX_K4 || ld_dout < H || ldo < H) return NAF_ERR_ARG;
@@ -745,11 +763,35 @@ extern "C" int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const floa
     const int k4d = k4 <= 6 ? 6 : 8;
     if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((H + FT_TX - 1) / FT_TX, 1), block(FT_TX, FT_TY);
+    const int n_tiles = (H + FT_TX - 1) / FT_TX;
+    B1Push p;
+    memset(&p, 0, sizeof(p));
+    int extra = 0;
+    if (push) {
+        if (!grad || (push_lo & 3) || (push_hi & 3) || push_lo >= push_hi || ((uintptr_t)grad & 15) || push->world < 2 ||
+            push->world > NAF_XGMI_MAX_WORLD || push_hi > push->n_pad)
+            return NAF_ERR_ARG;
+        p.d = *push;
+        p.grad = grad;
+        p.lo = push_lo;
+        p.hi = push_hi;
+        p.n_tiles = n_tiles;
+        extra = (int)((push_hi - push_lo + (size_t)FT_THREADS * 4 - 1) / ((size_t)FT_THREADS * 4));
+    }
+    dim3 grid(n_tiles + extra, 1), block(FT_TX, FT_TY);
     K4_DISPATCH(bn_relu_bwd_wgrad_kernel, k4, d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, save_invstd,
-                d_gamma, d_beta, d_bias, d_W, sumsq_partials, step_dev, B, H);
+                d_gamma, d_beta, d_bias, d_W, sumsq_partials, step_dev, B, H, p);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
+}
+
+extern "C" int naf_bn_relu_bwd_wgrad(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
+                                     const float* bias, const float* out, int ldo, const float* gamma,
+                                     const float* save_mean, const float* save_invstd, float* d_gamma, float* d_beta,
+                                     float* d_bias, float* d_W, float* sumsq_partials, int32_t* step_dev, int B, int H,
+                                     void* stream) {
+    return naf_bn_relu_bwd_wgrad_push(d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, save_invstd, d_gamma,
+                                      d_beta, d_bias, d_W, sumsq_partials, step_dev, B, H, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int naf_heads_bwd_bn_relu_bwd(const float* d_heads, int ldh, const float* Wh, int ldw, const float* g, int ldg,

@@ -17,15 +17,12 @@
 // Nothing here allocates or synchronises after naf_xgmi_connect; the launch is a plain kernel launch and can be captured
 // into a hipGraph (the epoch lives on the device).
 #include <string.h>
-#include "common.h"
-#include "../../include/naf_hip.h"
+#include "xgmi_dev.h"
 
 #define XG_THREADS 256
 #define XG_CHUNK (XG_THREADS * 4)          // floats per workgroup: one float4 per thread
 #define XG_FLAG_STRIDE 128                 // bytes: one flag per line
 #define XG_TICKS_PER_S 100000000ll         // wall_clock64() runs at 100 MHz
-
-typedef float xg_f4 __attribute__((ext_vector_type(4)));
 
 struct XgPeers {
     char* base[NAF_XGMI_MAX_WORLD];        // slab of every rank as mapped into THIS process (base[rank] = local)
@@ -41,10 +38,6 @@ struct XgmiComm {
     long long timeout_ticks;
 };
 
-__device__ static inline float* xg_slot(char* base, size_t data_off, size_t n_pad, int world, uint64_t epoch, int sender) {
-    return (float*)(base + data_off) + ((size_t)(epoch & 1) * world + sender) * n_pad;
-}
-
 // One launch per all-reduce. No workgroup waits for another workgroup of its own launch (the last one to ARRIVE raises
 // the flags; nobody polls the arrival counter), so the only waits are on the peers' flags, which depend on nothing but the
 // peers' own pushes: no circular wait whatever the residency of the grid.
@@ -54,7 +47,9 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peer
                                                                     size_t data_off, int rank,
                                                                     uint64_t* __restrict__ ctrl,
                                                                     float* __restrict__ sumsq_partials, int32_t* step_dev,
-                                                                    long long timeout_ticks) {
+                                                                    long long timeout_ticks, size_t pushed_lo) {
+    // pushed_lo: grad_in[pushed_lo, n) has already been pushed for this epoch (naf_xgmi_push_early or the layer-1
+    // backward kernel's extra workgroups, in an earlier launch of this stream); pushed_lo = n: nothing has
     __shared__ float red[XG_THREADS / 64];
     __shared__ int last;
     const uint64_t e = ctrl[0] + 1;        // nobody writes ctrl[0] before every workgroup has arrived below
@@ -62,8 +57,8 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peer
     const bool on = i < n;                 // n is a multiple of 4 (checked on the host)
     // ---- push: this workgroup's chunk of the local gradient into the slot `rank` of every peer ---------------------
     xg_f4 mine = {0.f, 0.f, 0.f, 0.f};
-    if (on) {
-        mine = *(const xg_f4*)(grad_in + i);
+    if (on) mine = *(const xg_f4*)(grad_in + i);
+    if (on && i < pushed_lo) {
         // branch-free on purpose (the own slab gets a copy nobody reads): with `if (p != rank)` around each store the
         // compiler put an s_waitcnt vmcnt(0) in front of every one of them — W-1 SERIAL round trips over xGMI
 #pragma unroll
@@ -218,10 +213,53 @@ extern "C" int naf_xgmi_connect(void* handle, const void* all_handle_bytes) {
     return NAF_OK;
 }
 
+static void xg_fill_desc(const XgmiComm* c, naf_xgmi_push_t* d) {
+    for (int p = 0; p < NAF_XGMI_MAX_WORLD; ++p) d->peer_base[p] = c->peers.base[p];
+    d->ctrl = c->ctrl;
+    d->data_off = c->data_off;
+    d->n_pad = c->n_pad;
+    d->rank = c->rank;
+    d->world = c->world;
+}
+
+extern "C" int naf_xgmi_push_desc(void* handle, naf_xgmi_push_t* out) {
+    if (!handle || !out) return NAF_ERR_ARG;
+    XgmiComm* c = xg_comm(handle);
+    for (int p = 0; p < c->world; ++p)
+        if (!c->peers.base[p]) return NAF_ERR_STATE;
+    xg_fill_desc(c, out);
+    return NAF_OK;
+}
+
+__global__ __launch_bounds__(XG_THREADS) void xgmi_push_early_kernel(naf_xgmi_push_t d, const float* __restrict__ grad,
+                                                                     size_t lo, size_t hi) {
+    xg_push_range<NAF_XGMI_MAX_WORLD>(d, grad, lo, hi, blockIdx.x, XG_THREADS, threadIdx.x);
+}
+
+extern "C" int naf_xgmi_push_early(void* handle, const float* grad_in, size_t lo, size_t hi, void* stream) {
+    if (!handle || !grad_in) return NAF_ERR_ARG;
+    XgmiComm* c = xg_comm(handle);
+    if ((lo & 3) || (hi & 3) || lo >= hi || hi > c->n || ((uintptr_t)grad_in & 15)) return NAF_ERR_ARG;
+    naf_xgmi_push_t d;
+    int rc = naf_xgmi_push_desc(handle, &d);
+    if (rc != NAF_OK) return rc;
+    const unsigned blocks = (unsigned)((hi - lo + XG_CHUNK - 1) / XG_CHUNK);
+    xgmi_push_early_kernel<<<blocks, XG_THREADS, 0, (hipStream_t)stream>>>(d, grad_in, lo, hi);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
 extern "C" int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
                                       int32_t* step_dev, void* stream) {
+    if (!handle) return NAF_ERR_ARG;
+    return naf_xgmi_allreduce_sum_from(handle, grad_in, grad_out, sumsq_partials, step_dev, xg_comm(handle)->n, stream);
+}
+
+extern "C" int naf_xgmi_allreduce_sum_from(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
+                                           int32_t* step_dev, size_t pushed_lo, void* stream) {
     if (!handle || !grad_in || !grad_out) return NAF_ERR_ARG;
     XgmiComm* c = xg_comm(handle);
+    if ((pushed_lo & 3) || pushed_lo > c->n) return NAF_ERR_ARG;
     if ((((uintptr_t)grad_in | (uintptr_t)grad_out) & 15) != 0) return NAF_ERR_ARG;
     for (int p = 0; p < c->world; ++p)
         if (!c->peers.base[p]) return NAF_ERR_STATE;           // naf_xgmi_connect has not mapped every peer
@@ -230,7 +268,7 @@ extern "C" int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float*
     case W:                                                                                                          \
         xgmi_allreduce_kernel<W><<<chunks, XG_THREADS, 0, (hipStream_t)stream>>>(                                    \
             c->peers, grad_in, grad_out, c->n, c->n_pad, c->data_off, c->rank, c->ctrl, sumsq_partials, step_dev,    \
-            c->timeout_ticks);                                                                                       \
+            c->timeout_ticks, pushed_lo);                                                                            \
         break;
     switch (c->world) {
         XG_REDUCE(2) XG_REDUCE(3) XG_REDUCE(4) XG_REDUCE(5) XG_REDUCE(6) XG_REDUCE(7) XG_REDUCE(8)

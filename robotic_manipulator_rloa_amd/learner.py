@@ -205,6 +205,7 @@ class Learner:
         # ring + the grad-norm launch when every rank could map every peer and the exact self-test passed on all of
         # them; otherwise (or with NAF_XGMI=0) the RCCL all-reduce below stays. try_create is collective.
         self.xgmi = None
+        self._push_desc = None
         if self.world_size > 1 and os.environ.get("NAF_XGMI", "1") != "0":
             self.xgmi = XgmiAllReduce.try_create(P, dev, self.pg)
             if self.xgmi is not None:
@@ -387,14 +388,23 @@ class Learner:
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
             torch.mm(self.dZ2, self.W2_main, out=self.dA1)
+        pushed_lo = None
         if "l1" in self.fuse:
-            # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written)
-            check(f.naf_bn_relu_bwd_wgrad(
+            # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written). Data parallel over peer
+            # memory: everything but layer 1's gradient is final by now (segments W2 .. Wh of the flat buffer) and goes
+            # to the peers from extra workgroups of this very launch, so its wire time runs under the kernel
+            push = None
+            if self.xgmi is not None:
+                if self._push_desc is None:
+                    self._push_desc = self.xgmi.push_desc()
+                push, pushed_lo = _lib.C.byref(self._push_desc), seg["W2"].offset
+            check(f.naf_bn_relu_bwd_wgrad_push(
                 ptr(self.dA1), H, rp, lay.row_floats, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                 ptr(self.A1[0]), H, t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, gp + 4 * seg["W1"].offset,
                 self.partials.data_ptr() + 4 * self._gb_blocks if self.fold_norm else None,
-                ptr(self.step_dev) if self.fold_norm else None, B, H, st), "bn_relu_bwd_wgrad")
+                ptr(self.step_dev) if self.fold_norm else None, B, H, push, gp if push is not None else None,
+                pushed_lo or 0, P if push is not None else 0, st), "bn_relu_bwd_wgrad")
         else:
             check(f.naf_bn_relu_bwd(
                 ptr(self.dA1), H, ptr(self.G1[0]), H, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
@@ -406,7 +416,7 @@ class Learner:
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
             if self.xgmi is not None:
                 # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
-                self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev)
+                self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=pushed_lo)
                 self.optimizer_step(norm_ready=True)
                 return
             all_reduce_flat_grad(self.grad, self.pg)

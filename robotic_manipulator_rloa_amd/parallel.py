@@ -131,17 +131,32 @@ class XgmiAllReduce:
             return None
         return comm
 
+    def push_desc(self):
+        """naf_xgmi_push_t for kernels that push part of the gradient early (naf_bn_relu_bwd_wgrad_push)."""
+        from ._lib import XgmiPushDesc, check
+        import ctypes as C
+        d = XgmiPushDesc()
+        check(self.lib.naf_xgmi_push_desc(self.handle, C.byref(d)), "xgmi_push_desc")
+        return d
+
+    def push_early(self, grad_in: torch.Tensor, lo: int, hi: int) -> None:
+        """grad_in[lo:hi] to the peers ahead of the all-reduce (which must then be called with pushed_lo=lo)."""
+        from ._lib import check, ptr, stream_ptr
+        check(self.lib.naf_xgmi_push_early(self.handle, ptr(grad_in), int(lo), int(hi), stream_ptr()), "xgmi_push_early")
+
     def all_reduce(self, grad_in: torch.Tensor, grad_out: torch.Tensor, partials: Optional[torch.Tensor] = None,
-                   step_dev: Optional[torch.Tensor] = None) -> None:
-        """grad_out = sum over ranks of grad_in on the current stream (in place allowed)."""
+                   step_dev: Optional[torch.Tensor] = None, pushed_lo: Optional[int] = None) -> None:
+        """grad_out = sum over ranks of grad_in on the current stream (in place allowed). pushed_lo: grad_in[pushed_lo:]
+        has already gone to the peers (push_early, or the layer-1 backward kernel's extra workgroups)."""
         from ._lib import check, ptr, stream_ptr
         if grad_in.numel() != self.n or grad_out.numel() != self.n or grad_in.dtype != torch.float32 or \
                 grad_out.dtype != torch.float32 or not grad_in.is_contiguous() or not grad_out.is_contiguous():
             raise ValueError("xgmi all_reduce: gradients must be contiguous f32 of the communicator's length")
         if partials is not None and partials.numel() < self.n_partials:
             raise ValueError("xgmi all_reduce: partials too short")
-        check(self.lib.naf_xgmi_allreduce_sum(self.handle, ptr(grad_in), ptr(grad_out), ptr(partials), ptr(step_dev),
-                                              stream_ptr()), "xgmi_allreduce")
+        lo = self.n if pushed_lo is None else int(pushed_lo)
+        check(self.lib.naf_xgmi_allreduce_sum_from(self.handle, ptr(grad_in), ptr(grad_out), ptr(partials), ptr(step_dev),
+                                                   lo, stream_ptr()), "xgmi_allreduce")
 
     def status(self) -> tuple:
         """(all-reduces done, timed-out waits) — blocking."""
@@ -165,11 +180,15 @@ class XgmiAllReduce:
                     return False
             base = ((i + 3 * k) % 61).to(torch.float32)
             g = base * float(self.rank + 1)
+            lo = None
+            if k % 3 == 2:                           # every third round: most of the vector goes ahead, as learn() does it
+                lo = 4 * ((self.n // 13) // 4)
+                self.push_early(g, lo, self.n)
             if k % 2:
-                self.all_reduce(g, g, part)          # in place
+                self.all_reduce(g, g, part, pushed_lo=lo)          # in place
                 got = g
             else:
-                self.all_reduce(g, out, part)
+                self.all_reduce(g, out, part, pushed_lo=lo)
                 got = out
             want = base * float(tri)
             bad += (got != want).sum()

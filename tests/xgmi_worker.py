@@ -51,11 +51,18 @@ def main():
     for k in range(rounds):
         g = rank_input(rank, k, n, dev)
         want = expected_sum(k, n, world, dev)
+        lo = None
+        if k % 4 == 1:                                 # part of the vector pushed ahead of the all-reduce proper
+            lo = 4 * (k * 97 % (n // 4))
+            if lo < n:
+                comm.push_early(g, lo, n)
+            else:
+                lo = None
         if k % 3 == 0:
-            comm.all_reduce(g, g, part)
+            comm.all_reduce(g, g, part, pushed_lo=lo)
             got = g
         else:
-            comm.all_reduce(g, out, part)
+            comm.all_reduce(g, out, part, pushed_lo=lo)
             got = out
         assert torch.equal(got, want), f"round {k}: {(got != want).sum().item()} elements differ"
         ss = (want.double() ** 2).sum()
@@ -122,9 +129,10 @@ def main():
             seen = []
             real = L.xgmi.all_reduce
 
-            def spy(grad_in, grad_out, partials=None, step_dev=None):
+            def spy(grad_in, grad_out, partials=None, step_dev=None, pushed_lo=None):
+                assert pushed_lo == L.lay.seg["W2"].offset      # everything but layer 1 went ahead, from inside B1
                 before = grad_in.clone()
-                real(grad_in, grad_out, partials, step_dev)
+                real(grad_in, grad_out, partials, step_dev, pushed_lo=pushed_lo)
                 seen.append((before, grad_out.clone(), partials[:L.xgmi.n_partials].clone()))
 
             L.xgmi.all_reduce = spy
