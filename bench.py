@@ -131,32 +131,29 @@ def main():
         one_step()
     # ---- timed region: exactly K steps between barrier + synchronize on both sides -------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev0 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        chunk.gather_events = ev[k]
+        chunk.gather_events, chunk.empty_events = ev[k], ev0[k]
         one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    chunk.gather_events = None
+    chunk.gather_events = chunk.empty_events = None
     t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     gather_bracket_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    # what an EMPTY event bracket reads on this stream: the part of every bracket that is not the kernel
-    cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(256)]
-    for a, b in cal:
-        a.record()
-        b.record()
-    torch.cuda.synchronize()
-    event_overhead_ms = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
+    # what an EMPTY event bracket reads on this stream: the part of every bracket that is not the kernel. Recorded in the
+    # timed loop itself, right behind each gather bracket (same stream, same surroundings), averaged the same way
+    event_overhead_ms = sum(a.elapsed_time(b) for a, b in ev0) / len(ev0)
     gather_ms = max(gather_bracket_ms - event_overhead_ms, 1e-6)
 
     finite = bool(torch.isfinite(L.theta2).all().item())
@@ -194,7 +191,7 @@ def main():
                        "avg_launch_ms": round(gather_ms, 5), "avg_event_bracket_ms": round(gather_bracket_ms, 5),
                        "empty_event_bracket_ms": round(event_overhead_ms, 5),
                        "note": "one launch per vector step inside the timed loop, bracketed by HIP events on its stream; "
-                               "avg_launch_ms = bracket - empty bracket; rocprofv3 --kernel-trace average of the same "
+                               "avg_launch_ms = bracket - empty bracket (an empty bracket is recorded right behind every gather bracket, inside the timed loop); rocprofv3 --kernel-trace average of the same "
                                "command: profiles/r01_bench_kernel_stats.csv (replay_gather_rows_kernel<1, 0>)"}
     out["roofline"]["traffic"] = pmc_traffic(rows_per_launch)
     if rank == 0 and world == 1:

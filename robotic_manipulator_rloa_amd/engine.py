@@ -66,6 +66,7 @@ class TrainChunk:
         self.teacher_forced = teacher_forced
         self.gather_outside_graph = gather_outside_graph
         self.gather_events = None          # optional (start, end) torch.cuda.Event pair recorded around the gather
+        self.empty_events = None           # optional pair recorded back to back right after it (what a bracket costs)
         B, dev = learner.B, learner.dev
         if replay.batch_size != B:
             raise ValueError("ReplayBuffer.batch_size must equal the learner's batch size")
@@ -84,6 +85,9 @@ class TrainChunk:
         self.replay.gather_rows(self.idx, self.batch, self.U * self.L.B)
         if ev is not None:
             ev[1].record()
+            if self.empty_events is not None:
+                self.empty_events[0].record()
+                self.empty_events[1].record()
 
     def _updates(self) -> None:
         for k in range(self.U):
