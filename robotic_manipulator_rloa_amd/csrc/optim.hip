@@ -123,12 +123,15 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
             const float total_norm = sqrtf(s) * inv_world;
             float clip = max_norm / (total_norm + 1e-6f);
             clip = clip > 1.0f ? 1.0f : clip;
-            const double bc1 = 1.0 - ipow((double)beta1, t);
-            const double bc2 = 1.0 - ipow((double)beta2, t);
             sh.clip_scale = clip * inv_world;
-            sh.step_size = (float)((double)lr / bc1);
-            sh.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
         }
+    } else if (threadIdx.x == 64) {
+        // the bias corrections (double precision, as torch computes them on the host) do not depend on the partials:
+        // the second wave works them out while the first one folds the norm (0.5 us when one thread did both in turn)
+        const double bc1 = 1.0 - ipow((double)beta1, t);
+        const double bc2 = 1.0 - ipow((double)beta2, t);
+        sh.step_size = (float)((double)lr / bc1);
+        sh.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     }
     __syncthreads();
     const AdamScalars sc = sh;
