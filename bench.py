@@ -181,6 +181,13 @@ def main():
     }
     if L.xgmi is not None:
         out["sanity"]["xgmi_allreduces"], out["sanity"]["xgmi_timed_out_waits"] = L.xgmi.status()
+    if world > 1:
+        # data-parallel replicas must have stayed in lock-step: same parameters, bit for bit, on every rank
+        chk = torch.stack([L.theta2.double().sum(), L.theta2.double().abs().sum(), L.adam_v.double().sum()])
+        chk = chk.cpu() if rehearsal else chk
+        every = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(every, chk)
+        out["sanity"]["replicas_identical"] = all(bool(torch.equal(e, every[0])) for e in every)
     # ---- roofline of the replay gather (the kernel north_star names), measured live with events -----------
     rows_per_launch = U * B
     alg_bytes = rows_per_launch * (4 * (2 * S + A + 2) * 2 + 4)       # 400 B/row read+written + 4 B index

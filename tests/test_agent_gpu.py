@@ -403,6 +403,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["parallelism"] == "dp2" and "one-shot" in out["config"]["grad_exchange"]
     assert out["sanity"]["params_finite"] and out["sanity"]["xgmi_timed_out_waits"] == 0
+    assert out["sanity"]["replicas_identical"] is True
     assert out["sanity"]["optimizer_steps"] == (6 + 2) * 64       # warm-up inside capture leaves no trace
     assert abs(out["value"] - 2 * 64 * 6 / (out["ms_per_step"] * 6e-3)) < 1e-3 * out["value"]
     assert "cpu_baseline" not in out                               # timed at N = 1 only
