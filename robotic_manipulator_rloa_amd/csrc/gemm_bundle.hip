@@ -176,7 +176,16 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bundle_kernel(const GemmBundl
         if (i < bundle.n && t >= bundle.d[i].tile0) gi = i;
     const GemmDesc& D = bundle.d[gi];
     const int lt = t - D.tile0;
-    const int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;
+    int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;
+    if (D.tiles_n == 8 && D.M == 256) {
+        // 8 x 8 blocks; workgroup t runs on XCD t % 8 (round-robin dispatch) and the column-tile kernels on either side of
+        // this launch keep columns 32 x .. 32 x + 31 on XCD x (naf_xcd_tile). k-major A (dW2 = dZ2^T A1): block ROW bm on
+        // XCD bm, the one that has just written those dZ2 columns; k-contiguous A (dA1 = dZ2 W2): block COLUMN bn on XCD
+        // bn, the one that reads those dA1 columns next. Producer and consumer then share an L2 (+1 % updates/s;
+        // placement is speed only, the result does not depend on it).
+        const int xcd = t & 7, slot = lt >> 3;
+        if (D.a_kmajor) { bm = xcd; bn = slot; } else { bn = xcd; bm = slot; }
+    }
     if (D.a_kmajor) {
         if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, sA, sB, sQ, sC);
         else gemm_block<true, false>(D, bm, bn, sA, sB, sQ, sC);
