@@ -268,7 +268,8 @@ int naf_synth_env_state_floats(int A);
  *   create  : allocates this rank's receive slab (uncached device memory) for n_floats-long gradients (n_floats % 4
  *             == 0); timeout_s bounds every wait on a peer (a time-out is counted, the kernel then proceeds)
  *   export  : writes the slab's 64-byte hipIpc handle; the host exchanges the W handles (torch.distributed)
- *   connect : all_handle_bytes = W x 64 bytes in rank order; maps every peer slab (hipIpcOpenMemHandle)
+ *   connect : all_handle_bytes = W x 64 bytes in rank order; maps every peer slab (hipIpcOpenMemHandle) after enabling
+ *             peer access to the devices the peers run on
  *   allreduce_sum : one launch on `stream`: grad_out[i] = sum over ranks of grad_in[i] (in place allowed);
  *             sumsq_partials (nullable) receives ceil(n_floats / naf_xgmi_chunk_floats()) partial sums of
  *             grad_out^2 for naf_adam_polyak_fused; step_dev (nullable) is advanced by one. Capturable.
@@ -278,7 +279,7 @@ int naf_xgmi_create(int rank, int world, size_t n_floats, double timeout_s, void
 int naf_xgmi_set_timeout(void* handle, double timeout_s); /* for launches enqueued (or captured) after this call */
 int naf_xgmi_mem_kind(void* handle); /* 2 = uncached, 1 = fine-grained */
 int naf_xgmi_export(void* handle, void* out_handle_bytes);
-int naf_xgmi_connect(void* handle, const void* all_handle_bytes);
+int naf_xgmi_connect(void* handle, const void* all_handle_bytes, const int* peer_devices /* nullable, W device indices */);
 int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
                            int32_t* step_dev, void* stream);
 /* Early push: grad[lo, hi) (multiples of 4, hi <= n_floats) goes to the peers ahead of the all-reduce proper, either from

@@ -187,16 +187,18 @@ extern "C" int naf_xgmi_export(void* handle, void* out_handle_bytes) {
     return NAF_OK;
 }
 
-extern "C" int naf_xgmi_connect(void* handle, const void* all_handle_bytes) {
+extern "C" int naf_xgmi_connect(void* handle, const void* all_handle_bytes, const int* peer_devices) {
     if (!handle || !all_handle_bytes) return NAF_ERR_ARG;
     XgmiComm* c = xg_comm(handle);
-    // peers may sit on any other device of the node: make them reachable before mapping (errors such as "already
-    // enabled" are not failures; hipIpcOpenMemHandle below is what decides)
+    // the peers' devices (peer_devices[rank], W entries; NULL: every other device of the node) must be reachable before
+    // their slabs are mapped (errors such as "already enabled" are not failures; hipIpcOpenMemHandle decides)
     int cur = 0, ndev = 0;
     if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&ndev) == hipSuccess) {
-        for (int d = 0; d < ndev; ++d) {
+        for (int k = 0; k < (peer_devices ? c->world : ndev); ++k) {
+            const int d = peer_devices ? peer_devices[k] : k;
             int can = 0;
-            if (d != cur && hipDeviceCanAccessPeer(&can, cur, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0);
+            if (d >= 0 && d < ndev && d != cur && hipDeviceCanAccessPeer(&can, cur, d) == hipSuccess && can)
+                (void)hipDeviceEnablePeerAccess(d, 0);
         }
         (void)hipGetLastError();
     }

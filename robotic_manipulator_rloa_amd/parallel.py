@@ -101,14 +101,15 @@ class XgmiAllReduce:
                 if rc == 0:
                     buf = C.create_string_buffer(64)
                     rc = lib.naf_xgmi_export(handle, buf)
-                    blob = bytes(buf.raw) if rc == 0 else None
+                    blob = (bytes(buf.raw), torch.device(device).index or 0) if rc == 0 else None
                 why = "" if rc == 0 else f"create/export rc={rc}"
         blobs = [None] * world
         dist.all_gather_object(blobs, blob, group=group)       # also orders every rank's slab memset before any push
         ok = all(b is not None for b in blobs)
         if ok:
             with torch.cuda.device(device):
-                rc = lib.naf_xgmi_connect(handle, b"".join(blobs))
+                devs = (C.c_int * world)(*[b[1] for b in blobs])
+                rc = lib.naf_xgmi_connect(handle, b"".join(b[0] for b in blobs), devs)
             ok, why = rc == 0, (why or (f"connect rc={rc}" if rc else ""))
         # load the library's code object and warm the launch path BEFORE the barrier below, so that the ranks enter the
         # self-test together (its waits are bounded by test_timeout_s)
