@@ -16,7 +16,9 @@ lib = _lib.load()
 dev = "cuda"
 
 def timed(fn, reps):
-    for _ in range(2): fn()
+    for _ in range(2):
+        rc = fn()
+        assert rc in (0, None), f"launch failed with status {rc}"      # a refused launch must not be timed as a fast one
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()
     for _ in range(reps): fn()

@@ -234,7 +234,7 @@ int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
  * NAF_NORM_CHUNK floats; n_partials = ceil(n / NAF_NORM_CHUNK). If step_dev != NULL also does *step_dev += 1
  * (the optimizer step count the following naf_adam_polyak_fused reads). */
 #define NAF_NORM_CHUNK 4096
-#define NAF_MAX_NORM_PARTIALS 256 /* naf_adam_polyak_fused accepts at most this many partials */
+#define NAF_MAX_NORM_PARTIALS 256 /* naf_adam_polyak_fused prefetches this many partials; more are accepted */
 int naf_grad_norm_partials(const float* g, size_t n, float* partials, int32_t* step_dev, void* stream);
 /* second half of clip_grad_norm_ + Adam.step() (naf_algorithm.py:209-210) + soft_update (:217-226) in one
  * pass over {theta, g, m, v, theta_target}: 36 B/param. `partials`: sums of squares covering every gradient element once

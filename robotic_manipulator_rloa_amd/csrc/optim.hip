@@ -117,6 +117,8 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NAF_MAX_NORM_PARTIALS / 64; ++j) s += ((int)threadIdx.x + 64 * j < n_partials) ? pr[j] : 0.f;
+        // more partials than were prefetched (flat buffers beyond 1M parameters): the rest in the same lane-major order
+        for (int k = (int)threadIdx.x + NAF_MAX_NORM_PARTIALS; k < n_partials; k += 64) s += partials[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (threadIdx.x == 0) {
@@ -170,9 +172,7 @@ extern "C" int naf_adam_polyak_fused(float* theta, const float* g, float* m, flo
                                      const float* partials, int n_partials, float max_norm, float lr, float beta1,
                                      float beta2, float eps, float tau, float one_minus_tau, const int32_t* step_dev,
                                      float inv_world, size_t n, void* stream) {
-    if (!theta || !g || !m || !v || !partials || !step_dev || n < 4 || n_partials <= 0 ||
-        n_partials > NAF_MAX_NORM_PARTIALS)
-        return NAF_ERR_ARG;
+    if (!theta || !g || !m || !v || !partials || !step_dev || n < 4 || n_partials <= 0) return NAF_ERR_ARG;
     if ((((uintptr_t)theta | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)theta_target) & 15) != 0)
         return NAF_ERR_ARG;
     size_t n4 = (n + 3) / 4;
