@@ -8,7 +8,9 @@ from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
 from robotic_manipulator_rloa_amd._lib import ptr, stream_ptr, check
 
 def timeit(fn, n=200):
-    for _ in range(5): fn()
+    for _ in range(5):
+        rc = fn()
+        assert not isinstance(rc, int) or rc == 0, f"launch refused with status {rc}"
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):

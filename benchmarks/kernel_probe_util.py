@@ -4,7 +4,8 @@ import torch
 def timeit(fn, n=200):
     """µs per call of fn replayed n times back to back inside one hipGraph."""
     for _ in range(5):
-        fn()
+        rc = fn()
+        assert not isinstance(rc, int) or rc == 0, f"launch refused with status {rc}"   # never time a refused launch
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
