@@ -75,6 +75,9 @@ int naf_replay_row_off_next_state(int S, int A);
  *          zero-initialised by the caller. */
 int naf_replay_create(uint64_t capacity, int S, int A, float* rows, uint64_t* meta, naf_replay_t** out);
 int naf_replay_destroy(naf_replay_t* h);
+/* replaces ReplayBuffer.__len__ (replay_buffer.py:69-75): current fill, read back from the device. The ONLY entry point
+ * that synchronises `stream` (the Python host keeps its own count and never calls it on the hot path). */
+int naf_replay_size(naf_replay_t* h, uint64_t* size_out /* host */, void* stream);
 /* replaces ReplayBuffer.add (replay_buffer.py:32-45) for n transitions at once: FIFO append with
  * eviction of the oldest when full. `src_rows`: n packed transition rows on the device. n <= capacity. */
 int naf_replay_add_batch(naf_replay_t* h, const float* src_rows, int n, void* stream);

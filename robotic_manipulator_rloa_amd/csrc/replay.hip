@@ -55,6 +55,15 @@ extern "C" int naf_replay_destroy(naf_replay_t* h) {
     return NAF_OK;
 }
 
+extern "C" int naf_replay_size(naf_replay_t* h, uint64_t* size_out, void* stream) {
+    if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
+    if (!size_out) return NAF_ERR_ARG;
+    // the one entry point that waits: the fill level lives on the device (appends are asynchronous)
+    hipError_t e = hipMemcpyAsync(size_out, &h->meta[META_SIZE], sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? NAF_OK : (int)e;
+}
+
 // ------------------------------------------------------------------------------------------------
 // add: scatter n packed rows to ring positions (head + i) mod capacity, then advance {head,size,total}
 // ------------------------------------------------------------------------------------------------

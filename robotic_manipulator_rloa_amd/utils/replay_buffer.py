@@ -164,6 +164,12 @@ class ReplayBuffer:
         actions = u.long() if self.action_mode == _lib.ACTION_TRUNC_INT else u
         return s, actions, r, s2, d
 
+    def device_len(self) -> int:
+        """Fill level as the device sees it (blocking; __len__ is the host-side count and never synchronises)."""
+        out = _lib.C.c_uint64()
+        check(self.lib.naf_replay_size(self.handle, _lib.C.byref(out), stream_ptr()), "naf_replay_size")
+        return int(out.value)
+
     def bad_index_count(self) -> int:
         return int(self.meta[7].item())
 

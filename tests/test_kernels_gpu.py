@@ -102,6 +102,8 @@ def test_replay_sample_api_contract_matches_reference_golden(lib):
         s[0] = float(i)
         buf.add(s, ac[i], float(rw[i]), ns[i].astype(np.float64), int(dn[i]))
     assert len(buf) == cap
+    buf.flush()
+    assert buf.device_len() == cap                  # naf_replay_size: the fill level as the device holds it
     pos = torch.from_numpy(g["positions_from_range"][0].astype(np.int32))
     s, a, r, s2, d = buf.sample(idx=pos)
     assert [str(t.dtype) for t in (s, a, r, s2, d)] == list(g["dtypes"])
