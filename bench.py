@@ -9,24 +9,77 @@ truncated actions = the reference's semantics. One "step" = one vector-env step 
 The simulator is the on-device synthetic stand-in (PyBullet is not installable here) — labelled in `data`.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, gradients all-reduced over RCCL each update)
+
+N > 1: one rank per GPU, gradients all-reduced once per update (one-shot peer-memory exchange over xGMI, RCCL as the
+fallback). Launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) — or plainly as `python bench.py --gpus N`: without WORLD_SIZE this process touches no
+GPU, starts that launcher as a child process, relays its output and exits with its code.
 
 Prints ONE JSON line (rank 0). `value` = env-steps/s summed over all ranks (= learn() updates/s).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000, help="timed vector steps (4000 x 64 updates: about 10 s)")
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--buffer", type=int, default=1_000_000)
+    ap.add_argument("--p-mode", choices=["hadamard", "matmul"], default="hadamard")
+    ap.add_argument("--robot", choices=["kuka", "xarm6", "panda"], default="kuka",
+                    help="shapes only: kuka/xarm6 S=21 A=6, panda S=23 A=7 (BASELINE configs[3], [4])")
+    ap.add_argument("--obstacle-jitter", type=float, default=0.0, help="per-env obstacle randomisation (configs[3])")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the host-vector-env and reference-API-path measurements (extra keys, outside `value`)")
+    ap.add_argument("--roofline-ring", type=int, default=4_000_000,
+                    help="rows of the ring the bulk gather roofline runs on (4e6 x 256 B = 1.02 GB: beyond the 256 MiB "
+                         "Infinity Cache, BASELINE configs[4]'s ring); 0 = skip")
+    ap.add_argument("--roofline-rows", type=int, default=1 << 22, help="rows gathered per bulk launch")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start torch.distributed.run as a CHILD process
+    (this parent has made no HIP call: counting devices does not initialise the GPU on this image) and hand back its
+    exit code. The ranks print; rank 0's JSON line is the last line of stdout."""
+    import torch
+    have = torch.cuda.device_count()
+    rehearsal = os.environ.get("NAF_BENCH_REHEARSAL") == "1"
+    if have < args.gpus and not rehearsal:
+        print(f"[bench] --gpus {args.gpus} but this host shows {have} GPU(s). Refusing to report a {args.gpus}-GPU number "
+              f"from fewer devices (NAF_BENCH_REHEARSAL=1 runs every rank on cuda:0 to exercise the N > 1 code path; "
+              f"its line is labelled, never a measurement).", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
 
 def synth_rows(n, S, A, row_floats, off_s2, seed, device):
     """Transition rows of the BASELINE value ranges, generated on the device."""
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     rows = torch.zeros(n, row_floats, device=device)
@@ -49,30 +102,23 @@ def synth_rows(n, S, A, row_floats, off_s2, seed, device):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1500)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--buffer", type=int, default=1_000_000)
-    ap.add_argument("--p-mode", choices=["hadamard", "matmul"], default="hadamard")
-    ap.add_argument("--robot", choices=["kuka", "xarm6", "panda"], default="kuka",
-                    help="shapes only: kuka/xarm6 S=21 A=6, panda S=23 A=7 (BASELINE configs[3], [4])")
-    ap.add_argument("--obstacle-jitter", type=float, default=0.0, help="per-env obstacle randomisation (configs[3])")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}, or "
+                         f"plain `python bench.py --gpus {args.gpus}`, which starts that launcher itself)")
     # NAF_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo as the control plane — the N > 1 code path of this file on
     # a 1-GPU box (RCCL refuses two ranks on one device). Never a measurement; the JSON line says so.
     rehearsal = os.environ.get("NAF_BENCH_REHEARSAL") == "1" and world > 1
+    if world > 1 and not rehearsal and torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPU(s) visible")
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -130,31 +176,27 @@ def main():
     for _ in range(args.warmup):
         one_step()
     # ---- timed region: exactly K steps between barrier + synchronize on both sides -------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    ev0 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    n_ev = min(args.steps, 512)          # the live gather launch is bracketed by HIP events on the first n_ev steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        chunk.gather_events, chunk.empty_events = ev[k], ev0[k]
+        chunk.gather_events = ev[k] if k < n_ev else None
         one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    chunk.gather_events = chunk.empty_events = None
+    chunk.gather_events = None
     t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    gather_bracket_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    # what an EMPTY event bracket reads on this stream: the part of every bracket that is not the kernel. Recorded in the
-    # timed loop itself, right behind each gather bracket (same stream, same surroundings), averaged the same way
-    event_overhead_ms = sum(a.elapsed_time(b) for a, b in ev0) / len(ev0)
-    gather_ms = max(gather_bracket_ms - event_overhead_ms, 1e-6)
+    gather_bracket_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
     finite = bool(torch.isfinite(L.theta2).all().item())
     bad = replay.bad_index_count()
@@ -162,21 +204,25 @@ def main():
     updates = args.steps * U * world
     value = env_steps / elapsed
 
+    is_cfg1 = (args.robot, B, N, E) == ("kuka", 256, 1000000, 64)
     out = {
         "metric": "env-steps/s (= learn() updates/s at update_freq=1,num_updates=1), KUKA 6-DoF NAF batch=256",
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (on-device kinematic stand-in env; replay pre-filled "
         "with synthetic transitions; random-init weights, seed 0)",
-        "config": {"workload": f"{'configs[1]: ' if (args.robot, B, N, E) == ('kuka', 256, 1000000, 64) else ''}{args.robot} shapes "
+        "config": {"workload": f"{'configs[1]: ' if is_cfg1 else ''}{args.robot} shapes "
                                f"S={S} A={A} H=256, {E} envs/GPU, batch {B}, HBM replay {N}, "
                                f"HIP NAF head ({args.p_mode} P), {U} learn() per vector step",
                    "launch": graph_note + (" [REHEARSAL: all ranks share cuda:0, not a measurement]" if rehearsal else ""),
                    "parallelism": f"dp{world}" if world > 1 else "single",
+                   "fused_kernels": ",".join(sorted(L.fuse)),
                    "grad_exchange": ("none" if world == 1 else
                                      "one-shot peer-memory all-reduce over xGMI (csrc/xgmi_reduce.hip)" if L.xgmi is not None
                                      else "RCCL all-reduce")},
         "updates_per_s": round(updates / elapsed, 1),
+        "us_per_update": round(1e6 * elapsed / (args.steps * U), 3),
+        "timed_seconds": round(elapsed, 3),
         "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": int(L.step_dev.item())},
     }
     if L.xgmi is not None:
@@ -188,21 +234,24 @@ def main():
         every = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(every, chk)
         out["sanity"]["replicas_identical"] = all(bool(torch.equal(e, every[0])) for e in every)
-    # ---- roofline of the replay gather (the kernel north_star names), measured live with events -----------
-    rows_per_launch = U * B
-    alg_bytes = rows_per_launch * (4 * (2 * S + A + 2) * 2 + 4)       # 400 B/row read+written + 4 B index
-    out["roofline"] = {"kernel": "replay_gather_rows_kernel", "bound": "hbm",
-                       "achieved": round(alg_bytes / (gather_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                       "frac": round(alg_bytes / (gather_ms * 1e-3) / 8e12, 4), "traffic": None,
-                       "rows_per_launch": rows_per_launch, "alg_bytes_per_launch": alg_bytes,
-                       "avg_launch_ms": round(gather_ms, 5), "avg_event_bracket_ms": round(gather_bracket_ms, 5),
-                       "empty_event_bracket_ms": round(event_overhead_ms, 5),
-                       "note": "one launch per vector step inside the timed loop, bracketed by HIP events on its stream; "
-                               "avg_launch_ms = bracket - empty bracket (an empty bracket is recorded right behind every gather bracket, inside the timed loop); rocprofv3 --kernel-trace average of the same "
-                               "command: profiles/r01_bench_kernel_stats.csv (replay_gather_rows_kernel<1, 0>)"}
-    out["roofline"]["traffic"] = pmc_traffic(rows_per_launch)
-    if rank == 0 and world == 1:
-        out["roofline_bulk"] = bulk_gather(replay, dev)
+    # ---- roofline of the replay gather (the kernel north_star names) ---------------------------------------
+    # headline: a launch big enough to be bandwidth-bound, on a ring bigger than the Infinity Cache. HIP events on the
+    # stream the kernel is launched on, around `reps` back-to-back launches; profiles/ holds the rocprofv3 kernel-trace
+    # stats of this very command, whose average for the same kernel instance must agree.
+    row_alg = 4 * (2 * S + A + 2) * 2 + 4                     # 400 B/row read+written + 4 B index
+    if rank == 0 and args.roofline_ring > 0:
+        del loop, chunk
+        out["roofline"] = bulk_gather_roofline(S, A, args.roofline_ring, args.roofline_rows, dev, row_alg)
+    # the launch that sits in the timed loop (one per vector step, U*B rows): latency, not bandwidth — reported as the
+    # RAW event bracket (an empty bracket reads ~5 us on this stream, so this overstates the kernel; the profiler's
+    # kernel-trace average is the number to quote for it)
+    rows_live = U * B
+    out["roofline_live"] = {"kernel": "replay_gather_rows_kernel<1, 0, W4>", "rows_per_launch": rows_live,
+                            "alg_bytes_per_launch": rows_live * row_alg,
+                            "avg_event_bracket_ms": round(gather_bracket_ms, 5),
+                            "achieved": round(rows_live * row_alg / (gather_bracket_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                            "frac": round(rows_live * row_alg / (gather_bracket_ms * 1e-3) / (PEAK_HBM_GBPS * 1e9), 4),
+                            "note": "latency-bound launch (6.6 MB); raw HIP-event bracket, no overhead subtracted"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.torch_cpu_port import time_baseline
         # the reference path is dispatch-bound (~1400 aten calls per update): more threads do not help and torch's
@@ -220,45 +269,140 @@ def main():
                                          f"steps/s by thread count {cb['other']}",
                                "learn_only_updates_per_s": round(cb["learn_updates_per_s"], 2)}
         out["speedup_vs_cpu_port"] = round(value / cb["steps_per_s"], 1)
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            out.update(extras(dev, args))
+        except Exception as e:                                   # extra keys never cost the headline line
+            out["extras_error"] = f"{type(e).__name__}: {e}"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def pmc_traffic(rows_per_launch):
-    """HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/gather_traffic.json (FETCH_SIZE doubled
-    per the gfx950 correction + WRITE_SIZE); None when no pass was recorded for this launch size."""
+def pmc_traffic(rows_per_launch, ring_rows):
+    """HBM bytes per launch as RECORDED by separate rocprofv3 --pmc passes over this command (FETCH_SIZE doubled per the
+    gfx950 correction + WRITE_SIZE; profiles/gather_traffic.json names the CSVs). Not measurable from inside the run:
+    None when no pass was recorded for this launch shape."""
     try:
         with open(os.path.join(ROOT, "profiles", "gather_traffic.json")) as f:
             for rec in json.load(f)["launches"]:
-                if rec["rows_per_launch"] == rows_per_launch:
-                    return int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024)
+                if rec["rows_per_launch"] == rows_per_launch and rec.get("ring_rows") == ring_rows:
+                    return int((2 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024), rec.get("source")
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
 
 
-def bulk_gather(replay, dev, n_rows=1 << 22, reps=20):
-    """The same gather kernel on a launch big enough to be bandwidth- instead of latency-bound: 4 Mi uniformly
-    random rows (1.07 GB of row traffic per launch) out of the 1e6-row (256 MB) ring."""
-    idx = torch.randint(0, len(replay), (n_rows,), device=dev, dtype=torch.int32)
-    out = torch.empty(n_rows, replay.row_floats, device=dev)
+def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
+    """replay_gather_rows_kernel<4, 2, W4> (the bulk instance: 4 float4 in flight per lane, nontemporal stores): n_rows
+    uniformly random positions out of a full ring of `ring_rows` 256-B rows, gathered into packed minibatch rows."""
+    import torch
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    ring = ReplayBuffer(ring_rows, 256, dev, seed=5, state_size=S, action_size=A)
+    rows = synth_rows(ring_rows, S, A, ring.row_floats, ring.off_s2, seed=99, device=dev)
+    ring.add_rows_device(rows, ring_rows)
+    del rows
+    brf = ring.batch_row_floats
+    idx = torch.randint(0, ring_rows, (n_rows,), device=dev, dtype=torch.int32)
+    out = torch.empty(n_rows, brf, device=dev)
     for _ in range(3):
-        replay.gather_rows(idx, out, n_rows)
+        ring.gather_rows(idx, out, n_rows)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
     a.record()
     for _ in range(reps):
-        replay.gather_rows(idx, out, n_rows)
+        ring.gather_rows(idx, out, n_rows)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / reps
-    alg = n_rows * (4 * (2 * replay.S + replay.A + 2) * 2 + 4)
-    phys = n_rows * (replay.row_floats * 4 * 2 + 4)
-    return {"kernel": "replay_gather_rows_kernel", "rows_per_launch": n_rows, "avg_launch_ms": round(ms, 4),
-            "traffic": pmc_traffic(n_rows), "alg_bytes_per_launch": alg,
-            "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 8e12, 4),
-            "physical_GBps": round(phys / (ms * 1e-3) / 1e9, 1)}
+    bad = ring.bad_index_count()
+    alg = n_rows * row_alg
+    phys = n_rows * (ring.row_floats * 4 + brf * 4 + 4)
+    traffic, source = pmc_traffic(n_rows, ring_rows)
+    w4 = brf // 4
+    return {"kernel": f"replay_gather_rows_kernel<4, 2, {w4}>", "bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1),
+            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / (PEAK_HBM_GBPS * 1e9), 4),
+            "traffic": traffic, "traffic_source": source, "rows_per_launch": n_rows, "alg_bytes_per_launch": alg,
+            "alg_bytes_per_row": row_alg, "physical_bytes_per_launch": phys, "avg_launch_ms": round(ms, 5),
+            "launches_timed": reps, "ring_rows": ring_rows, "ring_bytes": ring_rows * ring.row_floats * 4,
+            "infinity_cache_assisted": ring_rows * ring.row_floats * 4 <= 256 * 2 ** 20, "bad_indices": bad,
+            "physical_GBps": round(phys / (ms * 1e-3) / 1e9, 1),
+            "note": "HIP events around back-to-back launches on the launching stream; achieved = algorithmic bytes "
+                    "(404 B/row at S=21/A=6) / average launch time. The ring row is padded 200 -> 256 B (two whole "
+                    "lines per random row), the gathered row 200 -> 208 B: physical/algorithmic = 1.16, so frac <= 0.68 "
+                    "of the 6.3 TB/s a streaming copy reaches on this chip"}
+
+
+def extras(dev, args):
+    """Measurements outside `value`: (i) the host vector env — E=64 environments in worker
+    processes around the GPU learner, synchronous and asynchronous policy; (ii) the reference-API path — one host env,
+    NAFAgent.act / env.step / NAFAgent.step per timestep at configs[0]'s B=64 / N=1e5 — beside the CPU port at the same
+    B / N. The env is the synthetic kinematic stand-in (no PyBullet in the image)."""
+    import logging
+    import tempfile
+    import torch
+    from functools import partial
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
+    from robotic_manipulator_rloa_amd.environment.vector_env import HostVectorEnv
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    logging.getLogger('robotic_manipulator_rloa.utils.logger').setLevel(40)
+    res = {}
+    old = os.getcwd()
+    os.chdir(tempfile.mkdtemp(prefix="naf_bench_"))
+    try:
+        S, A, E = 21, 6, 64
+        # (ii) reference-API path, configs[0] shape
+        env = SyntheticEnvironment(A)
+        agent = NAFAgent(env, S, A, 256, 64, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, dev, 0)
+        state = env.reset(False)
+
+        def steps(n, state):
+            for _ in range(n):
+                a = agent.act(state)
+                nxt, r, d = env.step(a)
+                agent.step(state, a, r, nxt, d)
+                state = env.reset(False) if d else nxt
+            return state
+        state = steps(300, state)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_api = 3000
+        state = steps(n_api, state)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res["reference_api_path"] = {"value": round(n_api / dt, 1), "unit": "timesteps/s",
+                                     "what": "NAFAgent.act + env.step + NAFAgent.step (add, sample, learn) per timestep, one "
+                                             "host env (numpy stand-in), B=64, N=1e5 (configs[0] shape), naf_algorithm.py:249-261",
+                                     "timesteps": n_api}
+        if not args.no_cpu_baseline:
+            from oracle.torch_cpu_port import time_baseline
+            cb = time_baseline(S, A, 256, 64, 100000, budget_s=6.0, threads=8)
+            res["reference_api_path"]["cpu_port_same_shape"] = {"value": round(cb["steps_per_s"], 1), "unit": "timesteps/s",
+                                                                "cores": cb["threads"], "env": "none (agent only)"}
+        del agent
+        # (i) host vector env: 64 envs in worker processes (PyBullet would need one per process; the light stand-in
+        # shares workers), B=256, ring 1e5 pre-filled past the `len > batch` gate by the first vector steps
+        workers = max(1, min(E, (os.cpu_count() or 8) // 2))
+        per = (E + workers - 1) // workers
+        hv = {}
+        for mode in (False, True):
+            agent = NAFAgent(None, S, A, 256, 256, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, dev, 0)
+            vec = HostVectorEnv(partial(SyntheticEnvironment, A), E, S, A, envs_per_worker=per, max_frames=400, seed=1)
+            try:
+                agent.run_host_vectorized(vec, 20, async_policy=mode)               # fills 1280 rows, captures graphs
+                r = agent.run_host_vectorized(vec, 150, async_policy=mode)
+            finally:
+                vec.close()
+            hv["async_policy" if mode else "sync_policy"] = round(r["env_steps_per_s"], 1)
+            del agent
+        res["host_vector_env"] = {"unit": "env-steps/s", **hv, "envs": E, "worker_processes": (E + per - 1) // per,
+                                  "what": "NAFAgent.run_host_vectorized: batched act() on the GPU -> E host envs step in "
+                                          "worker processes (shared memory) -> E rows over PCIe -> HBM ring -> E learn() "
+                                          "updates; env = numpy kinematic stand-in (PyBullet absent: labelled, N2)"}
+    finally:
+        os.chdir(old)
+    return res
 
 
 if __name__ == "__main__":

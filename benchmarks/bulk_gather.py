@@ -14,7 +14,7 @@ for lo in range(0, N, 1 << 20):
     n = min(1 << 20, N - lo)
     buf.add_rows_device(torch.randn(n, 64, device="cuda"), n)
 idx = torch.randint(0, N, (M,), device="cuda", dtype=torch.int32)
-out = torch.empty(M, 64, device="cuda")
+out = torch.empty(M, buf.batch_row_floats, device="cuda")   # packed minibatch rows
 def measure():
     for _ in range(2):
         buf.gather_rows(idx, out, M)
@@ -31,6 +31,6 @@ if os.environ.get("NAF_AB_NT") == "1":       # interleaved A/B of the nontempora
             print(f"  nt={nt}: {measure():.4f} ms")
     buf.lib.naf_debug_set(1, -1)
 ms = measure()
-alg = M * (200 + 200 + 4); phys = M * (256 + 256 + 4)   # 4*(2S+A+2) B read + the same written per row
+alg = M * (200 + 200 + 4); phys = M * (256 + buf.batch_row_floats * 4 + 4)   # 4*(2S+A+2) B read + the same written per row
 print(f"ring {N} rows ({N*256/2**20:.0f} MiB), {M} rows/launch: {ms:.4f} ms  algorithmic {alg/ms/1e6:.1f} GB/s ({alg/ms/1e6/8000:.3f} of 8 TB/s)  "
       f"physical {phys/ms/1e6:.1f} GB/s; alg bytes/launch {alg}, physical {phys}")

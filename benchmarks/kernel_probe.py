@@ -52,7 +52,7 @@ tests["torch mm dA1"] = lambda: torch.mm(L.dZ2, L.W2_main, out=L.dA1)
 tests["torch mm dWh"] = lambda: torch.mm(L.dH.t(), L.A2[0], out=L.gWh)
 buf = ReplayBuffer(1_000_000, B, "cuda", 0, state_size=21, action_size=6)
 buf.add_rows_device(torch.randn(1_000_000, 64, device="cuda"), 1_000_000)
-idx = torch.randint(0, 1_000_000, (64, B), device="cuda", dtype=torch.int32); out = torch.empty(64*B, 64, device="cuda")
+idx = torch.randint(0, 1_000_000, (64, B), device="cuda", dtype=torch.int32); out = torch.empty(64*B, buf.batch_row_floats, device="cuda")
 tests["sample 64xB"] = lambda: buf.sample_indices(idx, 64)
 tests["gather 64xB rows"] = lambda: buf.gather_rows(idx, out, 64*B)
 L.step_dev.fill_(1)

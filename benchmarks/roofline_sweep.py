@@ -34,7 +34,7 @@ for lo in range(0, N, 1 << 20):
     buf.add_rows_device(torch.randn(n, 64, device=dev), n)
 for M in (256, 16384, 65536, 1 << 20, 1 << 22, 1 << 24):
     idx = torch.randint(0, N, (M,), device=dev, dtype=torch.int32)
-    out = torch.empty(M, 64, device=dev)
+    out = torch.empty(M, buf.batch_row_floats, device=dev)
     t = timed(lambda: buf.gather_rows(idx, out, M), 200 if M <= 65536 else 10)
     alg = M * 404
     print(f"| replay_gather_rows (ring 4e6 rows = 977 MiB) | {M} rows | {alg/1e6:.2f} MB | {t*1e6:.1f} us | {alg/t/1e9:.0f} GB/s | {alg/t/8e12:.3f} |")

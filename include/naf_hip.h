@@ -21,7 +21,8 @@
  *   - "transition row" = [state(S) | action(A) | reward | 0-pad | next_state(S) | done | 0-pad]: next_state starts
  *     at naf_replay_row_off_next_state(S,A) = round_up(S+A+1, 4) floats (16-byte aligned, = 28 at S=21/A=6, 32 at
  *     S=23/A=7), done follows it; rows are padded to naf_replay_row_floats(S,A) floats (64 for A<=8: 256 B = two
- *     128-B lines). This is the layout of both the HBM ring and of gathered minibatches.
+ *     128-B lines) in the HBM ring; gathered minibatches keep the same offsets inside a row and drop the tail padding
+ *     (row stride naf_replay_batch_row_floats(S,A) or anything up to the ring's).
  */
 #ifndef NAF_HIP_H
 #define NAF_HIP_H
@@ -60,6 +61,9 @@ typedef struct {
 } naf_xgmi_push_t;
 
 /* ---- library ------------------------------------------------------------------------------ */
+/* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
+ * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
+#define NAF_HIP_ABI_VERSION 2
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -88,8 +92,12 @@ int naf_replay_add_batch(naf_replay_t* h, const float* src_rows, int n, void* st
 int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const uint64_t* counter_dev, uint64_t counter_off,
                               int32_t* idx, int B, int n_batches, int without_replacement, void* stream);
 /* replaces the np.stack/vstack + from_numpy + .to(device) chain (replay_buffer.py:57-65):
- * out_rows[n][row_floats] = ring[deque position idx[i]], actions truncated when action_mode == TRUNC_INT. */
-int naf_replay_gather_rows(naf_replay_t* h, const int32_t* idx, float* out_rows, int n, int action_mode,
+ * out_rows[n][out_ld] = the leading out_ld floats of ring[deque position idx[i]], actions truncated when
+ * action_mode == TRUNC_INT. out_ld: a multiple of 4 between round_up(used floats, 4) and naf_replay_row_floats;
+ * naf_replay_batch_row_floats(S, A) is the minibatch row the learner kernels expect at least (52 floats at S=21/A=6,
+ * 56 at S=23/A=7: no padding to whole 128-B lines on the output side). */
+int naf_replay_batch_row_floats(int S, int A);
+int naf_replay_gather_rows(naf_replay_t* h, const int32_t* idx, float* out_rows, int n, int out_ld, int action_mode,
                            void* stream);
 /* same, to the reference's five separate tensors (states[n,S], actions[n,A], rewards[n], next_states[n,S],
  * dones[n]) — the ReplayBuffer.sample() return contract (replay_buffer.py:67). */

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 import shutil
 import subprocess
 from typing import Optional
@@ -38,23 +39,68 @@ def _stale() -> bool:
     return False
 
 
+def header_abi_version() -> int:
+    """NAF_HIP_ABI_VERSION as include/naf_hip.h states it (the header is the contract; the library must answer the same)."""
+    with open(os.path.join(CSRC, HEADERS[-1])) as f:
+        m = re.search(r"^#define\s+NAF_HIP_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    if not m:
+        raise NafHipError("include/naf_hip.h does not define NAF_HIP_ABI_VERSION")
+    return int(m.group(1))
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip into csrc/libnaf_hip.so for gfx950. Returns the library path."""
+    """Compile csrc/*.hip into csrc/libnaf_hip.so for gfx950. Returns the library path.
+    Safe with several processes importing at once (every rank of a torch.distributed.run launch): one of them builds
+    under an exclusive file lock into a temporary name of its own, the others wait for the lock and find the library
+    fresh."""
     if not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise NafHipError("hipcc not found: cannot build libnaf_hip.so")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-variable", "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
-    if os.environ.get("NAF_BUILD_DEFINES"):          # tile-shape experiments (benchmarks/): e.g. "-DFT_TX=4"
-        cmd[1:1] = os.environ["NAF_BUILD_DEFINES"].split()
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise NafHipError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():           # another process built it while this one waited
+                return LIB_PATH
+            tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+            flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable"]
+            if os.environ.get("NAF_BUILD_DEFINES"):  # tile-shape experiments (benchmarks/): e.g. "-DFT_TX=4"
+                flags += os.environ["NAF_BUILD_DEFINES"].split()
+            # one object per source (csrc/build/, keyed by the flags), compiled in parallel and only when the source
+            # or a header is newer: an edit of one kernel file rebuilds in seconds instead of a minute
+            import hashlib
+            from concurrent.futures import ThreadPoolExecutor
+            objdir = os.path.join(CSRC, "build", hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10])
+            os.makedirs(objdir, exist_ok=True)
+            hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+            def compile_one(src):
+                obj = os.path.join(objdir, src.replace(".hip", ".o"))
+                sp = os.path.join(CSRC, src)
+                if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(sp)):
+                    return obj, None
+                cmd = [hipcc] + flags + ["-c", sp, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                return obj, (None if r.returncode == 0 else r.stdout + r.stderr)
+
+            with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+                results = list(ex.map(compile_one, SOURCES))
+            errs = [e for _, e in results if e]
+            if errs:
+                raise NafHipError("hipcc failed:\n" + "\n".join(errs))
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [o for o, _ in results],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise NafHipError("hipcc (link) failed:\n" + r.stdout + r.stderr)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -74,7 +120,8 @@ _PROTOS = {
     "naf_replay_size": [_vp, C.POINTER(_u64), _vp],
     "naf_replay_add_batch": [_vp, _vp, _i, _vp],
     "naf_replay_sample_indices": [_vp, _u64, _vp, _u64, _vp, _i, _i, _i, _vp],
-    "naf_replay_gather_rows": [_vp, _vp, _vp, _i, _i, _vp],
+    "naf_replay_batch_row_floats": [_i, _i],
+    "naf_replay_gather_rows": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "naf_replay_gather_soa": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "naf_counter_add": [_vp, _u64, _vp],
     "naf_head_fwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
@@ -143,11 +190,7 @@ def load(allow_build: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     if _stale() and allow_build:
-        try:
-            build_library()
-        except NafHipError:
-            if not os.path.exists(LIB_PATH):
-                raise
+        build_library()          # a failed build raises: a stale library is never loaded silently behind it
     if not os.path.exists(LIB_PATH):
         raise NafHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
                           "This package has no CPU fallback.")
@@ -160,8 +203,10 @@ def load(allow_build: bool = True) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    if lib.naf_hip_abi_version() != 1:
-        raise NafHipError("libnaf_hip.so ABI version mismatch")
+    want = header_abi_version()
+    if lib.naf_hip_abi_version() != want:
+        raise NafHipError(f"libnaf_hip.so answers ABI version {lib.naf_hip_abi_version()}, include/naf_hip.h says {want}: "
+                          "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

@@ -2,5 +2,5 @@
 #include "common.h"
 #include "../../include/naf_hip.h"
 
-extern "C" int naf_hip_abi_version(void) { return 1; }
+extern "C" int naf_hip_abi_version(void) { return NAF_HIP_ABI_VERSION; }
 extern "C" const char* naf_hip_arch(void) { return "gfx950"; }

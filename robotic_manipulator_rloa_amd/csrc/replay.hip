@@ -252,68 +252,78 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
 }
 
 // ------------------------------------------------------------------------------------------------
-// gather (row layout): 2^k lanes x float4 per 256-B row, ROWS_PER_THREAD independent rows per lane so
-// several index->row dependent loads are in flight per lane. Algorithmic traffic: 4*(2S+A+2) B read +
-// the same written per row (400 B at S=21/A=6); physical: 2 x row_floats*4 B.
+// gather (row layout). The OUTPUT is a dense stream of float4: minibatch rows are `out_ld` floats apart (out_ld =
+// naf_replay_batch_row_floats: 52 at S=21/A=6, 56 at S=23/A=7 — the row without the ring's padding to two whole
+// 128-B lines), so output float4 j belongs to row j / W4, column j % W4 (W4 = out_ld / 4). One lane per output
+// float4, RPT of them in flight per lane: stores are perfectly coalesced (consecutive lanes, consecutive 16 B), the
+// W4 lanes of a row read the leading W4 * 16 B of its 256-B ring row. Nothing is written that the learner does not
+// read: the first version copied whole padded rows (physical traffic 512 B/row against 400 algorithmic = 1.28x); now
+// 256 B read (the row's two lines) + 208 B written = 1.15x.
+// Algorithmic traffic: 4*(2S+A+2) B read + the same written per row (400 B at S=21/A=6) + 4 B of index.
 // ------------------------------------------------------------------------------------------------
 typedef float nt_f4 __attribute__((ext_vector_type(4)));   // native vector type the nontemporal builtins accept
 
-template <int RPT, int NT /* bit 0: nontemporal loads, bit 1: nontemporal stores */>
+template <int RPT, int NT /* bit 0: nontemporal loads, bit 1: nontemporal stores */, int W4C /* 0 = run-time width */>
 __global__ __launch_bounds__(256) void replay_gather_rows_kernel(const float4* __restrict__ ring,
                                                                  uint64_t* __restrict__ meta,
                                                                  const int32_t* __restrict__ idx,
                                                                  float4* __restrict__ out, int n, uint64_t cap,
-                                                                 int rf4_shift, int trunc_lo, int trunc_hi) {
+                                                                 int rf4_shift, int w4_rt, int trunc_lo, int trunc_hi) {
     const uint64_t head = meta[META_HEAD];
     const uint64_t size = meta[META_SIZE];
     const uint64_t base = head + cap - size;  // physical position of deque element 0 (oldest)
-    const int rf4 = 1 << rf4_shift;
-    const int lanes_per_block_rows = blockDim.x >> rf4_shift;  // rows handled per block per pass
-    const int c = threadIdx.x & (rf4 - 1);
-    const int rl = threadIdx.x >> rf4_shift;
-    const int64_t row0 = ((int64_t)blockIdx.x * RPT) * lanes_per_block_rows + rl;
-    int64_t pos[RPT];
+    const unsigned w4 = W4C ? (unsigned)W4C : (unsigned)w4_rt;
+    const int64_t total = (int64_t)n * w4;    // float4 to produce
+    const int64_t j0 = (int64_t)blockIdx.x * (256 * RPT) + threadIdx.x;
+    int64_t src[RPT];
+    int col[RPT];
     bool ok[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        int64_t r = row0 + (int64_t)k * lanes_per_block_rows;
-        ok[k] = r < n;
-        int64_t i = ok[k] ? (int64_t)idx[r] : 0;
+        const int64_t j = j0 + (int64_t)k * 256;
+        ok[k] = j < total;
+        const unsigned jj = ok[k] ? (unsigned)j : 0u;       // total < 2^31 (checked on the host)
+        const unsigned r = jj / w4;
+        col[k] = (int)(jj - r * w4);
+        int64_t i = (int64_t)idx[r];
         if (ok[k] && (i < 0 || (uint64_t)i >= size)) {
-            if (c == 0) atomicAdd((unsigned long long*)&meta[META_BAD_IDX], 1ull);
+            if (col[k] == 0) atomicAdd((unsigned long long*)&meta[META_BAD_IDX], 1ull);
             i = 0;
         }
-        pos[k] = (int64_t)((base + (uint64_t)i) % cap);
+        // one wrap at most: base < 2 cap and i < size <= cap (a 64-bit modulo here is ~40 instructions per lane)
+        uint64_t pos = base + (uint64_t)i;
+        pos = pos >= cap ? pos - cap : pos;
+        pos = pos >= cap ? pos - cap : pos;
+        src[k] = (int64_t)((pos << rf4_shift) + (uint64_t)col[k]);
     }
     float4 v[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k)
-        if (ok[k]) {
-            // bulk launches (RPT > 1) stream: every ring row is touched once, nothing is re-read by this kernel
-            if (NT & 1) {
-                const nt_f4 t = __builtin_nontemporal_load((const nt_f4*)&ring[(pos[k] << rf4_shift) + c]);
-                v[k] = make_float4(t.x, t.y, t.z, t.w);
-            } else {
-                v[k] = ring[(pos[k] << rf4_shift) + c];
-            }
+    for (int k = 0; k < RPT; ++k) {
+        // unconditional (lanes beyond the end re-read row idx[0]): a branch around each load would serialise them
+        if (NT & 1) {
+            const nt_f4 t = __builtin_nontemporal_load((const nt_f4*)&ring[src[k]]);
+            v[k] = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            v[k] = ring[src[k]];
         }
+    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         if (!ok[k]) continue;
         // `.long()` of the reference: truncate the action columns toward zero
-        int f0 = c * 4;
+        const int f0 = col[k] * 4;
         if (f0 + 3 >= trunc_lo && f0 < trunc_hi) {
             if (f0 + 0 >= trunc_lo && f0 + 0 < trunc_hi) v[k].x = truncf(v[k].x);
             if (f0 + 1 >= trunc_lo && f0 + 1 < trunc_hi) v[k].y = truncf(v[k].y);
             if (f0 + 2 >= trunc_lo && f0 + 2 < trunc_hi) v[k].z = truncf(v[k].z);
             if (f0 + 3 >= trunc_lo && f0 + 3 < trunc_hi) v[k].w = truncf(v[k].w);
         }
-        int64_t r = row0 + (int64_t)k * lanes_per_block_rows;
+        const int64_t j = j0 + (int64_t)k * 256;
         if (NT & 2) {
             nt_f4 t = {v[k].x, v[k].y, v[k].z, v[k].w};
-            __builtin_nontemporal_store(t, (nt_f4*)&out[(r << rf4_shift) + c]);
+            __builtin_nontemporal_store(t, (nt_f4*)&out[j]);
         } else {
-            out[(r << rf4_shift) + c] = v[k];        // minibatch-sized launches: the learner reads these rows next
+            out[j] = v[k];                            // minibatch-sized launches: the learner reads these rows next
         }
     }
 }
@@ -321,41 +331,66 @@ __global__ __launch_bounds__(256) void replay_gather_rows_kernel(const float4* _
 // bulk launches: cache policy of the streamed rows (bit 0 nontemporal loads, bit 1 nontemporal stores)
 int g_gather_nt = -1;   // -1 = default (nontemporal stores on bulk launches)
 
-extern "C" int naf_replay_gather_rows(naf_replay_t* h, const int32_t* idx, float* out_rows, int n, int action_mode,
-                                      void* stream) {
+extern "C" int naf_replay_batch_row_floats(int S, int A) {
+    if (S <= 0 || A <= 0) return NAF_ERR_ARG;
+    // [state | action | reward | pad | next_state | done] rounded up to whole float4, and wide enough for the layer-1
+    // kernels, which read next_state as 6 or 8 float4 (fused_layers.hip: K4 = 6 up to S = 24, 8 up to S = 32)
+    const int k4 = (S + 3) / 4;
+    const int k4d = k4 <= 6 ? 6 : (k4 <= 8 ? 8 : k4);
+    int w = naf_row_off_done(S, A) + 1;
+    const int w2 = naf_row_off_s2(S, A) + 4 * k4d;
+    w = naf_round_up(w > w2 ? w : w2, 4);
+    const int rf = naf_replay_row_floats(S, A);
+    return w < rf ? w : rf;
+}
+
+extern "C" int naf_replay_gather_rows(naf_replay_t* h, const int32_t* idx, float* out_rows, int n, int out_ld,
+                                      int action_mode, void* stream) {
     if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
     if (!idx || !out_rows || n < 0 || ((uintptr_t)out_rows & 15) != 0) return NAF_ERR_ARG;
     if (action_mode != NAF_ACTION_TRUNC_INT && action_mode != NAF_ACTION_FLOAT) return NAF_ERR_ARG;
+    // out_ld: row stride of the output = number of leading floats copied per row; whole float4, at least the used part
+    // of a row, at most the ring's row
+    if ((out_ld & 3) != 0 || out_ld < naf_round_up(naf_row_off_done(h->S, h->A) + 1, 4) || out_ld > h->row_floats)
+        return NAF_ERR_ARG;
     if (n == 0) return NAF_OK;
-    const int rf4 = h->row_floats / 4;
-    const int sh = ilog2_exact(rf4);
-    const int rows_per_pass = 256 / rf4;
+    const int w4 = out_ld / 4;
+    if ((int64_t)n * w4 >= 0x7fffffffll) return NAF_ERR_ARG;
+    const int sh = ilog2_exact(h->row_floats / 4);
     int lo = h->S, hi = h->S + h->A;
     if (action_mode == NAF_ACTION_FLOAT) lo = hi = 0x7fffffff;
     hipStream_t st = (hipStream_t)stream;
-    // small launches: 1 row per lane-group so that every CU gets a workgroup; bulk launches: 4 rows in flight
-    if ((int64_t)n <= 256 * 8 * rows_per_pass) {
-        int blocks = (n + rows_per_pass - 1) / rows_per_pass;
-        replay_gather_rows_kernel<1, 0><<<blocks, 256, 0, st>>>((const float4*)h->rows, h->meta, idx, (float4*)out_rows, n,
-                                                             h->capacity, sh, lo, hi);
+    const int64_t total = (int64_t)n * w4;
+#define GATHER_LAUNCH(RPTV, NTV, W4V)                                                                                  \
+    replay_gather_rows_kernel<RPTV, NTV, W4V><<<blocks, 256, 0, st>>>((const float4*)h->rows, h->meta, idx,            \
+                                                                      (float4*)out_rows, n, h->capacity, sh, w4, lo, hi)
+#define GATHER_W4(RPTV, NTV)                                                                                           \
+    do {                                                                                                               \
+        if (w4 == 13) GATHER_LAUNCH(RPTV, NTV, 13);                                                                    \
+        else if (w4 == 14) GATHER_LAUNCH(RPTV, NTV, 14);                                                               \
+        else if (w4 == 16) GATHER_LAUNCH(RPTV, NTV, 16);                                                               \
+        else GATHER_LAUNCH(RPTV, NTV, 0);                                                                              \
+    } while (0)
+    // small launches: one float4 per lane so that every CU gets a workgroup; bulk launches: 4 in flight per lane
+    if (total <= 256 * 8 * 256) {
+        const int blocks = (int)((total + 255) / 256);
+        GATHER_W4(1, 0);
     } else {
-        int per_block = rows_per_pass * 4;
-        int blocks = (n + per_block - 1) / per_block;
-#define GATHER_BULK(NTV)                                                                                              \
-    replay_gather_rows_kernel<4, NTV><<<blocks, 256, 0, st>>>((const float4*)h->rows, h->meta, idx, (float4*)out_rows, n, \
-                                                              h->capacity, sh, lo, hi)
+        const int blocks = (int)((total + 1023) / 1024);
         // The gathered rows are written once and not re-read by this kernel: nontemporal STORES keep them from evicting
         // ring lines (measured, 4 Mi rows per launch, interleaved A/B: 977 MiB ring 0.393 -> 0.340 ms, 244 MiB ring
         // 0.346 -> 0.300 ms). Nontemporal LOADS of the ring do not help (0.388 ms) and cost 10 % on a ring that fits the
         // 256 MiB Infinity Cache, so loads stay temporal. naf_debug_set(1, mode) overrides for A/B timing.
-        int nt = g_gather_nt < 0 ? 2 : g_gather_nt;
+        const int nt = g_gather_nt < 0 ? 2 : g_gather_nt;
         switch (nt) {
-            case 1: GATHER_BULK(1); break;
-            case 2: GATHER_BULK(2); break;
-            case 3: GATHER_BULK(3); break;
-            default: GATHER_BULK(0); break;
+            case 1: GATHER_W4(4, 1); break;
+            case 2: GATHER_W4(4, 2); break;
+            case 3: GATHER_W4(4, 3); break;
+            default: GATHER_W4(4, 0); break;
         }
     }
+#undef GATHER_W4
+#undef GATHER_LAUNCH
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -71,7 +71,11 @@ class TrainChunk:
         if replay.batch_size != B:
             raise ValueError("ReplayBuffer.batch_size must equal the learner's batch size")
         self.idx = torch.zeros(self.U, B, dtype=torch.int32, device=dev)
-        self.batch = torch.zeros(self.U, B, learner.lay.row_floats, dtype=torch.float32, device=dev)
+        # gathered minibatches: packed rows (no padding to whole 128-B lines on the output side of the gather); the
+        # zero tail keeps the layer-1 kernels' whole-float4 reads of the last row inside the allocation for any S
+        brf = learner.lay.batch_row_floats
+        self._batch_store = torch.zeros(self.U * B * brf + 64, dtype=torch.float32, device=dev)
+        self.batch = self._batch_store[:self.U * B * brf].view(self.U, B, brf)
         self.loss_parts = torch.zeros(self.U, learner.n_loss_wg, dtype=torch.float32, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph

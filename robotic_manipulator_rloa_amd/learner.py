@@ -100,7 +100,8 @@ class NetLayout:
             self.seg[name] = Segment(off, shape)
             off = _round_up(off + self.seg[name].numel, 64)
         self.P = off
-        self.row_floats = _lib.load().naf_replay_row_floats(self.S, self.A)
+        self.row_floats = _lib.load().naf_replay_row_floats(self.S, self.A)              # ring rows (256 B)
+        self.batch_row_floats = _lib.load().naf_replay_batch_row_floats(self.S, self.A)  # gathered minibatch rows
         # offsets inside a transition row
         self.off_u = self.S
         self.off_r = self.S + self.A
@@ -290,9 +291,9 @@ class Learner:
 
     # ---- one learn() on the current stream --------------------------------------------------------------
     def _x2(self, rows: torch.Tensor) -> torch.Tensor:
-        """[2, B, S] view of a [B, row_floats] minibatch: net 0 reads `state`, net 1 reads `next_state`."""
+        """[2, B, S] view of a [B, ld] minibatch: net 0 reads `state`, net 1 reads `next_state`."""
         lay = self.lay
-        return rows.as_strided((2, self.B, lay.S), (lay.off_s2, lay.row_floats, 1), rows.storage_offset())
+        return rows.as_strided((2, self.B, lay.S), (lay.off_s2, rows.stride(0), 1), rows.storage_offset())
 
     def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True) -> None:
         """Both networks' training-mode forward up to the second hidden activation A2 (and, with heads_gemm, the
@@ -306,7 +307,7 @@ class Learner:
         if "l1" in self.fuse:
             # layer 1 (K = state size): GEMM + bias + BN + ReLU of both nets in one launch, straight off the rows
             check(self._f.naf_linear_bn_relu_fwd_train(
-                rows.data_ptr(), lay.off_s2, lay.row_floats, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                rows.data_ptr(), lay.off_s2, rows.stride(0), lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                 t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H,
                 ptr(self.save_mean[0]), ptr(self.save_invstd[0]), B, H, 2, BN_MOMENTUM, BN_EPS, st), "linear_bn_relu_fwd_train")
         else:
@@ -334,34 +335,37 @@ class Learner:
 
     def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None) -> None:
         """Enqueue one full NAFAgent.learn() (naf_algorithm.py:180-215) + soft_update (:217-226) on the minibatch
-        `rows` [B, row_floats] (actions already truncated by the gather if the reference's `.long()` is mimicked).
+        `rows` [B, ld] in the transition-row layout, ld = rows.stride(0) >= lay.batch_row_floats (actions already
+        truncated by the gather if the reference's `.long()` is mimicked).
         loss_partials: optional [ceil(B/32)] f32 receiving the per-workgroup parts of the MSE loss."""
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
         f = self._f
         t2p, gp = self.theta2.data_ptr(), self.grad.data_ptr()
-        rp = rows.data_ptr()
+        rp, ld = rows.data_ptr(), rows.stride(0)
+        if rows.shape[0] != B or rows.stride(1) != 1 or ld < lay.batch_row_floats or ld % 4 or rp % 16:
+            raise ValueError(f"learn_rows: need [B={B}, >={lay.batch_row_floats}] f32 rows, 16-B aligned, row stride % 4 == 0")
         lp = ptr(loss_partials) if loss_partials is not None else None
         if "f3" in self.fuse:
             self.forward_train(rows, heads_gemm=False)
             # heads GEMM (MFMA) + V'(s') + y = r + gamma V' ; Q ; loss ; d loss / d heads_pre — one launch
             check(f.naf_heads_gemm_head_fwd_bwd_mse(
-                ptr(self.A2), B * HP, HP, HP, t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, lay.row_floats,
-                rp + 4 * lay.off_r, lay.row_floats, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
+                ptr(self.A2), B * HP, HP, HP, t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld,
+                rp + 4 * lay.off_r, ld, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "heads_gemm_head_fwd_bwd_mse")
         elif "s3" in self.fuse:
             self.forward_train(rows)
             # the head adds the H/8 split-K slabs while staging its rows, then as below
             check(f.naf_head_fwd_bwd_mse_splitk(
                 ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), self.n_slabs, NHP, rp + 4 * lay.off_u,
-                lay.row_floats,
-                rp + 4 * lay.off_r, lay.row_floats, self.gamma, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
+                ld,
+                rp + 4 * lay.off_r, ld, self.gamma, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "head_fwd_bwd_mse_splitk")
         else:
             self.forward_train(rows)
             # y = r + gamma * V'(s') ; Q ; loss ; d loss / d heads_pre — one launch
             check(f.naf_head_fwd_bwd_mse(
-                ptr(self.Gh[0]), NHP, rp + 4 * lay.off_u, lay.row_floats, rp + 4 * lay.off_r, lay.row_floats,
+                ptr(self.Gh[0]), NHP, rp + 4 * lay.off_u, ld, rp + 4 * lay.off_r, ld,
                 self.Gh[1].data_ptr() + 4 * (lay.A + lay.T), NHP, self.gamma, ptr(self.q_out), ptr(self.dH), lp, B, lay.A,
                 self.p_mode, st), "head_fwd_bwd_mse")
         # heads GEMM backward: weight+bias gradient in one GEMM thanks to the ones column
@@ -399,7 +403,7 @@ class Learner:
                     self._push_desc = self.xgmi.push_desc()
                 push, pushed_lo = _lib.C.byref(self._push_desc), seg["W2"].offset
             check(f.naf_bn_relu_bwd_wgrad_push(
-                ptr(self.dA1), H, rp, lay.row_floats, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                 ptr(self.A1[0]), H, t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, gp + 4 * seg["W1"].offset,
                 self.partials.data_ptr() + 4 * self._gb_blocks if self.fold_norm else None,

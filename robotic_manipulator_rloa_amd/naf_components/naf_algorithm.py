@@ -108,7 +108,7 @@ class NAFAgent:
         self._act_graph = None
         self._obs_pinned = torch.zeros(1, state_size, dtype=torch.float32).pin_memory()
         self._act_pinned = torch.zeros(1, action_size, dtype=torch.float32).pin_memory()
-        self._learn_rows = torch.zeros(batch_size, L.lay.row_floats, dtype=torch.float32, device=self.device)
+        self._learn_rows = torch.zeros(batch_size + 1, L.lay.batch_row_floats, dtype=torch.float32, device=self.device)[:batch_size]
         self._learn_loss = torch.zeros(L.n_loss_wg, dtype=torch.float32, device=self.device)
 
     # ---- pretrained weights (naf_algorithm.py:91-127) ----------------------------------------------------------

@@ -48,6 +48,7 @@ class ReplayBuffer:
     def _allocate(self, S: int, A: int) -> None:
         self.S, self.A = S, A
         self.row_floats = self.lib.naf_replay_row_floats(S, A)
+        self.batch_row_floats = self.lib.naf_replay_batch_row_floats(S, A)    # gathered minibatch rows: no tail padding
         self.off_s2 = self.lib.naf_replay_row_off_next_state(S, A)
         self.rows = torch.zeros(self.buffer_size, self.row_floats, dtype=torch.float32, device=self.device)
         self.meta = torch.zeros(8, dtype=torch.int64, device=self.device)
@@ -136,8 +137,12 @@ class ReplayBuffer:
         check(self.lib.naf_counter_add(ptr(self._sample_ctr), int(n_batches), stream_ptr()), "naf_counter_add")
 
     def gather_rows(self, idx: torch.Tensor, out_rows: torch.Tensor, n: int) -> None:
-        check(self.lib.naf_replay_gather_rows(self.handle, ptr(idx), ptr(out_rows), int(n), self.action_mode,
-                                              stream_ptr()), "naf_replay_gather_rows")
+        """out_rows[..., ld] (contiguous) receives the leading ld floats of the n indexed rows; ld = out_rows.shape[-1]
+        between batch_row_floats (what the learner reads) and row_floats (the whole padded ring row)."""
+        if not out_rows.is_contiguous() or out_rows.numel() < int(n) * out_rows.shape[-1]:
+            raise ValueError("gather_rows: out_rows must be contiguous and hold n rows")
+        check(self.lib.naf_replay_gather_rows(self.handle, ptr(idx), ptr(out_rows), int(n), int(out_rows.shape[-1]),
+                                              self.action_mode, stream_ptr()), "naf_replay_gather_rows")
 
     def sample(self, idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, ...]:
         """(states, actions, rewards, next_states, dones) with the reference's shapes and dtypes

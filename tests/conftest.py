@@ -24,3 +24,19 @@ def load_group(npz, prefix):
     """Sub-dict of an npz whose keys start with `prefix/` (prefix stripped)."""
     pre = prefix + "/"
     return {k[len(pre):]: npz[k] for k in npz.files if k.startswith(pre)}
+
+
+def g3_case(tag):
+    """(npz, main0, target0) of a G3 learn() golden. The big-batch cases (BASELINE configs[3], [4]: 'xarm1024',
+    'panda2048', tests/golden/g3_learn_big.npz) start from the initial weights of the small case with the same
+    (S, A, seed), which make_golden.py asserted when it wrote them; the target starts equal to the main net."""
+    import numpy as np
+    small = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
+    if tag in ("kuka", "panda"):
+        return small, load_group(small, f"{tag}/main0"), load_group(small, f"{tag}/target0")
+    big = np.load(os.path.join(GOLDEN, "g3_learn_big.npz"))
+    init = str(big[f"{tag}/init_of"])
+    return big, load_group(small, f"{init}/main0"), load_group(small, f"{init}/target0")
+
+
+G3_TAGS = ["kuka", "panda", "xarm1024", "panda2048"]

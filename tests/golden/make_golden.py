@@ -141,56 +141,77 @@ def main():
         print("g2", len(out), "arrays")
 
     # ---------------- G3: one full learn() + 5-step trace --------------------------------------------
-    if want("g3"):
-        out = {}
-        for (S, A, B, tag) in ((21, 6, 256, "kuka"), (23, 7, 64, "panda")):
-            agent = NAFAgent(object(), S, A, 256, B, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, cpu, 0)
-            st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
-            losses, pre_clip = [], {}
-            real_mse, real_clip = ref_alg.F.mse_loss, ref_alg.clip_grad_norm_
+    def g3_case(S, A, B, tag, compact, out):
+        """compact: the initial weights are those of a smaller case with the same (S, A) and seed (asserted by the caller),
+        so only the results of the update are stored."""
+        agent = NAFAgent(object(), S, A, 256, B, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, cpu, 0)
+        st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
+        losses, pre_clip = [], {}
+        real_mse, real_clip = ref_alg.F.mse_loss, ref_alg.clip_grad_norm_
 
-            def tap_mse(a_, b_):
-                l_ = real_mse(a_, b_)
-                losses.append(float(l_.detach()))
-                tap_mse.q, tap_mse.y = a_.detach().numpy().copy(), b_.detach().numpy().copy()
-                return l_
+        def tap_mse(a_, b_):
+            l_ = real_mse(a_, b_)
+            losses.append(float(l_.detach()))
+            tap_mse.q, tap_mse.y = a_.detach().numpy().copy(), b_.detach().numpy().copy()
+            return l_
 
-            def tap_clip(params, max_norm):
-                params = list(params)
-                if "grads" not in pre_clip:
-                    names = [n for n, _ in agent.qnetwork_main.named_parameters()]
-                    pre_clip["grads"] = {n: p.grad.detach().numpy().copy() for n, p in zip(names, params)}
-                tn = real_clip(params, max_norm)
-                pre_clip.setdefault("norm", float(tn))
-                return tn
+        def tap_clip(params, max_norm):
+            params = list(params)
+            if "grads" not in pre_clip:
+                names = [n for n, _ in agent.qnetwork_main.named_parameters()]
+                pre_clip["grads"] = {n: p.grad.detach().numpy().copy() for n, p in zip(names, params)}
+            tn = real_clip(params, max_norm)
+            pre_clip.setdefault("norm", float(tn))
+            return tn
 
-            ref_alg.F.mse_loss = tap_mse
-            ref_alg.clip_grad_norm_ = tap_clip
-            out.update(flat(f"{tag}/main0", sd_np(agent.qnetwork_main.state_dict())))
+        ref_alg.F.mse_loss = tap_mse
+        ref_alg.clip_grad_norm_ = tap_clip
+        main0 = sd_np(agent.qnetwork_main.state_dict())
+        if not compact:
+            out.update(flat(f"{tag}/main0", main0))
             out.update(flat(f"{tag}/target0", sd_np(agent.qnetwork_target.state_dict())))
-            for k in range(5):
-                sl = slice(k * B, (k + 1) * B)
-                ex = (torch.from_numpy(st[sl]), torch.from_numpy(ac[sl]).long(), torch.from_numpy(rw[sl, None]),
-                      torch.from_numpy(ns[sl]), torch.from_numpy(dn[sl, None]))
-                agent.learn(ex)
-                if k == 0:
-                    out[f"{tag}/q1"], out[f"{tag}/y1"] = tap_mse.q, tap_mse.y
-                    out.update(flat(f"{tag}/grads1", pre_clip["grads"]))
-                    out[f"{tag}/grad_norm1"] = np.array(pre_clip["norm"])
-                    out.update(flat(f"{tag}/main1", sd_np(agent.qnetwork_main.state_dict())))
-                    out.update(flat(f"{tag}/target1", sd_np(agent.qnetwork_target.state_dict())))
+        for k in range(5):
+            sl = slice(k * B, (k + 1) * B)
+            ex = (torch.from_numpy(st[sl]), torch.from_numpy(ac[sl]).long(), torch.from_numpy(rw[sl, None]),
+                  torch.from_numpy(ns[sl]), torch.from_numpy(dn[sl, None]))
+            agent.learn(ex)
+            if k == 0:
+                out[f"{tag}/q1"], out[f"{tag}/y1"] = tap_mse.q, tap_mse.y
+                out.update(flat(f"{tag}/grads1", pre_clip["grads"]))
+                out[f"{tag}/grad_norm1"] = np.array(pre_clip["norm"])
+                out.update(flat(f"{tag}/main1", sd_np(agent.qnetwork_main.state_dict())))
+                out.update(flat(f"{tag}/target1", sd_np(agent.qnetwork_target.state_dict())))
+                if not compact:
                     opt = agent.optimizer.state_dict()["state"]
                     names = [n for n, _ in agent.qnetwork_main.named_parameters()]
                     for i, n in enumerate(names):
                         out[f"{tag}/adam_m1/{n}"] = opt[i]["exp_avg"].numpy().copy()
                         out[f"{tag}/adam_v1/{n}"] = opt[i]["exp_avg_sq"].numpy().copy()
-            ref_alg.F.mse_loss, ref_alg.clip_grad_norm_ = real_mse, real_clip
-            out[f"{tag}/losses5"] = np.array(losses)
+        ref_alg.F.mse_loss, ref_alg.clip_grad_norm_ = real_mse, real_clip
+        out[f"{tag}/losses5"] = np.array(losses)
+        if not compact:
             out.update(flat(f"{tag}/main5", sd_np(agent.qnetwork_main.state_dict())))
             out.update(flat(f"{tag}/target5", sd_np(agent.qnetwork_target.state_dict())))
-            out[f"{tag}/dims"] = np.array([S, A, B])
-            print("g3", tag, losses)
+        out[f"{tag}/dims"] = np.array([S, A, B])
+        print("g3", tag, losses)
+        return main0
+
+    if want("g3"):
+        out = {}
+        for (S, A, B, tag) in ((21, 6, 256, "kuka"), (23, 7, 64, "panda")):
+            g3_case(S, A, B, tag, False, out)
         np.savez_compressed(os.path.join(HERE, "g3_learn.npz"), **out)
+
+    # ---------------- G3 at the batch sizes of BASELINE configs[3] and [4] (one reference learn() trace each) ---------
+    if want("g3big"):
+        out = {}
+        small = np.load(os.path.join(HERE, "g3_learn.npz"))
+        for (S, A, B, tag, init_of) in ((21, 6, 1024, "xarm1024", "kuka"), (23, 7, 2048, "panda2048", "panda")):
+            main0 = g3_case(S, A, B, tag, True, out)
+            for k_, v_ in main0.items():       # same (S, A, seed) => same initial weights as the small case: not stored twice
+                assert np.array_equal(v_, small[f"{init_of}/main0/{k_}"]), k_
+            out[f"{tag}/init_of"] = np.array(init_of)
+        np.savez_compressed(os.path.join(HERE, "g3_learn_big.npz"), **out)
 
     # ---------------- G4: replay contract ------------------------------------------------------------
     if want("g4"):

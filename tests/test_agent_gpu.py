@@ -382,6 +382,21 @@ def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world):
         assert f"XGMI_OK_{k};" in r.stdout, r.stdout[-2000:]
 
 
+def _check_bench_line_n2(r, steps, rehearsal):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2"
+    assert ("REHEARSAL" in out["config"]["launch"]) == rehearsal
+    assert out["sanity"]["params_finite"] and out["sanity"]["replicas_identical"] is True
+    assert out["sanity"]["optimizer_steps"] == (steps + 2) * 64   # warm-up inside capture leaves no trace
+    assert abs(out["value"] - 2 * 64 * steps / (out["ms_per_step"] * steps * 1e-3)) < 1e-3 * out["value"]
+    assert "cpu_baseline" not in out                               # timed at N = 1 only
+    return out
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """bench.py's N > 1 code path (torch.distributed.run launch, rank-0-only JSON line, barrier-bracketed timing, MAX
     over ranks, whole-job aggregate, gradient exchange inside the captured graphs) with both ranks on cuda:0
@@ -394,16 +409,43 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
                MASTER_PORT=port, OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--buffer", "100000"],
+                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--buffer", "100000", "--roofline-ring", "0"],
                        env=env, capture_output=True, text=True, timeout=900)
+    out = _check_bench_line_n2(r, 6, rehearsal=True)
+    assert "one-shot" in out["config"]["grad_exchange"] and out["sanity"]["xgmi_timed_out_waits"] == 0
+
+
+def test_bench_gpus2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver invokes N = 1): the parent starts
+    torch.distributed.run as a child before touching the GPU and relays rank 0's line. On the 1-GPU box the two ranks
+    share cuda:0 (rehearsal, labelled); without the rehearsal switch the same command is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--buffer",
+           "100000", "--roofline-ring", "0"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        env["NAF_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    _check_bench_line_n2(r, 5, rehearsal=torch.cuda.device_count() < 2)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the gpurun box has one)")
+@pytest.mark.parametrize("xgmi", ["1", "0"])
+def test_bench_two_real_gpus_rccl_and_oneshot(xgmi):
+    """Two ranks on two DISTINCT devices: RCCL (NAF_XGMI=0) and the one-shot peer-memory exchange (default) each move
+    the gradient between devices; replicas stay bit-identical, no wait times out, RCCL saw two ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
+                                                            "NAF_BENCH_REHEARSAL")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", NAF_XGMI=xgmi)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                        "--buffer", "100000", "--roofline-ring", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["config"]["parallelism"] == "dp2" and "one-shot" in out["config"]["grad_exchange"]
-    assert out["sanity"]["params_finite"] and out["sanity"]["xgmi_timed_out_waits"] == 0
-    assert out["sanity"]["replicas_identical"] is True
-    assert out["sanity"]["optimizer_steps"] == (6 + 2) * 64       # warm-up inside capture leaves no trace
-    assert abs(out["value"] - 2 * 64 * 6 / (out["ms_per_step"] * 6e-3)) < 1e-3 * out["value"]
-    assert "cpu_baseline" not in out                               # timed at N = 1 only
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and "REHEARSAL" not in out["config"]["launch"]
+    assert out["sanity"]["replicas_identical"] is True and out["sanity"]["params_finite"]
+    if xgmi == "1" and "one-shot" in out["config"]["grad_exchange"]:
+        assert out["sanity"]["xgmi_timed_out_waits"] == 0 and out["sanity"]["xgmi_allreduces"] >= 23 * 64
+    else:
+        assert out["config"]["grad_exchange"] == "RCCL all-reduce"

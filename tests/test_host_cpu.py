@@ -246,13 +246,26 @@ def test_data_parallel_world2_gloo(tmp_path):
     assert "DP_OK_0;" in r.stdout and "DP_OK_1;" in r.stdout, r.stdout[-2000:]
 
 
-def test_bench_cli_contract_is_parseable():
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    for flag in ("--gpus", "--steps", "--warmup"):
-        assert flag in src
-    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
-                '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
-        assert key in src
+def test_bench_cli_refuses_to_fake_a_multi_gpu_run():
+    """bench.py --gpus N on a host with fewer GPUs: an error, never a silent 1-rank line labelled n_gpus=1 (VERDICT r01);
+    a launcher world that disagrees with --gpus: an error too. (No GPU is touched: the checks run before any HIP call.)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NAF_BENCH_REHEARSAL")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr and "GPU(s)" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    # the argument surface the driver uses
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+    d = bench.parse_args([])
+    assert d.gpus == 1 and d.batch == 256 and d.buffer == 1_000_000 and d.envs == 64 and d.robot == "kuka"
+    assert json.dumps({"roofline": None}) and bench.pmc_traffic(-1, -1) == (None, None)
 
 
 def test_pybullet_environment_adapter_with_fake_simulator(monkeypatch):

@@ -76,10 +76,86 @@ def test_replay_add_gather_fifo_and_trunc(lib, S, A):
     buf.gather_rows(big, outb, 70000)
     np.testing.assert_array_equal(outb.cpu().numpy(), exp_t_full(expect, big.cpu().numpy(), S, A))
     assert buf.bad_index_count() == 0
+    # packed minibatch rows (what TrainChunk gathers): the leading batch_row_floats of every row, nothing else written
+    brf = buf.batch_row_floats
+    assert brf == lib.naf_replay_batch_row_floats(S, A) and brf % 4 == 0 and O.row_offsets(S, A)[3] + 1 <= brf <= rf
+    assert (S, A, brf) in ((21, 6, 52), (23, 7, 56), (19, 5, 52))
+    for n_rows, src in ((cap, perm), (70000, big)):
+        outp = torch.full((n_rows * brf + 8,), -7.0, device="cuda")
+        buf.gather_rows(src, outp[:n_rows * brf].view(n_rows, brf), n_rows)
+        np.testing.assert_array_equal(outp[:n_rows * brf].view(n_rows, brf).cpu().numpy(),
+                                      exp_t_full(expect, src.cpu().numpy(), S, A)[:, :brf])
+        assert (outp[n_rows * brf:] == -7.0).all()
+    assert lib.naf_replay_gather_rows(buf.handle, perm.data_ptr(), out.data_ptr(), 4, brf - 8, 0, st()) == -1
+    assert lib.naf_replay_gather_rows(buf.handle, perm.data_ptr(), out.data_ptr(), 4, rf + 4, 0, st()) == -1
+    assert lib.naf_replay_gather_rows(buf.handle, perm.data_ptr(), out.data_ptr(), 4, brf + 2, 0, st()) == -1
     # out-of-range positions are counted, not silently used
     bad = torch.tensor([0, cap, -1, 5], dtype=torch.int32, device="cuda")
     buf.gather_rows(bad, out, 4)
     assert buf.bad_index_count() == 2
+
+
+@pytest.mark.parametrize("cap,S,A,B", [(1_000_000, 21, 6, 256), (4_000_000, 23, 7, 2048)])
+def test_replay_ring_at_baseline_sizes(lib, cap, S, A, B):
+    """The rings of BASELINE configs[1] (1e6 rows = 256 MB) and configs[4] (4e6 rows = 1.02 GB, beyond the Infinity
+    Cache): filled past wrap-around with id-tagged rows in ragged appends, then the ReplayBuffer.sample contract
+    (utils/replay_buffer.py:47-67) at the config's batch size — positions in range and distinct inside a minibatch,
+    sampler bit-exact against the oracle's restatement, gathered rows byte-exact (every float of a row is a function of
+    its id, so each of the U*B gathered rows is checked in full), FIFO eviction = the newest `cap` ids survive."""
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    buf = ReplayBuffer(cap, B, "cuda", 0xBEEF, state_size=S, action_size=A)
+    rf, brf, off2 = buf.row_floats, buf.batch_row_floats, buf.off_s2
+    total = cap + cap // 3 + 12345                                  # wraps; < 2^24 so ids are exact in f32
+    assert total < (1 << 24)
+
+    def rows_of(ids):                                               # [n] int64 ids -> [n, rf] f32 rows, exact arithmetic
+        idf = ids.to(torch.float32)
+        r = torch.zeros(ids.numel(), rf, device="cuda")
+        cols = torch.arange(S, device="cuda", dtype=torch.float32)
+        r[:, :S] = torch.where(cols[None, :] == 0, idf[:, None], (idf[:, None] % 4096.0) + cols[None, :] * 0.5)
+        r[:, S:S + A] = ((idf[:, None] % 7.0) - 3.0) * 0.75 + torch.arange(A, device="cuda")[None, :] * 0.125
+        r[:, S + A] = -(idf % 1000.0)
+        r[:, off2:off2 + S] = (idf[:, None] % 8192.0) * 0.25 - cols[None, :]
+        r[:, off2 + S] = (ids % 5 == 0).to(torch.float32)
+        return r
+
+    lo = 0
+    for n in [1, 63, 64, 65, 1000, 100_003] + [1 << 20] * 8:        # ragged appends: single rows up to 1 Mi rows at once
+        n = min(n, total - lo, cap)
+        if n > 0:
+            buf.add_rows_device(rows_of(torch.arange(lo, lo + n, device="cuda")), n)
+            lo += n
+    assert lo == total
+    torch.cuda.synchronize()
+    assert len(buf) == cap and buf.device_len() == cap
+    meta = buf.meta.cpu().numpy()
+    assert meta[0] == total % cap and meta[2] == total
+    U = 8
+    idx = torch.zeros(U, B, dtype=torch.int32, device="cuda")
+    buf.sample_indices(idx, U)
+    got = idx.cpu().numpy()
+    np.testing.assert_array_equal(got, O.replay_sample_indices(0xBEEF, 0, cap, B, U, True))
+    assert got.min() >= 0 and got.max() < cap and all(len(set(g.tolist())) == B for g in got)
+    out = torch.empty(U, B, brf, device="cuda")
+    buf.gather_rows(idx, out, U * B)                                # the minibatch-sized launch, packed rows
+    ids = idx.long().reshape(-1) + (total - cap)                    # deque position p holds id (total - cap) + p
+    exp = rows_of(ids)
+    exp[:, S:S + A] = torch.trunc(exp[:, S:S + A])                  # `.long()` (replay_buffer.py:60)
+    assert torch.equal(out.view(-1, brf), exp[:, :brf])
+    # the bulk launch (4 float4 in flight per lane, nontemporal stores) over 1 Mi random positions incl. both ends
+    M = 1 << 20
+    pos = torch.randint(0, cap, (M,), device="cuda", dtype=torch.int32)
+    pos[0], pos[1] = 0, cap - 1
+    outb = torch.empty(M, brf, device="cuda")
+    buf.gather_rows(pos, outb, M)
+    expb = rows_of(pos.long() + (total - cap))
+    expb[:, S:S + A] = torch.trunc(expb[:, S:S + A])
+    assert torch.equal(outb, expb[:, :brf])
+    # the reference-contract path: five tensors
+    s, a, r, s2, d = buf.sample(idx=idx[0])
+    assert torch.equal(s, exp[:B, :S]) and torch.equal(a, exp[:B, S:S + A].long()) and torch.equal(r[:, 0], exp[:B, S + A])
+    assert torch.equal(s2, exp[:B, off2:off2 + S]) and torch.equal(d[:, 0], exp[:B, off2 + S])
+    assert buf.bad_index_count() == 0
 
 
 def exp_t_full(expect, idx, S, A):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_group
+from conftest import GOLDEN, G3_TAGS, g3_case, load_group
 from oracle import naf_oracle as O
 from test_oracle_golden import assert_adam_stepped_close
 
@@ -33,16 +33,16 @@ def current_sd(L, net):
 
 
 @pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "s3", "l1,b2,gb,s3", "all"])
-@pytest.mark.parametrize("tag", ["kuka", "panda"])
+@pytest.mark.parametrize("tag", G3_TAGS)
 def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     """NAF_FUSE selects which small GEMMs are folded into the BN / head kernels (csrc/fused_layers.hip; "all" includes
     the MFMA heads GEMM): every combination must match the reference."""
     monkeypatch.setenv("NAF_FUSE", fused)
     from synth_data import make_transitions
-    g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
+    g, main0, target0 = g3_case(tag)      # 'xarm1024' / 'panda2048': the reference's learn() at configs[3] / [4]'s batch
     S, A, B = [int(x) for x in g[f"{tag}/dims"]]
     st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
-    L = make_learner(S, A, B, load_group(g, f"{tag}/main0"), load_group(g, f"{tag}/target0"))
+    L = make_learner(S, A, B, main0, target0)
     rows = rows_device(L, st, ac, rw, ns, dn)
     lp = torch.zeros(5, L.n_loss_wg, device="cuda")
     for k in range(5):
@@ -86,7 +86,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
 @pytest.mark.parametrize("fused", ["none", "all", "l1,b2,gb,s3"])
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32),
-                                   (21, 6, 512), (32, 8, 512)])
+                                   (21, 6, 512), (32, 8, 512), (21, 6, 1024), (21, 6, 768)])
 def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
     monkeypatch.setenv("NAF_FUSE", fused)
     """20 updates against the f32 numpy oracle (Hadamard = reference semantics; matmul = textbook NAF)."""
