@@ -40,8 +40,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--buffer", type=int, default=1_000_000)
     ap.add_argument("--p-mode", choices=["hadamard", "matmul"], default="hadamard")
-    ap.add_argument("--robot", choices=["kuka", "xarm6", "panda"], default="kuka",
-                    help="shapes only: kuka/xarm6 S=21 A=6, panda S=23 A=7 (BASELINE configs[3], [4])")
+    ap.add_argument("--robot", choices=["kuka", "xarm6", "xarm6_robot", "panda"], default="kuka",
+                    help="preset of the on-device env and the shapes: kuka / xarm6 / xarm6_robot S=21 A=6, panda S=23 A=7 "
+                         "(BASELINE configs[3]: --robot xarm6_robot --batch 1024 --obstacle-jitter 0.1; configs[4]: --robot "
+                         "panda --batch 2048 --buffer 4000000)")
     ap.add_argument("--obstacle-jitter", type=float, default=0.0, help="per-env obstacle randomisation (configs[3])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 2
+#define NAF_HIP_ABI_VERSION 3
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -301,6 +301,10 @@ int naf_xgmi_push_early(void* handle, const float* grad_in, size_t lo, size_t hi
 int naf_xgmi_allreduce_sum_from(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
                                 int32_t* step_dev, size_t pushed_lo, void* stream);
 int naf_xgmi_status(void* handle, uint64_t* epoch, uint64_t* timeouts);
+/* Time-outs so far, read from a pinned host word the kernel bumps: never synchronises, so the training loop polls it
+ * after every chunk. A timed-out all-reduce leaves -inf in its sumsq partial, which makes naf_adam_polyak_fused skip
+ * that update on this rank (no wrong step reaches the weights); the host is expected to stop on a non-zero count. */
+int naf_xgmi_timeouts_nowait(void* handle, uint64_t* timeouts);
 int naf_xgmi_destroy(void* handle);
 
 #ifdef __cplusplus

@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import math
 import random
-from collections import deque
+from collections import deque, namedtuple
 
 import numpy as np
 import torch
@@ -106,20 +106,25 @@ class TorchCpuAgent:
         self.main, self.target = Net(sd, A), Net(sd, A)
         self.opt = torch.optim.Adam(self.main.parameters(), lr=lr)
         self.memory = deque(maxlen=buffer_size)
+        # namedtuple records with the reference's field names (utils/replay_buffer.py:27, :43-45): attribute access and
+        # record size are what its sample() pays for
+        self.experience = namedtuple("Experience", field_names=["state", "action", "reward", "next_state", "done"])
         self.batch_size, self.tau, self.gamma = batch_size, tau, gamma
         self.update_freq, self.num_updates, self.t = update_freq, num_updates, 0
         self.losses = []
 
     def add(self, s, a, r, s2, d):
-        self.memory.append((s, a, r, s2, d))
+        self.memory.append(self.experience(s, a, r, s2, d))
 
     def sample(self):
         ex = random.sample(self.memory, k=self.batch_size)
-        states = torch.from_numpy(np.stack([e[0] for e in ex])).float()
-        actions = torch.from_numpy(np.vstack([e[1] for e in ex])).long()
-        rewards = torch.from_numpy(np.vstack([e[2] for e in ex])).float()
-        next_states = torch.from_numpy(np.stack([e[3] for e in ex])).float()
-        dones = torch.from_numpy(np.vstack([e[4] for e in ex]).astype(np.uint8)).float()
+        dev = torch.device("cpu")
+        states = torch.from_numpy(
+            np.stack([e.state if not isinstance(e.state, tuple) else e.state[0] for e in ex])).float().to(dev)
+        actions = torch.from_numpy(np.vstack([e.action for e in ex if e is not None])).long().to(dev)
+        rewards = torch.from_numpy(np.vstack([e.reward for e in ex if e is not None])).float().to(dev)
+        next_states = torch.from_numpy(np.stack([e.next_state for e in ex if e is not None])).float().to(dev)
+        dones = torch.from_numpy(np.vstack([e.done for e in ex if e is not None]).astype(np.uint8)).float().to(dev)
         return states, actions, rewards, next_states, dones
 
     def act(self, state):
@@ -168,7 +173,7 @@ def time_baseline(S=21, A=6, H=256, B=256, N=1_000_000, fill=None, budget_s=15.0
     st = rng.standard_normal((fill + 4097, S))
     ac = rng.uniform(-1, 1, (fill + 4097, A)).astype(np.float32)
     for i in range(fill):
-        agent.memory.append((st[i], ac[i], -0.5, st[i + 1], 0))
+        agent.add(st[i], ac[i], -0.5, st[i + 1], 0)
     # learn() only
     ex = agent.sample()
     for _ in range(3):

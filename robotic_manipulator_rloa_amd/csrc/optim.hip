@@ -71,6 +71,7 @@ struct AdamScalars {
     float clip_scale;   // inv_world * min(1, max_norm / (total_norm + 1e-6))
     float step_size;    // lr / (1 - beta1^t)
     float inv_bc2_sqrt; // 1 / sqrt(1 - beta2^t)
+    int skip;           // the norm partials carry the poison of a timed-out gradient exchange: leave every buffer as it is
 };
 
 __device__ static inline void adam_one(float& th, float gr, float& m, float& v, float* tg, const AdamScalars& sc,
@@ -122,6 +123,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (threadIdx.x == 0) {
+            // a sum of squares is never negative: -inf is what xgmi_allreduce_kernel leaves when a peer's contribution
+            // did not arrive in time (csrc/xgmi_reduce.hip) — the update is then skipped on this rank, whole
+            sh.skip = s < 0.f;
             const float total_norm = sqrtf(s) * inv_world;
             float clip = max_norm / (total_norm + 1e-6f);
             clip = clip > 1.0f ? 1.0f : clip;
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
     }
     __syncthreads();
     const AdamScalars sc = sh;
+    if (sc.skip) return;
     for (size_t i = i0; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 th, gr, mm, vv, tg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i == i0) {

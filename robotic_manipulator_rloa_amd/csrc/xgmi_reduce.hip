@@ -35,6 +35,7 @@ struct XgmiComm {
     XgPeers peers;
     bool opened[NAF_XGMI_MAX_WORLD];
     uint64_t* ctrl;                        // device, ordinary memory: [0] epoch [1] arrivals [2] time-outs [3] spare
+    uint64_t* host_timeouts;               // pinned host word the kernel bumps on a time-out: the host reads it WITHOUT a sync
     long long timeout_ticks;
 };
 
@@ -47,11 +48,14 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peer
                                                                     size_t data_off, int rank,
                                                                     uint64_t* __restrict__ ctrl,
                                                                     float* __restrict__ sumsq_partials, int32_t* step_dev,
-                                                                    long long timeout_ticks, size_t pushed_lo) {
+                                                                    long long timeout_ticks, size_t pushed_lo,
+                                                                    uint64_t* __restrict__ host_timeouts) {
     // pushed_lo: grad_in[pushed_lo, n) has already been pushed for this epoch (naf_xgmi_push_early or the layer-1
     // backward kernel's extra workgroups, in an earlier launch of this stream); pushed_lo = n: nothing has
     __shared__ float red[XG_THREADS / 64];
     __shared__ int last;
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;   // (published by the barrier behind the pushes)
     const uint64_t e = ctrl[0] + 1;        // nobody writes ctrl[0] before every workgroup has arrived below
     const size_t i = (size_t)blockIdx.x * XG_CHUNK + (size_t)threadIdx.x * 4;
     const bool on = i < n;                 // n is a multiple of 4 (checked on the host)
@@ -87,6 +91,8 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peer
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
             if (wall_clock64() - t0 > timeout_ticks) {       // the exit every wave reaches: peer missing or dead
                 atomicAdd((unsigned long long*)&ctrl[2], 1ull);
+                if (host_timeouts) __hip_atomic_fetch_add(host_timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                timed_out = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -115,8 +121,12 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peer
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int k = 0; k < XG_THREADS / 64; ++k) s += red[k];
-        if (sumsq_partials) sumsq_partials[blockIdx.x] = s;
-        if (blockIdx.x == 0 && step_dev) *step_dev += 1;
+        // a contribution is missing: what was summed is not the gradient. The partial is POISONED (a sum of squares is
+        // never negative): naf_adam_polyak_fused skips the whole update when the norm it folds comes out negative, so
+        // a slow or dead peer cannot push a wrong step into the weights; the time-out is counted where the host sees
+        // it without synchronising (naf_xgmi_timeouts_nowait) and the training loop raises on it
+        if (sumsq_partials) sumsq_partials[blockIdx.x] = timed_out ? -__builtin_huge_valf() : s;
+        if (blockIdx.x == 0 && step_dev && !timed_out) *step_dev += 1;
     }
 }
 
@@ -157,11 +167,15 @@ extern "C" int naf_xgmi_create(int rank, int world, size_t n_floats, double time
     c->peers.base[rank] = c->local;
     e = hipMalloc((void**)&c->ctrl, 64);
     if (e == hipSuccess) e = hipMemset(c->ctrl, 0, 64);
+    c->host_timeouts = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->host_timeouts, 64, hipHostMallocMapped);
+    if (e == hipSuccess) *c->host_timeouts = 0;
     if (e == hipSuccess) e = hipMemset(c->local, 0, c->slab_bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         (void)hipFree(c->local);
         if (c->ctrl) (void)hipFree(c->ctrl);
+        if (c->host_timeouts) (void)hipHostFree(c->host_timeouts);
         delete c;
         return (int)e;
     }
@@ -270,7 +284,7 @@ extern "C" int naf_xgmi_allreduce_sum_from(void* handle, const float* grad_in, f
     case W:                                                                                                          \
         xgmi_allreduce_kernel<W><<<chunks, XG_THREADS, 0, (hipStream_t)stream>>>(                                    \
             c->peers, grad_in, grad_out, c->n, c->n_pad, c->data_off, c->rank, c->ctrl, sumsq_partials, step_dev,    \
-            c->timeout_ticks, pushed_lo);                                                                            \
+            c->timeout_ticks, pushed_lo, c->host_timeouts);                                                          \
         break;
     switch (c->world) {
         XG_REDUCE(2) XG_REDUCE(3) XG_REDUCE(4) XG_REDUCE(5) XG_REDUCE(6) XG_REDUCE(7) XG_REDUCE(8)
@@ -291,6 +305,12 @@ extern "C" int naf_xgmi_status(void* handle, uint64_t* epoch, uint64_t* timeouts
     return NAF_OK;
 }
 
+extern "C" int naf_xgmi_timeouts_nowait(void* handle, uint64_t* timeouts) {
+    if (!handle || !timeouts) return NAF_ERR_ARG;
+    *timeouts = *(volatile uint64_t*)xg_comm(handle)->host_timeouts;   // pinned host memory the kernel writes: no sync
+    return NAF_OK;
+}
+
 extern "C" int naf_xgmi_destroy(void* handle) {
     if (!handle) return NAF_ERR_ARG;
     XgmiComm* c = xg_comm(handle);
@@ -303,6 +323,7 @@ extern "C" int naf_xgmi_destroy(void* handle) {
     // same process took a different update in ~1 of 2 runs); keeping either the slab or the mappings alive: 30 of 30
     // runs bit-identical. Peers wrote these pages through their own (importer-side) mappings.
     (void)hipFree(c->ctrl);
+    (void)hipHostFree(c->host_timeouts);
     delete c;
     return NAF_OK;
 }

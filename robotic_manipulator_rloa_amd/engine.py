@@ -18,6 +18,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .learner import ActPath, Learner
+from .presets import ROBOT_PRESETS, device_env_preset
 from .utils.replay_buffer import ReplayBuffer
 
 
@@ -112,6 +113,8 @@ class TrainChunk:
 
     def run(self) -> None:
         """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first."""
+        if self.L.xgmi is not None:
+            self.L.xgmi.raise_on_timeout()     # host word written by the kernel: costs a load, never a sync
         if self.use_graph:
             if self.graph is None:
                 self.capture()
@@ -129,13 +132,8 @@ class TrainChunk:
 class DeviceEnvLoop:
     """E synthetic manipulator envs living on the GPU (csrc/synth_env.hip) driven by the agent's policy."""
 
-    # [initial joint positions(8) | target | obstacle]: the reference's demo presets (rl_framework.py:547-555, :571-580);
-    # 'panda' has no reference preset (BASELINE configs[4] names only the URDF): a reachable target/obstacle pair
-    PRESETS = {
-        "kuka": [0.9, 0.45, 0, 0, 0, 0, 0, 0, 0.4, 0.85, 0.71, 0.45, 0.55, 0.55],
-        "xarm6": [0.0, 1.0, 0.0, -2.3, 0.0, 0.0, 0.0, 0, 0.3, 0.47, 0.61, 0.25, 0.27, 0.5],
-        "panda": [0.0, -0.6, 0.0, -2.0, 0.0, 1.6, 0.8, 0, 0.45, 0.3, 0.6, 0.35, 0.2, 0.45],
-    }
+    # [initial joint positions(8) | target | obstacle] per robot, from the one preset table (presets.py)
+    PRESETS = {name: device_env_preset(name) for name in ROBOT_PRESETS}
 
     def __init__(self, learner: Learner, replay: ReplayBuffer, n_envs: int, seed: int, max_frames: int = 400,
                  noise_scale: float = 1.0, use_graph: bool = True, robot: str = "kuka", obstacle_jitter: float = 0.0):

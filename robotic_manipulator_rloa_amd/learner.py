@@ -173,8 +173,8 @@ class Learner:
         self.fuse = set(names) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if self.lay.S > 32:
             self.fuse -= {"l1"}
-        if self.B % 16 != 0:
-            self.fuse -= {"gb"}
+        if self.B % 16 != 0 or self.lay.H % 16 != 0:
+            self.fuse -= {"gb", "f3"}          # the MFMA kernels take whole 16 x 16 x 16 steps: M, N, K % 16 == 0
         if self.B > 512 or self.lay.H not in (128, 256) or "f3" in self.fuse:
             self.fuse -= {"s3"}
         # with l1 + b2 + gb every gradient element is produced by one of our own kernels, which then also emit its

@@ -102,6 +102,8 @@ class NAFAgent:
         if self.rank:
             random.seed(seed)  # ReplayBuffer re-seeded Python's RNG with the rank offset; keep the reference's value
         self.update_t_step = 0
+        self._dp_ticks = 0                 # update-schedule ticks (step() calls + idle ticks): the gate under data parallel
+        self._last_loss_from = None        # "chunk" | "learn": which path ran the most recent update
         self.use_graph = use_graph
         self._chunk: Optional[TrainChunk] = None
         self._actor1: Optional[ActPath] = None
@@ -136,12 +138,24 @@ class NAFAgent:
         (sample + learn) (naf_algorithm.py:129-156). The updates are one captured graph:
         sample num_updates minibatches -> one gather -> num_updates x learn."""
         self.memory.add(state, action, reward, next_state, done)
+        self._update_tick()
+
+    def _update_tick(self) -> None:
+        """The update schedule of step() (naf_algorithm.py:144-156) without the add. Data parallel: every learn() holds a
+        gradient all-reduce, so every rank must run the SAME number of ticks and open the gate at the same tick — the
+        gate is therefore the tick count (identical on all ranks; equal to len(memory) whenever every tick added a row,
+        i.e. always on one GPU), not the local fill level; run() pads episodes that ended early with idle ticks. A rank
+        that falls out of step is caught by the exchange's time-out (TrainChunk.run raises)."""
         self.update_t_step = (self.update_t_step + 1) % self.update_freq
-        if self.update_t_step == 0 and len(self.memory) > self.batch_size:
+        self._dp_ticks += 1
+        ready = len(self.memory) > self.batch_size if self.world_size == 1 else \
+            (self._dp_ticks > self.batch_size and len(self.memory) > 0)
+        if self.update_t_step == 0 and ready:
             self.memory.flush()
             if self._chunk is None:
                 self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=self.use_graph)
             self._chunk.run()
+            self._last_loss_from = "chunk"
 
     def act(self, state) -> np.ndarray:
         """Noisy clamped action for one state, main net in eval mode (naf_algorithm.py:158-178)."""
@@ -197,12 +211,16 @@ class NAFAgent:
         r[:, lay.off_s2:lay.off_s2 + S] = next_states.to(self.device, torch.float32)
         r[:, lay.off_d] = dones.to(self.device, torch.float32).view(B)
         L.learn_rows(r, self._learn_loss)
+        self._last_loss_from = "learn"
 
     def last_loss(self) -> float:
-        """MSE loss of the most recent update (host sync). The reference computes it and drops it (:215)."""
-        if self._chunk is not None:
+        """MSE loss of the most recent update, whichever path ran it (host sync). The reference computes it and drops
+        it (:215)."""
+        if self._last_loss_from == "chunk":
             return float(self._chunk.losses()[-1].item())
-        return float(self._learn_loss.sum().item())
+        if self._last_loss_from == "learn":
+            return float(self._learn_loss.sum().item())
+        raise _lib.NafHipError("last_loss(): no update has run yet")
 
     def soft_update(self, main_nn, target_nn) -> None:
         """theta_target = tau*theta_main + (1 - tau)*theta_target over parameters() (naf_algorithm.py:217-226)."""
@@ -240,6 +258,11 @@ class NAFAgent:
                     logger.info(f'Reward: {reward}  -  Cumulative reward: {score}\n')
                 if done:
                     break
+            if self.world_size > 1:
+                # data parallel: every rank's episode costs exactly `frames` ticks of the update schedule, whatever its
+                # own environment did — the ranks' learn() calls (one gradient all-reduce each) stay paired
+                for _ in range(frame, frames):
+                    self._update_tick()
             scores[episode + 1] = (score, frame)
             logger.info(f'Reward:                             {score}')
             logger.info(f'Number of frames:                   {frame}')

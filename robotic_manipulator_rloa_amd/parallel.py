@@ -166,6 +166,24 @@ class XgmiAllReduce:
         self.lib.naf_xgmi_status(self.handle, C.byref(e), C.byref(t))
         return int(e.value), int(t.value)
 
+    def timeouts_nowait(self) -> int:
+        """Timed-out waits so far, read from pinned host memory the kernel writes: no synchronisation. The value lags the
+        stream by whatever is still queued; a non-zero count never goes back to zero."""
+        import ctypes as C
+        t = C.c_uint64()
+        self.lib.naf_xgmi_timeouts_nowait(self.handle, C.byref(t))
+        return int(t.value)
+
+    def raise_on_timeout(self) -> None:
+        """A peer's gradient did not arrive within the time-out: the affected updates were skipped on this rank (poisoned
+        norm partial -> naf_adam_polyak_fused leaves the buffers alone), the replicas can no longer be assumed identical."""
+        n = self.timeouts_nowait()
+        if n:
+            from ._lib import NafHipError
+            raise NafHipError(f"one-shot gradient all-reduce: {n} wait(s) on a peer timed out on rank {self.rank} — a rank is "
+                              "slow, dead, or made a different number of learn() calls; the data-parallel replicas are out "
+                              "of lock-step, stop and restart from a checkpoint")
+
     def self_test(self, rounds: int = 128) -> bool:
         """Exact check of this rank's results: rank r contributes (r+1) * ((i + 3*round) % 61), whose sum over ranks is
         an integer below 2^24 (exact in f32 whatever the order)."""

@@ -23,6 +23,7 @@ import torch
 
 from .environment.synthetic import SyntheticEnvironment
 from .naf_components.naf_algorithm import NAFAgent
+from .presets import ROBOT_PRESETS, pybullet_arguments, synthetic_initial_joints
 from .utils.exceptions import (ConfigurationIncomplete, EnvironmentNotInitialized, InvalidHyperParameter,
                                InvalidManipulatorFile, InvalidNAFAgentParameter, NAFAgentNotInitialized)
 from .utils.logger import Logger, get_global_logger
@@ -66,16 +67,9 @@ _HYPERPARAMETER_RULES = (
      'Buffer Size is not an int or has a value lower than 0'),
 )
 
-_DEMO_ENVS = {   # presets of run_demo_training / run_demo_testing (rl_framework.py:547-555, :571-580, :642-649, :669-678)
-    'kuka': dict(manipulator_file='kuka_iiwa/kuka_with_gripper2.sdf', endeffector_index=13,
-                 fixed_joints=[6, 7, 8, 9, 10, 11, 12, 13], involved_joints=[0, 1, 2, 3, 4, 5],
-                 target_position=[0.4, 0.85, 0.71], obstacle_position=[0.45, 0.55, 0.55],
-                 initial_joint_positions=[0.9, 0.45, 0, 0, 0, 0]),
-    'xarm6': dict(manipulator_file='xarm/xarm6_with_gripper.urdf', endeffector_index=12,
-                  fixed_joints=[0, 7, 8, 9, 10, 11, 12, 13], involved_joints=[1, 2, 3, 4, 5, 6],
-                  target_position=[0.3, 0.47, 0.61], obstacle_position=[0.25, 0.27, 0.5],
-                  initial_joint_positions=[0., 1., 0., -2.3, 0., 0., 0.]),
-}
+# presets of run_demo_training / run_demo_testing (rl_framework.py:547-555, :571-580, :642-649, :669-678) plus the two
+# robots BASELINE configs[3] / [4] name: one table, shared with the device env (presets.py)
+_DEMO_ENVS = {name: pybullet_arguments(name) for name in ROBOT_PRESETS}
 
 
 class ManipulatorFramework:
@@ -306,8 +300,9 @@ class ManipulatorFramework:
     def _demo_environment(self, robot: str, environment: str, variation, visualize: bool) -> None:
         preset = dict(_DEMO_ENVS[robot])
         if environment == 'synthetic':
-            self.initialize_synthetic_environment(len(preset['involved_joints']), preset['target_position'],
-                                                  preset['obstacle_position'], preset['initial_joint_positions'][:6], variation)
+            n = len(preset['involved_joints'])
+            self.initialize_synthetic_environment(n, preset['target_position'], preset['obstacle_position'],
+                                                  synthetic_initial_joints(robot), list(variation)[:n])
         else:
             import pybullet_data
             preset['manipulator_file'] = os.path.join(pybullet_data.getDataPath(), preset['manipulator_file'])
@@ -320,13 +315,13 @@ class ManipulatorFramework:
         old_level = logger.level
         logger.setLevel(10)
         try:
-            if demo_type not in ('kuka_training', 'xarm6_training'):
+            robot = demo_type[:-len('_training')] if demo_type.endswith('_training') else None
+            if robot not in ROBOT_PRESETS:       # the reference knows kuka_training / xarm6_training
                 logger.error('Incorrect demo type!')
                 return
             if not self._clear_for_demo(interactive):
                 return
-            robot = demo_type.split('_')[0]
-            variation = [0, 0, 0, 0, 0, 0] if robot == 'kuka' else [0, 0, 0, 0.3, 1, 1, 1]
+            variation = list(ROBOT_PRESETS[robot]['training_variation'])
             self._demo_environment(robot, environment, variation, visualize=True)
             self.initialize_naf_agent()
             self.run_training(episodes, frames, verbose=verbose)
@@ -343,14 +338,14 @@ class ManipulatorFramework:
         old_level = logger.level
         logger.setLevel(10)
         try:
-            if demo_type not in ('kuka_testing', 'xarm6_testing'):
+            robot = demo_type[:-len('_testing')] if demo_type.endswith('_testing') else None
+            if robot not in ROBOT_PRESETS:       # the reference knows kuka_testing / xarm6_testing
                 logger.error('Incorrect demo type!')
                 return None
             if not self._clear_for_demo(interactive):
                 return None
-            robot = demo_type.split('_')[0]
-            variation = [0, 0, .5, .5, .5, .5] if robot == 'kuka' else [0, 0, 0, 0.3, 1, 1, 1]
-            self._demo_environment(robot, environment, variation, visualize=(robot != 'kuka'))
+            variation = list(ROBOT_PRESETS[robot]['testing_variation'])
+            self._demo_environment(robot, environment, variation, visualize=ROBOT_PRESETS[robot]['visualize_testing'])
             self.initialize_naf_agent()
             if weights_file is not None:
                 self.load_pretrained_parameters_from_weights_file(weights_file)

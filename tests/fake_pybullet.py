@@ -32,7 +32,7 @@ def make_modules(n_joints=8):
             else:
                 N[:, 0], N[:, 1], N[:, 2] = R[:, 0] * c - R[:, 2] * s, R[:, 1], R[:, 0] * s + R[:, 2] * c
             R = N
-            p = p + R[:, 2] * LINKS[k]
+            p = p + R[:, 2] * (LINKS[k] if k < len(LINKS) else np.float32(0.03))   # gripper-ish stubs beyond the arm
             out.append(p.copy())
         return out
 

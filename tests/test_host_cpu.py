@@ -25,7 +25,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/naf_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.naf_hip_arch() == b"gfx950" and lib.naf_hip_abi_version() == 1
+    assert lib.naf_hip_arch() == b"gfx950" and lib.naf_hip_abi_version() == _lib.header_abi_version() >= 3
+    assert lib.naf_replay_batch_row_floats(21, 6) == 52 and lib.naf_replay_batch_row_floats(23, 7) == 56
     assert lib.naf_replay_row_floats(21, 6) == 64 and lib.naf_replay_row_floats(23, 7) == 64
     assert lib.naf_replay_row_floats(5, 1) == 32 and lib.naf_replay_row_floats(0, 6) == -1
 
@@ -339,6 +340,59 @@ def test_pybullet_environment_adapter_with_fake_simulator(monkeypatch):
     f.delete_environment()
     for m in ("robotic_manipulator_rloa_amd.utils.collision_detector", "robotic_manipulator_rloa_amd.environment.environment"):
         sys.modules.pop(m, None)
+
+
+@pytest.mark.parametrize("robot,n_joints,A", [("kuka", 14, 6), ("xarm6", 14, 6), ("xarm6_robot", 7, 6), ("panda", 12, 7)])
+def test_robot_presets_one_table_and_the_joint_index_quirk(robot, n_joints, A, monkeypatch):
+    """presets.py is the one table behind the framework's demo environments, the device env presets and bench.py's
+    --robot (BASELINE configs[3]: xarm/xarm6_robot.urdf, configs[4]: franka_panda/panda.urdf). Driven through the
+    PyBullet adapter on the test double: state size 9 + 2A, actions go to `involved_joints`, and get_state reports joints
+    0 .. A-1 whatever `involved_joints` says — the reference's quirk (environment/environment.py:442-444)."""
+    import importlib
+    import fake_pybullet
+    from robotic_manipulator_rloa_amd import presets
+    from robotic_manipulator_rloa_amd.rl_framework import _DEMO_ENVS
+    assert set(presets.ROBOT_PRESETS) == {"kuka", "xarm6", "xarm6_robot", "panda"} == set(_DEMO_ENVS)
+    assert presets.ROBOT_PRESETS["xarm6_robot"]["manipulator_file"] == "xarm/xarm6_robot.urdf"
+    assert presets.ROBOT_PRESETS["panda"]["manipulator_file"] == "franka_panda/panda.urdf"
+    kw = presets.pybullet_arguments(robot)
+    assert kw == _DEMO_ENVS[robot] and len(kw["involved_joints"]) == A == presets.action_size(robot)
+    assert not set(kw["involved_joints"]) & set(kw["fixed_joints"]) and max(kw["involved_joints"] + kw["fixed_joints"] +
+                                                                           [kw["endeffector_index"]]) < n_joints
+    dp = presets.device_env_preset(robot)
+    assert len(dp) == 14 and dp[8:11] == kw["target_position"] and dp[11:14] == kw["obstacle_position"]
+    assert dp[:A] == [float(x) for x in kw["initial_joint_positions"][:A]]
+    pb, pbd = fake_pybullet.make_modules(n_joints=n_joints)
+    monkeypatch.setitem(sys.modules, "pybullet", pb)
+    monkeypatch.setitem(sys.modules, "pybullet_data", pbd)
+    for m in ("robotic_manipulator_rloa_amd.utils.collision_detector", "robotic_manipulator_rloa_amd.environment.environment"):
+        sys.modules.pop(m, None)
+    try:
+        importlib.import_module("robotic_manipulator_rloa_amd.environment.environment")
+        from robotic_manipulator_rloa_amd import ManipulatorFramework
+        f = ManipulatorFramework()
+        f._demo_environment(robot, "pybullet", None, visualize=False)
+        env = f.env
+        s = env.reset(False)
+        S = 9 + 2 * A
+        assert s.shape == (S,) and env.observation_space.shape == (S,) and env.action_space.shape == (A,)
+        init = [float(x) for x in kw["initial_joint_positions"]]
+        np.testing.assert_allclose(s[:A], init[:A], atol=1e-6)        # value k went to joint index k; joints 0..A-1 reported
+        np.testing.assert_allclose(s[2 * A + 3:2 * A + 6], kw["target_position"])
+        np.testing.assert_allclose(s[2 * A + 6:], kw["obstacle_position"])
+        a = np.linspace(-1, 1, A).astype(np.float32)
+        s2, r, d = env.step(a)
+        moved = np.zeros(n_joints, np.float32)
+        moved[kw["involved_joints"]] = a / 240.0                        # velocity control on the INVOLVED joints, one tick
+        full0 = np.zeros(n_joints, np.float32)
+        full0[:len(init)] = init
+        full0[kw["fixed_joints"]] = 0.0                                  # fixed joints are held at 0 (environment.py:470)
+        np.testing.assert_allclose(s2[:A], (full0 + moved)[:A], atol=1e-6)   # ... but joints 0..A-1 are what is observed
+        assert np.isfinite(r) and d in (0, 1)
+        f.delete_environment()
+    finally:
+        for m in ("robotic_manipulator_rloa_amd.utils.collision_detector", "robotic_manipulator_rloa_amd.environment.environment"):
+            sys.modules.pop(m, None)
 
 
 def test_framework_misc_api_contract(tmp_path, monkeypatch):

@@ -458,6 +458,30 @@ def test_clip_adam_polyak_vs_oracle(lib, n, gscale, world):
             assert (thd.cpu().numpy()[zero] == th[zero]).all()        # zero gradient + zero moments: no movement
 
 
+def test_adam_skips_the_update_when_the_norm_partials_are_poisoned(lib):
+    """A timed-out one-shot gradient exchange leaves -inf in its sum-of-squares partial (csrc/xgmi_reduce.hip): the
+    optimizer kernel must then leave theta, m, v and the target untouched — and behave normally otherwise."""
+    n = 83264
+    torch.manual_seed(0)
+    theta, g, m, v, tgt = (torch.randn(n, device="cuda") for _ in range(5))
+    v = v.abs()
+    part = torch.rand(21, device="cuda")
+    step = torch.ones(1, dtype=torch.int32, device="cuda")
+    saved = [t.clone() for t in (theta, m, v, tgt)]
+
+    def run():
+        assert lib.naf_adam_polyak_fused(theta.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), tgt.data_ptr(),
+                                         part.data_ptr(), 21, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-3, 0.999, step.data_ptr(), 1.0,
+                                         n, st()) == 0
+        torch.cuda.synchronize()
+    part[13] = float("-inf")
+    run()
+    assert all(torch.equal(a, b) for a, b in zip((theta, m, v, tgt), saved))
+    part[13] = 0.5
+    run()
+    assert not torch.equal(theta, saved[0]) and not torch.equal(tgt, saved[3]) and torch.isfinite(theta).all()
+
+
 def test_symbols_exported(lib):
     from robotic_manipulator_rloa_amd import _lib
     for name in _lib.EXPORTED_SYMBOLS:

@@ -178,6 +178,34 @@ def main():
     d = (res["1"] - res["0"]).abs()
     assert d.max().item() <= 12 * 1.01e-3 and (d > 1e-5).float().mean().item() < 0.01, (d.max(), (d > 1e-5).float().mean())
 
+    # ---- 4. a peer that does not show up: bounded wait, poisoned norm partial, host-visible count, update skipped ----
+    dist.barrier()
+    comm.lib.naf_xgmi_set_timeout(comm.handle, 0.3)
+    if rank == 0:                                      # the other ranks make no call: rank 0's wait must time out
+        from robotic_manipulator_rloa_amd._lib import NafHipError
+        assert comm.timeouts_nowait() == 0
+        step.zero_()
+        g = rank_input(rank, 424242, n, dev)
+        t0 = time.perf_counter()
+        comm.all_reduce(g, out, part, step)
+        torch.cuda.synchronize()
+        assert 0.25 < time.perf_counter() - t0 < 5.0
+        assert torch.isinf(part[:comm.n_partials]).all() and (part[:comm.n_partials] < 0).all()   # every workgroup timed out
+        assert int(step.item()) == 0                   # the optimizer step count did not advance
+        assert comm.timeouts_nowait() > 0 and comm.status()[1] == comm.timeouts_nowait()
+        theta, m, v, tgt = (torch.randn(n, device=dev) for _ in range(4))
+        saved = [t.clone() for t in (theta, m, v, tgt)]
+        st = torch.cuda.current_stream().cuda_stream
+        rc = comm.lib.naf_adam_polyak_fused(theta.data_ptr(), out.data_ptr(), m.data_ptr(), v.data_ptr(), tgt.data_ptr(),
+                                            part.data_ptr(), comm.n_partials, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-3, 0.999,
+                                            step.data_ptr(), 1.0 / world, n, st)
+        torch.cuda.synchronize()
+        assert rc == 0 and all(torch.equal(a, b) for a, b in zip((theta, m, v, tgt), saved))       # skipped, whole
+        try:
+            comm.raise_on_timeout()
+            raise AssertionError("raise_on_timeout() did not raise")
+        except NafHipError:
+            pass
     dist.barrier()
     comm.close()
     dist.destroy_process_group()
