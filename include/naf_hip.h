@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 3
+#define NAF_HIP_ABI_VERSION 4
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -126,7 +126,7 @@ int naf_head_fwd_bwd_mse(const float* heads_pre, int ldh, const float* u, int ld
 /* the same, fed by the split-K partial heads of naf_bn_relu_fwd_heads_partial: heads_partial[n_slabs][B][ldh] (main
  * net; slabs slab_stride >= B*ldh floats apart — keep it off a power of two, the n_slabs pieces of one row are read
  * together and would otherwise share an L2 channel and set
- * net) and vnext_partial[n_slabs][B] (target net's V column) are summed in slab order while being staged; n_slabs in {16, 32}. */
+ * net) and vnext_partial[n_slabs][B] (target net's V column) are summed in slab order while being staged; n_slabs in {4, 16, 32}. */
 int naf_head_fwd_bwd_mse_splitk(const float* heads_partial, int64_t slab_stride, const float* vnext_partial, int n_slabs,
                                 int ldh,
                                 const float* u, int ldu, const float* r, int ldr, float gamma, float* q_out,
@@ -223,6 +223,63 @@ int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int 
                                     int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu, const float* r, int ldr,
                                     float gamma, float* heads_out, float* q_out, float* d_heads, float* loss_partials, int B,
                                     int A, int p_mode, void* stream);
+
+/* ---- learn() at large batches: row-split kernels, two-stage batch statistics (csrc/big_batch.hip) --------------
+ * For B > 512 (BASELINE configs[3]: B = 1024, configs[4]: B = 2048) the batch is cut into NAF_BB_ROWS-row blocks that
+ * spread over the whole chip. BatchNorm1d's training-mode statistics (naf_neural_network.py:76-78 via torch) become two
+ * stages: the producer of a pre-activation tile writes per block and column (sum, sum of squared deviations from the
+ * BLOCK mean) into partials[net][B/64][H] (float2), every consumer folds the B/64 partials of its columns in block order
+ * (Chan's formula; fixed order, no atomics). B % 64 == 0, 64 <= B <= 2048, H % 64 == 0 everywhere below. */
+#define NAF_BB_ROWS 64
+/* layer 1 for `nets` networks, K = state size <= 32 (rows and W as in naf_linear_bn_relu_fwd_train). apply = 0: statistics
+ * partials only (gamma .. save_invstd unused, may be NULL); apply = 1: recompute z, fold the partials, out = ReLU(BN(z)),
+ * running statistics (by the block-0 workgroups), save_mean / save_invstd [nets][H]. */
+int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+                  const float* gamma, const float* beta, int64_t param_net_stride, float* partials, float* running_mean,
+                  float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
+                  float* save_mean, float* save_invstd, int B, int H, int nets, float momentum, float eps, int apply,
+                  void* stream);
+/* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K in {128, 256}, N % 64 == 0) on f32 MFMA, 64 x 32 tiles, with the
+ * column statistics partials of every 64-row block written by the epilogue: replaces `self.hidden_layer(x)`
+ * (naf_neural_network.py:78) and the statistics pass of bn2 for both networks. */
+int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
+                        int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B, int N,
+                        int K, int nets, void* stream);
+/* layer 2 of BOTH nets from the pre-activations z and their partials: fold, normalise, ReLU -> out (A2, ldo >= H), running
+ * statistics, and the heads Linears split over H/64 column slices exactly as naf_bn_relu_fwd_heads_partial does over H/8
+ * (heads_partial[H/64][B][NHP] slab_stride floats apart, vnext_partial[H/64][B]); the head kernel adds the slabs
+ * (naf_head_fwd_bwd_mse_splitk with n_slabs = H/64 = 4). */
+int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
+                                 int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
+                                 int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo, float* save_mean,
+                                 float* save_invstd, const float* Wh, int64_t wh_net_stride, int ldw, int NHP, int v_col,
+                                 float* heads_partial, int64_t slab_stride, float* vnext_partial, int B, int H,
+                                 float momentum, float eps, void* stream);
+/* backward of layer 2 in two launches. stage 1: dy = ReLU'(a2) * (d_heads[B][ldh] @ Wh[ldh][ldw]) -> dy_out, partials[B/64][H]
+ * = per-block (sum dy, sum dy*xhat). stage 2: folds them, dy -> dz in place, d_gamma / d_beta, and dz_col_partials[B/64][H]
+ * (block sums of dz: the Linear bias gradient, finalised by naf_bb_layer1_bwd_finish). */
+int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const float* Wh, int ldw, const float* z, int ldz, const float* a2,
+                            int lda, const float* save_mean, const float* save_invstd, float* dy_out, int ldd,
+                            float* partials, int B, int H, void* stream);
+int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz, const float* gamma, const float* save_mean,
+                         const float* save_invstd, const float* partials, float* d_gamma, float* d_beta,
+                         float* dz_col_partials, int B, int H, void* stream);
+/* backward of layer 1 (naf_bn_relu_bwd_wgrad's contract), row-split, three launches:
+ *   stage = 1: z recomputed from x and W (the forward's arithmetic), dy = ReLU'(out) * d_out, block sums -> partials[B/64][H]
+ *   stage = 2: folds them, dz, this block's share of dW = dZ^T X -> dw_slabs[B/64][H][KP] (KP = naf_bb_layer1_bwd_kp(K): 24
+ *              or 32) and its column sums of dz -> dz1_col_partials[B/64][H]
+ *   finish   : adds slabs and block sums in block order -> d_W[H][K], d_gamma, d_beta, d_bias (layer 1) and d_bias2 (layer 2,
+ *              from naf_bb_bn_bwd_stage2's dz_col_partials). K <= 26. sumsq_partials (nullable): [ceil(H/8)] sums of squares of
+ *              everything written here plus d_gamma2 / d_beta2 (then required: read, not written) — the gradient-norm
+ *              partials of all vector gradients; step_dev (nullable): *step_dev += 1 like naf_grad_norm_partials. */
+int naf_bb_layer1_bwd(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W, const float* bias,
+                      const float* out, int ldo, const float* gamma, const float* save_mean, const float* save_invstd,
+                      float* partials, float* dw_slabs, float* dz1_col_partials, int B, int H, int stage, void* stream);
+int naf_bb_layer1_bwd_kp(int K);
+int naf_bb_layer1_bwd_finish(const float* dw_slabs, int K, const float* partials1, const float* dz1_col_partials,
+                             const float* dz2_col_partials, int nb, float* d_W, float* d_gamma, float* d_beta, float* d_bias,
+                             float* d_bias2, const float* d_gamma2, const float* d_beta2, float* sumsq_partials,
+                             int32_t* step_dev, int H, void* stream);
 
 /* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
 /* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is

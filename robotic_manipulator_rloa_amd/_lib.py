@@ -15,8 +15,8 @@ from typing import Optional
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
-SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "gemm_bundle.hip", "optim.hip", "synth_env.hip",
-           "xgmi_reduce.hip", "policy_act.hip"]
+SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "big_batch.hip", "gemm_bundle.hip", "optim.hip",
+           "synth_env.hip", "xgmi_reduce.hip", "policy_act.hip"]
 HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
@@ -145,6 +145,16 @@ _PROTOS = {
                                       _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
     "naf_heads_gemm_head_fwd_bwd_mse": [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i,
                                         _i, _i, _vp],
+    "naf_bb_layer1": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _f,
+                      _i, _vp],
+    "naf_bb_linear_stats": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp],
+    "naf_bb_bn_relu_heads_partial": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
+                                     _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
+    "naf_bb_heads_bwd_stage1": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "naf_bb_bn_bwd_stage2": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_bb_layer1_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "naf_bb_layer1_bwd_kp": [_i],
+    "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],

@@ -1,0 +1,885 @@
+// learn() at LARGE batches (B > 512: BASELINE configs[3] B = 1024, configs[4] B = 2048) for gfx950.
+//
+// The kernels of fused_layers.hip own whole feature columns (8 columns x ALL B rows per workgroup) so that BatchNorm's
+// batch statistics never leave the workgroup: 32-64 workgroups, ceil(B/64) rows per thread in registers — right for
+// B <= 512 where an update is launch-latency bound, wrong beyond it (a quarter of the chip busy, register spills).
+// Here the batch is split into 64-row blocks that spread over the whole chip, and BatchNorm becomes TWO-STAGE:
+//   stage 1  the kernel that produces a pre-activation tile also writes, per 64-row block and column, the block's
+//            (sum, M2 = sum of squared deviations from the BLOCK mean)           -> partials[net][block][column]
+//   stage 2  every consumer folds the B/64 partials of the columns it touches in block order (Chan's pairwise formula,
+//            fixed order => bitwise reproducible, no atomics) in its prologue, then normalises on the fly.
+// The backward statistics (sum dy, sum dy*xhat) go the same way. Replaces, for both networks in one launch each,
+// naf_neural_network.py:76-87 (forward), its autograd, and the BatchNorm1d training-mode statistics of torch.
+//
+// Chain of one update (Learner.learn_rows, fuse = "bb"):
+//   bb_layer1_stats -> bb_layer1_apply -> bb_linear_stats (f32 MFMA GEMM 2, statistics in the epilogue) ->
+//   bb_bn_relu_heads_partial (BN2 + ReLU + heads GEMM split over 4 column slices) -> naf_head_kernel<.., 4 slabs> ->
+//   bb_heads_bwd_stage1 (dA2 = dH Wh on the fly, ReLU mask, backward partials) -> bb_bn_bwd_stage2 (dZ2) ->
+//   gemm_bundle (dWh, dW2, dA1) -> bb_layer1_bwd (column-owning, streaming) -> grad norm -> Adam + Polyak
+#include <string.h>
+#include "bn_tile.h"
+#include "../../include/naf_hip.h"
+
+#define BB_ROWS NAF_BB_ROWS      // rows per statistics block
+#define BB_COLS 64               // feature columns per workgroup (row-split kernels)
+#define BB_THREADS 256
+#define BB_MAX_K4 8              // layer 1: K <= 32
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- stage 2 of the batch statistics: fold the NB block partials of one column, in block order -----------------
+__device__ static inline void bb_fold_stats(const float2* __restrict__ p, int H, int NB, int B, int col, float* mean,
+                                            float* var) {
+    float S = 0.f;
+#pragma unroll 8
+    for (int rb = 0; rb < NB; ++rb) S += p[(int64_t)rb * H + col].x;
+    const float m = S / (float)B;
+    float M2 = 0.f;
+#pragma unroll 8
+    for (int rb = 0; rb < NB; ++rb) {
+        const float2 v = p[(int64_t)rb * H + col];
+        const float d = v.x * (1.0f / BB_ROWS) - m;
+        M2 += v.y + (float)BB_ROWS * d * d;
+    }
+    *mean = m;
+    *var = M2 / (float)B;      // biased: what normalises
+}
+
+// sums over the 64 rows of a tile held as one value per (row, column) in LDS [64][BB_COLS + 1]: thread c < 64 adds
+// column c in row order
+__device__ static inline float bb_col_sum64(const float (*t)[BB_COLS + 1], int c) {
+    float s = 0.f;
+#pragma unroll 16
+    for (int r = 0; r < BB_ROWS; ++r) s += t[r][c];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// layer 1 (K = state size <= 32): z tile of 64 rows x 64 columns, thread (ty = tid >> 4, tx = tid & 15) owns rows
+// 4 ty .. +3 and columns 4 tx .. +3. Operands go through LDS TRANSPOSED ([k][row], [k][column]) so that a thread's four
+// rows / four columns are one 16-byte LDS read per k. z = b + sum_k x_k w_k, k ascending — the SAME code in the
+// statistics launch, the normalising launch and the backward, so z is the same bits everywhere.
+// ------------------------------------------------------------------------------------------------------------
+template <int K4>
+__device__ static inline void bb_l1_stage(const float* __restrict__ x, int ldx, int row0, const float* __restrict__ W, int K,
+                                          int col0, int H, float (*sXt)[BB_ROWS + 4], float (*sWt)[BB_COLS + 4], int tid) {
+    // X tile: 64 rows x K4 float4
+    for (int e = tid; e < BB_ROWS * K4; e += BB_THREADS) {
+        const int row = e / K4, q = e - row * K4;
+        const float4 v = ((const float4*)(x + (int64_t)(row0 + row) * ldx))[q];
+        sXt[4 * q + 0][row] = v.x;
+        sXt[4 * q + 1][row] = v.y;
+        sXt[4 * q + 2][row] = v.z;
+        sXt[4 * q + 3][row] = v.w;
+    }
+    // W tile: 64 columns x K floats (rows of the [H][K] matrix are K floats apart: scalar loads, 6 KB in all)
+    for (int e = tid; e < BB_COLS * 4 * K4; e += BB_THREADS) {
+        const int c = e / (4 * K4), k = e - c * (4 * K4);
+        sWt[k][c] = (k < K && col0 + c < H) ? W[(int64_t)(col0 + c) * K + k] : 0.f;
+    }
+}
+
+template <int K4>
+__device__ static inline void bb_l1_tile(const float (*sXt)[BB_ROWS + 4], const float (*sWt)[BB_COLS + 4], const float4 bias4,
+                                         int ty, int tx, float (&z)[4][4]) {
+    const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[i][j] = bb[j];
+#pragma unroll
+    for (int k = 0; k < 4 * K4; ++k) {
+        const float4 a = *(const float4*)&sXt[k][4 * ty];
+        const float4 w = *(const float4*)&sWt[k][4 * tx];
+        const float av[4] = {a.x, a.y, a.z, a.w}, wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[i][j] = __builtin_fmaf(av[i], wv[j], z[i][j]);
+    }
+}
+
+// column sums of a thread-tiled 64 x 64 tile (4 x 4 per thread, tid = 16 ty + tx): 4 rows in the thread, 4 row groups in
+// the wave (lane bits 4, 5), 4 waves through LDS. Every thread returns the sums of ITS four columns. Fixed order.
+__device__ static inline void bb_tile_col_sums(const float (&v)[4][4], float (*red)[BB_COLS], int tid, int tx, float (&out)[4]) {
+    float s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[j] = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
+        s[j] += __shfl_xor(s[j], 16);
+        s[j] += __shfl_xor(s[j], 32);
+    }
+    __syncthreads();                 // previous use of red is over
+    if ((tid & 63) < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[tid >> 6][4 * tx + j] = s[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (red[0][4 * tx + j] + red[1][4 * tx + j]) + (red[2][4 * tx + j] + red[3][4 * tx + j]);
+}
+
+template <int K4, bool APPLY>
+__global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
+    const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+    int64_t param_net_stride, float2* __restrict__ partials, float* __restrict__ running_mean,
+    float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out, int64_t out_net_stride, int ldo,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, int B, int H, float momentum, float eps) {
+    __shared__ __attribute__((aligned(16))) float sXt[4 * K4][BB_ROWS + 4];
+    __shared__ __attribute__((aligned(16))) float sWt[4 * K4][BB_COLS + 4];
+    __shared__ float red[4][BB_COLS];
+    __shared__ float sStat[4][BB_COLS];     // APPLY: mean, invstd, gamma, beta of this workgroup's columns
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS, net = blockIdx.z;
+    const int NB = gridDim.x;
+    const int64_t po = net * param_net_stride;
+    bb_l1_stage<K4>(x + net * x_net_stride, ldx, rb * BB_ROWS, W + po, K, col0, H, sXt, sWt, tid);
+    const float4 b4 = *(const float4*)(bias + po + col0 + 4 * tx);
+    const float2* pn = partials + (int64_t)net * NB * H;
+    if (APPLY && tid < BB_COLS) {
+        const int col = col0 + tid;
+        float mean, var;
+        bb_fold_stats(pn, H, NB, B, col, &mean, &var);
+        const float invstd = 1.0f / sqrtf(var + eps);
+        sStat[0][tid] = mean;
+        sStat[1][tid] = invstd;
+        sStat[2][tid] = gamma[po + col];
+        sStat[3][tid] = beta[po + col];
+        if (rb == 0) {
+            const int64_t so = net * stat_net_stride + col;
+            const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+            running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
+            running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+            save_mean[(int64_t)net * H + col] = mean;
+            save_invstd[(int64_t)net * H + col] = invstd;
+        }
+    }
+    __syncthreads();
+    float z[4][4];
+    bb_l1_tile<K4>(sXt, sWt, b4, ty, tx, z);
+    if (!APPLY) {
+        float S[4], M2[4], d[4][4];
+        bb_tile_col_sums(z, red, tid, tx, S);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = z[i][j] - S[j] * (1.0f / BB_ROWS);
+                d[i][j] = t * t;
+            }
+        bb_tile_col_sums(d, red, tid, tx, M2);
+        if (ty == 0) {
+            float2* dst = partials + ((int64_t)net * NB + rb) * H + col0 + 4 * tx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = make_float2(S[j], M2[j]);
+        }
+    } else {
+        float* oz = out + net * out_net_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 y;
+            float* yp = (float*)&y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * tx + j;
+                const float t = (z[i][j] - sStat[0][c]) * sStat[1][c] * sStat[2][c] + sStat[3][c];
+                yp[j] = t > 0.f ? t : 0.f;
+            }
+            *(float4*)(oz + (int64_t)(rb * BB_ROWS + 4 * ty + i) * ldo + col0 + 4 * tx) = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GEMM 2 (and any Linear with K <= 256): Z[net] = A[net] W[net]^T + bias on v_mfma_f32_16x16x4_f32, 64 x 32 output tile
+// per workgroup (4 waves: wave = (wm, wn) owns rows 32 wm .. +31 = two 16-row MFMA tiles, columns 16 wn .. +15), the
+// whole K staged into LDS at once (all of a thread's 24 16-byte loads in flight together), and the column statistics of
+// the 64-row block in the epilogue. 2 B / 64 x H / 32 workgroups: 256 at B = 1024, H = 256.
+// ------------------------------------------------------------------------------------------------------------
+#define BL_BM 64
+#define BL_BN 32
+#define BL_KMAX 256
+#define BL_LD (BL_KMAX + 4)
+__global__ __launch_bounds__(BB_THREADS) void bb_linear_stats_kernel(const float* __restrict__ a, int64_t a_net_stride,
+                                                                     int lda, const float* __restrict__ W,
+                                                                     const float* __restrict__ bias,
+                                                                     int64_t param_net_stride, float* __restrict__ z,
+                                                                     int64_t z_net_stride, int ldz,
+                                                                     float2* __restrict__ partials, int B, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float sA[BL_BM * BL_LD];
+    __shared__ __attribute__((aligned(16))) float sB[BL_BN * BL_LD];
+    __shared__ float red[2][BL_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NB = B / BB_ROWS;
+    const int net = blockIdx.x / NB, rb = blockIdx.x - net * NB;
+    const int n0 = blockIdx.y * BL_BN;
+    const float* an = a + net * a_net_stride + (int64_t)rb * BL_BM * lda;
+    const float* wn_ = W + net * param_net_stride + (int64_t)n0 * K;     // [N][K] row-major
+    const int k4n = K >> 2;                                             // float4 per row
+    {
+        // A: 64 rows x K, B: 32 rows x K; every load issued before the first LDS store
+        float4 va[BL_BM * BL_KMAX / 4 / BB_THREADS], vb[BL_BN * BL_KMAX / 4 / BB_THREADS];
+        const int shift = k4n == 64 ? 6 : 5;                             // K = 256 or 128 (checked on the host)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + BB_THREADS * i;
+            const int row = e >> shift, q = e & (k4n - 1);
+            va[i] = (row < BL_BM) ? ((const float4*)(an + (int64_t)row * lda))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + BB_THREADS * i;
+            const int row = e >> shift, q = e & (k4n - 1);
+            vb[i] = (row < BL_BN) ? ((const float4*)(wn_ + (int64_t)row * K))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + BB_THREADS * i;
+            const int row = e >> shift, q = e & (k4n - 1);
+            if (row < BL_BM) *(float4*)(sA + row * BL_LD + 4 * q) = va[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + BB_THREADS * i;
+            const int row = e >> shift, q = e & (k4n - 1);
+            if (row < BL_BN) *(float4*)(sB + row * BL_LD + 4 * q) = vb[i];
+        }
+    }
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const float bcol = bias[net * param_net_stride + n0 + 16 * wn + r];
+    __syncthreads();
+    f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+    const float* pa0 = sA + (32 * wm + r) * BL_LD + 4 * g;
+    const float* pa1 = pa0 + 16 * BL_LD;
+    const float* pb = sB + (16 * wn + r) * BL_LD + 4 * g;
+#pragma unroll 4
+    for (int kk = 0; kk < K; kk += 16) {
+        const float4 a0 = *(const float4*)(pa0 + kk), a1 = *(const float4*)(pa1 + kk), b = *(const float4*)(pb + kk);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc[1][1], 0, 0, 0);
+    }
+    // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+    float v[2][4];
+    float s = 0.f;
+    float* zn = z + net * z_net_stride + (int64_t)(rb * BL_BM + 32 * wm + 4 * g) * ldz + n0 + 16 * wn + r;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[mt][e] = (acc[mt][0][e] + acc[mt][1][e]) + bcol;
+            zn[(int64_t)(16 * mt + e) * ldz] = v[mt][e];
+            s += v[mt][e];
+        }
+    // column statistics of the 64-row block: 8 rows in the lane, 4 lane groups (bits 4, 5), 2 waves (wm) through LDS
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (g == 0) red[wm][16 * wn + r] = s;
+    __syncthreads();
+    const float S = red[0][16 * wn + r] + red[1][16 * wn + r];
+    const float mb = S * (1.0f / BB_ROWS);
+    float m2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = v[mt][e] - mb;
+            m2 += t * t;
+        }
+    m2 += __shfl_xor(m2, 16);
+    m2 += __shfl_xor(m2, 32);
+    __syncthreads();
+    if (g == 0) red[wm][16 * wn + r] = m2;
+    __syncthreads();
+    if (wm == 0 && g == 0)
+        partials[((int64_t)net * NB + rb) * N + n0 + 16 * wn + r] = make_float2(S, red[0][16 * wn + r] + red[1][16 * wn + r]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// layer 2, stage 2 + heads: fold the statistics of this workgroup's 64 columns, normalise + ReLU its 64 x 64 tile of Z2
+// (written out as A2 for the backward GEMMs), and multiply the tile — still in LDS — with Wh[:, 64 columns]: the heads
+// GEMM split over H/64 column slices. Main net: all NHP head columns; target net: the V column only.
+// ------------------------------------------------------------------------------------------------------------
+template <int NH4>
+__global__ __launch_bounds__(BB_THREADS) void bb_bn_relu_heads_partial_kernel(
+    const float* __restrict__ z, int64_t z_net_stride, int ldz, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int64_t param_net_stride, const float2* __restrict__ partials,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out,
+    int64_t out_net_stride, int ldo, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    const float* __restrict__ Wh, int64_t wh_net_stride, int ldw, int v_col, float* __restrict__ heads_partial,
+    int64_t slab_stride, float* __restrict__ vnext_partial, int B, int H, float momentum, float eps) {
+    constexpr int NHP = 4 * NH4, HPT = NHP / 4;          // heads per thread (main net): 4 threads share a row
+    __shared__ __attribute__((aligned(16))) float sA[BB_ROWS][BB_COLS + 4];
+    __shared__ __attribute__((aligned(16))) float sW[NHP][BB_COLS + 4];
+    __shared__ float sStat[4][BB_COLS];
+    __shared__ float sBias[NHP];
+    const int tid = threadIdx.x;
+    const int rb = blockIdx.x, slice = blockIdx.y, net = blockIdx.z, col0 = slice * BB_COLS;
+    const int NB = gridDim.x;
+    const int64_t po = net * param_net_stride;
+    const float* zn = z + net * z_net_stride + (int64_t)rb * BB_ROWS * ldz + col0;
+    // the tile's loads first (4 float4 per thread), the statistics fold runs under them
+    float4 zv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zv[i] = *(const float4*)(zn + (int64_t)((tid >> 4) + 16 * i) * ldz + 4 * (tid & 15));
+    const float* Whn = Wh + net * wh_net_stride;
+    if (net == 0) {
+        for (int e = tid; e < NHP * (BB_COLS / 4); e += BB_THREADS) {
+            const int h = e / (BB_COLS / 4), q = e - h * (BB_COLS / 4);
+            *(float4*)&sW[h][4 * q] = *(const float4*)(Whn + (int64_t)h * ldw + col0 + 4 * q);
+        }
+        if (tid < NHP) sBias[tid] = slice == 0 ? Whn[(int64_t)tid * ldw + H] : 0.f;      // bias = column H (ones column of A2)
+    } else {
+        if (tid < BB_COLS / 4) *(float4*)&sW[0][4 * tid] = *(const float4*)(Whn + (int64_t)v_col * ldw + col0 + 4 * tid);
+        if (tid == 0) sBias[0] = slice == 0 ? Whn[(int64_t)v_col * ldw + H] : 0.f;
+    }
+    if (tid < BB_COLS) {
+        const int col = col0 + tid;
+        float mean, var;
+        bb_fold_stats(partials + (int64_t)net * NB * H, H, NB, B, col, &mean, &var);
+        const float invstd = 1.0f / sqrtf(var + eps);
+        sStat[0][tid] = mean;
+        sStat[1][tid] = invstd;
+        sStat[2][tid] = gamma[po + col];
+        sStat[3][tid] = beta[po + col];
+        if (rb == 0) {
+            const int64_t so = net * stat_net_stride + col;
+            const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+            running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
+            running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+            save_mean[(int64_t)net * H + col] = mean;
+            save_invstd[(int64_t)net * H + col] = invstd;
+        }
+    }
+    __syncthreads();
+    float* on = out + net * out_net_stride + (int64_t)rb * BB_ROWS * ldo + col0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 16 * i, c = 4 * (tid & 15);
+        float4 y;
+        y.x = (zv[i].x - sStat[0][c + 0]) * sStat[1][c + 0] * sStat[2][c + 0] + sStat[3][c + 0];
+        y.y = (zv[i].y - sStat[0][c + 1]) * sStat[1][c + 1] * sStat[2][c + 1] + sStat[3][c + 1];
+        y.z = (zv[i].z - sStat[0][c + 2]) * sStat[1][c + 2] * sStat[2][c + 2] + sStat[3][c + 2];
+        y.w = (zv[i].w - sStat[0][c + 3]) * sStat[1][c + 3] * sStat[2][c + 3] + sStat[3][c + 3];
+        y.x = y.x > 0.f ? y.x : 0.f;
+        y.y = y.y > 0.f ? y.y : 0.f;
+        y.z = y.z > 0.f ? y.z : 0.f;
+        y.w = y.w > 0.f ? y.w : 0.f;
+        *(float4*)(on + (int64_t)row * ldo + c) = y;
+        *(float4*)&sA[row][c] = y;
+    }
+    __syncthreads();
+    const int row = tid >> 2, hq = tid & 3;
+    if (net == 0) {
+        // thread = (row, quarter of the heads): HPT heads x 64 k, k ascending
+        float acc[HPT];
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) acc[j] = sBias[hq * HPT + j];
+#pragma unroll 4
+        for (int c = 0; c < BB_COLS; c += 4) {
+            const float4 a = *(const float4*)&sA[row][c];
+#pragma unroll
+            for (int j = 0; j < HPT; ++j) {
+                const float4 w = *(const float4*)&sW[hq * HPT + j][c];
+                acc[j] = __builtin_fmaf(a.x, w.x, acc[j]);
+                acc[j] = __builtin_fmaf(a.y, w.y, acc[j]);
+                acc[j] = __builtin_fmaf(a.z, w.z, acc[j]);
+                acc[j] = __builtin_fmaf(a.w, w.w, acc[j]);
+            }
+        }
+        float* dst = heads_partial + (int64_t)slice * slab_stride + (int64_t)(rb * BB_ROWS + row) * NHP + hq * HPT;
+#pragma unroll
+        for (int j = 0; j < HPT; j += 4) *(float4*)(dst + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    } else {
+        // V'(s') share of this slice: 4 threads per row, 16 k each, folded by two xor shuffles (fixed order)
+        float p = 0.f;
+#pragma unroll
+        for (int c = 16 * hq; c < 16 * hq + 16; c += 4) {
+            const float4 a = *(const float4*)&sA[row][c];
+            const float4 w = *(const float4*)&sW[0][c];
+            p = __builtin_fmaf(a.x, w.x, p);
+            p = __builtin_fmaf(a.y, w.y, p);
+            p = __builtin_fmaf(a.z, w.z, p);
+            p = __builtin_fmaf(a.w, w.w, p);
+        }
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        if (hq == 0) vnext_partial[(int64_t)slice * B + rb * BB_ROWS + row] = p + sBias[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward of layer 2, stage 1: dA2 = dHeads Wh (reduction over the NHP <= 48 head outputs, on the fly), ReLU mask from
+// A2, xhat from Z2 and the saved statistics; writes dY2 and the per-block column sums (sum dy, sum dy*xhat).
+// ------------------------------------------------------------------------------------------------------------
+template <int NH4>
+__global__ __launch_bounds__(BB_THREADS) void bb_heads_bwd_stage1_kernel(
+    const float* __restrict__ d_heads, int ldh, const float* __restrict__ Wh, int ldw, const float* __restrict__ z, int ldz,
+    const float* __restrict__ a2, int lda, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+    float* __restrict__ dy_out, int ldd, float2* __restrict__ partials, int B, int H) {
+    constexpr int NHP = 4 * NH4;
+    __shared__ __attribute__((aligned(16))) float sDH[BB_ROWS][NHP + 4];
+    __shared__ __attribute__((aligned(16))) float sW[NHP][BB_COLS + 4];
+    __shared__ float sT[BB_ROWS][BB_COLS + 1];
+    __shared__ float sStat[2][BB_COLS];
+    const int tid = threadIdx.x;
+    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS;
+    const int row = tid >> 2, cq = tid & 3;               // thread = (row, 16 columns)
+    const int64_t grow = (int64_t)rb * BB_ROWS + row;
+    float4 zv[4], av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        zv[i] = *(const float4*)(z + grow * ldz + col0 + 16 * cq + 4 * i);
+        av[i] = *(const float4*)(a2 + grow * lda + col0 + 16 * cq + 4 * i);
+    }
+    for (int e = tid; e < BB_ROWS * NH4; e += BB_THREADS) {
+        const int r_ = e / NH4, q = e - r_ * NH4;
+        *(float4*)&sDH[r_][4 * q] = *(const float4*)(d_heads + ((int64_t)rb * BB_ROWS + r_) * ldh + 4 * q);
+    }
+    for (int e = tid; e < NHP * (BB_COLS / 4); e += BB_THREADS) {
+        const int h = e / (BB_COLS / 4), q = e - h * (BB_COLS / 4);
+        *(float4*)&sW[h][4 * q] = *(const float4*)(Wh + (int64_t)h * ldw + col0 + 4 * q);
+    }
+    if (tid < BB_COLS) {
+        sStat[0][tid] = save_mean[col0 + tid];
+        sStat[1][tid] = save_invstd[col0 + tid];
+    }
+    __syncthreads();
+    float4 dd[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                    make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll 4
+    for (int h = 0; h < NHP; ++h) {
+        const float d = sDH[row][h];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 w = *(const float4*)&sW[h][16 * cq + 4 * i];
+            dd[i].x = __builtin_fmaf(d, w.x, dd[i].x);
+            dd[i].y = __builtin_fmaf(d, w.y, dd[i].y);
+            dd[i].z = __builtin_fmaf(d, w.z, dd[i].z);
+            dd[i].w = __builtin_fmaf(d, w.w, dd[i].w);
+        }
+    }
+    float xh[16], dy[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w}, aa[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+        const float d4[4] = {dd[i].x, dd[i].y, dd[i].z, dd[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 16 * cq + 4 * i + j;
+            xh[4 * i + j] = (zz[j] - sStat[0][c]) * sStat[1][c];
+            dy[4 * i + j] = aa[j] > 0.f ? d4[j] : 0.f;      // ReLU mask from the forward's own output
+        }
+        *(float4*)(dy_out + grow * ldd + col0 + 16 * cq + 4 * i) =
+            make_float4(dy[4 * i], dy[4 * i + 1], dy[4 * i + 2], dy[4 * i + 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sT[row][16 * cq + j] = dy[j];
+    __syncthreads();
+    float s_dy = 0.f, s_dyxh = 0.f;
+    if (tid < BB_COLS) s_dy = bb_col_sum64(sT, tid);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sT[row][16 * cq + j] = dy[j] * xh[j];
+    __syncthreads();
+    if (tid < BB_COLS) {
+        s_dyxh = bb_col_sum64(sT, tid);
+        partials[(int64_t)rb * H + col0 + tid] = make_float2(s_dy, s_dyxh);
+    }
+}
+
+// stage 2: fold the backward sums, dz = gamma invstd (dy - sum_dy/B - xhat sum_dyxhat/B) in place over dy; block 0 of a
+// column slice writes d_gamma / d_beta; every block leaves its column sums of dz (the Linear bias gradient under a
+// train-mode BatchNorm: zero up to rounding) for the consumer that finalises d_bias.
+__global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __restrict__ dy, int ldd,
+                                                                      const float* __restrict__ z, int ldz,
+                                                                      const float* __restrict__ gamma,
+                                                                      const float* __restrict__ save_mean,
+                                                                      const float* __restrict__ save_invstd,
+                                                                      const float2* __restrict__ partials,
+                                                                      float* __restrict__ d_gamma, float* __restrict__ d_beta,
+                                                                      float* __restrict__ dz_col_partials, int B, int H) {
+    __shared__ float sT[BB_ROWS][BB_COLS + 1];
+    __shared__ float sC[5][BB_COLS];          // mean, invstd, k1, sum_dy / B, sum_dyxh / B
+    const int tid = threadIdx.x;
+    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS, NB = gridDim.x;
+    const int row = tid >> 2, cq = tid & 3;
+    const int64_t grow = (int64_t)rb * BB_ROWS + row;
+    float4 zv[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        zv[i] = *(const float4*)(z + grow * ldz + col0 + 16 * cq + 4 * i);
+        dv[i] = *(const float4*)(dy + grow * ldd + col0 + 16 * cq + 4 * i);
+    }
+    if (tid < BB_COLS) {
+        const int col = col0 + tid;
+        float sdy = 0.f, sdx = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) {
+            const float2 p = partials[(int64_t)k * H + col];
+            sdy += p.x;
+            sdx += p.y;
+        }
+        const float invstd = save_invstd[col];
+        sC[0][tid] = save_mean[col];
+        sC[1][tid] = invstd;
+        sC[2][tid] = gamma[col] * invstd;
+        sC[3][tid] = sdy / (float)B;
+        sC[4][tid] = sdx / (float)B;
+        if (rb == 0) {
+            d_gamma[col] = sdx;
+            d_beta[col] = sdy;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w}, d4[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 16 * cq + 4 * i + j;
+            const float xh = (zz[j] - sC[0][c]) * sC[1][c];
+            o[j] = sC[2][c] * (d4[j] - sC[3][c] - xh * sC[4][c]);
+            sT[row][c] = o[j];
+        }
+        *(float4*)(dy + grow * ldd + col0 + 16 * cq + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    if (tid < BB_COLS) dz_col_partials[(int64_t)rb * H + col0 + tid] = bb_col_sum64(sT, tid);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward of layer 1 (one network), row-split like the rest: three short launches instead of one column-owning kernel
+// that walks all B rows (measured at B = 1024 / 2048: 37.8 / 94.5 us for a streaming column owner — eight serial
+// stage -> barrier -> compute rounds per pass on 32 workgroups — against three launches of a few us each).
+//   stage 1   z recomputed from X and W1 (the forward's arithmetic), xhat, dy = ReLU'(A1) * dA1, block sums (sum dy,
+//             sum dy*xhat) per column                                                  -> partials[B/64][H]
+//   stage 2   the same recomputation, the folded sums, dz; the block's share of dW1 = dZ1^T X (64 columns x K) as a
+//             slab, and the block's column sums of dz                                  -> dw_slabs[B/64][H][KP], dzp[B/64][H]
+//   finish    slabs and block sums added in block order -> dW1, d_gamma1, d_beta1, d_bias1, and the bias gradient of
+//             layer 2 from ITS block sums; optionally the sum of squares of every vector gradient (both layers) for the
+//             gradient norm
+// ------------------------------------------------------------------------------------------------------------
+template <int K4, bool STAGE2>
+__global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
+    const float* __restrict__ d_out, int ld_dout, const float* __restrict__ x, int ldx, int K, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ out, int ldo, const float* __restrict__ gamma,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float2* __restrict__ partials,
+    float* __restrict__ dw_slabs, float* __restrict__ dz_col_partials, int B, int H) {
+    constexpr int KP = 4 * K4;
+    __shared__ __attribute__((aligned(16))) float sXt[KP][BB_ROWS + 4];
+    __shared__ __attribute__((aligned(16))) float sWt[KP][BB_COLS + 4];
+    __shared__ float red[4][BB_COLS];
+    __shared__ float sC[5][BB_COLS];                     // mean, invstd, k1, sum_dy / B, sum_dyxh / B
+    __shared__ float sDZ[STAGE2 ? BB_ROWS : 1][BB_COLS + 1];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS, NB = gridDim.x;
+    // this thread's 4 x 4 of dA1 and A1 first, the tile operands behind them
+    float4 dv[4], ov[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = (int64_t)rb * BB_ROWS + 4 * ty + i;
+        dv[i] = *(const float4*)(d_out + row * ld_dout + col0 + 4 * tx);
+        ov[i] = *(const float4*)(out + row * ldo + col0 + 4 * tx);
+    }
+    bb_l1_stage<K4>(x, ldx, rb * BB_ROWS, W, K, col0, H, sXt, sWt, tid);
+    const float4 b4 = *(const float4*)(bias + col0 + 4 * tx);
+    if (tid < BB_COLS) {
+        const int col = col0 + tid;
+        const float invstd = save_invstd[col];
+        sC[0][tid] = save_mean[col];
+        sC[1][tid] = invstd;
+        if (STAGE2) {
+            float sdy = 0.f, sdx = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < NB; ++k) {
+                const float2 p = partials[(int64_t)k * H + col];
+                sdy += p.x;
+                sdx += p.y;
+            }
+            sC[2][tid] = gamma[col] * invstd;
+            sC[3][tid] = sdy / (float)B;
+            sC[4][tid] = sdx / (float)B;
+        }
+    }
+    __syncthreads();
+    float z[4][4];
+    bb_l1_tile<K4>(sXt, sWt, b4, ty, tx, z);
+    float dy[4][4], dyxh[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float d4[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w}, o4[4] = {ov[i].x, ov[i].y, ov[i].z, ov[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * tx + j;
+            const float xh = (z[i][j] - sC[0][c]) * sC[1][c];
+            const float d = o4[j] > 0.f ? d4[j] : 0.f;
+            if (!STAGE2) {
+                dy[i][j] = d;
+                dyxh[i][j] = d * xh;
+            } else {
+                sDZ[4 * ty + i][c] = sC[2][c] * (d - sC[3][c] - xh * sC[4][c]);
+            }
+        }
+    }
+    if (!STAGE2) {
+        float s1[4], s2[4];
+        bb_tile_col_sums(dy, red, tid, tx, s1);
+        bb_tile_col_sums(dyxh, red, tid, tx, s2);
+        if (ty == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) partials[(int64_t)rb * H + col0 + 4 * tx + j] = make_float2(s1[j], s2[j]);
+        }
+        return;
+    }
+    __syncthreads();
+    // dW slab of this block: thread = (column c, quarter kq of the k range): sum over the 64 rows, row ascending
+    {
+        constexpr int KQ = KP / 4;
+        const int c = tid >> 2, kq = tid & 3;
+        float acc[KQ];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) acc[k] = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < BB_ROWS; ++r) {
+            const float dz = sDZ[r][c];
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) acc[k] = __builtin_fmaf(dz, sXt[KQ * kq + k][r], acc[k]);
+        }
+        float* dst = dw_slabs + ((int64_t)rb * H + col0 + c) * KP + KQ * kq;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) dst[k] = acc[k];
+    }
+    if (tid < BB_COLS) {
+        float sdz = 0.f;
+#pragma unroll 16
+        for (int r = 0; r < BB_ROWS; ++r) sdz += sDZ[r][tid];
+        dz_col_partials[(int64_t)rb * H + col0 + tid] = sdz;
+    }
+}
+
+// finish: one workgroup per 8 columns, thread = (column, k lane of 32)
+#define BF_COLS 8
+__global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
+    const float* __restrict__ dw_slabs, int KP, int K, const float2* __restrict__ partials1,
+    const float* __restrict__ dz1_col_partials, const float* __restrict__ dz2_col_partials, int NB,
+    float* __restrict__ d_W, float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias,
+    float* __restrict__ d_bias2, const float* __restrict__ d_gamma2, const float* __restrict__ d_beta2,
+    float* __restrict__ sumsq_partials, int32_t* step_dev, int H) {
+    __shared__ float sQ[BB_THREADS / 64];
+    const int tid = threadIdx.x, c = tid >> 5, k = tid & 31;
+    const int col = blockIdx.x * BF_COLS + c;
+    float sq = 0.f;
+    if (col < H) {
+        if (k < K) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int rb = 0; rb < NB; ++rb) s += dw_slabs[((int64_t)rb * H + col) * KP + k];
+            d_W[(int64_t)col * K + k] = s;
+            sq = s * s;
+        }
+        // the vector gradients of this column go to lanes that have no k to sum (K <= 26)
+        if (k == 27 || k == 28) {
+            float a = 0.f, b = 0.f;
+#pragma unroll 8
+            for (int rb = 0; rb < NB; ++rb) {
+                const float2 p = partials1[(int64_t)rb * H + col];
+                a += p.x;
+                b += p.y;
+            }
+            const float v = k == 27 ? b : a;               // d_gamma = sum dy*xhat, d_beta = sum dy
+            (k == 27 ? d_gamma : d_beta)[col] = v;
+            sq += v * v;
+        } else if (k == 29 || k == 30) {
+            const float* src = k == 29 ? dz1_col_partials : dz2_col_partials;
+            float* dst = k == 29 ? d_bias : d_bias2;
+            float s = 0.f;
+            for (int rb = 0; rb < NB; ++rb) s += src[(int64_t)rb * H + col];
+            dst[col] = s;
+            sq += s * s;
+        } else if (k == 31 && d_gamma2) {
+            const float g = d_gamma2[col], b = d_beta2[col];   // written by bb_bn_bwd_stage2, an earlier launch
+            sq += g * g + b * b;
+        }
+    }
+    if (sumsq_partials) {
+        const float tot = block_sum_to_thread0<BB_THREADS, true>(sq, sQ, tid);
+        if (tid == 0) {
+            sumsq_partials[blockIdx.x] = tot;
+            if (blockIdx.x == 0 && step_dev) *step_dev += 1;   // read by the NEXT launch (Adam) only
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && (B % BB_ROWS) == 0 && B <= 32 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
+
+extern "C" int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+                             const float* gamma, const float* beta, int64_t param_net_stride, float* partials,
+                             float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
+                             int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, int B, int H, int nets,
+                             float momentum, float eps, int apply, void* stream) {
+    if (!x || !W || !bias || !partials || !bb_shape_ok(B, H) || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4) return NAF_ERR_ARG;
+    if (apply && (!gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd || ldo < H || (ldo & 3)))
+        return NAF_ERR_ARG;
+    const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
+    if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d || (x_net_stride & 3) != 0) return NAF_ERR_ARG;
+    if ((((uintptr_t)bias | (uintptr_t)out) & 15) != 0 || (param_net_stride & 3) != 0 || (out_net_stride & 3) != 0 ||
+        ((uintptr_t)partials & 7) != 0)
+        return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B / BB_ROWS, H / BB_COLS, nets);
+#define BB_L1(K4V, AP)                                                                                                   \
+    bb_layer1_kernel<K4V, AP><<<grid, BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, \
+                                                           (float2*)partials, running_mean, running_var, stat_net_stride,  \
+                                                           out, out_net_stride, ldo, save_mean, save_invstd, B, H, momentum, eps)
+    if (k4d == 6) {
+        if (apply) BB_L1(6, true); else BB_L1(6, false);
+    } else {
+        if (apply) BB_L1(8, true); else BB_L1(8, false);
+    }
+#undef BB_L1
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
+                                   int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
+                                   int N, int K, int nets, void* stream) {
+    if (!a || !W || !bias || !z || !partials || !bb_shape_ok(B, N) || nets <= 0) return NAF_ERR_ARG;
+    if ((K != 128 && K != 256) || lda < K || (lda & 3) || ldz < N) return NAF_ERR_ARG;
+    if ((((uintptr_t)a | (uintptr_t)W) & 15) != 0 || (a_net_stride & 3) != 0 || (param_net_stride & 3) != 0 ||
+        ((uintptr_t)partials & 7) != 0)
+        return NAF_ERR_ARG;
+    dim3 grid(nets * (B / BB_ROWS), N / BL_BN);
+    bb_linear_stats_kernel<<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,
+                                                                         z_net_stride, ldz, (float2*)partials, B, N, K);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride, int ldz, const float* gamma,
+                                            const float* beta, int64_t param_net_stride, const float* partials,
+                                            float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
+                                            int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd,
+                                            const float* Wh, int64_t wh_net_stride, int ldw, int NHP, int v_col,
+                                            float* heads_partial, int64_t slab_stride, float* vnext_partial, int B, int H,
+                                            float momentum, float eps, void* stream) {
+    if (!z || !gamma || !beta || !partials || !running_mean || !running_var || !out || !save_mean || !save_invstd || !Wh ||
+        !heads_partial || !vnext_partial || !bb_shape_ok(B, H))
+        return NAF_ERR_ARG;
+    if ((NHP != 16 && NHP != 32 && NHP != 48) || v_col < 0 || v_col >= NHP || ldw <= H || (ldw & 3) || ldz < H || (ldz & 3) ||
+        ldo < H || (ldo & 3))
+        return NAF_ERR_ARG;
+    if ((((uintptr_t)z | (uintptr_t)out | (uintptr_t)Wh | (uintptr_t)heads_partial) & 15) != 0 || (z_net_stride & 3) ||
+        (out_net_stride & 3) || (wh_net_stride & 3) || (slab_stride & 3) || slab_stride < (int64_t)B * NHP)
+        return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B / BB_ROWS, H / BB_COLS, 2);
+#define BB_HP(NH4V)                                                                                                       \
+    bb_bn_relu_heads_partial_kernel<NH4V><<<grid, BB_THREADS, 0, st>>>(                                                   \
+        z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, running_mean, running_var,          \
+        stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, v_col, heads_partial,   \
+        slab_stride, vnext_partial, B, H, momentum, eps)
+    if (NHP == 16) BB_HP(4);
+    else if (NHP == 32) BB_HP(8);
+    else BB_HP(12);
+#undef BB_HP
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const float* Wh, int ldw, const float* z, int ldz,
+                                       const float* a2, int lda, const float* save_mean, const float* save_invstd,
+                                       float* dy_out, int ldd, float* partials, int B, int H, void* stream) {
+    if (!d_heads || !Wh || !z || !a2 || !save_mean || !save_invstd || !dy_out || !partials || !bb_shape_ok(B, H))
+        return NAF_ERR_ARG;
+    if ((ldh != 16 && ldh != 32 && ldh != 48) || ldw < H || (ldw & 3) || ldz < H || (ldz & 3) || lda < H || (lda & 3) ||
+        ldd < H || (ldd & 3))
+        return NAF_ERR_ARG;
+    if ((((uintptr_t)d_heads | (uintptr_t)Wh | (uintptr_t)z | (uintptr_t)a2 | (uintptr_t)dy_out) & 15) != 0) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B / BB_ROWS, H / BB_COLS);
+#define BB_S1(NH4V)                                                                                                    \
+    bb_heads_bwd_stage1_kernel<NH4V><<<grid, BB_THREADS, 0, st>>>(d_heads, ldh, Wh, ldw, z, ldz, a2, lda, save_mean,    \
+                                                                  save_invstd, dy_out, ldd, (float2*)partials, B, H)
+    if (ldh == 16) BB_S1(4);
+    else if (ldh == 32) BB_S1(8);
+    else BB_S1(12);
+#undef BB_S1
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz, const float* gamma, const float* save_mean,
+                                    const float* save_invstd, const float* partials, float* d_gamma, float* d_beta,
+                                    float* dz_col_partials, int B, int H, void* stream) {
+    if (!dy || !z || !gamma || !save_mean || !save_invstd || !partials || !d_gamma || !d_beta || !dz_col_partials ||
+        !bb_shape_ok(B, H))
+        return NAF_ERR_ARG;
+    if (ldd < H || (ldd & 3) || ldz < H || (ldz & 3) || (((uintptr_t)dy | (uintptr_t)z) & 15) != 0) return NAF_ERR_ARG;
+    dim3 grid(B / BB_ROWS, H / BB_COLS);
+    bb_bn_bwd_stage2_kernel<<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(dy, ldd, z, ldz, gamma, save_mean, save_invstd,
+                                                                          (const float2*)partials, d_gamma, d_beta,
+                                                                          dz_col_partials, B, H);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bb_layer1_bwd(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
+                                 const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, float* partials, float* dw_slabs, float* dz1_col_partials,
+                                 int B, int H, int stage, void* stream) {
+    if (!d_out || !x || !W || !bias || !out || !gamma || !save_mean || !save_invstd || !partials || !bb_shape_ok(B, H))
+        return NAF_ERR_ARG;
+    if (K <= 0 || K > 4 * BB_MAX_K4 || ld_dout < H || (ld_dout & 3) || ldo < H || (ldo & 3) || (stage != 1 && stage != 2))
+        return NAF_ERR_ARG;
+    if (stage == 2 && (!dw_slabs || !dz1_col_partials)) return NAF_ERR_ARG;
+    const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
+    if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d) return NAF_ERR_ARG;
+    if ((((uintptr_t)d_out | (uintptr_t)out | (uintptr_t)bias) & 15) != 0 || ((uintptr_t)partials & 7) != 0) return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B / BB_ROWS, H / BB_COLS);
+#define BB_B1(K4V, S2)                                                                                                     \
+    bb_layer1_bwd_kernel<K4V, S2><<<grid, BB_THREADS, 0, st>>>(d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, \
+                                                               save_invstd, (float2*)partials, dw_slabs, dz1_col_partials, B, H)
+    if (k4d == 6) {
+        if (stage == 2) BB_B1(6, true); else BB_B1(6, false);
+    } else {
+        if (stage == 2) BB_B1(8, true); else BB_B1(8, false);
+    }
+#undef BB_B1
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bb_layer1_bwd_kp(int K) {
+    if (K <= 0 || K > 4 * BB_MAX_K4) return NAF_ERR_ARG;
+    return (K + 3) / 4 <= 6 ? 24 : 32;
+}
+
+extern "C" int naf_bb_layer1_bwd_finish(const float* dw_slabs, int K, const float* partials1, const float* dz1_col_partials,
+                                        const float* dz2_col_partials, int nb, float* d_W, float* d_gamma, float* d_beta,
+                                        float* d_bias, float* d_bias2, const float* d_gamma2, const float* d_beta2,
+                                        float* sumsq_partials, int32_t* step_dev, int H, void* stream) {
+    if (!dw_slabs || !partials1 || !dz1_col_partials || !dz2_col_partials || !d_W || !d_gamma || !d_beta || !d_bias || !d_bias2 ||
+        nb <= 0 || H <= 0 || K <= 0 || K > 26)          // lanes 27-31 of a column's 32 carry the vector gradients
+        return NAF_ERR_ARG;
+    if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
+    const int kp = naf_bb_layer1_bwd_kp(K);
+    bb_layer1_bwd_finish_kernel<<<(H + BF_COLS - 1) / BF_COLS, BB_THREADS, 0, (hipStream_t)stream>>>(
+        dw_slabs, kp, K, (const float2*)partials1, dz1_col_partials, dz2_col_partials, nb, d_W, d_gamma, d_beta, d_bias, d_bias2,
+        d_gamma2, d_beta2, sumsq_partials, step_dev, H);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}

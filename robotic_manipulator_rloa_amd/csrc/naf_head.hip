@@ -153,7 +153,7 @@ extern "C" int naf_head_fwd_bwd_mse_splitk(const float* heads_partial, int64_t s
                                            float* d_heads, float* loss_partials, int B, int A, int p_mode,
                                            void* stream) {
     if (!head_args_ok(heads_partial, ldh, u, ldu, B, A, p_mode) || !r || !vnext_partial || !d_heads ||
-        ((uintptr_t)d_heads & 15) != 0 || ldr < 1 || (n_slabs != 32 && n_slabs != 16) || (slab_stride & 3) != 0 ||
+        ((uintptr_t)d_heads & 15) != 0 || ldr < 1 || (n_slabs != 32 && n_slabs != 16 && n_slabs != 4) || (slab_stride & 3) != 0 ||
         slab_stride < (int64_t)B * ldh)
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -164,10 +164,12 @@ extern "C" int naf_head_fwd_bwd_mse_splitk(const float* heads_partial, int64_t s
                                                                B, A, n_slabs, slab_stride, (int64_t)B)
     if (p_mode == NAF_P_HADAMARD) {
         if (n_slabs == 32) HEAD_SPLITK(NAF_P_HADAMARD, 32);
-        else HEAD_SPLITK(NAF_P_HADAMARD, 16);
+        else if (n_slabs == 16) HEAD_SPLITK(NAF_P_HADAMARD, 16);
+        else HEAD_SPLITK(NAF_P_HADAMARD, 4);
     } else {
         if (n_slabs == 32) HEAD_SPLITK(NAF_P_MATMUL, 32);
-        else HEAD_SPLITK(NAF_P_MATMUL, 16);
+        else if (n_slabs == 16) HEAD_SPLITK(NAF_P_MATMUL, 16);
+        else HEAD_SPLITK(NAF_P_MATMUL, 4);
     }
 #undef HEAD_SPLITK
     NAF_CHECK_LAUNCH();

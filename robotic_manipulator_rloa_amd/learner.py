@@ -168,9 +168,16 @@ class Learner:
         # The folded kernels keep their operand rows in registers (ceil(B/64) rows per thread): they win up to B = 512
         # and spill beyond (B=1024: 5.1k vs 11.7k updates/s unfused; B=2048: 2.0k vs 8.2k) — so large batches keep the
         # unfused BN / head chain and take only the GEMM bundle (B=1024: 12.7k, B=2048: 8.8k).
-        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else "gb").lower()
-        names = {"l1", "b2", "f3", "gb", "s3"}
-        self.fuse = set(names) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
+        #   bb = the LARGE-batch chain (csrc/big_batch.hip): 64-row blocks over the whole chip, BatchNorm statistics in two
+        #        stages (block partials from the producer, folded in the consumer's prologue), GEMM 2 on f32 MFMA with the
+        #        statistics in its epilogue, heads GEMM split over 4 column slices, streaming layer-1 backward
+        lay0 = self.lay
+        self.bb_ok = (self.B % 64 == 0 and 64 <= self.B <= 2048 and lay0.H in (128, 256) and lay0.S <= 26)
+        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else ("bb,gb" if self.bb_ok else "gb")).lower()
+        names = {"l1", "b2", "f3", "gb", "s3", "bb"}
+        self.fuse = (set(names) - {"bb"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
+        if "bb" in self.fuse:
+            self.fuse = ({"bb"} | (self.fuse & {"gb"})) if self.bb_ok else (self.fuse - {"bb"})
         if self.lay.S > 32:
             self.fuse -= {"l1"}
         if self.B % 16 != 0 or self.lay.H % 16 != 0:
@@ -180,7 +187,7 @@ class Learner:
         # with l1 + b2 + gb every gradient element is produced by one of our own kernels, which then also emit its
         # sum-of-squares partial: the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken
         # on the all-reduced gradient).
-        self.fold_norm = {"l1", "b2", "gb"} <= self.fuse and self.world_size == 1 and \
+        self.fold_norm = ({"l1", "b2", "gb"} <= self.fuse or {"bb", "gb"} <= self.fuse) and self.world_size == 1 and \
             os.environ.get("NAF_FORCE_ALLREDUCE") != "1" and os.environ.get("NAF_NO_FOLD_NORM") != "1"
         lay, B, dev = self.lay, self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
@@ -200,7 +207,9 @@ class Learner:
         ft_blocks = (H + ft_tx - 1) // ft_tx                               # workgroups of the column-tile kernels
         gb_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32) + ((H + 31) // 32) ** 2   # dWh + dW2 blocks of the bundle
         self.n_partials_norm = (P + _lib.NORM_CHUNK - 1) // _lib.NORM_CHUNK
-        self.n_partials_fold = gb_blocks + 2 * ft_blocks
+        # folded norm partials: the bundle's dWh + dW2 blocks, then the column-tile kernels (two launches of ft_blocks) or,
+        # in the large-batch chain, the (H + 7) // 8 workgroups of the layer-1 finish kernel
+        self.n_partials_fold = gb_blocks + ((H + 7) // 8 if "bb" in self.fuse else 2 * ft_blocks)
         self.n_partials = self.n_partials_fold if self.fold_norm else self.n_partials_norm
         # data parallel inside one node: the one-shot peer-memory all-reduce (csrc/xgmi_reduce.hip) replaces the RCCL
         # ring + the grad-norm launch when every rank could map every peer and the exact self-test passed on all of
@@ -231,6 +240,19 @@ class Learner:
         self.save_mean = torch.empty(2, 2, H, **f32)         # [layer][net][H]
         self.save_invstd = torch.empty(2, 2, H, **f32)
         self.q_out = torch.empty(B, **f32)
+        if "bb" in self.fuse:
+            NB = B // 64
+            self.n_slabs = H // 64
+            self.slab_stride = B * NHP + 64
+            self.heads_partial = torch.zeros(self.n_slabs * self.slab_stride, **f32)
+            self.vnext_partial = torch.zeros(self.n_slabs, B, **f32)
+            self.bb_st1 = torch.zeros(2, NB, H, 2, **f32)       # forward statistics partials of layer 1 / layer 2: (sum, M2)
+            self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)
+            self.bb_bw2 = torch.zeros(NB, H, 2, **f32)          # backward partials of layer 2: (sum dy, sum dy*xhat)
+            self.bb_dzp = torch.zeros(NB, H, **f32)             # block sums of dZ2 (-> gradient of the layer-2 bias)
+            self.bb_bw1 = torch.zeros(NB, H, 2, **f32)          # backward partials of layer 1
+            self.bb_dzp1 = torch.zeros(NB, H, **f32)
+            self.bb_dw1 = torch.zeros(NB, H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # per-block shares of dW1
         if "s3" in self.fuse:
             # split-K heads: one [B, NHP] slab per 8-column workgroup of layer 2's BN kernel (+ the target's V column)
             # slabs 256 B further apart than their size: the H/8 pieces of one row, read together by the head kernel,
@@ -304,6 +326,25 @@ class Learner:
         seg, P, H = lay.seg, lay.P, lay.H
         t2p = self.theta2.data_ptr()
         bnp = self.bn_stats.data_ptr()
+        if "bb" in self.fuse:
+            ld = rows.stride(0)
+            for apply in (0, 1):     # layer 1: statistics partials of every 64-row block, then fold + normalise + ReLU
+                check(self._f.naf_bb_layer1(
+                    rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                    t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(self.bb_st1), bnp, bnp + 4 * H, 4 * H,
+                    ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), B, H, 2, BN_MOMENTUM, BN_EPS,
+                    apply, st), "bb_layer1")
+            # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
+            check(self._f.naf_bb_linear_stats(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset, t2p + 4 * seg["b2"].offset, P,
+                                              ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, H, 2, st), "bb_linear_stats")
+            # fold + normalise + ReLU -> A2, and this column slice's share of the heads GEMM
+            check(self._f.naf_bb_bn_relu_heads_partial(
+                ptr(self.G2), B * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
+                bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2), B * lay.HP, lay.HP, ptr(self.save_mean[1]),
+                ptr(self.save_invstd[1]), t2p + 4 * seg["Wh"].offset, P, lay.HP, lay.NHP, lay.A + lay.T,
+                ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), B, H, BN_MOMENTUM, BN_EPS, st),
+                "bb_bn_relu_heads_partial")
+            return
         if "l1" in self.fuse:
             # layer 1 (K = state size): GEMM + bias + BN + ReLU of both nets in one launch, straight off the rows
             check(self._f.naf_linear_bn_relu_fwd_train(
@@ -353,9 +394,9 @@ class Learner:
                 ptr(self.A2), B * HP, HP, HP, t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld,
                 rp + 4 * lay.off_r, ld, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "heads_gemm_head_fwd_bwd_mse")
-        elif "s3" in self.fuse:
+        elif "s3" in self.fuse or "bb" in self.fuse:
             self.forward_train(rows)
-            # the head adds the H/8 split-K slabs while staging its rows, then as below
+            # the head adds the split-K slabs (H/8 of them, or H/64 in the large-batch chain) while staging its rows
             check(f.naf_head_fwd_bwd_mse_splitk(
                 ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), self.n_slabs, NHP, rp + 4 * lay.off_u,
                 ld,
@@ -372,7 +413,17 @@ class Learner:
         gb = "gb" in self.fuse
         if not gb:
             torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
-        if "b2" in self.fuse:
+        if "bb" in self.fuse:
+            NB = B // 64
+            # backward of layer 2, two stages: dy = ReLU' * (dH Wh) with its block sums, then dz in place
+            check(f.naf_bb_heads_bwd_stage1(ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H,
+                                            ptr(self.A2[0]), HP, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]),
+                                            ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, st), "bb_heads_bwd_stage1")
+            check(f.naf_bb_bn_bwd_stage2(ptr(self.dZ2), H, ptr(self.G2[0]), H, t2p + 4 * seg["g2"].offset,
+                                         ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.bb_bw2),
+                                         gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, ptr(self.bb_dzp), B, H, st),
+                  "bb_bn_bwd_stage2")
+        elif "b2" in self.fuse:
             # dA2 = dH @ Wh (K = NHP) folded into the ReLU/BN backward of layer 2
             check(f.naf_heads_bwd_bn_relu_bwd(
                 ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset,
@@ -393,7 +444,21 @@ class Learner:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
             torch.mm(self.dZ2, self.W2_main, out=self.dA1)
         pushed_lo = None
-        if "l1" in self.fuse:
+        if "bb" in self.fuse:
+            # layer 1 backward: block sums, block shares of dW1, then everything added in block order (+ the norm partials
+            # of all vector gradients and the layer-2 bias gradient)
+            for stage in (1, 2):
+                check(f.naf_bb_layer1_bwd(
+                    ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
+                    t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1),
+                    ptr(self.bb_dw1), ptr(self.bb_dzp1), B, H, stage, st), "bb_layer1_bwd")
+            check(f.naf_bb_layer1_bwd_finish(
+                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), ptr(self.bb_dzp1), ptr(self.bb_dzp), B // 64,
+                gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
+                gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
+                self.partials.data_ptr() + 4 * self._gb_blocks if self.fold_norm else None,
+                ptr(self.step_dev) if self.fold_norm else None, H, st), "bb_layer1_bwd_finish")
+        elif "l1" in self.fuse:
             # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written). Data parallel over peer
             # memory: everything but layer 1's gradient is final by now (segments W2 .. Wh of the flat buffer) and goes
             # to the peers from extra workgroups of this very launch, so its wire time runs under the kernel

@@ -32,17 +32,25 @@ def current_sd(L, net):
     return sd
 
 
-@pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "s3", "l1,b2,gb,s3", "all"])
+@pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "s3", "l1,b2,gb,s3", "all", "bb,gb", "bb", "default"])
 @pytest.mark.parametrize("tag", G3_TAGS)
 def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     """NAF_FUSE selects which small GEMMs are folded into the BN / head kernels (csrc/fused_layers.hip; "all" includes
-    the MFMA heads GEMM): every combination must match the reference."""
-    monkeypatch.setenv("NAF_FUSE", fused)
+    the MFMA heads GEMM; "bb" = the large-batch chain of csrc/big_batch.hip, the default beyond B = 512): every
+    combination must match the reference."""
+    if fused == "default":
+        monkeypatch.delenv("NAF_FUSE", raising=False)
+    else:
+        monkeypatch.setenv("NAF_FUSE", fused)
     from synth_data import make_transitions
     g, main0, target0 = g3_case(tag)      # 'xarm1024' / 'panda2048': the reference's learn() at configs[3] / [4]'s batch
     S, A, B = [int(x) for x in g[f"{tag}/dims"]]
     st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
     L = make_learner(S, A, B, main0, target0)
+    if fused == "default":
+        assert L.fuse == ({"bb", "gb"} if B > 512 else {"l1", "b2", "gb", "s3"})
+    if "bb" in fused:
+        assert "bb" in L.fuse and not L.fuse & {"l1", "b2", "s3", "f3"}
     rows = rows_device(L, st, ac, rw, ns, dn)
     lp = torch.zeros(5, L.n_loss_wg, device="cuda")
     for k in range(5):
@@ -83,7 +91,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     assert (L.grad[mask] == 0).all() and (L.theta2[0][mask] == 0).all() and (L.adam_v[mask] == 0).all()
 
 
-@pytest.mark.parametrize("fused", ["none", "all", "l1,b2,gb,s3"])
+@pytest.mark.parametrize("fused", ["none", "all", "l1,b2,gb,s3", "bb,gb"])
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32),
                                    (21, 6, 512), (32, 8, 512), (21, 6, 1024), (21, 6, 768)])
