@@ -331,9 +331,10 @@ def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
             "infinity_cache_assisted": ring_rows * ring.row_floats * 4 <= 256 * 2 ** 20, "bad_indices": bad,
             "physical_GBps": round(phys / (ms * 1e-3) / 1e9, 1),
             "note": "HIP events around back-to-back launches on the launching stream; achieved = algorithmic bytes "
-                    "(404 B/row at S=21/A=6) / average launch time. The ring row is padded 200 -> 256 B (two whole "
-                    "lines per random row), the gathered row 200 -> 208 B: physical/algorithmic = 1.16, so frac <= 0.68 "
-                    "of the 6.3 TB/s a streaming copy reaches on this chip"}
+                    "(4*(2S+A+2)*2 + 4 per row: 404 B at S=21/A=6) / average launch time; profiles/r02_bench_kernel_stats.csv is "
+                    "the rocprofv3 kernel-trace average of this kernel instance in the same command. A ring row is padded "
+                    "200 -> 256 B (two whole 128-B lines per random row) and a gathered row 200 -> 208 B, so the launch moves "
+                    "1.16 x its algorithmic bytes; `traffic` is the PMC record of that (FETCH_SIZE x 2 + WRITE_SIZE)"}
 
 
 def extras(dev, args):

@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 4
+#define NAF_HIP_ABI_VERSION 5
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -276,10 +276,19 @@ int naf_bb_layer1_bwd(const float* d_out, int ld_dout, const float* x, int ldx, 
                       const float* out, int ldo, const float* gamma, const float* save_mean, const float* save_invstd,
                       float* partials, float* dw_slabs, float* dz1_col_partials, int B, int H, int stage, void* stream);
 int naf_bb_layer1_bwd_kp(int K);
+/* segs (HOST array, n_segs <= 2, may be 0): split-K slabs of the bundle's weight gradients (naf_gemm_desc_t.k_split), added in
+ * slab order by extra workgroups of the same launch: dst[i] = sum_s src[s * stride + i], i < n (n % 4 == 0, n_slabs <= 8);
+ * their sums of squares follow the ceil(H/8) entries of sumsq_partials, ceil(n / 1024) entries per segment. */
+typedef struct naf_bb_slab_seg {
+    const float* src;
+    float* dst;
+    int64_t stride;
+    int n, n_slabs;
+} naf_bb_slab_seg_t;
 int naf_bb_layer1_bwd_finish(const float* dw_slabs, int K, const float* partials1, const float* dz1_col_partials,
                              const float* dz2_col_partials, int nb, float* d_W, float* d_gamma, float* d_beta, float* d_bias,
                              float* d_bias2, const float* d_gamma2, const float* d_beta2, float* sumsq_partials,
-                             int32_t* step_dev, int H, void* stream);
+                             int32_t* step_dev, int H, const naf_bb_slab_seg_t* segs, int n_segs, void* stream);
 
 /* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
 /* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is
@@ -294,6 +303,9 @@ typedef struct naf_gemm_desc {
     float* C;
     float* sumsq; /* nullable: [ceil(M/32)*ceil(N/32)] per-block sums of C^2 (gradient-norm partials) */
     int M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor;
+    int k_split;            /* 0 / 1: the whole K in one block. > 1: K cut into k_split ranges ((K / k_split) % 16 == 0), range s */
+    int64_t c_split_stride; /* writing its partial product to C + s * c_split_stride floats (sumsq must be NULL); the consumer adds
+                               the slabs in index order (naf_bb_layer1_bwd_finish) */
 } naf_gemm_desc_t;
 int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
 

@@ -154,7 +154,7 @@ _PROTOS = {
     "naf_bb_bn_bwd_stage2": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "naf_bb_layer1_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "naf_bb_layer1_bwd_kp": [_i],
-    "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
@@ -188,10 +188,16 @@ class XgmiPushDesc(C.Structure):
                 ("rank", C.c_int), ("world", C.c_int)]
 
 
+class SlabSeg(C.Structure):
+    """naf_bb_slab_seg_t (include/naf_hip.h)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("stride", C.c_int64), ("n", C.c_int), ("n_slabs", C.c_int)]
+
+
 class GemmDesc(C.Structure):
     """naf_gemm_desc_t (include/naf_hip.h)"""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("sumsq", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-                ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int)]
+                ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
+                ("k_split", C.c_int), ("c_split_stride", C.c_int64)]
 
 
 def load(allow_build: bool = True) -> C.CDLL:

@@ -28,21 +28,50 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- stage 2 of the batch statistics: fold the NB block partials of one column, in block order -----------------
+// NB <= BB_MAX_NB (B <= 2048): every partial is requested up front (indices clamped, adds predicated), ONE round trip
+// instead of NB / 8 dependent ones — this runs in the prologue of every consumer.
+#define BB_MAX_NB 32
 __device__ static inline void bb_fold_stats(const float2* __restrict__ p, int H, int NB, int B, int col, float* mean,
                                             float* var) {
+    float2 v[BB_MAX_NB];
+#pragma unroll
+    for (int rb = 0; rb < BB_MAX_NB; ++rb) v[rb] = p[(int64_t)(rb < NB ? rb : 0) * H + col];
     float S = 0.f;
-#pragma unroll 8
-    for (int rb = 0; rb < NB; ++rb) S += p[(int64_t)rb * H + col].x;
+#pragma unroll
+    for (int rb = 0; rb < BB_MAX_NB; ++rb) S += rb < NB ? v[rb].x : 0.f;
     const float m = S / (float)B;
     float M2 = 0.f;
-#pragma unroll 8
-    for (int rb = 0; rb < NB; ++rb) {
-        const float2 v = p[(int64_t)rb * H + col];
-        const float d = v.x * (1.0f / BB_ROWS) - m;
-        M2 += v.y + (float)BB_ROWS * d * d;
+#pragma unroll
+    for (int rb = 0; rb < BB_MAX_NB; ++rb) {
+        const float d = v[rb].x * (1.0f / BB_ROWS) - m;
+        M2 += rb < NB ? v[rb].y + (float)BB_ROWS * d * d : 0.f;
     }
     *mean = m;
     *var = M2 / (float)B;      // biased: what normalises
+}
+
+// the same for plain sums (backward partials): (sum .x, sum .y) over the NB blocks, block order
+__device__ static inline float2 bb_fold_sums(const float2* __restrict__ p, int H, int NB, int col) {
+    float2 v[BB_MAX_NB];
+#pragma unroll
+    for (int rb = 0; rb < BB_MAX_NB; ++rb) v[rb] = p[(int64_t)(rb < NB ? rb : 0) * H + col];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < BB_MAX_NB; ++rb) {
+        a += rb < NB ? v[rb].x : 0.f;
+        b += rb < NB ? v[rb].y : 0.f;
+    }
+    return make_float2(a, b);
+}
+
+__device__ static inline float bb_fold_sum1(const float* __restrict__ p, int64_t stride, int NB) {
+    float v[BB_MAX_NB];
+#pragma unroll
+    for (int rb = 0; rb < BB_MAX_NB; ++rb) v[rb] = p[(int64_t)(rb < NB ? rb : 0) * stride];
+    float a = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < BB_MAX_NB; ++rb) a += rb < NB ? v[rb] : 0.f;
+    return a;
 }
 
 // sums over the 64 rows of a tile held as one value per (row, column) in LDS [64][BB_COLS + 1]: thread c < 64 adds
@@ -520,13 +549,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
     }
     if (tid < BB_COLS) {
         const int col = col0 + tid;
-        float sdy = 0.f, sdx = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < NB; ++k) {
-            const float2 p = partials[(int64_t)k * H + col];
-            sdy += p.x;
-            sdx += p.y;
-        }
+        const float2 sums = bb_fold_sums(partials, H, NB, col);
+        const float sdy = sums.x, sdx = sums.y;
         const float invstd = save_invstd[col];
         sC[0][tid] = save_mean[col];
         sC[1][tid] = invstd;
@@ -598,13 +622,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
         sC[0][tid] = save_mean[col];
         sC[1][tid] = invstd;
         if (STAGE2) {
-            float sdy = 0.f, sdx = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < NB; ++k) {
-                const float2 p = partials[(int64_t)k * H + col];
-                sdy += p.x;
-                sdx += p.y;
-            }
+            const float2 sums = bb_fold_sums(partials, H, NB, col);
+            const float sdy = sums.x, sdx = sums.y;
             sC[2][tid] = gamma[col] * invstd;
             sC[3][tid] = sdy / (float)B;
             sC[4][tid] = sdx / (float)B;
@@ -666,48 +685,69 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
     }
 }
 
-// finish: one workgroup per 8 columns, thread = (column, k lane of 32)
+// finish: one workgroup per 8 columns, thread = (column, k lane of 32); behind them, workgroups that add the split-K
+// slabs of the bundle's weight gradients (dW2, dWh) in slab order, 1024 floats each — every gradient element leaves this
+// launch final, with its sum-of-squares partial.
 #define BF_COLS 8
+struct BbSlabSeg {
+    const float* src;       // slab 0; slab s at src + s * stride
+    float* dst;
+    int64_t stride;
+    int n, n_slabs, block0; // n floats (multiple of 4); first reduce block of this segment
+};
+struct BbSlabs {
+    BbSlabSeg seg[2];
+    int n_seg, n_finish_blocks;
+};
+#define BB_MAX_SLABS 8
 __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
     const float* __restrict__ dw_slabs, int KP, int K, const float2* __restrict__ partials1,
     const float* __restrict__ dz1_col_partials, const float* __restrict__ dz2_col_partials, int NB,
     float* __restrict__ d_W, float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias,
     float* __restrict__ d_bias2, const float* __restrict__ d_gamma2, const float* __restrict__ d_beta2,
-    float* __restrict__ sumsq_partials, int32_t* step_dev, int H) {
+    float* __restrict__ sumsq_partials, int32_t* step_dev, int H, const BbSlabs slabs) {
     __shared__ float sQ[BB_THREADS / 64];
-    const int tid = threadIdx.x, c = tid >> 5, k = tid & 31;
-    const int col = blockIdx.x * BF_COLS + c;
+    const int tid = threadIdx.x;
     float sq = 0.f;
-    if (col < H) {
-        if (k < K) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int rb = 0; rb < NB; ++rb) s += dw_slabs[((int64_t)rb * H + col) * KP + k];
-            d_W[(int64_t)col * K + k] = s;
-            sq = s * s;
+    if ((int)blockIdx.x >= slabs.n_finish_blocks) {
+        const int rbk = (int)blockIdx.x - slabs.n_finish_blocks;
+        const BbSlabSeg& sg = (slabs.n_seg > 1 && rbk >= slabs.seg[1].block0) ? slabs.seg[1] : slabs.seg[0];
+        const int i = (rbk - sg.block0) * (BB_THREADS * 4) + tid * 4;
+        if (i < sg.n) {
+            float4 v[BB_MAX_SLABS];
+#pragma unroll
+            for (int s_ = 0; s_ < BB_MAX_SLABS; ++s_)
+                v[s_] = *(const float4*)(sg.src + (int64_t)(s_ < sg.n_slabs ? s_ : 0) * sg.stride + i);
+            float4 a = v[0];
+#pragma unroll
+            for (int s_ = 1; s_ < BB_MAX_SLABS; ++s_)
+                if (s_ < sg.n_slabs) { a.x += v[s_].x; a.y += v[s_].y; a.z += v[s_].z; a.w += v[s_].w; }
+            *(float4*)(sg.dst + i) = a;
+            sq = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
         }
-        // the vector gradients of this column go to lanes that have no k to sum (K <= 26)
-        if (k == 27 || k == 28) {
-            float a = 0.f, b = 0.f;
-#pragma unroll 8
-            for (int rb = 0; rb < NB; ++rb) {
-                const float2 p = partials1[(int64_t)rb * H + col];
-                a += p.x;
-                b += p.y;
+    } else {
+        const int c = tid >> 5, k = tid & 31;
+        const int col = blockIdx.x * BF_COLS + c;
+        if (col < H) {
+            if (k < K) {
+                const float s = bb_fold_sum1(dw_slabs + (int64_t)col * KP + k, (int64_t)H * KP, NB);
+                d_W[(int64_t)col * K + k] = s;
+                sq = s * s;
             }
-            const float v = k == 27 ? b : a;               // d_gamma = sum dy*xhat, d_beta = sum dy
-            (k == 27 ? d_gamma : d_beta)[col] = v;
-            sq += v * v;
-        } else if (k == 29 || k == 30) {
-            const float* src = k == 29 ? dz1_col_partials : dz2_col_partials;
-            float* dst = k == 29 ? d_bias : d_bias2;
-            float s = 0.f;
-            for (int rb = 0; rb < NB; ++rb) s += src[(int64_t)rb * H + col];
-            dst[col] = s;
-            sq += s * s;
-        } else if (k == 31 && d_gamma2) {
-            const float g = d_gamma2[col], b = d_beta2[col];   // written by bb_bn_bwd_stage2, an earlier launch
-            sq += g * g + b * b;
+            // the vector gradients of this column go to lanes that have no k to sum (K <= 26)
+            if (k == 27 || k == 28) {
+                const float2 ab = bb_fold_sums(partials1, H, NB, col);
+                const float v = k == 27 ? ab.y : ab.x;         // d_gamma = sum dy*xhat, d_beta = sum dy
+                (k == 27 ? d_gamma : d_beta)[col] = v;
+                sq += v * v;
+            } else if (k == 29 || k == 30) {
+                const float s = bb_fold_sum1((k == 29 ? dz1_col_partials : dz2_col_partials) + col, H, NB);
+                (k == 29 ? d_bias : d_bias2)[col] = s;
+                sq += s * s;
+            } else if (k == 31 && d_gamma2) {
+                const float g = d_gamma2[col], b = d_beta2[col];   // written by bb_bn_bwd_stage2, an earlier launch
+                sq += g * g + b * b;
+            }
         }
     }
     if (sumsq_partials) {
@@ -871,15 +911,31 @@ extern "C" int naf_bb_layer1_bwd_kp(int K) {
 extern "C" int naf_bb_layer1_bwd_finish(const float* dw_slabs, int K, const float* partials1, const float* dz1_col_partials,
                                         const float* dz2_col_partials, int nb, float* d_W, float* d_gamma, float* d_beta,
                                         float* d_bias, float* d_bias2, const float* d_gamma2, const float* d_beta2,
-                                        float* sumsq_partials, int32_t* step_dev, int H, void* stream) {
+                                        float* sumsq_partials, int32_t* step_dev, int H, const naf_bb_slab_seg_t* segs,
+                                        int n_segs, void* stream) {
     if (!dw_slabs || !partials1 || !dz1_col_partials || !dz2_col_partials || !d_W || !d_gamma || !d_beta || !d_bias || !d_bias2 ||
-        nb <= 0 || H <= 0 || K <= 0 || K > 26)          // lanes 27-31 of a column's 32 carry the vector gradients
+        nb <= 0 || nb > BB_MAX_NB || H <= 0 || K <= 0 || K > 26)   // lanes 27-31 of a column's 32 carry the vector gradients
         return NAF_ERR_ARG;
     if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
+    if (n_segs < 0 || n_segs > 2 || (n_segs && !segs)) return NAF_ERR_ARG;
+    BbSlabs sl;
+    memset(&sl, 0, sizeof(sl));
+    sl.n_finish_blocks = (H + BF_COLS - 1) / BF_COLS;
+    sl.n_seg = n_segs;
+    int blocks = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const naf_bb_slab_seg_t& g = segs[i];
+        if (!g.src || !g.dst || g.n <= 0 || (g.n & 3) || g.n_slabs < 1 || g.n_slabs > BB_MAX_SLABS || g.stride < g.n || (g.stride & 3) ||
+            (((uintptr_t)g.src | (uintptr_t)g.dst) & 15) != 0)
+            return NAF_ERR_ARG;
+        sl.seg[i].src = g.src; sl.seg[i].dst = g.dst; sl.seg[i].stride = g.stride;
+        sl.seg[i].n = g.n; sl.seg[i].n_slabs = g.n_slabs; sl.seg[i].block0 = blocks;
+        blocks += (g.n + BB_THREADS * 4 - 1) / (BB_THREADS * 4);
+    }
     const int kp = naf_bb_layer1_bwd_kp(K);
-    bb_layer1_bwd_finish_kernel<<<(H + BF_COLS - 1) / BF_COLS, BB_THREADS, 0, (hipStream_t)stream>>>(
+    bb_layer1_bwd_finish_kernel<<<sl.n_finish_blocks + blocks, BB_THREADS, 0, (hipStream_t)stream>>>(
         dw_slabs, kp, K, (const float2*)partials1, dz1_col_partials, dz2_col_partials, nb, d_W, d_gamma, d_beta, d_bias, d_bias2,
-        d_gamma2, d_beta2, sumsq_partials, step_dev, H);
+        d_gamma2, d_beta2, sumsq_partials, step_dev, H, sl);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -16,6 +16,8 @@ struct GemmDesc {
     float* C;         // [M][N], ld = ldc
     float* sumsq;     // nullable: sumsq[block] = sum of C^2 over the block (grad-norm partial)
     int M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, tile0, tiles_n;
+    int k_split, tiles_mn;        // K cut into k_split ranges, one grid of tiles_mn blocks each, slab s at C + s * c_split_stride
+    int64_t c_split_stride;
 };
 struct GemmBundle {
     GemmDesc d[NAF_GEMM_BUNDLE_MAX];
@@ -99,7 +101,7 @@ __device__ static inline float4 read_frag(const float* __restrict__ sm, int row,
 }
 
 template <bool AK, bool BK>
-__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, float* sA, float* sB, float* sQ, float* sC) {
+__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int ks, float* sA, float* sB, float* sQ, float* sC) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     // 8 waves: two per 16 x 16 tile of the 32 x 32 block, each taking one half of the K chunk — the per-wave chain of
@@ -112,20 +114,25 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
     // Software pipeline over the K chunks (K = B for the weight gradients: 4 chunks at B = 1024): the global loads of
     // chunk i+1 are issued before the MFMAs of chunk i and land in registers while they run. As a plain
     // load -> store -> barrier -> compute loop every chunk paid its own L2 round trip: 13.3 us per launch at B = 1024.
+    // Split K (k_split > 1: the weight gradients at large batches, K = B): this block takes K range ks and writes slab ks;
+    // the slabs are added in slab order by the consumer (bb_layer1_bwd_finish's reduce blocks). 64 blocks walking
+    // K = 1024 pulled 256 KB each through one CU's L2 port (13.6 us per launch at B = 1024); 256 blocks of K = 256 do not.
+    const int kper = D.K / D.k_split, k_lo = ks * kper, k_hi = k_lo + kper;
+    float* Cs = D.C + (int64_t)ks * D.c_split_stride;
     float4 va[GB_PT], vb[GB_PT];
     {
-        const int kc0 = D.K < GB_KC ? D.K : GB_KC;
+        const int kc0 = kper < GB_KC ? kper : GB_KC;
         if (kc0 == GB_KC) {
-            load_panel<AK, true>(va, D.A, D.lda, m0, D.M, 0, kc0, tid);
-            load_panel<BK, true>(vb, D.B, D.ldb, n0, D.N, 0, kc0, tid);
+            load_panel<AK, true>(va, D.A, D.lda, m0, D.M, k_lo, kc0, tid);
+            load_panel<BK, true>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
         } else {
-            load_panel<AK, false>(va, D.A, D.lda, m0, D.M, 0, kc0, tid);
-            load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, 0, kc0, tid);
+            load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k_lo, kc0, tid);
+            load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
         }
     }
-    for (int k0 = 0; k0 < D.K; k0 += GB_KC) {
-        const int kc = (D.K - k0) < GB_KC ? (D.K - k0) : GB_KC;
-        if (k0) __syncthreads();                          // previous chunk fully consumed
+    for (int k0 = k_lo; k0 < k_hi; k0 += GB_KC) {
+        const int kc = (k_hi - k0) < GB_KC ? (k_hi - k0) : GB_KC;
+        if (k0 != k_lo) __syncthreads();                  // previous chunk fully consumed
         if (kc == GB_KC) {
             store_panel<AK, true>(sA, va, kc, tid);
             store_panel<BK, true>(sB, vb, kc, tid);
@@ -134,8 +141,8 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
             store_panel<BK, false>(sB, vb, kc, tid);
         }
         const int k1 = k0 + GB_KC;
-        if (k1 < D.K) {                                   // next chunk's loads fly under this chunk's MFMAs
-            const int kn = (D.K - k1) < GB_KC ? (D.K - k1) : GB_KC;
+        if (k1 < k_hi) {                                  // next chunk's loads fly under this chunk's MFMAs
+            const int kn = (k_hi - k1) < GB_KC ? (k_hi - k1) : GB_KC;
             if (kn == GB_KC) {
                 load_panel<AK, true>(va, D.A, D.lda, m0, D.M, k1, kn, tid);
                 load_panel<BK, true>(vb, D.B, D.ldb, n0, D.N, k1, kn, tid);
@@ -170,7 +177,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, floa
             for (int e = 0; e < 4; ++e)
                 if (cm + e < D.M) {
                     const float v = acc[e];
-                    D.C[(int64_t)(cm + e) * D.ldc + cn] = v;
+                    Cs[(int64_t)(cm + e) * D.ldc + cn] = v;
                     sq += v * v;
                 }
         }
@@ -195,7 +202,8 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bundle_kernel(const GemmBundl
     for (int i = 1; i < NAF_GEMM_BUNDLE_MAX; ++i)
         if (i < bundle.n && t >= bundle.d[i].tile0) gi = i;
     const GemmDesc& D = bundle.d[gi];
-    const int lt = t - D.tile0;
+    const int ks = (t - D.tile0) / D.tiles_mn;
+    const int lt = t - D.tile0 - ks * D.tiles_mn;
     int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;
     if (D.tiles_n == 8 && D.M == 256) {
         // 8 x 8 blocks; workgroup t runs on XCD t % 8 (round-robin dispatch) and the column-tile kernels on either side of
@@ -203,15 +211,15 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bundle_kernel(const GemmBundl
         // XCD bm, the one that has just written those dZ2 columns; k-contiguous A (dA1 = dZ2 W2): block COLUMN bn on XCD
         // bn, the one that reads those dA1 columns next. Producer and consumer then share an L2 (+1 % updates/s;
         // placement is speed only, the result does not depend on it).
-        const int xcd = t & 7, slot = lt >> 3;
+        const int xcd = lt & 7, slot = lt >> 3;
         if (D.a_kmajor) { bm = xcd; bn = slot; } else { bn = xcd; bm = slot; }
     }
     if (D.a_kmajor) {
-        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, sA, sB, sQ, sC);
-        else gemm_block<true, false>(D, bm, bn, sA, sB, sQ, sC);
+        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, ks, sA, sB, sQ, sC);
+        else gemm_block<true, false>(D, bm, bn, ks, sA, sB, sQ, sC);
     } else {
-        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, sA, sB, sQ, sC);
-        else gemm_block<false, false>(D, bm, bn, sA, sB, sQ, sC);
+        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, ks, sA, sB, sQ, sC);
+        else gemm_block<false, false>(D, bm, bn, ks, sA, sB, sQ, sC);
     }
 }
 
@@ -224,6 +232,8 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         const naf_gemm_desc_t& s = descs[i];
         if (!s.A || !s.B || !s.C || s.M <= 0 || s.N <= 0 || s.K <= 0) return NAF_ERR_ARG;
         if ((s.M & 15) || (s.N & 15) || (s.K & 15)) return NAF_ERR_ARG;            // whole 16x16x16 steps only
+        const int ksn = s.k_split > 0 ? s.k_split : 1;
+        if (ksn > 1 && (s.K % ksn || ((s.K / ksn) & 15) || s.sumsq || s.c_split_stride < (int64_t)s.M * s.ldc)) return NAF_ERR_ARG;
         if (s.lda < (s.a_kmajor ? s.M : s.K) || s.ldb < (s.b_kmajor ? s.N : s.K) || s.ldc < s.N) return NAF_ERR_ARG;
         if ((((uintptr_t)s.A) & 15) || (s.lda & 3) || (((uintptr_t)s.B) & 15) || (s.ldb & 3)) return NAF_ERR_ARG;   // float4 staging
         GemmDesc& d = b.d[i];
@@ -233,7 +243,10 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         d.a_kmajor = s.a_kmajor; d.b_kmajor = s.b_kmajor;
         d.tile0 = tiles;
         d.tiles_n = (s.N + 31) / 32;
-        tiles += ((s.M + 31) / 32) * d.tiles_n;
+        d.tiles_mn = ((s.M + 31) / 32) * d.tiles_n;
+        d.k_split = ksn;
+        d.c_split_stride = s.c_split_stride;
+        tiles += d.tiles_mn * ksn;
     }
     for (int i = n; i < NAF_GEMM_BUNDLE_MAX; ++i) b.d[i] = b.d[0];
     b.total_tiles = tiles;

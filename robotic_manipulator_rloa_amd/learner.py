@@ -209,7 +209,9 @@ class Learner:
         self.n_partials_norm = (P + _lib.NORM_CHUNK - 1) // _lib.NORM_CHUNK
         # folded norm partials: the bundle's dWh + dW2 blocks, then the column-tile kernels (two launches of ft_blocks) or,
         # in the large-batch chain, the (H + 7) // 8 workgroups of the layer-1 finish kernel
-        self.n_partials_fold = gb_blocks + ((H + 7) // 8 if "bb" in self.fuse else 2 * ft_blocks)
+        self.n_partials_fold = gb_blocks + 2 * ft_blocks
+        if "bb" in self.fuse:
+            self.n_partials_fold = (H + 7) // 8 + (H * H + 1023) // 1024 + (NHP * HP + 1023) // 1024
         self.n_partials = self.n_partials_fold if self.fold_norm else self.n_partials_norm
         # data parallel inside one node: the one-shot peer-memory all-reduce (csrc/xgmi_reduce.hip) replaces the RCCL
         # ring + the grad-norm launch when every rank could map every peer and the exact self-test passed on all of
@@ -285,6 +287,21 @@ class Learner:
             D(ptr(self.dH), ptr(self.A2[0]), ptr(self.gWh), sq_wh, NHP, HP, B, NHP, HP, HP, 1, 1),          # dWh
             D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.gW2), sq_w2, H, H, B, H, H, H, 1, 1),                  # dW2
             D(ptr(self.dZ2), ptr(self.W2_main), ptr(self.dA1), None, B, H, H, H, H, H, 0, 1))                 # dA1
+        self._bb_segs, self._bb_nsegs = None, 0
+        if "bb" in self.fuse and "gb" in self.fuse:
+            # large batches: the weight gradients reduce over K = B. Cut K into 256-row ranges, one grid of blocks each,
+            # writing partial slabs that the layer-1 finish launch adds in slab order (and takes the norm partials of)
+            ks = B // 256 if B % 256 == 0 else 1
+            self.bb_slab_w2 = torch.zeros(ks, H * H, **f32)
+            self.bb_slab_wh = torch.zeros(ks, NHP * HP, **f32)
+            self._bundle = (D * 3)(
+                D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks, NHP * HP),
+                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks, H * H),
+                D(ptr(self.dZ2), ptr(self.W2_main), ptr(self.dA1), None, B, H, H, H, H, H, 0, 1, 1, 0))
+            SS = _lib.SlabSeg
+            self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks),
+                                     SS(ptr(self.bb_slab_wh), ptr(self.gWh), NHP * HP, NHP * HP, ks))
+            self._bb_nsegs = 2
 
     # ---- parameters in / out ----------------------------------------------------------------------------
     def main_views(self) -> Dict[str, torch.Tensor]:
@@ -456,8 +473,8 @@ class Learner:
                 ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), ptr(self.bb_dzp1), ptr(self.bb_dzp), B // 64,
                 gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
                 gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
-                self.partials.data_ptr() + 4 * self._gb_blocks if self.fold_norm else None,
-                ptr(self.step_dev) if self.fold_norm else None, H, st), "bb_layer1_bwd_finish")
+                ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, H,
+                self._bb_segs, self._bb_nsegs, st), "bb_layer1_bwd_finish")
         elif "l1" in self.fuse:
             # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written). Data parallel over peer
             # memory: everything but layer 1's gradient is final by now (segments W2 .. Wh of the flat buffer) and goes
