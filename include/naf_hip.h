@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 5
+#define NAF_HIP_ABI_VERSION 6
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -262,8 +262,20 @@ int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const float* Wh, int 
                             int lda, const float* save_mean, const float* save_invstd, float* dy_out, int ldd,
                             float* partials, int B, int H, void* stream);
 int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz, const float* gamma, const float* save_mean,
-                         const float* save_invstd, const float* partials, float* d_gamma, float* d_beta,
-                         float* dz_col_partials, int B, int H, void* stream);
+                         const float* save_invstd, const float* partials, int n_partial_blocks /* B/64, or B/32 after
+                         naf_bb_layer2_head */, float* d_gamma, float* d_beta, float* dz_col_partials, int B, int H, void* stream);
+/* naf_bb_bn_relu_heads_partial + the NAF head (naf_head_fwd_bwd_mse: Q, y = r + gamma V'(s'), MSE, d_heads) +
+ * naf_bb_heads_bwd_stage1 in ONE launch for H = 256: a workgroup owns 32 batch rows across all features of both nets, heads and
+ * dA2 on f32 MFMA. Outputs: a2_out (main net's A2, ldo >= H; the target's is not needed again), running statistics, save_mean /
+ * save_invstd [2][H], q_out[B], d_heads[B][NHP], loss_partials[B/32], dy_out (dY2), partials_bw[B/32][H] (float2). u / r: the
+ * action and reward columns of the minibatch rows. Replaces naf_neural_network.py:78-115 + naf_algorithm.py:199-208 and the first
+ * half of layer 2's BatchNorm backward. */
+int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
+                       int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
+                       int64_t stat_net_stride, float* a2_out, int ldo, float* save_mean, float* save_invstd, const float* Wh,
+                       int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu, const float* r, int ldr, float gamma_td,
+                       float* q_out, float* d_heads, float* loss_partials, float* dy_out, int ldd, float* partials_bw, int B,
+                       int H, int A, int p_mode, float momentum, float eps, void* stream);
 /* backward of layer 1 (naf_bn_relu_bwd_wgrad's contract), row-split, three launches:
  *   stage = 1: z recomputed from x and W (the forward's arithmetic), dy = ReLU'(out) * d_out, block sums -> partials[B/64][H]
  *   stage = 2: folds them, dz, this block's share of dW = dZ^T X -> dw_slabs[B/64][H][KP] (KP = naf_bb_layer1_bwd_kp(K): 24

@@ -18,6 +18,7 @@
 //   gemm_bundle (dWh, dW2, dA1) -> bb_layer1_bwd (column-owning, streaming) -> grad norm -> Adam + Polyak
 #include <string.h>
 #include "bn_tile.h"
+#include "head_body.h"
 #include "../../include/naf_hip.h"
 
 #define BB_ROWS NAF_BB_ROWS      // rows per statistics block
@@ -445,6 +446,176 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_relu_heads_partial_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// layer 2 + heads + NAF head + first backward stage of layer 2 in ONE launch (H = 256): a workgroup owns 32 batch rows
+// across ALL 256 features, so nothing between the layer-2 pre-activations and dY2 leaves the chip:
+//   fold the layer-2 statistics of both nets (512 (net, column) pairs, one per thread) -> xhat tile of the main net in LDS
+//   (A2 = ReLU(gamma xhat + beta) written out for the dWh GEMM), V'(s') of the target net as a per-row dot product ->
+//   heads = A2 Wh^T on f32 MFMA (A2 formed from xhat while the fragments are read) -> naf_head_body (Q, TD target, MSE,
+//   d_heads) -> dA2 = d_heads Wh on f32 MFMA -> ReLU mask, dY2 and the block sums (sum dy, sum dy*xhat) per column.
+// Replaces bb_bn_relu_heads_partial + naf_head_kernel + bb_heads_bwd_stage1 (three launches, 19.9 us at B = 1024).
+// The backward partials are per 32-row block here: partials_bw[B/32][H].
+// ------------------------------------------------------------------------------------------------------------
+#define FK_ROWS 32
+#define FK_THREADS 512
+#define FK_H 256
+#define FK_LD (FK_H + 4)
+template <int PMODE, int NH4>
+__global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
+    const float* __restrict__ z, int64_t z_net_stride, int ldz, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int64_t param_net_stride, const float2* __restrict__ partials, int NB64,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride,
+    float* __restrict__ a2_out, int ldo, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    const float* __restrict__ Wh, int64_t wh_net_stride, int ldw, const float* __restrict__ u, int ldu,
+    const float* __restrict__ r, int ldr, float gamma_td, float* __restrict__ q_out, float* __restrict__ d_heads,
+    float* __restrict__ loss_partials, float* __restrict__ dy_out, int ldd, float2* __restrict__ partials_bw, int B, int A,
+    float momentum, float eps) {
+    constexpr int NHP = 4 * NH4, H = FK_H;
+    __shared__ __attribute__((aligned(16))) float sXH[FK_ROWS * FK_LD];
+    __shared__ __attribute__((aligned(16))) float sW[NHP * FK_LD];
+    __shared__ __attribute__((aligned(16))) float sHd[(FK_THREADS / 8) * NHP];      // heads rows (32 live)
+    __shared__ __attribute__((aligned(16))) float sDH[(FK_THREADS / 8) * NHP];      // d_heads rows
+    __shared__ __attribute__((aligned(16))) float sStat[2][4][H];                   // [net][mean, invstd, gamma, beta]
+    __shared__ __attribute__((aligned(16))) float sWv[H];
+    __shared__ float sBias[NHP + 1];
+    __shared__ float sV[FK_THREADS / 8];
+    __shared__ float sL[PMODE == NAF_P_MATMUL ? (FK_THREADS / 8) * 8 * LT_STRIDE : 1];
+    __shared__ float sRed[FK_THREADS / 64];
+    __shared__ float2 sP[2][H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = blockIdx.x;
+    const int64_t s0 = (int64_t)rb * FK_ROWS;
+    const int T = A * (A + 1) / 2, v_col = A + T;
+    // ---- phase 0: every global operand requested up front ---------------------------------------------------------
+    float4 zm[4], zt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave + 8 * i;                     // one wave per row: 64 lanes x 4 columns
+        zm[i] = *(const float4*)(z + (s0 + row) * ldz + 4 * lane);
+        zt[i] = *(const float4*)(z + z_net_stride + (s0 + row) * ldz + 4 * lane);
+    }
+    const int s_loc_ = tid >> 3, i_ = tid & 7;
+    const bool live_ = s_loc_ < FK_ROWS;
+    const float u_val = (live_ && i_ < A) ? u[(s0 + s_loc_) * ldu + i_] : 0.f;
+    const float r_val = (live_ && i_ == 0) ? r[(s0 + s_loc_) * ldr] : 0.f;
+    {
+        const int net = tid >> 8, col = tid & (H - 1);    // 512 threads = 2 nets x 256 columns
+        float mean, var;
+        bb_fold_stats(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
+        const float invstd = 1.0f / sqrtf(var + eps);
+        sStat[net][0][col] = mean;
+        sStat[net][1][col] = invstd;
+        sStat[net][2][col] = gamma[net * param_net_stride + col];
+        sStat[net][3][col] = beta[net * param_net_stride + col];
+        if (rb == 0) {
+            const int64_t so = net * stat_net_stride + col;
+            const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+            running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
+            running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+            save_mean[(int64_t)net * H + col] = mean;
+            save_invstd[(int64_t)net * H + col] = invstd;
+        }
+    }
+    for (int e = tid; e < NHP * (H / 4); e += FK_THREADS) {
+        const int h = e >> 6, q = e & 63;
+        *(float4*)(sW + h * FK_LD + 4 * q) = *(const float4*)(Wh + (int64_t)h * ldw + 4 * q);
+    }
+    if (tid < NHP) sBias[tid] = Wh[(int64_t)tid * ldw + H];          // bias = column H of Wh (the ones column of A2)
+    if (tid < H / 4) *(float4*)(sWv + 4 * tid) = *(const float4*)(Wh + wh_net_stride + (int64_t)v_col * ldw + 4 * tid);
+    if (tid == 0) sBias[NHP] = Wh[wh_net_stride + (int64_t)v_col * ldw + H];
+    for (int e = tid; e < (FK_THREADS / 8) * NHP; e += FK_THREADS) sDH[e] = 0.f;
+    __syncthreads();
+    // ---- phase 1: normalise. main net -> xhat (LDS) and A2 (memory); target net -> V'(s') ---------------------------
+    {
+        const float4 m0 = *(const float4*)&sStat[0][0][4 * lane], i0 = *(const float4*)&sStat[0][1][4 * lane];
+        const float4 g0 = *(const float4*)&sStat[0][2][4 * lane], b0 = *(const float4*)&sStat[0][3][4 * lane];
+        const float4 m1 = *(const float4*)&sStat[1][0][4 * lane], i1 = *(const float4*)&sStat[1][1][4 * lane];
+        const float4 g1 = *(const float4*)&sStat[1][2][4 * lane], b1 = *(const float4*)&sStat[1][3][4 * lane];
+        const float4 wv = *(const float4*)(sWv + 4 * lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave + 8 * i;
+            float4 xh, y;
+            xh.x = (zm[i].x - m0.x) * i0.x; xh.y = (zm[i].y - m0.y) * i0.y;
+            xh.z = (zm[i].z - m0.z) * i0.z; xh.w = (zm[i].w - m0.w) * i0.w;
+            y.x = fmaxf(__builtin_fmaf(xh.x, g0.x, b0.x), 0.f); y.y = fmaxf(__builtin_fmaf(xh.y, g0.y, b0.y), 0.f);
+            y.z = fmaxf(__builtin_fmaf(xh.z, g0.z, b0.z), 0.f); y.w = fmaxf(__builtin_fmaf(xh.w, g0.w, b0.w), 0.f);
+            *(float4*)(sXH + row * FK_LD + 4 * lane) = xh;
+            *(float4*)(a2_out + (s0 + row) * ldo + 4 * lane) = y;
+            float p = fmaxf(__builtin_fmaf((zt[i].x - m1.x) * i1.x, g1.x, b1.x), 0.f) * wv.x;
+            p = __builtin_fmaf(fmaxf(__builtin_fmaf((zt[i].y - m1.y) * i1.y, g1.y, b1.y), 0.f), wv.y, p);
+            p = __builtin_fmaf(fmaxf(__builtin_fmaf((zt[i].z - m1.z) * i1.z, g1.z, b1.z), 0.f), wv.z, p);
+            p = __builtin_fmaf(fmaxf(__builtin_fmaf((zt[i].w - m1.w) * i1.w, g1.w, b1.w), 0.f), wv.w, p);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+            if (lane == 0) sV[row] = p + sBias[NHP];
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: heads = A2 Wh^T + bias, 2 x NHP/16 MFMA tiles of K = 256 over the 8 waves --------------------------
+    const int rr = lane & 15, gg = lane >> 4;
+    for (int t = wave; t < 2 * (NHP / 16); t += 8) {
+        const int mt = t & 1, nt = t >> 1;
+        const float* pa = sXH + (16 * mt + rr) * FK_LD + 4 * gg;
+        const float* pb = sW + (16 * nt + rr) * FK_LD + 4 * gg;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int kk = 0; kk < H; kk += 16) {
+            const float4 xh = *(const float4*)(pa + kk), b = *(const float4*)(pb + kk);
+            const float4 g = *(const float4*)&sStat[0][2][kk + 4 * gg], be = *(const float4*)&sStat[0][3][kk + 4 * gg];
+            const float a0 = fmaxf(__builtin_fmaf(xh.x, g.x, be.x), 0.f), a1 = fmaxf(__builtin_fmaf(xh.y, g.y, be.y), 0.f);
+            const float a2 = fmaxf(__builtin_fmaf(xh.z, g.z, be.z), 0.f), a3 = fmaxf(__builtin_fmaf(xh.w, g.w, be.w), 0.f);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b.w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sHd[(16 * mt + 4 * gg + e) * NHP + 16 * nt + rr] = (acc0[e] + acc1[e]) + sBias[16 * nt + rr];
+    }
+    __syncthreads();
+    // ---- phase 3: the NAF head on the 32 rows (threads 0..255 carry samples; every thread joins the barriers) --------
+    naf_head_body<PMODE, 2, FK_THREADS>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td, q_out,
+                                        nullptr, loss_partials, B, A, s0, FK_ROWS);
+    if (tid < FK_ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
+    // ---- phase 4: dA2 = d_heads Wh (K = NHP), 2 x 16 tiles, 4 per wave; ReLU mask, dY2, block sums --------------------
+    {
+        const int mt = wave & 1;
+        const float* pa = sDH + (16 * mt + rr) * NHP + 4 * gg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nt = (wave >> 1) + 4 * j;
+            const int col = 16 * nt + rr;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NHP; kk += 16) {
+                const float4 a = *(const float4*)(pa + kk);
+                const float* q = sW + (kk + 4 * gg) * FK_LD + col;       // k-major operand: Wh[h][col]
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, q[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, q[FK_LD], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, q[2 * FK_LD], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, q[3 * FK_LD], acc, 0, 0, 0);
+            }
+            const float g = sStat[0][2][col], be = sStat[0][3][col];
+            float s_dy = 0.f, s_dx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 16 * mt + 4 * gg + e;
+                const float xh = sXH[row * FK_LD + col];
+                const float dy = __builtin_fmaf(xh, g, be) > 0.f ? acc[e] : 0.f;      // the forward's own ReLU decision
+                dy_out[(s0 + row) * ldd + col] = dy;
+                s_dy += dy;
+                s_dx += dy * xh;
+            }
+            s_dy += __shfl_xor(s_dy, 16); s_dy += __shfl_xor(s_dy, 32);
+            s_dx += __shfl_xor(s_dx, 16); s_dx += __shfl_xor(s_dx, 32);
+            if (gg == 0) sP[mt][col] = make_float2(s_dy, s_dx);
+        }
+    }
+    __syncthreads();
+    if (tid < H) partials_bw[(int64_t)rb * H + tid] = make_float2(sP[0][tid].x + sP[1][tid].x, sP[0][tid].y + sP[1][tid].y);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // backward of layer 2, stage 1: dA2 = dHeads Wh (reduction over the NHP <= 48 head outputs, on the fly), ReLU mask from
 // A2, xhat from Z2 and the saved statistics; writes dY2 and the per-block column sums (sum dy, sum dy*xhat).
 // ------------------------------------------------------------------------------------------------------------
@@ -532,13 +703,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
                                                                       const float* __restrict__ gamma,
                                                                       const float* __restrict__ save_mean,
                                                                       const float* __restrict__ save_invstd,
-                                                                      const float2* __restrict__ partials,
+                                                                      const float2* __restrict__ partials, int npb,
                                                                       float* __restrict__ d_gamma, float* __restrict__ d_beta,
                                                                       float* __restrict__ dz_col_partials, int B, int H) {
     __shared__ float sT[BB_ROWS][BB_COLS + 1];
     __shared__ float sC[5][BB_COLS];          // mean, invstd, k1, sum_dy / B, sum_dyxh / B
     const int tid = threadIdx.x;
-    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS, NB = gridDim.x;
+    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS;
     const int row = tid >> 2, cq = tid & 3;
     const int64_t grow = (int64_t)rb * BB_ROWS + row;
     float4 zv[4], dv[4];
@@ -549,7 +720,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
     }
     if (tid < BB_COLS) {
         const int col = col0 + tid;
-        const float2 sums = bb_fold_sums(partials, H, NB, col);
+        // npb partial blocks: B/64 from bb_heads_bwd_stage1, B/32 from bb_layer2_head (then folded in two rounds of 32)
+        float2 sums = bb_fold_sums(partials, H, npb < BB_MAX_NB ? npb : BB_MAX_NB, col);
+        if (npb > BB_MAX_NB) {
+            const float2 more = bb_fold_sums(partials + (int64_t)BB_MAX_NB * H, H, npb - BB_MAX_NB, col);
+            sums.x += more.x;
+            sums.y += more.y;
+        }
         const float sdy = sums.x, sdx = sums.y;
         const float invstd = save_invstd[col];
         sC[0][tid] = save_mean[col];
@@ -839,6 +1016,43 @@ extern "C" int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride
     return NAF_OK;
 }
 
+extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
+                                  int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
+                                  int64_t stat_net_stride, float* a2_out, int ldo, float* save_mean, float* save_invstd,
+                                  const float* Wh, int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu,
+                                  const float* r, int ldr, float gamma_td, float* q_out, float* d_heads, float* loss_partials,
+                                  float* dy_out, int ldd, float* partials_bw, int B, int H, int A, int p_mode, float momentum,
+                                  float eps, void* stream) {
+    if (!z || !gamma || !beta || !partials || !running_mean || !running_var || !a2_out || !save_mean || !save_invstd || !Wh ||
+        !u || !r || !q_out || !d_heads || !dy_out || !partials_bw || !bb_shape_ok(B, H) || H != FK_H)
+        return NAF_ERR_ARG;
+    if (A <= 0 || A > NAF_MAX_A || (NHP != 16 && NHP != 32 && NHP != 48) || NHP < A + A * (A + 1) / 2 + 1) return NAF_ERR_ARG;
+    if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
+    if (ldz < H || (ldz & 3) || ldo < H || (ldo & 3) || ldd < H || ldw <= H || (ldw & 3) || ldu < A || ldr < 1) return NAF_ERR_ARG;
+    if ((((uintptr_t)z | (uintptr_t)a2_out | (uintptr_t)Wh | (uintptr_t)d_heads) & 15) != 0 || (z_net_stride & 3) ||
+        (wh_net_stride & 3) || ((uintptr_t)partials & 7) || ((uintptr_t)partials_bw & 7))
+        return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = B / FK_ROWS;
+#define BB_FK(PM, NH4V)                                                                                                  \
+    bb_layer2_head_kernel<PM, NH4V><<<blocks, FK_THREADS, 0, st>>>(                                                      \
+        z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, B / BB_ROWS, running_mean, running_var, \
+        stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
+        loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps)
+#define BB_FK_NH(PM)                     \
+    do {                                 \
+        if (NHP == 16) BB_FK(PM, 4);     \
+        else if (NHP == 32) BB_FK(PM, 8); \
+        else BB_FK(PM, 12);              \
+    } while (0)
+    if (p_mode == NAF_P_HADAMARD) BB_FK_NH(NAF_P_HADAMARD);
+    else BB_FK_NH(NAF_P_MATMUL);
+#undef BB_FK_NH
+#undef BB_FK
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
 extern "C" int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const float* Wh, int ldw, const float* z, int ldz,
                                        const float* a2, int lda, const float* save_mean, const float* save_invstd,
                                        float* dy_out, int ldd, float* partials, int B, int H, void* stream) {
@@ -862,16 +1076,16 @@ extern "C" int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const floa
 }
 
 extern "C" int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz, const float* gamma, const float* save_mean,
-                                    const float* save_invstd, const float* partials, float* d_gamma, float* d_beta,
-                                    float* dz_col_partials, int B, int H, void* stream) {
+                                    const float* save_invstd, const float* partials, int n_partial_blocks, float* d_gamma,
+                                    float* d_beta, float* dz_col_partials, int B, int H, void* stream) {
     if (!dy || !z || !gamma || !save_mean || !save_invstd || !partials || !d_gamma || !d_beta || !dz_col_partials ||
-        !bb_shape_ok(B, H))
+        !bb_shape_ok(B, H) || n_partial_blocks < 1 || n_partial_blocks > 2 * BB_MAX_NB)
         return NAF_ERR_ARG;
     if (ldd < H || (ldd & 3) || ldz < H || (ldz & 3) || (((uintptr_t)dy | (uintptr_t)z) & 15) != 0) return NAF_ERR_ARG;
     dim3 grid(B / BB_ROWS, H / BB_COLS);
     bb_bn_bwd_stage2_kernel<<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(dy, ldd, z, ldz, gamma, save_mean, save_invstd,
-                                                                          (const float2*)partials, d_gamma, d_beta,
-                                                                          dz_col_partials, B, H);
+                                                                          (const float2*)partials, n_partial_blocks, d_gamma,
+                                                                          d_beta, dz_col_partials, B, H);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

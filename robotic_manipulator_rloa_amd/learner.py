@@ -173,11 +173,15 @@ class Learner:
         #        statistics in its epilogue, heads GEMM split over 4 column slices, streaming layer-1 backward
         lay0 = self.lay
         self.bb_ok = (self.B % 64 == 0 and 64 <= self.B <= 2048 and lay0.H in (128, 256) and lay0.S <= 26)
-        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else ("bb,gb" if self.bb_ok else "gb")).lower()
-        names = {"l1", "b2", "f3", "gb", "s3", "bb"}
-        self.fuse = (set(names) - {"bb"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
+        #   hk = (with bb, H = 256) layer 2 + heads + NAF head + first backward stage of layer 2 in one launch, a workgroup
+        #        per 32 batch rows (csrc/big_batch.hip: bb_layer2_head_kernel) instead of three launches
+        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else ("bb,gb,hk" if self.bb_ok else "gb")).lower()
+        names = {"l1", "b2", "f3", "gb", "s3", "bb", "hk"}
+        self.fuse = (set(names) - {"bb", "hk"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if "bb" in self.fuse:
-            self.fuse = ({"bb"} | (self.fuse & {"gb"})) if self.bb_ok else (self.fuse - {"bb"})
+            self.fuse = ({"bb"} | (self.fuse & {"gb", "hk"})) if self.bb_ok else (self.fuse - {"bb"})
+        if "bb" not in self.fuse or lay0.H != 256:
+            self.fuse -= {"hk"}
         if self.lay.S > 32:
             self.fuse -= {"l1"}
         if self.B % 16 != 0 or self.lay.H % 16 != 0:
@@ -250,7 +254,8 @@ class Learner:
             self.vnext_partial = torch.zeros(self.n_slabs, B, **f32)
             self.bb_st1 = torch.zeros(2, NB, H, 2, **f32)       # forward statistics partials of layer 1 / layer 2: (sum, M2)
             self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)
-            self.bb_bw2 = torch.zeros(NB, H, 2, **f32)          # backward partials of layer 2: (sum dy, sum dy*xhat)
+            self.bb_bw2 = torch.zeros(2 * NB, H, 2, **f32)      # backward partials of layer 2: (sum dy, sum dy*xhat); per 64-row
+            #                                                     block, or per 32-row block from the fused layer-2 + head launch
             self.bb_dzp = torch.zeros(NB, H, **f32)             # block sums of dZ2 (-> gradient of the layer-2 bias)
             self.bb_bw1 = torch.zeros(NB, H, 2, **f32)          # backward partials of layer 1
             self.bb_dzp1 = torch.zeros(NB, H, **f32)
@@ -354,6 +359,8 @@ class Learner:
             # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
             check(self._f.naf_bb_linear_stats(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset, t2p + 4 * seg["b2"].offset, P,
                                               ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, H, 2, st), "bb_linear_stats")
+            if "hk" in self.fuse:
+                return               # layer 2 from Z2 on is inside naf_bb_layer2_head (learn_rows)
             # fold + normalise + ReLU -> A2, and this column slice's share of the heads GEMM
             check(self._f.naf_bb_bn_relu_heads_partial(
                 ptr(self.G2), B * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
@@ -411,6 +418,16 @@ class Learner:
                 ptr(self.A2), B * HP, HP, HP, t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld,
                 rp + 4 * lay.off_r, ld, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "heads_gemm_head_fwd_bwd_mse")
+        elif "hk" in self.fuse:
+            self.forward_train(rows)
+            bnp = self.bn_stats.data_ptr()
+            # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
+            check(f.naf_bb_layer2_head(
+                ptr(self.G2), B * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
+                bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2[0]), HP, ptr(self.save_mean[1]), ptr(self.save_invstd[1]),
+                t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld, rp + 4 * lay.off_r, ld, self.gamma,
+                ptr(self.q_out), ptr(self.dH), lp, ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, lay.A, self.p_mode, BN_MOMENTUM,
+                BN_EPS, st), "bb_layer2_head")
         elif "s3" in self.fuse or "bb" in self.fuse:
             self.forward_train(rows)
             # the head adds the split-K slabs (H/8 of them, or H/64 in the large-batch chain) while staging its rows
@@ -431,13 +448,15 @@ class Learner:
         if not gb:
             torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
         if "bb" in self.fuse:
-            NB = B // 64
-            # backward of layer 2, two stages: dy = ReLU' * (dH Wh) with its block sums, then dz in place
-            check(f.naf_bb_heads_bwd_stage1(ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H,
-                                            ptr(self.A2[0]), HP, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]),
-                                            ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, st), "bb_heads_bwd_stage1")
+            # backward of layer 2, two stages: dy = ReLU' * (dH Wh) with its block sums (already done by the fused launch
+            # when "hk" is on), then dz in place
+            if "hk" not in self.fuse:
+                check(f.naf_bb_heads_bwd_stage1(ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H,
+                                                ptr(self.A2[0]), HP, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]),
+                                                ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, st), "bb_heads_bwd_stage1")
             check(f.naf_bb_bn_bwd_stage2(ptr(self.dZ2), H, ptr(self.G2[0]), H, t2p + 4 * seg["g2"].offset,
                                          ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.bb_bw2),
+                                         B // 32 if "hk" in self.fuse else B // 64,
                                          gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, ptr(self.bb_dzp), B, H, st),
                   "bb_bn_bwd_stage2")
         elif "b2" in self.fuse:
