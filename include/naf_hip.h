@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 6
+#define NAF_HIP_ABI_VERSION 7
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -231,14 +231,20 @@ int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int 
  * BLOCK mean) into partials[net][B/64][H] (float2), every consumer folds the B/64 partials of its columns in block order
  * (Chan's formula; fixed order, no atomics). B % 64 == 0, 64 <= B <= 2048, H % 64 == 0 everywhere below. */
 #define NAF_BB_ROWS 64
-/* layer 1 for `nets` networks, K = state size <= 32 (rows and W as in naf_linear_bn_relu_fwd_train). apply = 0: statistics
- * partials only (gamma .. save_invstd unused, may be NULL); apply = 1: recompute z, fold the partials, out = ReLU(BN(z)),
- * running statistics (by the block-0 workgroups), save_mean / save_invstd [nets][H]. */
+/* Layer 1 is linear in the minibatch rows, so its batch statistics (forward AND backward) follow from the first two
+ * moments of the input columns: record (naf_bb_moments_floats(K) f32) = [Sx(KP) | C(KP x KP)], Sx = column sums, C = centred
+ * second moments sum_r (x_j - m_j)(x_k - m_k), KP = 24 (K <= 24) or 32; accumulated in double. One launch for n_batches
+ * minibatches (x + b*batch_stride) x nets inputs (+ net*x_net_stride): mom[(b*nets + net) * record]. */
+int naf_bb_moments_floats(int K);
+int naf_bb_moments(const float* x, int64_t batch_stride, int64_t x_net_stride, int ldx, int K, float* mom, int B, int n_batches,
+                   int nets, void* stream);
+/* layer 1 for `nets` networks, K = state size <= 32 (rows and W as in naf_linear_bn_relu_fwd_train): mean_c = b_c + w_c . m,
+ * var_c = w_c^T C w_c / B from mom[net] (this minibatch's records), out = ReLU(BN(x W^T + b)), running statistics (by the
+ * block-0 workgroups), save_mean / save_invstd [nets][H]. */
 int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
-                  const float* gamma, const float* beta, int64_t param_net_stride, float* partials, float* running_mean,
+                  const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
                   float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
-                  float* save_mean, float* save_invstd, int B, int H, int nets, float momentum, float eps, int apply,
-                  void* stream);
+                  float* save_mean, float* save_invstd, int B, int H, int nets, float momentum, float eps, void* stream);
 /* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K in {128, 256}, N % 64 == 0) on f32 MFMA, 64 x 32 tiles, with the
  * column statistics partials of every 64-row block written by the epilogue: replaces `self.hidden_layer(x)`
  * (naf_neural_network.py:78) and the statistics pass of bn2 for both networks. */
@@ -276,17 +282,17 @@ int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const floa
                        int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu, const float* r, int ldr, float gamma_td,
                        float* q_out, float* d_heads, float* loss_partials, float* dy_out, int ldd, float* partials_bw, int B,
                        int H, int A, int p_mode, float momentum, float eps, void* stream);
-/* backward of layer 1 (naf_bn_relu_bwd_wgrad's contract), row-split, three launches:
- *   stage = 1: z recomputed from x and W (the forward's arithmetic), dy = ReLU'(out) * d_out, block sums -> partials[B/64][H]
- *   stage = 2: folds them, dz, this block's share of dW = dZ^T X -> dw_slabs[B/64][H][KP] (KP = naf_bb_layer1_bwd_kp(K): 24
- *              or 32) and its column sums of dz -> dz1_col_partials[B/64][H]
- *   finish   : adds slabs and block sums in block order -> d_W[H][K], d_gamma, d_beta, d_bias (layer 1) and d_bias2 (layer 2,
- *              from naf_bb_bn_bwd_stage2's dz_col_partials). K <= 26. sumsq_partials (nullable): [ceil(H/8)] sums of squares of
- *              everything written here plus d_gamma2 / d_beta2 (then required: read, not written) — the gradient-norm
- *              partials of all vector gradients; step_dev (nullable): *step_dev += 1 like naf_grad_norm_partials. */
+/* backward of layer 1 (naf_bn_relu_bwd_wgrad's contract), row-split: ONE pass over the batch and a finish launch. With
+ * dz = k1 (dy - c1 - xhat c2): dW[c][k] = k1_c (P[c][k] - c1_c Sx[k] - c2_c invstd_c (w_c C)[k]), P = dY^T X — the xhat term
+ * comes from the moments record, so the pass only produces dy = ReLU'(out) * d_out, its block sums partials[B/64][H] (float2:
+ * sum dy, sum dy*xhat) and the block shares p_slabs[B/64][H][KP] of P (KP = naf_bb_layer1_bwd_kp(K)).
+ * finish: folds them in block order -> d_W[H][K], d_gamma, d_beta, d_bias = 0 (sum_r dz vanishes identically; the reference's
+ * value is rounding noise that the train-mode BatchNorm cancels), d_bias2 (layer 2, from naf_bb_bn_bwd_stage2's
+ * dz_col_partials). K <= 26. mom: the MAIN net's moments record. sumsq_partials (nullable): sums of squares of everything
+ * written here plus d_gamma2 / d_beta2 (then required: read, not written); step_dev (nullable): *step_dev += 1. */
 int naf_bb_layer1_bwd(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W, const float* bias,
-                      const float* out, int ldo, const float* gamma, const float* save_mean, const float* save_invstd,
-                      float* partials, float* dw_slabs, float* dz1_col_partials, int B, int H, int stage, void* stream);
+                      const float* out, int ldo, const float* save_mean, const float* save_invstd, float* partials,
+                      float* p_slabs, int B, int H, void* stream);
 int naf_bb_layer1_bwd_kp(int K);
 /* segs (HOST array, n_segs <= 2, may be 0): split-K slabs of the bundle's weight gradients (naf_gemm_desc_t.k_split), added in
  * slab order by extra workgroups of the same launch: dst[i] = sum_s src[s * stride + i], i < n (n % 4 == 0, n_slabs <= 8);
@@ -297,10 +303,11 @@ typedef struct naf_bb_slab_seg {
     int64_t stride;
     int n, n_slabs;
 } naf_bb_slab_seg_t;
-int naf_bb_layer1_bwd_finish(const float* dw_slabs, int K, const float* partials1, const float* dz1_col_partials,
-                             const float* dz2_col_partials, int nb, float* d_W, float* d_gamma, float* d_beta, float* d_bias,
-                             float* d_bias2, const float* d_gamma2, const float* d_beta2, float* sumsq_partials,
-                             int32_t* step_dev, int H, const naf_bb_slab_seg_t* segs, int n_segs, void* stream);
+int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, const float* dz2_col_partials, int nb,
+                             const float* mom, const float* W, const float* gamma, const float* save_invstd, float* d_W,
+                             float* d_gamma, float* d_beta, float* d_bias, float* d_bias2, const float* d_gamma2,
+                             const float* d_beta2, float* sumsq_partials, int32_t* step_dev, int B, int H,
+                             const naf_bb_slab_seg_t* segs, int n_segs, void* stream);
 
 /* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
 /* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is

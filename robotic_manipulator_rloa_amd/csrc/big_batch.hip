@@ -85,6 +85,85 @@ __device__ static inline float bb_col_sum64(const float (*t)[BB_COLS + 1], int c
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Layer 1 is LINEAR in the minibatch rows, so everything BatchNorm needs from the batch dimension follows from the first
+// two moments of X = the state (net 0) / next-state (net 1) columns of the rows, which do not depend on the weights:
+//   Sx[k] = sum_r x[r][k],  m = Sx / B,  C[j][k] = sum_r (x[r][j] - m_j)(x[r][k] - m_k)        (double accumulation)
+//   mean_c = b_c + w_c . m          var_c = w_c^T C w_c / B                                     (forward statistics)
+//   sum_r xhat[r][c] x[r][k] = invstd_c (w_c C)[k]                                               (backward, see finish)
+// One launch computes them for ALL minibatches of a chunk (grid = minibatches x nets) right behind the gather, off the
+// per-update critical path: the statistics launch of layer 1 and the second stage of its backward disappear.
+// moments record (f32): [Sx (KP) | C (KP x KP)], KP = 24 or 32 (columns >= K meet zero weights).
+// ------------------------------------------------------------------------------------------------------------
+#define BM_CHUNK 256
+template <int K4>
+__global__ __launch_bounds__(BB_THREADS) void bb_moments_kernel(const float* __restrict__ x, int64_t batch_stride,
+                                                                int64_t x_net_stride, int ldx, float* __restrict__ mom,
+                                                                int B) {
+    constexpr int KP = 4 * K4, XS = KP + 4, REC = KP + KP * KP;
+    __shared__ __attribute__((aligned(16))) float sX[BM_CHUNK * XS];
+    __shared__ double sRed[8][32];
+    __shared__ double sM[32];
+    const int tid = threadIdx.x;
+    const float* xb = x + blockIdx.x * batch_stride + blockIdx.y * x_net_stride;
+    float* out = mom + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * REC;
+    auto stage = [&](int row0) {
+        for (int e = tid; e < BM_CHUNK * K4; e += BB_THREADS) {
+            const int r_ = e / K4, q = e - r_ * K4;
+            const int row = row0 + r_;
+            *(float4*)(sX + r_ * XS + 4 * q) =
+                row < B ? ((const float4*)(xb + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // pass 1: column sums
+    const int k1 = tid & 31, g1 = tid >> 5;
+    double s = 0.0;
+    for (int row0 = 0; row0 < B; row0 += BM_CHUNK) {
+        __syncthreads();
+        stage(row0);
+        __syncthreads();
+        if (k1 < KP)
+            for (int r_ = g1; r_ < BM_CHUNK; r_ += 8) s += (double)sX[r_ * XS + k1];
+    }
+    sRed[g1][k1] = s;
+    __syncthreads();
+    if (tid < 32) {
+        double t = 0.0;
+        for (int g = 0; g < 8; ++g) t += sRed[g][tid];
+        sM[tid] = t / (double)B;
+        if (tid < KP) out[tid] = (float)t;
+    }
+    // pass 2: centred second moments; thread owns entries e = tid + 256 i of the KP x KP matrix
+    constexpr int NE = (KP * KP + BB_THREADS - 1) / BB_THREADS;
+    double acc[NE];
+    int ej[NE], ek[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + BB_THREADS * i;
+        acc[i] = 0.0;
+        ej[i] = e < KP * KP ? e / KP : 0;
+        ek[i] = e < KP * KP ? e - ej[i] * KP : 0;
+    }
+    for (int row0 = 0; row0 < B; row0 += BM_CHUNK) {
+        __syncthreads();
+        stage(row0);
+        __syncthreads();
+        const int nr = (B - row0) < BM_CHUNK ? (B - row0) : BM_CHUNK;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const double mj = sM[ej[i]], mk = sM[ek[i]];
+            double a = 0.0;
+            for (int r_ = 0; r_ < nr; ++r_) a += ((double)sX[r_ * XS + ej[i]] - mj) * ((double)sX[r_ * XS + ek[i]] - mk);
+            acc[i] += a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + BB_THREADS * i;
+        if (e < KP * KP) out[KP + e] = (float)acc[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // layer 1 (K = state size <= 32): z tile of 64 rows x 64 columns, thread (ty = tid >> 4, tx = tid & 15) owns rows
 // 4 ty .. +3 and columns 4 tx .. +3. Operands go through LDS TRANSPOSED ([k][row], [k][column]) so that a thread's four
 // rows / four columns are one 16-byte LDS read per k. z = b + sum_k x_k w_k, k ascending — the SAME code in the
@@ -149,75 +228,89 @@ __device__ static inline void bb_tile_col_sums(const float (&v)[4][4], float (*r
     for (int j = 0; j < 4; ++j) out[j] = (red[0][4 * tx + j] + red[1][4 * tx + j]) + (red[2][4 * tx + j] + red[3][4 * tx + j]);
 }
 
-template <int K4, bool APPLY>
+// per-column forward statistics of layer 1 from the moments record: 4 threads per column (tid >> 2 = column of the
+// workgroup's 64, tid & 3 = quarter of the rows of C), folded by two xor shuffles. sMom: [Sx | C] in LDS, sWt: [k][column].
+template <int K4>
+__device__ static inline void bb_l1_stats_from_moments(const float* sMom, const float (*sWt)[BB_COLS + 4], float bias_c, int B,
+                                                       int tid, float* mean, float* var) {
+    constexpr int KP = 4 * K4, KQ = KP / 4;
+    const int c = tid >> 2, part = tid & 3;
+    float t = 0.f, mdot = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KQ; ++jj) {
+        const int j = part * KQ + jj;
+        const float wj = sWt[j][c];
+        float row = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) row = __builtin_fmaf(sMom[KP + j * KP + k], sWt[k][c], row);
+        t = __builtin_fmaf(wj, row, t);
+        mdot = __builtin_fmaf(wj, sMom[j], mdot);
+    }
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    mdot += __shfl_xor(mdot, 1);
+    mdot += __shfl_xor(mdot, 2);
+    *mean = bias_c + mdot / (float)B;
+    *var = fmaxf(t, 0.f) / (float)B;
+}
+
+// layer 1 forward for `nets` networks: statistics from the moments, z tile, normalise, ReLU -> out
+template <int K4>
 __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
     const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
-    int64_t param_net_stride, float2* __restrict__ partials, float* __restrict__ running_mean,
+    int64_t param_net_stride, const float* __restrict__ mom, float* __restrict__ running_mean,
     float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out, int64_t out_net_stride, int ldo,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, int B, int H, float momentum, float eps) {
-    __shared__ __attribute__((aligned(16))) float sXt[4 * K4][BB_ROWS + 4];
-    __shared__ __attribute__((aligned(16))) float sWt[4 * K4][BB_COLS + 4];
-    __shared__ float red[4][BB_COLS];
-    __shared__ float sStat[4][BB_COLS];     // APPLY: mean, invstd, gamma, beta of this workgroup's columns
+    constexpr int KP = 4 * K4, REC = KP + KP * KP;
+    __shared__ __attribute__((aligned(16))) float sXt[KP][BB_ROWS + 4];
+    __shared__ __attribute__((aligned(16))) float sWt[KP][BB_COLS + 4];
+    __shared__ __attribute__((aligned(16))) float sMom[REC];
+    __shared__ float sStat[4][BB_COLS];     // mean, invstd, gamma, beta of this workgroup's columns
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS, net = blockIdx.z;
-    const int NB = gridDim.x;
     const int64_t po = net * param_net_stride;
     bb_l1_stage<K4>(x + net * x_net_stride, ldx, rb * BB_ROWS, W + po, K, col0, H, sXt, sWt, tid);
+    for (int e = tid; e < REC / 4; e += BB_THREADS) ((float4*)sMom)[e] = ((const float4*)(mom + (int64_t)net * REC))[e];
     const float4 b4 = *(const float4*)(bias + po + col0 + 4 * tx);
-    const float2* pn = partials + (int64_t)net * NB * H;
-    if (APPLY && tid < BB_COLS) {
-        const int col = col0 + tid;
+    const float bias_c = bias[po + col0 + (tid >> 2)];
+    const float gm = gamma[po + col0 + (tid >> 2)], bt = beta[po + col0 + (tid >> 2)];
+    __syncthreads();
+    {
         float mean, var;
-        bb_fold_stats(pn, H, NB, B, col, &mean, &var);
-        const float invstd = 1.0f / sqrtf(var + eps);
-        sStat[0][tid] = mean;
-        sStat[1][tid] = invstd;
-        sStat[2][tid] = gamma[po + col];
-        sStat[3][tid] = beta[po + col];
-        if (rb == 0) {
-            const int64_t so = net * stat_net_stride + col;
-            const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-            running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
-            running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
-            save_mean[(int64_t)net * H + col] = mean;
-            save_invstd[(int64_t)net * H + col] = invstd;
+        bb_l1_stats_from_moments<K4>(sMom, sWt, bias_c, B, tid, &mean, &var);
+        if ((tid & 3) == 0) {
+            const int c = tid >> 2, col = col0 + c;
+            const float invstd = 1.0f / sqrtf(var + eps);
+            sStat[0][c] = mean;
+            sStat[1][c] = invstd;
+            sStat[2][c] = gm;
+            sStat[3][c] = bt;
+            if (rb == 0) {
+                const int64_t so = net * stat_net_stride + col;
+                const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+                running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
+                running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+                save_mean[(int64_t)net * H + col] = mean;
+                save_invstd[(int64_t)net * H + col] = invstd;
+            }
         }
     }
-    __syncthreads();
     float z[4][4];
     bb_l1_tile<K4>(sXt, sWt, b4, ty, tx, z);
-    if (!APPLY) {
-        float S[4], M2[4], d[4][4];
-        bb_tile_col_sums(z, red, tid, tx, S);
+    __syncthreads();
+    float* oz = out + net * out_net_stride;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        float4 y;
+        float* yp = (float*)&y;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float t = z[i][j] - S[j] * (1.0f / BB_ROWS);
-                d[i][j] = t * t;
-            }
-        bb_tile_col_sums(d, red, tid, tx, M2);
-        if (ty == 0) {
-            float2* dst = partials + ((int64_t)net * NB + rb) * H + col0 + 4 * tx;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = make_float2(S[j], M2[j]);
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * tx + j;
+            const float t = (z[i][j] - sStat[0][c]) * sStat[1][c] * sStat[2][c] + sStat[3][c];
+            yp[j] = t > 0.f ? t : 0.f;
         }
-    } else {
-        float* oz = out + net * out_net_stride;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 y;
-            float* yp = (float*)&y;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = 4 * tx + j;
-                const float t = (z[i][j] - sStat[0][c]) * sStat[1][c] * sStat[2][c] + sStat[3][c];
-                yp[j] = t > 0.f ? t : 0.f;
-            }
-            *(float4*)(oz + (int64_t)(rb * BB_ROWS + 4 * ty + i) * ldo + col0 + 4 * tx) = y;
-        }
+        *(float4*)(oz + (int64_t)(rb * BB_ROWS + 4 * ty + i) * ldo + col0 + 4 * tx) = y;
     }
 }
 
@@ -758,31 +851,31 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// backward of layer 1 (one network), row-split like the rest: three short launches instead of one column-owning kernel
-// that walks all B rows (measured at B = 1024 / 2048: 37.8 / 94.5 us for a streaming column owner — eight serial
-// stage -> barrier -> compute rounds per pass on 32 workgroups — against three launches of a few us each).
-//   stage 1   z recomputed from X and W1 (the forward's arithmetic), xhat, dy = ReLU'(A1) * dA1, block sums (sum dy,
-//             sum dy*xhat) per column                                                  -> partials[B/64][H]
-//   stage 2   the same recomputation, the folded sums, dz; the block's share of dW1 = dZ1^T X (64 columns x K) as a
-//             slab, and the block's column sums of dz                                  -> dw_slabs[B/64][H][KP], dzp[B/64][H]
-//   finish    slabs and block sums added in block order -> dW1, d_gamma1, d_beta1, d_bias1, and the bias gradient of
-//             layer 2 from ITS block sums; optionally the sum of squares of every vector gradient (both layers) for the
-//             gradient norm
+// backward of layer 1 (one network), row-split, ONE pass over the batch + a finish launch. With dz = k1 (dy - c1 - xhat c2)
+// (k1 = gamma invstd, c1 = sum dy / B, c2 = sum dy xhat / B, all per column):
+//   dW1[c][k] = sum_r dz[r][c] x[r][k] = k1_c ( P[c][k] - c1_c Sx[k] - c2_c invstd_c (w_c C)[k] ),   P = dY^T X
+// because sum_r xhat[r][c] x[r][k] = invstd_c sum_j w[c][j] C[j][k] (layer 1 is linear in x; Sx, C = the moments record).
+// So the batch pass only needs dy: its block sums (sum dy, sum dy*xhat) and the block's share of P. The bias gradient
+// sum_r dz is k1 c2 sum_r xhat = 0 by construction of the mean; it is written as 0 (the reference's value is rounding
+// noise that the train-mode BatchNorm cancels).
+//   pass     z recomputed from X and W1 (the forward's arithmetic), xhat, dy = ReLU'(A1) * dA1
+//                                                         -> partials[B/64][H] (float2), p_slabs[B/64][H][KP]
+//   finish   folds both in block order -> dW1, d_gamma1, d_beta1, d_bias1 = 0, the bias gradient of layer 2 from its
+//            block sums, the split-K slabs of the bundle, and the sum-of-squares partials of everything
 // ------------------------------------------------------------------------------------------------------------
-template <int K4, bool STAGE2>
+template <int K4>
 __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
     const float* __restrict__ d_out, int ld_dout, const float* __restrict__ x, int ldx, int K, const float* __restrict__ W,
-    const float* __restrict__ bias, const float* __restrict__ out, int ldo, const float* __restrict__ gamma,
-    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float2* __restrict__ partials,
-    float* __restrict__ dw_slabs, float* __restrict__ dz_col_partials, int B, int H) {
+    const float* __restrict__ bias, const float* __restrict__ out, int ldo, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, float2* __restrict__ partials, float* __restrict__ p_slabs, int B, int H) {
     constexpr int KP = 4 * K4;
     __shared__ __attribute__((aligned(16))) float sXt[KP][BB_ROWS + 4];
     __shared__ __attribute__((aligned(16))) float sWt[KP][BB_COLS + 4];
     __shared__ float red[4][BB_COLS];
-    __shared__ float sC[5][BB_COLS];                     // mean, invstd, k1, sum_dy / B, sum_dyxh / B
-    __shared__ float sDZ[STAGE2 ? BB_ROWS : 1][BB_COLS + 1];
+    __shared__ float sC[2][BB_COLS];                     // mean, invstd
+    __shared__ float sDY[BB_ROWS][BB_COLS + 1];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS, NB = gridDim.x;
+    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS;
     // this thread's 4 x 4 of dA1 and A1 first, the tile operands behind them
     float4 dv[4], ov[4];
 #pragma unroll
@@ -794,17 +887,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
     bb_l1_stage<K4>(x, ldx, rb * BB_ROWS, W, K, col0, H, sXt, sWt, tid);
     const float4 b4 = *(const float4*)(bias + col0 + 4 * tx);
     if (tid < BB_COLS) {
-        const int col = col0 + tid;
-        const float invstd = save_invstd[col];
-        sC[0][tid] = save_mean[col];
-        sC[1][tid] = invstd;
-        if (STAGE2) {
-            const float2 sums = bb_fold_sums(partials, H, NB, col);
-            const float sdy = sums.x, sdx = sums.y;
-            sC[2][tid] = gamma[col] * invstd;
-            sC[3][tid] = sdy / (float)B;
-            sC[4][tid] = sdx / (float)B;
-        }
+        sC[0][tid] = save_mean[col0 + tid];
+        sC[1][tid] = save_invstd[col0 + tid];
     }
     __syncthreads();
     float z[4][4];
@@ -818,26 +902,19 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
             const int c = 4 * tx + j;
             const float xh = (z[i][j] - sC[0][c]) * sC[1][c];
             const float d = o4[j] > 0.f ? d4[j] : 0.f;
-            if (!STAGE2) {
-                dy[i][j] = d;
-                dyxh[i][j] = d * xh;
-            } else {
-                sDZ[4 * ty + i][c] = sC[2][c] * (d - sC[3][c] - xh * sC[4][c]);
-            }
+            dy[i][j] = d;
+            dyxh[i][j] = d * xh;
+            sDY[4 * ty + i][c] = d;
         }
     }
-    if (!STAGE2) {
-        float s1[4], s2[4];
-        bb_tile_col_sums(dy, red, tid, tx, s1);
-        bb_tile_col_sums(dyxh, red, tid, tx, s2);
-        if (ty == 0) {
+    float s1[4], s2[4];
+    bb_tile_col_sums(dy, red, tid, tx, s1);              // (its barriers also publish sDY)
+    bb_tile_col_sums(dyxh, red, tid, tx, s2);
+    if (ty == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) partials[(int64_t)rb * H + col0 + 4 * tx + j] = make_float2(s1[j], s2[j]);
-        }
-        return;
+        for (int j = 0; j < 4; ++j) partials[(int64_t)rb * H + col0 + 4 * tx + j] = make_float2(s1[j], s2[j]);
     }
-    __syncthreads();
-    // dW slab of this block: thread = (column c, quarter kq of the k range): sum over the 64 rows, row ascending
+    // P slab of this block: thread = (column c, quarter kq of the k range): sum over the 64 rows, row ascending
     {
         constexpr int KQ = KP / 4;
         const int c = tid >> 2, kq = tid & 3;
@@ -846,19 +923,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
         for (int k = 0; k < KQ; ++k) acc[k] = 0.f;
 #pragma unroll 8
         for (int r = 0; r < BB_ROWS; ++r) {
-            const float dz = sDZ[r][c];
+            const float d = sDY[r][c];
 #pragma unroll
-            for (int k = 0; k < KQ; ++k) acc[k] = __builtin_fmaf(dz, sXt[KQ * kq + k][r], acc[k]);
+            for (int k = 0; k < KQ; ++k) acc[k] = __builtin_fmaf(d, sXt[KQ * kq + k][r], acc[k]);
         }
-        float* dst = dw_slabs + ((int64_t)rb * H + col0 + c) * KP + KQ * kq;
+        float* dst = p_slabs + ((int64_t)rb * H + col0 + c) * KP + KQ * kq;
 #pragma unroll
         for (int k = 0; k < KQ; ++k) dst[k] = acc[k];
-    }
-    if (tid < BB_COLS) {
-        float sdz = 0.f;
-#pragma unroll 16
-        for (int r = 0; r < BB_ROWS; ++r) sdz += sDZ[r][tid];
-        dz_col_partials[(int64_t)rb * H + col0 + tid] = sdz;
     }
 }
 
@@ -878,12 +949,14 @@ struct BbSlabs {
 };
 #define BB_MAX_SLABS 8
 __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
-    const float* __restrict__ dw_slabs, int KP, int K, const float2* __restrict__ partials1,
-    const float* __restrict__ dz1_col_partials, const float* __restrict__ dz2_col_partials, int NB,
-    float* __restrict__ d_W, float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias,
-    float* __restrict__ d_bias2, const float* __restrict__ d_gamma2, const float* __restrict__ d_beta2,
-    float* __restrict__ sumsq_partials, int32_t* step_dev, int H, const BbSlabs slabs) {
+    const float* __restrict__ p_slabs, int KP, int K, const float2* __restrict__ partials1,
+    const float* __restrict__ dz2_col_partials, int NB, const float* __restrict__ mom, const float* __restrict__ W,
+    const float* __restrict__ gamma, const float* __restrict__ save_invstd, float* __restrict__ d_W,
+    float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_bias2,
+    const float* __restrict__ d_gamma2, const float* __restrict__ d_beta2, float* __restrict__ sumsq_partials,
+    int32_t* step_dev, int B, int H, const BbSlabs slabs) {
     __shared__ float sQ[BB_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) float sMom[32 + 32 * 32];
     const int tid = threadIdx.x;
     float sq = 0.f;
     if ((int)blockIdx.x >= slabs.n_finish_blocks) {
@@ -905,22 +978,41 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
     } else {
         const int c = tid >> 5, k = tid & 31;
         const int col = blockIdx.x * BF_COLS + c;
-        if (col < H) {
+        const bool col_on = col < H;
+        const int colc = col_on ? col : H - 1;
+        // everything requested up front: the P slabs of (col, k), the block sums, the column's constants
+        const float P = k < K ? bb_fold_sum1(p_slabs + (int64_t)colc * KP + k, (int64_t)H * KP, NB) : 0.f;
+        float2 ab = make_float2(0.f, 0.f);
+        if (k == 27) ab = bb_fold_sums(partials1, H, NB, colc);
+        const float db2 = k == 30 ? bb_fold_sum1(dz2_col_partials + colc, H, NB) : 0.f;
+        const float invstd = save_invstd[colc], gm = gamma[colc];
+        const float wk = k < K ? W[(int64_t)colc * K + k] : 0.f;     // lane k holds w[c][k]
+        for (int e = tid; e < (KP + KP * KP) / 4; e += BB_THREADS) ((float4*)sMom)[e] = ((const float4*)mom)[e];
+        __syncthreads();
+        const int lbase = (tid & 63) & ~31;
+        const float sdy = __shfl(ab.x, lbase + 27), sdx = __shfl(ab.y, lbase + 27);
+        // (w_c C)[k] = sum_j w[c][j] C[j][k]: w[c][j] comes from lane j of this column's 32
+        float wc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float wj = __shfl(wk, lbase + j);
+            if (j < KP && k < KP) wc = __builtin_fmaf(wj, sMom[KP + j * KP + k], wc);
+        }
+        if (col_on) {
             if (k < K) {
-                const float s = bb_fold_sum1(dw_slabs + (int64_t)col * KP + k, (int64_t)H * KP, NB);
-                d_W[(int64_t)col * K + k] = s;
-                sq = s * s;
+                const float invB = 1.0f / (float)B;
+                const float g = (gm * invstd) * (P - (sdy * invB) * sMom[k] - (sdx * invB) * (invstd * wc));
+                d_W[(int64_t)col * K + k] = g;
+                sq = g * g;
             }
-            // the vector gradients of this column go to lanes that have no k to sum (K <= 26)
-            if (k == 27 || k == 28) {
-                const float2 ab = bb_fold_sums(partials1, H, NB, col);
-                const float v = k == 27 ? ab.y : ab.x;         // d_gamma = sum dy*xhat, d_beta = sum dy
-                (k == 27 ? d_gamma : d_beta)[col] = v;
-                sq += v * v;
-            } else if (k == 29 || k == 30) {
-                const float s = bb_fold_sum1((k == 29 ? dz1_col_partials : dz2_col_partials) + col, H, NB);
-                (k == 29 ? d_bias : d_bias2)[col] = s;
-                sq += s * s;
+            if (k == 27) {                                   // d_gamma = sum dy*xhat, d_beta = sum dy; d_bias = 0 (see above)
+                d_gamma[col] = sdx;
+                d_beta[col] = sdy;
+                d_bias[col] = 0.f;
+                sq += sdx * sdx + sdy * sdy;
+            } else if (k == 30) {
+                d_bias2[col] = db2;
+                sq += db2 * db2;
             } else if (k == 31 && d_gamma2) {
                 const float g = d_gamma2[col], b = d_beta2[col];   // written by bb_bn_bwd_stage2, an earlier launch
                 sq += g * g + b * b;
@@ -941,30 +1033,46 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
 // ------------------------------------------------------------------------------------------------------------
 static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && (B % BB_ROWS) == 0 && B <= 32 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
 
+extern "C" int naf_bb_moments_floats(int K) {
+    if (K <= 0 || K > 4 * BB_MAX_K4) return NAF_ERR_ARG;
+    const int kp = (K + 3) / 4 <= 6 ? 24 : 32;
+    return kp + kp * kp;
+}
+
+extern "C" int naf_bb_moments(const float* x, int64_t batch_stride, int64_t x_net_stride, int ldx, int K, float* mom, int B,
+                              int n_batches, int nets, void* stream) {
+    if (!x || !mom || B <= 0 || n_batches <= 0 || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4) return NAF_ERR_ARG;
+    const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
+    if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d || (x_net_stride & 3) != 0 || (batch_stride & 3) != 0 ||
+        ((uintptr_t)mom & 15) != 0)
+        return NAF_ERR_ARG;
+    dim3 grid(n_batches, nets);
+    if (k4d == 6) bb_moments_kernel<6><<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(x, batch_stride, x_net_stride, ldx, mom, B);
+    else bb_moments_kernel<8><<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(x, batch_stride, x_net_stride, ldx, mom, B);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
 extern "C" int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
-                             const float* gamma, const float* beta, int64_t param_net_stride, float* partials,
+                             const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
                              float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
                              int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, int B, int H, int nets,
-                             float momentum, float eps, int apply, void* stream) {
-    if (!x || !W || !bias || !partials || !bb_shape_ok(B, H) || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4) return NAF_ERR_ARG;
-    if (apply && (!gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd || ldo < H || (ldo & 3)))
+                             float momentum, float eps, void* stream) {
+    if (!x || !W || !bias || !mom || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd ||
+        !bb_shape_ok(B, H) || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4 || ldo < H || (ldo & 3))
         return NAF_ERR_ARG;
     const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
     if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d || (x_net_stride & 3) != 0) return NAF_ERR_ARG;
-    if ((((uintptr_t)bias | (uintptr_t)out) & 15) != 0 || (param_net_stride & 3) != 0 || (out_net_stride & 3) != 0 ||
-        ((uintptr_t)partials & 7) != 0)
+    if ((((uintptr_t)bias | (uintptr_t)out | (uintptr_t)mom) & 15) != 0 || (param_net_stride & 3) != 0 || (out_net_stride & 3) != 0)
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B / BB_ROWS, H / BB_COLS, nets);
-#define BB_L1(K4V, AP)                                                                                                   \
-    bb_layer1_kernel<K4V, AP><<<grid, BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, \
-                                                           (float2*)partials, running_mean, running_var, stat_net_stride,  \
-                                                           out, out_net_stride, ldo, save_mean, save_invstd, B, H, momentum, eps)
-    if (k4d == 6) {
-        if (apply) BB_L1(6, true); else BB_L1(6, false);
-    } else {
-        if (apply) BB_L1(8, true); else BB_L1(8, false);
-    }
+#define BB_L1(K4V)                                                                                                        \
+    bb_layer1_kernel<K4V><<<grid, BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
+                                                       running_mean, running_var, stat_net_stride, out, out_net_stride, ldo,  \
+                                                       save_mean, save_invstd, B, H, momentum, eps)
+    if (k4d == 6) BB_L1(6);
+    else BB_L1(8);
 #undef BB_L1
     NAF_CHECK_LAUNCH();
     return NAF_OK;
@@ -1091,28 +1199,22 @@ extern "C" int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz,
 }
 
 extern "C" int naf_bb_layer1_bwd(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
-                                 const float* bias, const float* out, int ldo, const float* gamma, const float* save_mean,
-                                 const float* save_invstd, float* partials, float* dw_slabs, float* dz1_col_partials,
-                                 int B, int H, int stage, void* stream) {
-    if (!d_out || !x || !W || !bias || !out || !gamma || !save_mean || !save_invstd || !partials || !bb_shape_ok(B, H))
+                                 const float* bias, const float* out, int ldo, const float* save_mean,
+                                 const float* save_invstd, float* partials, float* p_slabs, int B, int H, void* stream) {
+    if (!d_out || !x || !W || !bias || !out || !save_mean || !save_invstd || !partials || !p_slabs || !bb_shape_ok(B, H))
         return NAF_ERR_ARG;
-    if (K <= 0 || K > 4 * BB_MAX_K4 || ld_dout < H || (ld_dout & 3) || ldo < H || (ldo & 3) || (stage != 1 && stage != 2))
-        return NAF_ERR_ARG;
-    if (stage == 2 && (!dw_slabs || !dz1_col_partials)) return NAF_ERR_ARG;
+    if (K <= 0 || K > 4 * BB_MAX_K4 || ld_dout < H || (ld_dout & 3) || ldo < H || (ldo & 3)) return NAF_ERR_ARG;
     const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
     if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d) return NAF_ERR_ARG;
     if ((((uintptr_t)d_out | (uintptr_t)out | (uintptr_t)bias) & 15) != 0 || ((uintptr_t)partials & 7) != 0) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B / BB_ROWS, H / BB_COLS);
-#define BB_B1(K4V, S2)                                                                                                     \
-    bb_layer1_bwd_kernel<K4V, S2><<<grid, BB_THREADS, 0, st>>>(d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, \
-                                                               save_invstd, (float2*)partials, dw_slabs, dz1_col_partials, B, H)
-    if (k4d == 6) {
-        if (stage == 2) BB_B1(6, true); else BB_B1(6, false);
-    } else {
-        if (stage == 2) BB_B1(8, true); else BB_B1(8, false);
-    }
-#undef BB_B1
+    if (k4d == 6)
+        bb_layer1_bwd_kernel<6><<<grid, BB_THREADS, 0, st>>>(d_out, ld_dout, x, ldx, K, W, bias, out, ldo, save_mean, save_invstd,
+                                                             (float2*)partials, p_slabs, B, H);
+    else
+        bb_layer1_bwd_kernel<8><<<grid, BB_THREADS, 0, st>>>(d_out, ld_dout, x, ldx, K, W, bias, out, ldo, save_mean, save_invstd,
+                                                             (float2*)partials, p_slabs, B, H);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -1122,14 +1224,14 @@ extern "C" int naf_bb_layer1_bwd_kp(int K) {
     return (K + 3) / 4 <= 6 ? 24 : 32;
 }
 
-extern "C" int naf_bb_layer1_bwd_finish(const float* dw_slabs, int K, const float* partials1, const float* dz1_col_partials,
-                                        const float* dz2_col_partials, int nb, float* d_W, float* d_gamma, float* d_beta,
-                                        float* d_bias, float* d_bias2, const float* d_gamma2, const float* d_beta2,
-                                        float* sumsq_partials, int32_t* step_dev, int H, const naf_bb_slab_seg_t* segs,
-                                        int n_segs, void* stream) {
-    if (!dw_slabs || !partials1 || !dz1_col_partials || !dz2_col_partials || !d_W || !d_gamma || !d_beta || !d_bias || !d_bias2 ||
-        nb <= 0 || nb > BB_MAX_NB || H <= 0 || K <= 0 || K > 26)   // lanes 27-31 of a column's 32 carry the vector gradients
-        return NAF_ERR_ARG;
+extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, const float* dz2_col_partials,
+                                        int nb, const float* mom, const float* W, const float* gamma, const float* save_invstd,
+                                        float* d_W, float* d_gamma, float* d_beta, float* d_bias, float* d_bias2,
+                                        const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
+                                        int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, void* stream) {
+    if (!p_slabs || !partials1 || !dz2_col_partials || !mom || !W || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
+        !d_bias || !d_bias2 || nb <= 0 || nb > BB_MAX_NB || H <= 0 || B <= 0 || K <= 0 || K > 26 || ((uintptr_t)mom & 15))
+        return NAF_ERR_ARG;                              // lanes 27-31 of a column's 32 carry the vector gradients
     if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
     if (n_segs < 0 || n_segs > 2 || (n_segs && !segs)) return NAF_ERR_ARG;
     BbSlabs sl;
@@ -1148,8 +1250,8 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* dw_slabs, int K, const floa
     }
     const int kp = naf_bb_layer1_bwd_kp(K);
     bb_layer1_bwd_finish_kernel<<<sl.n_finish_blocks + blocks, BB_THREADS, 0, (hipStream_t)stream>>>(
-        dw_slabs, kp, K, (const float2*)partials1, dz1_col_partials, dz2_col_partials, nb, d_W, d_gamma, d_beta, d_bias, d_bias2,
-        d_gamma2, d_beta2, sumsq_partials, step_dev, H, sl);
+        p_slabs, kp, K, (const float2*)partials1, dz2_col_partials, nb, mom, W, gamma, save_invstd, d_W, d_gamma, d_beta, d_bias,
+        d_bias2, d_gamma2, d_beta2, sumsq_partials, step_dev, B, H, sl);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -78,6 +78,9 @@ class TrainChunk:
         self._batch_store = torch.zeros(self.U * B * brf + 64, dtype=torch.float32, device=dev)
         self.batch = self._batch_store[:self.U * B * brf].view(self.U, B, brf)
         self.loss_parts = torch.zeros(self.U, learner.n_loss_wg, dtype=torch.float32, device=dev)
+        # large-batch chain: the moments records of the U minibatches' layer-1 inputs, one launch behind the gather
+        self.moments = (torch.zeros(self.U, 2, learner.mom_floats, dtype=torch.float32, device=dev)
+                        if "bb" in learner.fuse else None)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph
 
@@ -95,8 +98,10 @@ class TrainChunk:
                 self.empty_events[1].record()
 
     def _updates(self) -> None:
+        if self.moments is not None:
+            self.L.moments(self.batch.view(self.U * self.L.B, -1), self.moments, self.U)
         for k in range(self.U):
-            self.L.learn_rows(self.batch[k], self.loss_parts[k])
+            self.L.learn_rows(self.batch[k], self.loss_parts[k], None if self.moments is None else self.moments[k])
 
     def _body(self) -> None:
         self._sample_gather()

@@ -252,13 +252,15 @@ class Learner:
             self.slab_stride = B * NHP + 64
             self.heads_partial = torch.zeros(self.n_slabs * self.slab_stride, **f32)
             self.vnext_partial = torch.zeros(self.n_slabs, B, **f32)
-            self.bb_st1 = torch.zeros(2, NB, H, 2, **f32)       # forward statistics partials of layer 1 / layer 2: (sum, M2)
+            # moments record of one minibatch's layer-1 inputs, [net][Sx | C]: everything layer 1's BatchNorm needs from
+            # the batch dimension (TrainChunk computes the records of all its minibatches in one launch behind the gather)
+            self.mom_floats = self.lib.naf_bb_moments_floats(lay.S)
+            self.bb_mom = torch.zeros(2, self.mom_floats, **f32)
             self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)
             self.bb_bw2 = torch.zeros(2 * NB, H, 2, **f32)      # backward partials of layer 2: (sum dy, sum dy*xhat); per 64-row
             #                                                     block, or per 32-row block from the fused layer-2 + head launch
             self.bb_dzp = torch.zeros(NB, H, **f32)             # block sums of dZ2 (-> gradient of the layer-2 bias)
             self.bb_bw1 = torch.zeros(NB, H, 2, **f32)          # backward partials of layer 1
-            self.bb_dzp1 = torch.zeros(NB, H, **f32)
             self.bb_dw1 = torch.zeros(NB, H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # per-block shares of dW1
         if "s3" in self.fuse:
             # split-K heads: one [B, NHP] slab per 8-column workgroup of layer 2's BN kernel (+ the target's V column)
@@ -339,7 +341,15 @@ class Learner:
         lay = self.lay
         return rows.as_strided((2, self.B, lay.S), (lay.off_s2, rows.stride(0), 1), rows.storage_offset())
 
-    def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True) -> None:
+    def moments(self, rows: torch.Tensor, out: torch.Tensor, n_batches: int = 1) -> None:
+        """Moments records of n_batches minibatches stored back to back in `rows` ([n_batches * B, ld]) -> out
+        [n_batches, 2, mom_floats]: one launch (large-batch chain only)."""
+        lay = self.lay
+        ld = rows.stride(-2)
+        check(self._f.naf_bb_moments(rows.data_ptr(), self.B * ld, lay.off_s2, ld, lay.S, ptr(out), self.B, int(n_batches), 2,
+                                     stream_ptr()), "bb_moments")
+
+    def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True, moments: Optional[torch.Tensor] = None) -> None:
         """Both networks' training-mode forward up to the second hidden activation A2 (and, with heads_gemm, the
         heads pre-activations Gh). Main net sees `state`, target net sees `next_state` (naf_algorithm.py:194-202);
         both use batch statistics and both update their running statistics (the reference never calls .eval() on the
@@ -350,12 +360,16 @@ class Learner:
         bnp = self.bn_stats.data_ptr()
         if "bb" in self.fuse:
             ld = rows.stride(0)
-            for apply in (0, 1):     # layer 1: statistics partials of every 64-row block, then fold + normalise + ReLU
-                check(self._f.naf_bb_layer1(
-                    rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
-                    t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(self.bb_st1), bnp, bnp + 4 * H, 4 * H,
-                    ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), B, H, 2, BN_MOMENTUM, BN_EPS,
-                    apply, st), "bb_layer1")
+            if moments is None:      # a minibatch that came without its moments (learn_rows called directly): one launch more
+                self.moments(rows, self.bb_mom)
+                moments = self.bb_mom
+            self._mom = moments
+            # layer 1: batch statistics from the moments, z, normalise, ReLU — one launch for both nets
+            check(self._f.naf_bb_layer1(
+                rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
+                ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), B, H, 2, BN_MOMENTUM, BN_EPS, st),
+                "bb_layer1")
             # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
             check(self._f.naf_bb_linear_stats(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset, t2p + 4 * seg["b2"].offset, P,
                                               ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, H, 2, st), "bb_linear_stats")
@@ -398,11 +412,14 @@ class Learner:
         if heads_gemm:
             torch.bmm(self.A2, self.WhT2, out=self.Gh)
 
-    def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None) -> None:
+    def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None,
+                   moments: Optional[torch.Tensor] = None) -> None:
         """Enqueue one full NAFAgent.learn() (naf_algorithm.py:180-215) + soft_update (:217-226) on the minibatch
         `rows` [B, ld] in the transition-row layout, ld = rows.stride(0) >= lay.batch_row_floats (actions already
         truncated by the gather if the reference's `.long()` is mimicked).
-        loss_partials: optional [ceil(B/32)] f32 receiving the per-workgroup parts of the MSE loss."""
+        loss_partials: optional [n_loss_wg] f32 receiving the per-workgroup parts of the MSE loss.
+        moments: optional [2, mom_floats] record of this minibatch (large-batch chain; Learner.moments); computed here when
+        missing."""
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
         f = self._f
@@ -419,7 +436,7 @@ class Learner:
                 rp + 4 * lay.off_r, ld, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "heads_gemm_head_fwd_bwd_mse")
         elif "hk" in self.fuse:
-            self.forward_train(rows)
+            self.forward_train(rows, moments=moments)
             bnp = self.bn_stats.data_ptr()
             # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
             check(f.naf_bb_layer2_head(
@@ -429,7 +446,7 @@ class Learner:
                 ptr(self.q_out), ptr(self.dH), lp, ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, lay.A, self.p_mode, BN_MOMENTUM,
                 BN_EPS, st), "bb_layer2_head")
         elif "s3" in self.fuse or "bb" in self.fuse:
-            self.forward_train(rows)
+            self.forward_train(rows, moments=moments)
             # the head adds the split-K slabs (H/8 of them, or H/64 in the large-batch chain) while staging its rows
             check(f.naf_head_fwd_bwd_mse_splitk(
                 ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), self.n_slabs, NHP, rp + 4 * lay.off_u,
@@ -481,18 +498,18 @@ class Learner:
             torch.mm(self.dZ2, self.W2_main, out=self.dA1)
         pushed_lo = None
         if "bb" in self.fuse:
-            # layer 1 backward: block sums, block shares of dW1, then everything added in block order (+ the norm partials
-            # of all vector gradients and the layer-2 bias gradient)
-            for stage in (1, 2):
-                check(f.naf_bb_layer1_bwd(
-                    ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
-                    t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1),
-                    ptr(self.bb_dw1), ptr(self.bb_dzp1), B, H, stage, st), "bb_layer1_bwd")
+            # layer 1 backward: one pass (dy, its block sums, block shares of P = dY^T X), then the finish launch: everything
+            # added in block order, the xhat term from the moments, the bundle's split-K slabs, the norm partials
+            check(f.naf_bb_layer1_bwd(
+                ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
+                ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1), B, H, st),
+                "bb_layer1_bwd")
             check(f.naf_bb_layer1_bwd_finish(
-                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), ptr(self.bb_dzp1), ptr(self.bb_dzp), B // 64,
+                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), ptr(self.bb_dzp), B // 64, ptr(self._mom),
+                t2p + 4 * seg["W1"].offset, t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
                 gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
-                ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, H,
+                ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, B, H,
                 self._bb_segs, self._bb_nsegs, st), "bb_layer1_bwd_finish")
         elif "l1" in self.fuse:
             # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written). Data parallel over peer
