@@ -245,7 +245,7 @@ int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const fl
                   const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
                   float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
                   float* save_mean, float* save_invstd, int B, int H, int nets, float momentum, float eps, void* stream);
-/* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K in {128, 256}, N % 64 == 0) on f32 MFMA, 64 x 32 tiles, with the
+/* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K = 256, N % 64 == 0) on f32 MFMA, 64 x 32 tiles, with the
  * column statistics partials of every 64-row block written by the epilogue: replaces `self.hidden_layer(x)`
  * (naf_neural_network.py:78) and the statistics pass of bn2 for both networks. */
 int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,

@@ -316,15 +316,58 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
 
 // ------------------------------------------------------------------------------------------------------------
 // GEMM 2 (and any Linear with K <= 256): Z[net] = A[net] W[net]^T + bias on v_mfma_f32_16x16x4_f32, 64 x 32 output tile
-// per workgroup (4 waves: wave = (wm, wn) owns rows 32 wm .. +31 = two 16-row MFMA tiles, columns 16 wn .. +15), the
-// whole K staged into LDS at once (all of a thread's 24 16-byte loads in flight together), and the column statistics of
-// the 64-row block in the epilogue. 2 B / 64 x H / 32 workgroups: 256 at B = 1024, H = 256.
+// per workgroup (4 waves: wave = (wm, wn) owns rows 32 wm .. +31 = two 16-row MFMA tiles, columns 16 wn .. +15), K
+// staged through LDS in chunks of 128 with the next chunk's loads in flight under the MFMAs, and the column statistics
+// of the 64-row block in the epilogue. 2 B / 64 x H / 32 workgroups: 256 at B = 1024, H = 256.
 // ------------------------------------------------------------------------------------------------------------
 #define BL_BM 64
 #define BL_BN 32
-#define BL_KMAX 256
-#define BL_LD (BL_KMAX + 4)
-__global__ __launch_bounds__(BB_THREADS) void bb_linear_stats_kernel(const float* __restrict__ a, int64_t a_net_stride,
+#define BL_KC 128                // k per staged chunk: (64 + 32) x 132 x 4 B = 50 KB of LDS, three workgroups per CU
+#define BL_LD (BL_KC + 4)
+__device__ __forceinline__ static void bl_load_chunk(f32x4 (&va)[8], f32x4 (&vb)[4], const float* __restrict__ an, int lda,
+                                                    const float* __restrict__ wn_, int K, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + BB_THREADS * i;
+        va[i] = ((const f32x4*)(an + (int64_t)(e >> 5) * lda + k0))[e & 31];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + BB_THREADS * i;
+        vb[i] = ((const f32x4*)(wn_ + (int64_t)(e >> 5) * K + k0))[e & 31];
+    }
+}
+__device__ __forceinline__ static void bl_mfma_chunk(const float* __restrict__ pa0, const float* __restrict__ pa1,
+                                            const float* __restrict__ pb, f32x4& c00, f32x4& c01, f32x4& c10, f32x4& c11) {
+#pragma unroll 2
+    for (int kk = 0; kk < BL_KC; kk += 16) {
+        const float4 a0 = *(const float4*)(pa0 + kk), a1 = *(const float4*)(pa1 + kk), b = *(const float4*)(pb + kk);
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, c11, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, c11, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ static void bl_store_chunk(const f32x4 (&va)[8], const f32x4 (&vb)[4], float* __restrict__ sA,
+                                                     float* __restrict__ sB, int tid) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + BB_THREADS * i;
+        *(f32x4*)(sA + (e >> 5) * BL_LD + 4 * (e & 31)) = va[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + BB_THREADS * i;
+        *(f32x4*)(sB + (e >> 5) * BL_LD + 4 * (e & 31)) = vb[i];
+    }
+}
+// (amdgpu_waves_per_eu: LDS admits 3 workgroups per CU; left alone the register allocator aimed at 4 waves per SIMD and
+// spilled the second chunk's 48 registers to scratch: 8.0 -> 12.8 us per launch)
+__global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3))) void bb_linear_stats_kernel(const float* __restrict__ a, int64_t a_net_stride,
                                                                      int lda, const float* __restrict__ W,
                                                                      const float* __restrict__ bias,
                                                                      int64_t param_net_stride, float* __restrict__ z,
@@ -339,56 +382,29 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats_kernel(const float
     const int n0 = blockIdx.y * BL_BN;
     const float* an = a + net * a_net_stride + (int64_t)rb * BL_BM * lda;
     const float* wn_ = W + net * param_net_stride + (int64_t)n0 * K;     // [N][K] row-major
-    const int k4n = K >> 2;                                             // float4 per row
-    {
-        // A: 64 rows x K, B: 32 rows x K; every load issued before the first LDS store
-        float4 va[BL_BM * BL_KMAX / 4 / BB_THREADS], vb[BL_BN * BL_KMAX / 4 / BB_THREADS];
-        const int shift = k4n == 64 ? 6 : 5;                             // K = 256 or 128 (checked on the host)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = tid + BB_THREADS * i;
-            const int row = e >> shift, q = e & (k4n - 1);
-            va[i] = (row < BL_BM) ? ((const float4*)(an + (int64_t)row * lda))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = tid + BB_THREADS * i;
-            const int row = e >> shift, q = e & (k4n - 1);
-            vb[i] = (row < BL_BN) ? ((const float4*)(wn_ + (int64_t)row * K))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = tid + BB_THREADS * i;
-            const int row = e >> shift, q = e & (k4n - 1);
-            if (row < BL_BM) *(float4*)(sA + row * BL_LD + 4 * q) = va[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = tid + BB_THREADS * i;
-            const int row = e >> shift, q = e & (k4n - 1);
-            if (row < BL_BN) *(float4*)(sB + row * BL_LD + 4 * q) = vb[i];
-        }
-    }
+    // chunk = 128 k: A 64 rows x 32 float4 (8 per thread), B 32 rows x 32 float4 (4 per thread); every load of a chunk is
+    // issued before its first LDS store, and the NEXT chunk's loads before this chunk's MFMAs
+    f32x4 va[8], vb[4];
     const int r = lane & 15, g = lane >> 4;
     const int wm = wave & 1, wn = wave >> 1;
     const float bcol = bias[net * param_net_stride + n0 + 16 * wn + r];
-    __syncthreads();
-    f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
     const float* pa0 = sA + (32 * wm + r) * BL_LD + 4 * g;
     const float* pa1 = pa0 + 16 * BL_LD;
     const float* pb = sB + (16 * wn + r) * BL_LD + 4 * g;
-#pragma unroll 4
-    for (int kk = 0; kk < K; kk += 16) {
-        const float4 a0 = *(const float4*)(pa0 + kk), a1 = *(const float4*)(pa1 + kk), b = *(const float4*)(pb + kk);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc[1][1], 0, 0, 0);
-    }
+    f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+    // the second chunk's loads are issued behind the first chunk's LDS stores and land in registers while its MFMAs run
+    // (all 24 loads up front made the register allocator park 12 of them in scratch)
+    f32x4 va1[8], vb1[4];
+    bl_load_chunk(va, vb, an, lda, wn_, K, 0, tid);
+    bl_store_chunk(va, vb, sA, sB, tid);
+    __builtin_amdgcn_sched_barrier(0);                    // keep chunk 1's loads behind chunk 0's stores
+    bl_load_chunk(va1, vb1, an, lda, wn_, K, BL_KC, tid);
+    __syncthreads();
+    bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
+    __syncthreads();                                      // first chunk fully consumed
+    bl_store_chunk(va1, vb1, sA, sB, tid);
+    __syncthreads();
+    bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
     float v[2][4];
     float s = 0.f;
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats_kernel(const float
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[mt][e] = (acc[mt][0][e] + acc[mt][1][e]) + bcol;
+            v[mt][e] = (mt ? c10[e] + c11[e] : c00[e] + c01[e]) + bcol;
             zn[(int64_t)(16 * mt + e) * ldz] = v[mt][e];
             s += v[mt][e];
         }
@@ -980,23 +996,39 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
         const int col = blockIdx.x * BF_COLS + c;
         const bool col_on = col < H;
         const int colc = col_on ? col : H - 1;
-        // everything requested up front: the P slabs of (col, k), the block sums, the column's constants
-        const float P = k < K ? bb_fold_sum1(p_slabs + (int64_t)colc * KP + k, (int64_t)H * KP, NB) : 0.f;
-        float2 ab = make_float2(0.f, 0.f);
-        if (k == 27) ab = bb_fold_sums(partials1, H, NB, colc);
-        const float db2 = k == 30 ? bb_fold_sum1(dz2_col_partials + colc, H, NB) : 0.f;
+        // everything requested up front and by EVERY lane (no branch around a load: the 32 lanes of a column read the same
+        // block sums, one broadcast each): P slabs of (col, k), the block sums of both layers, the column's constants
+        const int kc = k < KP ? k : 0;
+        float pv[BB_MAX_NB], dv[BB_MAX_NB];
+        float2 av[BB_MAX_NB];
+#pragma unroll
+        for (int rb = 0; rb < BB_MAX_NB; ++rb) {
+            const int64_t rbc = rb < NB ? rb : 0;
+            pv[rb] = p_slabs[(rbc * H + colc) * KP + kc];
+            av[rb] = partials1[rbc * H + colc];
+            dv[rb] = dz2_col_partials[rbc * H + colc];
+        }
         const float invstd = save_invstd[colc], gm = gamma[colc];
-        const float wk = k < K ? W[(int64_t)colc * K + k] : 0.f;     // lane k holds w[c][k]
+        const float wk = W[(int64_t)colc * K + (k < K ? k : 0)];
         for (int e = tid; e < (KP + KP * KP) / 4; e += BB_THREADS) ((float4*)sMom)[e] = ((const float4*)mom)[e];
+        float P = 0.f, db2 = 0.f;
+        float2 ab = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int rb = 0; rb < BB_MAX_NB; ++rb) {
+            P += rb < NB ? pv[rb] : 0.f;
+            db2 += rb < NB ? dv[rb] : 0.f;
+            ab.x += rb < NB ? av[rb].x : 0.f;
+            ab.y += rb < NB ? av[rb].y : 0.f;
+        }
         __syncthreads();
         const int lbase = (tid & 63) & ~31;
-        const float sdy = __shfl(ab.x, lbase + 27), sdx = __shfl(ab.y, lbase + 27);
+        const float sdy = ab.x, sdx = ab.y;
         // (w_c C)[k] = sum_j w[c][j] C[j][k]: w[c][j] comes from lane j of this column's 32
         float wc = 0.f;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const float wj = __shfl(wk, lbase + j);
-            if (j < KP && k < KP) wc = __builtin_fmaf(wj, sMom[KP + j * KP + k], wc);
+            if (j < K && k < KP) wc = __builtin_fmaf(wj, sMom[KP + j * KP + k], wc);
         }
         if (col_on) {
             if (k < K) {
@@ -1082,7 +1114,7 @@ extern "C" int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda
                                    int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
                                    int N, int K, int nets, void* stream) {
     if (!a || !W || !bias || !z || !partials || !bb_shape_ok(B, N) || nets <= 0) return NAF_ERR_ARG;
-    if ((K != 128 && K != 256) || lda < K || (lda & 3) || ldz < N) return NAF_ERR_ARG;
+    if (K != 2 * BL_KC || lda < K || (lda & 3) || ldz < N) return NAF_ERR_ARG;     // two chunks of 128: the framework's H = 256
     if ((((uintptr_t)a | (uintptr_t)W) & 15) != 0 || (a_net_stride & 3) != 0 || (param_net_stride & 3) != 0 ||
         ((uintptr_t)partials & 7) != 0)
         return NAF_ERR_ARG;

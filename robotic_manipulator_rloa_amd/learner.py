@@ -172,7 +172,7 @@ class Learner:
         #        stages (block partials from the producer, folded in the consumer's prologue), GEMM 2 on f32 MFMA with the
         #        statistics in its epilogue, heads GEMM split over 4 column slices, streaming layer-1 backward
         lay0 = self.lay
-        self.bb_ok = (self.B % 64 == 0 and 64 <= self.B <= 2048 and lay0.H in (128, 256) and lay0.S <= 26)
+        self.bb_ok = (self.B % 64 == 0 and 64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
         #   hk = (with bb, H = 256) layer 2 + heads + NAF head + first backward stage of layer 2 in one launch, a workgroup
         #        per 32 batch rows (csrc/big_batch.hip: bb_layer2_head_kernel) instead of three launches
         spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else ("bb,gb,hk" if self.bb_ok else "gb")).lower()
