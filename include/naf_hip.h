@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 7
+#define NAF_HIP_ABI_VERSION 8
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -393,6 +393,9 @@ int naf_xgmi_status(void* handle, uint64_t* epoch, uint64_t* timeouts);
  * after every chunk. A timed-out all-reduce leaves -inf in its sumsq partial, which makes naf_adam_polyak_fused skip
  * that update on this rank (no wrong step reaches the weights); the host is expected to stop on a non-zero count. */
 int naf_xgmi_timeouts_nowait(void* handle, uint64_t* timeouts);
+/* teardown in two collective halves: disconnect = wait for this device, then unmap every peer slab; destroy = (disconnect and)
+ * release this rank's own slab. The host runs a barrier between the two, so no slab is released while a peer still maps it. */
+int naf_xgmi_disconnect(void* handle);
 int naf_xgmi_destroy(void* handle);
 
 #ifdef __cplusplus

@@ -181,6 +181,7 @@ _PROTOS = {
     "naf_xgmi_allreduce_sum_from": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "naf_xgmi_status": [_vp, C.POINTER(_u64), C.POINTER(_u64)],
     "naf_xgmi_timeouts_nowait": [_vp, C.POINTER(_u64)],
+    "naf_xgmi_disconnect": [_vp],
     "naf_xgmi_destroy": [_vp],
 }
 _RESTYPES = {"naf_hip_arch": C.c_char_p}

@@ -16,6 +16,7 @@
 // workgroup waited for this rank's flag of e+1, raised only after this rank's launch of e had finished.
 // Nothing here allocates or synchronises after naf_xgmi_connect; the launch is a plain kernel launch and can be captured
 // into a hipGraph (the epoch lives on the device).
+#include <stdlib.h>
 #include <string.h>
 #include "xgmi_dev.h"
 
@@ -311,17 +312,69 @@ extern "C" int naf_xgmi_timeouts_nowait(void* handle, uint64_t* timeouts) {
     return NAF_OK;
 }
 
+// Teardown hygiene. Root cause of round 1's "stale slab" (reproduced with tests/xgmi_worker.py, NAF_XGMI_TEST_ORDER=1,0,1,0,
+// 4 ranks sharing one GPU: the learner built right after a communicator had been freed took different updates in every
+// run; the one-shot exchange itself was bit-identical throughout): the pages of a released slab come back to the next
+// allocation while L2 still holds lines of them from the slab's days — written through the peers' hipIpc mappings, read
+// uncached by the owner, so no ordinary kernel-boundary invalidate ever dropped them. Closing mappings before freeing, with a
+// barrier in between, does not help (tried); time does not help; streaming a buffer through every L2 right after the teardown
+// removes the effect (10 of 10 runs against 1 of 8 without). So both halves of the teardown end with a SCRUB: a grid over all
+// XCDs reads `mb` MiB (default 64: twice the 32 MiB of L2 on the chip; NAF_XGMI_SCRUB_MB overrides, 0 disables), and
+// system-scope fences bracket it. The raw memory life cycle alone does not reproduce it (benchmarks/probe/ipc_stale_repro.cpp).
+__global__ __launch_bounds__(256) void xg_scrub_kernel(const float4* __restrict__ p, size_t n4, float* sink) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = p[i];
+        s += v.x + v.y + v.z + v.w;
+    }
+    if (s == 12345.678f) *sink = s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+}
+
+static void xg_scrub_caches() {
+    const char* env = getenv("NAF_XGMI_SCRUB_MB");
+    const long mb = env ? atol(env) : 64;
+    if (mb <= 0) return;
+    void* buf = nullptr;
+    const size_t bytes = (size_t)mb << 20;
+    if (hipMalloc(&buf, bytes + 256) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    (void)hipMemsetAsync(buf, 0, bytes + 256, 0);
+    xg_scrub_kernel<<<2048, 256, 0, 0>>>((const float4*)buf, bytes / 16, (float*)((char*)buf + bytes));
+    (void)hipDeviceSynchronize();
+    (void)hipFree(buf);
+}
+
+extern "C" int naf_xgmi_disconnect(void* handle) {
+    if (!handle) return NAF_ERR_ARG;
+    XgmiComm* c = xg_comm(handle);
+    hipError_t e = hipDeviceSynchronize();
+    bool any = false;
+    for (int p = 0; p < c->world; ++p) any = any || c->opened[p];
+    if (any) xg_scrub_caches();            // before the peers' slabs are unmapped: this device's L2s forget them
+    for (int p = 0; p < c->world; ++p)
+        if (c->opened[p]) {
+            (void)hipIpcCloseMemHandle(c->peers.base[p]);
+            c->opened[p] = false;
+            c->peers.base[p] = nullptr;
+        }
+    return e == hipSuccess ? NAF_OK : (int)e;
+}
+
 extern "C" int naf_xgmi_destroy(void* handle) {
     if (!handle) return NAF_ERR_ARG;
     XgmiComm* c = xg_comm(handle);
-    (void)hipDeviceSynchronize();
-    for (int p = 0; p < c->world; ++p)
-        if (c->opened[p]) (void)hipIpcCloseMemHandle(c->peers.base[p]);
-    // The receive slab is deliberately NOT handed back to the allocator (<= 5.3 MB per communicator, released with the
-    // process). Measured with 4 ranks sharing one MI355X: once the slab had been freed AND every peer had closed its
-    // mapping, the recycled pages served a later allocation stale data now and then (a learner built afterwards in the
-    // same process took a different update in ~1 of 2 runs); keeping either the slab or the mappings alive: 30 of 30
-    // runs bit-identical. Peers wrote these pages through their own (importer-side) mappings.
+    (void)naf_xgmi_disconnect(handle);
+    // the own slab goes back to the allocator, scrubbed (see xg_scrub_kernel). NAF_XGMI_FREE_SLAB=0 parks it until the
+    // process ends instead (round 1's workaround: <= 5.3 MB per communicator).
+    const char* keep = getenv("NAF_XGMI_FREE_SLAB");
+    if (!(keep && keep[0] == '0')) {
+        xg_scrub_caches();
+        (void)hipFree(c->local);
+    }
     (void)hipFree(c->ctrl);
     (void)hipHostFree(c->host_timeouts);
     delete c;

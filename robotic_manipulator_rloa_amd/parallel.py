@@ -217,7 +217,16 @@ class XgmiAllReduce:
         done, timeouts = self.status()
         return int(bad.item()) == 0 and timeouts == 0 and done >= rounds
 
-    def close(self) -> None:
+    def close(self, collective: bool = True) -> None:
+        """Collective by default (every rank of the group calls it): unmap the peers' slabs, barrier, release the own slab —
+        no slab goes back to the allocator while a peer still maps it. collective=False (error paths where the peers may
+        not follow): no barrier."""
         if self.handle is not None and self.handle.value:
+            self.lib.naf_xgmi_disconnect(self.handle)
+            if collective and dist.is_initialized():
+                try:
+                    dist.barrier(group=self.group)
+                except Exception:
+                    pass
             self.lib.naf_xgmi_destroy(self.handle)
         self.handle = None

@@ -112,14 +112,20 @@ def main():
     from test_learner_gpu import _kuka_learner_and_replay
 
     def host_staged_all_reduce(grad, group=None):      # gloo reference for the exchange (eager, through the host)
+        torch.cuda.synchronize()
         t = grad.detach().cpu()
         dist.all_reduce(t, group=group)
         grad.copy_(t)
+        torch.cuda.synchronize()                       # `t` is pageable: it must outlive the copy
         return grad
 
     learner_mod.all_reduce_flat_grad = host_staged_all_reduce
     res = {}
-    for mode in ("1", "0"):                            # one-shot peer-memory path, then the gloo reference
+    # "1" = one-shot peer-memory exchange, "0" = gloo reference. The default order ends with a reference learner built right
+    # after a communicator has been torn down: the run that took different updates whenever the released slab's pages came
+    # back with stale L2 lines (csrc/xgmi_reduce.hip, xg_scrub_kernel; NAF_XGMI_SCRUB_MB=0 brings the symptom back).
+    order = os.environ.get("NAF_XGMI_TEST_ORDER", "1,0,1,0").split(",")
+    for slot, mode in enumerate(order):                # one-shot peer-memory path, then the gloo reference
         os.environ["NAF_XGMI"] = mode
         L, buf = _kuka_learner_and_replay(5000, 256, seed_data=5 + rank, learner_kw={"world_size": world})
         assert (L.xgmi is not None) == (mode == "1")
@@ -170,11 +176,25 @@ def main():
             assert torch.equal(other, everyone[0]), f"replicas diverged (NAF_XGMI={mode})"
         assert torch.isfinite(theta).all() and int(L.step_dev.item()) == 12
         res[mode] = theta
+        res[f"{mode}@{slot}"] = theta
         if L.xgmi is not None:
             dist.barrier()
             L.xgmi.close()
     # (c) same updates through either exchange. Not necessarily bit-equal: the norm partials are chunked differently,
     # and the biases in front of a train-mode BatchNorm have rounding-noise gradients that Adam turns into +-lr steps
+    if len(order) > 2:
+        keys = [f"{m}@{i}" for i, m in enumerate(order)]
+        for i in range(len(keys)):
+            for j in range(i + 1, len(keys)):
+                dd = (res[keys[i]] - res[keys[j]]).abs()
+                if rank == 0:
+                    print(f"DIFF {keys[i]} vs {keys[j]}: max {dd.max().item():.5f} frac>1e-5 {(dd > 1e-5).float().mean().item():.4f}", flush=True)
+        # same exchange, same data, same start: bit-identical whatever ran in between; the two kinds differ only by
+        # summation order (see (c))
+        for i in range(len(keys)):
+            for j in range(i + 1, len(keys)):
+                if order[i] == order[j]:
+                    assert torch.equal(res[keys[i]], res[keys[j]]), f"{keys[i]} and {keys[j]} differ"
     d = (res["1"] - res["0"]).abs()
     assert d.max().item() <= 12 * 1.01e-3 and (d > 1e-5).float().mean().item() < 0.01, (d.max(), (d > 1e-5).float().mean())
 
