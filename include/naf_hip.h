@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 8
+#define NAF_HIP_ABI_VERSION 9
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -303,7 +303,8 @@ typedef struct naf_bb_slab_seg {
     int64_t stride;
     int n, n_slabs;
 } naf_bb_slab_seg_t;
-int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, const float* dz2_col_partials, int nb,
+int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, int nb1 /* blocks of partials1 / p_slabs:
+                             B/64 from naf_bb_layer1_bwd, B/32 from the bundle's epilogue */, const float* dz2_col_partials, int nb,
                              const float* mom, const float* W, const float* gamma, const float* save_invstd, float* d_W,
                              float* d_gamma, float* d_beta, float* d_bias, float* d_bias2, const float* d_gamma2,
                              const float* d_beta2, float* sumsq_partials, int32_t* step_dev, int B, int H,
@@ -316,6 +317,20 @@ int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1
  * Replaces the dW2 / dA1 / dWh GEMMs of the backward pass (autograd of naf_neural_network.py:76-87) with one grid of
  * 32 x 32 output blocks computed on v_mfma_f32_16x16x4_f32. `descs` is a HOST array (copied into the launch). */
 #define NAF_GEMM_BUNDLE_MAX 4
+/* optional epilogue of a product whose C = dA1 (gradient w.r.t. the layer-1 activations, M = batch rows, N = layer-1 features;
+ * M, N multiples of 32): the batch pass of naf_bb_layer1_bwd on every 32 x 32 C block while it is in registers — partials
+ * [M/32][N] (float2) and p_slabs [M/32][N][kp] instead of [B/64]; C may then be NULL (dA1 is not stored). */
+typedef struct naf_gemm_l1bwd {
+    const float* x;          /* minibatch rows of the net (state columns), ldx floats apart */
+    const float* W;          /* W1 [N][K] */
+    const float* bias;       /* b1 [N] */
+    const float* a1;         /* layer-1 activations [M][lda1]: the ReLU mask */
+    const float* save_mean;  /* [N] */
+    const float* save_invstd;
+    float* partials;
+    float* p_slabs;
+    int ldx, K, kp, lda1;
+} naf_gemm_l1bwd_t;
 typedef struct naf_gemm_desc {
     const float* A;
     const float* B;
@@ -325,6 +340,7 @@ typedef struct naf_gemm_desc {
     int k_split;            /* 0 / 1: the whole K in one block. > 1: K cut into k_split ranges ((K / k_split) % 16 == 0), range s */
     int64_t c_split_stride; /* writing its partial product to C + s * c_split_stride floats (sumsq must be NULL); the consumer adds
                                the slabs in index order (naf_bb_layer1_bwd_finish) */
+    const naf_gemm_l1bwd_t* epi; /* nullable (HOST pointer, copied into the launch) */
 } naf_gemm_desc_t;
 int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
 

@@ -158,7 +158,7 @@ _PROTOS = {
                            _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "naf_bb_layer1_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "naf_bb_layer1_bwd_kp": [_i],
-    "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+    "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                  _vp, _i, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
@@ -203,7 +203,14 @@ class GemmDesc(C.Structure):
     """naf_gemm_desc_t (include/naf_hip.h)"""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("sumsq", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
-                ("k_split", C.c_int), ("c_split_stride", C.c_int64)]
+                ("k_split", C.c_int), ("c_split_stride", C.c_int64), ("epi", C.c_void_p)]
+
+
+class GemmL1Bwd(C.Structure):
+    """naf_gemm_l1bwd_t (include/naf_hip.h)"""
+    _fields_ = [("x", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("a1", C.c_void_p), ("save_mean", C.c_void_p),
+                ("save_invstd", C.c_void_p), ("partials", C.c_void_p), ("p_slabs", C.c_void_p), ("ldx", C.c_int), ("K", C.c_int),
+                ("kp", C.c_int), ("lda1", C.c_int)]
 
 
 def load(allow_build: bool = True) -> C.CDLL:

@@ -965,7 +965,7 @@ struct BbSlabs {
 };
 #define BB_MAX_SLABS 8
 __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
-    const float* __restrict__ p_slabs, int KP, int K, const float2* __restrict__ partials1,
+    const float* __restrict__ p_slabs, int KP, int K, const float2* __restrict__ partials1, int NB1,
     const float* __restrict__ dz2_col_partials, int NB, const float* __restrict__ mom, const float* __restrict__ W,
     const float* __restrict__ gamma, const float* __restrict__ save_invstd, float* __restrict__ d_W,
     float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_bias2,
@@ -1001,12 +1001,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
         const int kc = k < KP ? k : 0;
         float pv[BB_MAX_NB], dv[BB_MAX_NB];
         float2 av[BB_MAX_NB];
+        const int nba = NB1 < BB_MAX_NB ? NB1 : BB_MAX_NB;          // layer-1 blocks: first round of (at most) 32
 #pragma unroll
         for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-            const int64_t rbc = rb < NB ? rb : 0;
-            pv[rb] = p_slabs[(rbc * H + colc) * KP + kc];
-            av[rb] = partials1[rbc * H + colc];
-            dv[rb] = dz2_col_partials[rbc * H + colc];
+            const int64_t r1 = rb < nba ? rb : 0, r2 = rb < NB ? rb : 0;
+            pv[rb] = p_slabs[(r1 * H + colc) * KP + kc];
+            av[rb] = partials1[r1 * H + colc];
+            dv[rb] = dz2_col_partials[r2 * H + colc];
         }
         const float invstd = save_invstd[colc], gm = gamma[colc];
         const float wk = W[(int64_t)colc * K + (k < K ? k : 0)];
@@ -1015,10 +1016,25 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
         float2 ab = make_float2(0.f, 0.f);
 #pragma unroll
         for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-            P += rb < NB ? pv[rb] : 0.f;
+            P += rb < nba ? pv[rb] : 0.f;
             db2 += rb < NB ? dv[rb] : 0.f;
-            ab.x += rb < NB ? av[rb].x : 0.f;
-            ab.y += rb < NB ? av[rb].y : 0.f;
+            ab.x += rb < nba ? av[rb].x : 0.f;
+            ab.y += rb < nba ? av[rb].y : 0.f;
+        }
+        if (NB1 > BB_MAX_NB) {                                      // 32-row blocks from the bundle's epilogue at B = 2048: 64
+            const int nbb = NB1 - BB_MAX_NB;
+#pragma unroll
+            for (int rb = 0; rb < BB_MAX_NB; ++rb) {
+                const int64_t r1 = BB_MAX_NB + (rb < nbb ? rb : 0);
+                pv[rb] = p_slabs[(r1 * H + colc) * KP + kc];
+                av[rb] = partials1[r1 * H + colc];
+            }
+#pragma unroll
+            for (int rb = 0; rb < BB_MAX_NB; ++rb) {
+                P += rb < nbb ? pv[rb] : 0.f;
+                ab.x += rb < nbb ? av[rb].x : 0.f;
+                ab.y += rb < nbb ? av[rb].y : 0.f;
+            }
         }
         __syncthreads();
         const int lbase = (tid & 63) & ~31;
@@ -1256,13 +1272,14 @@ extern "C" int naf_bb_layer1_bwd_kp(int K) {
     return (K + 3) / 4 <= 6 ? 24 : 32;
 }
 
-extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, const float* dz2_col_partials,
-                                        int nb, const float* mom, const float* W, const float* gamma, const float* save_invstd,
+extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, int nb1,
+                                        const float* dz2_col_partials, int nb, const float* mom, const float* W, const float* gamma, const float* save_invstd,
                                         float* d_W, float* d_gamma, float* d_beta, float* d_bias, float* d_bias2,
                                         const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
                                         int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, void* stream) {
     if (!p_slabs || !partials1 || !dz2_col_partials || !mom || !W || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
-        !d_bias || !d_bias2 || nb <= 0 || nb > BB_MAX_NB || H <= 0 || B <= 0 || K <= 0 || K > 26 || ((uintptr_t)mom & 15))
+        !d_bias || !d_bias2 || nb <= 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > 2 * BB_MAX_NB || H <= 0 || B <= 0 || K <= 0 ||
+        K > 26 || ((uintptr_t)mom & 15))
         return NAF_ERR_ARG;                              // lanes 27-31 of a column's 32 carry the vector gradients
     if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
     if (n_segs < 0 || n_segs > 2 || (n_segs && !segs)) return NAF_ERR_ARG;
@@ -1282,7 +1299,7 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
     }
     const int kp = naf_bb_layer1_bwd_kp(K);
     bb_layer1_bwd_finish_kernel<<<sl.n_finish_blocks + blocks, BB_THREADS, 0, (hipStream_t)stream>>>(
-        p_slabs, kp, K, (const float2*)partials1, dz2_col_partials, nb, mom, W, gamma, save_invstd, d_W, d_gamma, d_beta, d_bias,
+        p_slabs, kp, K, (const float2*)partials1, nb1, dz2_col_partials, nb, mom, W, gamma, save_invstd, d_W, d_gamma, d_beta, d_bias,
         d_bias2, d_gamma2, d_beta2, sumsq_partials, step_dev, B, H, sl);
     NAF_CHECK_LAUNCH();
     return NAF_OK;

@@ -5,6 +5,7 @@
 // chip once.
 //
 // C/D map of the MFMA: col = l & 15, row = 4 (l >> 4) + reg. Summation order over k is fixed -> bitwise reproducible.
+#include <string.h>
 #include "common.h"
 #include "../../include/naf_hip.h"
 
@@ -18,6 +19,7 @@ struct GemmDesc {
     int M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, tile0, tiles_n;
     int k_split, tiles_mn;        // K cut into k_split ranges, one grid of tiles_mn blocks each, slab s at C + s * c_split_stride
     int64_t c_split_stride;
+    naf_gemm_l1bwd_t epi;         // epi.x != NULL: the layer-1 backward pass on the block's C tile (see gemm_l1bwd_epilogue)
 };
 struct GemmBundle {
     GemmDesc d[NAF_GEMM_BUNDLE_MAX];
@@ -100,6 +102,117 @@ __device__ static inline float4 read_frag(const float* __restrict__ sm, int row,
     return *(const float4*)(sm + row * GB_LD + kk + 4 * g);
 }
 
+// Epilogue of the dA1 = dZ2 W2 blocks in the large-batch chain: the C tile (32 batch rows x 32 layer-1 features) is the
+// gradient w.r.t. the layer-1 activation, and the whole batch pass of layer 1's backward runs on it without a trip through
+// memory (csrc/big_batch.hip, bb_layer1_bwd_kernel does the same as a launch of its own): z recomputed from the minibatch
+// rows and W1 (K <= 32), xhat, dy = ReLU'(A1) * dA1, the block sums (sum dy, sum dy*xhat) per column -> partials[M/32][N],
+// and the block's share of P = dY^T X -> p_slabs[M/32][N][KP]. dA1 itself is not written (C may be NULL).
+// Everything the epilogue reads from memory is requested BEFORE the K loop (gemm_l1bwd_prefetch) and waits in registers;
+// after the MFMAs the tile goes through LDS once so that all 512 threads (not only the four accumulator waves) share the
+// elementwise work: thread = (row, column) and (row + 16, column).
+struct L1bwdRegs {
+    f32x4 x;           // one float4 of the X tile (threads < 32 * KP / 4)
+    float w[2];        // two scalars of the W1 tile
+    float a1[2];       // A1 at this thread's two tile elements
+    float st;          // mean | invstd | bias (threads < 96)
+};
+__device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int bn, int tid, L1bwdRegs& R) {
+    const naf_gemm_l1bwd_t& E = D.epi;
+    const int KP = E.kp, m0 = bm * 32, n0 = bn * 32;
+    const int xr = tid / (KP / 4), xq = tid - xr * (KP / 4);
+    R.x = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (xr < 32) R.x = ((const f32x4*)(E.x + (int64_t)(m0 + xr) * E.ldx))[xq];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + GB_THREADS * i;
+        const int c = e / KP, k = e - c * KP;
+        R.w[i] = (c < 32 && k < E.K) ? E.W[(int64_t)(n0 + c) * E.K + k] : 0.f;
+        const int row = (tid >> 5) + 16 * i, col = tid & 31;
+        R.a1[i] = E.a1[(int64_t)(m0 + row) * E.lda1 + n0 + col];
+    }
+    R.st = 0.f;
+    if (tid < 32) R.st = E.save_mean[n0 + tid];
+    else if (tid < 64) R.st = E.save_invstd[n0 + tid - 32];
+    else if (tid < 96) R.st = E.bias[n0 + tid - 64];
+}
+
+__device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int bn, const f32x4& acc, bool owner, int wm, int wn,
+                                                  int r, int g, float* sA, float* sB, int tid, const L1bwdRegs& R) {
+    const naf_gemm_l1bwd_t& E = D.epi;
+    const int KP = E.kp, XS = KP + 4;
+    const int n0 = bn * 32;
+    float* sX = sA;                    // [32 rows][XS]
+    float* sW = sA + 32 * XS;          // [32 cols][XS]
+    float* sDA = sA + 64 * XS;         // [32 rows][33]: the C tile
+    float* sDY = sB;                   // [32 rows][33]
+    float* sSt = sB + 32 * 33;         // mean[32] | invstd[32] | bias[32]
+    float2* sRed = (float2*)(sB + 32 * 33 + 96);   // [8 waves][32]
+    // (the barrier behind the K halves' hand-over has every wave past its last fragment read: the panels are free)
+    {
+        const int xr = tid / (KP / 4), xq = tid - xr * (KP / 4);
+        if (xr < 32) *(f32x4*)(sX + xr * XS + 4 * xq) = R.x;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + GB_THREADS * i;
+            const int c = e / KP, k = e - c * KP;
+            if (c < 32) sW[c * XS + k] = R.w[i];
+        }
+        if (tid < 96) sSt[tid] = R.st;
+        if (owner) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sDA[(wm * 16 + 4 * g + e) * 33 + wn * 16 + r] = acc[e];
+        }
+    }
+    __syncthreads();
+    const int col = tid & 31;
+    const float mean = sSt[col], invstd = sSt[32 + col], b = sSt[64 + col];
+    float s_dy = 0.f, s_dx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 5) + 16 * i;
+        float z = b;                                         // b + sum_k x_k w_k, k ascending: the forward's arithmetic
+        for (int q = 0; q < KP / 4; ++q) {
+            const f32x4 xv = *(const f32x4*)(sX + row * XS + 4 * q), wv = *(const f32x4*)(sW + col * XS + 4 * q);
+            z = __builtin_fmaf(xv.x, wv.x, z);
+            z = __builtin_fmaf(xv.y, wv.y, z);
+            z = __builtin_fmaf(xv.z, wv.z, z);
+            z = __builtin_fmaf(xv.w, wv.w, z);
+        }
+        const float xh = (z - mean) * invstd;
+        const float dy = R.a1[i] > 0.f ? sDA[row * 33 + col] : 0.f;
+        sDY[row * 33 + col] = dy;
+        s_dy += dy;
+        s_dx += dy * xh;
+    }
+    s_dy += __shfl_xor(s_dy, 32);                            // the wave's other row of the same column
+    s_dx += __shfl_xor(s_dx, 32);
+    if ((tid & 63) < 32) sRed[(tid >> 6) * 32 + col] = make_float2(s_dy, s_dx);
+    __syncthreads();
+    if (tid < 32) {
+        float2 t = sRed[tid];
+#pragma unroll
+        for (int w = 1; w < GB_THREADS / 64; ++w) {
+            t.x += sRed[w * 32 + tid].x;
+            t.y += sRed[w * 32 + tid].y;
+        }
+        ((float2*)E.partials)[(int64_t)bm * D.N + n0 + tid] = t;
+    }
+    {   // P share of this block: thread = (column, k lane of 16): k = lane, lane + 16; sum over the 32 rows, row ascending
+        const int c = tid >> 4, kq = tid & 15;
+        float p0 = 0.f, p1 = 0.f;
+        const bool two = kq + 16 < KP;
+#pragma unroll 8
+        for (int row = 0; row < 32; ++row) {
+            const float dy = sDY[row * 33 + c];
+            p0 = __builtin_fmaf(dy, sX[row * XS + kq], p0);
+            p1 = __builtin_fmaf(dy, sX[row * XS + (two ? kq + 16 : kq)], p1);
+        }
+        float* dst = E.p_slabs + ((int64_t)bm * D.N + n0 + c) * KP;
+        dst[kq] = p0;
+        if (two) dst[kq + 16] = p1;
+    }
+}
+
 template <bool AK, bool BK>
 __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int ks, float* sA, float* sB, float* sQ, float* sC) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,6 +230,8 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     // Split K (k_split > 1: the weight gradients at large batches, K = B): this block takes K range ks and writes slab ks;
     // the slabs are added in slab order by the consumer (bb_layer1_bwd_finish's reduce blocks). 64 blocks walking
     // K = 1024 pulled 256 KB each through one CU's L2 port (13.6 us per launch at B = 1024); 256 blocks of K = 256 do not.
+    L1bwdRegs epi_regs;
+    if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, epi_regs);
     const int kper = D.K / D.k_split, k_lo = ks * kper, k_hi = k_lo + kper;
     float* Cs = D.C + (int64_t)ks * D.c_split_stride;
     float4 va[GB_PT], vb[GB_PT];
@@ -172,7 +287,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
 #pragma unroll
         for (int h = 1; h < GB_KSPLIT; ++h) acc = acc + *(const f32x4*)(sC + (((h - 1) * 4 + tile) * 64 + lane) * 4);
         const int cm = m0 + wm * 16 + 4 * g, cn = n0 + wn * 16 + r;
-        if (cn < D.N) {
+        if (cn < D.N && D.C) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (cm + e < D.M) {
@@ -182,6 +297,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
                 }
         }
     }
+    if (D.epi.x) gemm_l1bwd_epilogue(D, bm, bn, acc, !kh, wm, wn, r, g, sA, sB, tid, epi_regs);
     if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 tiles)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -230,7 +346,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         const naf_gemm_desc_t& s = descs[i];
-        if (!s.A || !s.B || !s.C || s.M <= 0 || s.N <= 0 || s.K <= 0) return NAF_ERR_ARG;
+        if (!s.A || !s.B || (!s.C && !s.epi) || s.M <= 0 || s.N <= 0 || s.K <= 0) return NAF_ERR_ARG;
         if ((s.M & 15) || (s.N & 15) || (s.K & 15)) return NAF_ERR_ARG;            // whole 16x16x16 steps only
         const int ksn = s.k_split > 0 ? s.k_split : 1;
         if (ksn > 1 && (s.K % ksn || ((s.K / ksn) & 15) || s.sumsq || s.c_split_stride < (int64_t)s.M * s.ldc)) return NAF_ERR_ARG;
@@ -246,6 +362,15 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         d.tiles_mn = ((s.M + 31) / 32) * d.tiles_n;
         d.k_split = ksn;
         d.c_split_stride = s.c_split_stride;
+        memset(&d.epi, 0, sizeof(d.epi));
+        if (s.epi) {
+            const naf_gemm_l1bwd_t& e = *s.epi;
+            if (!e.x || !e.W || !e.bias || !e.a1 || !e.save_mean || !e.save_invstd || !e.partials || !e.p_slabs || ksn != 1 ||
+                (s.M & 31) || (s.N & 31) || e.K <= 0 || (e.kp != 24 && e.kp != 32) || e.K > e.kp || e.ldx < e.kp || (e.ldx & 3) ||
+                e.lda1 < s.N || ((uintptr_t)e.x & 15) || ((uintptr_t)e.partials & 7))
+                return NAF_ERR_ARG;
+            d.epi = e;
+        }
         tiles += d.tiles_mn * ksn;
     }
     for (int i = n; i < NAF_GEMM_BUNDLE_MAX; ++i) b.d[i] = b.d[0];

@@ -175,13 +175,17 @@ class Learner:
         self.bb_ok = (self.B % 64 == 0 and 64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
         #   hk = (with bb, H = 256) layer 2 + heads + NAF head + first backward stage of layer 2 in one launch, a workgroup
         #        per 32 batch rows (csrc/big_batch.hip: bb_layer2_head_kernel) instead of three launches
-        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else ("bb,gb,hk" if self.bb_ok else "gb")).lower()
-        names = {"l1", "b2", "f3", "gb", "s3", "bb", "hk"}
-        self.fuse = (set(names) - {"bb", "hk"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
+        #   ep = (with bb + gb) the batch pass of layer 1's backward as the EPILOGUE of the bundle's dA1 blocks (dA1 never
+        #        leaves the registers of the block that computed it) instead of a launch of its own
+        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else ("bb,gb,hk,ep" if self.bb_ok else "gb")).lower()
+        names = {"l1", "b2", "f3", "gb", "s3", "bb", "hk", "ep"}
+        self.fuse = (set(names) - {"bb", "hk", "ep"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if "bb" in self.fuse:
-            self.fuse = ({"bb"} | (self.fuse & {"gb", "hk"})) if self.bb_ok else (self.fuse - {"bb"})
+            self.fuse = ({"bb"} | (self.fuse & {"gb", "hk", "ep"})) if self.bb_ok else (self.fuse - {"bb"})
         if "bb" not in self.fuse or lay0.H != 256:
             self.fuse -= {"hk"}
+        if not {"bb", "gb"} <= self.fuse or self.B % 32:
+            self.fuse -= {"ep"}
         if self.lay.S > 32:
             self.fuse -= {"l1"}
         if self.B % 16 != 0 or self.lay.H % 16 != 0:
@@ -260,8 +264,9 @@ class Learner:
             self.bb_bw2 = torch.zeros(2 * NB, H, 2, **f32)      # backward partials of layer 2: (sum dy, sum dy*xhat); per 64-row
             #                                                     block, or per 32-row block from the fused layer-2 + head launch
             self.bb_dzp = torch.zeros(NB, H, **f32)             # block sums of dZ2 (-> gradient of the layer-2 bias)
-            self.bb_bw1 = torch.zeros(NB, H, 2, **f32)          # backward partials of layer 1
-            self.bb_dw1 = torch.zeros(NB, H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # per-block shares of dW1
+            self.bb_bw1 = torch.zeros(2 * NB, H, 2, **f32)      # backward partials of layer 1 (per 64-row block, or per 32-row
+            #                                                     block from the bundle's epilogue)
+            self.bb_dw1 = torch.zeros(2 * NB, H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # per-block shares of P = dY1^T X
         if "s3" in self.fuse:
             # split-K heads: one [B, NHP] slab per 8-column workgroup of layer 2's BN kernel (+ the target's V column)
             # slabs 256 B further apart than their size: the H/8 pieces of one row, read together by the head kernel,
@@ -301,10 +306,17 @@ class Learner:
             ks = B // 256 if B % 256 == 0 else 1
             self.bb_slab_w2 = torch.zeros(ks, H * H, **f32)
             self.bb_slab_wh = torch.zeros(ks, NHP * HP, **f32)
+            self._epi = None
+            if "ep" in self.fuse:
+                t2p_, seg_ = self.theta2.data_ptr(), lay.seg
+                self._epi = _lib.GemmL1Bwd(None, t2p_ + 4 * seg_["W1"].offset, t2p_ + 4 * seg_["b1"].offset, ptr(self.A1[0]),
+                                           ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1),
+                                           0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H)     # x / ldx: set per minibatch
             self._bundle = (D * 3)(
                 D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks, NHP * HP),
                 D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks, H * H),
-                D(ptr(self.dZ2), ptr(self.W2_main), ptr(self.dA1), None, B, H, H, H, H, H, 0, 1, 1, 0))
+                D(ptr(self.dZ2), ptr(self.W2_main), None if self._epi is not None else ptr(self.dA1), None, B, H, H, H, H, H, 0, 1,
+                  1, 0, _lib.C.addressof(self._epi) if self._epi is not None else None))
             SS = _lib.SlabSeg
             self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks),
                                      SS(ptr(self.bb_slab_wh), ptr(self.gWh), NHP * HP, NHP * HP, ks))
@@ -492,6 +504,8 @@ class Learner:
                 gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
         if gb:
             # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles
+            if "ep" in self.fuse:
+                self._epi.x, self._epi.ldx = rp, ld      # this minibatch's rows: the epilogue recomputes layer 1's z from them
             check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
@@ -500,12 +514,14 @@ class Learner:
         if "bb" in self.fuse:
             # layer 1 backward: one pass (dy, its block sums, block shares of P = dY^T X), then the finish launch: everything
             # added in block order, the xhat term from the moments, the bundle's split-K slabs, the norm partials
-            check(f.naf_bb_layer1_bwd(
-                ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
-                ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1), B, H, st),
-                "bb_layer1_bwd")
+            if "ep" not in self.fuse:
+                check(f.naf_bb_layer1_bwd(
+                    ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
+                    ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1), B, H, st),
+                    "bb_layer1_bwd")
             check(f.naf_bb_layer1_bwd_finish(
-                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), ptr(self.bb_dzp), B // 64, ptr(self._mom),
+                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), B // 32 if "ep" in self.fuse else B // 64, ptr(self.bb_dzp), B // 64,
+                ptr(self._mom),
                 t2p + 4 * seg["W1"].offset, t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
                 gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
