@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 9
+#define NAF_HIP_ABI_VERSION 10
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -343,6 +343,10 @@ typedef struct naf_gemm_desc {
     const naf_gemm_l1bwd_t* epi; /* nullable (HOST pointer, copied into the launch) */
 } naf_gemm_desc_t;
 int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
+/* the same contract on 64 x 64 output blocks staged in 128-k chunks (csrc/gemm_bundle64.hip): for the large-batch chain, where
+ * 32 x 32 blocks are bound by L2 -> LDS traffic. Restrictions: b_kmajor = 1, sumsq = NULL, (K / k_split) % 128 == 0, M and N
+ * multiples of 4 (partial edge blocks are masked); with `epi`: M, N multiples of 64 and partials / p_slabs per 64-row block. */
+int naf_gemm_bundle64(const naf_gemm_desc_t* descs, int n, void* stream);
 
 /* ---- clip + Adam + Polyak over one flat parameter buffer -------------------------------------- */
 /* first half of clip_grad_norm_(params, 1) (naf_algorithm.py:209): partials[i] = sum of g^2 over chunk i of

@@ -594,83 +594,114 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const int rb = blockIdx.x;
     const int64_t s0 = (int64_t)rb * FK_ROWS;
     const int T = A * (A + 1) / 2, v_col = A + T;
-    // ---- phase 0: every global operand requested up front ---------------------------------------------------------
-    float4 zm[4], zt[4];
+    // ---- phase 0: every global operand requested up front, in ONE batch: the Z2 tiles, the head weights (into registers,
+    // native vectors), the statistics partials, the per-sample scalars — measured with the weights staged behind the
+    // statistics fold this phase took 4.4 of the kernel's 10.8 us (two dependent round trips to fresh data) -------------
+    f32x4 zm[4], zt[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = wave + 8 * i;                     // one wave per row: 64 lanes x 4 columns
-        zm[i] = *(const float4*)(z + (s0 + row) * ldz + 4 * lane);
-        zt[i] = *(const float4*)(z + z_net_stride + (s0 + row) * ldz + 4 * lane);
+        zm[i] = *(const f32x4*)(z + (s0 + row) * ldz + 4 * lane);
+        zt[i] = *(const f32x4*)(z + z_net_stride + (s0 + row) * ldz + 4 * lane);
     }
+    constexpr int WPT = NHP * (H / 4) / FK_THREADS;       // float4 of the Wh tile per thread: 2, 4 or 6
+    f32x4 wreg[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int e = tid + FK_THREADS * i;
+        wreg[i] = *(const f32x4*)(Wh + (int64_t)(e >> 6) * ldw + 4 * (e & 63));
+    }
+    const float bias_r = tid < NHP ? Wh[(int64_t)tid * ldw + H] : (tid == NHP ? Wh[wh_net_stride + (int64_t)v_col * ldw + H] : 0.f);
+    f32x4 wv_r = {0.f, 0.f, 0.f, 0.f};
+    if (tid < H / 4) wv_r = *(const f32x4*)(Wh + wh_net_stride + (int64_t)v_col * ldw + 4 * tid);
     const int s_loc_ = tid >> 3, i_ = tid & 7;
     const bool live_ = s_loc_ < FK_ROWS;
     const float u_val = (live_ && i_ < A) ? u[(s0 + s_loc_) * ldu + i_] : 0.f;
     const float r_val = (live_ && i_ == 0) ? r[(s0 + s_loc_) * ldr] : 0.f;
     {
         const int net = tid >> 8, col = tid & (H - 1);    // 512 threads = 2 nets x 256 columns
+        const float gm_ = gamma[net * param_net_stride + col], bt_ = beta[net * param_net_stride + col];
+        float rm_ = 0.f, rv_ = 0.f;
+        const int64_t so = net * stat_net_stride + col;
+        if (rb == 0) {
+            rm_ = running_mean[so];
+            rv_ = running_var[so];
+        }
         float mean, var;
         bb_fold_stats(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
         const float invstd = 1.0f / sqrtf(var + eps);
         sStat[net][0][col] = mean;
         sStat[net][1][col] = invstd;
-        sStat[net][2][col] = gamma[net * param_net_stride + col];
-        sStat[net][3][col] = beta[net * param_net_stride + col];
+        sStat[net][2][col] = gm_;
+        sStat[net][3][col] = bt_;
         if (rb == 0) {
-            const int64_t so = net * stat_net_stride + col;
             const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-            running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
-            running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+            running_mean[so] = (1.0f - momentum) * rm_ + momentum * mean;
+            running_var[so] = (1.0f - momentum) * rv_ + momentum * unbiased;
             save_mean[(int64_t)net * H + col] = mean;
             save_invstd[(int64_t)net * H + col] = invstd;
         }
     }
-    for (int e = tid; e < NHP * (H / 4); e += FK_THREADS) {
-        const int h = e >> 6, q = e & 63;
-        *(float4*)(sW + h * FK_LD + 4 * q) = *(const float4*)(Wh + (int64_t)h * ldw + 4 * q);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int e = tid + FK_THREADS * i;
+        *(f32x4*)(sW + (e >> 6) * FK_LD + 4 * (e & 63)) = wreg[i];
     }
-    if (tid < NHP) sBias[tid] = Wh[(int64_t)tid * ldw + H];          // bias = column H of Wh (the ones column of A2)
-    if (tid < H / 4) *(float4*)(sWv + 4 * tid) = *(const float4*)(Wh + wh_net_stride + (int64_t)v_col * ldw + 4 * tid);
-    if (tid == 0) sBias[NHP] = Wh[wh_net_stride + (int64_t)v_col * ldw + H];
+    if (tid <= NHP) sBias[tid] = bias_r;                   // bias = column H of Wh (the ones column of A2); [NHP] = the target's V bias
+    if (tid < H / 4) *(f32x4*)(sWv + 4 * tid) = wv_r;
     for (int e = tid; e < (FK_THREADS / 8) * NHP; e += FK_THREADS) sDH[e] = 0.f;
     __syncthreads();
     // ---- phase 1: normalise. main net -> xhat (LDS) and A2 (memory); target net -> V'(s') ---------------------------
     {
-        const float4 m0 = *(const float4*)&sStat[0][0][4 * lane], i0 = *(const float4*)&sStat[0][1][4 * lane];
-        const float4 g0 = *(const float4*)&sStat[0][2][4 * lane], b0 = *(const float4*)&sStat[0][3][4 * lane];
-        const float4 m1 = *(const float4*)&sStat[1][0][4 * lane], i1 = *(const float4*)&sStat[1][1][4 * lane];
-        const float4 g1 = *(const float4*)&sStat[1][2][4 * lane], b1 = *(const float4*)&sStat[1][3][4 * lane];
-        const float4 wv = *(const float4*)(sWv + 4 * lane);
+        const f32x4 m0 = *(const f32x4*)&sStat[0][0][4 * lane], i0 = *(const f32x4*)&sStat[0][1][4 * lane];
+        const f32x4 g0 = *(const f32x4*)&sStat[0][2][4 * lane], b0 = *(const f32x4*)&sStat[0][3][4 * lane];
+        const f32x4 m1 = *(const f32x4*)&sStat[1][0][4 * lane], i1 = *(const f32x4*)&sStat[1][1][4 * lane];
+        const f32x4 g1 = *(const f32x4*)&sStat[1][2][4 * lane], b1 = *(const f32x4*)&sStat[1][3][4 * lane];
+        const f32x4 wv = *(const f32x4*)(sWv + 4 * lane);
+        float p[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave + 8 * i;
-            float4 xh, y;
-            xh.x = (zm[i].x - m0.x) * i0.x; xh.y = (zm[i].y - m0.y) * i0.y;
-            xh.z = (zm[i].z - m0.z) * i0.z; xh.w = (zm[i].w - m0.w) * i0.w;
-            y.x = fmaxf(__builtin_fmaf(xh.x, g0.x, b0.x), 0.f); y.y = fmaxf(__builtin_fmaf(xh.y, g0.y, b0.y), 0.f);
-            y.z = fmaxf(__builtin_fmaf(xh.z, g0.z, b0.z), 0.f); y.w = fmaxf(__builtin_fmaf(xh.w, g0.w, b0.w), 0.f);
-            *(float4*)(sXH + row * FK_LD + 4 * lane) = xh;
-            *(float4*)(a2_out + (s0 + row) * ldo + 4 * lane) = y;
-            float p = fmaxf(__builtin_fmaf((zt[i].x - m1.x) * i1.x, g1.x, b1.x), 0.f) * wv.x;
-            p = __builtin_fmaf(fmaxf(__builtin_fmaf((zt[i].y - m1.y) * i1.y, g1.y, b1.y), 0.f), wv.y, p);
-            p = __builtin_fmaf(fmaxf(__builtin_fmaf((zt[i].z - m1.z) * i1.z, g1.z, b1.z), 0.f), wv.z, p);
-            p = __builtin_fmaf(fmaxf(__builtin_fmaf((zt[i].w - m1.w) * i1.w, g1.w, b1.w), 0.f), wv.w, p);
+            const f32x4 xh = (zm[i] - m0) * i0;
+            f32x4 y;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
-            if (lane == 0) sV[row] = p + sBias[NHP];
+            for (int c = 0; c < 4; ++c) y[c] = fmaxf(__builtin_fmaf(xh[c], g0[c], b0[c]), 0.f);
+            *(f32x4*)(sXH + row * FK_LD + 4 * lane) = xh;
+            *(f32x4*)(a2_out + (s0 + row) * ldo + 4 * lane) = y;
+            const f32x4 xt = (zt[i] - m1) * i1;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q = __builtin_fmaf(fmaxf(__builtin_fmaf(xt[c], g1[c], b1[c]), 0.f), wv[c], q);
+            p[i] = q;
+        }
+        // the four rows' wave reductions side by side (four independent shuffle chains instead of one after the other)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i] += __shfl_xor(p[i], o);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sV[wave + 8 * i] = p[i] + sBias[NHP];
         }
     }
     __syncthreads();
-    // ---- phase 2: heads = A2 Wh^T + bias, 2 x NHP/16 MFMA tiles of K = 256 over the 8 waves --------------------------
+    // ---- phase 2: heads = A2 Wh^T + bias: 2 x NHP/16 MFMA tiles, each cut into two K halves, over the 8 waves (with whole
+    // tiles half of the waves idled through the longest MFMA chain of the kernel: 2.2 of its 10.8 us). The halves meet in
+    // LDS, lower half first -------------------------------------------------------------------------------------------
     const int rr = lane & 15, gg = lane >> 4;
-    for (int t = wave; t < 2 * (NHP / 16); t += 8) {
-        const int mt = t & 1, nt = t >> 1;
+    constexpr int NT = 2 * (NHP / 16);                     // tiles: 2, 4 or 6
+    float* sHalf = sDH;                                    // upper-half partial tiles (sDH is zeroed again below)
+    for (int t = wave; t < 2 * NT; t += 8) {
+        const int tile = t % NT, kh = t / NT;
+        const int mt = tile & 1, nt = tile >> 1;
         const float* pa = sXH + (16 * mt + rr) * FK_LD + 4 * gg;
         const float* pb = sW + (16 * nt + rr) * FK_LD + 4 * gg;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int kk = 0; kk < H; kk += 16) {
-            const float4 xh = *(const float4*)(pa + kk), b = *(const float4*)(pb + kk);
-            const float4 g = *(const float4*)&sStat[0][2][kk + 4 * gg], be = *(const float4*)&sStat[0][3][kk + 4 * gg];
+        for (int kk = kh * (H / 2); kk < (kh + 1) * (H / 2); kk += 16) {
+            const f32x4 xh = *(const f32x4*)(pa + kk), b = *(const f32x4*)(pb + kk);
+            const f32x4 g = *(const f32x4*)&sStat[0][2][kk + 4 * gg], be = *(const f32x4*)&sStat[0][3][kk + 4 * gg];
             const float a0 = fmaxf(__builtin_fmaf(xh.x, g.x, be.x), 0.f), a1 = fmaxf(__builtin_fmaf(xh.y, g.y, be.y), 0.f);
             const float a2 = fmaxf(__builtin_fmaf(xh.z, g.z, be.z), 0.f), a3 = fmaxf(__builtin_fmaf(xh.w, g.w, be.w), 0.f);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0, 0, 0, 0);
@@ -678,8 +709,14 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b.z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b.w, acc1, 0, 0, 0);
         }
+        float* dst = kh ? sHalf : sHd;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sHd[(16 * mt + 4 * gg + e) * NHP + 16 * nt + rr] = (acc0[e] + acc1[e]) + sBias[16 * nt + rr];
+        for (int e = 0; e < 4; ++e) dst[(16 * mt + 4 * gg + e) * NHP + 16 * nt + rr] = acc0[e] + acc1[e];
+    }
+    __syncthreads();
+    for (int e = tid; e < FK_ROWS * NHP; e += FK_THREADS) {
+        sHd[e] = (sHd[e] + sHalf[e]) + sBias[e % NHP];
+        sHalf[e] = 0.f;
     }
     __syncthreads();
     // ---- phase 3: the NAF head on the 32 rows (threads 0..255 carry samples; every thread joins the barriers) --------

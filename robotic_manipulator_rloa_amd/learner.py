@@ -303,7 +303,12 @@ class Learner:
         if "bb" in self.fuse and "gb" in self.fuse:
             # large batches: the weight gradients reduce over K = B. Cut K into 256-row ranges, one grid of blocks each,
             # writing partial slabs that the layer-1 finish launch adds in slab order (and takes the norm partials of)
-            ks = B // 256 if B % 256 == 0 else 1
+            # 64 x 64 blocks (csrc/gemm_bundle64.hip) when every K range is whole 128-k chunks; else the 32 x 32 bundle
+            self._bundle64 = B % 128 == 0 and os.environ.get("NAF_BUNDLE64", "0") == "1"   # measured: no faster
+            if self._bundle64:       # K = B cut into at most 8 ranges of whole 128-k chunks, as many as divide it
+                ks = max(d for d in range(1, 9) if (B // 128) % d == 0)
+            else:
+                ks = B // 256 if B % 256 == 0 else 1
             self.bb_slab_w2 = torch.zeros(ks, H * H, **f32)
             self.bb_slab_wh = torch.zeros(ks, NHP * HP, **f32)
             self._epi = None
@@ -506,7 +511,10 @@ class Learner:
             # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles
             if "ep" in self.fuse:
                 self._epi.x, self._epi.ldx = rp, ld      # this minibatch's rows: the epilogue recomputes layer 1's z from them
-            check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
+            if getattr(self, "_bundle64", False):
+                check(f.naf_gemm_bundle64(self._bundle, 3, st), "gemm_bundle64")
+            else:
+                check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
             torch.mm(self.dZ2, self.W2_main, out=self.dA1)
@@ -520,7 +528,8 @@ class Learner:
                     ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1), B, H, st),
                     "bb_layer1_bwd")
             check(f.naf_bb_layer1_bwd_finish(
-                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), B // 32 if "ep" in self.fuse else B // 64, ptr(self.bb_dzp), B // 64,
+                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1),
+                B // 32 if ("ep" in self.fuse and not getattr(self, "_bundle64", False)) else B // 64, ptr(self.bb_dzp), B // 64,
                 ptr(self._mom),
                 t2p + 4 * seg["W1"].offset, t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
