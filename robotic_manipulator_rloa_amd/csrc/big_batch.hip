@@ -95,53 +95,61 @@ __device__ static inline float bb_col_sum64(const float (*t)[BB_COLS + 1], int c
 // moments record (f32): [Sx (KP) | C (KP x KP)], KP = 24 or 32 (columns >= K meet zero weights).
 // ------------------------------------------------------------------------------------------------------------
 #define BM_CHUNK 256
+#define BM_THREADS 512
 template <int K4>
-__global__ __launch_bounds__(BB_THREADS) void bb_moments_kernel(const float* __restrict__ x, int64_t batch_stride,
+__global__ __launch_bounds__(BM_THREADS) void bb_moments_kernel(const float* __restrict__ x, int64_t batch_stride,
                                                                 int64_t x_net_stride, int ldx, float* __restrict__ mom,
                                                                 int B) {
-    constexpr int KP = 4 * K4, XS = KP + 4, REC = KP + KP * KP;
+    constexpr int KP = 4 * K4, XS = KP + 4, REC = KP + KP * KP, NTRI = KP * (KP + 1) / 2;
     __shared__ __attribute__((aligned(16))) float sX[BM_CHUNK * XS];
-    __shared__ double sRed[8][32];
-    __shared__ double sM[32];
+    __shared__ double sRed[16][32];
+    __shared__ float sM[32];
     const int tid = threadIdx.x;
     const float* xb = x + blockIdx.x * batch_stride + blockIdx.y * x_net_stride;
     float* out = mom + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * REC;
     auto stage = [&](int row0) {
-        for (int e = tid; e < BM_CHUNK * K4; e += BB_THREADS) {
+        for (int e = tid; e < BM_CHUNK * K4; e += BM_THREADS) {
             const int r_ = e / K4, q = e - r_ * K4;
             const int row = row0 + r_;
             *(float4*)(sX + r_ * XS + 4 * q) =
                 row < B ? ((const float4*)(xb + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    // pass 1: column sums
+    // pass 1: column sums (double)
     const int k1 = tid & 31, g1 = tid >> 5;
     double s = 0.0;
     for (int row0 = 0; row0 < B; row0 += BM_CHUNK) {
         __syncthreads();
         stage(row0);
         __syncthreads();
-        if (k1 < KP)
-            for (int r_ = g1; r_ < BM_CHUNK; r_ += 8) s += (double)sX[r_ * XS + k1];
+        if (k1 < KP) {
+            float part = 0.f;
+            for (int r_ = g1; r_ < BM_CHUNK; r_ += 16) part += sX[r_ * XS + k1];
+            s += (double)part;
+        }
     }
     sRed[g1][k1] = s;
     __syncthreads();
     if (tid < 32) {
         double t = 0.0;
-        for (int g = 0; g < 8; ++g) t += sRed[g][tid];
-        sM[tid] = t / (double)B;
+        for (int g = 0; g < 16; ++g) t += sRed[g][tid];
+        sM[tid] = (float)(t / (double)B);
         if (tid < KP) out[tid] = (float)t;
     }
-    // pass 2: centred second moments; thread owns entries e = tid + 256 i of the KP x KP matrix
-    constexpr int NE = (KP * KP + BB_THREADS - 1) / BB_THREADS;
+    // pass 2: centred second moments, upper triangle only (C is symmetric): thread owns entries e = tid (+ 512) of the
+    // KP (KP + 1) / 2; products and the 256-row partial in f32 (the data are centred), the running sum in double
+    constexpr int NE = (NTRI + BM_THREADS - 1) / BM_THREADS;
     double acc[NE];
     int ej[NE], ek[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int e = tid + BB_THREADS * i;
+        int e = tid + BM_THREADS * i;
         acc[i] = 0.0;
-        ej[i] = e < KP * KP ? e / KP : 0;
-        ek[i] = e < KP * KP ? e - ej[i] * KP : 0;
+        if (e >= NTRI) e = 0;
+        int j = 0;                                       // row j of the triangle holds KP - j entries
+        while (e >= KP - j) { e -= KP - j; ++j; }
+        ej[i] = j;
+        ek[i] = j + e;
     }
     for (int row0 = 0; row0 < B; row0 += BM_CHUNK) {
         __syncthreads();
@@ -150,16 +158,20 @@ __global__ __launch_bounds__(BB_THREADS) void bb_moments_kernel(const float* __r
         const int nr = (B - row0) < BM_CHUNK ? (B - row0) : BM_CHUNK;
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const double mj = sM[ej[i]], mk = sM[ek[i]];
-            double a = 0.0;
-            for (int r_ = 0; r_ < nr; ++r_) a += ((double)sX[r_ * XS + ej[i]] - mj) * ((double)sX[r_ * XS + ek[i]] - mk);
-            acc[i] += a;
+            const float mj = sM[ej[i]], mk = sM[ek[i]];
+            float a = 0.f;
+#pragma unroll 8
+            for (int r_ = 0; r_ < nr; ++r_) a = __builtin_fmaf(sX[r_ * XS + ej[i]] - mj, sX[r_ * XS + ek[i]] - mk, a);
+            acc[i] += (double)a;
         }
     }
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int e = tid + BB_THREADS * i;
-        if (e < KP * KP) out[KP + e] = (float)acc[i];
+        const int e = tid + BM_THREADS * i;
+        if (e < NTRI) {
+            out[KP + ej[i] * KP + ek[i]] = (float)acc[i];
+            out[KP + ek[i] * KP + ej[i]] = (float)acc[i];
+        }
     }
 }
 
@@ -1132,8 +1144,8 @@ extern "C" int naf_bb_moments(const float* x, int64_t batch_stride, int64_t x_ne
         ((uintptr_t)mom & 15) != 0)
         return NAF_ERR_ARG;
     dim3 grid(n_batches, nets);
-    if (k4d == 6) bb_moments_kernel<6><<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(x, batch_stride, x_net_stride, ldx, mom, B);
-    else bb_moments_kernel<8><<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(x, batch_stride, x_net_stride, ldx, mom, B);
+    if (k4d == 6) bb_moments_kernel<6><<<grid, BM_THREADS, 0, (hipStream_t)stream>>>(x, batch_stride, x_net_stride, ldx, mom, B);
+    else bb_moments_kernel<8><<<grid, BM_THREADS, 0, (hipStream_t)stream>>>(x, batch_stride, x_net_stride, ldx, mom, B);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
