@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 10
+#define NAF_HIP_ABI_VERSION 11
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -245,6 +245,14 @@ int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const fl
                   const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
                   float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
                   float* save_mean, float* save_invstd, int B, int H, int nets, float momentum, float eps, void* stream);
+/* naf_bb_layer1 and naf_bb_linear_stats in ONE launch (H = 256, K <= 26): every GEMM-2 workgroup forms its own A panel
+ * A1 = ReLU(BN(x W1^T + b1)) in LDS from the rows and the moments record; the column-0 workgroups also write A1 (a1_out, for the
+ * backward pass), the running statistics and save_mean / save_invstd of layer 1. Outputs of naf_bb_linear_stats as below. */
+int naf_bb_layer12(const float* x, int64_t x_net_stride, int ldx, int K, const float* W1, const float* bias1,
+                   const float* gamma1, const float* beta1, const float* W2, const float* bias2, int64_t param_net_stride,
+                   const float* mom, float* running_mean, float* running_var, int64_t stat_net_stride, float* a1_out,
+                   int64_t a1_net_stride, int lda1, float* save_mean, float* save_invstd, float* z, int64_t z_net_stride, int ldz,
+                   float* partials, int B, int H, int nets, float momentum, float eps, void* stream);
 /* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K = 256, N % 64 == 0) on f32 MFMA, 64 x 32 tiles, with the
  * column statistics partials of every 64-row block written by the epilogue: replaces `self.hidden_layer(x)`
  * (naf_neural_network.py:78) and the statistics pass of bn2 for both networks. */

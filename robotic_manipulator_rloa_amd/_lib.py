@@ -149,6 +149,8 @@ _PROTOS = {
     "naf_bb_moments": [_vp, _i64, _i64, _i, _i, _vp, _i, _i, _i, _vp],
     "naf_bb_layer1": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _f,
                       _vp],
+    "naf_bb_layer12": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
+                       _i, _vp, _i, _i, _i, _f, _f, _vp],
     "naf_bb_linear_stats": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp],
     "naf_bb_bn_relu_heads_partial": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
                                      _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],

@@ -454,6 +454,264 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// layer 1 + GEMM 2 in ONE launch (bb_layer1_kernel + bb_linear_stats_kernel: skipping the former's launch was measured to
+// be worth 7.8 / 8.9 us per update at B = 1024 / 2048 — more than its own body, because A1 then never makes a round trip
+// through another XCD's L2). Layer 1's statistics come from the moments record, so A1 = ReLU(BN(X W1^T + b1)) is
+// elementwise on a recomputed z: every GEMM-2 workgroup (64 rows x 32 output columns) produces its own A panel — 64 rows x
+// 128 k per chunk — straight into LDS from the 64 x 24 tile of minibatch rows it has staged, 8 x redundantly across the
+// column workgroups of a row block (VALU time a workgroup can spare: its MFMA phase is 1.7 us). The column-0 workgroups also
+// write A1 to memory for the backward pass. Per chunk of 128 layer-1 features:
+//   W1 rows of the chunk flat in LDS -> statistics on MFMA (U = W1c C, then w . U rows) -> z tile on MFMA (X W1c^T, K = 24:
+//   a first VALU version of these two steps cost 9 us per workgroup) -> bias, normalise, ReLU -> sA -> the GEMM-2 MFMAs
+// ------------------------------------------------------------------------------------------------------------
+#define L12_KMAX 26
+template <int K4>
+__global__ __launch_bounds__(BB_THREADS) void bb_layer12_kernel(
+    const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W1,
+    const float* __restrict__ bias1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
+    const float* __restrict__ W2, const float* __restrict__ bias2, int64_t param_net_stride, const float* __restrict__ mom,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ a1_out,
+    int64_t a1_net_stride, int lda1, float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ z,
+    int64_t z_net_stride, int ldz, float2* __restrict__ partials, int B, float momentum, float eps) {
+    // every MFMA operand of layer 1 sits in LDS zero-padded to KP (+4) floats per row, k contiguous, so that a fragment is ONE
+    // unconditional 16-byte read (the first MFMA version read W1 flat with a `k < K ? .. : 0` per element: one dependent LDS
+    // round trip per MFMA — 4 us per phase instead of 0.5)
+    constexpr int KP = 4 * K4, LD1 = KP + 4, REC = KP + KP * KP, H = 2 * BL_KC, N = H;
+    __shared__ __attribute__((aligned(16))) float sA[BL_BM * BL_LD];
+    __shared__ __attribute__((aligned(16))) float sB[BL_BN * BL_LD];
+    __shared__ __attribute__((aligned(16))) float sXr[BB_ROWS * LD1];          // the row tile, [row][k]
+    __shared__ __attribute__((aligned(16))) float sW1[BL_KC * LD1];            // the chunk's W1 rows, [feature][k], zeros beyond K
+    __shared__ __attribute__((aligned(16))) float sC[32 * LD1];                // C of the moments record, zero rows / columns beyond KP
+    __shared__ float sSx[32];
+    __shared__ float sSt[5][BL_KC];                                             // mean, invstd, gamma, beta, bias of the chunk
+    __shared__ float red[2][BL_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NB = B / BB_ROWS;
+    const int net = blockIdx.x / NB, rb = blockIdx.x - net * NB;
+    const int n0 = blockIdx.y * BL_BN;
+    const int64_t po = net * param_net_stride;
+    const float* xn = x + net * x_net_stride + (int64_t)rb * BB_ROWS * ldx;
+    const float* w2n = W2 + po + (int64_t)n0 * H;                              // [N][K = H] row-major
+    const float* w1n = W1 + po;
+    const float* momn = mom + (int64_t)net * REC;
+    const bool writer = blockIdx.y == 0;                                         // this row block's A1 / statistics go to memory
+    // ---- everything the first chunk needs, requested in one batch ------------------------------------------------
+    f32x4 xv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + BB_THREADS * i;
+        const int row = e / K4, q = e - row * K4;
+        xv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (row < BB_ROWS) xv[i] = ((const f32x4*)(xn + (int64_t)row * ldx))[q];
+    }
+    f32x4 cv = {0.f, 0.f, 0.f, 0.f};                                            // C: KP rows x K4 float4; Sx: KP floats
+    const int crow = tid / K4, cq = tid - crow * K4;
+    if (crow < KP) cv = ((const f32x4*)(momn + KP + crow * KP))[cq];
+    const float sxv = tid < KP ? momn[tid] : 0.f;
+    // the chunk's W1 rows: a flat run of 128 K floats; element i = (feature i / K, k = i % K)
+    const int w1n4 = (BL_KC * K) / 4;
+    f32x4 w1v[4];
+    float st_g, st_b, st_bias;
+    auto load_l1_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + BB_THREADS * i;
+            w1v[i] = e < w1n4 ? ((const f32x4*)(w1n + (int64_t)c * BL_KC * K))[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int f = c * BL_KC + (tid & (BL_KC - 1));
+        st_g = gamma1[po + f];
+        st_b = beta1[po + f];
+        st_bias = bias1[po + f];
+    };
+    load_l1_chunk(0);
+    f32x4 vb0[4], vb1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + BB_THREADS * i;
+        vb0[i] = ((const f32x4*)(w2n + (int64_t)(e >> 5) * H))[e & 31];
+        vb1[i] = ((const f32x4*)(w2n + (int64_t)(e >> 5) * H + BL_KC))[e & 31];
+    }
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const float bcol = bias2[po + n0 + 16 * wn + r];
+    // ---- zero the padding once, stage the row tile and the moments ----------------------------------------------------
+    for (int e = tid; e < BL_KC * LD1; e += BB_THREADS) sW1[e] = 0.f;
+    for (int e = tid; e < 32 * LD1; e += BB_THREADS) sC[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + BB_THREADS * i;
+        const int row = e / K4, q = e - row * K4;
+        if (row < BB_ROWS) *(f32x4*)(sXr + row * LD1 + 4 * q) = xv[i];
+    }
+    if (crow < KP) *(f32x4*)(sC + crow * LD1 + 4 * cq) = cv;
+    if (tid < 32) sSx[tid] = sxv;
+    f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+    const float* pa0 = sA + (32 * wm + r) * BL_LD + 4 * g;
+    const float* pa1 = pa0 + 16 * BL_LD;
+    const float* pb = sB + (16 * wn + r) * BL_LD + 4 * g;
+    const unsigned kinv = (65536u + (unsigned)K - 1u) / (unsigned)K;             // i / K for i < 128 K <= 3328 (exact: checked on the host)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (c) __syncthreads();                           // chunk 0's MFMAs are done with sA / sB, its z tile with sW1 / sSt
+        // the chunk's W1 rows (scattered from the flat run to their padded rows) and per-feature parameters into LDS, the
+        // chunk's W2 panel too
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + BB_THREADS * i;
+            if (e < w1n4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned idx = 4u * (unsigned)e + (unsigned)q;
+                    const unsigned f = (idx * kinv) >> 16;
+                    sW1[f * LD1 + (idx - f * (unsigned)K)] = w1v[i][q];
+                }
+            }
+        }
+        if (tid < BL_KC) {
+            sSt[2][tid] = st_g;
+            sSt[3][tid] = st_b;
+            sSt[4][tid] = st_bias;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + BB_THREADS * i;
+            *(f32x4*)(sB + (e >> 5) * BL_LD + 4 * (e & 31)) = c ? vb1[i] : vb0[i];
+        }
+        if (c == 0) load_l1_chunk(1);                     // in flight under this chunk's arithmetic
+        __syncthreads();
+        {   // statistics of the chunk's 128 features from the moments, on MFMA: U = W1c C (128 x KP) — wave w owns features
+            // 32 w .. +31 (two m-tiles), both 16-column halves of U — then t_f = U[f] . w_f, mdot_f = w_f . Sx as a 16-lane
+            // reduction of the accumulator rows. A fragment = padded W1 rows, B fragment = rows of the symmetric C.
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float* wa = sW1 + (32 * wave + 16 * mt + r) * LD1 + 4 * g;
+                f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0;
+#pragma unroll
+                for (int kk = 0; kk < KP; kk += 16) {
+                    const bool in = kk + 4 * g < KP;                     // KP = 24: the last lane groups of the second step are past K
+                    const int ko = in ? kk : 0;
+                    f32x4 a = *(const f32x4*)(wa + ko), b0 = *(const f32x4*)(sC + r * LD1 + ko + 4 * g);
+                    f32x4 b1 = *(const f32x4*)(sC + (16 + r) * LD1 + ko + 4 * g);
+                    if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b0[q], u0, 0, 0, 0);
+                        u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b1[q], u1, 0, 0, 0);
+                    }
+                }
+                // lane (r, g) holds U[f = 32 w + 16 mt + 4 g + e][n = r] (u0) and [n = 16 + r] (u1)
+                const bool hi = 16 + r < KP;
+                const float sx0 = sSx[r], sx1 = sSx[16 + r];
+                float t[4], md[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* wf = sW1 + (32 * wave + 16 * mt + 4 * g + e) * LD1;
+                    const float w0 = wf[r], w1 = hi ? wf[16 + r] : 0.f;
+                    t[e] = u0[e] * w0 + u1[e] * w1;
+                    md[e] = w0 * sx0 + w1 * sx1;
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t[e] += __shfl_xor(t[e], o);
+                        md[e] += __shfl_xor(md[e], o);
+                    }
+                }
+                if (r < 4) {                                          // lane r of the group finishes feature 4 g + r
+                    const int f = 32 * wave + 16 * mt + 4 * g + r;
+                    const float tt = r == 0 ? t[0] : r == 1 ? t[1] : r == 2 ? t[2] : t[3];
+                    const float mm = r == 0 ? md[0] : r == 1 ? md[1] : r == 2 ? md[2] : md[3];
+                    const float mean = sSt[4][f] + mm / (float)B;
+                    const float var = fmaxf(tt, 0.f) / (float)B;
+                    const float invstd = 1.0f / sqrtf(var + eps);
+                    sSt[0][f] = mean;
+                    sSt[1][f] = invstd;
+                    if (writer && rb == 0) {
+                        const int col = c * BL_KC + f;
+                        const int64_t so = net * stat_net_stride + col;
+                        const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+                        running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
+                        running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+                        save_mean[(int64_t)net * H + col] = mean;
+                        save_invstd[(int64_t)net * H + col] = invstd;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {   // z tile on MFMA: Z = X (64 x KP) W1c^T — wave w owns rows 16 w .. +15 and all 8 feature tiles; then bias,
+            // normalise, ReLU into the A panel (and to memory from the column-0 workgroups)
+            f32x4 zt[8];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) zt[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KP; kk += 16) {
+                const bool in = kk + 4 * g < KP;
+                const int ko = in ? kk : 0;
+                f32x4 a = *(const f32x4*)(sXr + (16 * wave + r) * LD1 + ko + 4 * g);
+                if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 bv[8];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) bv[nt] = *(const f32x4*)(sW1 + (16 * nt + r) * LD1 + ko + 4 * g);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt) zt[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], bv[nt][q], zt[nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const int f = 16 * nt + r;
+                const float mean = sSt[0][f], invstd = sSt[1][f], gm = sSt[2][f], bt = sSt[3][f], bb = sSt[4][f];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * wave + 4 * g + e;
+                    const float y = fmaxf(((zt[nt][e] + bb) - mean) * invstd * gm + bt, 0.f);
+                    sA[row * BL_LD + f] = y;
+                    if (writer) a1_out[net * a1_net_stride + (int64_t)(rb * BB_ROWS + row) * lda1 + c * BL_KC + f] = y;
+                }
+            }
+        }
+        __syncthreads();
+        bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
+    }
+    // ---- epilogue: bias, Z2, statistics partials of the 64-row block (as bb_linear_stats_kernel) ----------------------
+    float v[2][4];
+    float s = 0.f;
+    float* zn = z + net * z_net_stride + (int64_t)(rb * BL_BM + 32 * wm + 4 * g) * ldz + n0 + 16 * wn + r;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[mt][e] = (mt ? c10[e] + c11[e] : c00[e] + c01[e]) + bcol;
+            zn[(int64_t)(16 * mt + e) * ldz] = v[mt][e];
+            s += v[mt][e];
+        }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (g == 0) red[wm][16 * wn + r] = s;
+    __syncthreads();
+    const float S = red[0][16 * wn + r] + red[1][16 * wn + r];
+    const float mb = S * (1.0f / BB_ROWS);
+    float m2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = v[mt][e] - mb;
+            m2 += t * t;
+        }
+    m2 += __shfl_xor(m2, 16);
+    m2 += __shfl_xor(m2, 32);
+    __syncthreads();
+    if (g == 0) red[wm][16 * wn + r] = m2;
+    __syncthreads();
+    if (wm == 0 && g == 0)
+        partials[((int64_t)net * NB + rb) * N + n0 + 16 * wn + r] = make_float2(S, red[0][16 * wn + r] + red[1][16 * wn + r]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // layer 2, stage 2 + heads: fold the statistics of this workgroup's 64 columns, normalise + ReLU its 64 x 64 tile of Z2
 // (written out as A2 for the backward GEMMs), and multiply the tile — still in LDS — with Wh[:, 64 columns]: the heads
 // GEMM split over H/64 column slices. Main net: all NHP head columns; target net: the V column only.
@@ -1186,6 +1444,36 @@ extern "C" int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda
     dim3 grid(nets * (B / BB_ROWS), N / BL_BN);
     bb_linear_stats_kernel<<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,
                                                                          z_net_stride, ldz, (float2*)partials, B, N, K);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_bb_layer12(const float* x, int64_t x_net_stride, int ldx, int K, const float* W1, const float* bias1,
+                              const float* gamma1, const float* beta1, const float* W2, const float* bias2,
+                              int64_t param_net_stride, const float* mom, float* running_mean, float* running_var,
+                              int64_t stat_net_stride, float* a1_out, int64_t a1_net_stride, int lda1, float* save_mean,
+                              float* save_invstd, float* z, int64_t z_net_stride, int ldz, float* partials, int B, int H, int nets,
+                              float momentum, float eps, void* stream) {
+    if (!x || !W1 || !bias1 || !gamma1 || !beta1 || !W2 || !bias2 || !mom || !running_mean || !running_var || !a1_out ||
+        !save_mean || !save_invstd || !z || !partials || !bb_shape_ok(B, H) || H != 2 * BL_KC || nets <= 0)
+        return NAF_ERR_ARG;
+    if (K <= 0 || K > L12_KMAX || lda1 < H || ldz < H) return NAF_ERR_ARG;
+    const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
+    if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d || (x_net_stride & 3) != 0) return NAF_ERR_ARG;
+    // W1 chunks are read as flat float4 streams: base and the second chunk's offset (128 K floats) 16-byte aligned
+    if ((((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)mom) & 15) != 0 || (param_net_stride & 3) != 0 || ((BL_KC * K) & 3) != 0 ||
+        ((uintptr_t)partials & 7) != 0)
+        return NAF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nets * (B / BB_ROWS), H / BL_BN);
+#define BB_L12(K4V)                                                                                                        \
+    bb_layer12_kernel<K4V><<<grid, BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W1, bias1, gamma1, beta1, W2, bias2,     \
+                                                        param_net_stride, mom, running_mean, running_var, stat_net_stride, \
+                                                        a1_out, a1_net_stride, lda1, save_mean, save_invstd, z, z_net_stride, \
+                                                        ldz, (float2*)partials, B, momentum, eps)
+    if (k4d == 6) BB_L12(6);
+    else BB_L12(8);
+#undef BB_L12
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -178,10 +178,15 @@ class Learner:
         #   ep = (with bb + gb) the batch pass of layer 1's backward as the EPILOGUE of the bundle's dA1 blocks (dA1 never
         #        leaves the registers of the block that computed it) instead of a launch of its own
         spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B <= 512 else ("bb,gb,hk,ep" if self.bb_ok else "gb")).lower()
-        names = {"l1", "b2", "f3", "gb", "s3", "bb", "hk", "ep"}
-        self.fuse = (set(names) - {"bb", "hk", "ep"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
+        #   l12 = (with bb; opt-in, NOT default) layer 1 inside GEMM 2's launch: every GEMM-2 workgroup forms its A panel from
+        #        the rows itself. Parity-tested; measured 17.0 us against 13.7 us for the two launches it replaces at B = 1024
+        #        (every workgroup repeats the moments statistics of its 128-feature chunks) — DESIGN.md section 4b
+        names = {"l1", "b2", "f3", "gb", "s3", "bb", "hk", "ep", "l12"}
+        self.fuse = (set(names) - {"bb", "hk", "ep", "l12"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if "bb" in self.fuse:
-            self.fuse = ({"bb"} | (self.fuse & {"gb", "hk", "ep"})) if self.bb_ok else (self.fuse - {"bb"})
+            self.fuse = ({"bb"} | (self.fuse & {"gb", "hk", "ep", "l12"})) if self.bb_ok else (self.fuse - {"bb"})
+        else:
+            self.fuse -= {"l12"}
         if "bb" not in self.fuse or lay0.H != 256:
             self.fuse -= {"hk"}
         if not {"bb", "gb"} <= self.fuse or self.B % 32:
@@ -317,11 +322,13 @@ class Learner:
                 self._epi = _lib.GemmL1Bwd(None, t2p_ + 4 * seg_["W1"].offset, t2p_ + 4 * seg_["b1"].offset, ptr(self.A1[0]),
                                            ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1),
                                            0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H)     # x / ldx: set per minibatch
+            # dA1 FIRST: its blocks carry the layer-1 epilogue and run longest; dispatched first, the short weight-gradient
+            # blocks fill in behind them instead of the other way round
             self._bundle = (D * 3)(
-                D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks, NHP * HP),
-                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks, H * H),
                 D(ptr(self.dZ2), ptr(self.W2_main), None if self._epi is not None else ptr(self.dA1), None, B, H, H, H, H, H, 0, 1,
-                  1, 0, _lib.C.addressof(self._epi) if self._epi is not None else None))
+                  1, 0, _lib.C.addressof(self._epi) if self._epi is not None else None),
+                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks, H * H),
+                D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks, NHP * HP))
             SS = _lib.SlabSeg
             self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks),
                                      SS(ptr(self.bb_slab_wh), ptr(self.gWh), NHP * HP, NHP * HP, ks))
@@ -381,15 +388,25 @@ class Learner:
                 self.moments(rows, self.bb_mom)
                 moments = self.bb_mom
             self._mom = moments
-            # layer 1: batch statistics from the moments, z, normalise, ReLU — one launch for both nets
-            check(self._f.naf_bb_layer1(
-                rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
-                t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
-                ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), B, H, 2, BN_MOMENTUM, BN_EPS, st),
-                "bb_layer1")
-            # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
-            check(self._f.naf_bb_linear_stats(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset, t2p + 4 * seg["b2"].offset, P,
-                                              ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, H, 2, st), "bb_linear_stats")
+            if "l12" in self.fuse:
+                # layer 1 + GEMM 2 of both nets in one launch (A1 formed in LDS by every GEMM-2 workgroup, written out by the
+                # column-0 ones), bias added, layer-2 statistics partials from the epilogue
+                check(self._f.naf_bb_layer12(
+                    rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                    t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, t2p + 4 * seg["W2"].offset,
+                    t2p + 4 * seg["b2"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H,
+                    ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, 2,
+                    BN_MOMENTUM, BN_EPS, st), "bb_layer12")
+            else:
+                # layer 1: batch statistics from the moments, z, normalise, ReLU — one launch for both nets
+                check(self._f.naf_bb_layer1(
+                    rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                    t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
+                    ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), B, H, 2, BN_MOMENTUM, BN_EPS, st),
+                    "bb_layer1")
+                # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
+                check(self._f.naf_bb_linear_stats(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset, t2p + 4 * seg["b2"].offset, P,
+                                                  ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, H, 2, st), "bb_linear_stats")
             if "hk" in self.fuse:
                 return               # layer 2 from Z2 on is inside naf_bb_layer2_head (learn_rows)
             # fold + normalise + ReLU -> A2, and this column slice's share of the heads GEMM

@@ -32,7 +32,7 @@ def current_sd(L, net):
     return sd
 
 
-@pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "s3", "l1,b2,gb,s3", "all", "bb,gb", "bb", "bb,gb,hk", "bb,gb,ep", "default"])
+@pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "s3", "l1,b2,gb,s3", "all", "bb,gb", "bb", "bb,gb,hk", "bb,gb,ep", "bb,l12", "default"])
 @pytest.mark.parametrize("tag", G3_TAGS)
 def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     """NAF_FUSE selects which small GEMMs are folded into the BN / head kernels (csrc/fused_layers.hip; "all" includes
@@ -91,7 +91,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     assert (L.grad[mask] == 0).all() and (L.theta2[0][mask] == 0).all() and (L.adam_v[mask] == 0).all()
 
 
-@pytest.mark.parametrize("fused", ["none", "all", "l1,b2,gb,s3", "bb,gb", "bb,gb,hk,ep"])
+@pytest.mark.parametrize("fused", ["none", "all", "l1,b2,gb,s3", "bb,gb", "bb,gb,hk,ep,l12"])
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32),
                                    (21, 6, 512), (32, 8, 512), (21, 6, 1024), (21, 6, 768)])
