@@ -1,0 +1,118 @@
+"""Where one update of the large-batch chain spends its time: phases INSIDE each kernel and the gaps BETWEEN kernels, from
+wall-clock marks the kernels leave themselves (csrc/common.h NAF_TL, include/naf_hip.h naf_timeline_read). rocprofv3 gives
+per-kernel durations; this gives the inside of them, with no profiler attached, under the graph replay the bench times.
+
+    NAF_BUILD_DEFINES=-DNAF_TIMELINE python benchmarks/kernel_timeline.py --batch 1024 [--robot kuka] [--out file.json]
+
+(the define selects an object directory of its own under csrc/build/, but the linked libnaf_hip.so is shared: rebuild
+without the define before measuring throughput — the marks cost a few stores per kernel.)
+Times are microseconds since the first mark of the update's first kernel; resolution 0.01 us (100 MHz clock).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+KERNELS = ["bb_layer1", "bb_linear_stats", "bb_layer2_head", "bb_bn_bwd_stage2", "gemm_bundle", "bb_layer1_bwd_finish", "adam_polyak"]
+MARKS = {
+    "bb_layer1": ["entry", "operands staged", "statistics from moments", "z tile", "normalise + store"],
+    "bb_linear_stats": ["entry", "chunk 0 staged", "chunk 0 MFMA", "chunk 1 staged", "chunk 1 MFMA", "Z2 + statistics partials"],
+    "bb_layer2_head": ["entry", "operands + statistics fold", "normalise, V'", "heads MFMA", "halves merged", "NAF head body", "dA2 MFMA + sums", "partials out"],
+    "bb_bn_bwd_stage2": ["entry", "loads + fold", "dz", "column sums"],
+    "gemm_bundle": ["entry", "chunk 0 staged", "K loop", "C stored", "layer-1 backward epilogue", "norm partial"],
+    "bb_layer1_bwd_finish": ["entry", "loads + folds", "dW1 / slab sums", "norm partial"],
+    "adam_polyak": ["entry", "norm folded", "update"],
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--robot", default="kuka")
+    ap.add_argument("--updates", type=int, default=64)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    if "NAF_TIMELINE" not in os.environ.get("NAF_BUILD_DEFINES", ""):
+        raise SystemExit("build with NAF_BUILD_DEFINES=-DNAF_TIMELINE")
+    import torch
+    sys.argv = [sys.argv[0]]
+    import bench
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.engine import TrainChunk
+    from robotic_manipulator_rloa_amd.learner import Learner
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+
+    dev = torch.device("cuda", 0)
+    S, A = (23, 7) if args.robot == "panda" else (21, 6)
+    B, N = args.batch, 200_000
+    L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, dev, p_mode=_lib.P_HADAMARD)
+    sd = reference_init_state_dict(S, A, 256, seed=0)
+    L.load_params(0, sd)
+    L.load_params(1, sd)
+    replay = ReplayBuffer(N, B, dev, seed=1000, state_size=S, action_size=A)
+    replay.add_rows_device(bench.synth_rows(N, S, A, replay.row_floats, replay.off_s2, seed=77, device=dev), N)
+    chunk = TrainChunk(L, replay, args.updates, use_graph=True, gather_outside_graph=True)
+    chunk.capture()
+    for _ in range(5):
+        chunk.run()
+    torch.cuda.synchronize()
+    lib = L.lib
+    raw = {}
+    for kid, name in enumerate(KERNELS):
+        buf = (C.c_longlong * 32)()
+        rc = lib.naf_timeline_read(kid, buf)
+        if rc != 0:
+            raise SystemExit(f"naf_timeline_read({name}) = {rc}")
+        raw[name] = [list(buf[:16]), list(buf[16:])]
+    # the marks are those of the LAST update of the last replay: one consistent pass through the chain
+    t0 = min(raw[KERNELS[0]][w][0] for w in (0, 1))
+    out = {"batch": B, "robot": args.robot, "fuse": sorted(L.fuse), "unit": "us since the first kernel's entry", "kernels": {}}
+    print(f"B = {B}, fuse = {sorted(L.fuse)}")
+    prev_end = None
+    for name in KERNELS:
+        n = len(MARKS[name])
+        rows = {}
+        for w, tag in ((0, "first workgroup"), (1, "last workgroup")):
+            rows[tag] = [round((raw[name][w][i] - t0) / 100.0, 2) for i in range(n)]
+            for i in range(1, n):           # a mark this workgroup did not pass (the finish launch's slab-reduce blocks)
+                if not (rows[tag][i - 1] - 1.0 <= rows[tag][i] <= rows[tag][i - 1] + 1000.0):
+                    rows[tag][i] = rows[tag][i - 1]
+        start = min(r[0] for r in rows.values())
+        end = max(r[-1] for r in rows.values())
+        out["kernels"][name] = {"marks": MARKS[name], **rows, "start": start, "end": end,
+                                "gap_before": None if prev_end is None else round(start - prev_end, 2)}
+        gap = "" if prev_end is None else f"   (gap {start - prev_end:+.2f})"
+        print(f"{name:22s} {start:7.2f} -> {end:7.2f} = {end - start:5.2f} us{gap}")
+        for tag, r in rows.items():
+            steps = " | ".join(f"{MARKS[name][i]} +{r[i] - r[i - 1]:.2f}" for i in range(1, n))
+            print(f"    {tag:16s} entry {r[0]:7.2f} | {steps}")
+        prev_end = end
+    # gemm_bundle, every workgroup: when it entered and left (a launch larger than the chip's resident set runs in rounds)
+    ent, ext = [], []
+    for i in range(256):
+        buf = (C.c_longlong * 32)()
+        if lib.naf_timeline_read(1024 + i, buf) != 0:
+            break
+        ent += list(buf[:16])
+        ext += list(buf[16:])
+    n_wg = sum(1 for t in ent if t > 0)             # workgroups write their own slot; the rest of the array stays zero
+    if n_wg:
+        ent = [round((t - t0) / 100.0, 2) for t in ent[:n_wg]]
+        ext = [round((t - t0) / 100.0, 2) for t in ext[:n_wg]]
+        out["gemm_bundle_workgroups"] = {"entry": ent, "exit": ext}
+        print(f"gemm_bundle: {n_wg} workgroups; entry / exit (us) of every 32nd:")
+        for i in range(0, n_wg, 32):
+            print(f"    wg {i:4d}: {ent[i]:7.2f} -> {ext[i]:7.2f}")
+        print(f"    last   : {ent[-1]:7.2f} -> {ext[-1]:7.2f}; latest exit {max(ext):7.2f}")
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

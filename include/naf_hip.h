@@ -63,12 +63,19 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 11
+#define NAF_HIP_ABI_VERSION 12
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
 /* development knob (tile-shape selection for A/B timing, benchmarks/kernel_probe.py); not part of the data path */
 int naf_debug_set(int key, int value);
+/* development aid: phase marks of the large-batch chain's kernels (csrc/common.h, NAF_TL_*; kernel_id 0..6 = bb_layer1,
+ * bb_linear_stats, bb_layer2_head, bb_bn_bwd_stage2, gemm_bundle, bb_layer1_bwd_finish, adam_polyak). Copies
+ * out[2][16] = 100 MHz wall-clock values left by the first and by the last workgroup of the kernel's most recent launch
+ * (synchronises the device). kernel_id 1024 + i: entry (out[0][..]) and exit (out[1][..]) clocks of workgroups 16 i .. 16 i + 15
+ * of the last gemm_bundle launch. NAF_ERR_STATE unless the library was built with -DNAF_TIMELINE (NAF_BUILD_DEFINES);
+ * benchmarks/kernel_timeline.py is the reader. Not part of the data path. */
+int naf_timeline_read(int kernel_id, long long* out);
 
 /* ---- replay buffer: HBM ring of transition rows ------------------------------------------ */
 /* replaces ReplayBuffer.__init__ (utils/replay_buffer.py:16-30): deque(maxlen=buffer_size) */
@@ -244,14 +251,14 @@ int naf_bb_moments(const float* x, int64_t batch_stride, int64_t x_net_stride, i
 int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                   const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
                   float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
-                  float* save_mean, float* save_invstd, int B, int H, int nets, float momentum, float eps, void* stream);
+                  float* save_mean, float* save_invstd, float* wc_out /* nullable: [H][KP], row c = w_c C of net 0, for naf_bb_layer1_bwd_finish */, int B, int H, int nets, float momentum, float eps, void* stream);
 /* naf_bb_layer1 and naf_bb_linear_stats in ONE launch (H = 256, K <= 26): every GEMM-2 workgroup forms its own A panel
  * A1 = ReLU(BN(x W1^T + b1)) in LDS from the rows and the moments record; the column-0 workgroups also write A1 (a1_out, for the
  * backward pass), the running statistics and save_mean / save_invstd of layer 1. Outputs of naf_bb_linear_stats as below. */
 int naf_bb_layer12(const float* x, int64_t x_net_stride, int ldx, int K, const float* W1, const float* bias1,
                    const float* gamma1, const float* beta1, const float* W2, const float* bias2, int64_t param_net_stride,
                    const float* mom, float* running_mean, float* running_var, int64_t stat_net_stride, float* a1_out,
-                   int64_t a1_net_stride, int lda1, float* save_mean, float* save_invstd, float* z, int64_t z_net_stride, int ldz,
+                   int64_t a1_net_stride, int lda1, float* save_mean, float* save_invstd, float* wc_out /* as naf_bb_layer1 */, float* z, int64_t z_net_stride, int ldz,
                    float* partials, int B, int H, int nets, float momentum, float eps, void* stream);
 /* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K = 256, N % 64 == 0) on f32 MFMA, 64 x 32 tiles, with the
  * column statistics partials of every 64-row block written by the epilogue: replaces `self.hidden_layer(x)`
@@ -296,24 +303,28 @@ int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const floa
  * sum dy, sum dy*xhat) and the block shares p_slabs[B/64][H][KP] of P (KP = naf_bb_layer1_bwd_kp(K)).
  * finish: folds them in block order -> d_W[H][K], d_gamma, d_beta, d_bias = 0 (sum_r dz vanishes identically; the reference's
  * value is rounding noise that the train-mode BatchNorm cancels), d_bias2 (layer 2, from naf_bb_bn_bwd_stage2's
- * dz_col_partials). K <= 26. mom: the MAIN net's moments record. sumsq_partials (nullable): sums of squares of everything
- * written here plus d_gamma2 / d_beta2 (then required: read, not written); step_dev (nullable): *step_dev += 1. */
+ * dz_col_partials). K <= 32. mom: the MAIN net's moments record (Sx); wc: [H][KP], row c = w_c C, left by the forward pass
+ * (naf_bb_layer1 / naf_bb_layer12, wc_out). sumsq_partials (nullable): sums of squares of everything written here plus
+ * d_gamma2 / d_beta2 (then required: read, not written), one entry per workgroup: naf_bb_layer1_bwd_finish_blocks(H) finish
+ * blocks, then the slab segments' (below); step_dev (nullable): *step_dev += 1. */
 int naf_bb_layer1_bwd(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W, const float* bias,
                       const float* out, int ldo, const float* save_mean, const float* save_invstd, float* partials,
                       float* p_slabs, int B, int H, void* stream);
 int naf_bb_layer1_bwd_kp(int K);
 /* segs (HOST array, n_segs <= 2, may be 0): split-K slabs of the bundle's weight gradients (naf_gemm_desc_t.k_split), added in
  * slab order by extra workgroups of the same launch: dst[i] = sum_s src[s * stride + i], i < n (n % 4 == 0, n_slabs <= 8);
- * their sums of squares follow the ceil(H/8) entries of sumsq_partials, ceil(n / 1024) entries per segment. */
+ * their sums of squares follow the naf_bb_layer1_bwd_finish_blocks(H) entries of sumsq_partials, ceil(n / 1024) entries per
+ * segment. */
 typedef struct naf_bb_slab_seg {
     const float* src;
     float* dst;
     int64_t stride;
     int n, n_slabs;
 } naf_bb_slab_seg_t;
+int naf_bb_layer1_bwd_finish_blocks(int H);
 int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, int nb1 /* blocks of partials1 / p_slabs:
                              B/64 from naf_bb_layer1_bwd, B/32 from the bundle's epilogue */, const float* dz2_col_partials, int nb,
-                             const float* mom, const float* W, const float* gamma, const float* save_invstd, float* d_W,
+                             const float* mom, const float* wc, const float* gamma, const float* save_invstd, float* d_W,
                              float* d_gamma, float* d_beta, float* d_bias, float* d_bias2, const float* d_gamma2,
                              const float* d_beta2, float* sumsq_partials, int32_t* step_dev, int B, int H,
                              const naf_bb_slab_seg_t* segs, int n_segs, void* stream);

@@ -28,8 +28,28 @@ class NafHipError(RuntimeError):
     pass
 
 
+def _build_flags() -> list:
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable"]
+    if os.environ.get("NAF_BUILD_DEFINES"):      # tile-shape experiments / -DNAF_TIMELINE (benchmarks/): e.g. "-DFT_TX=4"
+        flags += os.environ["NAF_BUILD_DEFINES"].split()
+    return flags
+
+
+def _flags_stamp() -> str:
+    return LIB_PATH + ".flags"
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
+        return True
+    # a library linked from objects of other flags (a -DNAF_TIMELINE build left behind) is stale too. No stamp = a
+    # library that travelled without one (prebuilt on another box): trusted when no defines are asked for.
+    want = " ".join(_build_flags())
+    if os.path.exists(_flags_stamp()):
+        with open(_flags_stamp()) as f:
+            if f.read().strip() != want:
+                return True
+    elif os.environ.get("NAF_BUILD_DEFINES"):
         return True
     t = os.path.getmtime(LIB_PATH)
     for f in SOURCES + HEADERS:
@@ -65,9 +85,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             if not force and not _stale():           # another process built it while this one waited
                 return LIB_PATH
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
-            flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable"]
-            if os.environ.get("NAF_BUILD_DEFINES"):  # tile-shape experiments (benchmarks/): e.g. "-DFT_TX=4"
-                flags += os.environ["NAF_BUILD_DEFINES"].split()
+            flags = _build_flags()
             # one object per source (csrc/build/, keyed by the flags), compiled in parallel and only when the source
             # or a header is newer: an edit of one kernel file rebuilds in seconds instead of a minute
             import hashlib
@@ -99,6 +117,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                     os.remove(tmp)
                 raise NafHipError("hipcc (link) failed:\n" + r.stdout + r.stderr)
             os.replace(tmp, LIB_PATH)
+            with open(_flags_stamp(), "w") as f:
+                f.write(" ".join(flags) + "\n")
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
@@ -113,6 +133,7 @@ _PROTOS = {
     "naf_hip_abi_version": [],
     "naf_hip_arch": [],
     "naf_debug_set": [_i, _i],
+    "naf_timeline_read": [_i, _vp],
     "naf_replay_row_floats": [_i, _i],
     "naf_replay_row_off_next_state": [_i, _i],
     "naf_replay_create": [_u64, _i, _i, _vp, _vp, C.POINTER(_vp)],
@@ -147,10 +168,10 @@ _PROTOS = {
                                         _i, _i, _vp],
     "naf_bb_moments_floats": [_i],
     "naf_bb_moments": [_vp, _i64, _i64, _i, _i, _vp, _i, _i, _i, _vp],
-    "naf_bb_layer1": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _f,
+    "naf_bb_layer1": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f,
                       _vp],
-    "naf_bb_layer12": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
-                       _i, _vp, _i, _i, _i, _f, _f, _vp],
+    "naf_bb_layer12": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp,
+                       _i64, _i, _vp, _i, _i, _i, _f, _f, _vp],
     "naf_bb_linear_stats": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp],
     "naf_bb_bn_relu_heads_partial": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
                                      _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
@@ -160,6 +181,7 @@ _PROTOS = {
                            _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "naf_bb_layer1_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "naf_bb_layer1_bwd_kp": [_i],
+    "naf_bb_layer1_bwd_finish_blocks": [_i],
     "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                  _vp, _i, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],

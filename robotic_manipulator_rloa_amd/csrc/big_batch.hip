@@ -32,6 +32,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // NB <= BB_MAX_NB (B <= 2048): every partial is requested up front (indices clamped, adds predicated), ONE round trip
 // instead of NB / 8 dependent ones — this runs in the prologue of every consumer.
 #define BB_MAX_NB 32
+NAF_TL_DECL(g_tl_bb);
+NAF_TL_READER(naf_tl_read_bb, g_tl_bb)
 __device__ static inline void bb_fold_stats(const float2* __restrict__ p, int H, int NB, int B, int col, float* mean,
                                             float* var) {
     float2 v[BB_MAX_NB];
@@ -242,19 +244,33 @@ __device__ static inline void bb_tile_col_sums(const float (&v)[4][4], float (*r
 
 // per-column forward statistics of layer 1 from the moments record: 4 threads per column (tid >> 2 = column of the
 // workgroup's 64, tid & 3 = quarter of the rows of C), folded by two xor shuffles. sMom: [Sx | C] in LDS, sWt: [k][column].
+// wc_row (nullable): this column's row of the [H][KP] matrix w_c C, left for the backward pass (bb_layer1_bwd_finish_kernel:
+// sum_r xhat[r][c] x[r][k] = invstd_c (w_c C)[k]; C is symmetric, so (C w_c)[j] computed here is the same vector).
 template <int K4>
 __device__ static inline void bb_l1_stats_from_moments(const float* sMom, const float (*sWt)[BB_COLS + 4], float bias_c, int B,
-                                                       int tid, float* mean, float* var) {
+                                                       int tid, float* mean, float* var, float* wc_row = nullptr) {
     constexpr int KP = 4 * K4, KQ = KP / 4;
     const int c = tid >> 2, part = tid & 3;
     float t = 0.f, mdot = 0.f;
+    float w[KP];                                        // the column's weights: read once (they were re-read per row of C)
+#pragma unroll
+    for (int k = 0; k < KP; ++k) w[k] = sWt[k][c];
 #pragma unroll
     for (int jj = 0; jj < KQ; ++jj) {
         const int j = part * KQ + jj;
-        const float wj = sWt[j][c];
+        float wj = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) wj = (k == j) ? w[k] : wj;       // (j is not a compile-time constant: select, no indexing)
         float row = 0.f;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) row = __builtin_fmaf(sMom[KP + j * KP + k], sWt[k][c], row);
+        for (int k4 = 0; k4 < K4; ++k4) {
+            const f32x4 cv = *(const f32x4*)(sMom + KP + j * KP + 4 * k4);   // the same address in 16 lanes of 64: a broadcast
+            row = __builtin_fmaf(cv[0], w[4 * k4 + 0], row);
+            row = __builtin_fmaf(cv[1], w[4 * k4 + 1], row);
+            row = __builtin_fmaf(cv[2], w[4 * k4 + 2], row);
+            row = __builtin_fmaf(cv[3], w[4 * k4 + 3], row);
+        }
+        if (wc_row) wc_row[j] = row;
         t = __builtin_fmaf(wj, row, t);
         mdot = __builtin_fmaf(wj, sMom[j], mdot);
     }
@@ -267,14 +283,21 @@ __device__ static inline void bb_l1_stats_from_moments(const float* sMom, const 
 }
 
 // layer 1 forward for `nets` networks: statistics from the moments, z tile, normalise, ReLU -> out
+// Prologue: every global operand — the row tile, the 64 columns' weights (ONE contiguous run of 64 K floats, read as float4
+// and scattered to [k][column] in LDS), the moments record, the per-column parameters — is requested before the first LDS
+// store. (As `for (e = tid; ...) lds[..] = global[..]` loops the compiler kept one load in flight per trip: nine dependent
+// round trips, 2.5 of this kernel's 5.0 us — benchmarks/kernel_timeline.py.)
 template <int K4>
 __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
     const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
     int64_t param_net_stride, const float* __restrict__ mom, float* __restrict__ running_mean,
     float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out, int64_t out_net_stride, int ldo,
-    float* __restrict__ save_mean, float* __restrict__ save_invstd, int B, int H, float momentum, float eps) {
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ wc_out, int B, int H, float momentum,
+    float eps) {
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
+    constexpr int XN = (BB_ROWS * K4 + BB_THREADS - 1) / BB_THREADS;           // float4 of the row tile per thread: 2
+    constexpr int MN = (REC / 4 + BB_THREADS - 1) / BB_THREADS;                // of the moments record: 1 or 2
     __shared__ __attribute__((aligned(16))) float sXt[KP][BB_ROWS + 4];
     __shared__ __attribute__((aligned(16))) float sWt[KP][BB_COLS + 4];
     __shared__ __attribute__((aligned(16))) float sMom[REC];
@@ -282,15 +305,74 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS, net = blockIdx.z;
     const int64_t po = net * param_net_stride;
-    bb_l1_stage<K4>(x + net * x_net_stride, ldx, rb * BB_ROWS, W + po, K, col0, H, sXt, sWt, tid);
-    for (int e = tid; e < REC / 4; e += BB_THREADS) ((float4*)sMom)[e] = ((const float4*)(mom + (int64_t)net * REC))[e];
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 0);
+    const float* xn = x + net * x_net_stride + (int64_t)rb * BB_ROWS * ldx;
+    f32x4 xv[XN], wv[2], mv[MN];
+#pragma unroll
+    for (int i = 0; i < XN; ++i) {
+        const int e = tid + BB_THREADS * i;
+        const int row = e / K4, q = e - row * K4;
+        xv[i] = ((const f32x4*)(xn + (int64_t)(row < BB_ROWS ? row : 0) * ldx))[q];
+    }
+    const int wn4 = (BB_COLS * K) >> 2;                                          // 16 K float4 (<= 512)
+    const f32x4* wsrc = (const f32x4*)(W + po + (int64_t)col0 * K);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + BB_THREADS * i;
+        wv[i] = wsrc[e < wn4 ? e : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < MN; ++i) {
+        const int e = tid + BB_THREADS * i;
+        mv[i] = ((const f32x4*)(mom + (int64_t)net * REC))[e < REC / 4 ? e : 0];
+    }
     const float4 b4 = *(const float4*)(bias + po + col0 + 4 * tx);
     const float bias_c = bias[po + col0 + (tid >> 2)];
     const float gm = gamma[po + col0 + (tid >> 2)], bt = beta[po + col0 + (tid >> 2)];
+    float rm_ = 0.f, rv_ = 0.f;
+    if (rb == 0 && (tid & 3) == 0) {
+        rm_ = running_mean[net * stat_net_stride + col0 + (tid >> 2)];
+        rv_ = running_var[net * stat_net_stride + col0 + (tid >> 2)];
+    }
+    // rows k >= K of the weight tile meet the padding columns of the row tile: zero
+    for (int e = tid; e < (KP - K) * BB_COLS; e += BB_THREADS) sWt[K + e / BB_COLS][e % BB_COLS] = 0.f;
+#pragma unroll
+    for (int i = 0; i < XN; ++i) {
+        const int e = tid + BB_THREADS * i;
+        const int row = e / K4, q = e - row * K4;
+        if (row < BB_ROWS) {
+            sXt[4 * q + 0][row] = xv[i][0];
+            sXt[4 * q + 1][row] = xv[i][1];
+            sXt[4 * q + 2][row] = xv[i][2];
+            sXt[4 * q + 3][row] = xv[i][3];
+        }
+    }
+    {
+        const unsigned kinv = (65536u + (unsigned)K - 1u) / (unsigned)K;        // i / K for i < 64 K <= 2048: exact (K <= 32)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + BB_THREADS * i;
+            if (e < wn4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned idx = 4u * (unsigned)e + (unsigned)q;
+                    const unsigned c = (idx * kinv) >> 16;
+                    sWt[idx - c * (unsigned)K][c] = wv[i][q];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MN; ++i) {
+        const int e = tid + BB_THREADS * i;
+        if (e < REC / 4) ((f32x4*)sMom)[e] = mv[i];
+    }
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 1);
     {
         float mean, var;
-        bb_l1_stats_from_moments<K4>(sMom, sWt, bias_c, B, tid, &mean, &var);
+        bb_l1_stats_from_moments<K4>(sMom, sWt, bias_c, B, tid, &mean, &var,
+                                     (wc_out && net == 0 && rb == 0) ? wc_out + (int64_t)(col0 + (tid >> 2)) * KP : nullptr);
         if ((tid & 3) == 0) {
             const int c = tid >> 2, col = col0 + c;
             const float invstd = 1.0f / sqrtf(var + eps);
@@ -301,16 +383,18 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
             if (rb == 0) {
                 const int64_t so = net * stat_net_stride + col;
                 const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-                running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
-                running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
+                running_mean[so] = (1.0f - momentum) * rm_ + momentum * mean;
+                running_var[so] = (1.0f - momentum) * rv_ + momentum * unbiased;
                 save_mean[(int64_t)net * H + col] = mean;
                 save_invstd[(int64_t)net * H + col] = invstd;
             }
         }
     }
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 2);
     float z[4][4];
     bb_l1_tile<K4>(sXt, sWt, b4, ty, tx, z);
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 3);
     float* oz = out + net * out_net_stride;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -324,6 +408,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
         }
         *(float4*)(oz + (int64_t)(rb * BB_ROWS + 4 * ty + i) * ldo + col0 + 4 * tx) = y;
     }
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 4);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -407,16 +492,21 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     // the second chunk's loads are issued behind the first chunk's LDS stores and land in registers while its MFMAs run
     // (all 24 loads up front made the register allocator park 12 of them in scratch)
     f32x4 va1[8], vb1[4];
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 0);
     bl_load_chunk(va, vb, an, lda, wn_, K, 0, tid);
     bl_store_chunk(va, vb, sA, sB, tid);
     __builtin_amdgcn_sched_barrier(0);                    // keep chunk 1's loads behind chunk 0's stores
     bl_load_chunk(va1, vb1, an, lda, wn_, K, BL_KC, tid);
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 1);
     bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
     __syncthreads();                                      // first chunk fully consumed
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 2);
     bl_store_chunk(va1, vb1, sA, sB, tid);
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 3);
     bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 4);
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
     float v[2][4];
     float s = 0.f;
@@ -451,6 +541,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     __syncthreads();
     if (wm == 0 && g == 0)
         partials[((int64_t)net * NB + rb) * N + n0 + 16 * wn + r] = make_float2(S, red[0][16 * wn + r] + red[1][16 * wn + r]);
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 5);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -471,8 +562,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer12_kernel(
     const float* __restrict__ bias1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
     const float* __restrict__ W2, const float* __restrict__ bias2, int64_t param_net_stride, const float* __restrict__ mom,
     float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ a1_out,
-    int64_t a1_net_stride, int lda1, float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ z,
-    int64_t z_net_stride, int ldz, float2* __restrict__ partials, int B, float momentum, float eps) {
+    int64_t a1_net_stride, int lda1, float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ wc_out,
+    float* __restrict__ z, int64_t z_net_stride, int ldz, float2* __restrict__ partials, int B, float momentum, float eps) {
     // every MFMA operand of layer 1 sits in LDS zero-padded to KP (+4) floats per row, k contiguous, so that a fragment is ONE
     // unconditional 16-byte read (the first MFMA version read W1 flat with a `k < K ? .. : 0` per element: one dependent LDS
     // round trip per MFMA — 4 us per phase instead of 0.5)
@@ -602,6 +693,14 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer12_kernel(
                 }
                 // lane (r, g) holds U[f = 32 w + 16 mt + 4 g + e][n = r] (u0) and [n = 16 + r] (u1)
                 const bool hi = 16 + r < KP;
+                if (wc_out && writer && rb == 0 && net == 0) {       // w_f C for the backward pass (bb_layer1_bwd_finish_kernel)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float* dst = wc_out + (int64_t)(c * BL_KC + 32 * wave + 16 * mt + 4 * g + e) * KP;
+                        dst[r] = u0[e];
+                        if (hi) dst[16 + r] = u1[e];
+                    }
+                }
                 const float sx0 = sSx[r], sx1 = sSx[16 + r];
                 float t[4], md[4];
 #pragma unroll
@@ -864,6 +963,12 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const int rb = blockIdx.x;
     const int64_t s0 = (int64_t)rb * FK_ROWS;
     const int T = A * (A + 1) / 2, v_col = A + T;
+    // every kernel argument this prologue needs, fetched NOW: left to itself the compiler fetches an argument where it is
+    // first used, behind the branches of this prologue — six dependent scalar round trips in front of the loads proper
+    asm volatile("" ::"s"(z), "s"(gamma), "s"(beta), "s"(partials), "s"(running_mean), "s"(running_var), "s"(a2_out), "s"(save_mean),
+                 "s"(save_invstd), "s"(Wh), "s"(u), "s"(r), "s"(z_net_stride), "s"(param_net_stride), "s"(stat_net_stride),
+                 "s"(wh_net_stride), "s"(ldz), "s"(ldw), "s"(ldu), "s"(ldr), "s"(NB64), "s"(B), "s"(A));
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 0);
     // ---- phase 0: every global operand requested up front, in ONE batch: the Z2 tiles, the head weights (into registers,
     // native vectors), the statistics partials, the per-sample scalars — measured with the weights staged behind the
     // statistics fold this phase took 4.4 of the kernel's 10.8 us (two dependent round trips to fresh data) -------------
@@ -921,6 +1026,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     if (tid < H / 4) *(f32x4*)(sWv + 4 * tid) = wv_r;
     for (int e = tid; e < (FK_THREADS / 8) * NHP; e += FK_THREADS) sDH[e] = 0.f;
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 1);
     // ---- phase 1: normalise. main net -> xhat (LDS) and A2 (memory); target net -> V'(s') ---------------------------
     {
         const f32x4 m0 = *(const f32x4*)&sStat[0][0][4 * lane], i0 = *(const f32x4*)&sStat[0][1][4 * lane];
@@ -956,6 +1062,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         }
     }
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 2);
     // ---- phase 2: heads = A2 Wh^T + bias: 2 x NHP/16 MFMA tiles, each cut into two K halves, over the 8 waves (with whole
     // tiles half of the waves idled through the longest MFMA chain of the kernel: 2.2 of its 10.8 us). The halves meet in
     // LDS, lower half first -------------------------------------------------------------------------------------------
@@ -984,14 +1091,17 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         for (int e = 0; e < 4; ++e) dst[(16 * mt + 4 * gg + e) * NHP + 16 * nt + rr] = acc0[e] + acc1[e];
     }
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 3);
     for (int e = tid; e < FK_ROWS * NHP; e += FK_THREADS) {
         sHd[e] = (sHd[e] + sHalf[e]) + sBias[e % NHP];
         sHalf[e] = 0.f;
     }
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 4);
     // ---- phase 3: the NAF head on the 32 rows (threads 0..255 carry samples; every thread joins the barriers) --------
     naf_head_body<PMODE, 2, FK_THREADS>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td, q_out,
                                         nullptr, loss_partials, B, A, s0, FK_ROWS);
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 5);
     if (tid < FK_ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
     // ---- phase 4: dA2 = d_heads Wh (K = NHP), 2 x 16 tiles, 4 per wave; ReLU mask, dY2, block sums --------------------
     {
@@ -1028,7 +1138,9 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         }
     }
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 6);
     if (tid < H) partials_bw[(int64_t)rb * H + tid] = make_float2(sP[0][tid].x + sP[1][tid].x, sP[0][tid].y + sP[1][tid].y);
+    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 7);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1128,6 +1240,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
     const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS;
     const int row = tid >> 2, cq = tid & 3;
     const int64_t grow = (int64_t)rb * BB_ROWS + row;
+    NAF_TL(g_tl_bb, NAF_TL_BB_STAGE2, 0);
     float4 zv[4], dv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1156,6 +1269,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
         }
     }
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_STAGE2, 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w}, d4[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
@@ -1170,7 +1284,9 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
         *(float4*)(dy + grow * ldd + col0 + 16 * cq + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_STAGE2, 2);
     if (tid < BB_COLS) dz_col_partials[(int64_t)rb * H + col0 + tid] = bb_col_sum64(sT, tid);
+    NAF_TL(g_tl_bb, NAF_TL_BB_STAGE2, 3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1256,10 +1372,16 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
     }
 }
 
-// finish: one workgroup per 8 columns, thread = (column, k lane of 32); behind them, workgroups that add the split-K
-// slabs of the bundle's weight gradients (dW2, dWh) in slab order, 1024 floats each — every gradient element leaves this
-// launch final, with its sum-of-squares partial.
-#define BF_COLS 8
+// finish: TWO columns per workgroup, two waves per column, lane = (k of 32, half): the column's p_slabs blocks are dealt in
+// four contiguous runs to the (wave, half) quarters — at most 16 loads per lane, all in flight at once — and meet in a fixed
+// order (quarters 0 + 1 by shuffle, 2 + 3 likewise, the pairs through LDS). The column's block sums are loaded ONE block per
+// lane and folded by an xor-shuffle tree. (The first version had 8 columns x 32 k lanes per workgroup, every lane walking all
+// 64 blocks of three arrays in two rounds and recomputing w_c C with 32 shuffles: 6.6 / 8.4 us at B = 1024 / 2048, most of it
+// waiting — benchmarks/kernel_timeline.py.) w_c C comes from the forward pass (wc, [H][KP]).
+// Behind the finish blocks, workgroups that add the split-K slabs of the bundle's weight gradients (dW2, dWh) in slab order,
+// 1024 floats each — every gradient element leaves this launch final, with its sum-of-squares partial.
+#define BF_COLS 2
+#define BB_MAX_NB1 64
 struct BbSlabSeg {
     const float* src;       // slab 0; slab s at src + s * stride
     float* dst;
@@ -1273,15 +1395,16 @@ struct BbSlabs {
 #define BB_MAX_SLABS 8
 __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
     const float* __restrict__ p_slabs, int KP, int K, const float2* __restrict__ partials1, int NB1,
-    const float* __restrict__ dz2_col_partials, int NB, const float* __restrict__ mom, const float* __restrict__ W,
+    const float* __restrict__ dz2_col_partials, int NB, const float* __restrict__ mom, const float* __restrict__ wc,
     const float* __restrict__ gamma, const float* __restrict__ save_invstd, float* __restrict__ d_W,
     float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_bias2,
     const float* __restrict__ d_gamma2, const float* __restrict__ d_beta2, float* __restrict__ sumsq_partials,
     int32_t* step_dev, int B, int H, const BbSlabs slabs) {
     __shared__ float sQ[BB_THREADS / 64];
-    __shared__ __attribute__((aligned(16))) float sMom[32 + 32 * 32];
+    __shared__ float sP[BF_COLS][2][32];
     const int tid = threadIdx.x;
     float sq = 0.f;
+    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 0);
     if ((int)blockIdx.x >= slabs.n_finish_blocks) {
         const int rbk = (int)blockIdx.x - slabs.n_finish_blocks;
         const BbSlabSeg& sg = (slabs.n_seg > 1 && rbk >= slabs.seg[1].block0) ? slabs.seg[1] : slabs.seg[0];
@@ -1299,81 +1422,73 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
             sq = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
         }
     } else {
-        const int c = tid >> 5, k = tid & 31;
-        const int col = blockIdx.x * BF_COLS + c;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int cl = wave >> 1, wq = wave & 1, k = lane & 31, hf = lane >> 5;
+        const int col = blockIdx.x * BF_COLS + cl;
         const bool col_on = col < H;
         const int colc = col_on ? col : H - 1;
-        // everything requested up front and by EVERY lane (no branch around a load: the 32 lanes of a column read the same
-        // block sums, one broadcast each): P slabs of (col, k), the block sums of both layers, the column's constants
         const int kc = k < KP ? k : 0;
-        float pv[BB_MAX_NB], dv[BB_MAX_NB];
-        float2 av[BB_MAX_NB];
-        const int nba = NB1 < BB_MAX_NB ? NB1 : BB_MAX_NB;          // layer-1 blocks: first round of (at most) 32
+        // everything requested up front, branch-free (indices clamped, sums predicated)
+        const int Q = (NB1 + 3) >> 2, rb0 = (2 * wq + hf) * Q;     // this quarter's run of blocks
+        float pv[BB_MAX_NB1 / 4];
 #pragma unroll
-        for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-            const int64_t r1 = rb < nba ? rb : 0, r2 = rb < NB ? rb : 0;
-            pv[rb] = p_slabs[(r1 * H + colc) * KP + kc];
-            av[rb] = partials1[r1 * H + colc];
-            dv[rb] = dz2_col_partials[r2 * H + colc];
+        for (int i = 0; i < BB_MAX_NB1 / 4; ++i) {
+            const int rb = rb0 + i;
+            pv[i] = p_slabs[((int64_t)((i < Q && rb < NB1) ? rb : 0) * H + colc) * KP + kc];
         }
+        // block sums: wave 0 of the column takes partials1 (block = lane), wave 1 the layer-2 bias partials
+        float2 av = make_float2(0.f, 0.f);
+        float dv = 0.f;
+        if (wq == 0) av = partials1[(int64_t)(lane < NB1 ? lane : 0) * H + colc];
+        else dv = dz2_col_partials[(int64_t)(lane < NB ? lane : 0) * H + colc];
         const float invstd = save_invstd[colc], gm = gamma[colc];
-        const float wk = W[(int64_t)colc * K + (k < K ? k : 0)];
-        for (int e = tid; e < (KP + KP * KP) / 4; e += BB_THREADS) ((float4*)sMom)[e] = ((const float4*)mom)[e];
-        float P = 0.f, db2 = 0.f;
-        float2 ab = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-            P += rb < nba ? pv[rb] : 0.f;
-            db2 += rb < NB ? dv[rb] : 0.f;
-            ab.x += rb < nba ? av[rb].x : 0.f;
-            ab.y += rb < nba ? av[rb].y : 0.f;
+        const float sxk = mom[kc], wck = wc[(int64_t)colc * KP + kc];
+        float g2 = 0.f, b2 = 0.f;
+        if (d_gamma2) {
+            g2 = d_gamma2[colc];                           // written by bb_bn_bwd_stage2, an earlier launch
+            b2 = d_beta2[colc];
         }
-        if (NB1 > BB_MAX_NB) {                                      // 32-row blocks from the bundle's epilogue at B = 2048: 64
-            const int nbb = NB1 - BB_MAX_NB;
+        float P = 0.f;
 #pragma unroll
-            for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-                const int64_t r1 = BB_MAX_NB + (rb < nbb ? rb : 0);
-                pv[rb] = p_slabs[(r1 * H + colc) * KP + kc];
-                av[rb] = partials1[r1 * H + colc];
-            }
+        for (int i = 0; i < BB_MAX_NB1 / 4; ++i) P += (i < Q && rb0 + i < NB1) ? pv[i] : 0.f;
+        {
+            const float other = __shfl_xor(P, 32);          // quarters (0, 1) of wave 0, (2, 3) of wave 1: lower + upper
+            P = hf ? other + P : P + other;
+        }
+        if (hf == 0) sP[cl][wq][k] = P;
+        float sdy = (wq == 0 && lane < NB1) ? av.x : 0.f, sdx = (wq == 0 && lane < NB1) ? av.y : 0.f;
+        float db2 = (wq == 1 && lane < NB) ? dv : 0.f;
 #pragma unroll
-            for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-                P += rb < nbb ? pv[rb] : 0.f;
-                ab.x += rb < nbb ? av[rb].x : 0.f;
-                ab.y += rb < nbb ? av[rb].y : 0.f;
-            }
+        for (int o = 1; o < 64; o <<= 1) {
+            sdy += __shfl_xor(sdy, o);
+            sdx += __shfl_xor(sdx, o);
+            db2 += __shfl_xor(db2, o);
         }
         __syncthreads();
-        const int lbase = (tid & 63) & ~31;
-        const float sdy = ab.x, sdx = ab.y;
-        // (w_c C)[k] = sum_j w[c][j] C[j][k]: w[c][j] comes from lane j of this column's 32
-        float wc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const float wj = __shfl(wk, lbase + j);
-            if (j < K && k < KP) wc = __builtin_fmaf(wj, sMom[KP + j * KP + k], wc);
-        }
+        NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 1);
         if (col_on) {
-            if (k < K) {
-                const float invB = 1.0f / (float)B;
-                const float g = (gm * invstd) * (P - (sdy * invB) * sMom[k] - (sdx * invB) * (invstd * wc));
-                d_W[(int64_t)col * K + k] = g;
-                sq = g * g;
-            }
-            if (k == 27) {                                   // d_gamma = sum dy*xhat, d_beta = sum dy; d_bias = 0 (see above)
-                d_gamma[col] = sdx;
-                d_beta[col] = sdy;
-                d_bias[col] = 0.f;
-                sq += sdx * sdx + sdy * sdy;
-            } else if (k == 30) {
+            if (wq == 0) {
+                if (hf == 0 && k < K) {
+                    const float invB = 1.0f / (float)B;
+                    const float Pt = sP[cl][0][k] + sP[cl][1][k];
+                    const float g = (gm * invstd) * (Pt - (sdy * invB) * sxk - (sdx * invB) * (invstd * wck));
+                    d_W[(int64_t)col * K + k] = g;
+                    sq = g * g;
+                } else if (lane == 32) {                      // d_gamma = sum dy*xhat, d_beta = sum dy; d_bias = 0 (see above)
+                    d_gamma[col] = sdx;
+                    d_beta[col] = sdy;
+                    d_bias[col] = 0.f;
+                    sq = sdx * sdx + sdy * sdy;
+                }
+            } else if (lane == 0) {
                 d_bias2[col] = db2;
-                sq += db2 * db2;
-            } else if (k == 31 && d_gamma2) {
-                const float g = d_gamma2[col], b = d_beta2[col];   // written by bb_bn_bwd_stage2, an earlier launch
-                sq += g * g + b * b;
+                sq = db2 * db2;
+            } else if (lane == 1) {
+                sq = g2 * g2 + b2 * b2;
             }
         }
     }
+    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 2);
     if (sumsq_partials) {
         const float tot = block_sum_to_thread0<BB_THREADS, true>(sq, sQ, tid);
         if (tid == 0) {
@@ -1381,6 +1496,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
             if (blockIdx.x == 0 && step_dev) *step_dev += 1;   // read by the NEXT launch (Adam) only
         }
     }
+    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1411,21 +1527,22 @@ extern "C" int naf_bb_moments(const float* x, int64_t batch_stride, int64_t x_ne
 extern "C" int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                              const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
                              float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
-                             int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, int B, int H, int nets,
-                             float momentum, float eps, void* stream) {
+                             int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
+                             int nets, float momentum, float eps, void* stream) {
     if (!x || !W || !bias || !mom || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd ||
         !bb_shape_ok(B, H) || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4 || ldo < H || (ldo & 3))
         return NAF_ERR_ARG;
     const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
     if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d || (x_net_stride & 3) != 0) return NAF_ERR_ARG;
-    if ((((uintptr_t)bias | (uintptr_t)out | (uintptr_t)mom) & 15) != 0 || (param_net_stride & 3) != 0 || (out_net_stride & 3) != 0)
-        return NAF_ERR_ARG;
+    if ((((uintptr_t)bias | (uintptr_t)out | (uintptr_t)mom | (uintptr_t)W) & 15) != 0 || (param_net_stride & 3) != 0 ||
+        (out_net_stride & 3) != 0)
+        return NAF_ERR_ARG;                              // (W: the 64-column runs of 64 K floats are read as float4)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B / BB_ROWS, H / BB_COLS, nets);
 #define BB_L1(K4V)                                                                                                        \
     bb_layer1_kernel<K4V><<<grid, BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
                                                        running_mean, running_var, stat_net_stride, out, out_net_stride, ldo,  \
-                                                       save_mean, save_invstd, B, H, momentum, eps)
+                                                       save_mean, save_invstd, wc_out, B, H, momentum, eps)
     if (k4d == 6) BB_L1(6);
     else BB_L1(8);
 #undef BB_L1
@@ -1452,8 +1569,8 @@ extern "C" int naf_bb_layer12(const float* x, int64_t x_net_stride, int ldx, int
                               const float* gamma1, const float* beta1, const float* W2, const float* bias2,
                               int64_t param_net_stride, const float* mom, float* running_mean, float* running_var,
                               int64_t stat_net_stride, float* a1_out, int64_t a1_net_stride, int lda1, float* save_mean,
-                              float* save_invstd, float* z, int64_t z_net_stride, int ldz, float* partials, int B, int H, int nets,
-                              float momentum, float eps, void* stream) {
+                              float* save_invstd, float* wc_out, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
+                              int H, int nets, float momentum, float eps, void* stream) {
     if (!x || !W1 || !bias1 || !gamma1 || !beta1 || !W2 || !bias2 || !mom || !running_mean || !running_var || !a1_out ||
         !save_mean || !save_invstd || !z || !partials || !bb_shape_ok(B, H) || H != 2 * BL_KC || nets <= 0)
         return NAF_ERR_ARG;
@@ -1469,8 +1586,8 @@ extern "C" int naf_bb_layer12(const float* x, int64_t x_net_stride, int ldx, int
 #define BB_L12(K4V)                                                                                                        \
     bb_layer12_kernel<K4V><<<grid, BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W1, bias1, gamma1, beta1, W2, bias2,     \
                                                         param_net_stride, mom, running_mean, running_var, stat_net_stride, \
-                                                        a1_out, a1_net_stride, lda1, save_mean, save_invstd, z, z_net_stride, \
-                                                        ldz, (float2*)partials, B, momentum, eps)
+                                                        a1_out, a1_net_stride, lda1, save_mean, save_invstd, wc_out, z,      \
+                                                        z_net_stride, ldz, (float2*)partials, B, momentum, eps)
     if (k4d == 6) BB_L12(6);
     else BB_L12(8);
 #undef BB_L12
@@ -1609,15 +1726,16 @@ extern "C" int naf_bb_layer1_bwd_kp(int K) {
     return (K + 3) / 4 <= 6 ? 24 : 32;
 }
 
+extern "C" int naf_bb_layer1_bwd_finish_blocks(int H) { return H > 0 ? (H + BF_COLS - 1) / BF_COLS : NAF_ERR_ARG; }
+
 extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, int nb1,
-                                        const float* dz2_col_partials, int nb, const float* mom, const float* W, const float* gamma, const float* save_invstd,
+                                        const float* dz2_col_partials, int nb, const float* mom, const float* wc, const float* gamma, const float* save_invstd,
                                         float* d_W, float* d_gamma, float* d_beta, float* d_bias, float* d_bias2,
                                         const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
                                         int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, void* stream) {
-    if (!p_slabs || !partials1 || !dz2_col_partials || !mom || !W || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
-        !d_bias || !d_bias2 || nb <= 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > 2 * BB_MAX_NB || H <= 0 || B <= 0 || K <= 0 ||
-        K > 26 || ((uintptr_t)mom & 15))
-        return NAF_ERR_ARG;                              // lanes 27-31 of a column's 32 carry the vector gradients
+    if (!p_slabs || !partials1 || !dz2_col_partials || !mom || !wc || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
+        !d_bias || !d_bias2 || nb <= 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
+        return NAF_ERR_ARG;
     if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
     if (n_segs < 0 || n_segs > 2 || (n_segs && !segs)) return NAF_ERR_ARG;
     BbSlabs sl;
@@ -1636,7 +1754,7 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
     }
     const int kp = naf_bb_layer1_bwd_kp(K);
     bb_layer1_bwd_finish_kernel<<<sl.n_finish_blocks + blocks, BB_THREADS, 0, (hipStream_t)stream>>>(
-        p_slabs, kp, K, (const float2*)partials1, nb1, dz2_col_partials, nb, mom, W, gamma, save_invstd, d_W, d_gamma, d_beta, d_bias,
+        p_slabs, kp, K, (const float2*)partials1, nb1, dz2_col_partials, nb, mom, wc, gamma, save_invstd, d_W, d_gamma, d_beta, d_bias,
         d_bias2, d_gamma2, d_beta2, sumsq_partials, step_dev, B, H, sl);
     NAF_CHECK_LAUNCH();
     return NAF_OK;

@@ -17,6 +17,36 @@
         if (e__ != hipSuccess) return (int)e__;               \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// Kernel timeline (development aid, compiled in with NAF_BUILD_DEFINES=-DNAF_TIMELINE only): thread 0 of the FIRST and of
+// the LAST workgroup of a launch leaves the 100 MHz wall clock at up to 16 marks per kernel; naf_timeline_read() copies
+// them out (benchmarks/kernel_timeline.py lays one update's launches side by side: phases inside a kernel, gaps between
+// kernels). Without the define the marks compile to nothing and naf_timeline_read() returns NAF_ERR_STATE.
+// ---------------------------------------------------------------------------------------------
+#define NAF_TL_SLOTS 16
+enum { NAF_TL_BB_LAYER1 = 0, NAF_TL_BB_LINEAR_STATS, NAF_TL_BB_LAYER2_HEAD, NAF_TL_BB_STAGE2, NAF_TL_GEMM_BUNDLE, NAF_TL_BB_FINISH,
+       NAF_TL_ADAM, NAF_TL_KERNELS };
+#ifdef NAF_TIMELINE
+#define NAF_TL_DECL(arr) __device__ long long arr[NAF_TL_KERNELS][2][NAF_TL_SLOTS]
+#define NAF_TL(arr, kid, slot)                                                                                       \
+    do {                                                                                                             \
+        if (threadIdx.x == 0) {                                                                                      \
+            if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) arr[kid][0][slot] = wall_clock64();             \
+            if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1)             \
+                arr[kid][1][slot] = wall_clock64();                                                                  \
+        }                                                                                                            \
+    } while (0)
+#define NAF_TL_READER(fn, arr)                                                                                        \
+    int fn(int kid, long long* out) {                                                                                 \
+        return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arr), 2 * NAF_TL_SLOTS * sizeof(long long),                    \
+                                        (size_t)kid * 2 * NAF_TL_SLOTS * sizeof(long long), hipMemcpyDeviceToHost);   \
+    }
+#else
+#define NAF_TL_DECL(arr)
+#define NAF_TL(arr, kid, slot) do { } while (0)
+#define NAF_TL_READER(fn, arr) int fn(int, long long*) { return NAF_ERR_STATE; }
+#endif
+
 __host__ __device__ static inline int naf_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // transition row layout: [state(S) | action(A) | reward | 0-pad to a multiple of 4 floats | next_state(S) | done | 0-pad]

@@ -32,7 +32,9 @@ struct GemmBundle {
 // every wave reads its fragments: lane (r, g) takes k = 16 j + 4 g .. +3 of row r for BOTH operands, so the four MFMAs
 // of macro-step j use each k once. One L2 round trip per 256 k instead of one per
 // fragment (the register-fed form of this kernel issued 256 4-byte loads per lane per tile and ran 10.2 us).
+#ifndef GB_KC
 #define GB_KC 256                 // k per staged chunk
+#endif
 #define GB_LD (GB_KC + 4)         // [row][k] panels: 16-B aligned rows, b128 fragment reads spread over the banks
 #define GB_LDK 36                 // [k][row] panels (k-major operands keep their memory layout): 32 rows + 4 pad
 #define GB_PANEL (GB_KC * GB_LDK) // floats per panel buffer (>= 32 * GB_LD)
@@ -213,6 +215,26 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
     }
 }
 
+NAF_TL_DECL(g_tl_gb);
+NAF_TL_READER(naf_tl_read_gb, g_tl_gb)
+// every workgroup's entry / exit (is the grid resident at once? in which order do the blocks of the three GEMMs drain?)
+#define GB_TL_WGS 4096
+#ifdef NAF_TIMELINE
+__device__ long long g_tl_gb_wg[2][GB_TL_WGS];
+#define GB_TL_WG(which) do { if (threadIdx.x == 0 && blockIdx.x < GB_TL_WGS) g_tl_gb_wg[which][blockIdx.x] = wall_clock64(); } while (0)
+int naf_tl_read_gb_wg(int first, long long* out) {
+    if (first < 0 || first + NAF_TL_SLOTS > GB_TL_WGS) return NAF_ERR_ARG;
+    for (int w = 0; w < 2; ++w) {
+        const hipError_t e = hipMemcpyFromSymbol(out + w * NAF_TL_SLOTS, HIP_SYMBOL(g_tl_gb_wg), NAF_TL_SLOTS * sizeof(long long),
+                                                 ((size_t)w * GB_TL_WGS + first) * sizeof(long long), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return (int)e;
+    }
+    return NAF_OK;
+}
+#else
+#define GB_TL_WG(which) do { } while (0)
+int naf_tl_read_gb_wg(int, long long*) { return NAF_ERR_STATE; }
+#endif
 template <bool AK, bool BK>
 __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int ks, float* sA, float* sB, float* sQ, float* sC) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -231,6 +253,8 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     // the slabs are added in slab order by the consumer (bb_layer1_bwd_finish's reduce blocks). 64 blocks walking
     // K = 1024 pulled 256 KB each through one CU's L2 port (13.6 us per launch at B = 1024); 256 blocks of K = 256 do not.
     L1bwdRegs epi_regs;
+    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 0);
+    GB_TL_WG(0);
     if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, epi_regs);
     const int kper = D.K / D.k_split, k_lo = ks * kper, k_hi = k_lo + kper;
     float* Cs = D.C + (int64_t)ks * D.c_split_stride;
@@ -267,6 +291,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
             }
         }
         __syncthreads();
+        if (k0 == k_lo) NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 1);
         const int steps = kc >> 4;                                    // macro-steps of 16 k, dealt in contiguous runs
         const int kbeg = (steps * kh / GB_KSPLIT) << 4, kend = (steps * (kh + 1) / GB_KSPLIT) << 4;
 #pragma unroll 4
@@ -280,6 +305,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         }
     }
     f32x4 acc = acc0 + acc1;
+    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 2);
     if (kh) *(f32x4*)(sC + (((kh - 1) * 4 + tile) * 64 + lane) * 4) = acc;
     __syncthreads();
     float sq = 0.f;
@@ -297,7 +323,9 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
                 }
         }
     }
+    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 3);
     if (D.epi.x) gemm_l1bwd_epilogue(D, bm, bn, acc, !kh, wm, wn, r, g, sA, sB, tid, epi_regs);
+    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 4);
     if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 tiles)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -305,9 +333,14 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         __syncthreads();
         if (tid == 0) D.sumsq[bm * D.tiles_n + bn] = sQ[0] + sQ[1] + sQ[2] + sQ[3];
     }
+    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 5);
+    GB_TL_WG(1);
 }
 
-__global__ __launch_bounds__(GB_THREADS) void gemm_bundle_kernel(const GemmBundle bundle) {
+#ifndef GB_WAVES_PER_EU
+#define GB_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_WAVES_PER_EU, GB_WAVES_PER_EU))) void gemm_bundle_kernel(const GemmBundle bundle) {
     __shared__ __attribute__((aligned(16))) float sA[GB_PANEL];
     __shared__ __attribute__((aligned(16))) float sB[GB_PANEL];
     __shared__ float sQ[4];

@@ -84,6 +84,8 @@ __device__ static inline void adam_one(float& th, float gr, float& m, float& v, 
     if (tg) *tg = tau * th + one_minus_tau * (*tg);    // soft_update with the freshly stepped main weights
 }
 
+NAF_TL_DECL(g_tl_opt);
+NAF_TL_READER(naf_tl_read_opt, g_tl_opt)
 __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restrict__ theta, const float* __restrict__ g,
                                                                   float* __restrict__ m, float* __restrict__ v,
                                                                   float* __restrict__ target,
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
                                                                   const int32_t* __restrict__ step_dev, float inv_world,
                                                                   size_t n) {
     __shared__ AdamScalars sh;
+    NAF_TL(g_tl_opt, NAF_TL_ADAM, 0);
     const size_t n4 = n / 4;
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // first trip's operands AND the norm partials are requested up front, branch-free (indices clamped, results masked
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
         sh.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     }
     __syncthreads();
+    NAF_TL(g_tl_opt, NAF_TL_ADAM, 1);
     const AdamScalars sc = sh;
     if (sc.skip) return;
     for (size_t i = i0; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
         ((float4*)v)[i] = vv;
         if (target) ((float4*)target)[i] = tg;
     }
+    NAF_TL(g_tl_opt, NAF_TL_ADAM, 2);
     // tail (n % 4 elements)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         size_t e = n4 * 4 + threadIdx.x;

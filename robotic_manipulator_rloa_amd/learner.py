@@ -221,10 +221,10 @@ class Learner:
         gb_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32) + ((H + 31) // 32) ** 2   # dWh + dW2 blocks of the bundle
         self.n_partials_norm = (P + _lib.NORM_CHUNK - 1) // _lib.NORM_CHUNK
         # folded norm partials: the bundle's dWh + dW2 blocks, then the column-tile kernels (two launches of ft_blocks) or,
-        # in the large-batch chain, the (H + 7) // 8 workgroups of the layer-1 finish kernel
+        # in the large-batch chain, the workgroups of the layer-1 finish kernel (two columns each)
         self.n_partials_fold = gb_blocks + 2 * ft_blocks
         if "bb" in self.fuse:
-            self.n_partials_fold = (H + 7) // 8 + (H * H + 1023) // 1024 + (NHP * HP + 1023) // 1024
+            self.n_partials_fold = self.lib.naf_bb_layer1_bwd_finish_blocks(H) + (H * H + 1023) // 1024 + (NHP * HP + 1023) // 1024
         self.n_partials = self.n_partials_fold if self.fold_norm else self.n_partials_norm
         # data parallel inside one node: the one-shot peer-memory all-reduce (csrc/xgmi_reduce.hip) replaces the RCCL
         # ring + the grad-norm launch when every rank could map every peer and the exact self-test passed on all of
@@ -265,6 +265,7 @@ class Learner:
             # the batch dimension (TrainChunk computes the records of all its minibatches in one launch behind the gather)
             self.mom_floats = self.lib.naf_bb_moments_floats(lay.S)
             self.bb_mom = torch.zeros(2, self.mom_floats, **f32)
+            self.bb_wc = torch.zeros(H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # w_c C of the main net, forward -> finish
             self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)
             self.bb_bw2 = torch.zeros(2 * NB, H, 2, **f32)      # backward partials of layer 2: (sum dy, sum dy*xhat); per 64-row
             #                                                     block, or per 32-row block from the fused layer-2 + head launch
@@ -314,8 +315,11 @@ class Learner:
                 ks = max(d for d in range(1, 9) if (B // 128) % d == 0)
             else:
                 ks = B // 256 if B % 256 == 0 else 1
-            self.bb_slab_w2 = torch.zeros(ks, H * H, **f32)
-            self.bb_slab_wh = torch.zeros(ks, NHP * HP, **f32)
+            ks_w2 = ks_wh = ks
+            if os.environ.get("NAF_BB_KS"):          # experiment: "w2,wh" K ranges of the two weight gradients
+                ks_w2, ks_wh = (int(v) for v in os.environ["NAF_BB_KS"].split(","))
+            self.bb_slab_w2 = torch.zeros(ks_w2, H * H, **f32)
+            self.bb_slab_wh = torch.zeros(ks_wh, NHP * HP, **f32)
             self._epi = None
             if "ep" in self.fuse:
                 t2p_, seg_ = self.theta2.data_ptr(), lay.seg
@@ -327,11 +331,11 @@ class Learner:
             self._bundle = (D * 3)(
                 D(ptr(self.dZ2), ptr(self.W2_main), None if self._epi is not None else ptr(self.dA1), None, B, H, H, H, H, H, 0, 1,
                   1, 0, _lib.C.addressof(self._epi) if self._epi is not None else None),
-                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks, H * H),
-                D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks, NHP * HP))
+                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks_w2, H * H),
+                D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks_wh, NHP * HP))
             SS = _lib.SlabSeg
-            self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks),
-                                     SS(ptr(self.bb_slab_wh), ptr(self.gWh), NHP * HP, NHP * HP, ks))
+            self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks_w2),
+                                     SS(ptr(self.bb_slab_wh), ptr(self.gWh), NHP * HP, NHP * HP, ks_wh))
             self._bb_nsegs = 2
 
     # ---- parameters in / out ----------------------------------------------------------------------------
@@ -395,15 +399,15 @@ class Learner:
                     rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                     t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, t2p + 4 * seg["W2"].offset,
                     t2p + 4 * seg["b2"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H,
-                    ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, 2,
+                    ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, 2,
                     BN_MOMENTUM, BN_EPS, st), "bb_layer12")
             else:
                 # layer 1: batch statistics from the moments, z, normalise, ReLU — one launch for both nets
                 check(self._f.naf_bb_layer1(
                     rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                     t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
-                    ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), B, H, 2, BN_MOMENTUM, BN_EPS, st),
-                    "bb_layer1")
+                    ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), B, H, 2, BN_MOMENTUM,
+                    BN_EPS, st), "bb_layer1")
                 # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
                 check(self._f.naf_bb_linear_stats(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset, t2p + 4 * seg["b2"].offset, P,
                                                   ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, H, 2, st), "bb_linear_stats")
@@ -547,8 +551,7 @@ class Learner:
             check(f.naf_bb_layer1_bwd_finish(
                 ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1),
                 B // 32 if ("ep" in self.fuse and not getattr(self, "_bundle64", False)) else B // 64, ptr(self.bb_dzp), B // 64,
-                ptr(self._mom),
-                t2p + 4 * seg["W1"].offset, t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
+                ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
                 gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
                 ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, B, H,
