@@ -53,6 +53,37 @@ __device__ static inline void bb_fold_stats(const float2* __restrict__ p, int H,
     *var = M2 / (float)B;      // biased: what normalises
 }
 
+// The same fold for kernels whose prologue is bound by VALU issue (8 waves = two per SIMD, each running this once per
+// thread): one instance per size class behind a UNIFORM branch, so a batch of 256 (NB = 4) executes 4 block steps, not
+// 32 predicated ones, and buffer loads (common.h: naf_buf_*): wave-uniform resource and block offset, one lane offset.
+// p = the partials; the thread's (block 0) element at byte wave_off + lane_off. Same arithmetic and order as above.
+template <int NMAX>
+__device__ __forceinline__ static void bb_fold_stats_n(__amdgpu_buffer_rsrc_t p, unsigned lane_off, unsigned wave_off, int H, int NB,
+                                                       int B, float* mean, float* var) {
+    naf_f32x2 v[NMAX];
+#pragma unroll
+    for (int rb = 0; rb < NMAX; ++rb) v[rb] = naf_buf_f2(p, lane_off, wave_off + (unsigned)(rb < NB ? rb : 0) * (unsigned)H * 8u);
+    float S = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < NMAX; ++rb) S += rb < NB ? v[rb].x : 0.f;
+    const float m = S / (float)B;
+    float M2 = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < NMAX; ++rb) {
+        const float d = v[rb].x * (1.0f / BB_ROWS) - m;
+        M2 += rb < NB ? v[rb].y + (float)BB_ROWS * d * d : 0.f;
+    }
+    *mean = m;
+    *var = M2 / (float)B;
+}
+__device__ __forceinline__ static void bb_fold_stats_u(__amdgpu_buffer_rsrc_t p, unsigned lane_off, unsigned wave_off, int H, int NB,
+                                                       int B, float* mean, float* var) {
+    if (NB <= 4) bb_fold_stats_n<4>(p, lane_off, wave_off, H, NB, B, mean, var);            // B <= 256 (uniform branches)
+    else if (NB <= 8) bb_fold_stats_n<8>(p, lane_off, wave_off, H, NB, B, mean, var);
+    else if (NB <= 16) bb_fold_stats_n<16>(p, lane_off, wave_off, H, NB, B, mean, var);
+    else bb_fold_stats_n<BB_MAX_NB>(p, lane_off, wave_off, H, NB, B, mean, var);
+}
+
 // the same for plain sums (backward partials): (sum .x, sum .y) over the NB blocks, block order
 __device__ static inline float2 bb_fold_sums(const float2* __restrict__ p, int H, int NB, int col) {
     float2 v[BB_MAX_NB];
@@ -972,19 +1003,25 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     // ---- phase 0: every global operand requested up front, in ONE batch: the Z2 tiles, the head weights (into registers,
     // native vectors), the statistics partials, the per-sample scalars — measured with the weights staged behind the
     // statistics fold this phase took 4.4 of the kernel's 10.8 us (two dependent round trips to fresh data) -------------
+    // (addresses: wave-uniform bases in SGPRs + one lane offset; with per-thread 64-bit arithmetic the 52 loads of this
+    // prologue cost ~460 vector instructions per wave, two waves per SIMD: 2 us of issue before the first byte arrived)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned l16 = 16u * (unsigned)lane, l8 = 8u * (unsigned)lane, l4 = 4u * (unsigned)lane;
     f32x4 zm[4], zt[4];
+    {
+        const __amdgpu_buffer_rsrc_t zb = naf_buf(z + (s0 + wave_s) * ldz), ztb = naf_buf(z + z_net_stride + (s0 + wave_s) * ldz);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave + 8 * i;                     // one wave per row: 64 lanes x 4 columns
-        zm[i] = *(const f32x4*)(z + (s0 + row) * ldz + 4 * lane);
-        zt[i] = *(const f32x4*)(z + z_net_stride + (s0 + row) * ldz + 4 * lane);
+        for (int i = 0; i < 4; ++i) {                     // one wave per row: 64 lanes x 4 columns; rows wave + 8 i
+            zm[i] = naf_buf_f4(zb, l16, (unsigned)(8 * i * ldz) * 4u);
+            zt[i] = naf_buf_f4(ztb, l16, (unsigned)(8 * i * ldz) * 4u);
+        }
     }
     constexpr int WPT = NHP * (H / 4) / FK_THREADS;       // float4 of the Wh tile per thread: 2, 4 or 6
     f32x4 wreg[WPT];
+    {
+        const __amdgpu_buffer_rsrc_t wb = naf_buf(Wh + (int64_t)wave_s * ldw);
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int e = tid + FK_THREADS * i;
-        wreg[i] = *(const f32x4*)(Wh + (int64_t)(e >> 6) * ldw + 4 * (e & 63));
+        for (int i = 0; i < WPT; ++i) wreg[i] = naf_buf_f4(wb, l16, (unsigned)(8 * i * ldw) * 4u);   // row = e >> 6, e = tid + 512 i
     }
     const float bias_r = tid < NHP ? Wh[(int64_t)tid * ldw + H] : (tid == NHP ? Wh[wh_net_stride + (int64_t)v_col * ldw + H] : 0.f);
     f32x4 wv_r = {0.f, 0.f, 0.f, 0.f};
@@ -994,16 +1031,20 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const float u_val = (live_ && i_ < A) ? u[(s0 + s_loc_) * ldu + i_] : 0.f;
     const float r_val = (live_ && i_ == 0) ? r[(s0 + s_loc_) * ldr] : 0.f;
     {
-        const int net = tid >> 8, col = tid & (H - 1);    // 512 threads = 2 nets x 256 columns
-        const float gm_ = gamma[net * param_net_stride + col], bt_ = beta[net * param_net_stride + col];
+        const int net = wave_s >> 2;                       // 512 threads = 2 nets x 256 columns: 4 waves per net
+        const int cb = (wave_s & 3) * 64;                  // the wave's 64 columns
+        const unsigned col = (unsigned)(cb + lane);
+        const float gm_ = naf_buf_f1(naf_buf(gamma + net * param_net_stride + cb), l4, 0);
+        const float bt_ = naf_buf_f1(naf_buf(beta + net * param_net_stride + cb), l4, 0);
         float rm_ = 0.f, rv_ = 0.f;
-        const int64_t so = net * stat_net_stride + col;
+        float* rmp = running_mean + net * stat_net_stride;
+        float* rvp = running_var + net * stat_net_stride;
         if (rb == 0) {
-            rm_ = running_mean[so];
-            rv_ = running_var[so];
+            rm_ = rmp[col];
+            rv_ = rvp[col];
         }
         float mean, var;
-        bb_fold_stats(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
+        bb_fold_stats_u(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
         const float invstd = 1.0f / sqrtf(var + eps);
         sStat[net][0][col] = mean;
         sStat[net][1][col] = invstd;
@@ -1011,10 +1052,10 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         sStat[net][3][col] = bt_;
         if (rb == 0) {
             const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-            running_mean[so] = (1.0f - momentum) * rm_ + momentum * mean;
-            running_var[so] = (1.0f - momentum) * rv_ + momentum * unbiased;
-            save_mean[(int64_t)net * H + col] = mean;
-            save_invstd[(int64_t)net * H + col] = invstd;
+            rmp[col] = (1.0f - momentum) * rm_ + momentum * mean;
+            rvp[col] = (1.0f - momentum) * rv_ + momentum * unbiased;
+            (save_mean + (int64_t)net * H)[col] = mean;
+            (save_invstd + (int64_t)net * H)[col] = invstd;
         }
     }
 #pragma unroll

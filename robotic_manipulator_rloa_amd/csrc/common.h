@@ -47,6 +47,34 @@ enum { NAF_TL_BB_LAYER1 = 0, NAF_TL_BB_LINEAR_STATS, NAF_TL_BB_LAYER2_HEAD, NAF_
 #define NAF_TL_READER(fn, arr) int fn(int, long long*) { return NAF_ERR_STATE; }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Buffer loads with SCALAR address arithmetic. A kernel prologue that requests ~50 operands per thread through flat/global
+// loads spends ~5 vector instructions per load on 64-bit addresses; with 8 waves per workgroup (two per SIMD) that was 2 us
+// of VALU issue in front of bb_layer2_head_kernel's first byte (benchmarks/kernel_timeline.py + the ISA). buffer_load takes
+// a wave-uniform resource (SGPRs), a wave-uniform byte offset (SGPR) and ONE 32-bit lane offset (VGPR) shared by every load
+// of the batch: the per-load arithmetic moves to the scalar unit. Bases and scalar offsets MUST be wave-uniform (derive them
+// from blockIdx, kernel arguments and __builtin_amdgcn_readfirstlane(wave)); all offsets are bytes, < 2 GiB from the base.
+// Reads past `bytes` return 0.
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+typedef float naf_f32x2 __attribute__((ext_vector_type(2)));
+typedef float naf_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned naf_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned naf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ static __amdgpu_buffer_rsrc_t naf_buf(const void* base, unsigned bytes = 0x7fffffffu) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ static float naf_buf_f1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, wave_off, 0));
+}
+__device__ __forceinline__ static naf_f32x2 naf_buf_f2(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off) {
+    return __builtin_bit_cast(naf_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, wave_off, 0));
+}
+__device__ __forceinline__ static naf_f32x4 naf_buf_f4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off) {
+    return __builtin_bit_cast(naf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, wave_off, 0));
+}
+#endif
+
 __host__ __device__ static inline int naf_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // transition row layout: [state(S) | action(A) | reward | 0-pad to a multiple of 4 floats | next_state(S) | done | 0-pad]
