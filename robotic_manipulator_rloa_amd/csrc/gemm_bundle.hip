@@ -94,6 +94,42 @@ __device__ static inline void store_panel(float* __restrict__ sm, const float4 (
     }
 }
 
+// The same panel (whole GB_KC chunks only) through buffer loads (common.h: naf_buf_*): wave-uniform resource and chunk /
+// row offsets on the scalar unit, ONE lane offset per panel computed once per block. The flat-addressed form above spends
+// ~10 vector instructions per float4 (64-bit multiply-adds, bounds selects); with 8 loads per thread per chunk, 8 waves per
+// block and two blocks per CU the blocks of a full launch were bound by VALU issue — every block of a 512-block round took
+// 6.3 us where an isolated one takes 3.2 (benchmarks/kernel_timeline.py, the ISA: 250 v_mul_lo_u32 + 170 v_mad_i64_i32 +
+// 300 v_lshl_add_u64 in the kernel). Rows / columns past the matrix read as 0: the resource ends at the matrix' last byte
+// (row bound), a lane whose float4 lies past the operand's contiguous dimension gets an offset past everything.
+struct PanelSrc {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff, ld4;
+};
+template <bool KMAJOR>
+__device__ __forceinline__ static PanelSrc panel_src(const float* __restrict__ p, int ld, int row0, int rows_total, int k_total, int tid) {
+    PanelSrc s;
+    s.ld4 = (unsigned)ld * 4u;
+    if (KMAJOR) {                                          // [K][rows]: (k, row) at (k * ld + row) * 4; k = (tid >> 3) + 64 i
+        s.rs = naf_buf(p, (unsigned)k_total * s.ld4);
+        const int r4 = (tid & 7) * 4;
+        s.voff = row0 + r4 < rows_total ? (unsigned)(tid >> 3) * s.ld4 + (unsigned)(row0 + r4) * 4u : 0x7f000000u;
+    } else {                                               // [rows][K]: row = wave + 8 i, k = 4 lane
+        s.rs = naf_buf(p, (unsigned)rows_total * s.ld4);
+        s.voff = (unsigned)(tid & 63) * 16u;
+    }
+    return s;
+}
+template <bool KMAJOR>
+__device__ __forceinline__ static void load_panel_buf(float4 (&v)[GB_PT], const PanelSrc& s, int row0, int k0, int wave) {
+#pragma unroll
+    for (int i = 0; i < GB_PT; ++i) {
+        const unsigned soff = KMAJOR ? (unsigned)(k0 + (GB_THREADS / 8) * i) * s.ld4
+                                     : (unsigned)(row0 + wave + (GB_THREADS / 64) * i) * s.ld4 + (unsigned)k0 * 4u;
+        const naf_f32x4 t = naf_buf_f4(s.rs, s.voff, soff);
+        v[i] = make_float4(t.x, t.y, t.z, t.w);
+    }
+}
+
 // fragment of macro-step kk for lane (r, g): elements k = kk + 4 g + c, c = 0..3, of panel row `row`
 template <bool KMAJOR>
 __device__ static inline float4 read_frag(const float* __restrict__ sm, int row, int g, int kk) {
@@ -109,109 +145,114 @@ __device__ static inline float4 read_frag(const float* __restrict__ sm, int row,
 // memory (csrc/big_batch.hip, bb_layer1_bwd_kernel does the same as a launch of its own): z recomputed from the minibatch
 // rows and W1 (K <= 32), xhat, dy = ReLU'(A1) * dA1, the block sums (sum dy, sum dy*xhat) per column -> partials[M/32][N],
 // and the block's share of P = dY^T X -> p_slabs[M/32][N][KP]. dA1 itself is not written (C may be NULL).
-// Everything the epilogue reads from memory is requested BEFORE the K loop (gemm_l1bwd_prefetch) and waits in registers;
-// after the MFMAs the tile goes through LDS once so that all 512 threads (not only the four accumulator waves) share the
-// elementwise work: thread = (row, column) and (row + 16, column).
+// Everything the epilogue reads from memory is requested BEFORE the K loop (gemm_l1bwd_prefetch) and waits in registers.
+// Both small products run on MFMA in the accumulator waves' own layout: z = X W1^T (2 x 2 tiles, K = KP) by the four waves
+// that hold the dA1 tiles — dy never leaves their registers before it is final — and P = dY^T X (2 x 2 tiles, K = 32 rows)
+// by the other four, from dy in LDS. (The first version did both on the VALU, one (row, column) pair per thread with LDS
+// operands: 2.1 - 2.8 us of a 7 us block, and two resident blocks per CU take turns at it — benchmarks/kernel_timeline.py.)
 struct L1bwdRegs {
     f32x4 x;           // one float4 of the X tile (threads < 32 * KP / 4)
     float w[2];        // two scalars of the W1 tile
-    float a1[2];       // A1 at this thread's two tile elements
-    float st;          // mean | invstd | bias (threads < 96)
+    float a1[4];       // accumulator waves: A1 at the lane's four C/D elements (rows 4 g + e, column r of the tile)
+    float mean, invstd, bias;   // of the lane's column
 };
-__device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int bn, int tid, L1bwdRegs& R) {
+__device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int bn, int tid, bool owner, int wm, int wn, int r, int g,
+                                                  L1bwdRegs& R) {
     const naf_gemm_l1bwd_t& E = D.epi;
     const int KP = E.kp, m0 = bm * 32, n0 = bn * 32;
-    const int xr = tid / (KP / 4), xq = tid - xr * (KP / 4);
+    const int xr = KP == 24 ? tid / 6 : tid / 8, xq = tid - xr * (KP / 4);       // (KP is 24 or 32: divisions by constants)
     R.x = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (xr < 32) R.x = ((const f32x4*)(E.x + (int64_t)(m0 + xr) * E.ldx))[xq];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int e = tid + GB_THREADS * i;
-        const int c = e / KP, k = e - c * KP;
+        const int c = KP == 24 ? e / 24 : e / 32, k = e - c * KP;
         R.w[i] = (c < 32 && k < E.K) ? E.W[(int64_t)(n0 + c) * E.K + k] : 0.f;
-        const int row = (tid >> 5) + 16 * i, col = tid & 31;
-        R.a1[i] = E.a1[(int64_t)(m0 + row) * E.lda1 + n0 + col];
     }
-    R.st = 0.f;
-    if (tid < 32) R.st = E.save_mean[n0 + tid];
-    else if (tid < 64) R.st = E.save_invstd[n0 + tid - 32];
-    else if (tid < 96) R.st = E.bias[n0 + tid - 64];
+    const int col = n0 + wn * 16 + r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) R.a1[e] = owner ? E.a1[(int64_t)(m0 + wm * 16 + 4 * g + e) * E.lda1 + col] : 0.f;
+    R.mean = E.save_mean[col];
+    R.invstd = E.save_invstd[col];
+    R.bias = E.bias[col];
 }
 
 __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int bn, const f32x4& acc, bool owner, int wm, int wn,
                                                   int r, int g, float* sA, float* sB, int tid, const L1bwdRegs& R) {
+    static_assert(GB_KSPLIT == 2, "the epilogue deals its two products to the accumulator waves and to the other four");
     const naf_gemm_l1bwd_t& E = D.epi;
     const int KP = E.kp, XS = KP + 4;
     const int n0 = bn * 32;
     float* sX = sA;                    // [32 rows][XS]
     float* sW = sA + 32 * XS;          // [32 cols][XS]
-    float* sDA = sA + 64 * XS;         // [32 rows][33]: the C tile
     float* sDY = sB;                   // [32 rows][33]
-    float* sSt = sB + 32 * 33;         // mean[32] | invstd[32] | bias[32]
-    float2* sRed = (float2*)(sB + 32 * 33 + 96);   // [8 waves][32]
+    float2* sRed = (float2*)(sB + 32 * 33);   // [2 row tiles][32 columns]
     // (the barrier behind the K halves' hand-over has every wave past its last fragment read: the panels are free)
     {
-        const int xr = tid / (KP / 4), xq = tid - xr * (KP / 4);
+        const int xr = KP == 24 ? tid / 6 : tid / 8, xq = tid - xr * (KP / 4);
         if (xr < 32) *(f32x4*)(sX + xr * XS + 4 * xq) = R.x;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + GB_THREADS * i;
-            const int c = e / KP, k = e - c * KP;
+            const int c = KP == 24 ? e / 24 : e / 32, k = e - c * KP;
             if (c < 32) sW[c * XS + k] = R.w[i];
         }
-        if (tid < 96) sSt[tid] = R.st;
-        if (owner) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sDA[(wm * 16 + 4 * g + e) * 33 + wn * 16 + r] = acc[e];
-        }
     }
     __syncthreads();
-    const int col = tid & 31;
-    const float mean = sSt[col], invstd = sSt[32 + col], b = sSt[64 + col];
-    float s_dy = 0.f, s_dx = 0.f;
+    if (owner) {
+        // z tile: rows wm * 16 .. +15 x columns wn * 16 .. +15, K = KP in two steps of 16 (KP = 24: lane groups 2, 3 of the second
+        // step are past the row: zeros)
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 5) + 16 * i;
-        float z = b;                                         // b + sum_k x_k w_k, k ascending: the forward's arithmetic
-        for (int q = 0; q < KP / 4; ++q) {
-            const f32x4 xv = *(const f32x4*)(sX + row * XS + 4 * q), wv = *(const f32x4*)(sW + col * XS + 4 * q);
-            z = __builtin_fmaf(xv.x, wv.x, z);
-            z = __builtin_fmaf(xv.y, wv.y, z);
-            z = __builtin_fmaf(xv.z, wv.z, z);
-            z = __builtin_fmaf(xv.w, wv.w, z);
+        for (int kk = 0; kk < 32; kk += 16) {
+            if (kk < KP) {
+                const bool in = kk + 4 * g < KP;
+                const int ko = in ? kk + 4 * g : 0;
+                f32x4 a = *(const f32x4*)(sX + (wm * 16 + r) * XS + ko), b = *(const f32x4*)(sW + (wn * 16 + r) * XS + ko);
+                if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], z, 0, 0, 0);
+            }
         }
-        const float xh = (z - mean) * invstd;
-        const float dy = R.a1[i] > 0.f ? sDA[row * 33 + col] : 0.f;
-        sDY[row * 33 + col] = dy;
-        s_dy += dy;
-        s_dx += dy * xh;
+        float s_dy = 0.f, s_dx = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = ((z[e] + R.bias) - R.mean) * R.invstd;
+            const float dy = R.a1[e] > 0.f ? acc[e] : 0.f;
+            sDY[(wm * 16 + 4 * g + e) * 33 + wn * 16 + r] = dy;
+            s_dy += dy;
+            s_dx += dy * xh;
+        }
+        s_dy += __shfl_xor(s_dy, 16);                        // the tile's other row groups of the same column
+        s_dy += __shfl_xor(s_dy, 32);
+        s_dx += __shfl_xor(s_dx, 16);
+        s_dx += __shfl_xor(s_dx, 32);
+        if (g == 0) sRed[wm * 32 + wn * 16 + r] = make_float2(s_dy, s_dx);
     }
-    s_dy += __shfl_xor(s_dy, 32);                            // the wave's other row of the same column
-    s_dx += __shfl_xor(s_dx, 32);
-    if ((tid & 63) < 32) sRed[(tid >> 6) * 32 + col] = make_float2(s_dy, s_dx);
     __syncthreads();
     if (tid < 32) {
-        float2 t = sRed[tid];
-#pragma unroll
-        for (int w = 1; w < GB_THREADS / 64; ++w) {
-            t.x += sRed[w * 32 + tid].x;
-            t.y += sRed[w * 32 + tid].y;
-        }
-        ((float2*)E.partials)[(int64_t)bm * D.N + n0 + tid] = t;
+        const float2 t0 = sRed[tid], t1 = sRed[32 + tid];
+        ((float2*)E.partials)[(int64_t)bm * D.N + n0 + tid] = make_float2(t0.x + t1.x, t0.y + t1.y);
     }
-    {   // P share of this block: thread = (column, k lane of 16): k = lane, lane + 16; sum over the 32 rows, row ascending
-        const int c = tid >> 4, kq = tid & 15;
-        float p0 = 0.f, p1 = 0.f;
-        const bool two = kq + 16 < KP;
-#pragma unroll 8
-        for (int row = 0; row < 32; ++row) {
-            const float dy = sDY[row * 33 + c];
-            p0 = __builtin_fmaf(dy, sX[row * XS + kq], p0);
-            p1 = __builtin_fmaf(dy, sX[row * XS + (two ? kq + 16 : kq)], p1);
+    if (!owner) {
+        // P share of this block: tile (mt, nt) = columns mt * 16 .. +15 x k nt * 16 .. +15, reduction over the 32 rows.
+        // A[m = column][k = row] = dy[row][column], B[k = row][n] = x[row][n]
+        const int mt = wm, nt = wn;                          // (the four non-accumulator waves carry the same (wm, wn) pairs)
+        const bool n_on = nt * 16 + r < KP;
+        const int xc = n_on ? nt * 16 + r : 0;
+        f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = kk + 4 * g + q;
+                pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sDY[row * 33 + mt * 16 + r], sX[row * XS + xc], pacc, 0, 0, 0);
+            }
         }
-        float* dst = E.p_slabs + ((int64_t)bm * D.N + n0 + c) * KP;
-        dst[kq] = p0;
-        if (two) dst[kq + 16] = p1;
+        if (n_on) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) E.p_slabs[((int64_t)bm * D.N + n0 + mt * 16 + 4 * g + e) * KP + nt * 16 + r] = pacc[e];
+        }
     }
 }
 
@@ -237,7 +278,9 @@ int naf_tl_read_gb_wg(int, long long*) { return NAF_ERR_STATE; }
 #endif
 template <bool AK, bool BK>
 __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int ks, float* sA, float* sB, float* sQ, float* sC) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(GB_KC == 256 && GB_THREADS == 512, "load_panel_buf's row / k decomposition");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform values on the scalar unit
     const int r = lane & 15, g = lane >> 4;
     // 8 waves: two per 16 x 16 tile of the 32 x 32 block, each taking one half of the K chunk — the per-wave chain of
     // dependent MFMAs (the longest single piece of this kernel: 1.5 of its 5.0 us with 64 of them) is halved; the two
@@ -255,15 +298,15 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     L1bwdRegs epi_regs;
     NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 0);
     GB_TL_WG(0);
-    if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, epi_regs);
+    if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, !kh, wm, wn, r, g, epi_regs);
     const int kper = D.K / D.k_split, k_lo = ks * kper, k_hi = k_lo + kper;
-    float* Cs = D.C + (int64_t)ks * D.c_split_stride;
+    const PanelSrc pa = panel_src<AK>(D.A, D.lda, m0, D.M, D.K, tid), pb = panel_src<BK>(D.B, D.ldb, n0, D.N, D.K, tid);
     float4 va[GB_PT], vb[GB_PT];
     {
         const int kc0 = kper < GB_KC ? kper : GB_KC;
         if (kc0 == GB_KC) {
-            load_panel<AK, true>(va, D.A, D.lda, m0, D.M, k_lo, kc0, tid);
-            load_panel<BK, true>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
+            load_panel_buf<AK>(va, pa, m0, k_lo, wave);
+            load_panel_buf<BK>(vb, pb, n0, k_lo, wave);
         } else {
             load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k_lo, kc0, tid);
             load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
@@ -283,8 +326,8 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         if (k1 < k_hi) {                                  // next chunk's loads fly under this chunk's MFMAs
             const int kn = (k_hi - k1) < GB_KC ? (k_hi - k1) : GB_KC;
             if (kn == GB_KC) {
-                load_panel<AK, true>(va, D.A, D.lda, m0, D.M, k1, kn, tid);
-                load_panel<BK, true>(vb, D.B, D.ldb, n0, D.N, k1, kn, tid);
+                load_panel_buf<AK>(va, pa, m0, k1, wave);
+                load_panel_buf<BK>(vb, pb, n0, k1, wave);
             } else {
                 load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k1, kn, tid);
                 load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k1, kn, tid);
@@ -312,15 +355,19 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     if (!kh) {
 #pragma unroll
         for (int h = 1; h < GB_KSPLIT; ++h) acc = acc + *(const f32x4*)(sC + (((h - 1) * 4 + tile) * 64 + lane) * 4);
-        const int cm = m0 + wm * 16 + 4 * g, cn = n0 + wn * 16 + r;
-        if (cn < D.N && D.C) {
+        if (D.C) {
+            // rows past M end the resource, a column past N gets an offset past everything: dropped by the hardware. Those
+            // elements are sums over zero panels, so they add nothing to sq either.
+            const unsigned ldc4 = (unsigned)D.ldc * 4u;
+            const __amdgpu_buffer_rsrc_t cr = naf_buf(D.C + (int64_t)ks * D.c_split_stride, (unsigned)D.M * ldc4);
+            const int cn = n0 + wn * 16 + r;
+            const unsigned voff = cn < D.N ? (unsigned)(4 * g) * ldc4 + (unsigned)cn * 4u : 0x7f000000u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (cm + e < D.M) {
-                    const float v = acc[e];
-                    Cs[(int64_t)(cm + e) * D.ldc + cn] = v;
-                    sq += v * v;
-                }
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[e];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), cr, voff, (unsigned)(m0 + wm * 16 + e) * ldc4, 0);
+                sq += v * v;
+            }
         }
     }
     NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 3);
