@@ -92,6 +92,8 @@ def main():
             steps = " | ".join(f"{MARKS[name][i]} +{r[i] - r[i - 1]:.2f}" for i in range(1, n))
             print(f"    {tag:16s} entry {r[0]:7.2f} | {steps}")
         prev_end = end
+        if os.environ.get("NAF_TL_RAW"):      # every slot as written (extra marks placed while investigating a phase)
+            print("    raw slots (first wg):", [round((t - t0) / 100.0, 2) if t > 0 else None for t in raw[name][0]])
     # gemm_bundle, every workgroup: when it entered and left (a launch larger than the chip's resident set runs in rounds)
     ent, ext = [], []
     for i in range(256):

@@ -260,8 +260,7 @@ __device__ static inline void bb_tile_col_sums(const float (&v)[4][4], float (*r
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         s[j] = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
-        s[j] += __shfl_xor(s[j], 16);
-        s[j] += __shfl_xor(s[j], 32);
+        s[j] = naf_xor32_add(naf_xor16_add(s[j]));
     }
     __syncthreads();                 // previous use of red is over
     if ((tid & 63) < 16) {
@@ -305,10 +304,8 @@ __device__ static inline void bb_l1_stats_from_moments(const float* sMom, const 
         t = __builtin_fmaf(wj, row, t);
         mdot = __builtin_fmaf(wj, sMom[j], mdot);
     }
-    t += __shfl_xor(t, 1);
-    t += __shfl_xor(t, 2);
-    mdot += __shfl_xor(mdot, 1);
-    mdot += __shfl_xor(mdot, 2);
+    t = naf_xor2_add(naf_xor1_add(t));
+    mdot = naf_xor2_add(naf_xor1_add(mdot));
     *mean = bias_c + mdot / (float)B;
     *var = fmaxf(t, 0.f) / (float)B;
 }
@@ -358,12 +355,15 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
         mv[i] = ((const f32x4*)(mom + (int64_t)net * REC))[e < REC / 4 ? e : 0];
     }
     const float4 b4 = *(const float4*)(bias + po + col0 + 4 * tx);
-    const float bias_c = bias[po + col0 + (tid >> 2)];
-    const float gm = gamma[po + col0 + (tid >> 2)], bt = beta[po + col0 + (tid >> 2)];
+    // the statistics of column cl are finished by lane (r < 4, g) of wave cl / 16 (see below): its constants
+    const int lane = tid & 63, wave = tid >> 6, mr = lane & 15, mg = lane >> 4;
+    const int cl = 16 * wave + 4 * mg + (mr & 3);
+    const float bias_c = bias[po + col0 + cl];
+    const float gm = gamma[po + col0 + cl], bt = beta[po + col0 + cl];
     float rm_ = 0.f, rv_ = 0.f;
-    if (rb == 0 && (tid & 3) == 0) {
-        rm_ = running_mean[net * stat_net_stride + col0 + (tid >> 2)];
-        rv_ = running_var[net * stat_net_stride + col0 + (tid >> 2)];
+    if (rb == 0 && mr < 4) {
+        rm_ = running_mean[net * stat_net_stride + col0 + cl];
+        rv_ = running_var[net * stat_net_stride + col0 + cl];
     }
     // rows k >= K of the weight tile meet the padding columns of the row tile: zero
     for (int e = tid; e < (KP - K) * BB_COLS; e += BB_THREADS) sWt[K + e / BB_COLS][e % BB_COLS] = 0.f;
@@ -401,11 +401,59 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
     __syncthreads();
     NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 1);
     {
-        float mean, var;
-        bb_l1_stats_from_moments<K4>(sMom, sWt, bias_c, B, tid, &mean, &var,
-                                     (wc_out && net == 0 && rb == 0) ? wc_out + (int64_t)(col0 + (tid >> 2)) * KP : nullptr);
-        if ((tid & 3) == 0) {
-            const int c = tid >> 2, col = col0 + c;
+        // statistics of the 64 columns from the moments on MFMA: U = W C (64 x KP; wave w owns columns 16 w .. +15, both
+        // 16-wide halves of the KP dimension), then var_c B = U[c] . w_c and (mean_c - b_c) B = w_c . Sx as 16-lane reductions
+        // of the accumulator rows. A[m = column][k] = sWt[k][column]; B[k][n] = C[k][n] = C[n][k] (symmetric): one 16-byte
+        // read of row n. (On the VALU — 4 threads per column, 144 FMAs each on LDS operands — this was 1.5 of the kernel's
+        // 3.7 us: benchmarks/kernel_timeline.py.)
+        const float* sC = sMom + KP;
+        f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0;
+        const bool hi = 16 + mr < KP;                        // KP = 24: rows 24 .. 31 of C do not exist
+        const float* c0 = sC + mr * KP, *c1 = sC + (hi ? 16 + mr : 0) * KP;
+#pragma unroll
+        for (int kk = 0; kk < KP; kk += 16) {
+            const bool in = kk + 4 * mg < KP;                // KP = 24: lane groups 2, 3 of the second step are past K
+            const int ko = in ? kk + 4 * mg : 0;
+            f32x4 b0 = *(const f32x4*)(c0 + ko), b1 = *(const f32x4*)(c1 + ko);
+            if (!hi) b1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a = in ? sWt[ko + q][16 * wave + mr] : 0.f;
+                u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[q], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[q], u1, 0, 0, 0);
+            }
+        }
+        NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 5);
+        // lane (mr, mg) holds U[column 16 w + 4 mg + e][n = mr] (u0) and [n = 16 + mr] (u1)
+        if (wc_out && net == 0 && rb == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* dst = wc_out + (int64_t)(col0 + 16 * wave + 4 * mg + e) * KP;
+                dst[mr] = u0[e];
+                if (hi) dst[16 + mr] = u1[e];
+            }
+        }
+        const float sx0 = sMom[mr], sx1 = hi ? sMom[16 + mr] : 0.f;
+        float t[4], md[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 16 * wave + 4 * mg + e;
+            const float w0 = sWt[mr][c], w1 = hi ? sWt[16 + mr][c] : 0.f;
+            t[e] = u0[e] * w0 + u1[e] * w1;
+            md[e] = w0 * sx0 + w1 * sx1;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t[e] = naf_sum16(t[e]);
+            md[e] = naf_sum16(md[e]);
+        }
+        NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 6);
+        if (mr < 4) {                                        // lane mr of the group finishes column 4 mg + mr (= cl)
+            const float tt = mr == 0 ? t[0] : mr == 1 ? t[1] : mr == 2 ? t[2] : t[3];
+            const float mm = mr == 0 ? md[0] : mr == 1 ? md[1] : mr == 2 ? md[2] : md[3];
+            const float mean = bias_c + mm / (float)B;
+            const float var = fmaxf(tt, 0.f) / (float)B;
+            const int c = cl, col = col0 + c;
             const float invstd = 1.0f / sqrtf(var + eps);
             sStat[0][c] = mean;
             sStat[1][c] = invstd;
@@ -551,8 +599,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
             s += v[mt][e];
         }
     // column statistics of the 64-row block: 8 rows in the lane, 4 lane groups (bits 4, 5), 2 waves (wm) through LDS
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    s = naf_xor32_add(naf_xor16_add(s));
     if (g == 0) red[wm][16 * wn + r] = s;
     __syncthreads();
     const float S = red[0][16 * wn + r] + red[1][16 * wn + r];
@@ -565,8 +612,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
             const float t = v[mt][e] - mb;
             m2 += t * t;
         }
-    m2 += __shfl_xor(m2, 16);
-    m2 += __shfl_xor(m2, 32);
+    m2 = naf_xor32_add(naf_xor16_add(m2));
     __syncthreads();
     if (g == 0) red[wm][16 * wn + r] = m2;
     __syncthreads();
@@ -742,12 +788,9 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer12_kernel(
                     md[e] = w0 * sx0 + w1 * sx1;
                 }
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        t[e] += __shfl_xor(t[e], o);
-                        md[e] += __shfl_xor(md[e], o);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    t[e] = naf_sum16(t[e]);
+                    md[e] = naf_sum16(md[e]);
                 }
                 if (r < 4) {                                          // lane r of the group finishes feature 4 g + r
                     const int f = 32 * wave + 16 * mt + 4 * g + r;
@@ -818,8 +861,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer12_kernel(
             zn[(int64_t)(16 * mt + e) * ldz] = v[mt][e];
             s += v[mt][e];
         }
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    s = naf_xor32_add(naf_xor16_add(s));
     if (g == 0) red[wm][16 * wn + r] = s;
     __syncthreads();
     const float S = red[0][16 * wn + r] + red[1][16 * wn + r];
@@ -832,8 +874,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer12_kernel(
             const float t = v[mt][e] - mb;
             m2 += t * t;
         }
-    m2 += __shfl_xor(m2, 16);
-    m2 += __shfl_xor(m2, 32);
+    m2 = naf_xor32_add(naf_xor16_add(m2));
     __syncthreads();
     if (g == 0) red[wm][16 * wn + r] = m2;
     __syncthreads();
@@ -948,8 +989,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_relu_heads_partial_kernel(
             p = __builtin_fmaf(a.z, w.z, p);
             p = __builtin_fmaf(a.w, w.w, p);
         }
-        p += __shfl_xor(p, 1);
-        p += __shfl_xor(p, 2);
+        p = naf_xor2_add(naf_xor1_add(p));
         if (hq == 0) vnext_partial[(int64_t)slice * B + rb * BB_ROWS + row] = p + sBias[0];
     }
 }
@@ -1091,12 +1131,9 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             for (int c = 0; c < 4; ++c) q = __builtin_fmaf(fmaxf(__builtin_fmaf(xt[c], g1[c], b1[c]), 0.f), wv[c], q);
             p[i] = q;
         }
-        // the four rows' wave reductions side by side (four independent shuffle chains instead of one after the other)
+        // the four rows' wave reductions (DPP + permlane swaps: common.h)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) p[i] += __shfl_xor(p[i], o);
-        }
+        for (int i = 0; i < 4; ++i) p[i] = naf_sum64(p[i]);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) sV[wave + 8 * i] = p[i] + sBias[NHP];
@@ -1173,8 +1210,8 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
                 s_dy += dy;
                 s_dx += dy * xh;
             }
-            s_dy += __shfl_xor(s_dy, 16); s_dy += __shfl_xor(s_dy, 32);
-            s_dx += __shfl_xor(s_dx, 16); s_dx += __shfl_xor(s_dx, 32);
+            s_dy = naf_xor32_add(naf_xor16_add(s_dy));
+            s_dx = naf_xor32_add(naf_xor16_add(s_dx));
             if (gg == 0) sP[mt][col] = make_float2(s_dy, s_dx);
         }
     }
@@ -1499,12 +1536,9 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
         if (hf == 0) sP[cl][wq][k] = P;
         float sdy = (wq == 0 && lane < NB1) ? av.x : 0.f, sdx = (wq == 0 && lane < NB1) ? av.y : 0.f;
         float db2 = (wq == 1 && lane < NB) ? dv : 0.f;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            sdy += __shfl_xor(sdy, o);
-            sdx += __shfl_xor(sdx, o);
-            db2 += __shfl_xor(db2, o);
-        }
+        sdy = naf_sum64(sdy);
+        sdx = naf_sum64(sdx);
+        db2 = naf_sum64(db2);
         __syncthreads();
         NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 1);
         if (col_on) {

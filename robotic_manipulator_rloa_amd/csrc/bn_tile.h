@@ -62,8 +62,7 @@ __device__ static inline float bn_col_reduce(float part, float (*red)[BN_TX + 1]
 // Fixed order (xor shuffles inside a wave, then the wave results in index order) -> bitwise reproducible.
 template <int NT, bool FRESH = false>
 __device__ static inline float block_sum_to_thread0(float v, float* sh /* >= NT/64 floats */, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = naf_sum64(v);
     if (!FRESH) __syncthreads();
     if ((tid & 63) == 0) sh[tid >> 6] = v;
     __syncthreads();

@@ -30,11 +30,13 @@ enum { NAF_TL_BB_LAYER1 = 0, NAF_TL_BB_LINEAR_STATS, NAF_TL_BB_LAYER2_HEAD, NAF_
 #define NAF_TL_DECL(arr) __device__ long long arr[NAF_TL_KERNELS][2][NAF_TL_SLOTS]
 #define NAF_TL(arr, kid, slot)                                                                                       \
     do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);       /* the clock read stays where the mark is written */                \
         if (threadIdx.x == 0) {                                                                                      \
             if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) arr[kid][0][slot] = wall_clock64();             \
             if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1)             \
                 arr[kid][1][slot] = wall_clock64();                                                                  \
         }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
     } while (0)
 #define NAF_TL_READER(fn, arr)                                                                                        \
     int fn(int kid, long long* out) {                                                                                 \
@@ -73,6 +75,57 @@ __device__ __forceinline__ static naf_f32x2 naf_buf_f2(__amdgpu_buffer_rsrc_t r,
 __device__ __forceinline__ static naf_f32x4 naf_buf_f4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off) {
     return __builtin_bit_cast(naf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, wave_off, 0));
 }
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Cross-lane sums without the LDS crossbar. hipcc lowers __shfl_xor / __shfl to ds_bpermute_b32 (an LDS-pipe round trip,
+// ~100 cycles each, and these kernels are chains of short dependent phases); DPP modifiers ride on the add itself, and
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves in the VALU.
+//   naf_xor1/2/8_add : v + v[lane ^ m], exact partners (quad_perm, row_ror:8)
+//   naf_xor16/32_add : v + v[lane ^ 16 / 32] (permlane swaps)
+//   naf_sum8 / 16 / 64: all-reduce over aligned groups of 8 / 16 / 64 lanes, every lane gets the sum. Levels 4 and 8 use
+//     row_half_mirror / row_mirror: after the quad levels every lane of a quad holds the quad's sum, so the mirrored
+//     partner holds exactly what the xor partner would — bitwise the xor-tree result in the order 1, 2, 4, 8, 16, 32.
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+template <int CTRL>
+__device__ __forceinline__ static float naf_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ static float naf_xor1_add(float v) { return v + naf_dpp<0xB1>(v); }     // quad_perm [1,0,3,2]
+__device__ __forceinline__ static float naf_xor2_add(float v) { return v + naf_dpp<0x4E>(v); }     // quad_perm [2,3,0,1]
+__device__ __forceinline__ static float naf_xor8_add(float v) { return v + naf_dpp<0x128>(v); }    // row_ror:8
+// (the swap instructions exchange rows BETWEEN their two operand registers and return both. Given ONE value for both
+//  operands, hipcc 7.2 treats the two results as equal and adds the first to itself — the sum came out as 2 v
+//  (benchmarks/probe/lane_ops_probe.hip caught it; the ISA showed v_add_f32 v, v6, v6). The empty asm statements make the
+//  second operand and the two results values of their own.)
+__device__ __forceinline__ static float naf_xor16_add(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    unsigned u2 = u;
+    asm volatile("" : "+v"(u2));
+    const auto p = __builtin_amdgcn_permlane16_swap(u, u2, false, false);  // (rows 0,0,2,2) and (rows 1,1,3,3)
+    unsigned a = p[0], b = p[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ static float naf_xor32_add(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    unsigned u2 = u;
+    asm volatile("" : "+v"(u2));
+    const auto p = __builtin_amdgcn_permlane32_swap(u, u2, false, false);  // (low half twice) and (high half twice)
+    unsigned a = p[0], b = p[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ static float naf_sum8(float v) {
+    v = naf_xor2_add(naf_xor1_add(v));
+    return v + naf_dpp<0x141>(v);                           // row_half_mirror
+}
+__device__ __forceinline__ static float naf_sum16(float v) {
+    v = naf_sum8(v);
+    return v + naf_dpp<0x140>(v);                           // row_mirror
+}
+__device__ __forceinline__ static float naf_sum64(float v) { return naf_xor32_add(naf_xor16_add(naf_sum16(v))); }
 #endif
 
 __host__ __device__ static inline int naf_round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -223,10 +223,8 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
             s_dy += dy;
             s_dx += dy * xh;
         }
-        s_dy += __shfl_xor(s_dy, 16);                        // the tile's other row groups of the same column
-        s_dy += __shfl_xor(s_dy, 32);
-        s_dx += __shfl_xor(s_dx, 16);
-        s_dx += __shfl_xor(s_dx, 32);
+        s_dy = naf_xor32_add(naf_xor16_add(s_dy));           // the tile's other row groups of the same column
+        s_dx = naf_xor32_add(naf_xor16_add(s_dx));
         if (g == 0) sRed[wm * 32 + wn * 16 + r] = make_float2(s_dy, s_dx);
     }
     __syncthreads();
@@ -374,8 +372,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     if (D.epi.x) gemm_l1bwd_epilogue(D, bm, bn, acc, !kh, wm, wn, r, g, sA, sB, tid, epi_regs);
     NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 4);
     if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 tiles)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        sq = naf_sum64(sq);
         if (!kh && lane == 0) sQ[tile] = sq;                  // sQ is touched nowhere else: no barrier in front
         __syncthreads();
         if (tid == 0) D.sumsq[bm * D.tiles_n + bn] = sQ[0] + sQ[1] + sQ[2] + sQ[3];

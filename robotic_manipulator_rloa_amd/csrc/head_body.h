@@ -12,10 +12,7 @@
 #define LT_STRIDE 9          // 8x8 L tile padded to 9 columns: column reads hit distinct banks
 
 __device__ static inline float group8_sum(float x) {
-    x += __shfl_xor(x, 1);
-    x += __shfl_xor(x, 2);
-    x += __shfl_xor(x, 4);
-    return x;
+    return naf_sum8(x);                                  // (DPP: common.h; bitwise the xor tree 1, 2, 4)
 }
 
 // sh_in : HEAD_SPB heads rows (stride ldh) already in LDS and visible (caller synchronised)
@@ -153,9 +150,7 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     if (MODE == 2) {
         // workgroup sum of squared TD errors, fixed order -> bitwise reproducible
         float x = sq_err;
-        x += __shfl_xor(x, 8);
-        x += __shfl_xor(x, 16);
-        x += __shfl_xor(x, 32);
+        x = naf_xor32_add(naf_xor16_add(naf_xor8_add(x)));
         if ((tid & 63) == 0) sh_red[tid >> 6] = x;
     }
     __syncthreads();

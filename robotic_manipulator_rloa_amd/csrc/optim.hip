@@ -36,8 +36,7 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_norm_partials_kernel(const f
 #pragma unroll
     for (int k = 0; k < NAF_NORM_CHUNK / (OPT_THREADS * 4); ++k)
         acc += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = naf_sum64(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -123,8 +122,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restr
         for (int j = 0; j < NAF_MAX_NORM_PARTIALS / 64; ++j) s += ((int)threadIdx.x + 64 * j < n_partials) ? pr[j] : 0.f;
         // more partials than were prefetched (flat buffers beyond 1M parameters): the rest in the same lane-major order
         for (int k = (int)threadIdx.x + NAF_MAX_NORM_PARTIALS; k < n_partials; k += 64) s += partials[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = naf_sum64(s);
         if (threadIdx.x == 0) {
             // a sum of squares is never negative: -inf is what xgmi_allreduce_kernel leaves when a peer's contribution
             // did not arrive in time (csrc/xgmi_reduce.hip) — the update is then skipped on this rank, whole

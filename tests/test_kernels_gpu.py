@@ -808,3 +808,23 @@ def test_bn_relu_fwd_heads_partial_and_splitk_head(lib, B, A, H, mode):
         g.data_ptr(), B * H, H, bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H, rm.data_ptr(), rv.data_ptr(), H,
         out.data_ptr(), B * HP, HP, sm.data_ptr(), si.data_ptr(), Wh.data_ptr(), NHP * HP, HP, 40, A + T, hp_flat.data_ptr(),
         slab_stride, vp.data_ptr(), B, H, 0.1, 1e-5, st()) == -1
+
+
+@pytest.mark.gpu
+def test_lane_ops_against_their_definition(tmp_path):
+    """csrc/common.h's cross-lane helpers (DPP adds, v_permlane16/32_swap sums) lane by lane on exact integers: the probe
+    that caught hipcc folding the two results of a swap into one (every reduction built on them would be wrong)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not on this box")
+    exe = str(tmp_path / "lane_ops")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "benchmarks", "probe", "lane_ops_probe.hip")
+    inc = os.path.join(root, "robotic_manipulator_rloa_amd", "csrc")
+    for opt in ("-O2", "-O3"):                  # the library is built -O3
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", opt, "-w", "-I", inc, src, "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.count(" ok ") == 8, r.stdout
