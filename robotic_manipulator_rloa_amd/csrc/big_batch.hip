@@ -98,6 +98,26 @@ __device__ static inline float2 bb_fold_sums(const float2* __restrict__ p, int H
     return make_float2(a, b);
 }
 
+// plain sums per size class, buffer loads (see bb_fold_stats_u): p's byte wave_off + lane_off = block 0 of the thread's column
+template <int NMAX>
+__device__ __forceinline__ static float2 bb_fold_sums_n(__amdgpu_buffer_rsrc_t p, unsigned lane_off, unsigned wave_off, int H, int NB) {
+    naf_f32x2 v[NMAX];
+#pragma unroll
+    for (int rb = 0; rb < NMAX; ++rb) v[rb] = naf_buf_f2(p, lane_off, wave_off + (unsigned)(rb < NB ? rb : 0) * (unsigned)H * 8u);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < NMAX; ++rb) {
+        a += rb < NB ? v[rb].x : 0.f;
+        b += rb < NB ? v[rb].y : 0.f;
+    }
+    return make_float2(a, b);
+}
+__device__ __forceinline__ static float2 bb_fold_sums_u(__amdgpu_buffer_rsrc_t p, unsigned lane_off, unsigned wave_off, int H, int NB) {
+    if (NB <= 8) return bb_fold_sums_n<8>(p, lane_off, wave_off, H, NB);                      // (uniform branches)
+    if (NB <= 16) return bb_fold_sums_n<16>(p, lane_off, wave_off, H, NB);
+    return bb_fold_sums_n<BB_MAX_NB>(p, lane_off, wave_off, H, NB);
+}
+
 __device__ static inline float bb_fold_sum1(const float* __restrict__ p, int64_t stride, int NB) {
     float v[BB_MAX_NB];
 #pragma unroll
@@ -500,18 +520,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
 #define BL_BN 32
 #define BL_KC 128                // k per staged chunk: (64 + 32) x 132 x 4 B = 50 KB of LDS, three workgroups per CU
 #define BL_LD (BL_KC + 4)
-__device__ __forceinline__ static void bl_load_chunk(f32x4 (&va)[8], f32x4 (&vb)[4], const float* __restrict__ an, int lda,
-                                                    const float* __restrict__ wn_, int K, int k0, int tid) {
+// chunk loads through buffer loads (common.h): row (tid >> 5) + 8 i, float4 (tid & 31) — lane offsets la / lw computed once
+__device__ __forceinline__ static void bl_load_chunk_buf(f32x4 (&va)[8], f32x4 (&vb)[4], __amdgpu_buffer_rsrc_t ab, unsigned la, int lda,
+                                                        __amdgpu_buffer_rsrc_t wb, unsigned lw, int K, int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int e = tid + BB_THREADS * i;
-        va[i] = ((const f32x4*)(an + (int64_t)(e >> 5) * lda + k0))[e & 31];
-    }
+    for (int i = 0; i < 8; ++i) va[i] = naf_buf_f4(ab, la, (unsigned)(8 * i * lda + k0) * 4u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + BB_THREADS * i;
-        vb[i] = ((const f32x4*)(wn_ + (int64_t)(e >> 5) * K + k0))[e & 31];
-    }
+    for (int i = 0; i < 4; ++i) vb[i] = naf_buf_f4(wb, lw, (unsigned)(8 * i * K + k0) * 4u);
 }
 __device__ __forceinline__ static void bl_mfma_chunk(const float* __restrict__ pa0, const float* __restrict__ pa1,
                                             const float* __restrict__ pb, f32x4& c00, f32x4& c01, f32x4& c10, f32x4& c11) {
@@ -572,10 +587,13 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     // (all 24 loads up front made the register allocator park 12 of them in scratch)
     f32x4 va1[8], vb1[4];
     NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 0);
-    bl_load_chunk(va, vb, an, lda, wn_, K, 0, tid);
+    const __amdgpu_buffer_rsrc_t ab = naf_buf(an), wb = naf_buf(wn_);
+    const unsigned la = ((unsigned)(tid >> 5) * (unsigned)lda + 4u * (unsigned)(tid & 31)) * 4u;
+    const unsigned lw = ((unsigned)(tid >> 5) * (unsigned)K + 4u * (unsigned)(tid & 31)) * 4u;
+    bl_load_chunk_buf(va, vb, ab, la, lda, wb, lw, K, 0);
     bl_store_chunk(va, vb, sA, sB, tid);
     __builtin_amdgcn_sched_barrier(0);                    // keep chunk 1's loads behind chunk 0's stores
-    bl_load_chunk(va1, vb1, an, lda, wn_, K, BL_KC, tid);
+    bl_load_chunk_buf(va1, vb1, ab, la, lda, wb, lw, K, BL_KC);
     __syncthreads();
     NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 1);
     bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
@@ -618,6 +636,108 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     __syncthreads();
     if (wm == 0 && g == 0)
         partials[((int64_t)net * NB + rb) * N + n0 + 16 * wn + r] = make_float2(S, red[0][16 * wn + r] + red[1][16 * wn + r]);
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 5);
+}
+
+// The same GEMM with 64 x 16 tiles for small batches (B <= 512): the 64 x 32 grid is 2 B / 64 x 8 = 64 workgroups at B = 256 and
+// each spends 2 x 1.2 us in its two MFMA phases — a quarter of the chip busy, latency all the way. Half as wide, twice as
+// many workgroups (wave w = rows 16 w .. +15, one MFMA tile): the MFMA phases halve. The statistics blocks stay 64 rows, so
+// the partials and every consumer are unchanged.
+__global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const float* __restrict__ a, int64_t a_net_stride, int lda,
+                                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                                       int64_t param_net_stride, float* __restrict__ z,
+                                                                       int64_t z_net_stride, int ldz, float2* __restrict__ partials,
+                                                                       int B, int N, int K) {
+    constexpr int BN = 16;
+    __shared__ __attribute__((aligned(16))) float sA[BL_BM * BL_LD];
+    __shared__ __attribute__((aligned(16))) float sB[BN * BL_LD];
+    __shared__ float red[4][BN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NB = B / BB_ROWS;
+    const int net = blockIdx.x / NB, rb = blockIdx.x - net * NB;
+    const int n0 = blockIdx.y * BN;
+    const int r = lane & 15, g = lane >> 4;
+    // operands through buffer loads (common.h): A rows (tid >> 5) + 8 i, float4 (tid & 31); B rows (tid >> 5) + 8 i < 16
+    const __amdgpu_buffer_rsrc_t ab = naf_buf(a + net * a_net_stride + (int64_t)rb * BL_BM * lda);
+    const __amdgpu_buffer_rsrc_t wb = naf_buf(W + net * param_net_stride + (int64_t)n0 * K);
+    const unsigned la = ((unsigned)(tid >> 5) * (unsigned)lda + 4u * (unsigned)(tid & 31)) * 4u;
+    const unsigned lw = ((unsigned)(tid >> 5) * (unsigned)K + 4u * (unsigned)(tid & 31)) * 4u;
+    const float bcol = bias[net * param_net_stride + n0 + r];
+    f32x4 va[8], vb[2], va1[8], vb1[2];
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) va[i] = naf_buf_f4(ab, la, (unsigned)(8 * i * lda) * 4u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vb[i] = naf_buf_f4(wb, lw, (unsigned)(8 * i * K) * 4u);
+    float* sa_t = sA + (tid >> 5) * BL_LD + 4 * (tid & 31);
+    float* sb_t = sB + (tid >> 5) * BL_LD + 4 * (tid & 31);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(f32x4*)(sa_t + 8 * i * BL_LD) = va[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(f32x4*)(sb_t + 8 * i * BL_LD) = vb[i];
+    __builtin_amdgcn_sched_barrier(0);                    // keep chunk 1's loads behind chunk 0's stores
+#pragma unroll
+    for (int i = 0; i < 8; ++i) va1[i] = naf_buf_f4(ab, la, (unsigned)(8 * i * lda + BL_KC) * 4u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vb1[i] = naf_buf_f4(wb, lw, (unsigned)(8 * i * K + BL_KC) * 4u);
+    __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 1);
+    const float* pa = sA + (16 * wave + r) * BL_LD + 4 * g;
+    const float* pb = sB + r * BL_LD + 4 * g;
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    auto mfma_chunk = [&]() {
+#pragma unroll 4
+        for (int kk = 0; kk < BL_KC; kk += 16) {
+            const f32x4 av = *(const f32x4*)(pa + kk), bv = *(const f32x4*)(pb + kk);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], c1, 0, 0, 0);
+        }
+    };
+    mfma_chunk();
+    __syncthreads();                                      // first chunk fully consumed
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(f32x4*)(sa_t + 8 * i * BL_LD) = va1[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(f32x4*)(sb_t + 8 * i * BL_LD) = vb1[i];
+    __syncthreads();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 3);
+    mfma_chunk();
+    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 4);
+    // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg. Z2 out, then the column statistics of the 64-row block: 4 rows in
+    // the lane, 4 lane groups, 4 waves through LDS
+    float v[4];
+    float sum = 0.f;
+    {
+        const unsigned ldz4 = (unsigned)ldz * 4u;
+        const __amdgpu_buffer_rsrc_t zb = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM + 16 * wave) * ldz + n0);
+        const unsigned lz = (unsigned)(4 * g) * ldz4 + 4u * (unsigned)r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (c0[e] + c1[e]) + bcol;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), zb, lz, (unsigned)e * ldz4, 0);
+            sum += v[e];
+        }
+    }
+    sum = naf_xor32_add(naf_xor16_add(sum));
+    if (g == 0) red[wave][r] = sum;
+    __syncthreads();
+    const float S = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+    const float mb = S * (1.0f / BB_ROWS);
+    float m2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = v[e] - mb;
+        m2 += t * t;
+    }
+    m2 = naf_xor32_add(naf_xor16_add(m2));
+    __syncthreads();
+    if (g == 0) red[wave][r] = m2;
+    __syncthreads();
+    if (tid < BN) partials[((int64_t)net * NB + rb) * N + n0 + tid] = make_float2(S, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
     NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 5);
 }
 
@@ -1019,7 +1139,12 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     float* __restrict__ loss_partials, float* __restrict__ dy_out, int ldd, float2* __restrict__ partials_bw, int B, int A,
     float momentum, float eps) {
     constexpr int NHP = 4 * NH4, H = FK_H;
+    // A2 = ReLU(gamma xhat + beta) as a tile of its own when the LDS budget allows (not with the 18 KB L tiles of the matmul
+    // mode): the heads GEMM then reads ONE operand row per macro-step instead of xhat + gamma + beta and forms nothing on the
+    // VALU inside its MFMA loop — that loop was bound by LDS reads (4 x 16 B per lane per step, 8 waves), 1.7 us for 0.4 us of MFMA
+    constexpr bool A2T = PMODE != NAF_P_MATMUL;
     __shared__ __attribute__((aligned(16))) float sXH[FK_ROWS * FK_LD];
+    __shared__ __attribute__((aligned(16))) float sA2[A2T ? FK_ROWS * FK_LD : 4];
     __shared__ __attribute__((aligned(16))) float sW[NHP * FK_LD];
     __shared__ __attribute__((aligned(16))) float sHd[(FK_THREADS / 8) * NHP];      // heads rows (32 live)
     __shared__ __attribute__((aligned(16))) float sDH[(FK_THREADS / 8) * NHP];      // d_heads rows
@@ -1124,6 +1249,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = fmaxf(__builtin_fmaf(xh[c], g0[c], b0[c]), 0.f);
             *(f32x4*)(sXH + row * FK_LD + 4 * lane) = xh;
+            if (A2T) *(f32x4*)(sA2 + row * FK_LD + 4 * lane) = y;
             *(f32x4*)(a2_out + (s0 + row) * ldo + 4 * lane) = y;
             const f32x4 xt = (zt[i] - m1) * i1;
             float q = 0.f;
@@ -1150,15 +1276,18 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     for (int t = wave; t < 2 * NT; t += 8) {
         const int tile = t % NT, kh = t / NT;
         const int mt = tile & 1, nt = tile >> 1;
-        const float* pa = sXH + (16 * mt + rr) * FK_LD + 4 * gg;
+        const float* pa = (A2T ? sA2 : sXH) + (16 * mt + rr) * FK_LD + 4 * gg;
         const float* pb = sW + (16 * nt + rr) * FK_LD + 4 * gg;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int kk = kh * (H / 2); kk < (kh + 1) * (H / 2); kk += 16) {
             const f32x4 xh = *(const f32x4*)(pa + kk), b = *(const f32x4*)(pb + kk);
-            const f32x4 g = *(const f32x4*)&sStat[0][2][kk + 4 * gg], be = *(const f32x4*)&sStat[0][3][kk + 4 * gg];
-            const float a0 = fmaxf(__builtin_fmaf(xh.x, g.x, be.x), 0.f), a1 = fmaxf(__builtin_fmaf(xh.y, g.y, be.y), 0.f);
-            const float a2 = fmaxf(__builtin_fmaf(xh.z, g.z, be.z), 0.f), a3 = fmaxf(__builtin_fmaf(xh.w, g.w, be.w), 0.f);
+            float a0 = xh.x, a1 = xh.y, a2 = xh.z, a3 = xh.w;
+            if (!A2T) {
+                const f32x4 g = *(const f32x4*)&sStat[0][2][kk + 4 * gg], be = *(const f32x4*)&sStat[0][3][kk + 4 * gg];
+                a0 = fmaxf(__builtin_fmaf(xh.x, g.x, be.x), 0.f), a1 = fmaxf(__builtin_fmaf(xh.y, g.y, be.y), 0.f);
+                a2 = fmaxf(__builtin_fmaf(xh.z, g.z, be.z), 0.f), a3 = fmaxf(__builtin_fmaf(xh.w, g.w, be.w), 0.f);
+            }
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b.z, acc0, 0, 0, 0);
@@ -1183,11 +1312,14 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     if (tid < FK_ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
     // ---- phase 4: dA2 = d_heads Wh (K = NHP), 2 x 16 tiles, 4 per wave; ReLU mask, dY2, block sums --------------------
     {
-        const int mt = wave & 1;
+        const int mt = wave_s & 1;
         const float* pa = sDH + (16 * mt + rr) * NHP + 4 * gg;
+        const unsigned ldd4 = (unsigned)ldd * 4u;
+        const __amdgpu_buffer_rsrc_t dyb = naf_buf(dy_out + s0 * ldd);
+        const unsigned ldy = (unsigned)(4 * gg) * ldd4 + 4u * (unsigned)rr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int nt = (wave >> 1) + 4 * j;
+            const int nt = (wave_s >> 1) + 4 * j;
             const int col = 16 * nt + rr;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1206,7 +1338,8 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
                 const int row = 16 * mt + 4 * gg + e;
                 const float xh = sXH[row * FK_LD + col];
                 const float dy = __builtin_fmaf(xh, g, be) > 0.f ? acc[e] : 0.f;      // the forward's own ReLU decision
-                dy_out[(s0 + row) * ldd + col] = dy;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dy), dyb, ldy,
+                                                      (unsigned)(16 * mt + e) * ldd4 + (unsigned)(16 * nt) * 4u, 0);
                 s_dy += dy;
                 s_dx += dy * xh;
             }
@@ -1314,6 +1447,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
                                                                       float* __restrict__ dz_col_partials, int B, int H) {
     __shared__ float sT[BB_ROWS][BB_COLS + 1];
     __shared__ float sC[5][BB_COLS];          // mean, invstd, k1, sum_dy / B, sum_dyxh / B
+    __shared__ float2 sF[4][BB_COLS];
     const int tid = threadIdx.x;
     const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS;
     const int row = tid >> 2, cq = tid & 3;
@@ -1325,14 +1459,30 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
         zv[i] = *(const float4*)(z + grow * ldz + col0 + 16 * cq + 4 * i);
         dv[i] = *(const float4*)(dy + grow * ldd + col0 + 16 * cq + 4 * i);
     }
+    // npb <= 64 partial blocks (B/64 from bb_heads_bwd_stage1, B/32 from bb_layer2_head), dealt to the four waves in contiguous
+    // runs of Q <= 16: every wave folds its run for all 64 columns (one round of loads), the runs meet in LDS in wave order.
+    // (One wave walking 64 blocks in two rounds while three waited: 3.1 of this kernel's 4.0 us at B = 2048.)
+    const bool wide = npb > 16;          // (uniform) B <= 512: one wave folds its <= 16 blocks directly, no barrier in between
+    if (wide) {
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6), Q = (npb + 3) >> 2;
+        const int nb_w = npb - w * Q < Q ? npb - w * Q : Q;                 // blocks of this wave's run (may be <= 0)
+        const float2 part = bb_fold_sums_n<16>(naf_buf(partials + col0), 8u * (unsigned)(tid & 63),
+                                               (unsigned)(nb_w > 0 ? w * Q : 0) * (unsigned)H * 8u, H, nb_w > 0 ? nb_w : 0);
+        sF[w][tid & 63] = part;
+        __syncthreads();
+    }
     if (tid < BB_COLS) {
         const int col = col0 + tid;
-        // npb partial blocks: B/64 from bb_heads_bwd_stage1, B/32 from bb_layer2_head (then folded in two rounds of 32)
-        float2 sums = bb_fold_sums(partials, H, npb < BB_MAX_NB ? npb : BB_MAX_NB, col);
-        if (npb > BB_MAX_NB) {
-            const float2 more = bb_fold_sums(partials + (int64_t)BB_MAX_NB * H, H, npb - BB_MAX_NB, col);
-            sums.x += more.x;
-            sums.y += more.y;
+        float2 sums;
+        if (wide) {
+            sums = sF[0][tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                sums.x += sF[w][tid].x;
+                sums.y += sF[w][tid].y;
+            }
+        } else {
+            sums = bb_fold_sums_u(naf_buf(partials + col0), 8u * (unsigned)tid, 0, H, npb);
         }
         const float sdy = sums.x, sdx = sums.y;
         const float invstd = save_invstd[col];
@@ -1633,6 +1783,13 @@ extern "C" int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda
     if ((((uintptr_t)a | (uintptr_t)W) & 15) != 0 || (a_net_stride & 3) != 0 || (param_net_stride & 3) != 0 ||
         ((uintptr_t)partials & 7) != 0)
         return NAF_ERR_ARG;
+    if (B <= 512) {                  // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
+        dim3 grid16(nets * (B / BB_ROWS), N / 16);
+        bb_linear_stats16_kernel<<<grid16, BB_THREADS, 0, (hipStream_t)stream>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,
+                                                                                 z_net_stride, ldz, (float2*)partials, B, N, K);
+        NAF_CHECK_LAUNCH();
+        return NAF_OK;
+    }
     dim3 grid(nets * (B / BB_ROWS), N / BL_BN);
     bb_linear_stats_kernel<<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,
                                                                          z_net_stride, ldz, (float2*)partials, B, N, K);

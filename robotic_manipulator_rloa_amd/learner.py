@@ -177,9 +177,9 @@ class Learner:
         #        per 32 batch rows (csrc/big_batch.hip: bb_layer2_head_kernel) instead of three launches
         #   ep = (with bb + gb) the batch pass of layer 1's backward as the EPILOGUE of the bundle's dA1 blocks (dA1 never
         #        leaves the registers of the block that computed it) instead of a launch of its own
-        # (the column-tile chain up to B = 256 — 25.5k updates/s against 24.9k for the row-split one; from B = 512 on the row-split
-        #  chain: 23.2k against 20.3k)
-        spec = os.environ.get("NAF_FUSE", "l1,b2,gb,s3" if self.B < 512 else ("bb,gb,hk,ep" if self.bb_ok else ("l1,b2,gb,s3" if self.B <= 512 else "gb"))).lower()
+        # (measured, updates/s, column-tile chain | row-split chain: B = 64: 32.5k | 29.3k, 128: 30.8k | 28.9k, 256: 25.7k | 26.9k,
+        #  512: 20.3k | 25.1k — the row-split chain is the default from B = 256)
+        spec = os.environ.get("NAF_FUSE", "bb,gb,hk,ep" if (self.B >= 256 and self.bb_ok) else ("l1,b2,gb,s3" if self.B <= 512 else "gb")).lower()
         #   l12 = (with bb; opt-in, NOT default) layer 1 inside GEMM 2's launch: every GEMM-2 workgroup forms its A panel from
         #        the rows itself. Parity-tested; measured 17.0 us against 13.7 us for the two launches it replaces at B = 1024
         #        (every workgroup repeats the moments statistics of its 128-feature chunks) — DESIGN.md section 4b

@@ -363,17 +363,22 @@ def test_host_vector_env_training_end_to_end(scratch_cwd, async_policy):
         vec.close()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world):
+@pytest.mark.parametrize("world,fuse", [(2, "l1,b2,gb,s3"), (4, None)])
+def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse):
     """csrc/xgmi_reduce.hip with W > 1 on the one GPU available: W processes on cuda:0 (tests/xgmi_worker.py) map each
     other's receive slabs through hipIpc and run the one-shot all-reduce eagerly, inside a captured graph and under
-    Learner.learn_rows — results bit-exact against the rank-ordered sum, replicas in lock-step, no timed-out wait."""
+    Learner.learn_rows — results bit-exact against the rank-ordered sum, replicas in lock-step, no timed-out wait.
+    Two ranks on the column-tile chain (part of the gradient pushed ahead from inside its last kernel), four on the default
+    chain of B = 256 (the row-split one: the vector travels whole)."""
     import socket
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = str(sock.getsockname()[1])
     env = dict(os.environ, NAF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                OMP_NUM_THREADS="2")
+    env.pop("NAF_FUSE", None)
+    if fuse:
+        env["NAF_FUSE"] = fuse
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "xgmi_worker.py")],
                        env=env, capture_output=True, text=True, timeout=900)

@@ -36,7 +36,7 @@ def current_sd(L, net):
 @pytest.mark.parametrize("tag", G3_TAGS)
 def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     """NAF_FUSE selects which small GEMMs are folded into the BN / head kernels (csrc/fused_layers.hip; "all" includes
-    the MFMA heads GEMM; "bb" = the large-batch chain of csrc/big_batch.hip, the default from B = 512): every
+    the MFMA heads GEMM; "bb" = the large-batch chain of csrc/big_batch.hip, the default from B = 256): every
     combination must match the reference."""
     if fused == "default":
         monkeypatch.delenv("NAF_FUSE", raising=False)
@@ -48,7 +48,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
     L = make_learner(S, A, B, main0, target0)
     if fused == "default":
-        assert L.fuse == ({"bb", "gb", "hk", "ep"} if B >= 512 and B % 64 == 0 else {"l1", "b2", "gb", "s3"})
+        assert L.fuse == ({"bb", "gb", "hk", "ep"} if B >= 256 and B % 64 == 0 else {"l1", "b2", "gb", "s3"})
     if "bb" in fused:
         assert "bb" in L.fuse and not L.fuse & {"l1", "b2", "s3", "f3"}
     rows = rows_device(L, st, ac, rw, ns, dn)

@@ -136,7 +136,8 @@ def main():
             real = L.xgmi.all_reduce
 
             def spy(grad_in, grad_out, partials=None, step_dev=None, pushed_lo=None):
-                assert pushed_lo == L.lay.seg["W2"].offset      # everything but layer 1 went ahead, from inside B1
+                # column-tile chain: everything but layer 1 went ahead, from inside B1; the row-split chain sends the vector whole
+                assert pushed_lo == (L.lay.seg["W2"].offset if "l1" in L.fuse else None), (pushed_lo, L.fuse)
                 before = grad_in.clone()
                 real(grad_in, grad_out, partials, step_dev, pushed_lo=pushed_lo)
                 seen.append((before, grad_out.clone(), partials[:L.xgmi.n_partials].clone()))
