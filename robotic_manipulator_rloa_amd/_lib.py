@@ -177,6 +177,7 @@ _PROTOS = {
                                      _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
     "naf_bb_heads_bwd_stage1": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
     "naf_bb_bn_bwd_stage2": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "naf_bb_layer2_head_rows": [_i],
     "naf_bb_layer2_head": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp,
                            _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "naf_bb_layer1_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],

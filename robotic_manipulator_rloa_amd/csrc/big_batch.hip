@@ -1124,11 +1124,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_relu_heads_partial_kernel(
 // Replaces bb_bn_relu_heads_partial + naf_head_kernel + bb_heads_bwd_stage1 (three launches, 19.9 us at B = 1024).
 // The backward partials are per 32-row block here: partials_bw[B/32][H].
 // ------------------------------------------------------------------------------------------------------------
-#define FK_ROWS 32
+#define FK_ROWS 32               // rows per workgroup; 16 for small batches (ROWS below)
 #define FK_THREADS 512
 #define FK_H 256
 #define FK_LD (FK_H + 4)
-template <int PMODE, int NH4>
+// ROWS = 16 (B <= 512): twice the workgroups, each phase of this latency chain roughly half as long (rows per wave in the
+// normalise phase, MFMA tiles per wave in the two products); the backward partials are then per 16-row block.
+template <int PMODE, int NH4, int ROWS>
 __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const float* __restrict__ z, int64_t z_net_stride, int ldz, const float* __restrict__ gamma,
     const float* __restrict__ beta, int64_t param_net_stride, const float2* __restrict__ partials, int NB64,
@@ -1139,12 +1141,16 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     float* __restrict__ loss_partials, float* __restrict__ dy_out, int ldd, float2* __restrict__ partials_bw, int B, int A,
     float momentum, float eps) {
     constexpr int NHP = 4 * NH4, H = FK_H;
+    constexpr int MT = ROWS / 16;                          // 16-row MFMA tiles
+    constexpr int RPW = ROWS / 8;                          // rows per wave where a wave owns whole rows
+    constexpr int KS = ROWS == 16 ? 4 : 2;                 // K split of the heads GEMM (keeps the 8 waves busy)
+    static_assert(ROWS == 16 || ROWS == 32, "rows per workgroup");
     // A2 = ReLU(gamma xhat + beta) as a tile of its own when the LDS budget allows (not with the 18 KB L tiles of the matmul
     // mode): the heads GEMM then reads ONE operand row per macro-step instead of xhat + gamma + beta and forms nothing on the
     // VALU inside its MFMA loop — that loop was bound by LDS reads (4 x 16 B per lane per step, 8 waves), 1.7 us for 0.4 us of MFMA
     constexpr bool A2T = PMODE != NAF_P_MATMUL;
-    __shared__ __attribute__((aligned(16))) float sXH[FK_ROWS * FK_LD];
-    __shared__ __attribute__((aligned(16))) float sA2[A2T ? FK_ROWS * FK_LD : 4];
+    __shared__ __attribute__((aligned(16))) float sXH[ROWS * FK_LD];
+    __shared__ __attribute__((aligned(16))) float sA2[A2T ? ROWS * FK_LD : 4];
     __shared__ __attribute__((aligned(16))) float sW[NHP * FK_LD];
     __shared__ __attribute__((aligned(16))) float sHd[(FK_THREADS / 8) * NHP];      // heads rows (32 live)
     __shared__ __attribute__((aligned(16))) float sDH[(FK_THREADS / 8) * NHP];      // d_heads rows
@@ -1154,10 +1160,10 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     __shared__ float sV[FK_THREADS / 8];
     __shared__ float sL[PMODE == NAF_P_MATMUL ? (FK_THREADS / 8) * 8 * LT_STRIDE : 1];
     __shared__ float sRed[FK_THREADS / 64];
-    __shared__ float2 sP[2][H];
+    __shared__ float2 sP[MT][H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = blockIdx.x;
-    const int64_t s0 = (int64_t)rb * FK_ROWS;
+    const int64_t s0 = (int64_t)rb * ROWS;
     const int T = A * (A + 1) / 2, v_col = A + T;
     // every kernel argument this prologue needs, fetched NOW: left to itself the compiler fetches an argument where it is
     // first used, behind the branches of this prologue — six dependent scalar round trips in front of the loads proper
@@ -1172,11 +1178,11 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     // prologue cost ~460 vector instructions per wave, two waves per SIMD: 2 us of issue before the first byte arrived)
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const unsigned l16 = 16u * (unsigned)lane, l8 = 8u * (unsigned)lane, l4 = 4u * (unsigned)lane;
-    f32x4 zm[4], zt[4];
+    f32x4 zm[RPW], zt[RPW];
     {
         const __amdgpu_buffer_rsrc_t zb = naf_buf(z + (s0 + wave_s) * ldz), ztb = naf_buf(z + z_net_stride + (s0 + wave_s) * ldz);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                     // one wave per row: 64 lanes x 4 columns; rows wave + 8 i
+        for (int i = 0; i < RPW; ++i) {                   // one wave per row: 64 lanes x 4 columns; rows wave + 8 i
             zm[i] = naf_buf_f4(zb, l16, (unsigned)(8 * i * ldz) * 4u);
             zt[i] = naf_buf_f4(ztb, l16, (unsigned)(8 * i * ldz) * 4u);
         }
@@ -1192,7 +1198,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     f32x4 wv_r = {0.f, 0.f, 0.f, 0.f};
     if (tid < H / 4) wv_r = *(const f32x4*)(Wh + wh_net_stride + (int64_t)v_col * ldw + 4 * tid);
     const int s_loc_ = tid >> 3, i_ = tid & 7;
-    const bool live_ = s_loc_ < FK_ROWS;
+    const bool live_ = s_loc_ < ROWS;
     const float u_val = (live_ && i_ < A) ? u[(s0 + s_loc_) * ldu + i_] : 0.f;
     const float r_val = (live_ && i_ == 0) ? r[(s0 + s_loc_) * ldr] : 0.f;
     {
@@ -1240,9 +1246,9 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         const f32x4 m1 = *(const f32x4*)&sStat[1][0][4 * lane], i1 = *(const f32x4*)&sStat[1][1][4 * lane];
         const f32x4 g1 = *(const f32x4*)&sStat[1][2][4 * lane], b1 = *(const f32x4*)&sStat[1][3][4 * lane];
         const f32x4 wv = *(const f32x4*)(sWv + 4 * lane);
-        float p[4];
+        float p[RPW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RPW; ++i) {
             const int row = wave + 8 * i;
             const f32x4 xh = (zm[i] - m0) * i0;
             f32x4 y;
@@ -1259,28 +1265,28 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         }
         // the four rows' wave reductions (DPP + permlane swaps: common.h)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p[i] = naf_sum64(p[i]);
+        for (int i = 0; i < RPW; ++i) p[i] = naf_sum64(p[i]);
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sV[wave + 8 * i] = p[i] + sBias[NHP];
+            for (int i = 0; i < RPW; ++i) sV[wave + 8 * i] = p[i] + sBias[NHP];
         }
     }
     __syncthreads();
     NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 2);
-    // ---- phase 2: heads = A2 Wh^T + bias: 2 x NHP/16 MFMA tiles, each cut into two K halves, over the 8 waves (with whole
-    // tiles half of the waves idled through the longest MFMA chain of the kernel: 2.2 of its 10.8 us). The halves meet in
-    // LDS, lower half first -------------------------------------------------------------------------------------------
+    // ---- phase 2: heads = A2 Wh^T + bias: MT x NHP/16 MFMA tiles, each cut into KS ranges of K, over the 8 waves (with whole
+    // tiles half of the waves idled through the longest MFMA chain of the kernel: 2.2 of its 10.8 us). The ranges meet in
+    // LDS, in K order -------------------------------------------------------------------------------------------------
     const int rr = lane & 15, gg = lane >> 4;
-    constexpr int NT = 2 * (NHP / 16);                     // tiles: 2, 4 or 6
-    float* sHalf = sDH;                                    // upper-half partial tiles (sDH is zeroed again below)
-    for (int t = wave; t < 2 * NT; t += 8) {
+    constexpr int NT = MT * (NHP / 16);                    // tiles
+    float* sHalf = sDH;                                    // partial tiles of K ranges 1 .. KS - 1 (sDH is zeroed again below)
+    for (int t = wave; t < KS * NT; t += 8) {
         const int tile = t % NT, kh = t / NT;
-        const int mt = tile & 1, nt = tile >> 1;
+        const int mt = tile % MT, nt = tile / MT;
         const float* pa = (A2T ? sA2 : sXH) + (16 * mt + rr) * FK_LD + 4 * gg;
         const float* pb = sW + (16 * nt + rr) * FK_LD + 4 * gg;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int kk = kh * (H / 2); kk < (kh + 1) * (H / 2); kk += 16) {
+        for (int kk = kh * (H / KS); kk < (kh + 1) * (H / KS); kk += 16) {
             const f32x4 xh = *(const f32x4*)(pa + kk), b = *(const f32x4*)(pb + kk);
             float a0 = xh.x, a1 = xh.y, a2 = xh.z, a3 = xh.w;
             if (!A2T) {
@@ -1293,33 +1299,38 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b.z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b.w, acc1, 0, 0, 0);
         }
-        float* dst = kh ? sHalf : sHd;
+        float* dst = kh ? sHalf + (kh - 1) * ROWS * NHP : sHd;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[(16 * mt + 4 * gg + e) * NHP + 16 * nt + rr] = acc0[e] + acc1[e];
     }
     __syncthreads();
     NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 3);
-    for (int e = tid; e < FK_ROWS * NHP; e += FK_THREADS) {
-        sHd[e] = (sHd[e] + sHalf[e]) + sBias[e % NHP];
-        sHalf[e] = 0.f;
+    for (int e = tid; e < ROWS * NHP; e += FK_THREADS) {
+        float hsum = sHd[e];
+#pragma unroll
+        for (int h = 0; h < KS - 1; ++h) {
+            hsum += sHalf[h * ROWS * NHP + e];
+            sHalf[h * ROWS * NHP + e] = 0.f;
+        }
+        sHd[e] = hsum + sBias[e % NHP];
     }
     __syncthreads();
     NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 4);
     // ---- phase 3: the NAF head on the 32 rows (threads 0..255 carry samples; every thread joins the barriers) --------
     naf_head_body<PMODE, 2, FK_THREADS>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td, q_out,
-                                        nullptr, loss_partials, B, A, s0, FK_ROWS);
+                                        nullptr, loss_partials, B, A, s0, ROWS);
     NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 5);
-    if (tid < FK_ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
-    // ---- phase 4: dA2 = d_heads Wh (K = NHP), 2 x 16 tiles, 4 per wave; ReLU mask, dY2, block sums --------------------
+    if (tid < ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
+    // ---- phase 4: dA2 = d_heads Wh (K = NHP), MT x 16 tiles, 2 MT per wave; ReLU mask, dY2, block sums ------------------
     {
-        const int mt = wave_s & 1;
+        const int mt = wave_s % MT;
         const float* pa = sDH + (16 * mt + rr) * NHP + 4 * gg;
         const unsigned ldd4 = (unsigned)ldd * 4u;
         const __amdgpu_buffer_rsrc_t dyb = naf_buf(dy_out + s0 * ldd);
         const unsigned ldy = (unsigned)(4 * gg) * ldd4 + 4u * (unsigned)rr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nt = (wave_s >> 1) + 4 * j;
+        for (int j = 0; j < 2 * MT; ++j) {
+            const int nt = wave_s / MT + (8 / MT) * j;
             const int col = 16 * nt + rr;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1350,7 +1361,14 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     }
     __syncthreads();
     NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 6);
-    if (tid < H) partials_bw[(int64_t)rb * H + tid] = make_float2(sP[0][tid].x + sP[1][tid].x, sP[0][tid].y + sP[1][tid].y);
+    if (tid < H) {
+        float2 t = sP[0][tid];
+        if (MT == 2) {
+            t.x += sP[MT - 1][tid].x;
+            t.y += sP[MT - 1][tid].y;
+        }
+        partials_bw[(int64_t)rb * H + tid] = t;
+    }
     NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 7);
 }
 
@@ -1462,7 +1480,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __r
     // npb <= 64 partial blocks (B/64 from bb_heads_bwd_stage1, B/32 from bb_layer2_head), dealt to the four waves in contiguous
     // runs of Q <= 16: every wave folds its run for all 64 columns (one round of loads), the runs meet in LDS in wave order.
     // (One wave walking 64 blocks in two rounds while three waited: 3.1 of this kernel's 4.0 us at B = 2048.)
-    const bool wide = npb > 16;          // (uniform) B <= 512: one wave folds its <= 16 blocks directly, no barrier in between
+    const bool wide = npb > 8;           // (uniform) up to 8 blocks one wave folds them directly, no barrier in between
     if (wide) {
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), Q = (npb + 3) >> 2;
         const int nb_w = npb - w * Q < Q ? npb - w * Q : Q;                 // blocks of this wave's run (may be <= 0)
@@ -1858,6 +1876,9 @@ extern "C" int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride
     return NAF_OK;
 }
 
+// rows per workgroup = rows per block of partials_bw (the consumer, naf_bb_bn_bwd_stage2, is told B / rows blocks)
+extern "C" int naf_bb_layer2_head_rows(int B) { return B <= 512 ? 16 : FK_ROWS; }
+
 extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
                                   int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
                                   int64_t stat_net_stride, float* a2_out, int ldo, float* save_mean, float* save_invstd,
@@ -1875,12 +1896,18 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
         (wh_net_stride & 3) || ((uintptr_t)partials & 7) || ((uintptr_t)partials_bw & 7))
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = B / FK_ROWS;
-#define BB_FK(PM, NH4V)                                                                                                  \
-    bb_layer2_head_kernel<PM, NH4V><<<blocks, FK_THREADS, 0, st>>>(                                                      \
+    const int rows = naf_bb_layer2_head_rows(B);
+    const int blocks = B / rows;
+#define BB_FK_R(PM, NH4V, RW)                                                                                            \
+    bb_layer2_head_kernel<PM, NH4V, RW><<<blocks, FK_THREADS, 0, st>>>(                                                  \
         z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, B / BB_ROWS, running_mean, running_var, \
         stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
         loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps)
+#define BB_FK(PM, NH4V)                   \
+    do {                                  \
+        if (rows == 16) BB_FK_R(PM, NH4V, 16); \
+        else BB_FK_R(PM, NH4V, 32);       \
+    } while (0)
 #define BB_FK_NH(PM)                     \
     do {                                 \
         if (NHP == 16) BB_FK(PM, 4);     \
@@ -1891,6 +1918,7 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     else BB_FK_NH(NAF_P_MATMUL);
 #undef BB_FK_NH
 #undef BB_FK
+#undef BB_FK_R
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -269,7 +269,8 @@ class Learner:
             self.bb_mom = torch.zeros(2, self.mom_floats, **f32)
             self.bb_wc = torch.zeros(H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # w_c C of the main net, forward -> finish
             self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)
-            self.bb_bw2 = torch.zeros(2 * NB, H, 2, **f32)      # backward partials of layer 2: (sum dy, sum dy*xhat); per 64-row
+            self.hk_rows = self.lib.naf_bb_layer2_head_rows(B)    # rows per block of the fused launch's backward partials
+            self.bb_bw2 = torch.zeros(max(2 * NB, B // self.hk_rows), H, 2, **f32)      # backward partials of layer 2: (sum dy, sum dy*xhat); per 64-row
             #                                                     block, or per 32-row block from the fused layer-2 + head launch
             self.bb_dzp = torch.zeros(NB, H, **f32)             # block sums of dZ2 (-> gradient of the layer-2 bias)
             self.bb_bw1 = torch.zeros(2 * NB, H, 2, **f32)      # backward partials of layer 1 (per 64-row block, or per 32-row
@@ -513,7 +514,7 @@ class Learner:
                                                 ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, st), "bb_heads_bwd_stage1")
             check(f.naf_bb_bn_bwd_stage2(ptr(self.dZ2), H, ptr(self.G2[0]), H, t2p + 4 * seg["g2"].offset,
                                          ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.bb_bw2),
-                                         B // 32 if "hk" in self.fuse else B // 64,
+                                         B // self.hk_rows if "hk" in self.fuse else B // 64,
                                          gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, ptr(self.bb_dzp), B, H, st),
                   "bb_bn_bwd_stage2")
         elif "b2" in self.fuse:
