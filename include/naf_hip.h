@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 12
+#define NAF_HIP_ABI_VERSION 13
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -306,7 +306,8 @@ int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const floa
  * sum dy, sum dy*xhat) and the block shares p_slabs[B/64][H][KP] of P (KP = naf_bb_layer1_bwd_kp(K)).
  * finish: folds them in block order -> d_W[H][K], d_gamma, d_beta, d_bias = 0 (sum_r dz vanishes identically; the reference's
  * value is rounding noise that the train-mode BatchNorm cancels), d_bias2 (layer 2, from naf_bb_bn_bwd_stage2's
- * dz_col_partials). K <= 32. mom: the MAIN net's moments record (Sx); wc: [H][KP], row c = w_c C, left by the forward pass
+ * dz_col_partials; nb = 0: d_bias2 = 0, the value that sum is identically — for the chain whose stage 2 runs inside the
+ * bundle, naf_gemm_bn2bwd_t). K <= 32. mom: the MAIN net's moments record (Sx); wc: [H][KP], row c = w_c C, left by the forward pass
  * (naf_bb_layer1 / naf_bb_layer12, wc_out). sumsq_partials (nullable): sums of squares of everything written here plus
  * d_gamma2 / d_beta2 (then required: read, not written), one entry per workgroup: naf_bb_layer1_bwd_finish_blocks(H) finish
  * blocks, then the slab segments' (below); step_dev (nullable): *step_dev += 1. */
@@ -353,6 +354,23 @@ typedef struct naf_gemm_l1bwd {
     float* p_slabs;
     int ldx, K, kp, lda1;
 } naf_gemm_l1bwd_t;
+/* optional prologue on the A operand of a product: A = dY2 (the ReLU-masked gradient w.r.t. layer 2's BatchNorm output, written by
+ * naf_bb_layer2_head) is turned into dZ2 = k1 (dy - c1 - xhat c2) WHILE the panel is staged — the second stage of layer 2's
+ * BatchNorm backward (naf_bb_bn_bwd_stage2) without its launch and without dZ2 in memory. Every block folds the block sums of the
+ * columns its A panel touches (all H for a k-contiguous A = dA1's product, its own 32 for a k-major A = dW2's), the k-major blocks
+ * of the first block column also write d_gamma / d_beta. The bias gradient of the Linear in front (sum_r dz) is identically zero
+ * under a train-mode BatchNorm and is not produced: pass nb = 0 to naf_bb_layer1_bwd_finish, which then writes d_bias2 = 0.
+ * Restrictions: H = 256, K / k_split = 256, M and N multiples of 32, npb <= 16 (B = 256 with 16-row blocks, 512 with 32-row ones). */
+typedef struct naf_gemm_bn2bwd {
+    const float* z;          /* Z2, same shape and leading dimension as A */
+    const float* partials;   /* float2 [npb][H]: (sum dy, sum dy*xhat) per row block (naf_bb_layer2_head's partials_bw) */
+    const float* gamma;      /* [H] */
+    const float* save_mean;
+    const float* save_invstd;
+    float* d_gamma;          /* [H] out */
+    float* d_beta;
+    int npb, B, H;
+} naf_gemm_bn2bwd_t;
 typedef struct naf_gemm_desc {
     const float* A;
     const float* B;
@@ -363,6 +381,7 @@ typedef struct naf_gemm_desc {
     int64_t c_split_stride; /* writing its partial product to C + s * c_split_stride floats (sumsq must be NULL); the consumer adds
                                the slabs in index order (naf_bb_layer1_bwd_finish) */
     const naf_gemm_l1bwd_t* epi; /* nullable (HOST pointer, copied into the launch) */
+    const naf_gemm_bn2bwd_t* pro; /* nullable (HOST pointer, copied into the launch) */
 } naf_gemm_desc_t;
 int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
 /* the same contract on 64 x 64 output blocks staged in 128-k chunks (csrc/gemm_bundle64.hip): for the large-batch chain, where

@@ -229,7 +229,14 @@ class GemmDesc(C.Structure):
     """naf_gemm_desc_t (include/naf_hip.h)"""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("sumsq", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
-                ("k_split", C.c_int), ("c_split_stride", C.c_int64), ("epi", C.c_void_p)]
+                ("k_split", C.c_int), ("c_split_stride", C.c_int64), ("epi", C.c_void_p), ("pro", C.c_void_p)]
+
+
+class GemmBn2Bwd(C.Structure):
+    """naf_gemm_bn2bwd_t (include/naf_hip.h)"""
+    _fields_ = [("z", C.c_void_p), ("partials", C.c_void_p), ("gamma", C.c_void_p), ("save_mean", C.c_void_p),
+                ("save_invstd", C.c_void_p), ("d_gamma", C.c_void_p), ("d_beta", C.c_void_p), ("npb", C.c_int), ("B", C.c_int),
+                ("H", C.c_int)]
 
 
 class GemmL1Bwd(C.Structure):

@@ -1994,7 +1994,7 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
                                         const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
                                         int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, void* stream) {
     if (!p_slabs || !partials1 || !dz2_col_partials || !mom || !wc || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
-        !d_bias || !d_bias2 || nb <= 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
+        !d_bias || !d_bias2 || nb < 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
         return NAF_ERR_ARG;
     if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
     if (n_segs < 0 || n_segs > 2 || (n_segs && !segs)) return NAF_ERR_ARG;

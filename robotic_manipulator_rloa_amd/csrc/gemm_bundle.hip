@@ -20,6 +20,7 @@ struct GemmDesc {
     int k_split, tiles_mn;        // K cut into k_split ranges, one grid of tiles_mn blocks each, slab s at C + s * c_split_stride
     int64_t c_split_stride;
     naf_gemm_l1bwd_t epi;         // epi.x != NULL: the layer-1 backward pass on the block's C tile (see gemm_l1bwd_epilogue)
+    naf_gemm_bn2bwd_t pro;        // pro.z != NULL: A = dY2 becomes dZ2 while it is staged (see gemm_bn2bwd_constants)
 };
 struct GemmBundle {
     GemmDesc d[NAF_GEMM_BUNDLE_MAX];
@@ -254,6 +255,74 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
     }
 }
 
+// Prologue of the products that read dZ2 (include/naf_hip.h, naf_gemm_bn2bwd_t): the second stage of layer 2's BatchNorm
+// backward folded into the staging of their A panel, so that stage's launch (2.8 us + a 1.3 us boundary at B = 256) and the
+// dZ2 round trip through memory disappear. The per-column constants go to `cst` (4 x 256 floats: the K-halves buffer, free
+// until the MFMAs are over):  dz = k1 dy - k1 c1 - (z - mean) (invstd k1 c2),  k1 = gamma invstd, c1 = sum dy / B, c2 = sum dy xhat / B
+//   cst[0][c] = mean, [1] = k1, [2] = k1 c1, [3] = invstd k1 c2
+// The npb <= 16 block sums are dealt over the whole workgroup: thread = (column pair, part); a part takes a contiguous run of
+// blocks as 16-byte loads (two columns' float2 at once) — four loads per thread for a k-contiguous A (256 columns, 4 parts), one
+// for a k-major A (32 columns, 32 parts) — and the parts meet in `scratch` (the A panel's LDS, not yet written) in part order.
+// (Every thread walking all 16 blocks of one column cost 2.2 us per dA1 block.) Ends with the constants written; the caller
+// puts the barrier behind it.
+template <bool AK>
+__device__ static inline void gemm_bn2bwd_constants(const GemmDesc& D, int m0, int bn, int ks, int tid, float* cst, float* scratch) {
+    const naf_gemm_bn2bwd_t& P = D.pro;
+    constexpr int NCOL = AK ? 32 : 256, NPAIR = NCOL / 2, PARTS = GB_THREADS / NPAIR, QMAX = AK ? 1 : 4;
+    static_assert(PARTS * QMAX >= 16, "npb <= 16");
+    const int col0 = AK ? m0 : 0;
+    const int pair = tid % NPAIR, part = tid / NPAIR;
+    const int npb = P.npb, Q = (npb + PARTS - 1) / PARTS, rb0 = part * Q;
+    const __amdgpu_buffer_rsrc_t pb = naf_buf(P.partials + 2 * col0);
+    f32x4 v[QMAX];
+#pragma unroll
+    for (int i = 0; i < QMAX; ++i) {
+        const int rb = rb0 + i;
+        v[i] = naf_buf_f4(pb, 16u * (unsigned)pair, (unsigned)((i < Q && rb < npb) ? rb : 0) * (unsigned)P.H * 8u);
+    }
+    const int c = tid & (NCOL - 1);
+    const float gm = P.gamma[col0 + c], mean = P.save_mean[col0 + c], invstd = P.save_invstd[col0 + c];
+    f32x4 sm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < QMAX; ++i)
+        if (i < Q && rb0 + i < npb) sm += v[i];
+    ((f32x4*)scratch)[part * NPAIR + pair] = sm;            // [part][column] float2
+    __syncthreads();
+    if (tid < NCOL) {
+        const float2* sp = (const float2*)scratch;
+        float sdy = 0.f, sdx = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) {
+            sdy += sp[q * NCOL + c].x;                        // (parts past the last block hold zeros)
+            sdx += sp[q * NCOL + c].y;
+        }
+        const float k1 = gm * invstd, invB = 1.0f / (float)P.B;
+        cst[c] = mean;
+        cst[256 + c] = k1;
+        cst[512 + c] = k1 * (sdy * invB);
+        cst[768 + c] = invstd * (k1 * (sdx * invB));
+        if (AK && bn == 0 && ks == 0) {                             // d_gamma = sum dy*xhat, d_beta = sum dy
+            P.d_gamma[col0 + c] = sdx;
+            P.d_beta[col0 + c] = sdy;
+        }
+    }
+}
+// dy -> dz on a staged A panel (whole chunks only). The thread's float4 i covers four consecutive COLUMNS of the operand:
+//   k-contiguous A: row wave + 8 i, columns k0 + 4 lane .. +3;  k-major A: k = (tid >> 3) + 64 i, columns 4 (tid & 7) .. +3 of the block
+template <bool AK>
+__device__ __forceinline__ static void gemm_bn2bwd_apply(float4 (&va)[GB_PT], const float4 (&vz)[GB_PT], const float* cst, int tid, int k0) {
+    const int ci = AK ? 4 * (tid & 7) : k0 + 4 * (tid & 63);
+    const f32x4 mean = *(const f32x4*)(cst + ci), k1 = *(const f32x4*)(cst + 256 + ci), kc1 = *(const f32x4*)(cst + 512 + ci),
+                q = *(const f32x4*)(cst + 768 + ci);
+#pragma unroll
+    for (int i = 0; i < GB_PT; ++i) {
+        va[i].x = __builtin_fmaf(k1[0], va[i].x, -kc1[0]) - (vz[i].x - mean[0]) * q[0];
+        va[i].y = __builtin_fmaf(k1[1], va[i].y, -kc1[1]) - (vz[i].y - mean[1]) * q[1];
+        va[i].z = __builtin_fmaf(k1[2], va[i].z, -kc1[2]) - (vz[i].z - mean[2]) * q[2];
+        va[i].w = __builtin_fmaf(k1[3], va[i].w, -kc1[3]) - (vz[i].w - mean[3]) * q[3];
+    }
+}
+
 NAF_TL_DECL(g_tl_gb);
 NAF_TL_READER(naf_tl_read_gb, g_tl_gb)
 // every workgroup's entry / exit (is the grid resident at once? in which order do the blocks of the three GEMMs drain?)
@@ -299,20 +368,28 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, !kh, wm, wn, r, g, epi_regs);
     const int kper = D.K / D.k_split, k_lo = ks * kper, k_hi = k_lo + kper;
     const PanelSrc pa = panel_src<AK>(D.A, D.lda, m0, D.M, D.K, tid), pb = panel_src<BK>(D.B, D.ldb, n0, D.N, D.K, tid);
-    float4 va[GB_PT], vb[GB_PT];
+    const bool pro = D.pro.z != nullptr;                  // (uniform; the host admits it with whole 256-k chunks only)
+    const PanelSrc pz = panel_src<AK>(pro ? D.pro.z : D.A, D.lda, m0, D.M, D.K, tid);
+    float4 va[GB_PT], vb[GB_PT], vz[GB_PT];
     {
         const int kc0 = kper < GB_KC ? kper : GB_KC;
         if (kc0 == GB_KC) {
             load_panel_buf<AK>(va, pa, m0, k_lo, wave);
+            if (pro) load_panel_buf<AK>(vz, pz, m0, k_lo, wave);
             load_panel_buf<BK>(vb, pb, n0, k_lo, wave);
         } else {
             load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k_lo, kc0, tid);
             load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
         }
     }
+    if (pro) {                                            // the column constants, under the panel loads' latency
+        gemm_bn2bwd_constants<AK>(D, m0, bn, ks, tid, sC, sA);
+        __syncthreads();
+    }
     for (int k0 = k_lo; k0 < k_hi; k0 += GB_KC) {
         const int kc = (k_hi - k0) < GB_KC ? (k_hi - k0) : GB_KC;
         if (k0 != k_lo) __syncthreads();                  // previous chunk fully consumed
+        if (pro) gemm_bn2bwd_apply<AK>(va, vz, sC, tid, k0);
         if (kc == GB_KC) {
             store_panel<AK, true>(sA, va, kc, tid);
             store_panel<BK, true>(sB, vb, kc, tid);
@@ -325,6 +402,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
             const int kn = (k_hi - k1) < GB_KC ? (k_hi - k1) : GB_KC;
             if (kn == GB_KC) {
                 load_panel_buf<AK>(va, pa, m0, k1, wave);
+                if (pro) load_panel_buf<AK>(vz, pz, m0, k1, wave);
                 load_panel_buf<BK>(vb, pb, n0, k1, wave);
             } else {
                 load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k1, kn, tid);
@@ -439,6 +517,15 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         d.tiles_mn = ((s.M + 31) / 32) * d.tiles_n;
         d.k_split = ksn;
         d.c_split_stride = s.c_split_stride;
+        memset(&d.pro, 0, sizeof(d.pro));
+        if (s.pro) {
+            const naf_gemm_bn2bwd_t& q = *s.pro;
+            if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 ||
+                q.npb > 16 || q.B <= 0 || q.H != 256 || (s.K / ksn) != GB_KC || (s.M & 31) || (s.N & 31) ||
+                (s.a_kmajor ? s.M != q.H : s.K != q.H) || ((uintptr_t)q.z & 15) || ((uintptr_t)q.partials & 7))
+                return NAF_ERR_ARG;      // (the A operand's columns are the H features: its M when k-major, its K otherwise)
+            d.pro = q;
+        }
         memset(&d.epi, 0, sizeof(d.epi));
         if (s.epi) {
             const naf_gemm_l1bwd_t& e = *s.epi;

@@ -179,20 +179,26 @@ class Learner:
         #        leaves the registers of the block that computed it) instead of a launch of its own
         # (measured, updates/s, column-tile chain | row-split chain: B = 64: 32.5k | 29.3k, 128: 30.8k | 28.9k, 256: 25.7k | 26.9k,
         #  512: 20.3k | 25.1k — the row-split chain is the default from B = 256)
-        spec = os.environ.get("NAF_FUSE", "bb,gb,hk,ep" if (self.B >= 256 and self.bb_ok) else ("l1,b2,gb,s3" if self.B <= 512 else "gb")).lower()
+        #   s2 = (with bb + gb + hk) the second stage of layer 2's BatchNorm backward inside the bundle: dY2 becomes dZ2 while the
+        #        products that read it stage their operand (csrc/gemm_bundle.hip, naf_gemm_bn2bwd_t) — one launch less; needs
+        #        whole 256-k chunks and at most 16 row blocks of backward partials: B = 256
+        spec = os.environ.get("NAF_FUSE", ("bb,gb,hk,ep,s2" if self.B == 256 else "bb,gb,hk,ep") if (self.B >= 256 and self.bb_ok)
+                              else ("l1,b2,gb,s3" if self.B <= 512 else "gb")).lower()
         #   l12 = (with bb; opt-in, NOT default) layer 1 inside GEMM 2's launch: every GEMM-2 workgroup forms its A panel from
         #        the rows itself. Parity-tested; measured 17.0 us against 13.7 us for the two launches it replaces at B = 1024
         #        (every workgroup repeats the moments statistics of its 128-feature chunks) — DESIGN.md section 4b
-        names = {"l1", "b2", "f3", "gb", "s3", "bb", "hk", "ep", "l12"}
-        self.fuse = (set(names) - {"bb", "hk", "ep", "l12"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
+        names = {"l1", "b2", "f3", "gb", "s3", "bb", "hk", "ep", "l12", "s2"}
+        self.fuse = (set(names) - {"bb", "hk", "ep", "l12", "s2"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
         if "bb" in self.fuse:
-            self.fuse = ({"bb"} | (self.fuse & {"gb", "hk", "ep", "l12"})) if self.bb_ok else (self.fuse - {"bb"})
+            self.fuse = ({"bb"} | (self.fuse & {"gb", "hk", "ep", "l12", "s2"})) if self.bb_ok else (self.fuse - {"bb"})
         else:
-            self.fuse -= {"l12"}
+            self.fuse -= {"l12", "s2"}
         if "bb" not in self.fuse or lay0.H != 256:
             self.fuse -= {"hk"}
         if not {"bb", "gb"} <= self.fuse or self.B % 32:
             self.fuse -= {"ep"}
+        if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or self.B // self.lib.naf_bb_layer2_head_rows(self.B) > 16:
+            self.fuse -= {"s2"}
         if self.lay.S > 32:
             self.fuse -= {"l1"}
         if self.B % 16 != 0 or self.lay.H % 16 != 0:
@@ -331,10 +337,17 @@ class Learner:
                                            0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H)     # x / ldx: set per minibatch
             # dA1 FIRST: its blocks carry the layer-1 epilogue and run longest; dispatched first, the short weight-gradient
             # blocks fill in behind them instead of the other way round
+            self._pro = None
+            if "s2" in self.fuse:        # dY2 -> dZ2 while the two products that read it stage their A panels
+                t2p_, seg_, gp_ = self.theta2.data_ptr(), lay.seg, self.grad.data_ptr()
+                self._pro = _lib.GemmBn2Bwd(ptr(self.G2[0]), ptr(self.bb_bw2), t2p_ + 4 * seg_["g2"].offset, ptr(self.save_mean[1, 0]),
+                                            ptr(self.save_invstd[1, 0]), gp_ + 4 * seg_["g2"].offset, gp_ + 4 * seg_["be2"].offset,
+                                            B // self.hk_rows, B, H)
+            pro_ = _lib.C.addressof(self._pro) if self._pro is not None else None
             self._bundle = (D * 3)(
                 D(ptr(self.dZ2), ptr(self.W2_main), None if self._epi is not None else ptr(self.dA1), None, B, H, H, H, H, H, 0, 1,
-                  1, 0, _lib.C.addressof(self._epi) if self._epi is not None else None),
-                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks_w2, H * H),
+                  1, 0, _lib.C.addressof(self._epi) if self._epi is not None else None, pro_),
+                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks_w2, H * H, None, pro_),
                 D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks_wh, NHP * HP))
             SS = _lib.SlabSeg
             self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks_w2),
@@ -512,11 +525,12 @@ class Learner:
                 check(f.naf_bb_heads_bwd_stage1(ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H,
                                                 ptr(self.A2[0]), HP, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]),
                                                 ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, st), "bb_heads_bwd_stage1")
-            check(f.naf_bb_bn_bwd_stage2(ptr(self.dZ2), H, ptr(self.G2[0]), H, t2p + 4 * seg["g2"].offset,
-                                         ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.bb_bw2),
-                                         B // self.hk_rows if "hk" in self.fuse else B // 64,
-                                         gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, ptr(self.bb_dzp), B, H, st),
-                  "bb_bn_bwd_stage2")
+            if "s2" not in self.fuse:     # (with s2 the bundle's blocks turn dY2 into dZ2 while they stage it)
+                check(f.naf_bb_bn_bwd_stage2(ptr(self.dZ2), H, ptr(self.G2[0]), H, t2p + 4 * seg["g2"].offset,
+                                             ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.bb_bw2),
+                                             B // self.hk_rows if "hk" in self.fuse else B // 64,
+                                             gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, ptr(self.bb_dzp), B, H, st),
+                      "bb_bn_bwd_stage2")
         elif "b2" in self.fuse:
             # dA2 = dH @ Wh (K = NHP) folded into the ReLU/BN backward of layer 2
             check(f.naf_heads_bwd_bn_relu_bwd(
@@ -553,7 +567,8 @@ class Learner:
                     "bb_layer1_bwd")
             check(f.naf_bb_layer1_bwd_finish(
                 ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1),
-                B // 32 if ("ep" in self.fuse and not getattr(self, "_bundle64", False)) else B // 64, ptr(self.bb_dzp), B // 64,
+                B // 32 if ("ep" in self.fuse and not getattr(self, "_bundle64", False)) else B // 64, ptr(self.bb_dzp),
+                0 if "s2" in self.fuse else B // 64,      # (s2: the layer-2 bias gradient is written as the 0 it identically is)
                 ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
                 gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,

@@ -32,7 +32,7 @@ def current_sd(L, net):
     return sd
 
 
-@pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "s3", "l1,b2,gb,s3", "all", "bb,gb", "bb", "bb,gb,hk", "bb,gb,ep", "bb,l12", "default"])
+@pytest.mark.parametrize("fused", ["none", "l1,b2", "gb", "l1,b2,gb", "s3", "l1,b2,gb,s3", "all", "bb,gb", "bb", "bb,gb,hk", "bb,gb,ep", "bb,l12", "bb,gb,hk,ep,s2", "default"])
 @pytest.mark.parametrize("tag", G3_TAGS)
 def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     """NAF_FUSE selects which small GEMMs are folded into the BN / head kernels (csrc/fused_layers.hip; "all" includes
@@ -48,7 +48,8 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
     L = make_learner(S, A, B, main0, target0)
     if fused == "default":
-        assert L.fuse == ({"bb", "gb", "hk", "ep"} if B >= 256 and B % 64 == 0 else {"l1", "b2", "gb", "s3"})
+        assert L.fuse == (({"bb", "gb", "hk", "ep", "s2"} if B == 256 else {"bb", "gb", "hk", "ep"}) if B >= 256 and B % 64 == 0
+                          else {"l1", "b2", "gb", "s3"})
     if "bb" in fused:
         assert "bb" in L.fuse and not L.fuse & {"l1", "b2", "s3", "f3"}
     rows = rows_device(L, st, ac, rw, ns, dn)
