@@ -360,7 +360,7 @@ typedef struct naf_gemm_l1bwd {
  * columns its A panel touches (all H for a k-contiguous A = dA1's product, its own 32 for a k-major A = dW2's), the k-major blocks
  * of the first block column also write d_gamma / d_beta. The bias gradient of the Linear in front (sum_r dz) is identically zero
  * under a train-mode BatchNorm and is not produced: pass nb = 0 to naf_bb_layer1_bwd_finish, which then writes d_bias2 = 0.
- * Restrictions: H = 256, K / k_split = 256, M and N multiples of 32, npb <= 16 (B = 256 with 16-row blocks, 512 with 32-row ones). */
+ * Restrictions: H = 256, K / k_split = 256, M and N multiples of 32, npb <= 32 (B = 256 / 512 with 16-row blocks). */
 typedef struct naf_gemm_bn2bwd {
     const float* z;          /* Z2, same shape and leading dimension as A */
     const float* partials;   /* float2 [npb][H]: (sum dy, sum dy*xhat) per row block (naf_bb_layer2_head's partials_bw) */

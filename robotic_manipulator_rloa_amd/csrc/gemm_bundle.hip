@@ -260,16 +260,16 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
 // dZ2 round trip through memory disappear. The per-column constants go to `cst` (4 x 256 floats: the K-halves buffer, free
 // until the MFMAs are over):  dz = k1 dy - k1 c1 - (z - mean) (invstd k1 c2),  k1 = gamma invstd, c1 = sum dy / B, c2 = sum dy xhat / B
 //   cst[0][c] = mean, [1] = k1, [2] = k1 c1, [3] = invstd k1 c2
-// The npb <= 16 block sums are dealt over the whole workgroup: thread = (column pair, part); a part takes a contiguous run of
-// blocks as 16-byte loads (two columns' float2 at once) — four loads per thread for a k-contiguous A (256 columns, 4 parts), one
+// The npb <= 32 block sums are dealt over the whole workgroup: thread = (column pair, part); a part takes a contiguous run of
+// blocks as 16-byte loads (two columns' float2 at once) — up to eight loads per thread for a k-contiguous A (256 columns, 4 parts), one
 // for a k-major A (32 columns, 32 parts) — and the parts meet in `scratch` (the A panel's LDS, not yet written) in part order.
 // (Every thread walking all 16 blocks of one column cost 2.2 us per dA1 block.) Ends with the constants written; the caller
 // puts the barrier behind it.
 template <bool AK>
 __device__ static inline void gemm_bn2bwd_constants(const GemmDesc& D, int m0, int bn, int ks, int tid, float* cst, float* scratch) {
     const naf_gemm_bn2bwd_t& P = D.pro;
-    constexpr int NCOL = AK ? 32 : 256, NPAIR = NCOL / 2, PARTS = GB_THREADS / NPAIR, QMAX = AK ? 1 : 4;
-    static_assert(PARTS * QMAX >= 16, "npb <= 16");
+    constexpr int NCOL = AK ? 32 : 256, NPAIR = NCOL / 2, PARTS = GB_THREADS / NPAIR, QMAX = AK ? 1 : 8;
+    static_assert(PARTS * QMAX >= 32, "npb <= 32");
     const int col0 = AK ? m0 : 0;
     const int pair = tid % NPAIR, part = tid / NPAIR;
     const int npb = P.npb, Q = (npb + PARTS - 1) / PARTS, rb0 = part * Q;
@@ -521,7 +521,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (s.pro) {
             const naf_gemm_bn2bwd_t& q = *s.pro;
             if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 ||
-                q.npb > 16 || q.B <= 0 || q.H != 256 || (s.K / ksn) != GB_KC || (s.M & 31) || (s.N & 31) ||
+                q.npb > 32 || q.B <= 0 || q.H != 256 || (s.K / ksn) != GB_KC || (s.M & 31) || (s.N & 31) ||
                 (s.a_kmajor ? s.M != q.H : s.K != q.H) || ((uintptr_t)q.z & 15) || ((uintptr_t)q.partials & 7))
                 return NAF_ERR_ARG;      // (the A operand's columns are the H features: its M when k-major, its K otherwise)
             d.pro = q;

@@ -181,8 +181,8 @@ class Learner:
         #  512: 20.3k | 25.1k — the row-split chain is the default from B = 256)
         #   s2 = (with bb + gb + hk) the second stage of layer 2's BatchNorm backward inside the bundle: dY2 becomes dZ2 while the
         #        products that read it stage their operand (csrc/gemm_bundle.hip, naf_gemm_bn2bwd_t) — one launch less; needs
-        #        whole 256-k chunks and at most 16 row blocks of backward partials: B = 256
-        spec = os.environ.get("NAF_FUSE", ("bb,gb,hk,ep,s2" if self.B == 256 else "bb,gb,hk,ep") if (self.B >= 256 and self.bb_ok)
+        #        whole 256-k chunks and at most 32 row blocks of backward partials: B = 256, 512
+        spec = os.environ.get("NAF_FUSE", ("bb,gb,hk,ep,s2" if self.B in (256, 512) else "bb,gb,hk,ep") if (self.B >= 256 and self.bb_ok)
                               else ("l1,b2,gb,s3" if self.B <= 512 else "gb")).lower()
         #   l12 = (with bb; opt-in, NOT default) layer 1 inside GEMM 2's launch: every GEMM-2 workgroup forms its A panel from
         #        the rows itself. Parity-tested; measured 17.0 us against 13.7 us for the two launches it replaces at B = 1024
@@ -197,7 +197,7 @@ class Learner:
             self.fuse -= {"hk"}
         if not {"bb", "gb"} <= self.fuse or self.B % 32:
             self.fuse -= {"ep"}
-        if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or self.B // self.lib.naf_bb_layer2_head_rows(self.B) > 16:
+        if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or self.B // self.lib.naf_bb_layer2_head_rows(self.B) > 32:
             self.fuse -= {"s2"}
         if self.lay.S > 32:
             self.fuse -= {"l1"}

@@ -48,7 +48,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
     L = make_learner(S, A, B, main0, target0)
     if fused == "default":
-        assert L.fuse == (({"bb", "gb", "hk", "ep", "s2"} if B == 256 else {"bb", "gb", "hk", "ep"}) if B >= 256 and B % 64 == 0
+        assert L.fuse == (({"bb", "gb", "hk", "ep", "s2"} if B in (256, 512) else {"bb", "gb", "hk", "ep"}) if B >= 256 and B % 64 == 0
                           else {"l1", "b2", "gb", "s3"})
     if "bb" in fused:
         assert "bb" in L.fuse and not L.fuse & {"l1", "b2", "s3", "f3"}
@@ -92,7 +92,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     assert (L.grad[mask] == 0).all() and (L.theta2[0][mask] == 0).all() and (L.adam_v[mask] == 0).all()
 
 
-@pytest.mark.parametrize("fused", ["none", "all", "l1,b2,gb,s3", "bb,gb", "bb,gb,hk,ep,l12"])
+@pytest.mark.parametrize("fused", ["none", "all", "l1,b2,gb,s3", "bb,gb", "bb,gb,hk,ep,l12", "bb,gb,hk,ep,s2"])
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32),
                                    (21, 6, 512), (32, 8, 512), (21, 6, 1024), (21, 6, 768)])
