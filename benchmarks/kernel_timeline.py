@@ -75,6 +75,9 @@ def main():
     print(f"B = {B}, fuse = {sorted(L.fuse)}")
     prev_end = None
     for name in KERNELS:
+        if max(raw[name][0][0], raw[name][1][0]) < t0:      # not part of this chain (e.g. stage 2 folded into the bundle: "s2")
+            print(f"{name:22s} (not launched in this chain)")
+            continue
         n = len(MARKS[name])
         rows = {}
         for w, tag in ((0, "first workgroup"), (1, "last workgroup")):
