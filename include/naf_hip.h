@@ -285,11 +285,11 @@ int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const float* Wh, int 
 int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz, const float* gamma, const float* save_mean,
                          const float* save_invstd, const float* partials, int n_partial_blocks /* B/64, or B / naf_bb_layer2_head_rows(B) after
                          naf_bb_layer2_head */, float* d_gamma, float* d_beta, float* dz_col_partials, int B, int H, void* stream);
-/* rows per workgroup of naf_bb_layer2_head at batch size B (16 up to B = 512, else 32) = rows per block of its partials_bw:
+/* rows per workgroup of naf_bb_layer2_head at batch size B (16 up to B = 1024, else 32) = rows per block of its partials_bw:
  * size partials_bw for B / rows blocks and tell naf_bb_bn_bwd_stage2 that many */
 int naf_bb_layer2_head_rows(int B);
 /* naf_bb_bn_relu_heads_partial + the NAF head (naf_head_fwd_bwd_mse: Q, y = r + gamma V'(s'), MSE, d_heads) +
- * naf_bb_heads_bwd_stage1 in ONE launch for H = 256: a workgroup owns 32 (16 up to B = 512) batch rows across all features of both nets, heads and
+ * naf_bb_heads_bwd_stage1 in ONE launch for H = 256: a workgroup owns 32 (16 up to B = 1024) batch rows across all features of both nets, heads and
  * dA2 on f32 MFMA. Outputs: a2_out (main net's A2, ldo >= H; the target's is not needed again), running statistics, save_mean /
  * save_invstd [2][H], q_out[B], d_heads[B][NHP], loss_partials[B/rows], dy_out (dY2), partials_bw[B/rows][H] (float2), rows = naf_bb_layer2_head_rows(B). u / r: the
  * action and reward columns of the minibatch rows. Replaces naf_neural_network.py:78-115 + naf_algorithm.py:199-208 and the first

@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_bn_relu_heads_partial_kernel(
 #define FK_THREADS 512
 #define FK_H 256
 #define FK_LD (FK_H + 4)
-// ROWS = 16 (B <= 512): twice the workgroups, each phase of this latency chain roughly half as long (rows per wave in the
+// ROWS = 16 (B <= 1024): twice the workgroups, each phase of this latency chain roughly half as long (rows per wave in the
 // normalise phase, MFMA tiles per wave in the two products); the backward partials are then per 16-row block.
 template <int PMODE, int NH4, int ROWS>
 __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
@@ -1877,7 +1877,7 @@ extern "C" int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride
 }
 
 // rows per workgroup = rows per block of partials_bw (the consumer, naf_bb_bn_bwd_stage2, is told B / rows blocks)
-extern "C" int naf_bb_layer2_head_rows(int B) { return B <= 512 ? 16 : FK_ROWS; }
+extern "C" int naf_bb_layer2_head_rows(int B) { return B <= 1024 ? 16 : FK_ROWS; }
 
 extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
                                   int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
