@@ -505,7 +505,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
             const float t = (z[i][j] - sStat[0][c]) * sStat[1][c] * sStat[2][c] + sStat[3][c];
             yp[j] = t > 0.f ? t : 0.f;
         }
-        *(float4*)(oz + (int64_t)(rb * BB_ROWS + 4 * ty + i) * ldo + col0 + 4 * tx) = y;
+        naf_buf_st_f4(naf_buf(oz + (int64_t)(rb * BB_ROWS) * ldo + col0), 4u * (unsigned)((4 * ty + i) * ldo + 4 * tx), 0,
+                      (f32x4){y.x, y.y, y.z, y.w}, B >= NAF_WT_MIN_B);
     }
     NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 4);
 }
@@ -607,13 +608,14 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
     float v[2][4];
     float s = 0.f;
-    float* zn = z + net * z_net_stride + (int64_t)(rb * BL_BM + 32 * wm + 4 * g) * ldz + n0 + 16 * wn + r;
+    const __amdgpu_buffer_rsrc_t zb_ = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM) * ldz + n0);
+    const unsigned lz_ = 4u * (unsigned)((32 * wm + 4 * g) * ldz + 16 * wn + r);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[mt][e] = (mt ? c10[e] + c11[e] : c00[e] + c01[e]) + bcol;
-            zn[(int64_t)(16 * mt + e) * ldz] = v[mt][e];
+            naf_buf_st_f1(zb_, lz_, (unsigned)((16 * mt + e) * ldz) * 4u, v[mt][e], B >= NAF_WT_MIN_B);
             s += v[mt][e];
         }
     // column statistics of the 64-row block: 8 rows in the lane, 4 lane groups (bits 4, 5), 2 waves (wm) through LDS
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[e] = (c0[e] + c1[e]) + bcol;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), zb, lz, (unsigned)e * ldz4, 0);
+            naf_buf_st_f1(zb, lz, (unsigned)e * ldz4, v[e], B >= NAF_WT_MIN_B);
             sum += v[e];
         }
     }
@@ -1256,7 +1258,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             for (int c = 0; c < 4; ++c) y[c] = fmaxf(__builtin_fmaf(xh[c], g0[c], b0[c]), 0.f);
             *(f32x4*)(sXH + row * FK_LD + 4 * lane) = xh;
             if (A2T) *(f32x4*)(sA2 + row * FK_LD + 4 * lane) = y;
-            *(f32x4*)(a2_out + (s0 + row) * ldo + 4 * lane) = y;
+            naf_buf_st_f4(naf_buf(a2_out + (s0 + wave_s) * ldo), l16, (unsigned)(8 * i * ldo) * 4u, y, B >= NAF_WT_MIN_B);
             const f32x4 xt = (zt[i] - m1) * i1;
             float q = 0.f;
 #pragma unroll
@@ -1349,8 +1351,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
                 const int row = 16 * mt + 4 * gg + e;
                 const float xh = sXH[row * FK_LD + col];
                 const float dy = __builtin_fmaf(xh, g, be) > 0.f ? acc[e] : 0.f;      // the forward's own ReLU decision
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dy), dyb, ldy,
-                                                      (unsigned)(16 * mt + e) * ldd4 + (unsigned)(16 * nt) * 4u, 0);
+                naf_buf_st_f1(dyb, ldy, (unsigned)(16 * mt + e) * ldd4 + (unsigned)(16 * nt) * 4u, dy, B >= NAF_WT_MIN_B);
                 s_dy += dy;
                 s_dx += dy * xh;
             }

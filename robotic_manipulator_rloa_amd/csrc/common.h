@@ -75,6 +75,22 @@ __device__ __forceinline__ static naf_f32x2 naf_buf_f2(__amdgpu_buffer_rsrc_t r,
 __device__ __forceinline__ static naf_f32x4 naf_buf_f4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off) {
     return __builtin_bit_cast(naf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, wave_off, 0));
 }
+// Stores of a kernel's bulk outputs (what the NEXT launch reads, on other XCDs), optionally sc0 sc1 = write-through to the
+// level every XCD sees: the lines are then clean when the kernel ends and the release at the kernel boundary has less to
+// write back. A/B over the whole chain (updates/s, write-through | plain): B = 256 30.0k | 30.2k, 1024 22.7k | 22.4k, 2048
+// 16.6k | 16.1k — it pays once a launch leaves megabytes dirty, so `wt` (wave-uniform) is B >= NAF_WT_MIN_B. (nt, the
+// streaming hint, changed nothing.)
+#ifndef NAF_WT_MIN_B
+#define NAF_WT_MIN_B 1024
+#endif
+__device__ __forceinline__ static void naf_buf_st_f1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off, float v, bool wt) {
+    if (wt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, lane_off, wave_off, 17);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, lane_off, wave_off, 0);
+}
+__device__ __forceinline__ static void naf_buf_st_f4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off, naf_f32x4 v, bool wt) {
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(naf_u32x4, v), r, lane_off, wave_off, 17);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(naf_u32x4, v), r, lane_off, wave_off, 0);
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -441,7 +441,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = acc[e];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), cr, voff, (unsigned)(m0 + wm * 16 + e) * ldc4, 0);
+                naf_buf_st_f1(cr, voff, (unsigned)(m0 + wm * 16 + e) * ldc4, v, (D.M > D.K ? D.M : D.K) >= NAF_WT_MIN_B);
                 sq += v * v;
             }
         }
