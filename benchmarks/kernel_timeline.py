@@ -19,13 +19,16 @@ sys.path.insert(0, ROOT)
 
 KERNELS = ["bb_layer1", "bb_linear_stats", "bb_layer2_head", "bb_bn_bwd_stage2", "gemm_bundle", "bb_layer1_bwd_finish", "adam_polyak"]
 MARKS = {
+    # (bb_layer1 with the previous update's optimizer step riding on it — every update of a chunk but the first — also leaves raw
+    # slots 7 .. 10: operands in LDS | clip scale derived | barrier | parameters evaluated, and 11 / 12: entry / exit of the first
+    # and last riding workgroup; NAF_TL_RAW=1 prints them)
     "bb_layer1": ["entry", "operands staged", "statistics from moments", "z tile", "normalise + store"],
     "bb_linear_stats": ["entry", "chunk 0 staged", "chunk 0 MFMA", "chunk 1 staged", "chunk 1 MFMA", "Z2 + statistics partials"],
     "bb_layer2_head": ["entry", "operands + statistics fold", "normalise, V'", "heads MFMA", "halves merged", "NAF head body", "dA2 MFMA + sums", "partials out"],
     "bb_bn_bwd_stage2": ["entry", "loads + fold", "dz", "column sums"],
     "gemm_bundle": ["entry", "chunk 0 staged", "K loop", "C stored", "layer-1 backward epilogue", "norm partial"],
     "bb_layer1_bwd_finish": ["entry", "loads + folds", "dW1 / slab sums", "norm partial"],
-    "adam_polyak": ["entry", "norm folded", "update"],
+    "adam_polyak": ["entry", "norm folded + update"],
 }
 
 
@@ -96,7 +99,8 @@ def main():
             print(f"    {tag:16s} entry {r[0]:7.2f} | {steps}")
         prev_end = end
         if os.environ.get("NAF_TL_RAW"):      # every slot as written (extra marks placed while investigating a phase)
-            print("    raw slots (first wg):", [round((t - t0) / 100.0, 2) if t > 0 else None for t in raw[name][0]])
+            for w, tag in ((0, "first"), (1, "last")):
+                print(f"    raw slots ({tag} wg):", [round((t - t0) / 100.0, 2) if t > 0 else None for t in raw[name][w]])
     # gemm_bundle, every workgroup: when it entered and left (a launch larger than the chip's resident set runs in rounds)
     ent, ext = [], []
     for i in range(256):

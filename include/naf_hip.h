@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 13
+#define NAF_HIP_ABI_VERSION 14
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -252,6 +252,38 @@ int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const fl
                   const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
                   float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
                   float* save_mean, float* save_invstd, float* wc_out /* nullable: [H][KP], row c = w_c C of net 0, for naf_bb_layer1_bwd_finish */, int B, int H, int nets, float momentum, float eps, void* stream);
+/* The DEFERRED optimizer step (round 2): clip + Adam + Polyak of the PREVIOUS learn() (naf_algorithm.py:209-213) carried by the
+ * first two launches of the NEXT one instead of a launch of its own — one launch and one launch boundary less per update in
+ * a chain of updates. All fields as the arguments of naf_adam_polyak_fused; the flat buffers hold n floats, the layer-1
+ * parameters [W1 | b1 | g1 | be1] of the main network are floats [0, l1_floats) of them (l1_floats % 4 == 0).
+ *   naf_bb_layer1_adam:       `adam` != NULL: extra workgroups of the launch step floats [l1_floats, n) in place; the layer-1
+ *                             workgroups read W / bias / gamma / beta (which must lie inside [theta, theta + l1_floats), the
+ *                             target's param_net_stride floats behind in theta_target) and evaluate them as the step WILL
+ *                             leave them — same code, same bits — without writing them.
+ *   naf_bb_linear_stats_adam: `adam` != NULL: extra workgroups step floats [0, l1_floats) in place.
+ * Both calls of one update get the same struct; gradient, partials and step count must stay untouched until both have run.
+ * The caller ends a chain of updates with naf_adam_polyak_fused (learner.py: TrainChunk). */
+typedef struct {
+    float* theta;
+    const float* grad;
+    float* m;
+    float* v;
+    float* theta_target;    /* nullable */
+    const float* partials;
+    int n_partials;
+    float max_norm, lr, beta1, beta2, eps, tau, one_minus_tau;
+    const int32_t* step_dev;
+    float inv_world;
+    int64_t n, l1_floats;
+} naf_adam_args_t;
+int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+                       const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
+                       float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
+                       float* save_mean, float* save_invstd, float* wc_out, int B, int H, int nets, float momentum, float eps,
+                       const naf_adam_args_t* adam /* nullable (HOST pointer, copied into the launch) */, void* stream);
+int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
+                             int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B, int N,
+                             int K, int nets, const naf_adam_args_t* adam /* nullable (HOST pointer) */, void* stream);
 /* naf_bb_layer1 and naf_bb_linear_stats in ONE launch (H = 256, K <= 26): every GEMM-2 workgroup forms its own A panel
  * A1 = ReLU(BN(x W1^T + b1)) in LDS from the rows and the moments record; the column-0 workgroups also write A1 (a1_out, for the
  * backward pass), the running statistics and save_mean / save_invstd of layer 1. Outputs of naf_bb_linear_stats as below. */

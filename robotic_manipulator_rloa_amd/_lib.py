@@ -17,7 +17,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
 SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "big_batch.hip", "gemm_bundle.hip", "gemm_bundle64.hip", "optim.hip",
            "synth_env.hip", "xgmi_reduce.hip", "policy_act.hip"]
-HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", os.path.join("..", "..", "include", "naf_hip.h")]
+HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", "adam_body.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
 ACTION_TRUNC_INT, ACTION_FLOAT = 0, 1
@@ -173,6 +173,9 @@ _PROTOS = {
     "naf_bb_layer12": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp,
                        _i64, _i, _vp, _i, _i, _i, _f, _f, _vp],
     "naf_bb_linear_stats": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp],
+    "naf_bb_layer1_adam": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i, _f,
+                           _f, _vp, _vp],
+    "naf_bb_linear_stats_adam": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "naf_bb_bn_relu_heads_partial": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
                                      _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
     "naf_bb_heads_bwd_stage1": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
@@ -230,6 +233,14 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("sumsq", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
                 ("k_split", C.c_int), ("c_split_stride", C.c_int64), ("epi", C.c_void_p), ("pro", C.c_void_p)]
+
+
+class AdamArgs(C.Structure):
+    """naf_adam_args_t (include/naf_hip.h): the deferred optimizer step carried by the next update's first two launches"""
+    _fields_ = [("theta", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("theta_target", C.c_void_p),
+                ("partials", C.c_void_p), ("n_partials", C.c_int), ("max_norm", C.c_float), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("tau", C.c_float), ("one_minus_tau", C.c_float),
+                ("step_dev", C.c_void_p), ("inv_world", C.c_float), ("n", C.c_int64), ("l1_floats", C.c_int64)]
 
 
 class GemmBn2Bwd(C.Structure):

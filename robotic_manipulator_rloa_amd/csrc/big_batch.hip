@@ -19,6 +19,7 @@
 #include <string.h>
 #include "bn_tile.h"
 #include "head_body.h"
+#include "adam_body.h"
 #include "../../include/naf_hip.h"
 
 #define BB_ROWS NAF_BB_ROWS      // rows per statistics block
@@ -335,14 +336,19 @@ __device__ static inline void bb_l1_stats_from_moments(const float* sMom, const 
 // and scattered to [k][column] in LDS), the moments record, the per-column parameters — is requested before the first LDS
 // store. (As `for (e = tid; ...) lds[..] = global[..]` loops the compiler kept one load in flight per trip: nine dependent
 // round trips, 2.5 of this kernel's 5.0 us — benchmarks/kernel_timeline.py.)
-template <int K4>
-__global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
+// ADAM (the deferred optimizer step, adam_body.h): the grid is the n_main layer-1 workgroups plus extra workgroups that step
+// floats [4 l1_4, 4 n4) of the flat buffers in place; the layer-1 workgroups request, with their operands, what the step needs
+// for the parameters they read (gradient, moments, the main network's old value for the target's workgroups) and evaluate
+// them as the step will leave them. Costs one more barrier (the clip scale must exist before the weights go to LDS).
+// The grid is one-dimensional: workgroup = rb + B/64 (column tile + H/64 net), the order the 3-D grid had.
+template <int K4, bool ADAM>
+__global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_kernel(
     const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
     int64_t param_net_stride, const float* __restrict__ mom, float* __restrict__ running_mean,
     float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out, int64_t out_net_stride, int ldo,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ wc_out, int B, int H, float momentum,
-    float eps) {
+    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4) {
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
     constexpr int XN = (BB_ROWS * K4 + BB_THREADS - 1) / BB_THREADS;           // float4 of the row tile per thread: 2
     constexpr int MN = (REC / 4 + BB_THREADS - 1) / BB_THREADS;                // of the moments record: 1 or 2
@@ -350,58 +356,123 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
     __shared__ __attribute__((aligned(16))) float sWt[KP][BB_COLS + 4];
     __shared__ __attribute__((aligned(16))) float sMom[REC];
     __shared__ float sStat[4][BB_COLS];     // mean, invstd, gamma, beta of this workgroup's columns
+    __shared__ AdamScalars shA;
+    __shared__ __attribute__((aligned(16))) float sPar[3][BB_COLS];   // ADAM: b, gamma, beta of the columns as the step leaves them
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS, net = blockIdx.z;
-    const int64_t po = net * param_net_stride;
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 0);
-    const float* xn = x + net * x_net_stride + (int64_t)rb * BB_ROWS * ldx;
-    f32x4 xv[XN], wv[2], mv[MN];
-#pragma unroll
-    for (int i = 0; i < XN; ++i) {
-        const int e = tid + BB_THREADS * i;
-        const int row = e / K4, q = e - row * K4;
-        xv[i] = ((const f32x4*)(xn + (int64_t)(row < BB_ROWS ? row : 0) * ldx))[q];
+    const int widx = blockIdx.x;
+    if (ADAM && __builtin_expect(widx >= n_main, 0)) {     // (unlikely: the riding step's code sits behind the kernel's own)
+        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 11, widx == n_main, widx == (int)gridDim.x - 1);    // (raw slots 11, 12: the riding step)
+        adam_block<2 * BB_THREADS>(ad, (size_t)l1_4, (size_t)n4, widx - n_main, (int)gridDim.x - n_main, &shA, tid, true);
+        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 12, widx == n_main, widx == (int)gridDim.x - 1);
+        return;
     }
+    const int gx = B / BB_ROWS, gy = H / BB_COLS;
+    const int rb = widx % gx, col0 = ((widx / gx) % gy) * BB_COLS, net = widx / (gx * gy);
+    const int64_t po = net * param_net_stride;
+#define L1_TL(slot) NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, slot, widx == 0, widx == n_main - 1)
+    L1_TL(0);
+    const float* xn = x + net * x_net_stride + (int64_t)rb * BB_ROWS * ldx;
+    // ADAM: the workgroup has 512 threads. Threads 0 .. 255 are the layer-1 workgroup as ever; ALL 512 take part in evaluating
+    // the parameters as the pending step leaves them (one float4 = four elements per thread: the update formula is ~100
+    // instructions per element — a division and a square root, correctly rounded), then waves 4 .. 7 are done.
+    const bool mainw = !ADAM || tid < BB_THREADS;
+    f32x4 xv[XN], wv[2], mv[MN];
     const int wn4 = (BB_COLS * K) >> 2;                                          // 16 K float4 (<= 512)
     const f32x4* wsrc = (const f32x4*)(W + po + (int64_t)col0 * K);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + BB_THREADS * i;
-        wv[i] = wsrc[e < wn4 ? e : 0];
-    }
-#pragma unroll
-    for (int i = 0; i < MN; ++i) {
-        const int e = tid + BB_THREADS * i;
-        mv[i] = ((const f32x4*)(mom + (int64_t)net * REC))[e < REC / 4 ? e : 0];
-    }
-    const float4 b4 = *(const float4*)(bias + po + col0 + 4 * tx);
     // the statistics of column cl are finished by lane (r < 4, g) of wave cl / 16 (see below): its constants
-    const int lane = tid & 63, wave = tid >> 6, mr = lane & 15, mg = lane >> 4;
+    const int lane = tid & 63, wave = (tid >> 6) & 3, mr = lane & 15, mg = lane >> 4;
     const int cl = 16 * wave + 4 * mg + (mr & 3);
-    const float bias_c = bias[po + col0 + cl];
-    const float gm = gamma[po + col0 + cl], bt = beta[po + col0 + cl];
+    float4 b4v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bias_cv = 0.f, gmv = 0.f, btv = 0.f;
     float rm_ = 0.f, rv_ = 0.f;
-    if (rb == 0 && mr < 4) {
-        rm_ = running_mean[net * stat_net_stride + col0 + cl];
-        rv_ = running_var[net * stat_net_stride + col0 + cl];
+    if (mainw) {
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int e = tid + BB_THREADS * i;
+            const int row = e / K4, q = e - row * K4;
+            xv[i] = ((const f32x4*)(xn + (int64_t)(row < BB_ROWS ? row : 0) * ldx))[q];
+        }
+    }
+    if (!ADAM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + BB_THREADS * i;
+            wv[i] = wsrc[e < wn4 ? e : 0];
+        }
+    } else {
+        wv[0] = wsrc[tid < wn4 ? tid : 0];
+    }
+    if (mainw) {
+#pragma unroll
+        for (int i = 0; i < MN; ++i) {
+            const int e = tid + BB_THREADS * i;
+            mv[i] = ((const f32x4*)(mom + (int64_t)net * REC))[e < REC / 4 ? e : 0];
+        }
+        if (!ADAM) {
+            b4v = *(const float4*)(bias + po + col0 + 4 * tx);
+            bias_cv = bias[po + col0 + cl];
+            gmv = gamma[po + col0 + cl];
+            btv = beta[po + col0 + cl];
+        }
+        if (rb == 0 && mr < 4) {
+            rm_ = running_mean[net * stat_net_stride + col0 + cl];
+            rv_ = running_var[net * stat_net_stride + col0 + cl];
+        }
+    }
+    // deferred step: everything it needs for the parameters this workgroup reads, in flight with the operands above. Every
+    // parameter is evaluated ONCE per workgroup and handed on through LDS (evaluated where they are used — the per-column
+    // parameters 16 x redundantly — a thread ran the formula 15 times: 2.6 us in front of the first barrier): thread t takes
+    // float4 t of the weight tile (t < 16 K), the last 48 threads one float4 each of [b | gamma | beta].
+    const bool tgt = net != 0;
+    constexpr int NPAR4 = 3 * BB_COLS / 4;
+    const int pj = tid - (2 * BB_THREADS - NPAR4);            // ADAM: >= 0 for the threads that take a parameter float4
+    AdamFly4 fw, fp;
+    f32x4 pcur;
+    AdamPrefetch apf;
+    if (ADAM) {
+        const int64_t oW = (W - ad.theta) + (int64_t)col0 * K;
+        fw = adam_fly_load4(ad, oW + 4 * (tid < wn4 ? tid : 0), tgt);
+        const int jc = pj >= 0 ? pj : 0, c4 = 4 * (jc & (BB_COLS / 4 - 1));
+        const float* pb = jc < BB_COLS / 4 ? bias : jc < BB_COLS / 2 ? gamma : beta;
+        pcur = *(const f32x4*)(pb + po + col0 + c4);
+        fp = adam_fly_load4(ad, (pb - ad.theta) + col0 + c4, tgt);
+        apf = adam_prefetch(ad, tid);
     }
     // rows k >= K of the weight tile meet the padding columns of the row tile: zero
     for (int e = tid; e < (KP - K) * BB_COLS; e += BB_THREADS) sWt[K + e / BB_COLS][e % BB_COLS] = 0.f;
+    if (mainw) {
 #pragma unroll
-    for (int i = 0; i < XN; ++i) {
-        const int e = tid + BB_THREADS * i;
-        const int row = e / K4, q = e - row * K4;
-        if (row < BB_ROWS) {
-            sXt[4 * q + 0][row] = xv[i][0];
-            sXt[4 * q + 1][row] = xv[i][1];
-            sXt[4 * q + 2][row] = xv[i][2];
-            sXt[4 * q + 3][row] = xv[i][3];
+        for (int i = 0; i < XN; ++i) {
+            const int e = tid + BB_THREADS * i;
+            const int row = e / K4, q = e - row * K4;
+            if (row < BB_ROWS) {
+                sXt[4 * q + 0][row] = xv[i][0];
+                sXt[4 * q + 1][row] = xv[i][1];
+                sXt[4 * q + 2][row] = xv[i][2];
+                sXt[4 * q + 3][row] = xv[i][3];
+            }
         }
+#pragma unroll
+        for (int i = 0; i < MN; ++i) {
+            const int e = tid + BB_THREADS * i;
+            if (e < REC / 4) ((f32x4*)sMom)[e] = mv[i];
+        }
+    }
+    if (ADAM) {
+        L1_TL(7);
+        adam_derive(ad, apf, &shA, tid);
+        L1_TL(8);
+        __syncthreads();
+        L1_TL(9);
+        const AdamScalars sc = shA;
+        if (tid < wn4) wv[0] = adam_fly_apply4(ad, sc, fw, wv[0], tgt);
+        if (pj >= 0) *(f32x4*)(&sPar[0][0] + 4 * pj) = adam_fly_apply4(ad, sc, fp, pcur, tgt);
+        L1_TL(10);
     }
     {
         const unsigned kinv = (65536u + (unsigned)K - 1u) / (unsigned)K;        // i / K for i < 64 K <= 2048: exact (K <= 32)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < (ADAM ? 1 : 2); ++i) {
             const int e = tid + BB_THREADS * i;
             if (e < wn4) {
 #pragma unroll
@@ -413,13 +484,18 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < MN; ++i) {
-        const int e = tid + BB_THREADS * i;
-        if (e < REC / 4) ((f32x4*)sMom)[e] = mv[i];
-    }
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 1);
+    if (ADAM && tid >= BB_THREADS) {             // waves 4 .. 7: done (they leave through the barrier the others still have ahead)
+        __syncthreads();
+        return;
+    }
+    if (ADAM) {
+        b4v = *(const float4*)&sPar[0][4 * tx];
+        bias_cv = sPar[0][cl];
+        gmv = sPar[1][cl];
+        btv = sPar[2][cl];
+    }
+    L1_TL(1);
     {
         // statistics of the 64 columns from the moments on MFMA: U = W C (64 x KP; wave w owns columns 16 w .. +15, both
         // 16-wide halves of the KP dimension), then var_c B = U[c] . w_c and (mean_c - b_c) B = w_c . Sx as 16-lane reductions
@@ -443,7 +519,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
                 u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[q], u1, 0, 0, 0);
             }
         }
-        NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 5);
+        L1_TL(5);
         // lane (mr, mg) holds U[column 16 w + 4 mg + e][n = mr] (u0) and [n = 16 + mr] (u1)
         if (wc_out && net == 0 && rb == 0) {
 #pragma unroll
@@ -467,18 +543,18 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
             t[e] = naf_sum16(t[e]);
             md[e] = naf_sum16(md[e]);
         }
-        NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 6);
+        L1_TL(6);
         if (mr < 4) {                                        // lane mr of the group finishes column 4 mg + mr (= cl)
             const float tt = mr == 0 ? t[0] : mr == 1 ? t[1] : mr == 2 ? t[2] : t[3];
             const float mm = mr == 0 ? md[0] : mr == 1 ? md[1] : mr == 2 ? md[2] : md[3];
-            const float mean = bias_c + mm / (float)B;
+            const float mean = bias_cv + mm / (float)B;
             const float var = fmaxf(tt, 0.f) / (float)B;
             const int c = cl, col = col0 + c;
             const float invstd = 1.0f / sqrtf(var + eps);
             sStat[0][c] = mean;
             sStat[1][c] = invstd;
-            sStat[2][c] = gm;
-            sStat[3][c] = bt;
+            sStat[2][c] = gmv;
+            sStat[3][c] = btv;
             if (rb == 0) {
                 const int64_t so = net * stat_net_stride + col;
                 const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
@@ -489,11 +565,11 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
             }
         }
     }
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 2);
+    L1_TL(2);
     float z[4][4];
-    bb_l1_tile<K4>(sXt, sWt, b4, ty, tx, z);
+    bb_l1_tile<K4>(sXt, sWt, b4v, ty, tx, z);
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 3);
+    L1_TL(3);
     float* oz = out + net * out_net_stride;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -508,7 +584,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_kernel(
         naf_buf_st_f4(naf_buf(oz + (int64_t)(rb * BB_ROWS) * ldo + col0), 4u * (unsigned)((4 * ty + i) * ldo + 4 * tx), 0,
                       (f32x4){y.x, y.y, y.z, y.w}, B >= NAF_WT_MIN_B);
     }
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER1, 4);
+    L1_TL(4);
+#undef L1_TL
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -559,19 +636,32 @@ __device__ __forceinline__ static void bl_store_chunk(const f32x4 (&va)[8], cons
 }
 // (amdgpu_waves_per_eu: LDS admits 3 workgroups per CU; left alone the register allocator aimed at 4 waves per SIMD and
 // spilled the second chunk's 48 registers to scratch: 8.0 -> 12.8 us per launch)
+// ADAM (the deferred optimizer step, adam_body.h): the one-dimensional grid carries, behind its n_main GEMM workgroups (index =
+// x + gx y of the former 2-D grid, gx = nets B/64), extra workgroups that step floats [0, 4 l1_4) of the flat buffers — the
+// layer-1 segment, which the launch in front of this one read for the last time.
+template <bool ADAM>
 __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3))) void bb_linear_stats_kernel(const float* __restrict__ a, int64_t a_net_stride,
                                                                      int lda, const float* __restrict__ W,
                                                                      const float* __restrict__ bias,
                                                                      int64_t param_net_stride, float* __restrict__ z,
                                                                      int64_t z_net_stride, int ldz,
-                                                                     float2* __restrict__ partials, int B, int N, int K) {
+                                                                     float2* __restrict__ partials, int B, int N, int K,
+                                                                     int gx, int n_main, const AdamArgs ad, int64_t l1_4) {
     __shared__ __attribute__((aligned(16))) float sA[BL_BM * BL_LD];
     __shared__ __attribute__((aligned(16))) float sB[BL_BN * BL_LD];
     __shared__ float red[2][BL_BN];
+    __shared__ AdamScalars shA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int widx = blockIdx.x;
+    if (ADAM && __builtin_expect(widx >= n_main, 0)) {     // (unlikely: the riding step's code sits behind the kernel's own)
+        adam_block<BB_THREADS>(ad, 0, (size_t)l1_4, widx - n_main, (int)gridDim.x - n_main, &shA, tid, true);
+        return;
+    }
+    const int bx = widx % gx, by = widx / gx;
+#define BL_TL(slot) NAF_TL_FL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, slot, widx == 0, widx == n_main - 1)
     const int NB = B / BB_ROWS;
-    const int net = blockIdx.x / NB, rb = blockIdx.x - net * NB;
-    const int n0 = blockIdx.y * BL_BN;
+    const int net = bx / NB, rb = bx - net * NB;
+    const int n0 = by * BL_BN;
     const float* an = a + net * a_net_stride + (int64_t)rb * BL_BM * lda;
     const float* wn_ = W + net * param_net_stride + (int64_t)n0 * K;     // [N][K] row-major
     // chunk = 128 k: A 64 rows x 32 float4 (8 per thread), B 32 rows x 32 float4 (4 per thread); every load of a chunk is
@@ -587,7 +677,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     // the second chunk's loads are issued behind the first chunk's LDS stores and land in registers while its MFMAs run
     // (all 24 loads up front made the register allocator park 12 of them in scratch)
     f32x4 va1[8], vb1[4];
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 0);
+    BL_TL(0);
     const __amdgpu_buffer_rsrc_t ab = naf_buf(an), wb = naf_buf(wn_);
     const unsigned la = ((unsigned)(tid >> 5) * (unsigned)lda + 4u * (unsigned)(tid & 31)) * 4u;
     const unsigned lw = ((unsigned)(tid >> 5) * (unsigned)K + 4u * (unsigned)(tid & 31)) * 4u;
@@ -596,15 +686,15 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     __builtin_amdgcn_sched_barrier(0);                    // keep chunk 1's loads behind chunk 0's stores
     bl_load_chunk_buf(va1, vb1, ab, la, lda, wb, lw, K, BL_KC);
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 1);
+    BL_TL(1);
     bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
     __syncthreads();                                      // first chunk fully consumed
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 2);
+    BL_TL(2);
     bl_store_chunk(va1, vb1, sA, sB, tid);
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 3);
+    BL_TL(3);
     bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 4);
+    BL_TL(4);
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
     float v[2][4];
     float s = 0.f;
@@ -638,27 +728,36 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     __syncthreads();
     if (wm == 0 && g == 0)
         partials[((int64_t)net * NB + rb) * N + n0 + 16 * wn + r] = make_float2(S, red[0][16 * wn + r] + red[1][16 * wn + r]);
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 5);
+    BL_TL(5);
 }
 
 // The same GEMM with 64 x 16 tiles for small batches (B <= 512): the 64 x 32 grid is 2 B / 64 x 8 = 64 workgroups at B = 256 and
 // each spends 2 x 1.2 us in its two MFMA phases — a quarter of the chip busy, latency all the way. Half as wide, twice as
 // many workgroups (wave w = rows 16 w .. +15, one MFMA tile): the MFMA phases halve. The statistics blocks stay 64 rows, so
 // the partials and every consumer are unchanged.
+template <bool ADAM>
 __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const float* __restrict__ a, int64_t a_net_stride, int lda,
                                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                                        int64_t param_net_stride, float* __restrict__ z,
                                                                        int64_t z_net_stride, int ldz, float2* __restrict__ partials,
-                                                                       int B, int N, int K) {
+                                                                       int B, int N, int K, int gx, int n_main, const AdamArgs ad,
+                                                                       int64_t l1_4) {
     constexpr int BN = 16;
     __shared__ __attribute__((aligned(16))) float sA[BL_BM * BL_LD];
     __shared__ __attribute__((aligned(16))) float sB[BN * BL_LD];
     __shared__ float red[4][BN];
+    __shared__ AdamScalars shA;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int widx = blockIdx.x;
+    if (ADAM && __builtin_expect(widx >= n_main, 0)) {     // (unlikely: the riding step's code sits behind the kernel's own)                     // (extra workgroups: the deferred step of the layer-1 segment, see above)
+        adam_block<BB_THREADS>(ad, 0, (size_t)l1_4, widx - n_main, (int)gridDim.x - n_main, &shA, tid, true);
+        return;
+    }
+    const int bx = widx % gx, by = widx / gx;
     const int NB = B / BB_ROWS;
-    const int net = blockIdx.x / NB, rb = blockIdx.x - net * NB;
-    const int n0 = blockIdx.y * BN;
+    const int net = bx / NB, rb = bx - net * NB;
+    const int n0 = by * BN;
     const int r = lane & 15, g = lane >> 4;
     // operands through buffer loads (common.h): A rows (tid >> 5) + 8 i, float4 (tid & 31); B rows (tid >> 5) + 8 i < 16
     const __amdgpu_buffer_rsrc_t ab = naf_buf(a + net * a_net_stride + (int64_t)rb * BL_BM * lda);
@@ -667,7 +766,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     const unsigned lw = ((unsigned)(tid >> 5) * (unsigned)K + 4u * (unsigned)(tid & 31)) * 4u;
     const float bcol = bias[net * param_net_stride + n0 + r];
     f32x4 va[8], vb[2], va1[8], vb1[2];
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 0);
+    BL_TL(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) va[i] = naf_buf_f4(ab, la, (unsigned)(8 * i * lda) * 4u);
 #pragma unroll
@@ -684,7 +783,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
 #pragma unroll
     for (int i = 0; i < 2; ++i) vb1[i] = naf_buf_f4(wb, lw, (unsigned)(8 * i * K + BL_KC) * 4u);
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 1);
+    BL_TL(1);
     const float* pa = sA + (16 * wave + r) * BL_LD + 4 * g;
     const float* pb = sB + r * BL_LD + 4 * g;
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
@@ -700,15 +799,15 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     };
     mfma_chunk();
     __syncthreads();                                      // first chunk fully consumed
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 2);
+    BL_TL(2);
 #pragma unroll
     for (int i = 0; i < 8; ++i) *(f32x4*)(sa_t + 8 * i * BL_LD) = va1[i];
 #pragma unroll
     for (int i = 0; i < 2; ++i) *(f32x4*)(sb_t + 8 * i * BL_LD) = vb1[i];
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 3);
+    BL_TL(3);
     mfma_chunk();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 4);
+    BL_TL(4);
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg. Z2 out, then the column statistics of the 64-row block: 4 rows in
     // the lane, 4 lane groups, 4 waves through LDS
     float v[4];
@@ -740,7 +839,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     if (g == 0) red[wave][r] = m2;
     __syncthreads();
     if (tid < BN) partials[((int64_t)net * NB + rb) * N + n0 + tid] = make_float2(S, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
-    NAF_TL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, 5);
+    BL_TL(5);
+#undef BL_TL
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1768,11 +1868,25 @@ extern "C" int naf_bb_moments(const float* x, int64_t batch_stride, int64_t x_ne
     return NAF_OK;
 }
 
-extern "C" int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
-                             const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
-                             float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
-                             int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
-                             int nets, float momentum, float eps, void* stream) {
+// the deferred optimizer step riding on a launch (include/naf_hip.h, naf_adam_args_t): the device-side arguments, the end of
+// the layer-1 segment and of the buffers in float4, and how many extra workgroups step floats [lo, hi)
+static bool bb_adam_setup(const naf_adam_args_t* adam, AdamArgs& ad, int64_t& l1_4, int64_t& n4) {
+    memset(&ad, 0, sizeof(ad));
+    l1_4 = n4 = 0;
+    if (!adam) return true;
+    if (!adam_args_from(*adam, ad) || adam->l1_floats <= 0 || (adam->l1_floats & 3) || adam->n <= adam->l1_floats || (adam->n & 3))
+        return false;
+    l1_4 = adam->l1_floats / 4;
+    n4 = adam->n / 4;
+    return true;
+}
+static int bb_adam_blocks(int64_t lo4, int64_t hi4, int threads) { return (int)((hi4 - lo4 + threads - 1) / threads); }
+
+extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+                                  const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
+                                  float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
+                                  int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
+                                  int nets, float momentum, float eps, const naf_adam_args_t* adam, void* stream) {
     if (!x || !W || !bias || !mom || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd ||
         !bb_shape_ok(B, H) || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4 || ldo < H || (ldo & 3))
         return NAF_ERR_ARG;
@@ -1781,39 +1895,73 @@ extern "C" int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int 
     if ((((uintptr_t)bias | (uintptr_t)out | (uintptr_t)mom | (uintptr_t)W) & 15) != 0 || (param_net_stride & 3) != 0 ||
         (out_net_stride & 3) != 0)
         return NAF_ERR_ARG;                              // (W: the 64-column runs of 64 K floats are read as float4)
+    AdamArgs ad;
+    int64_t l1_4, n4;
+    if (!bb_adam_setup(adam, ad, l1_4, n4)) return NAF_ERR_ARG;
+    if (adam) {
+        // the parameters this launch reads must be the main network's layer-1 segment, the target's param_net_stride behind
+        const float* lo = adam->theta, *hi = adam->theta + adam->l1_floats;
+        if ((((uintptr_t)gamma | (uintptr_t)beta) & 15) != 0) return NAF_ERR_ARG;       // (read as float4 here)
+        if (nets > 2 || W < lo || W + (int64_t)H * K > hi || bias < lo || bias + H > hi || gamma < lo || gamma + H > hi || beta < lo ||
+            beta + H > hi || (nets == 2 && adam->theta_target != adam->theta + param_net_stride))
+            return NAF_ERR_ARG;
+    }
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(B / BB_ROWS, H / BB_COLS, nets);
-#define BB_L1(K4V)                                                                                                        \
-    bb_layer1_kernel<K4V><<<grid, BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
-                                                       running_mean, running_var, stat_net_stride, out, out_net_stride, ldo,  \
-                                                       save_mean, save_invstd, wc_out, B, H, momentum, eps)
-    if (k4d == 6) BB_L1(6);
-    else BB_L1(8);
+    const int n_main = (B / BB_ROWS) * (H / BB_COLS) * nets;
+    const int grid = n_main + (adam ? bb_adam_blocks(l1_4, n4, 2 * BB_THREADS) : 0);
+#define BB_L1(K4V, AD)                                                                                                       \
+    bb_layer1_kernel<K4V, AD><<<grid, (AD) ? 2 * BB_THREADS : BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
+                                                           running_mean, running_var, stat_net_stride, out, out_net_stride, ldo, \
+                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4)
+    if (k4d == 6) { if (adam) BB_L1(6, true); else BB_L1(6, false); }
+    else { if (adam) BB_L1(8, true); else BB_L1(8, false); }
 #undef BB_L1
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
+extern "C" int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+                             const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
+                             float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
+                             int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
+                             int nets, float momentum, float eps, void* stream) {
+    return naf_bb_layer1_adam(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, running_mean, running_var,
+                              stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, wc_out, B, H, nets, momentum, eps,
+                              nullptr, stream);
+}
 
-extern "C" int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
-                                   int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
-                                   int N, int K, int nets, void* stream) {
+extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
+                                        int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
+                                        int N, int K, int nets, const naf_adam_args_t* adam, void* stream) {
     if (!a || !W || !bias || !z || !partials || !bb_shape_ok(B, N) || nets <= 0) return NAF_ERR_ARG;
     if (K != 2 * BL_KC || lda < K || (lda & 3) || ldz < N) return NAF_ERR_ARG;     // two chunks of 128: the framework's H = 256
     if ((((uintptr_t)a | (uintptr_t)W) & 15) != 0 || (a_net_stride & 3) != 0 || (param_net_stride & 3) != 0 ||
         ((uintptr_t)partials & 7) != 0)
         return NAF_ERR_ARG;
-    if (B <= 512) {                  // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
-        dim3 grid16(nets * (B / BB_ROWS), N / 16);
-        bb_linear_stats16_kernel<<<grid16, BB_THREADS, 0, (hipStream_t)stream>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,
-                                                                                 z_net_stride, ldz, (float2*)partials, B, N, K);
-        NAF_CHECK_LAUNCH();
-        return NAF_OK;
-    }
-    dim3 grid(nets * (B / BB_ROWS), N / BL_BN);
-    bb_linear_stats_kernel<<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,
-                                                                         z_net_stride, ldz, (float2*)partials, B, N, K);
+    AdamArgs ad;
+    int64_t l1_4, n4;
+    if (!bb_adam_setup(adam, ad, l1_4, n4)) return NAF_ERR_ARG;
+    const int extra = adam ? bb_adam_blocks(0, l1_4, BB_THREADS) : 0;
+    const int gx = nets * (B / BB_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+#define BB_LS(KERNEL, GY)                                                                                                   \
+    do {                                                                                                                    \
+        const int n_main = gx * (GY);                                                                                       \
+        if (adam) KERNEL<true><<<n_main + extra, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,   \
+                                                                      z_net_stride, ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4); \
+        else KERNEL<false><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride,  \
+                                                          ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4);             \
+    } while (0)
+    if (B <= 512) BB_LS(bb_linear_stats16_kernel, N / 16);     // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
+    else BB_LS(bb_linear_stats_kernel, N / BL_BN);
+#undef BB_LS
     NAF_CHECK_LAUNCH();
     return NAF_OK;
+}
+extern "C" int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
+                                   int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
+                                   int N, int K, int nets, void* stream) {
+    return naf_bb_linear_stats_adam(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride, ldz, partials, B, N, K, nets,
+                                    nullptr, stream);
 }
 
 extern "C" int naf_bb_layer12(const float* x, int64_t x_net_stride, int ldx, int K, const float* W1, const float* bias1,

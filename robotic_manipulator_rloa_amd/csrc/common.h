@@ -38,6 +38,17 @@ enum { NAF_TL_BB_LAYER1 = 0, NAF_TL_BB_LINEAR_STATS, NAF_TL_BB_LAYER2_HEAD, NAF_
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     } while (0)
+// the same with the caller saying which workgroup is the first / the last (one-dimensional grids that carry the workgroups
+// of another job behind the kernel's own)
+#define NAF_TL_FL(arr, kid, slot, is_first, is_last)                                                                 \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if (threadIdx.x == 0) {                                                                                      \
+            if (is_first) arr[kid][0][slot] = wall_clock64();                                                        \
+            if (is_last) arr[kid][1][slot] = wall_clock64();                                                         \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
 #define NAF_TL_READER(fn, arr)                                                                                        \
     int fn(int kid, long long* out) {                                                                                 \
         return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arr), 2 * NAF_TL_SLOTS * sizeof(long long),                    \
@@ -46,6 +57,7 @@ enum { NAF_TL_BB_LAYER1 = 0, NAF_TL_BB_LINEAR_STATS, NAF_TL_BB_LAYER2_HEAD, NAF_
 #else
 #define NAF_TL_DECL(arr)
 #define NAF_TL(arr, kid, slot) do { } while (0)
+#define NAF_TL_FL(arr, kid, slot, is_first, is_last) do { } while (0)
 #define NAF_TL_READER(fn, arr) int fn(int, long long*) { return NAF_ERR_STATE; }
 #endif
 

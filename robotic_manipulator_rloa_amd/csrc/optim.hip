@@ -6,6 +6,7 @@
 // step count are read from device memory.
 #include "common.h"
 #include "../../include/naf_hip.h"
+#include "adam_body.h"
 
 // FP contraction is switched off for the update formulas so that tau*a + (1-tau)*b rounds like the
 // reference's two multiplies and one add.
@@ -55,124 +56,24 @@ extern "C" int naf_grad_norm_partials(const float* g, size_t n, float* partials,
     return NAF_OK;
 }
 
-// b^t for integer t >= 0 by square-and-multiply in double: ~2 log2(t) multiplies instead of the libm pow() call
-__device__ static inline double ipow(double b, int t) {
-    double r = 1.0;
-    while (t > 0) {
-        if (t & 1) r *= b;
-        b *= b;
-        t >>= 1;
-    }
-    return r;
-}
-
-struct AdamScalars {
-    float clip_scale;   // inv_world * min(1, max_norm / (total_norm + 1e-6))
-    float step_size;    // lr / (1 - beta1^t)
-    float inv_bc2_sqrt; // 1 / sqrt(1 - beta2^t)
-    int skip;           // the norm partials carry the poison of a timed-out gradient exchange: leave every buffer as it is
-};
-
-__device__ static inline void adam_one(float& th, float gr, float& m, float& v, float* tg, const AdamScalars& sc,
-                                       float beta1, float beta2, float eps, float tau, float one_minus_tau) {
-    const float gs = gr * sc.clip_scale;
-    m = m + (gs - m) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * beta2 + ((1.0f - beta2) * gs) * gs;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const float denom = sqrtf(v) * sc.inv_bc2_sqrt + eps;
-    th = th - sc.step_size * (m / denom);              // param.addcdiv_(exp_avg, denom, value=-step_size)
-    if (tg) *tg = tau * th + one_minus_tau * (*tg);    // soft_update with the freshly stepped main weights
-}
-
 NAF_TL_DECL(g_tl_opt);
 NAF_TL_READER(naf_tl_read_opt, g_tl_opt)
-__global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(float* __restrict__ theta, const float* __restrict__ g,
-                                                                  float* __restrict__ m, float* __restrict__ v,
-                                                                  float* __restrict__ target,
-                                                                  const float* __restrict__ partials, int n_partials,
-                                                                  float max_norm, float lr, float beta1, float beta2,
-                                                                  float eps, float tau, float one_minus_tau,
-                                                                  const int32_t* __restrict__ step_dev, float inv_world,
-                                                                  size_t n) {
+// the update as a launch of its own: adam_block (adam_body.h) over the whole buffer
+__global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(const AdamArgs A, size_t n) {
     __shared__ AdamScalars sh;
     NAF_TL(g_tl_opt, NAF_TL_ADAM, 0);
     const size_t n4 = n / 4;
-    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // first trip's operands AND the norm partials are requested up front, branch-free (indices clamped, results masked
-    // later): the partial sum, the sqrt and the two double-precision powers of thread 0 then run under the latency of
-    // these loads instead of in front of it. (With the loads inside `if`s the compiler waited for the operand loads at
-    // the merge before it even issued the partials' loads: two serial round trips.)
-    const size_t i0c = i0 < n4 ? i0 : (n4 ? n4 - 1 : 0);
-    float4 th0 = ((float4*)theta)[i0c];
-    float4 gr0 = ((const float4*)g)[i0c];
-    float4 mm0 = ((float4*)m)[i0c];
-    float4 vv0 = ((float4*)v)[i0c];
-    float4 tg0 = ((float4*)(target ? target : theta))[i0c];
-    const int t = *step_dev;                 // (uniform: a scalar load, in flight with the rest)
-    float pr[NAF_MAX_NORM_PARTIALS / 64];
-#pragma unroll
-    for (int j = 0; j < NAF_MAX_NORM_PARTIALS / 64; ++j) {
-        const int k = (int)(threadIdx.x & 63) + 64 * j;
-        pr[j] = partials[k < n_partials ? k : 0];
-    }
-    if (threadIdx.x < 64) {
-        // every workgroup re-derives the same scalars from the same partials in the same order: the first wave takes
-        // the partials 64 at a time, folds them with xor shuffles
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < NAF_MAX_NORM_PARTIALS / 64; ++j) s += ((int)threadIdx.x + 64 * j < n_partials) ? pr[j] : 0.f;
-        // more partials than were prefetched (flat buffers beyond 1M parameters): the rest in the same lane-major order
-        for (int k = (int)threadIdx.x + NAF_MAX_NORM_PARTIALS; k < n_partials; k += 64) s += partials[k];
-        s = naf_sum64(s);
-        if (threadIdx.x == 0) {
-            // a sum of squares is never negative: -inf is what xgmi_allreduce_kernel leaves when a peer's contribution
-            // did not arrive in time (csrc/xgmi_reduce.hip) — the update is then skipped on this rank, whole
-            sh.skip = s < 0.f;
-            const float total_norm = sqrtf(s) * inv_world;
-            float clip = max_norm / (total_norm + 1e-6f);
-            clip = clip > 1.0f ? 1.0f : clip;
-            sh.clip_scale = clip * inv_world;
-        }
-    } else if (threadIdx.x == 64) {
-        // the bias corrections (double precision, as torch computes them on the host) do not depend on the partials:
-        // the second wave works them out while the first one folds the norm (0.5 us when one thread did both in turn)
-        const double bc1 = 1.0 - ipow((double)beta1, t);
-        const double bc2 = 1.0 - ipow((double)beta2, t);
-        sh.step_size = (float)((double)lr / bc1);
-        sh.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    }
-    __syncthreads();
+    if (!adam_block<OPT_THREADS>(A, 0, n4, blockIdx.x, gridDim.x, &sh, threadIdx.x, false)) return;
     NAF_TL(g_tl_opt, NAF_TL_ADAM, 1);
-    const AdamScalars sc = sh;
-    if (sc.skip) return;
-    for (size_t i = i0; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 th, gr, mm, vv, tg = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i == i0) {
-            th = th0; gr = gr0; mm = mm0; vv = vv0; tg = tg0;
-        } else {
-            th = ((float4*)theta)[i];
-            gr = ((const float4*)g)[i];
-            mm = ((float4*)m)[i];
-            vv = ((float4*)v)[i];
-            if (target) tg = ((float4*)target)[i];
-        }
-        adam_one(th.x, gr.x, mm.x, vv.x, target ? &tg.x : nullptr, sc, beta1, beta2, eps, tau, one_minus_tau);
-        adam_one(th.y, gr.y, mm.y, vv.y, target ? &tg.y : nullptr, sc, beta1, beta2, eps, tau, one_minus_tau);
-        adam_one(th.z, gr.z, mm.z, vv.z, target ? &tg.z : nullptr, sc, beta1, beta2, eps, tau, one_minus_tau);
-        adam_one(th.w, gr.w, mm.w, vv.w, target ? &tg.w : nullptr, sc, beta1, beta2, eps, tau, one_minus_tau);
-        ((float4*)theta)[i] = th;
-        ((float4*)m)[i] = mm;
-        ((float4*)v)[i] = vv;
-        if (target) ((float4*)target)[i] = tg;
-    }
-    NAF_TL(g_tl_opt, NAF_TL_ADAM, 2);
     // tail (n % 4 elements)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const AdamScalars sc = sh;
         size_t e = n4 * 4 + threadIdx.x;
-        float th = theta[e], mm = m[e], vv = v[e];
-        float tg = target ? target[e] : 0.f;
-        adam_one(th, g[e], mm, vv, target ? &tg : nullptr, sc, beta1, beta2, eps, tau, one_minus_tau);
-        theta[e] = th; m[e] = mm; v[e] = vv;
-        if (target) target[e] = tg;
+        float th = A.theta[e], mm = A.m[e], vv = A.v[e];
+        float tg = A.target ? A.target[e] : 0.f;
+        adam_one(th, A.g[e], mm, vv, A.target ? &tg : nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        A.theta[e] = th; A.m[e] = mm; A.v[e] = vv;
+        if (A.target) A.target[e] = tg;
     }
 }
 
@@ -186,9 +87,11 @@ extern "C" int naf_adam_polyak_fused(float* theta, const float* g, float* m, flo
     size_t n4 = (n + 3) / 4;
     int blocks = (int)((n4 + OPT_THREADS - 1) / OPT_THREADS);
     if (blocks > 2048) blocks = 2048;
-    adam_polyak_kernel<<<blocks, OPT_THREADS, 0, (hipStream_t)stream>>>(theta, g, m, v, theta_target, partials,
-                                                                        n_partials, max_norm, lr, beta1, beta2, eps,
-                                                                        tau, one_minus_tau, step_dev, inv_world, n);
+    AdamArgs A;
+    A.theta = theta; A.g = g; A.m = m; A.v = v; A.target = theta_target; A.partials = partials; A.n_partials = n_partials;
+    A.max_norm = max_norm; A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.tau = tau; A.one_minus_tau = one_minus_tau;
+    A.step_dev = step_dev; A.inv_world = inv_world;
+    adam_polyak_kernel<<<blocks, OPT_THREADS, 0, (hipStream_t)stream>>>(A, n);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -100,8 +100,13 @@ class TrainChunk:
     def _updates(self) -> None:
         if self.moments is not None:
             self.L.moments(self.batch.view(self.U * self.L.B, -1), self.moments, self.U)
+        # a chain of updates: the optimizer step of update k rides on the first two launches of update k + 1 (one launch
+        # less per update, Learner.defer_ok); the last one of the chunk takes its step as a launch of its own, so the
+        # parameter buffers are current whenever anything outside the chunk looks at them
+        d = self.L.defer_ok
         for k in range(self.U):
-            self.L.learn_rows(self.batch[k], self.loss_parts[k], None if self.moments is None else self.moments[k])
+            self.L.learn_rows(self.batch[k], self.loss_parts[k], None if self.moments is None else self.moments[k],
+                              pending=d and k > 0, defer=d and k < self.U - 1)
 
     def _body(self) -> None:
         self._sample_gather()

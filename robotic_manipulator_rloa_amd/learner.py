@@ -244,6 +244,14 @@ class Learner:
             if self.xgmi is not None:
                 self.n_partials = self.xgmi.n_partials
         self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm, self.n_partials), **f32)
+        # the optimizer step of update k carried by the first two launches of update k + 1 (csrc/adam_body.h): the row-split
+        # chain on one rank, gradient norm folded into the producers. NAF_DEFER_ADAM=0 keeps the launch of its own.
+        self.defer_ok = ("bb" in self.fuse and "l12" not in self.fuse and "f3" not in self.fuse and self.fold_norm
+                         and self.world_size == 1 and os.environ.get("NAF_DEFER_ADAM", "1") != "0")
+        self._adam_args = _lib.AdamArgs(
+            ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]), ptr(self.partials),
+            self.n_partials, MAX_GRAD_NORM, self.lr, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau, float(1.0 - self.tau),
+            ptr(self.step_dev), 1.0 / self.world_size, P, lay.seg["W2"].offset)
         self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
         self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
         self.n_loss_wg = (B + 7) // 8                  # loss partials per update (NAF_HEAD_SPB samples per workgroup)
@@ -399,11 +407,13 @@ class Learner:
         check(self._f.naf_bb_moments(rows.data_ptr(), self.B * ld, lay.off_s2, ld, lay.S, ptr(out), self.B, int(n_batches), 2,
                                      stream_ptr()), "bb_moments")
 
-    def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True, moments: Optional[torch.Tensor] = None) -> None:
+    def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True, moments: Optional[torch.Tensor] = None,
+                      adam_pending: bool = False) -> None:
         """Both networks' training-mode forward up to the second hidden activation A2 (and, with heads_gemm, the
         heads pre-activations Gh). Main net sees `state`, target net sees `next_state` (naf_algorithm.py:194-202);
         both use batch statistics and both update their running statistics (the reference never calls .eval() on the
-        target)."""
+        target). adam_pending: the optimizer step of the previous update was deferred (learn_rows(defer=True)) and rides
+        on the first two launches here."""
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H = lay.seg, lay.P, lay.H
         t2p = self.theta2.data_ptr()
@@ -425,14 +435,19 @@ class Learner:
                     BN_MOMENTUM, BN_EPS, st), "bb_layer12")
             else:
                 # layer 1: batch statistics from the moments, z, normalise, ReLU — one launch for both nets
-                check(self._f.naf_bb_layer1(
+                # (adam_pending: the previous update's clip + Adam + Polyak ride on these two launches — extra workgroups of
+                # the first step everything behind the layer-1 segment while its own workgroups evaluate the layer-1
+                # parameters as the step will leave them, extra workgroups of the second step the layer-1 segment)
+                adam = _lib.C.byref(self._adam_args) if adam_pending else None
+                check(self._f.naf_bb_layer1_adam(
                     rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                     t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
                     ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), B, H, 2, BN_MOMENTUM,
-                    BN_EPS, st), "bb_layer1")
+                    BN_EPS, adam, st), "bb_layer1")
                 # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
-                check(self._f.naf_bb_linear_stats(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset, t2p + 4 * seg["b2"].offset, P,
-                                                  ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, H, 2, st), "bb_linear_stats")
+                check(self._f.naf_bb_linear_stats_adam(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset,
+                                                       t2p + 4 * seg["b2"].offset, P, ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H,
+                                                       H, 2, adam, st), "bb_linear_stats")
             if "hk" in self.fuse:
                 return               # layer 2 from Z2 on is inside naf_bb_layer2_head (learn_rows)
             # fold + normalise + ReLU -> A2, and this column slice's share of the heads GEMM
@@ -473,13 +488,19 @@ class Learner:
             torch.bmm(self.A2, self.WhT2, out=self.Gh)
 
     def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None,
-                   moments: Optional[torch.Tensor] = None) -> None:
+                   moments: Optional[torch.Tensor] = None, pending: bool = False, defer: bool = False) -> None:
         """Enqueue one full NAFAgent.learn() (naf_algorithm.py:180-215) + soft_update (:217-226) on the minibatch
         `rows` [B, ld] in the transition-row layout, ld = rows.stride(0) >= lay.batch_row_floats (actions already
         truncated by the gather if the reference's `.long()` is mimicked).
         loss_partials: optional [n_loss_wg] f32 receiving the per-workgroup parts of the MSE loss.
         moments: optional [2, mom_floats] record of this minibatch (large-batch chain; Learner.moments); computed here when
-        missing."""
+        missing.
+        defer / pending (only where self.defer_ok; a chain of updates, engine.TrainChunk): defer = leave this update's
+        optimizer step (clip + Adam + Polyak) to the NEXT learn_rows call, which must then say pending = True and whose
+        first two launches carry it — one launch less per update. Between the two calls the parameter buffers still hold
+        the values from before this update; the chain ends with a call that does not defer."""
+        if (pending or defer) and not self.defer_ok:
+            raise ValueError("learn_rows: a deferred optimizer step needs the row-split chain on one rank (Learner.defer_ok)")
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
         f = self._f
@@ -496,7 +517,7 @@ class Learner:
                 rp + 4 * lay.off_r, ld, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "heads_gemm_head_fwd_bwd_mse")
         elif "hk" in self.fuse:
-            self.forward_train(rows, moments=moments)
+            self.forward_train(rows, moments=moments, adam_pending=pending)
             bnp = self.bn_stats.data_ptr()
             # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
             check(f.naf_bb_layer2_head(
@@ -506,7 +527,7 @@ class Learner:
                 ptr(self.q_out), ptr(self.dH), lp, ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, lay.A, self.p_mode, BN_MOMENTUM,
                 BN_EPS, st), "bb_layer2_head")
         elif "s3" in self.fuse or "bb" in self.fuse:
-            self.forward_train(rows, moments=moments)
+            self.forward_train(rows, moments=moments, adam_pending=pending)
             # the head adds the split-K slabs (H/8 of them, or H/64 in the large-batch chain) while staging its rows
             check(f.naf_head_fwd_bwd_mse_splitk(
                 ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), self.n_slabs, NHP, rp + 4 * lay.off_u,
@@ -611,6 +632,8 @@ class Learner:
                 self.optimizer_step(norm_ready=True)
                 return
             all_reduce_flat_grad(self.grad, self.pg)
+        if defer:
+            return                       # the next learn_rows(pending=True) carries the step
         self.optimizer_step(norm_ready=self.fold_norm)
 
     def optimizer_step(self, norm_ready: Optional[bool] = None) -> None:

@@ -212,6 +212,51 @@ def test_chunk_graph_equals_eager_and_sampler_advances():
     np.testing.assert_array_equal(res[0][1].cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("S,A,B,U", [(21, 6, 256, 7), (21, 6, 512, 3), (21, 6, 1024, 4), (23, 7, 2048, 3), (21, 6, 64, 5)])
+def test_deferred_optimizer_step_is_the_same_bits(S, A, B, U, monkeypatch):
+    """The optimizer step of update k carried by the first two launches of update k + 1 (csrc/adam_body.h; TrainChunk) against
+    the step as a launch of its own: parameters of both nets, Adam moments, BatchNorm buffers, step count and every loss
+    bit-identical after several chunks — eagerly and as replayed graphs (naf_algorithm.py:209-213 semantics unchanged)."""
+    from synth_data import make_transitions
+    from robotic_manipulator_rloa_amd.engine import TrainChunk
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    sd = reference_init_state_dict(S, A, 256, seed=3)
+    n_rows = 6000
+    st, ac, rw, ns, dn = make_transitions(n_rows, S, A, seed=11)
+    res = {}
+    for mode, use_graph in (("0", False), ("1", False), ("1", True)):
+        monkeypatch.setenv("NAF_DEFER_ADAM", mode)
+        L = make_learner(S, A, B, sd, sd)
+        if B >= 256:
+            assert L.defer_ok == (mode == "1")
+        buf = ReplayBuffer(n_rows, B, "cuda", 0, state_size=S, action_size=A)
+        buf.add_rows_device(torch.from_numpy(O.pack_rows(st, ac, rw, ns, dn, 64)).cuda(), n_rows)
+        chunk = TrainChunk(L, buf, U, use_graph=use_graph)
+        losses = []
+        for _ in range(3):
+            chunk.run()
+            losses.append(chunk.losses().clone())
+        torch.cuda.synchronize()
+        assert int(L.step_dev.item()) == 3 * U
+        res[(mode, use_graph)] = (L.theta2.clone(), L.adam_m.clone(), L.adam_v.clone(), L.bn_stats.clone(), torch.cat(losses))
+    ref = res[("0", False)]
+    assert torch.isfinite(ref[0]).all() and not torch.equal(ref[0][0], ref[0][1])
+    for key in (("1", False), ("1", True)):
+        for a, b, name in zip(ref, res[key], ("theta2", "adam_m", "adam_v", "bn_stats", "losses")):
+            assert torch.equal(a, b), f"{name} differs with the deferred step ({key})"
+
+
+def test_learn_rows_rejects_a_deferred_step_where_it_cannot_ride(monkeypatch):
+    monkeypatch.setenv("NAF_DEFER_ADAM", "0")
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    sd = reference_init_state_dict(21, 6, 256, seed=3)
+    L = make_learner(21, 6, 256, sd, sd)
+    rows = torch.zeros(256, L.lay.row_floats, device="cuda")
+    with pytest.raises(ValueError):
+        L.learn_rows(rows, defer=True)
+
+
 def test_device_env_loop_fills_replay_and_trains():
     from robotic_manipulator_rloa_amd.engine import DeviceEnvLoop, TrainChunk
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
