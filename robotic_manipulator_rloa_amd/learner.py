@@ -246,8 +246,11 @@ class Learner:
         self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm, self.n_partials), **f32)
         # the optimizer step of update k carried by the first two launches of update k + 1 (csrc/adam_body.h): the row-split
         # chain on one rank, gradient norm folded into the producers. NAF_DEFER_ADAM=0 keeps the launch of its own.
-        self.defer_ok = ("bb" in self.fuse and "l12" not in self.fuse and "f3" not in self.fuse and self.fold_norm
-                         and self.world_size == 1 and os.environ.get("NAF_DEFER_ADAM", "1") != "0")
+        # Data parallel over peer memory: the one-shot all-reduce launch leaves the norm partials and the step count exactly
+        # as the folded producers do on one rank, so the step can ride there too (the RCCL path keeps its two launches).
+        self.defer_ok = ("bb" in self.fuse and "l12" not in self.fuse and "f3" not in self.fuse
+                         and ((self.fold_norm and self.world_size == 1) or self.xgmi is not None)
+                         and os.environ.get("NAF_DEFER_ADAM", "1") != "0")
         self._adam_args = _lib.AdamArgs(
             ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]), ptr(self.partials),
             self.n_partials, MAX_GRAD_NORM, self.lr, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau, float(1.0 - self.tau),
@@ -500,7 +503,8 @@ class Learner:
         first two launches carry it — one launch less per update. Between the two calls the parameter buffers still hold
         the values from before this update; the chain ends with a call that does not defer."""
         if (pending or defer) and not self.defer_ok:
-            raise ValueError("learn_rows: a deferred optimizer step needs the row-split chain on one rank (Learner.defer_ok)")
+            raise ValueError("learn_rows: a deferred optimizer step needs the row-split chain with the gradient norm left by the "
+                             "producers or by the one-shot all-reduce (Learner.defer_ok)")
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
         f = self._f
@@ -629,7 +633,8 @@ class Learner:
             if self.xgmi is not None:
                 # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
                 self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=pushed_lo)
-                self.optimizer_step(norm_ready=True)
+                if not defer:
+                    self.optimizer_step(norm_ready=True)
                 return
             all_reduce_flat_grad(self.grad, self.pg)
         if defer:
