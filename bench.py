@@ -159,7 +159,9 @@ def main():
     loop = DeviceEnvLoop(L, replay, E, seed=31 + rank, max_frames=400, use_graph=not args.no_graph, robot=args.robot,
                          obstacle_jitter=args.obstacle_jitter)
     U = E   # update_freq = num_updates = 1: one learn() per env transition (naf_algorithm.py:147-156)
-    chunk = TrainChunk(L, replay, U, use_graph=not args.no_graph, gather_outside_graph=True)
+    # sample -> gather -> U updates as ONE graph per vector step (the launch of the gather alone is bracketed with events in a
+    # short loop of its own behind the timed region: `roofline_live`)
+    chunk = TrainChunk(L, replay, U, use_graph=not args.no_graph)
     graph_note = "hipGraph"
     try:
         if not args.no_graph:
@@ -178,29 +180,35 @@ def main():
     for _ in range(args.warmup):
         one_step()
     # ---- timed region: exactly K steps between barrier + synchronize on both sides -------------------------
-    n_ev = min(args.steps, 512)          # the live gather launch is bracketed by HIP events on the first n_ev steps
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        chunk.gather_events = ev[k] if k < n_ev else None
         one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    chunk.gather_events = None
     t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    gather_bracket_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-
     finite = bool(torch.isfinite(L.theta2).all().item())
+    opt_steps = int(L.step_dev.item())
+    # the gather launch of a vector step (U*B rows) on its own, bracketed by HIP events on the launching stream: the same
+    # sample + gather the graph holds, launched eagerly 200 times behind the timed region (the learner is not touched)
+    n_ev = 200
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for k in range(n_ev):
+        chunk.gather_events = ev[k]
+        chunk._sample_gather()
+    torch.cuda.synchronize()
+    chunk.gather_events = None
+    gather_bracket_ms = sum(a.elapsed_time(b) for a, b in ev) / n_ev
+
     bad = replay.bad_index_count()
     env_steps = args.steps * E * world
     updates = args.steps * U * world
@@ -225,7 +233,7 @@ def main():
         "updates_per_s": round(updates / elapsed, 1),
         "us_per_update": round(1e6 * elapsed / (args.steps * U), 3),
         "timed_seconds": round(elapsed, 3),
-        "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": int(L.step_dev.item())},
+        "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": opt_steps},
     }
     if L.xgmi is not None:
         out["sanity"]["xgmi_allreduces"], out["sanity"]["xgmi_timed_out_waits"] = L.xgmi.status()
@@ -253,7 +261,8 @@ def main():
                             "avg_event_bracket_ms": round(gather_bracket_ms, 5),
                             "achieved": round(rows_live * row_alg / (gather_bracket_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
                             "frac": round(rows_live * row_alg / (gather_bracket_ms * 1e-3) / (PEAK_HBM_GBPS * 1e9), 4),
-                            "note": "latency-bound launch (6.6 MB); raw HIP-event bracket, no overhead subtracted"}
+                            "note": "latency-bound launch; raw HIP-event bracket of the same sample + gather launched eagerly 200 times behind "
+                                    "the timed region (inside it they are nodes of the step's graph), no overhead subtracted"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.torch_cpu_port import time_baseline
         # the reference path is dispatch-bound (~1400 aten calls per update): more threads do not help and torch's
@@ -337,6 +346,43 @@ def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
                     "1.16 x its algorithmic bytes; `traffic` is the PMC record of that (FETCH_SIZE x 2 + WRITE_SIZE)"}
 
 
+def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0):
+    """The timed loop of main() at another BASELINE shape on this one GPU (same engines, same update-to-data ratio):
+    updates/s of E envs, batch B, ring N."""
+    import torch
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.engine import DeviceEnvLoop, TrainChunk
+    from robotic_manipulator_rloa_amd.learner import Learner
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    S, A = (23, 7) if robot == "panda" else (21, 6)
+    L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, dev, p_mode=_lib.P_HADAMARD)
+    sd = reference_init_state_dict(S, A, 256, seed=0)
+    L.load_params(0, sd)
+    L.load_params(1, sd)
+    replay = ReplayBuffer(N, B, dev, seed=1000, state_size=S, action_size=A)
+    rows = synth_rows(N, S, A, replay.row_floats, replay.off_s2, seed=77, device=dev)
+    replay.add_rows_device(rows, N)
+    del rows
+    loop = DeviceEnvLoop(L, replay, E, seed=31, max_frames=400, robot=robot, obstacle_jitter=jitter)
+    chunk = TrainChunk(L, replay, E)
+    loop.capture()
+    chunk.capture()
+    for _ in range(warmup):
+        loop.step()
+        chunk.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loop.step()
+        chunk.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.isfinite(L.theta2).all().item()) and replay.bad_index_count() == 0 and int(L.step_dev.item()) == (steps + warmup) * E
+    return {"updates_per_s": round(steps * E / dt, 1), "us_per_update": round(1e6 * dt / (steps * E), 2), "steps": steps,
+            "timed_seconds": round(dt, 3), "sane": ok, "fused_kernels": ",".join(sorted(L.fuse))}
+
+
 def extras(dev, args):
     """Measurements outside `value`: (i) the host vector env — E=64 environments in worker
     processes around the GPU learner, synchronous and asynchronous policy; (ii) the reference-API path — one host env,
@@ -403,6 +449,17 @@ def extras(dev, args):
                                   "what": "NAFAgent.run_host_vectorized: batched act() on the GPU -> E host envs step in "
                                           "worker processes (shared memory) -> E rows over PCIe -> HBM ring -> E learn() "
                                           "updates; env = numpy kinematic stand-in (PyBullet absent: labelled, N2)"}
+        # (iii) the other single-GPU shapes of BASELINE.json's configs (their 8-GPU aspect is the driver's to run): the same
+        # loop at configs[3]'s batch (xarm6_robot, per-env obstacle jitter, B = 1024) and configs[4]'s (panda 7x7 tiles,
+        # B = 2048, ring 4e6) — only when the line itself is configs[1]
+        if (args.robot, args.batch, args.buffer, args.envs) == ("kuka", 256, 1000000, 64):
+            res["other_configs"] = {
+                "configs[3] shape: xarm6_robot S=21 A=6, batch 1024, ring 1e6, obstacle jitter 0.1, 1 GPU":
+                    measure_shape(dev, "xarm6_robot", 1024, 1000000, E, 500, 30, jitter=0.1),
+                "configs[4] shape: panda S=23 A=7, batch 2048, ring 4e6, 1 GPU":
+                    measure_shape(dev, "panda", 2048, 4000000, E, 400, 30),
+                "batch 512 (kuka, ring 1e6)": measure_shape(dev, "kuka", 512, 1000000, E, 500, 30),
+            }
     finally:
         os.chdir(old)
     return res

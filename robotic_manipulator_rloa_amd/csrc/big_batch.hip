@@ -17,6 +17,7 @@
 //   bb_heads_bwd_stage1 (dA2 = dH Wh on the fly, ReLU mask, backward partials) -> bb_bn_bwd_stage2 (dZ2) ->
 //   gemm_bundle (dWh, dW2, dA1) -> bb_layer1_bwd (column-owning, streaming) -> grad norm -> Adam + Polyak
 #include <string.h>
+#include <stdlib.h>
 #include "bn_tile.h"
 #include "head_body.h"
 #include "adam_body.h"
@@ -2026,7 +2027,11 @@ extern "C" int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride
 }
 
 // rows per workgroup = rows per block of partials_bw (the consumer, naf_bb_bn_bwd_stage2, is told B / rows blocks)
-extern "C" int naf_bb_layer2_head_rows(int B) { return B <= 1024 ? 16 : FK_ROWS; }
+extern "C" int naf_bb_layer2_head_rows(int B) {
+    const char* e = getenv("NAF_HK_ROWS");               // experiments: 16 or 32 whatever the batch size
+    if (e && (atoi(e) == 16 || atoi(e) == 32)) return atoi(e);
+    return B <= 1024 ? 16 : FK_ROWS;
+}
 
 extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
                                   int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,

@@ -521,7 +521,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (s.pro) {
             const naf_gemm_bn2bwd_t& q = *s.pro;
             if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 ||
-                q.npb > 32 || q.B <= 0 || q.H != 256 || (s.K / ksn) != GB_KC || (s.M & 31) || (s.N & 31) ||
+                q.npb > 32 || q.B <= 0 || q.H != 256 || ((s.K / ksn) % GB_KC) != 0 || (s.M & 31) || (s.N & 31) ||
                 (s.a_kmajor ? s.M != q.H : s.K != q.H) || ((uintptr_t)q.z & 15) || ((uintptr_t)q.partials & 7))
                 return NAF_ERR_ARG;      // (the A operand's columns are the H features: its M when k-major, its K otherwise)
             d.pro = q;

@@ -2,6 +2,7 @@
 // Philox index generation, coalesced row gather. Replaces the reference's deque + random.sample +
 // numpy stacking (utils/replay_buffer.py:16-75). HBM-bound byte moving: no LDS reuse to exploit, the
 // rules that matter are 16-B/lane accesses, whole 128-B lines per row and enough loads in flight.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/naf_hip.h"
 #include <new>
@@ -162,8 +163,10 @@ __device__ static inline int sample_draw(uint64_t ctr, uint32_t t, uint32_t atte
 __global__ __launch_bounds__(1024) void replay_sample_kernel(const uint64_t* __restrict__ meta, uint64_t seed,
                                                              const uint64_t* __restrict__ counter_dev,
                                                              uint64_t counter_off, int32_t* __restrict__ idx, int B,
-                                                             int without_replacement) {
-    extern __shared__ __attribute__((aligned(16))) int vals[];  // 4*B ints: B sampled values, or the whole population in the dense regime
+                                                             int without_replacement, int hash_bits) {
+    // B sampled values (+ the hash table of the duplicate check: 2 x 2^hash_bits ints), or the whole population (< 4 B
+    // ints) in the dense regime
+    extern __shared__ __attribute__((aligned(16))) int vals[];
     const uint64_t size = meta[META_SIZE];
     const uint64_t ctr = (counter_dev ? *counter_dev : 0ull) + counter_off + (uint64_t)blockIdx.x;
     int32_t* out = idx + (int64_t)blockIdx.x * B;
@@ -195,7 +198,49 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(const uint64_t* __r
     uint32_t attempt[4] = {0, 0, 0, 0};
     for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) vals[t] = sample_draw(ctr, (uint32_t)t, 0u, seed, size);
     __syncthreads();
-    if (dedupe) {
+    if (dedupe && hash_bits > 0) {
+        // "some earlier element holds the same value" through a hash table in LDS instead of a scan: O(B) per round where
+        // the scan is O(B^2) — 92 us per launch at B = 2048, 30 at B = 1024, on the critical path of every vector step.
+        // Open addressing over M = 2^hash_bits >= 2 B slots: keys[] (the value, claimed by compare-and-swap) and tmin[] (the
+        // smallest element index holding it, atomic min): element t is a duplicate iff tmin of its value < t. The same rule,
+        // so the same indices bit for bit (oracle.replay_sample_indices), whatever order the lanes insert in. Rebuilt every
+        // round (a redrawn element's old value must not linger).
+        const int M = 1 << hash_bits;
+        int* keys = vals + B;
+        int* tmin = keys + M;
+        for (int round = 0; round < NAF_SAMPLE_MAX_ROUNDS; ++round) {
+            for (int e = threadIdx.x; e < M; e += blockDim.x) {
+                keys[e] = -1;
+                tmin[e] = 0x7fffffff;
+            }
+            __syncthreads();
+            int slot[4] = {0, 0, 0, 0};
+            for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) {
+                const int mine = vals[t];
+                unsigned h = ((unsigned)mine * 2654435761u) >> (32 - hash_bits);
+                for (int probe = 0; probe < M; ++probe) {          // (load factor <= 1/2: a free or matching slot exists)
+                    const int was = atomicCAS(&keys[h], -1, mine);
+                    if (was == -1 || was == mine) break;
+                    h = (h + 1) & (unsigned)(M - 1);
+                }
+                atomicMin(&tmin[h], t);
+                slot[k] = (int)h;
+            }
+            __syncthreads();
+            int dupmask = 0;
+            for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k)
+                if (tmin[slot[k]] < t) dupmask |= (1 << k);
+            int any = __syncthreads_or(dupmask);  // also orders the reads above before the writes below
+            if (!any) break;
+            for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) {
+                if (dupmask & (1 << k)) {
+                    attempt[k] += 1u;
+                    vals[t] = sample_draw(ctr, (uint32_t)t, attempt[k], seed, size);
+                }
+            }
+            __syncthreads();
+        }
+    } else if (dedupe) {
         for (int round = 0; round < NAF_SAMPLE_MAX_ROUNDS; ++round) {
             int dupmask = 0;
             for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) {
@@ -245,8 +290,18 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
     if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
     if (!idx || B <= 0 || B > 4096 || n_batches <= 0) return NAF_ERR_ARG;
     int threads = B >= 1024 ? 1024 : naf_round_up(B, 64);
-    replay_sample_kernel<<<n_batches, threads, (size_t)B * 4 * sizeof(int), (hipStream_t)stream>>>(
-        h->meta, seed, counter_dev, counter_off, idx, B, without_replacement);
+    // duplicate check through a hash table of M = 2^bits >= 2 B slots when B + 2 M ints fit the 64 KB a workgroup gets by
+    // default (B <= 2048); the scan beyond
+    int bits = 1;
+    while ((1 << bits) < 2 * B) ++bits;
+    size_t lds_ints = (size_t)B + 2 * ((size_t)1 << bits);
+    if (lds_ints * sizeof(int) > 64 * 1024 || getenv("NAF_SAMPLE_SCAN")) {
+        bits = 0;
+        lds_ints = 0;
+    }
+    if (lds_ints < (size_t)B * 4) lds_ints = (size_t)B * 4;
+    replay_sample_kernel<<<n_batches, threads, lds_ints * sizeof(int), (hipStream_t)stream>>>(
+        h->meta, seed, counter_dev, counter_off, idx, B, without_replacement, bits);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -195,7 +195,12 @@ def test_replay_sample_api_contract_matches_reference_golden(lib):
     assert len(set(ids.tolist())) == B and ids.min() >= 200 and ids.max() <= 499
 
 
-@pytest.mark.parametrize("size,B,nb", [(1000, 256, 8), (257, 256, 3), (300, 64, 5), (100000, 2048, 2), (5000, 1024, 2)])
+# (duplicates are resolved through an LDS hash table up to B = 2048 and by a scan beyond: (300, 64), (5000, 1024), (9000, 2048)
+#  and (20000, 2048) redraw dozens to hundreds of elements over several rounds, (50000, 4096) takes the scan, 100 and 48 are
+#  not powers of two)
+@pytest.mark.parametrize("size,B,nb", [(1000, 256, 8), (257, 256, 3), (300, 64, 5), (100000, 2048, 2), (5000, 1024, 2),
+                                       (9000, 2048, 3), (20000, 2048, 4), (50000, 4096, 2), (700, 100, 6), (200, 48, 9),
+                                       (1_000_000, 256, 64)])
 def test_replay_sampler_bit_exact_vs_oracle(lib, size, B, nb):
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     buf = ReplayBuffer(size, B, "cuda", 0x1234ABCD5678, state_size=21, action_size=6)
