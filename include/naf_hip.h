@@ -363,7 +363,8 @@ int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1
                              const float* mom, const float* wc, const float* gamma, const float* save_invstd, float* d_W,
                              float* d_gamma, float* d_beta, float* d_bias, float* d_bias2, const float* d_gamma2,
                              const float* d_beta2, float* sumsq_partials, int32_t* step_dev, int B, int H,
-                             const naf_bb_slab_seg_t* segs, int n_segs, void* stream);
+                             const naf_bb_slab_seg_t* segs, int n_segs,
+                             int* fold_flag /* nullable: *fold_flag = 0 (naf_gemm_bn2bwd_t.flag of the bundle launch in front) */, void* stream);
 
 /* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
 /* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is
@@ -392,7 +393,7 @@ typedef struct naf_gemm_l1bwd {
  * columns its A panel touches (all H for a k-contiguous A = dA1's product, its own 32 for a k-major A = dW2's), the k-major blocks
  * of the first block column also write d_gamma / d_beta. The bias gradient of the Linear in front (sum_r dz) is identically zero
  * under a train-mode BatchNorm and is not produced: pass nb = 0 to naf_bb_layer1_bwd_finish, which then writes d_bias2 = 0.
- * Restrictions: H = 256, K / k_split = 256, M and N multiples of 32, npb <= 32 (B = 256 / 512 with 16-row blocks). */
+ * Restrictions: H = 256, K / k_split a multiple of 256, M and N multiples of 32, npb <= 32 (64 with cst, below). */
 typedef struct naf_gemm_bn2bwd {
     const float* z;          /* Z2, same shape and leading dimension as A */
     const float* partials;   /* float2 [npb][H]: (sum dy, sum dy*xhat) per row block (naf_bb_layer2_head's partials_bw) */
@@ -402,6 +403,13 @@ typedef struct naf_gemm_bn2bwd {
     float* d_gamma;          /* [H] out */
     float* d_beta;
     int npb, B, H;
+    /* cst != NULL: the block sums are folded ONCE per launch — the launch's first H / 32 workgroups fold 32 columns each (npb <= 64)
+     * and publish one float4 of constants per column to cst ([H] float4, 16-B aligned, device scratch); the GEMM blocks wait for
+     * *flag (device word) to reach H / 32 (bounded by wall clock; a block that gives up poisons its result with NaN). *flag must be
+     * 0 when the launch starts and is left at H / 32: naf_bb_layer1_bwd_finish(fold_flag) resets it. cst == NULL: every block folds
+     * for itself (npb <= 32). */
+    float* cst;
+    int* flag;
 } naf_gemm_bn2bwd_t;
 typedef struct naf_gemm_desc {
     const float* A;

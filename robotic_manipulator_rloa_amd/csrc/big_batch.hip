@@ -1747,12 +1747,14 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
     const float* __restrict__ gamma, const float* __restrict__ save_invstd, float* __restrict__ d_W,
     float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_bias2,
     const float* __restrict__ d_gamma2, const float* __restrict__ d_beta2, float* __restrict__ sumsq_partials,
-    int32_t* step_dev, int B, int H, const BbSlabs slabs) {
+    int32_t* step_dev, int B, int H, const BbSlabs slabs, int* fold_flag) {
     __shared__ float sQ[BB_THREADS / 64];
     __shared__ float sP[BF_COLS][2][32];
     const int tid = threadIdx.x;
     float sq = 0.f;
     NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 0);
+    // the counter the bundle's folding workgroups raised (naf_gemm_bn2bwd_t.flag): zero again for the next update's launch
+    if (fold_flag && blockIdx.x == 0 && tid == 64) *fold_flag = 0;
     if ((int)blockIdx.x >= slabs.n_finish_blocks) {
         const int rbk = (int)blockIdx.x - slabs.n_finish_blocks;
         const BbSlabSeg& sg = (slabs.n_seg > 1 && rbk >= slabs.seg[1].block0) ? slabs.seg[1] : slabs.seg[0];
@@ -2146,7 +2148,7 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
                                         const float* dz2_col_partials, int nb, const float* mom, const float* wc, const float* gamma, const float* save_invstd,
                                         float* d_W, float* d_gamma, float* d_beta, float* d_bias, float* d_bias2,
                                         const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
-                                        int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, void* stream) {
+                                        int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, int* fold_flag, void* stream) {
     if (!p_slabs || !partials1 || !dz2_col_partials || !mom || !wc || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
         !d_bias || !d_bias2 || nb < 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
         return NAF_ERR_ARG;
@@ -2169,7 +2171,7 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
     const int kp = naf_bb_layer1_bwd_kp(K);
     bb_layer1_bwd_finish_kernel<<<sl.n_finish_blocks + blocks, BB_THREADS, 0, (hipStream_t)stream>>>(
         p_slabs, kp, K, (const float2*)partials1, nb1, dz2_col_partials, nb, mom, wc, gamma, save_invstd, d_W, d_gamma, d_beta, d_bias,
-        d_bias2, d_gamma2, d_beta2, sumsq_partials, step_dev, B, H, sl);
+        d_bias2, d_gamma2, d_beta2, sumsq_partials, step_dev, B, H, sl, fold_flag);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -99,6 +99,14 @@ __device__ __forceinline__ static void naf_buf_st_f1(__amdgpu_buffer_rsrc_t r, u
     if (wt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, lane_off, wave_off, 17);
     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, lane_off, wave_off, 0);
 }
+// sc1 accesses (aux bit 4): the two sides of a hand-off between workgroups of ONE launch (csrc/gemm_bundle.hip, the
+// BatchNorm-backward constants): stores written through to where every XCD reads them, loads that do not take a stale line
+__device__ __forceinline__ static naf_f32x4 naf_buf_f4_sc1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off) {
+    return __builtin_bit_cast(naf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, wave_off, 16));
+}
+__device__ __forceinline__ static void naf_buf_st_f4_sc1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off, naf_f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(naf_u32x4, v), r, lane_off, wave_off, 16);
+}
 __device__ __forceinline__ static void naf_buf_st_f4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned wave_off, naf_f32x4 v, bool wt) {
     if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(naf_u32x4, v), r, lane_off, wave_off, 17);
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(naf_u32x4, v), r, lane_off, wave_off, 0);

@@ -25,6 +25,7 @@ struct GemmDesc {
 struct GemmBundle {
     GemmDesc d[NAF_GEMM_BUNDLE_MAX];
     int n, total_tiles;
+    int n_fold, fold_desc;        // n_fold > 0: the first n_fold workgroups fold the block sums of d[fold_desc].pro ONCE for the launch
 };
 
 // ---- LDS-staged form -----------------------------------------------------------------------------------------------
@@ -307,6 +308,84 @@ __device__ static inline void gemm_bn2bwd_constants(const GemmDesc& D, int m0, i
         }
     }
 }
+// ---- the block sums folded ONCE per launch (pro.cst != NULL) ------------------------------------------------------------------
+// With every block folding for itself a dA1 block reads npb x 256 float2 — 32 KB at 16 row blocks, 128 KB at 64, on top of the
+// 64 KB of its panels — which is why the chain kept the stage-2 launch (3.0 us + a launch boundary) from B = 1024. Instead the
+// first H / 32 workgroups of the launch fold 32 columns each (up to 64 row blocks: the k-major fold above with two blocks per
+// part) and publish one float4 per column — (mean, k1, k1 c1, invstd k1 c2) — to `cst`; the GEMM blocks request their panels,
+// then wait for a counter and read the constants. A dependency INSIDE the launch, so: the folding workgroups are the launch's
+// first (dispatched before any block that waits for them; nothing they do depends on another workgroup), every store of the
+// constants is sc1 and waited for (s_waitcnt vmcnt(0), workgroup barrier) before ONE lane adds to the counter (agent scope),
+// the waiting side polls the counter with sc1 loads from one lane, joins a workgroup barrier, and only then reads the constants,
+// with sc1 loads only (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire: first table row). The wait is
+// bounded by wall clock (0.5 ms): a block that gives up poisons its constants with NaN — the update then fails loudly
+// (params_finite, the parity tests) instead of hanging the GPU. The counter is left at H / 32 and must be zero at the next
+// launch: naf_bb_layer1_bwd_finish, which follows the bundle in every chain, resets it.
+#define GB_FOLD_COLS 32
+__device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P, int f, int tid, float* scratch) {
+    constexpr int NPAIR = GB_FOLD_COLS / 2, PARTS = GB_THREADS / NPAIR, QMAX = 2;
+    static_assert(PARTS * QMAX >= 64, "npb <= 64");
+    const int col0 = f * GB_FOLD_COLS;
+    const int pair = tid % NPAIR, part = tid / NPAIR;
+    const int npb = P.npb, Q = (npb + PARTS - 1) / PARTS, rb0 = part * Q;
+    const __amdgpu_buffer_rsrc_t pb = naf_buf(P.partials + 2 * col0);
+    f32x4 v[QMAX];
+#pragma unroll
+    for (int i = 0; i < QMAX; ++i) {
+        const int rb = rb0 + i;
+        v[i] = naf_buf_f4(pb, 16u * (unsigned)pair, (unsigned)((i < Q && rb < npb) ? rb : 0) * (unsigned)P.H * 8u);
+    }
+    const int c = tid & (GB_FOLD_COLS - 1);
+    const float gm = P.gamma[col0 + c], mean = P.save_mean[col0 + c], invstd = P.save_invstd[col0 + c];
+    f32x4 sm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < QMAX; ++i)
+        if (i < Q && rb0 + i < npb) sm += v[i];
+    ((f32x4*)scratch)[part * NPAIR + pair] = sm;            // [part][column] float2
+    __syncthreads();
+    if (tid < GB_FOLD_COLS) {
+        const float2* sp = (const float2*)scratch;
+        float sdy = 0.f, sdx = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) {
+            sdy += sp[q * GB_FOLD_COLS + c].x;                // (parts past the last block hold zeros)
+            sdx += sp[q * GB_FOLD_COLS + c].y;
+        }
+        const float k1 = gm * invstd, invB = 1.0f / (float)P.B;
+        const f32x4 out = {mean, k1, k1 * (sdy * invB), invstd * (k1 * (sdx * invB))};
+        naf_buf_st_f4_sc1(naf_buf(P.cst), 16u * (unsigned)(col0 + c), 0, out);
+        P.d_gamma[col0 + c] = sdx;                            // d_gamma = sum dy*xhat, d_beta = sum dy (read after the launch)
+        P.d_beta[col0 + c] = sdy;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(P.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the waiting side: constants of the block's columns -> cst (LDS, [4][256] as gemm_bn2bwd_constants leaves them). The caller
+// puts the barrier behind it. `okw`: one LDS word.
+template <bool AK>
+__device__ static inline void gemm_bn2bwd_wait_constants(const naf_gemm_bn2bwd_t& P, int m0, int tid, float* cst, float* okw) {
+    constexpr int NCOL = AK ? 32 : 256;
+    const int col0 = AK ? m0 : 0, nfold = P.H / GB_FOLD_COLS;
+    if (tid == 0) {
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        while (__hip_atomic_load(P.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfold) {
+            if (wall_clock64() - t0 > 50000) { ok = false; break; }      // 0.5 ms at 100 MHz
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *okw = ok ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (tid < NCOL) {
+        f32x4 c = naf_buf_f4_sc1(naf_buf(P.cst), 16u * (unsigned)(col0 + tid), 0);
+        if (*okw == 0.f) c = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        cst[tid] = c[0];
+        cst[256 + tid] = c[1];
+        cst[512 + tid] = c[2];
+        cst[768 + tid] = c[3];
+    }
+}
 // dy -> dz on a staged A panel (whole chunks only). The thread's float4 i covers four consecutive COLUMNS of the operand:
 //   k-contiguous A: row wave + 8 i, columns k0 + 4 lane .. +3;  k-major A: k = (tid >> 3) + 64 i, columns 4 (tid & 7) .. +3 of the block
 template <bool AK>
@@ -343,8 +422,10 @@ int naf_tl_read_gb_wg(int first, long long* out) {
 #define GB_TL_WG(which) do { } while (0)
 int naf_tl_read_gb_wg(int, long long*) { return NAF_ERR_STATE; }
 #endif
+// (timeline marks: the first GEMM block — behind the folding workgroups, if any — and the launch's last)
+#define GB_TL(slot) NAF_TL_FL(g_tl_gb, NAF_TL_GEMM_BUNDLE, slot, (int)blockIdx.x == tl_first, blockIdx.x == gridDim.x - 1)
 template <bool AK, bool BK>
-__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int ks, float* sA, float* sB, float* sQ, float* sC) {
+__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int ks, float* sA, float* sB, float* sQ, float* sC, int tl_first) {
     static_assert(GB_KC == 256 && GB_THREADS == 512, "load_panel_buf's row / k decomposition");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform values on the scalar unit
@@ -363,7 +444,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     // the slabs are added in slab order by the consumer (bb_layer1_bwd_finish's reduce blocks). 64 blocks walking
     // K = 1024 pulled 256 KB each through one CU's L2 port (13.6 us per launch at B = 1024); 256 blocks of K = 256 do not.
     L1bwdRegs epi_regs;
-    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 0);
+    GB_TL(0);
     GB_TL_WG(0);
     if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, !kh, wm, wn, r, g, epi_regs);
     const int kper = D.K / D.k_split, k_lo = ks * kper, k_hi = k_lo + kper;
@@ -383,7 +464,8 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         }
     }
     if (pro) {                                            // the column constants, under the panel loads' latency
-        gemm_bn2bwd_constants<AK>(D, m0, bn, ks, tid, sC, sA);
+        if (D.pro.cst) gemm_bn2bwd_wait_constants<AK>(D.pro, m0, tid, sC, sQ);
+        else gemm_bn2bwd_constants<AK>(D, m0, bn, ks, tid, sC, sA);
         __syncthreads();
     }
     for (int k0 = k_lo; k0 < k_hi; k0 += GB_KC) {
@@ -410,7 +492,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
             }
         }
         __syncthreads();
-        if (k0 == k_lo) NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 1);
+        if (k0 == k_lo) GB_TL(1);
         const int steps = kc >> 4;                                    // macro-steps of 16 k, dealt in contiguous runs
         const int kbeg = (steps * kh / GB_KSPLIT) << 4, kend = (steps * (kh + 1) / GB_KSPLIT) << 4;
 #pragma unroll 4
@@ -424,7 +506,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         }
     }
     f32x4 acc = acc0 + acc1;
-    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 2);
+    GB_TL(2);
     if (kh) *(f32x4*)(sC + (((kh - 1) * 4 + tile) * 64 + lane) * 4) = acc;
     __syncthreads();
     float sq = 0.f;
@@ -446,16 +528,16 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
             }
         }
     }
-    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 3);
+    GB_TL(3);
     if (D.epi.x) gemm_l1bwd_epilogue(D, bm, bn, acc, !kh, wm, wn, r, g, sA, sB, tid, epi_regs);
-    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 4);
+    GB_TL(4);
     if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 tiles)
         sq = naf_sum64(sq);
         if (!kh && lane == 0) sQ[tile] = sq;                  // sQ is touched nowhere else: no barrier in front
         __syncthreads();
         if (tid == 0) D.sumsq[bm * D.tiles_n + bn] = sQ[0] + sQ[1] + sQ[2] + sQ[3];
     }
-    NAF_TL(g_tl_gb, NAF_TL_GEMM_BUNDLE, 5);
+    GB_TL(5);
     GB_TL_WG(1);
 }
 
@@ -467,7 +549,14 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
     __shared__ __attribute__((aligned(16))) float sB[GB_PANEL];
     __shared__ float sQ[4];
     __shared__ __attribute__((aligned(16))) float sC[(GB_KSPLIT - 1) * 4 * 64 * 4];
-    const int t = blockIdx.x;                             // one 32 x 32 block per workgroup
+    int t = blockIdx.x;                                   // one 32 x 32 block per workgroup
+    if (bundle.n_fold) {                                  // (uniform) the launch's first workgroups fold the BatchNorm-backward sums
+        if (__builtin_expect(t < bundle.n_fold, 0)) {
+            gemm_bn2bwd_fold_block(bundle.d[bundle.fold_desc].pro, t, threadIdx.x, sA);
+            return;
+        }
+        t -= bundle.n_fold;
+    }
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < NAF_GEMM_BUNDLE_MAX; ++i)
@@ -486,11 +575,11 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
         if (D.a_kmajor) { bm = xcd; bn = slot; } else { bn = xcd; bm = slot; }
     }
     if (D.a_kmajor) {
-        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, ks, sA, sB, sQ, sC);
-        else gemm_block<true, false>(D, bm, bn, ks, sA, sB, sQ, sC);
+        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
+        else gemm_block<true, false>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
     } else {
-        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, ks, sA, sB, sQ, sC);
-        else gemm_block<false, false>(D, bm, bn, ks, sA, sB, sQ, sC);
+        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
+        else gemm_block<false, false>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
     }
 }
 
@@ -498,6 +587,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     if (!descs || n <= 0 || n > NAF_GEMM_BUNDLE_MAX) return NAF_ERR_ARG;
     GemmBundle b;
     b.n = n;
+    b.n_fold = b.fold_desc = 0;
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         const naf_gemm_desc_t& s = descs[i];
@@ -521,10 +611,14 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (s.pro) {
             const naf_gemm_bn2bwd_t& q = *s.pro;
             if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 ||
-                q.npb > 32 || q.B <= 0 || q.H != 256 || ((s.K / ksn) % GB_KC) != 0 || (s.M & 31) || (s.N & 31) ||
+                q.npb > (q.cst ? 64 : 32) || (q.cst && (!q.flag || ((uintptr_t)q.cst & 15))) || q.B <= 0 || q.H != 256 || ((s.K / ksn) % GB_KC) != 0 || (s.M & 31) || (s.N & 31) ||
                 (s.a_kmajor ? s.M != q.H : s.K != q.H) || ((uintptr_t)q.z & 15) || ((uintptr_t)q.partials & 7))
                 return NAF_ERR_ARG;      // (the A operand's columns are the H features: its M when k-major, its K otherwise)
             d.pro = q;
+            if (q.cst && !b.n_fold) {
+                b.n_fold = q.H / GB_FOLD_COLS;
+                b.fold_desc = i;
+            }
         }
         memset(&d.epi, 0, sizeof(d.epi));
         if (s.epi) {
@@ -539,7 +633,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     }
     for (int i = n; i < NAF_GEMM_BUNDLE_MAX; ++i) b.d[i] = b.d[0];
     b.total_tiles = tiles;
-    gemm_bundle_kernel<<<tiles, GB_THREADS, 0, (hipStream_t)stream>>>(b);
+    gemm_bundle_kernel<<<tiles + b.n_fold, GB_THREADS, 0, (hipStream_t)stream>>>(b);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

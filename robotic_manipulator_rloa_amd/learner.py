@@ -182,7 +182,7 @@ class Learner:
         #   s2 = (with bb + gb + hk) the second stage of layer 2's BatchNorm backward inside the bundle: dY2 becomes dZ2 while the
         #        products that read it stage their operand (csrc/gemm_bundle.hip, naf_gemm_bn2bwd_t) — one launch less; needs
         #        whole 256-k chunks and at most 32 row blocks of backward partials: B = 256, 512
-        spec = os.environ.get("NAF_FUSE", ("bb,gb,hk,ep,s2" if self.B in (256, 512) else "bb,gb,hk,ep") if (self.B >= 256 and self.bb_ok)
+        spec = os.environ.get("NAF_FUSE", ("bb,gb,hk,ep,s2" if self.B <= 1024 else "bb,gb,hk,ep") if (self.B >= 256 and self.bb_ok)
                               else ("l1,b2,gb,s3" if self.B <= 512 else "gb")).lower()
         #   l12 = (with bb; opt-in, NOT default) layer 1 inside GEMM 2's launch: every GEMM-2 workgroup forms its A panel from
         #        the rows itself. Parity-tested; measured 17.0 us against 13.7 us for the two launches it replaces at B = 1024
@@ -197,7 +197,12 @@ class Learner:
             self.fuse -= {"hk"}
         if not {"bb", "gb"} <= self.fuse or self.B % 32:
             self.fuse -= {"ep"}
-        if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or self.B // self.lib.naf_bb_layer2_head_rows(self.B) > 32:
+        #        (round 2, later: the block sums are folded ONCE per launch by the bundle's first workgroups — csrc/gemm_bundle.hip,
+        #        gemm_bn2bwd_fold_block — so up to 64 row blocks: every batch size of the chain. NAF_S2_FOLD=0: every block folds
+        #        for itself, at most 32 row blocks)
+        npb_ = self.B // self.lib.naf_bb_layer2_head_rows(self.B)
+        self.s2_fold_once = (os.environ["NAF_S2_FOLD"] != "0") if "NAF_S2_FOLD" in os.environ else npb_ > 32
+        if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or npb_ > (64 if self.s2_fold_once else 32):
             self.fuse -= {"s2"}
         if self.lay.S > 32:
             self.fuse -= {"l1"}
@@ -357,9 +362,11 @@ class Learner:
             self._pro = None
             if "s2" in self.fuse:        # dY2 -> dZ2 while the two products that read it stage their A panels
                 t2p_, seg_, gp_ = self.theta2.data_ptr(), lay.seg, self.grad.data_ptr()
+                self.bb_cst = torch.zeros(H, 4, **f32) if self.s2_fold_once else None      # per-column constants of the launch
+                self.bb_fold_flag = torch.zeros(1, dtype=torch.int32, device=dev) if self.s2_fold_once else None
                 self._pro = _lib.GemmBn2Bwd(ptr(self.G2[0]), ptr(self.bb_bw2), t2p_ + 4 * seg_["g2"].offset, ptr(self.save_mean[1, 0]),
                                             ptr(self.save_invstd[1, 0]), gp_ + 4 * seg_["g2"].offset, gp_ + 4 * seg_["be2"].offset,
-                                            B // self.hk_rows, B, H)
+                                            B // self.hk_rows, B, H, ptr(self.bb_cst), ptr(self.bb_fold_flag))
             pro_ = _lib.C.addressof(self._pro) if self._pro is not None else None
             self._bundle = (D * 3)(
                 D(ptr(self.dZ2), ptr(self.W2_main), None if self._epi is not None else ptr(self.dA1), None, B, H, H, H, H, H, 0, 1,
@@ -604,7 +611,7 @@ class Learner:
                 gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
                 gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
                 ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, B, H,
-                self._bb_segs, self._bb_nsegs, st), "bb_layer1_bwd_finish")
+                self._bb_segs, self._bb_nsegs, ptr(getattr(self, "bb_fold_flag", None)), st), "bb_layer1_bwd_finish")
         elif "l1" in self.fuse:
             # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written). Data parallel over peer
             # memory: everything but layer 1's gradient is final by now (segments W2 .. Wh of the flat buffer) and goes
