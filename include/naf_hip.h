@@ -364,7 +364,7 @@ int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1
                              float* d_gamma, float* d_beta, float* d_bias, float* d_bias2, const float* d_gamma2,
                              const float* d_beta2, float* sumsq_partials, int32_t* step_dev, int B, int H,
                              const naf_bb_slab_seg_t* segs, int n_segs,
-                             int* fold_flag /* nullable: *fold_flag = 0 (naf_gemm_bn2bwd_t.flag of the bundle launch in front) */, void* stream);
+                             int* fold_epoch /* nullable: *fold_epoch += 1 (naf_gemm_bn2bwd_t.epoch of the bundle launch in front) */, void* stream);
 
 /* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
 /* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is
@@ -404,12 +404,12 @@ typedef struct naf_gemm_bn2bwd {
     float* d_beta;
     int npb, B, H;
     /* cst != NULL: the block sums are folded ONCE per launch — the launch's first H / 32 workgroups fold 32 columns each (npb <= 64)
-     * and publish one float4 of constants per column to cst ([H] float4, 16-B aligned, device scratch); the GEMM blocks wait for
-     * *flag (device word) to reach H / 32 (bounded by wall clock; a block that gives up poisons its result with NaN). *flag must be
-     * 0 when the launch starts and is left at H / 32: naf_bb_layer1_bwd_finish(fold_flag) resets it. cst == NULL: every block folds
-     * for itself (npb <= 32). */
+     * and publish one 16-byte record per column to cst ([H] x 4 floats, 16-B aligned, device scratch that nothing else touches):
+     * (k1 c1, invstd k1 c2, *epoch, 0); the GEMM blocks poll the records of their columns until they carry *epoch (bounded by wall
+     * clock; a thread that gives up poisons its result with NaN). *epoch (device word) must differ from launch to launch:
+     * naf_bb_layer1_bwd_finish(fold_epoch) advances it. cst == NULL: every block folds for itself (npb <= 32). */
     float* cst;
-    int* flag;
+    const int* epoch;
 } naf_gemm_bn2bwd_t;
 typedef struct naf_gemm_desc {
     const float* A;

@@ -247,7 +247,7 @@ class GemmBn2Bwd(C.Structure):
     """naf_gemm_bn2bwd_t (include/naf_hip.h)"""
     _fields_ = [("z", C.c_void_p), ("partials", C.c_void_p), ("gamma", C.c_void_p), ("save_mean", C.c_void_p),
                 ("save_invstd", C.c_void_p), ("d_gamma", C.c_void_p), ("d_beta", C.c_void_p), ("npb", C.c_int), ("B", C.c_int),
-                ("H", C.c_int), ("cst", C.c_void_p), ("flag", C.c_void_p)]
+                ("H", C.c_int), ("cst", C.c_void_p), ("epoch", C.c_void_p)]
 
 
 class GemmL1Bwd(C.Structure):

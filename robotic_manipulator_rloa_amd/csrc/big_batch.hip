@@ -1753,8 +1753,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
     const int tid = threadIdx.x;
     float sq = 0.f;
     NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 0);
-    // the counter the bundle's folding workgroups raised (naf_gemm_bn2bwd_t.flag): zero again for the next update's launch
-    if (fold_flag && blockIdx.x == 0 && tid == 64) *fold_flag = 0;
+    // the launch number the bundle's folded constants are tagged with (naf_gemm_bn2bwd_t.epoch): a new one for the next update
+    if (fold_flag && blockIdx.x == 0 && tid == 64) *fold_flag += 1;
     if ((int)blockIdx.x >= slabs.n_finish_blocks) {
         const int rbk = (int)blockIdx.x - slabs.n_finish_blocks;
         const BbSlabSeg& sg = (slabs.n_seg > 1 && rbk >= slabs.seg[1].block0) ? slabs.seg[1] : slabs.seg[0];

@@ -312,15 +312,16 @@ __device__ static inline void gemm_bn2bwd_constants(const GemmDesc& D, int m0, i
 // With every block folding for itself a dA1 block reads npb x 256 float2 — 32 KB at 16 row blocks, 128 KB at 64, on top of the
 // 64 KB of its panels — which is why the chain kept the stage-2 launch (3.0 us + a launch boundary) from B = 1024. Instead the
 // first H / 32 workgroups of the launch fold 32 columns each (up to 64 row blocks: the k-major fold above with two blocks per
-// part) and publish one float4 per column — (mean, k1, k1 c1, invstd k1 c2) — to `cst`; the GEMM blocks request their panels,
-// then wait for a counter and read the constants. A dependency INSIDE the launch, so: the folding workgroups are the launch's
-// first (dispatched before any block that waits for them; nothing they do depends on another workgroup), every store of the
-// constants is sc1 and waited for (s_waitcnt vmcnt(0), workgroup barrier) before ONE lane adds to the counter (agent scope),
-// the waiting side polls the counter with sc1 loads from one lane, joins a workgroup barrier, and only then reads the constants,
-// with sc1 loads only (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire: first table row). The wait is
-// bounded by wall clock (0.5 ms): a block that gives up poisons its constants with NaN — the update then fails loudly
-// (params_finite, the parity tests) instead of hanging the GPU. The counter is left at H / 32 and must be zero at the next
-// launch: naf_bb_layer1_bwd_finish, which follows the bundle in every chain, resets it.
+// part) and publish ONE 16-byte record per column to `cst`: (k1 c1, invstd k1 c2, epoch, 0) — the two constants that depend on
+// the fold plus the number of this launch (*epoch, a device word that naf_bb_layer1_bwd_finish advances behind every bundle
+// launch). The GEMM blocks request their panels, derive mean and k1 themselves (known since the forward pass), and every
+// thread that needs a column's constants polls THAT record until it carries this launch's epoch: a self-validating 16-byte
+// granule (one sc1 store instruction by one lane; sc1 loads observe it whole), so no flag, no barrier and no atomic sit
+// between the fold and its readers (a counter + flag protocol cost 2.2 us in front of a block's first MFMA, this one ~1).
+// A dependency INSIDE the launch, so: the folding workgroups are the launch's first (dispatched before any block that waits
+// for them; nothing they do depends on another workgroup), and the wait is bounded by wall clock (0.5 ms): a thread that gives
+// up poisons its constants with NaN — the update then fails loudly (params_finite, the parity tests) instead of hanging the
+// GPU. Records and polls are sc1 only (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire).
 #define GB_FOLD_COLS 32
 __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P, int f, int tid, float* scratch) {
     constexpr int NPAIR = GB_FOLD_COLS / 2, PARTS = GB_THREADS / NPAIR, QMAX = 2;
@@ -336,7 +337,8 @@ __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P,
         v[i] = naf_buf_f4(pb, 16u * (unsigned)pair, (unsigned)((i < Q && rb < npb) ? rb : 0) * (unsigned)P.H * 8u);
     }
     const int c = tid & (GB_FOLD_COLS - 1);
-    const float gm = P.gamma[col0 + c], mean = P.save_mean[col0 + c], invstd = P.save_invstd[col0 + c];
+    const float gm = P.gamma[col0 + c], invstd = P.save_invstd[col0 + c];
+    const int epoch = *P.epoch;
     f32x4 sm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < QMAX; ++i)
@@ -352,38 +354,53 @@ __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P,
             sdx += sp[q * GB_FOLD_COLS + c].y;
         }
         const float k1 = gm * invstd, invB = 1.0f / (float)P.B;
-        const f32x4 out = {mean, k1, k1 * (sdy * invB), invstd * (k1 * (sdx * invB))};
+        const f32x4 out = {k1 * (sdy * invB), invstd * (k1 * (sdx * invB)), __builtin_bit_cast(float, epoch), 0.f};
         naf_buf_st_f4_sc1(naf_buf(P.cst), 16u * (unsigned)(col0 + c), 0, out);
         P.d_gamma[col0 + c] = sdx;                            // d_gamma = sum dy*xhat, d_beta = sum dy (read after the launch)
         P.d_beta[col0 + c] = sdy;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(P.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the waiting side: constants of the block's columns -> cst (LDS, [4][256] as gemm_bn2bwd_constants leaves them). The caller
-// puts the barrier behind it. `okw`: one LDS word.
-template <bool AK>
-__device__ static inline void gemm_bn2bwd_wait_constants(const naf_gemm_bn2bwd_t& P, int m0, int tid, float* cst, float* okw) {
-    constexpr int NCOL = AK ? 32 : 256;
-    const int col0 = AK ? m0 : 0, nfold = P.H / GB_FOLD_COLS;
-    if (tid == 0) {
+// puts the barrier behind it.
+__device__ __forceinline__ static f32x4 gemm_bn2bwd_poll_record(__amdgpu_buffer_rsrc_t rb, int col, int epoch) {
+    // (the tag through a scalar copy: __builtin_bit_cast applied to the vector ELEMENT c[2] reads element 0 — clang 22 takes
+    //  the address of the vector for the element reference; seen in the IR, and as a wait that never ended)
+    f32x4 c = naf_buf_f4_sc1(rb, 16u * (unsigned)col, 0);
+    float tagf = c[2];
+    if (__builtin_bit_cast(int, tagf) != epoch) {
         const long long t0 = wall_clock64();
-        bool ok = true;
-        while (__hip_atomic_load(P.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfold) {
-            if (wall_clock64() - t0 > 50000) { ok = false; break; }      // 0.5 ms at 100 MHz
+        while (true) {
             __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");       // a poll: the load below must be issued again every trip (the intrinsic is
+            c = naf_buf_f4_sc1(rb, 16u * (unsigned)col, 0);   // not volatile: hoisted out of the loop, the wait never ended)
+            tagf = c[2];
+            if (__builtin_bit_cast(int, tagf) == epoch) break;
+            if (wall_clock64() - t0 > 50000) {                     // 0.5 ms at 100 MHz: poison, do not hang
+                c[0] = c[1] = __builtin_nanf("");
+                break;
+            }
         }
-        *okw = ok ? 1.f : 0.f;
     }
-    __syncthreads();
+    return c;
+}
+// Every thread that needs a column's constants polls that column's record itself. (Measured against two alternatives, updates/s
+// at B = 256 | 512 | 1024 | 2048: this 30.6k | 28.1k | 23.6k | 16.8k; a few lanes of the first wave polling one record per folding
+// workgroup, a barrier, then the records: 30.2k | 27.8k | 23.5k | 16.2k; a counter the folding workgroups add to after their
+// stores have landed, one polling lane, barrier, records: 30.1k | 27.3k | 24.0k on a box ~2 % faster | 16.4k. Every block folding
+// for itself, the form before: 29.9k | 27.2k | not possible | not possible.)
+template <bool AK>
+__device__ static inline void gemm_bn2bwd_wait_constants(const naf_gemm_bn2bwd_t& P, int m0, int tid, float* cst) {
+    constexpr int NCOL = AK ? 32 : 256;
+    const int col0 = AK ? m0 : 0;
     if (tid < NCOL) {
-        f32x4 c = naf_buf_f4_sc1(naf_buf(P.cst), 16u * (unsigned)(col0 + tid), 0);
-        if (*okw == 0.f) c = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-        cst[tid] = c[0];
-        cst[256 + tid] = c[1];
-        cst[512 + tid] = c[2];
-        cst[768 + tid] = c[3];
+        const int col = col0 + tid;
+        const int epoch = *P.epoch;
+        const float mean = P.save_mean[col], k1 = P.gamma[col] * P.save_invstd[col];
+        const f32x4 c = gemm_bn2bwd_poll_record(naf_buf(P.cst), col, epoch);
+        cst[tid] = mean;
+        cst[256 + tid] = k1;
+        cst[512 + tid] = c[0];
+        cst[768 + tid] = c[1];
     }
 }
 // dy -> dz on a staged A panel (whole chunks only). The thread's float4 i covers four consecutive COLUMNS of the operand:
@@ -464,7 +481,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         }
     }
     if (pro) {                                            // the column constants, under the panel loads' latency
-        if (D.pro.cst) gemm_bn2bwd_wait_constants<AK>(D.pro, m0, tid, sC, sQ);
+        if (D.pro.cst) gemm_bn2bwd_wait_constants<AK>(D.pro, m0, tid, sC);
         else gemm_bn2bwd_constants<AK>(D, m0, bn, ks, tid, sC, sA);
         __syncthreads();
     }
@@ -611,7 +628,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (s.pro) {
             const naf_gemm_bn2bwd_t& q = *s.pro;
             if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 ||
-                q.npb > (q.cst ? 64 : 32) || (q.cst && (!q.flag || ((uintptr_t)q.cst & 15))) || q.B <= 0 || q.H != 256 || ((s.K / ksn) % GB_KC) != 0 || (s.M & 31) || (s.N & 31) ||
+                q.npb > (q.cst ? 64 : 32) || (q.cst && (!q.epoch || ((uintptr_t)q.cst & 15))) || q.B <= 0 || q.H != 256 || ((s.K / ksn) % GB_KC) != 0 || (s.M & 31) || (s.N & 31) ||
                 (s.a_kmajor ? s.M != q.H : s.K != q.H) || ((uintptr_t)q.z & 15) || ((uintptr_t)q.partials & 7))
                 return NAF_ERR_ARG;      // (the A operand's columns are the H features: its M when k-major, its K otherwise)
             d.pro = q;

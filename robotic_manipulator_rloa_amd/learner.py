@@ -201,7 +201,7 @@ class Learner:
         #        gemm_bn2bwd_fold_block — so up to 64 row blocks: every batch size of the chain. NAF_S2_FOLD=0: every block folds
         #        for itself, at most 32 row blocks)
         npb_ = self.B // self.lib.naf_bb_layer2_head_rows(self.B)
-        self.s2_fold_once = (os.environ["NAF_S2_FOLD"] != "0") if "NAF_S2_FOLD" in os.environ else npb_ > 32
+        self.s2_fold_once = os.environ.get("NAF_S2_FOLD", "1") != "0"
         if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or npb_ > (64 if self.s2_fold_once else 32):
             self.fuse -= {"s2"}
         if self.lay.S > 32:
@@ -363,7 +363,7 @@ class Learner:
             if "s2" in self.fuse:        # dY2 -> dZ2 while the two products that read it stage their A panels
                 t2p_, seg_, gp_ = self.theta2.data_ptr(), lay.seg, self.grad.data_ptr()
                 self.bb_cst = torch.zeros(H, 4, **f32) if self.s2_fold_once else None      # per-column constants of the launch
-                self.bb_fold_flag = torch.zeros(1, dtype=torch.int32, device=dev) if self.s2_fold_once else None
+                self.bb_fold_flag = torch.ones(1, dtype=torch.int32, device=dev) if self.s2_fold_once else None   # launch number: finish advances it; never restored
                 self._pro = _lib.GemmBn2Bwd(ptr(self.G2[0]), ptr(self.bb_bw2), t2p_ + 4 * seg_["g2"].offset, ptr(self.save_mean[1, 0]),
                                             ptr(self.save_invstd[1, 0]), gp_ + 4 * seg_["g2"].offset, gp_ + 4 * seg_["be2"].offset,
                                             B // self.hk_rows, B, H, ptr(self.bb_cst), ptr(self.bb_fold_flag))
