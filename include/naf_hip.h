@@ -275,7 +275,29 @@ typedef struct {
     const int32_t* step_dev;
     float inv_world;
     int64_t n, l1_floats;
+    /* rec = 1 (with naf_bb_layer1_adam_fin below): `partials` are n_partials (<= NAF_MAX_NORM_PARTIALS) 16-byte RECORDS
+     * {sum of squares, step number, 0, 0} (16-B aligned), published with sc1 stores by the finish workgroups that ride on the same
+     * launch; the readers poll them for step number *step_dev + step_bias and then read the gradient with sc1 loads. The step
+     * count is advanced by a later launch (naf_bb_layer2_head, step_inc), hence step_bias = 1 there; 0 / 0 otherwise. */
+    int rec, step_bias;
 } naf_adam_args_t;
+/* The finish launch of the PREVIOUS update (every argument as naf_bb_layer1_bwd_finish's) riding on the next update's first launch
+ * beside its optimizer step: naf_bb_layer1_adam_fin = naf_bb_layer1_adam (adam != NULL, adam->rec = 1) whose launch also carries the
+ * finish workgroups. They store their share of the gradient (sc1), wait for the stores, and publish their sum-of-squares record into
+ * sumsq_records (= adam->partials) tagged with the step number; the optimizer workgroups and the layer-1 workgroups wait for all
+ * records. What the finish work READS must not be written by this launch: the caller keeps layer 1's save_invstd / wc in two
+ * buffers by update parity (learner.py). The step count is not advanced here. */
+typedef struct {
+    const float* p_slabs; int K; const float* partials1; int nb1; const float* dz2_col_partials; int nb;
+    const float* mom; const float* wc; const float* gamma; const float* save_invstd;
+    float* d_W; float* d_gamma; float* d_beta; float* d_bias; float* d_bias2; const float* d_gamma2; const float* d_beta2;
+    float* sumsq_records; int B, H; const struct naf_bb_slab_seg* segs; int n_segs; int* fold_epoch;
+} naf_bb_finish_args_t;
+int naf_bb_layer1_adam_fin(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+                           const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
+                           float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
+                           float* save_mean, float* save_invstd, float* wc_out, int B, int H, int nets, float momentum, float eps,
+                           const naf_adam_args_t* adam, const naf_bb_finish_args_t* fin /* nullable (HOST pointers) */, void* stream);
 int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                        const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
                        float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,

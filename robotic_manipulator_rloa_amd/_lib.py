@@ -175,6 +175,8 @@ _PROTOS = {
     "naf_bb_linear_stats": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp],
     "naf_bb_layer1_adam": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i, _f,
                            _f, _vp, _vp],
+    "naf_bb_layer1_adam_fin": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i,
+                               _f, _f, _vp, _vp, _vp],
     "naf_bb_linear_stats_adam": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "naf_bb_bn_relu_heads_partial": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
                                      _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
@@ -240,7 +242,18 @@ class AdamArgs(C.Structure):
     _fields_ = [("theta", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("theta_target", C.c_void_p),
                 ("partials", C.c_void_p), ("n_partials", C.c_int), ("max_norm", C.c_float), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("tau", C.c_float), ("one_minus_tau", C.c_float),
-                ("step_dev", C.c_void_p), ("inv_world", C.c_float), ("n", C.c_int64), ("l1_floats", C.c_int64)]
+                ("step_dev", C.c_void_p), ("inv_world", C.c_float), ("n", C.c_int64), ("l1_floats", C.c_int64),
+                ("rec", C.c_int), ("step_bias", C.c_int)]
+
+
+class BbFinishArgs(C.Structure):
+    """naf_bb_finish_args_t (include/naf_hip.h): the finish work of the previous update riding on naf_bb_layer1_adam_fin"""
+    _fields_ = [("p_slabs", C.c_void_p), ("K", C.c_int), ("partials1", C.c_void_p), ("nb1", C.c_int),
+                ("dz2_col_partials", C.c_void_p), ("nb", C.c_int), ("mom", C.c_void_p), ("wc", C.c_void_p), ("gamma", C.c_void_p),
+                ("save_invstd", C.c_void_p), ("d_W", C.c_void_p), ("d_gamma", C.c_void_p), ("d_beta", C.c_void_p),
+                ("d_bias", C.c_void_p), ("d_bias2", C.c_void_p), ("d_gamma2", C.c_void_p), ("d_beta2", C.c_void_p),
+                ("sumsq_records", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("segs", C.c_void_p), ("n_segs", C.c_int),
+                ("fold_epoch", C.c_void_p)]
 
 
 class GemmBn2Bwd(C.Structure):

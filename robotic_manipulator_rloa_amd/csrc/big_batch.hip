@@ -332,6 +332,164 @@ __device__ static inline void bb_l1_stats_from_moments(const float* sMom, const 
     *var = fmaxf(t, 0.f) / (float)B;
 }
 
+// finish: TWO columns per workgroup, two waves per column, lane = (k of 32, half): the column's p_slabs blocks are dealt in
+// four contiguous runs to the (wave, half) quarters — at most 16 loads per lane, all in flight at once — and meet in a fixed
+// order (quarters 0 + 1 by shuffle, 2 + 3 likewise, the pairs through LDS). The column's block sums are loaded ONE block per
+// lane and folded by an xor-shuffle tree. (The first version had 8 columns x 32 k lanes per workgroup, every lane walking all
+// 64 blocks of three arrays in two rounds and recomputing w_c C with 32 shuffles: 6.6 / 8.4 us at B = 1024 / 2048, most of it
+// waiting — benchmarks/kernel_timeline.py.) w_c C comes from the forward pass (wc, [H][KP]).
+// Behind the finish blocks, workgroups that add the split-K slabs of the bundle's weight gradients (dW2, dWh) in slab order,
+// 1024 floats each — every gradient element leaves this launch final, with its sum-of-squares partial.
+#define BF_COLS 2
+#define BB_MAX_NB1 64
+struct BbSlabSeg {
+    const float* src;       // slab 0; slab s at src + s * stride
+    float* dst;
+    int64_t stride;
+    int n, n_slabs, block0; // n floats (multiple of 4); first reduce block of this segment
+};
+struct BbSlabs {
+    BbSlabSeg seg[2];
+    int n_seg, n_finish_blocks;
+};
+#define BB_MAX_SLABS 8
+struct FinishArgs {
+    const float* p_slabs;
+    int KP, K;
+    const float2* partials1;
+    int NB1;
+    const float* dz2_col_partials;
+    int NB;
+    const float *mom, *wc, *gamma, *save_invstd;
+    float *d_W, *d_gamma, *d_beta, *d_bias, *d_bias2;
+    const float *d_gamma2, *d_beta2;
+    float* sumsq_partials;       // plain: one float per workgroup; tagged (tag != 0): one 16-byte record per workgroup
+    int32_t* step_dev;
+    int B, H;
+    BbSlabs slabs;
+    int* fold_flag;
+    int n_blocks;                // finish blocks + slab-reduce blocks
+};
+// stores of the gradient: plain, or sc1 when the readers sit in the SAME launch (tag != 0: bb_layer1_kernel carrying the finish
+// work of the previous update — the optimizer workgroups and the layer-1 workgroups beside it wait for this workgroup's record)
+__device__ __forceinline__ static void bf_st1(float* p, float v, bool sc1) {
+    if (sc1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+// One workgroup (BB_THREADS threads) of the finish work. tag == 0: as a launch of its own (plain stores, plain partial, step
+// count advanced). tag != 0: riding on the next update's first launch — every gradient store sc1 and waited for in front of the
+// workgroup's barrier, then ONE lane publishes the 16-byte record {sum of squares, tag, 0, 0}; the step count is left alone
+// (its readers sit in this launch: AdamArgs.step_bias).
+__device__ static inline void bb_finish_block(const FinishArgs& F, int block, int tid, float* sQ, float (*sP)[2][32], int tag) {
+    // (no FP contraction: this body is compiled into two kernels — the launch of its own and bb_layer1_kernel — and must round the
+    //  same way in both; left to the optimizer, the two instances fused different multiplies into their adds)
+#pragma clang fp contract(off)
+    const bool sc1 = tag != 0;
+    float sq = 0.f;
+    // the launch number the bundle's folded constants are tagged with (naf_gemm_bn2bwd_t.epoch): a new one for the next update
+    if (F.fold_flag && block == 0 && tid == 64) *F.fold_flag += 1;
+    if (block >= F.slabs.n_finish_blocks) {
+        const int rbk = block - F.slabs.n_finish_blocks;
+        const BbSlabSeg& sg = (F.slabs.n_seg > 1 && rbk >= F.slabs.seg[1].block0) ? F.slabs.seg[1] : F.slabs.seg[0];
+        const int i = (rbk - sg.block0) * (BB_THREADS * 4) + tid * 4;
+        if (i < sg.n) {
+            float4 v[BB_MAX_SLABS];
+#pragma unroll
+            for (int s_ = 0; s_ < BB_MAX_SLABS; ++s_)
+                v[s_] = *(const float4*)(sg.src + (int64_t)(s_ < sg.n_slabs ? s_ : 0) * sg.stride + i);
+            float4 a = v[0];
+#pragma unroll
+            for (int s_ = 1; s_ < BB_MAX_SLABS; ++s_)
+                if (s_ < sg.n_slabs) { a.x += v[s_].x; a.y += v[s_].y; a.z += v[s_].z; a.w += v[s_].w; }
+            if (sc1) naf_buf_st_f4_sc1(naf_buf(sg.dst), 4u * (unsigned)i, 0, (f32x4){a.x, a.y, a.z, a.w});
+            else *(float4*)(sg.dst + i) = a;
+            sq = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        }
+    } else {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int cl = wave >> 1, wq = wave & 1, k = lane & 31, hf = lane >> 5;
+        const int col = block * BF_COLS + cl;
+        const bool col_on = col < F.H;
+        const int colc = col_on ? col : F.H - 1;
+        const int kc = k < F.KP ? k : 0;
+        // everything requested up front, branch-free (indices clamped, sums predicated)
+        const int Q = (F.NB1 + 3) >> 2, rb0 = (2 * wq + hf) * Q;     // this quarter's run of blocks
+        float pv[BB_MAX_NB1 / 4];
+#pragma unroll
+        for (int i = 0; i < BB_MAX_NB1 / 4; ++i) {
+            const int rb = rb0 + i;
+            pv[i] = F.p_slabs[((int64_t)((i < Q && rb < F.NB1) ? rb : 0) * F.H + colc) * F.KP + kc];
+        }
+        // block sums: wave 0 of the column takes F.partials1 (block = lane), wave 1 the layer-2 bias partials
+        float2 av = make_float2(0.f, 0.f);
+        float dv = 0.f;
+        if (wq == 0) av = F.partials1[(int64_t)(lane < F.NB1 ? lane : 0) * F.H + colc];
+        else dv = F.dz2_col_partials[(int64_t)(lane < F.NB ? lane : 0) * F.H + colc];
+        const float invstd = F.save_invstd[colc], gm = F.gamma[colc];
+        const float sxk = F.mom[kc], wck = F.wc[(int64_t)colc * F.KP + kc];
+        float g2 = 0.f, b2 = 0.f;
+        if (F.d_gamma2) {
+            g2 = F.d_gamma2[colc];                           // written by bb_bn_bwd_stage2, an earlier launch
+            b2 = F.d_beta2[colc];
+        }
+        float P = 0.f;
+#pragma unroll
+        for (int i = 0; i < BB_MAX_NB1 / 4; ++i) P += (i < Q && rb0 + i < F.NB1) ? pv[i] : 0.f;
+        {
+            const float other = __shfl_xor(P, 32);          // quarters (0, 1) of wave 0, (2, 3) of wave 1: lower + upper
+            P = hf ? other + P : P + other;
+        }
+        if (hf == 0) sP[cl][wq][k] = P;
+        float sdy = (wq == 0 && lane < F.NB1) ? av.x : 0.f, sdx = (wq == 0 && lane < F.NB1) ? av.y : 0.f;
+        float db2 = (wq == 1 && lane < F.NB) ? dv : 0.f;
+        sdy = naf_sum64(sdy);
+        sdx = naf_sum64(sdx);
+        db2 = naf_sum64(db2);
+        __syncthreads();
+            if (col_on) {
+            if (wq == 0) {
+                if (hf == 0 && k < F.K) {
+                    const float invB = 1.0f / (float)F.B;
+                    const float Pt = sP[cl][0][k] + sP[cl][1][k];
+                    const float g = (gm * invstd) * (Pt - (sdy * invB) * sxk - (sdx * invB) * (invstd * wck));
+                    bf_st1(&F.d_W[(int64_t)col * F.K + k], g, sc1);
+                    sq = g * g;
+                } else if (lane == 32) {                      // F.d_gamma = sum dy*xhat, F.d_beta = sum dy; F.d_bias = 0 (see above)
+                    bf_st1(&F.d_gamma[col], sdx, sc1);
+                    bf_st1(&F.d_beta[col], sdy, sc1);
+                    bf_st1(&F.d_bias[col], 0.f, sc1);
+                    sq = sdx * sdx + sdy * sdy;
+                }
+            } else if (lane == 0) {
+                bf_st1(&F.d_bias2[col], db2, sc1);
+                sq = db2 * db2;
+            } else if (lane == 1) {
+                sq = g2 * g2 + b2 * b2;
+            }
+        }
+    }
+    if (F.sumsq_partials) {
+        if (sc1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave, in front of the barriers of the sum
+        const float tot = block_sum_to_thread0<BB_THREADS, true>(sq, sQ, tid);
+        if (tid == 0) {
+            if (sc1) {
+                naf_buf_st_f4_sc1(naf_buf(F.sumsq_partials), 16u * (unsigned)block, 0, (f32x4){tot, __builtin_bit_cast(float, tag), 0.f, 0.f});
+            } else {
+                F.sumsq_partials[block] = tot;
+                if (block == 0 && F.step_dev) *F.step_dev += 1;   // read by the NEXT launch (Adam) only
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(const FinishArgs F) {
+    __shared__ float sQ[BB_THREADS / 64];
+    __shared__ float sP[BF_COLS][2][32];
+    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 0);
+    bb_finish_block(F, (int)blockIdx.x, (int)threadIdx.x, sQ, sP, 0);
+    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 3);
+}
+
 // layer 1 forward for `nets` networks: statistics from the moments, z tile, normalise, ReLU -> out
 // Prologue: every global operand — the row tile, the 64 columns' weights (ONE contiguous run of 64 K floats, read as float4
 // and scattered to [k][column] in LDS), the moments record, the per-column parameters — is requested before the first LDS
@@ -349,7 +507,7 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     int64_t param_net_stride, const float* __restrict__ mom, float* __restrict__ running_mean,
     float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out, int64_t out_net_stride, int ldo,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ wc_out, int B, int H, float momentum,
-    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4) {
+    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4, int n_adam, const FinishArgs fin) {
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
     constexpr int XN = (BB_ROWS * K4 + BB_THREADS - 1) / BB_THREADS;           // float4 of the row tile per thread: 2
     constexpr int MN = (REC / 4 + BB_THREADS - 1) / BB_THREADS;                // of the moments record: 1 or 2
@@ -359,12 +517,28 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     __shared__ float sStat[4][BB_COLS];     // mean, invstd, gamma, beta of this workgroup's columns
     __shared__ AdamScalars shA;
     __shared__ __attribute__((aligned(16))) float sPar[3][BB_COLS];   // ADAM: b, gamma, beta of the columns as the step leaves them
+    __shared__ float sQf[BB_THREADS / 64];                            // (riding finish work)
+    __shared__ float sPf[BF_COLS][2][32];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const int widx = blockIdx.x;
-    if (ADAM && __builtin_expect(widx >= n_main, 0)) {     // (unlikely: the riding step's code sits behind the kernel's own)
-        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 11, widx == n_main, widx == (int)gridDim.x - 1);    // (raw slots 11, 12: the riding step)
-        adam_block<2 * BB_THREADS>(ad, (size_t)l1_4, (size_t)n4, widx - n_main, (int)gridDim.x - n_main, &shA, tid, true);
-        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 12, widx == n_main, widx == (int)gridDim.x - 1);
+    // grid: [riding finish work of the previous update | riding optimizer step | this kernel's own workgroups] — the producers of
+    // the records FIRST, so that they are dispatched before anything that waits for them, whatever the occupancy
+    const int n_ride = ADAM ? fin.n_blocks + n_adam : 0;
+    const int widx = (int)blockIdx.x - n_ride;             // >= 0: a layer-1 workgroup
+    if (ADAM && __builtin_expect(widx < 0, 0)) {           // (unlikely: the riding code sits behind the kernel's own)
+        const int r = (int)blockIdx.x;
+        if (r >= fin.n_blocks) {
+            const int ra = r - fin.n_blocks;
+            NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 11, ra == 0, ra == n_adam - 1);    // (raw slots 11, 12: the riding step)
+            adam_block<2 * BB_THREADS>(ad, (size_t)l1_4, (size_t)n4, ra, n_adam, &shA, tid, true);
+            NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 12, ra == 0, ra == n_adam - 1);
+            return;
+        }
+        // the finish work of the PREVIOUS update (bb_finish_block, 256 threads: waves 4 .. 7 have nothing to do here), its
+        // records tagged with the step number the readers beside it wait for
+        if (tid >= BB_THREADS) return;
+        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 13, r == 0, r == fin.n_blocks - 1);    // (raw slots 13, 14: riding finish)
+        bb_finish_block(fin, r, tid, sQf, sPf, *ad.step_dev + ad.step_bias);
+        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 14, r == 0, r == fin.n_blocks - 1);
         return;
     }
     const int gx = B / BB_ROWS, gy = H / BB_COLS;
@@ -430,13 +604,15 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     AdamFly4 fw, fp;
     f32x4 pcur;
     AdamPrefetch apf;
+    int64_t ofw = 0, ofp = 0;                                 // flat offsets of this thread's two float4 (main network)
     if (ADAM) {
-        const int64_t oW = (W - ad.theta) + (int64_t)col0 * K;
-        fw = adam_fly_load4(ad, oW + 4 * (tid < wn4 ? tid : 0), tgt);
+        ofw = (W - ad.theta) + (int64_t)col0 * K + 4 * (tid < wn4 ? tid : 0);
+        fw = adam_fly_load4(ad, ofw, tgt);
         const int jc = pj >= 0 ? pj : 0, c4 = 4 * (jc & (BB_COLS / 4 - 1));
         const float* pb = jc < BB_COLS / 4 ? bias : jc < BB_COLS / 2 ? gamma : beta;
         pcur = *(const f32x4*)(pb + po + col0 + c4);
-        fp = adam_fly_load4(ad, (pb - ad.theta) + col0 + c4, tgt);
+        ofp = (pb - ad.theta) + col0 + c4;
+        fp = adam_fly_load4(ad, ofp, tgt);
         apf = adam_prefetch(ad, tid);
     }
     // rows k >= K of the weight tile meet the padding columns of the row tile: zero
@@ -466,6 +642,10 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
         __syncthreads();
         L1_TL(9);
         const AdamScalars sc = shA;
+        if (ad.rec) {                                         // the records are in (adam_prefetch waited): the gradient now, sc1
+            fw.g = adam_fly_load_g4(ad, ofw);
+            fp.g = adam_fly_load_g4(ad, ofp);
+        }
         if (tid < wn4) wv[0] = adam_fly_apply4(ad, sc, fw, wv[0], tgt);
         if (pj >= 0) *(f32x4*)(&sPar[0][0] + 4 * pj) = adam_fly_apply4(ad, sc, fp, pcur, tgt);
         L1_TL(10);
@@ -1720,132 +1900,6 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
     }
 }
 
-// finish: TWO columns per workgroup, two waves per column, lane = (k of 32, half): the column's p_slabs blocks are dealt in
-// four contiguous runs to the (wave, half) quarters — at most 16 loads per lane, all in flight at once — and meet in a fixed
-// order (quarters 0 + 1 by shuffle, 2 + 3 likewise, the pairs through LDS). The column's block sums are loaded ONE block per
-// lane and folded by an xor-shuffle tree. (The first version had 8 columns x 32 k lanes per workgroup, every lane walking all
-// 64 blocks of three arrays in two rounds and recomputing w_c C with 32 shuffles: 6.6 / 8.4 us at B = 1024 / 2048, most of it
-// waiting — benchmarks/kernel_timeline.py.) w_c C comes from the forward pass (wc, [H][KP]).
-// Behind the finish blocks, workgroups that add the split-K slabs of the bundle's weight gradients (dW2, dWh) in slab order,
-// 1024 floats each — every gradient element leaves this launch final, with its sum-of-squares partial.
-#define BF_COLS 2
-#define BB_MAX_NB1 64
-struct BbSlabSeg {
-    const float* src;       // slab 0; slab s at src + s * stride
-    float* dst;
-    int64_t stride;
-    int n, n_slabs, block0; // n floats (multiple of 4); first reduce block of this segment
-};
-struct BbSlabs {
-    BbSlabSeg seg[2];
-    int n_seg, n_finish_blocks;
-};
-#define BB_MAX_SLABS 8
-__global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(
-    const float* __restrict__ p_slabs, int KP, int K, const float2* __restrict__ partials1, int NB1,
-    const float* __restrict__ dz2_col_partials, int NB, const float* __restrict__ mom, const float* __restrict__ wc,
-    const float* __restrict__ gamma, const float* __restrict__ save_invstd, float* __restrict__ d_W,
-    float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_bias, float* __restrict__ d_bias2,
-    const float* __restrict__ d_gamma2, const float* __restrict__ d_beta2, float* __restrict__ sumsq_partials,
-    int32_t* step_dev, int B, int H, const BbSlabs slabs, int* fold_flag) {
-    __shared__ float sQ[BB_THREADS / 64];
-    __shared__ float sP[BF_COLS][2][32];
-    const int tid = threadIdx.x;
-    float sq = 0.f;
-    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 0);
-    // the launch number the bundle's folded constants are tagged with (naf_gemm_bn2bwd_t.epoch): a new one for the next update
-    if (fold_flag && blockIdx.x == 0 && tid == 64) *fold_flag += 1;
-    if ((int)blockIdx.x >= slabs.n_finish_blocks) {
-        const int rbk = (int)blockIdx.x - slabs.n_finish_blocks;
-        const BbSlabSeg& sg = (slabs.n_seg > 1 && rbk >= slabs.seg[1].block0) ? slabs.seg[1] : slabs.seg[0];
-        const int i = (rbk - sg.block0) * (BB_THREADS * 4) + tid * 4;
-        if (i < sg.n) {
-            float4 v[BB_MAX_SLABS];
-#pragma unroll
-            for (int s_ = 0; s_ < BB_MAX_SLABS; ++s_)
-                v[s_] = *(const float4*)(sg.src + (int64_t)(s_ < sg.n_slabs ? s_ : 0) * sg.stride + i);
-            float4 a = v[0];
-#pragma unroll
-            for (int s_ = 1; s_ < BB_MAX_SLABS; ++s_)
-                if (s_ < sg.n_slabs) { a.x += v[s_].x; a.y += v[s_].y; a.z += v[s_].z; a.w += v[s_].w; }
-            *(float4*)(sg.dst + i) = a;
-            sq = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-        }
-    } else {
-        const int lane = tid & 63, wave = tid >> 6;
-        const int cl = wave >> 1, wq = wave & 1, k = lane & 31, hf = lane >> 5;
-        const int col = blockIdx.x * BF_COLS + cl;
-        const bool col_on = col < H;
-        const int colc = col_on ? col : H - 1;
-        const int kc = k < KP ? k : 0;
-        // everything requested up front, branch-free (indices clamped, sums predicated)
-        const int Q = (NB1 + 3) >> 2, rb0 = (2 * wq + hf) * Q;     // this quarter's run of blocks
-        float pv[BB_MAX_NB1 / 4];
-#pragma unroll
-        for (int i = 0; i < BB_MAX_NB1 / 4; ++i) {
-            const int rb = rb0 + i;
-            pv[i] = p_slabs[((int64_t)((i < Q && rb < NB1) ? rb : 0) * H + colc) * KP + kc];
-        }
-        // block sums: wave 0 of the column takes partials1 (block = lane), wave 1 the layer-2 bias partials
-        float2 av = make_float2(0.f, 0.f);
-        float dv = 0.f;
-        if (wq == 0) av = partials1[(int64_t)(lane < NB1 ? lane : 0) * H + colc];
-        else dv = dz2_col_partials[(int64_t)(lane < NB ? lane : 0) * H + colc];
-        const float invstd = save_invstd[colc], gm = gamma[colc];
-        const float sxk = mom[kc], wck = wc[(int64_t)colc * KP + kc];
-        float g2 = 0.f, b2 = 0.f;
-        if (d_gamma2) {
-            g2 = d_gamma2[colc];                           // written by bb_bn_bwd_stage2, an earlier launch
-            b2 = d_beta2[colc];
-        }
-        float P = 0.f;
-#pragma unroll
-        for (int i = 0; i < BB_MAX_NB1 / 4; ++i) P += (i < Q && rb0 + i < NB1) ? pv[i] : 0.f;
-        {
-            const float other = __shfl_xor(P, 32);          // quarters (0, 1) of wave 0, (2, 3) of wave 1: lower + upper
-            P = hf ? other + P : P + other;
-        }
-        if (hf == 0) sP[cl][wq][k] = P;
-        float sdy = (wq == 0 && lane < NB1) ? av.x : 0.f, sdx = (wq == 0 && lane < NB1) ? av.y : 0.f;
-        float db2 = (wq == 1 && lane < NB) ? dv : 0.f;
-        sdy = naf_sum64(sdy);
-        sdx = naf_sum64(sdx);
-        db2 = naf_sum64(db2);
-        __syncthreads();
-        NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 1);
-        if (col_on) {
-            if (wq == 0) {
-                if (hf == 0 && k < K) {
-                    const float invB = 1.0f / (float)B;
-                    const float Pt = sP[cl][0][k] + sP[cl][1][k];
-                    const float g = (gm * invstd) * (Pt - (sdy * invB) * sxk - (sdx * invB) * (invstd * wck));
-                    d_W[(int64_t)col * K + k] = g;
-                    sq = g * g;
-                } else if (lane == 32) {                      // d_gamma = sum dy*xhat, d_beta = sum dy; d_bias = 0 (see above)
-                    d_gamma[col] = sdx;
-                    d_beta[col] = sdy;
-                    d_bias[col] = 0.f;
-                    sq = sdx * sdx + sdy * sdy;
-                }
-            } else if (lane == 0) {
-                d_bias2[col] = db2;
-                sq = db2 * db2;
-            } else if (lane == 1) {
-                sq = g2 * g2 + b2 * b2;
-            }
-        }
-    }
-    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 2);
-    if (sumsq_partials) {
-        const float tot = block_sum_to_thread0<BB_THREADS, true>(sq, sQ, tid);
-        if (tid == 0) {
-            sumsq_partials[blockIdx.x] = tot;
-            if (blockIdx.x == 0 && step_dev) *step_dev += 1;   // read by the NEXT launch (Adam) only
-        }
-    }
-    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 3);
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
@@ -1885,11 +1939,43 @@ static bool bb_adam_setup(const naf_adam_args_t* adam, AdamArgs& ad, int64_t& l1
 }
 static int bb_adam_blocks(int64_t lo4, int64_t hi4, int threads) { return (int)((hi4 - lo4 + threads - 1) / threads); }
 
-extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+// naf_bb_finish_args_t -> FinishArgs (checks as naf_bb_layer1_bwd_finish)
+static int bb_finish_setup(const naf_bb_finish_args_t& a, FinishArgs& F) {
+    if (!a.p_slabs || !a.partials1 || !a.dz2_col_partials || !a.mom || !a.wc || !a.gamma || !a.save_invstd || !a.d_W || !a.d_gamma ||
+        !a.d_beta || !a.d_bias || !a.d_bias2 || a.nb < 0 || a.nb > BB_MAX_NB || a.nb1 <= 0 || a.nb1 > BB_MAX_NB1 || a.H <= 0 ||
+        a.B <= 0 || a.K <= 0 || a.K > 32)
+        return NAF_ERR_ARG;
+    if (a.sumsq_records && (!a.d_gamma2 || !a.d_beta2)) return NAF_ERR_ARG;
+    if (a.n_segs < 0 || a.n_segs > 2 || (a.n_segs && !a.segs)) return NAF_ERR_ARG;
+    BbSlabs sl;
+    memset(&sl, 0, sizeof(sl));
+    sl.n_finish_blocks = (a.H + BF_COLS - 1) / BF_COLS;
+    sl.n_seg = a.n_segs;
+    int blocks = 0;
+    for (int i = 0; i < a.n_segs; ++i) {
+        const naf_bb_slab_seg_t& g = a.segs[i];
+        if (!g.src || !g.dst || g.n <= 0 || (g.n & 3) || g.n_slabs < 1 || g.n_slabs > BB_MAX_SLABS || g.stride < g.n || (g.stride & 3) ||
+            (((uintptr_t)g.src | (uintptr_t)g.dst) & 15) != 0)
+            return NAF_ERR_ARG;
+        sl.seg[i].src = g.src; sl.seg[i].dst = g.dst; sl.seg[i].stride = g.stride;
+        sl.seg[i].n = g.n; sl.seg[i].n_slabs = g.n_slabs; sl.seg[i].block0 = blocks;
+        blocks += (g.n + BB_THREADS * 4 - 1) / (BB_THREADS * 4);
+    }
+    memset(&F, 0, sizeof(F));
+    F.p_slabs = a.p_slabs; F.KP = naf_bb_layer1_bwd_kp(a.K); F.K = a.K; F.partials1 = (const float2*)a.partials1; F.NB1 = a.nb1;
+    F.dz2_col_partials = a.dz2_col_partials; F.NB = a.nb; F.mom = a.mom; F.wc = a.wc; F.gamma = a.gamma; F.save_invstd = a.save_invstd;
+    F.d_W = a.d_W; F.d_gamma = a.d_gamma; F.d_beta = a.d_beta; F.d_bias = a.d_bias; F.d_bias2 = a.d_bias2; F.d_gamma2 = a.d_gamma2;
+    F.d_beta2 = a.d_beta2; F.sumsq_partials = a.sumsq_records; F.step_dev = nullptr; F.B = a.B; F.H = a.H; F.slabs = sl;
+    F.fold_flag = a.fold_epoch; F.n_blocks = sl.n_finish_blocks + blocks;
+    return NAF_OK;
+}
+
+extern "C" int naf_bb_layer1_adam_fin(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                                   const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
                                   float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
                                   int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
-                                  int nets, float momentum, float eps, const naf_adam_args_t* adam, void* stream) {
+                                  int nets, float momentum, float eps, const naf_adam_args_t* adam, const naf_bb_finish_args_t* fin,
+                                  void* stream) {
     if (!x || !W || !bias || !mom || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd ||
         !bb_shape_ok(B, H) || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4 || ldo < H || (ldo & 3))
         return NAF_ERR_ARG;
@@ -1909,18 +1995,40 @@ extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx,
             beta + H > hi || (nets == 2 && adam->theta_target != adam->theta + param_net_stride))
             return NAF_ERR_ARG;
     }
+    // the finish work of the previous update riding along: its records are what the optimizer step waits for
+    FinishArgs F;
+    memset(&F, 0, sizeof(F));
+    if (fin) {
+        if (!adam || !adam->rec || !fin->sumsq_records || fin->sumsq_records != adam->partials || ((uintptr_t)fin->sumsq_records & 15))
+            return NAF_ERR_ARG;
+        const int rc = bb_finish_setup(*fin, F);
+        if (rc != NAF_OK) return rc;
+        if (F.n_blocks != adam->n_partials) return NAF_ERR_ARG;      // one record per finish workgroup, all of them awaited
+        // (what the finish work reads must not be what this launch writes)
+        if (fin->save_invstd == save_invstd || fin->wc == wc_out) return NAF_ERR_ARG;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int n_main = (B / BB_ROWS) * (H / BB_COLS) * nets;
-    const int grid = n_main + (adam ? bb_adam_blocks(l1_4, n4, 2 * BB_THREADS) : 0);
+    const int n_adam = adam ? bb_adam_blocks(l1_4, n4, 2 * BB_THREADS) : 0;
+    const int grid = n_main + n_adam + F.n_blocks;
 #define BB_L1(K4V, AD)                                                                                                       \
     bb_layer1_kernel<K4V, AD><<<grid, (AD) ? 2 * BB_THREADS : BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
                                                            running_mean, running_var, stat_net_stride, out, out_net_stride, ldo, \
-                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4)
+                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4, n_adam, F)
     if (k4d == 6) { if (adam) BB_L1(6, true); else BB_L1(6, false); }
     else { if (adam) BB_L1(8, true); else BB_L1(8, false); }
 #undef BB_L1
     NAF_CHECK_LAUNCH();
     return NAF_OK;
+}
+extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+                                  const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
+                                  float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
+                                  int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
+                                  int nets, float momentum, float eps, const naf_adam_args_t* adam, void* stream) {
+    return naf_bb_layer1_adam_fin(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, running_mean, running_var,
+                                  stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, wc_out, B, H, nets, momentum,
+                                  eps, adam, nullptr, stream);
 }
 extern "C" int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                              const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
@@ -2149,29 +2257,13 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
                                         float* d_W, float* d_gamma, float* d_beta, float* d_bias, float* d_bias2,
                                         const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
                                         int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, int* fold_flag, void* stream) {
-    if (!p_slabs || !partials1 || !dz2_col_partials || !mom || !wc || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
-        !d_bias || !d_bias2 || nb < 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
-        return NAF_ERR_ARG;
-    if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
-    if (n_segs < 0 || n_segs > 2 || (n_segs && !segs)) return NAF_ERR_ARG;
-    BbSlabs sl;
-    memset(&sl, 0, sizeof(sl));
-    sl.n_finish_blocks = (H + BF_COLS - 1) / BF_COLS;
-    sl.n_seg = n_segs;
-    int blocks = 0;
-    for (int i = 0; i < n_segs; ++i) {
-        const naf_bb_slab_seg_t& g = segs[i];
-        if (!g.src || !g.dst || g.n <= 0 || (g.n & 3) || g.n_slabs < 1 || g.n_slabs > BB_MAX_SLABS || g.stride < g.n || (g.stride & 3) ||
-            (((uintptr_t)g.src | (uintptr_t)g.dst) & 15) != 0)
-            return NAF_ERR_ARG;
-        sl.seg[i].src = g.src; sl.seg[i].dst = g.dst; sl.seg[i].stride = g.stride;
-        sl.seg[i].n = g.n; sl.seg[i].n_slabs = g.n_slabs; sl.seg[i].block0 = blocks;
-        blocks += (g.n + BB_THREADS * 4 - 1) / (BB_THREADS * 4);
-    }
-    const int kp = naf_bb_layer1_bwd_kp(K);
-    bb_layer1_bwd_finish_kernel<<<sl.n_finish_blocks + blocks, BB_THREADS, 0, (hipStream_t)stream>>>(
-        p_slabs, kp, K, (const float2*)partials1, nb1, dz2_col_partials, nb, mom, wc, gamma, save_invstd, d_W, d_gamma, d_beta, d_bias,
-        d_bias2, d_gamma2, d_beta2, sumsq_partials, step_dev, B, H, sl, fold_flag);
+    const naf_bb_finish_args_t a = {p_slabs, K, partials1, nb1, dz2_col_partials, nb, mom, wc, gamma, save_invstd, d_W, d_gamma, d_beta,
+                                    d_bias, d_bias2, d_gamma2, d_beta2, sumsq_partials, B, H, segs, n_segs, fold_flag};
+    FinishArgs F;
+    const int rc = bb_finish_setup(a, F);
+    if (rc != NAF_OK) return rc;
+    F.step_dev = step_dev;
+    bb_layer1_bwd_finish_kernel<<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

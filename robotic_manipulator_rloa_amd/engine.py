@@ -106,7 +106,7 @@ class TrainChunk:
         d = self.L.defer_ok
         for k in range(self.U):
             self.L.learn_rows(self.batch[k], self.loss_parts[k], None if self.moments is None else self.moments[k],
-                              pending=d and k > 0, defer=d and k < self.U - 1)
+                              pending=d and k > 0, defer=d and k < self.U - 1, chain_pos=k)
 
     def _body(self) -> None:
         self._sample_gather()

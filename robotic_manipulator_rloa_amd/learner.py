@@ -256,10 +256,20 @@ class Learner:
         self.defer_ok = ("bb" in self.fuse and "l12" not in self.fuse and "f3" not in self.fuse
                          and ((self.fold_norm and self.world_size == 1) or self.xgmi is not None)
                          and os.environ.get("NAF_DEFER_ADAM", "1") != "0")
+        # ... and, OPT-IN (NAF_MERGE_FINISH=1), the finish launch of update k rides there too (csrc/big_batch.hip, bb_finish_block):
+        # its workgroups publish their sum-of-squares partials as tagged records which the optimizer workgroups and the layer-1
+        # workgroups of that launch wait for — four launches per update at B <= 1024, bit-identical (tested). Measured: 31.4k
+        # against 31.1k updates/s at B = 256, 23.4k / 23.5k at 1024, 16.6k / 16.5-16.9k at 2048 on the same boxes — the launch
+        # and its boundary (4.2 us) are traded for sc1 scalar stores in the finish work (+0.9 us), 1.6 us until the readers see
+        # the last record and a dependent round trip for the gradient (0.8 us): not the default.
+        self.merge_finish = (self.defer_ok and self.world_size == 1 and self.fold_norm and {"ep", "hk", "gb"} <= self.fuse
+                             and self.n_partials_fold <= 256 and os.environ.get("NAF_MERGE_FINISH", "0") == "1")
+        self.partial_recs = torch.zeros(max(self.n_partials_fold, 1), 4, **f32)
+        self._pending_fin = None
         self._adam_args = _lib.AdamArgs(
             ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]), ptr(self.partials),
             self.n_partials, MAX_GRAD_NORM, self.lr, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau, float(1.0 - self.tau),
-            ptr(self.step_dev), 1.0 / self.world_size, P, lay.seg["W2"].offset)
+            ptr(self.step_dev), 1.0 / self.world_size, P, lay.seg["W2"].offset, 0, 0)
         self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
         self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
         self.n_loss_wg = (B + 7) // 8                  # loss partials per update (NAF_HEAD_SPB samples per workgroup)
@@ -290,6 +300,12 @@ class Learner:
             self.mom_floats = self.lib.naf_bb_moments_floats(lay.S)
             self.bb_mom = torch.zeros(2, self.mom_floats, **f32)
             self.bb_wc = torch.zeros(H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # w_c C of the main net, forward -> finish
+            # second set of what layer 1's forward leaves for its backward (statistics, w_c C), by update parity: when the finish
+            # work of update k rides on update k + 1's first launch (merge_finish, below) it reads update k's while that launch's
+            # layer-1 workgroups write update k + 1's
+            self.l1_alt_mean = torch.empty(2, H, **f32)
+            self.l1_alt_invstd = torch.empty(2, H, **f32)
+            self.bb_wc_alt = torch.zeros(H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)
             self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)
             self.hk_rows = self.lib.naf_bb_layer2_head_rows(B)    # rows per block of the fused launch's backward partials
             self.bb_bw2 = torch.zeros(max(2 * NB, B // self.hk_rows), H, 2, **f32)      # backward partials of layer 2: (sum dy, sum dy*xhat); per 64-row
@@ -417,8 +433,14 @@ class Learner:
         check(self._f.naf_bb_moments(rows.data_ptr(), self.B * ld, lay.off_s2, ld, lay.S, ptr(out), self.B, int(n_batches), 2,
                                      stream_ptr()), "bb_moments")
 
+    def _l1_saved(self, parity: int):
+        """(save_mean[2][H], save_invstd[2][H], w_c C) of layer 1 for an update of this parity (row-split chain)"""
+        if parity & 1:
+            return self.l1_alt_mean, self.l1_alt_invstd, self.bb_wc_alt
+        return self.save_mean[0], self.save_invstd[0], self.bb_wc
+
     def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True, moments: Optional[torch.Tensor] = None,
-                      adam_pending: bool = False) -> None:
+                      adam_pending: bool = False, parity: int = 0, chain_pos: int = 0) -> None:
         """Both networks' training-mode forward up to the second hidden activation A2 (and, with heads_gemm, the
         heads pre-activations Gh). Main net sees `state`, target net sees `next_state` (naf_algorithm.py:194-202);
         both use batch statistics and both update their running statistics (the reference never calls .eval() on the
@@ -448,12 +470,22 @@ class Learner:
                 # (adam_pending: the previous update's clip + Adam + Polyak ride on these two launches — extra workgroups of
                 # the first step everything behind the layer-1 segment while its own workgroups evaluate the layer-1
                 # parameters as the step will leave them, extra workgroups of the second step the layer-1 segment)
-                adam = _lib.C.byref(self._adam_args) if adam_pending else None
-                check(self._f.naf_bb_layer1_adam(
+                # (merge_finish: the previous update's FINISH work rides on the first launch as well; the step then reads its
+                # norm partials as tagged records and the gradient behind them, and counts its step number from the chain's start)
+                adam = fin = None
+                if adam_pending:
+                    aa = self._adam_args
+                    if self._pending_fin is not None:
+                        aa = _lib.AdamArgs.from_buffer_copy(self._adam_args)
+                        aa.partials, aa.rec, aa.step_bias = ptr(self.partial_recs), 1, int(chain_pos)
+                        fin = _lib.C.byref(self._pending_fin)
+                    adam = _lib.C.byref(aa)
+                sm, si, wc = self._l1_saved(parity)
+                check(self._f.naf_bb_layer1_adam_fin(
                     rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                     t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
-                    ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), B, H, 2, BN_MOMENTUM,
-                    BN_EPS, adam, st), "bb_layer1")
+                    ptr(self.A1), B * H, H, ptr(sm), ptr(si), ptr(wc), B, H, 2, BN_MOMENTUM,
+                    BN_EPS, adam, fin, st), "bb_layer1")
                 # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
                 check(self._f.naf_bb_linear_stats_adam(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset,
                                                        t2p + 4 * seg["b2"].offset, P, ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H,
@@ -498,7 +530,7 @@ class Learner:
             torch.bmm(self.A2, self.WhT2, out=self.Gh)
 
     def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None,
-                   moments: Optional[torch.Tensor] = None, pending: bool = False, defer: bool = False) -> None:
+                   moments: Optional[torch.Tensor] = None, pending: bool = False, defer: bool = False, chain_pos: int = 0) -> None:
         """Enqueue one full NAFAgent.learn() (naf_algorithm.py:180-215) + soft_update (:217-226) on the minibatch
         `rows` [B, ld] in the transition-row layout, ld = rows.stride(0) >= lay.batch_row_floats (actions already
         truncated by the gather if the reference's `.long()` is mimicked).
@@ -508,7 +540,13 @@ class Learner:
         defer / pending (only where self.defer_ok; a chain of updates, engine.TrainChunk): defer = leave this update's
         optimizer step (clip + Adam + Polyak) to the NEXT learn_rows call, which must then say pending = True and whose
         first two launches carry it — one launch less per update. Between the two calls the parameter buffers still hold
-        the values from before this update; the chain ends with a call that does not defer."""
+        the values from before this update; the chain ends with a call that does not defer. chain_pos: 0-based position of
+        this update in its chain (with merge_finish the deferred updates' finish work rides along too, the step count is
+        advanced once at the chain's end, and layer 1's saved statistics alternate between two buffers by parity)."""
+        parity = chain_pos & 1 if (self.merge_finish and (pending or defer)) else 0
+        merge = self.merge_finish and (pending or defer)
+        if pending and merge and self._pending_fin is None:
+            raise ValueError("learn_rows(pending=True): the previous call did not defer")
         if (pending or defer) and not self.defer_ok:
             raise ValueError("learn_rows: a deferred optimizer step needs the row-split chain with the gradient norm left by the "
                              "producers or by the one-shot all-reduce (Learner.defer_ok)")
@@ -528,7 +566,8 @@ class Learner:
                 rp + 4 * lay.off_r, ld, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "heads_gemm_head_fwd_bwd_mse")
         elif "hk" in self.fuse:
-            self.forward_train(rows, moments=moments, adam_pending=pending)
+            self.forward_train(rows, moments=moments, adam_pending=pending, parity=parity, chain_pos=chain_pos)
+            self._pending_fin = None             # (consumed by the launch above)
             bnp = self.bn_stats.data_ptr()
             # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
             check(f.naf_bb_layer2_head(
@@ -538,7 +577,7 @@ class Learner:
                 ptr(self.q_out), ptr(self.dH), lp, ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, lay.A, self.p_mode, BN_MOMENTUM,
                 BN_EPS, st), "bb_layer2_head")
         elif "s3" in self.fuse or "bb" in self.fuse:
-            self.forward_train(rows, moments=moments, adam_pending=pending)
+            self.forward_train(rows, moments=moments, adam_pending=pending, parity=parity, chain_pos=chain_pos)
             # the head adds the split-K slabs (H/8 of them, or H/64 in the large-batch chain) while staging its rows
             check(f.naf_head_fwd_bwd_mse_splitk(
                 ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), self.n_slabs, NHP, rp + 4 * lay.off_u,
@@ -587,6 +626,8 @@ class Learner:
             # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles
             if "ep" in self.fuse:
                 self._epi.x, self._epi.ldx = rp, ld      # this minibatch's rows: the epilogue recomputes layer 1's z from them
+                sm_, si_, _ = self._l1_saved(parity)
+                self._epi.save_mean, self._epi.save_invstd = ptr(sm_[0]), ptr(si_[0])
             if getattr(self, "_bundle64", False):
                 check(f.naf_gemm_bundle64(self._bundle, 3, st), "gemm_bundle64")
             else:
@@ -603,11 +644,24 @@ class Learner:
                     ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
                     ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1), B, H, st),
                     "bb_layer1_bwd")
+            sm_, si_, wc_ = self._l1_saved(parity)
+            nb1_ = B // 32 if ("ep" in self.fuse and not getattr(self, "_bundle64", False)) else B // 64
+            nb_ = 0 if "s2" in self.fuse else B // 64      # (s2: the layer-2 bias gradient is written as the 0 it identically is)
+            if defer and merge:
+                # no finish launch: its work rides on the next update's first launch (forward_train), with this update's pointers
+                self._pending_fin = _lib.BbFinishArgs(
+                    ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), nb1_, ptr(self.bb_dzp), nb_, ptr(self._mom), ptr(wc_),
+                    t2p + 4 * seg["g1"].offset, ptr(si_[0]), gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset,
+                    gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset,
+                    gp + 4 * seg["be2"].offset, ptr(self.partial_recs), B, H,
+                    _lib.C.cast(self._bb_segs, _lib.C.c_void_p) if self._bb_segs is not None else None, self._bb_nsegs,
+                    ptr(getattr(self, "bb_fold_flag", None)))
+                return
+            if pending and merge and chain_pos > 0:
+                self.step_dev.add_(int(chain_pos))          # the deferred updates of the chain did not advance the step count
             check(f.naf_bb_layer1_bwd_finish(
-                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1),
-                B // 32 if ("ep" in self.fuse and not getattr(self, "_bundle64", False)) else B // 64, ptr(self.bb_dzp),
-                0 if "s2" in self.fuse else B // 64,      # (s2: the layer-2 bias gradient is written as the 0 it identically is)
-                ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
+                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), nb1_, ptr(self.bb_dzp), nb_,
+                ptr(self._mom), ptr(wc_), t2p + 4 * seg["g1"].offset, ptr(si_[0]),
                 gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
                 gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
                 ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, B, H,
