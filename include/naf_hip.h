@@ -280,6 +280,8 @@ typedef struct {
      * launch; the readers poll them for step number *step_dev + step_bias and then read the gradient with sc1 loads. The step
      * count is advanced by a later launch (naf_bb_layer2_head, step_inc), hence step_bias = 1 there; 0 / 0 otherwise. */
     int rec, step_bias;
+    float* bc;   /* nullable: 8 floats of device scratch (two slots by step parity); the workgroups that step the layer-1 segment (naf_bb_linear_stats_adam) leave the
+                    NEXT step's bias corrections there, tagged with its number, for the next launch's readers */
 } naf_adam_args_t;
 /* The finish launch of the PREVIOUS update (every argument as naf_bb_layer1_bwd_finish's) riding on the next update's first launch
  * beside its optimizer step: naf_bb_layer1_adam_fin = naf_bb_layer1_adam (adam != NULL, adam->rec = 1) whose launch also carries the

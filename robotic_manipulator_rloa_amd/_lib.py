@@ -243,7 +243,7 @@ class AdamArgs(C.Structure):
                 ("partials", C.c_void_p), ("n_partials", C.c_int), ("max_norm", C.c_float), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("tau", C.c_float), ("one_minus_tau", C.c_float),
                 ("step_dev", C.c_void_p), ("inv_world", C.c_float), ("n", C.c_int64), ("l1_floats", C.c_int64),
-                ("rec", C.c_int), ("step_bias", C.c_int)]
+                ("rec", C.c_int), ("step_bias", C.c_int), ("bc", C.c_void_p)]
 
 
 class BbFinishArgs(C.Structure):

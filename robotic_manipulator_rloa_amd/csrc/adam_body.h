@@ -31,6 +31,11 @@ struct AdamArgs {
     // it carries this step's number t and reads the gradient only afterwards, with sc1 loads. The step count is then advanced by
     // a LATER launch, hence step_bias = 1.
     int rec, step_bias;
+    // nullable: 2 x 4 floats of device scratch {step_size, inv_bc2_sqrt, t (as bits), 0}, slot = t & 1. The bias corrections are two double-precision
+    // powers, a division and a square root on ONE lane — 0.3 us on the critical path of every workgroup that derives the step's
+    // scalars. The workgroup that steps the layer-1 segment from the second launch (adam_block with lo4 == 0, off every critical
+    // path) leaves the NEXT step's here; a reader takes them when the tag is its step number and computes them itself otherwise.
+    float* bc;
 };
 
 struct AdamScalars {
@@ -134,6 +139,12 @@ __device__ __forceinline__ static AdamPrefetch adam_prefetch(const AdamArgs& A, 
     }
     return p;
 }
+__device__ static inline void adam_bias_corrections(const AdamArgs& A, int t, float* step_size, float* inv_bc2_sqrt) {
+    const double bc1 = 1.0 - adam_ipow((double)A.beta1, t);
+    const double bc2 = 1.0 - adam_ipow((double)A.beta2, t);
+    *step_size = (float)((double)A.lr / bc1);
+    *inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
 // Every workgroup re-derives the same scalars from the same partials in the same order: the first wave takes the partials 64
 // at a time and folds them with the fixed-order lane sums; the second wave's first lane works out the bias corrections (double
 // precision, as torch computes them on the host) meanwhile. The caller puts a workgroup barrier behind it (>= 128 threads).
@@ -157,10 +168,17 @@ __device__ __forceinline__ static void adam_derive(const AdamArgs& A, const Adam
             sh->clip_scale = clip * A.inv_world;
         }
     } else if (tid == 64) {
-        const double bc1 = 1.0 - adam_ipow((double)A.beta1, p.t);
-        const double bc2 = 1.0 - adam_ipow((double)A.beta2, p.t);
-        sh->step_size = (float)((double)A.lr / bc1);
-        sh->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+        bool have = false;
+        if (A.bc) {                          // (two slots by the parity of t: the writer of t + 1 never touches what readers of t read)
+            const float* b = A.bc + 4 * (p.t & 1);
+            const float tagf = b[2];
+            if (__builtin_bit_cast(int, tagf) == p.t) {
+                sh->step_size = b[0];
+                sh->inv_bc2_sqrt = b[1];
+                have = true;
+            }
+        }
+        if (!have) adam_bias_corrections(A, p.t, &sh->step_size, &sh->inv_bc2_sqrt);
     }
 }
 
@@ -185,6 +203,14 @@ __device__ static inline bool adam_block(const AdamArgs& A, size_t lo4, size_t h
     adam_derive(A, pf, sh, tid);
     __syncthreads();
     const AdamScalars sc = *sh;
+    if (A.bc && lo4 == 0 && wg == 0 && tid == NT - 1) {      // the next step's bias corrections, for the next launch's readers
+        float ss, ib;
+        adam_bias_corrections(A, pf.t + 1, &ss, &ib);
+        float* b = A.bc + 4 * ((pf.t + 1) & 1);
+        b[0] = ss;
+        b[1] = ib;
+        b[2] = __builtin_bit_cast(float, pf.t + 1);
+    }
     if (sc.skip) return false;
     float* target = A.target;
     if (A.rec) {                             // the records are in: the gradient is where sc1 loads find it
@@ -282,7 +308,7 @@ __host__ static inline bool adam_args_from(const naf_adam_args_t& s, AdamArgs& a
     a.partials = s.partials; a.n_partials = s.n_partials;
     a.max_norm = s.max_norm; a.lr = s.lr; a.beta1 = s.beta1; a.beta2 = s.beta2; a.eps = s.eps;
     a.tau = s.tau; a.one_minus_tau = s.one_minus_tau; a.step_dev = s.step_dev; a.inv_world = s.inv_world;
-    a.rec = s.rec; a.step_bias = s.step_bias;
+    a.rec = s.rec; a.step_bias = s.step_bias; a.bc = s.bc;
     if (s.rec && (s.n_partials > NAF_MAX_NORM_PARTIALS || ((uintptr_t)s.partials & 15))) return false;
     return true;
 }

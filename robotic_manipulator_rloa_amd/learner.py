@@ -266,10 +266,11 @@ class Learner:
                              and self.n_partials_fold <= 256 and os.environ.get("NAF_MERGE_FINISH", "0") == "1")
         self.partial_recs = torch.zeros(max(self.n_partials_fold, 1), 4, **f32)
         self._pending_fin = None
+        self.adam_bc = torch.zeros(8, **f32)     # the next step's bias corrections, left by the riding optimizer workgroups
         self._adam_args = _lib.AdamArgs(
             ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]), ptr(self.partials),
             self.n_partials, MAX_GRAD_NORM, self.lr, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau, float(1.0 - self.tau),
-            ptr(self.step_dev), 1.0 / self.world_size, P, lay.seg["W2"].offset, 0, 0)
+            ptr(self.step_dev), 1.0 / self.world_size, P, lay.seg["W2"].offset, 0, 0, ptr(self.adam_bc))
         self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
         self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
         self.n_loss_wg = (B + 7) // 8                  # loss partials per update (NAF_HEAD_SPB samples per workgroup)
