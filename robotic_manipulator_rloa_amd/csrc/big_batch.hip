@@ -162,12 +162,31 @@ __global__ __launch_bounds__(BM_THREADS) void bb_moments_kernel(const float* __r
     const int tid = threadIdx.x;
     const float* xb = x + blockIdx.x * batch_stride + blockIdx.y * x_net_stride;
     float* out = mom + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * REC;
-    auto stage = [&](int row0) {
-        for (int e = tid; e < BM_CHUNK * K4; e += BM_THREADS) {
-            const int r_ = e / K4, q = e - r_ * K4;
+    // a chunk = 256 rows x 8 float4 (the last 8 - K4 of a row are zeros): 4 per thread, ALL requested before the first LDS store
+    // (as a load -> store loop the compiler kept one load in flight per trip: four dependent round trips per chunk and pass — 21 of
+    // this launch's 21 us at B = 1024). `centre`: subtract the column means (pass 2).
+    auto stage = [&](int row0, bool centre) {
+        float4 v[BM_CHUNK * 8 / BM_THREADS];
+#pragma unroll
+        for (int i = 0; i < BM_CHUNK * 8 / BM_THREADS; ++i) {
+            const int e = tid + BM_THREADS * i;
+            const int r_ = e >> 3, q = e & 7;
             const int row = row0 + r_;
-            *(float4*)(sX + r_ * XS + 4 * q) =
-                row < B ? ((const float4*)(xb + (int64_t)row * ldx))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool on = row < B && q < K4;
+            v[i] = ((const float4*)(xb + (int64_t)(on ? row : 0) * ldx))[on ? q : 0];
+            if (!on) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < BM_CHUNK * 8 / BM_THREADS; ++i) {
+            const int e = tid + BM_THREADS * i;
+            const int r_ = e >> 3, q = e & 7;
+            if (centre && row0 + r_ < B && q < K4) {
+                v[i].x -= sM[4 * q + 0];
+                v[i].y -= sM[4 * q + 1];
+                v[i].z -= sM[4 * q + 2];
+                v[i].w -= sM[4 * q + 3];
+            }
+            *(float4*)(sX + r_ * XS + 4 * q) = v[i];
         }
     };
     // pass 1: column sums (double)
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(BM_THREADS) void bb_moments_kernel(const float* __r
     double s = 0.0;
     for (int row0 = 0; row0 < B; row0 += BM_CHUNK) {
         __syncthreads();
-        stage(row0);
+        stage(row0, false);
         __syncthreads();
         if (k1 < KP) {
             float part = 0.f;
@@ -204,19 +223,7 @@ __global__ __launch_bounds__(BM_THREADS) void bb_moments_kernel(const float* __r
         double dacc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int row0 = 0; row0 < B; row0 += BM_CHUNK) {
             __syncthreads();
-            for (int e = tid; e < BM_CHUNK * 8; e += BM_THREADS) {
-                const int r_ = e >> 3, q = e & 7;
-                const int row = row0 + r_;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < B && q < K4) {
-                    v = ((const float4*)(xb + (int64_t)row * ldx))[q];
-                    v.x -= sM[4 * q + 0];
-                    v.y -= sM[4 * q + 1];
-                    v.z -= sM[4 * q + 2];
-                    v.w -= sM[4 * q + 3];
-                }
-                *(float4*)(sX + r_ * XS + 4 * q) = v;
-            }
+            stage(row0, true);
             __syncthreads();
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* pa = sX + (128 * half + g) * XS + 16 * tm + r;
