@@ -339,9 +339,9 @@ int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const float* Wh, int 
                             int lda, const float* save_mean, const float* save_invstd, float* dy_out, int ldd,
                             float* partials, int B, int H, void* stream);
 int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz, const float* gamma, const float* save_mean,
-                         const float* save_invstd, const float* partials, int n_partial_blocks /* B/64, or B / naf_bb_layer2_head_rows(B) after
+                         const float* save_invstd, const float* partials, int n_partial_blocks /* <= 128: B/64, or B / naf_bb_layer2_head_rows(B) after
                          naf_bb_layer2_head */, float* d_gamma, float* d_beta, float* dz_col_partials, int B, int H, void* stream);
-/* rows per workgroup of naf_bb_layer2_head at batch size B (16 up to B = 1024, else 32) = rows per block of its partials_bw:
+/* rows per workgroup of naf_bb_layer2_head at batch size B (16; 32 is the other instance, NAF_HK_ROWS=32) = rows per block of its partials_bw:
  * size partials_bw for B / rows blocks and tell naf_bb_bn_bwd_stage2 that many */
 int naf_bb_layer2_head_rows(int B);
 /* naf_bb_bn_relu_heads_partial + the NAF head (naf_head_fwd_bwd_mse: Q, y = r + gamma V'(s'), MSE, d_heads) +
