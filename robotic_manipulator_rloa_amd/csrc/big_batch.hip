@@ -2084,7 +2084,9 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
         else KERNEL<false><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride,  \
                                                           ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4);             \
     } while (0)
-    if (B <= 512) BB_LS(bb_linear_stats16_kernel, N / 16);     // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
+    int max16 = 512;                                           // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
+    if (const char* e = getenv("NAF_GEMM2_16_MAXB")) max16 = atoi(e);     // (experiments)
+    if (B <= max16) BB_LS(bb_linear_stats16_kernel, N / 16);
     else BB_LS(bb_linear_stats_kernel, N / BL_BN);
 #undef BB_LS
     NAF_CHECK_LAUNCH();
