@@ -6,6 +6,7 @@
 //
 // C/D map of the MFMA: col = l & 15, row = 4 (l >> 4) + reg. Summation order over k is fixed -> bitwise reproducible.
 #include <string.h>
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/naf_hip.h"
 
@@ -25,6 +26,7 @@ struct GemmDesc {
 struct GemmBundle {
     GemmDesc d[NAF_GEMM_BUNDLE_MAX];
     int n, total_tiles;
+    int rowmap;                   // XCD-aware placement of the blocks (NAF_GB_ROWMAP=0: block t is block t)
     int n_fold, fold_desc;        // n_fold > 0: the first n_fold workgroups fold the block sums of d[fold_desc].pro ONCE for the launch
 };
 
@@ -582,14 +584,22 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
     const int ks = (t - D.tile0) / D.tiles_mn;
     const int lt = t - D.tile0 - ks * D.tiles_mn;
     int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;
-    if (D.tiles_n == 8 && D.M == 256) {
-        // 8 x 8 blocks; workgroup t runs on XCD t % 8 (round-robin dispatch) and the column-tile kernels on either side of
-        // this launch keep columns 32 x .. 32 x + 31 on XCD x (naf_xcd_tile). k-major A (dW2 = dZ2^T A1): block ROW bm on
-        // XCD bm, the one that has just written those dZ2 columns; k-contiguous A (dA1 = dZ2 W2): block COLUMN bn on XCD
-        // bn, the one that reads those dA1 columns next. Producer and consumer then share an L2 (+1 % updates/s;
-        // placement is speed only, the result does not depend on it).
+    if (D.tiles_n == 8 && bundle.rowmap) {
+        // 8 block columns; workgroup t runs on XCD t % 8 (round-robin dispatch). Placement is speed only, the result does not
+        // depend on it. Every XCD has its own L2, so what matters is how much of the operands each of the eight pulls:
+        //   k-major A (dW2 = dZ2^T A1): block ROW bm on XCD bm — an eighth of dZ2 (and Z2), all of A1;
+        //   k-contiguous A (dA1 = dZ2 W2, with the BatchNorm prologue and the layer-1 epilogue): block rows bm = x, x + 8, ... on
+        //   XCD x with all 8 block columns of a row — an eighth of dZ2, Z2, A1 and the minibatch rows plus the whole of W2,
+        //   instead of all of those and an eighth of W2. (Until the epilogue was fused the dA1 blocks sat by block COLUMN, next
+        //   to the kernel that read those dA1 columns; nothing reads them any more, and by rows: 31.7k -> 33.1k updates/s at
+        //   B = 256, 28.6k -> 29.4k at 512, 24.0k -> 25.6k at 1024, 17.5k -> 17.9k at 2048, A/B on the same boxes.)
         const int xcd = lt & 7, slot = lt >> 3;
-        if (D.a_kmajor) { bm = xcd; bn = slot; } else { bn = xcd; bm = slot; }
+        if (D.a_kmajor) {
+            if (D.M == 256) { bm = xcd; bn = slot; }
+        } else if ((D.tiles_mn & 63) == 0) {              // (whole groups of 8 block rows)
+            bm = xcd + 8 * (slot >> 3);
+            bn = slot & 7;
+        }
     }
     if (D.a_kmajor) {
         if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
@@ -605,6 +615,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     GemmBundle b;
     b.n = n;
     b.n_fold = b.fold_desc = 0;
+    { const char* e = getenv("NAF_GB_ROWMAP"); b.rowmap = e ? atoi(e) : 1; }
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         const naf_gemm_desc_t& s = descs[i];
