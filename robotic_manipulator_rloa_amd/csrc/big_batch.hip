@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const float* __restrict__ Wh, int64_t wh_net_stride, int ldw, const float* __restrict__ u, int ldu,
     const float* __restrict__ r, int ldr, float gamma_td, float* __restrict__ q_out, float* __restrict__ d_heads,
     float* __restrict__ loss_partials, float* __restrict__ dy_out, int ldd, float2* __restrict__ partials_bw, int B, int A,
-    float momentum, float eps) {
+    float momentum, float eps, int xcd_rows) {
     constexpr int NHP = 4 * NH4, H = FK_H;
     constexpr int MT = ROWS / 16;                          // 16-row MFMA tiles
     constexpr int RPW = ROWS / 8;                          // rows per wave where a wave owns whole rows
@@ -1465,7 +1465,12 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     __shared__ float sRed[FK_THREADS / 64];
     __shared__ float2 sP[MT][H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rb = blockIdx.x;
+    // which rows: workgroup i runs on XCD i % 8, and the bundle's dA1 blocks — the readers of the dY2 / A2 rows written here —
+    // sit by 32-row block row bm on XCD bm % 8 (gemm_bundle.hip). With 16-row workgroups, workgroup i takes row chunk
+    // 2 (i % 8) + (i / 8) % 2 + 16 (i / 16): both chunks of block row bm are then written on the XCD that reads them, and the
+    // lines are still in its L2 behind the launch boundary. (Whole groups of 16 chunks only; placement is speed only.)
+    int rb = blockIdx.x;
+    if (ROWS == 16 && (gridDim.x & 15) == 0 && xcd_rows) rb = 2 * (rb & 7) + ((rb >> 3) & 1) + 16 * (rb >> 4);
     const int64_t s0 = (int64_t)rb * ROWS;
     const int T = A * (A + 1) / 2, v_col = A + T;
     // every kernel argument this prologue needs, fetched NOW: left to itself the compiler fetches an argument where it is
@@ -2187,11 +2192,12 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     hipStream_t st = (hipStream_t)stream;
     const int rows = naf_bb_layer2_head_rows(B);
     const int blocks = B / rows;
+    const int xcd_rows = getenv("NAF_L2_XCD_ROWS") ? atoi(getenv("NAF_L2_XCD_ROWS")) : 1;
 #define BB_FK_R(PM, NH4V, RW)                                                                                            \
     bb_layer2_head_kernel<PM, NH4V, RW><<<blocks, FK_THREADS, 0, st>>>(                                                  \
         z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, B / BB_ROWS, running_mean, running_var, \
         stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
-        loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps)
+        loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows)
 #define BB_FK(PM, NH4V)                   \
     do {                                  \
         if (rows == 16) BB_FK_R(PM, NH4V, 16); \
