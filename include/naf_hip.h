@@ -417,7 +417,7 @@ typedef struct naf_gemm_l1bwd {
  * columns its A panel touches (all H for a k-contiguous A = dA1's product, its own 32 for a k-major A = dW2's), the k-major blocks
  * of the first block column also write d_gamma / d_beta. The bias gradient of the Linear in front (sum_r dz) is identically zero
  * under a train-mode BatchNorm and is not produced: pass nb = 0 to naf_bb_layer1_bwd_finish, which then writes d_bias2 = 0.
- * Restrictions: H = 256, K / k_split a multiple of 256, M and N multiples of 32, npb <= 32 (64 with cst, below). */
+ * Restrictions: H = 256, K / k_split a multiple of 256, M and N multiples of 32, npb <= 32 (128 with cst, below). */
 typedef struct naf_gemm_bn2bwd {
     const float* z;          /* Z2, same shape and leading dimension as A */
     const float* partials;   /* float2 [npb][H]: (sum dy, sum dy*xhat) per row block (naf_bb_layer2_head's partials_bw) */
@@ -427,7 +427,7 @@ typedef struct naf_gemm_bn2bwd {
     float* d_gamma;          /* [H] out */
     float* d_beta;
     int npb, B, H;
-    /* cst != NULL: the block sums are folded ONCE per launch — the launch's first H / 32 workgroups fold 32 columns each (npb <= 64)
+    /* cst != NULL: the block sums are folded ONCE per launch — the launch's first H / 32 workgroups fold 32 columns each (npb <= 128)
      * and publish one 16-byte record per column to cst ([H] x 4 floats, 16-B aligned, device scratch that nothing else touches):
      * (k1 c1, invstd k1 c2, *epoch, 0); the GEMM blocks poll the records of their columns until they carry *epoch (bounded by wall
      * clock; a thread that gives up poisons its result with NaN). *epoch (device word) must differ from launch to launch:

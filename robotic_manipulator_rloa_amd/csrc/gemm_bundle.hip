@@ -326,8 +326,8 @@ __device__ static inline void gemm_bn2bwd_constants(const GemmDesc& D, int m0, i
 // GPU. Records and polls are sc1 only (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire).
 #define GB_FOLD_COLS 32
 __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P, int f, int tid, float* scratch) {
-    constexpr int NPAIR = GB_FOLD_COLS / 2, PARTS = GB_THREADS / NPAIR, QMAX = 2;
-    static_assert(PARTS * QMAX >= 64, "npb <= 64");
+    constexpr int NPAIR = GB_FOLD_COLS / 2, PARTS = GB_THREADS / NPAIR, QMAX = 4;
+    static_assert(PARTS * QMAX >= 128, "npb <= 128");
     const int col0 = f * GB_FOLD_COLS;
     const int pair = tid % NPAIR, part = tid / NPAIR;
     const int npb = P.npb, Q = (npb + PARTS - 1) / PARTS, rb0 = part * Q;
@@ -639,7 +639,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (s.pro) {
             const naf_gemm_bn2bwd_t& q = *s.pro;
             if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 ||
-                q.npb > (q.cst ? 64 : 32) || (q.cst && (!q.epoch || ((uintptr_t)q.cst & 15))) || q.B <= 0 || q.H != 256 || ((s.K / ksn) % GB_KC) != 0 || (s.M & 31) || (s.N & 31) ||
+                q.npb > (q.cst ? 128 : 32) || (q.cst && (!q.epoch || ((uintptr_t)q.cst & 15))) || q.B <= 0 || q.H != 256 || ((s.K / ksn) % GB_KC) != 0 || (s.M & 31) || (s.N & 31) ||
                 (s.a_kmajor ? s.M != q.H : s.K != q.H) || ((uintptr_t)q.z & 15) || ((uintptr_t)q.partials & 7))
                 return NAF_ERR_ARG;      // (the A operand's columns are the H features: its M when k-major, its K otherwise)
             d.pro = q;

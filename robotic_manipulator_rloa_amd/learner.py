@@ -182,7 +182,7 @@ class Learner:
         #   s2 = (with bb + gb + hk) the second stage of layer 2's BatchNorm backward inside the bundle: dY2 becomes dZ2 while the
         #        products that read it stage their operand (csrc/gemm_bundle.hip, naf_gemm_bn2bwd_t) — one launch less; needs
         #        whole 256-k chunks and at most 32 row blocks of backward partials: B = 256, 512
-        spec = os.environ.get("NAF_FUSE", ("bb,gb,hk,ep,s2" if self.B <= 1024 else "bb,gb,hk,ep") if (self.B >= 256 and self.bb_ok)
+        spec = os.environ.get("NAF_FUSE", "bb,gb,hk,ep,s2" if (self.B >= 256 and self.bb_ok)
                               else ("l1,b2,gb,s3" if self.B <= 512 else "gb")).lower()
         #   l12 = (with bb; opt-in, NOT default) layer 1 inside GEMM 2's launch: every GEMM-2 workgroup forms its A panel from
         #        the rows itself. Parity-tested; measured 17.0 us against 13.7 us for the two launches it replaces at B = 1024
@@ -198,11 +198,11 @@ class Learner:
         if not {"bb", "gb"} <= self.fuse or self.B % 32:
             self.fuse -= {"ep"}
         #        (round 2, later: the block sums are folded ONCE per launch by the bundle's first workgroups — csrc/gemm_bundle.hip,
-        #        gemm_bn2bwd_fold_block — so up to 64 row blocks: every batch size of the chain. NAF_S2_FOLD=0: every block folds
+        #        gemm_bn2bwd_fold_block — so up to 128 row blocks: every batch size of the chain. NAF_S2_FOLD=0: every block folds
         #        for itself, at most 32 row blocks)
         npb_ = self.B // self.lib.naf_bb_layer2_head_rows(self.B)
         self.s2_fold_once = os.environ.get("NAF_S2_FOLD", "1") != "0"
-        if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or npb_ > (64 if self.s2_fold_once else 32):
+        if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or npb_ > (128 if self.s2_fold_once else 32):
             self.fuse -= {"s2"}
         if self.lay.S > 32:
             self.fuse -= {"l1"}

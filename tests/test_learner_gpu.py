@@ -48,7 +48,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
     L = make_learner(S, A, B, main0, target0)
     if fused == "default":
-        assert L.fuse == (({"bb", "gb", "hk", "ep", "s2"} if B <= 1024 else {"bb", "gb", "hk", "ep"}) if B >= 256 and B % 64 == 0
+        assert L.fuse == ({"bb", "gb", "hk", "ep", "s2"} if B >= 256 and B % 64 == 0
                           else {"l1", "b2", "gb", "s3"})
     if "bb" in fused:
         assert "bb" in L.fuse and not L.fuse & {"l1", "b2", "s3", "f3"}
