@@ -358,11 +358,10 @@ class Learner:
             else:
                 ks = B // 256 if B % 256 == 0 else 1
             ks_w2 = ks_wh = ks
-            # two blocks fit a CU: 512 at once. If the launch (dA1 + dW2 + dWh blocks) is one round with dW2's K ranges twice
-            # as long but not with 256-row ones, take the long ranges (B = 1024: 420 blocks instead of 548: 21.8k -> 22.5k
-            # updates/s; at B = 2048 neither fits and the short ranges win, 16.0k vs 15.9k)
-            n_fixed = (B // 32) * (H // 32) + ((NHP + 31) // 32) * ((HP + 31) // 32) * ks
-            if ks >= 2 and n_fixed + (H // 32) ** 2 * ks > 512 >= n_fixed + (H // 32) ** 2 * (ks // 2) and (B // (ks // 2)) % 256 == 0:
+            # dW2's K ranges twice as long (512 rows) from B = 1024 on: half the blocks, half the slabs for the finish launch
+            # to add (B = 1024: 420 blocks — one round of two per CU — instead of 548: 21.8k -> 22.5k updates/s when it was
+            # introduced; B = 2048 with the blocks placed by row on the XCDs: 19.3k -> 19.7k; four times as long: 18.4k)
+            if ks >= 2 and (B // (ks // 2)) % 256 == 0:
                 ks_w2 = ks // 2
             if os.environ.get("NAF_BB_KS"):          # experiment: "w2,wh" K ranges of the two weight gradients
                 ks_w2, ks_wh = (int(v) for v in os.environ["NAF_BB_KS"].split(","))
