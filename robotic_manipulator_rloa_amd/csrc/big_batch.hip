@@ -847,7 +847,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
                                                                      int64_t param_net_stride, float* __restrict__ z,
                                                                      int64_t z_net_stride, int ldz,
                                                                      float2* __restrict__ partials, int B, int N, int K,
-                                                                     int gx, int n_main, const AdamArgs ad, int64_t l1_4) {
+                                                                     int gx, int n_main, const AdamArgs ad, int64_t l1_4, int xcd_nets) {
     __shared__ __attribute__((aligned(16))) float sA[BL_BM * BL_LD];
     __shared__ __attribute__((aligned(16))) float sB[BL_BN * BL_LD];
     __shared__ float red[2][BL_BN];
@@ -858,9 +858,16 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
         adam_block<BB_THREADS>(ad, 0, (size_t)l1_4, widx - n_main, (int)gridDim.x - n_main, &shA, tid, true);
         return;
     }
-    const int bx = widx % gx, by = widx / gx;
+    int bx = widx % gx, by = widx / gx;
 #define BL_TL(slot) NAF_TL_FL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, slot, widx == 0, widx == n_main - 1)
     const int NB = B / BB_ROWS;
+    if (xcd_nets && gx == 2 * NB && (NB & 3) == 0) {
+        // workgroup t runs on XCD t % 8: XCDs 0 .. 3 take the main network, 4 .. 7 the target, each a quarter of the row blocks
+        // with all column tiles — an XCD's L2 then pulls ONE network's W (256 KB) and its rows of A, instead of both networks' W
+        const int x = widx & 7, slot = widx >> 3, q = NB >> 2;
+        bx = (x >> 2) * NB + (x & 3) * q + slot % q;
+        by = slot / q;
+    }
     const int net = bx / NB, rb = bx - net * NB;
     const int n0 = by * BL_BN;
     const float* an = a + net * a_net_stride + (int64_t)rb * BL_BM * lda;
@@ -942,7 +949,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
                                                                        int64_t param_net_stride, float* __restrict__ z,
                                                                        int64_t z_net_stride, int ldz, float2* __restrict__ partials,
                                                                        int B, int N, int K, int gx, int n_main, const AdamArgs ad,
-                                                                       int64_t l1_4) {
+                                                                       int64_t l1_4, int xcd_nets) {
     constexpr int BN = 16;
     __shared__ __attribute__((aligned(16))) float sA[BL_BM * BL_LD];
     __shared__ __attribute__((aligned(16))) float sB[BN * BL_LD];
@@ -955,8 +962,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
         adam_block<BB_THREADS>(ad, 0, (size_t)l1_4, widx - n_main, (int)gridDim.x - n_main, &shA, tid, true);
         return;
     }
-    const int bx = widx % gx, by = widx / gx;
+    int bx = widx % gx, by = widx / gx;
     const int NB = B / BB_ROWS;
+    if (xcd_nets && gx == 2 * NB && (NB & 3) == 0) {            // (placement by network and row quarter, see above)
+        const int x = widx & 7, slot = widx >> 3, q = NB >> 2;
+        bx = (x >> 2) * NB + (x & 3) * q + slot % q;
+        by = slot / q;
+    }
     const int net = bx / NB, rb = bx - net * NB;
     const int n0 = by * BN;
     const int r = lane & 15, g = lane >> 4;
@@ -2079,15 +2091,17 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
     int64_t l1_4, n4;
     if (!bb_adam_setup(adam, ad, l1_4, n4)) return NAF_ERR_ARG;
     const int extra = adam ? bb_adam_blocks(0, l1_4, BB_THREADS) : 0;
+    // (experiment, off: one network per XCD half — 29.9k | 25.6k | 19.5k updates/s at B = 512 | 1024 | 2048 without, 30.0k | 25.2k | 19.6k with)
+    const int xcd_nets = getenv("NAF_GEMM2_XCD_NETS") ? atoi(getenv("NAF_GEMM2_XCD_NETS")) : 0;
     const int gx = nets * (B / BB_ROWS);
     hipStream_t st = (hipStream_t)stream;
 #define BB_LS(KERNEL, GY)                                                                                                   \
     do {                                                                                                                    \
         const int n_main = gx * (GY);                                                                                       \
         if (adam) KERNEL<true><<<n_main + extra, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,   \
-                                                                      z_net_stride, ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4); \
+                                                                      z_net_stride, ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4, xcd_nets); \
         else KERNEL<false><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride,  \
-                                                          ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4);             \
+                                                          ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4, xcd_nets);             \
     } while (0)
     int max16 = 512;                                           // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
     if (const char* e = getenv("NAF_GEMM2_16_MAXB")) max16 = atoi(e);     // (experiments)
