@@ -581,7 +581,7 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
     for (int i = 1; i < NAF_GEMM_BUNDLE_MAX; ++i)
         if (i < bundle.n && t >= bundle.d[i].tile0) gi = i;
     const GemmDesc& D = bundle.d[gi];
-    const int ks = (t - D.tile0) / D.tiles_mn;
+    int ks = (t - D.tile0) / D.tiles_mn;
     const int lt = t - D.tile0 - ks * D.tiles_mn;
     int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;
     if (D.tiles_n == 8 && bundle.rowmap) {
@@ -595,7 +595,15 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
         //   B = 256, 28.6k -> 29.4k at 512, 24.0k -> 25.6k at 1024, 17.5k -> 17.9k at 2048, A/B on the same boxes.)
         const int xcd = lt & 7, slot = lt >> 3;
         if (D.a_kmajor) {
-            if (D.M == 256) { bm = xcd; bn = slot; }
+            const int S = D.k_split;
+            if (D.M == 256 && bundle.rowmap >= 2 && (S == 2 || S == 4 || S == 8)) {
+                // split K (the weight gradient at large batches): a K RANGE per group of 8 / S XCDs, S block rows each — an L2
+                // then pulls its range's rows of dZ2, Z2 (S of 8 column slices) and A1 instead of every range's
+                const int idx = t - D.tile0, x = idx & 7, sl = idx >> 3, per = 8 / S;
+                ks = x / per;
+                bm = S * (x % per) + sl % S;
+                bn = sl / S;
+            } else if (D.M == 256) { bm = xcd; bn = slot; }
         } else if ((D.tiles_mn & 63) == 0) {              // (whole groups of 8 block rows)
             bm = xcd + 8 * (slot >> 3);
             bn = slot & 7;
@@ -615,7 +623,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     GemmBundle b;
     b.n = n;
     b.n_fold = b.fold_desc = 0;
-    { const char* e = getenv("NAF_GB_ROWMAP"); b.rowmap = e ? atoi(e) : 1; }
+    { const char* e = getenv("NAF_GB_ROWMAP"); b.rowmap = e ? atoi(e) : 2; }    // 0: block t is block t; 1: dA1 by row; 2: and dW2's K ranges by XCD group
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         const naf_gemm_desc_t& s = descs[i];
