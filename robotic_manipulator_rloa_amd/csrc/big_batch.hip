@@ -2092,7 +2092,7 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
     if (!bb_adam_setup(adam, ad, l1_4, n4)) return NAF_ERR_ARG;
     const int extra = adam ? bb_adam_blocks(0, l1_4, BB_THREADS) : 0;
     // (experiment, off: one network per XCD half — 29.9k | 25.6k | 19.5k updates/s at B = 512 | 1024 | 2048 without, 30.0k | 25.2k | 19.6k with)
-    const int xcd_nets = getenv("NAF_GEMM2_XCD_NETS") ? atoi(getenv("NAF_GEMM2_XCD_NETS")) : 0;
+    const int xcd_nets = NAF_ENV_INT("NAF_GEMM2_XCD_NETS", 0);
     const int gx = nets * (B / BB_ROWS);
     hipStream_t st = (hipStream_t)stream;
 #define BB_LS(KERNEL, GY)                                                                                                   \
@@ -2103,8 +2103,7 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
         else KERNEL<false><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride,  \
                                                           ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4, xcd_nets);             \
     } while (0)
-    int max16 = 512;                                           // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
-    if (const char* e = getenv("NAF_GEMM2_16_MAXB")) max16 = atoi(e);     // (experiments)
+    const int max16 = NAF_ENV_INT("NAF_GEMM2_16_MAXB", 512);    // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
     if (B <= max16) BB_LS(bb_linear_stats16_kernel, N / 16);
     else BB_LS(bb_linear_stats_kernel, N / BL_BN);
 #undef BB_LS
@@ -2181,8 +2180,8 @@ extern "C" int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride
 
 // rows per workgroup = rows per block of partials_bw (the consumer, naf_bb_bn_bwd_stage2, is told B / rows blocks)
 extern "C" int naf_bb_layer2_head_rows(int B) {
-    const char* e = getenv("NAF_HK_ROWS");               // experiments: 16 or 32 whatever the batch size
-    if (e && (atoi(e) == 16 || atoi(e) == 32)) return atoi(e);
+    const int e = NAF_ENV_INT("NAF_HK_ROWS", 0);         // experiments: 16 or 32 whatever the batch size
+    if (e == 16 || e == 32) return e;
     (void)B;
     return 16;               // (32 = FK_ROWS at B = 2048 until stage 2 folded 128 row blocks: 16.9k -> 17.7k updates/s with 16)
 }
@@ -2206,7 +2205,7 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     hipStream_t st = (hipStream_t)stream;
     const int rows = naf_bb_layer2_head_rows(B);
     const int blocks = B / rows;
-    const int xcd_rows = getenv("NAF_L2_XCD_ROWS") ? atoi(getenv("NAF_L2_XCD_ROWS")) : 1;
+    const int xcd_rows = NAF_ENV_INT("NAF_L2_XCD_ROWS", 1);
 #define BB_FK_R(PM, NH4V, RW)                                                                                            \
     bb_layer2_head_kernel<PM, NH4V, RW><<<blocks, FK_THREADS, 0, st>>>(                                                  \
         z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, B / BB_ROWS, running_mean, running_var, \

@@ -166,6 +166,10 @@ __device__ __forceinline__ static float naf_sum64(float v) { return naf_xor32_ad
 
 __host__ __device__ static inline int naf_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// experiment switches of the host-side launchers: read once per call site, not per launch
+#include <stdlib.h>
+#define NAF_ENV_INT(name, dflt) ([]() -> int { static const int v = getenv(name) ? atoi(getenv(name)) : (dflt); return v; }())
+
 // transition row layout: [state(S) | action(A) | reward | 0-pad to a multiple of 4 floats | next_state(S) | done | 0-pad]
 // next_state starts on a 16-byte boundary so both observations of a row can be read as float4
 __host__ __device__ static inline int naf_row_off_s2(int S, int A) { return naf_round_up(S + A + 1, 4); }

@@ -623,7 +623,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     GemmBundle b;
     b.n = n;
     b.n_fold = b.fold_desc = 0;
-    { const char* e = getenv("NAF_GB_ROWMAP"); b.rowmap = e ? atoi(e) : 2; }    // 0: block t is block t; 1: dA1 by row; 2: and dW2's K ranges by XCD group
+    b.rowmap = NAF_ENV_INT("NAF_GB_ROWMAP", 2);      // 0: block t is block t; 1: dA1 by row; 2: and dW2's K ranges by XCD group
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         const naf_gemm_desc_t& s = descs[i];

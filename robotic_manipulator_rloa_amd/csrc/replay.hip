@@ -295,7 +295,7 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
     int bits = 1;
     while ((1 << bits) < 2 * B) ++bits;
     size_t lds_ints = (size_t)B + 2 * ((size_t)1 << bits);
-    if (lds_ints * sizeof(int) > 64 * 1024 || getenv("NAF_SAMPLE_SCAN")) {
+    if (lds_ints * sizeof(int) > 64 * 1024 || NAF_ENV_INT("NAF_SAMPLE_SCAN", 0)) {
         bits = 0;
         lds_ints = 0;
     }
