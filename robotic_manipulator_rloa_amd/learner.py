@@ -261,7 +261,8 @@ class Learner:
         # workgroups of that launch wait for — four launches per update at B <= 1024, bit-identical (tested). Measured: 31.4k
         # against 31.1k updates/s at B = 256, 23.4k / 23.5k at 1024, 16.6k / 16.5-16.9k at 2048 on the same boxes — the launch
         # and its boundary (4.2 us) are traded for sc1 scalar stores in the finish work (+0.9 us), 1.6 us until the readers see
-        # the last record and a dependent round trip for the gradient (0.8 us): not the default.
+        # the last record and a dependent round trip for the gradient (0.8 us): not the default (with the kernels of the end of
+        # the round: 33.3k against 33.7k at B = 256, 25.1k against 25.7k at 1024).
         self.merge_finish = (self.defer_ok and self.world_size == 1 and self.fold_norm and {"ep", "hk", "gb"} <= self.fuse
                              and self.n_partials_fold <= 256 and os.environ.get("NAF_MERGE_FINISH", "0") == "1")
         self.partial_recs = torch.zeros(max(self.n_partials_fold, 1), 4, **f32)
