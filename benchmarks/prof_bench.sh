@@ -13,3 +13,5 @@ cp $(find $d -name "*kernel_stats.csv") gpurun_out/${tag}_kernel_stats.csv
 python3 benchmarks/stats_summary.py gpurun_out/${tag}_kernel_stats.csv --updates $(( (steps + warm + 2) * 64 )) --top 22 --out gpurun_out/${tag}_digest.csv
 cat gpurun_out/${tag}_digest.csv
 grep -o '"value": [0-9.]*' /tmp/prof_$tag.out | head -1
+# the bench line of THIS (profiled) process: its roofline.avg_launch_ms is the HIP-event view of the very launches the CSV averages
+grep '^{' /tmp/prof_$tag.out | tail -1 > gpurun_out/${tag}_line_under_rocprof.json
