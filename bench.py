@@ -156,8 +156,10 @@ def main():
     rows = synth_rows(N, S, A, replay.row_floats, replay.off_s2, seed=77 + rank, device=dev)
     replay.add_rows_device(rows, N)
     del rows
+    # records=True: the per-env episode bookkeeping (score, frames, record ring drained every 64 vector steps — what
+    # NAFAgent.run_vectorized builds its {episode: (score, last_frame)} dict and checkpoints from) rides in the timed loop
     loop = DeviceEnvLoop(L, replay, E, seed=31 + rank, max_frames=400, use_graph=not args.no_graph, robot=args.robot,
-                         obstacle_jitter=args.obstacle_jitter)
+                         obstacle_jitter=args.obstacle_jitter, records=True, drain_every=64)
     U = E   # update_freq = num_updates = 1: one learn() per env transition (naf_algorithm.py:147-156)
     # sample -> gather -> U updates as ONE graph per vector step (the launch of the gather alone is bracketed with events in a
     # short loop of its own behind the timed region: `roofline_live`)
@@ -198,6 +200,7 @@ def main():
     elapsed = float(t.item())
     finite = bool(torch.isfinite(L.theta2).all().item())
     opt_steps = int(L.step_dev.item())
+    episodes = loop.drain(final=True)            # every episode the E envs finished during warm-up + timed steps
     # the gather launch of a vector step (U*B rows) on its own, bracketed by HIP events on the launching stream: the same
     # sample + gather the graph holds, launched eagerly 200 times behind the timed region (the learner is not touched)
     n_ev = 200
@@ -233,7 +236,9 @@ def main():
         "updates_per_s": round(updates / elapsed, 1),
         "us_per_update": round(1e6 * elapsed / (args.steps * U), 3),
         "timed_seconds": round(elapsed, 3),
-        "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": opt_steps},
+        "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": opt_steps,
+                   "episodes_booked": len(episodes),
+                   "episode_frames_booked": int(sum(e[1] for e in episodes))},
     }
     if L.xgmi is not None:
         out["sanity"]["xgmi_allreduces"], out["sanity"]["xgmi_timed_out_waits"] = L.xgmi.status()

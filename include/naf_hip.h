@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 14
+#define NAF_HIP_ABI_VERSION 15
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -476,13 +476,33 @@ int naf_polyak_update(float* target, const float* main, float tau, float one_min
 /* ---- synthetic manipulator environment (stand-in for the PyBullet Environment) ---------------- */
 /* One step of E independent kinematic-chain arms on the device, emitting transition rows
  * (environment/environment.py:431-485 state layout / reward constants); see csrc/synth_env.hip. */
+/* Per-env episode bookkeeping of the many-env training / evaluation loops — what NAFAgent.run keeps per episode
+ * (`score += reward`, `frame`; naf_algorithm.py:246-270) and what test_trained_model reads at an episode's end
+ * (`done`, `reward == 250`; rl_framework.py:341-355). One record per (vector step, env), frames == 0 when no episode of
+ * that env ended in that step. 32 bytes. */
+typedef struct naf_episode_record {
+    double score;        /* sum of the episode's rewards, accumulated in double in step order (Python's float sum) */
+    int32_t frames;      /* steps the episode took (the reference's last `frame`); 0 = no episode ended here */
+    int32_t done;        /* 1: terminal state (target reached / collision), 0: the frame budget ran out */
+    float last_reward;   /* reward of the episode's last step (+250 = target reached) */
+    int32_t episode;     /* 1-based ordinal of the episode among this env's episodes */
+    uint32_t step_lo;    /* low 32 bits of the vector-step counter the record was written at */
+    uint32_t env;        /* env index */
+} naf_episode_record_t;
+/* records (nullable): [record_slots][E] ring of episode records; the step writes slot (*counter_dev % record_slots) for
+ * every env on EVERY call, so a host that copies the ring once per record_slots steps sees every finished episode in
+ * (step, env) order without atomics or a per-step synchronisation. Needs counter_dev. */
 int naf_synth_env_step(float* env_state, const float* actions, float* out_rows, float* obs_next, int E, int A,
-                       uint64_t seed, const uint64_t* counter_dev, int max_frames, void* stream);
-/* preset_host (nullable, HOST pointer, 15 floats): [initial joint positions(8) | target xyz | obstacle xyz |
- * obstacle_jitter]; NULL = the reference's KUKA demo preset. obstacle_jitter > 0: per-env obstacle position, uniform in
- * a cube of that half-width around the preset (seeded by (seed, env)). */
+                       uint64_t seed, const uint64_t* counter_dev, int max_frames, naf_episode_record_t* records,
+                       int record_slots, void* stream);
+/* preset_host (nullable, HOST pointer, preset_floats = 15 or NAF_SYNTH_PRESET_FLOATS = 23 floats): [initial joint
+ * positions(8) | target xyz | obstacle xyz | obstacle_jitter | variation(8)]; NULL = the reference's KUKA demo preset.
+ * obstacle_jitter > 0: per-env obstacle position, uniform in a cube of that half-width around the preset (seeded by
+ * (seed, env)). variation[k]: half-width of the uniform range joint k's initial position is drawn from at every reset
+ * (initial_positions_variation_range, environment.py:284-293); 0.1 on every joint when only 15 floats are given. */
+#define NAF_SYNTH_PRESET_FLOATS 23
 int naf_synth_env_reset(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t counter,
-                        const float* preset_host, void* stream);
+                        const float* preset_host, int preset_floats, void* stream);
 int naf_synth_env_state_floats(int A);
 
 /* ---- one-shot gradient all-reduce over peer-mapped memory (no reference counterpart) ----------

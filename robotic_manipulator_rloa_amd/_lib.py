@@ -195,8 +195,8 @@ _PROTOS = {
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
     "naf_polyak_update": [_vp, _vp, _f, _f, _sz, _vp],
-    "naf_synth_env_step": [_vp, _vp, _vp, _vp, _i, _i, _u64, _vp, _i, _vp],
-    "naf_synth_env_reset": [_vp, _vp, _i, _i, _u64, _u64, _vp, _vp],
+    "naf_synth_env_step": [_vp, _vp, _vp, _vp, _i, _i, _u64, _vp, _i, _vp, _i, _vp],
+    "naf_synth_env_reset": [_vp, _vp, _i, _i, _u64, _u64, _vp, _i, _vp],
     "naf_synth_env_state_floats": [_i],
     "naf_policy_act": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i,
                        _vp, _u64, _vp, _vp, _f, _i, _i, _i, _vp],

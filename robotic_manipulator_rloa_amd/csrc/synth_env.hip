@@ -11,7 +11,12 @@
 #include "common.h"
 #include "../../include/naf_hip.h"
 
-#define ENV_STATE_FLOATS 24  // q[8] | target[3] | obstacle[3] | init_q[8] | frame | episode
+// q[8] | target[3] | obstacle[3] | init_q[8] | frame | episode | variation[8] | episode score (one double) | pad[2]
+// Per-env episode bookkeeping (the reference's `score += reward` / `frame` of NAFAgent.run, naf_algorithm.py:246-270)
+// rides in the step kernel: the running score is a DOUBLE summed in step order, as Python's float sum is.
+#define ENV_STATE_FLOATS 36
+#define ENV_OFF_VAR 24
+#define ENV_OFF_SCORE 32
 #define ENV_DT (1.0f / 240.0f)
 
 struct EnvCfg {
@@ -62,16 +67,20 @@ __device__ static inline void env_reset_one(float* st, int e, int A, uint64_t se
     for (int k = 0; k < A; k += 4) {
         Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)e, 0x52455345u + k, (uint32_t)seed,
                                   (uint32_t)(seed >> 32));
-        for (int j = 0; j < 4 && k + j < A; ++j) st[k + j] = st[14 + k + j] + (naf_u01(p.v[j]) * 2.f - 1.f) * 0.1f;
+        for (int j = 0; j < 4 && k + j < A; ++j)
+            st[k + j] = st[14 + k + j] + (naf_u01(p.v[j]) * 2.f - 1.f) * st[ENV_OFF_VAR + k + j];
     }
     st[22] = 0.f;
+    *(double*)(st + ENV_OFF_SCORE) = 0.0;
 }
 
-// preset: [init_q(8) | target(3) | obstacle(3) | obstacle_jitter] — the demo presets of the reference
+// preset: [init_q(8) | target(3) | obstacle(3) | obstacle_jitter | variation(8)] — the demo presets of the reference
 // (rl_framework.py:547-555 KUKA, :571-580 xArm6) or the caller's own; obstacle_jitter > 0 gives every env its own
-// obstacle position, uniform in a cube of that half-width around the preset (BASELINE configs[3])
+// obstacle position, uniform in a cube of that half-width around the preset (BASELINE configs[3]); variation[k] = half-width
+// of the uniform range joint k's initial position is drawn from at every reset (initial_positions_variation_range,
+// environment.py:284-293)
 struct EnvPreset {
-    float v[15];
+    float v[NAF_SYNTH_PRESET_FLOATS];
 };
 
 __global__ void synth_env_reset_kernel(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t ctr,
@@ -79,7 +88,8 @@ __global__ void synth_env_reset_kernel(float* env_state, float* obs, int E, int 
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     float* st = env_state + (int64_t)e * ENV_STATE_FLOATS;
-    for (int k = 0; k < 8; ++k) st[14 + k] = preset.v[k];
+    for (int k = 0; k < 8; ++k) { st[14 + k] = preset.v[k]; st[ENV_OFF_VAR + k] = preset.v[15 + k]; }
+    st[34] = st[35] = 0.f;
     for (int k = 0; k < 3; ++k) { st[8 + k] = preset.v[8 + k]; st[11 + k] = preset.v[11 + k]; }
     if (preset.v[14] > 0.f) {
         Philox4 p = philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)e, 0x4f425354u, 0x9E3779B9u, 0x243F6A88u);
@@ -95,7 +105,8 @@ __global__ void synth_env_reset_kernel(float* env_state, float* obs, int E, int 
 
 __global__ void synth_env_step_kernel(float* env_state, const float* __restrict__ actions, float* __restrict__ out_rows,
                                       float* __restrict__ obs_next, int E, int A, int row_floats, uint64_t seed,
-                                      const uint64_t* counter_dev, int max_frames) {
+                                      const uint64_t* counter_dev, int max_frames, naf_episode_record_t* __restrict__ records,
+                                      int record_slots) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const int S = 2 * A + 9;
@@ -127,7 +138,23 @@ __global__ void synth_env_step_kernel(float* env_state, const float* __restrict_
     for (int k = off_d + 1; k < row_floats; ++k) row[k] = 0.f;
 
     st[22] += 1.f;
-    if (done != 0.f || (max_frames > 0 && st[22] >= (float)max_frames)) {
+    const double score = *(double*)(st + ENV_OFF_SCORE) + (double)reward;      // score += reward (naf_algorithm.py:264)
+    *(double*)(st + ENV_OFF_SCORE) = score;
+    const bool over = done != 0.f || (max_frames > 0 && st[22] >= (float)max_frames);
+    if (records) {
+        // one record slot per (vector step mod record_slots, env), written EVERY step (frames == 0: no episode ended here):
+        // the host drains whole slots in (step, env) order — completion order without an atomic or a per-step sync
+        naf_episode_record_t rec;
+        rec.score = over ? score : 0.0;
+        rec.frames = over ? (int32_t)st[22] : 0;
+        rec.done = (int32_t)done;
+        rec.last_reward = reward;
+        rec.episode = (int32_t)st[23] + 1;
+        rec.step_lo = (uint32_t)ctr;
+        rec.env = (uint32_t)e;
+        records[(int64_t)(ctr % (uint64_t)record_slots) * E + e] = rec;
+    }
+    if (over) {
         // episode over (terminal state, or the frame budget of NAFAgent.run, naf_algorithm.py:249): auto-reset
         st[23] += 1.f;
         env_reset_one(st, e, A, seed, ctr * 0x9E3779B97F4A7C15ull + (uint64_t)st[23]);
@@ -142,23 +169,27 @@ __global__ void synth_env_step_kernel(float* env_state, const float* __restrict_
 extern "C" int naf_synth_env_state_floats(int A) { return (A > 0 && A <= NAF_MAX_A) ? ENV_STATE_FLOATS : NAF_ERR_ARG; }
 
 extern "C" int naf_synth_env_reset(float* env_state, float* obs, int E, int A, uint64_t seed, uint64_t counter,
-                                   const float* preset_host, void* stream) {
+                                   const float* preset_host, int preset_floats, void* stream) {
     if (!env_state || !obs || E <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
-    // default: the reference's KUKA demo preset (rl_framework.py:551-553), no obstacle jitter
-    EnvPreset p = {{0.9f, 0.45f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.4f, 0.85f, 0.71f, 0.45f, 0.55f, 0.55f, 0.f}};
+    if (preset_host && preset_floats != 15 && preset_floats != NAF_SYNTH_PRESET_FLOATS) return NAF_ERR_ARG;
+    // default: the reference's KUKA demo preset (rl_framework.py:551-553), no obstacle jitter, +-0.1 on every joint
+    EnvPreset p = {{0.9f, 0.45f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.4f, 0.85f, 0.71f, 0.45f, 0.55f, 0.55f, 0.f,
+                    0.1f, 0.1f, 0.1f, 0.1f, 0.1f, 0.1f, 0.1f, 0.1f}};
     if (preset_host)
-        for (int k = 0; k < 15; ++k) p.v[k] = preset_host[k];
+        for (int k = 0; k < preset_floats; ++k) p.v[k] = preset_host[k];
     synth_env_reset_kernel<<<(E + 63) / 64, 64, 0, (hipStream_t)stream>>>(env_state, obs, E, A, seed, counter, p);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
 
 extern "C" int naf_synth_env_step(float* env_state, const float* actions, float* out_rows, float* obs_next, int E, int A,
-                                  uint64_t seed, const uint64_t* counter_dev, int max_frames, void* stream) {
+                                  uint64_t seed, const uint64_t* counter_dev, int max_frames, naf_episode_record_t* records,
+                                  int record_slots, void* stream) {
     if (!env_state || !actions || !out_rows || !obs_next || E <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
+    if (records && (record_slots <= 0 || !counter_dev)) return NAF_ERR_ARG;
     int rf = naf_replay_row_floats(2 * A + 9, A);
     synth_env_step_kernel<<<(E + 63) / 64, 64, 0, (hipStream_t)stream>>>(env_state, actions, out_rows, obs_next, E, A, rf,
-                                                                         seed, counter_dev, max_frames);
+                                                                         seed, counter_dev, max_frames, records, record_slots);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -11,8 +11,11 @@ stream torch reports as current, which inside the capture context is the capturi
 """
 from __future__ import annotations
 
-from typing import Optional
+import json
+import os
+from typing import Callable, Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -139,14 +142,72 @@ class TrainChunk:
         return self.loss_parts.sum(dim=1)
 
 
+# naf_episode_record_t (include/naf_hip.h), 32 bytes
+EPISODE_RECORD = np.dtype([("score", "<f8"), ("frames", "<i4"), ("done", "<i4"), ("last_reward", "<f4"),
+                           ("episode", "<i4"), ("step_lo", "<u4"), ("env", "<u4")])
+
+
+class EpisodeLedger:
+    """What NAFAgent.run keeps and writes per finished episode (naf_algorithm.py:241-289), for loops in which E
+    environments finish episodes in any order: `scores` = {episode: (score, last_frame)} numbered in COMPLETION order,
+    `checkpoints/{episode}/weights.p` + `scores.txt` whenever the count reaches a multiple of checkpoint_frequency, and
+    `model.p` at the end — same file names, JSON shape and state-dict keys as the reference, written by rank 0 only."""
+
+    def __init__(self, episodes: Optional[int], checkpoint_frequency: int, state_dict_fn: Callable[[], dict],
+                 write: bool = True, model_path: str = "model.p"):
+        """episodes: the budget (`episodes` of run()); the dict is pre-filled with (0, 0) as the reference's is (:241) and
+        episodes beyond it are counted but not recorded. None: open-ended."""
+        self.limit = episodes
+        self.scores: Dict[int, Tuple[float, int]] = {} if episodes is None else {e: (0, 0) for e in range(1, episodes + 1)}
+        self.count = 0                      # episodes recorded
+        self.extra = 0                      # episodes that finished after the budget was met (not recorded)
+        self.every = int(checkpoint_frequency)
+        self._state_dict_fn, self.write, self.model_path = state_dict_fn, bool(write), model_path
+        self.checkpoints: List[int] = []
+
+    @property
+    def complete(self) -> bool:
+        return self.limit is not None and self.count >= self.limit
+
+    def add(self, score: float, frames: int) -> None:
+        if self.complete:
+            self.extra += 1
+            return
+        self.count += 1
+        self.scores[self.count] = (float(score), int(frames))
+        if self.every > 0 and self.count % self.every == 0 and self.write:
+            d = f"checkpoints/{self.count}/"
+            os.makedirs(d, exist_ok=True)
+            torch.save(self._state_dict_fn(), d + "weights.p")
+            with open(d + "scores.txt", "w") as f:
+                f.write(json.dumps(self.scores))
+            self.checkpoints.append(self.count)
+
+    def finish(self) -> Dict[int, Tuple[float, int]]:
+        if self.write:
+            torch.save(self._state_dict_fn(), self.model_path)
+        return self.scores
+
+
 class DeviceEnvLoop:
-    """E synthetic manipulator envs living on the GPU (csrc/synth_env.hip) driven by the agent's policy."""
+    """E synthetic manipulator envs living on the GPU (csrc/synth_env.hip) driven by the agent's policy.
+
+    Episode records (`records=True`): the step kernel keeps every env's running score and frame count and writes one
+    naf_episode_record_t per (vector step, env) into a ring of `drain_every` slots; every `drain_every` steps the ring is
+    copied to pinned host memory behind the step that filled it (asynchronous, an event marks it) and the PREVIOUS copy
+    — long finished by then — is parsed: finished episodes reach the host in (step, env) order with a lag of at most
+    2 x drain_every vector steps and without a synchronisation per step. `drain(final=True)` flushes the rest."""
 
     # [initial joint positions(8) | target | obstacle] per robot, from the one preset table (presets.py)
     PRESETS = {name: device_env_preset(name) for name in ROBOT_PRESETS}
 
-    def __init__(self, learner: Learner, replay: ReplayBuffer, n_envs: int, seed: int, max_frames: int = 400,
-                 noise_scale: float = 1.0, use_graph: bool = True, robot: str = "kuka", obstacle_jitter: float = 0.0):
+    def __init__(self, learner: Learner, replay: Optional[ReplayBuffer], n_envs: int, seed: int, max_frames: int = 400,
+                 noise_scale: float = 1.0, use_graph: bool = True, robot: str = "kuka", obstacle_jitter: float = 0.0,
+                 preset: Optional[List[float]] = None, variation: Optional[List[float]] = None, records: bool = False,
+                 drain_every: int = 64):
+        """replay=None: no transitions are appended (evaluation). preset: 14 floats [initial joint positions(8) | target |
+        obstacle] instead of a named robot's. variation: per-joint half-width of the reset range (None: 0.1 everywhere,
+        the stand-in's historical value)."""
         self.L, self.replay, self.E = learner, replay, int(n_envs)
         lay, dev = learner.lay, learner.dev
         self.lib = learner.lib
@@ -162,34 +223,58 @@ class DeviceEnvLoop:
         self.use_graph = use_graph
         self.env_steps = 0
         import ctypes
-        self._preset = (ctypes.c_float * 15)(*(self.PRESETS[robot] + [float(obstacle_jitter)]))
+        base = list(preset) if preset is not None else list(self.PRESETS[robot])
+        if len(base) != 14:
+            raise ValueError("DeviceEnvLoop: preset = [initial joint positions(8) | target xyz | obstacle xyz]")
+        var = [0.1] * 8 if variation is None else ([float(v) for v in variation] + [0.0] * 8)[:8]
+        self._preset = (ctypes.c_float * 23)(*(base + [float(obstacle_jitter)] + var))
+        self.drain_every = max(1, int(drain_every))
+        self.records = None
+        self._finished: List[tuple] = []
+        self._steps = 0              # vector steps enqueued since reset
+        self._copied = 0             # ... of which this many have had their record slots copied out
+        self._inflight = None        # (pinned copy, event, first step, n steps) not parsed yet
+        if records:
+            self.records = torch.zeros(self.drain_every, self.E, 8, dtype=torch.int32, device=dev)
+            self._pins = [torch.zeros(self.drain_every, self.E, 8, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._pin_i = 0
         self.reset()
 
     def reset(self) -> None:
         check(self.lib.naf_synth_env_reset(ptr(self.env_state), ptr(self.actor.obs), self.E, self.L.lay.A, self.seed, 0,
-                                           self._preset, stream_ptr()), "synth_env_reset")
+                                           self._preset, 23, stream_ptr()), "synth_env_reset")
+        self.step_ctr.zero_()
+        self._steps = self._copied = 0
+        self._inflight = None
+        self._finished = []
 
     def _body(self) -> None:
         st = stream_ptr()
         self.actor.act(self.noise_scale)                                     # NAFAgent.act for E states
         check(self.lib.naf_synth_env_step(ptr(self.env_state), ptr(self.actor.actions), ptr(self.rows),
                                           ptr(self.actor.obs), self.E, self.L.lay.A, self.seed, ptr(self.step_ctr),
-                                          self.max_frames, st), "synth_env_step")   # environment.step
+                                          self.max_frames, ptr(self.records), self.drain_every if self.records is not None else 0,
+                                          st), "synth_env_step")   # environment.step
         check(self.lib.naf_counter_add(ptr(self.step_ctr), 1, st), "counter_add")
-        check(self.lib.naf_replay_add_batch(self.replay.handle, ptr(self.rows), self.E, st), "replay_add_batch")
+        if self.replay is not None:
+            check(self.lib.naf_replay_add_batch(self.replay.handle, ptr(self.rows), self.E, st), "replay_add_batch")
 
     def capture(self) -> None:
         warmup = 2
-        snap = _StateSnapshot(self.L, self.replay, (self.env_state, self.rows, self.step_ctr, self.actor.obs,
-                                                    self.actor.counter, self.actor.actions))
-        # the warm-up appends rows to the ring: {head,size} come back with the snapshot, the ring slots it wrote
-        # (possibly live rows of a full ring) are saved and put back here
-        head = int(self.replay.meta[0].item())
-        pos = (head + torch.arange(warmup * self.E, device=self.L.dev)) % self.replay.buffer_size
-        saved = self.replay.rows[pos].clone()
+        extra = (self.env_state, self.rows, self.step_ctr, self.actor.obs, self.actor.counter, self.actor.actions)
+        if self.records is not None:
+            extra += (self.records,)
+        snap = _StateSnapshot(self.L, self.replay, extra)
+        put_back = None
+        if self.replay is not None:
+            # the warm-up appends rows to the ring: {head,size} come back with the snapshot, the ring slots it wrote
+            # (possibly live rows of a full ring) are saved and put back here
+            head = int(self.replay.meta[0].item())
+            pos = (head + torch.arange(warmup * self.E, device=self.L.dev)) % self.replay.buffer_size
+            saved = self.replay.rows[pos].clone()
 
-        def put_back():
-            self.replay.rows[pos] = saved
+            def put_back():
+                self.replay.rows[pos] = saved
         self.graph = _capture(self._body, snap, warmup=warmup, after_warmup=put_back)
 
     def step(self) -> None:
@@ -200,5 +285,50 @@ class DeviceEnvLoop:
             self.graph.replay()
         else:
             self._body()
-        self.replay._total_added += self.E
+        if self.replay is not None:
+            self.replay._total_added += self.E
         self.env_steps += self.E
+        self._steps += 1
+        if self.records is not None and self._steps - self._copied == self.drain_every:
+            self._copy_out()
+
+    # ---- episode records ----------------------------------------------------------------------------------------------
+    def _copy_out(self) -> None:
+        """Enqueue the copy of the record slots of steps [_copied, _steps) behind them; parse the copy before it."""
+        self._parse_inflight()
+        n = self._steps - self._copied
+        pin = self._pins[self._pin_i]
+        self._pin_i ^= 1
+        pin.copy_(self.records, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight = (pin, ev, self._copied, n)
+        self._copied = self._steps
+
+    def _parse_inflight(self) -> None:
+        if self._inflight is None:
+            return
+        pin, ev, first, n = self._inflight
+        self._inflight = None
+        ev.synchronize()
+        rec = pin.numpy().view(EPISODE_RECORD).reshape(self.drain_every, self.E)
+        # steps first .. first+n-1 sit in slots (first + j) % drain_every; first is a multiple of drain_every
+        for j in range(n):
+            row = rec[(first + j) % self.drain_every]
+            for e in np.nonzero(row["frames"] > 0)[0]:
+                r = row[e]
+                self._finished.append((float(r["score"]), int(r["frames"]), int(r["done"]), float(r["last_reward"]),
+                                       int(e), int(r["episode"]), first + j))
+
+    def drain(self, final: bool = False) -> List[tuple]:
+        """Finished episodes the host has seen since the last call, in (step, env) order:
+        (score, frames, done, last_reward, env, env's episode ordinal, vector step). final=True waits for the GPU and
+        returns everything up to the last enqueued step."""
+        if self.records is None:
+            raise _lib.NafHipError("DeviceEnvLoop(records=False) keeps no episode records")
+        if final:
+            if self._steps > self._copied:
+                self._copy_out()
+            self._parse_inflight()
+        out, self._finished = self._finished, []
+        return out

@@ -15,13 +15,13 @@ import json
 import os
 import random
 import time
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
 
 from .. import _lib
-from ..engine import DeviceEnvLoop, TrainChunk
+from ..engine import DeviceEnvLoop, EpisodeLedger, TrainChunk
 from ..learner import ActPath, Learner
 from ..utils.exceptions import MissingWeightsFile
 from ..utils.logger import get_global_logger
@@ -112,6 +112,7 @@ class NAFAgent:
         self._act_pinned = torch.zeros(1, action_size, dtype=torch.float32).pin_memory()
         self._learn_rows = torch.zeros(batch_size + 1, L.lay.batch_row_floats, dtype=torch.float32, device=self.device)[:batch_size]
         self._learn_loss = torch.zeros(L.n_loss_wg, dtype=torch.float32, device=self.device)
+        self.last_run_stats: Optional[dict] = None    # counters of the most recent run_vectorized / run_host_vectorized
 
     # ---- pretrained weights (naf_algorithm.py:91-127) ----------------------------------------------------------
     def _load_weights(self, path: str) -> None:
@@ -282,42 +283,102 @@ class NAFAgent:
         return type(self.qnetwork_main.state_dict())((k, v.cpu()) for k, v in self.qnetwork_main.state_dict().items())
 
     # ---- training loop with E on-device synthetic envs (the many-env path of BASELINE configs[1..4]) -----------
-    def run_vectorized(self, vector_steps: int, n_envs: int = 64, max_frames: int = 400, noise_scale: float = 1.0,
-                       robot: str = "kuka", obstacle_jitter: float = 0.0) -> dict:
-        """E synthetic arms on the GPU feed the HBM replay ring; each vector step is followed by
-        E * num_updates / update_freq learn() calls, i.e. the reference's update-to-data ratio. Returns counters;
-        everything stays on the device (no host sync per step)."""
+    def _ledger(self, episodes: Optional[int]) -> EpisodeLedger:
+        return EpisodeLedger(episodes, self.checkpoint_frequency, self._cpu_state_dict, write=self.rank == 0,
+                             model_path=self.MODEL_PATH)
+
+    def _stop_agreed(self, stop: bool) -> bool:
+        """Data parallel: every chunk of updates holds a gradient all-reduce, so all ranks must leave the loop after the
+        same vector step — rank 0's verdict (its envs fill the scores dict) is broadcast where the ranks compare notes."""
+        if self.world_size == 1:
+            return stop
+        import torch.distributed as dist
+        flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=self.device)
+        dist.broadcast(flag, src=0)
+        return bool(flag.item())
+
+    def run_vectorized(self, vector_steps: Optional[int] = None, n_envs: int = 64, max_frames: int = 400,
+                       noise_scale: float = 1.0, robot: str = "kuka", obstacle_jitter: float = 0.0, *,
+                       episodes: Optional[int] = None, preset=None, variation=None, drain_every: int = 64,
+                       verbose: bool = False) -> dict:
+        """NAFAgent.run (naf_algorithm.py:228-292) re-hosted for E synthetic arms on the GPU feeding the HBM replay ring;
+        each vector step is followed by E * num_updates / update_freq learn() calls, i.e. the reference's update-to-data
+        ratio. Everything stays on the device, no host sync per step.
+
+        What run() produces is produced here too: per-env episode bookkeeping rides in the env-step kernel (running score
+        in double, frame count, auto-reset on done / after `max_frames` = run()'s `frames`), finished episodes reach the host
+        every `drain_every` vector steps in (step, env) order and are numbered in completion order into
+        `scores = {episode: (score, last_frame)}`; `checkpoints/{episode}/weights.p` + `scores.txt` every
+        `checkpoint_frequency` finished episodes and `model.p` at the end (rank 0 only under data parallel) — the files
+        `plot_training_rewards` and `initialize_pretrained_agent_from_episode` read. A checkpoint's weights are those at
+        the drain that saw its episode, at most 2 x drain_every vector steps after the episode ended (drain_every=1: at
+        the step itself, one host sync per vector step).
+
+        Stops after `vector_steps` vector steps and/or once `episodes` episodes have finished (checked at the drains:
+        training may run up to 2 x drain_every steps past the last episode; episodes finishing there are counted in
+        `episodes_finished` but not recorded, as run() records exactly `episodes`).
+        Returns the counters of earlier rounds plus 'scores', 'episodes_finished', 'checkpoints'."""
         E = int(n_envs)
         if (E * self.num_updates) % self.update_freq != 0:
             raise ValueError("n_envs * num_updates must be a multiple of update_freq")
+        if vector_steps is None and episodes is None:
+            raise ValueError("run_vectorized: give vector_steps and/or episodes")
         U = E * self.num_updates // self.update_freq
         loop = DeviceEnvLoop(self.learner, self.memory, E, seed=self.seed + 104729 * self.rank, max_frames=max_frames,
-                             noise_scale=noise_scale, use_graph=self.use_graph, robot=robot, obstacle_jitter=obstacle_jitter)
+                             noise_scale=noise_scale, use_graph=self.use_graph, robot=robot, obstacle_jitter=obstacle_jitter,
+                             preset=preset, variation=variation, records=True, drain_every=drain_every)
         chunk = TrainChunk(self.learner, self.memory, U, use_graph=self.use_graph)
+        ledger = self._ledger(episodes)
         self.memory.flush()
+        logger.info(f'Training started ({E} environments on the device)')
         t0 = time.time()
-        updates = 0
-        for _ in range(vector_steps):
+        updates = steps = 0
+
+        def book(final=False):
+            for score, frames, *_ in loop.drain(final):
+                ledger.add(score, frames)
+                if verbose:
+                    logger.info(f'Episode {ledger.count + ledger.extra}: Reward {score}  Number of frames {frames}')
+
+        while vector_steps is None or steps < vector_steps:
             loop.step()
+            steps += 1
             if len(self.memory) > self.batch_size:
                 chunk.run()
                 updates += U
+            if steps % loop.drain_every == 0:
+                book()
+                if episodes is not None and self._stop_agreed(ledger.complete):
+                    break
         torch.cuda.synchronize()
         dt = time.time() - t0
-        return {"env_steps": vector_steps * E, "updates": updates, "seconds": dt,
-                "env_steps_per_s": vector_steps * E / dt, "last_loss": float(chunk.losses()[-1].item()) if updates else None}
+        book(final=True)
+        scores = ledger.finish()
+        if self.rank == 0:
+            logger.info(f'Model has been successfully saved in {self.MODEL_PATH}')
+        self.last_run_stats = {
+            "env_steps": steps * E, "updates": updates, "seconds": dt, "env_steps_per_s": steps * E / dt,
+            "last_loss": float(chunk.losses()[-1].item()) if updates else None, "scores": scores,
+            "episodes_finished": ledger.count + ledger.extra, "checkpoints": list(ledger.checkpoints)}
+        return self.last_run_stats
 
     # ---- training loop with E host environments in worker processes (PyBullet or any env with the reference protocol) --
-    def run_host_vectorized(self, vec_env, vector_steps: int, async_policy: bool = False, noise_scale: float = 1.0) -> dict:
+    def run_host_vectorized(self, vec_env, vector_steps: Optional[int] = None, async_policy: bool = False,
+                            noise_scale: float = 1.0, *, episodes: Optional[int] = None, verbose: bool = False) -> dict:
         """vec_env: environment.vector_env.HostVectorEnv with E envs. Per vector step: batched act() on the GPU for the E
         current states -> workers step their envs -> E transitions packed into pinned memory -> one H2D copy -> HBM
         replay ring -> E * num_updates / update_freq learn() calls (the reference's update-to-data ratio).
         async_policy=False keeps the reference's ordering (the policy of step t has seen every update of step t-1);
         async_policy=True enqueues the learn() chunk of step t-1 behind act(t), so the GPU learns while the workers
-        simulate (the policy then lags by one vector step: "asynchronous many-env training")."""
+        simulate (the policy then lags by one vector step: "asynchronous many-env training").
+        Scores / checkpoints / model.p as run() writes them (see run_vectorized; here the rewards pass through the host
+        every step, so an episode is booked — and a checkpoint written — in the very step it ends). The frame budget per
+        episode is vec_env.max_frames. Stops after `vector_steps` steps and/or `episodes` finished episodes."""
         E = vec_env.E
         if (E * self.num_updates) % self.update_freq != 0:
             raise ValueError("n_envs * num_updates must be a multiple of update_freq")
+        if vector_steps is None and episodes is None:
+            raise ValueError("run_host_vectorized: give vector_steps and/or episodes")
         U = E * self.num_updates // self.update_freq
         L, lay = self.learner, self.learner.lay
         actor = ActPath(L, E, seed=(self.seed * 40503 + 7 + self.rank) & 0xFFFFFFFFFFFFFFFF)
@@ -327,12 +388,15 @@ class NAFAgent:
         rows_pin = torch.zeros(E, lay.row_floats, dtype=torch.float32).pin_memory()
         rows_dev = torch.zeros(E, lay.row_floats, dtype=torch.float32, device=self.device)
         rows_np, obs_np = rows_pin.numpy(), obs_pin.numpy()
+        ledger = self._ledger(episodes)
+        ep_score, ep_frames = np.zeros(E, np.float64), np.zeros(E, np.int64)
         self.memory.flush()
         obs = vec_env.reset()
+        logger.info(f'Training started ({E} environments in worker processes)')
         t0 = time.time()
-        updates, reward_sum, pending_learn = 0, 0.0, False
+        updates, reward_sum, pending_learn, steps = 0, 0.0, False, 0
         stream = torch.cuda.current_stream()
-        for _ in range(vector_steps):
+        while vector_steps is None or steps < vector_steps:
             obs_np[...] = obs
             actor.obs.copy_(obs_pin, non_blocking=True)
             actor.act(noise_scale)
@@ -345,7 +409,11 @@ class NAFAgent:
                 pending_learn = False
             ev.synchronize()
             _, _, rewards, _, _, obs = vec_env.step(act_pin.numpy())
+            steps += 1
             reward_sum += float(rewards.sum())
+            ep_score += rewards                               # score += reward, per env (naf_algorithm.py:264)
+            ep_frames += 1
+            ended = np.nonzero(vec_env.arr["episode_end"])[0]
             vec_env.pack_rows(rows_np, lay.off_s2)
             rows_dev.copy_(rows_pin, non_blocking=True)
             self.memory.add_rows_device(rows_dev, E)
@@ -356,11 +424,88 @@ class NAFAgent:
                     chunk.run()
                     updates += U
             stream.synchronize()                              # rows_pin / obs_pin are rewritten next iteration
+            for e in ended:                                   # booked after the step's updates, as run() does (:266-287)
+                ledger.add(float(ep_score[e]), int(ep_frames[e]))
+                if verbose:
+                    logger.info(f'Episode {ledger.count + ledger.extra}: Reward {ep_score[e]}  Number of frames {ep_frames[e]}')
+                ep_score[e], ep_frames[e] = 0.0, 0
+            if episodes is not None and self._stop_agreed(ledger.complete):
+                break
         if pending_learn:
             chunk.run()
             updates += U
         torch.cuda.synchronize()
         dt = time.time() - t0
-        return {"env_steps": vector_steps * E, "updates": updates, "seconds": dt, "env_steps_per_s": vector_steps * E / dt,
-                "mean_reward": reward_sum / (vector_steps * E), "episodes_finished": vec_env.episodes_finished,
-                "last_loss": float(chunk.losses()[-1].item()) if updates else None}
+        scores = ledger.finish()
+        if self.rank == 0:
+            logger.info(f'Model has been successfully saved in {self.MODEL_PATH}')
+        self.last_run_stats = {
+            "env_steps": steps * E, "updates": updates, "seconds": dt, "env_steps_per_s": steps * E / dt,
+            "mean_reward": reward_sum / max(1, steps * E), "episodes_finished": vec_env.episodes_finished,
+            "last_loss": float(chunk.losses()[-1].item()) if updates else None, "scores": scores,
+            "checkpoints": list(ledger.checkpoints)}
+        return self.last_run_stats
+
+    # ---- evaluation with E environments (rl_framework.py:319-367 re-hosted) -------------------------------------------
+    @staticmethod
+    def _episode_quota(n_episodes: int, E: int) -> np.ndarray:
+        """Episodes each env contributes: its FIRST q_e episodes, sum = n_episodes. (Taking the first n_episodes to finish
+        anywhere would favour short episodes — collisions and quick successes finish before the time-outs do.)"""
+        q = np.full(E, n_episodes // E, np.int64)
+        q[:n_episodes % E] += 1
+        return q
+
+    def evaluate_vectorized(self, n_episodes: int, frames: int, n_envs: int = 64, noise_scale: float = 1.0,
+                            robot: str = "kuka", obstacle_jitter: float = 0.0, preset=None, variation=None,
+                            drain_every: int = 32) -> List[Tuple[bool, int, bool]]:
+        """test_trained_model's episode loop for E device envs: one batched act() (eval-mode BatchNorm, noisy as every
+        act() of the reference is) and one env step per vector step, nothing appended to the replay ring, no learning.
+        Returns [(completed, last frame index, done)] — completed iff the episode ended `done` with reward == 250; an
+        episode that used all `frames` steps without `done` is (False, frames - 1, False) (rl_framework.py:341-355); done
+        and not completed = a collision — ordered by (env's episode ordinal, env)."""
+        E = int(n_envs)
+        quota = self._episode_quota(int(n_episodes), E)
+        loop = DeviceEnvLoop(self.learner, None, E, seed=self.seed + 15485863 + 104729 * self.rank, max_frames=frames,
+                             noise_scale=noise_scale, use_graph=self.use_graph, robot=robot, obstacle_jitter=obstacle_jitter,
+                             preset=preset, variation=variation, records=True, drain_every=drain_every)
+        seen = np.zeros(E, np.int64)
+        results = []
+        while (seen < quota).any():
+            for _ in range(loop.drain_every):
+                loop.step()
+            for score, nfr, done, last_reward, env, ordinal, step in loop.drain(final=True):
+                if seen[env] < quota[env]:
+                    seen[env] += 1
+                    results.append((ordinal, env, bool(done) and last_reward == 250, nfr - 1, bool(done)))
+        results.sort()
+        return [tuple(r[2:]) for r in results]
+
+    def evaluate_host_vectorized(self, vec_env, n_episodes: int, noise_scale: float = 1.0) -> List[Tuple[bool, int, bool]]:
+        """The same for E host environments in worker processes (frame budget = vec_env.max_frames)."""
+        E = vec_env.E
+        quota = self._episode_quota(int(n_episodes), E)
+        actor = ActPath(self.learner, E, seed=(self.seed * 69069 + 11 + self.rank) & 0xFFFFFFFFFFFFFFFF, host_io=True)
+        seen, ordinal, fr = np.zeros(E, np.int64), np.zeros(E, np.int64), np.zeros(E, np.int64)
+        results = []
+        obs = vec_env.reset()
+        stream = torch.cuda.current_stream()
+        while (seen < quota).any():
+            if actor.host_io:
+                actor.obs_np[...] = obs
+                actor.act(noise_scale)
+                stream.synchronize()
+                actions = actor.actions_np
+            else:
+                actor.obs.copy_(torch.from_numpy(np.asarray(obs, np.float32)))
+                actions = actor.act(noise_scale).cpu().numpy()
+            _, _, rewards, _, dones, obs = vec_env.step(actions)
+            fr += 1
+            for e in np.nonzero(vec_env.arr["episode_end"])[0]:
+                ordinal[e] += 1
+                if seen[e] < quota[e]:
+                    seen[e] += 1
+                    results.append((int(ordinal[e]), int(e), bool(dones[e]) and rewards[e] == 250, int(fr[e]) - 1,
+                                    bool(dones[e])))
+                fr[e] = 0
+        results.sort()
+        return [tuple(r[2:]) for r in results]

@@ -9,9 +9,15 @@ Differences, all opt-in or forced by the image:
   * the demos take `interactive=False` to skip the reference's input() prompts (rl_framework.py:525,535) and
     `environment='synthetic'` to run without PyBullet.
   * p_mode / action_mode / use_graph can be passed to initialize_naf_agent(); defaults = reference semantics.
+  * many-env training and evaluation: initialize_naf_agent(..., n_envs=E), run_training(...,
+    n_envs=E) and test_trained_model(..., n_envs=E) run E copies of the configured environment — on the device for the
+    synthetic stand-in, in E worker processes for anything else (PyBullet) — and produce what the one-env calls
+    produce: the {episode: (score, last_frame)} dict, checkpoints/{episode}/weights.p + scores.txt, model.p, the logged
+    test summary. Without n_envs every call is the reference's one-env loop, signature and behaviour untouched.
 """
 from __future__ import annotations
 
+import functools
 import json
 import os
 import re
@@ -72,11 +78,25 @@ _HYPERPARAMETER_RULES = (
 _DEMO_ENVS = {name: pybullet_arguments(name) for name in ROBOT_PRESETS}
 
 
+def _build_environment(manipulator_file: str, config_kwargs: dict):
+    """Picklable factory of one PyBullet Environment (a worker process of environment.vector_env.HostVectorEnv calls it;
+    workers never open a GUI: DIRECT mode, as north_star's "N independent PyBullet DIRECT envs per GPU")."""
+    from .environment.environment import Environment, EnvironmentConfiguration
+    return Environment(manipulator_file=manipulator_file,
+                       environment_config=EnvironmentConfiguration(**dict(config_kwargs, visualize=False)))
+
+
+def _build_synthetic(n_joints, target, obstacle, init, variation):
+    return SyntheticEnvironment(n_joints, target, obstacle, init, variation)
+
+
 class ManipulatorFramework:
 
     def __init__(self) -> None:
         self.env = None
         self.naf_agent: Optional[NAFAgent] = None
+        self._env_factory = None          # picklable zero-argument factory of a copy of self.env (many-env paths)
+        self._n_envs: Optional[int] = None
         self._hyperparameters: Optional[HyperParameters] = None
         self._initialize_hyperparameters()
         logger.info('The Framework has been initialized with the default hyperparameters configuration')
@@ -178,12 +198,22 @@ class ManipulatorFramework:
             logger.info('* {:<40} {}'.format(label + ':', getattr(self.naf_agent, attr)))
 
     # ---- evaluation -----------------------------------------------------------------------------------------------
-    def test_trained_model(self, n_episodes: int, frames: int) -> dict:
+    def test_trained_model(self, n_episodes: int, frames: int, n_envs: Optional[int] = None) -> dict:
         """n_episodes test episodes of at most `frames` steps; success iff done with reward == 250
-        (rl_framework.py:319-367). Also returns the summary it logs."""
+        (rl_framework.py:319-367). Also returns the summary it logs. n_envs=E (or the n_envs given to
+        initialize_naf_agent): the episodes are spread over E copies of the environment and every vector step is one
+        batched act() — same result rule, same log lines."""
         if not self.naf_agent or not self.env:
             raise ConfigurationIncomplete
         results, num_collisions = [], 0
+        E = n_envs if n_envs is not None else self._n_envs
+        if E is not None and E > 1:
+            triples = self._many_env_results(n_episodes, frames, int(E))
+            results = [(ok, frame) for ok, frame, _ in triples]
+            num_collisions = sum(1 for ok, _, done in triples if done and not ok)
+            for ep in range(len(results)):
+                logger.info('Test Episode number {ep} completed\n'.format(ep=ep + 1))
+            n_episodes = 0
         for ep in range(n_episodes):
             state = self.env.reset()
             for frame in range(frames):
@@ -227,6 +257,11 @@ class ManipulatorFramework:
             initial_joint_positions=initial_joint_positions,
             initial_positions_variation_range=initial_positions_variation_range, max_force=max_force, visualize=visualize)
         self.env = Environment(manipulator_file=manipulator_file, environment_config=config)
+        self._env_factory = functools.partial(_build_environment, manipulator_file, dict(
+            endeffector_index=endeffector_index, fixed_joints=fixed_joints, involved_joints=involved_joints,
+            target_position=target_position, obstacle_position=obstacle_position,
+            initial_joint_positions=initial_joint_positions,
+            initial_positions_variation_range=initial_positions_variation_range, max_force=max_force))
         logger.info('Pybullet Environment successfully initialized')
 
     def initialize_synthetic_environment(self, n_joints: int = 6, target_position: List[float] = None,
@@ -234,6 +269,8 @@ class ManipulatorFramework:
                                          initial_positions_variation_range: List[float] = None) -> None:
         self.env = SyntheticEnvironment(n_joints, target_position, obstacle_position, initial_joint_positions,
                                         initial_positions_variation_range)
+        self._env_factory = functools.partial(_build_synthetic, n_joints, target_position, obstacle_position,
+                                              initial_joint_positions, initial_positions_variation_range)
         logger.info('Synthetic (kinematic stand-in) Environment successfully initialized')
 
     def delete_environment(self) -> None:
@@ -244,16 +281,22 @@ class ManipulatorFramework:
         if close:
             close()
         self.env = None
+        self._env_factory = None
         logger.info('Environment instance has been successfully removed')
 
     # ---- agent --------------------------------------------------------------------------------------------------------
-    def initialize_naf_agent(self, checkpoint_frequency: int = 500, seed: int = 0, **agent_options) -> None:
+    def initialize_naf_agent(self, checkpoint_frequency: int = 500, seed: int = 0, n_envs: Optional[int] = None,
+                             **agent_options) -> None:
         """rl_framework.py:431-465: same guards, same NAFAgent keyword arguments (layer_size is 256, :452).
-        The device is cuda:0 — this build has no CPU path, so a missing GPU is an error, not a silent fallback."""
+        The device is cuda:0 — this build has no CPU path, so a missing GPU is an error, not a silent fallback.
+        n_envs=E: run_training / test_trained_model of this agent use E copies of the environment (see the module text)."""
         if not self.env:
             raise EnvironmentNotInitialized
         if not isinstance(checkpoint_frequency, int) or not isinstance(seed, int):
             raise InvalidNAFAgentParameter('Checkpoint Frequency or Seed received is not an integer')
+        if n_envs is not None and (not isinstance(n_envs, int) or n_envs < 1):
+            raise InvalidNAFAgentParameter('Number of environments received is not a positive integer')
+        self._n_envs = n_envs
         hp = self._hyperparameters
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         device = torch.device(f'cuda:{local_rank}')
@@ -271,20 +314,61 @@ class ManipulatorFramework:
             logger.error('No existing instance of NAFAgent found')
             return
         self.naf_agent = None
+        self._n_envs = None
         logger.info('NAFAgent instance has been successfully removed')
 
     # ---- training ---------------------------------------------------------------------------------------------------
-    def run_training(self, episodes: int, frames: Optional[int] = 500, verbose: bool = True):
+    def run_training(self, episodes: int, frames: Optional[int] = 500, verbose: bool = True, n_envs: Optional[int] = None):
+        """rl_framework.py:478-501 -> NAFAgent.run(frames, episodes, verbose): {episode: (score, last_frame)}, checkpoints,
+        model.p. n_envs=E (or the n_envs given to initialize_naf_agent): the same outputs from E environments at once —
+        episodes numbered in completion order, `frames` the budget of each; counters in naf_agent.last_run_stats."""
         if not self.naf_agent or not self.env:
             raise ConfigurationIncomplete
-        return self.naf_agent.run(frames, episodes, verbose)
+        E = n_envs if n_envs is not None else self._n_envs
+        if E is None or E <= 1:
+            return self.naf_agent.run(frames, episodes, verbose)
+        if isinstance(self.env, SyntheticEnvironment):
+            return self.naf_agent.run_vectorized(episodes=episodes, n_envs=int(E), max_frames=frames, verbose=verbose,
+                                                 **self._device_env_arguments())['scores']
+        vec = self._host_vector_env(int(E), frames)
+        try:
+            return self.naf_agent.run_host_vectorized(vec, episodes=episodes, verbose=verbose)['scores']
+        finally:
+            vec.close()
 
     def run_vectorized_training(self, vector_steps: int, n_envs: int = 64, max_frames: int = 400) -> dict:
-        """Many-env training on the device-resident synthetic arms (BASELINE configs[1..4] shape); see
-        NAFAgent.run_vectorized."""
+        """Many-env training on the device-resident synthetic arms (BASELINE configs[1..4] shape) for a fixed number of
+        vector steps; see NAFAgent.run_vectorized (counters + 'scores')."""
         if not self.naf_agent or not self.env:
             raise ConfigurationIncomplete
-        return self.naf_agent.run_vectorized(vector_steps, n_envs=n_envs, max_frames=max_frames)
+        kw = self._device_env_arguments() if isinstance(self.env, SyntheticEnvironment) else {}
+        return self.naf_agent.run_vectorized(vector_steps, n_envs=n_envs, max_frames=max_frames, **kw)
+
+    # ---- E copies of the configured environment -------------------------------------------------------------------
+    def _device_env_arguments(self) -> dict:
+        """The synthetic environment's configuration as csrc/synth_env.hip takes it."""
+        env = self.env
+        pad8 = lambda v: ([float(x) for x in v] + [0.0] * 8)[:8]          # noqa: E731
+        var = env.initial_positions_variation_range
+        return {'preset': pad8(env.initial_joint_positions) + [float(x) for x in env.target_pos] +
+                [float(x) for x in env.obstacle_pos], 'variation': pad8(var) if var is not None else [0.0] * 8}
+
+    def _host_vector_env(self, n_envs: int, frames: int):
+        from .environment.vector_env import HostVectorEnv
+        if self._env_factory is None:
+            raise ConfigurationIncomplete('many-env runs need an environment built by initialize_environment() / '
+                                          'initialize_synthetic_environment() (a factory of copies of it)')
+        return HostVectorEnv(self._env_factory, n_envs, self.naf_agent.state_size, self.naf_agent.action_size,
+                             max_frames=frames, seed=self.naf_agent.seed)
+
+    def _many_env_results(self, n_episodes: int, frames: int, n_envs: int):
+        if isinstance(self.env, SyntheticEnvironment):
+            return self.naf_agent.evaluate_vectorized(n_episodes, frames, n_envs=n_envs, **self._device_env_arguments())
+        vec = self._host_vector_env(n_envs, frames)
+        try:
+            return self.naf_agent.evaluate_host_vectorized(vec, n_episodes)
+        finally:
+            vec.close()
 
     # ---- demos --------------------------------------------------------------------------------------------------------
     def _clear_for_demo(self, interactive: bool) -> bool:

@@ -249,7 +249,7 @@ def test_device_env_kernel_matches_numpy_environment():
     obs = torch.zeros(E, S, device=DEV)
     rows = torch.zeros(E, 64, device=DEV)
     stream = torch.cuda.current_stream().cuda_stream
-    assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 5, 0, None, stream) == 0
+    assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 5, 0, None, 0, stream) == 0
     envs = [SyntheticEnvironment(A) for _ in range(E)]
     q0 = st[:, :A].cpu().numpy()
     for e, env in enumerate(envs):
@@ -260,7 +260,7 @@ def test_device_env_kernel_matches_numpy_environment():
     for t in range(30):
         act = rng.uniform(-1, 1, (E, A)).astype(np.float32)
         a_d = torch.from_numpy(act).to(DEV)
-        assert lib.naf_synth_env_step(st.data_ptr(), a_d.data_ptr(), rows.data_ptr(), obs.data_ptr(), E, A, 5, None, 0, stream) == 0
+        assert lib.naf_synth_env_step(st.data_ptr(), a_d.data_ptr(), rows.data_ptr(), obs.data_ptr(), E, A, 5, None, 0, None, 0, stream) == 0
         r = rows.cpu().numpy()
         for e, env in enumerate(envs):
             s_before = env.get_state()
@@ -322,7 +322,7 @@ def test_device_env_presets_and_per_env_obstacles():
         st = torch.zeros(E, nst, device=DEV)
         obs = torch.zeros(E, S, device=DEV)
         preset = (ctypes.c_float * 15)(*(DeviceEnvLoop.PRESETS["xarm6"] + [0.1]))
-        assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 77, 0, preset, stream) == 0
+        assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 77, 0, preset, 15, stream) == 0
         outs.append(obs.cpu().numpy())
     np.testing.assert_array_equal(outs[0], outs[1])                               # deterministic in (seed, env)
     o = outs[0]
@@ -454,3 +454,195 @@ def test_bench_two_real_gpus_rccl_and_oneshot(xgmi):
         assert out["sanity"]["xgmi_timed_out_waits"] == 0 and out["sanity"]["xgmi_allreduces"] >= 23 * 64
     else:
         assert out["config"]["grad_exchange"] == "RCCL all-reduce"
+
+
+# ---- the many-env paths produce what NAFAgent.run / test_trained_model produce --------------------
+def test_device_env_episode_records_are_the_numpy_envs_scores():
+    """The step kernel's bookkeeping (running score in double, frame count, record per (step, env)) on scripted actions
+    against the numpy twin stepped serially with Python's `score += reward` (naf_algorithm.py:264): the record's score is
+    EXACTLY the float64 sum of the float32 rewards of the rows the kernel emitted, in step order, and equals the numpy
+    env's episode sum to the kinematics' rounding; frames and the done flag agree exactly."""
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.engine import EPISODE_RECORD
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
+    assert EPISODE_RECORD.itemsize == 32
+    lib = _lib.load()
+    E, A, S, K, T, MAXF = 8, 6, 21, 16, 40, 7
+    nst = lib.naf_synth_env_state_floats(A)
+    st = torch.zeros(E, nst, device=DEV)
+    obs = torch.zeros(E, S, device=DEV)
+    rows = torch.zeros(E, 64, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    recs = torch.zeros(K, E, 8, dtype=torch.int32, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    # target = where the arm's end effector starts: with +-0.1 on every joint some arms begin (or come) within reach of it
+    # (+250, done), the others run out of frames; obstacle out of the way
+    import ctypes
+    from robotic_manipulator_rloa_amd.environment.synthetic import forward_kinematics
+    q_init = np.array([0.9, 0.45, 0, 0, 0, 0], np.float32)
+    far = np.array([5, 5, 5], np.float32)
+    target, _ = forward_kinematics(q_init, far)
+    preset = (ctypes.c_float * 23)(*(list(q_init) + [0, 0] + [float(x) for x in target] + [5, 5, 5] + [0.0] + [0.1] * 8))
+    assert lib.naf_synth_env_reset(st.data_ptr(), obs.data_ptr(), E, A, 5, 0, preset, 23, stream) == 0
+    envs = [SyntheticEnvironment(A, target_position=list(target), obstacle_position=[5, 5, 5]) for _ in range(E)]
+    _, off_r, off_s2, off_d = O.row_offsets(S, A)
+    rng = np.random.default_rng(1)
+    score_np, score_rows, frames = np.zeros(E), np.zeros(E), np.zeros(E, int)
+    expected = []                                   # (step, env, numpy score, float64 sum of the kernel's rewards, frames, done)
+    for e, env in enumerate(envs):
+        env.reset(False)
+        env.q = st[e, :A].cpu().numpy().copy()
+    got = []
+    for t in range(T):
+        act = rng.uniform(-1, 1, (E, A)).astype(np.float32)
+        a_d = torch.from_numpy(act).to(DEV)
+        assert lib.naf_synth_env_step(st.data_ptr(), a_d.data_ptr(), rows.data_ptr(), obs.data_ptr(), E, A, 5, ctr.data_ptr(),
+                                      MAXF, recs.data_ptr(), K, stream) == 0
+        assert lib.naf_counter_add(ctr.data_ptr(), 1, stream) == 0
+        r = rows.cpu().numpy()
+        for e, env in enumerate(envs):
+            _, rew, done = env.step(act[e])
+            score_np[e] += rew
+            score_rows[e] += float(r[e, off_r])
+            frames[e] += 1
+            assert r[e, off_d] == done
+            if done or frames[e] >= MAXF:
+                expected.append((t, e, score_np[e], score_rows[e], frames[e], done))
+                score_np[e] = score_rows[e] = 0.0
+                frames[e] = 0
+                env.reset(False)
+                env.q = st[e, :A].cpu().numpy().copy()     # the kernel's reset draw
+        if (t + 1) % K == 0 or t == T - 1:
+            rec = recs.cpu().numpy().view(EPISODE_RECORD).reshape(K, E)
+            first = t + 1 - ((t % K) + 1)
+            for j in range(t - first + 1):
+                for e in np.nonzero(rec[j]["frames"] > 0)[0]:
+                    x = rec[j][e]
+                    got.append((first + j, int(e), float(x["score"]), int(x["frames"]), int(x["done"]), float(x["last_reward"]),
+                                int(x["step_lo"]), int(x["env"])))
+    assert len(got) == len(expected) >= E * (T // MAXF)
+    for g, x in zip(got, expected):
+        assert g[:2] == x[:2] and g[6] == g[0] and g[7] == g[1]
+        assert g[2] == x[3]                                                  # exact: float64 sum in step order
+        np.testing.assert_allclose(g[2], x[2], rtol=1e-4, atol=1e-5)         # numpy twin (kinematics rounding)
+        assert g[3] == x[4] and g[4] == x[5]
+        assert (g[5] in (250.0, -1000.0)) == bool(g[4])
+    assert any(g[4] for g in got) and any(not g[4] for g in got)            # both kinds of episode end occurred
+
+
+def test_run_vectorized_produces_runs_outputs(scratch_cwd):
+    """64 device envs: {episode: (score, last_frame)} in completion order, checkpoints/{ep}/weights.p + scores.txt every
+    checkpoint_frequency finished episodes, model.p — loadable by plot_training_rewards and
+    initialize_pretrained_agent_from_episode (naf_algorithm.py:273-289, rl_framework.py:124-157, :232-273)."""
+    import types
+    from robotic_manipulator_rloa_amd import ManipulatorFramework
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
+    env = SyntheticEnvironment(6)
+    agent = NAFAgent(env, 21, 6, 256, 64, 20000, 1e-3, 1e-3, 0.99, 1, 1, 50, DEV, 0)
+    out = agent.run_vectorized(episodes=200, n_envs=64, max_frames=25, drain_every=8)
+    scores = out["scores"]
+    assert list(scores.keys()) == list(range(1, 201))
+    assert all(1 <= fr <= 25 for _, fr in scores.values()) and all(np.isfinite(sc) for sc, _ in scores.values())
+    # 64 envs with a 25-frame budget: the first 64 episodes end together at step 25 (or earlier on a terminal event)
+    assert out["episodes_finished"] >= 200 and out["updates"] == (out["env_steps"] // 64 - 1) * 64
+    assert out["env_steps"] % (64 * 8) == 0 and out["env_steps"] <= 64 * (25 * 4 + 16)
+    assert out["checkpoints"] == [50, 100, 150, 200]
+    for ep in out["checkpoints"]:
+        saved = json.loads(open(f"checkpoints/{ep}/scores.txt").read())
+        assert list(saved.keys()) == [str(i) for i in range(1, 201)]
+        assert saved[str(ep)] == [scores[ep][0], scores[ep][1]] and saved["200"] == ([0, 0] if ep < 200 else list(scores[200]))
+        sd = torch.load(f"checkpoints/{ep}/weights.p", map_location="cpu")
+        assert list(sd.keys()) == list(agent.qnetwork_main.state_dict().keys())
+    final = torch.load("model.p", map_location="cpu")
+    for k, v in agent.qnetwork_main.state_dict().items():
+        np.testing.assert_array_equal(final[k].numpy(), v.cpu().numpy(), err_msg=k)
+    # time-outs score the sum of 25 small negative rewards; frames of a time-out = the budget
+    timeouts = [sc for sc, fr in scores.values() if fr == 25]
+    assert timeouts and all(-25 * 2.0 < sc < 0 for sc in timeouts)
+    agent2 = NAFAgent(env, 21, 6, 256, 64, 1000, 1e-3, 1e-3, 0.99, 1, 1, 50, DEV, 1)
+    agent2.initialize_pretrained_agent_from_episode(100)
+    w = torch.load("checkpoints/100/weights.p", map_location="cpu")
+    for k, v in agent2.qnetwork_target.state_dict().items():
+        np.testing.assert_array_equal(v.cpu().numpy(), w[k].numpy(), err_msg=k)
+    shown = {}
+    fake_plt = types.ModuleType("matplotlib.pyplot")
+    fake_plt.plot = lambda x, y: shown.update(x=list(x), y=list(y))
+    fake_plt.show = lambda: None
+    import unittest.mock as um
+    with um.patch.dict(sys.modules, {"matplotlib": types.ModuleType("matplotlib"), "matplotlib.pyplot": fake_plt}):
+        ManipulatorFramework.plot_training_rewards(200, mean_range=50)
+    want = [sum(scores[i][0] for i in range(b, b + 50)) / 50 for b in (1, 51, 101, 151)]
+    np.testing.assert_allclose(shown["y"], want, rtol=1e-12)
+    # a fixed number of vector steps, no episode budget: an open-ended dict, same bookkeeping
+    out2 = agent.run_vectorized(30, n_envs=64, max_frames=10, drain_every=64)
+    assert out2["env_steps"] == 30 * 64 and out2["episodes_finished"] == len(out2["scores"]) >= 3 * 64
+    assert [fr for _, fr in list(out2["scores"].values())[:64]].count(10) >= 50
+
+
+def test_framework_many_env_training_and_testing(scratch_cwd):
+    """initialize_naf_agent(n_envs=E) / run_training(..., n_envs=E) / test_trained_model(..., n_envs=E) with the old
+    signatures untouched (rl_framework.py:319-367, :431-501)."""
+    from robotic_manipulator_rloa_amd import ManipulatorFramework
+    f = ManipulatorFramework()
+    f.set_hyperparameter("batch_size", 64)
+    f.set_hyperparameter("buffer_size", 20000)
+    f.initialize_synthetic_environment(6, initial_positions_variation_range=[0, 0, .5, .5, .5, .5])
+    f.initialize_naf_agent(checkpoint_frequency=32, seed=1, n_envs=64)
+    scores = f.run_training(96, frames=20, verbose=False)
+    assert list(scores.keys()) == list(range(1, 97)) and all(1 <= fr <= 20 for _, fr in scores.values())
+    assert os.path.isfile("checkpoints/96/weights.p") and os.path.isfile("checkpoints/32/scores.txt") and os.path.isfile("model.p")
+    assert f.naf_agent.last_run_stats["updates"] > 0
+    f.load_pretrained_parameters_from_episode(64)
+    out = f.test_trained_model(70, 12)              # the agent's n_envs: 64 envs, quotas 2,2,2,2,2,2,1,1,...
+    assert out["episodes"] == 70 and 0 <= out["successes"] <= 70 and 0 <= out["collisions"] <= 70 - out["successes"]
+    res = f.naf_agent.evaluate_vectorized(10, 12, n_envs=4, **f._device_env_arguments())
+    assert len(res) == 10 and all(0 <= fr <= 11 and (fr == 11 or done) for ok, fr, done in res)
+    assert all(done for ok, fr, done in res if ok)
+    one = f.test_trained_model(2, 5, n_envs=1)      # one env: the reference's loop
+    assert one["episodes"] == 2
+    # initial joints really follow the configured variation: joints 0, 1 fixed, the others within +-0.5
+    from robotic_manipulator_rloa_amd.engine import DeviceEnvLoop
+    loop = DeviceEnvLoop(f.naf_agent.learner, None, 32, seed=3, records=True, **f._device_env_arguments())
+    q = loop.actor.obs.cpu().numpy()[:, :6]
+    np.testing.assert_allclose(q[:, 0], 0.9, atol=1e-7)
+    np.testing.assert_allclose(q[:, 1], 0.45, atol=1e-7)
+    assert np.abs(q[:, 2:]).max() <= 0.5 and np.abs(q[:, 2:]).max() > 0.3 and q[:, 2:].std() > 0.2
+
+
+def test_host_vector_paths_book_scripted_episodes_exactly(scratch_cwd):
+    """run_host_vectorized / evaluate_host_vectorized on environments whose episode lengths and rewards are known in
+    closed form (tests/scripted_env.py): every recorded (score, frames) is the scripted episode's, in completion order;
+    checkpoints and model.p as run() writes them; success iff done with reward == 250."""
+    import functools
+    from robotic_manipulator_rloa_amd.environment.vector_env import HostVectorEnv
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    from scripted_env import ScriptedEnvironment, make_scripted
+    E = 4
+    agent = NAFAgent(ScriptedEnvironment(), 21, 6, 256, 16, 1000, 1e-3, 1e-3, 0.99, 1, 1, 5, DEV, 0)
+    # every worker builds offset 0 envs: 4 identical scripts, so completion order is (step, env)
+    vec = HostVectorEnv(functools.partial(make_scripted, 0), E, 21, 6, max_frames=50, seed=0)
+    try:
+        out = agent.run_host_vectorized(vec, episodes=22)
+    finally:
+        vec.close()
+    ref = ScriptedEnvironment(0)
+    want = []
+    k = 0
+    while len(want) < 22:
+        want += [ref.expected(k)] * E
+        k += 1
+    assert [out["scores"][i] for i in range(1, 23)] == [(float(s), L) for s, L in want[:22]]
+    assert out["checkpoints"] == [5, 10, 15, 20] and os.path.isfile("model.p")
+    saved = json.loads(open("checkpoints/10/scores.txt").read())
+    assert saved["10"] == [float(want[9][0]), want[9][1]] and saved["11"] == [0, 0]
+    assert out["updates"] > 0 and np.isfinite(out["last_loss"])
+    vec = HostVectorEnv(functools.partial(make_scripted, 1), E, 21, 6, max_frames=4, seed=0)
+    try:
+        res = agent.evaluate_host_vectorized(vec, 10)
+    finally:
+        vec.close()
+    # offset 1: episode k lasts 3 + (1 + k) % 4 steps -> 4, 5, 6, 3, ...; budget 4 frames: k = 0 ends done at frame index 3
+    # (a collision: 1 + 0 is odd), k = 1, 2 time out at index 3, k = 3 (3 steps, 1 + 3 even) is a success at index 2
+    per_env = [(False, 3, True), (False, 3, False), (False, 3, False)]
+    assert res == [per_env[0]] * 4 + [per_env[1]] * 4 + [per_env[2]] * 2

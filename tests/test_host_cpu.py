@@ -477,3 +477,65 @@ def test_host_vector_env_workers_match_serial_envs():
     finally:
         vec.close()
     assert all(not p.is_alive() for p in vec._procs)
+
+
+def test_episode_ledger_writes_what_run_writes(tmp_path, monkeypatch):
+    """engine.EpisodeLedger = the per-episode bookkeeping of NAFAgent.run (naf_algorithm.py:241, :266, :273-289) for loops
+    whose episodes finish in any order: dict pre-filled with (0, 0), numbered in completion order, checkpoint every
+    checkpoint_frequency episodes (weights.p + the WHOLE dict as scores.txt), model.p at the end, rank 0 only; episodes
+    beyond the budget are counted, not recorded."""
+    import json
+    from robotic_manipulator_rloa_amd.engine import EPISODE_RECORD, EpisodeLedger
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    monkeypatch.chdir(tmp_path)
+    assert EPISODE_RECORD.itemsize == 32 and EPISODE_RECORD.fields["frames"][1] == 8 and EPISODE_RECORD.fields["env"][1] == 28
+    calls = []
+
+    def sd():
+        calls.append(1)
+        return {"w": torch.full((2,), float(len(calls)))}
+    led = EpisodeLedger(5, 2, sd)
+    assert led.scores == {e: (0, 0) for e in range(1, 6)} and not led.complete
+    for k in range(7):
+        led.add(-1.5 * k, 10 + k)
+    assert led.complete and led.count == 5 and led.extra == 2 and led.checkpoints == [2, 4]
+    assert led.scores[5] == (-6.0, 14) and led.scores[1] == (0.0, 10)
+    saved = json.loads(open("checkpoints/2/scores.txt").read())
+    assert saved == {"1": [0.0, 10], "2": [-1.5, 11], "3": [0, 0], "4": [0, 0], "5": [0, 0]}
+    assert torch.load("checkpoints/4/weights.p")["w"].tolist() == [2.0, 2.0]
+    assert led.finish() is led.scores and torch.load("model.p")["w"].tolist() == [3.0, 3.0]
+    # a rank other than 0 keeps the dict and writes nothing; open-ended ledgers grow
+    os.chdir(tmp_path / "checkpoints")
+    led2 = EpisodeLedger(None, 1, sd, write=False)
+    led2.add(1.0, 3)
+    led2.add(2.0, 4)
+    led2.finish()
+    assert led2.scores == {1: (1.0, 3), 2: (2.0, 4)} and not os.path.exists("checkpoints") and not os.path.exists("model.p")
+    # evaluation quotas: every env contributes its FIRST q_e episodes, sum = n_episodes
+    assert NAFAgent._episode_quota(70, 64).tolist() == [2] * 6 + [1] * 58
+    assert NAFAgent._episode_quota(3, 8).tolist() == [1, 1, 1, 0, 0, 0, 0, 0]
+    assert NAFAgent._episode_quota(128, 64).sum() == 128
+
+
+def test_framework_many_env_arguments_without_a_gpu(monkeypatch):
+    """n_envs plumbing of ManipulatorFramework that needs no device: validation, the synthetic env's configuration in
+    the device kernel's preset layout, a picklable factory of copies of the configured environment."""
+    import pickle
+    from robotic_manipulator_rloa_amd import ManipulatorFramework
+    from robotic_manipulator_rloa_amd.utils.exceptions import ConfigurationIncomplete, InvalidNAFAgentParameter
+    f = ManipulatorFramework()
+    f.initialize_synthetic_environment(6, [0.3, 0.47, 0.61], [0.25, 0.27, 0.5], [0., 1., 0., -2.3, 0., 0.], [0, 0, 0, 0.3, 1, 1])
+    with pytest.raises(InvalidNAFAgentParameter):
+        f.initialize_naf_agent(n_envs=0)
+    with pytest.raises(InvalidNAFAgentParameter):
+        f.initialize_naf_agent(n_envs=2.5)
+    kw = f._device_env_arguments()
+    np.testing.assert_allclose(kw["preset"], [0., 1., 0., -2.3, 0., 0., 0., 0., 0.3, 0.47, 0.61, 0.25, 0.27, 0.5], rtol=1e-6)
+    np.testing.assert_allclose(kw["variation"], [0, 0, 0, 0.3, 1, 1, 0, 0], rtol=1e-6)
+    env2 = pickle.loads(pickle.dumps(f._env_factory))()
+    np.testing.assert_array_equal(env2.target_pos, f.env.target_pos)
+    np.testing.assert_array_equal(env2.initial_positions_variation_range, f.env.initial_positions_variation_range)
+    with pytest.raises(ConfigurationIncomplete):
+        f.run_training(3, 10, n_envs=4)          # no agent yet
+    f.delete_environment()
+    assert f._env_factory is None
