@@ -24,12 +24,6 @@ def measure():
         buf.gather_rows(idx, out, M)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-if os.environ.get("NAF_AB_NT") == "1":       # interleaved A/B of the nontemporal variant
-    for rep in range(3):
-        for nt in (0, 1, 2, 3):
-            buf.lib.naf_debug_set(1, nt)
-            print(f"  nt={nt}: {measure():.4f} ms")
-    buf.lib.naf_debug_set(1, -1)
 ms = measure()
 alg = M * (200 + 200 + 4); phys = M * (256 + buf.batch_row_floats * 4 + 4)   # 4*(2S+A+2) B read + the same written per row
 print(f"ring {N} rows ({N*256/2**20:.0f} MiB), {M} rows/launch: {ms:.4f} ms  algorithmic {alg/ms/1e6:.1f} GB/s ({alg/ms/1e6/8000:.3f} of 8 TB/s)  "

@@ -63,12 +63,10 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 15
+#define NAF_HIP_ABI_VERSION 16
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
-/* development knob (tile-shape selection for A/B timing, benchmarks/kernel_probe.py); not part of the data path */
-int naf_debug_set(int key, int value);
 /* development aid: phase marks of the large-batch chain's kernels (csrc/common.h, NAF_TL_*; kernel_id 0..6 = bb_layer1,
  * bb_linear_stats, bb_layer2_head, bb_bn_bwd_stage2, gemm_bundle, bb_layer1_bwd_finish, adam_polyak). Copies
  * out[2][16] = 100 MHz wall-clock values left by the first and by the last workgroup of the kernel's most recent launch
@@ -222,14 +220,6 @@ int naf_bn_relu_fwd_heads_partial(const float* g, int64_t g_net_stride, int ldg,
                                   float* save_invstd, const float* Wh, int64_t wh_net_stride, int ldw, int NHP, int v_col,
                                   float* heads_partial, int64_t slab_stride, float* vnext_partial, int B, int H,
                                   float momentum, float eps, void* stream);
-/* heads_pre = a2[net 0] @ Wh[net 0]^T on f32 MFMA tiles (K % 16 == 0, NHP in {16,32,48}), V'(s') = a2[net 1] . Wh[net 1]
- * row A+T, then exactly naf_head_fwd_bwd_mse: replaces the three head Linears of both networks
- * (naf_neural_network.py:81-87) + the head + the TD/MSE epilogue. heads_out (nullable): [B][NHP]. This kernel works on
- * 32 samples per workgroup: loss_partials has ceil(B/32) entries here. */
-int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int lda, int K, const float* Wh,
-                                    int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu, const float* r, int ldr,
-                                    float gamma, float* heads_out, float* q_out, float* d_heads, float* loss_partials, int B,
-                                    int A, int p_mode, void* stream);
 
 /* ---- learn() at large batches: row-split kernels, two-stage batch statistics (csrc/big_batch.hip) --------------
  * For B > 512 (BASELINE configs[3]: B = 1024, configs[4]: B = 2048) the batch is cut into NAF_BB_ROWS-row blocks that
@@ -245,13 +235,6 @@ int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int 
 int naf_bb_moments_floats(int K);
 int naf_bb_moments(const float* x, int64_t batch_stride, int64_t x_net_stride, int ldx, int K, float* mom, int B, int n_batches,
                    int nets, void* stream);
-/* layer 1 for `nets` networks, K = state size <= 32 (rows and W as in naf_linear_bn_relu_fwd_train): mean_c = b_c + w_c . m,
- * var_c = w_c^T C w_c / B from mom[net] (this minibatch's records), out = ReLU(BN(x W^T + b)), running statistics (by the
- * block-0 workgroups), save_mean / save_invstd [nets][H]. */
-int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
-                  const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
-                  float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
-                  float* save_mean, float* save_invstd, float* wc_out /* nullable: [H][KP], row c = w_c C of net 0, for naf_bb_layer1_bwd_finish */, int B, int H, int nets, float momentum, float eps, void* stream);
 /* The DEFERRED optimizer step (round 2): clip + Adam + Polyak of the PREVIOUS learn() (naf_algorithm.py:209-213) carried by the
  * first two launches of the NEXT one instead of a launch of its own — one launch and one launch boundary less per update in
  * a chain of updates. All fields as the arguments of naf_adam_polyak_fused; the flat buffers hold n floats, the layer-1
@@ -262,7 +245,7 @@ int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const fl
  *                             leave them — same code, same bits — without writing them.
  *   naf_bb_linear_stats_adam: `adam` != NULL: extra workgroups step floats [0, l1_floats) in place.
  * Both calls of one update get the same struct; gradient, partials and step count must stay untouched until both have run.
- * The caller ends a chain of updates with naf_adam_polyak_fused (learner.py: TrainChunk). */
+ * The caller ends a chain of updates with naf_adam_polyak_fused (learner.py: TrainChunk). adam == NULL: no step rides along. */
 typedef struct {
     float* theta;
     const float* grad;
@@ -275,101 +258,51 @@ typedef struct {
     const int32_t* step_dev;
     float inv_world;
     int64_t n, l1_floats;
-    /* rec = 1 (with naf_bb_layer1_adam_fin below): `partials` are n_partials (<= NAF_MAX_NORM_PARTIALS) 16-byte RECORDS
-     * {sum of squares, step number, 0, 0} (16-B aligned), published with sc1 stores by the finish workgroups that ride on the same
-     * launch; the readers poll them for step number *step_dev + step_bias and then read the gradient with sc1 loads. The step
-     * count is advanced by a later launch (naf_bb_layer2_head, step_inc), hence step_bias = 1 there; 0 / 0 otherwise. */
-    int rec, step_bias;
     float* bc;   /* nullable: 8 floats of device scratch (two slots by step parity); the workgroups that step the layer-1 segment (naf_bb_linear_stats_adam) leave the
                     NEXT step's bias corrections there, tagged with its number, for the next launch's readers */
 } naf_adam_args_t;
-/* The finish launch of the PREVIOUS update (every argument as naf_bb_layer1_bwd_finish's) riding on the next update's first launch
- * beside its optimizer step: naf_bb_layer1_adam_fin = naf_bb_layer1_adam (adam != NULL, adam->rec = 1) whose launch also carries the
- * finish workgroups. They store their share of the gradient (sc1), wait for the stores, and publish their sum-of-squares record into
- * sumsq_records (= adam->partials) tagged with the step number; the optimizer workgroups and the layer-1 workgroups wait for all
- * records. What the finish work READS must not be written by this launch: the caller keeps layer 1's save_invstd / wc in two
- * buffers by update parity (learner.py). The step count is not advanced here. */
-typedef struct {
-    const float* p_slabs; int K; const float* partials1; int nb1; const float* dz2_col_partials; int nb;
-    const float* mom; const float* wc; const float* gamma; const float* save_invstd;
-    float* d_W; float* d_gamma; float* d_beta; float* d_bias; float* d_bias2; const float* d_gamma2; const float* d_beta2;
-    float* sumsq_records; int B, H; const struct naf_bb_slab_seg* segs; int n_segs; int* fold_epoch;
-} naf_bb_finish_args_t;
-int naf_bb_layer1_adam_fin(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
-                           const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
-                           float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
-                           float* save_mean, float* save_invstd, float* wc_out, int B, int H, int nets, float momentum, float eps,
-                           const naf_adam_args_t* adam, const naf_bb_finish_args_t* fin /* nullable (HOST pointers) */, void* stream);
+/* layer 1 for `nets` networks, K = state size <= 32 (rows and W as in naf_linear_bn_relu_fwd_train): mean_c = b_c + w_c . m,
+ * var_c = w_c^T C w_c / B from mom[net] (this minibatch's records), out = ReLU(BN(x W^T + b)), running statistics (by the
+ * block-0 workgroups), save_mean / save_invstd [nets][H]; wc_out (nullable): [H][KP], row c = w_c C of net 0, for
+ * naf_bb_layer1_bwd_finish. Replaces `self.bn1(self.input_layer(x))` + ReLU (naf_neural_network.py:76-77) for both networks. */
 int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                        const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
                        float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
                        float* save_mean, float* save_invstd, float* wc_out, int B, int H, int nets, float momentum, float eps,
                        const naf_adam_args_t* adam /* nullable (HOST pointer, copied into the launch) */, void* stream);
+/* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K = 256, N % 64 == 0) on f32 MFMA, 64 x 32 tiles (64 x 16 up to B = 512),
+ * with the column statistics partials of every 64-row block written by the epilogue: replaces `self.hidden_layer(x)`
+ * (naf_neural_network.py:78) and the statistics pass of bn2 for both networks. */
 int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
                              int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B, int N,
                              int K, int nets, const naf_adam_args_t* adam /* nullable (HOST pointer) */, void* stream);
-/* naf_bb_layer1 and naf_bb_linear_stats in ONE launch (H = 256, K <= 26): every GEMM-2 workgroup forms its own A panel
- * A1 = ReLU(BN(x W1^T + b1)) in LDS from the rows and the moments record; the column-0 workgroups also write A1 (a1_out, for the
- * backward pass), the running statistics and save_mean / save_invstd of layer 1. Outputs of naf_bb_linear_stats as below. */
-int naf_bb_layer12(const float* x, int64_t x_net_stride, int ldx, int K, const float* W1, const float* bias1,
-                   const float* gamma1, const float* beta1, const float* W2, const float* bias2, int64_t param_net_stride,
-                   const float* mom, float* running_mean, float* running_var, int64_t stat_net_stride, float* a1_out,
-                   int64_t a1_net_stride, int lda1, float* save_mean, float* save_invstd, float* wc_out /* as naf_bb_layer1 */, float* z, int64_t z_net_stride, int ldz,
-                   float* partials, int B, int H, int nets, float momentum, float eps, void* stream);
-/* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K = 256, N % 64 == 0) on f32 MFMA, 64 x 32 tiles, with the
- * column statistics partials of every 64-row block written by the epilogue: replaces `self.hidden_layer(x)`
- * (naf_neural_network.py:78) and the statistics pass of bn2 for both networks. */
-int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
-                        int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B, int N,
-                        int K, int nets, void* stream);
-/* layer 2 of BOTH nets from the pre-activations z and their partials: fold, normalise, ReLU -> out (A2, ldo >= H), running
- * statistics, and the heads Linears split over H/64 column slices exactly as naf_bn_relu_fwd_heads_partial does over H/8
- * (heads_partial[H/64][B][NHP] slab_stride floats apart, vnext_partial[H/64][B]); the head kernel adds the slabs
- * (naf_head_fwd_bwd_mse_splitk with n_slabs = H/64 = 4). */
-int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
-                                 int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
-                                 int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo, float* save_mean,
-                                 float* save_invstd, const float* Wh, int64_t wh_net_stride, int ldw, int NHP, int v_col,
-                                 float* heads_partial, int64_t slab_stride, float* vnext_partial, int B, int H,
-                                 float momentum, float eps, void* stream);
-/* backward of layer 2 in two launches. stage 1: dy = ReLU'(a2) * (d_heads[B][ldh] @ Wh[ldh][ldw]) -> dy_out, partials[B/64][H]
- * = per-block (sum dy, sum dy*xhat). stage 2: folds them, dy -> dz in place, d_gamma / d_beta, and dz_col_partials[B/64][H]
- * (block sums of dz: the Linear bias gradient, finalised by naf_bb_layer1_bwd_finish). */
-int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const float* Wh, int ldw, const float* z, int ldz, const float* a2,
-                            int lda, const float* save_mean, const float* save_invstd, float* dy_out, int ldd,
-                            float* partials, int B, int H, void* stream);
-int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz, const float* gamma, const float* save_mean,
-                         const float* save_invstd, const float* partials, int n_partial_blocks /* <= 128: B/64, or B / naf_bb_layer2_head_rows(B) after
-                         naf_bb_layer2_head */, float* d_gamma, float* d_beta, float* dz_col_partials, int B, int H, void* stream);
-/* rows per workgroup of naf_bb_layer2_head at batch size B (16; 32 is the other instance, NAF_HK_ROWS=32) = rows per block of its partials_bw:
- * size partials_bw for B / rows blocks and tell naf_bb_bn_bwd_stage2 that many */
+/* rows per workgroup of naf_bb_layer2_head (16) = rows per block of its partials_bw: size partials_bw for B / rows blocks and
+ * tell the bundle's BatchNorm-backward prologue (naf_gemm_bn2bwd_t.npb) that many */
 int naf_bb_layer2_head_rows(int B);
-/* naf_bb_bn_relu_heads_partial + the NAF head (naf_head_fwd_bwd_mse: Q, y = r + gamma V'(s'), MSE, d_heads) +
- * naf_bb_heads_bwd_stage1 in ONE launch for H = 256: a workgroup owns 32 (16 up to B = 1024) batch rows across all features of both nets, heads and
+/* layer 2 from its pre-activations on: fold the statistics partials, normalise, ReLU (A2), the three head Linears, the NAF head
+ * (naf_head_fwd_bwd_mse: Q, y = r + gamma V'(s'), MSE, d_heads) and the first half of layer 2's backward (dA2 = d_heads Wh, ReLU
+ * mask, dY2, block sums) in ONE launch for H = 256: a workgroup owns 16 batch rows across all features of both nets, heads and
  * dA2 on f32 MFMA. Outputs: a2_out (main net's A2, ldo >= H; the target's is not needed again), running statistics, save_mean /
- * save_invstd [2][H], q_out[B], d_heads[B][NHP], loss_partials[B/rows], dy_out (dY2), partials_bw[B/rows][H] (float2), rows = naf_bb_layer2_head_rows(B). u / r: the
- * action and reward columns of the minibatch rows. Replaces naf_neural_network.py:78-115 + naf_algorithm.py:199-208 and the first
- * half of layer 2's BatchNorm backward. */
+ * save_invstd [2][H], q_out[B], d_heads[B][NHP], loss_partials[B/rows], dy_out (dY2), partials_bw[B/rows][H] (float2: sum dy,
+ * sum dy*xhat), rows = naf_bb_layer2_head_rows(B). u / r: the action and reward columns of the minibatch rows. Replaces
+ * naf_neural_network.py:78-115 + naf_algorithm.py:199-208 and the first half of layer 2's BatchNorm backward. */
 int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
                        int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
                        int64_t stat_net_stride, float* a2_out, int ldo, float* save_mean, float* save_invstd, const float* Wh,
                        int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu, const float* r, int ldr, float gamma_td,
                        float* q_out, float* d_heads, float* loss_partials, float* dy_out, int ldd, float* partials_bw, int B,
                        int H, int A, int p_mode, float momentum, float eps, void* stream);
-/* backward of layer 1 (naf_bn_relu_bwd_wgrad's contract), row-split: ONE pass over the batch and a finish launch. With
- * dz = k1 (dy - c1 - xhat c2): dW[c][k] = k1_c (P[c][k] - c1_c Sx[k] - c2_c invstd_c (w_c C)[k]), P = dY^T X — the xhat term
- * comes from the moments record, so the pass only produces dy = ReLU'(out) * d_out, its block sums partials[B/64][H] (float2:
- * sum dy, sum dy*xhat) and the block shares p_slabs[B/64][H][KP] of P (KP = naf_bb_layer1_bwd_kp(K)).
+/* backward of layer 1, row-split: the batch pass is the epilogue of the bundle's dA1 blocks (naf_gemm_l1bwd_t below), this is
+ * the finish launch. With dz = k1 (dy - c1 - xhat c2): dW[c][k] = k1_c (P[c][k] - c1_c Sx[k] - c2_c invstd_c (w_c C)[k]),
+ * P = dY^T X — the xhat term comes from the moments record, so the pass only produces dy = ReLU'(out) * d_out, its block sums
+ * partials1[nb1][H] (float2: sum dy, sum dy*xhat) and the block shares p_slabs[nb1][H][KP] of P (KP = naf_bb_layer1_bwd_kp(K)).
  * finish: folds them in block order -> d_W[H][K], d_gamma, d_beta, d_bias = 0 (sum_r dz vanishes identically; the reference's
- * value is rounding noise that the train-mode BatchNorm cancels), d_bias2 (layer 2, from naf_bb_bn_bwd_stage2's
- * dz_col_partials; nb = 0: d_bias2 = 0, the value that sum is identically — for the chain whose stage 2 runs inside the
- * bundle, naf_gemm_bn2bwd_t). K <= 32. mom: the MAIN net's moments record (Sx); wc: [H][KP], row c = w_c C, left by the forward pass
- * (naf_bb_layer1 / naf_bb_layer12, wc_out). sumsq_partials (nullable): sums of squares of everything written here plus
- * d_gamma2 / d_beta2 (then required: read, not written), one entry per workgroup: naf_bb_layer1_bwd_finish_blocks(H) finish
- * blocks, then the slab segments' (below); step_dev (nullable): *step_dev += 1. */
-int naf_bb_layer1_bwd(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W, const float* bias,
-                      const float* out, int ldo, const float* save_mean, const float* save_invstd, float* partials,
-                      float* p_slabs, int B, int H, void* stream);
+ * value is rounding noise that the train-mode BatchNorm cancels), d_bias2 (layer 2: nb = 0 writes the 0 that sum is identically —
+ * the chain's stage 2 runs inside the bundle, naf_gemm_bn2bwd_t; nb > 0: dz2_col_partials[nb][H] block sums are added). K <= 32.
+ * mom: the MAIN net's moments record (Sx); wc: [H][KP], row c = w_c C, left by the forward pass (naf_bb_layer1_adam, wc_out).
+ * sumsq_partials (nullable): sums of squares of everything written here plus d_gamma2 / d_beta2 (then required: read, not
+ * written), one entry per workgroup: naf_bb_layer1_bwd_finish_blocks(H) finish blocks, then the slab segments' (below);
+ * step_dev (nullable): *step_dev += 1. */
 int naf_bb_layer1_bwd_kp(int K);
 /* segs (HOST array, n_segs <= 2, may be 0): split-K slabs of the bundle's weight gradients (naf_gemm_desc_t.k_split), added in
  * slab order by extra workgroups of the same launch: dst[i] = sum_s src[s * stride + i], i < n (n % 4 == 0, n_slabs <= 8);
@@ -383,7 +316,7 @@ typedef struct naf_bb_slab_seg {
 } naf_bb_slab_seg_t;
 int naf_bb_layer1_bwd_finish_blocks(int H);
 int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1, int nb1 /* blocks of partials1 / p_slabs:
-                             B/64 from naf_bb_layer1_bwd, B/32 from the bundle's epilogue */, const float* dz2_col_partials, int nb,
+                             M / 32 from the bundle's epilogue */, const float* dz2_col_partials, int nb,
                              const float* mom, const float* wc, const float* gamma, const float* save_invstd, float* d_W,
                              float* d_gamma, float* d_beta, float* d_bias, float* d_bias2, const float* d_gamma2,
                              const float* d_beta2, float* sumsq_partials, int32_t* step_dev, int B, int H,
@@ -398,8 +331,8 @@ int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1
  * 32 x 32 output blocks computed on v_mfma_f32_16x16x4_f32. `descs` is a HOST array (copied into the launch). */
 #define NAF_GEMM_BUNDLE_MAX 4
 /* optional epilogue of a product whose C = dA1 (gradient w.r.t. the layer-1 activations, M = batch rows, N = layer-1 features;
- * M, N multiples of 32): the batch pass of naf_bb_layer1_bwd on every 32 x 32 C block while it is in registers — partials
- * [M/32][N] (float2) and p_slabs [M/32][N][kp] instead of [B/64]; C may then be NULL (dA1 is not stored). */
+ * M, N multiples of 32): the batch pass of layer 1's backward (see naf_bb_layer1_bwd_finish) on every 32 x 32 C block while it is in registers — partials
+ * [M/32][N] (float2) and p_slabs [M/32][N][kp]; C may then be NULL (dA1 is not stored). */
 typedef struct naf_gemm_l1bwd {
     const float* x;          /* minibatch rows of the net (state columns), ldx floats apart */
     const float* W;          /* W1 [N][K] */
@@ -413,11 +346,11 @@ typedef struct naf_gemm_l1bwd {
 } naf_gemm_l1bwd_t;
 /* optional prologue on the A operand of a product: A = dY2 (the ReLU-masked gradient w.r.t. layer 2's BatchNorm output, written by
  * naf_bb_layer2_head) is turned into dZ2 = k1 (dy - c1 - xhat c2) WHILE the panel is staged — the second stage of layer 2's
- * BatchNorm backward (naf_bb_bn_bwd_stage2) without its launch and without dZ2 in memory. Every block folds the block sums of the
- * columns its A panel touches (all H for a k-contiguous A = dA1's product, its own 32 for a k-major A = dW2's), the k-major blocks
- * of the first block column also write d_gamma / d_beta. The bias gradient of the Linear in front (sum_r dz) is identically zero
- * under a train-mode BatchNorm and is not produced: pass nb = 0 to naf_bb_layer1_bwd_finish, which then writes d_bias2 = 0.
- * Restrictions: H = 256, K / k_split a multiple of 256, M and N multiples of 32, npb <= 32 (128 with cst, below). */
+ * BatchNorm backward without a launch of its own and without dZ2 in memory. The block sums are folded ONCE per launch: the
+ * launch's first H / 32 workgroups fold 32 columns each (npb <= 128) and publish one 16-byte record per column to cst; the k-major
+ * fold also writes d_gamma / d_beta. The bias gradient of the Linear in front (sum_r dz) is identically zero under a train-mode
+ * BatchNorm and is not produced: pass nb = 0 to naf_bb_layer1_bwd_finish, which then writes d_bias2 = 0.
+ * Restrictions: H = 256, M and N multiples of 32, npb <= 128. */
 typedef struct naf_gemm_bn2bwd {
     const float* z;          /* Z2, same shape and leading dimension as A */
     const float* partials;   /* float2 [npb][H]: (sum dy, sum dy*xhat) per row block (naf_bb_layer2_head's partials_bw) */
@@ -427,13 +360,14 @@ typedef struct naf_gemm_bn2bwd {
     float* d_gamma;          /* [H] out */
     float* d_beta;
     int npb, B, H;
-    /* cst != NULL: the block sums are folded ONCE per launch — the launch's first H / 32 workgroups fold 32 columns each (npb <= 128)
-     * and publish one 16-byte record per column to cst ([H] x 4 floats, 16-B aligned, device scratch that nothing else touches):
-     * (k1 c1, invstd k1 c2, *epoch, 0); the GEMM blocks poll the records of their columns until they carry *epoch (bounded by wall
-     * clock; a thread that gives up poisons its result with NaN). *epoch (device word) must differ from launch to launch:
-     * naf_bb_layer1_bwd_finish(fold_epoch) advances it. cst == NULL: every block folds for itself (npb <= 32). */
+    /* cst: [H] x 4 floats, 16-B aligned, device scratch that nothing else touches — one record per column (k1 c1, invstd k1 c2,
+     * *epoch, 0); the GEMM blocks poll the records of their columns until they carry *epoch. *epoch (device word) must differ from
+     * launch to launch: naf_bb_layer1_bwd_finish(fold_epoch) advances it. */
     float* cst;
     const int* epoch;
+    /* nullable: pinned HOST word (device-visible). The polls are bounded by wall clock as a hang guard (50 ms); a thread whose
+     * wait expires poisons its result with NaN and adds 1 here, where the host sees it without synchronising. */
+    uint64_t* errors;
 } naf_gemm_bn2bwd_t;
 typedef struct naf_gemm_desc {
     const float* A;
@@ -448,10 +382,6 @@ typedef struct naf_gemm_desc {
     const naf_gemm_bn2bwd_t* pro; /* nullable (HOST pointer, copied into the launch) */
 } naf_gemm_desc_t;
 int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
-/* the same contract on 64 x 64 output blocks staged in 128-k chunks (csrc/gemm_bundle64.hip): for the large-batch chain, where
- * 32 x 32 blocks are bound by L2 -> LDS traffic. Restrictions: b_kmajor = 1, sumsq = NULL, (K / k_split) % 128 == 0, M and N
- * multiples of 4 (partial edge blocks are masked); with `epi`: M, N multiples of 64 and partials / p_slabs per 64-row block. */
-int naf_gemm_bundle64(const naf_gemm_desc_t* descs, int n, void* stream);
 
 /* ---- clip + Adam + Polyak over one flat parameter buffer -------------------------------------- */
 /* first half of clip_grad_norm_(params, 1) (naf_algorithm.py:209): partials[i] = sum of g^2 over chunk i of

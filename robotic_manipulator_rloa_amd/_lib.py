@@ -15,7 +15,7 @@ from typing import Optional
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
-SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "big_batch.hip", "gemm_bundle.hip", "gemm_bundle64.hip", "optim.hip",
+SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "big_batch.hip", "gemm_bundle.hip", "optim.hip",
            "synth_env.hip", "xgmi_reduce.hip", "policy_act.hip"]
 HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", "adam_body.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
@@ -28,8 +28,12 @@ class NafHipError(RuntimeError):
     pass
 
 
+USAGE_PATH = LIB_PATH + ".usage.json"     # per-kernel registers / scratch / LDS as the compiler reported them (build_library)
+
+
 def _build_flags() -> list:
-    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable"]
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable",
+             "-Rpass-analysis=kernel-resource-usage"]
     if os.environ.get("NAF_BUILD_DEFINES"):      # tile-shape experiments / -DNAF_TIMELINE (benchmarks/): e.g. "-DFT_TX=4"
         flags += os.environ["NAF_BUILD_DEFINES"].split()
     return flags
@@ -97,12 +101,16 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             def compile_one(src):
                 obj = os.path.join(objdir, src.replace(".hip", ".o"))
                 sp = os.path.join(CSRC, src)
-                if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(sp)):
+                if not force and os.path.exists(obj) and os.path.exists(obj + ".usage") and \
+                        os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(sp)):
                     return obj, None
                 cmd = [hipcc] + flags + ["-c", sp, "-o", obj]
                 if verbose:
                     print(" ".join(cmd))
                 r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode == 0:
+                    with open(obj + ".usage", "w") as f:     # the compiler's resource remarks of this file's kernels
+                        f.write(r.stderr)
                 return obj, (None if r.returncode == 0 else r.stdout + r.stderr)
 
             with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
@@ -117,11 +125,34 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                     os.remove(tmp)
                 raise NafHipError("hipcc (link) failed:\n" + r.stdout + r.stderr)
             os.replace(tmp, LIB_PATH)
+            _write_usage([o + ".usage" for o, _ in results])
             with open(_flags_stamp(), "w") as f:
                 f.write(" ".join(flags) + "\n")
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
+
+
+def _write_usage(remark_files) -> None:
+    """libnaf_hip.so.usage.json: {kernel (mangled): {vgprs, agprs, sgprs, scratch_bytes_per_lane, lds_bytes, occupancy,
+    source}} from hipcc's -Rpass-analysis=kernel-resource-usage remarks — what tests/test_host_cpu.py holds the library to
+    (no kernel may spill to scratch)."""
+    import json
+    out, cur = {}, None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+            "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds_bytes", "VGPRs Spill": "vgpr_spills"}
+    for path in remark_files:
+        with open(path) as f:
+            for line in f:
+                m = re.search(r"remark: Function Name: (\S+)", line)
+                if m:
+                    cur = out.setdefault(m.group(1), {"source": os.path.basename(path).replace(".o.usage", ".hip")})
+                    continue
+                m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+                if m and cur is not None and m.group(1).strip() in keys:
+                    cur[keys[m.group(1).strip()]] = int(m.group(2))
+    with open(USAGE_PATH, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
 
 
 _lib: Optional[C.CDLL] = None
@@ -132,7 +163,6 @@ _vp, _i, _f, _u64, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_s
 _PROTOS = {
     "naf_hip_abi_version": [],
     "naf_hip_arch": [],
-    "naf_debug_set": [_i, _i],
     "naf_timeline_read": [_i, _vp],
     "naf_replay_row_floats": [_i, _i],
     "naf_replay_row_off_next_state": [_i, _i],
@@ -164,34 +194,19 @@ _PROTOS = {
                                   _vp],
     "naf_bn_relu_fwd_heads_partial": [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
                                       _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
-    "naf_heads_gemm_head_fwd_bwd_mse": [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i,
-                                        _i, _i, _vp],
     "naf_bb_moments_floats": [_i],
     "naf_bb_moments": [_vp, _i64, _i64, _i, _i, _vp, _i, _i, _i, _vp],
-    "naf_bb_layer1": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f,
-                      _vp],
-    "naf_bb_layer12": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp,
-                       _i64, _i, _vp, _i, _i, _i, _f, _f, _vp],
-    "naf_bb_linear_stats": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp],
     "naf_bb_layer1_adam": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i, _f,
                            _f, _vp, _vp],
-    "naf_bb_layer1_adam_fin": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i,
-                               _f, _f, _vp, _vp, _vp],
     "naf_bb_linear_stats_adam": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp, _vp],
-    "naf_bb_bn_relu_heads_partial": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i64,
-                                     _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
-    "naf_bb_heads_bwd_stage1": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
-    "naf_bb_bn_bwd_stage2": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "naf_bb_layer2_head_rows": [_i],
     "naf_bb_layer2_head": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp,
                            _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
-    "naf_bb_layer1_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "naf_bb_layer1_bwd_kp": [_i],
     "naf_bb_layer1_bwd_finish_blocks": [_i],
     "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                  _vp, _i, _vp, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],
-    "naf_gemm_bundle64": [_vp, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
     "naf_polyak_update": [_vp, _vp, _f, _f, _sz, _vp],
@@ -243,24 +258,14 @@ class AdamArgs(C.Structure):
                 ("partials", C.c_void_p), ("n_partials", C.c_int), ("max_norm", C.c_float), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("tau", C.c_float), ("one_minus_tau", C.c_float),
                 ("step_dev", C.c_void_p), ("inv_world", C.c_float), ("n", C.c_int64), ("l1_floats", C.c_int64),
-                ("rec", C.c_int), ("step_bias", C.c_int), ("bc", C.c_void_p)]
-
-
-class BbFinishArgs(C.Structure):
-    """naf_bb_finish_args_t (include/naf_hip.h): the finish work of the previous update riding on naf_bb_layer1_adam_fin"""
-    _fields_ = [("p_slabs", C.c_void_p), ("K", C.c_int), ("partials1", C.c_void_p), ("nb1", C.c_int),
-                ("dz2_col_partials", C.c_void_p), ("nb", C.c_int), ("mom", C.c_void_p), ("wc", C.c_void_p), ("gamma", C.c_void_p),
-                ("save_invstd", C.c_void_p), ("d_W", C.c_void_p), ("d_gamma", C.c_void_p), ("d_beta", C.c_void_p),
-                ("d_bias", C.c_void_p), ("d_bias2", C.c_void_p), ("d_gamma2", C.c_void_p), ("d_beta2", C.c_void_p),
-                ("sumsq_records", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("segs", C.c_void_p), ("n_segs", C.c_int),
-                ("fold_epoch", C.c_void_p)]
+                ("bc", C.c_void_p)]
 
 
 class GemmBn2Bwd(C.Structure):
     """naf_gemm_bn2bwd_t (include/naf_hip.h)"""
     _fields_ = [("z", C.c_void_p), ("partials", C.c_void_p), ("gamma", C.c_void_p), ("save_mean", C.c_void_p),
                 ("save_invstd", C.c_void_p), ("d_gamma", C.c_void_p), ("d_beta", C.c_void_p), ("npb", C.c_int), ("B", C.c_int),
-                ("H", C.c_int), ("cst", C.c_void_p), ("epoch", C.c_void_p)]
+                ("H", C.c_int), ("cst", C.c_void_p), ("epoch", C.c_void_p), ("errors", C.c_void_p)]
 
 
 class GemmL1Bwd(C.Structure):

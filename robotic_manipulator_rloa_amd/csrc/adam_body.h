@@ -23,14 +23,8 @@ struct AdamArgs {
     const float* partials;     // sums of squares covering every gradient element once
     int n_partials;
     float max_norm, lr, beta1, beta2, eps, tau, one_minus_tau;
-    const int32_t* step_dev;   // optimizer step count: t = *step_dev + step_bias
+    const int32_t* step_dev;   // optimizer step count t = *step_dev (already advanced by the launch that finalised the gradient)
     float inv_world;
-    // rec != 0: `partials` are 16-byte RECORDS {sum of squares, t, 0, 0}, written (sc1) by workgroups that may belong to the very
-    // launch that reads them — the finish work of the previous update riding beside its optimizer step (big_batch.hip,
-    // bb_finish_block) — each behind that workgroup's share of the gradient (sc1 stores, waited for). A reader polls a record until
-    // it carries this step's number t and reads the gradient only afterwards, with sc1 loads. The step count is then advanced by
-    // a LATER launch, hence step_bias = 1.
-    int rec, step_bias;
     // nullable: 2 x 4 floats of device scratch {step_size, inv_bc2_sqrt, t (as bits), 0}, slot = t & 1. The bias corrections are two double-precision
     // powers, a division and a square root on ONE lane — 0.3 us on the critical path of every workgroup that derives the step's
     // scalars. The workgroup that steps the layer-1 segment from the second launch (adam_block with lo4 == 0, off every critical
@@ -58,15 +52,16 @@ __device__ static inline double adam_ipow(double b, int t) {
 
 // FP contraction is switched off for the update formulas so that tau*a + (1-tau)*b rounds like the reference's two
 // multiplies and one add.
-__device__ static inline void adam_one(float& th, float gr, float& m, float& v, float* tg, const AdamScalars& sc,
-                                       float beta1, float beta2, float eps, float tau, float one_minus_tau) {
+// (tg by reference + a flag, not a nullable pointer: the address of a register value sent the kernel's locals to scratch)
+__device__ __forceinline__ static void adam_one(float& th, float gr, float& m, float& v, float& tg, bool has_tg, const AdamScalars& sc,
+                                                float beta1, float beta2, float eps, float tau, float one_minus_tau) {
 #pragma clang fp contract(off)
     const float gs = gr * sc.clip_scale;
     m = m + (gs - m) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
     v = v * beta2 + ((1.0f - beta2) * gs) * gs;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
     const float denom = sqrtf(v) * sc.inv_bc2_sqrt + eps;
     th = th - sc.step_size * (m / denom);              // param.addcdiv_(exp_avg, denom, value=-step_size)
-    if (tg) *tg = tau * th + one_minus_tau * (*tg);    // soft_update with the freshly stepped main weights
+    if (has_tg) tg = tau * th + one_minus_tau * tg;    // soft_update with the freshly stepped main weights
 }
 
 // The norm partials (NAF_MAX_NORM_PARTIALS of them, 64 per trip of wave 0) and the step count, requested by every thread
@@ -75,63 +70,9 @@ struct AdamPrefetch {
     float pr[NAF_MAX_NORM_PARTIALS / 64];
     int t;
 };
-// one record, polled until it carries `tag` (bounded by wall clock: 0.5 ms, then NaN — the update fails loudly, the GPU does
-// not hang). sc1 loads only; the compiler barrier keeps the load inside the loop (the intrinsic is not volatile).
-__device__ __forceinline__ static float adam_poll_record(const float* recs, int k, int tag) {
-    const __amdgpu_buffer_rsrc_t rb = naf_buf(recs);
-    naf_f32x4 c = naf_buf_f4_sc1(rb, 16u * (unsigned)k, 0);
-    float tagf = c[1];                       // (through a scalar copy: bit_cast on a vector element reads element 0)
-    if (__builtin_bit_cast(int, tagf) != tag) {
-        const long long t0 = wall_clock64();
-        while (true) {
-            __builtin_amdgcn_s_sleep(2);
-            asm volatile("" ::: "memory");
-            c = naf_buf_f4_sc1(rb, 16u * (unsigned)k, 0);
-            tagf = c[1];
-            if (__builtin_bit_cast(int, tagf) == tag) break;
-            if (wall_clock64() - t0 > 50000) return __builtin_nanf("");
-        }
-    }
-    return c[0];
-}
 __device__ __forceinline__ static AdamPrefetch adam_prefetch(const AdamArgs& A, int tid) {
     AdamPrefetch p;
-    p.t = *A.step_dev + A.step_bias;         // (uniform: a scalar load)
-    if (A.rec) {                             // (uniform) the first wave waits for the records; nobody else needs them
-        constexpr int NJ = NAF_MAX_NORM_PARTIALS / 64;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) p.pr[j] = 0.f;
-        if (tid < 64) {
-            // all of a lane's records requested at once, every trip (one after the other, each paid its own round trip even when
-            // all were in already: 2 us between the last finish workgroup's exit and the first reader seeing it)
-            const __amdgpu_buffer_rsrc_t rb = naf_buf(A.partials);
-            unsigned off[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) off[j] = 16u * (unsigned)(tid + 64 * j < A.n_partials ? tid + 64 * j : 0);
-            const long long t0 = wall_clock64();
-            while (true) {
-                naf_f32x4 c[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) c[j] = naf_buf_f4_sc1(rb, off[j], 0);
-                bool ok = true;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const float tagf = c[j][1];      // (through a scalar copy: bit_cast on a vector element reads element 0)
-                    ok &= __builtin_bit_cast(int, tagf) == p.t;
-                    p.pr[j] = c[j][0];
-                }
-                if (ok) break;
-                if (wall_clock64() - t0 > 50000) {           // 0.5 ms: poison (NaN norm -> NaN parameters), do not hang
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) p.pr[j] = __builtin_nanf("");
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-                asm volatile("" ::: "memory");               // (keeps the loads inside the loop: the intrinsic is not volatile)
-            }
-        }
-        return p;
-    }
+    p.t = *A.step_dev;                       // (uniform: a scalar load)
 #pragma unroll
     for (int j = 0; j < NAF_MAX_NORM_PARTIALS / 64; ++j) {
         const int k = (tid & 63) + 64 * j;
@@ -155,8 +96,7 @@ __device__ __forceinline__ static void adam_derive(const AdamArgs& A, const Adam
 #pragma unroll
         for (int j = 0; j < NAF_MAX_NORM_PARTIALS / 64; ++j) s += (tid + 64 * j < A.n_partials) ? p.pr[j] : 0.f;
         // more partials than were prefetched (flat buffers beyond 1M parameters): the rest in the same lane-major order
-        if (!A.rec)                                   // (record mode: at most NAF_MAX_NORM_PARTIALS, checked on the host)
-            for (int k = tid + NAF_MAX_NORM_PARTIALS; k < A.n_partials; k += 64) s += A.partials[k];
+        for (int k = tid + NAF_MAX_NORM_PARTIALS; k < A.n_partials; k += 64) s += A.partials[k];
         s = naf_sum64(s);
         if (tid == 0) {
             // a sum of squares is never negative: -inf is what xgmi_allreduce_kernel leaves when a peer's contribution
@@ -194,8 +134,7 @@ __device__ static inline bool adam_block(const AdamArgs& A, size_t lo4, size_t h
     const size_t i0 = lo4 + (size_t)wg * NT + tid;
     const size_t i0c = i0 < hi4 ? i0 : (hi4 > lo4 ? hi4 - 1 : lo4);
     float4 th0 = ((float4*)A.theta)[i0c];
-    float4 gr0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!A.rec) gr0 = ((const float4*)A.g)[i0c];
+    float4 gr0 = ((const float4*)A.g)[i0c];
     float4 mm0 = ((float4*)A.m)[i0c];
     float4 vv0 = ((float4*)A.v)[i0c];
     float4 tg0 = ((float4*)(A.target ? A.target : A.theta))[i0c];
@@ -213,30 +152,21 @@ __device__ static inline bool adam_block(const AdamArgs& A, size_t lo4, size_t h
     }
     if (sc.skip) return false;
     float* target = A.target;
-    if (A.rec) {                             // the records are in: the gradient is where sc1 loads find it
-        const naf_f32x4 t = naf_buf_f4_sc1(naf_buf(A.g), (unsigned)(i0c * 16), 0);
-        gr0 = make_float4(t[0], t[1], t[2], t[3]);
-    }
     for (size_t i = i0; i < hi4; i += (size_t)nwg * NT) {
         float4 th, gr, mm, vv, tg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i == i0) {
             th = th0; gr = gr0; mm = mm0; vv = vv0; tg = tg0;
         } else {
             th = ((float4*)A.theta)[i];
-            if (A.rec) {
-                const naf_f32x4 t = naf_buf_f4_sc1(naf_buf(A.g), (unsigned)(i * 16), 0);
-                gr = make_float4(t[0], t[1], t[2], t[3]);
-            } else {
-                gr = ((const float4*)A.g)[i];
-            }
+            gr = ((const float4*)A.g)[i];
             mm = ((float4*)A.m)[i];
             vv = ((float4*)A.v)[i];
             if (target) tg = ((float4*)target)[i];
         }
-        adam_one(th.x, gr.x, mm.x, vv.x, target ? &tg.x : nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
-        adam_one(th.y, gr.y, mm.y, vv.y, target ? &tg.y : nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
-        adam_one(th.z, gr.z, mm.z, vv.z, target ? &tg.z : nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
-        adam_one(th.w, gr.w, mm.w, vv.w, target ? &tg.w : nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(th.x, gr.x, mm.x, vv.x, tg.x, target != nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(th.y, gr.y, mm.y, vv.y, tg.y, target != nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(th.z, gr.z, mm.z, vv.z, tg.z, target != nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(th.w, gr.w, mm.w, vv.w, tg.w, target != nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
         if (wt) {                               // (buffers of a learner are far below 2 GiB: 32-bit byte offsets)
             const unsigned off = (unsigned)(i * 16);
             naf_buf_st_f4(naf_buf(A.theta), off, 0, (naf_f32x4){th.x, th.y, th.z, th.w}, true);
@@ -262,14 +192,9 @@ struct AdamFly4 {
 struct AdamFly1 {
     float g, m, v, thm;
 };
-// (record mode: g is NOT loaded here — adam_fly_load_g4 once the records are in)
-__device__ __forceinline__ static naf_f32x4 adam_fly_load_g4(const AdamArgs& A, int64_t o) {
-    return naf_buf_f4_sc1(naf_buf(A.g), (unsigned)(o * 4), 0);
-}
 __device__ __forceinline__ static AdamFly4 adam_fly_load4(const AdamArgs& A, int64_t o, bool is_target) {
     AdamFly4 p;
-    p.g = (naf_f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!A.rec) p.g = *(const naf_f32x4*)(A.g + o);
+    p.g = *(const naf_f32x4*)(A.g + o);
     p.m = *(const naf_f32x4*)(A.m + o);
     p.v = *(const naf_f32x4*)(A.v + o);
     p.thm = *(const naf_f32x4*)(A.theta + (is_target ? o : 0));     // (net 0 has the value already: any valid address)
@@ -287,7 +212,7 @@ __device__ __forceinline__ static float adam_fly_apply1(const AdamArgs& A, const
                                                         bool is_target) {
     if (sc.skip) return cur;
     float th = is_target ? p.thm : cur, m = p.m, v = p.v, tg = cur;
-    adam_one(th, p.g, m, v, is_target ? &tg : nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+    adam_one(th, p.g, m, v, tg, is_target, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
     return is_target ? tg : th;
 }
 __device__ __forceinline__ static naf_f32x4 adam_fly_apply4(const AdamArgs& A, const AdamScalars& sc, const AdamFly4& p, naf_f32x4 cur,
@@ -308,7 +233,6 @@ __host__ static inline bool adam_args_from(const naf_adam_args_t& s, AdamArgs& a
     a.partials = s.partials; a.n_partials = s.n_partials;
     a.max_norm = s.max_norm; a.lr = s.lr; a.beta1 = s.beta1; a.beta2 = s.beta2; a.eps = s.eps;
     a.tau = s.tau; a.one_minus_tau = s.one_minus_tau; a.step_dev = s.step_dev; a.inv_world = s.inv_world;
-    a.rec = s.rec; a.step_bias = s.step_bias; a.bc = s.bc;
-    if (s.rec && (s.n_partials > NAF_MAX_NORM_PARTIALS || ((uintptr_t)s.partials & 15))) return false;
+    a.bc = s.bc;
     return true;
 }

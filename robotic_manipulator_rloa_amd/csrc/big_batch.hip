@@ -383,28 +383,17 @@ struct FinishArgs {
     const float *mom, *wc, *gamma, *save_invstd;
     float *d_W, *d_gamma, *d_beta, *d_bias, *d_bias2;
     const float *d_gamma2, *d_beta2;
-    float* sumsq_partials;       // plain: one float per workgroup; tagged (tag != 0): one 16-byte record per workgroup
+    float* sumsq_partials;       // one float per workgroup
     int32_t* step_dev;
     int B, H;
     BbSlabs slabs;
     int* fold_flag;
     int n_blocks;                // finish blocks + slab-reduce blocks
 };
-// stores of the gradient: plain, or sc1 when the readers sit in the SAME launch (tag != 0: bb_layer1_kernel carrying the finish
-// work of the previous update — the optimizer workgroups and the layer-1 workgroups beside it wait for this workgroup's record)
-__device__ __forceinline__ static void bf_st1(float* p, float v, bool sc1) {
-    if (sc1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-// One workgroup (BB_THREADS threads) of the finish work. tag == 0: as a launch of its own (plain stores, plain partial, step
-// count advanced). tag != 0: riding on the next update's first launch — every gradient store sc1 and waited for in front of the
-// workgroup's barrier, then ONE lane publishes the 16-byte record {sum of squares, tag, 0, 0}; the step count is left alone
-// (its readers sit in this launch: AdamArgs.step_bias).
-__device__ static inline void bb_finish_block(const FinishArgs& F, int block, int tid, float* sQ, float (*sP)[2][32], int tag) {
-    // (no FP contraction: this body is compiled into two kernels — the launch of its own and bb_layer1_kernel — and must round the
-    //  same way in both; left to the optimizer, the two instances fused different multiplies into their adds)
+// One workgroup (BB_THREADS threads) of the finish work.
+__device__ static inline void bb_finish_block(const FinishArgs& F, int block, int tid, float* sQ, float (*sP)[2][32]) {
+    // (no FP contraction: the gradient of a build rounds the same way whatever the optimizer makes of this body)
 #pragma clang fp contract(off)
-    const bool sc1 = tag != 0;
     float sq = 0.f;
     // the launch number the bundle's folded constants are tagged with (naf_gemm_bn2bwd_t.epoch): a new one for the next update
     if (F.fold_flag && block == 0 && tid == 64) *F.fold_flag += 1;
@@ -421,8 +410,7 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
 #pragma unroll
             for (int s_ = 1; s_ < BB_MAX_SLABS; ++s_)
                 if (s_ < sg.n_slabs) { a.x += v[s_].x; a.y += v[s_].y; a.z += v[s_].z; a.w += v[s_].w; }
-            if (sc1) naf_buf_st_f4_sc1(naf_buf(sg.dst), 4u * (unsigned)i, 0, (f32x4){a.x, a.y, a.z, a.w});
-            else *(float4*)(sg.dst + i) = a;
+            *(float4*)(sg.dst + i) = a;
             sq = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
         }
     } else {
@@ -472,16 +460,16 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
                     const float invB = 1.0f / (float)F.B;
                     const float Pt = sP[cl][0][k] + sP[cl][1][k];
                     const float g = (gm * invstd) * (Pt - (sdy * invB) * sxk - (sdx * invB) * (invstd * wck));
-                    bf_st1(&F.d_W[(int64_t)col * F.K + k], g, sc1);
+                    F.d_W[(int64_t)col * F.K + k] = g;
                     sq = g * g;
                 } else if (lane == 32) {                      // F.d_gamma = sum dy*xhat, F.d_beta = sum dy; F.d_bias = 0 (see above)
-                    bf_st1(&F.d_gamma[col], sdx, sc1);
-                    bf_st1(&F.d_beta[col], sdy, sc1);
-                    bf_st1(&F.d_bias[col], 0.f, sc1);
+                    F.d_gamma[col] = sdx;
+                    F.d_beta[col] = sdy;
+                    F.d_bias[col] = 0.f;
                     sq = sdx * sdx + sdy * sdy;
                 }
             } else if (lane == 0) {
-                bf_st1(&F.d_bias2[col], db2, sc1);
+                F.d_bias2[col] = db2;
                 sq = db2 * db2;
             } else if (lane == 1) {
                 sq = g2 * g2 + b2 * b2;
@@ -489,15 +477,10 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
         }
     }
     if (F.sumsq_partials) {
-        if (sc1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave, in front of the barriers of the sum
         const float tot = block_sum_to_thread0<BB_THREADS, true>(sq, sQ, tid);
         if (tid == 0) {
-            if (sc1) {
-                naf_buf_st_f4_sc1(naf_buf(F.sumsq_partials), 16u * (unsigned)block, 0, (f32x4){tot, __builtin_bit_cast(float, tag), 0.f, 0.f});
-            } else {
-                F.sumsq_partials[block] = tot;
-                if (block == 0 && F.step_dev) *F.step_dev += 1;   // read by the NEXT launch (Adam) only
-            }
+            F.sumsq_partials[block] = tot;
+            if (block == 0 && F.step_dev) *F.step_dev += 1;   // read by the NEXT launch (Adam) only
         }
     }
 }
@@ -506,7 +489,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(const 
     __shared__ float sQ[BB_THREADS / 64];
     __shared__ float sP[BF_COLS][2][32];
     NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 0);
-    bb_finish_block(F, (int)blockIdx.x, (int)threadIdx.x, sQ, sP, 0);
+    bb_finish_block(F, (int)blockIdx.x, (int)threadIdx.x, sQ, sP);
     NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 3);
 }
 
@@ -527,7 +510,7 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     int64_t param_net_stride, const float* __restrict__ mom, float* __restrict__ running_mean,
     float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out, int64_t out_net_stride, int ldo,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ wc_out, int B, int H, float momentum,
-    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4, int n_adam, const FinishArgs fin) {
+    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4, int n_adam) {
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
     constexpr int XN = (BB_ROWS * K4 + BB_THREADS - 1) / BB_THREADS;           // float4 of the row tile per thread: 2
     constexpr int MN = (REC / 4 + BB_THREADS - 1) / BB_THREADS;                // of the moments record: 1 or 2
@@ -537,28 +520,15 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     __shared__ float sStat[4][BB_COLS];     // mean, invstd, gamma, beta of this workgroup's columns
     __shared__ AdamScalars shA;
     __shared__ __attribute__((aligned(16))) float sPar[3][BB_COLS];   // ADAM: b, gamma, beta of the columns as the step leaves them
-    __shared__ float sQf[BB_THREADS / 64];                            // (riding finish work)
-    __shared__ float sPf[BF_COLS][2][32];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    // grid: [riding finish work of the previous update | riding optimizer step | this kernel's own workgroups] — the producers of
-    // the records FIRST, so that they are dispatched before anything that waits for them, whatever the occupancy
-    const int n_ride = ADAM ? fin.n_blocks + n_adam : 0;
+    // grid: [riding optimizer step | this kernel's own workgroups]
+    const int n_ride = ADAM ? n_adam : 0;
     const int widx = (int)blockIdx.x - n_ride;             // >= 0: a layer-1 workgroup
     if (ADAM && __builtin_expect(widx < 0, 0)) {           // (unlikely: the riding code sits behind the kernel's own)
-        const int r = (int)blockIdx.x;
-        if (r >= fin.n_blocks) {
-            const int ra = r - fin.n_blocks;
-            NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 11, ra == 0, ra == n_adam - 1);    // (raw slots 11, 12: the riding step)
-            adam_block<2 * BB_THREADS>(ad, (size_t)l1_4, (size_t)n4, ra, n_adam, &shA, tid, true);
-            NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 12, ra == 0, ra == n_adam - 1);
-            return;
-        }
-        // the finish work of the PREVIOUS update (bb_finish_block, 256 threads: waves 4 .. 7 have nothing to do here), its
-        // records tagged with the step number the readers beside it wait for
-        if (tid >= BB_THREADS) return;
-        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 13, r == 0, r == fin.n_blocks - 1);    // (raw slots 13, 14: riding finish)
-        bb_finish_block(fin, r, tid, sQf, sPf, *ad.step_dev + ad.step_bias);
-        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 14, r == 0, r == fin.n_blocks - 1);
+        const int ra = (int)blockIdx.x;
+        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 11, ra == 0, ra == n_adam - 1);    // (raw slots 11, 12: the riding step)
+        adam_block<2 * BB_THREADS>(ad, (size_t)l1_4, (size_t)n4, ra, n_adam, &shA, tid, true);
+        NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 12, ra == 0, ra == n_adam - 1);
         return;
     }
     const int gx = B / BB_ROWS, gy = H / BB_COLS;
@@ -662,10 +632,6 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
         __syncthreads();
         L1_TL(9);
         const AdamScalars sc = shA;
-        if (ad.rec) {                                         // the records are in (adam_prefetch waited): the gradient now, sc1
-            fw.g = adam_fly_load_g4(ad, ofw);
-            fp.g = adam_fly_load_g4(ad, ofp);
-        }
         if (tid < wn4) wv[0] = adam_fly_apply4(ad, sc, fw, wv[0], tgt);
         if (pj >= 0) *(f32x4*)(&sPar[0][0] + 4 * pj) = adam_fly_apply4(ad, sc, fp, pcur, tgt);
         L1_TL(10);
@@ -1057,379 +1023,6 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// layer 1 + GEMM 2 in ONE launch (bb_layer1_kernel + bb_linear_stats_kernel: skipping the former's launch was measured to
-// be worth 7.8 / 8.9 us per update at B = 1024 / 2048 — more than its own body, because A1 then never makes a round trip
-// through another XCD's L2). Layer 1's statistics come from the moments record, so A1 = ReLU(BN(X W1^T + b1)) is
-// elementwise on a recomputed z: every GEMM-2 workgroup (64 rows x 32 output columns) produces its own A panel — 64 rows x
-// 128 k per chunk — straight into LDS from the 64 x 24 tile of minibatch rows it has staged, 8 x redundantly across the
-// column workgroups of a row block (VALU time a workgroup can spare: its MFMA phase is 1.7 us). The column-0 workgroups also
-// write A1 to memory for the backward pass. Per chunk of 128 layer-1 features:
-//   W1 rows of the chunk flat in LDS -> statistics on MFMA (U = W1c C, then w . U rows) -> z tile on MFMA (X W1c^T, K = 24:
-//   a first VALU version of these two steps cost 9 us per workgroup) -> bias, normalise, ReLU -> sA -> the GEMM-2 MFMAs
-// ------------------------------------------------------------------------------------------------------------
-#define L12_KMAX 26
-template <int K4>
-__global__ __launch_bounds__(BB_THREADS) void bb_layer12_kernel(
-    const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W1,
-    const float* __restrict__ bias1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
-    const float* __restrict__ W2, const float* __restrict__ bias2, int64_t param_net_stride, const float* __restrict__ mom,
-    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ a1_out,
-    int64_t a1_net_stride, int lda1, float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ wc_out,
-    float* __restrict__ z, int64_t z_net_stride, int ldz, float2* __restrict__ partials, int B, float momentum, float eps) {
-    // every MFMA operand of layer 1 sits in LDS zero-padded to KP (+4) floats per row, k contiguous, so that a fragment is ONE
-    // unconditional 16-byte read (the first MFMA version read W1 flat with a `k < K ? .. : 0` per element: one dependent LDS
-    // round trip per MFMA — 4 us per phase instead of 0.5)
-    constexpr int KP = 4 * K4, LD1 = KP + 4, REC = KP + KP * KP, H = 2 * BL_KC, N = H;
-    __shared__ __attribute__((aligned(16))) float sA[BL_BM * BL_LD];
-    __shared__ __attribute__((aligned(16))) float sB[BL_BN * BL_LD];
-    __shared__ __attribute__((aligned(16))) float sXr[BB_ROWS * LD1];          // the row tile, [row][k]
-    __shared__ __attribute__((aligned(16))) float sW1[BL_KC * LD1];            // the chunk's W1 rows, [feature][k], zeros beyond K
-    __shared__ __attribute__((aligned(16))) float sC[32 * LD1];                // C of the moments record, zero rows / columns beyond KP
-    __shared__ float sSx[32];
-    __shared__ float sSt[5][BL_KC];                                             // mean, invstd, gamma, beta, bias of the chunk
-    __shared__ float red[2][BL_BN];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NB = B / BB_ROWS;
-    const int net = blockIdx.x / NB, rb = blockIdx.x - net * NB;
-    const int n0 = blockIdx.y * BL_BN;
-    const int64_t po = net * param_net_stride;
-    const float* xn = x + net * x_net_stride + (int64_t)rb * BB_ROWS * ldx;
-    const float* w2n = W2 + po + (int64_t)n0 * H;                              // [N][K = H] row-major
-    const float* w1n = W1 + po;
-    const float* momn = mom + (int64_t)net * REC;
-    const bool writer = blockIdx.y == 0;                                         // this row block's A1 / statistics go to memory
-    // ---- everything the first chunk needs, requested in one batch ------------------------------------------------
-    f32x4 xv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + BB_THREADS * i;
-        const int row = e / K4, q = e - row * K4;
-        xv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (row < BB_ROWS) xv[i] = ((const f32x4*)(xn + (int64_t)row * ldx))[q];
-    }
-    f32x4 cv = {0.f, 0.f, 0.f, 0.f};                                            // C: KP rows x K4 float4; Sx: KP floats
-    const int crow = tid / K4, cq = tid - crow * K4;
-    if (crow < KP) cv = ((const f32x4*)(momn + KP + crow * KP))[cq];
-    const float sxv = tid < KP ? momn[tid] : 0.f;
-    // the chunk's W1 rows: a flat run of 128 K floats; element i = (feature i / K, k = i % K)
-    const int w1n4 = (BL_KC * K) / 4;
-    f32x4 w1v[4];
-    float st_g, st_b, st_bias;
-    auto load_l1_chunk = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + BB_THREADS * i;
-            w1v[i] = e < w1n4 ? ((const f32x4*)(w1n + (int64_t)c * BL_KC * K))[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        const int f = c * BL_KC + (tid & (BL_KC - 1));
-        st_g = gamma1[po + f];
-        st_b = beta1[po + f];
-        st_bias = bias1[po + f];
-    };
-    load_l1_chunk(0);
-    f32x4 vb0[4], vb1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + BB_THREADS * i;
-        vb0[i] = ((const f32x4*)(w2n + (int64_t)(e >> 5) * H))[e & 31];
-        vb1[i] = ((const f32x4*)(w2n + (int64_t)(e >> 5) * H + BL_KC))[e & 31];
-    }
-    const int r = lane & 15, g = lane >> 4;
-    const int wm = wave & 1, wn = wave >> 1;
-    const float bcol = bias2[po + n0 + 16 * wn + r];
-    // ---- zero the padding once, stage the row tile and the moments ----------------------------------------------------
-    for (int e = tid; e < BL_KC * LD1; e += BB_THREADS) sW1[e] = 0.f;
-    for (int e = tid; e < 32 * LD1; e += BB_THREADS) sC[e] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + BB_THREADS * i;
-        const int row = e / K4, q = e - row * K4;
-        if (row < BB_ROWS) *(f32x4*)(sXr + row * LD1 + 4 * q) = xv[i];
-    }
-    if (crow < KP) *(f32x4*)(sC + crow * LD1 + 4 * cq) = cv;
-    if (tid < 32) sSx[tid] = sxv;
-    f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
-    const float* pa0 = sA + (32 * wm + r) * BL_LD + 4 * g;
-    const float* pa1 = pa0 + 16 * BL_LD;
-    const float* pb = sB + (16 * wn + r) * BL_LD + 4 * g;
-    const unsigned kinv = (65536u + (unsigned)K - 1u) / (unsigned)K;             // i / K for i < 128 K <= 3328 (exact: checked on the host)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        if (c) __syncthreads();                           // chunk 0's MFMAs are done with sA / sB, its z tile with sW1 / sSt
-        // the chunk's W1 rows (scattered from the flat run to their padded rows) and per-feature parameters into LDS, the
-        // chunk's W2 panel too
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + BB_THREADS * i;
-            if (e < w1n4) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned idx = 4u * (unsigned)e + (unsigned)q;
-                    const unsigned f = (idx * kinv) >> 16;
-                    sW1[f * LD1 + (idx - f * (unsigned)K)] = w1v[i][q];
-                }
-            }
-        }
-        if (tid < BL_KC) {
-            sSt[2][tid] = st_g;
-            sSt[3][tid] = st_b;
-            sSt[4][tid] = st_bias;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + BB_THREADS * i;
-            *(f32x4*)(sB + (e >> 5) * BL_LD + 4 * (e & 31)) = c ? vb1[i] : vb0[i];
-        }
-        if (c == 0) load_l1_chunk(1);                     // in flight under this chunk's arithmetic
-        __syncthreads();
-        {   // statistics of the chunk's 128 features from the moments, on MFMA: U = W1c C (128 x KP) — wave w owns features
-            // 32 w .. +31 (two m-tiles), both 16-column halves of U — then t_f = U[f] . w_f, mdot_f = w_f . Sx as a 16-lane
-            // reduction of the accumulator rows. A fragment = padded W1 rows, B fragment = rows of the symmetric C.
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const float* wa = sW1 + (32 * wave + 16 * mt + r) * LD1 + 4 * g;
-                f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0;
-#pragma unroll
-                for (int kk = 0; kk < KP; kk += 16) {
-                    const bool in = kk + 4 * g < KP;                     // KP = 24: the last lane groups of the second step are past K
-                    const int ko = in ? kk : 0;
-                    f32x4 a = *(const f32x4*)(wa + ko), b0 = *(const f32x4*)(sC + r * LD1 + ko + 4 * g);
-                    f32x4 b1 = *(const f32x4*)(sC + (16 + r) * LD1 + ko + 4 * g);
-                    if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b0[q], u0, 0, 0, 0);
-                        u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b1[q], u1, 0, 0, 0);
-                    }
-                }
-                // lane (r, g) holds U[f = 32 w + 16 mt + 4 g + e][n = r] (u0) and [n = 16 + r] (u1)
-                const bool hi = 16 + r < KP;
-                if (wc_out && writer && rb == 0 && net == 0) {       // w_f C for the backward pass (bb_layer1_bwd_finish_kernel)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float* dst = wc_out + (int64_t)(c * BL_KC + 32 * wave + 16 * mt + 4 * g + e) * KP;
-                        dst[r] = u0[e];
-                        if (hi) dst[16 + r] = u1[e];
-                    }
-                }
-                const float sx0 = sSx[r], sx1 = sSx[16 + r];
-                float t[4], md[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float* wf = sW1 + (32 * wave + 16 * mt + 4 * g + e) * LD1;
-                    const float w0 = wf[r], w1 = hi ? wf[16 + r] : 0.f;
-                    t[e] = u0[e] * w0 + u1[e] * w1;
-                    md[e] = w0 * sx0 + w1 * sx1;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    t[e] = naf_sum16(t[e]);
-                    md[e] = naf_sum16(md[e]);
-                }
-                if (r < 4) {                                          // lane r of the group finishes feature 4 g + r
-                    const int f = 32 * wave + 16 * mt + 4 * g + r;
-                    const float tt = r == 0 ? t[0] : r == 1 ? t[1] : r == 2 ? t[2] : t[3];
-                    const float mm = r == 0 ? md[0] : r == 1 ? md[1] : r == 2 ? md[2] : md[3];
-                    const float mean = sSt[4][f] + mm / (float)B;
-                    const float var = fmaxf(tt, 0.f) / (float)B;
-                    const float invstd = 1.0f / sqrtf(var + eps);
-                    sSt[0][f] = mean;
-                    sSt[1][f] = invstd;
-                    if (writer && rb == 0) {
-                        const int col = c * BL_KC + f;
-                        const int64_t so = net * stat_net_stride + col;
-                        const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-                        running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
-                        running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
-                        save_mean[(int64_t)net * H + col] = mean;
-                        save_invstd[(int64_t)net * H + col] = invstd;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        {   // z tile on MFMA: Z = X (64 x KP) W1c^T — wave w owns rows 16 w .. +15 and all 8 feature tiles; then bias,
-            // normalise, ReLU into the A panel (and to memory from the column-0 workgroups)
-            f32x4 zt[8];
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) zt[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KP; kk += 16) {
-                const bool in = kk + 4 * g < KP;
-                const int ko = in ? kk : 0;
-                f32x4 a = *(const f32x4*)(sXr + (16 * wave + r) * LD1 + ko + 4 * g);
-                if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
-                f32x4 bv[8];
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) bv[nt] = *(const f32x4*)(sW1 + (16 * nt + r) * LD1 + ko + 4 * g);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int nt = 0; nt < 8; ++nt) zt[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], bv[nt][q], zt[nt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const int f = 16 * nt + r;
-                const float mean = sSt[0][f], invstd = sSt[1][f], gm = sSt[2][f], bt = sSt[3][f], bb = sSt[4][f];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = 16 * wave + 4 * g + e;
-                    const float y = fmaxf(((zt[nt][e] + bb) - mean) * invstd * gm + bt, 0.f);
-                    sA[row * BL_LD + f] = y;
-                    if (writer) a1_out[net * a1_net_stride + (int64_t)(rb * BB_ROWS + row) * lda1 + c * BL_KC + f] = y;
-                }
-            }
-        }
-        __syncthreads();
-        bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
-    }
-    // ---- epilogue: bias, Z2, statistics partials of the 64-row block (as bb_linear_stats_kernel) ----------------------
-    float v[2][4];
-    float s = 0.f;
-    float* zn = z + net * z_net_stride + (int64_t)(rb * BL_BM + 32 * wm + 4 * g) * ldz + n0 + 16 * wn + r;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[mt][e] = (mt ? c10[e] + c11[e] : c00[e] + c01[e]) + bcol;
-            zn[(int64_t)(16 * mt + e) * ldz] = v[mt][e];
-            s += v[mt][e];
-        }
-    s = naf_xor32_add(naf_xor16_add(s));
-    if (g == 0) red[wm][16 * wn + r] = s;
-    __syncthreads();
-    const float S = red[0][16 * wn + r] + red[1][16 * wn + r];
-    const float mb = S * (1.0f / BB_ROWS);
-    float m2 = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float t = v[mt][e] - mb;
-            m2 += t * t;
-        }
-    m2 = naf_xor32_add(naf_xor16_add(m2));
-    __syncthreads();
-    if (g == 0) red[wm][16 * wn + r] = m2;
-    __syncthreads();
-    if (wm == 0 && g == 0)
-        partials[((int64_t)net * NB + rb) * N + n0 + 16 * wn + r] = make_float2(S, red[0][16 * wn + r] + red[1][16 * wn + r]);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// layer 2, stage 2 + heads: fold the statistics of this workgroup's 64 columns, normalise + ReLU its 64 x 64 tile of Z2
-// (written out as A2 for the backward GEMMs), and multiply the tile — still in LDS — with Wh[:, 64 columns]: the heads
-// GEMM split over H/64 column slices. Main net: all NHP head columns; target net: the V column only.
-// ------------------------------------------------------------------------------------------------------------
-template <int NH4>
-__global__ __launch_bounds__(BB_THREADS) void bb_bn_relu_heads_partial_kernel(
-    const float* __restrict__ z, int64_t z_net_stride, int ldz, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int64_t param_net_stride, const float2* __restrict__ partials,
-    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out,
-    int64_t out_net_stride, int ldo, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-    const float* __restrict__ Wh, int64_t wh_net_stride, int ldw, int v_col, float* __restrict__ heads_partial,
-    int64_t slab_stride, float* __restrict__ vnext_partial, int B, int H, float momentum, float eps) {
-    constexpr int NHP = 4 * NH4, HPT = NHP / 4;          // heads per thread (main net): 4 threads share a row
-    __shared__ __attribute__((aligned(16))) float sA[BB_ROWS][BB_COLS + 4];
-    __shared__ __attribute__((aligned(16))) float sW[NHP][BB_COLS + 4];
-    __shared__ float sStat[4][BB_COLS];
-    __shared__ float sBias[NHP];
-    const int tid = threadIdx.x;
-    const int rb = blockIdx.x, slice = blockIdx.y, net = blockIdx.z, col0 = slice * BB_COLS;
-    const int NB = gridDim.x;
-    const int64_t po = net * param_net_stride;
-    const float* zn = z + net * z_net_stride + (int64_t)rb * BB_ROWS * ldz + col0;
-    // the tile's loads first (4 float4 per thread), the statistics fold runs under them
-    float4 zv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) zv[i] = *(const float4*)(zn + (int64_t)((tid >> 4) + 16 * i) * ldz + 4 * (tid & 15));
-    const float* Whn = Wh + net * wh_net_stride;
-    if (net == 0) {
-        for (int e = tid; e < NHP * (BB_COLS / 4); e += BB_THREADS) {
-            const int h = e / (BB_COLS / 4), q = e - h * (BB_COLS / 4);
-            *(float4*)&sW[h][4 * q] = *(const float4*)(Whn + (int64_t)h * ldw + col0 + 4 * q);
-        }
-        if (tid < NHP) sBias[tid] = slice == 0 ? Whn[(int64_t)tid * ldw + H] : 0.f;      // bias = column H (ones column of A2)
-    } else {
-        if (tid < BB_COLS / 4) *(float4*)&sW[0][4 * tid] = *(const float4*)(Whn + (int64_t)v_col * ldw + col0 + 4 * tid);
-        if (tid == 0) sBias[0] = slice == 0 ? Whn[(int64_t)v_col * ldw + H] : 0.f;
-    }
-    if (tid < BB_COLS) {
-        const int col = col0 + tid;
-        float mean, var;
-        bb_fold_stats(partials + (int64_t)net * NB * H, H, NB, B, col, &mean, &var);
-        const float invstd = 1.0f / sqrtf(var + eps);
-        sStat[0][tid] = mean;
-        sStat[1][tid] = invstd;
-        sStat[2][tid] = gamma[po + col];
-        sStat[3][tid] = beta[po + col];
-        if (rb == 0) {
-            const int64_t so = net * stat_net_stride + col;
-            const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
-            running_mean[so] = (1.0f - momentum) * running_mean[so] + momentum * mean;
-            running_var[so] = (1.0f - momentum) * running_var[so] + momentum * unbiased;
-            save_mean[(int64_t)net * H + col] = mean;
-            save_invstd[(int64_t)net * H + col] = invstd;
-        }
-    }
-    __syncthreads();
-    float* on = out + net * out_net_stride + (int64_t)rb * BB_ROWS * ldo + col0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 4) + 16 * i, c = 4 * (tid & 15);
-        float4 y;
-        y.x = (zv[i].x - sStat[0][c + 0]) * sStat[1][c + 0] * sStat[2][c + 0] + sStat[3][c + 0];
-        y.y = (zv[i].y - sStat[0][c + 1]) * sStat[1][c + 1] * sStat[2][c + 1] + sStat[3][c + 1];
-        y.z = (zv[i].z - sStat[0][c + 2]) * sStat[1][c + 2] * sStat[2][c + 2] + sStat[3][c + 2];
-        y.w = (zv[i].w - sStat[0][c + 3]) * sStat[1][c + 3] * sStat[2][c + 3] + sStat[3][c + 3];
-        y.x = y.x > 0.f ? y.x : 0.f;
-        y.y = y.y > 0.f ? y.y : 0.f;
-        y.z = y.z > 0.f ? y.z : 0.f;
-        y.w = y.w > 0.f ? y.w : 0.f;
-        *(float4*)(on + (int64_t)row * ldo + c) = y;
-        *(float4*)&sA[row][c] = y;
-    }
-    __syncthreads();
-    const int row = tid >> 2, hq = tid & 3;
-    if (net == 0) {
-        // thread = (row, quarter of the heads): HPT heads x 64 k, k ascending
-        float acc[HPT];
-#pragma unroll
-        for (int j = 0; j < HPT; ++j) acc[j] = sBias[hq * HPT + j];
-#pragma unroll 4
-        for (int c = 0; c < BB_COLS; c += 4) {
-            const float4 a = *(const float4*)&sA[row][c];
-#pragma unroll
-            for (int j = 0; j < HPT; ++j) {
-                const float4 w = *(const float4*)&sW[hq * HPT + j][c];
-                acc[j] = __builtin_fmaf(a.x, w.x, acc[j]);
-                acc[j] = __builtin_fmaf(a.y, w.y, acc[j]);
-                acc[j] = __builtin_fmaf(a.z, w.z, acc[j]);
-                acc[j] = __builtin_fmaf(a.w, w.w, acc[j]);
-            }
-        }
-        float* dst = heads_partial + (int64_t)slice * slab_stride + (int64_t)(rb * BB_ROWS + row) * NHP + hq * HPT;
-#pragma unroll
-        for (int j = 0; j < HPT; j += 4) *(float4*)(dst + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
-    } else {
-        // V'(s') share of this slice: 4 threads per row, 16 k each, folded by two xor shuffles (fixed order)
-        float p = 0.f;
-#pragma unroll
-        for (int c = 16 * hq; c < 16 * hq + 16; c += 4) {
-            const float4 a = *(const float4*)&sA[row][c];
-            const float4 w = *(const float4*)&sW[0][c];
-            p = __builtin_fmaf(a.x, w.x, p);
-            p = __builtin_fmaf(a.y, w.y, p);
-            p = __builtin_fmaf(a.z, w.z, p);
-            p = __builtin_fmaf(a.w, w.w, p);
-        }
-        p = naf_xor2_add(naf_xor1_add(p));
-        if (hq == 0) vnext_partial[(int64_t)slice * B + rb * BB_ROWS + row] = p + sBias[0];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // layer 2 + heads + NAF head + first backward stage of layer 2 in ONE launch (H = 256): a workgroup owns 32 batch rows
 // across ALL 256 features, so nothing between the layer-2 pre-activations and dY2 leaves the chip:
 //   fold the layer-2 statistics of both nets (512 (net, column) pairs, one per thread) -> xhat tile of the main net in LDS
@@ -1692,254 +1285,6 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// backward of layer 2, stage 1: dA2 = dHeads Wh (reduction over the NHP <= 48 head outputs, on the fly), ReLU mask from
-// A2, xhat from Z2 and the saved statistics; writes dY2 and the per-block column sums (sum dy, sum dy*xhat).
-// ------------------------------------------------------------------------------------------------------------
-template <int NH4>
-__global__ __launch_bounds__(BB_THREADS) void bb_heads_bwd_stage1_kernel(
-    const float* __restrict__ d_heads, int ldh, const float* __restrict__ Wh, int ldw, const float* __restrict__ z, int ldz,
-    const float* __restrict__ a2, int lda, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-    float* __restrict__ dy_out, int ldd, float2* __restrict__ partials, int B, int H) {
-    constexpr int NHP = 4 * NH4;
-    __shared__ __attribute__((aligned(16))) float sDH[BB_ROWS][NHP + 4];
-    __shared__ __attribute__((aligned(16))) float sW[NHP][BB_COLS + 4];
-    __shared__ float sT[BB_ROWS][BB_COLS + 1];
-    __shared__ float sStat[2][BB_COLS];
-    const int tid = threadIdx.x;
-    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS;
-    const int row = tid >> 2, cq = tid & 3;               // thread = (row, 16 columns)
-    const int64_t grow = (int64_t)rb * BB_ROWS + row;
-    float4 zv[4], av[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        zv[i] = *(const float4*)(z + grow * ldz + col0 + 16 * cq + 4 * i);
-        av[i] = *(const float4*)(a2 + grow * lda + col0 + 16 * cq + 4 * i);
-    }
-    for (int e = tid; e < BB_ROWS * NH4; e += BB_THREADS) {
-        const int r_ = e / NH4, q = e - r_ * NH4;
-        *(float4*)&sDH[r_][4 * q] = *(const float4*)(d_heads + ((int64_t)rb * BB_ROWS + r_) * ldh + 4 * q);
-    }
-    for (int e = tid; e < NHP * (BB_COLS / 4); e += BB_THREADS) {
-        const int h = e / (BB_COLS / 4), q = e - h * (BB_COLS / 4);
-        *(float4*)&sW[h][4 * q] = *(const float4*)(Wh + (int64_t)h * ldw + col0 + 4 * q);
-    }
-    if (tid < BB_COLS) {
-        sStat[0][tid] = save_mean[col0 + tid];
-        sStat[1][tid] = save_invstd[col0 + tid];
-    }
-    __syncthreads();
-    float4 dd[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
-                    make_float4(0.f, 0.f, 0.f, 0.f)};
-#pragma unroll 4
-    for (int h = 0; h < NHP; ++h) {
-        const float d = sDH[row][h];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 w = *(const float4*)&sW[h][16 * cq + 4 * i];
-            dd[i].x = __builtin_fmaf(d, w.x, dd[i].x);
-            dd[i].y = __builtin_fmaf(d, w.y, dd[i].y);
-            dd[i].z = __builtin_fmaf(d, w.z, dd[i].z);
-            dd[i].w = __builtin_fmaf(d, w.w, dd[i].w);
-        }
-    }
-    float xh[16], dy[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w}, aa[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
-        const float d4[4] = {dd[i].x, dd[i].y, dd[i].z, dd[i].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 16 * cq + 4 * i + j;
-            xh[4 * i + j] = (zz[j] - sStat[0][c]) * sStat[1][c];
-            dy[4 * i + j] = aa[j] > 0.f ? d4[j] : 0.f;      // ReLU mask from the forward's own output
-        }
-        *(float4*)(dy_out + grow * ldd + col0 + 16 * cq + 4 * i) =
-            make_float4(dy[4 * i], dy[4 * i + 1], dy[4 * i + 2], dy[4 * i + 3]);
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) sT[row][16 * cq + j] = dy[j];
-    __syncthreads();
-    float s_dy = 0.f, s_dyxh = 0.f;
-    if (tid < BB_COLS) s_dy = bb_col_sum64(sT, tid);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) sT[row][16 * cq + j] = dy[j] * xh[j];
-    __syncthreads();
-    if (tid < BB_COLS) {
-        s_dyxh = bb_col_sum64(sT, tid);
-        partials[(int64_t)rb * H + col0 + tid] = make_float2(s_dy, s_dyxh);
-    }
-}
-
-// stage 2: fold the backward sums, dz = gamma invstd (dy - sum_dy/B - xhat sum_dyxhat/B) in place over dy; block 0 of a
-// column slice writes d_gamma / d_beta; every block leaves its column sums of dz (the Linear bias gradient under a
-// train-mode BatchNorm: zero up to rounding) for the consumer that finalises d_bias.
-__global__ __launch_bounds__(BB_THREADS) void bb_bn_bwd_stage2_kernel(float* __restrict__ dy, int ldd,
-                                                                      const float* __restrict__ z, int ldz,
-                                                                      const float* __restrict__ gamma,
-                                                                      const float* __restrict__ save_mean,
-                                                                      const float* __restrict__ save_invstd,
-                                                                      const float2* __restrict__ partials, int npb,
-                                                                      float* __restrict__ d_gamma, float* __restrict__ d_beta,
-                                                                      float* __restrict__ dz_col_partials, int B, int H) {
-    __shared__ float sT[BB_ROWS][BB_COLS + 1];
-    __shared__ float sC[5][BB_COLS];          // mean, invstd, k1, sum_dy / B, sum_dyxh / B
-    __shared__ float2 sF[4][BB_COLS];
-    const int tid = threadIdx.x;
-    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS;
-    const int row = tid >> 2, cq = tid & 3;
-    const int64_t grow = (int64_t)rb * BB_ROWS + row;
-    NAF_TL(g_tl_bb, NAF_TL_BB_STAGE2, 0);
-    float4 zv[4], dv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        zv[i] = *(const float4*)(z + grow * ldz + col0 + 16 * cq + 4 * i);
-        dv[i] = *(const float4*)(dy + grow * ldd + col0 + 16 * cq + 4 * i);
-    }
-    // npb <= 64 partial blocks (B/64 from bb_heads_bwd_stage1, B/32 from bb_layer2_head), dealt to the four waves in contiguous
-    // runs of Q <= 16: every wave folds its run for all 64 columns (one round of loads), the runs meet in LDS in wave order.
-    // (One wave walking 64 blocks in two rounds while three waited: 3.1 of this kernel's 4.0 us at B = 2048.)
-    const bool wide = npb > 8;           // (uniform) up to 8 blocks one wave folds them directly, no barrier in between
-    if (wide) {
-        const int w = __builtin_amdgcn_readfirstlane(tid >> 6), Q = (npb + 3) >> 2;
-        const int nb_w = npb - w * Q < Q ? npb - w * Q : Q;                 // blocks of this wave's run (may be <= 0)
-        // (runs of up to 32 blocks: npb <= 128 = B / 16 at B = 2048 with 16-row workgroups in bb_layer2_head)
-        const unsigned woff = (unsigned)(nb_w > 0 ? w * Q : 0) * (unsigned)H * 8u;
-        const float2 part = Q <= 16 ? bb_fold_sums_n<16>(naf_buf(partials + col0), 8u * (unsigned)(tid & 63), woff, H, nb_w > 0 ? nb_w : 0)
-                                    : bb_fold_sums_n<32>(naf_buf(partials + col0), 8u * (unsigned)(tid & 63), woff, H, nb_w > 0 ? nb_w : 0);
-        sF[w][tid & 63] = part;
-        __syncthreads();
-    }
-    if (tid < BB_COLS) {
-        const int col = col0 + tid;
-        float2 sums;
-        if (wide) {
-            sums = sF[0][tid];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                sums.x += sF[w][tid].x;
-                sums.y += sF[w][tid].y;
-            }
-        } else {
-            sums = bb_fold_sums_u(naf_buf(partials + col0), 8u * (unsigned)tid, 0, H, npb);
-        }
-        const float sdy = sums.x, sdx = sums.y;
-        const float invstd = save_invstd[col];
-        sC[0][tid] = save_mean[col];
-        sC[1][tid] = invstd;
-        sC[2][tid] = gamma[col] * invstd;
-        sC[3][tid] = sdy / (float)B;
-        sC[4][tid] = sdx / (float)B;
-        if (rb == 0) {
-            d_gamma[col] = sdx;
-            d_beta[col] = sdy;
-        }
-    }
-    __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_STAGE2, 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w}, d4[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 16 * cq + 4 * i + j;
-            const float xh = (zz[j] - sC[0][c]) * sC[1][c];
-            o[j] = sC[2][c] * (d4[j] - sC[3][c] - xh * sC[4][c]);
-            sT[row][c] = o[j];
-        }
-        *(float4*)(dy + grow * ldd + col0 + 16 * cq + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-    __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_STAGE2, 2);
-    if (tid < BB_COLS) dz_col_partials[(int64_t)rb * H + col0 + tid] = bb_col_sum64(sT, tid);
-    NAF_TL(g_tl_bb, NAF_TL_BB_STAGE2, 3);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// backward of layer 1 (one network), row-split, ONE pass over the batch + a finish launch. With dz = k1 (dy - c1 - xhat c2)
-// (k1 = gamma invstd, c1 = sum dy / B, c2 = sum dy xhat / B, all per column):
-//   dW1[c][k] = sum_r dz[r][c] x[r][k] = k1_c ( P[c][k] - c1_c Sx[k] - c2_c invstd_c (w_c C)[k] ),   P = dY^T X
-// because sum_r xhat[r][c] x[r][k] = invstd_c sum_j w[c][j] C[j][k] (layer 1 is linear in x; Sx, C = the moments record).
-// So the batch pass only needs dy: its block sums (sum dy, sum dy*xhat) and the block's share of P. The bias gradient
-// sum_r dz is k1 c2 sum_r xhat = 0 by construction of the mean; it is written as 0 (the reference's value is rounding
-// noise that the train-mode BatchNorm cancels).
-//   pass     z recomputed from X and W1 (the forward's arithmetic), xhat, dy = ReLU'(A1) * dA1
-//                                                         -> partials[B/64][H] (float2), p_slabs[B/64][H][KP]
-//   finish   folds both in block order -> dW1, d_gamma1, d_beta1, d_bias1 = 0, the bias gradient of layer 2 from its
-//            block sums, the split-K slabs of the bundle, and the sum-of-squares partials of everything
-// ------------------------------------------------------------------------------------------------------------
-template <int K4>
-__global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_kernel(
-    const float* __restrict__ d_out, int ld_dout, const float* __restrict__ x, int ldx, int K, const float* __restrict__ W,
-    const float* __restrict__ bias, const float* __restrict__ out, int ldo, const float* __restrict__ save_mean,
-    const float* __restrict__ save_invstd, float2* __restrict__ partials, float* __restrict__ p_slabs, int B, int H) {
-    constexpr int KP = 4 * K4;
-    __shared__ __attribute__((aligned(16))) float sXt[KP][BB_ROWS + 4];
-    __shared__ __attribute__((aligned(16))) float sWt[KP][BB_COLS + 4];
-    __shared__ float red[4][BB_COLS];
-    __shared__ float sC[2][BB_COLS];                     // mean, invstd
-    __shared__ float sDY[BB_ROWS][BB_COLS + 1];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const int rb = blockIdx.x, col0 = blockIdx.y * BB_COLS;
-    // this thread's 4 x 4 of dA1 and A1 first, the tile operands behind them
-    float4 dv[4], ov[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t row = (int64_t)rb * BB_ROWS + 4 * ty + i;
-        dv[i] = *(const float4*)(d_out + row * ld_dout + col0 + 4 * tx);
-        ov[i] = *(const float4*)(out + row * ldo + col0 + 4 * tx);
-    }
-    bb_l1_stage<K4>(x, ldx, rb * BB_ROWS, W, K, col0, H, sXt, sWt, tid);
-    const float4 b4 = *(const float4*)(bias + col0 + 4 * tx);
-    if (tid < BB_COLS) {
-        sC[0][tid] = save_mean[col0 + tid];
-        sC[1][tid] = save_invstd[col0 + tid];
-    }
-    __syncthreads();
-    float z[4][4];
-    bb_l1_tile<K4>(sXt, sWt, b4, ty, tx, z);
-    float dy[4][4], dyxh[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float d4[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w}, o4[4] = {ov[i].x, ov[i].y, ov[i].z, ov[i].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 4 * tx + j;
-            const float xh = (z[i][j] - sC[0][c]) * sC[1][c];
-            const float d = o4[j] > 0.f ? d4[j] : 0.f;
-            dy[i][j] = d;
-            dyxh[i][j] = d * xh;
-            sDY[4 * ty + i][c] = d;
-        }
-    }
-    float s1[4], s2[4];
-    bb_tile_col_sums(dy, red, tid, tx, s1);              // (its barriers also publish sDY)
-    bb_tile_col_sums(dyxh, red, tid, tx, s2);
-    if (ty == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) partials[(int64_t)rb * H + col0 + 4 * tx + j] = make_float2(s1[j], s2[j]);
-    }
-    // P slab of this block: thread = (column c, quarter kq of the k range): sum over the 64 rows, row ascending
-    {
-        constexpr int KQ = KP / 4;
-        const int c = tid >> 2, kq = tid & 3;
-        float acc[KQ];
-#pragma unroll
-        for (int k = 0; k < KQ; ++k) acc[k] = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < BB_ROWS; ++r) {
-            const float d = sDY[r][c];
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) acc[k] = __builtin_fmaf(d, sXt[KQ * kq + k][r], acc[k]);
-        }
-        float* dst = p_slabs + ((int64_t)rb * H + col0 + c) * KP + KQ * kq;
-#pragma unroll
-        for (int k = 0; k < KQ; ++k) dst[k] = acc[k];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && (B % BB_ROWS) == 0 && B <= 32 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
@@ -1978,43 +1323,11 @@ static bool bb_adam_setup(const naf_adam_args_t* adam, AdamArgs& ad, int64_t& l1
 }
 static int bb_adam_blocks(int64_t lo4, int64_t hi4, int threads) { return (int)((hi4 - lo4 + threads - 1) / threads); }
 
-// naf_bb_finish_args_t -> FinishArgs (checks as naf_bb_layer1_bwd_finish)
-static int bb_finish_setup(const naf_bb_finish_args_t& a, FinishArgs& F) {
-    if (!a.p_slabs || !a.partials1 || !a.dz2_col_partials || !a.mom || !a.wc || !a.gamma || !a.save_invstd || !a.d_W || !a.d_gamma ||
-        !a.d_beta || !a.d_bias || !a.d_bias2 || a.nb < 0 || a.nb > BB_MAX_NB || a.nb1 <= 0 || a.nb1 > BB_MAX_NB1 || a.H <= 0 ||
-        a.B <= 0 || a.K <= 0 || a.K > 32)
-        return NAF_ERR_ARG;
-    if (a.sumsq_records && (!a.d_gamma2 || !a.d_beta2)) return NAF_ERR_ARG;
-    if (a.n_segs < 0 || a.n_segs > 2 || (a.n_segs && !a.segs)) return NAF_ERR_ARG;
-    BbSlabs sl;
-    memset(&sl, 0, sizeof(sl));
-    sl.n_finish_blocks = (a.H + BF_COLS - 1) / BF_COLS;
-    sl.n_seg = a.n_segs;
-    int blocks = 0;
-    for (int i = 0; i < a.n_segs; ++i) {
-        const naf_bb_slab_seg_t& g = a.segs[i];
-        if (!g.src || !g.dst || g.n <= 0 || (g.n & 3) || g.n_slabs < 1 || g.n_slabs > BB_MAX_SLABS || g.stride < g.n || (g.stride & 3) ||
-            (((uintptr_t)g.src | (uintptr_t)g.dst) & 15) != 0)
-            return NAF_ERR_ARG;
-        sl.seg[i].src = g.src; sl.seg[i].dst = g.dst; sl.seg[i].stride = g.stride;
-        sl.seg[i].n = g.n; sl.seg[i].n_slabs = g.n_slabs; sl.seg[i].block0 = blocks;
-        blocks += (g.n + BB_THREADS * 4 - 1) / (BB_THREADS * 4);
-    }
-    memset(&F, 0, sizeof(F));
-    F.p_slabs = a.p_slabs; F.KP = naf_bb_layer1_bwd_kp(a.K); F.K = a.K; F.partials1 = (const float2*)a.partials1; F.NB1 = a.nb1;
-    F.dz2_col_partials = a.dz2_col_partials; F.NB = a.nb; F.mom = a.mom; F.wc = a.wc; F.gamma = a.gamma; F.save_invstd = a.save_invstd;
-    F.d_W = a.d_W; F.d_gamma = a.d_gamma; F.d_beta = a.d_beta; F.d_bias = a.d_bias; F.d_bias2 = a.d_bias2; F.d_gamma2 = a.d_gamma2;
-    F.d_beta2 = a.d_beta2; F.sumsq_partials = a.sumsq_records; F.step_dev = nullptr; F.B = a.B; F.H = a.H; F.slabs = sl;
-    F.fold_flag = a.fold_epoch; F.n_blocks = sl.n_finish_blocks + blocks;
-    return NAF_OK;
-}
-
-extern "C" int naf_bb_layer1_adam_fin(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
+extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                                   const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
                                   float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
                                   int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
-                                  int nets, float momentum, float eps, const naf_adam_args_t* adam, const naf_bb_finish_args_t* fin,
-                                  void* stream) {
+                                  int nets, float momentum, float eps, const naf_adam_args_t* adam, void* stream) {
     if (!x || !W || !bias || !mom || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd ||
         !bb_shape_ok(B, H) || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4 || ldo < H || (ldo & 3))
         return NAF_ERR_ARG;
@@ -2034,51 +1347,20 @@ extern "C" int naf_bb_layer1_adam_fin(const float* x, int64_t x_net_stride, int 
             beta + H > hi || (nets == 2 && adam->theta_target != adam->theta + param_net_stride))
             return NAF_ERR_ARG;
     }
-    // the finish work of the previous update riding along: its records are what the optimizer step waits for
-    FinishArgs F;
-    memset(&F, 0, sizeof(F));
-    if (fin) {
-        if (!adam || !adam->rec || !fin->sumsq_records || fin->sumsq_records != adam->partials || ((uintptr_t)fin->sumsq_records & 15))
-            return NAF_ERR_ARG;
-        const int rc = bb_finish_setup(*fin, F);
-        if (rc != NAF_OK) return rc;
-        if (F.n_blocks != adam->n_partials) return NAF_ERR_ARG;      // one record per finish workgroup, all of them awaited
-        // (what the finish work reads must not be what this launch writes)
-        if (fin->save_invstd == save_invstd || fin->wc == wc_out) return NAF_ERR_ARG;
-    }
     hipStream_t st = (hipStream_t)stream;
     const int n_main = (B / BB_ROWS) * (H / BB_COLS) * nets;
     const int n_adam = adam ? bb_adam_blocks(l1_4, n4, 2 * BB_THREADS) : 0;
-    const int grid = n_main + n_adam + F.n_blocks;
+    const int grid = n_main + n_adam;
 #define BB_L1(K4V, AD)                                                                                                       \
     bb_layer1_kernel<K4V, AD><<<grid, (AD) ? 2 * BB_THREADS : BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
                                                            running_mean, running_var, stat_net_stride, out, out_net_stride, ldo, \
-                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4, n_adam, F)
+                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4, n_adam)
     if (k4d == 6) { if (adam) BB_L1(6, true); else BB_L1(6, false); }
     else { if (adam) BB_L1(8, true); else BB_L1(8, false); }
 #undef BB_L1
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
-extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
-                                  const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
-                                  float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
-                                  int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
-                                  int nets, float momentum, float eps, const naf_adam_args_t* adam, void* stream) {
-    return naf_bb_layer1_adam_fin(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, running_mean, running_var,
-                                  stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, wc_out, B, H, nets, momentum,
-                                  eps, adam, nullptr, stream);
-}
-extern "C" int naf_bb_layer1(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
-                             const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
-                             float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
-                             int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
-                             int nets, float momentum, float eps, void* stream) {
-    return naf_bb_layer1_adam(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, running_mean, running_var,
-                              stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, wc_out, B, H, nets, momentum, eps,
-                              nullptr, stream);
-}
-
 extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
                                         int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
                                         int N, int K, int nets, const naf_adam_args_t* adam, void* stream) {
@@ -2091,8 +1373,7 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
     int64_t l1_4, n4;
     if (!bb_adam_setup(adam, ad, l1_4, n4)) return NAF_ERR_ARG;
     const int extra = adam ? bb_adam_blocks(0, l1_4, BB_THREADS) : 0;
-    // (experiment, off: one network per XCD half — 29.9k | 25.6k | 19.5k updates/s at B = 512 | 1024 | 2048 without, 30.0k | 25.2k | 19.6k with)
-    const int xcd_nets = NAF_ENV_INT("NAF_GEMM2_XCD_NETS", 0);
+    const int xcd_nets = 0;      // (one network per XCD half: measured no faster — 29.9k | 25.6k | 19.5k without, 30.0k | 25.2k | 19.6k with)
     const int gx = nets * (B / BB_ROWS);
     hipStream_t st = (hipStream_t)stream;
 #define BB_LS(KERNEL, GY)                                                                                                   \
@@ -2103,87 +1384,17 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
         else KERNEL<false><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride,  \
                                                           ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4, xcd_nets);             \
     } while (0)
-    const int max16 = NAF_ENV_INT("NAF_GEMM2_16_MAXB", 512);    // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
+    const int max16 = 512;       // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
     if (B <= max16) BB_LS(bb_linear_stats16_kernel, N / 16);
     else BB_LS(bb_linear_stats_kernel, N / BL_BN);
 #undef BB_LS
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
-extern "C" int naf_bb_linear_stats(const float* a, int64_t a_net_stride, int lda, const float* W, const float* bias,
-                                   int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
-                                   int N, int K, int nets, void* stream) {
-    return naf_bb_linear_stats_adam(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride, ldz, partials, B, N, K, nets,
-                                    nullptr, stream);
-}
-
-extern "C" int naf_bb_layer12(const float* x, int64_t x_net_stride, int ldx, int K, const float* W1, const float* bias1,
-                              const float* gamma1, const float* beta1, const float* W2, const float* bias2,
-                              int64_t param_net_stride, const float* mom, float* running_mean, float* running_var,
-                              int64_t stat_net_stride, float* a1_out, int64_t a1_net_stride, int lda1, float* save_mean,
-                              float* save_invstd, float* wc_out, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
-                              int H, int nets, float momentum, float eps, void* stream) {
-    if (!x || !W1 || !bias1 || !gamma1 || !beta1 || !W2 || !bias2 || !mom || !running_mean || !running_var || !a1_out ||
-        !save_mean || !save_invstd || !z || !partials || !bb_shape_ok(B, H) || H != 2 * BL_KC || nets <= 0)
-        return NAF_ERR_ARG;
-    if (K <= 0 || K > L12_KMAX || lda1 < H || ldz < H) return NAF_ERR_ARG;
-    const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
-    if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d || (x_net_stride & 3) != 0) return NAF_ERR_ARG;
-    // W1 chunks are read as flat float4 streams: base and the second chunk's offset (128 K floats) 16-byte aligned
-    if ((((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)mom) & 15) != 0 || (param_net_stride & 3) != 0 || ((BL_KC * K) & 3) != 0 ||
-        ((uintptr_t)partials & 7) != 0)
-        return NAF_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(nets * (B / BB_ROWS), H / BL_BN);
-#define BB_L12(K4V)                                                                                                        \
-    bb_layer12_kernel<K4V><<<grid, BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W1, bias1, gamma1, beta1, W2, bias2,     \
-                                                        param_net_stride, mom, running_mean, running_var, stat_net_stride, \
-                                                        a1_out, a1_net_stride, lda1, save_mean, save_invstd, wc_out, z,      \
-                                                        z_net_stride, ldz, (float2*)partials, B, momentum, eps)
-    if (k4d == 6) BB_L12(6);
-    else BB_L12(8);
-#undef BB_L12
-    NAF_CHECK_LAUNCH();
-    return NAF_OK;
-}
-
-extern "C" int naf_bb_bn_relu_heads_partial(const float* z, int64_t z_net_stride, int ldz, const float* gamma,
-                                            const float* beta, int64_t param_net_stride, const float* partials,
-                                            float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
-                                            int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd,
-                                            const float* Wh, int64_t wh_net_stride, int ldw, int NHP, int v_col,
-                                            float* heads_partial, int64_t slab_stride, float* vnext_partial, int B, int H,
-                                            float momentum, float eps, void* stream) {
-    if (!z || !gamma || !beta || !partials || !running_mean || !running_var || !out || !save_mean || !save_invstd || !Wh ||
-        !heads_partial || !vnext_partial || !bb_shape_ok(B, H))
-        return NAF_ERR_ARG;
-    if ((NHP != 16 && NHP != 32 && NHP != 48) || v_col < 0 || v_col >= NHP || ldw <= H || (ldw & 3) || ldz < H || (ldz & 3) ||
-        ldo < H || (ldo & 3))
-        return NAF_ERR_ARG;
-    if ((((uintptr_t)z | (uintptr_t)out | (uintptr_t)Wh | (uintptr_t)heads_partial) & 15) != 0 || (z_net_stride & 3) ||
-        (out_net_stride & 3) || (wh_net_stride & 3) || (slab_stride & 3) || slab_stride < (int64_t)B * NHP)
-        return NAF_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(B / BB_ROWS, H / BB_COLS, 2);
-#define BB_HP(NH4V)                                                                                                       \
-    bb_bn_relu_heads_partial_kernel<NH4V><<<grid, BB_THREADS, 0, st>>>(                                                   \
-        z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, running_mean, running_var,          \
-        stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, v_col, heads_partial,   \
-        slab_stride, vnext_partial, B, H, momentum, eps)
-    if (NHP == 16) BB_HP(4);
-    else if (NHP == 32) BB_HP(8);
-    else BB_HP(12);
-#undef BB_HP
-    NAF_CHECK_LAUNCH();
-    return NAF_OK;
-}
-
-// rows per workgroup = rows per block of partials_bw (the consumer, naf_bb_bn_bwd_stage2, is told B / rows blocks)
+// rows per workgroup = rows per block of partials_bw (its consumer, the bundle's BatchNorm-backward prologue, is told B / rows blocks)
 extern "C" int naf_bb_layer2_head_rows(int B) {
-    const int e = NAF_ENV_INT("NAF_HK_ROWS", 0);         // experiments: 16 or 32 whatever the batch size
-    if (e == 16 || e == 32) return e;
     (void)B;
-    return 16;               // (32 = FK_ROWS at B = 2048 until stage 2 folded 128 row blocks: 16.9k -> 17.7k updates/s with 16)
+    return 16;               // (32 rows per workgroup measured slower at every batch size of the chain: 16.9k -> 17.7k updates/s at B = 2048)
 }
 
 extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
@@ -2205,17 +1416,13 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     hipStream_t st = (hipStream_t)stream;
     const int rows = naf_bb_layer2_head_rows(B);
     const int blocks = B / rows;
-    const int xcd_rows = NAF_ENV_INT("NAF_L2_XCD_ROWS", 1);
+    const int xcd_rows = 1;      // row chunks dealt to the XCD whose dA1 blocks read them (+0.4 %)
 #define BB_FK_R(PM, NH4V, RW)                                                                                            \
     bb_layer2_head_kernel<PM, NH4V, RW><<<blocks, FK_THREADS, 0, st>>>(                                                  \
         z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, B / BB_ROWS, running_mean, running_var, \
         stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
         loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows)
-#define BB_FK(PM, NH4V)                   \
-    do {                                  \
-        if (rows == 16) BB_FK_R(PM, NH4V, 16); \
-        else BB_FK_R(PM, NH4V, 32);       \
-    } while (0)
+#define BB_FK(PM, NH4V) BB_FK_R(PM, NH4V, 16)
 #define BB_FK_NH(PM)                     \
     do {                                 \
         if (NHP == 16) BB_FK(PM, 4);     \
@@ -2227,64 +1434,6 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
 #undef BB_FK_NH
 #undef BB_FK
 #undef BB_FK_R
-    NAF_CHECK_LAUNCH();
-    return NAF_OK;
-}
-
-extern "C" int naf_bb_heads_bwd_stage1(const float* d_heads, int ldh, const float* Wh, int ldw, const float* z, int ldz,
-                                       const float* a2, int lda, const float* save_mean, const float* save_invstd,
-                                       float* dy_out, int ldd, float* partials, int B, int H, void* stream) {
-    if (!d_heads || !Wh || !z || !a2 || !save_mean || !save_invstd || !dy_out || !partials || !bb_shape_ok(B, H))
-        return NAF_ERR_ARG;
-    if ((ldh != 16 && ldh != 32 && ldh != 48) || ldw < H || (ldw & 3) || ldz < H || (ldz & 3) || lda < H || (lda & 3) ||
-        ldd < H || (ldd & 3))
-        return NAF_ERR_ARG;
-    if ((((uintptr_t)d_heads | (uintptr_t)Wh | (uintptr_t)z | (uintptr_t)a2 | (uintptr_t)dy_out) & 15) != 0) return NAF_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(B / BB_ROWS, H / BB_COLS);
-#define BB_S1(NH4V)                                                                                                    \
-    bb_heads_bwd_stage1_kernel<NH4V><<<grid, BB_THREADS, 0, st>>>(d_heads, ldh, Wh, ldw, z, ldz, a2, lda, save_mean,    \
-                                                                  save_invstd, dy_out, ldd, (float2*)partials, B, H)
-    if (ldh == 16) BB_S1(4);
-    else if (ldh == 32) BB_S1(8);
-    else BB_S1(12);
-#undef BB_S1
-    NAF_CHECK_LAUNCH();
-    return NAF_OK;
-}
-
-extern "C" int naf_bb_bn_bwd_stage2(float* dy, int ldd, const float* z, int ldz, const float* gamma, const float* save_mean,
-                                    const float* save_invstd, const float* partials, int n_partial_blocks, float* d_gamma,
-                                    float* d_beta, float* dz_col_partials, int B, int H, void* stream) {
-    if (!dy || !z || !gamma || !save_mean || !save_invstd || !partials || !d_gamma || !d_beta || !dz_col_partials ||
-        !bb_shape_ok(B, H) || n_partial_blocks < 1 || n_partial_blocks > 4 * BB_MAX_NB)
-        return NAF_ERR_ARG;
-    if (ldd < H || (ldd & 3) || ldz < H || (ldz & 3) || (((uintptr_t)dy | (uintptr_t)z) & 15) != 0) return NAF_ERR_ARG;
-    dim3 grid(B / BB_ROWS, H / BB_COLS);
-    bb_bn_bwd_stage2_kernel<<<grid, BB_THREADS, 0, (hipStream_t)stream>>>(dy, ldd, z, ldz, gamma, save_mean, save_invstd,
-                                                                          (const float2*)partials, n_partial_blocks, d_gamma,
-                                                                          d_beta, dz_col_partials, B, H);
-    NAF_CHECK_LAUNCH();
-    return NAF_OK;
-}
-
-extern "C" int naf_bb_layer1_bwd(const float* d_out, int ld_dout, const float* x, int ldx, int K, const float* W,
-                                 const float* bias, const float* out, int ldo, const float* save_mean,
-                                 const float* save_invstd, float* partials, float* p_slabs, int B, int H, void* stream) {
-    if (!d_out || !x || !W || !bias || !out || !save_mean || !save_invstd || !partials || !p_slabs || !bb_shape_ok(B, H))
-        return NAF_ERR_ARG;
-    if (K <= 0 || K > 4 * BB_MAX_K4 || ld_dout < H || (ld_dout & 3) || ldo < H || (ldo & 3)) return NAF_ERR_ARG;
-    const int k4 = (K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
-    if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d) return NAF_ERR_ARG;
-    if ((((uintptr_t)d_out | (uintptr_t)out | (uintptr_t)bias) & 15) != 0 || ((uintptr_t)partials & 7) != 0) return NAF_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(B / BB_ROWS, H / BB_COLS);
-    if (k4d == 6)
-        bb_layer1_bwd_kernel<6><<<grid, BB_THREADS, 0, st>>>(d_out, ld_dout, x, ldx, K, W, bias, out, ldo, save_mean, save_invstd,
-                                                             (float2*)partials, p_slabs, B, H);
-    else
-        bb_layer1_bwd_kernel<8><<<grid, BB_THREADS, 0, st>>>(d_out, ld_dout, x, ldx, K, W, bias, out, ldo, save_mean, save_invstd,
-                                                             (float2*)partials, p_slabs, B, H);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -2301,12 +1450,32 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
                                         float* d_W, float* d_gamma, float* d_beta, float* d_bias, float* d_bias2,
                                         const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
                                         int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, int* fold_flag, void* stream) {
-    const naf_bb_finish_args_t a = {p_slabs, K, partials1, nb1, dz2_col_partials, nb, mom, wc, gamma, save_invstd, d_W, d_gamma, d_beta,
-                                    d_bias, d_bias2, d_gamma2, d_beta2, sumsq_partials, B, H, segs, n_segs, fold_flag};
+    if (!p_slabs || !partials1 || (nb > 0 && !dz2_col_partials) || !mom || !wc || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
+        !d_bias || !d_bias2 || nb < 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
+        return NAF_ERR_ARG;
+    if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
+    if (n_segs < 0 || n_segs > 2 || (n_segs && !segs)) return NAF_ERR_ARG;
+    BbSlabs sl;
+    memset(&sl, 0, sizeof(sl));
+    sl.n_finish_blocks = (H + BF_COLS - 1) / BF_COLS;
+    sl.n_seg = n_segs;
+    int blocks = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const naf_bb_slab_seg_t& g = segs[i];
+        if (!g.src || !g.dst || g.n <= 0 || (g.n & 3) || g.n_slabs < 1 || g.n_slabs > BB_MAX_SLABS || g.stride < g.n || (g.stride & 3) ||
+            (((uintptr_t)g.src | (uintptr_t)g.dst) & 15) != 0)
+            return NAF_ERR_ARG;
+        sl.seg[i].src = g.src; sl.seg[i].dst = g.dst; sl.seg[i].stride = g.stride;
+        sl.seg[i].n = g.n; sl.seg[i].n_slabs = g.n_slabs; sl.seg[i].block0 = blocks;
+        blocks += (g.n + BB_THREADS * 4 - 1) / (BB_THREADS * 4);
+    }
     FinishArgs F;
-    const int rc = bb_finish_setup(a, F);
-    if (rc != NAF_OK) return rc;
-    F.step_dev = step_dev;
+    memset(&F, 0, sizeof(F));
+    F.p_slabs = p_slabs; F.KP = naf_bb_layer1_bwd_kp(K); F.K = K; F.partials1 = (const float2*)partials1; F.NB1 = nb1;
+    F.dz2_col_partials = dz2_col_partials; F.NB = nb; F.mom = mom; F.wc = wc; F.gamma = gamma; F.save_invstd = save_invstd;
+    F.d_W = d_W; F.d_gamma = d_gamma; F.d_beta = d_beta; F.d_bias = d_bias; F.d_bias2 = d_bias2; F.d_gamma2 = d_gamma2;
+    F.d_beta2 = d_beta2; F.sumsq_partials = sumsq_partials; F.step_dev = step_dev; F.B = B; F.H = H; F.slabs = sl;
+    F.fold_flag = fold_flag; F.n_blocks = sl.n_finish_blocks + blocks;
     bb_layer1_bwd_finish_kernel<<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
     NAF_CHECK_LAUNCH();
     return NAF_OK;

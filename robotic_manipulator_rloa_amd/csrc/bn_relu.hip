@@ -158,16 +158,9 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_eval_kernel(const float* __re
     }
 }
 
-// Tile shapes to choose from (dev knob naf_debug_set(0, id); the default was picked with benchmarks/kernel_probe.py)
-static int g_bn_tile = -1;  // -1 = by batch size: 8 columns x 64 row phases up to B = 512 (fwd 3.3 us / bwd 3.7 us per launch
-                            // at B=256; 32x32: 4.5 / 5.6), 8 x 128 beyond (B=2048: 8.3 / 10.1 us vs 10.7 / 15.4 for 8 x 64)
-extern int g_gather_nt;   // replay.hip
-extern "C" int naf_debug_set(int key, int value) {
-    if (key == 0) g_bn_tile = value;
-    if (key == 1) g_gather_nt = value;
-    return NAF_OK;
-}
-
+// Tile: 8 feature columns x 64 row phases up to B = 512 (fwd 3.3 us / bwd 3.7 us per launch at B = 256; a 32 x 32 tile: 4.5 /
+// 5.6 — picked with benchmarks/kernel_probe.py among twelve shapes), 8 x 128 beyond (B = 2048: 8.3 / 10.1 us vs 10.7 / 15.4 for
+// 8 x 64). At most 16 rows per thread (B <= 2048): more rows per thread spill to scratch.
 #define BN_LAUNCH_RPT(KERNEL, TXv, TYv, ...)                                                               \
     do {                                                                                                   \
         dim3 grid((H + TXv - 1) / TXv, nets_), block(TXv, TYv);                                            \
@@ -176,30 +169,16 @@ extern "C" int naf_debug_set(int key, int value) {
         else if (rpt <= 4) KERNEL<4, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                       \
         else if (rpt <= 8) KERNEL<8, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                       \
         else if (rpt <= 16) KERNEL<16, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                     \
-        else if (rpt <= 32) KERNEL<32, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                     \
-        else if (rpt <= 64) KERNEL<64, TXv, TYv><<<grid, block, 0, st>>>(__VA_ARGS__);                     \
         else return NAF_ERR_ARG;                                                                           \
     } while (0)
 
 #define BN_DISPATCH(KERNEL, ...)                                                                           \
     do {                                                                                                   \
-        switch (g_bn_tile >= 0 ? g_bn_tile : (B <= 512 ? 9 : 10)) {                                        \
-            case 1: BN_LAUNCH_RPT(KERNEL, 32, 16, __VA_ARGS__); break;                                     \
-            case 2: BN_LAUNCH_RPT(KERNEL, 32, 8, __VA_ARGS__); break;                                      \
-            case 3: BN_LAUNCH_RPT(KERNEL, 16, 16, __VA_ARGS__); break;                                     \
-            case 4: BN_LAUNCH_RPT(KERNEL, 16, 32, __VA_ARGS__); break;                                     \
-            case 5: BN_LAUNCH_RPT(KERNEL, 64, 8, __VA_ARGS__); break;                                      \
-            case 6: BN_LAUNCH_RPT(KERNEL, 64, 16, __VA_ARGS__); break;                                     \
-            case 7: BN_LAUNCH_RPT(KERNEL, 16, 64, __VA_ARGS__); break;                                     \
-            case 8: BN_LAUNCH_RPT(KERNEL, 8, 32, __VA_ARGS__); break;                                      \
-            case 9: BN_LAUNCH_RPT(KERNEL, 8, 64, __VA_ARGS__); break;                                      \
-            case 10: BN_LAUNCH_RPT(KERNEL, 8, 128, __VA_ARGS__); break;                                    \
-            case 11: BN_LAUNCH_RPT(KERNEL, 4, 64, __VA_ARGS__); break;                                     \
-            default: BN_LAUNCH_RPT(KERNEL, 32, 32, __VA_ARGS__); break;                                    \
-        }                                                                                                  \
+        if (B <= 512) BN_LAUNCH_RPT(KERNEL, 8, 64, __VA_ARGS__);                                           \
+        else BN_LAUNCH_RPT(KERNEL, 8, 128, __VA_ARGS__);                                                   \
     } while (0)
 
-#define BN_MAX_B (64 * 128)  // 128 row phases x up to 64 rows per thread
+#define BN_MAX_B (16 * 128)  // 128 row phases x up to 16 rows per thread
 
 extern "C" int naf_bn_relu_fwd_train(const float* g, int64_t g_net_stride, int ldg, const float* bias,
                                      const float* gamma, const float* beta, int64_t param_net_stride,

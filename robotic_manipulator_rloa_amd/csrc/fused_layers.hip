@@ -5,8 +5,7 @@
 //   naf_linear_bn_relu_fwd_train : X[B,K<=32] @ W^T + b -> BatchNorm(train) -> ReLU          (replaces bmm + bn_relu_fwd)
 //   naf_bn_relu_bwd_wgrad        : ReLU/BN backward of that layer + dW = dZ^T X, no dZ round trip (replaces bn_bwd + mm)
 //   naf_heads_bwd_bn_relu_bwd    : dA = dHeads @ Wh (K = 32..48) -> ReLU/BN backward -> dZ     (replaces mm + bn_bwd)
-//   naf_heads_gemm_head_fwd_bwd_mse : heads = A2 @ Wh^T on f32 MFMA tiles written to LDS, V'(s') GEMV for the target
-//                                  net, then the whole NAF head fwd + TD/MSE + bwd               (replaces bmm + head)
+//   naf_bn_relu_fwd_heads_partial: layer-2 BatchNorm + ReLU and this tile's K-slice of the heads GEMM (replaces bn + bmm)
 // Reference lines replaced: naf_neural_network.py:76,81-115 (forward), their autograd, naf_algorithm.py:199-208.
 // Tile ownership as in bn_relu.hip: a workgroup owns 32 feature columns x ALL batch rows (32 x 32 threads).
 #include <string.h>
@@ -600,113 +599,6 @@ __global__ __launch_bounds__(S3_THREADS) void bn_relu_fwd_heads_partial_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// F3: heads GEMM on f32 MFMA + NAF head. Workgroup = 256 threads = 4 waves = 32 samples.
-// Each wave produces 16(samples) x 16(outputs) tiles with v_mfma_f32_16x16x4_f32 straight from global memory:
-// lane (r = l & 15, g = l >> 4) loads ONE float4 of row r at k = 16 j + 4 g for A and for B, and feeds components
-// x,y,z,w to four MFMAs — over the four lane groups the 16 k's of macro-step j are each used once (the order
-// of summation over k is a permutation of ascending, identical for A and B). Two accumulators hide the 40-cycle
-// dependent-accumulate latency. Tiles land in the LDS heads rows the head math reads.
-// ------------------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define KSTEPS 17   // K = 272 = layer_size 256 + 16: the framework's fixed hidden width (rl_framework.py:452)
-
-template <int PMODE>
-__global__ __launch_bounds__(HEAD_THREADS) void heads_gemm_head_kernel(
-    const float* __restrict__ a2, int64_t a2_net_stride, int lda, int K, const float* __restrict__ Wh,
-    int64_t wh_net_stride, int ldw, int NHP, const float* __restrict__ u, int ldu, const float* __restrict__ r, int ldr,
-    float gamma, float* __restrict__ heads_out, float* __restrict__ q_out, float* __restrict__ d_heads,
-    float* __restrict__ loss_partials, int B, int A) {
-    __shared__ __attribute__((aligned(16))) float sh_in[HEAD_SPB * HEAD_MAX_LDH];
-    __shared__ __attribute__((aligned(16))) float sh_out[HEAD_SPB * HEAD_MAX_LDH];
-    __shared__ float sh_L[PMODE == NAF_P_MATMUL ? HEAD_SPB * 8 * LT_STRIDE : 1];
-    __shared__ float sh_red[HEAD_THREADS / 64];
-    __shared__ float sh_vnext[HEAD_SPB];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int64_t s0 = (int64_t)blockIdx.x * HEAD_SPB;
-    const int ns = (B - s0) < HEAD_SPB ? (int)(B - s0) : HEAD_SPB;
-    const int T = A * (A + 1) / 2;
-
-    for (int k = tid; k < HEAD_SPB * NHP / 4; k += HEAD_THREADS) ((float4*)sh_out)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // per-sample scalars: requested before anything else
-    const int hs_loc = tid >> 3, hi = tid & 7;
-    const bool hlive = hs_loc < ns;
-    const float u_val = (hlive && hi < A) ? u[(s0 + hs_loc) * ldu + hi] : 0.f;
-    const float r_val = (hlive && hi == 0) ? r[(s0 + hs_loc) * ldr] : 0.f;
-
-    // ---- heads = A2[main] @ Wh[main]^T : 2 x (NHP/16) tiles of 16 x 16 over the 4 waves -----------------------
-    const int tiles_n = NHP >> 4;
-    const int rr = lane & 15, gg = lane >> 4;
-    for (int t = wave; t < 2 * tiles_n; t += 4) {
-        const int tm = t / tiles_n, tn = t - tm * tiles_n;
-        int srow = tm * 16 + rr;                       // sample row (within the workgroup) this lane loads for A
-        if (srow >= ns) srow = ns - 1;                 // clamp: rows beyond the batch are computed but never used
-        const float* ap = a2 + (s0 + srow) * (int64_t)lda + 4 * gg;
-        const float* bp = Wh + (int64_t)(tn * 16 + rr) * ldw + 4 * gg;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (K == 16 * KSTEPS) {
-            // one wave per SIMD and nothing else resident: spend registers, not latency — issue every operand load of
-            // the tile (2 x KSTEPS float4 per lane) before the first MFMA
-            float4 av[KSTEPS], bv[KSTEPS];
-#pragma unroll
-            for (int j = 0; j < KSTEPS; ++j) {
-                av[j] = *(const float4*)(ap + 16 * j);
-                bv[j] = *(const float4*)(bp + 16 * j);
-            }
-#pragma unroll
-            for (int j = 0; j < KSTEPS; ++j) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
-            }
-        } else {
-            for (int k0 = 0; k0 < K; k0 += 16) {
-                const float4 av = *(const float4*)(ap + k0);
-                const float4 bv = *(const float4*)(bp + k0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
-            }
-        }
-        // C/D map: col = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int srow_o = tm * 16 + 4 * gg + e;
-            sh_in[srow_o * NHP + tn * 16 + rr] = acc0[e] + acc1[e];
-        }
-    }
-    // ---- V'(s') of the target net: one 8-lane group per sample, k strided by 8 float4 --------------------------
-    {
-        const int s_loc = tid >> 3, i = tid & 7;
-        const float* ap = a2 + a2_net_stride + (s0 + (s_loc < ns ? s_loc : ns - 1)) * (int64_t)lda;
-        const float* wp = Wh + wh_net_stride + (int64_t)(A + T) * ldw;
-        float p = 0.f;
-#pragma unroll 9
-        for (int k0 = 4 * i; k0 < K; k0 += 32) {
-            const float4 av = *(const float4*)(ap + k0);
-            const float4 wv = *(const float4*)(wp + k0);
-            p += av.x * wv.x + av.y * wv.y + av.z * wv.z + av.w * wv.w;
-        }
-        p = group8_sum(p);
-        if (i == 0) sh_vnext[s_loc] = p;
-    }
-    __syncthreads();
-    if (heads_out) {
-        for (int k = tid; k < ns * NHP / 4; k += HEAD_THREADS) ((float4*)(heads_out + s0 * NHP))[k] = ((const float4*)sh_in)[k];
-    }
-    naf_head_body<PMODE, 2>(sh_in, sh_out, sh_L, sh_red, NHP, u_val, r_val, sh_vnext[hs_loc], 0.f, gamma, q_out, nullptr,
-                            loss_partials, B, A, s0, ns);
-    {
-        float4* dst = (float4*)(d_heads + s0 * NHP);
-        const int n4 = ns * NHP / 4;
-        for (int k = tid; k < n4; k += HEAD_THREADS) dst[k] = ((const float4*)sh_out)[k];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 #define RPT_DISPATCH(KERNEL, KK, ...)                                                      \
@@ -715,9 +607,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void heads_gemm_head_kernel(
         if (rpt <= 1) KERNEL<1, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                  \
         else if (rpt <= 2) KERNEL<2, KK><<<grid, block, 0, st>>>(__VA_ARGS__);             \
         else if (rpt <= 4) KERNEL<4, KK><<<grid, block, 0, st>>>(__VA_ARGS__);             \
-        else if (rpt <= 8) KERNEL<8, KK><<<grid, block, 0, st>>>(__VA_ARGS__);             \
-        else if (rpt <= 16) KERNEL<16, KK><<<grid, block, 0, st>>>(__VA_ARGS__);           \
-        else KERNEL<32, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                          \
+        else KERNEL<8, KK><<<grid, block, 0, st>>>(__VA_ARGS__);                           \
     } while (0)
 
 #define K4_DISPATCH(KERNEL, k4, ...)                                                        \
@@ -726,7 +616,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void heads_gemm_head_kernel(
         else RPT_DISPATCH(KERNEL, 8, __VA_ARGS__);                                          \
     } while (0)
 
-#define FUSED_MAX_B (FT_TY * 32)
+// B <= 512: ceil(B/64) <= 8 rows per thread stay in registers (16 / 32 rows per thread spilled 0.8 - 5.6 KB of scratch per
+// thread and lost to the unfused chain: larger batches take the row-split chain of big_batch.hip)
+#define FUSED_MAX_B (FT_TY * 8)
 
 extern "C" int naf_linear_bn_relu_fwd_train(const float* x, int64_t x_net_stride, int ldx, int K, const float* W,
                                             const float* bias, const float* gamma, const float* beta,
@@ -761,6 +653,9 @@ extern "C" int naf_bn_relu_bwd_wgrad_push(const float* d_out, int ld_dout, const
     if (B <= 0 || B > FUSED_MAX_B || H <= 0 || K <= 0 || K > 4 * MAX_K4 || ld_dout < H || ldo < H) return NAF_ERR_ARG;
     const int k4 = (K + 3) / 4;
     const int k4d = k4 <= 6 ? 6 : 8;
+    // (8 rows per thread x 8 float4 of each row do not fit the register file: state sizes 25 .. 32 take this kernel up to
+    //  B = 256; the host keeps the unfused layer 1 beyond — Learner: "l1" needs S <= 24 or B <= 256)
+    if (k4d == 8 && B > 4 * FT_TY) return NAF_ERR_ARG;
     if (((uintptr_t)x & 15) != 0 || (ldx & 3) != 0 || ldx < 4 * k4d) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int n_tiles = (H + FT_TX - 1) / FT_TX;
@@ -779,8 +674,16 @@ extern "C" int naf_bn_relu_bwd_wgrad_push(const float* d_out, int ld_dout, const
         extra = (int)((push_hi - push_lo + (size_t)FT_THREADS * 4 - 1) / ((size_t)FT_THREADS * 4));
     }
     dim3 grid(n_tiles + extra, 1), block(FT_TX, FT_TY);
-    K4_DISPATCH(bn_relu_bwd_wgrad_kernel, k4, d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, save_invstd,
-                d_gamma, d_beta, d_bias, d_W, sumsq_partials, step_dev, B, H, p);
+#define WG_ARGS d_out, ld_dout, x, ldx, K, W, bias, out, ldo, gamma, save_mean, save_invstd, d_gamma, d_beta, d_bias, d_W, sumsq_partials, step_dev, B, H, p
+    if (k4d == 6) {
+        RPT_DISPATCH(bn_relu_bwd_wgrad_kernel, 6, WG_ARGS);
+    } else {                                                  // (B <= 256, checked above: at most 4 rows per thread)
+        const int rpt = (B + FT_TY - 1) / FT_TY;
+        if (rpt <= 1) bn_relu_bwd_wgrad_kernel<1, 8><<<grid, block, 0, st>>>(WG_ARGS);
+        else if (rpt <= 2) bn_relu_bwd_wgrad_kernel<2, 8><<<grid, block, 0, st>>>(WG_ARGS);
+        else bn_relu_bwd_wgrad_kernel<4, 8><<<grid, block, 0, st>>>(WG_ARGS);
+    }
+#undef WG_ARGS
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -858,30 +761,3 @@ extern "C" int naf_bn_relu_fwd_heads_partial(const float* g, int64_t g_net_strid
 }
 
 extern "C" int naf_fused_tile_cols(void) { return FT_TX; }
-
-extern "C" int naf_heads_gemm_head_fwd_bwd_mse(const float* a2, int64_t a2_net_stride, int lda, int K, const float* Wh,
-                                               int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu,
-                                               const float* r, int ldr, float gamma, float* heads_out, float* q_out,
-                                               float* d_heads, float* loss_partials, int B, int A, int p_mode,
-                                               void* stream) {
-    if (!a2 || !Wh || !u || !r || !d_heads || B <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
-    if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
-    if ((NHP != 16 && NHP != 32 && NHP != 48) || NHP < A + A * (A + 1) / 2 + 1) return NAF_ERR_ARG;
-    if (K <= 0 || (K & 15) != 0 || lda < K || ldw < K || (lda & 3) != 0 || (ldw & 3) != 0 || ldu < A || ldr < 1)
-        return NAF_ERR_ARG;
-    if ((((uintptr_t)a2 | (uintptr_t)Wh | (uintptr_t)d_heads | (uintptr_t)heads_out) & 15) != 0 ||
-        (a2_net_stride & 3) != 0 || (wh_net_stride & 3) != 0)
-        return NAF_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    int blocks = (B + HEAD_SPB - 1) / HEAD_SPB;
-    if (p_mode == NAF_P_HADAMARD)
-        heads_gemm_head_kernel<NAF_P_HADAMARD><<<blocks, HEAD_THREADS, 0, st>>>(a2, a2_net_stride, lda, K, Wh, wh_net_stride,
-                                                                               ldw, NHP, u, ldu, r, ldr, gamma, heads_out,
-                                                                               q_out, d_heads, loss_partials, B, A);
-    else
-        heads_gemm_head_kernel<NAF_P_MATMUL><<<blocks, HEAD_THREADS, 0, st>>>(a2, a2_net_stride, lda, K, Wh, wh_net_stride,
-                                                                             ldw, NHP, u, ldu, r, ldr, gamma, heads_out, q_out,
-                                                                             d_heads, loss_partials, B, A);
-    NAF_CHECK_LAUNCH();
-    return NAF_OK;
-}

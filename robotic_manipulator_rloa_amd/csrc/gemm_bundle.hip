@@ -260,59 +260,12 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
 
 // Prologue of the products that read dZ2 (include/naf_hip.h, naf_gemm_bn2bwd_t): the second stage of layer 2's BatchNorm
 // backward folded into the staging of their A panel, so that stage's launch (2.8 us + a 1.3 us boundary at B = 256) and the
-// dZ2 round trip through memory disappear. The per-column constants go to `cst` (4 x 256 floats: the K-halves buffer, free
-// until the MFMAs are over):  dz = k1 dy - k1 c1 - (z - mean) (invstd k1 c2),  k1 = gamma invstd, c1 = sum dy / B, c2 = sum dy xhat / B
+// dZ2 round trip through memory disappear. The per-column constants sit in `cst` (4 x 256 floats of LDS: the K-halves buffer,
+// free until the MFMAs are over):  dz = k1 dy - k1 c1 - (z - mean) (invstd k1 c2),  k1 = gamma invstd, c1 = sum dy / B, c2 = sum dy xhat / B
 //   cst[0][c] = mean, [1] = k1, [2] = k1 c1, [3] = invstd k1 c2
-// The npb <= 32 block sums are dealt over the whole workgroup: thread = (column pair, part); a part takes a contiguous run of
-// blocks as 16-byte loads (two columns' float2 at once) — up to eight loads per thread for a k-contiguous A (256 columns, 4 parts), one
-// for a k-major A (32 columns, 32 parts) — and the parts meet in `scratch` (the A panel's LDS, not yet written) in part order.
-// (Every thread walking all 16 blocks of one column cost 2.2 us per dA1 block.) Ends with the constants written; the caller
-// puts the barrier behind it.
-template <bool AK>
-__device__ static inline void gemm_bn2bwd_constants(const GemmDesc& D, int m0, int bn, int ks, int tid, float* cst, float* scratch) {
-    const naf_gemm_bn2bwd_t& P = D.pro;
-    constexpr int NCOL = AK ? 32 : 256, NPAIR = NCOL / 2, PARTS = GB_THREADS / NPAIR, QMAX = AK ? 1 : 8;
-    static_assert(PARTS * QMAX >= 32, "npb <= 32");
-    const int col0 = AK ? m0 : 0;
-    const int pair = tid % NPAIR, part = tid / NPAIR;
-    const int npb = P.npb, Q = (npb + PARTS - 1) / PARTS, rb0 = part * Q;
-    const __amdgpu_buffer_rsrc_t pb = naf_buf(P.partials + 2 * col0);
-    f32x4 v[QMAX];
-#pragma unroll
-    for (int i = 0; i < QMAX; ++i) {
-        const int rb = rb0 + i;
-        v[i] = naf_buf_f4(pb, 16u * (unsigned)pair, (unsigned)((i < Q && rb < npb) ? rb : 0) * (unsigned)P.H * 8u);
-    }
-    const int c = tid & (NCOL - 1);
-    const float gm = P.gamma[col0 + c], mean = P.save_mean[col0 + c], invstd = P.save_invstd[col0 + c];
-    f32x4 sm = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < QMAX; ++i)
-        if (i < Q && rb0 + i < npb) sm += v[i];
-    ((f32x4*)scratch)[part * NPAIR + pair] = sm;            // [part][column] float2
-    __syncthreads();
-    if (tid < NCOL) {
-        const float2* sp = (const float2*)scratch;
-        float sdy = 0.f, sdx = 0.f;
-#pragma unroll
-        for (int q = 0; q < PARTS; ++q) {
-            sdy += sp[q * NCOL + c].x;                        // (parts past the last block hold zeros)
-            sdx += sp[q * NCOL + c].y;
-        }
-        const float k1 = gm * invstd, invB = 1.0f / (float)P.B;
-        cst[c] = mean;
-        cst[256 + c] = k1;
-        cst[512 + c] = k1 * (sdy * invB);
-        cst[768 + c] = invstd * (k1 * (sdx * invB));
-        if (AK && bn == 0 && ks == 0) {                             // d_gamma = sum dy*xhat, d_beta = sum dy
-            P.d_gamma[col0 + c] = sdx;
-            P.d_beta[col0 + c] = sdy;
-        }
-    }
-}
-// ---- the block sums folded ONCE per launch (pro.cst != NULL) ------------------------------------------------------------------
-// With every block folding for itself a dA1 block reads npb x 256 float2 — 32 KB at 16 row blocks, 128 KB at 64, on top of the
-// 64 KB of its panels — which is why the chain kept the stage-2 launch (3.0 us + a launch boundary) from B = 1024. Instead the
+// ---- the block sums are folded ONCE per launch ----------------------------------------------------------------------------------
+// With every block folding for itself (round 2's first form) a dA1 block reads npb x 256 float2 — 32 KB at 16 row blocks, 128 KB at
+// 64, on top of the 64 KB of its panels. Instead the
 // first H / 32 workgroups of the launch fold 32 columns each (up to 64 row blocks: the k-major fold above with two blocks per
 // part) and publish ONE 16-byte record per column to `cst`: (k1 c1, invstd k1 c2, epoch, 0) — the two constants that depend on
 // the fold plus the number of this launch (*epoch, a device word that naf_bb_layer1_bwd_finish advances behind every bundle
@@ -321,9 +274,12 @@ __device__ static inline void gemm_bn2bwd_constants(const GemmDesc& D, int m0, i
 // granule (one sc1 store instruction by one lane; sc1 loads observe it whole), so no flag, no barrier and no atomic sit
 // between the fold and its readers (a counter + flag protocol cost 2.2 us in front of a block's first MFMA, this one ~1).
 // A dependency INSIDE the launch, so: the folding workgroups are the launch's first (dispatched before any block that waits
-// for them; nothing they do depends on another workgroup), and the wait is bounded by wall clock (0.5 ms): a thread that gives
-// up poisons its constants with NaN — the update then fails loudly (params_finite, the parity tests) instead of hanging the
-// GPU. Records and polls are sc1 only (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire).
+// for them; nothing they do depends on another workgroup). The wait is bounded by wall clock as a HANG GUARD only (50 ms: far
+// beyond any preemption or time-slicing of the queue — several processes may share the GPU): a thread that gives up poisons its
+// constants with NaN AND bumps `errors`, a pinned host word the training loop reads before every chunk of updates
+// (Learner.raise_on_device_error: NafHipError), so an expired wait can never pass as a quiet NaN in the weights.
+// Records and polls are sc1 only (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire).
+#define GB_POLL_TICKS 5000000LL          // 50 ms at 100 MHz
 #define GB_FOLD_COLS 32
 __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P, int f, int tid, float* scratch) {
     constexpr int NPAIR = GB_FOLD_COLS / 2, PARTS = GB_THREADS / NPAIR, QMAX = 4;
@@ -364,7 +320,7 @@ __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P,
 }
 // the waiting side: constants of the block's columns -> cst (LDS, [4][256] as gemm_bn2bwd_constants leaves them). The caller
 // puts the barrier behind it.
-__device__ __forceinline__ static f32x4 gemm_bn2bwd_poll_record(__amdgpu_buffer_rsrc_t rb, int col, int epoch) {
+__device__ __forceinline__ static f32x4 gemm_bn2bwd_poll_record(__amdgpu_buffer_rsrc_t rb, int col, int epoch, unsigned long long* errors) {
     // (the tag through a scalar copy: __builtin_bit_cast applied to the vector ELEMENT c[2] reads element 0 — clang 22 takes
     //  the address of the vector for the element reference; seen in the IR, and as a wait that never ended)
     f32x4 c = naf_buf_f4_sc1(rb, 16u * (unsigned)col, 0);
@@ -377,8 +333,9 @@ __device__ __forceinline__ static f32x4 gemm_bn2bwd_poll_record(__amdgpu_buffer_
             c = naf_buf_f4_sc1(rb, 16u * (unsigned)col, 0);   // not volatile: hoisted out of the loop, the wait never ended)
             tagf = c[2];
             if (__builtin_bit_cast(int, tagf) == epoch) break;
-            if (wall_clock64() - t0 > 50000) {                     // 0.5 ms at 100 MHz: poison, do not hang
+            if (wall_clock64() - t0 > GB_POLL_TICKS) {             // hang guard: poison AND tell the host
                 c[0] = c[1] = __builtin_nanf("");
+                if (errors) __hip_atomic_fetch_add(errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -398,15 +355,17 @@ __device__ static inline void gemm_bn2bwd_wait_constants(const naf_gemm_bn2bwd_t
         const int col = col0 + tid;
         const int epoch = *P.epoch;
         const float mean = P.save_mean[col], k1 = P.gamma[col] * P.save_invstd[col];
-        const f32x4 c = gemm_bn2bwd_poll_record(naf_buf(P.cst), col, epoch);
+        const f32x4 c = gemm_bn2bwd_poll_record(naf_buf(P.cst), col, epoch, (unsigned long long*)P.errors);
         cst[tid] = mean;
         cst[256 + tid] = k1;
         cst[512 + tid] = c[0];
         cst[768 + tid] = c[1];
     }
 }
-// dy -> dz on a staged A panel (whole chunks only). The thread's float4 i covers four consecutive COLUMNS of the operand:
-//   k-contiguous A: row wave + 8 i, columns k0 + 4 lane .. +3;  k-major A: k = (tid >> 3) + 64 i, columns 4 (tid & 7) .. +3 of the block
+// dy -> dz on a staged A panel. The thread's float4 i covers four consecutive COLUMNS of the operand:
+//   k-contiguous A (K = H = 256: always whole chunks): row wave + 8 i, columns k0 + 4 lane .. +3;
+//   k-major A: k = (tid >> 3) + 64 i, columns 4 (tid & 7) .. +3 of the block — the same columns for every i, in whole chunks (buffer
+//   loads) and in the tail chunk of a K range that is not a multiple of 256 (load_panel<true, false>: e = tid + 512 i, column quad e & 7)
 template <bool AK>
 __device__ __forceinline__ static void gemm_bn2bwd_apply(float4 (&va)[GB_PT], const float4 (&vz)[GB_PT], const float* cst, int tid, int k0) {
     const int ci = AK ? 4 * (tid & 7) : k0 + 4 * (tid & 63);
@@ -468,7 +427,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, !kh, wm, wn, r, g, epi_regs);
     const int kper = D.K / D.k_split, k_lo = ks * kper, k_hi = k_lo + kper;
     const PanelSrc pa = panel_src<AK>(D.A, D.lda, m0, D.M, D.K, tid), pb = panel_src<BK>(D.B, D.ldb, n0, D.N, D.K, tid);
-    const bool pro = D.pro.z != nullptr;                  // (uniform; the host admits it with whole 256-k chunks only)
+    const bool pro = D.pro.z != nullptr;                  // (uniform)
     const PanelSrc pz = panel_src<AK>(pro ? D.pro.z : D.A, D.lda, m0, D.M, D.K, tid);
     float4 va[GB_PT], vb[GB_PT], vz[GB_PT];
     {
@@ -479,12 +438,12 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
             load_panel_buf<BK>(vb, pb, n0, k_lo, wave);
         } else {
             load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k_lo, kc0, tid);
+            if (pro) load_panel<AK, false>(vz, D.pro.z, D.lda, m0, D.M, k_lo, kc0, tid);
             load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
         }
     }
     if (pro) {                                            // the column constants, under the panel loads' latency
-        if (D.pro.cst) gemm_bn2bwd_wait_constants<AK>(D.pro, m0, tid, sC);
-        else gemm_bn2bwd_constants<AK>(D, m0, bn, ks, tid, sC, sA);
+        gemm_bn2bwd_wait_constants<AK>(D.pro, m0, tid, sC);
         __syncthreads();
     }
     for (int k0 = k_lo; k0 < k_hi; k0 += GB_KC) {
@@ -507,6 +466,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
                 load_panel_buf<BK>(vb, pb, n0, k1, wave);
             } else {
                 load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k1, kn, tid);
+                if (pro) load_panel<AK, false>(vz, D.pro.z, D.lda, m0, D.M, k1, kn, tid);
                 load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k1, kn, tid);
             }
         }
@@ -623,7 +583,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     GemmBundle b;
     b.n = n;
     b.n_fold = b.fold_desc = 0;
-    b.rowmap = NAF_ENV_INT("NAF_GB_ROWMAP", 2);      // 0: block t is block t; 1: dA1 by row; 2: and dW2's K ranges by XCD group
+    b.rowmap = 2;                 // dA1 blocks by block row on the XCDs, dW2's K ranges by XCD group (the kernel's comment)
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         const naf_gemm_desc_t& s = descs[i];
@@ -647,11 +607,11 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (s.pro) {
             const naf_gemm_bn2bwd_t& q = *s.pro;
             if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 ||
-                q.npb > (q.cst ? 128 : 32) || (q.cst && (!q.epoch || ((uintptr_t)q.cst & 15))) || q.B <= 0 || q.H != 256 || ((s.K / ksn) % GB_KC) != 0 || (s.M & 31) || (s.N & 31) ||
+                q.npb > 128 || !q.cst || !q.epoch || ((uintptr_t)q.cst & 15) || q.B <= 0 || q.H != 256 || (s.M & 31) || (s.N & 31) ||
                 (s.a_kmajor ? s.M != q.H : s.K != q.H) || ((uintptr_t)q.z & 15) || ((uintptr_t)q.partials & 7))
                 return NAF_ERR_ARG;      // (the A operand's columns are the H features: its M when k-major, its K otherwise)
             d.pro = q;
-            if (q.cst && !b.n_fold) {
+            if (!b.n_fold) {
                 b.n_fold = q.H / GB_FOLD_COLS;
                 b.fold_desc = i;
             }

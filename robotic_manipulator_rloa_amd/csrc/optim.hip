@@ -71,7 +71,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_polyak_kernel(const AdamArgs
         size_t e = n4 * 4 + threadIdx.x;
         float th = A.theta[e], mm = A.m[e], vv = A.v[e];
         float tg = A.target ? A.target[e] : 0.f;
-        adam_one(th, A.g[e], mm, vv, A.target ? &tg : nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(th, A.g[e], mm, vv, tg, A.target != nullptr, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
         A.theta[e] = th; A.m[e] = mm; A.v[e] = vv;
         if (A.target) A.target[e] = tg;
     }
@@ -91,7 +91,7 @@ extern "C" int naf_adam_polyak_fused(float* theta, const float* g, float* m, flo
     A.theta = theta; A.g = g; A.m = m; A.v = v; A.target = theta_target; A.partials = partials; A.n_partials = n_partials;
     A.max_norm = max_norm; A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.tau = tau; A.one_minus_tau = one_minus_tau;
     A.step_dev = step_dev; A.inv_world = inv_world;
-    A.rec = 0; A.step_bias = 0; A.bc = nullptr;
+    A.bc = nullptr;
     adam_polyak_kernel<<<blocks, OPT_THREADS, 0, (hipStream_t)stream>>>(A, n);
     NAF_CHECK_LAUNCH();
     return NAF_OK;

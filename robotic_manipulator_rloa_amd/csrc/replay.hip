@@ -295,7 +295,7 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
     int bits = 1;
     while ((1 << bits) < 2 * B) ++bits;
     size_t lds_ints = (size_t)B + 2 * ((size_t)1 << bits);
-    if (lds_ints * sizeof(int) > 64 * 1024 || NAF_ENV_INT("NAF_SAMPLE_SCAN", 0)) {
+    if (lds_ints * sizeof(int) > 64 * 1024) {
         bits = 0;
         lds_ints = 0;
     }
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void replay_gather_rows_kernel(const float4* _
         const unsigned r = jj / w4;
         col[k] = (int)(jj - r * w4);
         int64_t i = (int64_t)idx[r];
-        if (ok[k] && (i < 0 || (uint64_t)i >= size)) {
-            if (col[k] == 0) atomicAdd((unsigned long long*)&meta[META_BAD_IDX], 1ull);
+        if (i < 0 || (uint64_t)i >= size) {       // EVERY lane: the tail lanes load row idx[0] unconditionally below
+            if (ok[k] && col[k] == 0) atomicAdd((unsigned long long*)&meta[META_BAD_IDX], 1ull);
             i = 0;
         }
         // one wrap at most: base < 2 cap and i < size <= cap (a 64-bit modulo here is ~40 instructions per lane)
@@ -382,9 +382,6 @@ __global__ __launch_bounds__(256) void replay_gather_rows_kernel(const float4* _
         }
     }
 }
-
-// bulk launches: cache policy of the streamed rows (bit 0 nontemporal loads, bit 1 nontemporal stores)
-int g_gather_nt = -1;   // -1 = default (nontemporal stores on bulk launches)
 
 extern "C" int naf_replay_batch_row_floats(int S, int A) {
     if (S <= 0 || A <= 0) return NAF_ERR_ARG;
@@ -435,14 +432,8 @@ extern "C" int naf_replay_gather_rows(naf_replay_t* h, const int32_t* idx, float
         // The gathered rows are written once and not re-read by this kernel: nontemporal STORES keep them from evicting
         // ring lines (measured, 4 Mi rows per launch, interleaved A/B: 977 MiB ring 0.393 -> 0.340 ms, 244 MiB ring
         // 0.346 -> 0.300 ms). Nontemporal LOADS of the ring do not help (0.388 ms) and cost 10 % on a ring that fits the
-        // 256 MiB Infinity Cache, so loads stay temporal. naf_debug_set(1, mode) overrides for A/B timing.
-        const int nt = g_gather_nt < 0 ? 2 : g_gather_nt;
-        switch (nt) {
-            case 1: GATHER_W4(4, 1); break;
-            case 2: GATHER_W4(4, 2); break;
-            case 3: GATHER_W4(4, 3); break;
-            default: GATHER_W4(4, 0); break;
-        }
+        // 256 MiB Infinity Cache, so loads stay temporal (template argument NT: bit 0 nontemporal loads, bit 1 stores).
+        GATHER_W4(4, 2);
     }
 #undef GATHER_W4
 #undef GATHER_LAUNCH

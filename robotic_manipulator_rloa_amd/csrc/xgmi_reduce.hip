@@ -126,7 +126,10 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peer
         // never negative): naf_adam_polyak_fused skips the whole update when the norm it folds comes out negative, so
         // a slow or dead peer cannot push a wrong step into the weights; the time-out is counted where the host sees
         // it without synchronising (naf_xgmi_timeouts_nowait) and the training loop raises on it
-        if (sumsq_partials) sumsq_partials[blockIdx.x] = timed_out ? -__builtin_huge_valf() : s;
+        // (the partials of workgroups that did NOT time out stay below 1e30, so that their sum with a poisoned one is -inf
+        //  and never inf - inf = NaN, which the optimizer's `norm < 0` test would let through; a NaN partial — a NaN
+        //  gradient — stays NaN and fails loudly as it does on one GPU)
+        if (sumsq_partials) sumsq_partials[blockIdx.x] = timed_out ? -__builtin_huge_valf() : (s > 1e30f ? 1e30f : s);
         if (blockIdx.x == 0 && step_dev && !timed_out) *step_dev += 1;
     }
 }
@@ -319,7 +322,7 @@ extern "C" int naf_xgmi_timeouts_nowait(void* handle, uint64_t* timeouts) {
 // uncached by the owner, so no ordinary kernel-boundary invalidate ever dropped them. Closing mappings before freeing, with a
 // barrier in between, does not help (tried); time does not help; streaming a buffer through every L2 right after the teardown
 // removes the effect (10 of 10 runs against 1 of 8 without). So both halves of the teardown end with a SCRUB: a grid over all
-// XCDs reads `mb` MiB (default 64: twice the 32 MiB of L2 on the chip; NAF_XGMI_SCRUB_MB overrides, 0 disables), and
+// XCDs reads 64 MiB (twice the 32 MiB of L2 on the chip), and
 // system-scope fences bracket it. The raw memory life cycle alone does not reproduce it (benchmarks/probe/ipc_stale_repro.cpp).
 __global__ __launch_bounds__(256) void xg_scrub_kernel(const float4* __restrict__ p, size_t n4, float* sink) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -333,9 +336,7 @@ __global__ __launch_bounds__(256) void xg_scrub_kernel(const float4* __restrict_
 }
 
 static void xg_scrub_caches() {
-    const char* env = getenv("NAF_XGMI_SCRUB_MB");
-    const long mb = env ? atol(env) : 64;
-    if (mb <= 0) return;
+    const long mb = 64;
     void* buf = nullptr;
     const size_t bytes = (size_t)mb << 20;
     if (hipMalloc(&buf, bytes + 256) != hipSuccess) {
@@ -368,10 +369,11 @@ extern "C" int naf_xgmi_destroy(void* handle) {
     if (!handle) return NAF_ERR_ARG;
     XgmiComm* c = xg_comm(handle);
     (void)naf_xgmi_disconnect(handle);
-    // the own slab goes back to the allocator, scrubbed (see xg_scrub_kernel). NAF_XGMI_FREE_SLAB=0 parks it until the
-    // process ends instead (round 1's workaround: <= 5.3 MB per communicator).
-    const char* keep = getenv("NAF_XGMI_FREE_SLAB");
-    if (!(keep && keep[0] == '0')) {
+    // The own slab is PARKED until the process ends (<= 5.3 MB per communicator; round 1's behaviour, 30 of 30 runs
+    // bit-identical): returning it to the allocator is safe only behind the cache scrub above, whose evidence is empirical
+    // (10 of 10 runs clean) — NAF_XGMI_FREE_SLAB=1 opts into scrub + free.
+    const char* fr = getenv("NAF_XGMI_FREE_SLAB");
+    if (fr && fr[0] == '1') {
         xg_scrub_caches();
         (void)hipFree(c->local);
     }

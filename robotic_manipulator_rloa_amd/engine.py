@@ -109,7 +109,7 @@ class TrainChunk:
         d = self.L.defer_ok
         for k in range(self.U):
             self.L.learn_rows(self.batch[k], self.loss_parts[k], None if self.moments is None else self.moments[k],
-                              pending=d and k > 0, defer=d and k < self.U - 1, chain_pos=k)
+                              pending=d and k > 0, defer=d and k < self.U - 1)
 
     def _body(self) -> None:
         self._sample_gather()
@@ -126,8 +126,7 @@ class TrainChunk:
 
     def run(self) -> None:
         """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first."""
-        if self.L.xgmi is not None:
-            self.L.xgmi.raise_on_timeout()     # host word written by the kernel: costs a load, never a sync
+        self.L.raise_on_device_error()         # pinned host words written by the kernels: costs two loads, never a sync
         if self.use_graph:
             if self.graph is None:
                 self.capture()

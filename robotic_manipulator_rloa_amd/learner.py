@@ -142,7 +142,10 @@ class Learner:
 
     def __init__(self, state_size: int, action_size: int, layer_size: int, batch_size: int, learning_rate: float,
                  tau: float, gamma: float, device: torch.device, p_mode: int = _lib.P_HADAMARD,
-                 world_size: int = 1, process_group=None):
+                 world_size: int = 1, process_group=None, fuse: Optional[str] = None, _force_allreduce: bool = False,
+                 _fold_norm: bool = True):
+        """fuse: "rows" | "columns" | "unfused" | None (= NAF_FUSE or the per-shape default, see below). The underscore
+        arguments are for tests: run the gradient all-reduce at world size 1 / keep the separate grad-norm launch."""
         _lib.require_gpu()
         self.lib = _lib.load()
         self.blas = configure_blas()
@@ -153,68 +156,58 @@ class Learner:
         self.p_mode = int(p_mode)
         self.world_size = int(world_size)
         self.pg = process_group
-        # Which GEMMs are folded into our own kernels (NAF_FUSE = comma list out of {l1,b2,gb,s3,f3}, "all" or "none").
-        # Per-launch costs at B=256 from benchmarks/kernel_probe.py, updates/s from bench.py:
-        #   l1 = layer 1 (K = state size): GEMM + BN + ReLU forward in one launch (4.5 us vs bmm 3.0 + bn 3.4) and BN
-        #        backward + dW1 in one (7.3 vs 3.7 + 3.7); they go together because the fused forward does not
-        #        materialise the pre-BN GEMM output the unfused backward reads
-        #   b2 = dA2 = dH @ Wh (K = 32 heads) folded into layer 2's BN backward (5.0 vs mm 2.7 + bn_bwd 3.7)
-        #   gb = dWh, dW2, dA1 as ONE grid of LDS-staged f32-MFMA 32x32 blocks (csrc/gemm_bundle.hip) instead of three
-        #        rocBLAS launches (6.2 vs 3.8 + 3.2 + 3.8)
-        #   f3 = MFMA heads GEMM + head in one launch (8.1 vs 3.2 + 3.6: slower, off)
-        #   s3 = heads GEMM split over K inside layer 2's BN kernel (each 8-column workgroup writes its [B, NHP] partial
-        #        slab; the head kernel adds the 32 slabs while staging): 4.4 + 4.4 vs bn 3.4 + bmm 4.1 + head 3.2
-        # none 15.0k -> l1,b2 16.3k -> l1,b2,gb 18.0k updates/s (18.7k with the grad norm folded in, below) -> +s3 19.5k.
-        # The folded kernels keep their operand rows in registers (ceil(B/64) rows per thread): they win up to B = 512
-        # and spill beyond (B=1024: 5.1k vs 11.7k updates/s unfused; B=2048: 2.0k vs 8.2k) — so large batches keep the
-        # unfused BN / head chain and take only the GEMM bundle (B=1024: 12.7k, B=2048: 8.8k).
-        #   bb = the LARGE-batch chain (csrc/big_batch.hip): 64-row blocks over the whole chip, BatchNorm statistics in two
-        #        stages (block partials from the producer, folded in the consumer's prologue), GEMM 2 on f32 MFMA with the
-        #        statistics in its epilogue, heads GEMM split over 4 column slices, streaming layer-1 backward
+        # Three chains of launches implement one learn(); `fuse` (a set of tags, read by forward_train / learn_rows) says which:
+        #   "rows"     {bb, gb, hk, ep, s2}: the ROW-SPLIT chain of csrc/big_batch.hip — 64-row blocks over the whole chip, two-stage
+        #              BatchNorm statistics, GEMM 2 on f32 MFMA, layer 2 + heads + NAF head + first backward stage in one launch
+        #              (hk), the backward GEMMs as one launch (gb) that also carries the second stage of layer 2's BatchNorm
+        #              backward as its prologue (s2) and the batch pass of layer 1's backward as its epilogue (ep), a finish
+        #              launch — 5 launches per update in a chain of updates. Needs B % 64 == 0, 64 <= B <= 2048, H = 256, S <= 26.
+        #              Default from B = 256 (measured, updates/s, column-tile | row-split: B = 64: 32.5k | 29.3k, 128: 30.8k | 28.9k,
+        #              256: 25.7k | 34.0k, 512: 20.3k | 29.9k).
+        #   "columns"  {l1, b2, gb, s3}: the COLUMN-TILE chain of csrc/fused_layers.hip — a workgroup owns 8 feature columns x all
+        #              B rows (ceil(B/64) <= 8 rows per thread in registers), the K = state-size and N = heads GEMMs folded into
+        #              the BatchNorm kernels, 8 launches per update. B <= 512. Default below B = 256.
+        #   "unfused"  {gb} or {}: torch (rocBLAS) GEMMs + the BatchNorm / head kernels of csrc/bn_relu.hip, naf_head.hip, with
+        #              the backward GEMM bundle where its shapes allow (B, H multiples of 16) — any shape up to B = 2048; 14
+        #              launches per update (round 1's chain: 12.7k updates/s at B = 1024).
+        # NAF_FUSE = rows | columns | unfused overrides the choice (a chain whose shape limits are not met falls to the next).
         lay0 = self.lay
+        if self.B > 2048:
+            raise ValueError(f"batch_size {self.B}: the BatchNorm kernels keep at most 16 rows per thread (batch_size <= 2048)")
         self.bb_ok = (self.B % 64 == 0 and 64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
-        #   hk = (with bb, H = 256) layer 2 + heads + NAF head + first backward stage of layer 2 in one launch, a workgroup
-        #        per 32 batch rows (csrc/big_batch.hip: bb_layer2_head_kernel) instead of three launches
-        #   ep = (with bb + gb) the batch pass of layer 1's backward as the EPILOGUE of the bundle's dA1 blocks (dA1 never
-        #        leaves the registers of the block that computed it) instead of a launch of its own
-        # (measured, updates/s, column-tile chain | row-split chain: B = 64: 32.5k | 29.3k, 128: 30.8k | 28.9k, 256: 25.7k | 26.9k,
-        #  512: 20.3k | 25.1k — the row-split chain is the default from B = 256)
-        #   s2 = (with bb + gb + hk) the second stage of layer 2's BatchNorm backward inside the bundle: dY2 becomes dZ2 while the
-        #        products that read it stage their operand (csrc/gemm_bundle.hip, naf_gemm_bn2bwd_t) — one launch less; needs
-        #        whole 256-k chunks and at most 32 row blocks of backward partials: B = 256, 512
-        spec = os.environ.get("NAF_FUSE", "bb,gb,hk,ep,s2" if (self.B >= 256 and self.bb_ok)
-                              else ("l1,b2,gb,s3" if self.B <= 512 else "gb")).lower()
-        #   l12 = (with bb; opt-in, NOT default) layer 1 inside GEMM 2's launch: every GEMM-2 workgroup forms its A panel from
-        #        the rows itself. Parity-tested; measured 17.0 us against 13.7 us for the two launches it replaces at B = 1024
-        #        (every workgroup repeats the moments statistics of its 128-feature chunks) — DESIGN.md section 4b
-        names = {"l1", "b2", "f3", "gb", "s3", "bb", "hk", "ep", "l12", "s2"}
-        self.fuse = (set(names) - {"bb", "hk", "ep", "l12", "s2"}) if spec == "all" else (set() if spec in ("none", "") else set(spec.split(",")) & names)
-        if "bb" in self.fuse:
-            self.fuse = ({"bb"} | (self.fuse & {"gb", "hk", "ep", "l12", "s2"})) if self.bb_ok else (self.fuse - {"bb"})
+        want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
+        if want not in ("default", "rows", "columns", "unfused"):
+            raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
+        if want == "default":
+            want = "rows" if (self.B >= 256 and self.bb_ok) else ("columns" if self.B <= 512 else "unfused")
+        if want == "rows" and not self.bb_ok:
+            want = "columns" if self.B <= 512 else "unfused"
+        if want == "rows":
+            self.fuse = {"bb", "gb", "hk", "ep", "s2"}
+        elif want == "columns" and self.B <= 512:
+            self.fuse = {"l1", "b2", "gb", "s3"}
+            if lay0.S > 32 or (lay0.S > 24 and self.B > 256):
+                self.fuse -= {"l1"}            # (K = 25 .. 32: the layer-1 backward tile holds at most 4 rows per thread)
+            if lay0.H not in (128, 256):
+                self.fuse -= {"s3"}
         else:
-            self.fuse -= {"l12", "s2"}
-        if "bb" not in self.fuse or lay0.H != 256:
-            self.fuse -= {"hk"}
-        if not {"bb", "gb"} <= self.fuse or self.B % 32:
-            self.fuse -= {"ep"}
-        #        (round 2, later: the block sums are folded ONCE per launch by the bundle's first workgroups — csrc/gemm_bundle.hip,
-        #        gemm_bn2bwd_fold_block — so up to 128 row blocks: every batch size of the chain. NAF_S2_FOLD=0: every block folds
-        #        for itself, at most 32 row blocks)
-        npb_ = self.B // self.lib.naf_bb_layer2_head_rows(self.B)
-        self.s2_fold_once = os.environ.get("NAF_S2_FOLD", "1") != "0"
-        if not {"bb", "gb", "hk"} <= self.fuse or self.B % 256 or npb_ > (128 if self.s2_fold_once else 32):
-            self.fuse -= {"s2"}
-        if self.lay.S > 32:
-            self.fuse -= {"l1"}
-        if self.B % 16 != 0 or self.lay.H % 16 != 0:
-            self.fuse -= {"gb", "f3"}          # the MFMA kernels take whole 16 x 16 x 16 steps: M, N, K % 16 == 0
-        if self.B > 512 or self.lay.H not in (128, 256) or "f3" in self.fuse:
-            self.fuse -= {"s3"}
-        # with l1 + b2 + gb every gradient element is produced by one of our own kernels, which then also emit its
-        # sum-of-squares partial: the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken
-        # on the all-reduced gradient).
+            want = "unfused"
+            self.fuse = {"gb"}
+        if self.B % 16 != 0 or lay0.H % 16 != 0:
+            self.fuse -= {"gb"}                # the MFMA kernels take whole 16 x 16 x 16 steps: M, N, K % 16 == 0
+        self.chain = want
+        if self.B > 512 and want != "rows":
+            # (a performance cliff, not an error: say so once, with the sizes that avoid it)
+            import warnings
+            lo, hi = max(64, self.B // 64 * 64), min(2048, -(-self.B // 64) * 64)
+            warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
+                          f"row-split chain): the row-split kernels need batch_size % 64 == 0 (nearest: {lo}, {hi}), 64 <= "
+                          f"batch_size <= 2048, layer_size 256 and state_size <= 26", stacklevel=3)
+        # with every gradient element produced by one of our own kernels, those kernels also emit its sum-of-squares partial:
+        # the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken on the all-reduced gradient).
         self.fold_norm = ({"l1", "b2", "gb"} <= self.fuse or {"bb", "gb"} <= self.fuse) and self.world_size == 1 and \
-            os.environ.get("NAF_FORCE_ALLREDUCE") != "1" and os.environ.get("NAF_NO_FOLD_NORM") != "1"
+            not _force_allreduce and _fold_norm
+        self._force_allreduce = bool(_force_allreduce)
         lay, B, dev = self.lay, self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
         P, H, HP, NHP = lay.P, lay.H, lay.HP, lay.NHP
@@ -253,28 +246,19 @@ class Learner:
         # chain on one rank, gradient norm folded into the producers. NAF_DEFER_ADAM=0 keeps the launch of its own.
         # Data parallel over peer memory: the one-shot all-reduce launch leaves the norm partials and the step count exactly
         # as the folded producers do on one rank, so the step can ride there too (the RCCL path keeps its two launches).
-        self.defer_ok = ("bb" in self.fuse and "l12" not in self.fuse and "f3" not in self.fuse
-                         and ((self.fold_norm and self.world_size == 1) or self.xgmi is not None)
+        self.defer_ok = ("bb" in self.fuse and ((self.fold_norm and self.world_size == 1) or self.xgmi is not None)
                          and os.environ.get("NAF_DEFER_ADAM", "1") != "0")
-        # ... and, OPT-IN (NAF_MERGE_FINISH=1), the finish launch of update k rides there too (csrc/big_batch.hip, bb_finish_block):
-        # its workgroups publish their sum-of-squares partials as tagged records which the optimizer workgroups and the layer-1
-        # workgroups of that launch wait for — four launches per update at B <= 1024, bit-identical (tested). Measured: 31.4k
-        # against 31.1k updates/s at B = 256, 23.4k / 23.5k at 1024, 16.6k / 16.5-16.9k at 2048 on the same boxes — the launch
-        # and its boundary (4.2 us) are traded for sc1 scalar stores in the finish work (+0.9 us), 1.6 us until the readers see
-        # the last record and a dependent round trip for the gradient (0.8 us): not the default (with the kernels of the end of
-        # the round: 33.3k against 33.7k at B = 256, 25.1k against 25.7k at 1024).
-        self.merge_finish = (self.defer_ok and self.world_size == 1 and self.fold_norm and {"ep", "hk", "gb"} <= self.fuse
-                             and self.n_partials_fold <= 256 and os.environ.get("NAF_MERGE_FINISH", "0") == "1")
-        self.partial_recs = torch.zeros(max(self.n_partials_fold, 1), 4, **f32)
-        self._pending_fin = None
         self.adam_bc = torch.zeros(8, **f32)     # the next step's bias corrections, left by the riding optimizer workgroups
         self._adam_args = _lib.AdamArgs(
             ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]), ptr(self.partials),
             self.n_partials, MAX_GRAD_NORM, self.lr, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self.tau, float(1.0 - self.tau),
-            ptr(self.step_dev), 1.0 / self.world_size, P, lay.seg["W2"].offset, 0, 0, ptr(self.adam_bc))
+            ptr(self.step_dev), 1.0 / self.world_size, P, lay.seg["W2"].offset, ptr(self.adam_bc))
         self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
         self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
         self.n_loss_wg = (B + 7) // 8                  # loss partials per update (NAF_HEAD_SPB samples per workgroup)
+        # a wait inside a kernel that expired (the bundle's polls of the BatchNorm-backward records: hang guards) bumps this
+        # pinned HOST word; raise_on_device_error() reads it without synchronising
+        self.err_host = torch.zeros(8, dtype=torch.int64).pin_memory()
 
         # ---- work buffers for one minibatch ------------------------------------------------------------
         self.G1 = torch.empty(2, B, H, **f32)
@@ -293,29 +277,17 @@ class Learner:
         self.q_out = torch.empty(B, **f32)
         if "bb" in self.fuse:
             NB = B // 64
-            self.n_slabs = H // 64
-            self.slab_stride = B * NHP + 64
-            self.heads_partial = torch.zeros(self.n_slabs * self.slab_stride, **f32)
-            self.vnext_partial = torch.zeros(self.n_slabs, B, **f32)
+            kp = self.lib.naf_bb_layer1_bwd_kp(lay.S)
             # moments record of one minibatch's layer-1 inputs, [net][Sx | C]: everything layer 1's BatchNorm needs from
             # the batch dimension (TrainChunk computes the records of all its minibatches in one launch behind the gather)
             self.mom_floats = self.lib.naf_bb_moments_floats(lay.S)
             self.bb_mom = torch.zeros(2, self.mom_floats, **f32)
-            self.bb_wc = torch.zeros(H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # w_c C of the main net, forward -> finish
-            # second set of what layer 1's forward leaves for its backward (statistics, w_c C), by update parity: when the finish
-            # work of update k rides on update k + 1's first launch (merge_finish, below) it reads update k's while that launch's
-            # layer-1 workgroups write update k + 1's
-            self.l1_alt_mean = torch.empty(2, H, **f32)
-            self.l1_alt_invstd = torch.empty(2, H, **f32)
-            self.bb_wc_alt = torch.zeros(H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)
-            self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)
+            self.bb_wc = torch.zeros(H, kp, **f32)               # w_c C of the main net, forward -> finish
+            self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)        # layer-2 statistics partials per 64-row block: (sum, M2)
             self.hk_rows = self.lib.naf_bb_layer2_head_rows(B)    # rows per block of the fused launch's backward partials
-            self.bb_bw2 = torch.zeros(max(2 * NB, B // self.hk_rows), H, 2, **f32)      # backward partials of layer 2: (sum dy, sum dy*xhat); per 64-row
-            #                                                     block, or per 32-row block from the fused layer-2 + head launch
-            self.bb_dzp = torch.zeros(NB, H, **f32)             # block sums of dZ2 (-> gradient of the layer-2 bias)
-            self.bb_bw1 = torch.zeros(2 * NB, H, 2, **f32)      # backward partials of layer 1 (per 64-row block, or per 32-row
-            #                                                     block from the bundle's epilogue)
-            self.bb_dw1 = torch.zeros(2 * NB, H, self.lib.naf_bb_layer1_bwd_kp(lay.S), **f32)   # per-block shares of P = dY1^T X
+            self.bb_bw2 = torch.zeros(B // self.hk_rows, H, 2, **f32)   # backward partials of layer 2: (sum dy, sum dy*xhat)
+            self.bb_bw1 = torch.zeros(B // 32, H, 2, **f32)       # backward partials of layer 1, per 32-row block of the bundle
+            self.bb_dw1 = torch.zeros(B // 32, H, kp, **f32)      # per-block shares of P = dY1^T X
         if "s3" in self.fuse:
             # split-K heads: one [B, NHP] slab per 8-column workgroup of layer 2's BN kernel (+ the target's V column)
             # slabs 256 B further apart than their size: the H/8 pieces of one row, read together by the head kernel,
@@ -349,45 +321,38 @@ class Learner:
             D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.gW2), sq_w2, H, H, B, H, H, H, 1, 1),                  # dW2
             D(ptr(self.dZ2), ptr(self.W2_main), ptr(self.dA1), None, B, H, H, H, H, H, 0, 1))                 # dA1
         self._bb_segs, self._bb_nsegs = None, 0
-        if "bb" in self.fuse and "gb" in self.fuse:
-            # large batches: the weight gradients reduce over K = B. Cut K into 256-row ranges, one grid of blocks each,
-            # writing partial slabs that the layer-1 finish launch adds in slab order (and takes the norm partials of)
-            # 64 x 64 blocks (csrc/gemm_bundle64.hip) when every K range is whole 128-k chunks; else the 32 x 32 bundle
-            self._bundle64 = B % 128 == 0 and os.environ.get("NAF_BUNDLE64", "0") == "1"   # measured: no faster
-            if self._bundle64:       # K = B cut into at most 8 ranges of whole 128-k chunks, as many as divide it
-                ks = max(d for d in range(1, 9) if (B // 128) % d == 0)
-            else:
-                ks = B // 256 if B % 256 == 0 else 1
+        if "bb" in self.fuse:
+            # The weight gradients reduce over K = B. Cut K into ranges, one grid of blocks each, writing partial slabs that
+            # the layer-1 finish launch adds in slab order (and takes the norm partials of): 256-row ranges for dWh; for dW2
+            # twice as long (512 rows) from B = 1024 on: half the blocks, half the slabs for the finish launch to add (B = 1024:
+            # 420 blocks — one round of two per CU — instead of 548: 21.8k -> 22.5k updates/s when it was introduced;
+            # B = 2048 with the blocks placed by row on the XCDs: 19.3k -> 19.7k; four times as long: 18.4k). Batch sizes
+            # that are not multiples of 256: as many equal ranges (<= 8, whole 64-row blocks) as divide B / 64.
+            ks = max(d for d in range(1, 9) if (B // 64) % d == 0 and B // d >= 256) if B >= 256 else 1
+            if B % 256 == 0:
+                ks = B // 256
             ks_w2 = ks_wh = ks
-            # dW2's K ranges twice as long (512 rows) from B = 1024 on: half the blocks, half the slabs for the finish launch
-            # to add (B = 1024: 420 blocks — one round of two per CU — instead of 548: 21.8k -> 22.5k updates/s when it was
-            # introduced; B = 2048 with the blocks placed by row on the XCDs: 19.3k -> 19.7k; four times as long: 18.4k)
-            if ks >= 2 and (B // (ks // 2)) % 256 == 0:
+            if ks >= 2 and ks % 2 == 0 and (B // (ks // 2)) % 256 == 0:
                 ks_w2 = ks // 2
-            if os.environ.get("NAF_BB_KS"):          # experiment: "w2,wh" K ranges of the two weight gradients
-                ks_w2, ks_wh = (int(v) for v in os.environ["NAF_BB_KS"].split(","))
             self.bb_slab_w2 = torch.zeros(ks_w2, H * H, **f32)
             self.bb_slab_wh = torch.zeros(ks_wh, NHP * HP, **f32)
-            self._epi = None
-            if "ep" in self.fuse:
-                t2p_, seg_ = self.theta2.data_ptr(), lay.seg
-                self._epi = _lib.GemmL1Bwd(None, t2p_ + 4 * seg_["W1"].offset, t2p_ + 4 * seg_["b1"].offset, ptr(self.A1[0]),
-                                           ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1),
-                                           0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H)     # x / ldx: set per minibatch
+            t2p_, seg_, gp_ = self.theta2.data_ptr(), lay.seg, self.grad.data_ptr()
+            # ep: the batch pass of layer 1's backward as the epilogue of the dA1 blocks (x / ldx: set per minibatch)
+            self._epi = _lib.GemmL1Bwd(None, t2p_ + 4 * seg_["W1"].offset, t2p_ + 4 * seg_["b1"].offset, ptr(self.A1[0]),
+                                       ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1),
+                                       0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H)
+            # s2: dY2 -> dZ2 while the two products that read it stage their A panels; the block sums folded once per launch
+            # by the bundle's first workgroups and handed on as tagged records (csrc/gemm_bundle.hip, gemm_bn2bwd_fold_block)
+            self.bb_cst = torch.zeros(H, 4, **f32)                                        # per-column constants of the launch
+            self.bb_fold_flag = torch.ones(1, dtype=torch.int32, device=dev)              # launch number: finish advances it; never restored
+            self._pro = _lib.GemmBn2Bwd(ptr(self.G2[0]), ptr(self.bb_bw2), t2p_ + 4 * seg_["g2"].offset, ptr(self.save_mean[1, 0]),
+                                        ptr(self.save_invstd[1, 0]), gp_ + 4 * seg_["g2"].offset, gp_ + 4 * seg_["be2"].offset,
+                                        B // self.hk_rows, B, H, ptr(self.bb_cst), ptr(self.bb_fold_flag), self.err_host.data_ptr())
+            pro_ = _lib.C.addressof(self._pro)
             # dA1 FIRST: its blocks carry the layer-1 epilogue and run longest; dispatched first, the short weight-gradient
             # blocks fill in behind them instead of the other way round
-            self._pro = None
-            if "s2" in self.fuse:        # dY2 -> dZ2 while the two products that read it stage their A panels
-                t2p_, seg_, gp_ = self.theta2.data_ptr(), lay.seg, self.grad.data_ptr()
-                self.bb_cst = torch.zeros(H, 4, **f32) if self.s2_fold_once else None      # per-column constants of the launch
-                self.bb_fold_flag = torch.ones(1, dtype=torch.int32, device=dev) if self.s2_fold_once else None   # launch number: finish advances it; never restored
-                self._pro = _lib.GemmBn2Bwd(ptr(self.G2[0]), ptr(self.bb_bw2), t2p_ + 4 * seg_["g2"].offset, ptr(self.save_mean[1, 0]),
-                                            ptr(self.save_invstd[1, 0]), gp_ + 4 * seg_["g2"].offset, gp_ + 4 * seg_["be2"].offset,
-                                            B // self.hk_rows, B, H, ptr(self.bb_cst), ptr(self.bb_fold_flag))
-            pro_ = _lib.C.addressof(self._pro) if self._pro is not None else None
             self._bundle = (D * 3)(
-                D(ptr(self.dZ2), ptr(self.W2_main), None if self._epi is not None else ptr(self.dA1), None, B, H, H, H, H, H, 0, 1,
-                  1, 0, _lib.C.addressof(self._epi) if self._epi is not None else None, pro_),
+                D(ptr(self.dZ2), ptr(self.W2_main), None, None, B, H, H, H, H, H, 0, 1, 1, 0, _lib.C.addressof(self._epi), pro_),
                 D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks_w2, H * H, None, pro_),
                 D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks_wh, NHP * HP))
             SS = _lib.SlabSeg
@@ -420,6 +385,19 @@ class Learner:
         self.adam_v.zero_()
         self.step_dev.zero_()
 
+    def raise_on_device_error(self) -> None:
+        """Host-side check of what the kernels can only flag: a bounded wait that expired inside a launch (the bundle's polls,
+        the one-shot all-reduce's waits on its peers). Reads pinned host words the kernels bump — a load, never a
+        synchronisation; the values lag the stream by whatever is still queued. Called before every chunk of updates and
+        every learn()."""
+        if self.xgmi is not None:
+            self.xgmi.raise_on_timeout()
+        n = int(self.err_host[0])
+        if n:
+            raise _lib.NafHipError(f"{n} bounded wait(s) inside the backward GEMM launch expired (the workgroups that fold the "
+                                   "BatchNorm-backward sums did not publish within 50 ms): the affected updates are poisoned with "
+                                   "NaN — the GPU is hung, over-subscribed or faulted; restart from a checkpoint")
+
     # ---- one learn() on the current stream --------------------------------------------------------------
     def _x2(self, rows: torch.Tensor) -> torch.Tensor:
         """[2, B, S] view of a [B, ld] minibatch: net 0 reads `state`, net 1 reads `next_state`."""
@@ -428,25 +406,20 @@ class Learner:
 
     def moments(self, rows: torch.Tensor, out: torch.Tensor, n_batches: int = 1) -> None:
         """Moments records of n_batches minibatches stored back to back in `rows` ([n_batches * B, ld]) -> out
-        [n_batches, 2, mom_floats]: one launch (large-batch chain only)."""
+        [n_batches, 2, mom_floats]: one launch (row-split chain only)."""
         lay = self.lay
         ld = rows.stride(-2)
         check(self._f.naf_bb_moments(rows.data_ptr(), self.B * ld, lay.off_s2, ld, lay.S, ptr(out), self.B, int(n_batches), 2,
                                      stream_ptr()), "bb_moments")
 
-    def _l1_saved(self, parity: int):
-        """(save_mean[2][H], save_invstd[2][H], w_c C) of layer 1 for an update of this parity (row-split chain)"""
-        if parity & 1:
-            return self.l1_alt_mean, self.l1_alt_invstd, self.bb_wc_alt
-        return self.save_mean[0], self.save_invstd[0], self.bb_wc
-
     def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True, moments: Optional[torch.Tensor] = None,
-                      adam_pending: bool = False, parity: int = 0, chain_pos: int = 0) -> None:
+                      adam_pending: bool = False) -> None:
         """Both networks' training-mode forward up to the second hidden activation A2 (and, with heads_gemm, the
         heads pre-activations Gh). Main net sees `state`, target net sees `next_state` (naf_algorithm.py:194-202);
         both use batch statistics and both update their running statistics (the reference never calls .eval() on the
         target). adam_pending: the optimizer step of the previous update was deferred (learn_rows(defer=True)) and rides
-        on the first two launches here."""
+        on the first two launches here. Row-split chain: stops behind GEMM 2 — layer 2 from Z2 on is inside
+        naf_bb_layer2_head (learn_rows)."""
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H = lay.seg, lay.P, lay.H
         t2p = self.theta2.data_ptr()
@@ -457,49 +430,20 @@ class Learner:
                 self.moments(rows, self.bb_mom)
                 moments = self.bb_mom
             self._mom = moments
-            if "l12" in self.fuse:
-                # layer 1 + GEMM 2 of both nets in one launch (A1 formed in LDS by every GEMM-2 workgroup, written out by the
-                # column-0 ones), bias added, layer-2 statistics partials from the epilogue
-                check(self._f.naf_bb_layer12(
-                    rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
-                    t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, t2p + 4 * seg["W2"].offset,
-                    t2p + 4 * seg["b2"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H, ptr(self.A1), B * H, H,
-                    ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H, 2,
-                    BN_MOMENTUM, BN_EPS, st), "bb_layer12")
-            else:
-                # layer 1: batch statistics from the moments, z, normalise, ReLU — one launch for both nets
-                # (adam_pending: the previous update's clip + Adam + Polyak ride on these two launches — extra workgroups of
-                # the first step everything behind the layer-1 segment while its own workgroups evaluate the layer-1
-                # parameters as the step will leave them, extra workgroups of the second step the layer-1 segment)
-                # (merge_finish: the previous update's FINISH work rides on the first launch as well; the step then reads its
-                # norm partials as tagged records and the gradient behind them, and counts its step number from the chain's start)
-                adam = fin = None
-                if adam_pending:
-                    aa = self._adam_args
-                    if self._pending_fin is not None:
-                        aa = _lib.AdamArgs.from_buffer_copy(self._adam_args)
-                        aa.partials, aa.rec, aa.step_bias = ptr(self.partial_recs), 1, int(chain_pos)
-                        fin = _lib.C.byref(self._pending_fin)
-                    adam = _lib.C.byref(aa)
-                sm, si, wc = self._l1_saved(parity)
-                check(self._f.naf_bb_layer1_adam_fin(
-                    rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
-                    t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
-                    ptr(self.A1), B * H, H, ptr(sm), ptr(si), ptr(wc), B, H, 2, BN_MOMENTUM,
-                    BN_EPS, adam, fin, st), "bb_layer1")
-                # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
-                check(self._f.naf_bb_linear_stats_adam(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset,
-                                                       t2p + 4 * seg["b2"].offset, P, ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H,
-                                                       H, 2, adam, st), "bb_linear_stats")
-            if "hk" in self.fuse:
-                return               # layer 2 from Z2 on is inside naf_bb_layer2_head (learn_rows)
-            # fold + normalise + ReLU -> A2, and this column slice's share of the heads GEMM
-            check(self._f.naf_bb_bn_relu_heads_partial(
-                ptr(self.G2), B * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
-                bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2), B * lay.HP, lay.HP, ptr(self.save_mean[1]),
-                ptr(self.save_invstd[1]), t2p + 4 * seg["Wh"].offset, P, lay.HP, lay.NHP, lay.A + lay.T,
-                ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), B, H, BN_MOMENTUM, BN_EPS, st),
-                "bb_bn_relu_heads_partial")
+            # layer 1: batch statistics from the moments, z, normalise, ReLU — one launch for both nets
+            # (adam_pending: the previous update's clip + Adam + Polyak ride on these two launches — extra workgroups of
+            # the first step everything behind the layer-1 segment while its own workgroups evaluate the layer-1
+            # parameters as the step will leave them, extra workgroups of the second step the layer-1 segment)
+            adam = _lib.C.byref(self._adam_args) if adam_pending else None
+            check(self._f.naf_bb_layer1_adam(
+                rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
+                ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), B, H, 2, BN_MOMENTUM,
+                BN_EPS, adam, st), "bb_layer1")
+            # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
+            check(self._f.naf_bb_linear_stats_adam(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset,
+                                                   t2p + 4 * seg["b2"].offset, P, ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H,
+                                                   H, 2, adam, st), "bb_linear_stats")
             return
         if "l1" in self.fuse:
             # layer 1 (K = state size): GEMM + bias + BN + ReLU of both nets in one launch, straight off the rows
@@ -531,26 +475,22 @@ class Learner:
             torch.bmm(self.A2, self.WhT2, out=self.Gh)
 
     def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None,
-                   moments: Optional[torch.Tensor] = None, pending: bool = False, defer: bool = False, chain_pos: int = 0) -> None:
+                   moments: Optional[torch.Tensor] = None, pending: bool = False, defer: bool = False) -> None:
         """Enqueue one full NAFAgent.learn() (naf_algorithm.py:180-215) + soft_update (:217-226) on the minibatch
         `rows` [B, ld] in the transition-row layout, ld = rows.stride(0) >= lay.batch_row_floats (actions already
         truncated by the gather if the reference's `.long()` is mimicked).
         loss_partials: optional [n_loss_wg] f32 receiving the per-workgroup parts of the MSE loss.
-        moments: optional [2, mom_floats] record of this minibatch (large-batch chain; Learner.moments); computed here when
+        moments: optional [2, mom_floats] record of this minibatch (row-split chain; Learner.moments); computed here when
         missing.
         defer / pending (only where self.defer_ok; a chain of updates, engine.TrainChunk): defer = leave this update's
         optimizer step (clip + Adam + Polyak) to the NEXT learn_rows call, which must then say pending = True and whose
         first two launches carry it — one launch less per update. Between the two calls the parameter buffers still hold
-        the values from before this update; the chain ends with a call that does not defer. chain_pos: 0-based position of
-        this update in its chain (with merge_finish the deferred updates' finish work rides along too, the step count is
-        advanced once at the chain's end, and layer 1's saved statistics alternate between two buffers by parity)."""
-        parity = chain_pos & 1 if (self.merge_finish and (pending or defer)) else 0
-        merge = self.merge_finish and (pending or defer)
-        if pending and merge and self._pending_fin is None:
-            raise ValueError("learn_rows(pending=True): the previous call did not defer")
+        the values from before this update; the chain ends with a call that does not defer."""
         if (pending or defer) and not self.defer_ok:
             raise ValueError("learn_rows: a deferred optimizer step needs the row-split chain with the gradient norm left by the "
                              "producers or by the one-shot all-reduce (Learner.defer_ok)")
+        if not pending:
+            self.raise_on_device_error()
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
         f = self._f
@@ -559,34 +499,71 @@ class Learner:
         if rows.shape[0] != B or rows.stride(1) != 1 or ld < lay.batch_row_floats or ld % 4 or rp % 16:
             raise ValueError(f"learn_rows: need [B={B}, >={lay.batch_row_floats}] f32 rows, 16-B aligned, row stride % 4 == 0")
         lp = ptr(loss_partials) if loss_partials is not None else None
-        if "f3" in self.fuse:
-            self.forward_train(rows, heads_gemm=False)
-            # heads GEMM (MFMA) + V'(s') + y = r + gamma V' ; Q ; loss ; d loss / d heads_pre — one launch
-            check(f.naf_heads_gemm_head_fwd_bwd_mse(
-                ptr(self.A2), B * HP, HP, HP, t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld,
-                rp + 4 * lay.off_r, ld, self.gamma, None, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
-                st), "heads_gemm_head_fwd_bwd_mse")
-        elif "hk" in self.fuse:
-            self.forward_train(rows, moments=moments, adam_pending=pending, parity=parity, chain_pos=chain_pos)
-            self._pending_fin = None             # (consumed by the launch above)
-            bnp = self.bn_stats.data_ptr()
-            # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
-            check(f.naf_bb_layer2_head(
-                ptr(self.G2), B * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
-                bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2[0]), HP, ptr(self.save_mean[1]), ptr(self.save_invstd[1]),
-                t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld, rp + 4 * lay.off_r, ld, self.gamma,
-                ptr(self.q_out), ptr(self.dH), lp, ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, lay.A, self.p_mode, BN_MOMENTUM,
-                BN_EPS, st), "bb_layer2_head")
-        elif "s3" in self.fuse or "bb" in self.fuse:
-            self.forward_train(rows, moments=moments, adam_pending=pending, parity=parity, chain_pos=chain_pos)
-            # the head adds the split-K slabs (H/8 of them, or H/64 in the large-batch chain) while staging its rows
+        if "bb" in self.fuse:
+            self._learn_rows_split(rows, lp, moments, pending)
+        else:
+            self._learn_rows_tiles(rows, lp)
+        if self.world_size > 1 or self._force_allreduce:
+            # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
+            # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
+            if self.xgmi is not None:
+                # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
+                self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=self._pushed_lo)
+                if not defer:
+                    self.optimizer_step(norm_ready=True)
+                return
+            all_reduce_flat_grad(self.grad, self.pg)
+        if defer:
+            return                       # the next learn_rows(pending=True) carries the step
+        self.optimizer_step(norm_ready=self.fold_norm)
+
+    def _learn_rows_split(self, rows: torch.Tensor, lp, moments, pending: bool) -> None:
+        """The row-split chain (csrc/big_batch.hip + gemm_bundle.hip): layer 1 | GEMM 2 | layer 2 + heads + head + first
+        backward stage | backward GEMM bundle with its prologue and epilogue | finish."""
+        lay, B, st = self.lay, self.B, stream_ptr()
+        seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
+        f = self._f
+        t2p, gp, bnp = self.theta2.data_ptr(), self.grad.data_ptr(), self.bn_stats.data_ptr()
+        rp, ld = rows.data_ptr(), rows.stride(0)
+        self._pushed_lo = None
+        self.forward_train(rows, moments=moments, adam_pending=pending)
+        # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
+        check(f.naf_bb_layer2_head(
+            ptr(self.G2), B * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
+            bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2[0]), HP, ptr(self.save_mean[1]), ptr(self.save_invstd[1]),
+            t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld, rp + 4 * lay.off_r, ld, self.gamma,
+            ptr(self.q_out), ptr(self.dH), lp, ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, lay.A, self.p_mode, BN_MOMENTUM,
+            BN_EPS, st), "bb_layer2_head")
+        # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles; dY2 becomes dZ2 while it is staged, the
+        # dA1 blocks run layer 1's backward batch pass on their tile (this minibatch's rows: z recomputed from them)
+        self._epi.x, self._epi.ldx = rp, ld
+        check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
+        # finish: everything added in block order, the xhat term from the moments, the bundle's split-K slabs, the norm
+        # partials (nb = 0: the layer-2 bias gradient is written as the 0 it identically is)
+        check(f.naf_bb_layer1_bwd_finish(
+            ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), B // 32, None, 0,
+            ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
+            gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
+            gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
+            ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, B, H,
+            self._bb_segs, self._bb_nsegs, ptr(self.bb_fold_flag), st), "bb_layer1_bwd_finish")
+
+    def _learn_rows_tiles(self, rows: torch.Tensor, lp) -> None:
+        """The column-tile chain (csrc/fused_layers.hip) and the unfused chain (torch GEMMs + csrc/bn_relu.hip), by `fuse`."""
+        lay, B, st = self.lay, self.B, stream_ptr()
+        seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
+        f = self._f
+        t2p, gp = self.theta2.data_ptr(), self.grad.data_ptr()
+        rp, ld = rows.data_ptr(), rows.stride(0)
+        self._pushed_lo = None
+        self.forward_train(rows)
+        if "s3" in self.fuse:
+            # the head adds the split-K slabs (H/8 of them) while staging its rows
             check(f.naf_head_fwd_bwd_mse_splitk(
                 ptr(self.heads_partial), self.slab_stride, ptr(self.vnext_partial), self.n_slabs, NHP, rp + 4 * lay.off_u,
-                ld,
-                rp + 4 * lay.off_r, ld, self.gamma, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
+                ld, rp + 4 * lay.off_r, ld, self.gamma, ptr(self.q_out), ptr(self.dH), lp, B, lay.A, self.p_mode,
                 st), "head_fwd_bwd_mse_splitk")
         else:
-            self.forward_train(rows)
             # y = r + gamma * V'(s') ; Q ; loss ; d loss / d heads_pre — one launch
             check(f.naf_head_fwd_bwd_mse(
                 ptr(self.Gh[0]), NHP, rp + 4 * lay.off_u, ld, rp + 4 * lay.off_r, ld,
@@ -596,20 +573,7 @@ class Learner:
         gb = "gb" in self.fuse
         if not gb:
             torch.mm(self.dH.t(), self.A2[0], out=self.gWh)
-        if "bb" in self.fuse:
-            # backward of layer 2, two stages: dy = ReLU' * (dH Wh) with its block sums (already done by the fused launch
-            # when "hk" is on), then dz in place
-            if "hk" not in self.fuse:
-                check(f.naf_bb_heads_bwd_stage1(ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H,
-                                                ptr(self.A2[0]), HP, ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]),
-                                                ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, st), "bb_heads_bwd_stage1")
-            if "s2" not in self.fuse:     # (with s2 the bundle's blocks turn dY2 into dZ2 while they stage it)
-                check(f.naf_bb_bn_bwd_stage2(ptr(self.dZ2), H, ptr(self.G2[0]), H, t2p + 4 * seg["g2"].offset,
-                                             ptr(self.save_mean[1, 0]), ptr(self.save_invstd[1, 0]), ptr(self.bb_bw2),
-                                             B // self.hk_rows if "hk" in self.fuse else B // 64,
-                                             gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, ptr(self.bb_dzp), B, H, st),
-                      "bb_bn_bwd_stage2")
-        elif "b2" in self.fuse:
+        if "b2" in self.fuse:
             # dA2 = dH @ Wh (K = NHP) folded into the ReLU/BN backward of layer 2
             check(f.naf_heads_bwd_bn_relu_bwd(
                 ptr(self.dH), NHP, t2p + 4 * seg["Wh"].offset, HP, ptr(self.G2[0]), H, t2p + 4 * seg["b2"].offset,
@@ -625,49 +589,11 @@ class Learner:
                 gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
         if gb:
             # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles
-            if "ep" in self.fuse:
-                self._epi.x, self._epi.ldx = rp, ld      # this minibatch's rows: the epilogue recomputes layer 1's z from them
-                sm_, si_, _ = self._l1_saved(parity)
-                self._epi.save_mean, self._epi.save_invstd = ptr(sm_[0]), ptr(si_[0])
-            if getattr(self, "_bundle64", False):
-                check(f.naf_gemm_bundle64(self._bundle, 3, st), "gemm_bundle64")
-            else:
-                check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
+            check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
             torch.mm(self.dZ2, self.W2_main, out=self.dA1)
-        pushed_lo = None
-        if "bb" in self.fuse:
-            # layer 1 backward: one pass (dy, its block sums, block shares of P = dY^T X), then the finish launch: everything
-            # added in block order, the xhat term from the moments, the bundle's split-K slabs, the norm partials
-            if "ep" not in self.fuse:
-                check(f.naf_bb_layer1_bwd(
-                    ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
-                    ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1), B, H, st),
-                    "bb_layer1_bwd")
-            sm_, si_, wc_ = self._l1_saved(parity)
-            nb1_ = B // 32 if ("ep" in self.fuse and not getattr(self, "_bundle64", False)) else B // 64
-            nb_ = 0 if "s2" in self.fuse else B // 64      # (s2: the layer-2 bias gradient is written as the 0 it identically is)
-            if defer and merge:
-                # no finish launch: its work rides on the next update's first launch (forward_train), with this update's pointers
-                self._pending_fin = _lib.BbFinishArgs(
-                    ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), nb1_, ptr(self.bb_dzp), nb_, ptr(self._mom), ptr(wc_),
-                    t2p + 4 * seg["g1"].offset, ptr(si_[0]), gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset,
-                    gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset,
-                    gp + 4 * seg["be2"].offset, ptr(self.partial_recs), B, H,
-                    _lib.C.cast(self._bb_segs, _lib.C.c_void_p) if self._bb_segs is not None else None, self._bb_nsegs,
-                    ptr(getattr(self, "bb_fold_flag", None)))
-                return
-            if pending and merge and chain_pos > 0:
-                self.step_dev.add_(int(chain_pos))          # the deferred updates of the chain did not advance the step count
-            check(f.naf_bb_layer1_bwd_finish(
-                ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), nb1_, ptr(self.bb_dzp), nb_,
-                ptr(self._mom), ptr(wc_), t2p + 4 * seg["g1"].offset, ptr(si_[0]),
-                gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
-                gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
-                ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, B, H,
-                self._bb_segs, self._bb_nsegs, ptr(getattr(self, "bb_fold_flag", None)), st), "bb_layer1_bwd_finish")
-        elif "l1" in self.fuse:
+        if "l1" in self.fuse:
             # ReLU/BN backward of layer 1 + dW1 = dZ1^T X in one launch (dZ1 never written). Data parallel over peer
             # memory: everything but layer 1's gradient is final by now (segments W2 .. Wh of the flat buffer) and goes
             # to the peers from extra workgroups of this very launch, so its wire time runs under the kernel
@@ -675,33 +601,20 @@ class Learner:
             if self.xgmi is not None:
                 if self._push_desc is None:
                     self._push_desc = self.xgmi.push_desc()
-                push, pushed_lo = _lib.C.byref(self._push_desc), seg["W2"].offset
+                push, self._pushed_lo = _lib.C.byref(self._push_desc), seg["W2"].offset
             check(f.naf_bn_relu_bwd_wgrad_push(
                 ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                 ptr(self.A1[0]), H, t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]),
                 gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, gp + 4 * seg["W1"].offset,
                 self.partials.data_ptr() + 4 * self._gb_blocks if self.fold_norm else None,
                 ptr(self.step_dev) if self.fold_norm else None, B, H, push, gp if push is not None else None,
-                pushed_lo or 0, P if push is not None else 0, st), "bn_relu_bwd_wgrad")
+                self._pushed_lo or 0, P if push is not None else 0, st), "bn_relu_bwd_wgrad")
         else:
             check(f.naf_bn_relu_bwd(
                 ptr(self.dA1), H, ptr(self.G1[0]), H, t2p + 4 * seg["b1"].offset, ptr(self.A1[0]), H,
                 t2p + 4 * seg["g1"].offset, ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.dZ1), H,
                 gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset, B, H, st), "bn_relu_bwd(1)")
             torch.mm(self.dZ1.t(), self._x2(rows)[0], out=self.gW1)
-        if self.world_size > 1 or os.environ.get("NAF_FORCE_ALLREDUCE") == "1":
-            # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
-            # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
-            if self.xgmi is not None:
-                # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
-                self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=pushed_lo)
-                if not defer:
-                    self.optimizer_step(norm_ready=True)
-                return
-            all_reduce_flat_grad(self.grad, self.pg)
-        if defer:
-            return                       # the next learn_rows(pending=True) carries the step
-        self.optimizer_step(norm_ready=self.fold_norm)
 
     def optimizer_step(self, norm_ready: Optional[bool] = None) -> None:
         """clip_grad_norm_(params, 1) + Adam.step() + soft_update on the flat buffers: 2 launches (1 when the
@@ -748,8 +661,8 @@ class ActPath:
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)   # noise stream position (uint64 on device)
         # one launch for the whole act() (csrc/policy_act.hip) when the shapes are the framework's (H = 256, S <= 32);
-        # NAF_ACT_FUSED=0 keeps the seven-launch path (3 GEMMs, 2 BN kernels, noise, counter)
-        self.fused = lay.H == 256 and lay.S <= 32 and os.environ.get("NAF_ACT_FUSED", "1") != "0"
+        # other shapes take the seven-launch path (3 GEMMs, 2 BN kernels, noise, counter)
+        self.fused = lay.H == 256 and lay.S <= 32
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_io = bool(host_io) and self.fused
         if self.host_io:

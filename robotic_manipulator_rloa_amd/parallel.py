@@ -127,8 +127,18 @@ class XgmiAllReduce:
             if rank == 0:
                 import sys
                 print(f"[xgmi] one-shot all-reduce disabled ({why or 'a peer failed'}); using RCCL", file=sys.stderr)
+            # the teardown's barrier runs on EVERY rank, also on one whose create failed (null handle, no communicator):
+            # a rank that skipped it would pair the others' barrier with its next collective — the RCCL gradient all-reduce
+            # this very fallback leads to
             if comm is not None:
-                comm.close()
+                lib.naf_xgmi_disconnect(handle)
+            try:
+                dist.barrier(group=group)
+            except Exception:
+                pass
+            if comm is not None:
+                lib.naf_xgmi_destroy(handle)
+                comm.handle = None
             return None
         return comm
 

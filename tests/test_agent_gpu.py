@@ -207,10 +207,9 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 from test_learner_gpu import _kuka_learner_and_replay
 from robotic_manipulator_rloa_amd.engine import TrainChunk
 res = []
-os.environ["NAF_NO_FOLD_NORM"] = "1"      # both runs take the gradient norm with the same (post-all-reduce) kernel
-for force in ("0", "1"):
-    os.environ["NAF_FORCE_ALLREDUCE"] = force
-    L, buf = _kuka_learner_and_replay(5000, 256, seed_data=5)
+for force in (False, True):
+    # both runs take the gradient norm with the same (post-all-reduce) kernel
+    L, buf = _kuka_learner_and_replay(5000, 256, seed_data=5, learner_kw=dict(_fold_norm=False, _force_allreduce=force))
     chunk = TrainChunk(L, buf, 4)
     chunk.capture()                        # with force=1 the RCCL all-reduce is a node of the captured graph
     for _ in range(3):
@@ -363,7 +362,7 @@ def test_host_vector_env_training_end_to_end(scratch_cwd, async_policy):
         vec.close()
 
 
-@pytest.mark.parametrize("world,fuse", [(2, "l1,b2,gb,s3"), (4, None)])
+@pytest.mark.parametrize("world,fuse", [(2, "columns"), (4, None)])
 def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse):
     """csrc/xgmi_reduce.hip with W > 1 on the one GPU available: W processes on cuda:0 (tests/xgmi_worker.py) map each
     other's receive slabs through hipIpc and run the one-shot all-reduce eagerly, inside a captured graph and under

@@ -539,3 +539,36 @@ def test_framework_many_env_arguments_without_a_gpu(monkeypatch):
         f.run_training(3, 10, n_envs=4)          # no agent yet
     f.delete_environment()
     assert f._env_factory is None
+
+
+def test_no_kernel_spills_to_scratch_and_the_switch_list_is_short():
+    """nothing in libnaf_hip.so may keep values in scratch memory (private_segment_fixed_size, as hipcc's
+    -Rpass-analysis=kernel-resource-usage reports it for every kernel at build time -> csrc/libnaf_hip.so.usage.json), and the
+    product reads at most 8 NAF_* environment switches — the ones DESIGN.md section 4c documents."""
+    import json
+    from robotic_manipulator_rloa_amd import _lib
+    _lib.load()
+    if not os.path.exists(_lib.USAGE_PATH):
+        _lib.build_library(force=True)
+    usage = json.load(open(_lib.USAGE_PATH))
+    assert len(usage) >= 60, "resource report looks truncated"
+    spilling = {k: v for k, v in usage.items() if v.get("scratch_bytes_per_lane", 0) or v.get("vgpr_spills", 0)}
+    assert not spilling, spilling
+    for need in ("gemm_bundle_kernel", "bb_layer2_head_kernel", "replay_gather_rows_kernel", "naf_head_kernel", "adam_polyak_kernel",
+                 "synth_env_step_kernel", "policy_act_kernel", "xgmi_allreduce_kernel"):
+        assert any(need in k for k in usage), need
+    pkg = os.path.join(ROOT, "robotic_manipulator_rloa_amd")
+    names = set()
+    for dirpath, _, files in os.walk(pkg):
+        if os.sep + "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                names |= set(re.findall(r'(?:environ\.get\(|getenv\(|environ\[|NAF_ENV_INT\()\s*["\'](NAF_[A-Z0-9_]+)["\']', src))
+    documented = {"NAF_FUSE", "NAF_DEFER_ADAM", "NAF_XGMI", "NAF_XGMI_FREE_SLAB", "NAF_BLAS_DEFAULT", "NAF_BLAS_TUNING_FILE",
+                  "NAF_BUILD_DEFINES", "NAF_LOG_FILE"}
+    assert names <= documented, names - documented
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for n in names:
+        assert n in design, f"{n} is read by the product but not documented in DESIGN.md"
