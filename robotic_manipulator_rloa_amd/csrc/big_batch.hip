@@ -432,7 +432,7 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
         float2 av = make_float2(0.f, 0.f);
         float dv = 0.f;
         if (wq == 0) av = F.partials1[(int64_t)(lane < F.NB1 ? lane : 0) * F.H + colc];
-        else dv = F.dz2_col_partials[(int64_t)(lane < F.NB ? lane : 0) * F.H + colc];
+        else if (F.NB > 0) dv = F.dz2_col_partials[(int64_t)(lane < F.NB ? lane : 0) * F.H + colc];   // (NB = 0: no such array)
         const float invstd = F.save_invstd[colc], gm = F.gamma[colc];
         const float sxk = F.mom[kc], wck = F.wc[(int64_t)colc * F.KP + kc];
         float g2 = 0.f, b2 = 0.f;
