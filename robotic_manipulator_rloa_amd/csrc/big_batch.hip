@@ -372,7 +372,7 @@ struct BbSlabs {
     BbSlabSeg seg[2];
     int n_seg, n_finish_blocks;
 };
-#define BB_MAX_SLABS 8
+#define BB_MAX_SLABS 16
 struct FinishArgs {
     const float* p_slabs;
     int KP, K;
