@@ -36,32 +36,76 @@
 static_assert(GP_THREADS == GB_THREADS, "the fold / poll helpers of bn2bwd_fold.h run on this workgroup");
 static_assert(64 * GP_LDA <= GP_PANEL, "k-contiguous A panel fits a panel slot");
 
-struct GpDesc {
+// One product, exactly 64 bytes on a 64-byte boundary inside the kernel arguments: `bundle.d[gi]` with a run-time gi is then ONE
+// s_load_dwordx16. (As a 88-byte struct whose fields were fetched where first used — behind the branches of gp_load — a wave
+// spent 1.7 us on five dependent scalar round trips before it requested its first panel, and again in every trip of the loop:
+// benchmarks/kernel_timeline.py, GP_TL_STARTUP.)
+#define GP_F_AK 1
+#define GP_F_PRO 2
+#define GP_F_EPI 4
+struct __attribute__((aligned(64))) GpDesc {
     const float* A;   // a_kmajor ? [K][M] : [M][K]
     const float* B;   // [K][N]
-    float* C;         // [M][N] (slab s at C + s * c_split_stride); NULL with the epilogue
-    int M, N, K, lda, ldb, ldc, a_kmajor, has_pro, has_epi;
-    int64_t c_split_stride;
+    float* C;         // [M][N] (slab s at C + s * cstride); NULL with the epilogue
+    int M, N, lda, ldb, ldc, kper, flags, cstride;    // kper = K / k_split: K range s is [s kper, (s + 1) kper)
+    int pad[2];
 };
+static_assert(sizeof(GpDesc) == 64, "one s_load_dwordx16");
+// the desc BY VALUE, all of it requested now (the empty asm pins every field: nothing is fetched later, behind a branch)
+__device__ __forceinline__ static GpDesc gp_desc(const GpDesc* d, int gi) {
+    GpDesc D = d[__builtin_amdgcn_readfirstlane(gi)];     // (uniform by construction: say so, or the fetch becomes a vector load)
+    asm volatile("" ::"s"(D.A), "s"(D.B), "s"(D.C), "s"(D.M), "s"(D.N), "s"(D.lda), "s"(D.ldb), "s"(D.ldc), "s"(D.kper), "s"(D.flags),
+                 "s"(D.cstride));
+    return D;
+}
+// a block = one packed word: gi (2 bits) | bm << 2 (8) | bn << 10 (6) | K range << 16 (8); -1: end of the list
+#define GP_CODE(gi, bm, bn, s) ((gi) | ((bm) << 2) | ((bn) << 10) | ((s) << 16))
+#define GP_MAX_WG_IN_ARGS 256
 struct GpBundle {
     GpDesc d[NAF_GEMM_BUNDLE_MAX];
     naf_gemm_bn2bwd_t pro;    // ONE prologue for every product flagged has_pro (they read the same dY2 / Z2)
     naf_gemm_l1bwd_t epi;     // of the product flagged has_epi
-    const int4* plan;         // [n_wg][NAF_GEMM_P_MAX_BLOCKS]: {gi (-1: end), bm | bn << 16, k_lo | k_hi << 16, slab}
+    const int* plan;          // [n_wg][NAF_GEMM_P_MAX_BLOCKS] block codes
     int n, n_fold, any_pro;
+    // the FIRST block of every workgroup rides in the kernel arguments (n_wg <= 256): its panels are requested two dependent
+    // scalar loads after the wave starts instead of three, one of them a miss in L2 (the plan in memory: 1.5 us before the first
+    // byte was asked for — benchmarks/kernel_timeline.py)
+    int first[GP_MAX_WG_IN_ARGS];
 };
 
 struct GpRegs {
     f32x4 a[4], z[4], b[4];
 };
+
+// development aid (NAF_BUILD_DEFINES=-DNAF_TIMELINE): 16 wall-clock marks per workgroup — 0 entry, 1 first loads requested,
+// 2 constants in LDS, then per trip of the loop (while slots last) 3 + 3 j: chunk stored + next requested, 4 + 3 j: MFMAs (and
+// the block's end) done, 5 + 3 j: behind the barrier; 15: exit. naf_timeline_read(2048 + w) copies workgroups w and w + 1.
+#define GP_TL_WGS 512
+#ifdef NAF_TIMELINE
+__device__ long long g_tl_gp[GP_TL_WGS][NAF_TL_SLOTS];
+#define GP_TL(slot)                                                                                              \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < GP_TL_WGS && (slot) < NAF_TL_SLOTS) g_tl_gp[blockIdx.x][(slot)] = wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+int naf_tl_read_gp(int w, long long* out) {
+    if (w < 0 || w + 2 > GP_TL_WGS) return NAF_ERR_ARG;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl_gp), 2 * NAF_TL_SLOTS * sizeof(long long),
+                                    (size_t)w * NAF_TL_SLOTS * sizeof(long long), hipMemcpyDeviceToHost);
+}
+#else
+#define GP_TL(slot) do { } while (0)
+int naf_tl_read_gp(int, long long*) { return NAF_ERR_STATE; }
+#endif
 struct GpUnit {            // one chunk of one block (all fields wave-uniform)
     int gi, m0, n0, k0, k_hi, slab, first, last;
 };
 
 // ---- global -> registers: the chunk's panels, 4 float4 per thread and panel, every address part that can be on the scalar unit
 __device__ __forceinline__ static void gp_load(GpRegs& R, const GpDesc& D, const naf_gemm_bn2bwd_t& P, const GpUnit& U, int tid) {
-    const bool pro = D.has_pro != 0;
-    if (D.a_kmajor) {      // [K][M]: k = k0 + (tid >> 4) + 32 i, columns m0 + 4 (tid & 15) .. +3; rows past the K range read as 0
+    const bool pro = (D.flags & GP_F_PRO) != 0;
+    if (D.flags & GP_F_AK) {      // [K][M]: k = k0 + (tid >> 4) + 32 i, columns m0 + 4 (tid & 15) .. +3; rows past the K range read as 0
         const unsigned ld4 = (unsigned)D.lda * 4u;
         const int c = U.m0 + 4 * (tid & 15);
         const unsigned voff = c < D.M ? (unsigned)(tid >> 4) * ld4 + (unsigned)c * 4u : 0x7f000000u;
@@ -96,12 +140,13 @@ __device__ __forceinline__ static void gp_load(GpRegs& R, const GpDesc& D, const
 }
 
 // ---- registers -> LDS, dY2 -> dZ2 on the way (cst: [4][256] = mean, k1, k1 c1, invstd k1 c2 per layer-2 feature)
-__device__ __forceinline__ static void gp_store(const GpRegs& R, const GpDesc& D, const GpUnit& U, float* sA, float* sB,
+__device__ __forceinline__ static void gp_store(const GpRegs& R, const int flags, const GpUnit& U, float* sA, float* sB,
                                                 const float* cst, int tid) {
+    const bool a_kmajor = (flags & GP_F_AK) != 0;
     f32x4 va[4] = {R.a[0], R.a[1], R.a[2], R.a[3]};
-    if (D.has_pro) {
+    if (flags & GP_F_PRO) {
         // the thread's four floats are four consecutive FEATURES: of the block's columns (k-major A) or of the chunk's k (k-contiguous)
-        const int ci = D.a_kmajor ? U.m0 + 4 * (tid & 15) : U.k0 + 4 * (tid & 31);
+        const int ci = a_kmajor ? U.m0 + 4 * (tid & 15) : U.k0 + 4 * (tid & 31);
         const f32x4 mean = *(const f32x4*)(cst + ci), k1 = *(const f32x4*)(cst + 256 + ci), kc1 = *(const f32x4*)(cst + 512 + ci),
                     q = *(const f32x4*)(cst + 768 + ci);
 #pragma unroll
@@ -109,7 +154,7 @@ __device__ __forceinline__ static void gp_store(const GpRegs& R, const GpDesc& D
 #pragma unroll
             for (int j = 0; j < 4; ++j) va[i][j] = __builtin_fmaf(k1[j], va[i][j], -kc1[j]) - (R.z[i][j] - mean[j]) * q[j];
     }
-    if (D.a_kmajor) {
+    if (a_kmajor) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(f32x4*)(sA + ((tid >> 4) + 32 * i) * GP_LDK + 4 * (tid & 15)) = va[i];
     } else {
@@ -121,113 +166,137 @@ __device__ __forceinline__ static void gp_store(const GpRegs& R, const GpDesc& D
 }
 
 // ---- one chunk of MFMAs: wave (wm, wn) owns rows 16 wm .. +15 x columns 32 wn .. +31 (two 16-wide tiles), lane (r, g) takes
-// k = kk + 4 g .. +3 of row / column r of each operand: one A fragment feeds both tiles
+// k = kk + 4 g .. +3 of row / column r of each operand: one A fragment feeds both tiles. The fragments of step kk + 16 are read
+// BEFORE the MFMAs of step kk issue (software pipeline, fully unrolled): with the workgroup's halves in opposite phases a wave is
+// alone on its SIMD while it multiplies, and an in-order wave that reads, waits and then multiplies left the matrix pipe idle for
+// every LDS round trip (2.3 - 2.7 us per chunk where the MFMAs take 0.9: benchmarks/kernel_timeline.py).
+struct GpFrag {
+    f32x4 a, b0, b1;
+};
+template <bool AK>
+__device__ __forceinline__ static GpFrag gp_frag(const float* __restrict__ sA, const float* __restrict__ sB, int wm, int wn, int r, int g, int kk) {
+    GpFrag f;
+    if (AK) {
+        const float* q = sA + (kk + 4 * g) * GP_LDK + 16 * wm + r;
+        f.a = (f32x4){q[0], q[GP_LDK], q[2 * GP_LDK], q[3 * GP_LDK]};
+    } else {
+        f.a = *(const f32x4*)(sA + (16 * wm + r) * GP_LDA + kk + 4 * g);
+    }
+    const float* q = sB + (kk + 4 * g) * GP_LDK + 32 * wn + r;
+    f.b0 = (f32x4){q[0], q[GP_LDK], q[2 * GP_LDK], q[3 * GP_LDK]};
+    f.b1 = (f32x4){q[16], q[GP_LDK + 16], q[2 * GP_LDK + 16], q[3 * GP_LDK + 16]};
+    return f;
+}
 template <bool AK>
 __device__ __forceinline__ static void gp_mfma(const float* __restrict__ sA, const float* __restrict__ sB, int wm, int wn, int r, int g,
                                                f32x4 (&acc)[2][2]) {
-#pragma unroll 2
+    GpFrag cur = gp_frag<AK>(sA, sB, wm, wn, r, g, 0);
+#pragma unroll
     for (int kk = 0; kk < GP_KC; kk += 16) {
-        f32x4 a, b0, b1;
-        if (AK) {
-            const float* q = sA + (kk + 4 * g) * GP_LDK + 16 * wm + r;
-            a = (f32x4){q[0], q[GP_LDK], q[2 * GP_LDK], q[3 * GP_LDK]};
-        } else {
-            a = *(const f32x4*)(sA + (16 * wm + r) * GP_LDA + kk + 4 * g);
-        }
-        const float* q = sB + (kk + 4 * g) * GP_LDK + 32 * wn + r;
-        b0 = (f32x4){q[0], q[GP_LDK], q[2 * GP_LDK], q[3 * GP_LDK]};
-        b1 = (f32x4){q[16], q[GP_LDK + 16], q[2 * GP_LDK + 16], q[3 * GP_LDK + 16]};
+        GpFrag nxt = cur;
+        if (kk + 16 < GP_KC) nxt = gp_frag<AK>(sA, sB, wm, wn, r, g, kk + 16);
+        // (scheduling fences: left to itself the scheduler sinks every read to just in front of the two MFMAs that use it —
+        //  fewest live registers — and each pair of MFMAs then waits out a whole LDS round trip)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            acc[0][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b0[c], acc[0][c & 1], 0, 0, 0);
-            acc[1][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b1[c], acc[1][c & 1], 0, 0, 0);
+            acc[0][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[c], cur.b0[c], acc[0][c & 1], 0, 0, 0);
+            acc[1][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[c], cur.b1[c], acc[1][c & 1], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
 }
 
 // ---- epilogue of a dA1 tile: the batch pass of layer 1's backward on the 64 rows x 64 layer-1 features in registers
-// (csrc/gemm_bundle.hip, gemm_l1bwd_epilogue, for a 32 x 32 block): z = X W1^T recomputed on MFMA by the waves that hold the
-// tile, xhat, dy = ReLU'(A1) dA1, the block sums (sum dy, sum dy xhat) per column -> partials[M/64][N] and the block's share of
-// P = dY^T X -> p_slabs[M/64][N][KP] (one 16 x 16 tile of it per wave). Everything it reads from memory was requested at the
-// start of the kernel (gp_epi_prefetch): the plan puts a workgroup's dA1 block first.
+// (csrc/gemm_bundle.hip, gemm_l1bwd_epilogue, for a 32 x 32 block): xhat from z = X W1^T recomputed on MFMA, dy = ReLU'(A1) dA1,
+// the block sums (sum dy, sum dy xhat) per column -> partials[M/64][N] and the block's share of P = dY^T X -> p_slabs[M/64][N][KP]
+// (one 16 x 16 tile of it per wave). What does NOT depend on dA1 happens at the START of the kernel, while the workgroup waits
+// for the BatchNorm-backward constants anyway (gp_epi_early): the rows and W1 go to an LDS region of their own, xhat of the
+// wave's two tiles and the ReLU mask stay in registers — the plan puts a workgroup's dA1 block first. Behind the tile's last
+// MFMA only dy, its sums and the P product are left (two barriers; the first version staged and recomputed there: 2.8 us).
 struct GpEpiRegs {
-    f32x4 x;           // one float4 of the 64 x KP tile of minibatch rows (thread < 16 KP)
-    float w[4];        // four scalars of the 64 x K tile of W1
-    float a1[2][4];    // A1 at the lane's C/D elements (the ReLU mask)
-    float mean[2], invstd[2], bias[2];
+    float xh[2][4];    // xhat at the lane's C/D elements
+    float a1[2][4];    // A1 there (the ReLU mask)
 };
-__device__ __forceinline__ static void gp_epi_prefetch(const GpDesc& D, const naf_gemm_l1bwd_t& E, int m0, int n0, int tid, int wm, int wn,
-                                                       int r, int g, GpEpiRegs& R) {
-    const int KP = E.kp, q4 = KP >> 2;
-    const int xr = KP == 24 ? tid / 6 : tid >> 3, xq = tid - xr * q4;
-    R.x = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (xr < 64) R.x = ((const f32x4*)(E.x + (int64_t)(m0 + xr) * E.ldx))[xq];
+__device__ static inline void gp_epi_early(const GpDesc& D, const naf_gemm_l1bwd_t& E, int m0, int n0, float* sXW, int tid, int wm, int wn,
+                                           int r, int g, GpEpiRegs& R) {
+    const int KP = E.kp, XS = KP + 4, q4 = KP >> 2;
+    float* sX = sXW;                               // [64 rows][XS]
+    float* sW = sX + 64 * XS;                      // [64 columns][XS]
+    {
+        const int xr = KP == 24 ? tid / 6 : tid >> 3, xq = tid - xr * q4;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (xr < 64) x = ((const f32x4*)(E.x + (int64_t)(m0 + xr) * E.ldx))[xq];
+        float w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + GP_THREADS * i;
-        const int c = KP == 24 ? e / 24 : e >> 5, k = e - c * KP;
-        R.w[i] = (c < 64 && k < E.K) ? E.W[(int64_t)(n0 + c) * E.K + k] : 0.f;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + GP_THREADS * i;
+            const int c = KP == 24 ? e / 24 : e >> 5, k = e - c * KP;
+            w[i] = (c < 64 && k < E.K) ? E.W[(int64_t)(n0 + c) * E.K + k] : 0.f;
+        }
+        float mean[2], invstd[2], bias[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int col = n0 + 32 * wn + 16 * t + r;
+        for (int t = 0; t < 2; ++t) {
+            const int col = n0 + 32 * wn + 16 * t + r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) R.a1[t][e] = E.a1[(int64_t)(m0 + 16 * wm + 4 * g + e) * E.lda1 + col];
-        R.mean[t] = E.save_mean[col];
-        R.invstd[t] = E.save_invstd[col];
-        R.bias[t] = E.bias[col];
+            for (int e = 0; e < 4; ++e) R.a1[t][e] = E.a1[(int64_t)(m0 + 16 * wm + 4 * g + e) * E.lda1 + col];
+            mean[t] = E.save_mean[col];
+            invstd[t] = E.save_invstd[col];
+            bias[t] = E.bias[col];
+        }
+        if (xr < 64) *(f32x4*)(sX + xr * XS + 4 * xq) = x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + GP_THREADS * i;
+            const int c = KP == 24 ? e / 24 : e >> 5, k = e - c * KP;
+            if (c < 64) sW[c * XS + k] = w[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 32; kk += 16) {
+                if (kk < KP) {                          // KP = 24: lane groups 2, 3 of the second step are past the row: zeros
+                    const bool in = kk + 4 * g < KP;
+                    const int ko = in ? kk + 4 * g : 0;
+                    f32x4 a = *(const f32x4*)(sX + (16 * wm + r) * XS + ko);
+                    const f32x4 b = *(const f32x4*)(sW + (32 * wn + 16 * t + r) * XS + ko);
+                    if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], z, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) R.xh[t][e] = ((z[e] + bias[t]) - mean[t]) * invstd[t];
+        }
     }
 }
 // Split K (the dA1 product cut into two 128-feature halves where the batch gives too few tiles to fill the chip): everything the
 // pass produces is LINEAR in dA1 — dy = mask * dA1, the two column sums, P = dY^T X — so each half leaves its own "block" of
 // partials / p_slabs (block slab * M/64 + bm) and the finish launch, which adds blocks in index order anyway, adds the halves.
 __device__ static inline void gp_epilogue(const GpDesc& D, const naf_gemm_l1bwd_t& E, int m0, int n0, int slab, const f32x4 (&acc)[2],
-                                          float* buf, int tid, int wave, int wm, int wn, int r, int g, const GpEpiRegs& R) {
-    const int KP = E.kp, XS = KP + 4, q4 = KP >> 2;
+                                          float* buf, const float* sXW, int tid, int wave, int wm, int wn, int r, int g, const GpEpiRegs& R) {
+    const int KP = E.kp, XS = KP + 4;
     const int bm = slab * (D.M >> 6) + (m0 >> 6);
-    float* sX = buf;                               // [64 rows][XS]
-    float* sW = sX + 64 * XS;                      // [64 columns][XS]
-    float* sDY = sW + 64 * XS;                     // [64 rows][65]
-    float2* sRed = (float2*)(sDY + 64 * 65);       // [4 row tiles][64 columns] (64 * 65 and 128 XS are even: 8-byte aligned)
+    const float* sX = sXW;
+    float* sDY = buf;                              // [64 rows][65]
+    float2* sRed = (float2*)(sDY + 64 * 65);       // [4 row tiles][64 columns]
     __syncthreads();                               // every wave is past its last fragment read of this buffer
-    {
-        const int xr = KP == 24 ? tid / 6 : tid >> 3, xq = tid - xr * q4;
-        if (xr < 64) *(f32x4*)(sX + xr * XS + 4 * xq) = R.x;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + GP_THREADS * i;
-            const int c = KP == 24 ? e / 24 : e >> 5, k = e - c * KP;
-            if (c < 64) sW[c * XS + k] = R.w[i];
-        }
-    }
-    __syncthreads();
-    float s_dy[2] = {0.f, 0.f}, s_dx[2] = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 32; kk += 16) {
-            if (kk < KP) {                          // KP = 24: lane groups 2, 3 of the second step are past the row: zeros
-                const bool in = kk + 4 * g < KP;
-                const int ko = in ? kk + 4 * g : 0;
-                f32x4 a = *(const f32x4*)(sX + (16 * wm + r) * XS + ko);
-                const f32x4 b = *(const f32x4*)(sW + (32 * wn + 16 * t + r) * XS + ko);
-                if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], z, 0, 0, 0);
-            }
-        }
+        float s_dy = 0.f, s_dx = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = ((z[e] + R.bias[t]) - R.mean[t]) * R.invstd[t];
             const float dy = R.a1[t][e] > 0.f ? acc[t][e] : 0.f;
             sDY[(16 * wm + 4 * g + e) * 65 + 32 * wn + 16 * t + r] = dy;
-            s_dy[t] += dy;
-            s_dx[t] += dy * xh;
+            s_dy += dy;
+            s_dx += dy * R.xh[t][e];
         }
-        s_dy[t] = naf_xor32_add(naf_xor16_add(s_dy[t]));     // the wave's other row groups of the same column
-        s_dx[t] = naf_xor32_add(naf_xor16_add(s_dx[t]));
-        if (g == 0) sRed[wm * 64 + 32 * wn + 16 * t + r] = make_float2(s_dy[t], s_dx[t]);
+        s_dy = naf_xor32_add(naf_xor16_add(s_dy));           // the wave's other row groups of the same column
+        s_dx = naf_xor32_add(naf_xor16_add(s_dx));
+        if (g == 0) sRed[wm * 64 + 32 * wn + 16 * t + r] = make_float2(s_dy, s_dx);
     }
     __syncthreads();
     if (tid < 64) {                                           // the four row tiles in order
@@ -261,7 +330,7 @@ __device__ static inline void gp_epilogue(const GpDesc& D, const naf_gemm_l1bwd_
 // ---- C tile -> memory (rows past M end the resource, a column past N gets an offset past everything: dropped by the hardware)
 __device__ __forceinline__ static void gp_store_c(const GpDesc& D, const GpUnit& U, const f32x4 (&acc)[2], int wm, int wn, int r, int g) {
     const unsigned ldc4 = (unsigned)D.ldc * 4u;
-    const __amdgpu_buffer_rsrc_t cr = naf_buf(D.C + (int64_t)U.slab * D.c_split_stride, (unsigned)D.M * ldc4);
+    const __amdgpu_buffer_rsrc_t cr = naf_buf(D.C + (int64_t)U.slab * D.cstride, (unsigned)D.M * ldc4);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int cn = U.n0 + 32 * wn + 16 * t + r;
@@ -271,117 +340,136 @@ __device__ __forceinline__ static void gp_store_c(const GpDesc& D, const GpUnit&
     }
 }
 
-__device__ __forceinline__ static GpUnit gp_unit(const GpBundle& Bn, const int4 e, int chunk) {
+__device__ __forceinline__ static GpUnit gp_unit(const int kper, const int code, int chunk) {
     GpUnit U;
-    U.gi = e.x;
-    U.m0 = (e.y & 0xffff) * GP_BM;
-    U.n0 = (e.y >> 16) * GP_BN;
-    const int k_lo = e.z & 0xffff;
-    U.k_hi = e.z >> 16;
+    U.gi = code & 3;
+    U.m0 = ((code >> 2) & 255) * GP_BM;
+    U.n0 = ((code >> 10) & 63) * GP_BN;
+    U.slab = (code >> 16) & 255;
+    const int k_lo = U.slab * kper;
+    U.k_hi = k_lo + kper;
     U.k0 = k_lo + chunk * GP_KC;
-    U.slab = e.w;
     U.first = chunk == 0;
     U.last = U.k0 + GP_KC >= U.k_hi;
     return U;
 }
 
+#define GP_XW_FLOATS (2 * 64 * 36)      // the epilogue's rows + W1 tile (KP <= 32)
+#define GP_LDS_FLOATS (2 * GP_BUF + 4 * 256 + GP_XW_FLOATS)
+// one trip's three jobs; the two halves of the workgroup run them in opposite order (see the kernel)
+#define GP_STORE_AND_REQUEST()                                                               \
+    do {                                                                                     \
+        gp_store(R, flags_cur, Ucur, sA, sB, cst, tid);                                      \
+        if (have_next) gp_load(R, Dn, bundle.pro, Unext, tid);                               \
+    } while (0)
+#define GP_COMPUTE(UU, FL, BUFI)                                                             \
+    do {                                                                                     \
+        const float* pA = smem + (BUFI) * GP_BUF;                                            \
+        const float* pB = pA + GP_PANEL;                                                     \
+        if ((UU).first) {                                                                    \
+            acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = (f32x4){0.f, 0.f, 0.f, 0.f};     \
+        }                                                                                    \
+        if ((FL) & GP_F_AK) gp_mfma<true>(pA, pB, wm, wn, r, g, acc);                        \
+        else gp_mfma<false>(pA, pB, wm, wn, r, g, acc);                                      \
+        if ((UU).last) {                                                                     \
+            const GpDesc Dp = gp_desc(bundle.d, (UU).gi);     /* once per block: where C goes */ \
+            const f32x4 c[2] = {acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]};               \
+            if (Dp.C) gp_store_c(Dp, (UU), c, wm, wn, r, g);                                 \
+            if ((FL) & GP_F_EPI)                                                             \
+                gp_epilogue(Dp, bundle.epi, (UU).m0, (UU).n0, (UU).slab, c, smem + (BUFI) * GP_BUF, sXW, tid, wave, wm, wn, r, g, ER); \
+        }                                                                                    \
+    } while (0)
+
 __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bundle_p_kernel(const GpBundle bundle) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][GP_BUF] panels | [4][256] BatchNorm-backward constants
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][GP_BUF] panels | [4][256] BatchNorm-backward constants | X, W1
     float* const cst = smem + 2 * GP_BUF;
+    float* const sXW = cst + 4 * 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4, wm = wave & 3, wn = wave >> 2;
-    const int4* __restrict__ plan = bundle.plan + (int64_t)blockIdx.x * NAF_GEMM_P_MAX_BLOCKS;
-
-    // the first unit's panels fly before anything else happens
-    int bi = 0, chunk = 0;                 // position of the unit whose loads are issued next
-    int4 ent = plan[0];
-    GpRegs R;
-    GpEpiRegs ER;
-    const bool have_work = ent.x >= 0;
-    GpUnit Unext = gp_unit(bundle, have_work ? ent : make_int4(0, 0, 0, 0), 0);
-    if (have_work) {
-        gp_load(R, bundle.d[Unext.gi], bundle.pro, Unext, tid);
-        if (bundle.d[Unext.gi].has_epi) gp_epi_prefetch(bundle.d[Unext.gi], bundle.epi, Unext.m0, Unext.n0, tid, wm, wn, r, g, ER);
-    }
-    // the launch's first workgroups fold the BatchNorm-backward block sums once for everybody (buffer 1 as scratch: the first
-    // chunk goes to buffer 0), then EVERY workgroup that stages dZ2 takes the 256 columns' constants — they are the same for all
-    // of its blocks
+    const int* __restrict__ plan = bundle.plan + (int64_t)blockIdx.x * NAF_GEMM_P_MAX_BLOCKS;
+    GP_TL(0);
+    // The launch's first workgroups fold the BatchNorm-backward block sums for everybody, BEFORE anything of their own: every
+    // workgroup of the launch waits for their records (buffer 1 as scratch: the first chunk goes to buffer 0)
     if (bundle.n_fold && (int)blockIdx.x < bundle.n_fold) {
         gemm_bn2bwd_fold_block(bundle.pro, (int)blockIdx.x, tid, smem + GP_BUF);
         __syncthreads();
     }
+    // the first unit's panels fly before anything else happens
+    int bi = 0, chunk = 0;                 // position of the unit whose loads are issued next
+    int code = __builtin_amdgcn_readfirstlane((int)blockIdx.x < GP_MAX_WG_IN_ARGS ? bundle.first[blockIdx.x] : plan[0]);
+    GpRegs R;
+    GpEpiRegs ER;
+    const bool have_work = code >= 0;
+    GpDesc Dn = gp_desc(bundle.d, have_work ? code & 3 : 0);       // the product of the unit requested next
+    GpUnit Unext = gp_unit(Dn.kper, have_work ? code : 0, 0);
+    if (have_work) gp_load(R, Dn, bundle.pro, Unext, tid);
+    GP_TL(1);
+    // a dA1 block leads its workgroup's list: what its epilogue needs besides dA1 itself, now, under the wait for the constants
+    if (have_work && (Dn.flags & GP_F_EPI)) gp_epi_early(Dn, bundle.epi, Unext.m0, Unext.n0, sXW, tid, wm, wn, r, g, ER);
+    // EVERY workgroup that stages dZ2 takes the 256 columns' constants — they are the same for all of its blocks
     if (bundle.any_pro) {
         gemm_bn2bwd_wait_constants<false>(bundle.pro, 0, tid, cst);
         __syncthreads();
     }
+    GP_TL(2);
     if (!have_work) return;
 
+    // One flat loop over the units (chunks) of all blocks of the list. In trip u: unit u goes registers -> buffer u & 1, unit u + 1
+    // is requested from memory, unit u - 1 is multiplied out of the other buffer. The two halves of the workgroup take these jobs
+    // in OPPOSITE order — waves 0 .. 3 (one per SIMD) store first, waves 4 .. 7 multiply first — so that one wave of every SIMD
+    // feeds the matrix pipe while its partner moves 64 KB through the LDS store path (all eight storing at once left the pipe idle
+    // for 0.6 - 1.3 us per trip). The buffers differ, so the order inside a wave is free; one barrier per trip.
     f32x4 acc[2][2];
     GpUnit Uprev = Unext;                  // the unit whose MFMAs run in this trip (valid from the second trip on)
+    int flags_prev = 0, flags_cur = 0;
     bool have_prev = false;
+    const bool store_first = wave < 4;
     int u = 0;
     while (true) {
         const GpUnit Ucur = Unext;         // its panels are in R (in flight)
+        flags_cur = Dn.flags;
         float* sA = smem + (u & 1) * GP_BUF;
         float* sB = sA + GP_PANEL;
-        gp_store(R, bundle.d[Ucur.gi], Ucur, sA, sB, cst, tid);
-        // the unit after it: next chunk of the block, or the first chunk of the next block of the list
+        // the unit after it: next chunk of the block, or the first chunk of the next block of the list (its product's
+        // description is requested here, a whole job before gp_load needs it)
         bool have_next = true;
         if (!Ucur.last) {
             ++chunk;
         } else {
             ++bi;
             chunk = 0;
-            ent = bi < NAF_GEMM_P_MAX_BLOCKS ? plan[bi] : make_int4(-1, 0, 0, 0);
-            have_next = ent.x >= 0;
+            code = __builtin_amdgcn_readfirstlane(bi < NAF_GEMM_P_MAX_BLOCKS ? plan[bi] : -1);
+            have_next = code >= 0;
+            if (have_next) Dn = gp_desc(bundle.d, code & 3);
         }
-        if (have_next) {
-            Unext = gp_unit(bundle, ent, chunk);
-            gp_load(R, bundle.d[Unext.gi], bundle.pro, Unext, tid);
-        }
-        if (have_prev) {
-            const float* pA = smem + ((u - 1) & 1) * GP_BUF;
-            const float* pB = pA + GP_PANEL;
-            if (Uprev.first) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            const GpDesc& Dp = bundle.d[Uprev.gi];
-            if (Dp.a_kmajor) gp_mfma<true>(pA, pB, wm, wn, r, g, acc);
-            else gp_mfma<false>(pA, pB, wm, wn, r, g, acc);
-            if (Uprev.last) {
-                const f32x4 c[2] = {acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]};
-                if (Dp.C) gp_store_c(Dp, Uprev, c, wm, wn, r, g);
-                if (Dp.has_epi) gp_epilogue(Dp, bundle.epi, Uprev.m0, Uprev.n0, Uprev.slab, c, smem + ((u - 1) & 1) * GP_BUF, tid, wave, wm, wn, r, g, ER);
+        if (have_next) Unext = gp_unit(Dn.kper, code, chunk);
+#pragma clang loop unroll(disable)
+        for (int ph = 0; ph < 2; ++ph) {   // (a loop, not two copies of the jobs: twice the code spilled registers)
+            if ((ph == 0) == store_first) {
+                GP_STORE_AND_REQUEST();
+                GP_TL(3 + 3 * u);
+            } else if (have_prev) {
+                GP_COMPUTE(Uprev, flags_prev, (u - 1) & 1);
             }
         }
+        GP_TL(4 + 3 * u);
         __syncthreads();                   // chunk u is in LDS for everybody; everybody is done with buffer (u - 1) & 1
+        GP_TL(5 + 3 * u);
         Uprev = Ucur;
+        flags_prev = flags_cur;
         have_prev = true;
         ++u;
         if (!have_next) break;
     }
-    {   // the last unit
-        const float* pA = smem + ((u - 1) & 1) * GP_BUF;
-        const float* pB = pA + GP_PANEL;
-        if (Uprev.first) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        const GpDesc& Dp = bundle.d[Uprev.gi];
-        if (Dp.a_kmajor) gp_mfma<true>(pA, pB, wm, wn, r, g, acc);
-        else gp_mfma<false>(pA, pB, wm, wn, r, g, acc);
-        const f32x4 c[2] = {acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]};
-        if (Dp.C) gp_store_c(Dp, Uprev, c, wm, wn, r, g);
-        if (Dp.has_epi) gp_epilogue(Dp, bundle.epi, Uprev.m0, Uprev.n0, Uprev.slab, c, smem + ((u - 1) & 1) * GP_BUF, tid, wave, wm, wn, r, g, ER);
-    }
+    GP_COMPUTE(Uprev, flags_prev, (u - 1) & 1);        // the last unit
+    GP_TL(15);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-#define GP_LDS_BYTES ((size_t)(2 * GP_BUF + 4 * 256) * sizeof(float))
+#define GP_LDS_BYTES ((size_t)GP_LDS_FLOATS * sizeof(float))
 // more dynamic LDS than the default 64 KB per workgroup: asked for once per process — by the plan call, i.e. when a learner is
 // built, never inside a stream capture
 static int gp_allow_lds() {
@@ -412,6 +500,7 @@ static int gp_check(const naf_gemm_desc_t* descs, int n, bool planning) {
         if (s.lda < (s.a_kmajor ? s.M : s.K) || s.ldb < s.N || s.ldc < s.N || (s.lda & 3) || (s.ldb & 3)) return NAF_ERR_ARG;
         if ((((uintptr_t)s.A) & 15) || (((uintptr_t)s.B) & 15)) return NAF_ERR_ARG;
         if (!s.a_kmajor && ((s.K / ksn) % GP_KC)) return NAF_ERR_ARG;     // a k-contiguous A panel is read in whole 128-k chunks
+        if (s.M > 256 * GP_BM || s.N > 64 * GP_BN || ksn > 256 || i > 3) return NAF_ERR_ARG;   // (the packed block codes)
         if (s.pro) {
             const naf_gemm_bn2bwd_t& q = *s.pro;
             if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 || q.npb > 128 ||
@@ -432,7 +521,7 @@ static int gp_check(const naf_gemm_desc_t* descs, int n, bool planning) {
     return NAF_OK;
 }
 
-// The list of blocks every workgroup walks: plan_host[n_wg][NAF_GEMM_P_MAX_BLOCKS] int4 (see GpBundle.plan). Longest blocks first
+// The list of blocks every workgroup walks: plan_host[n_wg][NAF_GEMM_P_MAX_BLOCKS] block codes (GP_CODE). Longest blocks first
 // (the dA1 tiles with their epilogue lead their workgroup's list: the kernel prefetches the epilogue's operands at its start),
 // each to the least-loaded workgroup of the XCD — workgroup w runs on XCD w % 8 under round-robin dispatch; speed only — that
 // already pulls the block's operands: a block ROW of dA1 (an eighth of dY2, Z2, A1 and the minibatch rows per XCD, all of W2),
@@ -454,8 +543,10 @@ extern "C" int naf_gemm_bundle_p_plan(const naf_gemm_desc_t* descs, int n, int n
                     b.gi = i; b.bm = bm; b.bn = bn; b.k_lo = ks * kper; b.k_hi = b.k_lo + kper; b.slab = ks;
                     b.epi = s.epi != nullptr;
                     b.cost = (float)((kper + GP_KC - 1) / GP_KC) + (b.epi ? 0.6f : 0.f) + (s.pro ? 0.1f : 0.f);
-                    if (s.a_kmajor) b.xcd = ksn >= 8 ? ks % 8 : (ks * (8 / ksn) + (bm * tn + bn) % (8 / ksn)) % 8;
-                    else b.xcd = bm % 8;
+                    // batch rows the block reads: its K range (weight gradients) or its block row (dA1); XCD = the eighth of the
+                    // batch they lie in — where naf_bb_layer2_head wrote them (its chunk map for this bundle: contiguous eighths)
+                    const int row0 = s.a_kmajor ? b.k_lo : bm * GP_BM, rows = s.a_kmajor ? s.K : s.M;
+                    b.xcd = (int)(((int64_t)row0 * 8) / rows) & 7;
                     blocks.push_back(b);
                 }
     }
@@ -466,7 +557,7 @@ extern "C" int naf_gemm_bundle_p_plan(const naf_gemm_desc_t* descs, int n, int n
     std::vector<float> load(n_wg, 0.f);
     std::vector<int> count(n_wg, 0);
     std::vector<char> has_epi(n_wg, 0);
-    for (int i = 0; i < n_wg * NAF_GEMM_P_MAX_BLOCKS * 4; ++i) plan_host[i] = (i & 3) == 0 ? -1 : 0;
+    for (int i = 0; i < n_wg * NAF_GEMM_P_MAX_BLOCKS; ++i) plan_host[i] = -1;
     for (const GpBlock& b : blocks) {
         int best = -1, best_any = -1;
         for (int w = 0; w < n_wg; ++w) {
@@ -475,9 +566,8 @@ extern "C" int naf_gemm_bundle_p_plan(const naf_gemm_desc_t* descs, int n, int n
             if ((w & 7) == b.xcd && (best < 0 || load[w] < load[best])) best = w;
         }
         if (best_any < 0) return NAF_ERR_ARG;                        // more blocks than the lists hold
-        if (best < 0 || load[best] > load[best_any] + 1.0f) best = best_any;
-        int32_t* e = plan_host + ((size_t)best * NAF_GEMM_P_MAX_BLOCKS + count[best]) * 4;
-        e[0] = b.gi; e[1] = b.bm | (b.bn << 16); e[2] = b.k_lo | (b.k_hi << 16); e[3] = b.slab;
+        if (best < 0 || load[best] > load[best_any] + 2.0f) best = best_any;
+        plan_host[(size_t)best * NAF_GEMM_P_MAX_BLOCKS + count[best]] = GP_CODE(b.gi, b.bm, b.bn, b.slab);
         load[best] += b.cost;
         ++count[best];
         if (b.epi) has_epi[best] = 1;
@@ -488,19 +578,24 @@ extern "C" int naf_gemm_bundle_p_plan(const naf_gemm_desc_t* descs, int n, int n
     return NAF_OK;
 }
 
-extern "C" int naf_gemm_bundle_p(const naf_gemm_desc_t* descs, int n, const int32_t* plan_dev, int n_wg, void* stream) {
+extern "C" int naf_gemm_bundle_p(const naf_gemm_desc_t* descs, int n, const int32_t* plan_dev, const int32_t* plan_host, int n_wg,
+                                 void* stream) {
     const int rc = gp_check(descs, n, false);
     if (rc != NAF_OK) return rc;
-    if (!plan_dev || ((uintptr_t)plan_dev & 15) || n_wg < 8 || n_wg > 4096) return NAF_ERR_ARG;
+    if (!plan_dev || !plan_host || ((uintptr_t)plan_dev & 15) || n_wg < 8 || n_wg > 4096) return NAF_ERR_ARG;
     GpBundle b;
     memset(&b, 0, sizeof(b));
     b.n = n;
-    b.plan = (const int4*)plan_dev;
+    b.plan = (const int*)plan_dev;
+    for (int w = 0; w < GP_MAX_WG_IN_ARGS; ++w) b.first[w] = w < n_wg ? plan_host[(size_t)w * NAF_GEMM_P_MAX_BLOCKS] : -1;
     for (int i = 0; i < n; ++i) {
         const naf_gemm_desc_t& s = descs[i];
         GpDesc& d = b.d[i];
-        d.A = s.A; d.B = s.B; d.C = s.C; d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc;
-        d.a_kmajor = s.a_kmajor; d.has_pro = s.pro != nullptr; d.has_epi = s.epi != nullptr; d.c_split_stride = s.c_split_stride;
+        d.A = s.A; d.B = s.B; d.C = s.C; d.M = s.M; d.N = s.N; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc;
+        d.flags = (s.a_kmajor ? GP_F_AK : 0) | (s.pro ? GP_F_PRO : 0) | (s.epi ? GP_F_EPI : 0);
+        if (s.c_split_stride > 0x7fffffff) return NAF_ERR_ARG;
+        d.cstride = (int)s.c_split_stride;
+        d.kper = s.K / (s.k_split > 0 ? s.k_split : 1);
         if (s.pro) {
             b.pro = *s.pro;
             b.any_pro = 1;

@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KERNELS = ["bb_layer1", "bb_linear_stats", "bb_layer2_head", "bb_bn_bwd_stage2", "gemm_bundle", "bb_layer1_bwd_finish", "adam_polyak"]
+KERNELS = ["bb_layer1", "bb_linear_stats", "bb_layer2_head", "(unused)", "gemm_bundle", "bb_layer1_bwd_finish", "adam_polyak"]
 MARKS = {
     # (bb_layer1 with the previous update's optimizer step riding on it — every update of a chunk but the first — also leaves raw
     # slots 7 .. 10: operands in LDS | clip scale derived | barrier | parameters evaluated, and 11 / 12: entry / exit of the first
@@ -25,7 +25,7 @@ MARKS = {
     "bb_layer1": ["entry", "operands staged", "statistics from moments", "z tile", "normalise + store"],
     "bb_linear_stats": ["entry", "chunk 0 staged", "chunk 0 MFMA", "chunk 1 staged", "chunk 1 MFMA", "Z2 + statistics partials"],
     "bb_layer2_head": ["entry", "operands + statistics fold", "normalise, V'", "heads MFMA", "halves merged", "NAF head body", "dA2 MFMA + sums", "partials out"],
-    "bb_bn_bwd_stage2": ["entry", "loads + fold", "dz", "column sums"],
+    "(unused)": ["entry"],
     "gemm_bundle": ["entry", "chunk 0 staged", "K loop", "C stored", "layer-1 backward epilogue", "norm partial"],
     "bb_layer1_bwd_finish": ["entry", "loads + folds", "dW1 / slab sums", "norm partial"],
     "adam_polyak": ["entry", "norm folded + update"],

@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 17
+#define NAF_HIP_ABI_VERSION 18
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -305,7 +305,7 @@ int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const floa
  * step_dev (nullable): *step_dev += 1. */
 int naf_bb_layer1_bwd_kp(int K);
 /* segs (HOST array, n_segs <= 2, may be 0): split-K slabs of the bundle's weight gradients (naf_gemm_desc_t.k_split), added in
- * slab order by extra workgroups of the same launch: dst[i] = sum_s src[s * stride + i], i < n (n % 4 == 0, n_slabs <= 16);
+ * slab order by extra workgroups of the same launch: dst[i] = sum_s src[s * stride + i], i < n (n % 4 == 0, n_slabs <= 8);
  * their sums of squares follow the naf_bb_layer1_bwd_finish_blocks(H) entries of sumsq_partials, ceil(n / 1024) entries per
  * segment. */
 typedef struct naf_bb_slab_seg {
@@ -382,18 +382,6 @@ typedef struct naf_gemm_desc {
     const naf_gemm_bn2bwd_t* pro; /* nullable (HOST pointer, copied into the launch) */
 } naf_gemm_desc_t;
 int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
-/* The same products for LARGE batches as persistent workgroups (csrc/gemm_bundle_p.hip): n_wg workgroups (one per CU) each walk a
- * list of 64 x 64 x K-range blocks, K in 128-chunks through two LDS buffers with the next chunk's loads and stores under the
- * current chunk's MFMAs — across block boundaries too. Contract of naf_gemm_bundle with: b_kmajor = 1 and sumsq = NULL for every
- * product; at most one `pro` (shared by every product that names it) and one `epi`; with `epi`: M, N multiples of 64, a
- * k-contiguous A, k_split 1 or 2 ((K / k_split) % 128 == 0), and partials / p_slabs per 64-row block — block index
- * s * (M / 64) + bm for K range s, so naf_bb_layer1_bwd_finish is told nb1 = k_split * M / 64.
- * naf_gemm_bundle_p_plan fills plan_host[n_wg * NAF_GEMM_P_MAX_BLOCKS * 4] (int32) from the SHAPES of descs (pointers are not
- * looked at beyond NULL checks): which blocks each workgroup runs, longest first, on the XCD that shares their operands. The
- * caller copies it to device memory (16-byte aligned) once and passes it to every launch of the same shapes. */
-#define NAF_GEMM_P_MAX_BLOCKS 8
-int naf_gemm_bundle_p_plan(const naf_gemm_desc_t* descs, int n, int n_wg, int32_t* plan_host);
-int naf_gemm_bundle_p(const naf_gemm_desc_t* descs, int n, const int32_t* plan_dev, int n_wg, void* stream);
 
 /* ---- clip + Adam + Polyak over one flat parameter buffer -------------------------------------- */
 /* first half of clip_grad_norm_(params, 1) (naf_algorithm.py:209): partials[i] = sum of g^2 over chunk i of

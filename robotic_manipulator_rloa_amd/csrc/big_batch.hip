@@ -372,7 +372,7 @@ struct BbSlabs {
     BbSlabSeg seg[2];
     int n_seg, n_finish_blocks;
 };
-#define BB_MAX_SLABS 16
+#define BB_MAX_SLABS 8
 struct FinishArgs {
     const float* p_slabs;
     int KP, K;
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     // 2 (i % 8) + (i / 8) % 2 + 16 (i / 16): both chunks of block row bm are then written on the XCD that reads them, and the
     // lines are still in its L2 behind the launch boundary. (Whole groups of 16 chunks only; placement is speed only.)
     int rb = blockIdx.x;
-    if (ROWS == 16 && (gridDim.x & 15) == 0 && xcd_rows) rb = 2 * (rb & 7) + ((rb >> 3) & 1) + 16 * (rb >> 4);
+    if (ROWS == 16 && (gridDim.x & 15) == 0 && xcd_rows == 1) rb = 2 * (rb & 7) + ((rb >> 3) & 1) + 16 * (rb >> 4);
     const int64_t s0 = (int64_t)rb * ROWS;
     const int T = A * (A + 1) / 2, v_col = A + T;
     // every kernel argument this prologue needs, fetched NOW: left to itself the compiler fetches an argument where it is

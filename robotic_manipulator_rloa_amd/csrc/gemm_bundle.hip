@@ -322,6 +322,15 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     // the slabs are added in slab order by the consumer (bb_layer1_bwd_finish's reduce blocks). 64 blocks walking
     // K = 1024 pulled 256 KB each through one CU's L2 port (13.6 us per launch at B = 1024); 256 blocks of K = 256 do not.
     L1bwdRegs epi_regs;
+    // Every field of the product's description that the block uses up to its first MFMA, requested NOW, in one batch. Left to
+    // itself the compiler fetches a field where it is first used — behind the branches of the prefetch, of the panel sources and
+    // of the prologue — and the kernel arguments are not in the scalar cache when a workgroup starts: ten dependent scalar round
+    // trips in front of the first panel load (seen in the ISA; the persistent form of this kernel measured 1.7 us for five of
+    // them with benchmarks/kernel_timeline.py).
+    asm volatile("" ::"s"(D.A), "s"(D.B), "s"(D.M), "s"(D.N), "s"(D.K), "s"(D.lda), "s"(D.ldb), "s"(D.k_split), "s"(D.epi.x), "s"(D.epi.W),
+                 "s"(D.epi.bias), "s"(D.epi.a1), "s"(D.epi.save_mean), "s"(D.epi.save_invstd), "s"(D.epi.ldx), "s"(D.epi.K),
+                 "s"(D.epi.kp), "s"(D.epi.lda1), "s"(D.pro.z), "s"(D.pro.gamma), "s"(D.pro.save_mean), "s"(D.pro.save_invstd),
+                 "s"(D.pro.cst), "s"(D.pro.epoch), "s"(D.pro.errors));
     GB_TL(0);
     GB_TL_WG(0);
     if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, !kh, wm, wn, r, g, epi_regs);
@@ -441,6 +450,8 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
     for (int i = 1; i < NAF_GEMM_BUNDLE_MAX; ++i)
         if (i < bundle.n && t >= bundle.d[i].tile0) gi = i;
     const GemmDesc& D = bundle.d[gi];
+    // (what the block decode and the dispatch below read, in one batch of scalar loads: see gemm_block)
+    asm volatile("" ::"s"(D.tile0), "s"(D.tiles_mn), "s"(D.tiles_n), "s"(D.a_kmajor), "s"(D.b_kmajor), "s"(D.k_split), "s"(D.M), "s"(D.K));
     int ks = (t - D.tile0) / D.tiles_mn;
     const int lt = t - D.tile0 - ks * D.tiles_mn;
     int bm = lt / D.tiles_n, bn = lt - bm * D.tiles_n;

@@ -331,21 +331,10 @@ class Learner:
             def k_ranges(target, most):
                 """largest number of equal K ranges <= most, each whole 16-k steps and at least `target` rows long"""
                 return max([d for d in range(1, most + 1) if B % d == 0 and (B // d) % 16 == 0 and B // d >= target] or [1])
-            # From B = 1024 the bundle runs as persistent workgroups on 64 x 64 tiles (csrc/gemm_bundle_p.hip): K ranges of 256
-            # rows for dW2 and of 128 for dWh (many short blocks balance the 256 lists), and dA1 itself cut into two 128-feature
-            # halves while the batch gives fewer than 128 tiles (its epilogue is linear in dA1: the halves are two "blocks" of
-            # the finish launch's sums)
-            self.bundle_p = B >= 1024
-            ks_a1 = 1
-            if self.bundle_p:
-                ks_w2, ks_wh = k_ranges(256, 16), k_ranges(128, 16)
-                ks_a1 = 2 if (B // 64) * (H // 64) < 128 else 1
-            else:
-                ks = B // 256 if B % 256 == 0 else k_ranges(256, 8)
-                ks_w2 = ks_wh = ks
-                if ks >= 2 and ks % 2 == 0 and (B // (ks // 2)) % 256 == 0:
-                    ks_w2 = ks // 2
-            self._nb1 = ks_a1 * (B // 64) if self.bundle_p else B // 32     # blocks of layer 1's backward partials
+            ks = B // 256 if B % 256 == 0 else k_ranges(256, 8)
+            ks_w2 = ks_wh = ks
+            if ks >= 2 and ks % 2 == 0 and (B // (ks // 2)) % 256 == 0:
+                ks_w2 = ks // 2
             self.bb_slab_w2 = torch.zeros(ks_w2, H * H, **f32)
             self.bb_slab_wh = torch.zeros(ks_wh, NHP * HP, **f32)
             t2p_, seg_, gp_ = self.theta2.data_ptr(), lay.seg, self.grad.data_ptr()
@@ -364,18 +353,13 @@ class Learner:
             # dA1 FIRST: its blocks carry the layer-1 epilogue and run longest; dispatched first, the short weight-gradient
             # blocks fill in behind them instead of the other way round
             self._bundle = (D * 3)(
-                D(ptr(self.dZ2), ptr(self.W2_main), None, None, B, H, H, H, H, H, 0, 1, ks_a1, 0, _lib.C.addressof(self._epi), pro_),
+                D(ptr(self.dZ2), ptr(self.W2_main), None, None, B, H, H, H, H, H, 0, 1, 1, 0, _lib.C.addressof(self._epi), pro_),
                 D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks_w2, H * H, None, pro_),
                 D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks_wh, NHP * HP))
             SS = _lib.SlabSeg
             self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks_w2),
                                      SS(ptr(self.bb_slab_wh), ptr(self.gWh), NHP * HP, NHP * HP, ks_wh))
             self._bb_nsegs = 2
-            if self.bundle_p:
-                self._gp_wgs = torch.cuda.get_device_properties(dev).multi_processor_count
-                plan = (_lib.C.c_int32 * (self._gp_wgs * _lib.GEMM_P_MAX_BLOCKS * 4))()
-                check(self.lib.naf_gemm_bundle_p_plan(self._bundle, 3, self._gp_wgs, plan), "gemm_bundle_p_plan")
-                self._gp_plan = torch.tensor(list(plan), dtype=torch.int32).to(dev)
 
     # ---- parameters in / out ----------------------------------------------------------------------------
     def main_views(self) -> Dict[str, torch.Tensor]:
@@ -554,14 +538,11 @@ class Learner:
         # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles; dY2 becomes dZ2 while it is staged, the
         # dA1 blocks run layer 1's backward batch pass on their tile (this minibatch's rows: z recomputed from them)
         self._epi.x, self._epi.ldx = rp, ld
-        if self.bundle_p:
-            check(f.naf_gemm_bundle_p(self._bundle, 3, ptr(self._gp_plan), self._gp_wgs, st), "gemm_bundle_p")
-        else:
-            check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
+        check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
         # finish: everything added in block order, the xhat term from the moments, the bundle's split-K slabs, the norm
         # partials (nb = 0: the layer-2 bias gradient is written as the 0 it identically is)
         check(f.naf_bb_layer1_bwd_finish(
-            ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), self._nb1, None, 0,
+            ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), B // 32, None, 0,
             ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
             gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
             gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
