@@ -229,7 +229,7 @@ def main():
                                f"HIP NAF head ({args.p_mode} P), {U} learn() per vector step",
                    "launch": graph_note + (" [REHEARSAL: all ranks share cuda:0, not a measurement]" if rehearsal else ""),
                    "parallelism": f"dp{world}" if world > 1 else "single",
-                   "fused_kernels": ",".join(sorted(L.fuse)),
+                   "chain": L.chain, "fused_kernels": ",".join(sorted(L.fuse)),
                    "grad_exchange": ("none" if world == 1 else
                                      "one-shot peer-memory all-reduce over xGMI (csrc/xgmi_reduce.hip)" if L.xgmi is not None
                                      else "RCCL all-reduce")},
@@ -351,7 +351,7 @@ def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
                     "1.16 x its algorithmic bytes; `traffic` is the PMC record of that (FETCH_SIZE x 2 + WRITE_SIZE)"}
 
 
-def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0):
+def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadamard"):
     """The timed loop of main() at another BASELINE shape on this one GPU (same engines, same update-to-data ratio):
     updates/s of E envs, batch B, ring N."""
     import torch
@@ -361,7 +361,7 @@ def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0):
     from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     S, A = (23, 7) if robot == "panda" else (21, 6)
-    L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, dev, p_mode=_lib.P_HADAMARD)
+    L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, dev, p_mode=_lib.P_HADAMARD if p_mode == "hadamard" else _lib.P_MATMUL)
     sd = reference_init_state_dict(S, A, 256, seed=0)
     L.load_params(0, sd)
     L.load_params(1, sd)
@@ -369,7 +369,7 @@ def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0):
     rows = synth_rows(N, S, A, replay.row_floats, replay.off_s2, seed=77, device=dev)
     replay.add_rows_device(rows, N)
     del rows
-    loop = DeviceEnvLoop(L, replay, E, seed=31, max_frames=400, robot=robot, obstacle_jitter=jitter)
+    loop = DeviceEnvLoop(L, replay, E, seed=31, max_frames=400, robot=robot, obstacle_jitter=jitter, records=True)
     chunk = TrainChunk(L, replay, E)
     loop.capture()
     chunk.capture()
@@ -385,7 +385,7 @@ def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0):
     dt = time.perf_counter() - t0
     ok = bool(torch.isfinite(L.theta2).all().item()) and replay.bad_index_count() == 0 and int(L.step_dev.item()) == (steps + warmup) * E
     return {"updates_per_s": round(steps * E / dt, 1), "us_per_update": round(1e6 * dt / (steps * E), 2), "steps": steps,
-            "timed_seconds": round(dt, 3), "sane": ok, "fused_kernels": ",".join(sorted(L.fuse))}
+            "timed_seconds": round(dt, 3), "sane": ok, "chain": L.chain, "fused_kernels": ",".join(sorted(L.fuse))}
 
 
 def extras(dev, args):
@@ -464,6 +464,12 @@ def extras(dev, args):
                 "configs[4] shape: panda S=23 A=7, batch 2048, ring 4e6, 1 GPU":
                     measure_shape(dev, "panda", 2048, 4000000, E, 400, 30),
                 "batch 512 (kuka, ring 1e6)": measure_shape(dev, "kuka", 512, 1000000, E, 500, 30),
+                # the small-batch (column-tile) chain: configs[0]'s batch and ring with 64 device envs, and the reference's
+                # default batch (rl_framework.py:33-44)
+                "configs[0] batch and ring: kuka, batch 64, ring 1e5, 64 device envs": measure_shape(dev, "kuka", 64, 100000, E, 500, 30),
+                "reference default batch 128 (kuka, ring 1e5)": measure_shape(dev, "kuka", 128, 100000, E, 500, 30),
+                # north_star's literal head: textbook P = L L^T on 8 x 9 padded LDS tiles (--p-mode matmul)
+                "configs[1] with P = L L^T (p_mode matmul)": measure_shape(dev, "kuka", 256, 1000000, E, 500, 30, p_mode="matmul"),
             }
     finally:
         os.chdir(old)

@@ -63,9 +63,12 @@ class TrainChunk:
     """U consecutive learn() updates on U freshly sampled minibatches."""
 
     def __init__(self, learner: Learner, replay: ReplayBuffer, n_updates: int, teacher_forced: bool = False,
-                 use_graph: bool = True, gather_outside_graph: bool = False):
+                 use_graph: bool = True, gather_outside_graph: bool = False, tail=None, tail_state=()):
         """gather_outside_graph: launch sample+gather eagerly in front of the graph of U updates, so the caller can
-        bracket the gather launch with events (bench.py's live roofline measurement)."""
+        bracket the gather launch with events (bench.py's live roofline measurement).
+        tail: optional callable enqueued behind the last update, inside the same graph (NAFAgent puts the NEXT timestep's
+        act() there); tail_state: device tensors it changes, so that the capture's warm-up leaves no trace in them."""
+        self.tail, self._tail_state = tail, tuple(tail_state)
         self.L, self.replay, self.U = learner, replay, int(n_updates)
         self.teacher_forced = teacher_forced
         self.gather_outside_graph = gather_outside_graph
@@ -110,6 +113,8 @@ class TrainChunk:
         for k in range(self.U):
             self.L.learn_rows(self.batch[k], self.loss_parts[k], None if self.moments is None else self.moments[k],
                               pending=d and k > 0, defer=d and k < self.U - 1)
+        if self.tail is not None:
+            self.tail()
 
     def _body(self) -> None:
         self._sample_gather()
@@ -117,7 +122,7 @@ class TrainChunk:
 
     def capture(self) -> None:
         self.replay.flush()
-        snap = _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts))
+        snap = _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts) + self._tail_state)
         if self.gather_outside_graph:
             self._sample_gather()          # the updates need a valid batch to warm up on
             self.graph = _capture(self._updates, snap)

@@ -104,6 +104,7 @@ class NAFAgent:
         self.update_t_step = 0
         self._dp_ticks = 0                 # update-schedule ticks (step() calls + idle ticks): the gate under data parallel
         self._last_loss_from = None        # "chunk" | "learn": which path ran the most recent update
+        self._ahead = None                 # the state the last step()'s graph already ran the policy on (see _update_tick)
         self.use_graph = use_graph
         self._chunk: Optional[TrainChunk] = None
         self._actor1: Optional[ActPath] = None
@@ -139,14 +140,19 @@ class NAFAgent:
         (sample + learn) (naf_algorithm.py:129-156). The updates are one captured graph:
         sample num_updates minibatches -> one gather -> num_updates x learn."""
         self.memory.add(state, action, reward, next_state, done)
-        self._update_tick()
+        self._update_tick(None if done else next_state)
 
-    def _update_tick(self) -> None:
+    def _update_tick(self, next_state=None) -> None:
         """The update schedule of step() (naf_algorithm.py:144-156) without the add. Data parallel: every learn() holds a
         gradient all-reduce, so every rank must run the SAME number of ticks and open the gate at the same tick — the
         gate is therefore the tick count (identical on all ranks; equal to len(memory) whenever every tick added a row,
         i.e. always on one GPU), not the local fill level; run() pads episodes that ended early with idle ticks. A rank
-        that falls out of step is caught by the exchange's time-out (TrainChunk.run raises)."""
+        that falls out of step is caught by the exchange's time-out (TrainChunk.run raises).
+
+        next_state: where run()'s loop will ask act() next. The chunk's graph ends with the policy's forward on it — behind
+        the updates, so it has seen them, as the reference's ordering demands (naf_algorithm.py:249-261) — and the next
+        act(next_state) only waits for the graph and reads the action from pinned memory: one launch, one host round trip
+        and the idle gap between them less per timestep."""
         self.update_t_step = (self.update_t_step + 1) % self.update_freq
         self._dp_ticks += 1
         ready = len(self.memory) > self.batch_size if self.world_size == 1 else \
@@ -154,12 +160,19 @@ class NAFAgent:
         if self.update_t_step == 0 and ready:
             self.memory.flush()
             if self._chunk is None:
-                self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=self.use_graph)
+                a = self._actor()
+                tail = a.act if a.host_io else None        # (only the one-launch act() reads / writes pinned memory itself)
+                self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=self.use_graph,
+                                         tail=tail, tail_state=(a.counter, a._ticket) if tail else ())
+            if self._chunk.tail is not None and next_state is not None:
+                self._actor1.obs_np[0] = next_state
+                self._ahead = np.array(next_state, dtype=np.float32, copy=True)
+            else:
+                self._ahead = None
             self._chunk.run()
             self._last_loss_from = "chunk"
 
-    def act(self, state) -> np.ndarray:
-        """Noisy clamped action for one state, main net in eval mode (naf_algorithm.py:158-178)."""
+    def _actor(self) -> ActPath:
         if self._actor1 is None:
             self._actor1 = ActPath(self.learner, 1, seed=(self.seed * 2654435761 + 12345 + self.rank) & 0xFFFFFFFFFFFFFFFF,
                                    host_io=True)
@@ -177,8 +190,18 @@ class NAFAgent:
                     a.act()
                 a.counter.copy_(saved[0])
                 self._act_graph = g
-        a = self._actor1
+        return self._actor1
+
+    def act(self, state) -> np.ndarray:
+        """Noisy clamped action for one state, main net in eval mode (naf_algorithm.py:158-178)."""
+        a = self._actor()
         if a.host_io:
+            ahead, self._ahead = self._ahead, None
+            if ahead is not None:
+                # the last step()'s graph already ran the policy on the state it was told comes next
+                torch.cuda.current_stream().synchronize()
+                if np.array_equal(np.asarray(state, dtype=np.float32).reshape(-1), ahead.reshape(-1)):
+                    return a.actions_np[0].copy().squeeze()
             # the kernel reads the state from, and writes the action to, pinned host memory: no copies to enqueue
             a.obs_np[0] = state
             if self._act_graph is not None:
