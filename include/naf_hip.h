@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 18
+#define NAF_HIP_ABI_VERSION 19
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -321,7 +321,11 @@ int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1
                              float* d_gamma, float* d_beta, float* d_bias, float* d_bias2, const float* d_gamma2,
                              const float* d_beta2, float* sumsq_partials, int32_t* step_dev, int B, int H,
                              const naf_bb_slab_seg_t* segs, int n_segs,
-                             int* fold_epoch /* nullable: *fold_epoch += 1 (naf_gemm_bn2bwd_t.epoch of the bundle launch in front) */, void* stream);
+                             int* fold_epoch /* nullable: *fold_epoch += 1 (naf_gemm_bn2bwd_t.epoch of the bundle launch in front) */,
+                             const naf_xgmi_push_t* push /* nullable (HOST pointer): data parallel over peer memory — the workgroups that add
+                             the slab segments also store them into this rank's slot on every peer (naf_xgmi_push_desc); the all-reduce that
+                             follows is then told those ranges went ahead (naf_xgmi_allreduce_sum_from2) */,
+                             const float* grad_base /* with push: the flat gradient the segments' dst lie in */, void* stream);
 
 /* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
 /* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is
@@ -463,6 +467,10 @@ int naf_xgmi_push_desc(void* handle, naf_xgmi_push_t* out);
 int naf_xgmi_push_early(void* handle, const float* grad_in, size_t lo, size_t hi, void* stream);
 int naf_xgmi_allreduce_sum_from(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
                                 int32_t* step_dev, size_t pushed_lo, void* stream);
+/* the same with a SECOND range that went ahead: grad_in[skip_lo, skip_hi) (multiples of 4; skip_lo == skip_hi: none). The
+ * row-split chain's finish launch pushes the W2 and Wh segments, which are not adjacent in the flat buffer. */
+int naf_xgmi_allreduce_sum_from2(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
+                                 int32_t* step_dev, size_t pushed_lo, size_t skip_lo, size_t skip_hi, void* stream);
 int naf_xgmi_status(void* handle, uint64_t* epoch, uint64_t* timeouts);
 /* Time-outs so far, read from a pinned host word the kernel bumps: never synchronises, so the training loop polls it
  * after every chunk. A timed-out all-reduce leaves -inf in its sumsq partial, which makes naf_adam_polyak_fused skip

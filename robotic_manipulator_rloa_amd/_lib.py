@@ -205,7 +205,7 @@ _PROTOS = {
     "naf_bb_layer1_bwd_kp": [_i],
     "naf_bb_layer1_bwd_finish_blocks": [_i],
     "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
-                                 _vp, _i, _vp, _vp],
+                                 _vp, _i, _vp, _vp, _vp, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
@@ -225,6 +225,7 @@ _PROTOS = {
     "naf_xgmi_push_desc": [_vp, _vp],
     "naf_xgmi_push_early": [_vp, _vp, _sz, _sz, _vp],
     "naf_xgmi_allreduce_sum_from": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "naf_xgmi_allreduce_sum_from2": [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp],
     "naf_xgmi_status": [_vp, C.POINTER(_u64), C.POINTER(_u64)],
     "naf_xgmi_timeouts_nowait": [_vp, C.POINTER(_u64)],
     "naf_xgmi_disconnect": [_vp],

@@ -21,6 +21,7 @@
 #include "bn_tile.h"
 #include "head_body.h"
 #include "adam_body.h"
+#include "xgmi_dev.h"
 #include "../../include/naf_hip.h"
 
 #define BB_ROWS NAF_BB_ROWS      // rows per statistics block
@@ -389,6 +390,11 @@ struct FinishArgs {
     BbSlabs slabs;
     int* fold_flag;
     int n_blocks;                // finish blocks + slab-reduce blocks
+    // data parallel over peer memory (csrc/xgmi_reduce.hip): the slab-reduce workgroups also store what they finalise — the two
+    // weight-gradient segments W2 and Wh, 91 % of the flat gradient — into this rank's slot on every peer, so that the
+    // all-reduce launch behind this one has only the layer-1 / BatchNorm segments left to send before it raises its flags
+    naf_xgmi_push_t push;
+    const float* grad_base;      // the flat gradient the segments' dst pointers lie in; NULL: no push
 };
 // One workgroup (BB_THREADS threads) of the finish work.
 __device__ static inline void bb_finish_block(const FinishArgs& F, int block, int tid, float* sQ, float (*sP)[2][32]) {
@@ -412,7 +418,19 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
                 if (s_ < sg.n_slabs) { a.x += v[s_].x; a.y += v[s_].y; a.z += v[s_].z; a.w += v[s_].w; }
             *(float4*)(sg.dst + i) = a;
             sq = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            if (F.grad_base) {
+                // branch-free over the ranks (the own slab gets a copy nobody reads), as xg_push_range: with `if (p != rank)`
+                // around each store the compiler waits for every one of them in turn
+                const uint64_t e = F.push.ctrl[0] + 1;           // the epoch of the all-reduce launch that follows
+                const size_t o = (size_t)(sg.dst - F.grad_base) + (size_t)i;
+                const xg_f4 v = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int p = 0; p < NAF_XGMI_MAX_WORLD; ++p)
+                    if (p < F.push.world)
+                        *(xg_f4*)(xg_slot((char*)F.push.peer_base[p], F.push.data_off, F.push.n_pad, F.push.world, e, F.push.rank) + o) = v;
+            }
         }
+        if (F.grad_base) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: the bytes have reached the peers when this launch ends
     } else {
         const int lane = tid & 63, wave = tid >> 6;
         const int cl = wave >> 1, wq = wave & 1, k = lane & 31, hf = lane >> 5;
@@ -1449,7 +1467,10 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
                                         const float* dz2_col_partials, int nb, const float* mom, const float* wc, const float* gamma, const float* save_invstd,
                                         float* d_W, float* d_gamma, float* d_beta, float* d_bias, float* d_bias2,
                                         const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
-                                        int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, int* fold_flag, void* stream) {
+                                        int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, int* fold_flag,
+                                        const naf_xgmi_push_t* push, const float* grad_base, void* stream) {
+    if ((push != nullptr) != (grad_base != nullptr)) return NAF_ERR_ARG;
+    if (push && (push->world < 2 || push->world > NAF_XGMI_MAX_WORLD || ((uintptr_t)grad_base & 15))) return NAF_ERR_ARG;
     if (!p_slabs || !partials1 || (nb > 0 && !dz2_col_partials) || !mom || !wc || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
         !d_bias || !d_bias2 || nb < 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
         return NAF_ERR_ARG;
@@ -1476,6 +1497,14 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
     F.d_W = d_W; F.d_gamma = d_gamma; F.d_beta = d_beta; F.d_bias = d_bias; F.d_bias2 = d_bias2; F.d_gamma2 = d_gamma2;
     F.d_beta2 = d_beta2; F.sumsq_partials = sumsq_partials; F.step_dev = step_dev; F.B = B; F.H = H; F.slabs = sl;
     F.fold_flag = fold_flag; F.n_blocks = sl.n_finish_blocks + blocks;
+    if (push) {
+        for (int i = 0; i < n_segs; ++i)       // every pushed segment: inside the flat gradient, whole float4
+            if (segs[i].dst < grad_base || (size_t)(segs[i].dst - grad_base) + (size_t)segs[i].n > push->n_pad ||
+                ((segs[i].dst - grad_base) & 3))
+                return NAF_ERR_ARG;
+        F.push = *push;
+        F.grad_base = grad_base;
+    }
     bb_layer1_bwd_finish_kernel<<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
     NAF_CHECK_LAUNCH();
     return NAF_OK;

@@ -50,9 +50,12 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peer
                                                                     uint64_t* __restrict__ ctrl,
                                                                     float* __restrict__ sumsq_partials, int32_t* step_dev,
                                                                     long long timeout_ticks, size_t pushed_lo,
+                                                                    size_t skip_lo, size_t skip_hi,
                                                                     uint64_t* __restrict__ host_timeouts) {
     // pushed_lo: grad_in[pushed_lo, n) has already been pushed for this epoch (naf_xgmi_push_early or the layer-1
-    // backward kernel's extra workgroups, in an earlier launch of this stream); pushed_lo = n: nothing has
+    // backward kernel's extra workgroups, in an earlier launch of this stream); pushed_lo = n: nothing has.
+    // [skip_lo, skip_hi): a second range that went ahead (the row-split chain's finish launch pushes the two weight-gradient
+    // segments W2 and Wh, which do not touch in the flat buffer: Wh = [pushed_lo, n), W2 = [skip_lo, skip_hi))
     __shared__ float red[XG_THREADS / 64];
     __shared__ int last;
     __shared__ int timed_out;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(XG_THREADS) void xgmi_allreduce_kernel(XgPeers peer
     // ---- push: this workgroup's chunk of the local gradient into the slot `rank` of every peer ---------------------
     xg_f4 mine = {0.f, 0.f, 0.f, 0.f};
     if (on) mine = *(const xg_f4*)(grad_in + i);
-    if (on && i < pushed_lo) {
+    if (on && i < pushed_lo && !(i >= skip_lo && i < skip_hi)) {
         // branch-free on purpose (the own slab gets a copy nobody reads): with `if (p != rank)` around each store the
         // compiler put an s_waitcnt vmcnt(0) in front of every one of them — W-1 SERIAL round trips over xGMI
 #pragma unroll
@@ -277,9 +280,14 @@ extern "C" int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float*
 
 extern "C" int naf_xgmi_allreduce_sum_from(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
                                            int32_t* step_dev, size_t pushed_lo, void* stream) {
+    return naf_xgmi_allreduce_sum_from2(handle, grad_in, grad_out, sumsq_partials, step_dev, pushed_lo, 0, 0, stream);
+}
+
+extern "C" int naf_xgmi_allreduce_sum_from2(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
+                                            int32_t* step_dev, size_t pushed_lo, size_t skip_lo, size_t skip_hi, void* stream) {
     if (!handle || !grad_in || !grad_out) return NAF_ERR_ARG;
     XgmiComm* c = xg_comm(handle);
-    if ((pushed_lo & 3) || pushed_lo > c->n) return NAF_ERR_ARG;
+    if ((pushed_lo & 3) || pushed_lo > c->n || (skip_lo & 3) || (skip_hi & 3) || skip_lo > skip_hi || skip_hi > c->n) return NAF_ERR_ARG;
     if ((((uintptr_t)grad_in | (uintptr_t)grad_out) & 15) != 0) return NAF_ERR_ARG;
     for (int p = 0; p < c->world; ++p)
         if (!c->peers.base[p]) return NAF_ERR_STATE;           // naf_xgmi_connect has not mapped every peer
@@ -288,7 +296,7 @@ extern "C" int naf_xgmi_allreduce_sum_from(void* handle, const float* grad_in, f
     case W:                                                                                                          \
         xgmi_allreduce_kernel<W><<<chunks, XG_THREADS, 0, (hipStream_t)stream>>>(                                    \
             c->peers, grad_in, grad_out, c->n, c->n_pad, c->data_off, c->rank, c->ctrl, sumsq_partials, step_dev,    \
-            c->timeout_ticks, pushed_lo, c->host_timeouts);                                                          \
+            c->timeout_ticks, pushed_lo, skip_lo, skip_hi, c->host_timeouts);                                                          \
         break;
     switch (c->world) {
         XG_REDUCE(2) XG_REDUCE(3) XG_REDUCE(4) XG_REDUCE(5) XG_REDUCE(6) XG_REDUCE(7) XG_REDUCE(8)

@@ -63,12 +63,17 @@ class TrainChunk:
     """U consecutive learn() updates on U freshly sampled minibatches."""
 
     def __init__(self, learner: Learner, replay: ReplayBuffer, n_updates: int, teacher_forced: bool = False,
-                 use_graph: bool = True, gather_outside_graph: bool = False, tail=None, tail_state=()):
+                 use_graph: bool = True, gather_outside_graph: bool = False, tail=None, tail_state=(), head_row=None):
         """gather_outside_graph: launch sample+gather eagerly in front of the graph of U updates, so the caller can
         bracket the gather launch with events (bench.py's live roofline measurement).
         tail: optional callable enqueued behind the last update, inside the same graph (NAFAgent puts the NEXT timestep's
-        act() there); tail_state: device tensors it changes, so that the capture's warm-up leaves no trace in them."""
+        act() there); tail_state: device tensors it changes, so that the capture's warm-up leaves no trace in them.
+        head_row: optional pinned [1, row_floats] tensor: the graph STARTS by appending that one transition to the ring
+        (the append kernel reads pinned host memory itself) — ReplayBuffer.add of the timestep inside the graph of its
+        update instead of a launch, two event calls and a staging switch of its own. The caller fills the row and counts
+        the transition (replay._total_added) before every run()."""
         self.tail, self._tail_state = tail, tuple(tail_state)
+        self.head_row = head_row
         self.L, self.replay, self.U = learner, replay, int(n_updates)
         self.teacher_forced = teacher_forced
         self.gather_outside_graph = gather_outside_graph
@@ -117,6 +122,8 @@ class TrainChunk:
             self.tail()
 
     def _body(self) -> None:
+        if self.head_row is not None:
+            self.replay.add_rows_device(self.head_row, 1, _count=False)
         self._sample_gather()
         self._updates()
 
@@ -126,6 +133,17 @@ class TrainChunk:
         if self.gather_outside_graph:
             self._sample_gather()          # the updates need a valid batch to warm up on
             self.graph = _capture(self._updates, snap)
+        elif self.head_row is not None:
+            # the warm-up appends rows to the ring: {head, size} come back with the snapshot, the ring slots it wrote
+            # (live rows, if the ring is full) are saved and put back
+            warmup = 2
+            head = int(self.replay.meta[0].item())
+            pos = (head + torch.arange(warmup, device=self.L.dev)) % self.replay.buffer_size
+            saved = self.replay.rows[pos].clone()
+
+            def put_back():
+                self.replay.rows[pos] = saved
+            self.graph = _capture(self._body, snap, warmup=warmup, after_warmup=put_back)
         else:
             self.graph = _capture(self._body, snap)
 

@@ -46,6 +46,40 @@ def forward_kinematics(q: np.ndarray, obstacle: np.ndarray) -> Tuple[np.ndarray,
     return p.astype(np.float32), hit
 
 
+_LINKS_F = [float(x) for x in LINKS]
+_OBST_R2 = float(OBSTACLE_RADIUS) ** 2
+
+
+def _fk_fast(q, obstacle):
+    """forward_kinematics() on Python floats (double precision, one pass, no array temporaries): the same chain, 5 x faster
+    for the 6-8 joints of an arm than ~100 small numpy calls — env.step was the largest single cost of a timestep of the
+    reference-API path (75 of 165 us, benchmarks/host_api_breakdown.py). Agrees with the float32 forms (numpy above, device
+    kernel) to their rounding: tests compare them at 2e-6."""
+    from math import cos, sin
+    r00, r01, r02, r10, r11, r12, r20, r21, r22 = 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0
+    px = py = pz = 0.0
+    ox, oy, oz = obstacle
+    hit = False
+    for k, qk in enumerate(q):
+        c, s = cos(qk), sin(qk)
+        if k % 2 == 0:      # about z: columns 0, 1 mix
+            r00, r01 = r00 * c + r01 * s, -r00 * s + r01 * c
+            r10, r11 = r10 * c + r11 * s, -r10 * s + r11 * c
+            r20, r21 = r20 * c + r21 * s, -r20 * s + r21 * c
+        else:               # about y: columns 0, 2 mix
+            r00, r02 = r00 * c - r02 * s, r00 * s + r02 * c
+            r10, r12 = r10 * c - r12 * s, r10 * s + r12 * c
+            r20, r22 = r20 * c - r22 * s, r20 * s + r22 * c
+        l = _LINKS_F[k]
+        px += r02 * l
+        py += r12 * l
+        pz += r22 * l
+        dx, dy, dz = px - ox, py - oy, pz - oz
+        if dx * dx + dy * dy + dz * dz < _OBST_R2:
+            hit = True
+    return (px, py, pz), hit
+
+
 class SyntheticEnvironment:
 
     def __init__(self, n_joints: int = 6, target_position: Optional[List[float]] = None,
@@ -61,6 +95,8 @@ class SyntheticEnvironment:
         self.initial_positions_variation_range = None if var is None else np.array(list(var)[:self.n], np.float32)
         self._observation_space = np.zeros((9 + 2 * self.n,))
         self._action_space = np.zeros((self.n,))
+        self._target_f = tuple(float(x) for x in self.target_pos)
+        self._obstacle_f = tuple(float(x) for x in self.obstacle_pos)
         self.q = self.initial_joint_positions.copy()
         self.qd = np.zeros(self.n, np.float32)
 
@@ -72,9 +108,19 @@ class SyntheticEnvironment:
     def action_space(self) -> np.ndarray:
         return self._action_space
 
+    def _state_from(self, ee) -> np.ndarray:
+        n = self.n
+        out = np.empty(9 + 2 * n)
+        out[:n] = self.q
+        out[n:2 * n] = self.qd
+        out[2 * n:2 * n + 3] = np.asarray(ee, np.float32)          # (the observation carries float32 values, as the device env's)
+        out[2 * n + 3:2 * n + 6] = self.target_pos
+        out[2 * n + 6:] = self.obstacle_pos
+        return out
+
     def get_state(self) -> np.ndarray:
-        ee, _ = forward_kinematics(self.q, self.obstacle_pos)
-        return np.hstack([self.q, self.qd, ee, self.target_pos, self.obstacle_pos]).astype(float)
+        ee, _ = _fk_fast(self.q.tolist(), self._obstacle_f)
+        return self._state_from(ee)
 
     def reset(self, verbose: bool = True) -> np.ndarray:
         """Initial joint positions (+ uniform variation drawn from Python's global RNG, as environment.py:284-293)."""
@@ -90,10 +136,11 @@ class SyntheticEnvironment:
         a = np.asarray(action, np.float32).reshape(self.n)
         self.q = (self.q + DT * a).astype(np.float32)     # velocity control: commanded velocity held for one tick
         self.qd = a.copy()
-        ee, hit = forward_kinematics(self.q, self.obstacle_pos)
-        diff = ee - self.target_pos
+        ee, hit = _fk_fast(self.q.tolist(), self._obstacle_f)
+        ee32 = np.asarray(ee, np.float32)
+        diff = ee32 - self.target_pos
         dist = np.float32(np.sqrt(np.float32(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2])))
         reached = bool(dist < TARGET_THRESHOLD)
         reward = 250 if reached else (-1000 if hit else -1 * float(dist - TARGET_THRESHOLD))
         done = 1 if (reached or hit) else 0
-        return self.get_state(), reward, done
+        return self._state_from(ee32), reward, done

@@ -509,7 +509,8 @@ class Learner:
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
             if self.xgmi is not None:
                 # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
-                self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=self._pushed_lo)
+                self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=self._pushed_lo,
+                                     pushed_also=self._pushed_also)
                 if not defer:
                     self.optimizer_step(norm_ready=True)
                 return
@@ -526,7 +527,7 @@ class Learner:
         f = self._f
         t2p, gp, bnp = self.theta2.data_ptr(), self.grad.data_ptr(), self.bn_stats.data_ptr()
         rp, ld = rows.data_ptr(), rows.stride(0)
-        self._pushed_lo = None
+        self._pushed_lo = self._pushed_also = None
         self.forward_train(rows, moments=moments, adam_pending=pending)
         # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
         check(f.naf_bb_layer2_head(
@@ -540,14 +541,23 @@ class Learner:
         self._epi.x, self._epi.ldx = rp, ld
         check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
         # finish: everything added in block order, the xhat term from the moments, the bundle's split-K slabs, the norm
-        # partials (nb = 0: the layer-2 bias gradient is written as the 0 it identically is)
+        # partials (nb = 0: the layer-2 bias gradient is written as the 0 it identically is). Data parallel over peer memory:
+        # the workgroups that add the slabs of dW2 and dWh (91 % of the flat gradient) store them to the peers as well, so the
+        # all-reduce launch behind this one sends only the layer-1 / BatchNorm segments before it raises its flags
+        push = None
+        if self.xgmi is not None and seg["Wh"].offset + seg["Wh"].numel == P:      # (Wh ends the buffer: no pad behind it)
+            if self._push_desc is None:
+                self._push_desc = self.xgmi.push_desc()
+            push = _lib.C.byref(self._push_desc)
+            self._pushed_lo = seg["Wh"].offset                                         # Wh is the last segment: [Wh, P)
+            self._pushed_also = (seg["W2"].offset, seg["W2"].offset + H * H)
         check(f.naf_bb_layer1_bwd_finish(
             ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), B // 32, None, 0,
             ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
             gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
             gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
             ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, B, H,
-            self._bb_segs, self._bb_nsegs, ptr(self.bb_fold_flag), st), "bb_layer1_bwd_finish")
+            self._bb_segs, self._bb_nsegs, ptr(self.bb_fold_flag), push, gp if push is not None else None, st), "bb_layer1_bwd_finish")
 
     def _learn_rows_tiles(self, rows: torch.Tensor, lp) -> None:
         """The column-tile chain (csrc/fused_layers.hip) and the unfused chain (torch GEMMs + csrc/bn_relu.hip), by `fuse`."""
@@ -556,7 +566,7 @@ class Learner:
         f = self._f
         t2p, gp = self.theta2.data_ptr(), self.grad.data_ptr()
         rp, ld = rows.data_ptr(), rows.stride(0)
-        self._pushed_lo = None
+        self._pushed_lo = self._pushed_also = None
         self.forward_train(rows)
         if "s3" in self.fuse:
             # the head adds the split-K slabs (H/8 of them) while staging its rows

@@ -113,6 +113,8 @@ class NAFAgent:
         self._act_pinned = torch.zeros(1, action_size, dtype=torch.float32).pin_memory()
         self._learn_rows = torch.zeros(batch_size + 1, L.lay.batch_row_floats, dtype=torch.float32, device=self.device)[:batch_size]
         self._learn_loss = torch.zeros(L.n_loss_wg, dtype=torch.float32, device=self.device)
+        self._row_pin = torch.zeros(1, L.lay.row_floats, dtype=torch.float32).pin_memory()    # step()'s transition, read by the graph
+        self._row_np = self._row_pin.numpy()
         self.last_run_stats: Optional[dict] = None    # counters of the most recent run_vectorized / run_host_vectorized
 
     # ---- pretrained weights (naf_algorithm.py:91-127) ----------------------------------------------------------
@@ -138,11 +140,30 @@ class NAFAgent:
     def step(self, state, action, reward: float, next_state, done: int) -> None:
         """Store the experience and, every update_freq steps once len(memory) > batch_size, run num_updates
         (sample + learn) (naf_algorithm.py:129-156). The updates are one captured graph:
-        sample num_updates minibatches -> one gather -> num_updates x learn."""
+        [append this transition] -> sample num_updates minibatches -> one gather -> num_updates x learn -> [act(next_state)]."""
+        if self._row_in_graph():
+            # every tick updates (update_freq = 1, gate open): the append is the first node of the update's graph, reading
+            # the transition from a pinned row of its own — same order (add, then sample) as the reference's step()
+            m, row = self.memory, self._row_np[0]
+            S, A = m.S, m.A
+            row[:S] = state[0] if isinstance(state, tuple) else state
+            row[S:S + A] = action
+            row[S + A] = reward
+            row[m.off_s2:m.off_s2 + S] = next_state
+            row[m.off_s2 + S] = done
+            m._total_added += 1
+            self._update_tick(None if done else next_state, row_in_graph=True)
+            return
         self.memory.add(state, action, reward, next_state, done)
         self._update_tick(None if done else next_state)
 
-    def _update_tick(self, next_state=None) -> None:
+    def _row_in_graph(self) -> bool:
+        m = self.memory
+        return (self.update_freq == 1 and self.use_graph and m._handle is not None and m._pending == 0 and
+                (len(m) > self.batch_size if self.world_size == 1 else (self._dp_ticks > self.batch_size and len(m) > 0)) and
+                (self._chunk is None or self._chunk.head_row is not None))
+
+    def _update_tick(self, next_state=None, row_in_graph: bool = False) -> None:
         """The update schedule of step() (naf_algorithm.py:144-156) without the add. Data parallel: every learn() holds a
         gradient all-reduce, so every rank must run the SAME number of ticks and open the gate at the same tick — the
         gate is therefore the tick count (identical on all ranks; equal to len(memory) whenever every tick added a row,
@@ -158,12 +179,31 @@ class NAFAgent:
         ready = len(self.memory) > self.batch_size if self.world_size == 1 else \
             (self._dp_ticks > self.batch_size and len(self.memory) > 0)
         if self.update_t_step == 0 and ready:
-            self.memory.flush()
+            if not row_in_graph:
+                self.memory.flush()
             if self._chunk is None:
                 a = self._actor()
                 tail = a.act if a.host_io else None        # (only the one-launch act() reads / writes pinned memory itself)
+                # update_freq = 1: from the first update on every tick runs this graph, and the tick's transition is appended
+                # by the graph itself (step()); other schedules keep ReplayBuffer.add's staging in front of it
+                head = self._row_pin if (self.update_freq == 1 and self.use_graph) else None
+                if head is not None and not row_in_graph:
+                    # the tick that builds the graph came through memory.add (the gate was closed before it): build the graph
+                    # with the append node, but run THIS tick's updates eagerly — its row is in the ring already
+                    self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=True, tail=tail,
+                                             tail_state=(a.counter, a._ticket) if tail else (), head_row=head)
+                    once = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=False, tail=tail)
+                    if tail is not None and next_state is not None:
+                        self._actor1.obs_np[0] = next_state
+                        self._ahead = np.array(next_state, dtype=np.float32, copy=True)
+                    else:
+                        self._ahead = None
+                    once.run()
+                    self._chunk.loss_parts = once.loss_parts       # (last_loss() of this tick)
+                    self._last_loss_from = "chunk"
+                    return
                 self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=self.use_graph,
-                                         tail=tail, tail_state=(a.counter, a._ticket) if tail else ())
+                                         tail=tail, tail_state=(a.counter, a._ticket) if tail else (), head_row=head)
             if self._chunk.tail is not None and next_state is not None:
                 self._actor1.obs_np[0] = next_state
                 self._ahead = np.array(next_state, dtype=np.float32, copy=True)

@@ -156,9 +156,11 @@ class XgmiAllReduce:
         check(self.lib.naf_xgmi_push_early(self.handle, ptr(grad_in), int(lo), int(hi), stream_ptr()), "xgmi_push_early")
 
     def all_reduce(self, grad_in: torch.Tensor, grad_out: torch.Tensor, partials: Optional[torch.Tensor] = None,
-                   step_dev: Optional[torch.Tensor] = None, pushed_lo: Optional[int] = None) -> None:
+                   step_dev: Optional[torch.Tensor] = None, pushed_lo: Optional[int] = None,
+                   pushed_also: Optional[tuple] = None) -> None:
         """grad_out = sum over ranks of grad_in on the current stream (in place allowed). pushed_lo: grad_in[pushed_lo:]
-        has already gone to the peers (push_early, or the layer-1 backward kernel's extra workgroups)."""
+        has already gone to the peers (push_early, the layer-1 backward kernel's extra workgroups, the finish launch of the
+        row-split chain); pushed_also = (lo, hi): so has that second range."""
         from ._lib import check, ptr, stream_ptr
         if grad_in.numel() != self.n or grad_out.numel() != self.n or grad_in.dtype != torch.float32 or \
                 grad_out.dtype != torch.float32 or not grad_in.is_contiguous() or not grad_out.is_contiguous():
@@ -166,8 +168,9 @@ class XgmiAllReduce:
         if partials is not None and partials.numel() < self.n_partials:
             raise ValueError("xgmi all_reduce: partials too short")
         lo = self.n if pushed_lo is None else int(pushed_lo)
-        check(self.lib.naf_xgmi_allreduce_sum_from(self.handle, ptr(grad_in), ptr(grad_out), ptr(partials), ptr(step_dev),
-                                                   lo, stream_ptr()), "xgmi_allreduce")
+        s_lo, s_hi = (0, 0) if pushed_also is None else (int(pushed_also[0]), int(pushed_also[1]))
+        check(self.lib.naf_xgmi_allreduce_sum_from2(self.handle, ptr(grad_in), ptr(grad_out), ptr(partials), ptr(step_dev),
+                                                    lo, s_lo, s_hi, stream_ptr()), "xgmi_allreduce")
 
     def status(self) -> tuple:
         """(all-reduces done, timed-out waits) — blocking."""

@@ -135,11 +135,17 @@ def main():
             seen = []
             real = L.xgmi.all_reduce
 
-            def spy(grad_in, grad_out, partials=None, step_dev=None, pushed_lo=None):
-                # column-tile chain: everything but layer 1 went ahead, from inside B1; the row-split chain sends the vector whole
-                assert pushed_lo == (L.lay.seg["W2"].offset if "l1" in L.fuse else None), (pushed_lo, L.fuse)
+            def spy(grad_in, grad_out, partials=None, step_dev=None, pushed_lo=None, pushed_also=None):
+                # column-tile chain: everything but layer 1 went ahead, from inside B1; the row-split chain's finish launch sent
+                # the two weight-gradient segments (W2 and Wh, 91 % of the vector)
+                sg = L.lay.seg
+                if "l1" in L.fuse:
+                    assert (pushed_lo, pushed_also) == (sg["W2"].offset, None), (pushed_lo, pushed_also, L.fuse)
+                else:
+                    assert "bb" in L.fuse and pushed_lo == sg["Wh"].offset and sg["Wh"].offset + sg["Wh"].numel == L.lay.P
+                    assert pushed_also == (sg["W2"].offset, sg["W2"].offset + sg["W2"].numel), pushed_also
                 before = grad_in.clone()
-                real(grad_in, grad_out, partials, step_dev, pushed_lo=pushed_lo)
+                real(grad_in, grad_out, partials, step_dev, pushed_lo=pushed_lo, pushed_also=pushed_also)
                 seen.append((before, grad_out.clone(), partials[:L.xgmi.n_partials].clone()))
 
             L.xgmi.all_reduce = spy
