@@ -430,7 +430,11 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
                         *(xg_f4*)(xg_slot((char*)F.push.peer_base[p], F.push.data_off, F.push.n_pad, F.push.world, e, F.push.rank) + o) = v;
             }
         }
-        if (F.grad_base) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: the bytes have reached the peers when this launch ends
+        // Every pushing wave waits until its stores to the peers' (uncached) slabs are acknowledged; no release fence: the flags
+        // that tell the peers to read are raised by the NEXT launch of this stream, behind the launch boundary and behind that
+        // launch's own system-scope release. (A release fence in each of the 73 pushing workgroups — an L2 write-back each, of
+        // lines that have nothing to do with the slabs — cost 7 - 15 us per update in the shared-GPU rehearsal.)
+        if (F.grad_base) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         const int lane = tid & 63, wave = tid >> 6;
         const int cl = wave >> 1, wq = wave & 1, k = lane & 31, hf = lane >> 5;

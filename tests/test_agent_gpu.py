@@ -368,7 +368,7 @@ def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse):
     other's receive slabs through hipIpc and run the one-shot all-reduce eagerly, inside a captured graph and under
     Learner.learn_rows — results bit-exact against the rank-ordered sum, replicas in lock-step, no timed-out wait.
     Two ranks on the column-tile chain (part of the gradient pushed ahead from inside its last kernel), four on the default
-    chain of B = 256 (the row-split one: the vector travels whole)."""
+    chain of B = 256 (the row-split one: its finish launch pushes the two weight-gradient segments ahead)."""
     import socket
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
