@@ -281,9 +281,11 @@ def main():
                                "sample": f"oracle/torch_cpu_port.py (reference op order incl. deque+random.sample "
                                          f"sampler), act+add+sample+learn for {cb['n_steps']} timesteps, B={B}, "
                                          f"deque filled to N={N}; learn()-only {cb['learn_updates_per_s']:.1f} "
-                                         f"updates/s over {cb['n_learn']} calls; host has {cb['host_cpus']} cpus; "
+                                         f"updates/s over {cb['n_learn']} calls; sample() alone {cb['sample_ms']:.2f} ms (deque "
+                                         f"indexing: memory latency, the host-dependent part); host has {cb['host_cpus']} cpus; "
                                          f"steps/s by thread count {cb['other']}",
-                               "learn_only_updates_per_s": round(cb["learn_updates_per_s"], 2)}
+                               "learn_only_updates_per_s": round(cb["learn_updates_per_s"], 2),
+                               "sample_only_ms": round(cb["sample_ms"], 3)}
         out["speedup_vs_cpu_port"] = round(value / cb["steps_per_s"], 1)
     if rank == 0 and world == 1 and not args.no_extras:
         try:
@@ -345,7 +347,7 @@ def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
             "infinity_cache_assisted": ring_rows * ring.row_floats * 4 <= 256 * 2 ** 20, "bad_indices": bad,
             "physical_GBps": round(phys / (ms * 1e-3) / 1e9, 1),
             "note": "HIP events around back-to-back launches on the launching stream; achieved = algorithmic bytes "
-                    "(4*(2S+A+2)*2 + 4 per row: 404 B at S=21/A=6) / average launch time; profiles/r02_bench_kernel_stats.csv is "
+                    "(4*(2S+A+2)*2 + 4 per row: 404 B at S=21/A=6) / average launch time; profiles/r03_bench_kernel_stats.csv is "
                     "the rocprofv3 kernel-trace average of this kernel instance in the same command. A ring row is padded "
                     "200 -> 256 B (two whole 128-B lines per random row) and a gathered row 200 -> 208 B, so the launch moves "
                     "1.16 x its algorithmic bytes; `traffic` is the PMC record of that (FETCH_SIZE x 2 + WRITE_SIZE)"}

@@ -183,6 +183,13 @@ def time_baseline(S=21, A=6, H=256, B=256, N=1_000_000, fill=None, budget_s=15.0
         agent.learn(ex)
         n_learn += 1
     t_learn = (time.perf_counter() - t0) / n_learn
+    # sample() only (replay_buffer.py:47-67): random.sample over a deque walks O(N) pointers per draw — memory latency, the
+    # part of the timestep that differs most from host to host (a 256-cpu server's L3 swallows most of a 1e6-entry deque)
+    t0, n_sample = time.perf_counter(), 0
+    while time.perf_counter() - t0 < min(2.0, budget_s * 0.1) or n_sample < 3:
+        agent.sample()
+        n_sample += 1
+    t_sample = (time.perf_counter() - t0) / n_sample
     # full timestep
     s = st[fill]
     t0, n_step = time.perf_counter(), 0
@@ -193,5 +200,5 @@ def time_baseline(S=21, A=6, H=256, B=256, N=1_000_000, fill=None, budget_s=15.0
         s = s2
         n_step += 1
     t_step = (time.perf_counter() - t0) / n_step
-    return {"steps_per_s": 1.0 / t_step, "learn_updates_per_s": 1.0 / t_learn, "n_steps": n_step, "n_learn": n_learn,
+    return {"steps_per_s": 1.0 / t_step, "learn_updates_per_s": 1.0 / t_learn, "sample_ms": 1e3 * t_sample, "n_steps": n_step, "n_learn": n_learn,
             "threads": torch.get_num_threads(), "host_cpus": os.cpu_count(), "B": B, "N": N, "fill": fill}
