@@ -1093,11 +1093,12 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     __shared__ float2 sP[MT][H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // which rows: workgroup i runs on XCD i % 8, and the bundle's dA1 blocks — the readers of the dY2 / A2 rows written here —
-    // sit by 32-row block row bm on XCD bm % 8 (gemm_bundle.hip). With 16-row workgroups, workgroup i takes row chunk
-    // 2 (i % 8) + (i / 8) % 2 + 16 (i / 16): both chunks of block row bm are then written on the XCD that reads them, and the
-    // lines are still in its L2 behind the launch boundary. (Whole groups of 16 chunks only; placement is speed only.)
+    // sit on XCD x for the block rows of the x-th EIGHTH of the batch (gemm_bundle.hip; the same rows are the K range of the
+    // dW2 blocks on that XCD). Workgroup i takes row chunk (i % 8) (chunks / 8) + i / 8: every chunk is then written on the XCD
+    // that reads it, and the lines are still in its L2 behind the launch boundary. (Whole groups of 16 chunks only; placement
+    // is speed only.)
     int rb = blockIdx.x;
-    if (ROWS == 16 && (gridDim.x & 15) == 0 && xcd_rows == 1) rb = 2 * (rb & 7) + ((rb >> 3) & 1) + 16 * (rb >> 4);
+    if (ROWS == 16 && (gridDim.x & 15) == 0 && xcd_rows) rb = (rb & 7) * ((int)gridDim.x >> 3) + (rb >> 3);
     const int64_t s0 = (int64_t)rb * ROWS;
     const int T = A * (A + 1) / 2, v_col = A + T;
     // every kernel argument this prologue needs, fetched NOW: left to itself the compiler fetches an argument where it is
@@ -1438,7 +1439,7 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     hipStream_t st = (hipStream_t)stream;
     const int rows = naf_bb_layer2_head_rows(B);
     const int blocks = B / rows;
-    const int xcd_rows = 1;      // row chunks dealt to the XCD whose dA1 blocks read them (+0.4 %)
+    const int xcd_rows = 1;      // row chunks dealt to the XCD whose dA1 blocks read them (+0.4 - 1 %)
 #define BB_FK_R(PM, NH4V, RW)                                                                                            \
     bb_layer2_head_kernel<PM, NH4V, RW><<<blocks, FK_THREADS, 0, st>>>(                                                  \
         z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, B / BB_ROWS, running_mean, running_var, \

@@ -459,11 +459,13 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
         // 8 block columns; workgroup t runs on XCD t % 8 (round-robin dispatch). Placement is speed only, the result does not
         // depend on it. Every XCD has its own L2, so what matters is how much of the operands each of the eight pulls:
         //   k-major A (dW2 = dZ2^T A1): block ROW bm on XCD bm — an eighth of dZ2 (and Z2), all of A1;
-        //   k-contiguous A (dA1 = dZ2 W2, with the BatchNorm prologue and the layer-1 epilogue): block rows bm = x, x + 8, ... on
-        //   XCD x with all 8 block columns of a row — an eighth of dZ2, Z2, A1 and the minibatch rows plus the whole of W2,
-        //   instead of all of those and an eighth of W2. (Until the epilogue was fused the dA1 blocks sat by block COLUMN, next
+        //   k-contiguous A (dA1 = dZ2 W2, with the BatchNorm prologue and the layer-1 epilogue): the block rows of the x-th EIGHTH
+        //   of the batch on XCD x, with all 8 block columns of a row — an eighth of dZ2, Z2, A1 and the minibatch rows plus the whole
+        //   of W2, instead of all of those and an eighth of W2. (Until the epilogue was fused the dA1 blocks sat by block COLUMN, next
         //   to the kernel that read those dA1 columns; nothing reads them any more, and by rows: 31.7k -> 33.1k updates/s at
-        //   B = 256, 28.6k -> 29.4k at 512, 24.0k -> 25.6k at 1024, 17.5k -> 17.9k at 2048, A/B on the same boxes.)
+        //   B = 256, 28.6k -> 29.4k at 512, 24.0k -> 25.6k at 1024, 17.5k -> 17.9k at 2048, A/B on the same boxes. Contiguous
+        //   eighths instead of rows x, x + 8, ...: the rows an XCD pulls for its dA1 blocks are then inside the K range its dW2
+        //   blocks walk — +1 % at B = 1024, +0.4 % at 2048, A/B/A/B on one box; bb_layer2_head writes them there.)
         const int xcd = lt & 7, slot = lt >> 3;
         if (D.a_kmajor) {
             const int S = D.k_split;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
                 bn = sl / S;
             } else if (D.M == 256) { bm = xcd; bn = slot; }
         } else if ((D.tiles_mn & 63) == 0) {              // (whole groups of 8 block rows)
-            bm = xcd + 8 * (slot >> 3);
+            bm = xcd * (D.tiles_mn >> 6) + (slot >> 3);
             bn = slot & 7;
         }
     }

@@ -326,14 +326,15 @@ class Learner:
             # the layer-1 finish launch adds in slab order (and takes the norm partials of): 256-row ranges for dWh; for dW2
             # twice as long (512 rows) from B = 1024 on: half the blocks, half the slabs for the finish launch to add (B = 1024:
             # 420 blocks — one round of two per CU — instead of 548: 21.8k -> 22.5k updates/s when it was introduced;
-            # B = 2048 with the blocks placed by row on the XCDs: 19.3k -> 19.7k; four times as long: 18.4k). Batch sizes
+            # B = 2048 with the blocks placed by row on the XCDs: 19.3k -> 19.7k; four times as long: 18.4k; NOT at B = 512,
+            # where one 512-row range means 64 two-chunk blocks on a quarter of the chip: 30.1k -> 30.5k with two). Batch sizes
             # that are not multiples of 256: as many equal ranges (<= 8, whole 64-row blocks) as divide B / 64.
             def k_ranges(target, most):
                 """largest number of equal K ranges <= most, each whole 16-k steps and at least `target` rows long"""
                 return max([d for d in range(1, most + 1) if B % d == 0 and (B // d) % 16 == 0 and B // d >= target] or [1])
             ks = B // 256 if B % 256 == 0 else k_ranges(256, 8)
             ks_w2 = ks_wh = ks
-            if ks >= 2 and ks % 2 == 0 and (B // (ks // 2)) % 256 == 0:
+            if ks >= 4 and ks % 2 == 0 and (B // (ks // 2)) % 256 == 0:
                 ks_w2 = ks // 2
             self.bb_slab_w2 = torch.zeros(ks_w2, H * H, **f32)
             self.bb_slab_wh = torch.zeros(ks_wh, NHP * HP, **f32)
