@@ -1,14 +1,11 @@
 // The second stage of layer 2's BatchNorm backward inside the backward GEMM launch (include/naf_hip.h, naf_gemm_bn2bwd_t): the
 // fold of the block sums by the launch's first workgroups and the readers' side of the hand-off. Shared by the two forms of the
 // bundle (gemm_bundle.hip: one 32 x 32 block per workgroup; gemm_bundle_p.hip: persistent workgroups on 64 x 64 tiles); both
-// run 512 threads per workgroup.
+// run 512 threads per workgroup; the shipping one also 256 (THREADS).
 #pragma once
 #include "common.h"
 #include "../../include/naf_hip.h"
 
-#ifndef GB_THREADS
-#define GB_THREADS 512
-#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- the block sums are folded ONCE per launch ----------------------------------------------------------------------------------
@@ -29,8 +26,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Records and polls are sc1 only (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire).
 #define GB_POLL_TICKS 5000000LL          // 50 ms at 100 MHz
 #define GB_FOLD_COLS 32
+template <int THREADS = 512>
 __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P, int f, int tid, float* scratch) {
-    constexpr int NPAIR = GB_FOLD_COLS / 2, PARTS = GB_THREADS / NPAIR, QMAX = 4;
+    constexpr int NPAIR = GB_FOLD_COLS / 2, PARTS = THREADS / NPAIR, QMAX = 128 / PARTS;
     static_assert(PARTS * QMAX >= 128, "npb <= 128");
     const int col0 = f * GB_FOLD_COLS;
     const int pair = tid % NPAIR, part = tid / NPAIR;

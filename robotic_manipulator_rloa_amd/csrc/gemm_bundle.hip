@@ -35,69 +35,79 @@ struct GemmBundle {
 // every wave reads its fragments: lane (r, g) takes k = 16 j + 4 g .. +3 of row r for BOTH operands, so the four MFMAs
 // of macro-step j use each k once. One L2 round trip per 256 k instead of one per
 // fragment (the register-fed form of this kernel issued 256 4-byte loads per lane per tile and ran 10.2 us).
-#ifndef GB_KC
-#define GB_KC 256                 // k per staged chunk
-#endif
-#define GB_LD (GB_KC + 4)         // [row][k] panels: 16-B aligned rows, b128 fragment reads spread over the banks
-#define GB_LDK 36                 // [k][row] panels (k-major operands keep their memory layout): 32 rows + 4 pad
-#define GB_PANEL (GB_KC * GB_LDK) // floats per panel buffer (>= 32 * GB_LD)
+// Two forms of the kernel (template parameters T = threads per workgroup, KC = k per staged chunk):
+//   <512, 256>  8 waves, two per 16 x 16 tile (K halves), 77.8 KB of LDS: two workgroups per CU. Launches of up to 512 blocks
+//               (B <= 1024): one round, and the block's own latency chain is what counts.
+//   <256, 128>  4 waves, one per tile, 40 KB of LDS: FOUR workgroups per CU (the same 16 waves), so the 920 blocks of a
+//               B = 2048 launch are resident at once instead of in two rounds of 512. Worth 1.5 - 2 %, not more: with every
+//               block staging at once the staging phase takes 4.5 us instead of 2.6 — the launch pulls 87 MB of panels through
+//               the L2 -> L1 path either way (~19 TB/s over the chip, ~75 GB/s per CU), and its waves spend 43 % of their cycles
+//               parked on memory or barriers and 38 % waiting for the MFMA pipe their neighbours hold (SQ_WAIT_ANY /
+//               SQ_WAIT_INST_ANY, profiles/r03_pmc_sq_b2048.csv): phases of co-resident blocks coincide instead of interleaving.
+template <int T, int KC>
+struct GB {
+    static constexpr int THREADS = T, CHUNK = KC;
+    static constexpr int LD = KC + 4;          // [row][k] panels: 16-B aligned rows, b128 fragment reads spread over the banks
+    static constexpr int LDK = 36;             // [k][row] panels (k-major operands keep their memory layout): 32 rows + 4 pad
+    static constexpr int PANEL = KC * LDK;     // floats per panel buffer (>= 32 * LD)
+    static constexpr int KSPLIT = T / 256;     // waves per 16 x 16 tile: each takes 1/KSPLIT of the K chunk
+    static constexpr int PT = KC * 8 / T;      // float4 per thread per panel
+    static constexpr int RK = KC / 4;          // float4 per row of a k-contiguous panel: T / RK = 8 rows per pass
+    static_assert(PT == 4 && T / RK == 8 && 32 * LD <= PANEL && (KSPLIT == 1 || KSPLIT == 2), "panel decomposition");
+};
+#define GB_PT 4
 
 // Stage a 32-row x kc panel with 16-byte loads AND 16-byte LDS stores, in the operand's own memory order:
-//   k-contiguous operand -> LDS [row][k] (stride GB_LD), fragments read as one ds_read_b128 per macro-step
-//   k-major operand      -> LDS [k][row] (stride GB_LDK), fragments read as four ds_read_b32 (bank = 4k + row: the two
+//   k-contiguous operand -> LDS [row][k] (stride LD), fragments read as one ds_read_b128 per macro-step
+//   k-major operand      -> LDS [k][row] (stride LDK), fragments read as four ds_read_b32 (bank = 4k + row: the two
 //                           16-lane groups a b32 read serves per cycle never collide)
 // (the first version transposed k-major panels while staging: 4 ds_write_b32 per float4 with a 4-way bank conflict)
-// A panel is 32 rows x kc k = kc * 8 float4, GB_KC * 8 / 256 = 8 per thread. ALL of a thread's loads — of both panels —
+// A panel is 32 rows x kc k = kc * 8 float4, KC * 8 / T = 4 per thread. ALL of a thread's loads — of both panels —
 // are issued before the first LDS store: as a load -> store loop (one load in flight per thread) the staging was 16
 // serial memory round trips per block, ~200 cycles each on L2 hits but 545+ on data the previous kernel had just
 // written (Infinity Cache): the whole fresh-data penalty of this kernel (benchmarks/chain_probe.py: 1.8 of its 8.5 us).
-#ifndef GB_THREADS
-#define GB_THREADS 512
-#endif
-#define GB_KSPLIT (GB_THREADS / 256)   // waves per 16 x 16 tile: each takes 1/GB_KSPLIT of the K chunk
-#define GB_PT (GB_KC * 8 / GB_THREADS)   // float4 per thread per panel
-// FULL = the chunk is a whole GB_KC (every call but the tail of a K that is not a multiple of 256): row / k indices are
+// FULL = the chunk is a whole KC (every call but the tail of a K that is not a multiple of it): row / k indices are
 // shifts; the general form divides by a run-time k4n once per element — ~20 integer instructions, 32 times per thread,
 // in a kernel whose waves run ~1,100 instructions in all.
-template <bool KMAJOR, bool FULL>
+template <class G, bool KMAJOR, bool FULL>
 __device__ static inline void load_panel(float4 (&v)[GB_PT], const float* __restrict__ p, int ld, int row0,
                                          int rows_total, int k0, int kc, int tid) {
 #pragma unroll
     for (int i = 0; i < GB_PT; ++i) {
-        const int e = tid + GB_THREADS * i;
+        const int e = tid + G::THREADS * i;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (FULL || e < kc * 8) {
             if (KMAJOR) {
                 const int k = e >> 3, r4 = (e & 7) * 4;
                 if (row0 + r4 < rows_total) v[i] = *(const float4*)(p + (int64_t)(k0 + k) * ld + row0 + r4);
             } else {
-                const int k4n = FULL ? GB_KC / 4 : kc >> 2;
-                const int row = FULL ? e / (GB_KC / 4) : e / k4n, k4 = (e - row * k4n) * 4;
+                const int k4n = FULL ? G::RK : kc >> 2;
+                const int row = FULL ? e / G::RK : e / k4n, k4 = (e - row * k4n) * 4;
                 if (row0 + row < rows_total) v[i] = *(const float4*)(p + (int64_t)(row0 + row) * ld + k0 + k4);
             }
         }
     }
 }
 
-template <bool KMAJOR, bool FULL>
+template <class G, bool KMAJOR, bool FULL>
 __device__ static inline void store_panel(float* __restrict__ sm, const float4 (&v)[GB_PT], int kc, int tid) {
 #pragma unroll
     for (int i = 0; i < GB_PT; ++i) {
-        const int e = tid + GB_THREADS * i;
+        const int e = tid + G::THREADS * i;
         if (FULL || e < kc * 8) {
             if (KMAJOR) {
                 const int k = e >> 3, r4 = (e & 7) * 4;
-                *(float4*)(sm + k * GB_LDK + r4) = v[i];
+                *(float4*)(sm + k * G::LDK + r4) = v[i];
             } else {
-                const int k4n = FULL ? GB_KC / 4 : kc >> 2;
-                const int row = FULL ? e / (GB_KC / 4) : e / k4n, k4 = (e - row * k4n) * 4;
-                *(float4*)(sm + row * GB_LD + k4) = v[i];
+                const int k4n = FULL ? G::RK : kc >> 2;
+                const int row = FULL ? e / G::RK : e / k4n, k4 = (e - row * k4n) * 4;
+                *(float4*)(sm + row * G::LD + k4) = v[i];
             }
         }
     }
 }
 
-// The same panel (whole GB_KC chunks only) through buffer loads (common.h: naf_buf_*): wave-uniform resource and chunk /
+// The same panel (whole KC chunks only) through buffer loads (common.h: naf_buf_*): wave-uniform resource and chunk /
 // row offsets on the scalar unit, ONE lane offset per panel computed once per block. The flat-addressed form above spends
 // ~10 vector instructions per float4 (64-bit multiply-adds, bounds selects); with 8 loads per thread per chunk, 8 waves per
 // block and two blocks per CU the blocks of a full launch were bound by VALU issue — every block of a 512-block round took
@@ -108,39 +118,40 @@ struct PanelSrc {
     __amdgpu_buffer_rsrc_t rs;
     unsigned voff, ld4;
 };
-template <bool KMAJOR>
+template <class G, bool KMAJOR>
 __device__ __forceinline__ static PanelSrc panel_src(const float* __restrict__ p, int ld, int row0, int rows_total, int k_total, int tid) {
     PanelSrc s;
     s.ld4 = (unsigned)ld * 4u;
-    if (KMAJOR) {                                          // [K][rows]: (k, row) at (k * ld + row) * 4; k = (tid >> 3) + 64 i
+    if (KMAJOR) {                                          // [K][rows]: (k, row) at (k * ld + row) * 4; k = (tid >> 3) + (T / 8) i
         s.rs = naf_buf(p, (unsigned)k_total * s.ld4);
         const int r4 = (tid & 7) * 4;
         s.voff = row0 + r4 < rows_total ? (unsigned)(tid >> 3) * s.ld4 + (unsigned)(row0 + r4) * 4u : 0x7f000000u;
-    } else {                                               // [rows][K]: row = wave + 8 i, k = 4 lane
+    } else {                                               // [rows][K]: row = tid / RK + 8 i, k = 4 (tid % RK); RK = 64: one row per wave
         s.rs = naf_buf(p, (unsigned)rows_total * s.ld4);
-        s.voff = (unsigned)(tid & 63) * 16u;
+        const int lane = tid & 63;
+        s.voff = (unsigned)(lane % G::RK) * 16u + (unsigned)(lane / G::RK) * s.ld4;
     }
     return s;
 }
-template <bool KMAJOR>
+template <class G, bool KMAJOR>
 __device__ __forceinline__ static void load_panel_buf(float4 (&v)[GB_PT], const PanelSrc& s, int row0, int k0, int wave) {
 #pragma unroll
     for (int i = 0; i < GB_PT; ++i) {
-        const unsigned soff = KMAJOR ? (unsigned)(k0 + (GB_THREADS / 8) * i) * s.ld4
-                                     : (unsigned)(row0 + wave + (GB_THREADS / 64) * i) * s.ld4 + (unsigned)k0 * 4u;
+        const unsigned soff = KMAJOR ? (unsigned)(k0 + (G::THREADS / 8) * i) * s.ld4
+                                     : (unsigned)(row0 + wave * (64 / G::RK) + 8 * i) * s.ld4 + (unsigned)k0 * 4u;
         const naf_f32x4 t = naf_buf_f4(s.rs, s.voff, soff);
         v[i] = make_float4(t.x, t.y, t.z, t.w);
     }
 }
 
 // fragment of macro-step kk for lane (r, g): elements k = kk + 4 g + c, c = 0..3, of panel row `row`
-template <bool KMAJOR>
+template <class G, bool KMAJOR>
 __device__ static inline float4 read_frag(const float* __restrict__ sm, int row, int g, int kk) {
     if (KMAJOR) {
-        const float* q = sm + (kk + 4 * g) * GB_LDK + row;
-        return make_float4(q[0], q[GB_LDK], q[2 * GB_LDK], q[3 * GB_LDK]);
+        const float* q = sm + (kk + 4 * g) * G::LDK + row;
+        return make_float4(q[0], q[G::LDK], q[2 * G::LDK], q[3 * G::LDK]);
     }
-    return *(const float4*)(sm + row * GB_LD + kk + 4 * g);
+    return *(const float4*)(sm + row * G::LD + kk + 4 * g);
 }
 
 // Epilogue of the dA1 = dZ2 W2 blocks in the large-batch chain: the C tile (32 batch rows x 32 layer-1 features) is the
@@ -153,22 +164,25 @@ __device__ static inline float4 read_frag(const float* __restrict__ sm, int row,
 // that hold the dA1 tiles — dy never leaves their registers before it is final — and P = dY^T X (2 x 2 tiles, K = 32 rows)
 // by the other four, from dy in LDS. (The first version did both on the VALU, one (row, column) pair per thread with LDS
 // operands: 2.1 - 2.8 us of a 7 us block, and two resident blocks per CU take turns at it — benchmarks/kernel_timeline.py.)
+template <class G>
 struct L1bwdRegs {
+    static constexpr int NW = 1024 / G::THREADS;      // scalars of the 32 x KP W1 tile per thread
     f32x4 x;           // one float4 of the X tile (threads < 32 * KP / 4)
-    float w[2];        // two scalars of the W1 tile
+    float w[NW];
     float a1[4];       // accumulator waves: A1 at the lane's four C/D elements (rows 4 g + e, column r of the tile)
     float mean, invstd, bias;   // of the lane's column
 };
+template <class G>
 __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int bn, int tid, bool owner, int wm, int wn, int r, int g,
-                                                  L1bwdRegs& R) {
+                                                  L1bwdRegs<G>& R) {
     const naf_gemm_l1bwd_t& E = D.epi;
     const int KP = E.kp, m0 = bm * 32, n0 = bn * 32;
     const int xr = KP == 24 ? tid / 6 : tid / 8, xq = tid - xr * (KP / 4);       // (KP is 24 or 32: divisions by constants)
     R.x = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (xr < 32) R.x = ((const f32x4*)(E.x + (int64_t)(m0 + xr) * E.ldx))[xq];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + GB_THREADS * i;
+    for (int i = 0; i < L1bwdRegs<G>::NW; ++i) {
+        const int e = tid + G::THREADS * i;
         const int c = KP == 24 ? e / 24 : e / 32, k = e - c * KP;
         R.w[i] = (c < 32 && k < E.K) ? E.W[(int64_t)(n0 + c) * E.K + k] : 0.f;
     }
@@ -180,9 +194,11 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
     R.bias = E.bias[col];
 }
 
+template <class G>
 __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int bn, const f32x4& acc, bool owner, int wm, int wn,
-                                                  int r, int g, float* sA, float* sB, int tid, const L1bwdRegs& R) {
-    static_assert(GB_KSPLIT == 2, "the epilogue deals its two products to the accumulator waves and to the other four");
+                                                  int r, int g, float* sA, float* sB, int tid, const L1bwdRegs<G>& R) {
+    // KSPLIT = 2: the two products are dealt to the accumulator waves (owner) and to the other four, which run side by side;
+    // KSPLIT = 1: every wave holds an accumulator tile and takes its share of P behind the barrier.
     const naf_gemm_l1bwd_t& E = D.epi;
     const int KP = E.kp, XS = KP + 4;
     const int n0 = bn * 32;
@@ -190,13 +206,14 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
     float* sW = sA + 32 * XS;          // [32 cols][XS]
     float* sDY = sB;                   // [32 rows][33]
     float2* sRed = (float2*)(sB + 32 * 33);   // [2 row tiles][32 columns]
-    // (the barrier behind the K halves' hand-over has every wave past its last fragment read: the panels are free)
+    // (KSPLIT = 2: the barrier behind the K halves' hand-over has every wave past its last fragment read: the panels are free)
+    if (G::KSPLIT == 1) __syncthreads();
     {
         const int xr = KP == 24 ? tid / 6 : tid / 8, xq = tid - xr * (KP / 4);
         if (xr < 32) *(f32x4*)(sX + xr * XS + 4 * xq) = R.x;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = tid + GB_THREADS * i;
+        for (int i = 0; i < L1bwdRegs<G>::NW; ++i) {
+            const int e = tid + G::THREADS * i;
             const int c = KP == 24 ? e / 24 : e / 32, k = e - c * KP;
             if (c < 32) sW[c * XS + k] = R.w[i];
         }
@@ -235,10 +252,10 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
         const float2 t0 = sRed[tid], t1 = sRed[32 + tid];
         ((float2*)E.partials)[(int64_t)bm * D.N + n0 + tid] = make_float2(t0.x + t1.x, t0.y + t1.y);
     }
-    if (!owner) {
+    if (G::KSPLIT == 1 || !owner) {
         // P share of this block: tile (mt, nt) = columns mt * 16 .. +15 x k nt * 16 .. +15, reduction over the 32 rows.
         // A[m = column][k = row] = dy[row][column], B[k = row][n] = x[row][n]
-        const int mt = wm, nt = wn;                          // (the four non-accumulator waves carry the same (wm, wn) pairs)
+        const int mt = wm, nt = wn;                          // (KSPLIT = 2: the four non-accumulator waves carry the same (wm, wn) pairs)
         const bool n_on = nt * 16 + r < KP;
         const int xc = n_on ? nt * 16 + r : 0;
         f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
@@ -263,12 +280,12 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
 // free until the MFMAs are over):  dz = k1 dy - k1 c1 - (z - mean) (invstd k1 c2),  k1 = gamma invstd, c1 = sum dy / B, c2 = sum dy xhat / B
 //   cst[0][c] = mean, [1] = k1, [2] = k1 c1, [3] = invstd k1 c2
 // dy -> dz on a staged A panel. The thread's float4 i covers four consecutive COLUMNS of the operand:
-//   k-contiguous A (K = H = 256: always whole chunks): row wave + 8 i, columns k0 + 4 lane .. +3;
-//   k-major A: k = (tid >> 3) + 64 i, columns 4 (tid & 7) .. +3 of the block — the same columns for every i, in whole chunks (buffer
-//   loads) and in the tail chunk of a K range that is not a multiple of 256 (load_panel<true, false>: e = tid + 512 i, column quad e & 7)
-template <bool AK>
+//   k-contiguous A (K = H = 256: always whole chunks): row tid / RK + 8 i, columns k0 + 4 (tid % RK) .. +3;
+//   k-major A: k = (tid >> 3) + (T / 8) i, columns 4 (tid & 7) .. +3 of the block — the same columns for every i, in whole chunks (buffer
+//   loads) and in the tail chunk of a K range that is not a multiple of KC (load_panel<true, false>: e = tid + T i, column quad e & 7)
+template <class G, bool AK>
 __device__ __forceinline__ static void gemm_bn2bwd_apply(float4 (&va)[GB_PT], const float4 (&vz)[GB_PT], const float* cst, int tid, int k0) {
-    const int ci = AK ? 4 * (tid & 7) : k0 + 4 * (tid & 63);
+    const int ci = AK ? 4 * (tid & 7) : k0 + 4 * (tid & (G::RK - 1));
     const f32x4 mean = *(const f32x4*)(cst + ci), k1 = *(const f32x4*)(cst + 256 + ci), kc1 = *(const f32x4*)(cst + 512 + ci),
                 q = *(const f32x4*)(cst + 768 + ci);
 #pragma unroll
@@ -302,15 +319,15 @@ int naf_tl_read_gb_wg(int, long long*) { return NAF_ERR_STATE; }
 #endif
 // (timeline marks: the first GEMM block — behind the folding workgroups, if any — and the launch's last)
 #define GB_TL(slot) NAF_TL_FL(g_tl_gb, NAF_TL_GEMM_BUNDLE, slot, (int)blockIdx.x == tl_first, blockIdx.x == gridDim.x - 1)
-template <bool AK, bool BK>
-__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int ks, float* sA, float* sB, float* sQ, float* sC, int tl_first) {
-    static_assert(GB_KC == 256 && GB_THREADS == 512, "load_panel_buf's row / k decomposition");
+template <class G, bool AK, bool BK>
+__device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int ks, float* sA, float* sB, float* sC, int tl_first) {
+    constexpr int KC = G::CHUNK, KSPLIT = G::KSPLIT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform values on the scalar unit
     const int r = lane & 15, g = lane >> 4;
-    // 8 waves: two per 16 x 16 tile of the 32 x 32 block, each taking one half of the K chunk — the per-wave chain of
+    // KSPLIT = 2 (8 waves): two per 16 x 16 tile of the 32 x 32 block, each taking one half of the K chunk — the per-wave chain of
     // dependent MFMAs (the longest single piece of this kernel: 1.5 of its 5.0 us with 64 of them) is halved; the two
-    // halves meet through LDS, lower half first (fixed order)
+    // halves meet through LDS, lower half first (fixed order). KSPLIT = 1 (4 waves): one wave per tile, whole chunks.
     const int tile = wave & 3, kh = wave >> 2;
     const int wm = tile >> 1, wn = tile & 1;
     const int m0 = bm * 32, n0 = bn * 32;
@@ -321,7 +338,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     // Split K (k_split > 1: the weight gradients at large batches, K = B): this block takes K range ks and writes slab ks;
     // the slabs are added in slab order by the consumer (bb_layer1_bwd_finish's reduce blocks). 64 blocks walking
     // K = 1024 pulled 256 KB each through one CU's L2 port (13.6 us per launch at B = 1024); 256 blocks of K = 256 do not.
-    L1bwdRegs epi_regs;
+    L1bwdRegs<G> epi_regs;
     // Every field of the product's description that the block uses up to its first MFMA, requested NOW, in one batch. Left to
     // itself the compiler fetches a field where it is first used — behind the branches of the prefetch, of the panel sources and
     // of the prologue — and the kernel arguments are not in the scalar cache when a workgroup starts: ten dependent scalar round
@@ -333,60 +350,60 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
                  "s"(D.pro.cst), "s"(D.pro.epoch), "s"(D.pro.errors));
     GB_TL(0);
     GB_TL_WG(0);
-    if (D.epi.x) gemm_l1bwd_prefetch(D, bm, bn, tid, !kh, wm, wn, r, g, epi_regs);
+    if (D.epi.x) gemm_l1bwd_prefetch<G>(D, bm, bn, tid, !kh, wm, wn, r, g, epi_regs);
     const int kper = D.K / D.k_split, k_lo = ks * kper, k_hi = k_lo + kper;
-    const PanelSrc pa = panel_src<AK>(D.A, D.lda, m0, D.M, D.K, tid), pb = panel_src<BK>(D.B, D.ldb, n0, D.N, D.K, tid);
+    const PanelSrc pa = panel_src<G, AK>(D.A, D.lda, m0, D.M, D.K, tid), pb = panel_src<G, BK>(D.B, D.ldb, n0, D.N, D.K, tid);
     const bool pro = D.pro.z != nullptr;                  // (uniform)
-    const PanelSrc pz = panel_src<AK>(pro ? D.pro.z : D.A, D.lda, m0, D.M, D.K, tid);
+    const PanelSrc pz = panel_src<G, AK>(pro ? D.pro.z : D.A, D.lda, m0, D.M, D.K, tid);
     float4 va[GB_PT], vb[GB_PT], vz[GB_PT];
     {
-        const int kc0 = kper < GB_KC ? kper : GB_KC;
-        if (kc0 == GB_KC) {
-            load_panel_buf<AK>(va, pa, m0, k_lo, wave);
-            if (pro) load_panel_buf<AK>(vz, pz, m0, k_lo, wave);
-            load_panel_buf<BK>(vb, pb, n0, k_lo, wave);
+        const int kc0 = kper < KC ? kper : KC;
+        if (kc0 == KC) {
+            load_panel_buf<G, AK>(va, pa, m0, k_lo, wave);
+            if (pro) load_panel_buf<G, AK>(vz, pz, m0, k_lo, wave);
+            load_panel_buf<G, BK>(vb, pb, n0, k_lo, wave);
         } else {
-            load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k_lo, kc0, tid);
-            if (pro) load_panel<AK, false>(vz, D.pro.z, D.lda, m0, D.M, k_lo, kc0, tid);
-            load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
+            load_panel<G, AK, false>(va, D.A, D.lda, m0, D.M, k_lo, kc0, tid);
+            if (pro) load_panel<G, AK, false>(vz, D.pro.z, D.lda, m0, D.M, k_lo, kc0, tid);
+            load_panel<G, BK, false>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
         }
     }
     if (pro) {                                            // the column constants, under the panel loads' latency
         gemm_bn2bwd_wait_constants<AK>(D.pro, m0, tid, sC);
         __syncthreads();
     }
-    for (int k0 = k_lo; k0 < k_hi; k0 += GB_KC) {
-        const int kc = (k_hi - k0) < GB_KC ? (k_hi - k0) : GB_KC;
+    for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
+        const int kc = (k_hi - k0) < KC ? (k_hi - k0) : KC;
         if (k0 != k_lo) __syncthreads();                  // previous chunk fully consumed
-        if (pro) gemm_bn2bwd_apply<AK>(va, vz, sC, tid, k0);
-        if (kc == GB_KC) {
-            store_panel<AK, true>(sA, va, kc, tid);
-            store_panel<BK, true>(sB, vb, kc, tid);
+        if (pro) gemm_bn2bwd_apply<G, AK>(va, vz, sC, tid, k0);
+        if (kc == KC) {
+            store_panel<G, AK, true>(sA, va, kc, tid);
+            store_panel<G, BK, true>(sB, vb, kc, tid);
         } else {
-            store_panel<AK, false>(sA, va, kc, tid);
-            store_panel<BK, false>(sB, vb, kc, tid);
+            store_panel<G, AK, false>(sA, va, kc, tid);
+            store_panel<G, BK, false>(sB, vb, kc, tid);
         }
-        const int k1 = k0 + GB_KC;
+        const int k1 = k0 + KC;
         if (k1 < k_hi) {                                  // next chunk's loads fly under this chunk's MFMAs
-            const int kn = (k_hi - k1) < GB_KC ? (k_hi - k1) : GB_KC;
-            if (kn == GB_KC) {
-                load_panel_buf<AK>(va, pa, m0, k1, wave);
-                if (pro) load_panel_buf<AK>(vz, pz, m0, k1, wave);
-                load_panel_buf<BK>(vb, pb, n0, k1, wave);
+            const int kn = (k_hi - k1) < KC ? (k_hi - k1) : KC;
+            if (kn == KC) {
+                load_panel_buf<G, AK>(va, pa, m0, k1, wave);
+                if (pro) load_panel_buf<G, AK>(vz, pz, m0, k1, wave);
+                load_panel_buf<G, BK>(vb, pb, n0, k1, wave);
             } else {
-                load_panel<AK, false>(va, D.A, D.lda, m0, D.M, k1, kn, tid);
-                if (pro) load_panel<AK, false>(vz, D.pro.z, D.lda, m0, D.M, k1, kn, tid);
-                load_panel<BK, false>(vb, D.B, D.ldb, n0, D.N, k1, kn, tid);
+                load_panel<G, AK, false>(va, D.A, D.lda, m0, D.M, k1, kn, tid);
+                if (pro) load_panel<G, AK, false>(vz, D.pro.z, D.lda, m0, D.M, k1, kn, tid);
+                load_panel<G, BK, false>(vb, D.B, D.ldb, n0, D.N, k1, kn, tid);
             }
         }
         __syncthreads();
         if (k0 == k_lo) GB_TL(1);
         const int steps = kc >> 4;                                    // macro-steps of 16 k, dealt in contiguous runs
-        const int kbeg = (steps * kh / GB_KSPLIT) << 4, kend = (steps * (kh + 1) / GB_KSPLIT) << 4;
+        const int kbeg = (steps * kh / KSPLIT) << 4, kend = (steps * (kh + 1) / KSPLIT) << 4;
 #pragma unroll 4
         for (int kk = kbeg; kk < kend; kk += 16) {
-            const float4 a = read_frag<AK>(sA, wm * 16 + r, g, kk);
-            const float4 b = read_frag<BK>(sB, wn * 16 + r, g, kk);
+            const float4 a = read_frag<G, AK>(sA, wm * 16 + r, g, kk);
+            const float4 b = read_frag<G, BK>(sB, wn * 16 + r, g, kk);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
@@ -395,12 +412,14 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     }
     f32x4 acc = acc0 + acc1;
     GB_TL(2);
-    if (kh) *(f32x4*)(sC + (((kh - 1) * 4 + tile) * 64 + lane) * 4) = acc;
-    __syncthreads();
+    if (KSPLIT > 1) {
+        if (kh) *(f32x4*)(sC + (((kh - 1) * 4 + tile) * 64 + lane) * 4) = acc;
+        __syncthreads();
+    }
     float sq = 0.f;
     if (!kh) {
 #pragma unroll
-        for (int h = 1; h < GB_KSPLIT; ++h) acc = acc + *(const f32x4*)(sC + (((h - 1) * 4 + tile) * 64 + lane) * 4);
+        for (int h = 1; h < KSPLIT; ++h) acc = acc + *(const f32x4*)(sC + (((h - 1) * 4 + tile) * 64 + lane) * 4);
         if (D.C) {
             // rows past M end the resource, a column past N gets an offset past everything: dropped by the hardware. Those
             // elements are sums over zero panels, so they add nothing to sq either.
@@ -417,11 +436,13 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         }
     }
     GB_TL(3);
-    if (D.epi.x) gemm_l1bwd_epilogue(D, bm, bn, acc, !kh, wm, wn, r, g, sA, sB, tid, epi_regs);
+    if (D.epi.x) gemm_l1bwd_epilogue<G>(D, bm, bn, acc, !kh, wm, wn, r, g, sA, sB, tid, epi_regs);
     GB_TL(4);
     if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 tiles)
+        float* sQ = sA;                                       // (the panels are dead: behind the barrier every wave is past them)
         sq = naf_sum64(sq);
-        if (!kh && lane == 0) sQ[tile] = sq;                  // sQ is touched nowhere else: no barrier in front
+        __syncthreads();
+        if (!kh && lane == 0) sQ[tile] = sq;
         __syncthreads();
         if (tid == 0) D.sumsq[bm * D.tiles_n + bn] = sQ[0] + sQ[1] + sQ[2] + sQ[3];
     }
@@ -432,15 +453,16 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
 #ifndef GB_WAVES_PER_EU
 #define GB_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_WAVES_PER_EU, GB_WAVES_PER_EU))) void gemm_bundle_kernel(const GemmBundle bundle) {
-    __shared__ __attribute__((aligned(16))) float sA[GB_PANEL];
-    __shared__ __attribute__((aligned(16))) float sB[GB_PANEL];
-    __shared__ float sQ[4];
-    __shared__ __attribute__((aligned(16))) float sC[(GB_KSPLIT - 1) * 4 * 64 * 4];
+template <int T, int KC>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(GB_WAVES_PER_EU, GB_WAVES_PER_EU))) void gemm_bundle_kernel(const GemmBundle bundle) {
+    using G = GB<T, KC>;
+    __shared__ __attribute__((aligned(16))) float sA[G::PANEL];
+    __shared__ __attribute__((aligned(16))) float sB[G::PANEL];
+    __shared__ __attribute__((aligned(16))) float sC[4 * 64 * 4];   // the column constants of the prologue, then the K halves' hand-over
     int t = blockIdx.x;                                   // one 32 x 32 block per workgroup
     if (bundle.n_fold) {                                  // (uniform) the launch's first workgroups fold the BatchNorm-backward sums
         if (__builtin_expect(t < bundle.n_fold, 0)) {
-            gemm_bn2bwd_fold_block(bundle.d[bundle.fold_desc].pro, t, threadIdx.x, sA);
+            gemm_bn2bwd_fold_block<T>(bundle.d[bundle.fold_desc].pro, t, threadIdx.x, sA);
             return;
         }
         t -= bundle.n_fold;
@@ -483,11 +505,11 @@ __global__ __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(GB_W
         }
     }
     if (D.a_kmajor) {
-        if (D.b_kmajor) gemm_block<true, true>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
-        else gemm_block<true, false>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
+        if (D.b_kmajor) gemm_block<G, true, true>(D, bm, bn, ks, sA, sB, sC, bundle.n_fold);
+        else gemm_block<G, true, false>(D, bm, bn, ks, sA, sB, sC, bundle.n_fold);
     } else {
-        if (D.b_kmajor) gemm_block<false, true>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
-        else gemm_block<false, false>(D, bm, bn, ks, sA, sB, sQ, sC, bundle.n_fold);
+        if (D.b_kmajor) gemm_block<G, false, true>(D, bm, bn, ks, sA, sB, sC, bundle.n_fold);
+        else gemm_block<G, false, false>(D, bm, bn, ks, sA, sB, sC, bundle.n_fold);
     }
 }
 
@@ -542,7 +564,11 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     }
     for (int i = n; i < NAF_GEMM_BUNDLE_MAX; ++i) b.d[i] = b.d[0];
     b.total_tiles = tiles;
-    gemm_bundle_kernel<<<tiles + b.n_fold, GB_THREADS, 0, (hipStream_t)stream>>>(b);
+    // more blocks than the 8-wave form has room for at once (two per CU): the 4-wave form, four workgroups per CU
+    // (updates/s, A/B/A/B on one box: B = 1536 20.6k -> 21.0k, B = 2048 20.05k -> 20.35k; B = 1024, 428 blocks: 26.1k -> 25.2k)
+    const bool big = tiles + b.n_fold > 512;
+    if (big) gemm_bundle_kernel<256, 128><<<tiles + b.n_fold, 256, 0, (hipStream_t)stream>>>(b);
+    else gemm_bundle_kernel<512, 256><<<tiles + b.n_fold, 512, 0, (hipStream_t)stream>>>(b);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
