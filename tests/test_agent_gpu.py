@@ -386,6 +386,24 @@ def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse):
         assert f"XGMI_OK_{k};" in r.stdout, r.stdout[-2000:]
 
 
+def test_xgmi_try_create_falls_back_on_every_rank_when_one_fails():
+    """parallel.XgmiAllReduce.try_create is collective also in failure: rank 1 cannot create its communicator (injected:
+    naf_xgmi_create returns an error, null handle) -> both ranks get None, the fallback's barrier pairs up on both, the next
+    collective completes, and a second attempt without the fault brings the path up."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, NAF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+               OMP_NUM_THREADS="2", NAF_TEST_XGMI_FAIL_RANK="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "xgmi_worker.py")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert "XGMI_OK_0;" in r.stdout and "XGMI_OK_1;" in r.stdout, r.stdout[-2000:]
+    assert "one-shot all-reduce disabled" in r.stderr
+
+
 def _check_bench_line_n2(r, steps, rehearsal):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -40,8 +40,39 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     n = 81152                                          # the flat parameter count at S=21/A=6 (NetLayout.P)
+    fail_rank = os.environ.get("NAF_TEST_XGMI_FAIL_RANK")
+    if fail_rank is not None:
+        # one rank cannot create its communicator (null handle): EVERY rank must come back with None, and the collective
+        # that follows must pair up — the fallback's barrier runs on the failing rank too (parallel.py)
+        from robotic_manipulator_rloa_amd import _lib
+        real, real_load = _lib.load(), _lib.load
+
+        class NoCreate:
+            def __getattr__(self, name):
+                return getattr(real, name)
+
+            def naf_xgmi_create(self, *args):
+                return -1
+
+        if rank == int(fail_rank):
+            _lib.load = lambda: NoCreate()
+        c0 = parallel.XgmiAllReduce.try_create(n, dev)
+        _lib.load = real_load
+        assert c0 is None, "a rank failed to create its communicator, yet try_create returned one"
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)                                # would hang or mismatch if a rank had skipped the barrier
+        assert t.item() == world * (world + 1) / 2, t
     comm = parallel.XgmiAllReduce.try_create(n, dev)
     assert comm is not None, "xgmi communicator was not created / did not pass its self-test"
+    if fail_rank is not None:                             # (the path still comes up behind a failed attempt)
+        g = rank_input(rank, 1, n, dev)
+        comm.all_reduce(g, g)
+        assert torch.equal(g, expected_sum(1, n, world, dev))
+        torch.cuda.synchronize()
+        comm.close()
+        print(f"XGMI_OK_{rank};", flush=True)
+        dist.destroy_process_group()
+        return
     base_epoch = comm.status()[0]
 
     # ---- 1. random data, eager launches, alternating in-place / out-of-place -------------------------------------
