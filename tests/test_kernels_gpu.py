@@ -663,6 +663,69 @@ def test_gemm_bundle_mfma_vs_numpy(lib, ak, bk):
     assert lib.naf_gemm_bundle(bad, 1, st()) == -1            # M not a multiple of 16
 
 
+@pytest.mark.parametrize("B", [128, 2048])
+def test_gemm_bundle_bn2bwd_prologue_fold_once_and_hang_guard(lib, B):
+    """naf_gemm_bn2bwd_t through the C ABI: the second stage of layer 2's BatchNorm backward (autograd of
+    naf_neural_network.py:79-80) applied to the A panels while they are staged, its block sums folded ONCE per launch by the
+    launch's first workgroups and handed on as tagged records — against numpy in double (both operand orders, i.e. the dA1- and
+    the dW2-shaped product; B = 2048: the four-wave form of the kernel) — and the hang guard: a product whose records nobody
+    folds gives up after 50 ms, poisons its output AND counts the event in the pinned error word."""
+    from robotic_manipulator_rloa_amd import _lib
+    rng = np.random.default_rng(B)
+    H, N, rows = 256, 64, 16
+    N1 = 256 if B == 2048 else N                         # (B = 2048: 648 blocks > 512 -> gemm_bundle_kernel<256, 128>)
+    npb = B // rows
+    dy = rng.standard_normal((B, H)) * (rng.random((B, H)) > 0.4)
+    z = rng.standard_normal((B, H)) * 1.5 + 0.3
+    W = rng.standard_normal((H, N1))                     # k-major B operand of the dA1-shaped product: [K = H][N]
+    A1 = rng.standard_normal((B, N))                     # k-major B operand of the dW2-shaped product: [K = B][N]
+    gamma = rng.standard_normal(H) + 1.5
+    mean, var = z.mean(0), z.var(0)
+    invstd = 1.0 / np.sqrt(var + 1e-5)
+    xhat = (z - mean) * invstd
+    sdy, sdx = dy.sum(0), (dy * xhat).sum(0)
+    k1 = gamma * invstd
+    dz = k1 * dy - k1 * (sdy / B) - (z - mean) * (invstd * k1 * (sdx / B))
+    parts = np.stack([np.stack([dy[i * rows:(i + 1) * rows].sum(0), (dy * xhat)[i * rows:(i + 1) * rows].sum(0)], -1)
+                      for i in range(npb)])             # [npb][H][2]
+    t = dict(dy=dev(dy), z=dev(z), W=dev(W), A1=dev(A1), gamma=dev(gamma), mean=dev(mean), inv=dev(invstd), parts=dev(parts))
+    dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    cst = torch.zeros(H, 4, device="cuda")
+    epoch = torch.full((1,), 5, dtype=torch.int32, device="cuda")
+    err = torch.zeros(8, dtype=torch.int64).pin_memory()
+    pro = _lib.GemmBn2Bwd(t["z"].data_ptr(), t["parts"].data_ptr(), t["gamma"].data_ptr(), t["mean"].data_ptr(), t["inv"].data_ptr(),
+                          dg.data_ptr(), db.data_ptr(), npb, B, H, cst.data_ptr(), epoch.data_ptr(), err.data_ptr())
+    ks = max(1, B // 256)
+    c1 = torch.full((B, N1), -7.0, device="cuda")
+    slabs = torch.full((ks, H, N), -7.0, device="cuda")
+    D = _lib.GemmDesc
+    arr = (D * 2)(D(t["dy"].data_ptr(), t["W"].data_ptr(), c1.data_ptr(), None, B, N1, H, H, N1, N1, 0, 1, 1, 0, None, C.addressof(pro)),
+                  D(t["dy"].data_ptr(), t["A1"].data_ptr(), slabs.data_ptr(), None, H, N, B, H, N, N, 1, 1, ks, H * N, None,
+                    C.addressof(pro)))
+    assert lib.naf_gemm_bundle(arr, 2, st()) == 0
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0
+    np.testing.assert_allclose(c1.cpu().numpy(), dz @ W, rtol=2e-4, atol=2e-4 * np.sqrt(H))
+    np.testing.assert_allclose(slabs.sum(0).cpu().numpy(), dz.T @ A1, rtol=2e-4, atol=2e-4 * np.sqrt(B))
+    np.testing.assert_allclose(dg.cpu().numpy(), sdx, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), sdy, rtol=1e-4, atol=1e-3)
+    if B != 128:
+        return
+    # a second product with records of its own that no workgroup folds (only the launch's first prologue is folded): its
+    # blocks wait 50 ms, then give up loudly
+    cst2 = torch.zeros(H, 4, device="cuda")
+    pro2 = _lib.GemmBn2Bwd(t["z"].data_ptr(), t["parts"].data_ptr(), t["gamma"].data_ptr(), t["mean"].data_ptr(), t["inv"].data_ptr(),
+                           dg.data_ptr(), db.data_ptr(), npb, B, H, cst2.data_ptr(), epoch.data_ptr(), err.data_ptr())
+    c2 = torch.zeros(32, N, device="cuda")
+    arr2 = (D * 2)(D(t["dy"].data_ptr(), t["W"].data_ptr(), c1.data_ptr(), None, B, N1, H, H, N1, N1, 0, 1, 1, 0, None, C.addressof(pro)),
+                   D(t["dy"].data_ptr(), t["W"].data_ptr(), c2.data_ptr(), None, 32, N, H, H, N, N, 0, 1, 1, 0, None, C.addressof(pro2)))
+    assert lib.naf_gemm_bundle(arr2, 2, st()) == 0
+    torch.cuda.synchronize()
+    assert int(err[0]) > 0                                # counted on the host ...
+    assert torch.isnan(c2).any()                          # ... and poisoned, never a quiet wrong number
+    np.testing.assert_allclose(c1.cpu().numpy(), dz @ W, rtol=2e-4, atol=2e-4 * np.sqrt(H))   # the folded product is untouched
+
+
 def test_replay_edge_cases(lib):
     """Boundary behaviour the reference has by construction: population == batch (random.sample returns a permutation),
     host add() beyond the pinned staging size, n = 0 appends, sample() on a too-small buffer."""
