@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_eval_kernel(const float* __re
 }
 
 // Tile: 8 feature columns x 64 row phases up to B = 512 (fwd 3.3 us / bwd 3.7 us per launch at B = 256; a 32 x 32 tile: 4.5 /
-// 5.6 — picked with benchmarks/kernel_probe.py among twelve shapes), 8 x 128 beyond (B = 2048: 8.3 / 10.1 us vs 10.7 / 15.4 for
+// 5.6 — picked with round 2's benchmarks/kernel_probe.py among twelve shapes), 8 x 128 beyond (B = 2048: 8.3 / 10.1 us vs 10.7 / 15.4 for
 // 8 x 64). At most 16 rows per thread (B <= 2048): more rows per thread spill to scratch.
 #define BN_LAUNCH_RPT(KERNEL, TXv, TYv, ...)                                                               \
     do {                                                                                                   \

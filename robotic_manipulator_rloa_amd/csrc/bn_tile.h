@@ -6,7 +6,7 @@
 // two-net grids too, their x extent being a multiple of 8), and an 8-column f32 tile is a quarter of a 128-B line: with
 // tile = blockIdx.x the four tiles sharing every line of the activation matrices sit on four different XCDs, and each
 // of those L2s pulls the whole line over the fabric — for data the previous kernel has only just written (the dominant
-// cost of an update, benchmarks/chain_probe.py). Dealing CONTIGUOUS runs of tiles to an XCD lets one L2 fetch a line
+// cost of an update, round 2's benchmarks/chain_probe.py). Dealing CONTIGUOUS runs of tiles to an XCD lets one L2 fetch a line
 // once for all its tiles. Placement is speed only: results do not depend on it.
 __device__ static inline int naf_xcd_tile(int b, int n) { return (n & 7) == 0 ? (b & 7) * (n >> 3) + (b >> 3) : b; }
 

@@ -60,7 +60,7 @@ __device__ static inline void load_w_column(const float* __restrict__ Wn, int co
 // Rows that all FT_TX column lanes of a wave need (the layer input X, the heads gradient dH) go through LDS once per
 // workgroup: read straight from memory by every thread they were 8x redundant register fills — one wave-instruction per
 // 8 distinct rows — and the texture path, not the ALUs, set these kernels' pace (F1 4.2 us with the loads, 3.0 without;
-// B2 4.8 / 3.2: benchmarks/kernel_probe.py with the loads stubbed out). Cooperative, coalesced, branch-free (clamped)
+// B2 4.8 / 3.2: round 2's benchmarks/kernel_probe.py with the loads stubbed out). Cooperative, coalesced, branch-free (clamped)
 // loads; rows beyond B become zeros. Row stride 4*V4 + 4 floats: the 8 rows a wave reads at once start in 8 different
 // bank quads. Used up to RPT = 8 (B <= 512); larger tiles keep the direct loads (LDS budget).
 #define FT_STAGE_MAX_RPT 8

@@ -25,7 +25,7 @@ struct GemmDesc {
 struct GemmBundle {
     GemmDesc d[NAF_GEMM_BUNDLE_MAX];
     int n, total_tiles;
-    int rowmap;                   // XCD-aware placement of the blocks (NAF_GB_ROWMAP=0: block t is block t)
+    int rowmap;                   // XCD-aware placement of the blocks (0: block t is block t; the host sets 2)
     int n_fold, fold_desc;        // n_fold > 0: the first n_fold workgroups fold the block sums of d[fold_desc].pro ONCE for the launch
 };
 
@@ -65,7 +65,7 @@ struct GB {
 // A panel is 32 rows x kc k = kc * 8 float4, KC * 8 / T = 4 per thread. ALL of a thread's loads — of both panels —
 // are issued before the first LDS store: as a load -> store loop (one load in flight per thread) the staging was 16
 // serial memory round trips per block, ~200 cycles each on L2 hits but 545+ on data the previous kernel had just
-// written (Infinity Cache): the whole fresh-data penalty of this kernel (benchmarks/chain_probe.py: 1.8 of its 8.5 us).
+// written (Infinity Cache): the whole fresh-data penalty of this kernel (round 2's benchmarks/chain_probe.py: 1.8 of its 8.5 us).
 // FULL = the chunk is a whole KC (every call but the tail of a K that is not a multiple of it): row / k indices are
 // shifts; the general form divides by a run-time k4n once per element — ~20 integer instructions, 32 times per thread,
 // in a kernel whose waves run ~1,100 instructions in all.
