@@ -53,7 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--roofline-ring", type=int, default=4_000_000,
                     help="rows of the ring the bulk gather roofline runs on (4e6 x 256 B = 1.02 GB: beyond the 256 MiB "
                          "Infinity Cache, BASELINE configs[4]'s ring); 0 = skip")
-    ap.add_argument("--roofline-rows", type=int, default=1 << 22, help="rows gathered per bulk launch")
+    ap.add_argument("--roofline-rows", type=int, default=1 << 24,
+                    help="rows gathered per bulk launch (16 Mi: 1.1 ms per launch; the ~9 us of ramp and tail of a launch are 3 %% of a 4 Mi one)")
     return ap.parse_args(argv)
 
 
