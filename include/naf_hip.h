@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 19
+#define NAF_HIP_ABI_VERSION 20
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -286,12 +286,24 @@ int naf_bb_layer2_head_rows(int B);
  * save_invstd [2][H], q_out[B], d_heads[B][NHP], loss_partials[B/rows], dy_out (dY2), partials_bw[B/rows][H] (float2: sum dy,
  * sum dy*xhat), rows = naf_bb_layer2_head_rows(B). u / r: the action and reward columns of the minibatch rows. Replaces
  * naf_neural_network.py:78-115 + naf_algorithm.py:199-208 and the first half of layer 2's BatchNorm backward. */
+/* optional: the statistics of layer 2 folded ONCE per launch instead of by every workgroup. With more than 16 statistics blocks
+ * (B > 1024) the launch's first 16 workgroups fold 32 (net, column) pairs each and publish one 16-byte record per pair — (mean,
+ * invstd, *epoch, biased variance) — to `records` ([2 H] x 4 floats, 16-B aligned, device scratch nothing else touches); the other
+ * workgroups poll the records until they carry *epoch (same protocol and hang guard as naf_gemm_bn2bwd_t below: *epoch must differ
+ * from launch to launch — naf_bb_layer1_bwd_finish(fold_epoch) advances it once per update, so ONE launch per update may use a given
+ * records buffer; `errors`: nullable pinned host word that counts expired waits). At smaller batches the argument is ignored. */
+typedef struct naf_bb_stats_once {
+    float* records;
+    const int* epoch;
+    uint64_t* errors;
+} naf_bb_stats_once_t;
 int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
                        int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
                        int64_t stat_net_stride, float* a2_out, int ldo, float* save_mean, float* save_invstd, const float* Wh,
                        int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu, const float* r, int ldr, float gamma_td,
                        float* q_out, float* d_heads, float* loss_partials, float* dy_out, int ldd, float* partials_bw, int B,
-                       int H, int A, int p_mode, float momentum, float eps, void* stream);
+                       int H, int A, int p_mode, float momentum, float eps, const naf_bb_stats_once_t* once /* nullable */,
+                       void* stream);
 /* backward of layer 1, row-split: the batch pass is the epilogue of the bundle's dA1 blocks (naf_gemm_l1bwd_t below), this is
  * the finish launch. With dz = k1 (dy - c1 - xhat c2): dW[c][k] = k1_c (P[c][k] - c1_c Sx[k] - c2_c invstd_c (w_c C)[k]),
  * P = dY^T X — the xhat term comes from the moments record, so the pass only produces dy = ReLU'(out) * d_out, its block sums

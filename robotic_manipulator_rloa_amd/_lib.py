@@ -201,7 +201,7 @@ _PROTOS = {
     "naf_bb_linear_stats_adam": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "naf_bb_layer2_head_rows": [_i],
     "naf_bb_layer2_head": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp,
-                           _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
+                           _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "naf_bb_layer1_bwd_kp": [_i],
     "naf_bb_layer1_bwd_finish_blocks": [_i],
     "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
@@ -267,6 +267,11 @@ class GemmBn2Bwd(C.Structure):
     _fields_ = [("z", C.c_void_p), ("partials", C.c_void_p), ("gamma", C.c_void_p), ("save_mean", C.c_void_p),
                 ("save_invstd", C.c_void_p), ("d_gamma", C.c_void_p), ("d_beta", C.c_void_p), ("npb", C.c_int), ("B", C.c_int),
                 ("H", C.c_int), ("cst", C.c_void_p), ("epoch", C.c_void_p), ("errors", C.c_void_p)]
+
+
+class BbStatsOnce(C.Structure):
+    """naf_bb_stats_once_t (include/naf_hip.h)"""
+    _fields_ = [("records", C.c_void_p), ("epoch", C.c_void_p), ("errors", C.c_void_p)]
 
 
 class GemmL1Bwd(C.Structure):

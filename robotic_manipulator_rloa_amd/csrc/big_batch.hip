@@ -21,6 +21,7 @@
 #include "bn_tile.h"
 #include "head_body.h"
 #include "adam_body.h"
+#include "bn2bwd_fold.h"   // gemm_bn2bwd_poll_record: the readers' side of a self-validating 16-byte record
 #include "xgmi_dev.h"
 #include "../../include/naf_hip.h"
 
@@ -1069,7 +1070,9 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const float* __restrict__ Wh, int64_t wh_net_stride, int ldw, const float* __restrict__ u, int ldu,
     const float* __restrict__ r, int ldr, float gamma_td, float* __restrict__ q_out, float* __restrict__ d_heads,
     float* __restrict__ loss_partials, float* __restrict__ dy_out, int ldd, float2* __restrict__ partials_bw, int B, int A,
-    float momentum, float eps, int xcd_rows) {
+    float momentum, float eps, int xcd_rows, float* stat_rec /* polled while other workgroups of the launch write it: NOT __restrict__ — with it the compiler
+    hoisted the poll's load out of its loop (the asm memory clobber does not reach a noalias argument) and the wait never ended */,
+    const int* epoch_p, unsigned long long* errors, int n_fold) {
     constexpr int NHP = 4 * NH4, H = FK_H;
     constexpr int MT = ROWS / 16;                          // 16-row MFMA tiles
     constexpr int RPW = ROWS / 8;                          // rows per wave where a wave owns whole rows
@@ -1097,8 +1100,29 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     // dW2 blocks on that XCD). Workgroup i takes row chunk (i % 8) (chunks / 8) + i / 8: every chunk is then written on the XCD
     // that reads it, and the lines are still in its L2 behind the launch boundary. (Whole groups of 16 chunks only; placement
     // is speed only.)
+    // n_fold > 0 (more than 16 statistics blocks, B > 1024): the launch's first n_fold workgroups fold the layer-2 statistics ONCE —
+    // 32 (net, column) pairs each, one thread per pair, the arithmetic of bb_fold_stats — and publish (mean, invstd, *epoch, var)
+    // as one self-validating 16-byte record per pair; every other workgroup polls the 512 records instead of pulling all
+    // 2 x NB x 256 partials itself (128 KB per workgroup at B = 2048, 2.6 of the prologue's 4 us at the ~75 GB/s a CU gets out of
+    // L2). The protocol, its ordering argument and its hang guard are the bundle's (bn2bwd_fold.h).
     int rb = blockIdx.x;
-    if (ROWS == 16 && (gridDim.x & 15) == 0 && xcd_rows) rb = (rb & 7) * ((int)gridDim.x >> 3) + (rb >> 3);
+    const int n_main = (int)gridDim.x - n_fold;
+    if (n_fold) {
+        if (__builtin_expect(rb < n_fold, 0)) {
+            if (tid < 32) {
+                const int pair = 32 * rb + tid, net = pair >> 8, col = pair & 255;
+                float mean, var;
+                bb_fold_stats(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
+                const float invstd = 1.0f / sqrtf(var + eps);
+                const int epoch = *epoch_p;
+                const f32x4 rec = {mean, invstd, __builtin_bit_cast(float, epoch), var};
+                naf_buf_st_f4_sc1(naf_buf(stat_rec), 16u * (unsigned)pair, 0, rec);
+            }
+            return;
+        }
+        rb -= n_fold;
+    }
+    if (ROWS == 16 && (n_main & 15) == 0 && xcd_rows) rb = (rb & 7) * (n_main >> 3) + (rb >> 3);
     const int64_t s0 = (int64_t)rb * ROWS;
     const int T = A * (A + 1) / 2, v_col = A + T;
     // every kernel argument this prologue needs, fetched NOW: left to itself the compiler fetches an argument where it is
@@ -1106,7 +1130,8 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     asm volatile("" ::"s"(z), "s"(gamma), "s"(beta), "s"(partials), "s"(running_mean), "s"(running_var), "s"(a2_out), "s"(save_mean),
                  "s"(save_invstd), "s"(Wh), "s"(u), "s"(r), "s"(z_net_stride), "s"(param_net_stride), "s"(stat_net_stride),
                  "s"(wh_net_stride), "s"(ldz), "s"(ldw), "s"(ldu), "s"(ldr), "s"(NB64), "s"(B), "s"(A));
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 0);
+    #define FK_TL(slot) NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, slot, (int)blockIdx.x == n_fold, blockIdx.x == gridDim.x - 1)
+    FK_TL(0);
     // ---- phase 0: every global operand requested up front, in ONE batch: the Z2 tiles, the head weights (into registers,
     // native vectors), the statistics partials, the per-sample scalars — measured with the weights staged behind the
     // statistics fold this phase took 4.4 of the kernel's 10.8 us (two dependent round trips to fresh data) -------------
@@ -1150,9 +1175,16 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             rm_ = rmp[col];
             rv_ = rvp[col];
         }
-        float mean, var;
-        bb_fold_stats_u(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
-        const float invstd = 1.0f / sqrtf(var + eps);
+        float mean, var, invstd;
+        if (n_fold) {                                       // (uniform) the folded statistics, once their record carries this launch
+            const f32x4 c = gemm_bn2bwd_poll_record(naf_buf(stat_rec), net * H + (int)col, *epoch_p, errors);
+            mean = c[0];
+            invstd = c[1];
+            var = c[3];
+        } else {
+            bb_fold_stats_u(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
+            invstd = 1.0f / sqrtf(var + eps);
+        }
         sStat[net][0][col] = mean;
         sStat[net][1][col] = invstd;
         sStat[net][2][col] = gm_;
@@ -1174,7 +1206,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     if (tid < H / 4) *(f32x4*)(sWv + 4 * tid) = wv_r;
     for (int e = tid; e < (FK_THREADS / 8) * NHP; e += FK_THREADS) sDH[e] = 0.f;
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 1);
+    FK_TL(1);
     // ---- phase 1: normalise. main net -> xhat (LDS) and A2 (memory); target net -> V'(s') ---------------------------
     {
         const f32x4 m0 = *(const f32x4*)&sStat[0][0][4 * lane], i0 = *(const f32x4*)&sStat[0][1][4 * lane];
@@ -1208,7 +1240,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         }
     }
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 2);
+    FK_TL(2);
     // ---- phase 2: heads = A2 Wh^T + bias: MT x NHP/16 MFMA tiles, each cut into KS ranges of K, over the 8 waves (with whole
     // tiles half of the waves idled through the longest MFMA chain of the kernel: 2.2 of its 10.8 us). The ranges meet in
     // LDS, in K order -------------------------------------------------------------------------------------------------
@@ -1240,7 +1272,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         for (int e = 0; e < 4; ++e) dst[(16 * mt + 4 * gg + e) * NHP + 16 * nt + rr] = acc0[e] + acc1[e];
     }
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 3);
+    FK_TL(3);
     for (int e = tid; e < ROWS * NHP; e += FK_THREADS) {
         float hsum = sHd[e];
 #pragma unroll
@@ -1251,11 +1283,11 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         sHd[e] = hsum + sBias[e % NHP];
     }
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 4);
+    FK_TL(4);
     // ---- phase 3: the NAF head on the 32 rows (threads 0..255 carry samples; every thread joins the barriers) --------
     naf_head_body<PMODE, 2, FK_THREADS>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td, q_out,
                                         nullptr, loss_partials, B, A, s0, ROWS);
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 5);
+    FK_TL(5);
     if (tid < ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
     // ---- phase 4: dA2 = d_heads Wh (K = NHP), MT x 16 tiles, 2 MT per wave; ReLU mask, dY2, block sums ------------------
     {
@@ -1295,7 +1327,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         }
     }
     __syncthreads();
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 6);
+    FK_TL(6);
     if (tid < H) {
         float2 t = sP[0][tid];
         if (MT == 2) {
@@ -1304,7 +1336,8 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         }
         partials_bw[(int64_t)rb * H + tid] = t;
     }
-    NAF_TL(g_tl_bb, NAF_TL_BB_LAYER2_HEAD, 7);
+    FK_TL(7);
+#undef FK_TL
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1426,7 +1459,8 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
                                   const float* Wh, int64_t wh_net_stride, int ldw, int NHP, const float* u, int ldu,
                                   const float* r, int ldr, float gamma_td, float* q_out, float* d_heads, float* loss_partials,
                                   float* dy_out, int ldd, float* partials_bw, int B, int H, int A, int p_mode, float momentum,
-                                  float eps, void* stream) {
+                                  float eps, const naf_bb_stats_once_t* once, void* stream) {
+    if (once && (!once->records || !once->epoch || ((uintptr_t)once->records & 15))) return NAF_ERR_ARG;
     if (!z || !gamma || !beta || !partials || !running_mean || !running_var || !a2_out || !save_mean || !save_invstd || !Wh ||
         !u || !r || !q_out || !d_heads || !dy_out || !partials_bw || !bb_shape_ok(B, H) || H != FK_H)
         return NAF_ERR_ARG;
@@ -1438,13 +1472,19 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int rows = naf_bb_layer2_head_rows(B);
-    const int blocks = B / rows;
+    // folded once per launch where a workgroup would pull more than 16 statistics blocks per column (B > 1024) — and only there:
+    // the readers wait ~2.6 us for the records, which is what the prologue takes anyway at B = 1024 (2.6) and more than at 256 (1.8)
+    const int n_fold = (once && B / BB_ROWS > 16) ? 2 * FK_H / 32 : 0;
+    const int blocks = B / rows + n_fold;
+    float* rec = once ? once->records : nullptr;
+    const int* epoch_p = once ? once->epoch : nullptr;
+    unsigned long long* errors = once ? (unsigned long long*)once->errors : nullptr;
     const int xcd_rows = 1;      // row chunks dealt to the XCD whose dA1 blocks read them (+0.4 - 1 %)
 #define BB_FK_R(PM, NH4V, RW)                                                                                            \
     bb_layer2_head_kernel<PM, NH4V, RW><<<blocks, FK_THREADS, 0, st>>>(                                                  \
         z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, B / BB_ROWS, running_mean, running_var, \
         stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
-        loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows)
+        loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows, rec, epoch_p, errors, n_fold)
 #define BB_FK(PM, NH4V) BB_FK_R(PM, NH4V, 16)
 #define BB_FK_NH(PM)                     \
     do {                                 \

@@ -64,6 +64,9 @@ __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P,
         P.d_beta[col0 + c] = sdy;
     }
 }
+// A POLLED BUFFER MUST NOT BE A `__restrict__` KERNEL ARGUMENT: the asm memory clobber in the loop below does not reach a noalias
+// argument, the compiler hoists the load out of the loop and the wait never ends (bb_layer2_head_kernel's records, round 3: 45 -
+// 75 % of the pollers ran into the hang guard until the qualifier was dropped; here the records come out of a struct field).
 // the waiting side: constants of the block's columns -> cst (LDS, [4][256] as gemm_bn2bwd_constants leaves them). The caller
 // puts the barrier behind it.
 __device__ __forceinline__ static f32x4 gemm_bn2bwd_poll_record(__amdgpu_buffer_rsrc_t rb, int col, int epoch, unsigned long long* errors) {

@@ -351,6 +351,11 @@ class Learner:
                                         ptr(self.save_invstd[1, 0]), gp_ + 4 * seg_["g2"].offset, gp_ + 4 * seg_["be2"].offset,
                                         B // self.hk_rows, B, H, ptr(self.bb_cst), ptr(self.bb_fold_flag), self.err_host.data_ptr())
             pro_ = _lib.C.addressof(self._pro)
+            # layer 2's forward statistics folded once per launch too where a workgroup would pull more than 16 blocks of them
+            # (B > 1024; the library decides): records of their own, the same launch counter and error word
+            self.bb_stat_rec = torch.zeros(2 * H, 4, **f32)
+            self._stats_once_s = _lib.BbStatsOnce(ptr(self.bb_stat_rec), ptr(self.bb_fold_flag), self.err_host.data_ptr())
+            self._stats_once = _lib.C.byref(self._stats_once_s)
             # dA1 FIRST: its blocks carry the layer-1 epilogue and run longest; dispatched first, the short weight-gradient
             # blocks fill in behind them instead of the other way round
             self._bundle = (D * 3)(
@@ -536,7 +541,7 @@ class Learner:
             bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2[0]), HP, ptr(self.save_mean[1]), ptr(self.save_invstd[1]),
             t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld, rp + 4 * lay.off_r, ld, self.gamma,
             ptr(self.q_out), ptr(self.dH), lp, ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, lay.A, self.p_mode, BN_MOMENTUM,
-            BN_EPS, st), "bb_layer2_head")
+            BN_EPS, self._stats_once, st), "bb_layer2_head")
         # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles; dY2 becomes dZ2 while it is staged, the
         # dA1 blocks run layer 1's backward batch pass on their tile (this minibatch's rows: z recomputed from them)
         self._epi.x, self._epi.ldx = rp, ld
