@@ -286,8 +286,8 @@ int naf_bb_layer2_head_rows(int B);
  * save_invstd [2][H], q_out[B], d_heads[B][NHP], loss_partials[B/rows], dy_out (dY2), partials_bw[B/rows][H] (float2: sum dy,
  * sum dy*xhat), rows = naf_bb_layer2_head_rows(B). u / r: the action and reward columns of the minibatch rows. Replaces
  * naf_neural_network.py:78-115 + naf_algorithm.py:199-208 and the first half of layer 2's BatchNorm backward. */
-/* optional: the statistics of layer 2 folded ONCE per launch instead of by every workgroup. With more than 16 statistics blocks
- * (B > 1024) the launch's first 16 workgroups fold 32 (net, column) pairs each and publish one 16-byte record per pair — (mean,
+/* optional: the statistics of layer 2 folded ONCE per launch instead of by every workgroup. With more than 8 statistics blocks
+ * (B > 512) the launch's first 16 workgroups fold 32 (net, column) pairs each and publish one 16-byte record per pair — (mean,
  * invstd, *epoch, biased variance) — to `records` ([2 H] x 4 floats, 16-B aligned, device scratch nothing else touches); the other
  * workgroups poll the records until they carry *epoch (same protocol and hang guard as naf_gemm_bn2bwd_t below: *epoch must differ
  * from launch to launch — naf_bb_layer1_bwd_finish(fold_epoch) advances it once per update, so ONE launch per update may use a given

@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     // dW2 blocks on that XCD). Workgroup i takes row chunk (i % 8) (chunks / 8) + i / 8: every chunk is then written on the XCD
     // that reads it, and the lines are still in its L2 behind the launch boundary. (Whole groups of 16 chunks only; placement
     // is speed only.)
-    // n_fold > 0 (more than 16 statistics blocks, B > 1024): the launch's first n_fold workgroups fold the layer-2 statistics ONCE —
+    // n_fold > 0 (more than 8 statistics blocks, B > 512): the launch's first n_fold workgroups fold the layer-2 statistics ONCE —
     // 32 (net, column) pairs each, one thread per pair, the arithmetic of bb_fold_stats — and publish (mean, invstd, *epoch, var)
     // as one self-validating 16-byte record per pair; every other workgroup polls the 512 records instead of pulling all
     // 2 x NB x 256 partials itself (128 KB per workgroup at B = 2048, 2.6 of the prologue's 4 us at the ~75 GB/s a CU gets out of
@@ -1472,9 +1472,10 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int rows = naf_bb_layer2_head_rows(B);
-    // folded once per launch where a workgroup would pull more than 16 statistics blocks per column (B > 1024) — and only there:
-    // the readers wait ~2.6 us for the records, which is what the prologue takes anyway at B = 1024 (2.6) and more than at 256 (1.8)
-    const int n_fold = (once && B / BB_ROWS > 16) ? 2 * FK_H / 32 : 0;
+    // folded once per launch where a workgroup would pull more than 8 statistics blocks per column (B > 512) — and only there: the
+    // readers wait ~2.6 us for the records (updates/s, A/B/A/B on one box: B = 512 30.4k -> 30.2k with it, 1024 25.9k -> 26.3k,
+    // 1536 21.0k -> 21.65k, 2048 20.35k -> 20.58k)
+    const int n_fold = (once && B / BB_ROWS > 8) ? 2 * FK_H / 32 : 0;
     const int blocks = B / rows + n_fold;
     float* rec = once ? once->records : nullptr;
     const int* epoch_p = once ? once->epoch : nullptr;
