@@ -237,7 +237,7 @@ def main():
         "updates_per_s": round(updates / elapsed, 1),
         "us_per_update": round(1e6 * elapsed / (args.steps * U), 3),
         "timed_seconds": round(elapsed, 3),
-        "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": opt_steps,
+        "sanity": {"params_finite": finite, "bad_replay_indices": bad, "optimizer_steps": opt_steps, "fold_fallbacks": L.fold_fallbacks,
                    "episodes_booked": len(episodes),
                    "episode_frames_booked": int(sum(e[1] for e in episodes))},
     }

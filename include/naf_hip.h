@@ -289,9 +289,10 @@ int naf_bb_layer2_head_rows(int B);
 /* optional: the statistics of layer 2 folded ONCE per launch instead of by every workgroup. With more than 8 statistics blocks
  * (B > 512) the launch's first 16 workgroups fold 32 (net, column) pairs each and publish one 16-byte record per pair — (mean,
  * invstd, *epoch, biased variance) — to `records` ([2 H] x 4 floats, 16-B aligned, device scratch nothing else touches); the other
- * workgroups poll the records until they carry *epoch (same protocol and hang guard as naf_gemm_bn2bwd_t below: *epoch must differ
+ * workgroups poll the records until they carry *epoch (same protocol, and the same way out of a long wait — the thread folds its pair
+ * itself — as naf_gemm_bn2bwd_t below: *epoch must differ
  * from launch to launch — naf_bb_layer1_bwd_finish(fold_epoch) advances it once per update, so ONE launch per update may use a given
- * records buffer; `errors`: nullable pinned host word that counts expired waits). At smaller batches the argument is ignored. */
+ * records buffer; `errors`: nullable pinned host word that counts those fallbacks). At smaller batches the argument is ignored. */
 typedef struct naf_bb_stats_once {
     float* records;
     const int* epoch;
@@ -381,8 +382,10 @@ typedef struct naf_gemm_bn2bwd {
      * launch to launch: naf_bb_layer1_bwd_finish(fold_epoch) advances it. */
     float* cst;
     const int* epoch;
-    /* nullable: pinned HOST word (device-visible). The polls are bounded by wall clock as a hang guard (50 ms); a thread whose
-     * wait expires poisons its result with NaN and adds 1 here, where the host sees it without synchronising. */
+    /* nullable: pinned HOST word (device-visible), a diagnostic. A poll lasts 20 us at most; a thread whose record has not come by
+     * then (several processes share the GPU and the folding workgroup of its XCD is still queued) folds its column itself — the
+     * same sums in the same order, so the result is the same bits either way — and adds 1 here, where the host sees it without
+     * synchronising. No wait can expire into a wrong number. */
     uint64_t* errors;
 } naf_gemm_bn2bwd_t;
 typedef struct naf_gemm_desc {

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     // 32 (net, column) pairs each, one thread per pair, the arithmetic of bb_fold_stats — and publish (mean, invstd, *epoch, var)
     // as one self-validating 16-byte record per pair; every other workgroup polls the 512 records instead of pulling all
     // 2 x NB x 256 partials itself (128 KB per workgroup at B = 2048, 2.6 of the prologue's 4 us at the ~75 GB/s a CU gets out of
-    // L2). The protocol, its ordering argument and its hang guard are the bundle's (bn2bwd_fold.h).
+    // L2). The protocol, its ordering argument and its way out of a wait that lasts are the bundle's (bn2bwd_fold.h).
     int rb = blockIdx.x;
     const int n_main = (int)gridDim.x - n_fold;
     if (n_fold) {
@@ -1176,12 +1176,15 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             rv_ = rvp[col];
         }
         float mean, var, invstd;
-        if (n_fold) {                                       // (uniform) the folded statistics, once their record carries this launch
-            const f32x4 c = gemm_bn2bwd_poll_record(naf_buf(stat_rec), net * H + (int)col, *epoch_p, errors);
+        f32x4 c;
+        // (uniform n_fold) the folded statistics, once their record carries this launch; a thread whose budget runs out — the GPU is
+        // shared and this XCD's folding workgroup still queued (bn2bwd_fold.h) — folds its pair itself: same arithmetic, same bits
+        if (n_fold && gemm_bn2bwd_poll_record(naf_buf(stat_rec), net * H + (int)col, *epoch_p, &c)) {
             mean = c[0];
             invstd = c[1];
             var = c[3];
         } else {
+            if (n_fold && errors) __hip_atomic_fetch_add(errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             bb_fold_stats_u(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
             invstd = 1.0f / sqrtf(var + eps);
         }

@@ -369,7 +369,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         }
     }
     if (pro) {                                            // the column constants, under the panel loads' latency
-        gemm_bn2bwd_wait_constants<AK>(D.pro, m0, tid, sC);
+        gemm_bn2bwd_wait_constants<AK, G::THREADS>(D.pro, m0, tid, sC);
         __syncthreads();
     }
     for (int k0 = k_lo; k0 < k_hi; k0 += KC) {

@@ -256,8 +256,8 @@ class Learner:
         self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
         self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
         self.n_loss_wg = (B + 7) // 8                  # loss partials per update (NAF_HEAD_SPB samples per workgroup)
-        # a wait inside a kernel that expired (the bundle's polls of the BatchNorm-backward records: hang guards) bumps this
-        # pinned HOST word; raise_on_device_error() reads it without synchronising
+        # a poll inside a fused launch that gave up on the folded records and folded for itself (csrc/bn2bwd_fold.h) bumps this
+        # pinned HOST word; fold_fallbacks reads it without synchronising
         self.err_host = torch.zeros(8, dtype=torch.int64).pin_memory()
 
         # ---- work buffers for one minibatch ------------------------------------------------------------
@@ -393,17 +393,19 @@ class Learner:
         self.step_dev.zero_()
 
     def raise_on_device_error(self) -> None:
-        """Host-side check of what the kernels can only flag: a bounded wait that expired inside a launch (the bundle's polls,
-        the one-shot all-reduce's waits on its peers). Reads pinned host words the kernels bump — a load, never a
-        synchronisation; the values lag the stream by whatever is still queued. Called before every chunk of updates and
-        every learn()."""
+        """Host-side check of what the kernels can only flag: a bounded wait on a PEER that expired (the one-shot all-reduce).
+        Reads a pinned host word the kernel bumps — a load, never a synchronisation; the value lags the stream by whatever is
+        still queued. Called before every chunk of updates and every learn(). (The waits INSIDE a launch — the records of the
+        BatchNorm folds — cannot fail: a thread that waits too long folds for itself, see fold_fallbacks.)"""
         if self.xgmi is not None:
             self.xgmi.raise_on_timeout()
-        n = int(self.err_host[0])
-        if n:
-            raise _lib.NafHipError(f"{n} bounded wait(s) inside the backward GEMM launch expired (the workgroups that fold the "
-                                   "BatchNorm-backward sums did not publish within 50 ms): the affected updates are poisoned with "
-                                   "NaN — the GPU is hung, over-subscribed or faulted; restart from a checkpoint")
+
+    @property
+    def fold_fallbacks(self) -> int:
+        """How many polls inside the fused launches gave up on the folded records after 20 us and folded for themselves (same
+        bits either way: csrc/bn2bwd_fold.h). Zero when the process has the GPU to itself; a count that grows means the GPU is
+        shared or over-subscribed. Read from pinned host memory without a synchronisation."""
+        return int(self.err_host[0])
 
     # ---- one learn() on the current stream --------------------------------------------------------------
     def _x2(self, rows: torch.Tensor) -> torch.Tensor:
