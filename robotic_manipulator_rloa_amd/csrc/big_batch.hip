@@ -675,8 +675,33 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
         }
     }
     __syncthreads();
-    if (ADAM && tid >= BB_THREADS) {             // waves 4 .. 7: done (they leave through the barrier the others still have ahead)
-        __syncthreads();
+    float* oz = out + net * out_net_stride;
+    // normalise + ReLU + store of a thread's 4 x 4 piece of the tile (statistics in sStat)
+    auto tile_out = [&](const float (&zt)[4][4], int ty_, int tx_) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 y;
+            float* yp = (float*)&y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * tx_ + j;
+                const float t = (zt[i][j] - sStat[0][c]) * sStat[1][c] * sStat[2][c] + sStat[3][c];
+                yp[j] = t > 0.f ? t : 0.f;
+            }
+            naf_buf_st_f4(naf_buf(oz + (int64_t)(rb * BB_ROWS) * ldo + col0), 4u * (unsigned)((4 * ty_ + i) * ldo + 4 * tx_), 0,
+                          (f32x4){y.x, y.y, y.z, y.w}, B >= NAF_WT_MIN_B);
+        }
+    };
+    if (ADAM && tid >= BB_THREADS) {
+        // waves 4 .. 7: the z tile, WHILE waves 0 .. 3 derive the statistics — neither needs the other, only the normalisation
+        // needs both (in one sequence in the same four waves: 1.24 + 0.68 us of this kernel's 5.0; side by side: 1.24)
+        const int ty2 = ty - BB_THREADS / 16;
+        float z[4][4];
+        bb_l1_tile<K4>(sXt, sWt, *(const float4*)&sPar[0][4 * tx], ty2, tx, z);
+        __syncthreads();                         // the statistics of waves 0 .. 3 are in sStat
+        NAF_TL_FL_T(g_tl_bb, NAF_TL_BB_LAYER1, 3, widx == 0, widx == n_main - 1, BB_THREADS);
+        tile_out(z, ty2, tx);
+        NAF_TL_FL_T(g_tl_bb, NAF_TL_BB_LAYER1, 4, widx == 0, widx == n_main - 1, BB_THREADS);
         return;
     }
     if (ADAM) {
@@ -756,24 +781,15 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
         }
     }
     L1_TL(2);
+    if (ADAM) {                                  // (waves 4 .. 7 normalise and store the tile they computed meanwhile)
+        __syncthreads();
+        return;
+    }
     float z[4][4];
     bb_l1_tile<K4>(sXt, sWt, b4v, ty, tx, z);
     __syncthreads();
     L1_TL(3);
-    float* oz = out + net * out_net_stride;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float4 y;
-        float* yp = (float*)&y;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 4 * tx + j;
-            const float t = (z[i][j] - sStat[0][c]) * sStat[1][c] * sStat[2][c] + sStat[3][c];
-            yp[j] = t > 0.f ? t : 0.f;
-        }
-        naf_buf_st_f4(naf_buf(oz + (int64_t)(rb * BB_ROWS) * ldo + col0), 4u * (unsigned)((4 * ty + i) * ldo + 4 * tx), 0,
-                      (f32x4){y.x, y.y, y.z, y.w}, B >= NAF_WT_MIN_B);
-    }
+    tile_out(z, ty, tx);
     L1_TL(4);
 #undef L1_TL
 }

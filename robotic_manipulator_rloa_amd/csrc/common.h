@@ -49,6 +49,15 @@ enum { NAF_TL_BB_LAYER1 = 0, NAF_TL_BB_LINEAR_STATS, NAF_TL_BB_LAYER2_HEAD, NAF_
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     } while (0)
+#define NAF_TL_FL_T(arr, kid, slot, is_first, is_last, thread) /* the mark written by thread `thread` instead of thread 0 */ \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if ((int)threadIdx.x == (thread)) {                                                                          \
+            if (is_first) arr[kid][0][slot] = wall_clock64();                                                        \
+            if (is_last) arr[kid][1][slot] = wall_clock64();                                                         \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
 #define NAF_TL_READER(fn, arr)                                                                                        \
     int fn(int kid, long long* out) {                                                                                 \
         return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arr), 2 * NAF_TL_SLOTS * sizeof(long long),                    \
@@ -58,6 +67,7 @@ enum { NAF_TL_BB_LAYER1 = 0, NAF_TL_BB_LINEAR_STATS, NAF_TL_BB_LAYER2_HEAD, NAF_
 #define NAF_TL_DECL(arr)
 #define NAF_TL(arr, kid, slot) do { } while (0)
 #define NAF_TL_FL(arr, kid, slot, is_first, is_last) do { } while (0)
+#define NAF_TL_FL_T(arr, kid, slot, is_first, is_last, thread) do { } while (0)
 #define NAF_TL_READER(fn, arr) int fn(int, long long*) { return NAF_ERR_STATE; }
 #endif
 
