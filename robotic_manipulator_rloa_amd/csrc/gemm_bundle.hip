@@ -194,20 +194,18 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
     R.bias = E.bias[col];
 }
 
+// xhat of the block's layer-1 tile, EARLY: it needs only the minibatch rows and W1 (requested first of all), not the product, so it
+// is formed while the panels are in flight and the block waits for the BatchNorm-backward records anyway — the panels' LDS space is
+// still free then. Accumulator waves return xhat at their four C/D elements; all waves take the two barriers. (Inside the
+// epilogue this was 0.5 of its 0.9 us, behind the product: updates/s A/B on one box 26.7k -> 26.9k at B = 1024, no change at
+// 256, where the weight-gradient blocks end the launch.)
 template <class G>
-__device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int bn, const f32x4& acc, bool owner, int wm, int wn,
-                                                  int r, int g, float* sA, float* sB, int tid, const L1bwdRegs<G>& R) {
-    // KSPLIT = 2: the two products are dealt to the accumulator waves (owner) and to the other four, which run side by side;
-    // KSPLIT = 1: every wave holds an accumulator tile and takes its share of P behind the barrier.
+__device__ static inline f32x4 gemm_l1bwd_xhat(const GemmDesc& D, bool owner, int wm, int wn, int r, int g, float* sA, int tid,
+                                               const L1bwdRegs<G>& R) {
     const naf_gemm_l1bwd_t& E = D.epi;
     const int KP = E.kp, XS = KP + 4;
-    const int n0 = bn * 32;
     float* sX = sA;                    // [32 rows][XS]
     float* sW = sA + 32 * XS;          // [32 cols][XS]
-    float* sDY = sB;                   // [32 rows][33]
-    float2* sRed = (float2*)(sB + 32 * 33);   // [2 row tiles][32 columns]
-    // (KSPLIT = 2: the barrier behind the K halves' hand-over has every wave past its last fragment read: the panels are free)
-    if (G::KSPLIT == 1) __syncthreads();
     {
         const int xr = KP == 24 ? tid / 6 : tid / 8, xq = tid - xr * (KP / 4);
         if (xr < 32) *(f32x4*)(sX + xr * XS + 4 * xq) = R.x;
@@ -219,6 +217,7 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
         }
     }
     __syncthreads();
+    f32x4 xh = {0.f, 0.f, 0.f, 0.f};
     if (owner) {
         // z tile: rows wm * 16 .. +15 x columns wn * 16 .. +15, K = KP in two steps of 16 (KP = 24: lane groups 2, 3 of the second
         // step are past the row: zeros)
@@ -234,14 +233,38 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
                 for (int q = 0; q < 4; ++q) z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], z, 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xh[e] = ((z[e] + R.bias) - R.mean) * R.invstd;
+    }
+    __syncthreads();                   // the panels may be stored now
+    return xh;
+}
+
+template <class G>
+__device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int bn, const f32x4& acc, const f32x4& xh, bool owner,
+                                                  int wm, int wn, int r, int g, float* sA, float* sB, int tid, const L1bwdRegs<G>& R) {
+    // KSPLIT = 2: the two products are dealt to the accumulator waves (owner) and to the other four;
+    // KSPLIT = 1: every wave holds an accumulator tile and takes its share of P behind the barrier.
+    const naf_gemm_l1bwd_t& E = D.epi;
+    const int KP = E.kp, XS = KP + 4;
+    const int n0 = bn * 32;
+    float* sX = sA;                    // [32 rows][XS]: the minibatch rows again, for P = dY^T X
+    float* sDY = sB;                   // [32 rows][33]
+    float2* sRed = (float2*)(sB + 32 * 33);   // [2 row tiles][32 columns]
+    // (KSPLIT = 2: the barrier behind the K halves' hand-over has every wave past its last fragment read: the panels are free)
+    if (G::KSPLIT == 1) __syncthreads();
+    {
+        const int xr = KP == 24 ? tid / 6 : tid / 8, xq = tid - xr * (KP / 4);
+        if (xr < 32) *(f32x4*)(sX + xr * XS + 4 * xq) = R.x;
+    }
+    if (owner) {
         float s_dy = 0.f, s_dx = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = ((z[e] + R.bias) - R.mean) * R.invstd;
             const float dy = R.a1[e] > 0.f ? acc[e] : 0.f;
             sDY[(wm * 16 + 4 * g + e) * 33 + wn * 16 + r] = dy;
             s_dy += dy;
-            s_dx += dy * xh;
+            s_dx += dy * xh[e];
         }
         s_dy = naf_xor32_add(naf_xor16_add(s_dy));           // the tile's other row groups of the same column
         s_dx = naf_xor32_add(naf_xor16_add(s_dx));
@@ -368,7 +391,9 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
             load_panel<G, BK, false>(vb, D.B, D.ldb, n0, D.N, k_lo, kc0, tid);
         }
     }
-    if (pro) {                                            // the column constants, under the panel loads' latency
+    f32x4 epi_xh = {0.f, 0.f, 0.f, 0.f};
+    if (D.epi.x) epi_xh = gemm_l1bwd_xhat<G>(D, !kh, wm, wn, r, g, sA, tid, epi_regs);   // under the panel loads' latency
+    if (pro) {                                            // the column constants, under the panel loads' latency too
         gemm_bn2bwd_wait_constants<AK, G::THREADS>(D.pro, m0, tid, sC);
         __syncthreads();
     }
@@ -436,7 +461,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         }
     }
     GB_TL(3);
-    if (D.epi.x) gemm_l1bwd_epilogue<G>(D, bm, bn, acc, !kh, wm, wn, r, g, sA, sB, tid, epi_regs);
+    if (D.epi.x) gemm_l1bwd_epilogue<G>(D, bm, bn, acc, epi_xh, !kh, wm, wn, r, g, sA, sB, tid, epi_regs);
     GB_TL(4);
     if (D.sumsq) {   // gradient-norm partial of this block (fixed order: shuffles, then the 4 tiles)
         float* sQ = sA;                                       // (the panels are dead: behind the barrier every wave is past them)
