@@ -1125,6 +1125,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const int n_main = (int)gridDim.x - n_fold;
     if (n_fold) {
         if (__builtin_expect(rb < n_fold, 0)) {
+            asm volatile("" ::"s"(partials), "s"(NB64), "s"(B), "s"(eps), "s"(epoch_p), "s"(stat_rec));   // (one batch of scalar loads)
             if (tid < 32) {
                 const int pair = 32 * rb + tid, net = pair >> 8, col = pair & 255;
                 float mean, var;

@@ -27,6 +27,7 @@ struct GemmBundle {
     int n, total_tiles;
     int rowmap;                   // XCD-aware placement of the blocks (0: block t is block t; the host sets 2)
     int n_fold, fold_desc;        // n_fold > 0: the first n_fold workgroups fold the block sums of d[fold_desc].pro ONCE for the launch
+    naf_gemm_bn2bwd_t fold_pro;   // = d[fold_desc].pro, at an offset the folding workgroups know without reading anything first
 };
 
 // ---- LDS-staged form -----------------------------------------------------------------------------------------------
@@ -478,20 +479,29 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
 #ifndef GB_WAVES_PER_EU
 #define GB_WAVES_PER_EU 4
 #endif
-template <int T, int KC>
+#define GB_FOLD_WGS (256 / GB_FOLD_COLS)     // folding workgroups of a launch with a prologue (H = 256)
+// FOLD: the launch has a BatchNorm-backward prologue and its first GB_FOLD_WGS workgroups fold the block sums. A template
+// parameter, not a kernel argument: everything that waits in this launch waits for those workgroups, and as arguments their way to
+// the first load of the partials led through three dependent scalar round trips (n_fold -> fold_desc -> the fields of
+// d[fold_desc].pro, ~0.25 us each in front of a cold scalar cache) plus one more in front of the record store; now it is one batch.
+template <int T, int KC, bool FOLD>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(GB_WAVES_PER_EU, GB_WAVES_PER_EU))) void gemm_bundle_kernel(const GemmBundle bundle) {
     using G = GB<T, KC>;
     __shared__ __attribute__((aligned(16))) float sA[G::PANEL];
     __shared__ __attribute__((aligned(16))) float sB[G::PANEL];
     __shared__ __attribute__((aligned(16))) float sC[4 * 64 * 4];   // the column constants of the prologue, then the K halves' hand-over
     int t = blockIdx.x;                                   // one 32 x 32 block per workgroup
-    if (bundle.n_fold) {                                  // (uniform) the launch's first workgroups fold the BatchNorm-backward sums
-        if (__builtin_expect(t < bundle.n_fold, 0)) {
-            gemm_bn2bwd_fold_block<T>(bundle.d[bundle.fold_desc].pro, t, threadIdx.x, sA);
+    if (FOLD) {
+        if (__builtin_expect(t < GB_FOLD_WGS, 0)) {
+            const naf_gemm_bn2bwd_t& P = bundle.fold_pro;
+            asm volatile("" ::"s"(P.partials), "s"(P.gamma), "s"(P.save_invstd), "s"(P.epoch), "s"(P.npb), "s"(P.B), "s"(P.H), "s"(P.cst),
+                         "s"(P.d_gamma), "s"(P.d_beta));
+            gemm_bn2bwd_fold_block<T>(P, t, threadIdx.x, sA);
             return;
         }
-        t -= bundle.n_fold;
+        t -= GB_FOLD_WGS;
     }
+    const int n_fold = FOLD ? GB_FOLD_WGS : 0;
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < NAF_GEMM_BUNDLE_MAX; ++i)
@@ -530,11 +540,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(GB_WAVES_PER_
         }
     }
     if (D.a_kmajor) {
-        if (D.b_kmajor) gemm_block<G, true, true>(D, bm, bn, ks, sA, sB, sC, bundle.n_fold);
-        else gemm_block<G, true, false>(D, bm, bn, ks, sA, sB, sC, bundle.n_fold);
+        if (D.b_kmajor) gemm_block<G, true, true>(D, bm, bn, ks, sA, sB, sC, n_fold);
+        else gemm_block<G, true, false>(D, bm, bn, ks, sA, sB, sC, n_fold);
     } else {
-        if (D.b_kmajor) gemm_block<G, false, true>(D, bm, bn, ks, sA, sB, sC, bundle.n_fold);
-        else gemm_block<G, false, false>(D, bm, bn, ks, sA, sB, sC, bundle.n_fold);
+        if (D.b_kmajor) gemm_block<G, false, true>(D, bm, bn, ks, sA, sB, sC, n_fold);
+        else gemm_block<G, false, false>(D, bm, bn, ks, sA, sB, sC, n_fold);
     }
 }
 
@@ -592,8 +602,16 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     // more blocks than the 8-wave form has room for at once (two per CU): the 4-wave form, four workgroups per CU
     // (updates/s, A/B/A/B on one box: B = 1536 20.6k -> 21.0k, B = 2048 20.05k -> 20.35k; B = 1024, 428 blocks: 26.1k -> 25.2k)
     const bool big = tiles + b.n_fold > 512;
-    if (big) gemm_bundle_kernel<256, 128><<<tiles + b.n_fold, 256, 0, (hipStream_t)stream>>>(b);
-    else gemm_bundle_kernel<512, 256><<<tiles + b.n_fold, 512, 0, (hipStream_t)stream>>>(b);
+    hipStream_t st = (hipStream_t)stream;
+    if (b.n_fold) {
+        b.fold_pro = b.d[b.fold_desc].pro;
+        if (big) gemm_bundle_kernel<256, 128, true><<<tiles + b.n_fold, 256, 0, st>>>(b);
+        else gemm_bundle_kernel<512, 256, true><<<tiles + b.n_fold, 512, 0, st>>>(b);
+    } else {
+        memset(&b.fold_pro, 0, sizeof(b.fold_pro));
+        if (big) gemm_bundle_kernel<256, 128, false><<<tiles, 256, 0, st>>>(b);
+        else gemm_bundle_kernel<512, 256, false><<<tiles, 512, 0, st>>>(b);
+    }
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
