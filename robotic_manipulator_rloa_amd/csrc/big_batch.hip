@@ -1337,7 +1337,10 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
                 const int row = 16 * mt + 4 * gg + e;
                 const float xh = sXH[row * FK_LD + col];
                 const float dy = __builtin_fmaf(xh, g, be) > 0.f ? acc[e] : 0.f;      // the forward's own ReLU decision
-                naf_buf_st_f1(dyb, ldy, (unsigned)(16 * mt + e) * ldd4 + (unsigned)(16 * nt) * 4u, dy, B >= NAF_WT_MIN_B);
+                // dY2 leaves as whole rows behind the barrier where there is a tile to collect it in (A2's, free since the heads
+                // GEMM): 16 wave-stores of 1 KB instead of 64 of 4 x 64 B per workgroup
+                if (A2T) sA2[row * FK_LD + col] = dy;
+                else naf_buf_st_f1(dyb, ldy, (unsigned)(16 * mt + e) * ldd4 + (unsigned)(16 * nt) * 4u, dy, B >= NAF_WT_MIN_B);
                 s_dy += dy;
                 s_dx += dy * xh;
             }
@@ -1347,6 +1350,14 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         }
     }
     __syncthreads();
+    if (A2T) {
+        const __amdgpu_buffer_rsrc_t dyr = naf_buf(dy_out + s0 * ldd);
+#pragma unroll
+        for (int i = 0; i < ROWS * (H / 4) / FK_THREADS; ++i) {
+            const int e = tid + FK_THREADS * i, row = e >> 6, q = e & 63;
+            naf_buf_st_f4(dyr, (unsigned)(row * ldd + 4 * q) * 4u, 0, *(const f32x4*)(sA2 + row * FK_LD + 4 * q), B >= NAF_WT_MIN_B);
+        }
+    }
     FK_TL(6);
     if (tid < H) {
         float2 t = sP[0][tid];
