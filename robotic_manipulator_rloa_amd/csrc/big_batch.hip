@@ -402,6 +402,16 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
     // (no FP contraction: the gradient of a build rounds the same way whatever the optimizer makes of this body)
 #pragma clang fp contract(off)
     float sq = 0.f;
+    // every field of the (by-value) argument either branch needs, requested NOW in one batch of scalar loads: fetched where they are
+    // first used they came in three dependent batches in front of the first vector load (~0.25 us each: the scalar cache is cold at
+    // the start of a launch, and this launch is nothing but one round trip to fresh data and a store)
+    asm volatile("" ::"s"(F.p_slabs), "s"(F.KP), "s"(F.K), "s"(F.partials1), "s"(F.NB1), "s"(F.dz2_col_partials), "s"(F.NB), "s"(F.mom),
+                 "s"(F.wc), "s"(F.gamma), "s"(F.save_invstd), "s"(F.d_W), "s"(F.d_gamma), "s"(F.d_beta), "s"(F.d_bias), "s"(F.d_bias2),
+                 "s"(F.d_gamma2), "s"(F.d_beta2), "s"(F.sumsq_partials), "s"(F.step_dev), "s"(F.B), "s"(F.H), "s"(F.fold_flag),
+                 "s"(F.slabs.n_finish_blocks), "s"(F.slabs.n_seg), "s"(F.grad_base));
+    asm volatile("" ::"s"(F.slabs.seg[0].src), "s"(F.slabs.seg[0].dst), "s"(F.slabs.seg[0].stride), "s"(F.slabs.seg[0].n),
+                 "s"(F.slabs.seg[0].n_slabs), "s"(F.slabs.seg[0].block0), "s"(F.slabs.seg[1].src), "s"(F.slabs.seg[1].dst),
+                 "s"(F.slabs.seg[1].stride), "s"(F.slabs.seg[1].n), "s"(F.slabs.seg[1].n_slabs), "s"(F.slabs.seg[1].block0));
     // the launch number the bundle's folded constants are tagged with (naf_gemm_bn2bwd_t.epoch): a new one for the next update
     if (F.fold_flag && block == 0 && tid == 64) *F.fold_flag += 1;
     if (block >= F.slabs.n_finish_blocks) {
@@ -544,6 +554,17 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     __shared__ AdamScalars shA;
     __shared__ __attribute__((aligned(16))) float sPar[3][BB_COLS];   // ADAM: b, gamma, beta of the columns as the step leaves them
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    // every kernel argument, requested NOW in one batch of scalar loads: fetched where they are first used they came in five
+    // dependent batches threaded through the prologue (~0.25 us each against a scalar cache that is cold when a launch starts), each
+    // holding back the vector loads behind it
+    asm volatile("" ::"s"(x), "s"(x_net_stride), "s"(ldx), "s"(K), "s"(W), "s"(bias), "s"(gamma), "s"(beta), "s"(param_net_stride),
+                 "s"(mom), "s"(running_mean), "s"(running_var), "s"(stat_net_stride), "s"(out), "s"(out_net_stride), "s"(ldo),
+                 "s"(save_mean), "s"(save_invstd), "s"(wc_out), "s"(B), "s"(H), "s"(momentum), "s"(eps), "s"(n_main), "s"(l1_4),
+                 "s"(n4), "s"(n_adam));
+    if (ADAM)
+        asm volatile("" ::"s"(ad.theta), "s"(ad.g), "s"(ad.m), "s"(ad.v), "s"(ad.target), "s"(ad.partials), "s"(ad.n_partials),
+                     "s"(ad.max_norm), "s"(ad.lr), "s"(ad.beta1), "s"(ad.beta2), "s"(ad.eps), "s"(ad.tau), "s"(ad.one_minus_tau),
+                     "s"(ad.step_dev), "s"(ad.inv_world), "s"(ad.bc));
     // grid: [riding optimizer step | this kernel's own workgroups]
     const int n_ride = ADAM ? n_adam : 0;
     const int widx = (int)blockIdx.x - n_ride;             // >= 0: a layer-1 workgroup
@@ -859,6 +880,13 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     __shared__ AdamScalars shA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int widx = blockIdx.x;
+    // (every argument in one batch of scalar loads: see bb_layer1_kernel)
+    asm volatile("" ::"s"(a), "s"(a_net_stride), "s"(lda), "s"(W), "s"(bias), "s"(param_net_stride), "s"(z), "s"(z_net_stride), "s"(ldz),
+                 "s"(partials), "s"(B), "s"(N), "s"(K), "s"(gx), "s"(n_main), "s"(l1_4), "s"(xcd_nets));
+    if (ADAM)
+        asm volatile("" ::"s"(ad.theta), "s"(ad.g), "s"(ad.m), "s"(ad.v), "s"(ad.target), "s"(ad.partials), "s"(ad.n_partials),
+                     "s"(ad.max_norm), "s"(ad.lr), "s"(ad.beta1), "s"(ad.beta2), "s"(ad.eps), "s"(ad.tau), "s"(ad.one_minus_tau),
+                     "s"(ad.step_dev), "s"(ad.inv_world), "s"(ad.bc));
     if (ADAM && __builtin_expect(widx >= n_main, 0)) {     // (unlikely: the riding step's code sits behind the kernel's own)
         adam_block<BB_THREADS>(ad, 0, (size_t)l1_4, widx - n_main, (int)gridDim.x - n_main, &shA, tid, true);
         return;
@@ -963,7 +991,14 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int widx = blockIdx.x;
-    if (ADAM && __builtin_expect(widx >= n_main, 0)) {     // (unlikely: the riding step's code sits behind the kernel's own)                     // (extra workgroups: the deferred step of the layer-1 segment, see above)
+    // (every argument in one batch of scalar loads: see bb_layer1_kernel)
+    asm volatile("" ::"s"(a), "s"(a_net_stride), "s"(lda), "s"(W), "s"(bias), "s"(param_net_stride), "s"(z), "s"(z_net_stride), "s"(ldz),
+                 "s"(partials), "s"(B), "s"(N), "s"(K), "s"(gx), "s"(n_main), "s"(l1_4), "s"(xcd_nets));
+    if (ADAM)
+        asm volatile("" ::"s"(ad.theta), "s"(ad.g), "s"(ad.m), "s"(ad.v), "s"(ad.target), "s"(ad.partials), "s"(ad.n_partials),
+                     "s"(ad.max_norm), "s"(ad.lr), "s"(ad.beta1), "s"(ad.beta2), "s"(ad.eps), "s"(ad.tau), "s"(ad.one_minus_tau),
+                     "s"(ad.step_dev), "s"(ad.inv_world), "s"(ad.bc));
+    if (ADAM && __builtin_expect(widx >= n_main, 0)) {     // (extra workgroups: the deferred step of the layer-1 segment, see above)
         adam_block<BB_THREADS>(ad, 0, (size_t)l1_4, widx - n_main, (int)gridDim.x - n_main, &shA, tid, true);
         return;
     }
