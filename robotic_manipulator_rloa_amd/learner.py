@@ -162,11 +162,13 @@ class Learner:
         #              (hk), the backward GEMMs as one launch (gb) that also carries the second stage of layer 2's BatchNorm
         #              backward as its prologue (s2) and the batch pass of layer 1's backward as its epilogue (ep), a finish
         #              launch — 5 launches per update in a chain of updates. Needs B % 64 == 0, 64 <= B <= 2048, H = 256, S <= 26.
-        #              Default from B = 256 (measured, updates/s, column-tile | row-split: B = 64: 32.5k | 29.3k, 128: 30.8k | 28.9k,
-        #              256: 25.7k | 34.0k, 512: 20.3k | 29.9k).
+        #              Default wherever the shape fits (measured at the end of round 3, updates/s, column-tile | row-split: B = 64:
+        #              32.3k | 36.0k, 128: 30.7k | 35.4k, 192: 25.8k | 34.0k, 256: 25.7k | 34.7k, 512: 20.3k | 30.9k; until then the
+        #              column-tile chain led below B = 256 — 32.5k | 29.3k at 64 in round 2).
         #   "columns"  {l1, b2, gb, s3}: the COLUMN-TILE chain of csrc/fused_layers.hip — a workgroup owns 8 feature columns x all
         #              B rows (ceil(B/64) <= 8 rows per thread in registers), the K = state-size and N = heads GEMMs folded into
-        #              the BatchNorm kernels, 8 launches per update. B <= 512. Default below B = 256.
+        #              the BatchNorm kernels, 8 launches per update. B <= 512. Default for batch sizes up to 512 that are not
+        #              multiples of 64.
         #   "unfused"  {gb} or {}: torch (rocBLAS) GEMMs + the BatchNorm / head kernels of csrc/bn_relu.hip, naf_head.hip, with
         #              the backward GEMM bundle where its shapes allow (B, H multiples of 16) — any shape up to B = 2048; 14
         #              launches per update (round 1's chain: 12.7k updates/s at B = 1024).
@@ -179,7 +181,7 @@ class Learner:
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
         if want == "default":
-            want = "rows" if (self.B >= 256 and self.bb_ok) else ("columns" if self.B <= 512 else "unfused")
+            want = "rows" if self.bb_ok else ("columns" if self.B <= 512 else "unfused")
         if want == "rows" and not self.bb_ok:
             want = "columns" if self.B <= 512 else "unfused"
         if want == "rows":

@@ -50,7 +50,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
         warnings.simplefilter("ignore")          # (the unfused chain beyond B = 512 warns about its speed)
         L = make_learner(S, A, B, main0, target0, fuse=None if fused == "default" else fused)
     if fused in ("default", "rows"):
-        assert L.fuse == (ROWS if (B >= 256 or fused == "rows") and B % 64 == 0 else COLUMNS)
+        assert L.fuse == (ROWS if B % 64 == 0 else COLUMNS)
     elif fused == "columns":
         assert L.fuse == (COLUMNS if B <= 512 else {"gb"})
     else:
@@ -131,7 +131,7 @@ def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
         L = make_learner(S, A, B, sd, sd, p_mode=p_mode, fuse=None if fused == "default" else fused)
     rows_ok = B % 64 == 0 and 64 <= B <= 2048 and S <= 26
     if fused == "default":
-        assert L.fuse == (ROWS if rows_ok and B >= 256 else (L.fuse if B > 512 or S > 24 else COLUMNS))
+        assert L.fuse == (ROWS if rows_ok else (L.fuse if B > 512 or S > 24 else COLUMNS))
     if fused == "rows" and rows_ok:
         assert L.fuse == ROWS
     if B > 512 and "bb" not in L.fuse:
@@ -251,7 +251,7 @@ def test_deferred_optimizer_step_is_the_same_bits(S, A, B, U, monkeypatch):
     for mode, use_graph in (("0", False), ("1", False), ("1", True)):
         monkeypatch.setenv("NAF_DEFER_ADAM", mode)
         L = make_learner(S, A, B, sd, sd)
-        if B >= 256:
+        if B % 64 == 0:
             assert L.defer_ok == (mode == "1")
         buf = ReplayBuffer(n_rows, B, "cuda", 0, state_size=S, action_size=A)
         buf.add_rows_device(torch.from_numpy(O.pack_rows(st, ac, rw, ns, dn, 64)).cuda(), n_rows)
