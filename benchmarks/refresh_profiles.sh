@@ -15,9 +15,10 @@ stats)     # rocprofv3 kernel-trace stats + digest of the bench at configs[1] an
   benchmarks/prof_bench.sh r03_b512 200 30 --batch 512 > gpurun_out/prof_b512.log 2>&1; tail -2 gpurun_out/prof_b512.log
   benchmarks/prof_bench.sh r03_b1024 150 20 --batch 1024 --robot xarm6_robot --obstacle-jitter 0.1 > gpurun_out/prof_b1024.log 2>&1; tail -2 gpurun_out/prof_b1024.log
   benchmarks/prof_bench.sh r03_b2048 100 15 --batch 2048 --robot panda --buffer 4000000 > gpurun_out/prof_b2048.log 2>&1; tail -2 gpurun_out/prof_b2048.log ;;
-small)     # the column-tile chain: configs[0]'s batch and the reference's default
+small)     # small batches: configs[0]'s batch and the reference's default (row-split chain), and B = 96 (column-tile chain)
   benchmarks/prof_bench.sh r03_b64 300 40 --batch 64 --buffer 100000 > gpurun_out/prof_b64.log 2>&1; tail -2 gpurun_out/prof_b64.log
-  benchmarks/prof_bench.sh r03_b128 300 40 --batch 128 --buffer 100000 > gpurun_out/prof_b128.log 2>&1; tail -2 gpurun_out/prof_b128.log ;;
+  benchmarks/prof_bench.sh r03_b128 300 40 --batch 128 --buffer 100000 > gpurun_out/prof_b128.log 2>&1; tail -2 gpurun_out/prof_b128.log
+  benchmarks/prof_bench.sh r03_b96 300 40 --batch 96 --buffer 100000 > gpurun_out/prof_b96.log 2>&1; tail -2 gpurun_out/prof_b96.log ;;
 sweep)     # SURVEY 8d bulk sweep of the streaming kernels, HIP events (the table) AND rocprofv3 kernel stats of the same process
   d=/tmp/prof_sweep; rm -rf $d
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r03_sweep -- python3 benchmarks/roofline_sweep.py > gpurun_out/r03_roofline_sweep.md 2> gpurun_out/sweep.err
