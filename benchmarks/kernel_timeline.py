@@ -27,7 +27,7 @@ MARKS = {
     "bb_layer2_head": ["entry", "operands + statistics fold", "normalise, V'", "heads MFMA", "halves merged", "NAF head body", "dA2 MFMA + sums", "partials out"],
     "(unused)": ["entry"],
     "gemm_bundle": ["entry", "chunk 0 staged", "K loop", "C stored", "layer-1 backward epilogue", "norm partial"],
-    "bb_layer1_bwd_finish": ["entry", "loads + folds", "dW1 / slab sums", "norm partial"],
+    "bb_layer1_bwd_finish": ["entry", "loads, folds, dW1 / slab sums, norm partial"],
     "adam_polyak": ["entry", "norm folded + update"],
 }
 

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(const 
     __shared__ float sP[BF_COLS][2][32];
     NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 0);
     bb_finish_block(F, (int)blockIdx.x, (int)threadIdx.x, sQ, sP);
-    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 3);
+    NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 1);
 }
 
 // layer 1 forward for `nets` networks: statistics from the moments, z tile, normalise, ReLU -> out
