@@ -526,6 +526,27 @@ __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(const 
     NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 1);
 }
 
+// Rows by eighths: workgroup w of a launch runs on XCD (w + shift) % 8 (round-robin dispatch; `shift` = the workgroups in front of
+// these in the grid), and XCD x is given the rows [x B/8, (x+1) B/8) of BOTH networks in every launch of the chain — the 64-row
+// blocks of layer 1 and GEMM 2 here, the 16-row chunks of bb_layer2_head, the 32-row blocks of the bundle's dA1 product and the K
+// ranges of its dW2 product — so that what a launch reads of the previous launch's output is still in ITS OWN L2 (lines written by
+// a launch stay valid there behind the boundary; data from another XCD comes back over the fabric, ~2.5 us instead of ~1).
+// NB = 64-row blocks per network (a multiple of 8: B = 512, 1024, 1536, 2048), GY = column tiles: XCD x takes blocks
+// [x NB/8, (x+1) NB/8), all tiles, both networks. Updates/s, A/B/A/B on one box: B = 512 30.7k -> 31.2k, 1024 26.5k -> 26.9k,
+// 2048 21.05k -> 21.35k. (Smaller batches, where a block straddles 8 / NB eighths and its tiles would be dealt to those XCDs:
+// nothing at B = 256, -1.8 % at 64 — left alone.) Placement is speed only; false = leave the workgroup's own indices as they are.
+__device__ __forceinline__ static bool bb_place_rows(int w, int shift, int NB, int GY, int& net, int& rb, int& ct) {
+    if (NB < 8 || (NB & 7)) return false;
+    const int s = shift & 7, x = (w + s) & 7;
+    const int slot = ((w + s) >> 3) - (x < s ? 1 : 0);     // the slot-th workgroup of these on XCD x
+    const int G = NB >> 3, per = G * GY;
+    net = slot / per;
+    const int rem = slot - net * per;
+    ct = rem / G;
+    rb = x * G + (rem - ct * G);
+    return true;
+}
+
 // layer 1 forward for `nets` networks: statistics from the moments, z tile, normalise, ReLU -> out
 // Prologue: every global operand — the row tile, the 64 columns' weights (ONE contiguous run of 64 K floats, read as float4
 // and scattered to [k][column] in LDS), the moments record, the per-column parameters — is requested before the first LDS
@@ -543,7 +564,7 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     int64_t param_net_stride, const float* __restrict__ mom, float* __restrict__ running_mean,
     float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out, int64_t out_net_stride, int ldo,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ wc_out, int B, int H, float momentum,
-    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4, int n_adam) {
+    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4, int n_adam, int xcd_rows) {
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
     constexpr int XN = (BB_ROWS * K4 + BB_THREADS - 1) / BB_THREADS;           // float4 of the row tile per thread: 2
     constexpr int MN = (REC / 4 + BB_THREADS - 1) / BB_THREADS;                // of the moments record: 1 or 2
@@ -576,7 +597,9 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
         return;
     }
     const int gx = B / BB_ROWS, gy = H / BB_COLS;
-    const int rb = widx % gx, col0 = ((widx / gx) % gy) * BB_COLS, net = widx / (gx * gy);
+    int rb = widx % gx, ct_ = (widx / gx) % gy, net = widx / (gx * gy);
+    if (xcd_rows && n_main == 2 * gx * gy) bb_place_rows(widx, n_ride, gx, gy, net, rb, ct_);
+    const int col0 = ct_ * BB_COLS;
     const int64_t po = net * param_net_stride;
 #define L1_TL(slot) NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, slot, widx == 0, widx == n_main - 1)
     L1_TL(0);
@@ -894,14 +917,8 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     int bx = widx % gx, by = widx / gx;
 #define BL_TL(slot) NAF_TL_FL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, slot, widx == 0, widx == n_main - 1)
     const int NB = B / BB_ROWS;
-    if (xcd_nets && gx == 2 * NB && (NB & 3) == 0) {
-        // workgroup t runs on XCD t % 8: XCDs 0 .. 3 take the main network, 4 .. 7 the target, each a quarter of the row blocks
-        // with all column tiles — an XCD's L2 then pulls ONE network's W (256 KB) and its rows of A, instead of both networks' W
-        const int x = widx & 7, slot = widx >> 3, q = NB >> 2;
-        bx = (x >> 2) * NB + (x & 3) * q + slot % q;
-        by = slot / q;
-    }
-    const int net = bx / NB, rb = bx - net * NB;
+    int net = bx / NB, rb = bx - net * NB;
+    if (xcd_nets && gx == 2 * NB) bb_place_rows(widx, 0, NB, n_main / gx, net, rb, by);     // rows by eighths (see bb_place_rows)
     const int n0 = by * BL_BN;
     const float* an = a + net * a_net_stride + (int64_t)rb * BL_BM * lda;
     const float* wn_ = W + net * param_net_stride + (int64_t)n0 * K;     // [N][K] row-major
@@ -1004,12 +1021,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     }
     int bx = widx % gx, by = widx / gx;
     const int NB = B / BB_ROWS;
-    if (xcd_nets && gx == 2 * NB && (NB & 3) == 0) {            // (placement by network and row quarter, see above)
-        const int x = widx & 7, slot = widx >> 3, q = NB >> 2;
-        bx = (x >> 2) * NB + (x & 3) * q + slot % q;
-        by = slot / q;
-    }
-    const int net = bx / NB, rb = bx - net * NB;
+    int net = bx / NB, rb = bx - net * NB;
+    if (xcd_nets && gx == 2 * NB) bb_place_rows(widx, 0, NB, n_main / gx, net, rb, by);     // rows by eighths (see bb_place_rows)
     const int n0 = by * BN;
     const int r = lane & 15, g = lane >> 4;
     // operands through buffer loads (common.h): A rows (tid >> 5) + 8 i, float4 (tid & 31); B rows (tid >> 5) + 8 i < 16
@@ -1473,10 +1486,11 @@ extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx,
     const int n_main = (B / BB_ROWS) * (H / BB_COLS) * nets;
     const int n_adam = adam ? bb_adam_blocks(l1_4, n4, 2 * BB_THREADS) : 0;
     const int grid = n_main + n_adam;
+    const int xcd_rows = 1;      // rows by eighths (bb_place_rows)
 #define BB_L1(K4V, AD)                                                                                                       \
     bb_layer1_kernel<K4V, AD><<<grid, (AD) ? 2 * BB_THREADS : BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
                                                            running_mean, running_var, stat_net_stride, out, out_net_stride, ldo, \
-                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4, n_adam)
+                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4, n_adam, xcd_rows)
     if (k4d == 6) { if (adam) BB_L1(6, true); else BB_L1(6, false); }
     else { if (adam) BB_L1(8, true); else BB_L1(8, false); }
 #undef BB_L1
@@ -1495,7 +1509,7 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
     int64_t l1_4, n4;
     if (!bb_adam_setup(adam, ad, l1_4, n4)) return NAF_ERR_ARG;
     const int extra = adam ? bb_adam_blocks(0, l1_4, BB_THREADS) : 0;
-    const int xcd_nets = 0;      // (one network per XCD half: measured no faster — 29.9k | 25.6k | 19.5k without, 30.0k | 25.2k | 19.6k with)
+    const int xcd_nets = 1;      // rows by eighths (bb_place_rows)
     const int gx = nets * (B / BB_ROWS);
     hipStream_t st = (hipStream_t)stream;
 #define BB_LS(KERNEL, GY)                                                                                                   \
