@@ -325,18 +325,24 @@ class Learner:
         self._bb_segs, self._bb_nsegs = None, 0
         if "bb" in self.fuse:
             # The weight gradients reduce over K = B. Cut K into ranges, one grid of blocks each, writing partial slabs that
-            # the layer-1 finish launch adds in slab order (and takes the norm partials of): 256-row ranges for dWh; for dW2
-            # twice as long (512 rows) from B = 1024 on: half the blocks, half the slabs for the finish launch to add (B = 1024:
-            # 420 blocks — one round of two per CU — instead of 548: 21.8k -> 22.5k updates/s when it was introduced;
-            # B = 2048 with the blocks placed by row on the XCDs: 19.3k -> 19.7k; four times as long: 18.4k; NOT at B = 512,
-            # where one 512-row range means 64 two-chunk blocks on a quarter of the chip: 30.1k -> 30.5k with two). Batch sizes
+            # the layer-1 finish launch adds in slab order (and takes the norm partials of): 256-row ranges — with every launch
+            # of the chain working by eighths of the batch (csrc/big_batch.hip, bb_place_rows) a 256-row range is what one XCD
+            # (or two) already holds of dY2, Z2 and A1. For dW2 twice as long (512 rows) where the launch would otherwise not fit
+            # the chip at once — more than the 1024 blocks the four-wave form of the bundle has room for: B = 2048 (1096 blocks
+            # with eight ranges, 840 with four). Updates/s with 256- | 512-row ranges, A/B/A/B on one box at the end of round 3:
+            # B = 1024 28.0k | 27.0k, 1536 22.7k | 22.0k, 2048 20.9k | 21.3k. (Round 2 had it the other way round at 1024 — 420
+            # blocks in one round of the eight-wave form against 548 — before the rows went to the XCDs by eighths.) Batch sizes
             # that are not multiples of 256: as many equal ranges (<= 8, whole 64-row blocks) as divide B / 64.
             def k_ranges(target, most):
                 """largest number of equal K ranges <= most, each whole 16-k steps and at least `target` rows long"""
                 return max([d for d in range(1, most + 1) if B % d == 0 and (B // d) % 16 == 0 and B // d >= target] or [1])
+
+            def blocks(M, N, k_split):
+                """32 x 32 blocks of one product of the bundle (csrc/gemm_bundle.hip)"""
+                return ((M + 31) // 32) * ((N + 31) // 32) * k_split
             ks = B // 256 if B % 256 == 0 else k_ranges(256, 8)
             ks_w2 = ks_wh = ks
-            if ks >= 4 and ks % 2 == 0 and (B // (ks // 2)) % 256 == 0:
+            if blocks(B, H, 1) + blocks(H, H, ks) + blocks(NHP, HP, ks) + 8 > 1024 and ks % 2 == 0 and (B // (ks // 2)) % 256 == 0:
                 ks_w2 = ks // 2
             self.bb_slab_w2 = torch.zeros(ks_w2, H * H, **f32)
             self.bb_slab_wh = torch.zeros(ks_wh, NHP * HP, **f32)
