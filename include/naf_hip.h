@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 20
+#define NAF_HIP_ABI_VERSION 21
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -268,8 +268,10 @@ typedef struct {
 int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                        const float* gamma, const float* beta, int64_t param_net_stride, const float* mom, float* running_mean,
                        float* running_var, int64_t stat_net_stride, float* out, int64_t out_net_stride, int ldo,
-                       float* save_mean, float* save_invstd, float* wc_out, int B, int H, int nets, float momentum, float eps,
-                       const naf_adam_args_t* adam /* nullable (HOST pointer, copied into the launch) */, void* stream);
+                       float* save_mean, float* save_invstd, float* wc_out,
+                       float* xhat_out /* nullable: [B][ldo], xhat of net 0 — for naf_gemm_l1bwd_t.xhat */, int B, int H, int nets,
+                       float momentum, float eps, const naf_adam_args_t* adam /* nullable (HOST pointer, copied into the launch) */,
+                       void* stream);
 /* z[net] = a[net] W[net]^T + bias[net] (torch Linear, K = 256, N % 64 == 0) on f32 MFMA, 64 x 32 tiles (64 x 16 up to B = 512),
  * with the column statistics partials of every 64-row block written by the epilogue: replaces `self.hidden_layer(x)`
  * (naf_neural_network.py:78) and the statistics pass of bn2 for both networks. */
@@ -360,6 +362,13 @@ typedef struct naf_gemm_l1bwd {
     float* partials;
     float* p_slabs;
     int ldx, K, kp, lda1;
+    /* nullable: xhat of layer 1 as naf_bb_layer1_adam left it ([M][lda1], with gamma / beta [N]): the epilogue then reads its tile
+     * of it (the ReLU mask is fma(xhat, gamma, beta) > 0, the forward's own expression) instead of recomputing z = x W^T + b and
+     * xhat from W, bias, a1, save_mean and save_invstd — on the critical path of small batches, where the launch is one round of
+     * blocks, that recomputation was 0.6 us of an update; at large batches the extra B x N floats each way cost more than it. */
+    const float* xhat;
+    const float* gamma;
+    const float* beta;
 } naf_gemm_l1bwd_t;
 /* optional prologue on the A operand of a product: A = dY2 (the ReLU-masked gradient w.r.t. layer 2's BatchNorm output, written by
  * naf_bb_layer2_head) is turned into dZ2 = k1 (dy - c1 - xhat c2) WHILE the panel is staged — the second stage of layer 2's

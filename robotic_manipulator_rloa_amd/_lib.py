@@ -196,8 +196,8 @@ _PROTOS = {
                                       _i, _i, _i, _vp, _i64, _vp, _i, _i, _f, _f, _vp],
     "naf_bb_moments_floats": [_i],
     "naf_bb_moments": [_vp, _i64, _i64, _i, _i, _vp, _i, _i, _i, _vp],
-    "naf_bb_layer1_adam": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i, _f,
-                           _f, _vp, _vp],
+    "naf_bb_layer1_adam": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i, _i,
+                           _f, _f, _vp, _vp],
     "naf_bb_linear_stats_adam": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "naf_bb_layer2_head_rows": [_i],
     "naf_bb_layer2_head": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp,
@@ -278,7 +278,7 @@ class GemmL1Bwd(C.Structure):
     """naf_gemm_l1bwd_t (include/naf_hip.h)"""
     _fields_ = [("x", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("a1", C.c_void_p), ("save_mean", C.c_void_p),
                 ("save_invstd", C.c_void_p), ("partials", C.c_void_p), ("p_slabs", C.c_void_p), ("ldx", C.c_int), ("K", C.c_int),
-                ("kp", C.c_int), ("lda1", C.c_int)]
+                ("kp", C.c_int), ("lda1", C.c_int), ("xhat", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p)]
 
 
 def load(allow_build: bool = True) -> C.CDLL:

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     int64_t param_net_stride, const float* __restrict__ mom, float* __restrict__ running_mean,
     float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out, int64_t out_net_stride, int ldo,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ wc_out, int B, int H, float momentum,
-    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4, int n_adam, int xcd_rows) {
+    float eps, int n_main, const AdamArgs ad, int64_t l1_4, int64_t n4, int n_adam, int xcd_rows, float* __restrict__ xhat_out) {
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
     constexpr int XN = (BB_ROWS * K4 + BB_THREADS - 1) / BB_THREADS;           // float4 of the row tile per thread: 2
     constexpr int MN = (REC / 4 + BB_THREADS - 1) / BB_THREADS;                // of the moments record: 1 or 2
@@ -726,14 +726,21 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
         for (int i = 0; i < 4; ++i) {
             float4 y;
             float* yp = (float*)&y;
+            f32x4 xh4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = 4 * tx_ + j;
-                const float t = (zt[i][j] - sStat[0][c]) * sStat[1][c] * sStat[2][c] + sStat[3][c];
+                const float xh = (zt[i][j] - sStat[0][c]) * sStat[1][c];
+                const float t = __builtin_fmaf(xh, sStat[2][c], sStat[3][c]);     // (the ReLU decision the backward repeats from xhat)
+                xh4[j] = xh;
                 yp[j] = t > 0.f ? t : 0.f;
             }
             naf_buf_st_f4(naf_buf(oz + (int64_t)(rb * BB_ROWS) * ldo + col0), 4u * (unsigned)((4 * ty_ + i) * ldo + 4 * tx_), 0,
                           (f32x4){y.x, y.y, y.z, y.w}, B >= NAF_WT_MIN_B);
+            // the main network's xhat too where the backward wants it ready-made (naf_gemm_l1bwd_t.xhat: small batches)
+            if (xhat_out && net == 0)
+                naf_buf_st_f4(naf_buf(xhat_out + (int64_t)(rb * BB_ROWS) * ldo + col0), 4u * (unsigned)((4 * ty_ + i) * ldo + 4 * tx_), 0, xh4,
+                              B >= NAF_WT_MIN_B);
         }
     };
     if (ADAM && tid >= BB_THREADS) {
@@ -1461,8 +1468,10 @@ static int bb_adam_blocks(int64_t lo4, int64_t hi4, int threads) { return (int)(
 extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx, int K, const float* W, const float* bias,
                                   const float* gamma, const float* beta, int64_t param_net_stride, const float* mom,
                                   float* running_mean, float* running_var, int64_t stat_net_stride, float* out,
-                                  int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out, int B, int H,
-                                  int nets, float momentum, float eps, const naf_adam_args_t* adam, void* stream) {
+                                  int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, float* wc_out,
+                                  float* xhat_out, int B, int H, int nets, float momentum, float eps, const naf_adam_args_t* adam,
+                                  void* stream) {
+    if (xhat_out && ((uintptr_t)xhat_out & 15)) return NAF_ERR_ARG;
     if (!x || !W || !bias || !mom || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd ||
         !bb_shape_ok(B, H) || nets <= 0 || K <= 0 || K > 4 * BB_MAX_K4 || ldo < H || (ldo & 3))
         return NAF_ERR_ARG;
@@ -1490,7 +1499,7 @@ extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx,
 #define BB_L1(K4V, AD)                                                                                                       \
     bb_layer1_kernel<K4V, AD><<<grid, (AD) ? 2 * BB_THREADS : BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
                                                            running_mean, running_var, stat_net_stride, out, out_net_stride, ldo, \
-                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4, n_adam, xcd_rows)
+                                                           save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4, n_adam, xcd_rows, xhat_out)
     if (k4d == 6) { if (adam) BB_L1(6, true); else BB_L1(6, false); }
     else { if (adam) BB_L1(8, true); else BB_L1(8, false); }
 #undef BB_L1

@@ -185,9 +185,19 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
     for (int i = 0; i < L1bwdRegs<G>::NW; ++i) {
         const int e = tid + G::THREADS * i;
         const int c = KP == 24 ? e / 24 : e / 32, k = e - c * KP;
-        R.w[i] = (c < 32 && k < E.K) ? E.W[(int64_t)(n0 + c) * E.K + k] : 0.f;
+        R.w[i] = (!E.xhat && c < 32 && k < E.K) ? E.W[(int64_t)(n0 + c) * E.K + k] : 0.f;
     }
     const int col = n0 + wn * 16 + r;
+    if (E.xhat) {
+        // xhat ready-made (naf_bb_layer1_adam kept it): the lane's four C/D elements of it in a1[], gamma / beta of its column in
+        // mean / invstd — the ReLU mask is the forward's own fma(xhat, gamma, beta) > 0; nothing of W1 is needed
+#pragma unroll
+        for (int e = 0; e < 4; ++e) R.a1[e] = owner ? E.xhat[(int64_t)(m0 + wm * 16 + 4 * g + e) * E.lda1 + col] : 0.f;
+        R.mean = E.gamma[col];
+        R.invstd = E.beta[col];
+        R.bias = 0.f;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) R.a1[e] = owner ? E.a1[(int64_t)(m0 + wm * 16 + 4 * g + e) * E.lda1 + col] : 0.f;
     R.mean = E.save_mean[col];
@@ -260,12 +270,15 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
     }
     if (owner) {
         float s_dy = 0.f, s_dx = 0.f;
+        const bool kept = E.xhat != nullptr;                 // (uniform) a1[] = xhat, mean / invstd = gamma / beta of the column
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float dy = R.a1[e] > 0.f ? acc[e] : 0.f;
+            const float xhe = kept ? R.a1[e] : xh[e];
+            const bool on = kept ? __builtin_fmaf(R.a1[e], R.mean, R.invstd) > 0.f : R.a1[e] > 0.f;
+            const float dy = on ? acc[e] : 0.f;
             sDY[(wm * 16 + 4 * g + e) * 33 + wn * 16 + r] = dy;
             s_dy += dy;
-            s_dx += dy * xh[e];
+            s_dx += dy * xhe;
         }
         s_dy = naf_xor32_add(naf_xor16_add(s_dy));           // the tile's other row groups of the same column
         s_dx = naf_xor32_add(naf_xor16_add(s_dx));
@@ -370,7 +383,7 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     // them with benchmarks/kernel_timeline.py).
     asm volatile("" ::"s"(D.A), "s"(D.B), "s"(D.M), "s"(D.N), "s"(D.K), "s"(D.lda), "s"(D.ldb), "s"(D.k_split), "s"(D.epi.x), "s"(D.epi.W),
                  "s"(D.epi.bias), "s"(D.epi.a1), "s"(D.epi.save_mean), "s"(D.epi.save_invstd), "s"(D.epi.ldx), "s"(D.epi.K),
-                 "s"(D.epi.kp), "s"(D.epi.lda1), "s"(D.pro.z), "s"(D.pro.gamma), "s"(D.pro.save_mean), "s"(D.pro.save_invstd),
+                 "s"(D.epi.kp), "s"(D.epi.lda1), "s"(D.epi.xhat), "s"(D.epi.gamma), "s"(D.epi.beta), "s"(D.pro.z), "s"(D.pro.gamma), "s"(D.pro.save_mean), "s"(D.pro.save_invstd),
                  "s"(D.pro.cst), "s"(D.pro.epoch), "s"(D.pro.errors));
     GB_TL(0);
     GB_TL_WG(0);
@@ -393,7 +406,8 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
         }
     }
     f32x4 epi_xh = {0.f, 0.f, 0.f, 0.f};
-    if (D.epi.x) epi_xh = gemm_l1bwd_xhat<G>(D, !kh, wm, wn, r, g, sA, tid, epi_regs);   // under the panel loads' latency
+    // (uniform) recomputed under the panel loads' latency — or nothing to do: the forward pass kept it and the prefetch has it
+    if (D.epi.x && !D.epi.xhat) epi_xh = gemm_l1bwd_xhat<G>(D, !kh, wm, wn, r, g, sA, tid, epi_regs);
     if (pro) {                                            // the column constants, under the panel loads' latency too
         gemm_bn2bwd_wait_constants<AK, G::THREADS>(D.pro, m0, tid, sC);
         __syncthreads();
@@ -591,7 +605,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
             const naf_gemm_l1bwd_t& e = *s.epi;
             if (!e.x || !e.W || !e.bias || !e.a1 || !e.save_mean || !e.save_invstd || !e.partials || !e.p_slabs || ksn != 1 ||
                 (s.M & 31) || (s.N & 31) || e.K <= 0 || (e.kp != 24 && e.kp != 32) || e.K > e.kp || e.ldx < e.kp || (e.ldx & 3) ||
-                e.lda1 < s.N || ((uintptr_t)e.x & 15) || ((uintptr_t)e.partials & 7))
+                e.lda1 < s.N || ((uintptr_t)e.x & 15) || ((uintptr_t)e.partials & 7) || (e.xhat && (!e.gamma || !e.beta)))
                 return NAF_ERR_ARG;
             d.epi = e;
         }

@@ -348,9 +348,14 @@ class Learner:
             self.bb_slab_wh = torch.zeros(ks_wh, NHP * HP, **f32)
             t2p_, seg_, gp_ = self.theta2.data_ptr(), lay.seg, self.grad.data_ptr()
             # ep: the batch pass of layer 1's backward as the epilogue of the dA1 blocks (x / ldx: set per minibatch)
+            # (xhat of layer 1 kept by the forward pass for the epilogue up to B = 512 — one round of blocks, where recomputing it
+            # sat on the critical path: updates/s 36.0k -> 36.8k at B = 64, 35.2k -> 36.0k at 128, 34.6k -> 35.1k at 256, 31.25k ->
+            # 31.5k at 512; beyond that the recomputation hides and the extra B x H floats each way do not: 28.3k -> 27.7k at 1024)
+            self.XH1 = torch.empty(B, H, **f32) if B <= 512 else None
             self._epi = _lib.GemmL1Bwd(None, t2p_ + 4 * seg_["W1"].offset, t2p_ + 4 * seg_["b1"].offset, ptr(self.A1[0]),
                                        ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1),
-                                       0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H)
+                                       0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H, ptr(self.XH1),
+                                       t2p_ + 4 * seg_["g1"].offset, t2p_ + 4 * seg_["be1"].offset)
             # s2: dY2 -> dZ2 while the two products that read it stage their A panels; the block sums folded once per launch
             # by the bundle's first workgroups and handed on as tagged records (csrc/gemm_bundle.hip, gemm_bn2bwd_fold_block)
             self.bb_cst = torch.zeros(H, 4, **f32)                                        # per-column constants of the launch
@@ -455,8 +460,8 @@ class Learner:
             check(self._f.naf_bb_layer1_adam(
                 rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                 t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
-                ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), B, H, 2, BN_MOMENTUM,
-                BN_EPS, adam, st), "bb_layer1")
+                ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), ptr(self.XH1), B, H, 2,
+                BN_MOMENTUM, BN_EPS, adam, st), "bb_layer1")
             # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
             check(self._f.naf_bb_linear_stats_adam(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset,
                                                    t2p + 4 * seg["b2"].offset, P, ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H,
