@@ -34,9 +34,12 @@ def g3_case(tag):
     small = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
     if tag in ("kuka", "panda"):
         return small, load_group(small, f"{tag}/main0"), load_group(small, f"{tag}/target0")
-    big = np.load(os.path.join(GOLDEN, "g3_learn_big.npz"))
+    big = np.load(os.path.join(GOLDEN, "g3_learn_default.npz" if tag in G3_DEFAULT_TAGS else "g3_learn_big.npz"))
     init = str(big[f"{tag}/init_of"])
     return big, load_group(small, f"{init}/main0"), load_group(small, f"{init}/target0")
 
 
-G3_TAGS = ["kuka", "panda", "xarm1024", "panda2048"]
+# 'kuka64' / 'kuka128' / 'kuka192': the reference's learn() at configs[0]'s batch, at its default batch (rl_framework.py:68-74)
+# and at three 64-row blocks (tests/golden/g3_learn_default.npz, make_golden.py --only g3def)
+G3_DEFAULT_TAGS = ["kuka64", "kuka128", "kuka192"]
+G3_TAGS = ["kuka", "panda", "xarm1024", "panda2048"] + G3_DEFAULT_TAGS

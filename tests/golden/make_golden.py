@@ -213,6 +213,19 @@ def main():
             out[f"{tag}/init_of"] = np.array(init_of)
         np.savez_compressed(os.path.join(HERE, "g3_learn_big.npz"), **out)
 
+    # ---------------- G3 at the batch sizes the reference itself defaults to: configs[0]'s 64 and HyperParameters' 128
+    # (rl_framework.py:68-74), KUKA 21/6, and 192 = three 64-row blocks (the row-split chain's first odd block count) ----
+    if want("g3def"):
+        out = {}
+        small = np.load(os.path.join(HERE, "g3_learn.npz"))
+        for (S, A, B, tag, init_of) in ((21, 6, 64, "kuka64", "kuka"), (21, 6, 128, "kuka128", "kuka"),
+                                        (21, 6, 192, "kuka192", "kuka")):
+            main0 = g3_case(S, A, B, tag, True, out)
+            for k_, v_ in main0.items():
+                assert np.array_equal(v_, small[f"{init_of}/main0/{k_}"]), k_
+            out[f"{tag}/init_of"] = np.array(init_of)
+        np.savez_compressed(os.path.join(HERE, "g3_learn_default.npz"), **out)
+
     # ---------------- G4: replay contract ------------------------------------------------------------
     if want("g4"):
         S, A, cap, B = 21, 6, 300, 64

@@ -99,7 +99,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32),
                                    (21, 6, 512), (32, 8, 512), (21, 6, 1024), (21, 6, 768), (21, 6, 320), (21, 6, 1536),
-                                   (23, 7, 1984), (21, 6, 1000), (21, 6, 1008)])
+                                   (23, 7, 1984), (21, 6, 1000), (21, 6, 1008), (21, 6, 64), (21, 6, 128), (21, 6, 192)])
 def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
     """20 updates against the f32 numpy oracle (Hadamard = reference semantics; matmul = textbook NAF), every chain at
     every shape it admits — including batch sizes that are multiples of 64 but not of 256 (K ranges of the weight
