@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--roofline-ring", type=int, default=4_000_000,
                     help="rows of the ring the bulk gather roofline runs on (4e6 x 256 B = 1.02 GB: beyond the 256 MiB "
                          "Infinity Cache, BASELINE configs[4]'s ring); 0 = skip")
+    ap.add_argument("--roofline-hbm-ring", type=int, default=16_000_000,
+                    help="rows of a second, larger ring for the same bulk launch (16e6 x 256 B = 4.1 GB = 16 x the Infinity "
+                         "Cache: `roofline.hbm_only_frac`); <= --roofline-ring = skip")
     ap.add_argument("--roofline-rows", type=int, default=1 << 24,
                     help="rows gathered per bulk launch (16 Mi: 1.1 ms per launch; the ~9 us of ramp and tail of a launch are 3 %% of a 4 Mi one)")
     return ap.parse_args(argv)
@@ -258,6 +261,13 @@ def main():
     if rank == 0 and args.roofline_ring > 0:
         del loop, chunk
         out["roofline"] = bulk_gather_roofline(S, A, args.roofline_ring, args.roofline_rows, dev, row_alg)
+        # the same launch on a ring 16 times the Infinity Cache (16e6 rows = 4.1 GB: at most 1 / 16 of the row fetches can be
+        # served by the 256-MiB LLC): the figure that is HBM and nothing else
+        if args.roofline_hbm_ring > args.roofline_ring:
+            far = bulk_gather_roofline(S, A, args.roofline_hbm_ring, args.roofline_rows, dev, row_alg)
+            out["roofline"]["hbm_only_frac"] = far["frac"]
+            out["roofline"]["hbm_only"] = {k: far[k] for k in ("achieved", "avg_launch_ms", "ring_rows", "ring_bytes",
+                                                                "infinity_cache_share", "physical_GBps", "bad_indices")}
     # the launch that sits in the timed loop (one per vector step, U*B rows): latency, not bandwidth — reported as the
     # RAW event bracket (an empty bracket reads ~5 us on this stream, so this overstates the kernel; the profiler's
     # kernel-trace average is the number to quote for it)
@@ -345,13 +355,18 @@ def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
             "traffic": traffic, "traffic_source": source, "rows_per_launch": n_rows, "alg_bytes_per_launch": alg,
             "alg_bytes_per_row": row_alg, "physical_bytes_per_launch": phys, "avg_launch_ms": round(ms, 5),
             "launches_timed": reps, "ring_rows": ring_rows, "ring_bytes": ring_rows * ring.row_floats * 4,
-            "infinity_cache_assisted": ring_rows * ring.row_floats * 4 <= 256 * 2 ** 20, "bad_indices": bad,
+            # the share of the ring the 256-MiB Infinity Cache can hold: an upper bound of the share of row fetches it can
+            # serve (uniformly random rows, each fetched n_rows / ring_rows times per launch); FETCH_SIZE counts those hits too
+            "infinity_cache_share": round(min(1.0, 256 * 2 ** 20 / (ring_rows * ring.row_floats * 4)), 4), "bad_indices": bad,
             "physical_GBps": round(phys / (ms * 1e-3) / 1e9, 1),
             "note": "HIP events around back-to-back launches on the launching stream; achieved = algorithmic bytes "
-                    "(4*(2S+A+2)*2 + 4 per row: 404 B at S=21/A=6) / average launch time; profiles/r03_bench_kernel_stats.csv is "
+                    "(4*(2S+A+2)*2 + 4 per row: 404 B at S=21/A=6) / average launch time; profiles/r04_bench_kernel_stats.csv is "
                     "the rocprofv3 kernel-trace average of this kernel instance in the same command. A ring row is padded "
                     "200 -> 256 B (two whole 128-B lines per random row) and a gathered row 200 -> 208 B, so the launch moves "
-                    "1.16 x its algorithmic bytes; `traffic` is the PMC record of that (FETCH_SIZE x 2 + WRITE_SIZE)"}
+                    "1.16 x its algorithmic bytes; `traffic` is the PMC record of that (FETCH_SIZE x 2 + WRITE_SIZE). NOT an "
+                    "HBM-only figure on this ring: up to `infinity_cache_share` of the row fetches can hit the 256-MiB LLC "
+                    "(configs[4]'s real ring, so the number is the workload's); `hbm_only_frac` is the same launch on a ring 16 x "
+                    "the LLC"}
 
 
 def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadamard"):
@@ -475,6 +490,9 @@ def extras(dev, args):
                 "batch 96 (kuka, ring 1e5): the column-tile chain": measure_shape(dev, "kuka", 96, 100000, E, 500, 30),
                 # north_star's literal head: textbook P = L L^T on 8 x 9 padded LDS tiles (--p-mode matmul)
                 "configs[1] with P = L L^T (p_mode matmul)": measure_shape(dev, "kuka", 256, 1000000, E, 500, 30, p_mode="matmul"),
+                # ... and at configs[4]'s literal shape: 7 x 7 L / P tiles, batch 2048, ring 4e6
+                "configs[4] with P = L L^T (p_mode matmul): panda, batch 2048, ring 4e6":
+                    measure_shape(dev, "panda", 2048, 4000000, E, 300, 30, p_mode="matmul"),
             }
     finally:
         os.chdir(old)

@@ -11,18 +11,17 @@ logging.getLogger('robotic_manipulator_rloa.utils.logger').setLevel(40)
 env = SyntheticEnvironment(6)
 agent = NAFAgent(env, 21, 6, 256, 64, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, torch.device("cuda:0"), 0)
 state = env.reset(False)
-T = {"act": 0.0, "env.step": 0.0, "memory.add": 0.0, "update_tick": 0.0}
+T = {"act": 0.0, "env.step": 0.0, "agent.step": 0.0}
 def steps(n, timed):
     global state
     pc = time.perf_counter
     for _ in range(n):
         t0 = pc(); a = agent.act(state)
         t1 = pc(); nxt, r, d = env.step(a)
-        t2 = pc(); agent.memory.add(state, a, r, nxt, d)
-        t3 = pc(); agent._update_tick(None if d else nxt)
-        t4 = pc()
+        t2 = pc(); agent.step(state, a, r, nxt, d)      # the product's own path: the row is appended by the update's graph
+        t3 = pc()
         if timed:
-            T["act"] += t1 - t0; T["env.step"] += t2 - t1; T["memory.add"] += t3 - t2; T["update_tick"] += t4 - t3
+            T["act"] += t1 - t0; T["env.step"] += t2 - t1; T["agent.step"] += t3 - t2
         state = env.reset(False) if d else nxt
 steps(300, False)
 torch.cuda.synchronize(); t0 = time.perf_counter(); steps(2000, True); torch.cuda.synchronize(); dt = time.perf_counter() - t0
@@ -33,6 +32,6 @@ for k, v in T.items():
 ch = agent._chunk
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(2000):
-    ch.run()
+    ch.run()          # head_rows = 0: the graph's append node finds a zero row count and appends nothing
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"  chunk (flush-less) back to back: {dt/2000*1e6:.1f} us per update incl. the riding act()")

@@ -109,15 +109,20 @@ def main():
             break
         ent += list(buf[:16])
         ext += list(buf[16:])
-    n_wg = sum(1 for t in ent if t > 0)             # workgroups write their own slot; the rest of the array stays zero
+    # workgroups write their own slot; the rest of the array stays zero — and so do the slots of workgroups that leave no
+    # mark (the launch's first workgroups, which fold the BatchNorm-backward sums and exit): None, not a clock value
+    n_wg = max([i + 1 for i, t in enumerate(ent) if t > 0], default=0)
     if n_wg:
-        ent = [round((t - t0) / 100.0, 2) for t in ent[:n_wg]]
-        ext = [round((t - t0) / 100.0, 2) for t in ext[:n_wg]]
+        ent = [round((t - t0) / 100.0, 2) if t > 0 else None for t in ent[:n_wg]]
+        ext = [round((t - t0) / 100.0, 2) if t > 0 else None for t in ext[:n_wg]]
         out["gemm_bundle_workgroups"] = {"entry": ent, "exit": ext}
-        print(f"gemm_bundle: {n_wg} workgroups; entry / exit (us) of every 32nd:")
+        print(f"gemm_bundle: {n_wg} workgroups; entry / exit (us) of every 32nd that left marks:")
+        fmt = lambda v: "   (none)" if v is None else f"{v:7.2f}"          # noqa: E731
         for i in range(0, n_wg, 32):
-            print(f"    wg {i:4d}: {ent[i]:7.2f} -> {ext[i]:7.2f}")
-        print(f"    last   : {ent[-1]:7.2f} -> {ext[-1]:7.2f}; latest exit {max(ext):7.2f}")
+            j = next((k for k in range(i, min(i + 32, n_wg)) if ent[k] is not None), None)
+            if j is not None:
+                print(f"    wg {j:4d}: {fmt(ent[j])} -> {fmt(ext[j])}")
+        print(f"    last   : {fmt(ent[-1])} -> {fmt(ext[-1])}; latest exit {max(v for v in ext if v is not None):7.2f}")
     if args.out:
         with open(args.out, "w") as f:
             json.dump(out, f, indent=1)

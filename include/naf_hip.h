@@ -63,7 +63,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 21
+#define NAF_HIP_ABI_VERSION 22
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -90,6 +90,11 @@ int naf_replay_size(naf_replay_t* h, uint64_t* size_out /* host */, void* stream
 /* replaces ReplayBuffer.add (replay_buffer.py:32-45) for n transitions at once: FIFO append with
  * eviction of the oldest when full. `src_rows`: n packed transition rows on the device. n <= capacity. */
 int naf_replay_add_batch(naf_replay_t* h, const float* src_rows, int n, void* stream);
+/* The same for a launch that is captured ONCE and replayed on timesteps with and without a new transition (the head
+ * node of NAFAgent.step's update graph, naf_algorithm.py:144 `self.memory.add(...)` followed by :147-156): the row count
+ * is read by the kernel from `n_word` (device-visible memory, e.g. pinned host; clamped to [0, n_max]); 0 appends nothing
+ * and leaves {head, size, total} alone. n_max rows must fit one workgroup (n_max * row_floats <= 4096). */
+int naf_replay_add_counted(naf_replay_t* h, const float* src_rows, const int32_t* n_word, int n_max, void* stream);
 /* replaces `random.sample(self.memory, k)` (replay_buffer.py:55): n_batches independent minibatches of
  * B deque positions (0 = oldest), uniform over the current size, without replacement inside a
  * minibatch when `without_replacement` != 0 (and size >= B). Philox4x32-10 keyed by `seed`; stream position

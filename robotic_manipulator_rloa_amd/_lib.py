@@ -170,6 +170,7 @@ _PROTOS = {
     "naf_replay_destroy": [_vp],
     "naf_replay_size": [_vp, C.POINTER(_u64), _vp],
     "naf_replay_add_batch": [_vp, _vp, _i, _vp],
+    "naf_replay_add_counted": [_vp, _vp, _vp, _i, _vp],
     "naf_replay_sample_indices": [_vp, _u64, _vp, _u64, _vp, _i, _i, _i, _vp],
     "naf_replay_batch_row_floats": [_i, _i],
     "naf_replay_gather_rows": [_vp, _vp, _vp, _i, _i, _i, _vp],

@@ -114,6 +114,33 @@ __global__ __launch_bounds__(1024) void replay_add_small_kernel(float4* __restri
     }
 }
 
+// the same with the row count read where the kernel runs: a captured graph whose FIRST node is "append this timestep's
+// transition" is replayed on ticks that have no new transition too (idle ticks of a data-parallel run(), a step() that went
+// through the staging area) — the host sets the word to 0 for those and the node appends nothing
+__global__ __launch_bounds__(1024) void replay_add_counted_kernel(float4* __restrict__ ring, uint64_t* meta,
+                                                                  const float4* __restrict__ src, const int32_t* n_word,
+                                                                  int n_max, uint64_t cap, int rf4_shift) {
+    int n = __builtin_nontemporal_load(n_word);
+    n = n < 0 ? 0 : (n > n_max ? n_max : n);
+    const uint64_t head = meta[META_HEAD];
+    const uint64_t size = meta[META_SIZE];
+    const int rf4 = 1 << rf4_shift;
+    __syncthreads();
+    int g = threadIdx.x;
+    if (g < (n << rf4_shift)) {
+        int r = g >> rf4_shift;
+        int c = g & (rf4 - 1);
+        uint64_t phys = (head + (uint64_t)r) % cap;
+        ring[(phys << rf4_shift) + c] = src[g];
+    }
+    if (threadIdx.x == 0 && n > 0) {
+        meta[META_HEAD] = (head + (uint64_t)n) % cap;
+        uint64_t s2 = size + (uint64_t)n;
+        meta[META_SIZE] = s2 > cap ? cap : s2;
+        meta[META_TOTAL] += (uint64_t)n;
+    }
+}
+
 static inline int ilog2_exact(int x) {
     int s = 0;
     while ((1 << s) < x) ++s;
@@ -141,6 +168,18 @@ extern "C" int naf_replay_add_batch(naf_replay_t* h, const float* src_rows, int 
                                                     h->capacity, sh);
     NAF_CHECK_LAUNCH();
     replay_advance_kernel<<<1, 64, 0, st>>>(h->meta, (uint64_t)n, h->capacity);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_replay_add_counted(naf_replay_t* h, const float* src_rows, const int32_t* n_word, int n_max, void* stream) {
+    if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
+    const int rf4 = h->row_floats / 4;
+    if (!src_rows || !n_word || n_max < 1 || (uint64_t)n_max > h->capacity || (int64_t)n_max * rf4 > 1024 ||
+        ((uintptr_t)src_rows & 15) != 0 || ((uintptr_t)n_word & 3) != 0)
+        return NAF_ERR_ARG;
+    replay_add_counted_kernel<<<1, naf_round_up(n_max * rf4, 64), 0, (hipStream_t)stream>>>(
+        (float4*)h->rows, h->meta, (const float4*)src_rows, n_word, n_max, h->capacity, ilog2_exact(rf4));
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -71,9 +71,13 @@ class TrainChunk:
         head_row: optional pinned [1, row_floats] tensor: the graph STARTS by appending that one transition to the ring
         (the append kernel reads pinned host memory itself) — ReplayBuffer.add of the timestep inside the graph of its
         update instead of a launch, two event calls and a staging switch of its own. The caller fills the row and counts
-        the transition (replay._total_added) before every run()."""
+        the transition (replay._total_added) before every run(head_rows=1); a run() without a new transition (an idle
+        tick of a data-parallel run(), a timestep whose row went through the staging area) appends nothing: the node
+        reads its row count from a pinned word that run() sets (naf_replay_add_counted)."""
         self.tail, self._tail_state = tail, tuple(tail_state)
         self.head_row = head_row
+        self.head_count = torch.zeros(1, dtype=torch.int32).pin_memory() if head_row is not None else None
+        self._ran = None                   # event behind the last run(): the pinned words are free again once it has passed
         self.L, self.replay, self.U = learner, replay, int(n_updates)
         self.teacher_forced = teacher_forced
         self.gather_outside_graph = gather_outside_graph
@@ -123,7 +127,8 @@ class TrainChunk:
 
     def _body(self) -> None:
         if self.head_row is not None:
-            self.replay.add_rows_device(self.head_row, 1, _count=False)
+            check(self.L.lib.naf_replay_add_counted(self.replay.handle, ptr(self.head_row), ptr(self.head_count), 1, stream_ptr()),
+                  "naf_replay_add_counted")
         self._sample_gather()
         self._updates()
 
@@ -140,16 +145,31 @@ class TrainChunk:
             head = int(self.replay.meta[0].item())
             pos = (head + torch.arange(warmup, device=self.L.dev)) % self.replay.buffer_size
             saved = self.replay.rows[pos].clone()
+            count = int(self.head_count[0])
+            self.head_count[0] = 1         # the warm-up runs really append (and are undone)
 
             def put_back():
                 self.replay.rows[pos] = saved
+                self.head_count[0] = count
             self.graph = _capture(self._body, snap, warmup=warmup, after_warmup=put_back)
         else:
             self.graph = _capture(self._body, snap)
 
-    def run(self) -> None:
-        """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first."""
+    def wait_pinned_free(self) -> None:
+        """Block until the last run() has passed: what it reads from pinned host memory (the head row, its count, a tail's
+        observation) may be rewritten afterwards. In NAFAgent.run's loop act() has waited for it already."""
+        if self._ran is not None:
+            self._ran.synchronize()
+
+    def run(self, head_rows: int = 0) -> None:
+        """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first. head_rows (chunks built with
+        head_row): 1 = the pinned row holds a new transition that the chunk's first node appends, 0 = it appends nothing.
+        The caller has waited (wait_pinned_free) before it rewrote the row."""
         self.L.raise_on_device_error()         # pinned host words written by the kernels: costs two loads, never a sync
+        if self.head_row is not None:
+            if self.use_graph and self.graph is None:
+                self.capture()
+            self.head_count[0] = 1 if head_rows else 0
         if self.use_graph:
             if self.graph is None:
                 self.capture()
@@ -158,6 +178,10 @@ class TrainChunk:
             self.graph.replay()
         else:
             self._body()
+        if self.head_row is not None or self.tail is not None:
+            if self._ran is None:
+                self._ran = torch.cuda.Event()
+            self._ran.record()
 
     def losses(self) -> torch.Tensor:
         """[U] MSE losses of the last run (device tensor; summing the per-workgroup parts in index order)."""

@@ -146,6 +146,7 @@ class NAFAgent:
             # the transition from a pinned row of its own — same order (add, then sample) as the reference's step()
             m, row = self.memory, self._row_np[0]
             S, A = m.S, m.A
+            self._chunk.wait_pinned_free()     # the previous graph's append has read the row (run()'s act() waited already)
             row[:S] = state[0] if isinstance(state, tuple) else state
             row[S:S + A] = action
             row[S + A] = reward
@@ -161,7 +162,7 @@ class NAFAgent:
         m = self.memory
         return (self.update_freq == 1 and self.use_graph and m._handle is not None and m._pending == 0 and
                 (len(m) > self.batch_size if self.world_size == 1 else (self._dp_ticks > self.batch_size and len(m) > 0)) and
-                (self._chunk is None or self._chunk.head_row is not None))
+                self._chunk is not None and self._chunk.head_row is not None)
 
     def _update_tick(self, next_state=None, row_in_graph: bool = False) -> None:
         """The update schedule of step() (naf_algorithm.py:144-156) without the add. Data parallel: every learn() holds a
@@ -205,11 +206,14 @@ class NAFAgent:
                 self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=self.use_graph,
                                          tail=tail, tail_state=(a.counter, a._ticket) if tail else (), head_row=head)
             if self._chunk.tail is not None and next_state is not None:
+                self._chunk.wait_pinned_free()     # (a no-op behind step()'s own wait; idle ticks and staged rows come here)
                 self._actor1.obs_np[0] = next_state
                 self._ahead = np.array(next_state, dtype=np.float32, copy=True)
             else:
                 self._ahead = None
-            self._chunk.run()
+            # the graph's first node appends the pinned row only when this tick brought one (step()'s fast path): an idle
+            # tick of a data-parallel run() or a row that went through memory.add's staging must not re-append the last one
+            self._chunk.run(head_rows=1 if row_in_graph else 0)
             self._last_loss_from = "chunk"
 
     def _actor(self) -> ActPath:
@@ -356,8 +360,9 @@ class NAFAgent:
         if self.world_size == 1:
             return stop
         import torch.distributed as dist
+        pg = self.learner.pg
         flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=self.device)
-        dist.broadcast(flag, src=0)
+        dist.broadcast(flag, src=0 if pg is None else dist.get_global_rank(pg, 0), group=pg)
         return bool(flag.item())
 
     def run_vectorized(self, vector_steps: Optional[int] = None, n_envs: int = 64, max_frames: int = 400,
@@ -492,7 +497,9 @@ class NAFAgent:
                 if verbose:
                     logger.info(f'Episode {ledger.count + ledger.extra}: Reward {ep_score[e]}  Number of frames {ep_frames[e]}')
                 ep_score[e], ep_frames[e] = 0.0, 0
-            if episodes is not None and self._stop_agreed(ledger.complete):
+            # (data parallel: the verdict is a blocking broadcast — compared every 8th vector step, not on every one; the
+            # loop may run up to 7 steps past the last episode, whose episodes are counted but not recorded)
+            if episodes is not None and (self.world_size == 1 or steps % 8 == 0) and self._stop_agreed(ledger.complete):
                 break
         if pending_learn:
             chunk.run()

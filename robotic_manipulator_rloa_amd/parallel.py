@@ -16,6 +16,18 @@ import torch
 import torch.distributed as dist
 
 
+def share_one_gpu() -> bool:
+    """NAF_DP_SHARE_GPU=1: every rank of the launch uses cuda:0 and gloo is the control plane (RCCL refuses two ranks on
+    one device). A REHEARSAL of the data-parallel code on a 1-GPU box — hipIpc mappings, the one-shot all-reduce, the
+    training loops' lock-step logic are the multi-GPU code; only the wire is local HBM. Never a performance mode."""
+    return os.environ.get("NAF_DP_SHARE_GPU") == "1"
+
+
+def local_device() -> torch.device:
+    """The device of this rank: cuda:LOCAL_RANK (one process per GPU), cuda:0 for every rank in the rehearsal mode."""
+    return torch.device("cuda", 0 if share_one_gpu() else int(os.environ.get("LOCAL_RANK", "0")))
+
+
 def init_distributed(backend: Optional[str] = None) -> tuple:
     """(rank, local_rank, world). Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -24,11 +36,13 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if torch.cuda.is_available() and not share_one_gpu() else "gloo"
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local_device())
         dist.init_process_group(backend, **kw)
     return rank, local_rank, world
 

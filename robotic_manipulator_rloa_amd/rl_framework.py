@@ -266,9 +266,13 @@ class ManipulatorFramework:
 
     def initialize_synthetic_environment(self, n_joints: int = 6, target_position: List[float] = None,
                                          obstacle_position: List[float] = None, initial_joint_positions: List[float] = None,
-                                         initial_positions_variation_range: List[float] = None) -> None:
+                                         initial_positions_variation_range: List[float] = None,
+                                         obstacle_jitter: float = 0.0) -> None:
+        """obstacle_jitter (many-env runs on the device only): each env's obstacle sits at obstacle_position + U(-j, j)^3,
+        drawn once per (rank, env) — BASELINE configs[3]'s "randomized obstacle_position per env"."""
         self.env = SyntheticEnvironment(n_joints, target_position, obstacle_position, initial_joint_positions,
                                         initial_positions_variation_range)
+        self._obstacle_jitter = float(obstacle_jitter)
         self._env_factory = functools.partial(_build_synthetic, n_joints, target_position, obstacle_position,
                                               initial_joint_positions, initial_positions_variation_range)
         logger.info('Synthetic (kinematic stand-in) Environment successfully initialized')
@@ -298,8 +302,8 @@ class ManipulatorFramework:
             raise InvalidNAFAgentParameter('Number of environments received is not a positive integer')
         self._n_envs = n_envs
         hp = self._hyperparameters
-        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-        device = torch.device(f'cuda:{local_rank}')
+        from .parallel import local_device
+        device = local_device()              # cuda:LOCAL_RANK — one process per GPU under torch.distributed.run
         self.naf_agent = NAFAgent(environment=self.env,
                                   state_size=self.env.observation_space.shape[0],
                                   action_size=self.env.action_space.shape[0],
@@ -351,7 +355,8 @@ class ManipulatorFramework:
         pad8 = lambda v: ([float(x) for x in v] + [0.0] * 8)[:8]          # noqa: E731
         var = env.initial_positions_variation_range
         return {'preset': pad8(env.initial_joint_positions) + [float(x) for x in env.target_pos] +
-                [float(x) for x in env.obstacle_pos], 'variation': pad8(var) if var is not None else [0.0] * 8}
+                [float(x) for x in env.obstacle_pos], 'variation': pad8(var) if var is not None else [0.0] * 8,
+                'obstacle_jitter': getattr(self, '_obstacle_jitter', 0.0)}
 
     def _host_vector_env(self, n_envs: int, frames: int):
         from .environment.vector_env import HostVectorEnv
