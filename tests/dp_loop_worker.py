@@ -33,7 +33,10 @@ def main():
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
     env = ScriptedEnvironment(offset=rank)
     frames, episodes, B = 8, 14, 8
-    agent = NAFAgent(env, env.S, env.A, 256, B, 1000, 1e-3, 1e-3, 0.99, 1, 1, 5, dev, 0)
+    # NAF_XGMI=0 puts the gradient on torch.distributed's all-reduce — gloo in this rehearsal, which (unlike RCCL) cannot be
+    # captured into a graph: the same launches run eagerly there
+    agent = NAFAgent(env, env.S, env.A, 256, B, 1000, 1e-3, 1e-3, 0.99, 1, 1, 5, dev, 0,
+                     use_graph=os.environ.get("NAF_XGMI", "1") != "0")
     assert agent.world_size == world and agent.rank == rank
     scores = agent.run(frames, episodes, verbose=False)
     torch.cuda.synchronize()
