@@ -28,7 +28,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // diagnostic of an over-subscribed GPU, no result depends on it). No wait can expire into a wrong number.
 // Records and polls are sc1 only (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire).
 #define GB_POLL_TICKS 2000LL             // 20 us at 100 MHz
+#ifndef GB_FOLD_COLS
 #define GB_FOLD_COLS 32
+#endif
 template <int THREADS = 512>
 __device__ static inline void gemm_bn2bwd_fold_block(const naf_gemm_bn2bwd_t& P, int f, int tid, float* scratch) {
     constexpr int NPAIR = GB_FOLD_COLS / 2, PARTS = THREADS / NPAIR, QMAX = 128 / PARTS;

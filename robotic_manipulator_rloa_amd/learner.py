@@ -342,7 +342,19 @@ class Learner:
                 return ((M + 31) // 32) * ((N + 31) // 32) * k_split
             ks = B // 256 if B % 256 == 0 else k_ranges(256, 8)
             ks_w2 = ks_wh = ks
-            if blocks(B, H, 1) + blocks(H, H, ks) + blocks(NHP, HP, ks) + 8 > 1024 and ks % 2 == 0 and (B // (ks // 2)) % 256 == 0:
+            # Which form of the bundle launch (include/naf_hip.h, naf_gemm_bundle_ex): one 32 x 32 block per workgroup (form 1, the
+            # default at every batch size) or the LDS-DMA ring on 64 x 32 tiles (form 2, csrc/gemm_ring.h; NAF_GEMM_FORM = 2 opts in
+            # where the K ranges are whole 32-k chunks). Round 4 built the ring with two and more chunks in flight and measured it
+            # against form 1 on the same boxes — updates/s at B = 1024 | 2048: 28.2k | 21.4k (form 1) against 27.0k | 20.8k; the
+            # launch itself under rocprofv3 10.2 | 15.6 us against 11.4 | 17.6 us. Why: DESIGN.md section 4b, round 4 (the launch is
+            # not bound by staging — the DMAs alone take a fifth of a block's K loop — but by per-block fixed latencies and by how
+            # evenly a few hundred blocks cover 1024 SIMDs).
+            self.gemm_form = int(os.environ.get("NAF_GEMM_FORM", "0"))
+            if self.gemm_form not in (0, 1, 2):
+                raise ValueError("NAF_GEMM_FORM: 0 / 1 (32 x 32 blocks) or 2 (LDS-DMA ring)")
+            self.gemm_ring = self.gemm_form == 2 and (B // ks) % 32 == 0
+            if not self.gemm_ring and blocks(B, H, 1) + blocks(H, H, ks) + blocks(NHP, HP, ks) + 8 > 1024 and ks % 2 == 0 and \
+                    (B // (ks // 2)) % 256 == 0:
                 ks_w2 = ks // 2
             self.bb_slab_w2 = torch.zeros(ks_w2, H * H, **f32)
             self.bb_slab_wh = torch.zeros(ks_wh, NHP * HP, **f32)
@@ -351,7 +363,8 @@ class Learner:
             # (xhat of layer 1 kept by the forward pass for the epilogue up to B = 512 — one round of blocks, where recomputing it
             # sat on the critical path: updates/s 36.0k -> 36.8k at B = 64, 35.2k -> 36.0k at 128, 34.6k -> 35.1k at 256, 31.25k ->
             # 31.5k at 512; beyond that the recomputation hides and the extra B x H floats each way do not: 28.3k -> 27.7k at 1024)
-            self.XH1 = torch.empty(B, H, **f32) if B <= 512 else None
+            # The ring form's epilogue always reads the kept xhat (it has no W1 / X product of its own).
+            self.XH1 = torch.empty(B, H, **f32) if (B <= 512 or self.gemm_ring) else None
             self._epi = _lib.GemmL1Bwd(None, t2p_ + 4 * seg_["W1"].offset, t2p_ + 4 * seg_["b1"].offset, ptr(self.A1[0]),
                                        ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1),
                                        0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H, ptr(self.XH1),
@@ -560,7 +573,7 @@ class Learner:
         # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles; dY2 becomes dZ2 while it is staged, the
         # dA1 blocks run layer 1's backward batch pass on their tile (this minibatch's rows: z recomputed from them)
         self._epi.x, self._epi.ldx = rp, ld
-        check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
+        check(f.naf_gemm_bundle_ex(self._bundle, 3, 2 if self.gemm_ring else 1, st), "gemm_bundle")
         # finish: everything added in block order, the xhat term from the moments, the bundle's split-K slabs, the norm
         # partials (nb = 0: the layer-2 bias gradient is written as the 0 it identically is). Data parallel over peer memory:
         # the workgroups that add the slabs of dW2 and dWh (91 % of the flat gradient) store them to the peers as well, so the
@@ -621,7 +634,7 @@ class Learner:
                 gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
         if gb:
             # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles
-            check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
+            check(f.naf_gemm_bundle_ex(self._bundle, 3, 1, st), "gemm_bundle")
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
             torch.mm(self.dZ2, self.W2_main, out=self.dA1)
