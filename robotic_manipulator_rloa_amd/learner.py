@@ -248,8 +248,12 @@ class Learner:
         # chain on one rank, gradient norm folded into the producers. NAF_DEFER_ADAM=0 keeps the launch of its own.
         # Data parallel over peer memory: the one-shot all-reduce launch leaves the norm partials and the step count exactly
         # as the folded producers do on one rank, so the step can ride there too (the RCCL path keeps its two launches).
-        self.defer_ok = ("bb" in self.fuse and ((self.fold_norm and self.world_size == 1) or self.xgmi is not None)
-                         and os.environ.get("NAF_DEFER_ADAM", "1") != "0")
+        # The collective path (RCCL, or the test-only forced all-reduce): the norm must be taken on the REDUCED gradient, so a norm
+        # launch stays behind the collective — and the optimizer step rides on the next update behind it all the same (round 4:
+        # one launch and one boundary less per update there too; before, that path kept both launches).
+        self.defer_ok = ("bb" in self.fuse and os.environ.get("NAF_DEFER_ADAM", "1") != "0" and
+                         ((self.fold_norm and self.world_size == 1) or self.xgmi is not None or self.world_size > 1 or
+                          self._force_allreduce))
         self.adam_bc = torch.zeros(8, **f32)     # the next step's bias corrections, left by the riding optimizer workgroups
         self._adam_args = _lib.AdamArgs(
             ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]), ptr(self.partials),
@@ -549,6 +553,11 @@ class Learner:
                     self.optimizer_step(norm_ready=True)
                 return
             all_reduce_flat_grad(self.grad, self.pg)
+            if defer:
+                # the step rides on the next update; the sum-of-squares partials of the reduced gradient (and the step count) it
+                # reads are left by this launch
+                check(self._f.naf_grad_norm_partials(ptr(self.grad), P, ptr(self.partials), ptr(self.step_dev), st), "grad_norm")
+                return
         if defer:
             return                       # the next learn_rows(pending=True) carries the step
         self.optimizer_step(norm_ready=self.fold_norm)

@@ -298,6 +298,41 @@ def test_deferred_optimizer_step_is_the_same_bits(S, A, B, U, monkeypatch):
             assert torch.equal(a, b), f"{name} differs with the deferred step ({key})"
 
 
+@pytest.mark.parametrize("B", [256, 1024])
+def test_deferred_optimizer_step_behind_a_collective_is_the_same_bits(B, monkeypatch):
+    """The collective path of data parallel (RCCL all-reduce of the flat gradient, then a norm launch on the reduced gradient) with
+    the optimizer step riding on the next update (round 4) against the same path with the step as a launch of its own: world 1 with
+    the all-reduce forced (a no-op that keeps every launch of the path), eager and as replayed graphs — bit-identical."""
+    from synth_data import make_transitions
+    from robotic_manipulator_rloa_amd.engine import TrainChunk
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    S, A, U = 21, 6, 6
+    sd = reference_init_state_dict(S, A, 256, seed=3)
+    n_rows = 6000
+    st, ac, rw, ns, dn = make_transitions(n_rows, S, A, seed=11)
+    res = {}
+    for mode, use_graph in (("0", False), ("1", False), ("1", True)):
+        monkeypatch.setenv("NAF_DEFER_ADAM", mode)
+        L = make_learner(S, A, B, sd, sd, _force_allreduce=True)
+        assert not L.fold_norm and L.defer_ok == (mode == "1")
+        buf = ReplayBuffer(n_rows, B, "cuda", 0, state_size=S, action_size=A)
+        buf.add_rows_device(torch.from_numpy(O.pack_rows(st, ac, rw, ns, dn, 64)).cuda(), n_rows)
+        chunk = TrainChunk(L, buf, U, use_graph=use_graph)
+        losses = []
+        for _ in range(3):
+            chunk.run()
+            losses.append(chunk.losses().clone())
+        torch.cuda.synchronize()
+        assert int(L.step_dev.item()) == 3 * U
+        res[(mode, use_graph)] = (L.theta2.clone(), L.adam_m.clone(), L.adam_v.clone(), L.bn_stats.clone(), torch.cat(losses))
+    ref = res[("0", False)]
+    assert torch.isfinite(ref[0]).all() and not torch.equal(ref[0][0], ref[0][1])
+    for key in (("1", False), ("1", True)):
+        for a, b, name in zip(ref, res[key], ("theta2", "adam_m", "adam_v", "bn_stats", "losses")):
+            assert torch.equal(a, b), f"{name} differs with the deferred step ({key})"
+
+
 def test_learn_rows_rejects_a_deferred_step_where_it_cannot_ride(monkeypatch):
     monkeypatch.setenv("NAF_DEFER_ADAM", "0")
     from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
