@@ -58,12 +58,14 @@ typedef struct {
     uint64_t* ctrl;
     uint64_t data_off, n_pad;
     int rank, world;
+    long long timeout_ticks;             /* bound of a wait on a peer's flag, 100-MHz ticks (naf_xgmi_set_timeout) */
+    uint64_t* host_timeouts;             /* pinned host word a timed-out wait bumps (naf_xgmi_timeouts_nowait) */
 } naf_xgmi_push_t;
 
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 23
+#define NAF_HIP_ABI_VERSION 24
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -345,7 +347,15 @@ int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float* partials1
                              const naf_xgmi_push_t* push /* nullable (HOST pointer): data parallel over peer memory — the workgroups that add
                              the slab segments also store them into this rank's slot on every peer (naf_xgmi_push_desc); the all-reduce that
                              follows is then told those ranges went ahead (naf_xgmi_allreduce_sum_from2) */,
-                             const float* grad_base /* with push: the flat gradient the segments' dst lie in */, void* stream);
+                             const float* grad_base /* with push: the flat gradient the segments' dst lie in */,
+                             size_t merge_total /* 0: push only. n (the flat gradient's length; the two segments must be its last two
+                             pieces): the WHOLE exchange happens in this launch — its last-arriving workgroup pushes what the segments do
+                             not cover and raises the epoch flags, every workgroup that holds gradient elements waits for the peers' flags
+                             (bounded: naf_xgmi_set_timeout) and leaves the rank-ordered sum over ranks in the flat gradient;
+                             sumsq_partials (required) then hold the REDUCED gradient's sums of squares, one entry per workgroup PLUS ONE
+                             (the ranges the segments do not cover, at index [workgroups]), -inf where a wait timed out; *step_dev += 1. No naf_xgmi_allreduce_* call follows (where clip_grad_norm_ sits in
+                             the reference, naf_algorithm.py:207-210) */,
+                             void* stream);
 
 /* ---- several small f32 GEMMs in one launch (csrc/gemm_bundle.hip) ------------------------------------------- */
 /* C[M][N] = op(A) op(B): A is [M][K] row-major (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), B is

@@ -206,7 +206,7 @@ _PROTOS = {
     "naf_bb_layer1_bwd_kp": [_i],
     "naf_bb_layer1_bwd_finish_blocks": [_i],
     "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
-                                 _vp, _i, _vp, _vp, _vp, _vp],
+                                 _vp, _i, _vp, _vp, _vp, _sz, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],
     "naf_gemm_bundle_ex": [_vp, _i, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
@@ -240,7 +240,7 @@ EXPORTED_SYMBOLS = tuple(_PROTOS)
 class XgmiPushDesc(C.Structure):
     """naf_xgmi_push_t (include/naf_hip.h)"""
     _fields_ = [("peer_base", C.c_void_p * 8), ("ctrl", C.c_void_p), ("data_off", C.c_uint64), ("n_pad", C.c_uint64),
-                ("rank", C.c_int), ("world", C.c_int)]
+                ("rank", C.c_int), ("world", C.c_int), ("timeout_ticks", C.c_longlong), ("host_timeouts", C.c_void_p)]
 
 
 class SlabSeg(C.Structure):

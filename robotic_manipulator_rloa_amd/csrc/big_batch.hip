@@ -396,7 +396,156 @@ struct FinishArgs {
     // all-reduce launch behind this one has only the layer-1 / BatchNorm segments left to send before it raises its flags
     naf_xgmi_push_t push;
     const float* grad_base;      // the flat gradient the segments' dst pointers lie in; NULL: no push
+    // merge != 0: the WHOLE exchange happens in this launch (bb_finish_exchange): what is not a slab segment — the layer-1 and
+    // BatchNorm ranges [r_lo[i], r_hi[i]) of the flat gradient, 27 KB — is pushed by the launch's last-arriving workgroup, which
+    // then raises the epoch flags; every workgroup that holds gradient elements waits for the peers' flags and leaves its elements
+    // as the rank-ordered sum, with the sum-of-squares partials of the REDUCED gradient — no all-reduce launch behind this one
+    int merge;
+    size_t r_lo[2], r_hi[2];
 };
+// a float4 of this rank's gradient into its slot on a peer, inside the launch that also raises the flags (merge)
+#ifndef BB_PUSH_MODE
+// 0: plain stores + a system-scope release fence per workgroup in front of its ticket (the protocol of csrc/xgmi_reduce.hip);
+// 1: sc1 stores, 2: sc0 sc1 stores (written through, no fence). Shared-GPU rehearsal, W = 2, us per update (benchmarks/
+// ab_push_mode.sh; the peers' slabs are LOCAL memory there, cached by the writer's L2 unless written through): 61.8 | 94.8 | 95.0 —
+// against 48.1 with the all-reduce as a launch of its own (NAF_XGMI_MERGE=0), which is why that stays the default until a
+// multi-GPU box has measured both over real xGMI (where a peer's memory is not cached locally and the ranking may differ).
+#define BB_PUSH_MODE 0
+#endif
+__device__ __forceinline__ static void bb_push_st(float* sl, xg_f4 v) {
+#if BB_PUSH_MODE == 0
+    *(xg_f4*)sl = v;
+#elif BB_PUSH_MODE == 1
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(naf_u32x4, v), naf_buf(sl, 16), 0, 0, 16);
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(naf_u32x4, v), naf_buf(sl, 16), 0, 0, 17);
+#endif
+}
+
+// a gradient element of the column workgroups: written THROUGH (sc1) when the launch's last-arriving workgroup will read it
+__device__ __forceinline__ static void bb_st(float* p, float v, int through) {
+    if (through) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), naf_buf(p, 4), 0, 0, 16);
+    else *p = v;
+}
+
+// The gradient exchange of data parallel INSIDE the finish launch (round 4; until then a launch of its own behind it,
+// csrc/xgmi_reduce.hip, whose protocol — slots by epoch parity, one epoch flag per peer, wall-clock bounded waits, a poisoned norm
+// partial on a time-out — this is, dealt over the workgroups that already hold the gradient):
+//   every workgroup: its pushes into the peers' slabs released at system scope and acknowledged (BB_PUSH_MODE), its own elements
+//     of the small ranges written through (sc1) -> a ticket.
+//   the LAST to arrive: reads the ranges no slab workgroup covers (layer 1 and the BatchNorm vectors, sc1 loads: the column
+//     workgroups wrote them through), pushes them, waits for the acknowledgements, raises this rank's flag on every peer, advances
+//     the epoch.
+//   every workgroup that holds gradient elements (slab workgroups; the last one for the small ranges): waits for the W - 1 peers'
+//     flags, then leaves grad = the sum over ranks in RANK ORDER (its own contribution from registers), and its sum-of-squares partial.
+// No workgroup waits for another workgroup of its own launch — the ticket is not polled — only for the peers' flags, which depend
+// on nothing but the peers' own launches: no circular wait whatever the residency of the grid.
+#define BB_EX_SMALL 8            // float4 per thread of the last workgroup: the small ranges are at most 8 KB floats
+__device__ static inline void bb_finish_exchange(const FinishArgs& F, int block, int tid, float4 ex_a, size_t ex_o, bool ex_on, float* sQ) {
+    __shared__ int s_last, s_timed;
+    const naf_xgmi_push_t& X = F.push;
+    const int W = X.world, rank = X.rank;
+    const uint64_t e = X.ctrl[0] + 1;          // (read before this workgroup's ticket: only the last arrival writes ctrl[0])
+    if (tid == 0) s_timed = 0;
+#if BB_PUSH_MODE == 0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd((unsigned long long*)&X.ctrl[1], 1ull) == (unsigned long long)F.n_blocks - 1;
+    __syncthreads();
+    const bool last = s_last != 0;
+    const bool slab_wg = block >= F.slabs.n_finish_blocks;
+    float* grad = (float*)F.grad_base;
+    xg_f4 mine[BB_EX_SMALL];
+    size_t moff[BB_EX_SMALL];
+    const size_t n0 = (F.r_hi[0] - F.r_lo[0]) >> 2, n1 = (F.r_hi[1] - F.r_lo[1]) >> 2;
+    if (last) {
+        const __amdgpu_buffer_rsrc_t gr = naf_buf(grad);
+#pragma unroll
+        for (int q = 0; q < BB_EX_SMALL; ++q) {
+            const size_t j = (size_t)tid + (size_t)BB_THREADS * q;
+            const bool on = j < n0 + n1;
+            moff[q] = !on ? 0 : (j < n0 ? F.r_lo[0] + 4 * j : F.r_lo[1] + 4 * (j - n0));
+            mine[q] = naf_buf_f4_sc1(gr, (unsigned)(moff[q] * 4), 0);
+        }
+#pragma unroll
+        for (int q = 0; q < BB_EX_SMALL; ++q) {
+            const size_t j = (size_t)tid + (size_t)BB_THREADS * q;
+            if (j < n0 + n1) {
+#pragma unroll
+                for (int p = 0; p < NAF_XGMI_MAX_WORLD; ++p)
+                    if (p < W)
+                        bb_push_st(xg_slot((char*)X.peer_base[p], X.data_off, X.n_pad, W, e, rank) + moff[q], mine[q]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < W && tid != rank) {
+            uint64_t* flag = (uint64_t*)((char*)X.peer_base[tid] + (size_t)rank * 128);
+            __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (tid == 0) {
+            X.ctrl[1] = 0;
+            X.ctrl[0] = e;
+        }
+    }
+    if (!slab_wg && !last) {                   // a column workgroup that is not the last: nothing of the sum is its to form
+        if (tid == 0 && F.sumsq_partials) F.sumsq_partials[block] = 0.f;
+        return;
+    }
+    if (tid < W && tid != rank) {
+        const uint64_t* flag = (const uint64_t*)((char*)X.peer_base[rank] + (size_t)tid * 128);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+            if (wall_clock64() - t0 > X.timeout_ticks) {         // the exit every wave reaches: peer missing or dead
+                atomicAdd((unsigned long long*)&X.ctrl[2], 1ull);
+                if (X.host_timeouts) __hip_atomic_fetch_add(X.host_timeouts, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_timed = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");            // system scope: drop anything this CU still holds of the slots
+    const bool timed = s_timed != 0;
+    float ss = 0.f;
+    // the rank-ordered sum of one float4: every peer's contribution in flight together, the own one from registers
+    auto reduce4 = [&](size_t off, xg_f4 own) {
+        const float* slot0 = xg_slot((char*)X.peer_base[rank], X.data_off, X.n_pad, W, e, 0) + off;
+        xg_f4 v[NAF_XGMI_MAX_WORLD];
+#pragma unroll
+        for (int s_ = 0; s_ < NAF_XGMI_MAX_WORLD; ++s_) v[s_] = *(const xg_f4*)(slot0 + (size_t)(s_ < W ? s_ : 0) * X.n_pad);
+        xg_f4 acc = rank == 0 ? own : v[0];
+#pragma unroll
+        for (int s_ = 1; s_ < NAF_XGMI_MAX_WORLD; ++s_)
+            if (s_ < W) acc = acc + (s_ == rank ? own : v[s_]);
+        *(xg_f4*)(grad + off) = acc;
+        ss += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+    };
+    if (slab_wg && ex_on) reduce4(ex_o, (xg_f4){ex_a.x, ex_a.y, ex_a.z, ex_a.w});
+    const float tot = block_sum_to_thread0<BB_THREADS, true>(ss, sQ, tid);
+    // a contribution is missing: the partial is POISONED (csrc/xgmi_reduce.hip: naf_adam_polyak_fused skips the whole update on a
+    // negative norm; partials of workgroups that did not time out stay below 1e30, so the sum is -inf, never inf - inf)
+    if (tid == 0 && F.sumsq_partials) F.sumsq_partials[block] = timed ? -__builtin_huge_valf() : (tot > 1e30f ? 1e30f : tot);
+    if (last) {
+        // the small ranges' sum of squares goes to an entry of ITS OWN behind the workgroups' (index n_blocks): WHICH workgroup
+        // arrives last differs from rank to rank and from launch to launch, and the optimizer adds the partials in index order —
+        // folded into the last workgroup's own entry, the norm rounded differently on different ranks and the replicas drifted apart
+        ss = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BB_EX_SMALL; ++q)
+            if ((size_t)tid + (size_t)BB_THREADS * q < n0 + n1) reduce4(moff[q], mine[q]);
+        const float tot2 = block_sum_to_thread0<BB_THREADS, true>(ss, sQ, tid);
+        if (tid == 0) {
+            if (F.sumsq_partials) F.sumsq_partials[F.n_blocks] = timed ? -__builtin_huge_valf() : (tot2 > 1e30f ? 1e30f : tot2);
+            if (F.step_dev && !timed) *F.step_dev += 1;
+        }
+    }
+}
+
 // One workgroup (BB_THREADS threads) of the finish work.
 __device__ static inline void bb_finish_block(const FinishArgs& F, int block, int tid, float* sQ, float (*sP)[2][32]) {
     // (no FP contraction: the gradient of a build rounds the same way whatever the optimizer makes of this body)
@@ -414,6 +563,9 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
                  "s"(F.slabs.seg[1].stride), "s"(F.slabs.seg[1].n), "s"(F.slabs.seg[1].n_slabs), "s"(F.slabs.seg[1].block0));
     // the launch number the bundle's folded constants are tagged with (naf_gemm_bn2bwd_t.epoch): a new one for the next update
     if (F.fold_flag && block == 0 && tid == 64) *F.fold_flag += 1;
+    float4 ex_a = make_float4(0.f, 0.f, 0.f, 0.f);          // merge: this thread's float4 of a slab segment and its flat offset
+    size_t ex_o = 0;
+    bool ex_on = false;
     if (block >= F.slabs.n_finish_blocks) {
         const int rbk = block - F.slabs.n_finish_blocks;
         const BbSlabSeg& sg = (F.slabs.n_seg > 1 && rbk >= F.slabs.seg[1].block0) ? F.slabs.seg[1] : F.slabs.seg[0];
@@ -435,10 +587,16 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
                 const uint64_t e = F.push.ctrl[0] + 1;           // the epoch of the all-reduce launch that follows
                 const size_t o = (size_t)(sg.dst - F.grad_base) + (size_t)i;
                 const xg_f4 v = {a.x, a.y, a.z, a.w};
+                ex_a = a; ex_o = o; ex_on = true;
+                // (merge: the flags go up inside THIS launch, with no launch boundary in between to write the L2 back — where a
+                //  peer's slab is mapped cacheable, as with several ranks on one GPU, the stores must be written through themselves)
 #pragma unroll
                 for (int p = 0; p < NAF_XGMI_MAX_WORLD; ++p)
-                    if (p < F.push.world)
-                        *(xg_f4*)(xg_slot((char*)F.push.peer_base[p], F.push.data_off, F.push.n_pad, F.push.world, e, F.push.rank) + o) = v;
+                    if (p < F.push.world) {
+                        float* sl = xg_slot((char*)F.push.peer_base[p], F.push.data_off, F.push.n_pad, F.push.world, e, F.push.rank) + o;
+                        if (F.merge) bb_push_st(sl, v);
+                        else *(xg_f4*)sl = v;
+                    }
             }
         }
         // Every pushing wave waits until its stores to the peers' (uncached) slabs are acknowledged; no release fence: the flags
@@ -493,21 +651,25 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
                     const float invB = 1.0f / (float)F.B;
                     const float Pt = sP[cl][0][k] + sP[cl][1][k];
                     const float g = (gm * invstd) * (Pt - (sdy * invB) * sxk - (sdx * invB) * (invstd * wck));
-                    F.d_W[(int64_t)col * F.K + k] = g;
+                    bb_st(F.d_W + (int64_t)col * F.K + k, g, F.merge);
                     sq = g * g;
                 } else if (lane == 32) {                      // F.d_gamma = sum dy*xhat, F.d_beta = sum dy; F.d_bias = 0 (see above)
-                    F.d_gamma[col] = sdx;
-                    F.d_beta[col] = sdy;
-                    F.d_bias[col] = 0.f;
+                    bb_st(F.d_gamma + col, sdx, F.merge);
+                    bb_st(F.d_beta + col, sdy, F.merge);
+                    bb_st(F.d_bias + col, 0.f, F.merge);
                     sq = sdx * sdx + sdy * sdy;
                 }
             } else if (lane == 0) {
-                F.d_bias2[col] = db2;
+                bb_st(F.d_bias2 + col, db2, F.merge);
                 sq = db2 * db2;
             } else if (lane == 1) {
                 sq = g2 * g2 + b2 * b2;
             }
         }
+    }
+    if (F.merge) {
+        bb_finish_exchange(F, block, tid, ex_a, ex_o, ex_on, sQ);
+        return;
     }
     if (F.sumsq_partials) {
         const float tot = block_sum_to_thread0<BB_THREADS, true>(sq, sQ, tid);
@@ -1603,8 +1765,11 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
                                         float* d_W, float* d_gamma, float* d_beta, float* d_bias, float* d_bias2,
                                         const float* d_gamma2, const float* d_beta2, float* sumsq_partials, int32_t* step_dev,
                                         int B, int H, const naf_bb_slab_seg_t* segs, int n_segs, int* fold_flag,
-                                        const naf_xgmi_push_t* push, const float* grad_base, void* stream) {
+                                        const naf_xgmi_push_t* push, const float* grad_base, size_t merge_total, void* stream) {
     if ((push != nullptr) != (grad_base != nullptr)) return NAF_ERR_ARG;
+    if (merge_total && (!push || n_segs != 2 || (merge_total & 3) || merge_total > push->n_pad || !sumsq_partials || !step_dev ||
+                        !(push->timeout_ticks > 0)))
+        return NAF_ERR_ARG;
     if (push && (push->world < 2 || push->world > NAF_XGMI_MAX_WORLD || ((uintptr_t)grad_base & 15))) return NAF_ERR_ARG;
     if (!p_slabs || !partials1 || (nb > 0 && !dz2_col_partials) || !mom || !wc || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
         !d_bias || !d_bias2 || nb < 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
@@ -1639,6 +1804,19 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
                 return NAF_ERR_ARG;
         F.push = *push;
         F.grad_base = grad_base;
+        if (merge_total) {
+            // what no slab workgroup covers: the flat gradient minus the two segments — [0, first), [first end, second) (and nothing
+            // behind the second: it ends the buffer) — float4 ranges small enough for one workgroup
+            size_t o[2] = {(size_t)(segs[0].dst - grad_base), (size_t)(segs[1].dst - grad_base)};
+            int first = o[0] <= o[1] ? 0 : 1, second = 1 - first;
+            if (o[second] + (size_t)segs[second].n != merge_total || o[first] + (size_t)segs[first].n > o[second]) return NAF_ERR_ARG;
+            F.r_lo[0] = 0; F.r_hi[0] = o[first];
+            F.r_lo[1] = o[first] + (size_t)segs[first].n; F.r_hi[1] = o[second];
+            if ((F.r_hi[0] & 3) || (F.r_lo[1] & 3) || (F.r_hi[1] & 3) ||
+                ((F.r_hi[0] - F.r_lo[0]) + (F.r_hi[1] - F.r_lo[1])) > (size_t)BB_EX_SMALL * BB_THREADS * 4)
+                return NAF_ERR_ARG;
+            F.merge = 1;
+        }
     }
     bb_layer1_bwd_finish_kernel<<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
     NAF_CHECK_LAUNCH();

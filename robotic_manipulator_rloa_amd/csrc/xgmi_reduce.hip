@@ -243,6 +243,8 @@ static void xg_fill_desc(const XgmiComm* c, naf_xgmi_push_t* d) {
     d->n_pad = c->n_pad;
     d->rank = c->rank;
     d->world = c->world;
+    d->timeout_ticks = c->timeout_ticks;
+    d->host_timeouts = c->host_timeouts;
 }
 
 extern "C" int naf_xgmi_push_desc(void* handle, naf_xgmi_push_t* out) {

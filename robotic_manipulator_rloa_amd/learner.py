@@ -238,12 +238,22 @@ class Learner:
         # ring + the grad-norm launch when every rank could map every peer and the exact self-test passed on all of
         # them; otherwise (or with NAF_XGMI=0) the RCCL all-reduce below stays. try_create is collective.
         self.xgmi = None
+        self.xgmi_merged = False
         self._push_desc = None
         if self.world_size > 1 and os.environ.get("NAF_XGMI", "1") != "0":
             self.xgmi = XgmiAllReduce.try_create(P, dev, self.pg)
             if self.xgmi is not None:
                 self.n_partials = self.xgmi.n_partials
-        self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm, self.n_partials), **f32)
+                # row-split chain, NAF_XGMI_MERGE=1: the exchange happens INSIDE the finish launch (csrc/big_batch.hip,
+                # bb_finish_exchange): no all-reduce launch, the finish launch's workgroups leave the reduced gradient's norm
+                # partials — five launches per update as on one GPU. Built and verified in round 4 (W = 2 / 4 on one GPU: the
+                # rank-ordered sum bit for bit, replicas identical, no time-out) and measured SLOWER there than the all-reduce as a
+                # launch of its own (61.8 against 48.1 us per update at W = 2; the merged launch serialises a release, the small
+                # ranges' push and the flags behind its last workgroup): opt-in until a multi-GPU box has timed both over xGMI.
+                self.xgmi_merged = "bb" in self.fuse and os.environ.get("NAF_XGMI_MERGE", "0") == "1"
+                if self.xgmi_merged:
+                    self.n_partials = self.n_partials_fold + 1      # (+ the layer-1 / BatchNorm ranges' entry of the last workgroup)
+        self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm, self.n_partials) + 1, **f32)
         # the optimizer step of update k carried by the first two launches of update k + 1 (csrc/adam_body.h): the row-split
         # chain on one rank, gradient norm folded into the producers. NAF_DEFER_ADAM=0 keeps the launch of its own.
         # Data parallel over peer memory: the one-shot all-reduce launch leaves the norm partials and the step count exactly
@@ -547,8 +557,10 @@ class Learner:
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
             if self.xgmi is not None:
                 # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
-                self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=self._pushed_lo,
-                                     pushed_also=self._pushed_also)
+                # (merged: the finish launch of the row-split chain has done all of that already)
+                if not (self.xgmi_merged and "bb" in self.fuse):
+                    self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=self._pushed_lo,
+                                         pushed_also=self._pushed_also)
                 if not defer:
                     self.optimizer_step(norm_ready=True)
                 return
@@ -588,19 +600,25 @@ class Learner:
         # the workgroups that add the slabs of dW2 and dWh (91 % of the flat gradient) store them to the peers as well, so the
         # all-reduce launch behind this one sends only the layer-1 / BatchNorm segments before it raises its flags
         push = None
+        merged = False
         if self.xgmi is not None and seg["Wh"].offset + seg["Wh"].numel == P:      # (Wh ends the buffer: no pad behind it)
             if self._push_desc is None:
                 self._push_desc = self.xgmi.push_desc()
             push = _lib.C.byref(self._push_desc)
             self._pushed_lo = seg["Wh"].offset                                         # Wh is the last segment: [Wh, P)
             self._pushed_also = (seg["W2"].offset, seg["W2"].offset + H * H)
+            merged = self.xgmi_merged
+        elif self.xgmi_merged:
+            raise _lib.NafHipError("merged gradient exchange: the flat layout must end with the Wh segment")
+        norm_here = self.fold_norm or merged
         check(f.naf_bb_layer1_bwd_finish(
             ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), B // 32, None, 0,
             ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
             gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
             gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
-            ptr(self.partials) if self.fold_norm else None, ptr(self.step_dev) if self.fold_norm else None, B, H,
-            self._bb_segs, self._bb_nsegs, ptr(self.bb_fold_flag), push, gp if push is not None else None, st), "bb_layer1_bwd_finish")
+            ptr(self.partials) if norm_here else None, ptr(self.step_dev) if norm_here else None, B, H,
+            self._bb_segs, self._bb_nsegs, ptr(self.bb_fold_flag), push, gp if push is not None else None, P if merged else 0, st),
+            "bb_layer1_bwd_finish")
 
     def _learn_rows_tiles(self, rows: torch.Tensor, lp) -> None:
         """The column-tile chain (csrc/fused_layers.hip) and the unfused chain (torch GEMMs + csrc/bn_relu.hip), by `fuse`."""

@@ -394,13 +394,15 @@ def test_host_vector_env_training_end_to_end(scratch_cwd, async_policy):
         vec.close()
 
 
-@pytest.mark.parametrize("world,fuse", [(2, "columns"), (4, None)])
-def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse):
+@pytest.mark.parametrize("world,fuse,merge", [(2, "columns", "1"), (4, None, "1"), (2, None, "1"), (2, None, "0")])
+def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse, merge):
     """csrc/xgmi_reduce.hip with W > 1 on the one GPU available: W processes on cuda:0 (tests/xgmi_worker.py) map each
     other's receive slabs through hipIpc and run the one-shot all-reduce eagerly, inside a captured graph and under
     Learner.learn_rows — results bit-exact against the rank-ordered sum, replicas in lock-step, no timed-out wait.
-    Two ranks on the column-tile chain (part of the gradient pushed ahead from inside its last kernel), four on the default
-    chain of B = 256 (the row-split one: its finish launch pushes the two weight-gradient segments ahead)."""
+    Two ranks on the column-tile chain (part of the gradient pushed ahead from inside its last kernel, the all-reduce a launch of
+    its own), four and two on the default chain of B = 256 (the row-split one: the WHOLE exchange inside its finish launch, round 4
+    — five launches per update as on one GPU), two on the same chain with NAF_XGMI_MERGE=0 (round 3's form: the finish launch
+    pushes the two weight-gradient segments, the all-reduce launch behind it the rest)."""
     import socket
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -408,6 +410,7 @@ def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse):
     env = dict(os.environ, NAF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                OMP_NUM_THREADS="2")
     env.pop("NAF_FUSE", None)
+    env["NAF_XGMI_MERGE"] = merge
     if fuse:
         env["NAF_FUSE"] = fuse
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",

@@ -188,7 +188,32 @@ def main():
         os.environ["NAF_XGMI"] = mode
         L, buf = _kuka_learner_and_replay(5000, 256, seed_data=5 + rank, learner_kw={"world_size": world})
         assert (L.xgmi is not None) == (mode == "1")
-        if mode == "1":
+        if mode == "1" and L.xgmi_merged:
+            # (a') the exchange INSIDE the finish launch of the row-split chain (round 4: no all-reduce launch to spy on). What the
+            #      rank put in is what a twin learner without an exchange (world 1, same weights, same rows: the same kernels, bit
+            #      for bit) leaves in its gradient buffer; what leaves learn_rows() must be the rank-ordered sum of those, and the
+            #      partials the sum-of-squares of that sum
+            assert "bb" in L.fuse and L.n_partials == L.n_partials_fold + 1
+            twin, _ = _kuka_learner_and_replay(8, 256, seed_data=5 + rank, learner_kw={"world_size": 1})
+            state = [t.clone() for t in (L.theta2, L.adam_m, L.adam_v, L.bn_stats, L.step_dev)]
+            rows = buf.rows[:256]
+            twin.learn_rows(rows)
+            L.learn_rows(rows)
+            torch.cuda.synchronize()
+            mine = twin.grad.cpu()
+            allg = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allg, mine)
+            want = allg[0].clone()
+            for other in allg[1:]:
+                want = want + other
+            assert torch.equal(L.grad.cpu(), want), f"{(L.grad.cpu() != want).sum().item()} elements differ from the rank-ordered sum"
+            ss = (want.double() ** 2).sum().item()
+            assert abs(L.partials[:L.n_partials].double().sum().item() - ss) < 1e-5 * ss
+            assert int(L.step_dev.item()) == 1 and L.xgmi.status()[1] == 0
+            for t, saved in zip((L.theta2, L.adam_m, L.adam_v, L.bn_stats, L.step_dev), state):
+                t.copy_(saved)
+            del twin
+        elif mode == "1":
             # (a) the exchange as learn_rows() issues it, eagerly: what leaves it must be the rank-ordered sum of what
             #     every rank put in, bit for bit
             seen = []
