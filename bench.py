@@ -235,6 +235,8 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "chain": L.chain, "fused_kernels": ",".join(sorted(L.fuse)),
                    "grad_exchange": ("none" if world == 1 else
+                                     "one-shot peer-memory exchange inside the finish launch (csrc/big_batch.hip, NAF_XGMI_MERGE=1)"
+                                     if getattr(L, "xgmi_merged", False) else
                                      "one-shot peer-memory all-reduce over xGMI (csrc/xgmi_reduce.hip)" if L.xgmi is not None
                                      else "RCCL all-reduce")},
         "updates_per_s": round(updates / elapsed, 1),

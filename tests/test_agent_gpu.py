@@ -539,20 +539,27 @@ def test_bench_gpus2_launches_its_own_ranks():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the gpurun box has one)")
-@pytest.mark.parametrize("xgmi", ["1", "0"])
-def test_bench_two_real_gpus_rccl_and_oneshot(xgmi):
-    """Two ranks on two DISTINCT devices: RCCL (NAF_XGMI=0) and the one-shot peer-memory exchange (default) each move
-    the gradient between devices; replicas stay bit-identical, no wait times out, RCCL saw two ranks."""
+@pytest.mark.parametrize("xgmi,merge", [("1", "0"), ("1", "1"), ("0", "0")])
+def test_bench_two_real_gpus_rccl_and_oneshot(xgmi, merge, capsys):
+    """Two ranks on two DISTINCT devices: RCCL (NAF_XGMI=0), the one-shot peer-memory exchange as a launch of its own (default) and
+    inside the finish launch (NAF_XGMI_MERGE=1) each move the gradient between devices; replicas stay bit-identical, no wait times
+    out, RCCL saw two ranks. Prints the env-steps/s of each: the first numbers over real xGMI (which of the two one-shot forms
+    should be the default is decided here)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
                                                             "NAF_BENCH_REHEARSAL")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", NAF_XGMI=xgmi)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", NAF_XGMI=xgmi, NAF_XGMI_MERGE=merge)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
                         "--buffer", "100000", "--roofline-ring", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and "REHEARSAL" not in out["config"]["launch"]
     assert out["sanity"]["replicas_identical"] is True and out["sanity"]["params_finite"]
-    if xgmi == "1" and "one-shot" in out["config"]["grad_exchange"]:
+    with capsys.disabled():
+        print(f"\n[two GPUs] NAF_XGMI={xgmi} NAF_XGMI_MERGE={merge}: {out['value']} env-steps/s, {out['us_per_update']} us per update "
+              f"({out['config']['grad_exchange']})")
+    if xgmi == "1" and merge == "1" and "one-shot" in out["config"]["grad_exchange"]:
+        assert out["sanity"]["xgmi_timed_out_waits"] == 0
+    elif xgmi == "1" and "one-shot" in out["config"]["grad_exchange"]:
         assert out["sanity"]["xgmi_timed_out_waits"] == 0 and out["sanity"]["xgmi_allreduces"] >= 23 * 64
     else:
         assert out["config"]["grad_exchange"] == "RCCL all-reduce"
