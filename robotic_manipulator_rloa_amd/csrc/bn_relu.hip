@@ -141,6 +141,102 @@ __global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_kernel(
     }
 }
 
+// ---- any batch size: the same tile with the rows STREAMED instead of held (B > 2048) ------------------------------------------------
+// The reference takes any positive batch_size (rl_framework.py:186-189). Beyond 16 rows per thread the register-resident kernels
+// above would spill, so these read the matrix once per pass — column sums; squared deviations from the mean (the two-pass variance
+// of the kernels above, same order of the partial sums per thread); normalise — from L2 / the Infinity Cache (a 4096 x 256 f32
+// matrix is 4 MB). Slower per row (three reads instead of one) and only ever used where nothing else fits.
+template <int BN_TX, int BN_TY>
+__global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_fwd_train_stream_kernel(
+    const float* __restrict__ g, int64_t g_net_stride, int ldg, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int64_t param_net_stride,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t stat_net_stride, float* __restrict__ out,
+    int64_t out_net_stride, int ldo, float* __restrict__ save_mean, float* __restrict__ save_invstd, int B, int H,
+    float momentum, float eps) {
+    __shared__ float red[BN_TX * BN_TY / 64][BN_TX + 1];
+    __shared__ float redv[BN_TX * BN_TY / 64][BN_TX + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = naf_xcd_tile(blockIdx.x, gridDim.x) * BN_TX + tx;
+    const int net = blockIdx.y;
+    const bool col_on = col < H;
+    const int colc = col_on ? col : H - 1;
+    const float* gz = g + net * g_net_stride;
+    float* oz = out + net * out_net_stride;
+    const int64_t po = net * param_net_stride;
+    const float b = (bias && col_on) ? bias[po + col] : 0.f;
+    const float gm = col_on ? gamma[po + col] : 0.f;
+    const float bt = col_on ? beta[po + col] : 0.f;
+    const int64_t so = net * stat_net_stride + col;
+    const float rm_old = (ty == 0 && col_on) ? running_mean[so] : 0.f;
+    const float rv_old = (ty == 0 && col_on) ? running_var[so] : 0.f;
+    float sum = 0.f;
+    for (int row = ty; row < B; row += BN_TY) sum += col_on ? gz[(int64_t)row * ldg + colc] + b : 0.f;
+    const float mean = bn_col_reduce<BN_TX, BN_TY, true>(sum, red, tx, ty) / (float)B;
+    float ss = 0.f;
+    for (int row = ty; row < B; row += BN_TY) {
+        const float dlt = col_on ? (gz[(int64_t)row * ldg + colc] + b) - mean : 0.f;
+        ss += dlt * dlt;
+    }
+    const float var = bn_col_reduce<BN_TX, BN_TY, true>(ss, redv, tx, ty) / (float)B;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    if (col_on)
+        for (int row = ty; row < B; row += BN_TY) {
+            const float y = ((gz[(int64_t)row * ldg + col] + b) - mean) * invstd * gm + bt;
+            oz[(int64_t)row * ldo + col] = y > 0.f ? y : 0.f;
+        }
+    if (ty == 0 && col_on) {
+        const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
+        running_mean[so] = (1.0f - momentum) * rm_old + momentum * mean;
+        running_var[so] = (1.0f - momentum) * rv_old + momentum * unbiased;
+        save_mean[(int64_t)net * H + col] = mean;
+        save_invstd[(int64_t)net * H + col] = invstd;
+    }
+}
+
+template <int BN_TX, int BN_TY>
+__global__ __launch_bounds__(BN_TX* BN_TY) void bn_relu_bwd_stream_kernel(
+    const float* __restrict__ d_out, int ld_dout, const float* __restrict__ g, int ldg, const float* __restrict__ bias,
+    const float* __restrict__ out, int ldo, const float* __restrict__ gamma, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, float* __restrict__ d_z, int ldd, float* __restrict__ d_gamma,
+    float* __restrict__ d_beta, float* __restrict__ d_bias, int B, int H) {
+    __shared__ float red[BN_TX * BN_TY / 64][BN_TX + 1];
+    __shared__ float red2[BN_TX * BN_TY / 64][BN_TX + 1];
+    __shared__ float red3[BN_TX * BN_TY / 64][BN_TX + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = naf_xcd_tile(blockIdx.x, gridDim.x) * BN_TX + tx;
+    const bool col_on = col < H;
+    const int colc = col_on ? col : H - 1;
+    const float b = (bias && col_on) ? bias[col] : 0.f;
+    const float mean = col_on ? save_mean[col] : 0.f;
+    const float invstd = col_on ? save_invstd[col] : 0.f;
+    const float gm = col_on ? gamma[col] : 0.f;
+    float s_dy = 0.f, s_dyxh = 0.f;
+    for (int row = ty; row < B; row += BN_TY) {
+        const float z = g[(int64_t)row * ldg + colc] + b, o = out[(int64_t)row * ldo + colc], dd = d_out[(int64_t)row * ld_dout + colc];
+        const float dy = (col_on && o > 0.f) ? dd : 0.f;
+        s_dy += dy;
+        s_dyxh += dy * ((z - mean) * invstd);
+    }
+    float dbeta, dgamma;
+    bn_col_reduce2<BN_TX, BN_TY, true>(s_dy, s_dyxh, red, red2, tx, ty, &dbeta, &dgamma);
+    const float invB = 1.0f / (float)B, k1 = gm * invstd;
+    float s_dz = 0.f;
+    if (col_on)
+        for (int row = ty; row < B; row += BN_TY) {
+            const float z = g[(int64_t)row * ldg + col] + b, o = out[(int64_t)row * ldo + col], dd = d_out[(int64_t)row * ld_dout + col];
+            const float dy = o > 0.f ? dd : 0.f, xh = (z - mean) * invstd;
+            const float dz = k1 * (dy - dbeta * invB - xh * (dgamma * invB));
+            d_z[(int64_t)row * ldd + col] = dz;
+            s_dz += dz;
+        }
+    const float dbias = bn_col_reduce<BN_TX, BN_TY, true>(s_dz, red3, tx, ty);
+    if (ty == 0 && col_on) {
+        d_gamma[col] = dgamma;
+        d_beta[col] = dbeta;
+        if (d_bias) d_bias[col] = dbias;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_relu_fwd_eval_kernel(const float* __restrict__ g, int ldg,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ gamma,
@@ -186,9 +282,17 @@ extern "C" int naf_bn_relu_fwd_train(const float* g, int64_t g_net_stride, int l
                                      int64_t out_net_stride, int ldo, float* save_mean, float* save_invstd, int B, int H,
                                      int nets, float momentum, float eps, void* stream) {
     if (!g || !gamma || !beta || !running_mean || !running_var || !out || !save_mean || !save_invstd) return NAF_ERR_ARG;
-    if (B <= 0 || B > BN_MAX_B || H <= 0 || nets <= 0 || ldg < H || ldo < H) return NAF_ERR_ARG;
+    if (B <= 0 || H <= 0 || nets <= 0 || ldg < H || ldo < H) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nets_ = nets;
+    if (B > BN_MAX_B) {                         // any batch size: the streamed form
+        dim3 grid((H + 7) / 8, nets), block(8, 128);
+        bn_relu_fwd_train_stream_kernel<8, 128><<<grid, block, 0, st>>>(g, g_net_stride, ldg, bias, gamma, beta, param_net_stride,
+                                                                          running_mean, running_var, stat_net_stride, out, out_net_stride,
+                                                                          ldo, save_mean, save_invstd, B, H, momentum, eps);
+        NAF_CHECK_LAUNCH();
+        return NAF_OK;
+    }
     BN_DISPATCH(bn_relu_fwd_train_kernel, g, g_net_stride, ldg, bias, gamma, beta, param_net_stride, running_mean,
                 running_var, stat_net_stride, out, out_net_stride, ldo, save_mean, save_invstd, B, H, momentum, eps);
     NAF_CHECK_LAUNCH();
@@ -200,9 +304,16 @@ extern "C" int naf_bn_relu_bwd(const float* d_out, int ld_dout, const float* g, 
                                const float* save_invstd, float* d_z, int ldd, float* d_gamma, float* d_beta,
                                float* d_bias, int B, int H, void* stream) {
     if (!d_out || !g || !out || !gamma || !save_mean || !save_invstd || !d_z || !d_gamma || !d_beta) return NAF_ERR_ARG;
-    if (B <= 0 || B > BN_MAX_B || H <= 0 || ld_dout < H || ldg < H || ldo < H || ldd < H) return NAF_ERR_ARG;
+    if (B <= 0 || H <= 0 || ld_dout < H || ldg < H || ldo < H || ldd < H) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nets_ = 1;
+    if (B > BN_MAX_B) {
+        dim3 grid((H + 7) / 8, 1), block(8, 128);
+        bn_relu_bwd_stream_kernel<8, 128><<<grid, block, 0, st>>>(d_out, ld_dout, g, ldg, bias, out, ldo, gamma, save_mean, save_invstd,
+                                                                   d_z, ldd, d_gamma, d_beta, d_bias, B, H);
+        NAF_CHECK_LAUNCH();
+        return NAF_OK;
+    }
     BN_DISPATCH(bn_relu_bwd_kernel, d_out, ld_dout, g, ldg, bias, out, ldo, gamma, save_mean, save_invstd, d_z, ldd,
                 d_gamma, d_beta, d_bias, B, H);
     NAF_CHECK_LAUNCH();

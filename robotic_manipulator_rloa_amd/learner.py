@@ -174,8 +174,12 @@ class Learner:
         #              launches per update (round 1's chain: 12.7k updates/s at B = 1024).
         # NAF_FUSE = rows | columns | unfused overrides the choice (a chain whose shape limits are not met falls to the next).
         lay0 = self.lay
-        if self.B > 2048:
-            raise ValueError(f"batch_size {self.B}: the BatchNorm kernels keep at most 16 rows per thread (batch_size <= 2048)")
+        # The reference takes any positive batch_size (rl_framework.py:186-189). Here: every size up to 4096 trains — multiples of
+        # 64 up to 2048 on the row-split chain, other sizes up to 512 on the column-tile chain, everything else on the unfused chain
+        # (beyond 2048 with the streamed BatchNorm kernels of csrc/bn_relu.hip) with a warning that names the faster sizes. 4096 is
+        # the replay sampler's limit (one workgroup draws a minibatch without replacement in LDS, csrc/replay.hip).
+        if self.B < 1 or self.B > 4096:
+            raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 4096 (the sampler draws a minibatch in one workgroup's LDS)")
         self.bb_ok = (self.B % 64 == 0 and 64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
@@ -201,9 +205,10 @@ class Learner:
         if self.B > 512 and want != "rows":
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)
             import warnings
-            lo, hi = max(64, self.B // 64 * 64), min(2048, -(-self.B // 64) * 64)
+            lo, hi = min(2048, max(64, self.B // 64 * 64)), min(2048, -(-self.B // 64) * 64)
+            near = f"{lo}, {hi}" if lo != hi else f"{lo}"
             warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
-                          f"row-split chain): the row-split kernels need batch_size % 64 == 0 (nearest: {lo}, {hi}), 64 <= "
+                          f"row-split chain): the row-split kernels need batch_size % 64 == 0 (nearest: {near}), 64 <= "
                           f"batch_size <= 2048, layer_size 256 and state_size <= 26", stacklevel=3)
         # with every gradient element produced by one of our own kernels, those kernels also emit its sum-of-squares partial:
         # the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken on the all-reduced gradient).

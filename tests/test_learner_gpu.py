@@ -124,7 +124,8 @@ def test_learn_with_the_ring_form_of_the_backward_gemms_g3(tag, monkeypatch):
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32),
                                    (21, 6, 512), (32, 8, 512), (21, 6, 1024), (21, 6, 768), (21, 6, 320), (21, 6, 1536),
-                                   (23, 7, 1984), (21, 6, 1000), (21, 6, 1008), (21, 6, 64), (21, 6, 128), (21, 6, 192)])
+                                   (23, 7, 1984), (21, 6, 1000), (21, 6, 1008), (21, 6, 64), (21, 6, 128), (21, 6, 192),
+                                   (21, 6, 4096), (21, 6, 2500)])
 def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
     """20 updates against the f32 numpy oracle (Hadamard = reference semantics; matmul = textbook NAF), every chain at
     every shape it admits — including batch sizes that are multiples of 64 but not of 256 (K ranges of the weight
@@ -132,8 +133,10 @@ def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
     warning that names the nearest row-split sizes)."""
     monkeypatch.delenv("NAF_FUSE", raising=False)
     import warnings
-    if B in (1000, 1008, 1984) and fused in ("rows", "columns"):
+    if B in (1000, 1008, 1984, 4096, 2500) and fused in ("rows", "columns"):
         pytest.skip("same chain as default at this size")
+    if B > 2048 and fused == "unfused":
+        pytest.skip("the default at this size IS the unfused chain")
     from synth_data import make_transitions
     g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
     n_upd = 20
@@ -163,6 +166,8 @@ def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
         assert any("nearest" in str(w.message) for w in caught), "the unfused chain beyond B = 512 must say so"
         if B == 1000:
             assert any("960, 1024" in str(w.message) for w in caught)
+        if B > 2048:      # beyond the row-split chain's sizes: the streamed BatchNorm kernels, any batch size up to the sampler's 4096
+            assert L.chain == "unfused" and any("nearest: 2048)" in str(w.message) for w in caught)
     else:
         assert not caught
     Or = O.LearnerOracle(sd, p_mode=p_mode, dtype=np.float32)
