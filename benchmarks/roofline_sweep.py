@@ -41,6 +41,22 @@ for M in (256, 16384, 65536, 1 << 20, 1 << 22, 1 << 24):
     del idx, out
 del buf
 torch.cuda.empty_cache()
+# the same bulk launch on a ring 16 x the 256-MiB Infinity Cache (16e6 rows = 3.8 GiB): at most 1 / 16 of the row fetches can be
+# LLC hits — the HBM-only figure beside the workload's (configs[4]'s 4e6-row ring, where up to a quarter can)
+N = 16_000_000
+buf = ReplayBuffer(N, 256, dev, 0, state_size=21, action_size=6)
+for lo in range(0, N, 1 << 20):
+    n = min(1 << 20, N - lo)
+    buf.add_rows_device(torch.randn(n, 64, device=dev), n)
+for M in (1 << 22, 1 << 24):
+    idx = torch.randint(0, N, (M,), device=dev, dtype=torch.int32)
+    out = torch.empty(M, buf.batch_row_floats, device=dev)
+    t = timed(lambda: buf.gather_rows(idx, out, M), 10)
+    alg = M * 404
+    print(f"| replay_gather_rows (ring 16e6 rows = 3.8 GiB) | {M} rows | {alg/1e6:.2f} MB | {t*1e6:.1f} us | {alg/t/1e9:.0f} GB/s | {alg/t/8e12:.3f} |")
+    del idx, out
+del buf
+torch.cuda.empty_cache()
 P = NetLayout(21, 6, 256).P
 for R in (1, 64, 1024):
     n = P * R
