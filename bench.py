@@ -269,7 +269,15 @@ def main():
             far = bulk_gather_roofline(S, A, args.roofline_hbm_ring, args.roofline_rows, dev, row_alg)
             out["roofline"]["hbm_only_frac"] = far["frac"]
             out["roofline"]["hbm_only"] = {k: far[k] for k in ("achieved", "avg_launch_ms", "ring_rows", "ring_bytes",
-                                                                "infinity_cache_share", "physical_GBps", "bad_indices")}
+                                                                "infinity_cache_share", "physical_GBps", "bad_indices", "traffic")}
+            # both measurements launch the same kernel instance the same number of times (3 warm-up + 20 timed each): a
+            # rocprofv3 --kernel-trace --stats summary of this command averages the two populations under ONE name
+            near, n_each = out["roofline"], 3 + out["roofline"]["launches_timed"]
+            out["roofline"]["kernel_stats_check"] = {
+                "calls": 2 * n_each, "expected_avg_ms": round((near["avg_launch_ms"] + far["avg_launch_ms"]) / 2, 5),
+                "what": "the stats file's average for this kernel instance = the mean of `avg_launch_ms` (ring of "
+                        f"{near['ring_rows']} rows) and `hbm_only.avg_launch_ms` (ring of {far['ring_rows']} rows), {n_each} launches "
+                        "each; its MinDuration belongs to the smaller ring"}
     # the launch that sits in the timed loop (one per vector step, U*B rows): latency, not bandwidth — reported as the
     # RAW event bracket (an empty bracket reads ~5 us on this stream, so this overstates the kernel; the profiler's
     # kernel-trace average is the number to quote for it)
