@@ -169,6 +169,9 @@ class TrainChunk:
         if self.head_row is not None:
             if self.use_graph and self.graph is None:
                 self.capture()
+            # the previous run's append node must have read its count before the word changes (an idle tick right behind a
+            # step() would otherwise zero the count of a row the GPU has not appended yet); in run()'s loop act() has waited
+            self.wait_pinned_free()
             self.head_count[0] = 1 if head_rows else 0
         if self.use_graph:
             if self.graph is None:
