@@ -18,7 +18,7 @@ stats)     # rocprofv3 kernel-trace stats + digest of the bench at configs[1] an
 small)     # small batches: configs[0]'s batch and the reference's default (row-split chain), and B = 96 (column-tile chain)
   benchmarks/prof_bench.sh r04_b64 300 40 --batch 64 --buffer 100000 > gpurun_out/prof_b64.log 2>&1; tail -2 gpurun_out/prof_b64.log
   benchmarks/prof_bench.sh r04_b128 300 40 --batch 128 --buffer 100000 > gpurun_out/prof_b128.log 2>&1; tail -2 gpurun_out/prof_b128.log
-  benchmarks/prof_bench.sh r04_b96 300 40 --batch 96 --buffer 100000 > gpurun_out/prof_b96.log 2>&1; tail -2 gpurun_out/prof_b96.log ;;
+  benchmarks/prof_bench.sh r04_b100 300 40 --batch 100 --buffer 100000 > gpurun_out/prof_b100.log 2>&1; tail -2 gpurun_out/prof_b100.log ;;
 sweep)     # SURVEY 8d bulk sweep of the streaming kernels, HIP events (the table) AND rocprofv3 kernel stats of the same process
   d=/tmp/prof_sweep; rm -rf $d
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r04_sweep -- python3 benchmarks/roofline_sweep.py > gpurun_out/r04_roofline_sweep.md 2> gpurun_out/sweep.err

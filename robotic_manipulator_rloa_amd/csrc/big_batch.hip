@@ -48,10 +48,13 @@ __device__ static inline void bb_fold_stats(const float2* __restrict__ p, int H,
     for (int rb = 0; rb < BB_MAX_NB; ++rb) S += rb < NB ? v[rb].x : 0.f;
     const float m = S / (float)B;
     float M2 = 0.f;
+    // (the last block holds B - 64 (NB - 1) rows: 64 where the batch is whole blocks — then this is the arithmetic it always was)
+    const float n_last = (float)(B - BB_ROWS * (NB - 1)), inv_last = 1.0f / n_last;
 #pragma unroll
     for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-        const float d = v[rb].x * (1.0f / BB_ROWS) - m;
-        M2 += rb < NB ? v[rb].y + (float)BB_ROWS * d * d : 0.f;
+        const bool lastb = rb == NB - 1;
+        const float d = v[rb].x * (lastb ? inv_last : 1.0f / BB_ROWS) - m;
+        M2 += rb < NB ? v[rb].y + (lastb ? n_last : (float)BB_ROWS) * d * d : 0.f;
     }
     *mean = m;
     *var = M2 / (float)B;      // biased: what normalises
@@ -72,10 +75,12 @@ __device__ __forceinline__ static void bb_fold_stats_n(__amdgpu_buffer_rsrc_t p,
     for (int rb = 0; rb < NMAX; ++rb) S += rb < NB ? v[rb].x : 0.f;
     const float m = S / (float)B;
     float M2 = 0.f;
+    const float n_last = (float)(B - BB_ROWS * (NB - 1)), inv_last = 1.0f / n_last;      // (see bb_fold_stats)
 #pragma unroll
     for (int rb = 0; rb < NMAX; ++rb) {
-        const float d = v[rb].x * (1.0f / BB_ROWS) - m;
-        M2 += rb < NB ? v[rb].y + (float)BB_ROWS * d * d : 0.f;
+        const bool lastb = rb == NB - 1;
+        const float d = v[rb].x * (lastb ? inv_last : 1.0f / BB_ROWS) - m;
+        M2 += rb < NB ? v[rb].y + (lastb ? n_last : (float)BB_ROWS) * d * d : 0.f;
     }
     *mean = m;
     *var = M2 / (float)B;
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
         NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, 12, ra == 0, ra == n_adam - 1);
         return;
     }
-    const int gx = B / BB_ROWS, gy = H / BB_COLS;
+    const int gx = (B + BB_ROWS - 1) / BB_ROWS, gy = H / BB_COLS;
     int rb = widx % gx, ct_ = (widx / gx) % gy, net = widx / (gx * gy);
     if (xcd_rows && n_main == 2 * gx * gy) bb_place_rows(widx, n_ride, gx, gy, net, rb, ct_);
     const int col0 = ct_ * BB_COLS;
@@ -766,6 +771,9 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
 #define L1_TL(slot) NAF_TL_FL(g_tl_bb, NAF_TL_BB_LAYER1, slot, widx == 0, widx == n_main - 1)
     L1_TL(0);
     const float* xn = x + net * x_net_stride + (int64_t)rb * BB_ROWS * ldx;
+    // rows of this block that exist (the last block of a batch that is not whole 64-row blocks holds fewer): rows past them are
+    // read as copies of row 0 and never stored (the output resources end at the last row that exists)
+    const int valid = B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS;
     // ADAM: the workgroup has 512 threads. Threads 0 .. 255 are the layer-1 workgroup as ever; ALL 512 take part in evaluating
     // the parameters as the pending step leaves them (one float4 = four elements per thread: the update formula is ~100
     // instructions per element — a division and a square root, correctly rounded), then waves 4 .. 7 are done.
@@ -784,7 +792,7 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
         for (int i = 0; i < XN; ++i) {
             const int e = tid + BB_THREADS * i;
             const int row = e / K4, q = e - row * K4;
-            xv[i] = ((const f32x4*)(xn + (int64_t)(row < BB_ROWS ? row : 0) * ldx))[q];
+            xv[i] = ((const f32x4*)(xn + (int64_t)(row < valid ? row : 0) * ldx))[q];
         }
     }
     if (!ADAM) {
@@ -897,11 +905,12 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
                 xh4[j] = xh;
                 yp[j] = t > 0.f ? t : 0.f;
             }
-            naf_buf_st_f4(naf_buf(oz + (int64_t)(rb * BB_ROWS) * ldo + col0), 4u * (unsigned)((4 * ty_ + i) * ldo + 4 * tx_), 0,
+            const unsigned obytes = ((unsigned)(valid - 1) * (unsigned)ldo + BB_COLS) * 4u;
+            naf_buf_st_f4(naf_buf(oz + (int64_t)(rb * BB_ROWS) * ldo + col0, obytes), 4u * (unsigned)((4 * ty_ + i) * ldo + 4 * tx_), 0,
                           (f32x4){y.x, y.y, y.z, y.w}, B >= NAF_WT_MIN_B);
             // the main network's xhat too where the backward wants it ready-made (naf_gemm_l1bwd_t.xhat: small batches)
             if (xhat_out && net == 0)
-                naf_buf_st_f4(naf_buf(xhat_out + (int64_t)(rb * BB_ROWS) * ldo + col0), 4u * (unsigned)((4 * ty_ + i) * ldo + 4 * tx_), 0, xh4,
+                naf_buf_st_f4(naf_buf(xhat_out + (int64_t)(rb * BB_ROWS) * ldo + col0, obytes), 4u * (unsigned)((4 * ty_ + i) * ldo + 4 * tx_), 0, xh4,
                               B >= NAF_WT_MIN_B);
         }
     };
@@ -1085,9 +1094,12 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     }
     int bx = widx % gx, by = widx / gx;
 #define BL_TL(slot) NAF_TL_FL(g_tl_bb, NAF_TL_BB_LINEAR_STATS, slot, widx == 0, widx == n_main - 1)
-    const int NB = B / BB_ROWS;
+    const int NB = (B + BB_ROWS - 1) / BB_ROWS;
     int net = bx / NB, rb = bx - net * NB;
     if (xcd_nets && gx == 2 * NB) bb_place_rows(widx, 0, NB, n_main / gx, net, rb, by);     // rows by eighths (see bb_place_rows)
+    // rows of this block that exist (64 but for the last block of a batch that is not whole blocks, B % 16 == 0): rows past them
+    // read as zeros (the A resource ends there), are not stored (the Z resource ends there) and stay out of the statistics
+    const int valid = B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS;
     const int n0 = by * BL_BN;
     const float* an = a + net * a_net_stride + (int64_t)rb * BL_BM * lda;
     const float* wn_ = W + net * param_net_stride + (int64_t)n0 * K;     // [N][K] row-major
@@ -1105,7 +1117,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     // (all 24 loads up front made the register allocator park 12 of them in scratch)
     f32x4 va1[8], vb1[4];
     BL_TL(0);
-    const __amdgpu_buffer_rsrc_t ab = naf_buf(an), wb = naf_buf(wn_);
+    const __amdgpu_buffer_rsrc_t ab = naf_buf(an, (unsigned)valid * (unsigned)lda * 4u), wb = naf_buf(wn_);
     const unsigned la = ((unsigned)(tid >> 5) * (unsigned)lda + 4u * (unsigned)(tid & 31)) * 4u;
     const unsigned lw = ((unsigned)(tid >> 5) * (unsigned)K + 4u * (unsigned)(tid & 31)) * 4u;
     bl_load_chunk_buf(va, vb, ab, la, lda, wb, lw, K, 0);
@@ -1125,29 +1137,32 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
     float v[2][4];
     float s = 0.f;
-    const __amdgpu_buffer_rsrc_t zb_ = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM) * ldz + n0);
+    const __amdgpu_buffer_rsrc_t zb_ = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM) * ldz + n0,
+                                               ((unsigned)(valid - 1) * (unsigned)ldz + BL_BN) * 4u);
     const unsigned lz_ = 4u * (unsigned)((32 * wm + 4 * g) * ldz + 16 * wn + r);
+    bool on[2][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            on[mt][e] = 32 * wm + 16 * mt + 4 * g + e < valid;
             v[mt][e] = (mt ? c10[e] + c11[e] : c00[e] + c01[e]) + bcol;
             naf_buf_st_f1(zb_, lz_, (unsigned)((16 * mt + e) * ldz) * 4u, v[mt][e], B >= NAF_WT_MIN_B);
-            s += v[mt][e];
+            s += on[mt][e] ? v[mt][e] : 0.f;
         }
     // column statistics of the 64-row block: 8 rows in the lane, 4 lane groups (bits 4, 5), 2 waves (wm) through LDS
     s = naf_xor32_add(naf_xor16_add(s));
     if (g == 0) red[wm][16 * wn + r] = s;
     __syncthreads();
     const float S = red[0][16 * wn + r] + red[1][16 * wn + r];
-    const float mb = S * (1.0f / BB_ROWS);
+    const float mb = S * (valid == BB_ROWS ? 1.0f / BB_ROWS : 1.0f / (float)valid);
     float m2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float t = v[mt][e] - mb;
-            m2 += t * t;
+            m2 += on[mt][e] ? t * t : 0.f;
         }
     m2 = naf_xor32_add(naf_xor16_add(m2));
     __syncthreads();
@@ -1189,13 +1204,14 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
         return;
     }
     int bx = widx % gx, by = widx / gx;
-    const int NB = B / BB_ROWS;
+    const int NB = (B + BB_ROWS - 1) / BB_ROWS;
     int net = bx / NB, rb = bx - net * NB;
     if (xcd_nets && gx == 2 * NB) bb_place_rows(widx, 0, NB, n_main / gx, net, rb, by);     // rows by eighths (see bb_place_rows)
+    const int valid = B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS;              // (see bb_linear_stats_kernel)
     const int n0 = by * BN;
     const int r = lane & 15, g = lane >> 4;
     // operands through buffer loads (common.h): A rows (tid >> 5) + 8 i, float4 (tid & 31); B rows (tid >> 5) + 8 i < 16
-    const __amdgpu_buffer_rsrc_t ab = naf_buf(a + net * a_net_stride + (int64_t)rb * BL_BM * lda);
+    const __amdgpu_buffer_rsrc_t ab = naf_buf(a + net * a_net_stride + (int64_t)rb * BL_BM * lda, (unsigned)valid * (unsigned)lda * 4u);
     const __amdgpu_buffer_rsrc_t wb = naf_buf(W + net * param_net_stride + (int64_t)n0 * K);
     const unsigned la = ((unsigned)(tid >> 5) * (unsigned)lda + 4u * (unsigned)(tid & 31)) * 4u;
     const unsigned lw = ((unsigned)(tid >> 5) * (unsigned)K + 4u * (unsigned)(tid & 31)) * 4u;
@@ -1249,25 +1265,28 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     float sum = 0.f;
     {
         const unsigned ldz4 = (unsigned)ldz * 4u;
-        const __amdgpu_buffer_rsrc_t zb = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM + 16 * wave) * ldz + n0);
+        const int vw = valid - 16 * wave;                 // rows of this wave's 16 that exist (<= 0: none; B % 16 == 0: 0 or 16)
+        const __amdgpu_buffer_rsrc_t zb = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM + 16 * wave) * ldz + n0,
+                                                  vw > 0 ? (15u * (unsigned)ldz + BN) * 4u : 0u);
         const unsigned lz = (unsigned)(4 * g) * ldz4 + 4u * (unsigned)r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[e] = (c0[e] + c1[e]) + bcol;
             naf_buf_st_f1(zb, lz, (unsigned)e * ldz4, v[e], B >= NAF_WT_MIN_B);
-            sum += v[e];
+            sum += vw > 0 ? v[e] : 0.f;
         }
     }
+    const bool w_on = valid - 16 * wave > 0;
     sum = naf_xor32_add(naf_xor16_add(sum));
     if (g == 0) red[wave][r] = sum;
     __syncthreads();
     const float S = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
-    const float mb = S * (1.0f / BB_ROWS);
+    const float mb = S * (valid == BB_ROWS ? 1.0f / BB_ROWS : 1.0f / (float)valid);
     float m2 = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float t = v[e] - mb;
-        m2 += t * t;
+        m2 += w_on ? t * t : 0.f;
     }
     m2 = naf_xor32_add(naf_xor16_add(m2));
     __syncthreads();
@@ -1591,7 +1610,9 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && (B % BB_ROWS) == 0 && B <= 32 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
+// (B: whole 16-row groups — the rows of a bb_layer2_head workgroup and of an MFMA tile; the last 64-row block may hold 16, 32 or 48)
+static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && (B % 16) == 0 && B <= 32 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
+static int bb_blocks(int B) { return (B + BB_ROWS - 1) / BB_ROWS; }
 
 extern "C" int naf_bb_moments_floats(int K) {
     if (K <= 0 || K > 4 * BB_MAX_K4) return NAF_ERR_ARG;
@@ -1654,7 +1675,7 @@ extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx,
             return NAF_ERR_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int n_main = (B / BB_ROWS) * (H / BB_COLS) * nets;
+    const int n_main = bb_blocks(B) * (H / BB_COLS) * nets;
     const int n_adam = adam ? bb_adam_blocks(l1_4, n4, 2 * BB_THREADS) : 0;
     const int grid = n_main + n_adam;
     const int xcd_rows = 1;      // rows by eighths (bb_place_rows)
@@ -1681,7 +1702,7 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
     if (!bb_adam_setup(adam, ad, l1_4, n4)) return NAF_ERR_ARG;
     const int extra = adam ? bb_adam_blocks(0, l1_4, BB_THREADS) : 0;
     const int xcd_nets = 1;      // rows by eighths (bb_place_rows)
-    const int gx = nets * (B / BB_ROWS);
+    const int gx = nets * bb_blocks(B);
     hipStream_t st = (hipStream_t)stream;
 #define BB_LS(KERNEL, GY)                                                                                                   \
     do {                                                                                                                    \
@@ -1726,7 +1747,7 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     // folded once per launch where a workgroup would pull more than 8 statistics blocks per column (B > 512) — and only there: the
     // readers wait ~2.6 us for the records (updates/s, A/B/A/B on one box: B = 512 30.4k -> 30.2k with it, 1024 25.9k -> 26.3k,
     // 1536 21.0k -> 21.65k, 2048 20.35k -> 20.58k)
-    const int n_fold = (once && B / BB_ROWS > 8) ? 2 * FK_H / 32 : 0;
+    const int n_fold = (once && bb_blocks(B) > 8) ? 2 * FK_H / 32 : 0;
     const int blocks = B / rows + n_fold;
     float* rec = once ? once->records : nullptr;
     const int* epoch_p = once ? once->epoch : nullptr;
@@ -1734,7 +1755,7 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     const int xcd_rows = 1;      // row chunks dealt to the XCD whose dA1 blocks read them (+0.4 - 1 %)
 #define BB_FK_R(PM, NH4V, RW)                                                                                            \
     bb_layer2_head_kernel<PM, NH4V, RW><<<blocks, FK_THREADS, 0, st>>>(                                                  \
-        z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, B / BB_ROWS, running_mean, running_var, \
+        z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, bb_blocks(B), running_mean, running_var, \
         stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
         loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows, rec, epoch_p, errors, n_fold)
 #define BB_FK(PM, NH4V) BB_FK_R(PM, NH4V, 16)

@@ -161,7 +161,7 @@ class Learner:
         #              BatchNorm statistics, GEMM 2 on f32 MFMA, layer 2 + heads + NAF head + first backward stage in one launch
         #              (hk), the backward GEMMs as one launch (gb) that also carries the second stage of layer 2's BatchNorm
         #              backward as its prologue (s2) and the batch pass of layer 1's backward as its epilogue (ep), a finish
-        #              launch — 5 launches per update in a chain of updates. Needs B % 64 == 0, 64 <= B <= 2048, H = 256, S <= 26.
+        #              launch — 5 launches per update in a chain of updates. Needs B % 16 == 0, 64 <= B <= 2048, H = 256, S <= 26.
         #              Default wherever the shape fits (measured at the end of round 3, updates/s, column-tile | row-split: B = 64:
         #              32.3k | 36.0k, 128: 30.7k | 35.4k, 192: 25.8k | 34.0k, 256: 25.7k | 34.7k, 512: 20.3k | 30.9k; until then the
         #              column-tile chain led below B = 256 — 32.5k | 29.3k at 64 in round 2).
@@ -180,7 +180,9 @@ class Learner:
         # the replay sampler's limit (one workgroup draws a minibatch without replacement in LDS, csrc/replay.hip).
         if self.B < 1 or self.B > 4096:
             raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 4096 (the sampler draws a minibatch in one workgroup's LDS)")
-        self.bb_ok = (self.B % 64 == 0 and 64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
+        # (round 4: whole 16-row groups, not whole 64-row blocks — the last block of layer 1 / GEMM 2 and of the bundle's dA1 product
+        #  may be partial: rows past the batch read as zeros, are never stored and stay out of every statistic)
+        self.bb_ok = (self.B % 16 == 0 and 64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
@@ -205,10 +207,10 @@ class Learner:
         if self.B > 512 and want != "rows":
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)
             import warnings
-            lo, hi = min(2048, max(64, self.B // 64 * 64)), min(2048, -(-self.B // 64) * 64)
+            lo, hi = min(2048, max(64, self.B // 16 * 16)), min(2048, -(-self.B // 16) * 16)
             near = f"{lo}, {hi}" if lo != hi else f"{lo}"
             warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
-                          f"row-split chain): the row-split kernels need batch_size % 64 == 0 (nearest: {near}), 64 <= "
+                          f"row-split chain): the row-split kernels need batch_size % 16 == 0 (nearest: {near}), 64 <= "
                           f"batch_size <= 2048, layer_size 256 and state_size <= 26", stacklevel=3)
         # with every gradient element produced by one of our own kernels, those kernels also emit its sum-of-squares partial:
         # the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken on the all-reduced gradient).
@@ -297,7 +299,8 @@ class Learner:
         self.save_invstd = torch.empty(2, 2, H, **f32)
         self.q_out = torch.empty(B, **f32)
         if "bb" in self.fuse:
-            NB = B // 64
+            NB = -(-B // 64)                                     # 64-row statistics blocks (the last may hold 16, 32 or 48 rows)
+            NB1 = -(-B // 32)                                    # 32-row blocks of the bundle's dA1 product
             kp = self.lib.naf_bb_layer1_bwd_kp(lay.S)
             # moments record of one minibatch's layer-1 inputs, [net][Sx | C]: everything layer 1's BatchNorm needs from
             # the batch dimension (TrainChunk computes the records of all its minibatches in one launch behind the gather)
@@ -307,8 +310,9 @@ class Learner:
             self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)        # layer-2 statistics partials per 64-row block: (sum, M2)
             self.hk_rows = self.lib.naf_bb_layer2_head_rows(B)    # rows per block of the fused launch's backward partials
             self.bb_bw2 = torch.zeros(B // self.hk_rows, H, 2, **f32)   # backward partials of layer 2: (sum dy, sum dy*xhat)
-            self.bb_bw1 = torch.zeros(B // 32, H, 2, **f32)       # backward partials of layer 1, per 32-row block of the bundle
-            self.bb_dw1 = torch.zeros(B // 32, H, kp, **f32)      # per-block shares of P = dY1^T X
+            self.bb_bw1 = torch.zeros(NB1, H, 2, **f32)           # backward partials of layer 1, per 32-row block of the bundle
+            self.bb_dw1 = torch.zeros(NB1, H, kp, **f32)          # per-block shares of P = dY1^T X
+            self._nb1 = NB1
         if "s3" in self.fuse:
             # split-K heads: one [B, NHP] slab per 8-column workgroup of layer 2's BN kernel (+ the target's V column)
             # slabs 256 B further apart than their size: the H/8 pieces of one row, read together by the head kernel,
@@ -371,7 +375,7 @@ class Learner:
             self.gemm_form = int(os.environ.get("NAF_GEMM_FORM", "0"))
             if self.gemm_form not in (0, 1, 2):
                 raise ValueError("NAF_GEMM_FORM: 0 / 1 (32 x 32 blocks) or 2 (LDS-DMA ring)")
-            self.gemm_ring = self.gemm_form == 2 and (B // ks) % 32 == 0
+            self.gemm_ring = self.gemm_form == 2 and (B // ks) % 32 == 0 and B % 64 == 0
             if not self.gemm_ring and blocks(B, H, 1) + blocks(H, H, ks) + blocks(NHP, HP, ks) + 8 > 1024 and ks % 2 == 0 and \
                     (B // (ks // 2)) % 256 == 0:
                 ks_w2 = ks // 2
@@ -617,7 +621,7 @@ class Learner:
             raise _lib.NafHipError("merged gradient exchange: the flat layout must end with the Wh segment")
         norm_here = self.fold_norm or merged
         check(f.naf_bb_layer1_bwd_finish(
-            ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), B // 32, None, 0,
+            ptr(self.bb_dw1), lay.S, ptr(self.bb_bw1), self._nb1, None, 0,
             ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
             gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
             gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
