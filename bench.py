@@ -493,12 +493,14 @@ def extras(dev, args):
                     measure_shape(dev, "panda", 2048, 4000000, E, 400, 30),
                 "batch 512 (kuka, ring 1e6)": measure_shape(dev, "kuka", 512, 1000000, E, 500, 30),
                 # small batches: configs[0]'s batch and ring with 64 device envs, and the reference's default batch
-                # (rl_framework.py:33-44) — the row-split chain since the end of round 3; a batch size that is not a multiple of
-                # 16, for the column-tile chain, and one that is a multiple of 16 but not of 64 (round 4: a partial last block)
+                # (rl_framework.py:33-44) — the row-split chain since the end of round 3; batch sizes that are not whole 64-row blocks
+                # or whole 16-row groups (round 4: partial last block / workgroup / MFMA tile on the row-split chain) and one below
+                # 64, the column-tile chain's range
                 "configs[0] batch and ring: kuka, batch 64, ring 1e5, 64 device envs": measure_shape(dev, "kuka", 64, 100000, E, 500, 30),
                 "reference default batch 128 (kuka, ring 1e5)": measure_shape(dev, "kuka", 128, 100000, E, 500, 30),
-                "batch 100 (kuka, ring 1e5): the column-tile chain": measure_shape(dev, "kuka", 100, 100000, E, 500, 30),
-                "batch 96 (kuka, ring 1e5): the row-split chain with a partial last block": measure_shape(dev, "kuka", 96, 100000, E, 500, 30),
+                "batch 100 (kuka, ring 1e5): the row-split chain with a partial last 16-row group": measure_shape(dev, "kuka", 100, 100000, E, 500, 30),
+                "batch 1000 (kuka, ring 1e6): the same at a large batch": measure_shape(dev, "kuka", 1000, 1000000, E, 500, 30),
+                "batch 48 (kuka, ring 1e5): the column-tile chain": measure_shape(dev, "kuka", 48, 100000, E, 500, 30),
                 # north_star's literal head: textbook P = L L^T on 8 x 9 padded LDS tiles (--p-mode matmul)
                 "configs[1] with P = L L^T (p_mode matmul)": measure_shape(dev, "kuka", 256, 1000000, E, 500, 30, p_mode="matmul"),
                 # ... and at configs[4]'s literal shape: 7 x 7 L / P tiles, batch 2048, ring 4e6

@@ -65,7 +65,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 24
+#define NAF_HIP_ABI_VERSION 25
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -384,6 +384,10 @@ typedef struct naf_gemm_l1bwd {
     const float* xhat;
     const float* gamma;
     const float* beta;
+    /* rows of the M that are samples (0: all M). A batch that is not whole 16-row groups runs with M = the next multiple of 16 over
+     * buffers of that many rows; the rows past `rows` (M - 16 < rows <= M) carry nothing into partials / p_slabs, and x is read up
+     * to row rows - 1 only. */
+    int rows;
 } naf_gemm_l1bwd_t;
 /* optional prologue on the A operand of a product: A = dY2 (the ReLU-masked gradient w.r.t. layer 2's BatchNorm output, written by
  * naf_bb_layer2_head) is turned into dZ2 = k1 (dy - c1 - xhat c2) WHILE the panel is staged — the second stage of layer 2's

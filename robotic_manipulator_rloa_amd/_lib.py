@@ -280,7 +280,8 @@ class GemmL1Bwd(C.Structure):
     """naf_gemm_l1bwd_t (include/naf_hip.h)"""
     _fields_ = [("x", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("a1", C.c_void_p), ("save_mean", C.c_void_p),
                 ("save_invstd", C.c_void_p), ("partials", C.c_void_p), ("p_slabs", C.c_void_p), ("ldx", C.c_int), ("K", C.c_int),
-                ("kp", C.c_int), ("lda1", C.c_int), ("xhat", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p)]
+                ("kp", C.c_int), ("lda1", C.c_int), ("xhat", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("rows", C.c_int)]
 
 
 def load(allow_build: bool = True) -> C.CDLL:

@@ -1265,18 +1265,19 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     float sum = 0.f;
     {
         const unsigned ldz4 = (unsigned)ldz * 4u;
-        const int vw = valid - 16 * wave;                 // rows of this wave's 16 that exist (<= 0: none; B % 16 == 0: 0 or 16)
+        const int vw = valid - 16 * wave;                 // rows of this wave's 16 that exist (<= 0: none)
+        const int vwc = vw > 16 ? 16 : vw;
         const __amdgpu_buffer_rsrc_t zb = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM + 16 * wave) * ldz + n0,
-                                                  vw > 0 ? (15u * (unsigned)ldz + BN) * 4u : 0u);
+                                                  vw > 0 ? ((unsigned)(vwc - 1) * (unsigned)ldz + BN) * 4u : 0u);
         const unsigned lz = (unsigned)(4 * g) * ldz4 + 4u * (unsigned)r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[e] = (c0[e] + c1[e]) + bcol;
             naf_buf_st_f1(zb, lz, (unsigned)e * ldz4, v[e], B >= NAF_WT_MIN_B);
-            sum += vw > 0 ? v[e] : 0.f;
+            sum += 4 * g + e < vw ? v[e] : 0.f;
         }
     }
-    const bool w_on = valid - 16 * wave > 0;
+    const int vw_ = valid - 16 * wave;
     sum = naf_xor32_add(naf_xor16_add(sum));
     if (g == 0) red[wave][r] = sum;
     __syncthreads();
@@ -1286,7 +1287,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float t = v[e] - mb;
-        m2 += w_on ? t * t : 0.f;
+        m2 += 4 * g + e < vw_ ? t * t : 0.f;
     }
     m2 = naf_xor32_add(naf_xor16_add(m2));
     __syncthreads();
@@ -1412,7 +1413,11 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     f32x4 wv_r = {0.f, 0.f, 0.f, 0.f};
     if (tid < H / 4) wv_r = *(const f32x4*)(Wh + wh_net_stride + (int64_t)v_col * ldw + 4 * tid);
     const int s_loc_ = tid >> 3, i_ = tid & 7;
-    const bool live_ = s_loc_ < ROWS;
+    // rows of this workgroup that exist (the last workgroup of a batch that is not whole 16-row groups holds fewer): the others are
+    // not samples — the head body leaves their d_heads zero (so dA2, dY2 and every block sum get nothing from them), their Z2 rows
+    // are the zeros the buffer was allocated with, and nothing of the minibatch is read for them
+    const int ns_ = B - (int)s0 < ROWS ? B - (int)s0 : ROWS;
+    const bool live_ = s_loc_ < ns_;
     const float u_val = (live_ && i_ < A) ? u[(s0 + s_loc_) * ldu + i_] : 0.f;
     const float r_val = (live_ && i_ == 0) ? r[(s0 + s_loc_) * ldr] : 0.f;
     {
@@ -1542,7 +1547,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     FK_TL(4);
     // ---- phase 3: the NAF head on the 32 rows (threads 0..255 carry samples; every thread joins the barriers) --------
     naf_head_body<PMODE, 2, FK_THREADS>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td, q_out,
-                                        nullptr, loss_partials, B, A, s0, ROWS);
+                                        nullptr, loss_partials, B, A, s0, ns_);
     FK_TL(5);
     if (tid < ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
     // ---- phase 4: dA2 = d_heads Wh (K = NHP), MT x 16 tiles, 2 MT per wave; ReLU mask, dY2, block sums ------------------
@@ -1610,8 +1615,10 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-// (B: whole 16-row groups — the rows of a bb_layer2_head workgroup and of an MFMA tile; the last 64-row block may hold 16, 32 or 48)
-static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && (B % 16) == 0 && B <= 32 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
+// (any B from 64 to 2048: the last 64-row block, the last 16-row workgroup of bb_layer2_head and the last MFMA tile may be partial —
+//  rows past the batch read as zeros, are never stored and stay out of every sum; the caller's activation buffers hold whole 16-row
+//  groups, zero-initialised, so that the rows past the batch ARE zeros wherever a later launch walks them as a K dimension)
+static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && B <= 32 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
 static int bb_blocks(int B) { return (B + BB_ROWS - 1) / BB_ROWS; }
 
 extern "C" int naf_bb_moments_floats(int K) {
@@ -1748,7 +1755,7 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     // readers wait ~2.6 us for the records (updates/s, A/B/A/B on one box: B = 512 30.4k -> 30.2k with it, 1024 25.9k -> 26.3k,
     // 1536 21.0k -> 21.65k, 2048 20.35k -> 20.58k)
     const int n_fold = (once && bb_blocks(B) > 8) ? 2 * FK_H / 32 : 0;
-    const int blocks = B / rows + n_fold;
+    const int blocks = (B + rows - 1) / rows + n_fold;
     float* rec = once ? once->records : nullptr;
     const int* epoch_p = once ? once->epoch : nullptr;
     unsigned long long* errors = once ? (unsigned long long*)once->errors : nullptr;

@@ -180,10 +180,10 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
     const int KP = E.kp, m0 = bm * 32, n0 = bn * 32;
     const int xr = KP == 24 ? tid / 6 : tid / 8, xq = tid - xr * (KP / 4);       // (KP is 24 or 32: divisions by constants)
     R.x = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // (rows past M — the second half of the last block of a batch that is 16 mod 32 — are read as the last row that exists and carry
-    //  dy = 0 through the epilogue)
-    const int mlast = D.M - 1;
-    if (xr < 32) R.x = ((const f32x4*)(E.x + (int64_t)(m0 + xr < D.M ? m0 + xr : mlast) * E.ldx))[xq];
+    // (rows past the batch — E.rows of the M rows are samples: the last block of a batch that is not whole 32-row blocks — are read as
+    //  the last row that exists and carry dy = 0 through the epilogue)
+    const int Mv = E.rows, mlast = Mv - 1;
+    if (xr < 32) R.x = ((const f32x4*)(E.x + (int64_t)(m0 + xr < Mv ? m0 + xr : mlast) * E.ldx))[xq];
 #pragma unroll
     for (int i = 0; i < L1bwdRegs<G>::NW; ++i) {
         const int e = tid + G::THREADS * i;
@@ -197,7 +197,7 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = m0 + wm * 16 + 4 * g + e;
-            R.a1[e] = owner ? E.xhat[(int64_t)(row < D.M ? row : mlast) * E.lda1 + col] : 0.f;
+            R.a1[e] = owner ? E.xhat[(int64_t)(row < Mv ? row : mlast) * E.lda1 + col] : 0.f;
         }
         R.mean = E.gamma[col];
         R.invstd = E.beta[col];
@@ -207,7 +207,7 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int row = m0 + wm * 16 + 4 * g + e;
-        R.a1[e] = owner ? E.a1[(int64_t)(row < D.M ? row : mlast) * E.lda1 + col] : 0.f;
+        R.a1[e] = owner ? E.a1[(int64_t)(row < Mv ? row : mlast) * E.lda1 + col] : 0.f;
     }
     R.mean = E.save_mean[col];
     R.invstd = E.save_invstd[col];
@@ -284,7 +284,7 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
         for (int e = 0; e < 4; ++e) {
             const float xhe = kept ? R.a1[e] : xh[e];
             const bool on = (kept ? __builtin_fmaf(R.a1[e], R.mean, R.invstd) > 0.f : R.a1[e] > 0.f) &&
-                            bm * 32 + wm * 16 + 4 * g + e < D.M;            // (a row past the batch contributes nothing)
+                            bm * 32 + wm * 16 + 4 * g + e < E.rows;         // (a row past the batch contributes nothing)
             const float dy = on ? acc[e] : 0.f;
             sDY[(wm * 16 + 4 * g + e) * 33 + wn * 16 + r] = dy;
             s_dy += dy;
@@ -626,9 +626,11 @@ extern "C" int naf_gemm_bundle_ex(const naf_gemm_desc_t* descs, int n, int form,
             const naf_gemm_l1bwd_t& e = *s.epi;
             if (!e.x || !e.W || !e.bias || !e.a1 || !e.save_mean || !e.save_invstd || !e.partials || !e.p_slabs || ksn != 1 ||
                 (s.M & 15) || (s.N & 31) || e.K <= 0 || (e.kp != 24 && e.kp != 32) || e.K > e.kp || e.ldx < e.kp || (e.ldx & 3) ||
-                e.lda1 < s.N || ((uintptr_t)e.x & 15) || ((uintptr_t)e.partials & 7) || (e.xhat && (!e.gamma || !e.beta)))
+                e.lda1 < s.N || ((uintptr_t)e.x & 15) || ((uintptr_t)e.partials & 7) || (e.xhat && (!e.gamma || !e.beta)) ||
+                e.rows < 0 || e.rows > s.M || (e.rows && e.rows <= s.M - 16))
                 return NAF_ERR_ARG;
             d.epi = e;
+            if (!d.epi.rows) d.epi.rows = s.M;
         }
         tiles += d.tiles_mn * ksn;
     }

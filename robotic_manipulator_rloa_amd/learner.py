@@ -161,28 +161,31 @@ class Learner:
         #              BatchNorm statistics, GEMM 2 on f32 MFMA, layer 2 + heads + NAF head + first backward stage in one launch
         #              (hk), the backward GEMMs as one launch (gb) that also carries the second stage of layer 2's BatchNorm
         #              backward as its prologue (s2) and the batch pass of layer 1's backward as its epilogue (ep), a finish
-        #              launch — 5 launches per update in a chain of updates. Needs B % 16 == 0, 64 <= B <= 2048, H = 256, S <= 26.
+        #              launch — 5 launches per update in a chain of updates. Needs 64 <= B <= 2048 (any size in it), H = 256, S <= 26.
         #              Default wherever the shape fits (measured at the end of round 3, updates/s, column-tile | row-split: B = 64:
         #              32.3k | 36.0k, 128: 30.7k | 35.4k, 192: 25.8k | 34.0k, 256: 25.7k | 34.7k, 512: 20.3k | 30.9k; until then the
         #              column-tile chain led below B = 256 — 32.5k | 29.3k at 64 in round 2).
         #   "columns"  {l1, b2, gb, s3}: the COLUMN-TILE chain of csrc/fused_layers.hip — a workgroup owns 8 feature columns x all
         #              B rows (ceil(B/64) <= 8 rows per thread in registers), the K = state-size and N = heads GEMMs folded into
-        #              the BatchNorm kernels, 8 launches per update. B <= 512. Default for batch sizes up to 512 that are not
-        #              multiples of 64.
+        #              the BatchNorm kernels, 8 launches per update. B <= 512. Default below B = 64 (and up to 512 where H or S
+        #              do not fit the row-split chain).
         #   "unfused"  {gb} or {}: torch (rocBLAS) GEMMs + the BatchNorm / head kernels of csrc/bn_relu.hip, naf_head.hip, with
         #              the backward GEMM bundle where its shapes allow (B, H multiples of 16) — any shape up to B = 2048; 14
         #              launches per update (round 1's chain: 12.7k updates/s at B = 1024).
         # NAF_FUSE = rows | columns | unfused overrides the choice (a chain whose shape limits are not met falls to the next).
         lay0 = self.lay
-        # The reference takes any positive batch_size (rl_framework.py:186-189). Here: every size up to 4096 trains — multiples of
-        # 64 up to 2048 on the row-split chain, other sizes up to 512 on the column-tile chain, everything else on the unfused chain
-        # (beyond 2048 with the streamed BatchNorm kernels of csrc/bn_relu.hip) with a warning that names the faster sizes. 4096 is
+        # The reference takes any positive batch_size (rl_framework.py:186-189). Here: every size up to 4096 trains — 64 ... 2048
+        # on the row-split chain, smaller ones on the column-tile chain, everything else on the unfused chain (beyond 2048 with
+        # the streamed BatchNorm kernels of csrc/bn_relu.hip) with a warning that names the row-split chain's range. 4096 is
         # the replay sampler's limit (one workgroup draws a minibatch without replacement in LDS, csrc/replay.hip).
         if self.B < 1 or self.B > 4096:
             raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 4096 (the sampler draws a minibatch in one workgroup's LDS)")
-        # (round 4: whole 16-row groups, not whole 64-row blocks — the last block of layer 1 / GEMM 2 and of the bundle's dA1 product
-        #  may be partial: rows past the batch read as zeros, are never stored and stay out of every statistic)
-        self.bb_ok = (self.B % 16 == 0 and 64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
+        # (round 4: ANY batch size from 64 to 2048 — the last 64-row block of layer 1 / GEMM 2, the last 16-row workgroup of the fused
+        #  layer-2 + head launch and the last block of the bundle's dA1 product may be partial: rows past the batch read as zeros, are
+        #  never stored and stay out of every statistic and sum. The work buffers hold Bp = the next multiple of 16 rows,
+        #  zero-initialised: the weight-gradient products walk Bp rows as their K dimension, and a row past the batch is a zero in at
+        #  least one operand of each — dH and dY2 rows the head body never writes, A1 rows layer 1 never stores.)
+        self.bb_ok = (64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
@@ -201,17 +204,15 @@ class Learner:
         else:
             want = "unfused"
             self.fuse = {"gb"}
-        if self.B % 16 != 0 or lay0.H % 16 != 0:
+        if (self.B % 16 != 0 and want != "rows") or lay0.H % 16 != 0:
             self.fuse -= {"gb"}                # the MFMA kernels take whole 16 x 16 x 16 steps: M, N, K % 16 == 0
         self.chain = want
         if self.B > 512 and want != "rows":
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)
             import warnings
-            lo, hi = min(2048, max(64, self.B // 16 * 16)), min(2048, -(-self.B // 16) * 16)
-            near = f"{lo}, {hi}" if lo != hi else f"{lo}"
             warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
-                          f"row-split chain): the row-split kernels need batch_size % 16 == 0 (nearest: {near}), 64 <= "
-                          f"batch_size <= 2048, layer_size 256 and state_size <= 26", stacklevel=3)
+                          f"row-split chain): the row-split kernels need 64 <= batch_size <= 2048, layer_size 256 and "
+                          f"state_size <= 26", stacklevel=3)
         # with every gradient element produced by one of our own kernels, those kernels also emit its sum-of-squares partial:
         # the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken on the all-reduced gradient).
         self.fold_norm = ({"l1", "b2", "gb"} <= self.fuse or {"bb", "gb"} <= self.fuse) and self.world_size == 1 and \
@@ -220,6 +221,8 @@ class Learner:
         lay, B, dev = self.lay, self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
         P, H, HP, NHP = lay.P, lay.H, lay.HP, lay.NHP
+        # rows of the work buffers: whole 16-row groups on the row-split chain (see bb_ok above), B everywhere else
+        self.Bp = Bp = -(-B // 16) * 16 if "bb" in self.fuse else B
 
         # ---- persistent state --------------------------------------------------------------------------
         self.theta2 = torch.zeros(2, P, **f32)             # [main; target]
@@ -284,17 +287,17 @@ class Learner:
         self.err_host = torch.zeros(8, dtype=torch.int64).pin_memory()
 
         # ---- work buffers for one minibatch ------------------------------------------------------------
-        self.G1 = torch.empty(2, B, H, **f32)
-        self.A1 = torch.empty(2, B, H, **f32)
-        self.G2 = torch.empty(2, B, H, **f32)
-        self.A2 = torch.zeros(2, B, HP, **f32)
+        self.G1 = torch.zeros(2, Bp, H, **f32)
+        self.A1 = torch.zeros(2, Bp, H, **f32)
+        self.G2 = torch.zeros(2, Bp, H, **f32)
+        self.A2 = torch.zeros(2, Bp, HP, **f32)
         self.A2[:, :, H] = 1.0                               # the constant-1 column that carries the head biases
-        self.Gh = torch.empty(2, B, NHP, **f32)
-        self.dH = torch.zeros(B, NHP, **f32)
-        self.dA2 = torch.empty(B, HP, **f32)
-        self.dZ2 = torch.empty(B, H, **f32)
-        self.dA1 = torch.empty(B, H, **f32)
-        self.dZ1 = torch.empty(B, H, **f32)
+        self.Gh = torch.zeros(2, Bp, NHP, **f32)
+        self.dH = torch.zeros(Bp, NHP, **f32)
+        self.dA2 = torch.zeros(Bp, HP, **f32)
+        self.dZ2 = torch.zeros(Bp, H, **f32)
+        self.dA1 = torch.zeros(Bp, H, **f32)
+        self.dZ1 = torch.zeros(Bp, H, **f32)
         self.save_mean = torch.empty(2, 2, H, **f32)         # [layer][net][H]
         self.save_invstd = torch.empty(2, 2, H, **f32)
         self.q_out = torch.empty(B, **f32)
@@ -309,7 +312,7 @@ class Learner:
             self.bb_wc = torch.zeros(H, kp, **f32)               # w_c C of the main net, forward -> finish
             self.bb_st2 = torch.zeros(2, NB, H, 2, **f32)        # layer-2 statistics partials per 64-row block: (sum, M2)
             self.hk_rows = self.lib.naf_bb_layer2_head_rows(B)    # rows per block of the fused launch's backward partials
-            self.bb_bw2 = torch.zeros(B // self.hk_rows, H, 2, **f32)   # backward partials of layer 2: (sum dy, sum dy*xhat)
+            self.bb_bw2 = torch.zeros(Bp // self.hk_rows, H, 2, **f32)   # backward partials of layer 2: (sum dy, sum dy*xhat)
             self.bb_bw1 = torch.zeros(NB1, H, 2, **f32)           # backward partials of layer 1, per 32-row block of the bundle
             self.bb_dw1 = torch.zeros(NB1, H, kp, **f32)          # per-block shares of P = dY1^T X
             self._nb1 = NB1
@@ -358,12 +361,12 @@ class Learner:
             # that are not multiples of 256: as many equal ranges (<= 8, whole 64-row blocks) as divide B / 64.
             def k_ranges(target, most):
                 """largest number of equal K ranges <= most, each whole 16-k steps and at least `target` rows long"""
-                return max([d for d in range(1, most + 1) if B % d == 0 and (B // d) % 16 == 0 and B // d >= target] or [1])
+                return max([d for d in range(1, most + 1) if Bp % d == 0 and (Bp // d) % 16 == 0 and Bp // d >= target] or [1])
 
             def blocks(M, N, k_split):
                 """32 x 32 blocks of one product of the bundle (csrc/gemm_bundle.hip)"""
                 return ((M + 31) // 32) * ((N + 31) // 32) * k_split
-            ks = B // 256 if B % 256 == 0 else k_ranges(256, 8)
+            ks = Bp // 256 if Bp % 256 == 0 else k_ranges(256, 8)
             ks_w2 = ks_wh = ks
             # Which form of the bundle launch (include/naf_hip.h, naf_gemm_bundle_ex): one 32 x 32 block per workgroup (form 1, the
             # default at every batch size) or the LDS-DMA ring on 64 x 32 tiles (form 2, csrc/gemm_ring.h; NAF_GEMM_FORM = 2 opts in
@@ -376,8 +379,8 @@ class Learner:
             if self.gemm_form not in (0, 1, 2):
                 raise ValueError("NAF_GEMM_FORM: 0 / 1 (32 x 32 blocks) or 2 (LDS-DMA ring)")
             self.gemm_ring = self.gemm_form == 2 and (B // ks) % 32 == 0 and B % 64 == 0
-            if not self.gemm_ring and blocks(B, H, 1) + blocks(H, H, ks) + blocks(NHP, HP, ks) + 8 > 1024 and ks % 2 == 0 and \
-                    (B // (ks // 2)) % 256 == 0:
+            if not self.gemm_ring and blocks(Bp, H, 1) + blocks(H, H, ks) + blocks(NHP, HP, ks) + 8 > 1024 and ks % 2 == 0 and \
+                    (Bp // (ks // 2)) % 256 == 0:
                 ks_w2 = ks // 2
             self.bb_slab_w2 = torch.zeros(ks_w2, H * H, **f32)
             self.bb_slab_wh = torch.zeros(ks_wh, NHP * HP, **f32)
@@ -387,18 +390,18 @@ class Learner:
             # sat on the critical path: updates/s 36.0k -> 36.8k at B = 64, 35.2k -> 36.0k at 128, 34.6k -> 35.1k at 256, 31.25k ->
             # 31.5k at 512; beyond that the recomputation hides and the extra B x H floats each way do not: 28.3k -> 27.7k at 1024)
             # The ring form's epilogue always reads the kept xhat (it has no W1 / X product of its own).
-            self.XH1 = torch.empty(B, H, **f32) if (B <= 512 or self.gemm_ring) else None
+            self.XH1 = torch.zeros(Bp, H, **f32) if (B <= 512 or self.gemm_ring) else None
             self._epi = _lib.GemmL1Bwd(None, t2p_ + 4 * seg_["W1"].offset, t2p_ + 4 * seg_["b1"].offset, ptr(self.A1[0]),
                                        ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1),
                                        0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H, ptr(self.XH1),
-                                       t2p_ + 4 * seg_["g1"].offset, t2p_ + 4 * seg_["be1"].offset)
+                                       t2p_ + 4 * seg_["g1"].offset, t2p_ + 4 * seg_["be1"].offset, B)
             # s2: dY2 -> dZ2 while the two products that read it stage their A panels; the block sums folded once per launch
             # by the bundle's first workgroups and handed on as tagged records (csrc/gemm_bundle.hip, gemm_bn2bwd_fold_block)
             self.bb_cst = torch.zeros(H, 4, **f32)                                        # per-column constants of the launch
             self.bb_fold_flag = torch.ones(1, dtype=torch.int32, device=dev)              # launch number: finish advances it; never restored
             self._pro = _lib.GemmBn2Bwd(ptr(self.G2[0]), ptr(self.bb_bw2), t2p_ + 4 * seg_["g2"].offset, ptr(self.save_mean[1, 0]),
                                         ptr(self.save_invstd[1, 0]), gp_ + 4 * seg_["g2"].offset, gp_ + 4 * seg_["be2"].offset,
-                                        B // self.hk_rows, B, H, ptr(self.bb_cst), ptr(self.bb_fold_flag), self.err_host.data_ptr())
+                                        Bp // self.hk_rows, B, H, ptr(self.bb_cst), ptr(self.bb_fold_flag), self.err_host.data_ptr())
             pro_ = _lib.C.addressof(self._pro)
             # layer 2's forward statistics folded once per launch too where a workgroup would pull more than 16 blocks of them
             # (B > 1024; the library decides): records of their own, the same launch counter and error word
@@ -408,9 +411,9 @@ class Learner:
             # dA1 FIRST: its blocks carry the layer-1 epilogue and run longest; dispatched first, the short weight-gradient
             # blocks fill in behind them instead of the other way round
             self._bundle = (D * 3)(
-                D(ptr(self.dZ2), ptr(self.W2_main), None, None, B, H, H, H, H, H, 0, 1, 1, 0, _lib.C.addressof(self._epi), pro_),
-                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, B, H, H, H, 1, 1, ks_w2, H * H, None, pro_),
-                D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks_wh, NHP * HP))
+                D(ptr(self.dZ2), ptr(self.W2_main), None, None, Bp, H, H, H, H, H, 0, 1, 1, 0, _lib.C.addressof(self._epi), pro_),
+                D(ptr(self.dZ2), ptr(self.A1[0]), ptr(self.bb_slab_w2), None, H, H, Bp, H, H, H, 1, 1, ks_w2, H * H, None, pro_),
+                D(ptr(self.dH), ptr(self.A2[0]), ptr(self.bb_slab_wh), None, NHP, HP, Bp, NHP, HP, HP, 1, 1, ks_wh, NHP * HP))
             SS = _lib.SlabSeg
             self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks_w2),
                                      SS(ptr(self.bb_slab_wh), ptr(self.gWh), NHP * HP, NHP * HP, ks_wh))
@@ -496,11 +499,11 @@ class Learner:
             check(self._f.naf_bb_layer1_adam(
                 rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
                 t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
-                ptr(self.A1), B * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), ptr(self.XH1), B, H, 2,
+                ptr(self.A1), self.Bp * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), ptr(self.XH1), B, H, 2,
                 BN_MOMENTUM, BN_EPS, adam, st), "bb_layer1")
             # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
-            check(self._f.naf_bb_linear_stats_adam(ptr(self.A1), B * H, H, t2p + 4 * seg["W2"].offset,
-                                                   t2p + 4 * seg["b2"].offset, P, ptr(self.G2), B * H, H, ptr(self.bb_st2), B, H,
+            check(self._f.naf_bb_linear_stats_adam(ptr(self.A1), self.Bp * H, H, t2p + 4 * seg["W2"].offset,
+                                                   t2p + 4 * seg["b2"].offset, P, ptr(self.G2), self.Bp * H, H, ptr(self.bb_st2), B, H,
                                                    H, 2, adam, st), "bb_linear_stats")
             return
         if "l1" in self.fuse:
@@ -595,7 +598,7 @@ class Learner:
         self.forward_train(rows, moments=moments, adam_pending=pending)
         # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
         check(f.naf_bb_layer2_head(
-            ptr(self.G2), B * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
+            ptr(self.G2), self.Bp * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
             bnp + 8 * H, bnp + 12 * H, 4 * H, ptr(self.A2[0]), HP, ptr(self.save_mean[1]), ptr(self.save_invstd[1]),
             t2p + 4 * seg["Wh"].offset, P, HP, NHP, rp + 4 * lay.off_u, ld, rp + 4 * lay.off_r, ld, self.gamma,
             ptr(self.q_out), ptr(self.dH), lp, ptr(self.dZ2), H, ptr(self.bb_bw2), B, H, lay.A, self.p_mode, BN_MOMENTUM,
