@@ -385,7 +385,7 @@ typedef struct naf_gemm_l1bwd {
     const float* gamma;
     const float* beta;
     /* rows of the M that are samples (0: all M). A batch that is not whole 16-row groups runs with M = the next multiple of 16 over
-     * buffers of that many rows; the rows past `rows` (M - 16 < rows <= M) carry nothing into partials / p_slabs, and x is read up
+     * buffers of that many rows; the rows past `rows` (0 < rows <= M) carry nothing into partials / p_slabs, and x is read up
      * to row rows - 1 only. */
     int rows;
 } naf_gemm_l1bwd_t;

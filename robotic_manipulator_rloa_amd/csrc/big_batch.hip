@@ -93,6 +93,39 @@ __device__ __forceinline__ static void bb_fold_stats_u(__amdgpu_buffer_rsrc_t p,
     else bb_fold_stats_n<BB_MAX_NB>(p, lane_off, wave_off, H, NB, B, mean, var);
 }
 
+// More than BB_MAX_NB blocks (2048 < B <= 4096: up to BB_MAX_NB2): the partials do not fit a thread's registers at once, so they are
+// read twice — once for the sum, once (out of L2) for the squares about the mean — 16 at a time. The same sums in the same order
+// as above, extended; both the folding workgroups of bb_layer2_head and a thread that folds for itself come here, so the two agree
+// bit for bit as they do below 2048.
+#define BB_MAX_NB2 64
+__device__ static inline void bb_fold_stats_big(const float2* p, int H, int NB, int B, int col, float* mean, float* var) {
+    float S = 0.f;
+    for (int r0 = 0; r0 < NB; r0 += 16) {
+        float2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(r0 + i < NB ? r0 + i : 0) * H + col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S += r0 + i < NB ? v[i].x : 0.f;
+    }
+    const float m = S / (float)B;
+    const float n_last = (float)(B - BB_ROWS * (NB - 1)), inv_last = 1.0f / n_last;
+    float M2 = 0.f;
+    for (int r0 = 0; r0 < NB; r0 += 16) {
+        float2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(r0 + i < NB ? r0 + i : 0) * H + col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rb = r0 + i;
+            const bool lastb = rb == NB - 1;
+            const float d = v[i].x * (lastb ? inv_last : 1.0f / BB_ROWS) - m;
+            M2 += rb < NB ? v[i].y + (lastb ? n_last : (float)BB_ROWS) * d * d : 0.f;
+        }
+    }
+    *mean = m;
+    *var = M2 / (float)B;
+}
+
 // the same for plain sums (backward partials): (sum .x, sum .y) over the NB blocks, block order
 __device__ static inline float2 bb_fold_sums(const float2* __restrict__ p, int H, int NB, int col) {
     float2 v[BB_MAX_NB];
@@ -368,7 +401,7 @@ __device__ static inline void bb_l1_stats_from_moments(const float* sMom, const 
 // Behind the finish blocks, workgroups that add the split-K slabs of the bundle's weight gradients (dW2, dWh) in slab order,
 // 1024 floats each — every gradient element leaves this launch final, with its sum-of-squares partial.
 #define BF_COLS 2
-#define BB_MAX_NB1 64
+#define BB_MAX_NB1 64            // 32-row blocks of the dA1 product held at once (B <= 2048); up to twice as many behind a uniform branch
 struct BbSlabSeg {
     const float* src;       // slab 0; slab s at src + s * stride
     float* dst;
@@ -618,16 +651,26 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
         const int kc = k < F.KP ? k : 0;
         // everything requested up front, branch-free (indices clamped, sums predicated)
         const int Q = (F.NB1 + 3) >> 2, rb0 = (2 * wq + hf) * Q;     // this quarter's run of blocks
-        float pv[BB_MAX_NB1 / 4];
+        float pv[BB_MAX_NB1 / 4], pw[BB_MAX_NB1 / 4];
 #pragma unroll
         for (int i = 0; i < BB_MAX_NB1 / 4; ++i) {
             const int rb = rb0 + i;
             pv[i] = F.p_slabs[((int64_t)((i < Q && rb < F.NB1) ? rb : 0) * F.H + colc) * F.KP + kc];
         }
+        const bool big = F.NB1 > BB_MAX_NB1;               // (uniform) 2048 < B <= 4096: the second half of each quarter's run
+        if (big) {
+#pragma unroll
+            for (int i = 0; i < BB_MAX_NB1 / 4; ++i) {
+                const int j = BB_MAX_NB1 / 4 + i, rb = rb0 + j;
+                pw[i] = F.p_slabs[((int64_t)((j < Q && rb < F.NB1) ? rb : 0) * F.H + colc) * F.KP + kc];
+            }
+        }
         // block sums: wave 0 of the column takes F.partials1 (block = lane), wave 1 the layer-2 bias partials
         float2 av = make_float2(0.f, 0.f);
         float dv = 0.f;
+        float2 aw = make_float2(0.f, 0.f);
         if (wq == 0) av = F.partials1[(int64_t)(lane < F.NB1 ? lane : 0) * F.H + colc];
+        if (wq == 0 && big) aw = F.partials1[(int64_t)(64 + lane < F.NB1 ? 64 + lane : 0) * F.H + colc];
         else if (F.NB > 0) dv = F.dz2_col_partials[(int64_t)(lane < F.NB ? lane : 0) * F.H + colc];   // (NB = 0: no such array)
         const float invstd = F.save_invstd[colc], gm = F.gamma[colc];
         const float sxk = F.mom[kc], wck = F.wc[(int64_t)colc * F.KP + kc];
@@ -639,12 +682,20 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
         float P = 0.f;
 #pragma unroll
         for (int i = 0; i < BB_MAX_NB1 / 4; ++i) P += (i < Q && rb0 + i < F.NB1) ? pv[i] : 0.f;
+        if (big) {
+#pragma unroll
+            for (int i = 0; i < BB_MAX_NB1 / 4; ++i) P += (BB_MAX_NB1 / 4 + i < Q && rb0 + BB_MAX_NB1 / 4 + i < F.NB1) ? pw[i] : 0.f;
+        }
         {
             const float other = __shfl_xor(P, 32);          // quarters (0, 1) of wave 0, (2, 3) of wave 1: lower + upper
             P = hf ? other + P : P + other;
         }
         if (hf == 0) sP[cl][wq][k] = P;
         float sdy = (wq == 0 && lane < F.NB1) ? av.x : 0.f, sdx = (wq == 0 && lane < F.NB1) ? av.y : 0.f;
+        if (big && wq == 0 && 64 + lane < F.NB1) {          // blocks 64 .. 127: the lane's second block
+            sdy += aw.x;
+            sdx += aw.y;
+        }
         float db2 = (wq == 1 && lane < F.NB) ? dv : 0.f;
         sdy = naf_sum64(sdy);
         sdx = naf_sum64(sdx);
@@ -1366,7 +1417,8 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             if (tid < 32) {
                 const int pair = 32 * rb + tid, net = pair >> 8, col = pair & 255;
                 float mean, var;
-                bb_fold_stats(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
+                if (NB64 <= BB_MAX_NB) bb_fold_stats(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
+                else bb_fold_stats_big(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
                 const float invstd = 1.0f / sqrtf(var + eps);
                 const int epoch = *epoch_p;
                 const f32x4 rec = {mean, invstd, __builtin_bit_cast(float, epoch), var};
@@ -1443,7 +1495,8 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             var = c[3];
         } else {
             if (n_fold && errors) __hip_atomic_fetch_add(errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            bb_fold_stats_u(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
+            if (NB64 <= BB_MAX_NB) bb_fold_stats_u(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
+            else bb_fold_stats_big(partials + (int64_t)net * NB64 * H, H, NB64, B, cb + lane, &mean, &var);
             invstd = 1.0f / sqrtf(var + eps);
         }
         sStat[net][0][col] = mean;
@@ -1615,10 +1668,10 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-// (any B from 64 to 2048: the last 64-row block, the last 16-row workgroup of bb_layer2_head and the last MFMA tile may be partial —
+// (any B from 64 to 4096: the last 64-row block, the last 16-row workgroup of bb_layer2_head and the last MFMA tile may be partial —
 //  rows past the batch read as zeros, are never stored and stay out of every sum; the caller's activation buffers hold whole 16-row
 //  groups, zero-initialised, so that the rows past the batch ARE zeros wherever a later launch walks them as a K dimension)
-static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && B <= 32 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
+static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && B <= BB_MAX_NB2 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
 static int bb_blocks(int B) { return (B + BB_ROWS - 1) / BB_ROWS; }
 
 extern "C" int naf_bb_moments_floats(int K) {
@@ -1728,8 +1781,9 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
 }
 // rows per workgroup = rows per block of partials_bw (its consumer, the bundle's BatchNorm-backward prologue, is told B / rows blocks)
 extern "C" int naf_bb_layer2_head_rows(int B) {
-    (void)B;
-    return 16;               // (32 rows per workgroup measured slower at every batch size of the chain: 16.9k -> 17.7k updates/s at B = 2048)
+    // (32 rows per workgroup measured slower at every batch size up to 2048: 16.9k -> 17.7k updates/s there with 16. Beyond 2048 it
+    //  is 32 all the same: the bundle's BatchNorm-backward fold takes at most 128 blocks of backward partials, bn2bwd_fold.h)
+    return B > 32 * BB_ROWS ? 32 : 16;
 }
 
 extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
@@ -1765,7 +1819,11 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
         z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, bb_blocks(B), running_mean, running_var, \
         stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
         loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows, rec, epoch_p, errors, n_fold)
-#define BB_FK(PM, NH4V) BB_FK_R(PM, NH4V, 16)
+#define BB_FK(PM, NH4V)                   \
+    do {                                  \
+        if (rows == 16) BB_FK_R(PM, NH4V, 16); \
+        else BB_FK_R(PM, NH4V, 32);       \
+    } while (0)
 #define BB_FK_NH(PM)                     \
     do {                                 \
         if (NHP == 16) BB_FK(PM, 4);     \
@@ -1800,7 +1858,7 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
         return NAF_ERR_ARG;
     if (push && (push->world < 2 || push->world > NAF_XGMI_MAX_WORLD || ((uintptr_t)grad_base & 15))) return NAF_ERR_ARG;
     if (!p_slabs || !partials1 || (nb > 0 && !dz2_col_partials) || !mom || !wc || !gamma || !save_invstd || !d_W || !d_gamma || !d_beta ||
-        !d_bias || !d_bias2 || nb < 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
+        !d_bias || !d_bias2 || nb < 0 || nb > BB_MAX_NB || nb1 <= 0 || nb1 > 2 * BB_MAX_NB1 || H <= 0 || B <= 0 || K <= 0 || K > 32)
         return NAF_ERR_ARG;
     if (sumsq_partials && (!d_gamma2 || !d_beta2)) return NAF_ERR_ARG;
     if (n_segs < 0 || n_segs > 2 || (n_segs && !segs)) return NAF_ERR_ARG;

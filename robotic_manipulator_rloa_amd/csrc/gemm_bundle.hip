@@ -627,7 +627,7 @@ extern "C" int naf_gemm_bundle_ex(const naf_gemm_desc_t* descs, int n, int form,
             if (!e.x || !e.W || !e.bias || !e.a1 || !e.save_mean || !e.save_invstd || !e.partials || !e.p_slabs || ksn != 1 ||
                 (s.M & 15) || (s.N & 31) || e.K <= 0 || (e.kp != 24 && e.kp != 32) || e.K > e.kp || e.ldx < e.kp || (e.ldx & 3) ||
                 e.lda1 < s.N || ((uintptr_t)e.x & 15) || ((uintptr_t)e.partials & 7) || (e.xhat && (!e.gamma || !e.beta)) ||
-                e.rows < 0 || e.rows > s.M || (e.rows && e.rows <= s.M - 16))
+                e.rows < 0 || e.rows > s.M)
                 return NAF_ERR_ARG;
             d.epi = e;
             if (!d.epi.rows) d.epi.rows = s.M;

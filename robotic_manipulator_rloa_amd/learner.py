@@ -161,7 +161,7 @@ class Learner:
         #              BatchNorm statistics, GEMM 2 on f32 MFMA, layer 2 + heads + NAF head + first backward stage in one launch
         #              (hk), the backward GEMMs as one launch (gb) that also carries the second stage of layer 2's BatchNorm
         #              backward as its prologue (s2) and the batch pass of layer 1's backward as its epilogue (ep), a finish
-        #              launch — 5 launches per update in a chain of updates. Needs 64 <= B <= 2048 (any size in it), H = 256, S <= 26.
+        #              launch — 5 launches per update in a chain of updates. Needs 64 <= B <= 4096 (any size in it), H = 256, S <= 26.
         #              Default wherever the shape fits (measured at the end of round 3, updates/s, column-tile | row-split: B = 64:
         #              32.3k | 36.0k, 128: 30.7k | 35.4k, 192: 25.8k | 34.0k, 256: 25.7k | 34.7k, 512: 20.3k | 30.9k; until then the
         #              column-tile chain led below B = 256 — 32.5k | 29.3k at 64 in round 2).
@@ -170,22 +170,23 @@ class Learner:
         #              the BatchNorm kernels, 8 launches per update. B <= 512. Default below B = 64 (and up to 512 where H or S
         #              do not fit the row-split chain).
         #   "unfused"  {gb} or {}: torch (rocBLAS) GEMMs + the BatchNorm / head kernels of csrc/bn_relu.hip, naf_head.hip, with
-        #              the backward GEMM bundle where its shapes allow (B, H multiples of 16) — any shape up to B = 2048; 14
+        #              the backward GEMM bundle where its shapes allow (B, H multiples of 16) — any shape up to B = 4096; 14
         #              launches per update (round 1's chain: 12.7k updates/s at B = 1024).
         # NAF_FUSE = rows | columns | unfused overrides the choice (a chain whose shape limits are not met falls to the next).
         lay0 = self.lay
-        # The reference takes any positive batch_size (rl_framework.py:186-189). Here: every size up to 4096 trains — 64 ... 2048
-        # on the row-split chain, smaller ones on the column-tile chain, everything else on the unfused chain (beyond 2048 with
-        # the streamed BatchNorm kernels of csrc/bn_relu.hip) with a warning that names the row-split chain's range. 4096 is
+        # The reference takes any positive batch_size (rl_framework.py:186-189). Here: every size up to 4096 trains — 64 ... 4096
+        # on the row-split chain, smaller ones on the column-tile chain, other layer / state sizes on the unfused chain (beyond 2048
+        # with the streamed BatchNorm kernels of csrc/bn_relu.hip) with a warning that names the row-split chain's range. 4096 is
         # the replay sampler's limit (one workgroup draws a minibatch without replacement in LDS, csrc/replay.hip).
         if self.B < 1 or self.B > 4096:
             raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 4096 (the sampler draws a minibatch in one workgroup's LDS)")
-        # (round 4: ANY batch size from 64 to 2048 — the last 64-row block of layer 1 / GEMM 2, the last 16-row workgroup of the fused
+        # (round 4: ANY batch size from 64 to 4096 — the last 64-row block of layer 1 / GEMM 2, the last 16-row workgroup of the fused
         #  layer-2 + head launch and the last block of the bundle's dA1 product may be partial: rows past the batch read as zeros, are
-        #  never stored and stay out of every statistic and sum. The work buffers hold Bp = the next multiple of 16 rows,
+        #  never stored and stay out of every statistic and sum. The work buffers hold Bp = the next multiple of 16 rows (of 32 beyond
+        #  B = 2048, where the fused layer-2 + head launch runs 32 rows per workgroup),
         #  zero-initialised: the weight-gradient products walk Bp rows as their K dimension, and a row past the batch is a zero in at
         #  least one operand of each — dH and dY2 rows the head body never writes, A1 rows layer 1 never stores.)
-        self.bb_ok = (64 <= self.B <= 2048 and lay0.H == 256 and lay0.S <= 26)
+        self.bb_ok = (64 <= self.B <= 4096 and lay0.H == 256 and lay0.S <= 26)
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
@@ -211,7 +212,7 @@ class Learner:
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)
             import warnings
             warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
-                          f"row-split chain): the row-split kernels need 64 <= batch_size <= 2048, layer_size 256 and "
+                          f"row-split chain): the row-split kernels need 64 <= batch_size <= 4096, layer_size 256 and "
                           f"state_size <= 26", stacklevel=3)
         # with every gradient element produced by one of our own kernels, those kernels also emit its sum-of-squares partial:
         # the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken on the all-reduced gradient).
@@ -222,7 +223,10 @@ class Learner:
         f32 = dict(dtype=torch.float32, device=dev)
         P, H, HP, NHP = lay.P, lay.H, lay.HP, lay.NHP
         # rows of the work buffers: whole 16-row groups on the row-split chain (see bb_ok above), B everywhere else
-        self.Bp = Bp = -(-B // 16) * 16 if "bb" in self.fuse else B
+        # (beyond B = 256 whole 64-row blocks: the K ranges of the weight-gradient products then divide as they do for the next
+        #  multiple of 64 — B = 1000 runs the products of B = 1024 with 24 zero rows, four 256-row ranges instead of three of 336)
+        hk_rows = (self.lib.naf_bb_layer2_head_rows(B) if B <= 256 else 64) if "bb" in self.fuse else 1
+        self.Bp = Bp = -(-B // hk_rows) * hk_rows
 
         # ---- persistent state --------------------------------------------------------------------------
         self.theta2 = torch.zeros(2, P, **f32)             # [main; target]
@@ -303,7 +307,7 @@ class Learner:
         self.q_out = torch.empty(B, **f32)
         if "bb" in self.fuse:
             NB = -(-B // 64)                                     # 64-row statistics blocks (the last may hold 16, 32 or 48 rows)
-            NB1 = -(-B // 32)                                    # 32-row blocks of the bundle's dA1 product
+            NB1 = -(-Bp // 32)                                   # 32-row blocks of the bundle's dA1 product (M = Bp rows)
             kp = self.lib.naf_bb_layer1_bwd_kp(lay.S)
             # moments record of one minibatch's layer-1 inputs, [net][Sx | C]: everything layer 1's BatchNorm needs from
             # the batch dimension (TrainChunk computes the records of all its minibatches in one launch behind the gather)
@@ -366,7 +370,7 @@ class Learner:
             def blocks(M, N, k_split):
                 """32 x 32 blocks of one product of the bundle (csrc/gemm_bundle.hip)"""
                 return ((M + 31) // 32) * ((N + 31) // 32) * k_split
-            ks = Bp // 256 if Bp % 256 == 0 else k_ranges(256, 8)
+            ks = Bp // 256 if (Bp % 256 == 0 and Bp <= 2048) else k_ranges(256, 8)      # (at most 8 slabs: csrc/big_batch.hip)
             ks_w2 = ks_wh = ks
             # Which form of the bundle launch (include/naf_hip.h, naf_gemm_bundle_ex): one 32 x 32 block per workgroup (form 1, the
             # default at every batch size) or the LDS-DMA ring on 64 x 32 tiles (form 2, csrc/gemm_ring.h; NAF_GEMM_FORM = 2 opts in
