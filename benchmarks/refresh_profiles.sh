@@ -15,10 +15,12 @@ stats)     # rocprofv3 kernel-trace stats + digest of the bench at configs[1] an
   benchmarks/prof_bench.sh r04_b512 200 30 --batch 512 > gpurun_out/prof_b512.log 2>&1; tail -2 gpurun_out/prof_b512.log
   benchmarks/prof_bench.sh r04_b1024 150 20 --batch 1024 --robot xarm6_robot --obstacle-jitter 0.1 > gpurun_out/prof_b1024.log 2>&1; tail -2 gpurun_out/prof_b1024.log
   benchmarks/prof_bench.sh r04_b2048 100 15 --batch 2048 --robot panda --buffer 4000000 > gpurun_out/prof_b2048.log 2>&1; tail -2 gpurun_out/prof_b2048.log ;;
-small)     # small batches: configs[0]'s batch and the reference's default (row-split chain), and B = 96 (column-tile chain)
+small)     # other batch sizes: configs[0]'s batch, the reference's default, sizes that are not whole 16-row groups, and B = 4096
   benchmarks/prof_bench.sh r04_b64 300 40 --batch 64 --buffer 100000 > gpurun_out/prof_b64.log 2>&1; tail -2 gpurun_out/prof_b64.log
   benchmarks/prof_bench.sh r04_b128 300 40 --batch 128 --buffer 100000 > gpurun_out/prof_b128.log 2>&1; tail -2 gpurun_out/prof_b128.log
-  benchmarks/prof_bench.sh r04_b100 300 40 --batch 100 --buffer 100000 > gpurun_out/prof_b100.log 2>&1; tail -2 gpurun_out/prof_b100.log ;;
+  benchmarks/prof_bench.sh r04_b100 300 40 --batch 100 --buffer 100000 > gpurun_out/prof_b100.log 2>&1; tail -2 gpurun_out/prof_b100.log
+  benchmarks/prof_bench.sh r04_b1000 150 20 --batch 1000 > gpurun_out/prof_b1000.log 2>&1; tail -2 gpurun_out/prof_b1000.log
+  benchmarks/prof_bench.sh r04_b4096 60 10 --batch 4096 > gpurun_out/prof_b4096.log 2>&1; tail -2 gpurun_out/prof_b4096.log ;;
 sweep)     # SURVEY 8d bulk sweep of the streaming kernels, HIP events (the table) AND rocprofv3 kernel stats of the same process
   d=/tmp/prof_sweep; rm -rf $d
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r04_sweep -- python3 benchmarks/roofline_sweep.py > gpurun_out/r04_roofline_sweep.md 2> gpurun_out/sweep.err
