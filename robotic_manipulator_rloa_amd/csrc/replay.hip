@@ -329,14 +329,21 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
     if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
     if (!idx || B <= 0 || B > 4096 || n_batches <= 0) return NAF_ERR_ARG;
     int threads = B >= 1024 ? 1024 : naf_round_up(B, 64);
-    // duplicate check through a hash table of M = 2^bits >= 2 B slots when B + 2 M ints fit the 64 KB a workgroup gets by
-    // default (B <= 2048); the scan beyond
+    // duplicate check through a hash table of M = 2^bits >= 2 B slots: B + 2 M ints of LDS — up to 80 KB at B = 4096, more than
+    // the 64 KB a workgroup gets without asking (gfx950 has 160 KB per CU), so the kernel's limit is raised once per process.
+    // (Until round 4 the larger batches fell back to the O(B^2) scan: 392 us per launch at B = 4096 against 12 at 2048.)
     int bits = 1;
     while ((1 << bits) < 2 * B) ++bits;
     size_t lds_ints = (size_t)B + 2 * ((size_t)1 << bits);
     if (lds_ints * sizeof(int) > 64 * 1024) {
-        bits = 0;
-        lds_ints = 0;
+        static int raised = 0;       // 0 = not tried, 1 = raised, -1 = refused (then: the scan)
+        if (!raised)
+            raised = hipFuncSetAttribute((const void*)replay_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) ==
+                             hipSuccess ? 1 : -1;
+        if (raised < 0 || lds_ints * sizeof(int) > 96 * 1024) {
+            bits = 0;
+            lds_ints = 0;
+        }
     }
     if (lds_ints < (size_t)B * 4) lds_ints = (size_t)B * 4;
     replay_sample_kernel<<<n_batches, threads, lds_ints * sizeof(int), (hipStream_t)stream>>>(

@@ -195,11 +195,12 @@ def test_replay_sample_api_contract_matches_reference_golden(lib):
     assert len(set(ids.tolist())) == B and ids.min() >= 200 and ids.max() <= 499
 
 
-# (duplicates are resolved through an LDS hash table up to B = 2048 and by a scan beyond: (300, 64), (5000, 1024), (9000, 2048)
-#  and (20000, 2048) redraw dozens to hundreds of elements over several rounds, (50000, 4096) takes the scan, 100 and 48 are
-#  not powers of two)
+# (duplicates are resolved through an LDS hash table — up to 80 KB of LDS at B = 4096, csrc/replay.hip: (300, 64), (5000, 1024),
+#  (9000, 2048), (20000, 2048), (20000, 4096) and (9000, 3000) redraw dozens to hundreds of elements over several rounds; 100, 48
+#  and 3000 are not powers of two)
 @pytest.mark.parametrize("size,B,nb", [(1000, 256, 8), (257, 256, 3), (300, 64, 5), (100000, 2048, 2), (5000, 1024, 2),
-                                       (9000, 2048, 3), (20000, 2048, 4), (50000, 4096, 2), (700, 100, 6), (200, 48, 9),
+                                       (9000, 2048, 3), (20000, 2048, 4), (50000, 4096, 2), (20000, 4096, 3), (9000, 3000, 2),
+                                       (700, 100, 6), (200, 48, 9),
                                        (1_000_000, 256, 64)])
 def test_replay_sampler_bit_exact_vs_oracle(lib, size, B, nb):
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
