@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--robot", default="kuka")
     ap.add_argument("--updates", type=int, default=64)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--reps", type=int, default=1, help="average the marks of this many replays")
     args = ap.parse_args()
     if "NAF_TIMELINE" not in os.environ.get("NAF_BUILD_DEFINES", ""):
         raise SystemExit("build with NAF_BUILD_DEFINES=-DNAF_TIMELINE")
@@ -68,13 +69,32 @@ def main():
         chunk.run()
     torch.cuda.synchronize()
     lib = L.lib
-    raw = {}
-    for kid, name in enumerate(KERNELS):
-        buf = (C.c_longlong * 32)()
-        rc = lib.naf_timeline_read(kid, buf)
-        if rc != 0:
-            raise SystemExit(f"naf_timeline_read({name}) = {rc}")
-        raw[name] = [list(buf[:16]), list(buf[16:])]
+
+    def read_marks():
+        raw = {}
+        for kid, name in enumerate(KERNELS):
+            buf = (C.c_longlong * 32)()
+            rc = lib.naf_timeline_read(kid, buf)
+            if rc != 0:
+                raise SystemExit(f"naf_timeline_read({name}) = {rc}")
+            raw[name] = [list(buf[:16]), list(buf[16:])]
+        return raw
+    raw = read_marks()
+    if args.reps > 1:
+        # --reps N: the last update of N replays, every mark averaged relative to that replay's first entry (one pass is +- 0.4 us
+        # on a kernel: enough to see a phase, not to compare two builds)
+        acc = {name: [[0.0] * 16, [0.0] * 16] for name in KERNELS}
+        for _ in range(args.reps):
+            chunk.run()
+            torch.cuda.synchronize()
+            r = read_marks()
+            t0r = min(r[KERNELS[0]][w][0] for w in (0, 1))
+            for name in KERNELS:
+                for w in (0, 1):
+                    for i in range(16):
+                        acc[name][w][i] += (r[name][w][i] - t0r) if r[name][w][i] > 0 else -1e15
+        raw = {name: [[acc[name][w][i] / args.reps if acc[name][w][i] > -1e14 else -1e9 for i in range(16)] for w in (0, 1)]
+               for name in KERNELS}
     # the marks are those of the LAST update of the last replay: one consistent pass through the chain
     t0 = min(raw[KERNELS[0]][w][0] for w in (0, 1))
     out = {"batch": B, "robot": args.robot, "fuse": sorted(L.fuse), "unit": "us since the first kernel's entry", "kernels": {}}

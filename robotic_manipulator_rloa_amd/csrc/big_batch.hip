@@ -38,6 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define BB_MAX_NB 32
 NAF_TL_DECL(g_tl_bb);
 NAF_TL_READER(naf_tl_read_bb, g_tl_bb)
+template <bool FULL>
 __device__ static inline void bb_fold_stats(const float2* __restrict__ p, int H, int NB, int B, int col, float* mean,
                                             float* var) {
     float2 v[BB_MAX_NB];
@@ -48,11 +49,11 @@ __device__ static inline void bb_fold_stats(const float2* __restrict__ p, int H,
     for (int rb = 0; rb < BB_MAX_NB; ++rb) S += rb < NB ? v[rb].x : 0.f;
     const float m = S / (float)B;
     float M2 = 0.f;
-    // (the last block holds B - 64 (NB - 1) rows: 64 where the batch is whole blocks — then this is the arithmetic it always was)
-    const float n_last = (float)(B - BB_ROWS * (NB - 1)), inv_last = 1.0f / n_last;
+    // (the last block holds B - 64 (NB - 1) rows: 64 where the batch is whole blocks (FULL) — then this is the arithmetic it always was)
+    const float n_last = FULL ? (float)BB_ROWS : (float)(B - BB_ROWS * (NB - 1)), inv_last = FULL ? 1.0f / BB_ROWS : 1.0f / n_last;
 #pragma unroll
     for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-        const bool lastb = rb == NB - 1;
+        const bool lastb = !FULL && rb == NB - 1;
         const float d = v[rb].x * (lastb ? inv_last : 1.0f / BB_ROWS) - m;
         M2 += rb < NB ? v[rb].y + (lastb ? n_last : (float)BB_ROWS) * d * d : 0.f;
     }
@@ -64,7 +65,7 @@ __device__ static inline void bb_fold_stats(const float2* __restrict__ p, int H,
 // thread): one instance per size class behind a UNIFORM branch, so a batch of 256 (NB = 4) executes 4 block steps, not
 // 32 predicated ones, and buffer loads (common.h: naf_buf_*): wave-uniform resource and block offset, one lane offset.
 // p = the partials; the thread's (block 0) element at byte wave_off + lane_off. Same arithmetic and order as above.
-template <int NMAX>
+template <int NMAX, bool FULL>
 __device__ __forceinline__ static void bb_fold_stats_n(__amdgpu_buffer_rsrc_t p, unsigned lane_off, unsigned wave_off, int H, int NB,
                                                        int B, float* mean, float* var) {
     naf_f32x2 v[NMAX];
@@ -75,22 +76,24 @@ __device__ __forceinline__ static void bb_fold_stats_n(__amdgpu_buffer_rsrc_t p,
     for (int rb = 0; rb < NMAX; ++rb) S += rb < NB ? v[rb].x : 0.f;
     const float m = S / (float)B;
     float M2 = 0.f;
-    const float n_last = (float)(B - BB_ROWS * (NB - 1)), inv_last = 1.0f / n_last;      // (see bb_fold_stats)
+    // (FULL: whole 64-row blocks — no last-block weights and no division; the same bits as the general form gives there)
+    const float n_last = FULL ? (float)BB_ROWS : (float)(B - BB_ROWS * (NB - 1)), inv_last = FULL ? 1.0f / BB_ROWS : 1.0f / n_last;
 #pragma unroll
     for (int rb = 0; rb < NMAX; ++rb) {
-        const bool lastb = rb == NB - 1;
+        const bool lastb = !FULL && rb == NB - 1;
         const float d = v[rb].x * (lastb ? inv_last : 1.0f / BB_ROWS) - m;
         M2 += rb < NB ? v[rb].y + (lastb ? n_last : (float)BB_ROWS) * d * d : 0.f;
     }
     *mean = m;
     *var = M2 / (float)B;
 }
+template <bool FULL>
 __device__ __forceinline__ static void bb_fold_stats_u(__amdgpu_buffer_rsrc_t p, unsigned lane_off, unsigned wave_off, int H, int NB,
                                                        int B, float* mean, float* var) {
-    if (NB <= 4) bb_fold_stats_n<4>(p, lane_off, wave_off, H, NB, B, mean, var);            // B <= 256 (uniform branches)
-    else if (NB <= 8) bb_fold_stats_n<8>(p, lane_off, wave_off, H, NB, B, mean, var);
-    else if (NB <= 16) bb_fold_stats_n<16>(p, lane_off, wave_off, H, NB, B, mean, var);
-    else bb_fold_stats_n<BB_MAX_NB>(p, lane_off, wave_off, H, NB, B, mean, var);
+    if (NB <= 4) bb_fold_stats_n<4, FULL>(p, lane_off, wave_off, H, NB, B, mean, var);            // B <= 256 (uniform branches)
+    else if (NB <= 8) bb_fold_stats_n<8, FULL>(p, lane_off, wave_off, H, NB, B, mean, var);
+    else if (NB <= 16) bb_fold_stats_n<16, FULL>(p, lane_off, wave_off, H, NB, B, mean, var);
+    else bb_fold_stats_n<BB_MAX_NB, FULL>(p, lane_off, wave_off, H, NB, B, mean, var);
 }
 
 // More than BB_MAX_NB blocks (2048 < B <= 4096: up to BB_MAX_NB2): the partials do not fit a thread's registers at once, so they are
@@ -584,7 +587,10 @@ __device__ static inline void bb_finish_exchange(const FinishArgs& F, int block,
     }
 }
 
-// One workgroup (BB_THREADS threads) of the finish work.
+// One workgroup (BB_THREADS threads) of the finish work. MERGE: the gradient exchange of data parallel inside this launch
+// (F.merge; a kernel of its own so that the launch of one GPU — and of the separate all-reduce — carries none of its code: with a
+// run-time flag the single-GPU update was 0.25 us slower, A/B on one box).
+template <bool MERGE, bool BIG>
 __device__ static inline void bb_finish_block(const FinishArgs& F, int block, int tid, float* sQ, float (*sP)[2][32]) {
     // (no FP contraction: the gradient of a build rounds the same way whatever the optimizer makes of this body)
 #pragma clang fp contract(off)
@@ -632,7 +638,7 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
                 for (int p = 0; p < NAF_XGMI_MAX_WORLD; ++p)
                     if (p < F.push.world) {
                         float* sl = xg_slot((char*)F.push.peer_base[p], F.push.data_off, F.push.n_pad, F.push.world, e, F.push.rank) + o;
-                        if (F.merge) bb_push_st(sl, v);
+                        if (MERGE) bb_push_st(sl, v);
                         else *(xg_f4*)sl = v;
                     }
             }
@@ -657,7 +663,7 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
             const int rb = rb0 + i;
             pv[i] = F.p_slabs[((int64_t)((i < Q && rb < F.NB1) ? rb : 0) * F.H + colc) * F.KP + kc];
         }
-        const bool big = F.NB1 > BB_MAX_NB1;               // (uniform) 2048 < B <= 4096: the second half of each quarter's run
+        const bool big = BIG;                              // 2048 < B <= 4096 (more than 64 dA1 blocks): the second half of each quarter's run
         if (big) {
 #pragma unroll
             for (int i = 0; i < BB_MAX_NB1 / 4; ++i) {
@@ -707,23 +713,23 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
                     const float invB = 1.0f / (float)F.B;
                     const float Pt = sP[cl][0][k] + sP[cl][1][k];
                     const float g = (gm * invstd) * (Pt - (sdy * invB) * sxk - (sdx * invB) * (invstd * wck));
-                    bb_st(F.d_W + (int64_t)col * F.K + k, g, F.merge);
+                    bb_st(F.d_W + (int64_t)col * F.K + k, g, MERGE);
                     sq = g * g;
                 } else if (lane == 32) {                      // F.d_gamma = sum dy*xhat, F.d_beta = sum dy; F.d_bias = 0 (see above)
-                    bb_st(F.d_gamma + col, sdx, F.merge);
-                    bb_st(F.d_beta + col, sdy, F.merge);
-                    bb_st(F.d_bias + col, 0.f, F.merge);
+                    bb_st(F.d_gamma + col, sdx, MERGE);
+                    bb_st(F.d_beta + col, sdy, MERGE);
+                    bb_st(F.d_bias + col, 0.f, MERGE);
                     sq = sdx * sdx + sdy * sdy;
                 }
             } else if (lane == 0) {
-                bb_st(F.d_bias2 + col, db2, F.merge);
+                bb_st(F.d_bias2 + col, db2, MERGE);
                 sq = db2 * db2;
             } else if (lane == 1) {
                 sq = g2 * g2 + b2 * b2;
             }
         }
     }
-    if (F.merge) {
+    if (MERGE) {
         bb_finish_exchange(F, block, tid, ex_a, ex_o, ex_on, sQ);
         return;
     }
@@ -736,11 +742,12 @@ __device__ static inline void bb_finish_block(const FinishArgs& F, int block, in
     }
 }
 
+template <bool MERGE, bool BIG>
 __global__ __launch_bounds__(BB_THREADS) void bb_layer1_bwd_finish_kernel(const FinishArgs F) {
     __shared__ float sQ[BB_THREADS / 64];
     __shared__ float sP[BF_COLS][2][32];
     NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 0);
-    bb_finish_block(F, (int)blockIdx.x, (int)threadIdx.x, sQ, sP);
+    bb_finish_block<MERGE, BIG>(F, (int)blockIdx.x, (int)threadIdx.x, sQ, sP);
     NAF_TL(g_tl_bb, NAF_TL_BB_FINISH, 1);
 }
 
@@ -775,7 +782,9 @@ __device__ __forceinline__ static bool bb_place_rows(int w, int shift, int NB, i
 // for the parameters they read (gradient, moments, the main network's old value for the target's workgroups) and evaluate
 // them as the step will leave them. Costs one more barrier (the clip scale must exist before the weights go to LDS).
 // The grid is one-dimensional: workgroup = rb + B/64 (column tile + H/64 net), the order the 3-D grid had.
-template <int K4, bool ADAM>
+// FULL: the batch is whole 64-row blocks (every BASELINE config) — `valid` is then the constant 64 and the row masks, clamps and
+// resource bounds of the partial last block fold away at compile time (with them at run time an update at B = 256 was 0.3 us slower)
+template <int K4, bool ADAM, bool FULL>
 __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_kernel(
     const float* __restrict__ x, int64_t x_net_stride, int ldx, int K, const float* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -824,7 +833,7 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
     const float* xn = x + net * x_net_stride + (int64_t)rb * BB_ROWS * ldx;
     // rows of this block that exist (the last block of a batch that is not whole 64-row blocks holds fewer): rows past them are
     // read as copies of row 0 and never stored (the output resources end at the last row that exists)
-    const int valid = B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS;
+    const int valid = FULL ? BB_ROWS : (B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS);
     // ADAM: the workgroup has 512 threads. Threads 0 .. 255 are the layer-1 workgroup as ever; ALL 512 take part in evaluating
     // the parameters as the pending step leaves them (one float4 = four elements per thread: the update formula is ~100
     // instructions per element — a division and a square root, correctly rounded), then waves 4 .. 7 are done.
@@ -956,7 +965,7 @@ __global__ __launch_bounds__(ADAM ? 2 * BB_THREADS : BB_THREADS) void bb_layer1_
                 xh4[j] = xh;
                 yp[j] = t > 0.f ? t : 0.f;
             }
-            const unsigned obytes = ((unsigned)(valid - 1) * (unsigned)ldo + BB_COLS) * 4u;
+            const unsigned obytes = FULL ? 0x7fffffffu : ((unsigned)(valid - 1) * (unsigned)ldo + BB_COLS) * 4u;
             naf_buf_st_f4(naf_buf(oz + (int64_t)(rb * BB_ROWS) * ldo + col0, obytes), 4u * (unsigned)((4 * ty_ + i) * ldo + 4 * tx_), 0,
                           (f32x4){y.x, y.y, y.z, y.w}, B >= NAF_WT_MIN_B);
             // the main network's xhat too where the backward wants it ready-made (naf_gemm_l1bwd_t.xhat: small batches)
@@ -1118,7 +1127,7 @@ __device__ __forceinline__ static void bl_store_chunk(const f32x4 (&va)[8], cons
 // ADAM (the deferred optimizer step, adam_body.h): the one-dimensional grid carries, behind its n_main GEMM workgroups (index =
 // x + gx y of the former 2-D grid, gx = nets B/64), extra workgroups that step floats [0, 4 l1_4) of the flat buffers — the
 // layer-1 segment, which the launch in front of this one read for the last time.
-template <bool ADAM>
+template <bool ADAM, bool FULL>
 __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3))) void bb_linear_stats_kernel(const float* __restrict__ a, int64_t a_net_stride,
                                                                      int lda, const float* __restrict__ W,
                                                                      const float* __restrict__ bias,
@@ -1150,7 +1159,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     if (xcd_nets && gx == 2 * NB) bb_place_rows(widx, 0, NB, n_main / gx, net, rb, by);     // rows by eighths (see bb_place_rows)
     // rows of this block that exist (64 but for the last block of a batch that is not whole blocks, B % 16 == 0): rows past them
     // read as zeros (the A resource ends there), are not stored (the Z resource ends there) and stay out of the statistics
-    const int valid = B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS;
+    const int valid = FULL ? BB_ROWS : (B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS);
     const int n0 = by * BL_BN;
     const float* an = a + net * a_net_stride + (int64_t)rb * BL_BM * lda;
     const float* wn_ = W + net * param_net_stride + (int64_t)n0 * K;     // [N][K] row-major
@@ -1168,7 +1177,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     // (all 24 loads up front made the register allocator park 12 of them in scratch)
     f32x4 va1[8], vb1[4];
     BL_TL(0);
-    const __amdgpu_buffer_rsrc_t ab = naf_buf(an, (unsigned)valid * (unsigned)lda * 4u), wb = naf_buf(wn_);
+    const __amdgpu_buffer_rsrc_t ab = naf_buf(an, FULL ? 0x7fffffffu : (unsigned)valid * (unsigned)lda * 4u), wb = naf_buf(wn_);
     const unsigned la = ((unsigned)(tid >> 5) * (unsigned)lda + 4u * (unsigned)(tid & 31)) * 4u;
     const unsigned lw = ((unsigned)(tid >> 5) * (unsigned)K + 4u * (unsigned)(tid & 31)) * 4u;
     bl_load_chunk_buf(va, vb, ab, la, lda, wb, lw, K, 0);
@@ -1189,14 +1198,14 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     float v[2][4];
     float s = 0.f;
     const __amdgpu_buffer_rsrc_t zb_ = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM) * ldz + n0,
-                                               ((unsigned)(valid - 1) * (unsigned)ldz + BL_BN) * 4u);
+                                               FULL ? 0x7fffffffu : ((unsigned)(valid - 1) * (unsigned)ldz + BL_BN) * 4u);
     const unsigned lz_ = 4u * (unsigned)((32 * wm + 4 * g) * ldz + 16 * wn + r);
     bool on[2][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            on[mt][e] = 32 * wm + 16 * mt + 4 * g + e < valid;
+            on[mt][e] = FULL || 32 * wm + 16 * mt + 4 * g + e < valid;
             v[mt][e] = (mt ? c10[e] + c11[e] : c00[e] + c01[e]) + bcol;
             naf_buf_st_f1(zb_, lz_, (unsigned)((16 * mt + e) * ldz) * 4u, v[mt][e], B >= NAF_WT_MIN_B);
             s += on[mt][e] ? v[mt][e] : 0.f;
@@ -1206,7 +1215,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     if (g == 0) red[wm][16 * wn + r] = s;
     __syncthreads();
     const float S = red[0][16 * wn + r] + red[1][16 * wn + r];
-    const float mb = S * (valid == BB_ROWS ? 1.0f / BB_ROWS : 1.0f / (float)valid);
+    const float mb = S * ((FULL || valid == BB_ROWS) ? 1.0f / BB_ROWS : 1.0f / (float)valid);
     float m2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -1228,7 +1237,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
 // each spends 2 x 1.2 us in its two MFMA phases — a quarter of the chip busy, latency all the way. Half as wide, twice as
 // many workgroups (wave w = rows 16 w .. +15, one MFMA tile): the MFMA phases halve. The statistics blocks stay 64 rows, so
 // the partials and every consumer are unchanged.
-template <bool ADAM>
+template <bool ADAM, bool FULL>
 __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const float* __restrict__ a, int64_t a_net_stride, int lda,
                                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                                        int64_t param_net_stride, float* __restrict__ z,
@@ -1258,11 +1267,12 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     const int NB = (B + BB_ROWS - 1) / BB_ROWS;
     int net = bx / NB, rb = bx - net * NB;
     if (xcd_nets && gx == 2 * NB) bb_place_rows(widx, 0, NB, n_main / gx, net, rb, by);     // rows by eighths (see bb_place_rows)
-    const int valid = B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS;              // (see bb_linear_stats_kernel)
+    const int valid = FULL ? BB_ROWS : (B - rb * BB_ROWS < BB_ROWS ? B - rb * BB_ROWS : BB_ROWS);   // (see bb_linear_stats_kernel)
     const int n0 = by * BN;
     const int r = lane & 15, g = lane >> 4;
     // operands through buffer loads (common.h): A rows (tid >> 5) + 8 i, float4 (tid & 31); B rows (tid >> 5) + 8 i < 16
-    const __amdgpu_buffer_rsrc_t ab = naf_buf(a + net * a_net_stride + (int64_t)rb * BL_BM * lda, (unsigned)valid * (unsigned)lda * 4u);
+    const __amdgpu_buffer_rsrc_t ab = naf_buf(a + net * a_net_stride + (int64_t)rb * BL_BM * lda,
+                                              FULL ? 0x7fffffffu : (unsigned)valid * (unsigned)lda * 4u);
     const __amdgpu_buffer_rsrc_t wb = naf_buf(W + net * param_net_stride + (int64_t)n0 * K);
     const unsigned la = ((unsigned)(tid >> 5) * (unsigned)lda + 4u * (unsigned)(tid & 31)) * 4u;
     const unsigned lw = ((unsigned)(tid >> 5) * (unsigned)K + 4u * (unsigned)(tid & 31)) * 4u;
@@ -1319,13 +1329,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
         const int vw = valid - 16 * wave;                 // rows of this wave's 16 that exist (<= 0: none)
         const int vwc = vw > 16 ? 16 : vw;
         const __amdgpu_buffer_rsrc_t zb = naf_buf(z + net * z_net_stride + (int64_t)(rb * BL_BM + 16 * wave) * ldz + n0,
-                                                  vw > 0 ? ((unsigned)(vwc - 1) * (unsigned)ldz + BN) * 4u : 0u);
+                                                  FULL ? 0x7fffffffu : vw > 0 ? ((unsigned)(vwc - 1) * (unsigned)ldz + BN) * 4u : 0u);
         const unsigned lz = (unsigned)(4 * g) * ldz4 + 4u * (unsigned)r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[e] = (c0[e] + c1[e]) + bcol;
             naf_buf_st_f1(zb, lz, (unsigned)e * ldz4, v[e], B >= NAF_WT_MIN_B);
-            sum += 4 * g + e < vw ? v[e] : 0.f;
+            sum += (FULL || 4 * g + e < vw) ? v[e] : 0.f;
         }
     }
     const int vw_ = valid - 16 * wave;
@@ -1333,12 +1343,12 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     if (g == 0) red[wave][r] = sum;
     __syncthreads();
     const float S = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
-    const float mb = S * (valid == BB_ROWS ? 1.0f / BB_ROWS : 1.0f / (float)valid);
+    const float mb = S * ((FULL || valid == BB_ROWS) ? 1.0f / BB_ROWS : 1.0f / (float)valid);
     float m2 = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float t = v[e] - mb;
-        m2 += 4 * g + e < vw_ ? t * t : 0.f;
+        m2 += (FULL || 4 * g + e < vw_) ? t * t : 0.f;
     }
     m2 = naf_xor32_add(naf_xor16_add(m2));
     __syncthreads();
@@ -1365,7 +1375,10 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
 #define FK_LD (FK_H + 4)
 // ROWS = 16 (B <= 1024): twice the workgroups, each phase of this latency chain roughly half as long (rows per wave in the
 // normalise phase, MFMA tiles per wave in the two products); the backward partials are then per 16-row block.
-template <int PMODE, int NH4, int ROWS>
+// FULL: whole 64-row blocks, at most 32 of them (every BASELINE config): the kernel as it was before round 4 took other batch sizes
+// — every row of every workgroup is a sample, the statistics fold has no last-block weights and no two-pass form. The general form
+// is a kernel of its own: inside one kernel its extra paths (never taken at these sizes) cost 0.2 us per update at B = 256.
+template <int PMODE, int NH4, int ROWS, bool FULL>
 __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const float* __restrict__ z, int64_t z_net_stride, int ldz, const float* __restrict__ gamma,
     const float* __restrict__ beta, int64_t param_net_stride, const float2* __restrict__ partials, int NB64,
@@ -1417,7 +1430,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             if (tid < 32) {
                 const int pair = 32 * rb + tid, net = pair >> 8, col = pair & 255;
                 float mean, var;
-                if (NB64 <= BB_MAX_NB) bb_fold_stats(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
+                if (FULL || NB64 <= BB_MAX_NB) bb_fold_stats<FULL>(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
                 else bb_fold_stats_big(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
                 const float invstd = 1.0f / sqrtf(var + eps);
                 const int epoch = *epoch_p;
@@ -1468,7 +1481,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     // rows of this workgroup that exist (the last workgroup of a batch that is not whole 16-row groups holds fewer): the others are
     // not samples — the head body leaves their d_heads zero (so dA2, dY2 and every block sum get nothing from them), their Z2 rows
     // are the zeros the buffer was allocated with, and nothing of the minibatch is read for them
-    const int ns_ = B - (int)s0 < ROWS ? B - (int)s0 : ROWS;
+    const int ns_ = FULL ? ROWS : (B - (int)s0 < ROWS ? B - (int)s0 : ROWS);
     const bool live_ = s_loc_ < ns_;
     const float u_val = (live_ && i_ < A) ? u[(s0 + s_loc_) * ldu + i_] : 0.f;
     const float r_val = (live_ && i_ == 0) ? r[(s0 + s_loc_) * ldr] : 0.f;
@@ -1495,7 +1508,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             var = c[3];
         } else {
             if (n_fold && errors) __hip_atomic_fetch_add(errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (NB64 <= BB_MAX_NB) bb_fold_stats_u(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
+            if (FULL || NB64 <= BB_MAX_NB) bb_fold_stats_u<FULL>(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
             else bb_fold_stats_big(partials + (int64_t)net * NB64 * H, H, NB64, B, cb + lane, &mean, &var);
             invstd = 1.0f / sqrtf(var + eps);
         }
@@ -1739,13 +1752,19 @@ extern "C" int naf_bb_layer1_adam(const float* x, int64_t x_net_stride, int ldx,
     const int n_adam = adam ? bb_adam_blocks(l1_4, n4, 2 * BB_THREADS) : 0;
     const int grid = n_main + n_adam;
     const int xcd_rows = 1;      // rows by eighths (bb_place_rows)
-#define BB_L1(K4V, AD)                                                                                                       \
-    bb_layer1_kernel<K4V, AD><<<grid, (AD) ? 2 * BB_THREADS : BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
+#define BB_L1_(K4V, AD, FL)                                                                                                    \
+    bb_layer1_kernel<K4V, AD, FL><<<grid, (AD) ? 2 * BB_THREADS : BB_THREADS, 0, st>>>(x, x_net_stride, ldx, K, W, bias, gamma, beta, param_net_stride, mom, \
                                                            running_mean, running_var, stat_net_stride, out, out_net_stride, ldo, \
                                                            save_mean, save_invstd, wc_out, B, H, momentum, eps, n_main, ad, l1_4, n4, n_adam, xcd_rows, xhat_out)
+#define BB_L1(K4V, AD)                       \
+    do {                                     \
+        if (B % BB_ROWS == 0) BB_L1_(K4V, AD, true); \
+        else BB_L1_(K4V, AD, false);         \
+    } while (0)
     if (k4d == 6) { if (adam) BB_L1(6, true); else BB_L1(6, false); }
     else { if (adam) BB_L1(8, true); else BB_L1(8, false); }
 #undef BB_L1
+#undef BB_L1_
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -1764,18 +1783,24 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
     const int xcd_nets = 1;      // rows by eighths (bb_place_rows)
     const int gx = nets * bb_blocks(B);
     hipStream_t st = (hipStream_t)stream;
-#define BB_LS(KERNEL, GY)                                                                                                   \
+#define BB_LS_(KERNEL, GY, FL)                                                                                              \
     do {                                                                                                                    \
         const int n_main = gx * (GY);                                                                                       \
-        if (adam) KERNEL<true><<<n_main + extra, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z,   \
+        if (adam) KERNEL<true, FL><<<n_main + extra, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, \
                                                                       z_net_stride, ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4, xcd_nets); \
-        else KERNEL<false><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride,  \
+        else KERNEL<false, FL><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride, \
                                                           ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4, xcd_nets);             \
+    } while (0)
+#define BB_LS(KERNEL, GY)                            \
+    do {                                             \
+        if (B % BB_ROWS == 0) BB_LS_(KERNEL, GY, true); \
+        else BB_LS_(KERNEL, GY, false);              \
     } while (0)
     const int max16 = 512;       // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
     if (B <= max16) BB_LS(bb_linear_stats16_kernel, N / 16);
     else BB_LS(bb_linear_stats_kernel, N / BL_BN);
 #undef BB_LS
+#undef BB_LS_
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -1814,15 +1839,16 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     const int* epoch_p = once ? once->epoch : nullptr;
     unsigned long long* errors = once ? (unsigned long long*)once->errors : nullptr;
     const int xcd_rows = 1;      // row chunks dealt to the XCD whose dA1 blocks read them (+0.4 - 1 %)
-#define BB_FK_R(PM, NH4V, RW)                                                                                            \
-    bb_layer2_head_kernel<PM, NH4V, RW><<<blocks, FK_THREADS, 0, st>>>(                                                  \
+#define BB_FK_R(PM, NH4V, RW, FL)                                                                                           \
+    bb_layer2_head_kernel<PM, NH4V, RW, FL><<<blocks, FK_THREADS, 0, st>>>(                                                  \
         z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, bb_blocks(B), running_mean, running_var, \
         stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
         loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows, rec, epoch_p, errors, n_fold)
-#define BB_FK(PM, NH4V)                   \
-    do {                                  \
-        if (rows == 16) BB_FK_R(PM, NH4V, 16); \
-        else BB_FK_R(PM, NH4V, 32);       \
+#define BB_FK(PM, NH4V)                                                          \
+    do {                                                                         \
+        if (rows == 16 && B % BB_ROWS == 0) BB_FK_R(PM, NH4V, 16, true);          \
+        else if (rows == 16) BB_FK_R(PM, NH4V, 16, false);                       \
+        else BB_FK_R(PM, NH4V, 32, false);                                       \
     } while (0)
 #define BB_FK_NH(PM)                     \
     do {                                 \
@@ -1904,7 +1930,11 @@ extern "C" int naf_bb_layer1_bwd_finish(const float* p_slabs, int K, const float
             F.merge = 1;
         }
     }
-    bb_layer1_bwd_finish_kernel<<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
+    const bool big1 = nb1 > BB_MAX_NB1;
+    if (F.merge && big1) bb_layer1_bwd_finish_kernel<true, true><<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
+    else if (F.merge) bb_layer1_bwd_finish_kernel<true, false><<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
+    else if (big1) bb_layer1_bwd_finish_kernel<false, true><<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
+    else bb_layer1_bwd_finish_kernel<false, false><<<F.n_blocks, BB_THREADS, 0, (hipStream_t)stream>>>(F);
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -11,6 +11,16 @@
 #include "../../include/naf_hip.h"
 #include "bn2bwd_fold.h"
 
+// naf_gemm_l1bwd_t as the kernel sees it: the ABI struct WITHOUT its `rows` field — that one travels in GemmDesc::c_split_stride
+// (free in a descriptor with an epilogue: k_split == 1). The layout of a descriptor is then what it was before round 4 added the
+// field: with 8 bytes more per descriptor the launch was 0.3 us slower at B = 256 (A/B on one box, same kernel code otherwise —
+// which scalar loads share a cache line in front of the first vector load is all that changed).
+struct L1bwdDev {
+    const float *x, *W, *bias, *a1, *save_mean, *save_invstd;
+    float *partials, *p_slabs;
+    int ldx, K, kp, lda1;
+    const float *xhat, *gamma, *beta;
+};
 struct GemmDesc {
     const float* A;   // a_kmajor ? [K][M] (ld = lda) : [M][K]
     const float* B;   // b_kmajor ? [K][N] (ld = ldb) : [N][K]
@@ -18,8 +28,8 @@ struct GemmDesc {
     float* sumsq;     // nullable: sumsq[block] = sum of C^2 over the block (grad-norm partial)
     int M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, tile0, tiles_n;
     int k_split, tiles_mn;        // K cut into k_split ranges, one grid of tiles_mn blocks each, slab s at C + s * c_split_stride
-    int64_t c_split_stride;
-    naf_gemm_l1bwd_t epi;         // epi.x != NULL: the layer-1 backward pass on the block's C tile (see gemm_l1bwd_epilogue)
+    int64_t c_split_stride;       // (a descriptor with an epilogue: the number of its M rows that are samples, naf_gemm_l1bwd_t.rows)
+    L1bwdDev epi;                 // epi.x != NULL: the layer-1 backward pass on the block's C tile (see gemm_l1bwd_epilogue)
     naf_gemm_bn2bwd_t pro;        // pro.z != NULL: A = dY2 becomes dZ2 while it is staged (see gemm_bn2bwd_constants)
 };
 struct GemmBundle {
@@ -45,8 +55,12 @@ struct GemmBundle {
 //               the L2 -> L1 path either way (~19 TB/s over the chip, ~75 GB/s per CU), and its waves spend 43 % of their cycles
 //               parked on memory or barriers and 38 % waiting for the MFMA pipe their neighbours hold (SQ_WAIT_ANY /
 //               SQ_WAIT_INST_ANY, profiles/r03_pmc_sq_b2048.csv): phases of co-resident blocks coincide instead of interleaving.
-template <int T, int KC>
+// TAIL: some descriptor with an epilogue has rows past the batch in its last row block (a batch that is not whole 32-row blocks):
+// a kernel of its own. The launches of every other batch size run code without a trace of it — as a block-uniform branch inside one
+// kernel the clamps and the mask cost 0.25 us per update at B = 256 (A/B on one box; the blocks' cold straight-line code got longer).
+template <int T, int KC, bool TAIL_ = false>
 struct GB {
+    static constexpr bool TAIL = TAIL_;
     static constexpr int THREADS = T, CHUNK = KC;
     static constexpr int LD = KC + 4;          // [row][k] panels: 16-B aligned rows, b128 fragment reads spread over the banks
     static constexpr int LDK = 36;             // [k][row] panels (k-major operands keep their memory layout): 32 rows + 4 pad
@@ -172,18 +186,24 @@ struct L1bwdRegs {
     float w[NW];
     float a1[4];       // accumulator waves: A1 at the lane's four C/D elements (rows 4 g + e, column r of the tile)
     float mean, invstd, bias;   // of the lane's column
+    int rows_on;       // bit e: the lane's row 4 g + e of the tile is a sample (a batch that is not whole 32-row blocks: E.rows)
 };
 template <class G>
 __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int bn, int tid, bool owner, int wm, int wn, int r, int g,
                                                   L1bwdRegs<G>& R) {
-    const naf_gemm_l1bwd_t& E = D.epi;
+    const L1bwdDev& E = D.epi;
     const int KP = E.kp, m0 = bm * 32, n0 = bn * 32;
     const int xr = KP == 24 ? tid / 6 : tid / 8, xq = tid - xr * (KP / 4);       // (KP is 24 or 32: divisions by constants)
     R.x = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // (rows past the batch — E.rows of the M rows are samples: the last block of a batch that is not whole 32-row blocks — are read as
-    //  the last row that exists and carry dy = 0 through the epilogue)
-    const int Mv = E.rows, mlast = Mv - 1;
-    if (xr < 32) R.x = ((const f32x4*)(E.x + (int64_t)(m0 + xr < Mv ? m0 + xr : mlast) * E.ldx))[xq];
+    // (G::TAIL: rows past the batch — D.c_split_stride of the M rows are samples — are read as the last row that exists and carry
+    //  dy = 0 through the epilogue)
+    const int Mv = G::TAIL ? (int)D.c_split_stride : 0x7fffffff, mlast = Mv - 1;
+    R.rows_on = 15;
+    if (G::TAIL) {
+        const int row0 = m0 + wm * 16 + 4 * g;
+        R.rows_on = (row0 < Mv ? 1 : 0) | (row0 + 1 < Mv ? 2 : 0) | (row0 + 2 < Mv ? 4 : 0) | (row0 + 3 < Mv ? 8 : 0);
+    }
+    if (xr < 32) R.x = ((const f32x4*)(E.x + (int64_t)((G::TAIL && m0 + xr >= Mv) ? mlast : m0 + xr) * E.ldx))[xq];
 #pragma unroll
     for (int i = 0; i < L1bwdRegs<G>::NW; ++i) {
         const int e = tid + G::THREADS * i;
@@ -197,7 +217,7 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = m0 + wm * 16 + 4 * g + e;
-            R.a1[e] = owner ? E.xhat[(int64_t)(row < Mv ? row : mlast) * E.lda1 + col] : 0.f;
+            R.a1[e] = owner ? E.xhat[(int64_t)((G::TAIL && row >= Mv) ? mlast : row) * E.lda1 + col] : 0.f;
         }
         R.mean = E.gamma[col];
         R.invstd = E.beta[col];
@@ -207,7 +227,7 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int row = m0 + wm * 16 + 4 * g + e;
-        R.a1[e] = owner ? E.a1[(int64_t)(row < Mv ? row : mlast) * E.lda1 + col] : 0.f;
+        R.a1[e] = owner ? E.a1[(int64_t)((G::TAIL && row >= Mv) ? mlast : row) * E.lda1 + col] : 0.f;
     }
     R.mean = E.save_mean[col];
     R.invstd = E.save_invstd[col];
@@ -222,7 +242,7 @@ __device__ static inline void gemm_l1bwd_prefetch(const GemmDesc& D, int bm, int
 template <class G>
 __device__ static inline f32x4 gemm_l1bwd_xhat(const GemmDesc& D, bool owner, int wm, int wn, int r, int g, float* sA, int tid,
                                                const L1bwdRegs<G>& R) {
-    const naf_gemm_l1bwd_t& E = D.epi;
+    const L1bwdDev& E = D.epi;
     const int KP = E.kp, XS = KP + 4;
     float* sX = sA;                    // [32 rows][XS]
     float* sW = sA + 32 * XS;          // [32 cols][XS]
@@ -265,7 +285,7 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
                                                   int wm, int wn, int r, int g, float* sA, float* sB, int tid, const L1bwdRegs<G>& R) {
     // KSPLIT = 2: the two products are dealt to the accumulator waves (owner) and to the other four;
     // KSPLIT = 1: every wave holds an accumulator tile and takes its share of P behind the barrier.
-    const naf_gemm_l1bwd_t& E = D.epi;
+    const L1bwdDev& E = D.epi;
     const int KP = E.kp, XS = KP + 4;
     const int n0 = bn * 32;
     float* sX = sA;                    // [32 rows][XS]: the minibatch rows again, for P = dY^T X
@@ -283,8 +303,11 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xhe = kept ? R.a1[e] : xh[e];
-            const bool on = (kept ? __builtin_fmaf(R.a1[e], R.mean, R.invstd) > 0.f : R.a1[e] > 0.f) &&
-                            bm * 32 + wm * 16 + 4 * g + e < E.rows;         // (a row past the batch contributes nothing)
+            // (TAIL: a row past the batch contributes nothing. Bitwise, not `&&`: the short-circuit form turned the selects of this
+            //  loop into branches — +290 instructions in the kernel, +0.2 us in the epilogue of every dA1 block, also where the
+            //  second operand was the constant true)
+            const bool on0 = kept ? __builtin_fmaf(R.a1[e], R.mean, R.invstd) > 0.f : R.a1[e] > 0.f;
+            const bool on = G::TAIL ? (bool)((int)on0 & (R.rows_on >> e) & 1) : on0;
             const float dy = on ? acc[e] : 0.f;
             sDY[(wm * 16 + 4 * g + e) * 33 + wn * 16 + r] = dy;
             s_dy += dy;
@@ -508,9 +531,9 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
 // parameter, not a kernel argument: everything that waits in this launch waits for those workgroups, and as arguments their way to
 // the first load of the partials led through three dependent scalar round trips (n_fold -> fold_desc -> the fields of
 // d[fold_desc].pro, ~0.25 us each in front of a cold scalar cache) plus one more in front of the record store; now it is one batch.
-template <int T, int KC, bool FOLD>
+template <int T, int KC, bool FOLD, bool TAIL = false>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(GB_WAVES_PER_EU, GB_WAVES_PER_EU))) void gemm_bundle_kernel(const GemmBundle bundle) {
-    using G = GB<T, KC>;
+    using G = GB<T, KC, TAIL>;
     __shared__ __attribute__((aligned(16))) float sA[G::PANEL];
     __shared__ __attribute__((aligned(16))) float sB[G::PANEL];
     __shared__ __attribute__((aligned(16))) float sC[4 * 64 * 4];   // the column constants of the prologue, then the K halves' hand-over
@@ -590,6 +613,7 @@ extern "C" int naf_gemm_bundle_ex(const naf_gemm_desc_t* descs, int n, int form,
     b.n_fold = b.fold_desc = 0;
     b.rowmap = 2;                 // dA1 blocks by block row on the XCDs, dW2's K ranges by XCD group (the kernel's comment)
     int tiles = 0;
+    bool tail = false;           // some epilogue has rows past the batch in its last 32-row block: the TAIL form of the kernel
     for (int i = 0; i < n; ++i) {
         const naf_gemm_desc_t& s = descs[i];
         if (!s.A || !s.B || (!s.C && !s.epi) || s.M <= 0 || s.N <= 0 || s.K <= 0) return NAF_ERR_ARG;
@@ -629,8 +653,10 @@ extern "C" int naf_gemm_bundle_ex(const naf_gemm_desc_t* descs, int n, int form,
                 e.lda1 < s.N || ((uintptr_t)e.x & 15) || ((uintptr_t)e.partials & 7) || (e.xhat && (!e.gamma || !e.beta)) ||
                 e.rows < 0 || e.rows > s.M)
                 return NAF_ERR_ARG;
-            d.epi = e;
-            if (!d.epi.rows) d.epi.rows = s.M;
+            d.epi = L1bwdDev{e.x, e.W, e.bias, e.a1, e.save_mean, e.save_invstd, e.partials, e.p_slabs, e.ldx, e.K, e.kp, e.lda1,
+                             e.xhat, e.gamma, e.beta};
+            d.c_split_stride = e.rows ? e.rows : s.M;
+            if (d.c_split_stride & 31) tail = true;
         }
         tiles += d.tiles_mn * ksn;
     }
@@ -642,11 +668,17 @@ extern "C" int naf_gemm_bundle_ex(const naf_gemm_desc_t* descs, int n, int form,
     hipStream_t st = (hipStream_t)stream;
     if (b.n_fold) {
         b.fold_pro = b.d[b.fold_desc].pro;
-        if (big) gemm_bundle_kernel<256, 128, true><<<tiles + b.n_fold, 256, 0, st>>>(b);
+        if (tail) {
+            if (big) gemm_bundle_kernel<256, 128, true, true><<<tiles + b.n_fold, 256, 0, st>>>(b);
+            else gemm_bundle_kernel<512, 256, true, true><<<tiles + b.n_fold, 512, 0, st>>>(b);
+        } else if (big) gemm_bundle_kernel<256, 128, true><<<tiles + b.n_fold, 256, 0, st>>>(b);
         else gemm_bundle_kernel<512, 256, true><<<tiles + b.n_fold, 512, 0, st>>>(b);
     } else {
         memset(&b.fold_pro, 0, sizeof(b.fold_pro));
-        if (big) gemm_bundle_kernel<256, 128, false><<<tiles, 256, 0, st>>>(b);
+        if (tail) {
+            if (big) gemm_bundle_kernel<256, 128, false, true><<<tiles, 256, 0, st>>>(b);
+            else gemm_bundle_kernel<512, 256, false, true><<<tiles, 512, 0, st>>>(b);
+        } else if (big) gemm_bundle_kernel<256, 128, false><<<tiles, 256, 0, st>>>(b);
         else gemm_bundle_kernel<512, 256, false><<<tiles, 512, 0, st>>>(b);
     }
     NAF_CHECK_LAUNCH();
