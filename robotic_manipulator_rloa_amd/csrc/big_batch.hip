@@ -129,59 +129,6 @@ __device__ static inline void bb_fold_stats_big(const float2* p, int H, int NB, 
     *var = M2 / (float)B;
 }
 
-// the same for plain sums (backward partials): (sum .x, sum .y) over the NB blocks, block order
-__device__ static inline float2 bb_fold_sums(const float2* __restrict__ p, int H, int NB, int col) {
-    float2 v[BB_MAX_NB];
-#pragma unroll
-    for (int rb = 0; rb < BB_MAX_NB; ++rb) v[rb] = p[(int64_t)(rb < NB ? rb : 0) * H + col];
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < BB_MAX_NB; ++rb) {
-        a += rb < NB ? v[rb].x : 0.f;
-        b += rb < NB ? v[rb].y : 0.f;
-    }
-    return make_float2(a, b);
-}
-
-// plain sums per size class, buffer loads (see bb_fold_stats_u): p's byte wave_off + lane_off = block 0 of the thread's column
-template <int NMAX>
-__device__ __forceinline__ static float2 bb_fold_sums_n(__amdgpu_buffer_rsrc_t p, unsigned lane_off, unsigned wave_off, int H, int NB) {
-    naf_f32x2 v[NMAX];
-#pragma unroll
-    for (int rb = 0; rb < NMAX; ++rb) v[rb] = naf_buf_f2(p, lane_off, wave_off + (unsigned)(rb < NB ? rb : 0) * (unsigned)H * 8u);
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < NMAX; ++rb) {
-        a += rb < NB ? v[rb].x : 0.f;
-        b += rb < NB ? v[rb].y : 0.f;
-    }
-    return make_float2(a, b);
-}
-__device__ __forceinline__ static float2 bb_fold_sums_u(__amdgpu_buffer_rsrc_t p, unsigned lane_off, unsigned wave_off, int H, int NB) {
-    if (NB <= 8) return bb_fold_sums_n<8>(p, lane_off, wave_off, H, NB);                      // (uniform branches)
-    if (NB <= 16) return bb_fold_sums_n<16>(p, lane_off, wave_off, H, NB);
-    return bb_fold_sums_n<BB_MAX_NB>(p, lane_off, wave_off, H, NB);
-}
-
-__device__ static inline float bb_fold_sum1(const float* __restrict__ p, int64_t stride, int NB) {
-    float v[BB_MAX_NB];
-#pragma unroll
-    for (int rb = 0; rb < BB_MAX_NB; ++rb) v[rb] = p[(int64_t)(rb < NB ? rb : 0) * stride];
-    float a = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < BB_MAX_NB; ++rb) a += rb < NB ? v[rb] : 0.f;
-    return a;
-}
-
-// sums over the 64 rows of a tile held as one value per (row, column) in LDS [64][BB_COLS + 1]: thread c < 64 adds
-// column c in row order
-__device__ static inline float bb_col_sum64(const float (*t)[BB_COLS + 1], int c) {
-    float s = 0.f;
-#pragma unroll 16
-    for (int r = 0; r < BB_ROWS; ++r) s += t[r][c];
-    return s;
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // Layer 1 is LINEAR in the minibatch rows, so everything BatchNorm needs from the batch dimension follows from the first
 // two moments of X = the state (net 0) / next-state (net 1) columns of the rows, which do not depend on the weights:
@@ -300,25 +247,6 @@ __global__ __launch_bounds__(BM_THREADS) void bb_moments_kernel(const float* __r
 // statistics launch, the normalising launch and the backward, so z is the same bits everywhere.
 // ------------------------------------------------------------------------------------------------------------
 template <int K4>
-__device__ static inline void bb_l1_stage(const float* __restrict__ x, int ldx, int row0, const float* __restrict__ W, int K,
-                                          int col0, int H, float (*sXt)[BB_ROWS + 4], float (*sWt)[BB_COLS + 4], int tid) {
-    // X tile: 64 rows x K4 float4
-    for (int e = tid; e < BB_ROWS * K4; e += BB_THREADS) {
-        const int row = e / K4, q = e - row * K4;
-        const float4 v = ((const float4*)(x + (int64_t)(row0 + row) * ldx))[q];
-        sXt[4 * q + 0][row] = v.x;
-        sXt[4 * q + 1][row] = v.y;
-        sXt[4 * q + 2][row] = v.z;
-        sXt[4 * q + 3][row] = v.w;
-    }
-    // W tile: 64 columns x K floats (rows of the [H][K] matrix are K floats apart: scalar loads, 6 KB in all)
-    for (int e = tid; e < BB_COLS * 4 * K4; e += BB_THREADS) {
-        const int c = e / (4 * K4), k = e - c * (4 * K4);
-        sWt[k][c] = (k < K && col0 + c < H) ? W[(int64_t)(col0 + c) * K + k] : 0.f;
-    }
-}
-
-template <int K4>
 __device__ static inline void bb_l1_tile(const float (*sXt)[BB_ROWS + 4], const float (*sWt)[BB_COLS + 4], const float4 bias4,
                                          int ty, int tx, float (&z)[4][4]) {
     const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
@@ -336,63 +264,6 @@ __device__ static inline void bb_l1_tile(const float (*sXt)[BB_ROWS + 4], const 
 #pragma unroll
             for (int j = 0; j < 4; ++j) z[i][j] = __builtin_fmaf(av[i], wv[j], z[i][j]);
     }
-}
-
-// column sums of a thread-tiled 64 x 64 tile (4 x 4 per thread, tid = 16 ty + tx): 4 rows in the thread, 4 row groups in
-// the wave (lane bits 4, 5), 4 waves through LDS. Every thread returns the sums of ITS four columns. Fixed order.
-__device__ static inline void bb_tile_col_sums(const float (&v)[4][4], float (*red)[BB_COLS], int tid, int tx, float (&out)[4]) {
-    float s[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[j] = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
-        s[j] = naf_xor32_add(naf_xor16_add(s[j]));
-    }
-    __syncthreads();                 // previous use of red is over
-    if ((tid & 63) < 16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red[tid >> 6][4 * tx + j] = s[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = (red[0][4 * tx + j] + red[1][4 * tx + j]) + (red[2][4 * tx + j] + red[3][4 * tx + j]);
-}
-
-// per-column forward statistics of layer 1 from the moments record: 4 threads per column (tid >> 2 = column of the
-// workgroup's 64, tid & 3 = quarter of the rows of C), folded by two xor shuffles. sMom: [Sx | C] in LDS, sWt: [k][column].
-// wc_row (nullable): this column's row of the [H][KP] matrix w_c C, left for the backward pass (bb_layer1_bwd_finish_kernel:
-// sum_r xhat[r][c] x[r][k] = invstd_c (w_c C)[k]; C is symmetric, so (C w_c)[j] computed here is the same vector).
-template <int K4>
-__device__ static inline void bb_l1_stats_from_moments(const float* sMom, const float (*sWt)[BB_COLS + 4], float bias_c, int B,
-                                                       int tid, float* mean, float* var, float* wc_row = nullptr) {
-    constexpr int KP = 4 * K4, KQ = KP / 4;
-    const int c = tid >> 2, part = tid & 3;
-    float t = 0.f, mdot = 0.f;
-    float w[KP];                                        // the column's weights: read once (they were re-read per row of C)
-#pragma unroll
-    for (int k = 0; k < KP; ++k) w[k] = sWt[k][c];
-#pragma unroll
-    for (int jj = 0; jj < KQ; ++jj) {
-        const int j = part * KQ + jj;
-        float wj = 0.f;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) wj = (k == j) ? w[k] : wj;       // (j is not a compile-time constant: select, no indexing)
-        float row = 0.f;
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) {
-            const f32x4 cv = *(const f32x4*)(sMom + KP + j * KP + 4 * k4);   // the same address in 16 lanes of 64: a broadcast
-            row = __builtin_fmaf(cv[0], w[4 * k4 + 0], row);
-            row = __builtin_fmaf(cv[1], w[4 * k4 + 1], row);
-            row = __builtin_fmaf(cv[2], w[4 * k4 + 2], row);
-            row = __builtin_fmaf(cv[3], w[4 * k4 + 3], row);
-        }
-        if (wc_row) wc_row[j] = row;
-        t = __builtin_fmaf(wj, row, t);
-        mdot = __builtin_fmaf(wj, sMom[j], mdot);
-    }
-    t = naf_xor2_add(naf_xor1_add(t));
-    mdot = naf_xor2_add(naf_xor1_add(mdot));
-    *mean = bias_c + mdot / (float)B;
-    *var = fmaxf(t, 0.f) / (float)B;
 }
 
 // finish: TWO columns per workgroup, two waves per column, lane = (k of 32, half): the column's p_slabs blocks are dealt in

@@ -25,24 +25,6 @@ typedef float ft_f2 __attribute__((ext_vector_type(2)));
 #define FT_NW (FT_THREADS / 64)
 #define MAX_K4 8    // small-K layers: K <= 32 (8 float4 per input row)
 
-// z[row] = b + sum_k x[row][k] * w[k], k ascending; x rows are 16-B aligned, read as K4 float4 (columns >= K hit
-// zero weights)
-template <int K4>
-__device__ static inline float small_k_dot(const float* __restrict__ xrow, const float* w, float b) {
-    float4 v[K4];
-#pragma unroll
-    for (int q = 0; q < K4; ++q) v[q] = ((const float4*)xrow)[q];
-    float z = b;
-#pragma unroll
-    for (int q = 0; q < K4; ++q) {
-        z += v[q].x * w[4 * q + 0];
-        z += v[q].y * w[4 * q + 1];
-        z += v[q].z * w[4 * q + 2];
-        z += v[q].w * w[4 * q + 3];
-    }
-    return z;
-}
-
 // stage this workgroup's TX x K weight tile (contiguous TX*K floats of a row-major [H][K] matrix) and return the
 // calling thread's column in registers, zero-padded to 4*K4
 template <int K4>
