@@ -379,7 +379,7 @@ def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
                     "the LLC"}
 
 
-def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadamard"):
+def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadamard", fuse=None):
     """The timed loop of main() at another BASELINE shape on this one GPU (same engines, same update-to-data ratio):
     updates/s of E envs, batch B, ring N."""
     import torch
@@ -389,7 +389,7 @@ def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadama
     from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     S, A = (23, 7) if robot == "panda" else (21, 6)
-    L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, dev, p_mode=_lib.P_HADAMARD if p_mode == "hadamard" else _lib.P_MATMUL)
+    L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, dev, p_mode=_lib.P_HADAMARD if p_mode == "hadamard" else _lib.P_MATMUL, fuse=fuse)
     sd = reference_init_state_dict(S, A, 256, seed=0)
     L.load_params(0, sd)
     L.load_params(1, sd)
@@ -495,12 +495,14 @@ def extras(dev, args):
                 # small batches: configs[0]'s batch and ring with 64 device envs, and the reference's default batch
                 # (rl_framework.py:33-44) — the row-split chain since the end of round 3; batch sizes that are not whole 64-row blocks
                 # or whole 16-row groups (round 4: partial last block / workgroup / MFMA tile on the row-split chain) and one below
-                # 64, the column-tile chain's range
+                # 64 (a single partial block), beside the column-tile chain at that size
                 "configs[0] batch and ring: kuka, batch 64, ring 1e5, 64 device envs": measure_shape(dev, "kuka", 64, 100000, E, 500, 30),
                 "reference default batch 128 (kuka, ring 1e5)": measure_shape(dev, "kuka", 128, 100000, E, 500, 30),
                 "batch 100 (kuka, ring 1e5): the row-split chain with a partial last 16-row group": measure_shape(dev, "kuka", 100, 100000, E, 500, 30),
                 "batch 1000 (kuka, ring 1e6): the same at a large batch": measure_shape(dev, "kuka", 1000, 1000000, E, 500, 30),
-                "batch 48 (kuka, ring 1e5): the column-tile chain": measure_shape(dev, "kuka", 48, 100000, E, 500, 30),
+                "batch 48 (kuka, ring 1e5): one partial 64-row block on the row-split chain": measure_shape(dev, "kuka", 48, 100000, E, 500, 30),
+                "batch 48 on the column-tile chain (fuse = columns: the default for other layer / state sizes)":
+                    measure_shape(dev, "kuka", 48, 100000, E, 500, 30, fuse="columns"),
                 # north_star's literal head: textbook P = L L^T on 8 x 9 padded LDS tiles (--p-mode matmul)
                 "configs[1] with P = L L^T (p_mode matmul)": measure_shape(dev, "kuka", 256, 1000000, E, 500, 30, p_mode="matmul"),
                 # ... and at configs[4]'s literal shape: 7 x 7 L / P tiles, batch 2048, ring 4e6

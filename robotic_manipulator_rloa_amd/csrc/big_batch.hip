@@ -1552,10 +1552,10 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-// (any B from 64 to 4096: the last 64-row block, the last 16-row workgroup of bb_layer2_head and the last MFMA tile may be partial —
+// (any B from 16 to 4096: the last 64-row block, the last 16-row workgroup of bb_layer2_head and the last MFMA tile may be partial —
 //  rows past the batch read as zeros, are never stored and stay out of every sum; the caller's activation buffers hold whole 16-row
 //  groups, zero-initialised, so that the rows past the batch ARE zeros wherever a later launch walks them as a K dimension)
-static int bb_shape_ok(int B, int H) { return B >= BB_ROWS && B <= BB_MAX_NB2 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
+static int bb_shape_ok(int B, int H) { return B >= 16 && B <= BB_MAX_NB2 * BB_ROWS && H >= BB_COLS && (H % BB_COLS) == 0; }
 static int bb_blocks(int B) { return (B + BB_ROWS - 1) / BB_ROWS; }
 
 extern "C" int naf_bb_moments_floats(int K) {

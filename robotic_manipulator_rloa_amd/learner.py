@@ -161,32 +161,33 @@ class Learner:
         #              BatchNorm statistics, GEMM 2 on f32 MFMA, layer 2 + heads + NAF head + first backward stage in one launch
         #              (hk), the backward GEMMs as one launch (gb) that also carries the second stage of layer 2's BatchNorm
         #              backward as its prologue (s2) and the batch pass of layer 1's backward as its epilogue (ep), a finish
-        #              launch — 5 launches per update in a chain of updates. Needs 64 <= B <= 4096 (any size in it), H = 256, S <= 26.
+        #              launch — 5 launches per update in a chain of updates. Needs 16 <= B <= 4096 (any size in it), H = 256, S <= 26.
         #              Default wherever the shape fits (measured at the end of round 3, updates/s, column-tile | row-split: B = 64:
         #              32.3k | 36.0k, 128: 30.7k | 35.4k, 192: 25.8k | 34.0k, 256: 25.7k | 34.7k, 512: 20.3k | 30.9k; until then the
         #              column-tile chain led below B = 256 — 32.5k | 29.3k at 64 in round 2).
         #   "columns"  {l1, b2, gb, s3}: the COLUMN-TILE chain of csrc/fused_layers.hip — a workgroup owns 8 feature columns x all
         #              B rows (ceil(B/64) <= 8 rows per thread in registers), the K = state-size and N = heads GEMMs folded into
-        #              the BatchNorm kernels, 8 launches per update. B <= 512. Default below B = 64 (and up to 512 where H or S
-        #              do not fit the row-split chain).
+        #              the BatchNorm kernels, 8 launches per update. B <= 512. Default below B = 16 (and up to 512 where H or S
+        #              do not fit the row-split chain). (B = 16 ... 63 moved to the row-split chain in round 4: one partial
+        #              block — 37.1k against 31.0k updates/s at B = 32, 36.5k against 21.1k at 63.)
         #   "unfused"  {gb} or {}: torch (rocBLAS) GEMMs + the BatchNorm / head kernels of csrc/bn_relu.hip, naf_head.hip, with
         #              the backward GEMM bundle where its shapes allow (B, H multiples of 16) — any shape up to B = 4096; 14
         #              launches per update (round 1's chain: 12.7k updates/s at B = 1024).
         # NAF_FUSE = rows | columns | unfused overrides the choice (a chain whose shape limits are not met falls to the next).
         lay0 = self.lay
-        # The reference takes any positive batch_size (rl_framework.py:186-189). Here: every size up to 4096 trains — 64 ... 4096
+        # The reference takes any positive batch_size (rl_framework.py:186-189). Here: every size up to 4096 trains — 16 ... 4096
         # on the row-split chain, smaller ones on the column-tile chain, other layer / state sizes on the unfused chain (beyond 2048
         # with the streamed BatchNorm kernels of csrc/bn_relu.hip) with a warning that names the row-split chain's range. 4096 is
         # the replay sampler's limit (one workgroup draws a minibatch without replacement in LDS, csrc/replay.hip).
         if self.B < 1 or self.B > 4096:
             raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 4096 (the sampler draws a minibatch in one workgroup's LDS)")
-        # (round 4: ANY batch size from 64 to 4096 — the last 64-row block of layer 1 / GEMM 2, the last 16-row workgroup of the fused
+        # (round 4: ANY batch size from 16 to 4096 — the last 64-row block of layer 1 / GEMM 2, the last 16-row workgroup of the fused
         #  layer-2 + head launch and the last block of the bundle's dA1 product may be partial: rows past the batch read as zeros, are
         #  never stored and stay out of every statistic and sum. The work buffers hold Bp = the next multiple of 16 rows (of 32 beyond
         #  B = 2048, where the fused layer-2 + head launch runs 32 rows per workgroup),
         #  zero-initialised: the weight-gradient products walk Bp rows as their K dimension, and a row past the batch is a zero in at
         #  least one operand of each — dH and dY2 rows the head body never writes, A1 rows layer 1 never stores.)
-        self.bb_ok = (64 <= self.B <= 4096 and lay0.H == 256 and lay0.S <= 26)
+        self.bb_ok = (16 <= self.B <= 4096 and lay0.H == 256 and lay0.S <= 26)
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
@@ -212,7 +213,7 @@ class Learner:
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)
             import warnings
             warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
-                          f"row-split chain): the row-split kernels need 64 <= batch_size <= 4096, layer_size 256 and "
+                          f"row-split chain): the row-split kernels need 16 <= batch_size <= 4096, layer_size 256 and "
                           f"state_size <= 26", stacklevel=3)
         # with every gradient element produced by one of our own kernels, those kernels also emit its sum-of-squares partial:
         # the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken on the all-reduced gradient).
