@@ -336,7 +336,10 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
     while ((1 << bits) < 2 * B) ++bits;
     size_t lds_ints = (size_t)B + 2 * ((size_t)1 << bits);
     if (lds_ints * sizeof(int) > 64 * 1024) {
-        static int raised = 0;       // 0 = not tried, 1 = raised, -1 = refused (then: the scan)
+        static int raised_dev[64];   // per device: 0 = not tried, 1 = raised, -1 = refused (then: the scan)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        int& raised = raised_dev[dev];
         if (!raised)
             raised = hipFuncSetAttribute((const void*)replay_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) ==
                              hipSuccess ? 1 : -1;
