@@ -1667,7 +1667,10 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
         if (B % BB_ROWS == 0) BB_LS_(KERNEL, GY, true); \
         else BB_LS_(KERNEL, GY, false);              \
     } while (0)
-    const int max16 = 512;       // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
+#ifndef BB_MAX16
+#define BB_MAX16 512
+#endif
+    const int max16 = BB_MAX16;  // small batches: 64 x 16 tiles, twice the workgroups (see the kernel)
     if (B <= max16) BB_LS(bb_linear_stats16_kernel, N / 16);
     else BB_LS(bb_linear_stats_kernel, N / BL_BN);
 #undef BB_LS
