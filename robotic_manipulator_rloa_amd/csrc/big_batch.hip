@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             if (tid < 32) {
                 const int pair = 32 * rb + tid, net = pair >> 8, col = pair & 255;
                 float mean, var;
-                if (FULL || NB64 <= BB_MAX_NB) bb_fold_stats<FULL>(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
+                if (ROWS == 16) bb_fold_stats<FULL>(partials      /* (16 rows per workgroup <=> B <= 2048 <=> at most 32 blocks) */ + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
                 else bb_fold_stats_big(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
                 const float invstd = 1.0f / sqrtf(var + eps);
                 const int epoch = *epoch_p;
@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             var = c[3];
         } else {
             if (n_fold && errors) __hip_atomic_fetch_add(errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (FULL || NB64 <= BB_MAX_NB) bb_fold_stats_u<FULL>(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
+            if (ROWS == 16) bb_fold_stats_u<FULL>(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
             else bb_fold_stats_big(partials + (int64_t)net * NB64 * H, H, NB64, B, cb + lane, &mean, &var);
             invstd = 1.0f / sqrtf(var + eps);
         }
