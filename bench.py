@@ -423,6 +423,7 @@ def extras(dev, args):
     B / N. The env is the synthetic kinematic stand-in (no PyBullet in the image)."""
     import logging
     import tempfile
+    import numpy as np
     import torch
     from functools import partial
     from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
@@ -434,29 +435,48 @@ def extras(dev, args):
     os.chdir(tempfile.mkdtemp(prefix="naf_bench_"))
     try:
         S, A, E = 21, 6, 64
-        # (ii) reference-API path, configs[0] shape
-        env = SyntheticEnvironment(A)
-        agent = NAFAgent(env, S, A, 256, 64, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, dev, 0)
-        state = env.reset(False)
+        # (ii) reference-API path: one host env, NAFAgent.act -> env.step -> NAFAgent.step per timestep (naf_algorithm.py:249-261):
+        # configs[0]'s literal shape (B = 64, ring 1e5) and the same loop at configs[1]'s batch (B = 256). Steady state as
+        # SURVEY.md section 8(d) defines it: the ring filled to capacity before anything is timed (the sampler's redraw rounds and
+        # the gather's locality are then those of a long run, not of its first thousand steps).
+        def api_path(batch, n_api):
+            env = SyntheticEnvironment(A)
+            agent = NAFAgent(env, S, A, 256, batch, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, dev, 0)
+            m = agent.memory
+            rng = np.random.default_rng(1)
+            r = np.zeros((100000, m.row_floats), np.float32)
+            r[:, :S] = rng.standard_normal((100000, S))
+            r[:, S:S + A] = rng.uniform(-1, 1, (100000, A))
+            r[:, S + A] = -rng.random(100000)
+            r[:, m.off_s2:m.off_s2 + S] = r[:, :S] + 0.05 * rng.standard_normal((100000, S))
+            m.add_rows_device(torch.from_numpy(r).to(dev), 100000)
+            state = env.reset(False)
 
-        def steps(n, state):
-            for _ in range(n):
-                a = agent.act(state)
-                nxt, r, d = env.step(a)
-                agent.step(state, a, r, nxt, d)
-                state = env.reset(False) if d else nxt
-            return state
-        state = steps(300, state)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+            def steps(n, state):
+                for _ in range(n):
+                    a = agent.act(state)
+                    nxt, r_, d = env.step(a)
+                    agent.step(state, a, r_, nxt, d)
+                    state = env.reset(False) if d else nxt
+                return state
+            state = steps(300, state)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            state = steps(n_api, state)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ch = agent._chunk
+            launches = 7 if (ch is not None and ch.fused_prep and ch.fused_tail) else 12
+            out = {"value": round(n_api / dt, 1), "unit": "timesteps/s", "timesteps": n_api, "batch": batch, "ring": "1e5 rows, full",
+                   "launches_per_timestep": launches, "optimizer_steps": int(agent.learner.step_dev.item())}
+            del agent
+            return out
         n_api = 3000
-        state = steps(n_api, state)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        res["reference_api_path"] = {"value": round(n_api / dt, 1), "unit": "timesteps/s",
-                                     "what": "NAFAgent.act + env.step + NAFAgent.step (add, sample, learn) per timestep, one "
-                                             "host env (numpy stand-in), B=64, N=1e5 (configs[0] shape), naf_algorithm.py:249-261",
-                                     "timesteps": n_api}
+        res["reference_api_path"] = api_path(64, n_api)
+        res["reference_api_path"]["what"] = ("NAFAgent.act + env.step + NAFAgent.step (add, sample, learn) per timestep, one host env "
+                                             "(numpy stand-in), B=64, N=1e5 (configs[0] shape), naf_algorithm.py:249-261")
+        res["reference_api_path_b256"] = api_path(256, n_api)
+        res["reference_api_path_b256"]["what"] = "the same loop at configs[1]'s batch (B=256, N=1e5)"
         if not args.no_cpu_baseline:
             from oracle.torch_cpu_port import time_baseline
             cb = time_baseline(S, A, 256, 64, 100000, budget_s=6.0, threads=8)

@@ -12,6 +12,27 @@ env = SyntheticEnvironment(6)
 BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 agent = NAFAgent(env, 21, 6, 256, BATCH, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, torch.device("cuda:0"), 0)
 state = env.reset(False)
+
+
+def prefill(agent, rows):
+    """the steady state SURVEY.md section 8(d) asks for: the ring filled (here: to `rows` transitions of the stand-in env's value
+    ranges) before anything is timed — the sampler's redraw rounds and the gather's locality are then those of a long run"""
+    import numpy as np
+    if rows <= 0:
+        return
+    m = agent.memory
+    rng = np.random.default_rng(1)
+    r = np.zeros((rows, m.row_floats), np.float32)
+    r[:, :m.S] = rng.standard_normal((rows, m.S))
+    r[:, m.S:m.S + m.A] = rng.uniform(-1, 1, (rows, m.A))
+    r[:, m.S + m.A] = -rng.random(rows)
+    r[:, m.off_s2:m.off_s2 + m.S] = r[:, :m.S] + 0.05 * rng.standard_normal((rows, m.S))
+    m.add_rows_device(torch.from_numpy(r).cuda(), rows)
+    torch.cuda.synchronize()
+
+
+FILL = int(os.environ.get("NAF_BENCH_FILL", "100000"))
+prefill(agent, FILL)
 T = {"act": 0.0, "env.step": 0.0, "agent.step": 0.0}
 def steps(n, timed):
     global state
@@ -24,7 +45,20 @@ def steps(n, timed):
         if timed:
             T["act"] += t1 - t0; T["env.step"] += t2 - t1; T["agent.step"] += t3 - t2
         state = env.reset(False) if d else nxt
-steps(300, False)
+steps(max(300, 4 * BATCH + 60), False)      # (past the dense regime of the sampler: population >= 4 B)
+# inside agent.step(): the launch call alone (TrainChunk.run_row: the row into device memory + hipGraphLaunch)
+_ch = agent._chunk
+if _ch is not None and _ch._seq_np is not None:
+    _rr = _ch.run_row
+    T["  step: launch"] = 0.0
+    def _timed_run_row():
+        t0 = time.perf_counter(); _rr(); T["  step: launch"] += time.perf_counter() - t0
+    _ch.run_row = _timed_run_row
+    _wt = _ch.wait_tail
+    T["  act: wait"] = 0.0
+    def _timed_wait():
+        t0 = time.perf_counter(); _wt(); T["  act: wait"] += time.perf_counter() - t0
+    _ch.wait_tail = _timed_wait
 torch.cuda.synchronize(); t0 = time.perf_counter(); steps(2000, True); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"{2000/dt:.0f} timesteps/s, {dt/2000*1e6:.1f} us per timestep")
 for k, v in T.items():

@@ -65,17 +65,27 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 25
+#define NAF_HIP_ABI_VERSION 26
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
 /* development aid: phase marks of the large-batch chain's kernels (csrc/common.h, NAF_TL_*; kernel_id 0..6 = bb_layer1,
- * bb_linear_stats, bb_layer2_head, bb_bn_bwd_stage2, gemm_bundle, bb_layer1_bwd_finish, adam_polyak). Copies
+ * bb_linear_stats, bb_layer2_head, bb_bn_bwd_stage2, gemm_bundle, bb_layer1_bwd_finish, adam_polyak, 7 = step_prep, 8 = adam_act). Copies
  * out[2][16] = 100 MHz wall-clock values left by the first and by the last workgroup of the kernel's most recent launch
  * (synchronises the device). kernel_id 1024 + i: entry (out[0][..]) and exit (out[1][..]) clocks of workgroups 16 i .. 16 i + 15
  * of the last gemm_bundle launch. NAF_ERR_STATE unless the library was built with -DNAF_TIMELINE (NAF_BUILD_DEFINES);
  * benchmarks/kernel_timeline.py is the reader. Not part of the data path. */
 int naf_timeline_read(int kernel_id, long long* out);
+
+/* Host-side half of a hand-over through DEVICE memory (no stream, no copy engine): memcpy of `bytes` bytes from host memory
+ * straight into device memory — every device allocation is mapped for the CPU on this platform (large BAR) — followed by a store
+ * fence, so the bytes have left the CPU before the caller launches the kernel that reads them. That kernel must load them with
+ * system scope. naf_step_prep's src_row / n_word may point to such memory: its first dependent load is then a local-memory
+ * latency instead of a PCIe round trip to pinned host memory. */
+int naf_host_publish(void* dst_device, const void* src_host, size_t bytes);
+/* the same followed by hipGraphLaunch(graph_exec, stream) — one call per timestep of the per-timestep path (bytes == 0: launch
+ * only). graph_exec: a hipGraphExec_t (e.g. torch.cuda.CUDAGraph.raw_cuda_graph_exec()). */
+int naf_host_publish_launch(void* dst_device, const void* src_host, size_t bytes, void* graph_exec, void* stream);
 
 /* ---- replay buffer: HBM ring of transition rows ------------------------------------------ */
 /* replaces ReplayBuffer.__init__ (utils/replay_buffer.py:16-30): deque(maxlen=buffer_size) */
@@ -456,6 +466,50 @@ int naf_adam_polyak_fused(float* theta, const float* g, float* m, float* v, floa
                           void* stream);
 /* NAFAgent.soft_update (naf_algorithm.py:217-226): target = tau*main + one_minus_tau*target, 12 B/param */
 int naf_polyak_update(float* target, const float* main, float tau, float one_minus_tau, size_t n, void* stream);
+
+/* ---- the per-timestep path: one environment, one transition, one minibatch, one update per timestep (csrc/step_path.hip) ------
+ * What NAFAgent.step() does between two act() calls of the reference's loop (naf_algorithm.py:144-156, :249-261), in two
+ * launches around the five of the row-split chain instead of seven.
+ *
+ * naf_step_prep: `self.memory.add(...)` of the timestep's transition (naf_algorithm.py:144 / utils/replay_buffer.py:32-45) +
+ * `random.sample(self.memory, k)` (:55) + the stacking of the minibatch (:57-65) + the moments record of layer 1's inputs
+ * (naf_bb_moments) in ONE launch of one workgroup:
+ *   src_row / n_word (both or neither): one transition row (device-visible memory, e.g. pinned host) and the word that says
+ *     whether this tick brings it (0 / 1, read where the kernel runs, as naf_replay_add_counted); NULL: nothing is appended;
+ *     row_out (nullable, device, naf_replay_row_floats floats): a copy of the row as read, whatever the count says — the
+ *     launch that ends the timestep (naf_adam_polyak_act) takes the policy's next observation from its next_state columns
+ *     instead of paying for a second read of host memory on its critical path;
+ *   the draw is naf_replay_sample_indices' (Philox stream position *counter_dev, advanced by one HERE; same indices bit for bit),
+ *     taken on the ring as the append leaves it (add, then sample: the reference's order); idx_out (nullable): the B positions;
+ *   out_rows [B][out_ld], action_mode: naf_replay_gather_rows' output; mom [2][naf_bb_moments_floats(S)]: naf_bb_moments'
+ *     records of the state (net 0) and next-state (net 1) columns, bit for bit. B <= 4096, S <= 32. */
+int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed,
+                  uint64_t* counter_dev, int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B,
+                  int without_replacement, void* stream);
+/* naf_adam_polyak_act: naf_adam_polyak_fused (clip_grad_norm_ + Adam.step + soft_update, naf_algorithm.py:209-213, :217-226) AND
+ * naf_policy_act for ONE state (NAFAgent.act, :158-178: the loop's next `self.act(state)`, :249) in one launch: the workgroups
+ * that step a slice of the main network's parameters keep the new values in registers and multiply them with the policy's
+ * activations, which cross workgroups as (value, epoch) records. Same parameters, Adam state and target as naf_adam_polyak_fused
+ * leaves them, same action as naf_policy_act computes from them (bit for bit, both: tests/test_kernels_gpu.py).
+ *   adam: as naf_bb_layer1_adam's (l1_floats and bc are ignored); the flat buffers must be exactly
+ *     [W1 (H x S) | b1 | g1 | be1 | W2 (H x H) | b2 | g2 | be2 | Wh (NHP x HP)] at the offsets `net` names (floats), H = 256;
+ *   obs [S] and action_out [A] may be pinned host memory; heads_out (nullable) [A + T + 1] pre-activations;
+ *   seed / counter_dev / noise_scale / p_mode: naf_policy_act's noise stream (*counter_dev advanced by one);
+ *   sync: naf_adam_polyak_act_sync_ints() int32 of device scratch, zero-initialised ONCE by the caller, 16-byte aligned, used by
+ *     this entry point only (one launch in flight per buffer);
+ *   host_errors (nullable): pinned host word that counts polls whose 2-ms bound ran out (the action is then NaN: an error);
+ *   host_seq (nullable): pinned host uint32 that receives the launch's ordinal (1, 2, ...: the number of calls on `sync`) once
+ *     the action has been written — a host that polls it needs no stream synchronisation to read the action. */
+typedef struct naf_act_net {
+    int S, A, H, NHP, HP;
+    int64_t off_W1, off_b1, off_g1, off_be1, off_W2, off_b2, off_g2, off_be2, off_Wh;
+    const float *running_mean1, *running_var1, *running_mean2, *running_var2;
+    float eps;
+} naf_act_net_t;
+int naf_adam_polyak_act_sync_ints(void);
+int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
+                        float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode, int32_t* sync,
+                        uint64_t* host_errors, uint32_t* host_seq, void* stream);
 
 /* ---- synthetic manipulator environment (stand-in for the PyBullet Environment) ---------------- */
 /* One step of E independent kinematic-chain arms on the device, emitting transition rows

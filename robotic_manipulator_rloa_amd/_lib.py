@@ -16,8 +16,8 @@ from typing import Optional
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
 SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "big_batch.hip", "gemm_bundle.hip", "optim.hip",
-           "synth_env.hip", "xgmi_reduce.hip", "policy_act.hip"]
-HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", "adam_body.h", "bn2bwd_fold.h", "gemm_ring.h", os.path.join("..", "..", "include", "naf_hip.h")]
+           "synth_env.hip", "xgmi_reduce.hip", "policy_act.hip", "step_path.hip"]
+HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", "adam_body.h", "bn2bwd_fold.h", "gemm_ring.h", "act_body.h", "moments_body.h", "sample_body.h", "replay_dev.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
 ACTION_TRUNC_INT, ACTION_FLOAT = 0, 1
@@ -164,6 +164,8 @@ _PROTOS = {
     "naf_hip_abi_version": [],
     "naf_hip_arch": [],
     "naf_timeline_read": [_i, _vp],
+    "naf_host_publish": [_vp, _vp, _sz],
+    "naf_host_publish_launch": [_vp, _vp, _sz, _vp, _vp],
     "naf_replay_row_floats": [_i, _i],
     "naf_replay_row_off_next_state": [_i, _i],
     "naf_replay_create": [_u64, _i, _i, _vp, _vp, C.POINTER(_vp)],
@@ -217,6 +219,9 @@ _PROTOS = {
     "naf_synth_env_state_floats": [_i],
     "naf_policy_act": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i,
                        _vp, _u64, _vp, _vp, _f, _i, _i, _i, _vp],
+    "naf_step_prep": [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "naf_adam_polyak_act_sync_ints": [],
+    "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp],
     "naf_xgmi_chunk_floats": [],
     "naf_xgmi_create": [_i, _i, _sz, C.c_double, C.POINTER(_vp)],
     "naf_xgmi_set_timeout": [_vp, C.c_double],
@@ -262,6 +267,15 @@ class AdamArgs(C.Structure):
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("tau", C.c_float), ("one_minus_tau", C.c_float),
                 ("step_dev", C.c_void_p), ("inv_world", C.c_float), ("n", C.c_int64), ("l1_floats", C.c_int64),
                 ("bc", C.c_void_p)]
+
+
+class ActNet(C.Structure):
+    """naf_act_net_t (include/naf_hip.h): where the main network's parameters sit in the flat buffers, for naf_adam_polyak_act"""
+    _fields_ = [("S", C.c_int), ("A", C.c_int), ("H", C.c_int), ("NHP", C.c_int), ("HP", C.c_int),
+                ("off_W1", C.c_int64), ("off_b1", C.c_int64), ("off_g1", C.c_int64), ("off_be1", C.c_int64), ("off_W2", C.c_int64),
+                ("off_b2", C.c_int64), ("off_g2", C.c_int64), ("off_be2", C.c_int64), ("off_Wh", C.c_int64),
+                ("running_mean1", C.c_void_p), ("running_var1", C.c_void_p), ("running_mean2", C.c_void_p),
+                ("running_var2", C.c_void_p), ("eps", C.c_float)]
 
 
 class GemmBn2Bwd(C.Structure):

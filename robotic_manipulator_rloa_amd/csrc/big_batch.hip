@@ -21,6 +21,7 @@
 #include "bn_tile.h"
 #include "head_body.h"
 #include "adam_body.h"
+#include "moments_body.h"
 #include "bn2bwd_fold.h"   // gemm_bn2bwd_poll_record: the readers' side of a self-validating 16-byte record
 #include "xgmi_dev.h"
 #include "../../include/naf_hip.h"
@@ -130,114 +131,18 @@ __device__ static inline void bb_fold_stats_big(const float2* p, int H, int NB, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Layer 1 is LINEAR in the minibatch rows, so everything BatchNorm needs from the batch dimension follows from the first
-// two moments of X = the state (net 0) / next-state (net 1) columns of the rows, which do not depend on the weights:
-//   Sx[k] = sum_r x[r][k],  m = Sx / B,  C[j][k] = sum_r (x[r][j] - m_j)(x[r][k] - m_k)        (double accumulation)
-//   mean_c = b_c + w_c . m          var_c = w_c^T C w_c / B                                     (forward statistics)
-//   sum_r xhat[r][c] x[r][k] = invstd_c (w_c C)[k]                                               (backward, see finish)
-// One launch computes them for ALL minibatches of a chunk (grid = minibatches x nets) right behind the gather, off the
-// per-update critical path: the statistics launch of layer 1 and the second stage of its backward disappear.
-// moments record (f32): [Sx (KP) | C (KP x KP)], KP = 24 or 32 (columns >= K meet zero weights).
+// The moments of layer 1's inputs for ALL minibatches of a chunk (grid = minibatches x nets), one launch behind the gather; the
+// arithmetic is csrc/moments_body.h (shared with the per-timestep launch of csrc/step_path.hip).
 // ------------------------------------------------------------------------------------------------------------
-#define BM_CHUNK 256
-#define BM_THREADS 512
 template <int K4>
 __global__ __launch_bounds__(BM_THREADS) void bb_moments_kernel(const float* __restrict__ x, int64_t batch_stride,
                                                                 int64_t x_net_stride, int ldx, float* __restrict__ mom,
                                                                 int B) {
-    constexpr int KP = 4 * K4, XS = 36, REC = KP + KP * KP;      // XS: 32 columns (the MFMA tiles of pass 2) + 4 pad
-    __shared__ __attribute__((aligned(16))) float sX[BM_CHUNK * XS];
-    __shared__ double sRed[16][32];
-    __shared__ float sM[32];
-    const int tid = threadIdx.x;
+    constexpr int KP = 4 * K4, REC = KP + KP * KP;
+    __shared__ __attribute__((aligned(16))) BmShared S;
     const float* xb = x + blockIdx.x * batch_stride + blockIdx.y * x_net_stride;
     float* out = mom + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * REC;
-    // a chunk = 256 rows x 8 float4 (the last 8 - K4 of a row are zeros): 4 per thread, ALL requested before the first LDS store
-    // (as a load -> store loop the compiler kept one load in flight per trip: four dependent round trips per chunk and pass — 21 of
-    // this launch's 21 us at B = 1024). `centre`: subtract the column means (pass 2).
-    auto stage = [&](int row0, bool centre) {
-        float4 v[BM_CHUNK * 8 / BM_THREADS];
-#pragma unroll
-        for (int i = 0; i < BM_CHUNK * 8 / BM_THREADS; ++i) {
-            const int e = tid + BM_THREADS * i;
-            const int r_ = e >> 3, q = e & 7;
-            const int row = row0 + r_;
-            const bool on = row < B && q < K4;
-            v[i] = ((const float4*)(xb + (int64_t)(on ? row : 0) * ldx))[on ? q : 0];
-            if (!on) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < BM_CHUNK * 8 / BM_THREADS; ++i) {
-            const int e = tid + BM_THREADS * i;
-            const int r_ = e >> 3, q = e & 7;
-            if (centre && row0 + r_ < B && q < K4) {
-                v[i].x -= sM[4 * q + 0];
-                v[i].y -= sM[4 * q + 1];
-                v[i].z -= sM[4 * q + 2];
-                v[i].w -= sM[4 * q + 3];
-            }
-            *(float4*)(sX + r_ * XS + 4 * q) = v[i];
-        }
-    };
-    // pass 1: column sums (double)
-    const int k1 = tid & 31, g1 = tid >> 5;
-    double s = 0.0;
-    for (int row0 = 0; row0 < B; row0 += BM_CHUNK) {
-        __syncthreads();
-        stage(row0, false);
-        __syncthreads();
-        if (k1 < KP) {
-            float part = 0.f;
-            for (int r_ = g1; r_ < BM_CHUNK; r_ += 16) part += sX[r_ * XS + k1];
-            s += (double)part;
-        }
-    }
-    sRed[g1][k1] = s;
-    __syncthreads();
-    if (tid < 32) {
-        double t = 0.0;
-        for (int g = 0; g < 16; ++g) t += sRed[g][tid];
-        sM[tid] = (float)(t / (double)B);
-        if (tid < KP) out[tid] = (float)t;
-    }
-    // pass 2: centred second moments C = Xc^T Xc on MFMA (v_mfma_f32_16x16x4_f32): the 32 x 32 padding of C is 2 x 2 tiles, wave =
-    // (tile, half of the chunk's rows); the chunk is staged CENTRED (columns >= KP zero), a chunk's 128-row partial accumulates in
-    // f32 (the data are centred), the running sum over chunks in double; the two row halves meet through LDS, lower + upper.
-    // (On the VALU — one triangle entry per thread walking every row — this launch took 59 us per 64 minibatches at B = 2048, 31 at
-    // B = 1024: ~1 us per update of the large batches for 1.2 MFLOP.) C/D map: col = lane & 15, row = 4 (lane >> 4) + reg; both
-    // off-diagonal tiles are computed, from the same products in the same order: C is symmetric bit for bit.
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        const int tile = wave & 3, half = wave >> 2, tm = tile >> 1, tn = tile & 1;
-        const int r = lane & 15, g = lane >> 4;
-        double dacc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int row0 = 0; row0 < B; row0 += BM_CHUNK) {
-            __syncthreads();
-            stage(row0, true);
-            __syncthreads();
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float* pa = sX + (128 * half + g) * XS + 16 * tm + r;
-            const float* pb = sX + (128 * half + g) * XS + 16 * tn + r;
-#pragma unroll 8
-            for (int kk = 0; kk < 128; kk += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk * XS], pb[kk * XS], acc, 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dacc[e] += (double)acc[e];
-        }
-        __syncthreads();                                    // the last chunk is consumed: sX becomes the halves' meeting place
-        double* sD = (double*)sX;                           // [tile][lane][4]
-        if (half) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sD[(tile * 64 + lane) * 4 + e] = dacc[e];
-        }
-        __syncthreads();
-        if (!half) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = 16 * tm + 4 * g + e, col = 16 * tn + r;
-                if (row < KP && col < KP) out[KP + row * KP + col] = (float)(dacc[e] + sD[(tile * 64 + lane) * 4 + e]);
-            }
-        }
-    }
+    bb_moments_body<K4>([&](int row, int q) { return ((const float4*)(xb + (int64_t)row * ldx))[q]; }, S, threadIdx.x, out, B);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@
 // ---------------------------------------------------------------------------------------------
 #define NAF_TL_SLOTS 16
 enum { NAF_TL_BB_LAYER1 = 0, NAF_TL_BB_LINEAR_STATS, NAF_TL_BB_LAYER2_HEAD, NAF_TL_BB_STAGE2, NAF_TL_GEMM_BUNDLE, NAF_TL_BB_FINISH,
-       NAF_TL_ADAM, NAF_TL_KERNELS };
+       NAF_TL_ADAM, NAF_TL_STEP_PREP, NAF_TL_ADAM_ACT, NAF_TL_KERNELS };
 #ifdef NAF_TIMELINE
 #define NAF_TL_DECL(arr) __device__ long long arr[NAF_TL_KERNELS][2][NAF_TL_SLOTS]
 #define NAF_TL(arr, kid, slot)                                                                                       \

@@ -167,13 +167,24 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
 // back substitution over the group. hrow: the sample's heads row (global or LDS); Lt: 8 * LT_STRIDE floats of LDS
 // (matmul mode). Contains a __syncthreads() in matmul mode: call it from every thread of the workgroup (live = false
 // for lanes without a sample).
+// the draw itself: z ~ N(0, 1) of (seed, stream position, sample, row) by Philox + Box-Muller — it depends on nothing else, so a
+// caller may take it ahead of the heads (naf_act_noise_body_z)
+__device__ static inline float naf_act_noise_z(uint64_t seed, uint64_t ctr, int64_t s, int i, bool row_on) {
+    float z = 0.f;
+    if (row_on) {
+        Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)s, (uint32_t)i, (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+        float u1 = naf_u01(p.v[0]), u2 = naf_u01(p.v[1]);
+        z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
+    return z;
+}
 template <int PMODE>
-__device__ static inline void naf_act_noise_body(const float* hrow, float* Lt, float* __restrict__ action_out,
-                                                 uint64_t seed, uint64_t ctr, float noise_scale, int64_t s, bool live,
-                                                 int A, int tid) {
+__device__ static inline void naf_act_noise_body_z(const float* hrow, float* Lt, float* __restrict__ action_out, float z,
+                                                   float noise_scale, int64_t s, bool live, int A, int tid) {
     const int i = tid & 7;
     const bool row_on = live && i < A;
-    float mu = 0.f, z = 0.f, Lii = 1.f;
+    float mu = 0.f, Lii = 1.f;
     float L_row[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) L_row[j] = 0.f;
@@ -191,10 +202,6 @@ __device__ static inline void naf_act_noise_body(const float* hrow, float* Lt, f
                 }
             }
         }
-        Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)s, (uint32_t)i, (uint32_t)seed,
-                                  (uint32_t)(seed >> 32));
-        float u1 = naf_u01(p.v[0]), u2 = naf_u01(p.v[1]);
-        z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
     }
     float x = 0.f;
     if (PMODE == NAF_P_HADAMARD) {
@@ -221,4 +228,11 @@ __device__ static inline void naf_act_noise_body(const float* hrow, float* Lt, f
         a = fminf(1.0f, fmaxf(-1.0f, a));
         action_out[s * A + i] = a;
     }
+}
+template <int PMODE>
+__device__ static inline void naf_act_noise_body(const float* hrow, float* Lt, float* __restrict__ action_out,
+                                                 uint64_t seed, uint64_t ctr, float noise_scale, int64_t s, bool live,
+                                                 int A, int tid) {
+    const float z = naf_act_noise_z(seed, ctr, s, tid & 7, live && (tid & 7) < A);
+    naf_act_noise_body_z<PMODE>(hrow, Lt, action_out, z, noise_scale, s, live, A, tid);
 }

@@ -9,13 +9,14 @@
 // partial sums of the 64 lanes are folded by a recursive-halving exchange (a lane keeps half of its values and sends
 // the other half at each xor level), 32 values in 32 cross-lane moves instead of 192.
 // The hidden width is the framework's fixed 256 (rl_framework.py:452): H is a compile-time constant here.
+#include "act_body.h"
 #include "head_body.h"
 
 #define PA_H 256
 #define PA_THREADS 512
 #define PA_WAVES (PA_THREADS / 64)
 #define PA_ROWS_PER_WAVE (PA_H / PA_WAVES)   // 32 output rows of layer 2 per wave
-#define PA_MAX_S 32
+#define PA_MAX_S ACT_MAX_S
 
 typedef float pa_f4 __attribute__((ext_vector_type(4)));
 
@@ -76,13 +77,7 @@ __global__ __launch_bounds__(PA_THREADS) void policy_act_kernel(
     for (int r = 0; r < PA_ROWS_PER_WAVE; ++r)
         w2[r] = *(const pa_f4*)(W2 + (int64_t)(wave * PA_ROWS_PER_WAVE + r) * PA_H + 4 * lane);
     __syncthreads();
-    if (tid < PA_H) {
-        float z = p1;
-#pragma unroll
-        for (int k = 0; k < PA_MAX_S; ++k) z += w1[k] * sObs[k];
-        const float y = (z - t1) * (1.0f / sqrtf(u1 + eps)) * q1 + r1;
-        sA1[tid] = y > 0.f ? y : 0.f;
-    }
+    if (tid < PA_H) sA1[tid] = act_layer1_row(w1, sObs, p1, q1, r1, t1, u1, eps);
     __syncthreads();
 
     // ---- layer 2: wave w owns rows 32 w .. 32 w + 31, lane l the inputs 4 l .. 4 l + 3 --------------------------------
@@ -90,15 +85,10 @@ __global__ __launch_bounds__(PA_THREADS) void policy_act_kernel(
         const pa_f4 x = *(const pa_f4*)(sA1 + 4 * lane);
         float part[PA_ROWS_PER_WAVE];
 #pragma unroll
-        for (int r = 0; r < PA_ROWS_PER_WAVE; ++r)
-            part[r] = w2[r].x * x.x + w2[r].y * x.y + w2[r].z * x.z + w2[r].w * x.w;
+        for (int r = 0; r < PA_ROWS_PER_WAVE; ++r) part[r] = act_dot4(w2[r], x);
         int rfold;
         const float z = pa_fold32(part, lane, &rfold);      // rfold == rloc
-        if (lane < 32) {
-            const float zz = z + p2;
-            const float y = (zz - t2) * (1.0f / sqrtf(u2 + eps)) * q2 + r2;
-            sA2[row2] = y > 0.f ? y : 0.f;
-        }
+        if (lane < 32) sA2[row2] = act_bn_relu(z + p2, t2, u2, q2, r2, eps);
     }
     __syncthreads();
 
@@ -107,9 +97,7 @@ __global__ __launch_bounds__(PA_THREADS) void policy_act_kernel(
         const pa_f4 x = *(const pa_f4*)(sA2 + 4 * lane);
         for (int h = wave; h < NH; h += PA_WAVES) {
             const pa_f4 w = *(const pa_f4*)(Wh + (int64_t)h * ldw + 4 * lane);
-            float p = w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+            float p = act_sum64(act_dot4(w, x));
             if (lane == 0) {
                 p += Wh[(int64_t)h * ldw + PA_H];
                 sHeads[h] = p;

@@ -4,19 +4,10 @@
 // rules that matter are 16-B/lane accesses, whole 128-B lines per row and enough loads in flight.
 #include <stdlib.h>
 #include "common.h"
+#include "sample_body.h"
+#include "replay_dev.h"
 #include "../../include/naf_hip.h"
 #include <new>
-
-struct naf_replay {
-    uint64_t capacity;
-    int S, A, row_floats;
-    float* rows;
-    uint64_t* meta;  // {head, size, total_added, sample_counter, -, -, -, bad_index_count}
-    uint32_t magic;
-};
-#define NAF_REPLAY_MAGIC 0x4e414652u
-
-enum { META_HEAD = 0, META_SIZE = 1, META_TOTAL = 2, META_SAMPLE_CTR = 3, META_BAD_IDX = 7 };
 
 extern "C" int naf_replay_row_floats(int S, int A) {
     if (S <= 0 || A <= 0) return NAF_ERR_ARG;
@@ -185,20 +176,9 @@ extern "C" int naf_replay_add_counted(naf_replay_t* h, const float* src_rows, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// sample: one workgroup per minibatch. Draw t of attempt a = mulhi64(philox(ctr, t, a), size).
-// Without replacement: element t redraws while an element j < t holds the same value; rounds repeat
-// until no duplicate is left (expected number of redraws ~ B^2 / 2N; population >= 4B so a redraw collides with
-// probability <= 1/4 and NAF_SAMPLE_MAX_ROUNDS rounds always suffice in practice). Deterministic in
-// (seed, counter, size): the numpy restatement (oracle.replay_sample_indices) reproduces it bit for bit.
+// sample: one workgroup per minibatch; the draw itself is csrc/sample_body.h (shared with the per-timestep launch of
+// csrc/step_path.hip).
 // ------------------------------------------------------------------------------------------------
-#define NAF_SAMPLE_MAX_ROUNDS 64
-
-__device__ static inline int sample_draw(uint64_t ctr, uint32_t t, uint32_t attempt, uint64_t seed, uint64_t size) {
-    Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), t, attempt, (uint32_t)seed, (uint32_t)(seed >> 32));
-    uint64_t r = ((uint64_t)p.v[0] << 32) | (uint64_t)p.v[1];
-    return (int)__umul64hi(r, size);
-}
-
 __global__ __launch_bounds__(1024) void replay_sample_kernel(const uint64_t* __restrict__ meta, uint64_t seed,
                                                              const uint64_t* __restrict__ counter_dev,
                                                              uint64_t counter_off, int32_t* __restrict__ idx, int B,
@@ -209,117 +189,7 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(const uint64_t* __r
     const uint64_t size = meta[META_SIZE];
     const uint64_t ctr = (counter_dev ? *counter_dev : 0ull) + counter_off + (uint64_t)blockIdx.x;
     int32_t* out = idx + (int64_t)blockIdx.x * B;
-    if (size == 0) {  // nothing to sample from: emit position 0 (the gather flags it as a bad index)
-        for (int t = threadIdx.x; t < B; t += blockDim.x) out[t] = 0;
-        return;
-    }
-    if (without_replacement && size >= (uint64_t)B && size < 4ull * (uint64_t)B) {
-        // dense regime (population < 4B, i.e. the first learn() calls after the `len > batch_size` gate,
-        // naf_algorithm.py:150): rejection would need ~size rounds, so do a partial Fisher-Yates over the
-        // population held in LDS (size < 4B ints fits the 4B-int allocation). Sequential, rare, short.
-        int* perm = vals;
-        for (int t = threadIdx.x; t < (int)size; t += blockDim.x) perm[t] = t;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int t = 0; t < B; ++t) {
-                int j = t + sample_draw(ctr, (uint32_t)t, 0xFFFFFFFFu, seed, size - (uint64_t)t);
-                int a = perm[t];
-                perm[t] = perm[j];
-                perm[j] = a;
-            }
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < B; t += blockDim.x) out[t] = perm[t];
-        return;
-    }
-    const bool dedupe = without_replacement && size >= (uint64_t)B;
-    // elements owned by this thread: t = threadIdx.x + k*blockDim.x, k < 4 (B <= 4096)
-    uint32_t attempt[4] = {0, 0, 0, 0};
-    for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) vals[t] = sample_draw(ctr, (uint32_t)t, 0u, seed, size);
-    __syncthreads();
-    if (dedupe && hash_bits > 0) {
-        // "some earlier element holds the same value" through a hash table in LDS instead of a scan: O(B) per round where
-        // the scan is O(B^2) — 92 us per launch at B = 2048, 30 at B = 1024, on the critical path of every vector step.
-        // Open addressing over M = 2^hash_bits >= 2 B slots: keys[] (the value, claimed by compare-and-swap) and tmin[] (the
-        // smallest element index holding it, atomic min): element t is a duplicate iff tmin of its value < t. The same rule,
-        // so the same indices bit for bit (oracle.replay_sample_indices), whatever order the lanes insert in. Rebuilt every
-        // round (a redrawn element's old value must not linger).
-        const int M = 1 << hash_bits;
-        int* keys = vals + B;
-        int* tmin = keys + M;
-        for (int round = 0; round < NAF_SAMPLE_MAX_ROUNDS; ++round) {
-            for (int e = threadIdx.x; e < M; e += blockDim.x) {
-                keys[e] = -1;
-                tmin[e] = 0x7fffffff;
-            }
-            __syncthreads();
-            int slot[4] = {0, 0, 0, 0};
-            for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) {
-                const int mine = vals[t];
-                unsigned h = ((unsigned)mine * 2654435761u) >> (32 - hash_bits);
-                for (int probe = 0; probe < M; ++probe) {          // (load factor <= 1/2: a free or matching slot exists)
-                    const int was = atomicCAS(&keys[h], -1, mine);
-                    if (was == -1 || was == mine) break;
-                    h = (h + 1) & (unsigned)(M - 1);
-                }
-                atomicMin(&tmin[h], t);
-                slot[k] = (int)h;
-            }
-            __syncthreads();
-            int dupmask = 0;
-            for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k)
-                if (tmin[slot[k]] < t) dupmask |= (1 << k);
-            int any = __syncthreads_or(dupmask);  // also orders the reads above before the writes below
-            if (!any) break;
-            for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) {
-                if (dupmask & (1 << k)) {
-                    attempt[k] += 1u;
-                    vals[t] = sample_draw(ctr, (uint32_t)t, attempt[k], seed, size);
-                }
-            }
-            __syncthreads();
-        }
-    } else if (dedupe) {
-        for (int round = 0; round < NAF_SAMPLE_MAX_ROUNDS; ++round) {
-            int dupmask = 0;
-            for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) {
-                // "some earlier element holds the same value": four candidates per LDS read, eight reads in flight (the
-                // one-int-per-iteration form was a chain of ~B/2 dependent LDS round trips: 20 us per launch at B = 256)
-                const int mine = vals[t];
-                // The scan is VALU-bound (B candidates per element). Wave-uniform trip counts keep the loops unrolled
-                // into independent LDS reads (with a per-lane bound they ran as one dependent read per iteration):
-                // candidates below the wave's first element need no position mask, only the wave's own 64 positions do.
-                // (A sort-based variant, bitonic in LDS, measured slower: 8.9 vs 7.1 us at B = 256.)
-                const int wave_first = t & ~63;                   // uniform inside a wave
-                const int4* v4 = (const int4*)vals;
-                bool dup = false;
-                const int full4 = wave_first >> 2;
-#pragma unroll 8
-                for (int j4 = 0; j4 < full4; ++j4) {
-                    const int4 q = v4[j4];
-                    dup |= (q.x == mine) | (q.y == mine) | (q.z == mine) | (q.w == mine);
-                }
-                const int end4 = (wave_first + 64 < B ? wave_first + 64 : B + 3) >> 2;
-#pragma unroll 8
-                for (int j4 = full4; j4 < end4; ++j4) {
-                    const int4 q = v4[j4];
-                    const int j = 4 * j4;
-                    dup |= ((q.x == mine) & (j + 0 < t)) | ((q.y == mine) & (j + 1 < t)) | ((q.z == mine) & (j + 2 < t)) |
-                           ((q.w == mine) & (j + 3 < t));
-                }
-                if (dup) dupmask |= (1 << k);
-            }
-            int any = __syncthreads_or(dupmask);  // also orders the reads above before the writes below
-            if (!any) break;
-            for (int k = 0, t = threadIdx.x; t < B; t += blockDim.x, ++k) {
-                if (dupmask & (1 << k)) {
-                    attempt[k] += 1u;
-                    vals[t] = sample_draw(ctr, (uint32_t)t, attempt[k], seed, size);
-                }
-            }
-            __syncthreads();
-        }
-    }
+    replay_sample_body(vals, threadIdx.x, blockDim.x, size, ctr, seed, B, without_replacement, hash_bits);
     for (int t = threadIdx.x; t < B; t += blockDim.x) out[t] = vals[t];
 }
 
@@ -332,9 +202,8 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
     // duplicate check through a hash table of M = 2^bits >= 2 B slots: B + 2 M ints of LDS — up to 80 KB at B = 4096, more than
     // the 64 KB a workgroup gets without asking (gfx950 has 160 KB per CU), so the kernel's limit is raised once per process.
     // (Until round 4 the larger batches fell back to the O(B^2) scan: 392 us per launch at B = 4096 against 12 at 2048.)
-    int bits = 1;
-    while ((1 << bits) < 2 * B) ++bits;
-    size_t lds_ints = (size_t)B + 2 * ((size_t)1 << bits);
+    int bits = sample_hash_bits(B);
+    size_t lds_ints = sample_lds_ints(B, bits);
     if (lds_ints * sizeof(int) > 64 * 1024) {
         static int raised_dev[64];   // per device: 0 = not tried, 1 = raised, -1 = refused (then: the scan)
         int dev = 0;
@@ -343,12 +212,10 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
         if (!raised)
             raised = hipFuncSetAttribute((const void*)replay_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) ==
                              hipSuccess ? 1 : -1;
-        if (raised < 0 || lds_ints * sizeof(int) > 96 * 1024) {
-            bits = 0;
-            lds_ints = 0;
-        }
+        if (raised < 0 || lds_ints * sizeof(int) > 96 * 1024) bits = 0;
+        lds_ints = sample_lds_ints(B, bits);         // (5 B ints = 80 KB at B = 4096: needs the raised limit too)
+        if (raised < 0 && lds_ints * sizeof(int) > 64 * 1024) return NAF_ERR_STATE;
     }
-    if (lds_ints < (size_t)B * 4) lds_ints = (size_t)B * 4;
     replay_sample_kernel<<<n_batches, threads, lds_ints * sizeof(int), (hipStream_t)stream>>>(
         h->meta, seed, counter_dev, counter_off, idx, B, without_replacement, bits);
     NAF_CHECK_LAUNCH();

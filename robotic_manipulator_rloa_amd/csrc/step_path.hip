@@ -1,0 +1,663 @@
+// The per-timestep path of the reference's training loop (NAFAgent.step -> act, naf_algorithm.py:129-178, :249-261) as the
+// reference runs it — ONE environment, one transition, one minibatch, one update per timestep — for gfx950.
+//
+// With every launch of a chunk of updates serving one update only, the timestep was 12 launches (counted append, sample, counter,
+// gather, moments, the five of the row-split chain, the optimizer step, act()) and the launch boundaries between them were a third
+// of its device time. Two launches take seven of those:
+//
+//   step_prep_kernel      ReplayBuffer.add of the timestep's transition (utils/replay_buffer.py:32-45; read from pinned host memory,
+//                         counted by a pinned word: 0 = this tick brings no row) + random.sample (:55) + the stacking of the
+//                         minibatch (:57-65) + the moments record of layer 1's inputs (csrc/moments_body.h) — ONE workgroup of 1024
+//                         threads: the draw and the duplicate check live in LDS anyway, the rows of a minibatch are 13 - 52 KB,
+//                         and nothing here is bound by anything but dependent latencies. The draw and the moments are the bodies
+//                         the chunked launches run (sample_body.h, moments_body.h): same indices, same record, bit for bit.
+//   adam_act_kernel       clip_grad_norm_ + Adam.step + soft_update (naf_algorithm.py:209-213, :217-226) of the timestep's update
+//                         AND NAFAgent.act (:158-178) for the next timestep's state in one launch: the workgroups that step a
+//                         slice of the parameters HOLD THE NEW WEIGHTS IN REGISTERS, so they also multiply them with the policy's
+//                         activations — the eval-mode forward costs no second pass over the 330 KB of weights (as a launch of its
+//                         own, one workgroup streaming them fresh from another XCD's write-back, act() was the longest kernel of
+//                         the timestep: 8.6 - 10.7 us). The layers' activations (256 + 256 floats) cross workgroups as
+//                         self-validating (value, epoch) records written and polled with sc1 accesses, the protocol of
+//                         csrc/bn2bwd_fold.h; every poll is bounded by wall clock and a bound that runs out is counted where the
+//                         host sees it and turns the action into NaN (the host raises) — no wave can wait forever.
+#include <string.h>
+#include "common.h"
+NAF_TL_DECL(g_tl_sp);
+#ifdef NAF_TIMELINE
+#define BM_MARK(slot) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot)
+#define SB_MARK(slot) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot)
+#endif
+#include "act_body.h"
+#include "adam_body.h"
+#include "head_body.h"
+#include "moments_body.h"
+#include "replay_dev.h"
+#include "sample_body.h"
+
+NAF_TL_READER(naf_tl_read_sp, g_tl_sp)
+
+// =====================================================================================================================
+// step_prep_kernel
+// =====================================================================================================================
+#define SP_THREADS 1024
+#define SP_RPT 4
+#define SP_CACHE_ROWS 256
+
+struct StepPrepArgs {
+    float4* ring;
+    uint64_t* meta;
+    uint64_t cap;
+    int rf4_shift;
+    const float4* src_row;     // nullable: pinned host (or device) row of this timestep's transition
+    const int32_t* n_word;     // nullable: 0 / 1 rows to append (read where the kernel runs)
+    float4* row_out;           // nullable: the row as read, in device memory (whatever the count says)
+    uint64_t seed;
+    uint64_t* counter;         // the sampler's stream position: read, advanced by one
+    int32_t* idx_out;          // nullable: the B deque positions drawn
+    float4* out_rows;          // the minibatch, w4 float4 per row
+    int w4, trunc_lo, trunc_hi, off_s2_4;
+    float* mom;                // [2][KP + KP * KP]
+    int B, without_replacement, hash_bits;
+};
+
+// the leading floats of a ring row as the learner sees them: `.long()` of the reference on the action columns
+__device__ __forceinline__ static float4 sp_trunc(float4 v, int f0, int lo, int hi) {
+    if (f0 + 3 >= lo && f0 < hi) {
+        if (f0 + 0 >= lo && f0 + 0 < hi) v.x = truncf(v.x);
+        if (f0 + 1 >= lo && f0 + 1 < hi) v.y = truncf(v.y);
+        if (f0 + 2 >= lo && f0 + 2 < hi) v.z = truncf(v.z);
+        if (f0 + 3 >= lo && f0 + 3 < hi) v.w = truncf(v.w);
+    }
+    return v;
+}
+
+// CACHE: B <= SP_CACHE_ROWS (a kernel of its own: with the choice made at run time every load of the moments' staging sat behind
+// a branch with both forms' code around it, and a cold instruction stream is what these few microseconds are made of)
+template <int K4, bool CACHE>
+__global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArgs P) {
+    constexpr int KP = 4 * K4, REC = KP + KP * KP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    BmShared* S = (BmShared*)sp_smem;                                  // [2]: one per net; the draw's table lives here first
+    int* sPos = (int*)(sp_smem + 2 * sizeof(BmShared));                // [B]: physical ring rows of the minibatch
+    // up to SP_CACHE_ROWS rows the gathered minibatch also stays in LDS, where the moments take it from (behind sPos, 16-B aligned)
+    float4* sRows = (float4*)(sp_smem + 2 * sizeof(BmShared) + (size_t)naf_round_up(P.B, 4) * sizeof(int));
+    __shared__ float4 sNew[16];                                        // the appended row (rf4 <= 16 float4)
+    // Small batches (the per-timestep shapes): EVERY global store waits for the end of the kernel. A store in flight makes each
+    // workgroup barrier behind it wait for its acknowledgement (the barrier's release), ~1 us a time, and there are a dozen
+    // barriers between here and there; the appended row is taken from LDS by whoever draws it.
+    constexpr bool cache = CACHE;
+    int* vals = (int*)sp_smem;
+    const int tid = threadIdx.x, B = P.B;
+    const int rf4 = 1 << P.rf4_shift;
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 0);
+
+    // ---- ReplayBuffer.add: 0 or 1 rows, from (pinned host) memory -------------------------------------------------------
+    int n = 0;
+    float4 row4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_row = P.n_word && P.src_row;
+    if (has_row) {
+        // system-scope loads: pinned host memory, or device memory the HOST has stored into (naf_host_publish) — this XCD's L2
+        // may hold what the previous launch read there
+        n = (int)__builtin_amdgcn_raw_buffer_load_b32(naf_buf(P.n_word, 4), 0, 0, 17);
+        n = n < 0 ? 0 : (n > 1 ? 1 : n);
+        if (tid < rf4) {                               // (unconditional: flies beside the count)
+            const naf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(naf_buf(P.src_row), 16u * (unsigned)tid, 0, 17);
+            const unsigned r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];      // (scalar copies: a bit_cast of a vector ELEMENT reads element 0)
+            row4 = make_float4(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1), __builtin_bit_cast(float, r2),
+                               __builtin_bit_cast(float, r3));
+        }
+    }
+    const uint64_t head = P.meta[META_HEAD], size = P.meta[META_SIZE], total = P.meta[META_TOTAL];
+    const uint64_t ctr = *P.counter;
+    const uint64_t head2 = n ? (head + 1 == P.cap ? 0 : head + 1) : head;
+    uint64_t size2 = size + (uint64_t)n;
+    size2 = size2 > P.cap ? P.cap : size2;
+    const int newpos = n ? (int)head : -1;              // physical row the append fills
+    if (tid < rf4) sNew[tid] = row4;
+    auto store_row_and_counters = [&]() {
+        if (n && tid < rf4) P.ring[(head << P.rf4_shift) + tid] = row4;
+        if (P.row_out && has_row && tid < rf4) P.row_out[tid] = row4;
+        if (tid == 0) {
+            if (n) {
+                P.meta[META_HEAD] = head2;
+                P.meta[META_SIZE] = size2;
+                P.meta[META_TOTAL] = total + 1ull;
+            }
+            *P.counter = ctr + 1;
+        }
+    };
+    if (!cache) {
+        __syncthreads();                                // every thread has read {head, size, counter} before thread 0 rewrites them
+        store_row_and_counters();
+    }
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 1);
+
+    // ---- random.sample: the chunked sampler's body on the ring as the append leaves it ---------------------------------------
+    replay_sample_body(vals, tid, SP_THREADS, size2, ctr, P.seed, B, P.without_replacement, P.hash_bits);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 2);
+    const uint64_t base = head2 + P.cap - size2;        // physical position of deque element 0 (oldest)
+    int mypos[4], myidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = tid + SP_THREADS * k;
+        int64_t i = t < B ? (int64_t)vals[t] : 0;
+        myidx[k] = (int)i;
+        bool bad = i < 0 || (uint64_t)i >= size2;
+        if (bad && t < B) atomicAdd((unsigned long long*)&P.meta[META_BAD_IDX], 1ull);
+        if (bad) i = 0;
+        uint64_t pos = base + (uint64_t)i;
+        pos = pos >= P.cap ? pos - P.cap : pos;
+        pos = pos >= P.cap ? pos - P.cap : pos;
+        mypos[k] = (int)pos;
+    }
+    // (sPos is LDS of its own; the draw's table is dead and becomes the moments' staging area behind the barriers below)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = tid + SP_THREADS * k;
+        if (t < B) {
+            sPos[t] = mypos[k];
+            if (!cache && P.idx_out) P.idx_out[t] = myidx[k];
+        }
+    }
+    __syncthreads();                                    // (!cache: the appended row's store has completed too — a workgroup-scope release)
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 3);
+
+    // ---- the minibatch rows: one lane per output float4, SP_RPT in flight ---------------------------------------------------
+    const unsigned w4 = (unsigned)P.w4;
+    const int total4 = B * P.w4;
+    for (int j0 = tid; j0 < total4; j0 += SP_THREADS * SP_RPT) {
+        float4 v[SP_RPT];
+        int col[SP_RPT], pos[SP_RPT];
+#pragma unroll
+        for (int k = 0; k < SP_RPT; ++k) {
+            const int j = j0 + SP_THREADS * k;
+            const unsigned jj = j < total4 ? (unsigned)j : 0u;
+            const unsigned r = jj / w4;
+            col[k] = (int)(jj - r * w4);
+            pos[k] = sPos[r];
+            v[k] = P.ring[((int64_t)pos[k] << P.rf4_shift) + col[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < SP_RPT; ++k) {
+            const int j = j0 + SP_THREADS * k;
+            if (j < total4) {
+                if (cache && pos[k] == newpos) v[k] = sNew[col[k]];        // (the row this launch appends: not in the ring yet)
+                const float4 t = sp_trunc(v[k], 4 * col[k], P.trunc_lo, P.trunc_hi);
+                if (cache) sRows[j] = t;
+                else P.out_rows[j] = t;
+            }
+        }
+    }
+
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 4);
+    // ---- the moments of layer 1's inputs: threads 0 .. 511 the states (net 0), 512 .. 1023 the next states (net 1) ------------
+    const int net = tid >> 9;
+    const int c0 = net ? P.off_s2_4 : 0;
+    // (a record is K4 float4 wide from the net's first column: where that runs past the minibatch row — S = 26 with A >= 2 — the
+    //  chunked launch reads on into the NEXT minibatch row, zeros behind the last one; columns beyond the state size meet zero
+    //  weights, but the record is the same bits here)
+    bb_moments_body<K4>(
+        [&](int row, int q) {
+            int c = c0 + q;
+            if (c >= P.w4) {
+                c -= P.w4;
+                row += 1;
+            }
+            const int rr = row < B ? row : 0;
+            float4 v = cache ? sRows[rr * P.w4 + c]
+                             : sp_trunc(P.ring[((int64_t)sPos[rr] << P.rf4_shift) + c], 4 * c, P.trunc_lo, P.trunc_hi);
+            if (row >= B) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            return v;
+        },
+        S[net], tid & (BM_THREADS - 1), P.mom + net * REC, B);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 5);
+    if (cache) {
+        // everything this launch leaves in memory, in one go (the moments' records left just above)
+        store_row_and_counters();
+        for (int j = tid; j < total4; j += SP_THREADS) P.out_rows[j] = sRows[j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = tid + SP_THREADS * k;
+            if (t < B && P.idx_out) P.idx_out[t] = myidx[k];
+        }
+    }
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
+}
+
+extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed,
+                             uint64_t* counter_dev, int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B,
+                             int without_replacement, void* stream) {
+    if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
+    if (!counter_dev || !out_rows || !mom || B <= 0 || B > 4096 || (((uintptr_t)out_rows | (uintptr_t)mom) & 15) != 0)
+        return NAF_ERR_ARG;
+    if ((src_row == nullptr) != (n_word == nullptr) || ((uintptr_t)src_row & 15) != 0 || ((uintptr_t)n_word & 3) != 0) return NAF_ERR_ARG;
+    if (((uintptr_t)row_out & 15) != 0 || (row_out && !src_row)) return NAF_ERR_ARG;
+    if (action_mode != NAF_ACTION_TRUNC_INT && action_mode != NAF_ACTION_FLOAT) return NAF_ERR_ARG;
+    if ((out_ld & 3) != 0 || out_ld < naf_round_up(naf_row_off_done(h->S, h->A) + 1, 4) || out_ld > h->row_floats) return NAF_ERR_ARG;
+    const int k4 = (h->S + 3) / 4;
+    if (k4 > 8 || out_ld != naf_replay_batch_row_floats(h->S, h->A)) return NAF_ERR_ARG;   // (the row the learner's kernels and the moments expect)
+    StepPrepArgs P;
+    P.ring = (float4*)h->rows;
+    P.meta = h->meta;
+    P.cap = h->capacity;
+    int sh = 0;
+    while ((1 << sh) < h->row_floats / 4) ++sh;
+    P.rf4_shift = sh;
+    P.src_row = (const float4*)src_row;
+    P.n_word = n_word;
+    P.row_out = (float4*)row_out;
+    P.seed = seed;
+    P.counter = counter_dev;
+    P.idx_out = idx_out;
+    P.out_rows = (float4*)out_rows;
+    P.w4 = out_ld / 4;
+    P.trunc_lo = h->S;
+    P.trunc_hi = h->S + h->A;
+    if (action_mode == NAF_ACTION_FLOAT) P.trunc_lo = P.trunc_hi = 0x7fffffff;
+    P.off_s2_4 = naf_row_off_s2(h->S, h->A) / 4;
+    P.mom = mom;
+    P.B = B;
+    P.without_replacement = without_replacement;
+    P.hash_bits = sample_hash_bits(B);
+    size_t draw = sample_lds_ints(B, P.hash_bits) * sizeof(int);
+    size_t lds = 2 * sizeof(BmShared);
+    if (draw > lds) return NAF_ERR_ARG;                  // (cannot happen for B <= 4096: 81,920 <= 82,176)
+    lds += (size_t)naf_round_up(B, 4) * sizeof(int);
+    if (B <= SP_CACHE_ROWS) lds += (size_t)B * out_ld * sizeof(float);       // the minibatch itself (<= 56 KB)
+    static int raised_dev[64];                           // per device: the kernels' dynamic-LDS limit raised once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised_dev[dev]) {
+        const void* ks[4] = {(const void*)step_prep_kernel<6, true>, (const void*)step_prep_kernel<6, false>,
+                             (const void*)step_prep_kernel<8, true>, (const void*)step_prep_kernel<8, false>};
+        for (const void* k : ks) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            if (e != hipSuccess) return (int)e;
+        }
+        raised_dev[dev] = 1;
+    }
+    const bool cache = B <= SP_CACHE_ROWS;
+    if (k4 <= 6 && cache) step_prep_kernel<6, true><<<1, SP_THREADS, lds, (hipStream_t)stream>>>(P);
+    else if (k4 <= 6) step_prep_kernel<6, false><<<1, SP_THREADS, lds, (hipStream_t)stream>>>(P);
+    else if (cache) step_prep_kernel<8, true><<<1, SP_THREADS, lds, (hipStream_t)stream>>>(P);
+    else step_prep_kernel<8, false><<<1, SP_THREADS, lds, (hipStream_t)stream>>>(P);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+// =====================================================================================================================
+// adam_act_kernel
+// =====================================================================================================================
+#define AA_THREADS 512
+#define AA_H 256
+#define AA_L1_WGS 8                       // layer-1 workgroups: 32 rows of W1 each (one float4 of the slice per thread)
+#define AA_L1_ROWS (AA_H / AA_L1_WGS)
+#define AA_L2_WGS 32                      // layer-2 workgroups: 8 rows of W2 each (one wave per row)
+#define AA_POLL_TICKS 200000LL            // 2 ms at 100 MHz: a hang guard, not a schedule (records arrive within ~2 us)
+
+typedef float aa_f4 __attribute__((ext_vector_type(4)));
+
+struct AdamActArgs {
+    AdamArgs ad;
+    int64_t off_W1, off_b1, off_g1, off_be1, off_W2, off_b2, off_g2, off_be2, off_Wh;   // floats, inside the flat buffers
+    int S, NH, NHP, HP, A;
+    const float* obs;                     // [S] (pinned host or device)
+    const float *rm1, *rv1, *rm2, *rv2;   // BatchNorm running statistics of the main net
+    float eps;
+    float* heads_out;                     // nullable [NH]
+    float* action_out;                    // [A] (pinned host or device)
+    uint64_t seed;
+    uint64_t* counter_dev;                // noise stream position: read, advanced by one
+    float noise_scale;
+    // device scratch, zero-initialised once by the caller and owned by this kernel: ints {epoch, wh_arrivals, timeouts, 0 ...} in the
+    // first 64 bytes, then 256 (value, epoch) records of layer 1's activations and 256 of layer 2's
+    int* sync;
+    int wh_wgs;                           // workgroups that step the heads' weights
+    uint64_t* host_errors;                // nullable pinned host word: timed-out polls
+    uint32_t* host_seq;                   // nullable pinned host word: = the launch's epoch once the action has been written
+};
+
+// one float4 / one float of the flat buffers through the pending update (adam_one: the code every other launch of the step runs);
+// loads and arithmetic are separate so that a workgroup has every operand in flight before it derives the step's scalars
+struct AaOld4 {
+    float4 th, gr, mm, vv, tg;
+};
+__device__ __forceinline__ static AaOld4 aa_load4(const AdamArgs& A, int64_t f4) {
+    AaOld4 o;
+    o.th = ((float4*)A.theta)[f4];
+    o.gr = ((const float4*)A.g)[f4];
+    o.mm = ((float4*)A.m)[f4];
+    o.vv = ((float4*)A.v)[f4];
+    o.tg = ((float4*)(A.target ? A.target : A.theta))[f4];
+    return o;
+}
+__device__ __forceinline__ static aa_f4 aa_apply4(const AdamArgs& A, const AdamScalars& sc, AaOld4 o, int64_t f4, bool through) {
+    if (!sc.skip) {
+        const bool ht = A.target != nullptr;
+        adam_one(o.th.x, o.gr.x, o.mm.x, o.vv.x, o.tg.x, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(o.th.y, o.gr.y, o.mm.y, o.vv.y, o.tg.y, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(o.th.z, o.gr.z, o.mm.z, o.vv.z, o.tg.z, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(o.th.w, o.gr.w, o.mm.w, o.vv.w, o.tg.w, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        const unsigned off = (unsigned)(f4 * 16);
+        if (through) naf_buf_st_f4_sc1(naf_buf(A.theta), off, 0, (naf_f32x4){o.th.x, o.th.y, o.th.z, o.th.w});
+        else ((float4*)A.theta)[f4] = o.th;
+        ((float4*)A.m)[f4] = o.mm;
+        ((float4*)A.v)[f4] = o.vv;
+        if (ht) ((float4*)A.target)[f4] = o.tg;
+    }
+    return (aa_f4){o.th.x, o.th.y, o.th.z, o.th.w};
+}
+struct AaOld1 {
+    float th, gr, mm, vv, tg;
+};
+__device__ __forceinline__ static AaOld1 aa_load1(const AdamArgs& A, int64_t e) {
+    AaOld1 o;
+    o.th = A.theta[e];
+    o.gr = A.g[e];
+    o.mm = A.m[e];
+    o.vv = A.v[e];
+    o.tg = (A.target ? A.target : A.theta)[e];
+    return o;
+}
+__device__ __forceinline__ static float aa_apply1(const AdamArgs& A, const AdamScalars& sc, AaOld1 o, int64_t e) {
+    if (!sc.skip) {
+        const bool ht = A.target != nullptr;
+        adam_one(o.th, o.gr, o.mm, o.vv, o.tg, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        A.theta[e] = o.th;
+        A.m[e] = o.mm;
+        A.v[e] = o.vv;
+        if (ht) A.target[e] = o.tg;
+    }
+    return o.th;
+}
+
+// ---- (value, epoch) records: 8 bytes, one sc1 store by the producer; the reader polls two of them per 16-byte sc1 load -------
+__device__ __forceinline__ static void aa_publish(int* recs, int i, float v, int epoch) {
+    const naf_u32x2 r = {__builtin_bit_cast(unsigned, v), (unsigned)epoch};
+    __builtin_amdgcn_raw_buffer_store_b64(r, naf_buf(recs), 8u * (unsigned)i, 0, 16);
+}
+// the four activations 4 l .. 4 l + 3 (records 4 l .. 4 l + 3 = two 16-byte granules); NaN in every slot if the bound ran out
+__device__ __forceinline__ static aa_f4 aa_poll4(int* recs, int l, int epoch, bool* timed_out) {
+    const __amdgpu_buffer_rsrc_t rb = naf_buf(recs);
+    const long long t0 = wall_clock64();
+    while (true) {
+        const naf_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rb, 32u * (unsigned)l, 0, 16);
+        const naf_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rb, 32u * (unsigned)l + 16u, 0, 16);
+        const unsigned a1 = a[1], a3 = a[3], b1 = b[1], b3 = b[3];
+        if ((int)a1 == epoch && (int)a3 == epoch && (int)b1 == epoch && (int)b3 == epoch) {
+            const unsigned x0 = a[0], x1 = a[2], x2 = b[0], x3 = b[2];
+            return (aa_f4){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1), __builtin_bit_cast(float, x2),
+                           __builtin_bit_cast(float, x3)};
+        }
+        if (wall_clock64() - t0 > AA_POLL_TICKS) break;
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");                  // a poll: the loads above are issued again every trip
+    }
+    *timed_out = true;
+    const float nan = __builtin_nanf("");
+    return (aa_f4){nan, nan, nan, nan};
+}
+__device__ static inline void aa_count_timeout(const AdamActArgs& P) {
+    atomicAdd(&P.sync[2], 1);
+    if (P.host_errors) __hip_atomic_fetch_add((unsigned long long*)P.host_errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// a workgroup barrier for LDS hand-overs only: __syncthreads() also releases at workgroup scope, i.e. waits for every global store
+// the wave has in flight (the stepped parameters: ~1 us of acknowledgements) — nothing here reads those stores in this launch
+__device__ __forceinline__ static void aa_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int PMODE>
+__global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs P) {
+    __shared__ AdamScalars sSc;
+    __shared__ __attribute__((aligned(16))) float sAct[AA_H];                 // a1 (layer-2 workgroups) / a2 (the last workgroup)
+    __shared__ __attribute__((aligned(16))) float sW[64 * ACT_MAX_S + 3 * 64]; // layer-1 workgroups: their 64 rows of W1, b1, g1, be1
+    __shared__ float sObs[ACT_MAX_S];
+    __shared__ float sHeads[HEAD_MAX_LDH];
+    __shared__ float sL[PMODE == NAF_P_MATMUL ? 8 * LT_STRIDE : 1];
+    __shared__ int sTimed;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x;
+    const AdamArgs& A = P.ad;
+    // (only the last workgroup writes the epoch, behind everything it waits for; unsigned arithmetic: it may wrap)
+    const int epoch = (int)((unsigned)P.sync[0] + 1u);
+    int* rec1 = P.sync + 16;
+    int* rec2 = P.sync + 16 + 2 * AA_H;
+    if (tid == 0) sTimed = 0;
+    const int wh_wgs = P.wh_wgs;                        // workgroups that step Wh: ceil(NHP * HP / 4 / AA_THREADS)
+    const bool tl_l2 = wg == AA_L1_WGS + wh_wgs;        // (timeline: the first layer-2 workgroup leaves slots 8 ...)
+    NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 0);
+
+    if (wg < AA_L1_WGS) {
+        // ---- layer 1: rows 32 wg .. 32 wg + 31 of W1 and of b1 / g1 / be1 --------------------------------------------------
+        constexpr int R = AA_L1_ROWS;
+        const int S = P.S, row0 = R * wg;
+        const int nW4 = R * S / 4, items = nW4 + 3 * R / 4;   // float4 of this workgroup's slice (R S floats start 16-byte aligned)
+        if (tid < ACT_MAX_S) sObs[tid] = tid < S ? P.obs[tid] : 0.f;
+        // this thread's float4 of the flat buffers, and where its new value goes in LDS
+        int lds;
+        int64_t f4;
+        {
+            const int it = tid < items ? tid : 0;
+            if (it < nW4) {
+                lds = 4 * it;
+                f4 = (P.off_W1 + (int64_t)row0 * S) / 4 + it;
+            } else {
+                const int j = it - nW4, seg = j / (R / 4), c = j % (R / 4);
+                lds = R * ACT_MAX_S + R * seg + 4 * c;
+                const int64_t off = seg == 0 ? P.off_b1 : (seg == 1 ? P.off_g1 : P.off_be1);
+                f4 = (off + row0) / 4 + c;
+            }
+        }
+        const AaOld4 o = aa_load4(A, f4);
+        const float rm = P.rm1[row0 + (tid & (R - 1))], rv = P.rv1[row0 + (tid & (R - 1))];
+        const AdamPrefetch pf = adam_prefetch(A, tid);
+        adam_derive(A, pf, &sSc, tid);
+        __syncthreads();
+        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 1);
+        const AdamScalars sc = sSc;
+        if (tid < items) {
+            const aa_f4 nv = aa_apply4(A, sc, o, f4, false);
+            *(aa_f4*)(sW + lds) = nv;
+        }
+        aa_lds_barrier();
+        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 2);
+        if (tid < R) {
+            const int row = row0 + tid;
+            float w1[ACT_MAX_S];
+#pragma unroll
+            for (int k = 0; k < ACT_MAX_S; ++k) w1[k] = k < S ? sW[tid * S + k] : 0.f;
+            const float a1 = act_layer1_row(w1, sObs, sW[R * ACT_MAX_S + tid], sW[R * ACT_MAX_S + R + tid],
+                                            sW[R * ACT_MAX_S + 2 * R + tid], rm, rv, P.eps);
+            aa_publish(rec1, row, a1, epoch);
+        }
+        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 3);
+        return;
+    }
+
+    if (wg < AA_L1_WGS + wh_wgs) {
+        // ---- the heads' weights: one float4 per thread, written THROUGH (the last workgroup reads them in this launch), then one
+        // arrival per workgroup once the stores have landed. Dispatched ahead of the layer-2 workgroups and depending on nothing:
+        // long done when the last workgroup asks.
+        const int64_t i = (int64_t)(wg - AA_L1_WGS) * AA_THREADS + tid, n4 = (int64_t)P.NHP * (P.HP / 4);
+        const bool on = i < n4;
+        const int64_t f = P.off_Wh / 4 + (on ? i : 0);
+        const AaOld4 o = aa_load4(A, f);
+        const AdamPrefetch pf = adam_prefetch(A, tid);
+        adam_derive(A, pf, &sSc, tid);
+        __syncthreads();
+        const AdamScalars sc = sSc;
+        if (on) aa_apply4(A, sc, o, f, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&P.sync[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+
+    if (wg < AA_L1_WGS + wh_wgs + AA_L2_WGS) {
+        // ---- layer 2: wave = one row of W2 (64 float4, lane l holds inputs 4 l .. 4 l + 3) --------------------------------------
+        NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 8, tl_l2, false);
+        const int w = wg - AA_L1_WGS - wh_wgs, row = 8 * w + wave;
+        const int64_t fW2 = P.off_W2 / 4 + 64 * (int64_t)row + lane;
+        const AaOld4 o2 = aa_load4(A, fW2);
+        AaOld1 ob = {}, og = {}, obe = {};
+        if (lane == 0) {
+            ob = aa_load1(A, P.off_b2 + row);
+            og = aa_load1(A, P.off_g2 + row);
+            obe = aa_load1(A, P.off_be2 + row);
+        }
+        const float rm = P.rm2[row], rv = P.rv2[row];
+        const AdamPrefetch pf = adam_prefetch(A, tid);
+        adam_derive(A, pf, &sSc, tid);
+        __syncthreads();
+        NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 9, tl_l2, false);
+        const AdamScalars sc = sSc;
+        const aa_f4 w2 = aa_apply4(A, sc, o2, fW2, false);
+        float b2 = 0.f, g2 = 0.f, be2 = 0.f;
+        if (lane == 0) {
+            b2 = aa_apply1(A, sc, ob, P.off_b2 + row);
+            g2 = aa_apply1(A, sc, og, P.off_g2 + row);
+            be2 = aa_apply1(A, sc, obe, P.off_be2 + row);
+        }
+        NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 10, tl_l2, false);
+        // layer 1's activations: polled by the first wave, shared through LDS
+        if (wave == 0) {
+            bool timed = false;
+            const aa_f4 x = aa_poll4(rec1, lane, epoch, &timed);
+            *(aa_f4*)(sAct + 4 * lane) = x;
+            if (timed) sTimed = 1;
+        }
+        aa_lds_barrier();
+        NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 11, tl_l2, false);
+        if (sTimed && tid == 0) aa_count_timeout(P);
+        const aa_f4 x = *(const aa_f4*)(sAct + 4 * lane);
+        float p = act_dot4(w2, x);
+        p = act_sum64(p);
+        if (lane == 0) aa_publish(rec2, row, act_bn_relu(p + b2, rm, rv, g2, be2, P.eps), epoch);
+        NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 12, tl_l2, false);
+        return;
+    }
+
+    // ---- the last workgroup: heads, exploration noise, clamp ----------------------------------------------------------------------
+    {
+        const uint64_t ctr = *P.counter_dev;
+        const int NH = P.NH;
+        // every float4 of Wh has been stepped and written through once its workgroups have arrived
+        if (tid == 0) {
+            const unsigned want = (unsigned)epoch * (unsigned)wh_wgs;
+            const long long t0 = wall_clock64();
+            while ((int)((unsigned)__hip_atomic_load(&P.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                if (wall_clock64() - t0 > AA_POLL_TICKS) { sTimed = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 1);
+        const __amdgpu_buffer_rsrc_t whb = naf_buf(A.theta + P.off_Wh);
+        aa_f4 wh[HEAD_MAX_LDH / 8];
+        float bias[HEAD_MAX_LDH / 8];
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_LDH / 8; ++k) {
+            const int h = wave + 8 * k;
+            const unsigned roff = (unsigned)(h < NH ? h : 0) * (unsigned)P.HP * 4u;
+            wh[k] = naf_buf_f4_sc1(whb, 16u * (unsigned)lane, roff);
+            const naf_f32x4 bq = naf_buf_f4_sc1(whb, 16u * (unsigned)(AA_H / 4), roff);
+            bias[k] = bq[0];
+        }
+        // the standard normal draw of the noise depends on nothing the launch computes: taken while the activations are under way
+        const float zn = naf_act_noise_z(P.seed, ctr, 0, tid & 7, tid < 8 && (tid & 7) < P.A);
+        if (wave == 0) {
+            bool timed = false;
+            const aa_f4 x = aa_poll4(rec2, lane, epoch, &timed);
+            *(aa_f4*)(sAct + 4 * lane) = x;
+            if (timed) sTimed = 1;
+        }
+        __syncthreads();
+        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 2);
+        const bool timed = sTimed != 0;
+        const aa_f4 x = *(const aa_f4*)(sAct + 4 * lane);
+        float ph[HEAD_MAX_LDH / 8];
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_LDH / 8; ++k) ph[k] = act_dot4(wh[k], x);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_LDH / 8; ++k) {
+            const int h = wave + 8 * k;
+            if (h < NH) {                                   // (wave-uniform)
+                float p = act_sum64(ph[k]);
+                if (lane == 0) {
+                    p += bias[k];
+                    sHeads[h] = timed ? __builtin_nanf("") : p;
+                    if (P.heads_out) P.heads_out[h] = p;
+                }
+            }
+        }
+        __syncthreads();
+        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 3);
+        naf_act_noise_body_z<PMODE>(sHeads, sL, P.action_out, zn, P.noise_scale, 0, tid < 8, P.A, tid);
+        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 4);
+        if (tid < 64) {                                     // (the first wave: it holds the lanes that wrote the action)
+            if (tid == 0) {
+                if (timed) aa_count_timeout(P);
+                *P.counter_dev = ctr + 1;
+                P.sync[0] = epoch;
+            }
+            if (P.host_seq) {
+                // the action's stores (to fine-grained host memory: written through) are acknowledged before the word that announces
+                // them leaves — no release fence, which would write back this XCD's whole L2 first
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tid == 0) __hip_atomic_store(P.host_seq, (uint32_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 5);
+    }
+}
+
+extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
+                                   float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode,
+                                   int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, void* stream) {
+    if (!adam || !net || !obs || !action_out || !counter_dev || !sync || ((uintptr_t)sync & 15) != 0) return NAF_ERR_ARG;
+    AdamActArgs P;
+    memset(&P, 0, sizeof(P));
+    if (!adam_args_from(*adam, P.ad)) return NAF_ERR_ARG;
+    P.ad.bc = nullptr;
+    const int S = net->S, A = net->A, H = net->H, NHP = net->NHP, HP = net->HP;
+    const int NH = A + A * (A + 1) / 2 + 1;
+    if (H != AA_H || S <= 0 || S > ACT_MAX_S || A <= 0 || A > NAF_MAX_A || NH > HEAD_MAX_LDH || NHP < NH ||
+        HP <= H || (HP & 3) != 0 || HP / 4 > AA_THREADS)
+        return NAF_ERR_ARG;
+    if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
+    // the flat layout this kernel walks: [W1 | b1 | g1 | be1 | W2 | b2 | g2 | be2 | Wh] back to back (offsets in floats, multiples of
+    // 4; W1 rows of 64 start on 16-byte boundaries because 64 S floats do), covering the whole buffer — every parameter is stepped
+    const int64_t o[9] = {net->off_W1, net->off_b1, net->off_g1, net->off_be1, net->off_W2, net->off_b2, net->off_g2, net->off_be2, net->off_Wh};
+    const int64_t len[9] = {(int64_t)H * S, H, H, H, (int64_t)H * H, H, H, H, (int64_t)NHP * HP};
+    int64_t at = 0;
+    for (int i = 0; i < 9; ++i) {
+        if (o[i] != at || (o[i] & 3) != 0) return NAF_ERR_ARG;
+        at += len[i];
+    }
+    if (at != adam->n) return NAF_ERR_ARG;
+    if (!net->running_mean1 || !net->running_var1 || !net->running_mean2 || !net->running_var2) return NAF_ERR_ARG;
+    P.off_W1 = o[0]; P.off_b1 = o[1]; P.off_g1 = o[2]; P.off_be1 = o[3]; P.off_W2 = o[4]; P.off_b2 = o[5]; P.off_g2 = o[6];
+    P.off_be2 = o[7]; P.off_Wh = o[8];
+    P.S = S; P.NH = NH; P.NHP = NHP; P.HP = HP; P.A = A;
+    P.obs = obs;
+    P.rm1 = net->running_mean1; P.rv1 = net->running_var1; P.rm2 = net->running_mean2; P.rv2 = net->running_var2;
+    P.eps = net->eps;
+    P.heads_out = heads_out;
+    P.action_out = action_out;
+    P.seed = seed;
+    P.counter_dev = counter_dev;
+    P.noise_scale = noise_scale;
+    P.sync = sync;
+    P.host_errors = host_errors;
+    P.host_seq = host_seq;
+    P.wh_wgs = (int)(((int64_t)NHP * (HP / 4) + AA_THREADS - 1) / AA_THREADS);
+    const int grid = AA_L1_WGS + P.wh_wgs + AA_L2_WGS + 1;
+    if (p_mode == NAF_P_HADAMARD) adam_act_kernel<NAF_P_HADAMARD><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P);
+    else adam_act_kernel<NAF_P_MATMUL><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+extern "C" int naf_adam_polyak_act_sync_ints(void) { return 16 + 4 * AA_H; }

@@ -77,6 +77,11 @@ class TrainChunk:
         self.tail, self._tail_state = tail, tuple(tail_state)
         self.head_row = head_row
         self.head_count = torch.zeros(1, dtype=torch.int32).pin_memory() if head_row is not None else None
+        rf = learner.lay.row_floats
+        if head_row is not None and head_row.numel() >= rf + 4:
+            # (a row with room for its count behind it: [row (rf floats) | count (int32) | 0 0 0] — one contiguous piece of host
+            #  memory, so the per-timestep path can hand both to the GPU in one store, see head_dev below)
+            self.head_count = head_row.view(-1)[rf:rf + 1].view(torch.int32)
         self._ran = None                   # event behind the last run(): the pinned words are free again once it has passed
         self.L, self.replay, self.U = learner, replay, int(n_updates)
         self.teacher_forced = teacher_forced
@@ -98,6 +103,40 @@ class TrainChunk:
                         if "bb" in learner.fuse else None)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph
+        # The per-timestep shape (ONE update per chunk on the row-split chain: the reference's own loop, NAFAgent.step with
+        # num_updates = 1) runs two fused launches of csrc/step_path.hip around the chain's five:
+        #   fused_prep: [counted append +] sample + gather + moments in one launch (naf_step_prep) instead of five;
+        #   fused_tail: the update's optimizer step and the tail's act() in one launch (naf_adam_polyak_act) instead of two —
+        #               `tail` must then be the bound `act` of an ActPath that can take the step along (ActPath.can_ride).
+        # NAF_STEP_FUSED=0 keeps the separate launches (A/B measurements; the bit-equality test runs both).
+        fused = os.environ.get("NAF_STEP_FUSED", "1") != "0"
+        self.fused_prep = (fused and self.U == 1 and self.moments is not None and not teacher_forced and not gather_outside_graph)
+        actor = getattr(tail, "__self__", None)
+        self.fused_tail = (fused and isinstance(actor, ActPath) and actor.can_ride and learner.defer_ok)
+        self._tail_actor = actor if self.fused_tail else None
+        # with both: the first launch leaves a device copy of the pinned row, and the last takes the policy's observation from its
+        # next_state columns (the state the loop asks about next IS the transition's next state) — one read of host memory per
+        # timestep instead of two, and none on the last launch's critical path
+        self.row_dev = None
+        if self.fused_prep and self.fused_tail and head_row is not None:
+            self.row_dev = torch.zeros(learner.lay.row_floats, dtype=torch.float32, device=dev)
+            self._obs_ptr = self.row_dev.data_ptr() + 4 * learner.lay.off_s2
+        # fused_prep with a [row | count] head row: the launch reads both from DEVICE memory that the host stores into directly
+        # (naf_host_publish: every device allocation is CPU-mapped here) — its first dependent load is then a local-memory
+        # latency (~0.8 us) instead of a PCIe round trip to pinned host memory (~2.8 us, measured inside the kernel)
+        self.head_dev = None
+        if self.fused_prep and head_row is not None and head_row.numel() >= rf + 4 and os.environ.get("NAF_HOST_STORE", "1") != "0":
+            self.head_dev = torch.zeros(rf + 4, dtype=torch.float32, device=dev)
+            self._head_src, self._head_dst, self._head_bytes = head_row.data_ptr(), self.head_dev.data_ptr(), 4 * (rf + 1)
+            self._publish = learner.lib.naf_host_publish
+        # fused tail: the launch writes its ordinal to a pinned host word behind the action (ActPath.seq) — the host learns that
+        # a run() has passed by polling that word instead of synchronising an event / the stream
+        self._seq_np = actor.seq_np if self.fused_tail else None
+        self._seq_prev = 0
+        self._inflight = False             # a run() whose ordinal the host has not seen yet
+        self._exec = None
+        self._err_np = learner.err_host.numpy()
+        self._head_count_np = self.head_count.numpy() if self.head_count is not None else None
 
     def _sample_gather(self) -> None:
         if not self.teacher_forced:
@@ -112,8 +151,8 @@ class TrainChunk:
                 self.empty_events[0].record()
                 self.empty_events[1].record()
 
-    def _updates(self) -> None:
-        if self.moments is not None:
+    def _updates(self, moments_ready: bool = False) -> None:
+        if self.moments is not None and not moments_ready:
             self.L.moments(self.batch.view(self.U * self.L.B, -1), self.moments, self.U)
         # a chain of updates: the optimizer step of update k rides on the first two launches of update k + 1 (one launch
         # less per update, Learner.defer_ok); the last one of the chunk takes its step as a launch of its own, so the
@@ -121,11 +160,24 @@ class TrainChunk:
         d = self.L.defer_ok
         for k in range(self.U):
             self.L.learn_rows(self.batch[k], self.loss_parts[k], None if self.moments is None else self.moments[k],
-                              pending=d and k > 0, defer=d and k < self.U - 1)
-        if self.tail is not None:
+                              pending=d and k > 0, defer=d and (k < self.U - 1 or self.fused_tail))
+        if self.fused_tail:
+            # the last update's clip + Adam + Polyak and the tail's act(): one launch
+            self._tail_actor.act_with_optimizer_step(obs_ptr=self._obs_ptr if self.row_dev is not None else None)
+        elif self.tail is not None:
             self.tail()
 
     def _body(self) -> None:
+        if self.fused_prep:
+            r = self.replay
+            src, cnt = ptr(self.head_row), ptr(self.head_count)
+            if self.head_dev is not None:
+                src, cnt = self.head_dev.data_ptr(), self.head_dev.data_ptr() + 4 * self.L.lay.row_floats
+            check(self.L.lib.naf_step_prep(r.handle, src, cnt, ptr(self.row_dev), r.seed,
+                                           ptr(r._sample_ctr), ptr(self.idx), ptr(self.batch), self.batch.shape[-1], r.action_mode,
+                                           ptr(self.moments), self.L.B, int(r.without_replacement), stream_ptr()), "naf_step_prep")
+            self._updates(moments_ready=True)
+            return
         if self.head_row is not None:
             check(self.L.lib.naf_replay_add_counted(self.replay.handle, ptr(self.head_row), ptr(self.head_count), 1, stream_ptr()),
                   "naf_replay_add_counted")
@@ -147,6 +199,8 @@ class TrainChunk:
             saved = self.replay.rows[pos].clone()
             count = int(self.head_count[0])
             self.head_count[0] = 1         # the warm-up runs really append (and are undone)
+            if self.head_dev is not None:
+                self._publish(self._head_dst, self._head_src, self._head_bytes)
 
             def put_back():
                 self.replay.rows[pos] = saved
@@ -154,12 +208,47 @@ class TrainChunk:
             self.graph = _capture(self._body, snap, warmup=warmup, after_warmup=put_back)
         else:
             self.graph = _capture(self._body, snap)
+        self._raw_exec()
+
+    def _raw_exec(self) -> None:
+        """the instantiated graph's handle, for run_row()'s direct launch (None: torch's replay())"""
+        self._exec = None
+        self._launch = self.L.lib.naf_host_publish_launch
+        if self.graph is not None and self.head_dev is not None and hasattr(self.graph, "raw_cuda_graph_exec"):
+            try:
+                self._exec = int(self.graph.raw_cuda_graph_exec())
+            except Exception:                      # (a torch build that keeps the handle to itself)
+                self._exec = None
 
     def wait_pinned_free(self) -> None:
         """Block until the last run() has passed: what it reads from pinned host memory (the head row, its count, a tail's
         observation) may be rewritten afterwards. In NAFAgent.run's loop act() has waited for it already."""
-        if self._ran is not None:
+        if self._seq_np is not None:
+            if self._inflight:
+                self.wait_tail()
+        elif self._ran is not None:
             self._ran.synchronize()
+
+    def wait_tail(self) -> None:
+        """Block until the last run()'s tail has written its action to pinned host memory. Fused tail: a spin on the pinned
+        ordinal the launch writes behind the action (no stream synchronisation: the hipStreamSynchronize round trip was a tenth
+        of a timestep); other tails: the stream."""
+        if self._seq_np is None:
+            torch.cuda.current_stream().synchronize()
+            return
+        if not self._inflight:
+            return
+        sq, prev, n = self._seq_np, self._seq_prev, 0
+        while sq[0] == prev:
+            n += 1
+            if n > 4000000:                 # (seconds: something is wrong — let the runtime say what)
+                torch.cuda.current_stream().synchronize()
+                if sq[0] == prev:
+                    raise _lib.NafHipError("the update graph finished without its tail launch writing an action")
+        self._inflight = False
+        if self._err_np[1]:
+            raise _lib.NafHipError(f"naf_adam_polyak_act: {int(self.L.err_host[1])} polls inside the launch ran into their 2-ms bound "
+                                   "(the GPU is over-subscribed or a workgroup died): the action is not valid")
 
     def run(self, head_rows: int = 0) -> None:
         """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first. head_rows (chunks built with
@@ -173,18 +262,43 @@ class TrainChunk:
             # step() would otherwise zero the count of a row the GPU has not appended yet); in run()'s loop act() has waited
             self.wait_pinned_free()
             self.head_count[0] = 1 if head_rows else 0
+        if self.use_graph and self.graph is None:
+            self.capture()
+        if self._seq_np is not None:
+            if self._inflight:
+                self.wait_tail()               # (its ordinal must be in before the next launch's "before" value is read)
+            self._seq_prev = int(self._seq_np[0])
+        if self.head_dev is not None:
+            self._publish(self._head_dst, self._head_src, self._head_bytes)
         if self.use_graph:
-            if self.graph is None:
-                self.capture()
             if self.gather_outside_graph:
                 self._sample_gather()
             self.graph.replay()
         else:
             self._body()
-        if self.head_row is not None or self.tail is not None:
+        if self._seq_np is not None:
+            self._inflight = True
+        elif self.head_row is not None or self.tail is not None:
             if self._ran is None:
                 self._ran = torch.cuda.Event()
             self._ran.record()
+
+    def run_row(self) -> None:
+        """run(head_rows=1) for the caller that has done run()'s checks itself (NAFAgent.step's per-timestep path: the graph
+        exists, the previous run has passed, the pinned row is filled)."""
+        self._head_count_np[0] = 1
+        self._seq_prev = int(self._seq_np[0])
+        if self._exec is not None:
+            # the row into device memory and the graph's launch in ONE foreign call (torch's replay() is that launch plus
+            # device guards and generator bookkeeping this graph does not need)
+            rc = self._launch(self._head_dst, self._head_src, self._head_bytes, self._exec, torch.cuda.current_stream().cuda_stream)
+            if rc:
+                check(rc, "naf_host_publish_launch")
+        else:
+            if self.head_dev is not None:
+                self._publish(self._head_dst, self._head_src, self._head_bytes)
+            self.graph.replay()
+        self._inflight = True
 
     def losses(self) -> torch.Tensor:
         """[U] MSE losses of the last run (device tensor; summing the per-workgroup parts in index order)."""

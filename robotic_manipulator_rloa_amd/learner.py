@@ -761,6 +761,41 @@ class ActPath:
         self.W1T = learner.W1T2[0]
         self.W2T = learner.W2T2[0]
         self.WhT = learner.WhT2[0]
+        # ONE state on the row-split chain: the optimizer step of the update in front can take this act() along
+        # (naf_adam_polyak_act, csrc/step_path.hip: the workgroups that step the weights multiply them with the policy's
+        # activations) — NAFAgent.step's graph then ends with one launch instead of two. `seq` (pinned host): the launch's ordinal,
+        # written behind the action: a host that polls it reads the action without synchronising the stream.
+        seg = lay.seg
+        self.can_ride = (self.fused and E == 1 and learner.defer_ok and lay.NHP <= 64 and
+                         [seg[k].offset for k in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "Wh")] ==
+                         [0, H * lay.S, H * lay.S + H, H * lay.S + 2 * H, H * lay.S + 3 * H, H * lay.S + 3 * H + H * H,
+                          H * lay.S + 4 * H + H * H, H * lay.S + 5 * H + H * H, H * lay.S + 6 * H + H * H] and
+                         lay.P == H * lay.S + 6 * H + H * H + lay.NHP * lay.HP)
+        self.sync = self.seq = self.seq_np = None
+        if self.can_ride:
+            self.sync = torch.zeros(learner.lib.naf_adam_polyak_act_sync_ints(), dtype=torch.int32, device=dev)
+            self.seq = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self.seq_np = self.seq.numpy()
+            bnp = learner.bn_stats.data_ptr()
+            self._net = _lib.ActNet(lay.S, lay.A, H, lay.NHP, lay.HP, *[seg[k].offset for k in
+                                    ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "Wh")],
+                                    bnp, bnp + 4 * H, bnp + 8 * H, bnp + 12 * H, BN_EPS)
+
+    def act_with_optimizer_step(self, noise_scale: float = 1.0, obs_ptr: Optional[int] = None) -> torch.Tensor:
+        """The pending optimizer step of the learner (a learn_rows(defer=True) in front) and act() on the parameters it leaves, in
+        one launch. Same parameters as Learner.optimizer_step() and the same action as act() behind it, bit for bit.
+        obs_ptr: where the observation lies instead of self.obs (device-visible, S floats)."""
+        L = self.L
+        check(L.lib.naf_adam_polyak_act(_lib.C.byref(L._adam_args), _lib.C.byref(self._net), obs_ptr or ptr(self.obs), ptr(self.Gh),
+                                        ptr(self.actions), self.seed, ptr(self.counter), float(noise_scale), L.p_mode,
+                                        ptr(self.sync), L.err_host.data_ptr() + 8, ptr(self.seq), stream_ptr()), "adam_polyak_act")
+        return self.actions
+
+    @property
+    def act_timeouts(self) -> int:
+        """Polls inside naf_adam_polyak_act whose 2-ms bound ran out (pinned host word; 0 on a healthy GPU): the action of such a
+        launch is NaN."""
+        return int(self.L.err_host[1])
 
     def heads(self) -> None:
         L, lay, E, st = self.L, self.L.lay, self.E, stream_ptr()

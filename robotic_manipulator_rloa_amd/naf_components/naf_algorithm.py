@@ -105,6 +105,7 @@ class NAFAgent:
         self._dp_ticks = 0                 # update-schedule ticks (step() calls + idle ticks): the gate under data parallel
         self._last_loss_from = None        # "chunk" | "learn": which path ran the most recent update
         self._ahead = None                 # the state the last step()'s graph already ran the policy on (see _update_tick)
+        self._fast = None                  # (chunk, pinned row) once every step() is "write the row, replay the graph" (step())
         self.use_graph = use_graph
         self._chunk: Optional[TrainChunk] = None
         self._actor1: Optional[ActPath] = None
@@ -113,7 +114,8 @@ class NAFAgent:
         self._act_pinned = torch.zeros(1, action_size, dtype=torch.float32).pin_memory()
         self._learn_rows = torch.zeros(batch_size + 1, L.lay.batch_row_floats, dtype=torch.float32, device=self.device)[:batch_size]
         self._learn_loss = torch.zeros(L.n_loss_wg, dtype=torch.float32, device=self.device)
-        self._row_pin = torch.zeros(1, L.lay.row_floats, dtype=torch.float32).pin_memory()    # step()'s transition, read by the graph
+        # step()'s transition, read by the graph: [row | count (int32, kept by TrainChunk) | pad]
+        self._row_pin = torch.zeros(1, L.lay.row_floats + 4, dtype=torch.float32).pin_memory()
         self._row_np = self._row_pin.numpy()
         self.last_run_stats: Optional[dict] = None    # counters of the most recent run_vectorized / run_host_vectorized
 
@@ -140,19 +142,56 @@ class NAFAgent:
     def step(self, state, action, reward: float, next_state, done: int) -> None:
         """Store the experience and, every update_freq steps once len(memory) > batch_size, run num_updates
         (sample + learn) (naf_algorithm.py:129-156). The updates are one captured graph:
-        [append this transition] -> sample num_updates minibatches -> one gather -> num_updates x learn -> [act(next_state)]."""
-        if self._row_in_graph():
+        [append this transition] -> sample num_updates minibatches -> one gather -> num_updates x learn -> [act(next_state)];
+        with one update per timestep (the reference's own loop) it is seven launches: the append, the draw, the gather and the
+        moments in one (naf_step_prep), the five of the row-split chain, the optimizer step and the policy's forward on the next
+        state in one (naf_adam_polyak_act)."""
+        f = self._fast
+        if f is not None and self.memory._pending == 0:
             # every tick updates (update_freq = 1, gate open): the append is the first node of the update's graph, reading
             # the transition from a pinned row of its own — same order (add, then sample) as the reference's step()
+            ch, row = f
+            ch.wait_pinned_free()     # the previous graph's append has read the row (run()'s act() waited already)
+            S, A, o2 = self._S, self._A, self._o2
+            row[:S] = state[0] if isinstance(state, tuple) else state
+            row[S:S + A] = action
+            row[S + A] = reward
+            row[o2:o2 + S] = next_state
+            row[o2 + S] = done
+            self.memory._total_added += 1
+            self._dp_ticks += 1                                    # (update_t_step stays 0: update_freq = 1)
+            if done or ch.tail is None:
+                self._ahead = None
+            else:
+                # the graph ends with the policy's forward on the state the loop will ask about next (_update_tick) — taken
+                # from the row's own next_state columns where both ends of the graph are the fused launches
+                if not self._obs_in_row:
+                    self._obs1[:] = next_state
+                self._ahead = self._obs1
+            if ch._seq_np is not None and self.world_size == 1:
+                ch.run_row()
+            else:
+                ch.run(head_rows=1)
+            self._last_loss_from = "chunk"
+            return
+        if self._row_in_graph():
             m, row = self.memory, self._row_np[0]
             S, A = m.S, m.A
-            self._chunk.wait_pinned_free()     # the previous graph's append has read the row (run()'s act() waited already)
+            self._chunk.wait_pinned_free()
             row[:S] = state[0] if isinstance(state, tuple) else state
             row[S:S + A] = action
             row[S + A] = reward
             row[m.off_s2:m.off_s2 + S] = next_state
             row[m.off_s2 + S] = done
             m._total_added += 1
+            # from here on every step() takes the short way above (the gate never closes again; a row waiting in the staging
+            # area — memory._pending — is checked there)
+            if self.use_graph and self._chunk.graph is not None:
+                self._S, self._A, self._o2 = S, A, m.off_s2
+                self._obs_in_row = self._chunk.row_dev is not None
+                self._obs1 = (row[m.off_s2:m.off_s2 + S] if self._obs_in_row else
+                              (self._actor1.obs_np[0] if (self._actor1 is not None and self._actor1.host_io) else None))
+                self._fast = (self._chunk, row)
             self._update_tick(None if done else next_state, row_in_graph=True)
             return
         self.memory.add(state, action, reward, next_state, done)
@@ -196,19 +235,25 @@ class NAFAgent:
                     once = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=False, tail=tail)
                     if tail is not None and next_state is not None:
                         self._actor1.obs_np[0] = next_state
-                        self._ahead = np.array(next_state, dtype=np.float32, copy=True)
+                        self._ahead = self._actor1.obs_np[0]
                     else:
                         self._ahead = None
                     once.run()
                     self._chunk.loss_parts = once.loss_parts       # (last_loss() of this tick)
+                    self._chunk.idx.copy_(once.idx)                # (... and the minibatch it drew, where a reader looks for it)
                     self._last_loss_from = "chunk"
                     return
                 self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=self.use_graph,
                                          tail=tail, tail_state=(a.counter, a._ticket) if tail else (), head_row=head)
             if self._chunk.tail is not None and next_state is not None:
                 self._chunk.wait_pinned_free()     # (a no-op behind step()'s own wait; idle ticks and staged rows come here)
-                self._actor1.obs_np[0] = next_state
-                self._ahead = np.array(next_state, dtype=np.float32, copy=True)
+                if self._chunk.row_dev is not None:        # (the fused launches: the observation rides in the pinned row)
+                    o2 = self.memory.off_s2
+                    self._ahead = self._row_np[0][o2:o2 + self.memory.S]
+                    self._ahead[:] = next_state
+                else:
+                    self._actor1.obs_np[0] = next_state
+                    self._ahead = self._actor1.obs_np[0]   # (the pinned observation itself: what the graph's act() runs on)
             else:
                 self._ahead = None
             # the graph's first node appends the pinned row only when this tick brought one (step()'s fast path): an idle
@@ -238,14 +283,19 @@ class NAFAgent:
 
     def act(self, state) -> np.ndarray:
         """Noisy clamped action for one state, main net in eval mode (naf_algorithm.py:158-178)."""
-        a = self._actor()
+        a = self._actor1 or self._actor()
         if a.host_io:
             ahead, self._ahead = self._ahead, None
             if ahead is not None:
-                # the last step()'s graph already ran the policy on the state it was told comes next
-                torch.cuda.current_stream().synchronize()
-                if np.array_equal(np.asarray(state, dtype=np.float32).reshape(-1), ahead.reshape(-1)):
-                    return a.actions_np[0].copy().squeeze()
+                # the last step()'s graph already ran the policy on the state it was told comes next: wait for its action
+                # (a spin on the pinned word the graph's last launch writes; the stream for graphs without that launch)
+                self._chunk.wait_tail()
+                s32 = np.asarray(state, dtype=np.float32)
+                if s32.shape == ahead.shape and (s32 == ahead).all():
+                    out = a.actions_np[0].copy()
+                    return out.squeeze() if out.size == 1 else out
+            elif self._chunk is not None:
+                self._chunk.wait_pinned_free()             # (the graph's tail may still be reading the pinned observation)
             # the kernel reads the state from, and writes the action to, pinned host memory: no copies to enqueue
             a.obs_np[0] = state
             if self._act_graph is not None:

@@ -544,7 +544,7 @@ def test_framework_many_env_arguments_without_a_gpu(monkeypatch):
 def test_no_kernel_spills_to_scratch_and_the_switch_list_is_short():
     """nothing in libnaf_hip.so may keep values in scratch memory (private_segment_fixed_size, as hipcc's
     -Rpass-analysis=kernel-resource-usage reports it for every kernel at build time -> csrc/libnaf_hip.so.usage.json), and the
-    product reads at most 11 NAF_* environment switches — the ones DESIGN.md section 4c documents."""
+    product reads at most 13 NAF_* environment switches — the ones DESIGN.md section 4c documents."""
     import json
     from robotic_manipulator_rloa_amd import _lib
     _lib.load()
@@ -567,7 +567,7 @@ def test_no_kernel_spills_to_scratch_and_the_switch_list_is_short():
                 src = open(os.path.join(dirpath, f)).read()
                 names |= set(re.findall(r'(?:environ\.get\(|getenv\(|environ\[|NAF_ENV_INT\()\s*["\'](NAF_[A-Z0-9_]+)["\']', src))
     documented = {"NAF_FUSE", "NAF_DEFER_ADAM", "NAF_XGMI", "NAF_XGMI_FREE_SLAB", "NAF_BLAS_DEFAULT", "NAF_BLAS_TUNING_FILE",
-                  "NAF_BUILD_DEFINES", "NAF_LOG_FILE", "NAF_DP_SHARE_GPU", "NAF_GEMM_FORM", "NAF_XGMI_MERGE"}
+                  "NAF_BUILD_DEFINES", "NAF_LOG_FILE", "NAF_DP_SHARE_GPU", "NAF_GEMM_FORM", "NAF_XGMI_MERGE", "NAF_STEP_FUSED", "NAF_HOST_STORE"}
     assert names <= documented, names - documented
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     for n in names:

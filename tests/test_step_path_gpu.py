@@ -1,0 +1,311 @@
+"""The per-timestep path (csrc/step_path.hip): NAFAgent.step -> act of the reference's own loop (one env, one transition, one
+minibatch, one update per timestep; naf_algorithm.py:129-178, :249-261) in seven launches instead of twelve. Everything here is
+BIT-EXACT: the two fused launches against the launches they replace (same draw, same rows, same moments record; same parameters,
+Adam state, target and action), and the whole path against the chunked path on the same minibatches."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import naf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from robotic_manipulator_rloa_amd import _lib
+    _lib.require_gpu()
+    return _lib.load(allow_build=False)
+
+
+@pytest.fixture()
+def scratch_cwd(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _filled_buffer(cap, B, S, A, n_rows, seed):
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    from synth_data import make_transitions
+    buf = ReplayBuffer(cap, B, "cuda", seed, state_size=S, action_size=A)
+    if n_rows:
+        s_, ac, rw, ns, dn = make_transitions(n_rows, S, A, seed=seed + 1)
+        rows = torch.from_numpy(O.pack_rows(s_, ac, rw, ns, dn, buf.row_floats)).cuda()
+        for lo in range(0, n_rows, cap):
+            buf.add_rows_device(rows[lo:lo + cap], min(cap, n_rows - lo))
+    torch.cuda.synchronize()
+    return buf
+
+
+# (S, A, B, capacity, rows in the ring before the launch, append a row?)
+PREP_CASES = [
+    (21, 6, 64, 1000, 500, 1),          # configs[0]'s shape
+    (21, 6, 256, 5000, 3000, 1),        # configs[1]'s batch
+    (21, 6, 256, 5000, 3000, 0),        # an idle tick: the count word says 0
+    (21, 6, 64, 1000, 100, 1),          # dense regime: B <= population < 4 B (partial Fisher-Yates)
+    (21, 6, 64, 1000, 0, 1),            # the very first row: population 1 < B (with replacement, as the chunked sampler)
+    (21, 6, 64, 300, 899, 1),           # full ring, head about to wrap (899 = 3 * 300 - 1 rows went in)
+    (21, 6, 100, 1000, 700, 1),         # a batch that is not whole 64-row blocks
+    (23, 7, 2048, 20000, 15000, 1),     # configs[4]'s batch: 8 chunks of the moments passes, 7 x 7 tiles' rows
+    (26, 6, 128, 1000, 600, 1),         # 32-column moments records (K4 = 7 -> 8)
+    (21, 6, 4096, 40000, 30000, 1),     # the sampler's largest batch: an 80-KB hash table under the moments' staging area
+    (21, 6, 256, 5000, 3000, None),     # no append node at all (schedules other than update_freq = 1)
+]
+
+
+@pytest.mark.parametrize("S,A,B,cap,n0,append", PREP_CASES)
+def test_step_prep_equals_the_launches_it_replaces(lib, S, A, B, cap, n0, append):
+    """naf_step_prep == naf_replay_add_counted + naf_replay_sample_indices + naf_counter_add + naf_replay_gather_rows +
+    naf_bb_moments, bit for bit: ring, {head, size, total}, sampler counter, indices, minibatch rows, both moments records."""
+    from robotic_manipulator_rloa_amd import _lib
+    from synth_data import make_transitions
+    bufs = [_filled_buffer(cap, B, S, A, n0, seed=5) for _ in range(2)]
+    brf = bufs[0].batch_row_floats
+    mf = lib.naf_bb_moments_floats(S)
+    off_s2 = bufs[0].off_s2
+    s_, ac, rw, ns, dn = make_transitions(3, S, A, seed=77)
+    new_rows = O.pack_rows(s_, ac, rw, ns, dn, bufs[0].row_floats)
+    outs = []
+    for which, buf in enumerate(bufs):
+        row_pin = torch.zeros(1, buf.row_floats).pin_memory()
+        cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+        idx = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        batch = torch.zeros(B * brf + 64, device="cuda")
+        mom = torch.zeros(2, mf, device="cuda")
+        row_dev = torch.zeros(buf.row_floats, device="cuda")
+        buf._sample_ctr.fill_(41)
+        for rep in range(3):                                 # three timesteps in a row: the counters carry over
+            row_pin.copy_(torch.from_numpy(new_rows[rep:rep + 1]))
+            cnt[0] = 1 if append else 0
+            if which == 0:
+                if append is not None:
+                    _lib.check(lib.naf_replay_add_counted(buf.handle, row_pin.data_ptr(), cnt.data_ptr(), 1, st()), "add")
+                buf.sample_indices(idx, 1)
+                buf.gather_rows(idx, batch[:B * brf].view(B, brf), B)
+                _lib.check(lib.naf_bb_moments(batch.data_ptr(), B * brf, off_s2, brf, S, mom.data_ptr(), B, 1, 2, st()), "moments")
+            else:
+                rp, cp = (row_pin.data_ptr(), cnt.data_ptr()) if append is not None else (None, None)
+                _lib.check(lib.naf_step_prep(buf.handle, rp, cp, row_dev.data_ptr() if rp else None, buf.seed,
+                                             buf._sample_ctr.data_ptr(), idx.data_ptr(), batch.data_ptr(), brf, buf.action_mode,
+                                             mom.data_ptr(), B, 1, st()), "step_prep")
+            torch.cuda.synchronize()
+            if which == 1 and append is not None:
+                np.testing.assert_array_equal(row_dev.cpu().numpy(), new_rows[rep])     # the row's device copy, count or no count
+        outs.append((buf.rows.clone(), buf.meta.clone(), buf._sample_ctr.clone(), idx.clone(), batch.clone(), mom.clone()))
+    names = ("ring", "meta", "sampler counter", "indices", "minibatch rows", "moments")
+    for name, a, b in zip(names, outs[0], outs[1]):
+        assert torch.equal(a, b), name
+    meta = outs[1][1].cpu().numpy()
+    n_app = 3 if append else 0
+    assert meta[1] == min(cap, n0 + n_app) and meta[2] == n0 + n_app and int(outs[1][2].item()) == 44
+    if n0 + n_app >= B:
+        assert len(set(outs[1][3].cpu().numpy().tolist())) == B          # without replacement
+    assert meta[7] == 0 or n0 + n_app == 0
+
+
+def test_step_prep_refuses_bad_arguments(lib):
+    buf = _filled_buffer(100, 16, 21, 6, 50, seed=1)
+    brf, mf = buf.batch_row_floats, lib.naf_bb_moments_floats(21)
+    idx = torch.zeros(16, dtype=torch.int32, device="cuda")
+    batch, mom = torch.zeros(16 * brf, device="cuda"), torch.zeros(2, mf, device="cuda")
+    row = torch.zeros(1, buf.row_floats).pin_memory()
+    ok = lambda **kw: lib.naf_step_prep(buf.handle, kw.get("row"), kw.get("cnt"), None, 0, buf._sample_ctr.data_ptr(), idx.data_ptr(),   # noqa: E731
+                                       batch.data_ptr(), kw.get("ld", brf), 0, mom.data_ptr(), kw.get("B", 16), 1, st())
+    assert ok() == 0
+    assert ok(row=row.data_ptr()) == -1                       # a row without its count word
+    assert ok(ld=brf - 4) == -1 and ok(ld=brf + 4) == -1 and ok(B=0) == -1 and ok(B=5000) == -1
+    torch.cuda.synchronize()
+
+
+def _two_learners(S, A, B, seed):
+    from robotic_manipulator_rloa_amd.learner import Learner
+    Ls = []
+    for _ in range(2):
+        L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, DEV)
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        L.theta2.copy_(0.1 * torch.randn(L.theta2.shape, generator=g, device="cuda"))
+        L.grad.copy_(0.05 * torch.randn(L.grad.shape, generator=g, device="cuda"))
+        L.adam_m.copy_(0.01 * torch.randn(L.grad.shape, generator=g, device="cuda"))
+        L.adam_v.copy_(1e-4 * torch.rand(L.grad.shape, generator=g, device="cuda"))
+        L.bn_stats[:, 0::2].copy_(0.3 * torch.randn(2, 2, 256, generator=g, device="cuda"))
+        L.bn_stats[:, 1::2].copy_(0.5 + torch.rand(2, 2, 256, generator=g, device="cuda"))
+        L.step_dev.fill_(7)
+        Ls.append(L)
+    return Ls
+
+
+@pytest.mark.parametrize("p_mode", [0, 1])
+@pytest.mark.parametrize("S,A", [(21, 6), (23, 7), (10, 5), (21, 8)])
+def test_adam_polyak_act_equals_the_two_launches_it_replaces(lib, S, A, p_mode):
+    """naf_adam_polyak_act == naf_adam_polyak_fused followed by naf_policy_act: theta, theta', m, v, the heads' pre-activations
+    and the (noisy, clamped) action bit for bit, over three consecutive launches (epochs of the records, the noise counter and the
+    pinned ordinal move on); A = 8 takes two rows of Wh per layer-2 workgroup."""
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.learner import ActPath
+    La, Lb = _two_learners(S, A, 64, seed=3)
+    La.p_mode = Lb.p_mode = p_mode
+    acts = [ActPath(La, 1, seed=99, host_io=True), ActPath(Lb, 1, seed=99, host_io=True)]
+    assert acts[1].can_ride
+    rng = np.random.default_rng(0)
+    for rep in range(3):
+        obs = rng.standard_normal(S).astype(np.float32)
+        for L in (La, Lb):
+            _lib.check(lib.naf_grad_norm_partials(L.grad.data_ptr(), L.lay.P, L.partials.data_ptr(), L.step_dev.data_ptr(), st()), "norm")
+            L._adam_args.n_partials = L.n_partials_norm
+        acts[0].obs_np[0] = acts[1].obs_np[0] = obs
+        _lib.check(lib.naf_adam_polyak_fused(
+            La.theta2[0].data_ptr(), La.grad.data_ptr(), La.adam_m.data_ptr(), La.adam_v.data_ptr(), La.theta2[1].data_ptr(),
+            La.partials.data_ptr(), La.n_partials_norm, 1.0, La.lr, 0.9, 0.999, 1e-8, La.tau, float(1.0 - La.tau),
+            La.step_dev.data_ptr(), 1.0, La.lay.P, st()), "adam")
+        acts[0].act(1.0)
+        acts[1].act_with_optimizer_step(1.0)
+        torch.cuda.synchronize()
+        assert int(acts[1].seq_np[0]) == rep + 1 and acts[1].act_timeouts == 0
+        for name in ("theta2", "adam_m", "adam_v"):
+            assert torch.equal(getattr(La, name), getattr(Lb, name)), (name, rep)
+        NH = La.lay.NH
+        assert torch.equal(acts[0].Gh[0, :NH], acts[1].Gh[0, :NH]), rep
+        np.testing.assert_array_equal(acts[0].actions_np, acts[1].actions_np)
+        assert np.isfinite(acts[1].actions_np).all() and (np.abs(acts[1].actions_np) <= 1).all()
+        assert int(acts[0].counter.item()) == int(acts[1].counter.item()) == rep + 1
+        # move the gradient on so that the three launches differ
+        for L in (La, Lb):
+            L.grad.mul_(-0.7)
+    # the new parameters differ from the old ones (the step did run)
+    assert not torch.equal(La.theta2[0], _two_learners(S, A, 64, seed=3)[0].theta2[0])
+
+
+def test_adam_polyak_act_skips_a_poisoned_update_and_still_acts(lib):
+    """A -inf norm partial (a timed-out gradient exchange under data parallel, csrc/xgmi_reduce.hip) makes the optimizer leave
+    every buffer alone; the action is then the policy's on the OLD parameters — as naf_adam_polyak_fused + naf_policy_act."""
+    from robotic_manipulator_rloa_amd.learner import ActPath
+    La, Lb = _two_learners(21, 6, 64, seed=4)
+    before = La.theta2.clone()
+    acts = [ActPath(La, 1, seed=5, host_io=True), ActPath(Lb, 1, seed=5, host_io=True)]
+    for L in (La, Lb):
+        L.partials.fill_(1.0)
+        L.partials[3] = float("-inf")
+    obs = np.linspace(-1, 1, 21).astype(np.float32)
+    acts[0].obs_np[0] = acts[1].obs_np[0] = obs
+    La.optimizer_step(norm_ready=True)
+    acts[0].act(1.0)
+    acts[1].act_with_optimizer_step(1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(La.theta2, before) and torch.equal(Lb.theta2, before)
+    np.testing.assert_array_equal(acts[0].actions_np, acts[1].actions_np)
+
+
+def _drive(agent, env_seed, warm, steps, record):
+    """the reference's loop body (naf_algorithm.py:249-262) on a scripted stream of transitions; returns the actions taken"""
+    from synth_data import make_transitions
+    S, A = agent.state_size, agent.action_size
+    st_, ac, rw, ns, dn = make_transitions(warm + steps + 1, S, A, seed=env_seed)
+    actions = []
+    state = st_[0].astype(np.float64)
+    for t in range(warm + steps):
+        a = agent.act(state)
+        actions.append(np.array(a, copy=True))
+        nxt = ns[t].astype(np.float64)
+        agent.step(state, a, float(rw[t]), nxt, 0)
+        if record is not None and t >= warm:
+            torch.cuda.synchronize()
+            record.append(agent._chunk.idx.cpu().numpy().copy())
+        state = nxt
+    torch.cuda.synchronize()
+    return np.array(actions)
+
+
+@pytest.mark.parametrize("B", [64, 256, 100])
+def test_per_timestep_path_is_the_separate_launches_and_the_chunked_path_bit_for_bit(scratch_cwd, monkeypatch, B):
+    """(a) NAFAgent.act / step through the two fused launches == the same loop through the twelve separate
+    launches (NAF_STEP_FUSED=0): every action the policy took, parameters, target, Adam state, BatchNorm buffers, ring and counters
+    bit-equal after 150 updates; (b) == the CHUNKED path: a TrainChunk of 150 teacher-forced updates (deferred optimizer steps,
+    one moments launch for all) on the minibatches the per-timestep path drew, from the same initial state."""
+    from robotic_manipulator_rloa_amd.engine import TrainChunk
+    from robotic_manipulator_rloa_amd.learner import Learner
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    S, A, N, T = 21, 6, 5000, 150
+    warm = B                                                  # the gate: len(memory) > batch_size (naf_algorithm.py:150) opens at step B
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NAF_STEP_FUSED", fused)
+        agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+        theta0 = agent.learner.theta2.clone()
+        idx = [] if fused == "1" else None
+        acts = _drive(agent, 21, warm, T, idx)
+        ch = agent._chunk
+        assert ch.fused_prep == ch.fused_tail == (fused == "1") and ch.head_row is not None and (agent._fast is not None)
+        L = agent.learner
+        runs.append(dict(acts=acts, theta=L.theta2.clone(), m=L.adam_m.clone(), v=L.adam_v.clone(), bn=L.bn_stats.clone(),
+                         ring=agent.memory.rows.clone(), meta=agent.memory.meta.clone(), step=int(L.step_dev.item()),
+                         loss=agent.last_loss(), idx=idx, theta0=theta0))
+    a, b = runs
+    assert a["step"] == b["step"] == T
+    np.testing.assert_array_equal(a["acts"], b["acts"])
+    for k in ("theta", "m", "v", "bn", "ring", "meta"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["loss"] == b["loss"] and torch.isfinite(a["theta"]).all()
+    assert not torch.equal(a["theta"], a["theta0"])
+    # (b) the chunked path on the same minibatches: positions are stable while the ring only grows (no eviction here)
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    monkeypatch.setenv("NAF_STEP_FUSED", "1")
+    L2 = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, DEV)
+    L2.theta2.copy_(a["theta0"])
+    buf = ReplayBuffer(N, B, DEV, 0, state_size=S, action_size=A)
+    n_rows = int(a["meta"][1].item())
+    buf.add_rows_device(a["ring"][:n_rows].contiguous(), n_rows)
+    chunk = TrainChunk(L2, buf, T, teacher_forced=True)
+    chunk.idx.copy_(torch.from_numpy(np.concatenate(a["idx"], 0)).view(T, B))
+    chunk.run()
+    torch.cuda.synchronize()
+    assert int(L2.step_dev.item()) == T
+    assert torch.equal(L2.theta2, a["theta"]) and torch.equal(L2.adam_m, a["m"]) and torch.equal(L2.adam_v, a["v"])
+    assert torch.equal(L2.bn_stats, a["bn"])
+    assert float(chunk.losses()[-1].item()) == a["loss"]
+
+
+def test_per_timestep_path_is_seven_launches(scratch_cwd):
+    """The update graph of NAFAgent.step() at num_updates = 1: naf_step_prep + the five launches of the row-split chain +
+    naf_adam_polyak_act (profiles/r05_api_path_kernel_stats.csv has the same count from rocprofv3)."""
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    agent = NAFAgent(object(), 21, 6, 256, 64, 1000, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+    _drive(agent, 3, 65, 5, None)
+    ch = agent._chunk
+    assert ch.fused_prep and ch.fused_tail and ch.graph is not None
+    g = ch.graph
+    if hasattr(g, "debug_dump"):
+        pass                                                   # (the node count is not exposed by torch: counted under rocprofv3)
+    calls = []
+    lib = agent.learner.lib
+    names = ["naf_step_prep", "naf_bb_layer1_adam", "naf_bb_linear_stats_adam", "naf_bb_layer2_head", "naf_gemm_bundle_ex",
+             "naf_bb_layer1_bwd_finish", "naf_adam_polyak_act", "naf_replay_add_counted", "naf_replay_sample_indices",
+             "naf_counter_add", "naf_replay_gather_rows", "naf_bb_moments", "naf_adam_polyak_fused", "naf_policy_act",
+             "naf_grad_norm_partials"]
+
+    class Spy:
+        def __init__(self, inner):
+            self._inner = inner
+
+        def __getattr__(self, name):
+            fn = getattr(self._inner, name)
+            if name in names:
+                def wrapped(*a, **k):
+                    calls.append(name)
+                    return fn(*a, **k)
+                return wrapped
+            return fn
+    spy = Spy(lib)
+    agent.learner.lib = agent.learner._f = spy
+    ch.L.lib = spy
+    ch._body()                                                 # one eager pass through exactly what the graph holds
+    torch.cuda.synchronize()
+    agent.learner.lib = agent.learner._f = lib
+    assert calls == names[:7], calls
