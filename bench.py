@@ -234,11 +234,10 @@ def main():
                    "launch": graph_note + (" [REHEARSAL: all ranks share cuda:0, not a measurement]" if rehearsal else ""),
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "chain": L.chain, "fused_kernels": ",".join(sorted(L.fuse)),
-                   "grad_exchange": ("none" if world == 1 else
-                                     "one-shot peer-memory exchange inside the finish launch (csrc/big_batch.hip, NAF_XGMI_MERGE=1)"
-                                     if getattr(L, "xgmi_merged", False) else
-                                     "one-shot peer-memory all-reduce over xGMI (csrc/xgmi_reduce.hip)" if L.xgmi is not None
-                                     else "RCCL all-reduce")},
+                   "grad_exchange": {"none": "none",
+                                     "merged": "one-shot peer-memory exchange inside the finish launch (csrc/big_batch.hip)",
+                                     "oneshot": "one-shot peer-memory all-reduce over xGMI, a launch of its own (csrc/xgmi_reduce.hip)",
+                                     "rccl": "RCCL all-reduce (torch.distributed) + norm launch"}[L.exchange]},
         "updates_per_s": round(updates / elapsed, 1),
         "us_per_update": round(1e6 * elapsed / (args.steps * U), 3),
         "timed_seconds": round(elapsed, 3),
@@ -248,6 +247,22 @@ def main():
     }
     if L.xgmi is not None:
         out["sanity"]["xgmi_allreduces"], out["sanity"]["xgmi_timed_out_waits"] = L.xgmi.status()
+    if world > 1:
+        # what a SCALE record needs to be read without a second run: which collective back-end and world size the job saw, whether
+        # every rank could map every peer's receive slab (hipIpc) and pass the exact self-test, what each form of the exchange took
+        # per update ON THIS NODE at start-up (Learner.autotune_exchange; MAX over ranks) and which one the ranks agreed on
+        at = L.exchange_autotune or {}
+        out["preflight"] = {
+            "backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
+            "rehearsal_one_gpu": bool(rehearsal),
+            "hipipc_peer_slabs_mapped_and_self_test_passed": L.xgmi is not None,
+            "xgmi_slab_memory": getattr(L.xgmi, "mem_kind", None),
+            "exchange_forms_available": L.exchange_forms(),
+            "exchange_us_per_update_at_startup": {k: v for k, v in at.items() if k in ("oneshot", "merged", "rccl")} or None,
+            "exchange_chosen": L.exchange,
+            "exchange_pinned_by_env": os.environ.get("NAF_DP_EXCHANGE", "auto") != "auto",
+            "xgmi_timed_out_waits": out["sanity"].get("xgmi_timed_out_waits", 0),
+        }
     if world > 1:
         # data-parallel replicas must have stayed in lock-step: same parameters, bit for bit, on every rank
         chk = torch.stack([L.theta2.double().sum(), L.theta2.double().abs().sum(), L.adam_v.double().sum()])

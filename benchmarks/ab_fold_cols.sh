@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export NAF_GEMM_FORM=1
 for cols in 32 8 16 32 8 16; do
   export NAF_BUILD_DEFINES="-DGB_FOLD_COLS=$cols"
   for cfg in "--robot panda --batch 2048 --buffer 4000000" "--robot xarm6_robot --batch 1024 --obstacle-jitter 0.1" "--batch 256"; do

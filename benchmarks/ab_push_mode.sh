@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export NAF_BENCH_REHEARSAL=1 HSA_ENABLE_IPC_MODE_LEGACY=0 OMP_NUM_THREADS=2 NAF_XGMI_MERGE=1
+export NAF_BENCH_REHEARSAL=1 HSA_ENABLE_IPC_MODE_LEGACY=0 OMP_NUM_THREADS=2 NAF_DP_EXCHANGE=merged
 for mode in 0 1 2; do
   export NAF_BUILD_DEFINES="-DBB_PUSH_MODE=$mode"
   python -c "from robotic_manipulator_rloa_amd import _lib; _lib.build_library()" 

@@ -58,9 +58,6 @@ def main():
     sd = reference_init_state_dict(S, A, 256, seed=0)
     L.load_params(0, sd)
     L.load_params(1, sd)
-    if getattr(L, "gemm_ring", False):       # csrc/gemm_ring.h leaves its own marks in the bundle's slots
-        MARKS["gemm_bundle"] = ["entry", "first DMAs issued", "constants", "K loop done", "hand-over + store + epilogue",
-                                "chunk 0 landed"]
     replay = ReplayBuffer(N, B, dev, seed=1000, state_size=S, action_size=A)
     replay.add_rows_device(bench.synth_rows(N, S, A, replay.row_floats, replay.off_s2, seed=77, device=dev), N)
     chunk = TrainChunk(L, replay, args.updates, use_graph=True, gather_outside_graph=True)

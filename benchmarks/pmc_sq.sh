@@ -1,6 +1,6 @@
 #!/bin/bash
-# SQ counters per launch of the row-split chain's kernels at B = 2048 (two 8-counter passes, kernel trace only), for one form of the
-# backward GEMM launch:  NAF_GEMM_FORM=1|2 bash benchmarks/pmc_sq.sh <tag>   ->  gpurun_out/<tag>_p{1,2}.csv
+# SQ counters per launch of the row-split chain's kernels at B = 2048 (two 8-counter passes, kernel trace only):
+#   bash benchmarks/pmc_sq.sh <tag>   ->  gpurun_out/<tag>_p{1,2}.csv
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 tag=$1

@@ -81,7 +81,7 @@ def bundle_plain(o, B):
         D(ptr(o["dH"]), ptr(o["A2"]), ptr(slab_wh), None, NHP, HP, B, NHP, HP, HP, 1, 1, ks, NHP * HP, None, None))
 
     def body():
-        _lib.check(lib.naf_gemm_bundle_ex(descs, 3, 1, torch.cuda.current_stream().cuda_stream), "gemm_bundle")
+        _lib.check(lib.naf_gemm_bundle(descs, 3, torch.cuda.current_stream().cuda_stream), "gemm_bundle")
     body._keep = (slab_w2, slab_wh, descs)
     # parity of the operands' use (slabs summed = the vendor result)
     body()

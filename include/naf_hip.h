@@ -439,13 +439,6 @@ typedef struct naf_gemm_desc {
     const naf_gemm_bn2bwd_t* pro; /* nullable (HOST pointer, copied into the launch) */
 } naf_gemm_desc_t;
 int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream);
-/* The same with the form of the launch named: 0 / 1 = one 32 x 32 output block per workgroup, panels staged through registers
- * (csrc/gemm_bundle.hip; what naf_gemm_bundle runs), 2 = 64 x 32 tiles whose panels reach LDS by LDS-DMA into a ring of K chunks,
- * two and more chunks in flight under the MFMAs, loader and consumer waves (csrc/gemm_ring.h; B operands k-major, K ranges multiples
- * of 32, the layer-1 epilogue with the kept xhat: NAF_ERR_ARG for a bundle that does not fit). Same results to rounding (the order
- * of the K sums differs between the forms; each is bitwise reproducible). Form 2 is an experiment of round 4 that measured no
- * faster; it stays callable and tested. */
-int naf_gemm_bundle_ex(const naf_gemm_desc_t* descs, int n, int form, void* stream);
 
 /* ---- clip + Adam + Polyak over one flat parameter buffer -------------------------------------- */
 /* first half of clip_grad_norm_(params, 1) (naf_algorithm.py:209): partials[i] = sum of g^2 over chunk i of

@@ -17,7 +17,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
 SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "big_batch.hip", "gemm_bundle.hip", "optim.hip",
            "synth_env.hip", "xgmi_reduce.hip", "policy_act.hip", "step_path.hip"]
-HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", "adam_body.h", "bn2bwd_fold.h", "gemm_ring.h", "act_body.h", "moments_body.h", "sample_body.h", "replay_dev.h", os.path.join("..", "..", "include", "naf_hip.h")]
+HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", "adam_body.h", "bn2bwd_fold.h", "act_body.h", "moments_body.h", "sample_body.h", "replay_dev.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
 ACTION_TRUNC_INT, ACTION_FLOAT = 0, 1
@@ -210,7 +210,6 @@ _PROTOS = {
     "naf_bb_layer1_bwd_finish": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                  _vp, _i, _vp, _vp, _vp, _sz, _vp],
     "naf_gemm_bundle": [_vp, _i, _vp],
-    "naf_gemm_bundle_ex": [_vp, _i, _i, _vp],
     "naf_grad_norm_partials": [_vp, _sz, _vp, _vp, _vp],
     "naf_adam_polyak_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _sz, _vp],
     "naf_polyak_update": [_vp, _vp, _f, _f, _sz, _vp],

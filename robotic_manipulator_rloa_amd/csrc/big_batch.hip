@@ -225,7 +225,7 @@ struct FinishArgs {
 // 0: plain stores + a system-scope release fence per workgroup in front of its ticket (the protocol of csrc/xgmi_reduce.hip);
 // 1: sc1 stores, 2: sc0 sc1 stores (written through, no fence). Shared-GPU rehearsal, W = 2, us per update (benchmarks/
 // ab_push_mode.sh; the peers' slabs are LOCAL memory there, cached by the writer's L2 unless written through): 61.8 | 94.8 | 95.0 —
-// against 48.1 with the all-reduce as a launch of its own (NAF_XGMI_MERGE=0), which is why that stays the default until a
+// against 48.1 with the all-reduce as a launch of its own (NAF_DP_EXCHANGE=oneshot), which is why the start-up autotune (Learner.autotune_exchange) ranks it first until a
 // multi-GPU box has measured both over real xGMI (where a peer's memory is not cached locally and the ranking may differ).
 #define BB_PUSH_MODE 0
 #endif

@@ -595,19 +595,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(GB_WAVES_PER_
     }
 }
 
-#include "gemm_ring.h"
-
-// form: 0 or 1 = one 32 x 32 block per workgroup (this file; the library's choice at every size), 2 = the LDS-DMA ring on 64 x 32 /
-// 64 x 64 tiles (gemm_ring.h; NAF_ERR_ARG when the bundle does not fit it) — built and measured in round 4, not faster
-extern "C" int naf_gemm_bundle_ex(const naf_gemm_desc_t* descs, int n, int form, void* stream);
-extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream) { return naf_gemm_bundle_ex(descs, n, 0, stream); }
-
-extern "C" int naf_gemm_bundle_ex(const naf_gemm_desc_t* descs, int n, int form, void* stream) {
-    if (!descs || n <= 0 || n > NAF_GEMM_BUNDLE_MAX || form < 0 || form > 2) return NAF_ERR_ARG;
-    if (form == 2) {
-        const int rc = naf_gemm_ring_launch(descs, n, (hipStream_t)stream);
-        return rc == 1 ? NAF_ERR_ARG : rc;
-    }
+// (round 4's second form of this launch — 64 x 32 / 64 x 64 tiles fed by an LDS-DMA ring, measured slower at every size — lives in
+//  benchmarks/experimental/gemm_ring.h with its tests and A/B scripts; it is not compiled into the library)
+extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream) {
+    if (!descs || n <= 0 || n > NAF_GEMM_BUNDLE_MAX) return NAF_ERR_ARG;
     GemmBundle b;
     b.n = n;
     b.n_fold = b.fold_desc = 0;

@@ -249,26 +249,30 @@ class Learner:
         if "bb" in self.fuse:
             self.n_partials_fold = self.lib.naf_bb_layer1_bwd_finish_blocks(H) + (H * H + 1023) // 1024 + (NHP * HP + 1023) // 1024
         self.n_partials = self.n_partials_fold if self.fold_norm else self.n_partials_norm
-        # data parallel inside one node: the one-shot peer-memory all-reduce (csrc/xgmi_reduce.hip) replaces the RCCL
-        # ring + the grad-norm launch when every rank could map every peer and the exact self-test passed on all of
-        # them; otherwise (or with NAF_XGMI=0) the RCCL all-reduce below stays. try_create is collective.
+        # Data parallel inside one node — three forms of the one exchange (the sum of the flat gradient over the ranks, where
+        # loss.backward() -> clip_grad_norm_ sit in the reference, naf_algorithm.py:207-210):
+        #   "oneshot"  the one-shot peer-memory all-reduce as a launch of its own behind the finish launch (csrc/xgmi_reduce.hip; the
+        #              finish launch pushes 91 % of the bytes early)
+        #   "merged"   the whole exchange INSIDE the finish launch of the row-split chain (csrc/big_batch.hip, bb_finish_exchange):
+        #              five launches per update as on one GPU
+        #   "rccl"     torch.distributed's all-reduce (RCCL over xGMI) captured in the graph + a norm launch
+        # The peer-memory forms exist when every rank could map every peer and the exact self-test passed on all of them
+        # (XgmiAllReduce.try_create is collective; NAF_XGMI=0 skips it). WHICH form runs is measured where the job runs:
+        # autotune_exchange() (end of this constructor) times them on this node and every rank takes the collectively fastest —
+        # the one-GPU rehearsal ranks them oneshot < merged < collective, real xGMI may not (a peer's slab is not behind the
+        # writer's L2 there). NAF_DP_EXCHANGE = oneshot | merged | rccl pins the form instead.
         self.xgmi = None
+        self._xg = None                    # the communicator the CURRENT form uses (None: the collective)
         self.xgmi_merged = False
+        self.exchange = "none" if self.world_size == 1 else "rccl"
+        self.exchange_autotune = None      # {form: us per update ..., "chosen": form} once autotune_exchange() has run
         self._push_desc = None
+        n_partials_most = max(self.n_partials_fold + 1, self.n_partials_norm, self.n_partials)
         if self.world_size > 1 and os.environ.get("NAF_XGMI", "1") != "0":
             self.xgmi = XgmiAllReduce.try_create(P, dev, self.pg)
             if self.xgmi is not None:
-                self.n_partials = self.xgmi.n_partials
-                # row-split chain, NAF_XGMI_MERGE=1: the exchange happens INSIDE the finish launch (csrc/big_batch.hip,
-                # bb_finish_exchange): no all-reduce launch, the finish launch's workgroups leave the reduced gradient's norm
-                # partials — five launches per update as on one GPU. Built and verified in round 4 (W = 2 / 4 on one GPU: the
-                # rank-ordered sum bit for bit, replicas identical, no time-out) and measured SLOWER there than the all-reduce as a
-                # launch of its own (61.8 against 48.1 us per update at W = 2; the merged launch serialises a release, the small
-                # ranges' push and the flags behind its last workgroup): opt-in until a multi-GPU box has timed both over xGMI.
-                self.xgmi_merged = "bb" in self.fuse and os.environ.get("NAF_XGMI_MERGE", "0") == "1"
-                if self.xgmi_merged:
-                    self.n_partials = self.n_partials_fold + 1      # (+ the layer-1 / BatchNorm ranges' entry of the last workgroup)
-        self.partials = torch.zeros(max(self.n_partials_fold, self.n_partials_norm, self.n_partials) + 1, **f32)
+                n_partials_most = max(n_partials_most, self.xgmi.n_partials)
+        self.partials = torch.zeros(n_partials_most + 1, **f32)
         # the optimizer step of update k carried by the first two launches of update k + 1 (csrc/adam_body.h): the row-split
         # chain on one rank, gradient norm folded into the producers. NAF_DEFER_ADAM=0 keeps the launch of its own.
         # Data parallel over peer memory: the one-shot all-reduce launch leaves the norm partials and the step count exactly
@@ -277,8 +281,7 @@ class Learner:
         # launch stays behind the collective — and the optimizer step rides on the next update behind it all the same (round 4:
         # one launch and one boundary less per update there too; before, that path kept both launches).
         self.defer_ok = ("bb" in self.fuse and os.environ.get("NAF_DEFER_ADAM", "1") != "0" and
-                         ((self.fold_norm and self.world_size == 1) or self.xgmi is not None or self.world_size > 1 or
-                          self._force_allreduce))
+                         ((self.fold_norm and self.world_size == 1) or self.world_size > 1 or self._force_allreduce))
         self.adam_bc = torch.zeros(8, **f32)     # the next step's bias corrections, left by the riding optimizer workgroups
         self._adam_args = _lib.AdamArgs(
             ptr(self.theta2[0]), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.theta2[1]), ptr(self.partials),
@@ -373,18 +376,8 @@ class Learner:
                 return ((M + 31) // 32) * ((N + 31) // 32) * k_split
             ks = Bp // 256 if (Bp % 256 == 0 and Bp <= 2048) else k_ranges(256, 8)      # (at most 8 slabs: csrc/big_batch.hip)
             ks_w2 = ks_wh = ks
-            # Which form of the bundle launch (include/naf_hip.h, naf_gemm_bundle_ex): one 32 x 32 block per workgroup (form 1, the
-            # default at every batch size) or the LDS-DMA ring on 64 x 32 tiles (form 2, csrc/gemm_ring.h; NAF_GEMM_FORM = 2 opts in
-            # where the K ranges are whole 32-k chunks). Round 4 built the ring with two and more chunks in flight and measured it
-            # against form 1 on the same boxes — updates/s at B = 1024 | 2048: 28.2k | 21.4k (form 1) against 27.0k | 20.8k; the
-            # launch itself under rocprofv3 10.2 | 15.6 us against 11.4 | 17.6 us. Why: DESIGN.md section 4b, round 4 (the launch is
-            # not bound by staging — the DMAs alone take a fifth of a block's K loop — but by per-block fixed latencies and by how
-            # evenly a few hundred blocks cover 1024 SIMDs).
-            self.gemm_form = int(os.environ.get("NAF_GEMM_FORM", "0"))
-            if self.gemm_form not in (0, 1, 2):
-                raise ValueError("NAF_GEMM_FORM: 0 / 1 (32 x 32 blocks) or 2 (LDS-DMA ring)")
-            self.gemm_ring = self.gemm_form == 2 and (B // ks) % 32 == 0 and B % 64 == 0
-            if not self.gemm_ring and blocks(Bp, H, 1) + blocks(H, H, ks) + blocks(NHP, HP, ks) + 8 > 1024 and ks % 2 == 0 and \
+            # (round 4's LDS-DMA ring form of this launch measured slower at every size: benchmarks/experimental/gemm_ring.h)
+            if blocks(Bp, H, 1) + blocks(H, H, ks) + blocks(NHP, HP, ks) + 8 > 1024 and ks % 2 == 0 and \
                     (Bp // (ks // 2)) % 256 == 0:
                 ks_w2 = ks // 2
             self.bb_slab_w2 = torch.zeros(ks_w2, H * H, **f32)
@@ -394,8 +387,7 @@ class Learner:
             # (xhat of layer 1 kept by the forward pass for the epilogue up to B = 512 — one round of blocks, where recomputing it
             # sat on the critical path: updates/s 36.0k -> 36.8k at B = 64, 35.2k -> 36.0k at 128, 34.6k -> 35.1k at 256, 31.25k ->
             # 31.5k at 512; beyond that the recomputation hides and the extra B x H floats each way do not: 28.3k -> 27.7k at 1024)
-            # The ring form's epilogue always reads the kept xhat (it has no W1 / X product of its own).
-            self.XH1 = torch.zeros(Bp, H, **f32) if (B <= 512 or self.gemm_ring) else None
+            self.XH1 = torch.zeros(Bp, H, **f32) if B <= 512 else None
             self._epi = _lib.GemmL1Bwd(None, t2p_ + 4 * seg_["W1"].offset, t2p_ + 4 * seg_["b1"].offset, ptr(self.A1[0]),
                                        ptr(self.save_mean[0, 0]), ptr(self.save_invstd[0, 0]), ptr(self.bb_bw1), ptr(self.bb_dw1),
                                        0, lay.S, self.lib.naf_bb_layer1_bwd_kp(lay.S), H, ptr(self.XH1),
@@ -423,6 +415,124 @@ class Learner:
             self._bb_segs = (SS * 2)(SS(ptr(self.bb_slab_w2), ptr(self.gW2), H * H, H * H, ks_w2),
                                      SS(ptr(self.bb_slab_wh), ptr(self.gWh), NHP * HP, NHP * HP, ks_wh))
             self._bb_nsegs = 2
+        # ---- which form the gradient exchange takes (data parallel) -------------------------------------------------------
+        if self.world_size > 1:
+            want_x = os.environ.get("NAF_DP_EXCHANGE", "auto").lower()
+            if want_x not in ("auto", "oneshot", "merged", "rccl"):
+                raise ValueError(f"NAF_DP_EXCHANGE = {want_x!r}: one of auto, oneshot, merged, rccl")
+            forms = self.exchange_forms()
+            if want_x == "auto":
+                self._set_exchange(forms[0])
+                if len(forms) > 1:
+                    self.autotune_exchange()
+            else:
+                if want_x not in forms:
+                    raise _lib.NafHipError(f"NAF_DP_EXCHANGE={want_x}: not available here (forms: {forms})")
+                self._set_exchange(want_x)
+
+    # ---- data parallel: the form of the gradient exchange -------------------------------------------------------------
+    def exchange_forms(self):
+        """The forms this learner can run, fastest-in-the-rehearsal first: see the constructor."""
+        if self.world_size == 1:
+            return ["none"]
+        seg, P = self.lay.seg, self.lay.P
+        forms = []
+        if self.xgmi is not None:
+            forms.append("oneshot")
+            if "bb" in self.fuse and seg["Wh"].offset + seg["Wh"].numel == P:
+                forms.append("merged")
+        return forms + ["rccl"]
+
+    def _set_exchange(self, form: str) -> None:
+        """Switch the exchange of every learn_rows() enqueued (or captured) from now on. Collective in effect: every rank must make
+        the same switch between the same two updates."""
+        if form not in self.exchange_forms():
+            raise ValueError(f"exchange form {form!r} not available (forms: {self.exchange_forms()})")
+        self.exchange = form
+        self._xg = self.xgmi if form in ("oneshot", "merged") else None
+        self.xgmi_merged = form == "merged"
+        if self.world_size > 1:
+            # who leaves the sum-of-squares partials of the REDUCED gradient, and how many
+            self.n_partials = {"oneshot": self.xgmi.n_partials if self.xgmi is not None else 0,
+                               "merged": self.n_partials_fold + 1,       # (+ the layer-1 / BatchNorm ranges' entry of the last workgroup)
+                               "rccl": self.n_partials_norm}[form]
+            self._adam_args.n_partials = self.n_partials
+
+    def autotune_exchange(self, updates: int = 200, chunk: int = 8) -> dict:
+        """Time `updates` graph-replayed learn() calls under every available form of the exchange ON THIS NODE, agree on the
+        fastest (every rank's time, MAX over the ranks, then the smallest: all ranks see the same three numbers and make the same
+        choice) and switch to it. Collective: every rank of the group calls it at the same point — the constructor does. The
+        learner's state is put back afterwards bit for bit. Returns {form: us per update, ..., "chosen": form} (also kept as
+        self.exchange_autotune; bench.py prints it in its `preflight` object)."""
+        import time
+        import torch.distributed as dist
+        forms = self.exchange_forms()
+        lay, B, dev = self.lay, self.B, self.dev
+        saved = [(t, t.clone()) for t in (self.theta2, self.grad, self.adam_m, self.adam_v, self.bn_stats, self.step_dev,
+                                          self.partials, self.adam_bc)]
+        g = torch.Generator(device=dev).manual_seed(1234)          # (the same rows on every rank: timing, not learning)
+        rows = torch.randn(chunk, B, lay.batch_row_floats, generator=g, device=dev)
+        rows[:, :, lay.S:lay.S + lay.A].clamp_(-1, 1).trunc_()
+        store = torch.zeros(chunk * B * lay.batch_row_floats + 64, device=dev)
+        store[:rows.numel()].copy_(rows.view(-1))
+        rows = store[:rows.numel()].view(chunk, B, lay.batch_row_floats)
+        d = self.defer_ok
+        nccl = dist.get_backend(self.pg) == "nccl"
+
+        def body():
+            for k in range(chunk):
+                self.learn_rows(rows[k], pending=d and k > 0, defer=d and k < chunk - 1)
+
+        def restore():
+            for live, keep in saved:
+                live.copy_(keep)
+
+        # two passes over the forms, the faster reading of each: the first launches of a process read five times too long
+        # (clocks, first-touch, code objects) — with one pass the first form timed paid for all of that
+        times = {}
+        for form in forms + forms:
+            self._set_exchange(form)
+            graph = None
+            capturable = form != "rccl" or nccl              # (gloo, the one-GPU rehearsal's control plane, cannot be captured)
+            body()                                           # warm the launch paths (and the collective's communicator)
+            torch.cuda.synchronize(dev)
+            if capturable:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    body()
+                torch.cuda.synchronize(dev)
+            run = graph.replay if graph is not None else body
+            reps = max(1, updates // chunk) if graph is not None else max(1, updates // (4 * chunk))
+            run()
+            torch.cuda.synchronize(dev)
+            dist.barrier(group=self.pg)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize(dev)
+            took = (time.perf_counter() - t0) / (reps * chunk) * 1e6
+            if os.environ.get("NAF_AUTOTUNE_DEBUG"):
+                import sys
+                print(f"[autotune rank {dist.get_rank(self.pg)}] {form}: {took:.1f} us per update ({reps} x {chunk}, graph={graph is not None}, "
+                      f"fold fallbacks {self.fold_fallbacks})", file=sys.stderr, flush=True)
+            times[form] = min(times.get(form, 1e30), took)
+            del graph
+            restore()
+            torch.cuda.synchronize(dev)
+        t = torch.tensor([times[f] for f in forms], dtype=torch.float64, device=dev if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)       # the slowest rank bounds a lock-step update
+        agreed = {f: round(float(v), 2) for f, v in zip(forms, t.tolist())}
+        best = min(forms, key=lambda f: (agreed[f], forms.index(f)))
+        timeouts = self.xgmi.status()[1] if self.xgmi is not None else 0
+        if timeouts and best != "rccl":                      # a peer-memory form that lost a wait while being timed is not trusted
+            best = "rccl"
+        self._set_exchange(best)
+        self.exchange_autotune = dict(agreed, chosen=best, updates_timed=updates, xgmi_timed_out_waits=int(timeouts))
+        if dist.get_rank(self.pg) == 0:
+            import sys
+            print("[naf] gradient exchange on this node, us per update: " + ", ".join(f"{f} {agreed[f]:.1f}" for f in forms) +
+                  f" -> {best}", file=sys.stderr, flush=True)
+        return self.exchange_autotune
 
     # ---- parameters in / out ----------------------------------------------------------------------------
     def main_views(self) -> Dict[str, torch.Tensor]:
@@ -454,8 +564,8 @@ class Learner:
         Reads a pinned host word the kernel bumps — a load, never a synchronisation; the value lags the stream by whatever is
         still queued. Called before every chunk of updates and every learn(). (The waits INSIDE a launch — the records of the
         BatchNorm folds — cannot fail: a thread that waits too long folds for itself, see fold_fallbacks.)"""
-        if self.xgmi is not None:
-            self.xgmi.raise_on_timeout()
+        if self._xg is not None:
+            self._xg.raise_on_timeout()
 
     @property
     def fold_fallbacks(self) -> int:
@@ -572,11 +682,11 @@ class Learner:
         if self.world_size > 1 or self._force_allreduce:
             # data parallel: one sum all-reduce of the flat gradient over RCCL/xGMI; the 1/W is folded into the
             # clip scale of the optimizer kernel (the clip acts on the averaged gradient)
-            if self.xgmi is not None:
+            if self._xg is not None:
                 # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
                 # (merged: the finish launch of the row-split chain has done all of that already)
                 if not (self.xgmi_merged and "bb" in self.fuse):
-                    self.xgmi.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=self._pushed_lo,
+                    self._xg.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=self._pushed_lo,
                                          pushed_also=self._pushed_also)
                 if not defer:
                     self.optimizer_step(norm_ready=True)
@@ -611,16 +721,16 @@ class Learner:
         # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles; dY2 becomes dZ2 while it is staged, the
         # dA1 blocks run layer 1's backward batch pass on their tile (this minibatch's rows: z recomputed from them)
         self._epi.x, self._epi.ldx = rp, ld
-        check(f.naf_gemm_bundle_ex(self._bundle, 3, 2 if self.gemm_ring else 1, st), "gemm_bundle")
+        check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
         # finish: everything added in block order, the xhat term from the moments, the bundle's split-K slabs, the norm
         # partials (nb = 0: the layer-2 bias gradient is written as the 0 it identically is). Data parallel over peer memory:
         # the workgroups that add the slabs of dW2 and dWh (91 % of the flat gradient) store them to the peers as well, so the
         # all-reduce launch behind this one sends only the layer-1 / BatchNorm segments before it raises its flags
         push = None
         merged = False
-        if self.xgmi is not None and seg["Wh"].offset + seg["Wh"].numel == P:      # (Wh ends the buffer: no pad behind it)
+        if self._xg is not None and seg["Wh"].offset + seg["Wh"].numel == P:      # (Wh ends the buffer: no pad behind it)
             if self._push_desc is None:
-                self._push_desc = self.xgmi.push_desc()
+                self._push_desc = self._xg.push_desc()
             push = _lib.C.byref(self._push_desc)
             self._pushed_lo = seg["Wh"].offset                                         # Wh is the last segment: [Wh, P)
             self._pushed_also = (seg["W2"].offset, seg["W2"].offset + H * H)
@@ -678,7 +788,7 @@ class Learner:
                 gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset, gp + 4 * seg["b2"].offset, B, H, st), "bn_relu_bwd(2)")
         if gb:
             # dWh = dH^T A2, dW2 = dZ2^T A1, dA1 = dZ2 W2: one launch of MFMA tiles
-            check(f.naf_gemm_bundle_ex(self._bundle, 3, 1, st), "gemm_bundle")
+            check(f.naf_gemm_bundle(self._bundle, 3, st), "gemm_bundle")
         else:
             torch.mm(self.dZ2.t(), self.A1[0], out=self.gW2)
             torch.mm(self.dZ2, self.W2_main, out=self.dA1)
@@ -687,9 +797,9 @@ class Learner:
             # memory: everything but layer 1's gradient is final by now (segments W2 .. Wh of the flat buffer) and goes
             # to the peers from extra workgroups of this very launch, so its wire time runs under the kernel
             push = None
-            if self.xgmi is not None:
+            if self._xg is not None:
                 if self._push_desc is None:
-                    self._push_desc = self.xgmi.push_desc()
+                    self._push_desc = self._xg.push_desc()
                 push, self._pushed_lo = _lib.C.byref(self._push_desc), seg["W2"].offset
             check(f.naf_bn_relu_bwd_wgrad_push(
                 ptr(self.dA1), H, rp, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,

@@ -394,15 +394,18 @@ def test_host_vector_env_training_end_to_end(scratch_cwd, async_policy):
         vec.close()
 
 
-@pytest.mark.parametrize("world,fuse,merge", [(2, "columns", "1"), (4, None, "1"), (2, None, "1"), (2, None, "0")])
-def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse, merge):
+@pytest.mark.parametrize("world,fuse,exchange", [(2, "columns", "oneshot"), (4, None, "merged"), (2, None, "merged"),
+                                                 (2, None, "oneshot"), (2, None, "auto"), (4, None, "auto")])
+def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse, exchange):
     """csrc/xgmi_reduce.hip with W > 1 on the one GPU available: W processes on cuda:0 (tests/xgmi_worker.py) map each
     other's receive slabs through hipIpc and run the one-shot all-reduce eagerly, inside a captured graph and under
     Learner.learn_rows — results bit-exact against the rank-ordered sum, replicas in lock-step, no timed-out wait.
     Two ranks on the column-tile chain (part of the gradient pushed ahead from inside its last kernel, the all-reduce a launch of
     its own), four and two on the default chain of B = 256 (the row-split one: the WHOLE exchange inside its finish launch, round 4
-    — five launches per update as on one GPU), two on the same chain with NAF_XGMI_MERGE=0 (round 3's form: the finish launch
-    pushes the two weight-gradient segments, the all-reduce launch behind it the rest)."""
+    — five launches per update as on one GPU: NAF_DP_EXCHANGE=merged), two on the same chain with the all-reduce as a launch of its
+    own (oneshot: the finish launch pushes the two weight-gradient segments, the all-reduce launch behind it the rest), and two / four
+    with the form left to Learner.autotune_exchange (round 5: every rank times every form on the node it runs on and all take the
+    collectively fastest — in this rehearsal that must be `oneshot` — with the learner's state put back bit for bit)."""
     import socket
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -410,7 +413,7 @@ def test_xgmi_oneshot_allreduce_ranks_sharing_one_gpu(world, fuse, merge):
     env = dict(os.environ, NAF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                OMP_NUM_THREADS="2")
     env.pop("NAF_FUSE", None)
-    env["NAF_XGMI_MERGE"] = merge
+    env["NAF_DP_EXCHANGE"] = exchange
     if fuse:
         env["NAF_FUSE"] = fuse
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
@@ -520,6 +523,16 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
                        env=env, capture_output=True, text=True, timeout=900)
     out = _check_bench_line_n2(r, 6, rehearsal=True)
     assert "one-shot" in out["config"]["grad_exchange"] and out["sanity"]["xgmi_timed_out_waits"] == 0
+    # the form of the exchange is measured at start-up on the node the job runs on (Learner.autotune_exchange)
+    # and the bench line says what it found (`preflight`). On one GPU — the peers' slabs are local memory behind the writer's L2 —
+    # the all-reduce as a launch of its own must come out first (48 against 62 us per update in the rehearsal's own timed loop).
+    pf = out["preflight"]
+    assert pf["backend"] == "gloo" and pf["world_size_seen"] == 2 and pf["rehearsal_one_gpu"] is True
+    assert pf["hipipc_peer_slabs_mapped_and_self_test_passed"] is True and pf["xgmi_timed_out_waits"] == 0
+    assert pf["exchange_forms_available"] == ["oneshot", "merged", "rccl"] and not pf["exchange_pinned_by_env"]
+    us = pf["exchange_us_per_update_at_startup"]
+    assert set(us) == {"oneshot", "merged", "rccl"} and all(v > 0 for v in us.values())
+    assert pf["exchange_chosen"] == "oneshot" == min(us, key=us.get), pf
 
 
 def test_bench_gpus2_launches_its_own_ranks():
@@ -539,30 +552,35 @@ def test_bench_gpus2_launches_its_own_ranks():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the gpurun box has one)")
-@pytest.mark.parametrize("xgmi,merge", [("1", "0"), ("1", "1"), ("0", "0")])
-def test_bench_two_real_gpus_rccl_and_oneshot(xgmi, merge, capsys):
-    """Two ranks on two DISTINCT devices: RCCL (NAF_XGMI=0), the one-shot peer-memory exchange as a launch of its own (default) and
-    inside the finish launch (NAF_XGMI_MERGE=1) each move the gradient between devices; replicas stay bit-identical, no wait times
-    out, RCCL saw two ranks. Prints the env-steps/s of each: the first numbers over real xGMI (which of the two one-shot forms
-    should be the default is decided here)."""
+@pytest.mark.parametrize("exchange", ["auto", "oneshot", "merged", "rccl"])
+def test_bench_two_real_gpus_rccl_and_oneshot(exchange, capsys):
+    """Two ranks on two DISTINCT devices — the first thing to run on a multi-GPU box. `auto`: Learner.autotune_exchange times the
+    three forms of the gradient exchange over real xGMI at start-up (one-shot peer-memory all-reduce as a launch of its own, the
+    same exchange inside the finish launch, RCCL) and the ranks take the fastest; then each form pinned (NAF_DP_EXCHANGE). Every
+    run: replicas bit-identical, no wait timed out, RCCL saw two ranks, and the bench line carries the `preflight` object a SCALE
+    record is read by (what was available, what each form took per update on this node, what was chosen). Prints the env-steps/s
+    of each: the first numbers over real xGMI."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
                                                             "NAF_BENCH_REHEARSAL")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", NAF_XGMI=xgmi, NAF_XGMI_MERGE=merge)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", NAF_DP_EXCHANGE=exchange)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
                         "--buffer", "100000", "--roofline-ring", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and "REHEARSAL" not in out["config"]["launch"]
     assert out["sanity"]["replicas_identical"] is True and out["sanity"]["params_finite"]
+    pf = out["preflight"]
     with capsys.disabled():
-        print(f"\n[two GPUs] NAF_XGMI={xgmi} NAF_XGMI_MERGE={merge}: {out['value']} env-steps/s, {out['us_per_update']} us per update "
-              f"({out['config']['grad_exchange']})")
-    if xgmi == "1" and merge == "1" and "one-shot" in out["config"]["grad_exchange"]:
-        assert out["sanity"]["xgmi_timed_out_waits"] == 0
-    elif xgmi == "1" and "one-shot" in out["config"]["grad_exchange"]:
-        assert out["sanity"]["xgmi_timed_out_waits"] == 0 and out["sanity"]["xgmi_allreduces"] >= 23 * 64
+        print(f"\n[two GPUs] NAF_DP_EXCHANGE={exchange}: {out['value']} env-steps/s, {out['us_per_update']} us per update "
+              f"({out['config']['grad_exchange']}); preflight {pf}")
+    assert pf["backend"] == "nccl" and pf["world_size_seen"] == 2 and pf["xgmi_timed_out_waits"] == 0
+    if exchange == "auto":
+        assert pf["exchange_us_per_update_at_startup"] and pf["exchange_chosen"] in pf["exchange_forms_available"]
     else:
-        assert out["config"]["grad_exchange"] == "RCCL all-reduce"
+        assert pf["exchange_chosen"] == exchange and pf["exchange_pinned_by_env"]
+    if pf["exchange_chosen"] == "oneshot":
+        assert out["sanity"]["xgmi_allreduces"] >= 23 * 64
+    assert out["sanity"].get("xgmi_timed_out_waits", 0) == 0
 
 
 # ---- SURVEY section 8f N1: the many-env paths produce what NAFAgent.run / test_trained_model produce --------------------

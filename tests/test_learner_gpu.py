@@ -95,31 +95,6 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
     assert (L.grad[mask] == 0).all() and (L.theta2[0][mask] == 0).all() and (L.adam_v[mask] == 0).all()
 
 
-@pytest.mark.parametrize("tag", ["xarm1024", "panda2048"])
-def test_learn_with_the_ring_form_of_the_backward_gemms_g3(tag, monkeypatch):
-    """NAF_GEMM_FORM=2: the row-split chain with its backward GEMM launch on the LDS-DMA ring (csrc/gemm_ring.h, round 4's
-    experiment — callable, not the default) against the unmodified reference's learn() at configs[3] / [4]'s batch sizes: the five
-    losses, and bitwise the same run twice."""
-    monkeypatch.delenv("NAF_FUSE", raising=False)
-    monkeypatch.setenv("NAF_GEMM_FORM", "2")
-    from synth_data import make_transitions
-    g, main0, target0 = g3_case(tag)
-    S, A, B = [int(x) for x in g[f"{tag}/dims"]]
-    st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
-    out = []
-    for rep in range(2):
-        L = make_learner(S, A, B, main0, target0)
-        assert L.fuse == ROWS and L.gemm_ring
-        rows = rows_device(L, st, ac, rw, ns, dn)
-        lp = torch.zeros(5, L.n_loss_wg, device="cuda")
-        for k in range(5):
-            L.learn_rows(rows[k * B:(k + 1) * B], lp[k])
-        torch.cuda.synchronize()
-        out.append((lp.sum(1).cpu().numpy(), L.theta2.clone()))
-    np.testing.assert_allclose(out[0][0], g[f"{tag}/losses5"], rtol=5e-3)
-    assert np.array_equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
-
-
 @pytest.mark.parametrize("fused", ["default", "rows", "columns", "unfused"])
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,B", [(21, 6, 256), (23, 7, 2048), (19, 5, 64), (25, 8, 100), (11, 1, 48), (40, 4, 32),

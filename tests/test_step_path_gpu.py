@@ -285,7 +285,7 @@ def test_per_timestep_path_is_seven_launches(scratch_cwd):
         pass                                                   # (the node count is not exposed by torch: counted under rocprofv3)
     calls = []
     lib = agent.learner.lib
-    names = ["naf_step_prep", "naf_bb_layer1_adam", "naf_bb_linear_stats_adam", "naf_bb_layer2_head", "naf_gemm_bundle_ex",
+    names = ["naf_step_prep", "naf_bb_layer1_adam", "naf_bb_linear_stats_adam", "naf_bb_layer2_head", "naf_gemm_bundle",
              "naf_bb_layer1_bwd_finish", "naf_adam_polyak_act", "naf_replay_add_counted", "naf_replay_sample_indices",
              "naf_counter_add", "naf_replay_gather_rows", "naf_bb_moments", "naf_adam_polyak_fused", "naf_policy_act",
              "naf_grad_norm_partials"]
