@@ -34,6 +34,9 @@ def g3_case(tag):
     small = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
     if tag in ("kuka", "panda"):
         return small, load_group(small, f"{tag}/main0"), load_group(small, f"{tag}/target0")
+    if tag == "h128":       # NAF(10, 5, 128), batch 64: the network of the reference's own agent test (make_golden.py --only g3h128)
+        g = np.load(os.path.join(GOLDEN, "g3_learn_h128.npz"))
+        return g, load_group(g, "h128/main0"), load_group(g, "h128/target0")
     big = np.load(os.path.join(GOLDEN, "g3_learn_default.npz" if tag in G3_DEFAULT_TAGS else "g3_learn_big.npz"))
     init = str(big[f"{tag}/init_of"])
     return big, load_group(small, f"{init}/main0"), load_group(small, f"{init}/target0")
@@ -43,3 +46,4 @@ def g3_case(tag):
 # and at three 64-row blocks (tests/golden/g3_learn_default.npz, make_golden.py --only g3def)
 G3_DEFAULT_TAGS = ["kuka64", "kuka128", "kuka192"]
 G3_TAGS = ["kuka", "panda", "xarm1024", "panda2048"] + G3_DEFAULT_TAGS
+G3_ORACLE_TAGS = G3_TAGS + ["h128"]      # (+ layer_size 128: the oracle is pinned there too; the GPU test of it is its own)

@@ -141,10 +141,10 @@ def main():
         print("g2", len(out), "arrays")
 
     # ---------------- G3: one full learn() + 5-step trace --------------------------------------------
-    def g3_case(S, A, B, tag, compact, out):
+    def g3_case(S, A, B, tag, compact, out, H=256):
         """compact: the initial weights are those of a smaller case with the same (S, A) and seed (asserted by the caller),
         so only the results of the update are stored."""
-        agent = NAFAgent(object(), S, A, 256, B, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, cpu, 0)
+        agent = NAFAgent(object(), S, A, H, B, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, cpu, 0)
         st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
         losses, pre_clip = [], {}
         real_mse, real_clip = ref_alg.F.mse_loss, ref_alg.clip_grad_norm_
@@ -192,7 +192,7 @@ def main():
         if not compact:
             out.update(flat(f"{tag}/main5", sd_np(agent.qnetwork_main.state_dict())))
             out.update(flat(f"{tag}/target5", sd_np(agent.qnetwork_target.state_dict())))
-        out[f"{tag}/dims"] = np.array([S, A, B])
+        out[f"{tag}/dims"] = np.array([S, A, B]) if H == 256 else np.array([S, A, B, H])
         print("g3", tag, losses)
         return main0
 
@@ -201,6 +201,14 @@ def main():
         for (S, A, B, tag) in ((21, 6, 256, "kuka"), (23, 7, 64, "panda")):
             g3_case(S, A, B, tag, False, out)
         np.savez_compressed(os.path.join(HERE, "g3_learn.npz"), **out)
+
+    # ---------------- G3 at the network of the reference's own agent test: NAF(10, 5, 128), batch 64 -----------------------------
+    # (tests/robotic_manipulator_rloa/naf_components/test_naf_algorithm.py:74 builds NAF(10, 5, 128, 0, 'cpu'); layer_size is a
+    #  hyper-parameter of the framework, rl_framework.py:68-74)
+    if want("g3h128"):
+        out = {}
+        g3_case(10, 5, 64, "h128", False, out, H=128)
+        np.savez_compressed(os.path.join(HERE, "g3_learn_h128.npz"), **out)
 
     # ---------------- G3 at the batch sizes of BASELINE configs[3] and [4] (one reference learn() trace each) ---------
     if want("g3big"):
