@@ -14,7 +14,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Every call only enqueues
  *     work on `stream` and returns; no call synchronises, so all of them are HIP-graph capturable.
  *   - Return value: 0 = NAF_OK, <0 = argument/state error (NAF_ERR_*), >0 = hipError_t.
- *   - A = action size, 1 <= A <= 8.  T = A(A+1)/2.  "heads row" = [mu_pre(A) | l_pre(T) | V(1)],
+ *   - A = action size, 1 <= A <= 8 for the fused kernels (every BASELINE config), up to 16 for the replay ring and the stand-alone
+ *     head / noise entry points (naf_head_*, naf_act_noise: one sample per 16-lane group beyond 8).  T = A(A+1)/2.  "heads row" = [mu_pre(A) | l_pre(T) | V(1)],
  *     row stride ldh >= A+T+1 floats; l_pre is the row-major lower triangle
  *     (0,0),(1,0),(1,1),(2,0)... exactly as torch.tril_indices orders it
  *     (naf_components/naf_neural_network.py:98-100).
@@ -113,6 +114,13 @@ int naf_replay_add_counted(naf_replay_t* h, const float* src_rows, const int32_t
  * = *counter_dev + counter_off + minibatch (counter_dev may be NULL). idx: n_batches*B int32. */
 int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const uint64_t* counter_dev, uint64_t counter_off,
                               int32_t* idx, int B, int n_batches, int without_replacement, void* stream);
+/* the same draw for minibatches beyond 4096 (the reference takes any positive batch_size: rl_framework.py:186-189): the duplicate
+ * check's table lives in device memory — `scratch`: n_batches * naf_replay_sample_scratch_ints(B) int32, owned by the caller, no
+ * initialisation needed — instead of one workgroup's LDS. Same rule, same indices (bit for bit what the LDS form would draw).
+ * 1 <= B <= 16384. */
+int naf_replay_sample_scratch_ints(int B);
+int naf_replay_sample_indices_big(naf_replay_t* h, uint64_t seed, const uint64_t* counter_dev, uint64_t counter_off, int32_t* idx,
+                                  int B, int n_batches, int without_replacement, int32_t* scratch, void* stream);
 /* replaces the np.stack/vstack + from_numpy + .to(device) chain (replay_buffer.py:57-65):
  * out_rows[n][out_ld] = the leading out_ld floats of ring[deque position idx[i]], actions truncated when
  * action_mode == TRUNC_INT. out_ld: a multiple of 4 between round_up(used floats, 4) and naf_replay_row_floats;

@@ -16,7 +16,7 @@ from typing import Optional
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libnaf_hip.so")
 SOURCES = ["lib.hip", "replay.hip", "naf_head.hip", "bn_relu.hip", "fused_layers.hip", "big_batch.hip", "gemm_bundle.hip", "optim.hip",
-           "synth_env.hip", "xgmi_reduce.hip", "policy_act.hip", "step_path.hip"]
+           "synth_env.hip", "xgmi_reduce.hip", "policy_act.hip", "step_path.hip", "naf_head_wide.hip"]
 HEADERS = ["common.h", "head_body.h", "bn_tile.h", "xgmi_dev.h", "adam_body.h", "bn2bwd_fold.h", "act_body.h", "moments_body.h", "sample_body.h", "replay_dev.h", os.path.join("..", "..", "include", "naf_hip.h")]
 
 P_HADAMARD, P_MATMUL = 0, 1
@@ -174,6 +174,8 @@ _PROTOS = {
     "naf_replay_add_batch": [_vp, _vp, _i, _vp],
     "naf_replay_add_counted": [_vp, _vp, _vp, _i, _vp],
     "naf_replay_sample_indices": [_vp, _u64, _vp, _u64, _vp, _i, _i, _i, _vp],
+    "naf_replay_sample_scratch_ints": [_i],
+    "naf_replay_sample_indices_big": [_vp, _u64, _vp, _u64, _vp, _i, _i, _i, _vp, _vp],
     "naf_replay_batch_row_floats": [_i, _i],
     "naf_replay_gather_rows": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "naf_replay_gather_soa": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -94,10 +94,18 @@ __global__ __launch_bounds__(NH_THREADS) void naf_head_kernel(const float* __res
     }
 }
 
+// 9 <= A <= 16: one sample per 16-lane group (csrc/naf_head_wide.hip)
+int naf_head_wide_launch(int mode, const float* heads, int ldh, const float* u, int ldu, const float* r, int ldr, const float* v_next,
+                         int ldv, const float* dq, float gamma, float* q_out, float* mu_out, float* d_heads, float* loss_partials,
+                         int B, int A, int p_mode, hipStream_t st);
+int naf_act_noise_wide_launch(const float* heads, int ldh, float* action_out, uint64_t seed, const uint64_t* counter_dev,
+                              uint64_t counter_off, float noise_scale, int E, int A, int p_mode, hipStream_t st);
+#define HEAD_WIDE_MAX_LDH 160
+
 static int head_args_ok(const float* heads, int ldh, const float* u, int ldu, int B, int A, int p_mode) {
-    if (!heads || !u || B <= 0 || A <= 0 || A > NAF_MAX_A) return 0;
+    if (!heads || !u || B <= 0 || A <= 0 || A > NAF_MAX_A_WIDE) return 0;
     if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return 0;
-    if (ldh < A + A * (A + 1) / 2 + 1 || ldh > HEAD_MAX_LDH || (ldh & 3) != 0) return 0;
+    if (ldh < A + A * (A + 1) / 2 + 1 || ldh > (A > NAF_MAX_A ? HEAD_WIDE_MAX_LDH : HEAD_MAX_LDH) || (ldh & 3) != 0) return 0;
     if (((uintptr_t)heads & 15) != 0 || ldu < A) return 0;
     return 1;
 }
@@ -114,6 +122,8 @@ extern "C" int naf_head_fwd(const float* heads_pre, int ldh, const float* u, int
                             int A, int p_mode, void* stream) {
     if (!head_args_ok(heads_pre, ldh, u, ldu, B, A, p_mode) || !q) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (A > NAF_MAX_A)
+        return naf_head_wide_launch(0, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, nullptr, 0.f, q, mu_out, nullptr, nullptr, B, A, p_mode, st);
     int blocks = (B + NH_SPB - 1) / NH_SPB;
     HEAD_LAUNCH(p_mode, 0, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, nullptr, 0.f, q, mu_out, nullptr, nullptr, B, A,
                 1, 0, 0);
@@ -126,6 +136,8 @@ extern "C" int naf_head_bwd(const float* heads_pre, int ldh, const float* u, int
     if (!head_args_ok(heads_pre, ldh, u, ldu, B, A, p_mode) || !dq || !d_heads || ((uintptr_t)d_heads & 15) != 0)
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (A > NAF_MAX_A)
+        return naf_head_wide_launch(1, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, dq, 0.f, nullptr, nullptr, d_heads, nullptr, B, A, p_mode, st);
     int blocks = (B + NH_SPB - 1) / NH_SPB;
     HEAD_LAUNCH(p_mode, 1, heads_pre, ldh, u, ldu, nullptr, 0, nullptr, 0, dq, 0.f, nullptr, nullptr, d_heads, nullptr, B, A,
                 1, 0, 0);
@@ -140,6 +152,9 @@ extern "C" int naf_head_fwd_bwd_mse(const float* heads_pre, int ldh, const float
         ((uintptr_t)d_heads & 15) != 0 || ldr < 1 || ldv < 1)
         return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (A > NAF_MAX_A)
+        return naf_head_wide_launch(2, heads_pre, ldh, u, ldu, r, ldr, v_next, ldv, nullptr, gamma, q_out, nullptr, d_heads, loss_partials, B,
+                                    A, p_mode, st);
     int blocks = (B + NH_SPB - 1) / NH_SPB;
     HEAD_LAUNCH(p_mode, 2, heads_pre, ldh, u, ldu, r, ldr, v_next, ldv, nullptr, gamma, q_out, nullptr, d_heads,
                 loss_partials, B, A, 1, 0, 0);
@@ -152,7 +167,7 @@ extern "C" int naf_head_fwd_bwd_mse_splitk(const float* heads_partial, int64_t s
                                            const float* u, int ldu, const float* r, int ldr, float gamma, float* q_out,
                                            float* d_heads, float* loss_partials, int B, int A, int p_mode,
                                            void* stream) {
-    if (!head_args_ok(heads_partial, ldh, u, ldu, B, A, p_mode) || !r || !vnext_partial || !d_heads ||
+    if (!head_args_ok(heads_partial, ldh, u, ldu, B, A, p_mode) || A > NAF_MAX_A || !r || !vnext_partial || !d_heads ||
         ((uintptr_t)d_heads & 15) != 0 || ldr < 1 || (n_slabs != 32 && n_slabs != 16 && n_slabs != 4) || (slab_stride & 3) != 0 ||
         slab_stride < (int64_t)B * ldh)
         return NAF_ERR_ARG;
@@ -198,10 +213,12 @@ __global__ __launch_bounds__(HEAD_THREADS) void naf_act_noise_kernel(const float
 extern "C" int naf_act_noise(const float* heads_pre, int ldh, float* action_out, uint64_t seed,
                              const uint64_t* counter_dev, uint64_t counter_off, float noise_scale, int E, int A,
                              int p_mode, void* stream) {
-    if (!heads_pre || !action_out || E <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
+    if (!heads_pre || !action_out || E <= 0 || A <= 0 || A > NAF_MAX_A_WIDE) return NAF_ERR_ARG;
     if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
     if (ldh < A + A * (A + 1) / 2 + 1) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (A > NAF_MAX_A)
+        return naf_act_noise_wide_launch(heads_pre, ldh, action_out, seed, counter_dev, counter_off, noise_scale, E, A, p_mode, st);
     int blocks = (E + HEAD_SPB - 1) / HEAD_SPB;
     if (p_mode == NAF_P_HADAMARD)
         naf_act_noise_kernel<NAF_P_HADAMARD><<<blocks, HEAD_THREADS, 0, st>>>(heads_pre, ldh, action_out, seed, counter_dev,

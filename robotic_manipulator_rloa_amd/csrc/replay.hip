@@ -24,7 +24,7 @@ extern "C" int naf_replay_row_off_next_state(int S, int A) {
 }
 
 extern "C" int naf_replay_create(uint64_t capacity, int S, int A, float* rows, uint64_t* meta, naf_replay_t** out) {
-    if (!out || !rows || !meta || capacity == 0 || S <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
+    if (!out || !rows || !meta || capacity == 0 || S <= 0 || A <= 0 || A > NAF_MAX_A_WIDE) return NAF_ERR_ARG;
     if (capacity > 0x7fffffffull) return NAF_ERR_ARG;  // deque positions are int32
     if (((uintptr_t)rows & 15) != 0) return NAF_ERR_ARG;
     naf_replay* h = new (std::nothrow) naf_replay;
@@ -218,6 +218,116 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
     }
     replay_sample_kernel<<<n_batches, threads, lds_ints * sizeof(int), (hipStream_t)stream>>>(
         h->meta, seed, counter_dev, counter_off, idx, B, without_replacement, bits);
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample, minibatches beyond 4096: the reference takes any positive batch_size (rl_framework.py:186-189 -> random.sample,
+// utils/replay_buffer.py:55). The draw above lives in one workgroup's LDS (B values + a hash table of >= 4 B ints: 80 KB at
+// B = 4096); beyond that the SAME rule — element t redraws while an earlier element holds its value — runs on a table in device
+// memory: one workgroup per minibatch again, the values in the output array itself, attempts / keys / smallest-holder in a scratch
+// area of naf_replay_sample_scratch_ints(B) ints per minibatch. Table reads go through agent-scope atomic loads (a plain load could
+// be served by a stale line of this CU's L1 from the round before). Tens of microseconds per round instead of two — at batch
+// sizes whose update takes a millisecond. Same indices as the LDS form would give, bit for bit (oracle.replay_sample_indices).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void replay_sample_big_kernel(const uint64_t* __restrict__ meta, uint64_t seed,
+                                                                 const uint64_t* __restrict__ counter_dev, uint64_t counter_off,
+                                                                 int32_t* idx, int B, int without_replacement, int hash_bits,
+                                                                 int* scratch, int64_t scratch_stride) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const uint64_t size = meta[META_SIZE];
+    const uint64_t ctr = (counter_dev ? *counter_dev : 0ull) + counter_off + (uint64_t)blockIdx.x;
+    int* vals = idx + (int64_t)blockIdx.x * B;
+    int* attempt = scratch + (int64_t)blockIdx.x * scratch_stride;       // [B]
+    int* keys = attempt + B;                                             // [M]
+    int* tmin = keys + (1 << hash_bits);                                 // [M]
+    if (size == 0) {
+        for (int t = tid; t < B; t += nt) vals[t] = 0;
+        return;
+    }
+    if (without_replacement && size >= (uint64_t)B && size < 4ull * (uint64_t)B) {
+        // dense regime: partial Fisher-Yates over the population (< 4 B ints: the table's room, 2 M >= 4 B), swap targets in vals
+        int* perm = keys;
+        for (int t = tid; t < B; t += nt) vals[t] = t + sample_draw(ctr, (uint32_t)t, 0xFFFFFFFFu, seed, size - (uint64_t)t);
+        for (int t = tid; t < (int)size; t += nt) perm[t] = t;
+        __syncthreads();
+        if (tid == 0) {
+            for (int t = 0; t < B; ++t) {
+                const int j = __hip_atomic_load(&vals[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int a = __hip_atomic_load(&perm[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int b = __hip_atomic_load(&perm[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&perm[t], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&perm[j], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < B; t += nt) vals[t] = __hip_atomic_load(&perm[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    for (int t = tid; t < B; t += nt) {
+        vals[t] = sample_draw(ctr, (uint32_t)t, 0u, seed, size);
+        attempt[t] = 0;
+    }
+    if (!(without_replacement && size >= (uint64_t)B)) return;
+    const int M = 1 << hash_bits;
+    for (int round = 0; round < NAF_SAMPLE_MAX_ROUNDS; ++round) {
+        for (int e = tid; e < M; e += nt) {
+            keys[e] = -1;
+            tmin[e] = 0x7fffffff;
+        }
+        __syncthreads();
+        for (int t = tid; t < B; t += nt) {
+            const int mine = vals[t];                  // (written by this thread)
+            unsigned h = ((unsigned)mine * 2654435761u) >> (32 - hash_bits);
+            for (int probe = 0; probe < M; ++probe) {
+                const int was = atomicCAS(&keys[h], -1, mine);
+                if (was == -1 || was == mine) break;
+                h = (h + 1) & (unsigned)(M - 1);
+            }
+            atomicMin(&tmin[h], t);
+            attempt[t] = (attempt[t] & 0xffff) | ((int)h << 16);         // (slot in the high half: M <= 32768)
+        }
+        __syncthreads();
+        int dup_any = 0;
+        for (int t = tid; t < B; t += nt) {
+            const int a = attempt[t];
+            const unsigned h = (unsigned)a >> 16;
+            const bool dup = __hip_atomic_load(&tmin[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t;
+            attempt[t] = (a & 0xffff) | (dup ? (1 << 15) : 0);           // (bit 15: redraw)
+            dup_any |= dup;
+        }
+        const int any = __syncthreads_or(dup_any);
+        if (!any) break;
+        for (int t = tid; t < B; t += nt) {
+            const int a = attempt[t];
+            if (a & (1 << 15)) {
+                const int att = (a & 0x7fff) + 1;
+                attempt[t] = att;
+                vals[t] = sample_draw(ctr, (uint32_t)t, (uint32_t)att, seed, size);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int naf_replay_sample_scratch_ints(int B) {
+    if (B <= 0 || B > 16384) return NAF_ERR_ARG;
+    int bits = 1;
+    while ((1 << bits) < 2 * B) ++bits;
+    return B + 2 * (1 << bits);
+}
+
+extern "C" int naf_replay_sample_indices_big(naf_replay_t* h, uint64_t seed, const uint64_t* counter_dev, uint64_t counter_off,
+                                             int32_t* idx, int B, int n_batches, int without_replacement, int32_t* scratch,
+                                             void* stream) {
+    if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
+    if (!idx || !scratch || B <= 0 || B > 16384 || n_batches <= 0) return NAF_ERR_ARG;
+    int bits = 1;
+    while ((1 << bits) < 2 * B) ++bits;
+    replay_sample_big_kernel<<<n_batches, 1024, 0, (hipStream_t)stream>>>(h->meta, seed, counter_dev, counter_off, idx, B,
+                                                                          without_replacement, bits, (int*)scratch,
+                                                                          (int64_t)naf_replay_sample_scratch_ints(B));
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -235,6 +235,7 @@ extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_
     if (action_mode != NAF_ACTION_TRUNC_INT && action_mode != NAF_ACTION_FLOAT) return NAF_ERR_ARG;
     if ((out_ld & 3) != 0 || out_ld < naf_round_up(naf_row_off_done(h->S, h->A) + 1, 4) || out_ld > h->row_floats) return NAF_ERR_ARG;
     const int k4 = (h->S + 3) / 4;
+    if (h->row_floats > 64) return NAF_ERR_ARG;          // (the appended row is held in 16 float4 of LDS)
     if (k4 > 8 || out_ld != naf_replay_batch_row_floats(h->S, h->A)) return NAF_ERR_ARG;   // (the row the learner's kernels and the moments expect)
     StepPrepArgs P;
     P.ring = (float4*)h->rows;

@@ -378,6 +378,9 @@ class DeviceEnvLoop:
         self.max_frames = int(max_frames)
         self.noise_scale = float(noise_scale)
         self.actor = ActPath(learner, self.E, seed=self.seed ^ 0xA5A5A5A5)
+        if lay.A > 8:
+            raise _lib.NafHipError(f"the on-device stand-in environment models arms of up to 8 joints (action_size {lay.A}): drive "
+                                   "such an agent through run() / run_host_vectorized with a host environment")
         nst = self.lib.naf_synth_env_state_floats(lay.A)
         self.env_state = torch.zeros(self.E, nst, dtype=torch.float32, device=dev)
         self.rows = torch.zeros(self.E, lay.row_floats, dtype=torch.float32, device=dev)

@@ -85,8 +85,9 @@ class NetLayout:
     zero gradients and therefore stay zero under Adam."""
 
     def __init__(self, state_size: int, action_size: int, layer_size: int):
-        if not (1 <= action_size <= 8):
-            raise ValueError("action_size must be in 1..8 (one sample per 8-lane group in the head kernel)")
+        if not (1 <= action_size <= 16):
+            raise ValueError("action_size must be in 1..16 (one sample per 8-lane group in the fused head kernels, per 16-lane "
+                             "group in the stand-alone ones)")
         self.S, self.A, self.H = state_size, action_size, layer_size
         self.T = action_size * (action_size + 1) // 2
         self.NH = self.A + self.T + 1                  # [mu | l | V]
@@ -179,15 +180,15 @@ class Learner:
         # on the row-split chain, smaller ones on the column-tile chain, other layer / state sizes on the unfused chain (beyond 2048
         # with the streamed BatchNorm kernels of csrc/bn_relu.hip) with a warning that names the row-split chain's range. 4096 is
         # the replay sampler's limit (one workgroup draws a minibatch without replacement in LDS, csrc/replay.hip).
-        if self.B < 1 or self.B > 4096:
-            raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 4096 (the sampler draws a minibatch in one workgroup's LDS)")
+        if self.B < 1 or self.B > 16384:
+            raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 16384 (the replay sampler's table, csrc/replay.hip)")
         # (round 4: ANY batch size from 16 to 4096 — the last 64-row block of layer 1 / GEMM 2, the last 16-row workgroup of the fused
         #  layer-2 + head launch and the last block of the bundle's dA1 product may be partial: rows past the batch read as zeros, are
         #  never stored and stay out of every statistic and sum. The work buffers hold Bp = the next multiple of 16 rows (of 32 beyond
         #  B = 2048, where the fused layer-2 + head launch runs 32 rows per workgroup),
         #  zero-initialised: the weight-gradient products walk Bp rows as their K dimension, and a row past the batch is a zero in at
         #  least one operand of each — dH and dY2 rows the head body never writes, A1 rows layer 1 never stores.)
-        self.bb_ok = (16 <= self.B <= 4096 and lay0.H == 256 and lay0.S <= 26)
+        self.bb_ok = (16 <= self.B <= 4096 and lay0.H == 256 and lay0.S <= 26 and lay0.A <= 8)
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
@@ -195,6 +196,8 @@ class Learner:
             want = "rows" if self.bb_ok else ("columns" if self.B <= 512 else "unfused")
         if want == "rows" and not self.bb_ok:
             want = "columns" if self.B <= 512 else "unfused"
+        if lay0.A > 8 and want != "rows":
+            want = "unfused"                   # (9 .. 16 joints: the fused kernels hold one sample per 8-lane group)
         if want == "rows":
             self.fuse = {"bb", "gb", "hk", "ep", "s2"}
         elif want == "columns" and self.B <= 512:
@@ -209,7 +212,11 @@ class Learner:
         if (self.B % 16 != 0 and want != "rows") or lay0.H % 16 != 0:
             self.fuse -= {"gb"}                # the MFMA kernels take whole 16 x 16 x 16 steps: M, N, K % 16 == 0
         self.chain = want
-        if self.B > 512 and want != "rows":
+        if lay0.A > 8:
+            import warnings
+            warnings.warn(f"action_size {lay0.A} runs the unfused chain: the fused kernels take at most 8 joints (every arm the "
+                          f"reference ships: KUKA / xArm 6, Panda 7)", stacklevel=3)
+        elif self.B > 512 and want != "rows":
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)
             import warnings
             warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
@@ -861,7 +868,7 @@ class ActPath:
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)   # noise stream position (uint64 on device)
         # one launch for the whole act() (csrc/policy_act.hip) when the shapes are the framework's (H = 256, S <= 32);
         # other shapes take the seven-launch path (3 GEMMs, 2 BN kernels, noise, counter)
-        self.fused = lay.H == 256 and lay.S <= 32
+        self.fused = lay.H == 256 and lay.S <= 32 and lay.A <= 8
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_io = bool(host_io) and self.fused
         if self.host_io:

@@ -65,6 +65,7 @@ class ReplayBuffer:
         self._stage_np = self._stage_hosts[0].numpy()
         self._idx = torch.zeros(self.batch_size, dtype=torch.int32, device=self.device)
         self._sample_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._sample_scratch = None        # (batch sizes beyond 4096: the sampler's table, allocated at the first draw)
 
     def __del__(self):
         try:
@@ -131,9 +132,20 @@ class ReplayBuffer:
 
     # ---- sample -----------------------------------------------------------------------------------------------
     def sample_indices(self, idx_out: torch.Tensor, n_batches: int = 1) -> None:
-        check(self.lib.naf_replay_sample_indices(self.handle, self.seed, ptr(self._sample_ctr), 0, ptr(idx_out),
-                                                 self.batch_size, int(n_batches), int(self.without_replacement),
-                                                 stream_ptr()), "naf_replay_sample_indices")
+        if self.batch_size > 4096:
+            # beyond one workgroup's LDS: the duplicate check's table in device memory (csrc/replay.hip, replay_sample_big_kernel)
+            per = self.lib.naf_replay_sample_scratch_ints(self.batch_size)
+            if per < 0:
+                raise ValueError(f"batch_size {self.batch_size}: the replay sampler draws minibatches of at most 16384")
+            if self._sample_scratch is None or self._sample_scratch.numel() < per * int(n_batches):
+                self._sample_scratch = torch.zeros(per * int(n_batches), dtype=torch.int32, device=self.device)
+            check(self.lib.naf_replay_sample_indices_big(self.handle, self.seed, ptr(self._sample_ctr), 0, ptr(idx_out),
+                                                         self.batch_size, int(n_batches), int(self.without_replacement),
+                                                         ptr(self._sample_scratch), stream_ptr()), "naf_replay_sample_indices_big")
+        else:
+            check(self.lib.naf_replay_sample_indices(self.handle, self.seed, ptr(self._sample_ctr), 0, ptr(idx_out),
+                                                     self.batch_size, int(n_batches), int(self.without_replacement),
+                                                     stream_ptr()), "naf_replay_sample_indices")
         check(self.lib.naf_counter_add(ptr(self._sample_ctr), int(n_batches), stream_ptr()), "naf_counter_add")
 
     def gather_rows(self, idx: torch.Tensor, out_rows: torch.Tensor, n: int) -> None:

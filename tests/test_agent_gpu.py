@@ -138,6 +138,35 @@ def test_step_appends_every_transition_exactly_once(scratch_cwd):
     assert torch.isfinite(agent.learner.theta2).all()
 
 
+@pytest.mark.parametrize("S,A,B", [(27, 9, 64), (21, 6, 5000)])
+def test_agent_trains_at_shapes_beyond_the_fused_kernels(scratch_cwd, S, A, B):
+    """the reference takes any positive batch_size (rl_framework.py:186-189) and builds its head for any action
+    size (naf_neural_network.py:53-54). A 9-joint arm and a 5000-row minibatch go through NAFAgent.act / step like any other shape
+    (unfused chain, the sampler's table in device memory, one sample per 16-lane group in the head and noise kernels): the gate
+    opens at len(memory) > batch_size, every later step is one update, actions are finite and clamped, the ring holds what was added."""
+    import warnings
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    from synth_data import make_transitions
+    n = B + 40
+    st, ac, rw, ns, dn = make_transitions(n, S, A, seed=13)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        agent = NAFAgent(object(), S, A, 256, B, 2 * n, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+    assert agent.learner.chain == "unfused" and len(caught) == 1
+    state = st[0].astype(np.float64)
+    for t in range(n):
+        a = agent.act(state)
+        assert a.shape == (A,) and np.isfinite(a).all() and (np.abs(a) <= 1).all()
+        agent.step(state, a, float(rw[t]), ns[t].astype(np.float64), 0)
+        state = ns[t].astype(np.float64)
+    torch.cuda.synchronize()
+    assert int(agent.learner.step_dev.item()) == n - B and agent.memory.device_len() == len(agent.memory) == n
+    assert torch.isfinite(agent.learner.theta2).all() and np.isfinite(agent.last_loss())
+    np.testing.assert_array_equal(agent.memory.rows[:n, S + A].cpu().numpy(), rw[:n])
+    idx = agent._chunk.idx.cpu().numpy().ravel()
+    assert len(set(idx.tolist())) == B and idx.min() >= 0 and idx.max() < n          # without replacement, inside the ring
+
+
 def test_learn_api_with_reference_sample_tuple(scratch_cwd):
     """NAFAgent.learn((states, actions int64, rewards, next_states, dones)) == the reference's losses (G3)."""
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent

@@ -81,8 +81,11 @@ def test_reference_init_bit_exact_and_layout_roundtrip():
         assert total == lay.n_ref_params() and (flat[~used] == 0).all()
         assert lay.P % 64 == 0 and lay.NHP % 8 == 0 and all(s.offset % 64 == 0 for s in lay.seg.values())
     assert NetLayout(21, 6, 256).n_ref_params() == 79644 and NetLayout(23, 7, 256).n_ref_params() == 82212
+    # 9 .. 16 joints: a layout like any other (one sample per 16-lane group in the stand-alone head kernels); beyond: refused
+    wide = NetLayout(27, 9, 256)
+    assert (wide.T, wide.NH, wide.NHP, wide.row_floats) == (45, 55, 64, 128) and wide.n_ref_params() == 256 * 27 + 256 * 256 + 6 * 256 + 55 * 257
     with pytest.raises(ValueError):
-        NetLayout(27, 9, 256)
+        NetLayout(40, 17, 256)
 
 
 def test_hyperparameter_rules_match_reference_contract():

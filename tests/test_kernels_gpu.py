@@ -198,10 +198,14 @@ def test_replay_sample_api_contract_matches_reference_golden(lib):
 # (duplicates are resolved through an LDS hash table — up to 80 KB of LDS at B = 4096, csrc/replay.hip: (300, 64), (5000, 1024),
 #  (9000, 2048), (20000, 2048), (20000, 4096) and (9000, 3000) redraw dozens to hundreds of elements over several rounds; 100, 48
 #  and 3000 are not powers of two)
+# (beyond 4096 the table is in device memory, csrc/replay.hip replay_sample_big_kernel — the same rule, so the same restatement:
+#  (100000, 8192) a few redraws, (30000, 8192) a thousand over several rounds, (20000, 8192) the dense regime's partial
+#  Fisher-Yates, (40000, 5000) not a power of two, (200000, 16384) the largest minibatch)
 @pytest.mark.parametrize("size,B,nb", [(1000, 256, 8), (257, 256, 3), (300, 64, 5), (100000, 2048, 2), (5000, 1024, 2),
                                        (9000, 2048, 3), (20000, 2048, 4), (50000, 4096, 2), (20000, 4096, 3), (9000, 3000, 2),
                                        (700, 100, 6), (200, 48, 9),
-                                       (1_000_000, 256, 64)])
+                                       (1_000_000, 256, 64),
+                                       (100000, 8192, 2), (30000, 8192, 3), (20000, 8192, 2), (40000, 5000, 2), (200000, 16384, 1)])
 def test_replay_sampler_bit_exact_vs_oracle(lib, size, B, nb):
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     buf = ReplayBuffer(size, B, "cuda", 0x1234ABCD5678, state_size=21, action_size=6)
@@ -268,7 +272,9 @@ def test_head_vs_reference_golden(lib, A, B, tag):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("A,B", [(6, 256), (7, 2048), (3, 33), (8, 100), (1, 5)])
+# (A > 8: one sample per 16-lane group, csrc/naf_head_wide.hip — the reference builds matrix_entries for any action size,
+#  naf_neural_network.py:53-54)
+@pytest.mark.parametrize("A,B", [(6, 256), (7, 2048), (3, 33), (8, 100), (1, 5), (9, 256), (12, 100), (16, 37), (10, 1)])
 def test_head_both_modes_vs_oracle_f64(lib, mode, A, B):
     rng = np.random.default_rng(10 * A + B + mode)
     T = A * (A + 1) // 2
@@ -289,6 +295,17 @@ def test_head_both_modes_vs_oracle_f64(lib, mode, A, B):
     lp = torch.zeros(nwg, device="cuda")
     assert lib.naf_head_fwd_bwd_mse(h.data_ptr(), ldh, ud.data_ptr(), A, rd.data_ptr(), 1, vnd.data_ptr(), 1, gamma,
                                     q.data_ptr(), dh.data_ptr(), lp.data_ptr(), B, A, mode, st()) == 0
+    if A > 8:
+        # the forward-only and the backward-given-dq entry points on the same inputs
+        q0, mu0 = torch.empty(B, device="cuda"), torch.empty(B, A, device="cuda")
+        assert lib.naf_head_fwd(h.data_ptr(), ldh, ud.data_ptr(), A, q0.data_ptr(), mu0.data_ptr(), B, A, mode, st()) == 0
+        dh0 = torch.full((B, ldh), 7.0, device="cuda")
+        assert lib.naf_head_bwd(h.data_ptr(), ldh, ud.data_ptr(), A, dev(dq).data_ptr(), dh0.data_ptr(), B, A, mode, st()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(q0, q)
+        np.testing.assert_allclose(mu0.cpu().numpy(), np.tanh(mu_pre), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(dh0.cpu().numpy(), dh.cpu().numpy(), rtol=2e-4, atol=1e-7)
+        assert (dh0[:, A + T + 1:] == 0).all()
     np.testing.assert_allclose(q.cpu().numpy(), f["Q"], rtol=3e-5, atol=3e-5)
     dhn = dh.cpu().numpy()
     scale = np.abs(dq).max() * 10
@@ -308,7 +325,8 @@ def test_head_argument_errors(lib):
     h = torch.zeros(4, 32, device="cuda")
     u = torch.zeros(4, 6, device="cuda")
     q = torch.zeros(4, device="cuda")
-    assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 9, 0, st()) == -1   # A > 8
+    assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 17, 0, st()) == -1  # A > 16
+    assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 9, q.data_ptr(), None, 4, 9, 0, st()) == -1   # A = 9 needs ldh >= 55
     assert lib.naf_head_fwd(h.data_ptr(), 24, u.data_ptr(), 6, q.data_ptr(), None, 4, 6, 0, st()) == -1   # ldh too small
     assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 6, 2, st()) == -1   # bad mode
     assert lib.naf_head_fwd(None, 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 6, 0, st()) == -1
