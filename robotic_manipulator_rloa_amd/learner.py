@@ -465,7 +465,7 @@ class Learner:
                                "rccl": self.n_partials_norm}[form]
             self._adam_args.n_partials = self.n_partials
 
-    def autotune_exchange(self, updates: int = 200, chunk: int = 8) -> dict:
+    def autotune_exchange(self, updates: int = 200, chunk: int = 8, verbose: bool = False) -> dict:
         """Time `updates` graph-replayed learn() calls under every available form of the exchange ON THIS NODE, agree on the
         fastest (every rank's time, MAX over the ranks, then the smallest: all ranks see the same three numbers and make the same
         choice) and switch to it. Collective: every rank of the group calls it at the same point — the constructor does. The
@@ -518,7 +518,7 @@ class Learner:
                 run()
             torch.cuda.synchronize(dev)
             took = (time.perf_counter() - t0) / (reps * chunk) * 1e6
-            if os.environ.get("NAF_AUTOTUNE_DEBUG"):
+            if verbose:
                 import sys
                 print(f"[autotune rank {dist.get_rank(self.pg)}] {form}: {took:.1f} us per update ({reps} x {chunk}, graph={graph is not None}, "
                       f"fold fallbacks {self.fold_fallbacks})", file=sys.stderr, flush=True)
