@@ -10,11 +10,14 @@ rm -rf $d
 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o api -- python3 benchmarks/host_api_steps.py $batch > /tmp/prof_api_$tag.out 2>&1 || { tail -20 /tmp/prof_api_$tag.out; exit 1; }
 tail -3 /tmp/prof_api_$tag.out
 cp $(find $d -name "*kernel_stats.csv") gpurun_out/${tag}_api_path_kernel_stats.csv
-python3 benchmarks/stats_summary.py gpurun_out/${tag}_api_path_kernel_stats.csv --updates 3300 --top 24 --out gpurun_out/${tag}_api_path_digest.csv
+# timesteps of the process: warm-up max(300, 4 B + 60) + 3000 timed
+steps=$(python3 -c "print(max(300, 4 * $batch + 60) + 3000)")
+python3 benchmarks/stats_summary.py gpurun_out/${tag}_api_path_kernel_stats.csv --updates $steps --top 24 --out gpurun_out/${tag}_api_path_digest.csv
 cat gpurun_out/${tag}_api_path_digest.csv
 python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("gpurun_out/${tag}_api_path_kernel_stats.csv")))
 calls = sum(int(r["Calls"]) for r in rows)
-print(f"launches in the process: {calls}; per timestep (3300 timesteps incl. warm-up): {calls / 3300:.2f}")
+own = sum(int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("step_prep", "bb_layer1", "bb_linear", "bb_layer2", "gemm_bundle", "adam_act", "policy_act", "replay_", "counter_add", "bb_moments", "adam_polyak")))
+print(f"launches in the process: {calls} ({own} of the path's own kernels); per timestep ($steps timesteps incl. warm-up): {own / $steps:.2f}")
 PY
