@@ -497,7 +497,6 @@ def extras(dev, args):
             cb = time_baseline(S, A, 256, 64, 100000, budget_s=6.0, threads=8)
             res["reference_api_path"]["cpu_port_same_shape"] = {"value": round(cb["steps_per_s"], 1), "unit": "timesteps/s",
                                                                 "cores": cb["threads"], "env": "none (agent only)"}
-        del agent
         # (i) host vector env: 64 envs in worker processes (PyBullet would need one per process; the light stand-in
         # shares workers), B=256, ring 1e5 pre-filled past the `len > batch` gate by the first vector steps
         workers = max(1, min(E, (os.cpu_count() or 8) // 2))
