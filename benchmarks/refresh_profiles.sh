@@ -28,11 +28,14 @@ sweep)     # SURVEY 8d bulk sweep of the streaming kernels, HIP events (the tabl
   d=/tmp/prof_sweep; rm -rf $d
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r05_sweep -- python3 benchmarks/roofline_sweep.py > gpurun_out/r05_roofline_sweep.md 2> gpurun_out/sweep.err
   cp $(find $d -name "*kernel_stats.csv") gpurun_out/r05_sweep_kernel_stats.csv; cat gpurun_out/r05_roofline_sweep.md ;;
-pmc)       # HBM traffic of the bulk gather: separate passes per counter, kernel trace only (never combined with other domains)
+pmc)       # HBM traffic of the bulk gather: separate passes per counter AND per ring (a process each), kernel trace only (never
+           # combined with other trace domains)
+  for ring in 4000000 16000000; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    d=/tmp/pmc_$c; rm -rf $d
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o g -- python3 bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-extras > /tmp/pmc_$c.out 2>&1
-    python benchmarks/pmc_gather.py $d gpurun_out/r05_gather_pmc_$c.csv
+    d=/tmp/pmc_${ring}_$c; rm -rf $d
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o g -- python3 bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-extras --roofline-ring $ring --roofline-hbm-ring 0 > /tmp/pmc_${ring}_$c.out 2>&1
+    python benchmarks/pmc_gather.py $d gpurun_out/r05_gather_pmc_ring${ring}_$c.csv
+  done
   done ;;
 timeline)  # phases inside the kernels, gaps between them (no profiler attached); needs its own build
   export NAF_BUILD_DEFINES=-DNAF_TIMELINE

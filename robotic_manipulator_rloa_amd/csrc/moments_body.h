@@ -80,8 +80,8 @@ __device__ __forceinline__ static void bb_moments_body(Load4 load4, BmShared& S,
     S.sRed[g1][k1] = s;
     __syncthreads();
     BM_MARK(8);
-    float sx_out = 0.f;                                     // (stored at the END: a global store in flight here makes every barrier
-    if (tid < 32) {                                         //  below wait for its acknowledgement — ~1 us in a 5-us body)
+    float sx_out = 0.f;                                     // (stored at the end, with the rest of the record)
+    if (tid < 32) {
         double t = 0.0;
         for (int g = 0; g < 16; ++g) t += S.sRed[g][tid];
         sM[tid] = (float)(t / (double)B);

@@ -82,9 +82,10 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
     // up to SP_CACHE_ROWS rows the gathered minibatch also stays in LDS, where the moments take it from (behind sPos, 16-B aligned)
     float4* sRows = (float4*)(sp_smem + 2 * sizeof(BmShared) + (size_t)naf_round_up(P.B, 4) * sizeof(int));
     __shared__ float4 sNew[16];                                        // the appended row (rf4 <= 16 float4)
-    // Small batches (the per-timestep shapes): EVERY global store waits for the end of the kernel. A store in flight makes each
-    // workgroup barrier behind it wait for its acknowledgement (the barrier's release), ~1 us a time, and there are a dozen
-    // barriers between here and there; the appended row is taken from LDS by whoever draws it.
+    // Small batches (the per-timestep shapes): everything the launch leaves in memory is stored in one go at its end, from LDS; the
+    // appended row is taken from LDS by whoever draws it. (Tried for speed — on the theory that a store in flight holds up the
+    // barriers behind it — and measured neutral: hipcc's workgroup barrier on gfx950 waits for LDS traffic only, s_waitcnt
+    // lgkmcnt(0). Kept: the phases between the draw and the moments then touch memory for loads only.)
     constexpr bool cache = CACHE;
     int* vals = (int*)sp_smem;
     const int tid = threadIdx.x, B = P.B;
@@ -403,12 +404,6 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
     if (P.host_errors) __hip_atomic_fetch_add((unsigned long long*)P.host_errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// a workgroup barrier for LDS hand-overs only: __syncthreads() also releases at workgroup scope, i.e. waits for every global store
-// the wave has in flight (the stepped parameters: ~1 us of acknowledgements) — nothing here reads those stores in this launch
-__device__ __forceinline__ static void aa_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 template <int PMODE>
 __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs P) {
     __shared__ AdamScalars sSc;
@@ -462,7 +457,7 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
             const aa_f4 nv = aa_apply4(A, sc, o, f4, false);
             *(aa_f4*)(sW + lds) = nv;
         }
-        aa_lds_barrier();
+        __syncthreads();
         NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 2);
         if (tid < R) {
             const int row = row0 + tid;
@@ -529,7 +524,7 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
             *(aa_f4*)(sAct + 4 * lane) = x;
             if (timed) sTimed = 1;
         }
-        aa_lds_barrier();
+        __syncthreads();
         NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 11, tl_l2, false);
         if (sTimed && tid == 0) aa_count_timeout(P);
         const aa_f4 x = *(const aa_f4*)(sAct + 4 * lane);

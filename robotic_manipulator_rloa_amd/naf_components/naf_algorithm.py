@@ -239,6 +239,9 @@ class NAFAgent:
                     else:
                         self._ahead = None
                     once.run()
+                    # (the eager chunk's tail writes the same pinned action / ordinal words the graph's will: what act() waits
+                    #  for next is THIS run)
+                    self._chunk._seq_prev, self._chunk._inflight = once._seq_prev, once._inflight
                     self._chunk.loss_parts = once.loss_parts       # (last_loss() of this tick)
                     self._chunk.idx.copy_(once.idx)                # (... and the minibatch it drew, where a reader looks for it)
                     self._last_loss_from = "chunk"
