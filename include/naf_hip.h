@@ -83,6 +83,7 @@ int naf_timeline_read(int kernel_id, long long* out);
  * fence, so the bytes have left the CPU before the caller launches the kernel that reads them. That kernel must load them with
  * system scope. naf_step_prep's src_row / n_word may point to such memory: its first dependent load is then a local-memory
  * latency instead of a PCIe round trip to pinned host memory. */
+int naf_host_store_supported(int device); /* 1: the CPU can store into this device's allocations (large BAR); 0: not; ask first */
 int naf_host_publish(void* dst_device, const void* src_host, size_t bytes);
 /* the same followed by hipGraphLaunch(graph_exec, stream) — one call per timestep of the per-timestep path (bytes == 0: launch
  * only). graph_exec: a hipGraphExec_t (e.g. torch.cuda.CUDAGraph.raw_cuda_graph_exec()). */

@@ -164,6 +164,7 @@ _PROTOS = {
     "naf_hip_abi_version": [],
     "naf_hip_arch": [],
     "naf_timeline_read": [_i, _vp],
+    "naf_host_store_supported": [_i],
     "naf_host_publish": [_vp, _vp, _sz],
     "naf_host_publish_launch": [_vp, _vp, _sz, _vp, _vp],
     "naf_replay_row_floats": [_i, _i],

@@ -27,6 +27,14 @@ extern "C" int naf_timeline_read(int kernel_id, long long* out) {
 // L2 of its XCD may still hold the line from the previous read. A kernel that reads its input this way pays a local memory
 // latency on its first dependent load instead of a PCIe round trip to pinned host memory (~0.8 against ~2.8 us on MI355X).
 #include <string.h>
+// 1: the CPU can store into this device's memory (the runtime reports a large BAR); 0: it cannot — callers keep pinned host
+// memory and let the kernel read across PCIe; < 0: error. (A store through an unmapped device pointer is a segmentation fault:
+// nobody calls naf_host_publish without asking here first.)
+extern "C" int naf_host_store_supported(int device) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, device) != hipSuccess) return NAF_ERR_STATE;
+    return v ? 1 : 0;
+}
 extern "C" int naf_host_publish(void* dst_device, const void* src_host, size_t bytes) {
     if (!dst_device || !src_host) return NAF_ERR_ARG;
     memcpy(dst_device, src_host, bytes);

@@ -125,7 +125,8 @@ class TrainChunk:
         # (naf_host_publish: every device allocation is CPU-mapped here) — its first dependent load is then a local-memory
         # latency (~0.8 us) instead of a PCIe round trip to pinned host memory (~2.8 us, measured inside the kernel)
         self.head_dev = None
-        if self.fused_prep and head_row is not None and head_row.numel() >= rf + 4 and os.environ.get("NAF_HOST_STORE", "1") != "0":
+        if self.fused_prep and head_row is not None and head_row.numel() >= rf + 4 and os.environ.get("NAF_HOST_STORE", "1") != "0" and \
+                learner.lib.naf_host_store_supported(dev.index or 0) == 1:       # (no large BAR: the kernel reads the pinned row itself)
             self.head_dev = torch.zeros(rf + 4, dtype=torch.float32, device=dev)
             self._head_src, self._head_dst, self._head_bytes = head_row.data_ptr(), self.head_dev.data_ptr(), 4 * (rf + 1)
             self._publish = learner.lib.naf_host_publish
