@@ -259,6 +259,7 @@ def main():
             "xgmi_slab_memory": getattr(L.xgmi, "mem_kind", None),
             "exchange_forms_available": L.exchange_forms(),
             "exchange_us_per_update_at_startup": {k: v for k, v in at.items() if k in ("oneshot", "merged", "rccl")} or None,
+            "exchange_forms_that_failed_at_startup": at.get("errors"),
             "exchange_chosen": L.exchange,
             "exchange_pinned_by_env": os.environ.get("NAF_DP_EXCHANGE", "auto") != "auto",
             "xgmi_timed_out_waits": out["sanity"].get("xgmi_timed_out_waits", 0),

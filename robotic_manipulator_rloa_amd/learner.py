@@ -496,18 +496,36 @@ class Learner:
 
         # two passes over the forms, the faster reading of each: the first launches of a process read five times too long
         # (clocks, first-touch, code objects) — with one pass the first form timed paid for all of that
-        times = {}
+        from .parallel import _agree
+        times, errors = {}, {}
         for form in forms + forms:
+            if form in errors:
+                continue
             self._set_exchange(form)
-            graph = None
+            graph, err = None, None
             capturable = form != "rccl" or nccl              # (gloo, the one-GPU rehearsal's control plane, cannot be captured)
-            body()                                           # warm the launch paths (and the collective's communicator)
-            torch.cuda.synchronize(dev)
-            if capturable:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    body()
+            # A form that cannot be warmed or captured HERE (a collective that refuses stream capture, a mapping that faults) must
+            # cost this node that form, not the job: the attempt is fenced, and the ranks agree on its outcome before anyone times
+            # anything (a rank that went on alone would wait at the barrier below for ever).
+            try:
+                body()                                       # warm the launch paths (and the collective's communicator)
                 torch.cuda.synchronize(dev)
+                if capturable:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        body()
+                    torch.cuda.synchronize(dev)
+            except Exception as e:                           # noqa: BLE001
+                err, graph = f"{type(e).__name__}: {e}"[:300], None
+                try:
+                    torch.cuda.synchronize(dev)
+                except Exception:                            # noqa: BLE001
+                    pass
+            if not _agree(err is None, dev, self.pg):
+                errors[form] = err or "failed on another rank"
+                times[form] = float("inf")
+                restore()
+                continue
             run = graph.replay if graph is not None else body
             reps = max(1, updates // chunk) if graph is not None else max(1, updates // (4 * chunk))
             run()
@@ -528,16 +546,20 @@ class Learner:
             torch.cuda.synchronize(dev)
         t = torch.tensor([times[f] for f in forms], dtype=torch.float64, device=dev if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)       # the slowest rank bounds a lock-step update
-        agreed = {f: round(float(v), 2) for f, v in zip(forms, t.tolist())}
-        best = min(forms, key=lambda f: (agreed[f], forms.index(f)))
+        agreed = {f: (round(float(v), 2) if v != float("inf") else None) for f, v in zip(forms, t.tolist())}
+        usable = [f for f in forms if agreed[f] is not None] or forms[:1]
+        best = min(usable, key=lambda f: (agreed[f] if agreed[f] is not None else 0.0, forms.index(f)))
         timeouts = self.xgmi.status()[1] if self.xgmi is not None else 0
         if timeouts and best != "rccl":                      # a peer-memory form that lost a wait while being timed is not trusted
             best = "rccl"
         self._set_exchange(best)
         self.exchange_autotune = dict(agreed, chosen=best, updates_timed=updates, xgmi_timed_out_waits=int(timeouts))
+        if errors:
+            self.exchange_autotune["errors"] = errors
         if dist.get_rank(self.pg) == 0:
             import sys
-            print("[naf] gradient exchange on this node, us per update: " + ", ".join(f"{f} {agreed[f]:.1f}" for f in forms) +
+            print("[naf] gradient exchange on this node, us per update: " +
+                  ", ".join(f"{f} {agreed[f]:.1f}" if agreed[f] is not None else f"{f} unavailable ({errors.get(f, '?')})" for f in forms) +
                   f" -> {best}", file=sys.stderr, flush=True)
         return self.exchange_autotune
 

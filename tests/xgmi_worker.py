@@ -187,17 +187,29 @@ def main():
     for slot, mode in enumerate(order):                # one-shot peer-memory path, then the gloo reference
         os.environ["NAF_XGMI"] = mode
         want_x = os.environ.get("NAF_DP_EXCHANGE", "auto")
+        fail_form = os.environ.get("NAF_TEST_AUTOTUNE_FAIL") if mode == "1" else None
+        if fail_form == "rccl":
+            # a form that cannot run on this node — here: the collective refuses, on every rank alike, as a collective that cannot
+            # be captured into a graph would — must cost the node that form, not the job
+            def refusing_all_reduce(grad, group=None):
+                raise RuntimeError("injected: this collective cannot run here")
+            learner_mod.all_reduce_flat_grad = refusing_all_reduce
         if mode == "0":
             os.environ.pop("NAF_DP_EXCHANGE", None)        # (the gloo reference has one form)
         L, buf = _kuka_learner_and_replay(5000, 256, seed_data=5 + rank, learner_kw={"world_size": world})
         os.environ["NAF_DP_EXCHANGE"] = want_x
+        learner_mod.all_reduce_flat_grad = host_staged_all_reduce
         assert (L.xgmi is not None) == (mode == "1")
-        if mode == "1" and want_x == "auto":
+        if fail_form == "rccl":
+            at = L.exchange_autotune
+            assert at is not None and at["rccl"] is None and "injected" in at["errors"]["rccl"], at
+            assert at["chosen"] in ("oneshot", "merged") and L.exchange == at["chosen"], at
+        elif mode == "1" and want_x == "auto":
             # Learner.autotune_exchange ran in the constructor: every form timed here, the same verdict on every rank, the
             # learner as if nothing had happened (a twin built without an exchange holds the same bits)
             at = L.exchange_autotune
             assert at is not None and set(at) >= {"oneshot", "rccl", "chosen"} and at["chosen"] == L.exchange, at
-            assert at["xgmi_timed_out_waits"] == 0 and all(at[f] > 0 for f in L.exchange_forms())
+            assert at["xgmi_timed_out_waits"] == 0 and "errors" not in at and all(at[f] > 0 for f in L.exchange_forms())
             mine = torch.tensor([L.exchange_forms().index(at["chosen"])], dtype=torch.int64)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
