@@ -32,6 +32,7 @@ def prefill(agent, rows):
 
 
 FILL = int(os.environ.get("NAF_BENCH_FILL", "100000"))
+DELAY = float(os.environ.get("NAF_BENCH_ENV_DELAY_US", "0")) * 1e-6
 prefill(agent, FILL)
 T = {"act": 0.0, "env.step": 0.0, "agent.step": 0.0}
 def steps(n, timed):
@@ -40,6 +41,9 @@ def steps(n, timed):
     for _ in range(n):
         t0 = pc(); a = agent.act(state)
         t1 = pc(); nxt, r, d = env.step(a)
+        if DELAY:                                        # (a slower environment: NAF_BENCH_ENV_DELAY_US of busy waiting per step)
+            while pc() - t1 < DELAY:
+                pass
         t2 = pc(); agent.step(state, a, r, nxt, d)      # the product's own path: the row is appended by the update's graph
         t3 = pc()
         if timed:

@@ -66,7 +66,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 26
+#define NAF_HIP_ABI_VERSION 27
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -484,10 +484,17 @@ int naf_polyak_update(float* target, const float* main, float tau, float one_min
  *   the draw is naf_replay_sample_indices' (Philox stream position *counter_dev, advanced by one HERE; same indices bit for bit),
  *     taken on the ring as the append leaves it (add, then sample: the reference's order); idx_out (nullable): the B positions;
  *   out_rows [B][out_ld], action_mode: naf_replay_gather_rows' output; mom [2][naf_bb_moments_floats(S)]: naf_bb_moments'
- *     records of the state (net 0) and next-state (net 1) columns, bit for bit. B <= 4096, S <= 32. */
+ *     records of the state (net 0) and next-state (net 1) columns, bit for bit. B <= 4096, S <= 32;
+ *   spec_rec / idx_spec (nullable, device: NAF_STEP_SPEC_INTS int32, 16-byte aligned, zero-initialised by the caller / B int32): the
+ *     record and the indices of a PREFETCH of this timestep's minibatch that the previous timestep's last launch left in out_rows /
+ *     mom (naf_adam_polyak_act with `prefetch`). The record says what that launch assumed — one row to append to the {head, size} it
+ *     found, the stream position — and whether the row to come was among the positions drawn; if all of it holds HERE, this launch
+ *     appends the row, advances the counters, copies idx_spec to idx_out and is done (1 us instead of 10); otherwise — and always
+ *     without a record — it does everything itself. The same minibatch, moments and indices either way. The record is cleared. */
+#define NAF_STEP_SPEC_INTS 12 /* [8], [9]: timesteps that took the prefetched minibatch / that drew for themselves */
 int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed,
                   uint64_t* counter_dev, int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B,
-                  int without_replacement, void* stream);
+                  int without_replacement, int32_t* spec_rec, const int32_t* idx_spec, void* stream);
 /* naf_adam_polyak_act: naf_adam_polyak_fused (clip_grad_norm_ + Adam.step + soft_update, naf_algorithm.py:209-213, :217-226) AND
  * naf_policy_act for ONE state (NAFAgent.act, :158-178: the loop's next `self.act(state)`, :249) in one launch: the workgroups
  * that step a slice of the main network's parameters keep the new values in registers and multiply them with the policy's
@@ -501,7 +508,23 @@ int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, 
  *     this entry point only (one launch in flight per buffer);
  *   host_errors (nullable): pinned host word that counts polls whose 2-ms bound ran out (the action is then NaN: an error);
  *   host_seq (nullable): pinned host uint32 that receives the launch's ordinal (1, 2, ...: the number of calls on `sync`) once
- *     the action has been written — a host that polls it needs no stream synchronisation to read the action. */
+ *     the action has been written — a host that polls it needs no stream synchronisation to read the action;
+ *   prefetch (nullable, HOST pointer): one more workgroup of the launch draws, gathers and takes the moments of the NEXT
+ *     timestep's minibatch — naf_step_prep's arguments of the same names, on the ring as ONE more append will leave it — beside the
+ *     launch's own work and behind the action's announcement to the host (what a timestep draws depends on the row it appends only
+ *     through the fill level, and through the row itself if the draw picks it). Nothing is committed: the ring's counters and
+ *     *counter_dev stay as they are; spec_rec / idx_spec receive the record and the indices the next naf_step_prep checks. */
+typedef struct naf_step_prefetch {
+    naf_replay_t* replay;
+    uint64_t seed;
+    uint64_t* counter_dev;     /* the SAMPLER's stream position (read only) */
+    int32_t* idx_spec;         /* [B] */
+    float* out_rows;           /* [B][out_ld] */
+    int out_ld, action_mode;
+    float* mom;
+    int B, without_replacement;
+    int32_t* spec_rec;         /* NAF_STEP_SPEC_INTS int32 */
+} naf_step_prefetch_t;
 typedef struct naf_act_net {
     int S, A, H, NHP, HP;
     int64_t off_W1, off_b1, off_g1, off_be1, off_W2, off_b2, off_g2, off_be2, off_Wh;
@@ -511,7 +534,7 @@ typedef struct naf_act_net {
 int naf_adam_polyak_act_sync_ints(void);
 int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
                         float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode, int32_t* sync,
-                        uint64_t* host_errors, uint32_t* host_seq, void* stream);
+                        uint64_t* host_errors, uint32_t* host_seq, const naf_step_prefetch_t* prefetch, void* stream);
 
 /* ---- synthetic manipulator environment (stand-in for the PyBullet Environment) ---------------- */
 /* One step of E independent kinematic-chain arms on the device, emitting transition rows

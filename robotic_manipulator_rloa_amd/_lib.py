@@ -221,9 +221,9 @@ _PROTOS = {
     "naf_synth_env_state_floats": [_i],
     "naf_policy_act": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i,
                        _vp, _u64, _vp, _vp, _f, _i, _i, _i, _vp],
-    "naf_step_prep": [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "naf_step_prep": [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
     "naf_adam_polyak_act_sync_ints": [],
-    "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp],
+    "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "naf_xgmi_chunk_floats": [],
     "naf_xgmi_create": [_i, _i, _sz, C.c_double, C.POINTER(_vp)],
     "naf_xgmi_set_timeout": [_vp, C.c_double],
@@ -278,6 +278,13 @@ class ActNet(C.Structure):
                 ("off_b2", C.c_int64), ("off_g2", C.c_int64), ("off_be2", C.c_int64), ("off_Wh", C.c_int64),
                 ("running_mean1", C.c_void_p), ("running_var1", C.c_void_p), ("running_mean2", C.c_void_p),
                 ("running_var2", C.c_void_p), ("eps", C.c_float)]
+
+
+class StepPrefetch(C.Structure):
+    """naf_step_prefetch_t (include/naf_hip.h): the next timestep's minibatch, drawn by one more workgroup of naf_adam_polyak_act"""
+    _fields_ = [("replay", C.c_void_p), ("seed", C.c_uint64), ("counter_dev", C.c_void_p), ("idx_spec", C.c_void_p),
+                ("out_rows", C.c_void_p), ("out_ld", C.c_int), ("action_mode", C.c_int), ("mom", C.c_void_p), ("B", C.c_int),
+                ("without_replacement", C.c_int), ("spec_rec", C.c_void_p)]
 
 
 class GemmBn2Bwd(C.Structure):

@@ -22,10 +22,12 @@
 //                         host sees it and turns the action into NaN (the host raises) — no wave can wait forever.
 #include <string.h>
 #include "common.h"
+#include "../../include/naf_hip.h"
 NAF_TL_DECL(g_tl_sp);
 #ifdef NAF_TIMELINE
-#define BM_MARK(slot) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot)
-#define SB_MARK(slot) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot)
+// (the stand-alone launch only: the same bodies inside adam_act_kernel's prefetching workgroup leave no marks)
+#define BM_MARK(slot) do { if (gridDim.x == 1) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot); } while (0)
+#define SB_MARK(slot) do { if (gridDim.x == 1) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot); } while (0)
 #endif
 #include "act_body.h"
 #include "adam_body.h"
@@ -58,7 +60,15 @@ struct StepPrepArgs {
     int w4, trunc_lo, trunc_hi, off_s2_4;
     float* mom;                // [2][KP + KP * KP]
     int B, without_replacement, hash_bits;
+    // the prefetch of the NEXT timestep's minibatch (see step_prep_body): its record and the positions it drew
+    int32_t* spec_rec;         // nullable: SP_REC_INTS ints
+    int32_t* idx_spec;         // nullable [B]
 };
+// the prefetch's record: what it assumed — the ring as ONE more append leaves the state it found, the sampler's stream position —
+// and whether the minibatch it left in out_rows / mom / idx_spec can stand for the one the next timestep's launch would draw
+// (+ two counters for the host: timesteps that took the prefetched minibatch / that drew for themselves)
+enum { SP_REC_VALID = 0, SP_REC_B, SP_REC_CTR, SP_REC_HEAD = 4, SP_REC_SIZE = 6, SP_REC_TAKEN = 8, SP_REC_DRAWN = 9, SP_REC_INTS = 12 };
+static_assert(SP_REC_INTS == NAF_STEP_SPEC_INTS, "include/naf_hip.h");
 
 // the leading floats of a ring row as the learner sees them: `.long()` of the reference on the action columns
 __device__ __forceinline__ static float4 sp_trunc(float4 v, int f0, int lo, int hi) {
@@ -71,17 +81,28 @@ __device__ __forceinline__ static float4 sp_trunc(float4 v, int f0, int lo, int 
     return v;
 }
 
+// The body of the launch, and of the PREFETCH that adam_act_kernel's extra workgroup runs for the next timestep (SPEC):
+//
+// What a timestep draws depends on the transition it appends in two ways only — the ring's fill level, and the row itself IF the
+// draw picks it (probability B / fill: 0.06 % at B = 64 in a ring of 1e5 rows). So the last launch of timestep t can already
+// draw, gather and take the moments of timestep t + 1's minibatch from the ring "as one more append will leave it", beside its
+// own work and off the host's critical path (the launch announces its action to the host before this workgroup is done, and the
+// host then steps the environment). The prefetch commits nothing — not the ring's counters, not the sampler's stream position
+// — and leaves a record of what it assumed; timestep t + 1's launch checks the record against what it finds (a row to append,
+// the same {head, size}, the same stream position, the new row not among the positions drawn) and, if it holds, appends the row,
+// advances the counters and is done: 1 us instead of 10. If not — the first timestep, an idle tick of a data-parallel run, the new
+// row drawn, the ring touched in between — it does everything itself as before. Either way the minibatch, its moments and the
+// indices are the bits the chunked launches produce: the same bodies on the same state.
+//
 // CACHE: B <= SP_CACHE_ROWS (a kernel of its own: with the choice made at run time every load of the moments' staging sat behind
 // a branch with both forms' code around it, and a cold instruction stream is what these few microseconds are made of)
-template <int K4, bool CACHE>
-__global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArgs P) {
+template <int K4, bool CACHE, bool SPEC>
+__device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, unsigned char* sp_smem, float4* sNew, int* sHit) {
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     BmShared* S = (BmShared*)sp_smem;                                  // [2]: one per net; the draw's table lives here first
     int* sPos = (int*)(sp_smem + 2 * sizeof(BmShared));                // [B]: physical ring rows of the minibatch
     // up to SP_CACHE_ROWS rows the gathered minibatch also stays in LDS, where the moments take it from (behind sPos, 16-B aligned)
     float4* sRows = (float4*)(sp_smem + 2 * sizeof(BmShared) + (size_t)naf_round_up(P.B, 4) * sizeof(int));
-    __shared__ float4 sNew[16];                                        // the appended row (rf4 <= 16 float4)
     // Small batches (the per-timestep shapes): everything the launch leaves in memory is stored in one go at its end, from LDS; the
     // appended row is taken from LDS by whoever draws it. (Tried for speed — on the theory that a store in flight holds up the
     // barriers behind it — and measured neutral: hipcc's workgroup barrier on gfx950 waits for LDS traffic only, s_waitcnt
@@ -90,12 +111,12 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
     int* vals = (int*)sp_smem;
     const int tid = threadIdx.x, B = P.B;
     const int rf4 = 1 << P.rf4_shift;
-    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 0);
+    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 0);
 
     // ---- ReplayBuffer.add: 0 or 1 rows, from (pinned host) memory -------------------------------------------------------
-    int n = 0;
+    int n = SPEC ? 1 : 0;                               // (the prefetch: the ring as the next append will leave it)
     float4 row4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool has_row = P.n_word && P.src_row;
+    const bool has_row = !SPEC && P.n_word && P.src_row;
     if (has_row) {
         // system-scope loads: pinned host memory, or device memory the HOST has stored into (naf_host_publish) — this XCD's L2
         // may hold what the previous launch read there
@@ -110,11 +131,25 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
     }
     const uint64_t head = P.meta[META_HEAD], size = P.meta[META_SIZE], total = P.meta[META_TOTAL];
     const uint64_t ctr = *P.counter;
+    // the prefetch's record, as the previous timestep's last launch left it (a launch boundary ago: plain loads)
+    bool take = false;
+    int ispec[4] = {0, 0, 0, 0};                        // (its indices: requested beside the record, whether they will be wanted or not)
+    if (!SPEC && P.spec_rec) {
+        if (P.idx_out && P.idx_spec) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ispec[k] = P.idx_spec[tid + SP_THREADS * k < B ? tid + SP_THREADS * k : 0];
+        }
+        const int4 ra = ((const int4*)P.spec_rec)[0], rb = ((const int4*)P.spec_rec)[1];
+        const uint64_t r_ctr = (uint64_t)(uint32_t)ra.z | ((uint64_t)(uint32_t)ra.w << 32);
+        const uint64_t r_head = (uint64_t)(uint32_t)rb.x | ((uint64_t)(uint32_t)rb.y << 32);
+        const uint64_t r_size = (uint64_t)(uint32_t)rb.z | ((uint64_t)(uint32_t)rb.w << 32);
+        take = n == 1 && ra.x == 1 && ra.y == B && r_ctr == ctr && r_head == head && r_size == size;      // (uniform)
+    }
     const uint64_t head2 = n ? (head + 1 == P.cap ? 0 : head + 1) : head;
     uint64_t size2 = size + (uint64_t)n;
     size2 = size2 > P.cap ? P.cap : size2;
     const int newpos = n ? (int)head : -1;              // physical row the append fills
-    if (tid < rf4) sNew[tid] = row4;
+    if (!SPEC && tid < rf4) sNew[tid] = row4;
     auto store_row_and_counters = [&]() {
         if (n && tid < rf4) P.ring[(head << P.rf4_shift) + tid] = row4;
         if (P.row_out && has_row && tid < rf4) P.row_out[tid] = row4;
@@ -125,17 +160,34 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
                 P.meta[META_TOTAL] = total + 1ull;
             }
             *P.counter = ctr + 1;
+            if (P.spec_rec) {
+                P.spec_rec[SP_REC_VALID] = 0;                  // (a record serves one timestep)
+                P.spec_rec[take ? SP_REC_TAKEN : SP_REC_DRAWN] += 1;
+            }
         }
     };
-    if (!cache) {
+    if (!SPEC && take) {
+        // the minibatch, its moments and its indices are in place: the append and the counters are all that is left
+        __syncthreads();                                // every thread has read {head, size, counter, record} before thread 0 rewrites them
+        store_row_and_counters();
+        if (P.idx_out && P.idx_spec) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tid + SP_THREADS * k < B) P.idx_out[tid + SP_THREADS * k] = ispec[k];
+        }
+        NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
+        return;
+    }
+    if (SPEC && tid == 0) *sHit = 0;                    // (visible behind the draw's barriers)
+    if (!SPEC && !cache) {
         __syncthreads();                                // every thread has read {head, size, counter} before thread 0 rewrites them
         store_row_and_counters();
     }
-    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 1);
+    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 1);
 
     // ---- random.sample: the chunked sampler's body on the ring as the append leaves it ---------------------------------------
     replay_sample_body(vals, tid, SP_THREADS, size2, ctr, P.seed, B, P.without_replacement, P.hash_bits);
-    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 2);
+    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 2);
     const uint64_t base = head2 + P.cap - size2;        // physical position of deque element 0 (oldest)
     int mypos[4], myidx[4];
 #pragma unroll
@@ -144,12 +196,14 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
         int64_t i = t < B ? (int64_t)vals[t] : 0;
         myidx[k] = (int)i;
         bool bad = i < 0 || (uint64_t)i >= size2;
-        if (bad && t < B) atomicAdd((unsigned long long*)&P.meta[META_BAD_IDX], 1ull);
+        if (!SPEC && bad && t < B) atomicAdd((unsigned long long*)&P.meta[META_BAD_IDX], 1ull);
+        if (SPEC && bad && t < B) *sHit = 1;            // (left to the launch that counts it)
         if (bad) i = 0;
         uint64_t pos = base + (uint64_t)i;
         pos = pos >= P.cap ? pos - P.cap : pos;
         pos = pos >= P.cap ? pos - P.cap : pos;
         mypos[k] = (int)pos;
+        if (SPEC && t < B && mypos[k] == newpos) *sHit = 1;       // the row that does not exist yet
     }
     // (sPos is LDS of its own; the draw's table is dead and becomes the moments' staging area behind the barriers below)
 #pragma unroll
@@ -161,7 +215,11 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
         }
     }
     __syncthreads();                                    // (!cache: the appended row's store has completed too — a workgroup-scope release)
-    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 3);
+    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 3);
+    if (SPEC && *sHit) {                                // (uniform) nothing usable: say so and go
+        if (tid == 0 && P.spec_rec) P.spec_rec[SP_REC_VALID] = 0;
+        return;
+    }
 
     // ---- the minibatch rows: one lane per output float4, SP_RPT in flight ---------------------------------------------------
     const unsigned w4 = (unsigned)P.w4;
@@ -182,7 +240,7 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
         for (int k = 0; k < SP_RPT; ++k) {
             const int j = j0 + SP_THREADS * k;
             if (j < total4) {
-                if (cache && pos[k] == newpos) v[k] = sNew[col[k]];        // (the row this launch appends: not in the ring yet)
+                if (!SPEC && cache && pos[k] == newpos) v[k] = sNew[col[k]];        // (the row this launch appends: not in the ring yet)
                 const float4 t = sp_trunc(v[k], 4 * col[k], P.trunc_lo, P.trunc_hi);
                 if (cache) sRows[j] = t;
                 else P.out_rows[j] = t;
@@ -190,7 +248,7 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
         }
     }
 
-    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 4);
+    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 4);
     // ---- the moments of layer 1's inputs: threads 0 .. 511 the states (net 0), 512 .. 1023 the next states (net 1) ------------
     const int net = tid >> 9;
     const int c0 = net ? P.off_s2_4 : 0;
@@ -211,10 +269,10 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
             return v;
         },
         S[net], tid & (BM_THREADS - 1), P.mom + net * REC, B);
-    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 5);
+    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 5);
     if (cache) {
         // everything this launch leaves in memory, in one go (the moments' records left just above)
-        store_row_and_counters();
+        if (!SPEC) store_row_and_counters();
         for (int j = tid; j < total4; j += SP_THREADS) P.out_rows[j] = sRows[j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -222,23 +280,46 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
             if (t < B && P.idx_out) P.idx_out[t] = myidx[k];
         }
     }
-    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
+    if (SPEC && tid == 0 && P.spec_rec) {
+        // what was assumed: the state this workgroup found, which the next timestep's launch must find unchanged before its append
+        int4 ra, rb;
+        ra.x = 1;
+        ra.y = B;
+        ra.z = (int)(uint32_t)ctr;
+        ra.w = (int)(uint32_t)(ctr >> 32);
+        rb.x = (int)(uint32_t)head;
+        rb.y = (int)(uint32_t)(head >> 32);
+        rb.z = (int)(uint32_t)size;
+        rb.w = (int)(uint32_t)(size >> 32);
+        ((int4*)P.spec_rec)[1] = rb;
+        ((int4*)P.spec_rec)[0] = ra;
+    }
+    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
 }
 
-extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed,
-                             uint64_t* counter_dev, int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B,
-                             int without_replacement, void* stream) {
+template <int K4, bool CACHE>
+__global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArgs P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    __shared__ float4 sNew[16];                                        // the appended row (rf4 <= 16 float4)
+    __shared__ int sHit;
+    step_prep_body<K4, CACHE, false>(P, sp_smem, sNew, &sHit);
+}
+
+// arguments of a launch of step_prep_body, checked; lds = its dynamic LDS
+static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed, uint64_t* counter_dev,
+                    int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B, int without_replacement,
+                    int32_t* spec_rec, int32_t* idx_spec, StepPrepArgs& P, size_t& lds, int& k4) {
     if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
     if (!counter_dev || !out_rows || !mom || B <= 0 || B > 4096 || (((uintptr_t)out_rows | (uintptr_t)mom) & 15) != 0)
         return NAF_ERR_ARG;
     if ((src_row == nullptr) != (n_word == nullptr) || ((uintptr_t)src_row & 15) != 0 || ((uintptr_t)n_word & 3) != 0) return NAF_ERR_ARG;
     if (((uintptr_t)row_out & 15) != 0 || (row_out && !src_row)) return NAF_ERR_ARG;
+    if (((uintptr_t)spec_rec & 15) != 0 || ((uintptr_t)idx_spec & 3) != 0) return NAF_ERR_ARG;
     if (action_mode != NAF_ACTION_TRUNC_INT && action_mode != NAF_ACTION_FLOAT) return NAF_ERR_ARG;
     if ((out_ld & 3) != 0 || out_ld < naf_round_up(naf_row_off_done(h->S, h->A) + 1, 4) || out_ld > h->row_floats) return NAF_ERR_ARG;
-    const int k4 = (h->S + 3) / 4;
+    k4 = (h->S + 3) / 4;
     if (h->row_floats > 64) return NAF_ERR_ARG;          // (the appended row is held in 16 float4 of LDS)
     if (k4 > 8 || out_ld != naf_replay_batch_row_floats(h->S, h->A)) return NAF_ERR_ARG;   // (the row the learner's kernels and the moments expect)
-    StepPrepArgs P;
     P.ring = (float4*)h->rows;
     P.meta = h->meta;
     P.cap = h->capacity;
@@ -261,11 +342,27 @@ extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_
     P.B = B;
     P.without_replacement = without_replacement;
     P.hash_bits = sample_hash_bits(B);
+    P.spec_rec = spec_rec;
+    P.idx_spec = idx_spec;
     size_t draw = sample_lds_ints(B, P.hash_bits) * sizeof(int);
-    size_t lds = 2 * sizeof(BmShared);
+    lds = 2 * sizeof(BmShared);
     if (draw > lds) return NAF_ERR_ARG;                  // (cannot happen for B <= 4096: 81,920 <= 82,176)
     lds += (size_t)naf_round_up(B, 4) * sizeof(int);
-    if (B <= SP_CACHE_ROWS) lds += (size_t)B * out_ld * sizeof(float);       // the minibatch itself (<= 56 KB)
+    if (B <= SP_CACHE_ROWS) lds += (size_t)B * out_ld * sizeof(float);       // the minibatch itself (<= 64 KB)
+    return NAF_OK;
+}
+#define SP_MAX_DYN_LDS (149 * 1024)                      // 82,176 + 1,024 + 65,536 at most; adam_act_kernel's own arrays beside it
+
+extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed,
+                             uint64_t* counter_dev, int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B,
+                             int without_replacement, int32_t* spec_rec, const int32_t* idx_spec, void* stream) {
+    StepPrepArgs P;
+    size_t lds = 0;
+    int k4 = 0;
+    if ((spec_rec == nullptr) != (idx_spec == nullptr) && idx_out) return NAF_ERR_ARG;     // (a record without its indices: only if nobody asks for them)
+    const int rc = sp_build(h, src_row, n_word, row_out, seed, counter_dev, idx_out, out_rows, out_ld, action_mode, mom, B,
+                            without_replacement, spec_rec, (int32_t*)idx_spec, P, lds, k4);
+    if (rc != NAF_OK) return rc;
     static int raised_dev[64];                           // per device: the kernels' dynamic-LDS limit raised once
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -273,7 +370,7 @@ extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_
         const void* ks[4] = {(const void*)step_prep_kernel<6, true>, (const void*)step_prep_kernel<6, false>,
                              (const void*)step_prep_kernel<8, true>, (const void*)step_prep_kernel<8, false>};
         for (const void* k : ks) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_DYN_LDS);
             if (e != hipSuccess) return (int)e;
         }
         raised_dev[dev] = 1;
@@ -404,8 +501,24 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
     if (P.host_errors) __hip_atomic_fetch_add((unsigned long long*)P.host_errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int PMODE>
-__global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs P) {
+// SPEC: one more workgroup — the launch's last, of SP_THREADS threads like all of them then (the others' upper half leaves at once) —
+// prefetches the next timestep's minibatch (step_prep_body above): 0 = none, 1 / 2 = K <= 24 with / without the rows cached in LDS,
+// 3 / 4 = K <= 32. It depends on nothing in this launch and nothing in this launch depends on it.
+template <int PMODE, int SPEC>
+__global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP) {
+    if (SPEC) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+        __shared__ float4 sNewS[16];
+        __shared__ int sHitS;
+        if (blockIdx.x == gridDim.x - 1) {
+            NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 13, true, false);
+            step_prep_body<(SPEC <= 2 ? 6 : 8), (SPEC & 1) != 0, true>(SP, aa_smem, sNewS, &sHitS);
+            NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 14, true, false);
+            return;
+        }
+        if (threadIdx.x >= AA_THREADS) return;          // (whole waves: the barriers below count the waves that are left)
+    }
+#define AA_TL(slot) NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, slot, blockIdx.x == 0, (int)blockIdx.x == (int)gridDim.x - (SPEC ? 2 : 1))
     __shared__ AdamScalars sSc;
     __shared__ __attribute__((aligned(16))) float sAct[AA_H];                 // a1 (layer-2 workgroups) / a2 (the last workgroup)
     __shared__ __attribute__((aligned(16))) float sW[64 * ACT_MAX_S + 3 * 64]; // layer-1 workgroups: their 64 rows of W1, b1, g1, be1
@@ -423,7 +536,7 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
     if (tid == 0) sTimed = 0;
     const int wh_wgs = P.wh_wgs;                        // workgroups that step Wh: ceil(NHP * HP / 4 / AA_THREADS)
     const bool tl_l2 = wg == AA_L1_WGS + wh_wgs;        // (timeline: the first layer-2 workgroup leaves slots 8 ...)
-    NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 0);
+    AA_TL(0);
 
     if (wg < AA_L1_WGS) {
         // ---- layer 1: rows 32 wg .. 32 wg + 31 of W1 and of b1 / g1 / be1 --------------------------------------------------
@@ -451,14 +564,14 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
         const AdamPrefetch pf = adam_prefetch(A, tid);
         adam_derive(A, pf, &sSc, tid);
         __syncthreads();
-        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 1);
+        AA_TL(1);
         const AdamScalars sc = sSc;
         if (tid < items) {
             const aa_f4 nv = aa_apply4(A, sc, o, f4, false);
             *(aa_f4*)(sW + lds) = nv;
         }
         __syncthreads();
-        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 2);
+        AA_TL(2);
         if (tid < R) {
             const int row = row0 + tid;
             float w1[ACT_MAX_S];
@@ -468,7 +581,7 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
                                             sW[R * ACT_MAX_S + 2 * R + tid], rm, rv, P.eps);
             aa_publish(rec1, row, a1, epoch);
         }
-        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 3);
+        AA_TL(3);
         return;
     }
 
@@ -549,7 +662,7 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
             }
         }
         __syncthreads();
-        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 1);
+        AA_TL(1);
         const __amdgpu_buffer_rsrc_t whb = naf_buf(A.theta + P.off_Wh);
         aa_f4 wh[HEAD_MAX_LDH / 8];
         float bias[HEAD_MAX_LDH / 8];
@@ -570,7 +683,7 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
             if (timed) sTimed = 1;
         }
         __syncthreads();
-        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 2);
+        AA_TL(2);
         const bool timed = sTimed != 0;
         const aa_f4 x = *(const aa_f4*)(sAct + 4 * lane);
         float ph[HEAD_MAX_LDH / 8];
@@ -589,9 +702,9 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
             }
         }
         __syncthreads();
-        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 3);
+        AA_TL(3);
         naf_act_noise_body_z<PMODE>(sHeads, sL, P.action_out, zn, P.noise_scale, 0, tid < 8, P.A, tid);
-        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 4);
+        AA_TL(4);
         if (tid < 64) {                                     // (the first wave: it holds the lanes that wrote the action)
             if (tid == 0) {
                 if (timed) aa_count_timeout(P);
@@ -605,13 +718,15 @@ __global__ __launch_bounds__(AA_THREADS) void adam_act_kernel(const AdamActArgs 
                 if (tid == 0) __hip_atomic_store(P.host_seq, (uint32_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        NAF_TL(g_tl_sp, NAF_TL_ADAM_ACT, 5);
+        AA_TL(5);
     }
+#undef AA_TL
 }
 
 extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
                                    float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode,
-                                   int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, void* stream) {
+                                   int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, const naf_step_prefetch_t* prefetch,
+                                   void* stream) {
     if (!adam || !net || !obs || !action_out || !counter_dev || !sync || ((uintptr_t)sync & 15) != 0) return NAF_ERR_ARG;
     AdamActArgs P;
     memset(&P, 0, sizeof(P));
@@ -650,8 +765,50 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     P.host_seq = host_seq;
     P.wh_wgs = (int)(((int64_t)NHP * (HP / 4) + AA_THREADS - 1) / AA_THREADS);
     const int grid = AA_L1_WGS + P.wh_wgs + AA_L2_WGS + 1;
-    if (p_mode == NAF_P_HADAMARD) adam_act_kernel<NAF_P_HADAMARD><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P);
-    else adam_act_kernel<NAF_P_MATMUL><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P);
+    StepPrepArgs SP;
+    memset(&SP, 0, sizeof(SP));
+    if (!prefetch) {
+        if (p_mode == NAF_P_HADAMARD) adam_act_kernel<NAF_P_HADAMARD, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+        else adam_act_kernel<NAF_P_MATMUL, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+        NAF_CHECK_LAUNCH();
+        return NAF_OK;
+    }
+    // with the prefetch of the next timestep's minibatch (step_prep_body<.., SPEC>): the record and the indices are its own, nothing
+    // of the ring or the sampler's stream is committed
+    if (!prefetch->spec_rec || !prefetch->idx_spec) return NAF_ERR_ARG;
+    size_t lds = 0;
+    int k4 = 0;
+    const int rc = sp_build(prefetch->replay, nullptr, nullptr, nullptr, prefetch->seed, prefetch->counter_dev, prefetch->idx_spec,
+                            prefetch->out_rows, prefetch->out_ld, prefetch->action_mode, prefetch->mom, prefetch->B,
+                            prefetch->without_replacement, prefetch->spec_rec, nullptr, SP, lds, k4);
+    if (rc != NAF_OK) return rc;
+    static int raised_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised_dev[dev]) {
+        const void* ks[8] = {(const void*)adam_act_kernel<NAF_P_HADAMARD, 1>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2>,
+                             (const void*)adam_act_kernel<NAF_P_HADAMARD, 3>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4>,
+                             (const void*)adam_act_kernel<NAF_P_MATMUL, 1>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2>,
+                             (const void*)adam_act_kernel<NAF_P_MATMUL, 3>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4>};
+        for (const void* k : ks) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_DYN_LDS);
+            if (e != hipSuccess) return (int)e;
+        }
+        raised_dev[dev] = 1;
+    }
+    const int spec = (k4 <= 6 ? 1 : 3) + (prefetch->B <= SP_CACHE_ROWS ? 0 : 1);
+    const hipStream_t st = (hipStream_t)stream;
+#define AA_LAUNCH(PM, SV) adam_act_kernel<PM, SV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP)
+#define AA_LAUNCH_PM(PM)                \
+    switch (spec) {                     \
+        case 1: AA_LAUNCH(PM, 1); break; \
+        case 2: AA_LAUNCH(PM, 2); break; \
+        case 3: AA_LAUNCH(PM, 3); break; \
+        default: AA_LAUNCH(PM, 4); break; \
+    }
+    if (p_mode == NAF_P_HADAMARD) { AA_LAUNCH_PM(NAF_P_HADAMARD) } else { AA_LAUNCH_PM(NAF_P_MATMUL) }
+#undef AA_LAUNCH_PM
+#undef AA_LAUNCH
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

@@ -132,12 +132,33 @@ class TrainChunk:
             self._publish = learner.lib.naf_host_publish
         # fused tail: the launch writes its ordinal to a pinned host word behind the action (ActPath.seq) — the host learns that
         # a run() has passed by polling that word instead of synchronising an event / the stream
+        # with both fused launches: the last launch of a timestep also draws, gathers and takes the moments of the NEXT timestep's
+        # minibatch (one more workgroup, beside its own work and behind the action's announcement to the host: what a timestep draws
+        # depends on the row it appends only through the fill level — and through the row itself if the draw picks it, which the
+        # record says); the next timestep's first launch then only appends its row (csrc/step_path.hip, step_prep_body).
+        # NAF_STEP_PREFETCH=0: every timestep draws for itself.
+        self.spec_rec = self.idx_spec = self._prefetch = None
+        if self.fused_prep and self.fused_tail and os.environ.get("NAF_STEP_PREFETCH", "1") != "0":
+            self.spec_rec = torch.zeros(12, dtype=torch.int32, device=dev)
+            self.idx_spec = torch.zeros(B, dtype=torch.int32, device=dev)
+            r = replay
+            self._prefetch = _lib.StepPrefetch(r.handle, r.seed, ptr(r._sample_ctr), ptr(self.idx_spec), ptr(self.batch),
+                                               self.batch.shape[-1], r.action_mode, ptr(self.moments), B,
+                                               int(r.without_replacement), ptr(self.spec_rec))
         self._seq_np = actor.seq_np if self.fused_tail else None
         self._seq_prev = 0
         self._inflight = False             # a run() whose ordinal the host has not seen yet
         self._exec = None
         self._err_np = learner.err_host.numpy()
         self._head_count_np = self.head_count.numpy() if self.head_count is not None else None
+
+    def prefetch_stats(self) -> Tuple[int, int]:
+        """(timesteps that took the minibatch the previous timestep's last launch had prefetched, timesteps that drew for
+        themselves) since the chunk was built; (0, 0) without the prefetch. Synchronises."""
+        if self.spec_rec is None:
+            return 0, 0
+        r = self.spec_rec.cpu()
+        return int(r[8]), int(r[9])
 
     def _sample_gather(self) -> None:
         if not self.teacher_forced:
@@ -164,7 +185,8 @@ class TrainChunk:
                               pending=d and k > 0, defer=d and (k < self.U - 1 or self.fused_tail))
         if self.fused_tail:
             # the last update's clip + Adam + Polyak and the tail's act(): one launch
-            self._tail_actor.act_with_optimizer_step(obs_ptr=self._obs_ptr if self.row_dev is not None else None)
+            self._tail_actor.act_with_optimizer_step(obs_ptr=self._obs_ptr if self.row_dev is not None else None,
+                                                     prefetch=self._prefetch)
         elif self.tail is not None:
             self.tail()
 
@@ -176,7 +198,8 @@ class TrainChunk:
                 src, cnt = self.head_dev.data_ptr(), self.head_dev.data_ptr() + 4 * self.L.lay.row_floats
             check(self.L.lib.naf_step_prep(r.handle, src, cnt, ptr(self.row_dev), r.seed,
                                            ptr(r._sample_ctr), ptr(self.idx), ptr(self.batch), self.batch.shape[-1], r.action_mode,
-                                           ptr(self.moments), self.L.B, int(r.without_replacement), stream_ptr()), "naf_step_prep")
+                                           ptr(self.moments), self.L.B, int(r.without_replacement), ptr(self.spec_rec),
+                                           ptr(self.idx_spec), stream_ptr()), "naf_step_prep")
             self._updates(moments_ready=True)
             return
         if self.head_row is not None:
@@ -187,7 +210,9 @@ class TrainChunk:
 
     def capture(self) -> None:
         self.replay.flush()
-        snap = _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts) + self._tail_state)
+        # (the prefetch's record among them: the warm-up's last run leaves a valid one, for a ring that is put back)
+        snap = _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts) + self._tail_state +
+                              ((self.spec_rec,) if self.spec_rec is not None else ()))
         if self.gather_outside_graph:
             self._sample_gather()          # the updates need a valid batch to warm up on
             self.graph = _capture(self._updates, snap)

@@ -920,14 +920,16 @@ class ActPath:
                                     ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "Wh")],
                                     bnp, bnp + 4 * H, bnp + 8 * H, bnp + 12 * H, BN_EPS)
 
-    def act_with_optimizer_step(self, noise_scale: float = 1.0, obs_ptr: Optional[int] = None) -> torch.Tensor:
+    def act_with_optimizer_step(self, noise_scale: float = 1.0, obs_ptr: Optional[int] = None, prefetch=None) -> torch.Tensor:
         """The pending optimizer step of the learner (a learn_rows(defer=True) in front) and act() on the parameters it leaves, in
         one launch. Same parameters as Learner.optimizer_step() and the same action as act() behind it, bit for bit.
-        obs_ptr: where the observation lies instead of self.obs (device-visible, S floats)."""
+        obs_ptr: where the observation lies instead of self.obs (device-visible, S floats). prefetch: a _lib.StepPrefetch — one
+        more workgroup of the launch draws the NEXT timestep's minibatch (engine.TrainChunk)."""
         L = self.L
         check(L.lib.naf_adam_polyak_act(_lib.C.byref(L._adam_args), _lib.C.byref(self._net), obs_ptr or ptr(self.obs), ptr(self.Gh),
                                         ptr(self.actions), self.seed, ptr(self.counter), float(noise_scale), L.p_mode,
-                                        ptr(self.sync), L.err_host.data_ptr() + 8, ptr(self.seq), stream_ptr()), "adam_polyak_act")
+                                        ptr(self.sync), L.err_host.data_ptr() + 8, ptr(self.seq),
+                                        _lib.C.byref(prefetch) if prefetch is not None else None, stream_ptr()), "adam_polyak_act")
         return self.actions
 
     @property

@@ -95,7 +95,7 @@ def test_step_prep_equals_the_launches_it_replaces(lib, S, A, B, cap, n0, append
                 rp, cp = (row_pin.data_ptr(), cnt.data_ptr()) if append is not None else (None, None)
                 _lib.check(lib.naf_step_prep(buf.handle, rp, cp, row_dev.data_ptr() if rp else None, buf.seed,
                                              buf._sample_ctr.data_ptr(), idx.data_ptr(), batch.data_ptr(), brf, buf.action_mode,
-                                             mom.data_ptr(), B, 1, st()), "step_prep")
+                                             mom.data_ptr(), B, 1, None, None, st()), "step_prep")
             torch.cuda.synchronize()
             if which == 1 and append is not None:
                 np.testing.assert_array_equal(row_dev.cpu().numpy(), new_rows[rep])     # the row's device copy, count or no count
@@ -118,10 +118,14 @@ def test_step_prep_refuses_bad_arguments(lib):
     batch, mom = torch.zeros(16 * brf, device="cuda"), torch.zeros(2, mf, device="cuda")
     row = torch.zeros(1, buf.row_floats).pin_memory()
     ok = lambda **kw: lib.naf_step_prep(buf.handle, kw.get("row"), kw.get("cnt"), None, 0, buf._sample_ctr.data_ptr(), idx.data_ptr(),   # noqa: E731
-                                       batch.data_ptr(), kw.get("ld", brf), 0, mom.data_ptr(), kw.get("B", 16), 1, st())
+                                       batch.data_ptr(), kw.get("ld", brf), 0, mom.data_ptr(), kw.get("B", 16), 1, kw.get("rec"), kw.get("ispec"),
+                                       st())
     assert ok() == 0
     assert ok(row=row.data_ptr()) == -1                       # a row without its count word
     assert ok(ld=brf - 4) == -1 and ok(ld=brf + 4) == -1 and ok(B=0) == -1 and ok(B=5000) == -1
+    rec = torch.zeros(12, dtype=torch.int32, device="cuda")
+    assert ok(rec=rec.data_ptr()) == -1                       # a prefetch record without the prefetch's indices
+    assert ok(rec=rec.data_ptr() + 4, ispec=idx.data_ptr()) == -1 and ok(rec=rec.data_ptr(), ispec=idx.data_ptr()) == 0
     torch.cuda.synchronize()
 
 
@@ -203,6 +207,74 @@ def test_adam_polyak_act_skips_a_poisoned_update_and_still_acts(lib):
     np.testing.assert_array_equal(acts[0].actions_np, acts[1].actions_np)
 
 
+PREFETCH_CASES = [
+    # S, A, B, capacity, rows in the ring, counts of the timesteps (1 = brings a row, 0 = an idle tick)
+    (21, 6, 64, 100000, 50000, (1, 1, 1, 1, 1, 1)),         # the steady state: the new row is hardly ever drawn
+    (21, 6, 64, 5000, 70, (1, 1, 1, 1, 1, 1, 1, 1)),         # a young ring: the new row is drawn most of the time
+    (21, 6, 256, 100000, 3000, (1, 1, 0, 1, 1, 0, 0, 1)),    # idle ticks in between: the record assumed an append
+    (23, 7, 64, 512, 512, (1, 1, 1, 1, 1, 1)),               # a full ring: every append evicts the oldest row
+    (21, 6, 512, 100000, 20000, (1, 1, 1, 1)),               # B > 256: the form that gathers through memory
+    (26, 6, 100, 4000, 3990, (1,) * 14),                     # K = 28 (the wide moments record), the ring fills up and wraps
+]
+
+
+@pytest.mark.parametrize("S,A,B,cap,n0,counts", PREFETCH_CASES)
+def test_prefetched_minibatch_is_the_one_the_timestep_would_draw(lib, S, A, B, cap, n0, counts):
+    """naf_adam_polyak_act's prefetching workgroup + the naf_step_prep that checks its record == naf_step_prep alone, timestep by
+    timestep: ring, {head, size, total}, sampler counter, indices, minibatch rows and both moments records bit for bit — whether the
+    record held (the launch only appended) or not (an idle tick, the new row among the positions drawn, the first timestep)."""
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.learner import ActPath
+    from synth_data import make_transitions
+    bufs = [_filled_buffer(cap, B, S, A, n0, seed=11) for _ in range(2)]
+    brf, mf, rf = bufs[0].batch_row_floats, lib.naf_bb_moments_floats(S), bufs[0].row_floats
+    s_, ac, rw, ns, dn = make_transitions(len(counts), S, A, seed=78)
+    new_rows = O.pack_rows(s_, ac, rw, ns, dn, rf)
+    L = _two_learners(S, A, 64, seed=3)[0]
+    act = ActPath(L, 1, seed=9, host_io=True)
+    _lib.check(lib.naf_grad_norm_partials(L.grad.data_ptr(), L.lay.P, L.partials.data_ptr(), L.step_dev.data_ptr(), st()), "norm")
+    L._adam_args.n_partials = L.n_partials_norm
+    state = []
+    for buf in bufs:
+        buf._sample_ctr.fill_(17)
+        state.append(dict(idx=torch.full((B,), -1, dtype=torch.int32, device="cuda"), batch=torch.zeros(B * brf + 64, device="cuda"),
+                          mom=torch.zeros(2, mf, device="cuda"), row_dev=torch.zeros(rf, device="cuda")))
+    rec = torch.zeros(12, dtype=torch.int32, device="cuda")
+    idx_spec = torch.zeros(B, dtype=torch.int32, device="cuda")
+    b1, s1 = bufs[1], state[1]
+    pf = _lib.StepPrefetch(b1.handle, b1.seed, b1._sample_ctr.data_ptr(), idx_spec.data_ptr(), s1["batch"].data_ptr(), brf,
+                           b1.action_mode, s1["mom"].data_ptr(), B, 1, rec.data_ptr())
+    row_pin = torch.zeros(1, rf).pin_memory()
+    cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+    for t, c in enumerate(counts):
+        row_pin.copy_(torch.from_numpy(new_rows[t:t + 1]))
+        cnt[0] = c
+        for which, (buf, s) in enumerate(zip(bufs, state)):
+            _lib.check(lib.naf_step_prep(buf.handle, row_pin.data_ptr(), cnt.data_ptr(), s["row_dev"].data_ptr(), buf.seed,
+                                         buf._sample_ctr.data_ptr(), s["idx"].data_ptr(), s["batch"].data_ptr(), brf, buf.action_mode,
+                                         s["mom"].data_ptr(), B, 1, rec.data_ptr() if which else None,
+                                         idx_spec.data_ptr() if which else None, st()), "step_prep")
+        torch.cuda.synchronize()
+        for name in ("idx", "batch", "mom", "row_dev"):
+            assert torch.equal(state[0][name], state[1][name]), (name, t)
+        assert torch.equal(bufs[0].rows, bufs[1].rows) and torch.equal(bufs[0].meta, bufs[1].meta), t
+        assert int(bufs[0]._sample_ctr.item()) == int(bufs[1]._sample_ctr.item()) == 18 + t
+        assert int(rec[0].item()) == 0                         # a record serves one timestep
+        # the launch that ends the timestep: the optimizer step, act() and the prefetch for timestep t + 1
+        act.obs_np[0] = new_rows[t][b1.off_s2:b1.off_s2 + S]
+        act.act_with_optimizer_step(1.0, prefetch=pf)
+        torch.cuda.synchronize()
+        assert act.act_timeouts == 0 and int(bufs[1]._sample_ctr.item()) == 18 + t      # nothing committed
+        assert torch.equal(bufs[0].meta, bufs[1].meta)
+    taken, drawn = int(rec[8].item()), int(rec[9].item())
+    assert taken + drawn == len(counts) and drawn >= 1 + sum(1 for c in counts[1:] if c == 0)
+    if n0 >= 20000:
+        assert taken == sum(1 for c in counts[1:] if c == 1)   # (B / fill < 2 %: no draw met the new row with these seeds)
+    if (cap, n0) == (5000, 70):
+        assert drawn >= 3                                      # (B / fill = 0.9: the new row is among the positions most of the time)
+
+
+
 def _drive(agent, env_seed, warm, steps, record):
     """the reference's loop body (naf_algorithm.py:249-262) on a scripted stream of transitions; returns the actions taken"""
     from synth_data import make_transitions
@@ -235,24 +307,34 @@ def test_per_timestep_path_is_the_separate_launches_and_the_chunked_path_bit_for
     S, A, N, T = 21, 6, 5000, 150
     warm = B                                                  # the gate: len(memory) > batch_size (naf_algorithm.py:150) opens at step B
     runs = []
-    for fused in ("1", "0"):
+    for fused, prefetch in (("1", "1"), ("0", "1"), ("1", "0")):
         monkeypatch.setenv("NAF_STEP_FUSED", fused)
+        monkeypatch.setenv("NAF_STEP_PREFETCH", prefetch)      # (the next timestep's minibatch drawn by the last launch, or not)
         agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
         theta0 = agent.learner.theta2.clone()
         idx = [] if fused == "1" else None
         acts = _drive(agent, 21, warm, T, idx)
         ch = agent._chunk
         assert ch.fused_prep == ch.fused_tail == (fused == "1") and ch.head_row is not None and (agent._fast is not None)
+        assert (ch.spec_rec is not None) == (fused == "1" and prefetch == "1")
+        if ch.spec_rec is not None:
+            taken, drawn = ch.prefetch_stats()
+            # the ring holds B + 1 ... B + T rows: the new row is among the B positions drawn about as often as not — both ways
+            # of a timestep are in this run
+            assert taken + drawn in (T - 1, T) and taken >= 5 and drawn >= 5, (taken, drawn)
         L = agent.learner
         runs.append(dict(acts=acts, theta=L.theta2.clone(), m=L.adam_m.clone(), v=L.adam_v.clone(), bn=L.bn_stats.clone(),
                          ring=agent.memory.rows.clone(), meta=agent.memory.meta.clone(), step=int(L.step_dev.item()),
                          loss=agent.last_loss(), idx=idx, theta0=theta0))
-    a, b = runs
-    assert a["step"] == b["step"] == T
-    np.testing.assert_array_equal(a["acts"], b["acts"])
-    for k in ("theta", "m", "v", "bn", "ring", "meta"):
-        assert torch.equal(a[k], b[k]), k
-    assert a["loss"] == b["loss"] and torch.isfinite(a["theta"]).all()
+    a = runs[0]
+    for b in runs[1:]:
+        assert a["step"] == b["step"] == T
+        np.testing.assert_array_equal(a["acts"], b["acts"])
+        for k in ("theta", "m", "v", "bn", "ring", "meta"):
+            assert torch.equal(a[k], b[k]), k
+        assert a["loss"] == b["loss"] and torch.isfinite(a["theta"]).all()
+    for i, j in zip(runs[0]["idx"], runs[2]["idx"]):
+        np.testing.assert_array_equal(i, j)                    # (the indices a reader finds in chunk.idx: the timestep's own)
     assert not torch.equal(a["theta"], a["theta0"])
     # (b) the chunked path on the same minibatches: positions are stable while the ring only grows (no eviction here)
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
