@@ -485,6 +485,12 @@ def extras(dev, args):
             launches = 7 if (ch is not None and ch.fused_prep and ch.fused_tail) else 12
             out = {"value": round(n_api / dt, 1), "unit": "timesteps/s", "timesteps": n_api, "batch": batch, "ring": "1e5 rows, full",
                    "launches_per_timestep": launches, "optimizer_steps": int(agent.learner.step_dev.item())}
+            if ch is not None and getattr(ch, "pipelined", False):
+                # the pipelined form: naf_adam_polyak_act (append, the waiting gradient's step, act(), prefetch) + the chain on the
+                # prefetched minibatch = 6 launches; a timestep whose prefetch did not hold starts over with the 12-launch graph
+                runs = max(1, ch.fast_runs + ch.slow_runs)
+                out["launches_per_timestep"] = round((6 * ch.fast_runs + 12 * ch.slow_runs) / runs, 2)
+                out["pipelined"] = {"timesteps_on_the_prefetched_minibatch": ch.fast_runs, "timesteps_that_started_over": ch.slow_runs}
             del agent
             return out
         n_api = 3000

@@ -73,4 +73,8 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(2000):
     ch.run()          # head_rows = 0: the graph's append node finds a zero row count and appends nothing
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"  chunk (flush-less) back to back: {dt/2000*1e6:.1f} us per update incl. the riding act()")
+if getattr(ch, "pipelined", False):
+    print(f"  the start-over graph (draw + chain + act + prefetch + chain: 12 launches, TWO chains) back to back: {dt/2000*1e6:.1f} us; "
+          f"timesteps above: {ch.fast_runs} on the prefetched minibatch (6 launches), {ch.slow_runs - 2000} started over")
+else:
+    print(f"  chunk (flush-less) back to back: {dt/2000*1e6:.1f} us per update incl. the riding act()")

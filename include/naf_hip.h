@@ -66,7 +66,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 27
+#define NAF_HIP_ABI_VERSION 28
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -492,9 +492,18 @@ int naf_polyak_update(float* target, const float* main, float tau, float one_min
  *     appends the row, advances the counters, copies idx_spec to idx_out and is done (1 us instead of 10); otherwise — and always
  *     without a record — it does everything itself. The same minibatch, moments and indices either way. The record is cleared. */
 #define NAF_STEP_SPEC_INTS 12 /* [8], [9]: timesteps that took the prefetched minibatch / that drew for themselves */
+/*   copies (nullable, HOST pointer): up to three ranges of 4-byte words (<= 2048 each) copied src -> dst by the launch before anything
+ *     else — the pipelined form of the path keeps a WORKING copy of what a learn() chain changes besides the gradient (BatchNorm
+ *     running statistics, optimizer step count, loss partials) next to the public one; a launch that starts a timestep over resets
+ *     working from public here, naf_adam_polyak_act commits working to public (its `prefetch->copies`). */
+typedef struct naf_step_copies {
+    const void* src[3];
+    void* dst[3];
+    int n_words[3];            /* 0: unused */
+} naf_step_copies_t;
 int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed,
                   uint64_t* counter_dev, int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B,
-                  int without_replacement, int32_t* spec_rec, const int32_t* idx_spec, void* stream);
+                  int without_replacement, int32_t* spec_rec, const int32_t* idx_spec, const naf_step_copies_t* copies, void* stream);
 /* naf_adam_polyak_act: naf_adam_polyak_fused (clip_grad_norm_ + Adam.step + soft_update, naf_algorithm.py:209-213, :217-226) AND
  * naf_policy_act for ONE state (NAFAgent.act, :158-178: the loop's next `self.act(state)`, :249) in one launch: the workgroups
  * that step a slice of the main network's parameters keep the new values in registers and multiply them with the policy's
@@ -512,18 +521,34 @@ int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, 
  *   prefetch (nullable, HOST pointer): one more workgroup of the launch draws, gathers and takes the moments of the NEXT
  *     timestep's minibatch — naf_step_prep's arguments of the same names, on the ring as ONE more append will leave it — beside the
  *     launch's own work and behind the action's announcement to the host (what a timestep draws depends on the row it appends only
- *     through the fill level, and through the row itself if the draw picks it). Nothing is committed: the ring's counters and
- *     *counter_dev stay as they are; spec_rec / idx_spec receive the record and the indices the next naf_step_prep checks. */
+ *     through the fill level, and through the row itself if the draw picks it). mode 1: nothing is committed — the ring's counters
+ *     and *counter_dev stay as they are; spec_rec / idx_spec receive the record and the indices the next naf_step_prep checks.
+ *     mode 2 (the PIPELINED timestep: this launch is the first of its graph, the learn() chain on the prefetched minibatch follows
+ *     it and computes the NEXT update's gradient while the host steps the environment): the workgroup first does what naf_step_prep
+ *     does when the record holds — reads [src_row | n_word], appends, advances the counters, hands idx_spec to idx_out — and then
+ *     prefetches on the ring as it has become. The host launches this form only after it has read `valid` from host_spec; a
+ *     record that does not hold here is counted in *pipe_errors (pinned host; the caller raises). host_spec (nullable, pinned host
+ *     uint32[2]): [1] = whether the prefetch holds (the row to come was not among the positions drawn), then [0] = the launch's
+ *     ordinal (as host_seq). copies: committed working -> public state, see naf_step_copies_t.
+ *   obs_system_scope: obs lies in device memory the host stored into (naf_host_publish): read with system-scope loads. */
 typedef struct naf_step_prefetch {
     naf_replay_t* replay;
     uint64_t seed;
-    uint64_t* counter_dev;     /* the SAMPLER's stream position (read only) */
+    uint64_t* counter_dev;     /* the SAMPLER's stream position (mode 1: read only) */
     int32_t* idx_spec;         /* [B] */
     float* out_rows;           /* [B][out_ld] */
     int out_ld, action_mode;
     float* mom;
     int B, without_replacement;
     int32_t* spec_rec;         /* NAF_STEP_SPEC_INTS int32 */
+    int mode;                  /* 1: prefetch only; 2: this timestep's append, then the prefetch */
+    const float* src_row;      /* mode 2 */
+    const int32_t* n_word;     /* mode 2 */
+    float* row_out;            /* mode 2, nullable */
+    int32_t* idx_out;          /* mode 2, nullable [B] */
+    uint32_t* host_spec;       /* nullable */
+    uint64_t* pipe_errors;     /* nullable */
+    naf_step_copies_t copies;
 } naf_step_prefetch_t;
 typedef struct naf_act_net {
     int S, A, H, NHP, HP;
@@ -534,7 +559,8 @@ typedef struct naf_act_net {
 int naf_adam_polyak_act_sync_ints(void);
 int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
                         float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode, int32_t* sync,
-                        uint64_t* host_errors, uint32_t* host_seq, const naf_step_prefetch_t* prefetch, void* stream);
+                        uint64_t* host_errors, uint32_t* host_seq, const naf_step_prefetch_t* prefetch, int obs_system_scope,
+                        void* stream);
 
 /* ---- synthetic manipulator environment (stand-in for the PyBullet Environment) ---------------- */
 /* One step of E independent kinematic-chain arms on the device, emitting transition rows

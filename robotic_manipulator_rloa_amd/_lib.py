@@ -221,9 +221,9 @@ _PROTOS = {
     "naf_synth_env_state_floats": [_i],
     "naf_policy_act": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i,
                        _vp, _u64, _vp, _vp, _f, _i, _i, _i, _vp],
-    "naf_step_prep": [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
+    "naf_step_prep": [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "naf_adam_polyak_act_sync_ints": [],
-    "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "naf_xgmi_chunk_floats": [],
     "naf_xgmi_create": [_i, _i, _sz, C.c_double, C.POINTER(_vp)],
     "naf_xgmi_set_timeout": [_vp, C.c_double],
@@ -280,11 +280,25 @@ class ActNet(C.Structure):
                 ("running_var2", C.c_void_p), ("eps", C.c_float)]
 
 
+class StepCopies(C.Structure):
+    """naf_step_copies_t (include/naf_hip.h): up to three word ranges a step launch copies before anything else"""
+    _fields_ = [("src", C.c_void_p * 3), ("dst", C.c_void_p * 3), ("n_words", C.c_int * 3)]
+
+    @classmethod
+    def of(cls, *triples):
+        c = cls()
+        for i, (src, dst, n) in enumerate(triples):
+            c.src[i], c.dst[i], c.n_words[i] = src, dst, int(n)
+        return c
+
+
 class StepPrefetch(C.Structure):
     """naf_step_prefetch_t (include/naf_hip.h): the next timestep's minibatch, drawn by one more workgroup of naf_adam_polyak_act"""
     _fields_ = [("replay", C.c_void_p), ("seed", C.c_uint64), ("counter_dev", C.c_void_p), ("idx_spec", C.c_void_p),
                 ("out_rows", C.c_void_p), ("out_ld", C.c_int), ("action_mode", C.c_int), ("mom", C.c_void_p), ("B", C.c_int),
-                ("without_replacement", C.c_int), ("spec_rec", C.c_void_p)]
+                ("without_replacement", C.c_int), ("spec_rec", C.c_void_p), ("mode", C.c_int), ("src_row", C.c_void_p),
+                ("n_word", C.c_void_p), ("row_out", C.c_void_p), ("idx_out", C.c_void_p), ("host_spec", C.c_void_p),
+                ("pipe_errors", C.c_void_p), ("copies", StepCopies)]
 
 
 class GemmBn2Bwd(C.Structure):

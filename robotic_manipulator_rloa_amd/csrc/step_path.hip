@@ -63,7 +63,14 @@ struct StepPrepArgs {
     // the prefetch of the NEXT timestep's minibatch (see step_prep_body): its record and the positions it drew
     int32_t* spec_rec;         // nullable: SP_REC_INTS ints
     int32_t* idx_spec;         // nullable [B]
+    // the pipelined form (step_prep_body, MODE 2) and the learner's working / public state (`copies`)
+    uint32_t* host_spec;       // nullable pinned host words {ordinal, valid}: the prefetch's verdict where the host reads it
+    uint64_t* pipe_errors;     // nullable pinned host word: MODE 2 launches whose record did not hold (a host-side logic error)
+    const unsigned* cp_src[3];
+    unsigned* cp_dst[3];
+    int cp_n[3];
 };
+#define SP_COPY_WPT 2          // words per thread and copy: ranges of up to 2048 words
 // the prefetch's record: what it assumed — the ring as ONE more append leaves the state it found, the sampler's stream position —
 // and whether the minibatch it left in out_rows / mom / idx_spec can stand for the one the next timestep's launch would draw
 // (+ two counters for the host: timesteps that took the prefetched minibatch / that drew for themselves)
@@ -96,8 +103,20 @@ __device__ __forceinline__ static float4 sp_trunc(float4 v, int f0, int lo, int 
 //
 // CACHE: B <= SP_CACHE_ROWS (a kernel of its own: with the choice made at run time every load of the moments' staging sat behind
 // a branch with both forms' code around it, and a cold instruction stream is what these few microseconds are made of)
-template <int K4, bool CACHE, bool SPEC>
-__device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, unsigned char* sp_smem, float4* sNew, int* sHit) {
+// MODE 0: the timestep's own launch (append, then draw — or take what the prefetch left).
+// MODE 1: the prefetch alone (SPEC): the ring as ONE more append will leave it; commits nothing.
+// MODE 2: the timestep's append AND the prefetch for the next one in the same workgroup — the PIPELINED form of the path
+//         (engine.TrainChunk): the host has read the previous prefetch's verdict and launches a graph that starts with
+//         adam_act_kernel; this workgroup appends the row (its minibatch is in place, and so is the gradient the chain has taken
+//         from it while the host stepped the environment), hands the prefetched indices over, and prefetches again. It checks the
+//         record all the same: a mismatch here is a host-side logic error and is counted where the host raises.
+// `copies`: up to three word ranges copied at the start (MODE 0: public -> working state of the learner, the reset that discards
+// what a chain run on a prefetch that did not hold has left; MODE 1 / 2: working -> public, the commit of the update the launch's
+// other workgroups apply). 4-byte words, ranges that no other workgroup of the launch writes.
+template <int K4, bool CACHE, int MODE>
+__device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, unsigned char* sp_smem, float4* sNew, int* sHit, int epoch) {
+    constexpr bool SPEC = MODE != 0;                    // the draw is for the NEXT timestep
+    constexpr bool APPEND = MODE != 1;                  // reads [row | count] and appends for THIS timestep
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
     BmShared* S = (BmShared*)sp_smem;                                  // [2]: one per net; the draw's table lives here first
     int* sPos = (int*)(sp_smem + 2 * sizeof(BmShared));                // [B]: physical ring rows of the minibatch
@@ -114,9 +133,9 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
     if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 0);
 
     // ---- ReplayBuffer.add: 0 or 1 rows, from (pinned host) memory -------------------------------------------------------
-    int n = SPEC ? 1 : 0;                               // (the prefetch: the ring as the next append will leave it)
+    int n = 0;
     float4 row4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool has_row = !SPEC && P.n_word && P.src_row;
+    const bool has_row = APPEND && P.n_word && P.src_row;
     if (has_row) {
         // system-scope loads: pinned host memory, or device memory the HOST has stored into (naf_host_publish) — this XCD's L2
         // may hold what the previous launch read there
@@ -129,12 +148,21 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
                                __builtin_bit_cast(float, r3));
         }
     }
-    const uint64_t head = P.meta[META_HEAD], size = P.meta[META_SIZE], total = P.meta[META_TOTAL];
-    const uint64_t ctr = *P.counter;
+    uint64_t head = P.meta[META_HEAD], size = P.meta[META_SIZE], total = P.meta[META_TOTAL];
+    uint64_t ctr = *P.counter;
+    // (the copies' words: requested with everything else)
+    unsigned cpw[3][SP_COPY_WPT];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < SP_COPY_WPT; ++k) {
+            const int w = tid + SP_THREADS * k;
+            cpw[c][k] = (P.cp_src[c] && w < P.cp_n[c]) ? P.cp_src[c][w] : 0u;
+        }
     // the prefetch's record, as the previous timestep's last launch left it (a launch boundary ago: plain loads)
     bool take = false;
     int ispec[4] = {0, 0, 0, 0};                        // (its indices: requested beside the record, whether they will be wanted or not)
-    if (!SPEC && P.spec_rec) {
+    if (APPEND && P.spec_rec) {
         if (P.idx_out && P.idx_spec) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ispec[k] = P.idx_spec[tid + SP_THREADS * k < B ? tid + SP_THREADS * k : 0];
@@ -145,11 +173,18 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
         const uint64_t r_size = (uint64_t)(uint32_t)rb.z | ((uint64_t)(uint32_t)rb.w << 32);
         take = n == 1 && ra.x == 1 && ra.y == B && r_ctr == ctr && r_head == head && r_size == size;      // (uniform)
     }
-    const uint64_t head2 = n ? (head + 1 == P.cap ? 0 : head + 1) : head;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < SP_COPY_WPT; ++k) {
+            const int w = tid + SP_THREADS * k;
+            if (P.cp_dst[c] && w < P.cp_n[c]) P.cp_dst[c][w] = cpw[c][k];
+        }
+    uint64_t head2 = n ? (head + 1 == P.cap ? 0 : head + 1) : head;
     uint64_t size2 = size + (uint64_t)n;
     size2 = size2 > P.cap ? P.cap : size2;
-    const int newpos = n ? (int)head : -1;              // physical row the append fills
-    if (!SPEC && tid < rf4) sNew[tid] = row4;
+    int newpos = n ? (int)head : -1;                    // physical row the append fills
+    if (APPEND && tid < rf4) sNew[tid] = row4;
     auto store_row_and_counters = [&]() {
         if (n && tid < rf4) P.ring[(head << P.rf4_shift) + tid] = row4;
         if (P.row_out && has_row && tid < rf4) P.row_out[tid] = row4;
@@ -166,8 +201,10 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
             }
         }
     };
-    if (!SPEC && take) {
+    if (APPEND && (take || MODE == 2)) {
         // the minibatch, its moments and its indices are in place: the append and the counters are all that is left
+        if (MODE == 2 && !take && tid == 0 && P.pipe_errors)
+            __hip_atomic_fetch_add((unsigned long long*)P.pipe_errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();                                // every thread has read {head, size, counter, record} before thread 0 rewrites them
         store_row_and_counters();
         if (P.idx_out && P.idx_spec) {
@@ -175,10 +212,25 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
             for (int k = 0; k < 4; ++k)
                 if (tid + SP_THREADS * k < B) P.idx_out[tid + SP_THREADS * k] = ispec[k];
         }
-        NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
-        return;
+        if (MODE == 0) {
+            NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
+            return;
+        }
+        // ... and on to the next timestep's minibatch, on the ring as it now is (the stores above have landed before the first of the
+        // draw's barriers lets anyone read the row back: the gather may well draw it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        head = head2;
+        size = size2;
+        total += (uint64_t)n;
+        ctr += 1;
     }
-    if (SPEC && tid == 0) *sHit = 0;                    // (visible behind the draw's barriers)
+    if (SPEC) {
+        n = 1;                                          // the ring as the next append will leave it
+        head2 = head + 1 == P.cap ? 0 : head + 1;
+        size2 = size + 1 > P.cap ? P.cap : size + 1;
+        newpos = (int)head;
+        if (tid == 0) *sHit = 0;                        // (visible behind the draw's barriers)
+    }
     if (!SPEC && !cache) {
         __syncthreads();                                // every thread has read {head, size, counter} before thread 0 rewrites them
         store_row_and_counters();
@@ -206,18 +258,30 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
         if (SPEC && t < B && mypos[k] == newpos) *sHit = 1;       // the row that does not exist yet
     }
     // (sPos is LDS of its own; the draw's table is dead and becomes the moments' staging area behind the barriers below)
+    int32_t* const idx_dst = SPEC ? P.idx_spec : P.idx_out;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int t = tid + SP_THREADS * k;
         if (t < B) {
             sPos[t] = mypos[k];
-            if (!cache && P.idx_out) P.idx_out[t] = myidx[k];
+            if (!cache && idx_dst) idx_dst[t] = myidx[k];
         }
     }
     __syncthreads();                                    // (!cache: the appended row's store has completed too — a workgroup-scope release)
     if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 3);
+    // the verdict for the host (pinned words, system scope: [1] = does the prefetch hold, then [0] = this launch's ordinal)
+    auto tell_host = [&](int valid) {
+        if (P.host_spec) {
+            __hip_atomic_store(P.host_spec + 1, (uint32_t)valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(P.host_spec, (uint32_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
     if (SPEC && *sHit) {                                // (uniform) nothing usable: say so and go
-        if (tid == 0 && P.spec_rec) P.spec_rec[SP_REC_VALID] = 0;
+        if (tid == 0) {
+            if (P.spec_rec) P.spec_rec[SP_REC_VALID] = 0;
+            tell_host(0);
+        }
         return;
     }
 
@@ -277,22 +341,26 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int t = tid + SP_THREADS * k;
-            if (t < B && P.idx_out) P.idx_out[t] = myidx[k];
+            if (t < B && idx_dst) idx_dst[t] = myidx[k];
         }
     }
-    if (SPEC && tid == 0 && P.spec_rec) {
-        // what was assumed: the state this workgroup found, which the next timestep's launch must find unchanged before its append
-        int4 ra, rb;
-        ra.x = 1;
-        ra.y = B;
-        ra.z = (int)(uint32_t)ctr;
-        ra.w = (int)(uint32_t)(ctr >> 32);
-        rb.x = (int)(uint32_t)head;
-        rb.y = (int)(uint32_t)(head >> 32);
-        rb.z = (int)(uint32_t)size;
-        rb.w = (int)(uint32_t)(size >> 32);
-        ((int4*)P.spec_rec)[1] = rb;
-        ((int4*)P.spec_rec)[0] = ra;
+    if (SPEC && tid == 0) {
+        if (P.spec_rec) {
+            // what was assumed: the state this workgroup found (MODE 2: left), which the next timestep's launch must find unchanged
+            // before its append
+            int4 ra, rb;
+            ra.x = 1;
+            ra.y = B;
+            ra.z = (int)(uint32_t)ctr;
+            ra.w = (int)(uint32_t)(ctr >> 32);
+            rb.x = (int)(uint32_t)head;
+            rb.y = (int)(uint32_t)(head >> 32);
+            rb.z = (int)(uint32_t)size;
+            rb.w = (int)(uint32_t)(size >> 32);
+            ((int4*)P.spec_rec)[1] = rb;
+            ((int4*)P.spec_rec)[0] = ra;
+        }
+        tell_host(1);
     }
     if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
 }
@@ -302,13 +370,14 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     __shared__ float4 sNew[16];                                        // the appended row (rf4 <= 16 float4)
     __shared__ int sHit;
-    step_prep_body<K4, CACHE, false>(P, sp_smem, sNew, &sHit);
+    step_prep_body<K4, CACHE, 0>(P, sp_smem, sNew, &sHit, 0);
 }
 
 // arguments of a launch of step_prep_body, checked; lds = its dynamic LDS
 static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed, uint64_t* counter_dev,
                     int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B, int without_replacement,
-                    int32_t* spec_rec, int32_t* idx_spec, StepPrepArgs& P, size_t& lds, int& k4) {
+                    int32_t* spec_rec, int32_t* idx_spec, const naf_step_copies_t* copies, uint32_t* host_spec, uint64_t* pipe_errors,
+                    StepPrepArgs& P, size_t& lds, int& k4) {
     if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
     if (!counter_dev || !out_rows || !mom || B <= 0 || B > 4096 || (((uintptr_t)out_rows | (uintptr_t)mom) & 15) != 0)
         return NAF_ERR_ARG;
@@ -344,6 +413,21 @@ static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word
     P.hash_bits = sample_hash_bits(B);
     P.spec_rec = spec_rec;
     P.idx_spec = idx_spec;
+    P.host_spec = host_spec;
+    P.pipe_errors = pipe_errors;
+    for (int c = 0; c < 3; ++c) {
+        P.cp_src[c] = nullptr;
+        P.cp_dst[c] = nullptr;
+        P.cp_n[c] = 0;
+        if (copies && copies->n_words[c] > 0) {
+            if (!copies->src[c] || !copies->dst[c] || copies->n_words[c] > SP_COPY_WPT * SP_THREADS ||
+                (((uintptr_t)copies->src[c] | (uintptr_t)copies->dst[c]) & 3) != 0)
+                return NAF_ERR_ARG;
+            P.cp_src[c] = (const unsigned*)copies->src[c];
+            P.cp_dst[c] = (unsigned*)copies->dst[c];
+            P.cp_n[c] = copies->n_words[c];
+        }
+    }
     size_t draw = sample_lds_ints(B, P.hash_bits) * sizeof(int);
     lds = 2 * sizeof(BmShared);
     if (draw > lds) return NAF_ERR_ARG;                  // (cannot happen for B <= 4096: 81,920 <= 82,176)
@@ -355,13 +439,14 @@ static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word
 
 extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed,
                              uint64_t* counter_dev, int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B,
-                             int without_replacement, int32_t* spec_rec, const int32_t* idx_spec, void* stream) {
+                             int without_replacement, int32_t* spec_rec, const int32_t* idx_spec, const naf_step_copies_t* copies,
+                             void* stream) {
     StepPrepArgs P;
     size_t lds = 0;
     int k4 = 0;
     if ((spec_rec == nullptr) != (idx_spec == nullptr) && idx_out) return NAF_ERR_ARG;     // (a record without its indices: only if nobody asks for them)
     const int rc = sp_build(h, src_row, n_word, row_out, seed, counter_dev, idx_out, out_rows, out_ld, action_mode, mom, B,
-                            without_replacement, spec_rec, (int32_t*)idx_spec, P, lds, k4);
+                            without_replacement, spec_rec, (int32_t*)idx_spec, copies, nullptr, nullptr, P, lds, k4);
     if (rc != NAF_OK) return rc;
     static int raised_dev[64];                           // per device: the kernels' dynamic-LDS limit raised once
     int dev = 0;
@@ -401,6 +486,7 @@ struct AdamActArgs {
     int64_t off_W1, off_b1, off_g1, off_be1, off_W2, off_b2, off_g2, off_be2, off_Wh;   // floats, inside the flat buffers
     int S, NH, NHP, HP, A;
     const float* obs;                     // [S] (pinned host or device)
+    int obs_sys;                          // the observation lies in device memory the HOST stored into: system-scope loads
     const float *rm1, *rv1, *rm2, *rv2;   // BatchNorm running statistics of the main net
     float eps;
     float* heads_out;                     // nullable [NH]
@@ -503,7 +589,8 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
 
 // SPEC: one more workgroup — the launch's last, of SP_THREADS threads like all of them then (the others' upper half leaves at once) —
 // prefetches the next timestep's minibatch (step_prep_body above): 0 = none, 1 / 2 = K <= 24 with / without the rows cached in LDS,
-// 3 / 4 = K <= 32. It depends on nothing in this launch and nothing in this launch depends on it.
+// 3 / 4 = K <= 32; 5 .. 8 = the same four with this timestep's append in front (MODE 2). It depends on nothing in this launch and
+// nothing in this launch depends on it.
 template <int PMODE, int SPEC>
 __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP) {
     if (SPEC) {
@@ -512,7 +599,8 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         __shared__ int sHitS;
         if (blockIdx.x == gridDim.x - 1) {
             NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 13, true, false);
-            step_prep_body<(SPEC <= 2 ? 6 : 8), (SPEC & 1) != 0, true>(SP, aa_smem, sNewS, &sHitS);
+            step_prep_body<(((SPEC - 1) & 3) < 2 ? 6 : 8), ((SPEC - 1) & 1) == 0, (SPEC <= 4 ? 1 : 2)>(
+                SP, aa_smem, sNewS, &sHitS, (int)((unsigned)P.sync[0] + 1u));
             NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 14, true, false);
             return;
         }
@@ -543,7 +631,14 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         constexpr int R = AA_L1_ROWS;
         const int S = P.S, row0 = R * wg;
         const int nW4 = R * S / 4, items = nW4 + 3 * R / 4;   // float4 of this workgroup's slice (R S floats start 16-byte aligned)
-        if (tid < ACT_MAX_S) sObs[tid] = tid < S ? P.obs[tid] : 0.f;
+        if (tid < ACT_MAX_S) {
+            float o = 0.f;
+            if (tid < S) {
+                if (P.obs_sys) o = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(naf_buf(P.obs), 4u * (unsigned)tid, 0, 17));
+                else o = P.obs[tid];
+            }
+            sObs[tid] = o;
+        }
         // this thread's float4 of the flat buffers, and where its new value goes in LDS
         int lds;
         int64_t f4;
@@ -726,7 +821,7 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
 extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
                                    float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode,
                                    int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, const naf_step_prefetch_t* prefetch,
-                                   void* stream) {
+                                   int obs_system_scope, void* stream) {
     if (!adam || !net || !obs || !action_out || !counter_dev || !sync || ((uintptr_t)sync & 15) != 0) return NAF_ERR_ARG;
     AdamActArgs P;
     memset(&P, 0, sizeof(P));
@@ -753,6 +848,7 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     P.off_be2 = o[7]; P.off_Wh = o[8];
     P.S = S; P.NH = NH; P.NHP = NHP; P.HP = HP; P.A = A;
     P.obs = obs;
+    P.obs_sys = obs_system_scope ? 1 : 0;
     P.rm1 = net->running_mean1; P.rv1 = net->running_var1; P.rm2 = net->running_mean2; P.rv2 = net->running_var2;
     P.eps = net->eps;
     P.heads_out = heads_out;
@@ -775,28 +871,37 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     }
     // with the prefetch of the next timestep's minibatch (step_prep_body<.., SPEC>): the record and the indices are its own, nothing
     // of the ring or the sampler's stream is committed
-    if (!prefetch->spec_rec || !prefetch->idx_spec) return NAF_ERR_ARG;
+    if (!prefetch->spec_rec || !prefetch->idx_spec || (prefetch->mode != 1 && prefetch->mode != 2)) return NAF_ERR_ARG;
+    if (prefetch->mode == 2 && (!prefetch->src_row || !prefetch->n_word)) return NAF_ERR_ARG;
     size_t lds = 0;
     int k4 = 0;
-    const int rc = sp_build(prefetch->replay, nullptr, nullptr, nullptr, prefetch->seed, prefetch->counter_dev, prefetch->idx_spec,
+    const bool app = prefetch->mode == 2;
+    const int rc = sp_build(prefetch->replay, app ? prefetch->src_row : nullptr, app ? prefetch->n_word : nullptr,
+                            app ? prefetch->row_out : nullptr, prefetch->seed, prefetch->counter_dev, app ? prefetch->idx_out : nullptr,
                             prefetch->out_rows, prefetch->out_ld, prefetch->action_mode, prefetch->mom, prefetch->B,
-                            prefetch->without_replacement, prefetch->spec_rec, nullptr, SP, lds, k4);
+                            prefetch->without_replacement, prefetch->spec_rec, prefetch->idx_spec, &prefetch->copies,
+                            prefetch->host_spec, prefetch->pipe_errors, SP, lds, k4);
     if (rc != NAF_OK) return rc;
     static int raised_dev[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!raised_dev[dev]) {
-        const void* ks[8] = {(const void*)adam_act_kernel<NAF_P_HADAMARD, 1>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2>,
-                             (const void*)adam_act_kernel<NAF_P_HADAMARD, 3>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4>,
-                             (const void*)adam_act_kernel<NAF_P_MATMUL, 1>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2>,
-                             (const void*)adam_act_kernel<NAF_P_MATMUL, 3>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4>};
+        const void* ks[16] = {
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 1>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 3>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 5>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 6>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 7>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 8>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 1>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 3>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 5>, (const void*)adam_act_kernel<NAF_P_MATMUL, 6>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 7>, (const void*)adam_act_kernel<NAF_P_MATMUL, 8>};
         for (const void* k : ks) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_DYN_LDS);
             if (e != hipSuccess) return (int)e;
         }
         raised_dev[dev] = 1;
     }
-    const int spec = (k4 <= 6 ? 1 : 3) + (prefetch->B <= SP_CACHE_ROWS ? 0 : 1);
+    const int spec = (k4 <= 6 ? 1 : 3) + (prefetch->B <= SP_CACHE_ROWS ? 0 : 1) + (app ? 4 : 0);
     const hipStream_t st = (hipStream_t)stream;
 #define AA_LAUNCH(PM, SV) adam_act_kernel<PM, SV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP)
 #define AA_LAUNCH_PM(PM)                \
@@ -804,7 +909,11 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
         case 1: AA_LAUNCH(PM, 1); break; \
         case 2: AA_LAUNCH(PM, 2); break; \
         case 3: AA_LAUNCH(PM, 3); break; \
-        default: AA_LAUNCH(PM, 4); break; \
+        case 4: AA_LAUNCH(PM, 4); break; \
+        case 5: AA_LAUNCH(PM, 5); break; \
+        case 6: AA_LAUNCH(PM, 6); break; \
+        case 7: AA_LAUNCH(PM, 7); break; \
+        default: AA_LAUNCH(PM, 8); break; \
     }
     if (p_mode == NAF_P_HADAMARD) { AA_LAUNCH_PM(NAF_P_HADAMARD) } else { AA_LAUNCH_PM(NAF_P_MATMUL) }
 #undef AA_LAUNCH_PM

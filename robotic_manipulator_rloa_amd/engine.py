@@ -144,7 +144,24 @@ class TrainChunk:
             r = replay
             self._prefetch = _lib.StepPrefetch(r.handle, r.seed, ptr(r._sample_ctr), ptr(self.idx_spec), ptr(self.batch),
                                                self.batch.shape[-1], r.action_mode, ptr(self.moments), B,
-                                               int(r.without_replacement), ptr(self.spec_rec))
+                                               int(r.without_replacement), ptr(self.spec_rec), 1)
+        # ... and PIPELINED (one GPU, graphs): with the minibatch of timestep t + 1 in place before its transition exists, its whole
+        # learn() chain can run before it too — the gradient depends on the parameters update t leaves and on that minibatch, not
+        # on the new row. A timestep's graph is then [naf_adam_polyak_act: append the row, apply the gradient that is waiting, act(),
+        # prefetch] -> [the chain on the prefetched minibatch], and what the host waits for is the first launch: the chain runs
+        # while it steps the environment. The chain works on copies of the state it advances besides the gradient (BatchNorm
+        # running statistics, step count, loss partials); the first launch of the next graph commits them with the update, so the
+        # learner's public buffers are exactly "after update t" between graphs. If the prefetch does not hold (the host reads the
+        # verdict from pinned memory before it launches) the other graph runs: reset the working copies, draw, chain, and from
+        # there as above. NAF_STEP_PIPELINE=0: the prefetch only. (_init_pipeline, at capture time.)
+        self.pipelined = (self._prefetch is not None and head_row is not None and self.head_dev is not None and use_graph and
+                          learner.world_size == 1 and learner.fold_norm and not learner._force_allreduce and
+                          os.environ.get("NAF_STEP_PIPELINE", "1") != "0")
+        self.graph_fast = None
+        self._exec_fast = None
+        self._spec_armed = False           # the last launch was one of the pipelined graphs: a verdict on its prefetch will come
+        self._r_gen = self._l_gen = self._r_total = -1
+        self.fast_runs = self.slow_runs = 0
         self._seq_np = actor.seq_np if self.fused_tail else None
         self._seq_prev = 0
         self._inflight = False             # a run() whose ordinal the host has not seen yet
@@ -190,7 +207,66 @@ class TrainChunk:
         elif self.tail is not None:
             self.tail()
 
+    def _init_pipeline(self) -> None:
+        """working copies, argument structures and the verdict word of the pipelined graphs (at capture time: the public tensors'
+        addresses are final by then)"""
+        L, r, a = self.L, self.replay, self._tail_actor
+        H, rf, B = L.lay.H, L.lay.row_floats, L.B
+        self.bn_work = L.bn_stats.clone()
+        self.step_work = L.step_dev.clone()
+        self.loss_work = torch.zeros_like(self.loss_parts[0])
+        self.host_spec = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._host_spec_np = self.host_spec.numpy()
+        bw = self.bn_work.data_ptr()
+        self._net_work = _lib.ActNet.from_buffer_copy(a._net)
+        self._net_work.running_mean1, self._net_work.running_var1 = bw, bw + 4 * H
+        self._net_work.running_mean2, self._net_work.running_var2 = bw + 8 * H, bw + 12 * H
+        self._adam_work = _lib.AdamArgs.from_buffer_copy(L._adam_args)
+        self._adam_work.step_dev = self.step_work.data_ptr()
+        commit = _lib.StepCopies.of((bw, L.bn_stats.data_ptr(), 8 * H),
+                                    (self.loss_work.data_ptr(), self.loss_parts.data_ptr(), self.loss_work.numel()),
+                                    (self.step_work.data_ptr(), L.step_dev.data_ptr(), 1))
+        self._reset = _lib.StepCopies.of((L.bn_stats.data_ptr(), bw, 8 * H), (L.step_dev.data_ptr(), self.step_work.data_ptr(), 1))
+        rowp = self.head_dev.data_ptr()
+        common = (r.handle, r.seed, ptr(r._sample_ctr), ptr(self.idx_spec), ptr(self.batch), self.batch.shape[-1], r.action_mode,
+                  ptr(self.moments), B, int(r.without_replacement), ptr(self.spec_rec))
+        errp = L.err_host.data_ptr() + 16
+        self._pf_fast = _lib.StepPrefetch(*common, 2, rowp, rowp + 4 * rf, ptr(self.row_dev), ptr(self.idx), ptr(self.host_spec),
+                                          errp, commit)
+        self._pf_slow = _lib.StepPrefetch(*common, 1, None, None, None, None, ptr(self.host_spec), errp, commit)
+
+    def _chain_on_working_state(self) -> None:
+        L = self.L
+        L.bn_live, L.step_live = self.bn_work, self.step_work
+        try:
+            L.learn_rows(self.batch[0], self.loss_work, self.moments[0], pending=False, defer=True)
+        finally:
+            L.bn_live, L.step_live = L.bn_stats, L.step_dev
+
+    def _body_fast(self) -> None:
+        """the prefetch held: append + apply the waiting gradient + act() + prefetch in ONE launch, then the chain for the next
+        update (six launches; the host waits for the first)"""
+        self._tail_actor.act_with_optimizer_step(obs_ptr=self.head_dev.data_ptr() + 4 * self.L.lay.off_s2, prefetch=self._pf_fast,
+                                                 obs_system_scope=True, adam_args=self._adam_work, net=self._net_work)
+        self._chain_on_working_state()
+
+    def _body_slow(self) -> None:
+        """it did not (or nothing was prefetched): reset the working state, draw, chain — and from there as the other graph"""
+        r = self.replay
+        src = self.head_dev.data_ptr()
+        check(self.L.lib.naf_step_prep(r.handle, src, src + 4 * self.L.lay.row_floats, ptr(self.row_dev), r.seed,
+                                       ptr(r._sample_ctr), ptr(self.idx), ptr(self.batch), self.batch.shape[-1], r.action_mode,
+                                       ptr(self.moments), self.L.B, int(r.without_replacement), ptr(self.spec_rec),
+                                       ptr(self.idx_spec), _lib.C.byref(self._reset), stream_ptr()), "naf_step_prep")
+        self._chain_on_working_state()
+        self._tail_actor.act_with_optimizer_step(obs_ptr=self._obs_ptr, prefetch=self._pf_slow, adam_args=self._adam_work,
+                                                 net=self._net_work)
+        self._chain_on_working_state()
+
     def _body(self) -> None:
+        if self.pipelined:
+            self._body_slow()
+            return
         if self.fused_prep:
             r = self.replay
             src, cnt = ptr(self.head_row), ptr(self.head_count)
@@ -199,7 +275,7 @@ class TrainChunk:
             check(self.L.lib.naf_step_prep(r.handle, src, cnt, ptr(self.row_dev), r.seed,
                                            ptr(r._sample_ctr), ptr(self.idx), ptr(self.batch), self.batch.shape[-1], r.action_mode,
                                            ptr(self.moments), self.L.B, int(r.without_replacement), ptr(self.spec_rec),
-                                           ptr(self.idx_spec), stream_ptr()), "naf_step_prep")
+                                           ptr(self.idx_spec), None, stream_ptr()), "naf_step_prep")
             self._updates(moments_ready=True)
             return
         if self.head_row is not None:
@@ -210,9 +286,12 @@ class TrainChunk:
 
     def capture(self) -> None:
         self.replay.flush()
+        if self.pipelined:
+            self._init_pipeline()
         # (the prefetch's record among them: the warm-up's last run leaves a valid one, for a ring that is put back)
         snap = _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts) + self._tail_state +
-                              ((self.spec_rec,) if self.spec_rec is not None else ()))
+                              ((self.spec_rec,) if self.spec_rec is not None else ()) +
+                              ((self.bn_work, self.step_work, self.loss_work) if self.pipelined else ()))
         if self.gather_outside_graph:
             self._sample_gather()          # the updates need a valid batch to warm up on
             self.graph = _capture(self._updates, snap)
@@ -232,6 +311,11 @@ class TrainChunk:
                 self.replay.rows[pos] = saved
                 self.head_count[0] = count
             self.graph = _capture(self._body, snap, warmup=warmup, after_warmup=put_back)
+            if self.pipelined:
+                # (its kernels are warm — the other graph's are the same but for a template argument of the first — and a run of it
+                #  needs a prefetch that holds: captured without one)
+                self.graph_fast = _capture(self._body_fast, snap, warmup=0)
+                self._spec_armed = False
         else:
             self.graph = _capture(self._body, snap)
         self._raw_exec()
@@ -243,8 +327,10 @@ class TrainChunk:
         if self.graph is not None and self.head_dev is not None and hasattr(self.graph, "raw_cuda_graph_exec"):
             try:
                 self._exec = int(self.graph.raw_cuda_graph_exec())
+                if self.graph_fast is not None:
+                    self._exec_fast = int(self.graph_fast.raw_cuda_graph_exec())
             except Exception:                      # (a torch build that keeps the handle to itself)
-                self._exec = None
+                self._exec = self._exec_fast = None
 
     def wait_pinned_free(self) -> None:
         """Block until the last run() has passed: what it reads from pinned host memory (the head row, its count, a tail's
@@ -272,6 +358,9 @@ class TrainChunk:
                 if sq[0] == prev:
                     raise _lib.NafHipError("the update graph finished without its tail launch writing an action")
         self._inflight = False
+        if self._err_np[2]:
+            raise _lib.NafHipError("the pipelined timestep found its prefetched minibatch not to hold although the host had read that "
+                                   "it does (engine.TrainChunk._holds): the update is not valid")
         if self._err_np[1]:
             raise _lib.NafHipError(f"naf_adam_polyak_act: {int(self.L.err_host[1])} polls inside the launch ran into their 2-ms bound "
                                    "(the GPU is over-subscribed or a workgroup died): the action is not valid")
@@ -299,7 +388,10 @@ class TrainChunk:
         if self.use_graph:
             if self.gather_outside_graph:
                 self._sample_gather()
-            self.graph.replay()
+            if self.pipelined and self._holds(bool(head_rows)):
+                self.graph_fast.replay()
+            else:
+                self.graph.replay()
         else:
             self._body()
         if self._seq_np is not None:
@@ -314,17 +406,44 @@ class TrainChunk:
         exists, the previous run has passed, the pinned row is filled)."""
         self._head_count_np[0] = 1
         self._seq_prev = int(self._seq_np[0])
+        fast = self.pipelined and self._holds(True)
         if self._exec is not None:
             # the row into device memory and the graph's launch in ONE foreign call (torch's replay() is that launch plus
             # device guards and generator bookkeeping this graph does not need)
-            rc = self._launch(self._head_dst, self._head_src, self._head_bytes, self._exec, torch.cuda.current_stream().cuda_stream)
+            rc = self._launch(self._head_dst, self._head_src, self._head_bytes, self._exec_fast if fast else self._exec,
+                              torch.cuda.current_stream().cuda_stream)
             if rc:
                 check(rc, "naf_host_publish_launch")
         else:
             if self.head_dev is not None:
                 self._publish(self._head_dst, self._head_src, self._head_bytes)
-            self.graph.replay()
+            (self.graph_fast if fast else self.graph).replay()
         self._inflight = True
+
+    def _holds(self, brings_row: bool) -> bool:
+        """Pipelined chunk, about to launch: may this timestep run the graph that starts with the append and the waiting gradient?
+        Yes if it brings a row, the last launch was one of this chunk's graphs whose prefetch says it holds (pinned words its extra
+        workgroup wrote a few microseconds behind the action; _seq_prev is that launch's ordinal: the caller has seen its action),
+        and nobody has touched the ring, the sampler's stream or the learner in between (their call counters). Also does the
+        bookkeeping for the launch that follows."""
+        r, L = self.replay, self.L
+        ok = False
+        if brings_row and self._spec_armed and r._gen == self._r_gen and L._gen == self._l_gen and \
+                r._total_added == self._r_total + 1 and r._pending == 0:
+            hs, want, n = self._host_spec_np, self._seq_prev, 0
+            while hs[0] != want:
+                n += 1
+                if n > 2000000:                 # (the verdict is a few microseconds behind the action: something is wrong)
+                    torch.cuda.current_stream().synchronize()
+                    break
+            ok = hs[0] == want and hs[1] == 1
+        self._spec_armed = True
+        self._r_gen, self._l_gen, self._r_total = r._gen, L._gen, r._total_added
+        if ok:
+            self.fast_runs += 1
+        else:
+            self.slow_runs += 1
+        return ok
 
     def losses(self) -> torch.Tensor:
         """[U] MSE losses of the last run (device tensor; summing the per-workgroup parts in index order)."""

@@ -245,7 +245,13 @@ class Learner:
         self.bn_stats = torch.zeros(2, 4, H, **f32)
         self.bn_stats[:, 1].fill_(1.0)
         self.bn_stats[:, 3].fill_(1.0)
+        # what the row-split chain reads and advances: the public buffers themselves — except while a pipelined per-timestep chunk
+        # (engine.TrainChunk) captures its graphs, whose chains work on copies of their own that the chunk's last launch commits
+        self.bn_live = self.bn_stats
+        self._gen = 0              # bumped by every method that changes parameters, optimizer state, statistics or the gradient
+                                   # when CALLED (graph replays do not count): a pipelined chunk's pending gradient is void then
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # optimizer steps taken
+        self.step_live = self.step_dev
         ft_tx = self.lib.naf_fused_tile_cols()
         ft_blocks = (H + ft_tx - 1) // ft_tx                               # workgroups of the column-tile kernels
         gb_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32) + ((H + 31) // 32) ** 2   # dWh + dW2 blocks of the bundle
@@ -575,6 +581,7 @@ class Learner:
         return {"bn1.running_mean": s[0], "bn1.running_var": s[1], "bn2.running_mean": s[2], "bn2.running_var": s[3]}
 
     def load_params(self, net: int, sd: Dict[str, torch.Tensor]) -> None:
+        self._gen += 1
         views = self.lay.param_views(self.theta2[net])
         with torch.no_grad():
             for k, v in views.items():
@@ -584,6 +591,7 @@ class Learner:
                     v.copy_(torch.as_tensor(sd[k]).to(self.dev, torch.float32))
 
     def reset_optimizer(self) -> None:
+        self._gen += 1
         self.adam_m.zero_()
         self.adam_v.zero_()
         self.step_dev.zero_()
@@ -630,6 +638,7 @@ class Learner:
         t2p = self.theta2.data_ptr()
         bnp = self.bn_stats.data_ptr()
         if "bb" in self.fuse:
+            bnp = self.bn_live.data_ptr()      # (the row-split chain's statistics: bn_stats itself unless a pipelined chunk says otherwise)
             ld = rows.stride(0)
             if moments is None:      # a minibatch that came without its moments (learn_rows called directly): one launch more
                 self.moments(rows, self.bb_mom)
@@ -691,6 +700,7 @@ class Learner:
         optimizer step (clip + Adam + Polyak) to the NEXT learn_rows call, which must then say pending = True and whose
         first two launches carry it — one launch less per update. Between the two calls the parameter buffers still hold
         the values from before this update; the chain ends with a call that does not defer."""
+        self._gen += 1
         if (pending or defer) and not self.defer_ok:
             raise ValueError("learn_rows: a deferred optimizer step needs the row-split chain with the gradient norm left by the "
                              "producers or by the one-shot all-reduce (Learner.defer_ok)")
@@ -736,7 +746,7 @@ class Learner:
         lay, B, st = self.lay, self.B, stream_ptr()
         seg, P, H, HP, NHP = lay.seg, lay.P, lay.H, lay.HP, lay.NHP
         f = self._f
-        t2p, gp, bnp = self.theta2.data_ptr(), self.grad.data_ptr(), self.bn_stats.data_ptr()
+        t2p, gp, bnp = self.theta2.data_ptr(), self.grad.data_ptr(), self.bn_live.data_ptr()
         rp, ld = rows.data_ptr(), rows.stride(0)
         self._pushed_lo = self._pushed_also = None
         self.forward_train(rows, moments=moments, adam_pending=pending)
@@ -772,7 +782,7 @@ class Learner:
             ptr(self._mom), ptr(self.bb_wc), t2p + 4 * seg["g1"].offset, ptr(self.save_invstd[0, 0]),
             gp + 4 * seg["W1"].offset, gp + 4 * seg["g1"].offset, gp + 4 * seg["be1"].offset, gp + 4 * seg["b1"].offset,
             gp + 4 * seg["b2"].offset, gp + 4 * seg["g2"].offset, gp + 4 * seg["be2"].offset,
-            ptr(self.partials) if norm_here else None, ptr(self.step_dev) if norm_here else None, B, H,
+            ptr(self.partials) if norm_here else None, ptr(self.step_live) if norm_here else None, B, H,
             self._bb_segs, self._bb_nsegs, ptr(self.bb_fold_flag), push, gp if push is not None else None, P if merged else 0, st),
             "bb_layer1_bwd_finish")
 
@@ -847,6 +857,7 @@ class Learner:
     def optimizer_step(self, norm_ready: Optional[bool] = None) -> None:
         """clip_grad_norm_(params, 1) + Adam.step() + soft_update on the flat buffers: 2 launches (1 when the
         producers of the gradient already left its sum-of-squares partials)."""
+        self._gen += 1
         st, P = stream_ptr(), self.lay.P
         f = self._f
         if norm_ready is None:
@@ -860,6 +871,7 @@ class Learner:
 
     def soft_update(self) -> None:
         """Standalone NAFAgent.soft_update(main, target) (naf_algorithm.py:217-226) over the flat buffers."""
+        self._gen += 1
         check(self._f.naf_polyak_update(ptr(self.theta2[1]), ptr(self.theta2[0]), self.tau, float(1.0 - self.tau),
                                         self.lay.P, stream_ptr()), "polyak")
 
@@ -920,16 +932,21 @@ class ActPath:
                                     ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "Wh")],
                                     bnp, bnp + 4 * H, bnp + 8 * H, bnp + 12 * H, BN_EPS)
 
-    def act_with_optimizer_step(self, noise_scale: float = 1.0, obs_ptr: Optional[int] = None, prefetch=None) -> torch.Tensor:
+    def act_with_optimizer_step(self, noise_scale: float = 1.0, obs_ptr: Optional[int] = None, prefetch=None,
+                                obs_system_scope: bool = False, adam_args=None, net=None) -> torch.Tensor:
         """The pending optimizer step of the learner (a learn_rows(defer=True) in front) and act() on the parameters it leaves, in
         one launch. Same parameters as Learner.optimizer_step() and the same action as act() behind it, bit for bit.
         obs_ptr: where the observation lies instead of self.obs (device-visible, S floats). prefetch: a _lib.StepPrefetch — one
-        more workgroup of the launch draws the NEXT timestep's minibatch (engine.TrainChunk)."""
+        more workgroup of the launch draws the NEXT timestep's minibatch (engine.TrainChunk). obs_system_scope: the observation
+        lies in device memory the host stores into. adam_args / net: the structures to pass instead of the learner's / this path's
+        own (the pipelined chunk's: optimizer step count and BatchNorm statistics of its working state)."""
         L = self.L
-        check(L.lib.naf_adam_polyak_act(_lib.C.byref(L._adam_args), _lib.C.byref(self._net), obs_ptr or ptr(self.obs), ptr(self.Gh),
+        check(L.lib.naf_adam_polyak_act(_lib.C.byref(adam_args if adam_args is not None else L._adam_args),
+                                        _lib.C.byref(net if net is not None else self._net), obs_ptr or ptr(self.obs), ptr(self.Gh),
                                         ptr(self.actions), self.seed, ptr(self.counter), float(noise_scale), L.p_mode,
                                         ptr(self.sync), L.err_host.data_ptr() + 8, ptr(self.seq),
-                                        _lib.C.byref(prefetch) if prefetch is not None else None, stream_ptr()), "adam_polyak_act")
+                                        _lib.C.byref(prefetch) if prefetch is not None else None, int(bool(obs_system_scope)),
+                                        stream_ptr()), "adam_polyak_act")
         return self.actions
 
     @property

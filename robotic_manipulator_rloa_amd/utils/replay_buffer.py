@@ -40,6 +40,8 @@ class ReplayBuffer:
         self._handle = None
         self._total_added = 0      # host mirror of the device counters (adds are host-initiated: always known)
         self._pending = 0
+        self._gen = 0              # bumped by everything here that changes the ring or the sampler's stream position (a pipelined
+                                   # per-timestep chunk, engine.TrainChunk, trusts its prefetch only while this stands still)
         self.S = self.A = None
         if state_size is not None and action_size is not None:
             self._allocate(int(state_size), int(action_size))
@@ -85,6 +87,7 @@ class ReplayBuffer:
     def add(self, state, action, reward: float, next_state, done: int) -> None:
         """Append one experience (replay_buffer.py:32-45). Staged in pinned host memory; reaches the HBM ring at the
         next flush() (sample() and the agent's update path flush first), so FIFO order and eviction are exact."""
+        self._gen += 1
         if self._handle is None:
             self._allocate(int(np.asarray(state).shape[-1]), int(np.asarray(action).shape[-1]))
         S, A = self.S, self.A
@@ -103,6 +106,7 @@ class ReplayBuffer:
         n = self._pending
         if n == 0:
             return
+        self._gen += 1
         cur = self._stage_cur
         host, dev = self._stage_hosts[cur], self._stage_devs[cur]
         if n <= _DIRECT_ROWS:
@@ -122,6 +126,7 @@ class ReplayBuffer:
 
     def add_rows_device(self, rows_dev: torch.Tensor, n: int, _count: bool = True) -> None:
         """Append n packed transition rows that already live on the device (vector-env path)."""
+        self._gen += 1
         if self._handle is None:
             raise _lib.NafHipError("allocate the ReplayBuffer with state_size/action_size before add_rows_device")
         if n > self.buffer_size:
@@ -132,6 +137,7 @@ class ReplayBuffer:
 
     # ---- sample -----------------------------------------------------------------------------------------------
     def sample_indices(self, idx_out: torch.Tensor, n_batches: int = 1) -> None:
+        self._gen += 1
         if self.batch_size > 4096:
             # beyond one workgroup's LDS: the duplicate check's table in device memory (csrc/replay.hip, replay_sample_big_kernel)
             per = self.lib.naf_replay_sample_scratch_ints(self.batch_size)

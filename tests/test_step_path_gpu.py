@@ -95,7 +95,7 @@ def test_step_prep_equals_the_launches_it_replaces(lib, S, A, B, cap, n0, append
                 rp, cp = (row_pin.data_ptr(), cnt.data_ptr()) if append is not None else (None, None)
                 _lib.check(lib.naf_step_prep(buf.handle, rp, cp, row_dev.data_ptr() if rp else None, buf.seed,
                                              buf._sample_ctr.data_ptr(), idx.data_ptr(), batch.data_ptr(), brf, buf.action_mode,
-                                             mom.data_ptr(), B, 1, None, None, st()), "step_prep")
+                                             mom.data_ptr(), B, 1, None, None, None, st()), "step_prep")
             torch.cuda.synchronize()
             if which == 1 and append is not None:
                 np.testing.assert_array_equal(row_dev.cpu().numpy(), new_rows[rep])     # the row's device copy, count or no count
@@ -119,7 +119,7 @@ def test_step_prep_refuses_bad_arguments(lib):
     row = torch.zeros(1, buf.row_floats).pin_memory()
     ok = lambda **kw: lib.naf_step_prep(buf.handle, kw.get("row"), kw.get("cnt"), None, 0, buf._sample_ctr.data_ptr(), idx.data_ptr(),   # noqa: E731
                                        batch.data_ptr(), kw.get("ld", brf), 0, mom.data_ptr(), kw.get("B", 16), 1, kw.get("rec"), kw.get("ispec"),
-                                       st())
+                                       None, st())
     assert ok() == 0
     assert ok(row=row.data_ptr()) == -1                       # a row without its count word
     assert ok(ld=brf - 4) == -1 and ok(ld=brf + 4) == -1 and ok(B=0) == -1 and ok(B=5000) == -1
@@ -243,7 +243,7 @@ def test_prefetched_minibatch_is_the_one_the_timestep_would_draw(lib, S, A, B, c
     idx_spec = torch.zeros(B, dtype=torch.int32, device="cuda")
     b1, s1 = bufs[1], state[1]
     pf = _lib.StepPrefetch(b1.handle, b1.seed, b1._sample_ctr.data_ptr(), idx_spec.data_ptr(), s1["batch"].data_ptr(), brf,
-                           b1.action_mode, s1["mom"].data_ptr(), B, 1, rec.data_ptr())
+                           b1.action_mode, s1["mom"].data_ptr(), B, 1, rec.data_ptr(), 1)
     row_pin = torch.zeros(1, rf).pin_memory()
     cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
     for t, c in enumerate(counts):
@@ -253,7 +253,7 @@ def test_prefetched_minibatch_is_the_one_the_timestep_would_draw(lib, S, A, B, c
             _lib.check(lib.naf_step_prep(buf.handle, row_pin.data_ptr(), cnt.data_ptr(), s["row_dev"].data_ptr(), buf.seed,
                                          buf._sample_ctr.data_ptr(), s["idx"].data_ptr(), s["batch"].data_ptr(), brf, buf.action_mode,
                                          s["mom"].data_ptr(), B, 1, rec.data_ptr() if which else None,
-                                         idx_spec.data_ptr() if which else None, st()), "step_prep")
+                                         idx_spec.data_ptr() if which else None, None, st()), "step_prep")
         torch.cuda.synchronize()
         for name in ("idx", "batch", "mom", "row_dev"):
             assert torch.equal(state[0][name], state[1][name]), (name, t)
@@ -307,9 +307,10 @@ def test_per_timestep_path_is_the_separate_launches_and_the_chunked_path_bit_for
     S, A, N, T = 21, 6, 5000, 150
     warm = B                                                  # the gate: len(memory) > batch_size (naf_algorithm.py:150) opens at step B
     runs = []
-    for fused, prefetch in (("1", "1"), ("0", "1"), ("1", "0")):
+    for fused, prefetch, pipeline in (("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("1", "1", "0")):
         monkeypatch.setenv("NAF_STEP_FUSED", fused)
         monkeypatch.setenv("NAF_STEP_PREFETCH", prefetch)      # (the next timestep's minibatch drawn by the last launch, or not)
+        monkeypatch.setenv("NAF_STEP_PIPELINE", pipeline)      # (... and its learn() chain run before its transition exists, or not)
         agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
         theta0 = agent.learner.theta2.clone()
         idx = [] if fused == "1" else None
@@ -317,6 +318,10 @@ def test_per_timestep_path_is_the_separate_launches_and_the_chunked_path_bit_for
         ch = agent._chunk
         assert ch.fused_prep == ch.fused_tail == (fused == "1") and ch.head_row is not None and (agent._fast is not None)
         assert (ch.spec_rec is not None) == (fused == "1" and prefetch == "1")
+        assert ch.pipelined == (fused == "1" and prefetch == "1" and pipeline == "1")
+        if ch.pipelined:
+            # both graphs ran: the one that starts with the waiting gradient, and the one that starts over
+            assert ch.fast_runs >= 5 and ch.slow_runs >= 5 and ch.fast_runs + ch.slow_runs in (T - 1, T), (ch.fast_runs, ch.slow_runs)
         if ch.spec_rec is not None:
             taken, drawn = ch.prefetch_stats()
             # the ring holds B + 1 ... B + T rows: the new row is among the B positions drawn about as often as not — both ways
@@ -333,12 +338,14 @@ def test_per_timestep_path_is_the_separate_launches_and_the_chunked_path_bit_for
         for k in ("theta", "m", "v", "bn", "ring", "meta"):
             assert torch.equal(a[k], b[k]), k
         assert a["loss"] == b["loss"] and torch.isfinite(a["theta"]).all()
-    for i, j in zip(runs[0]["idx"], runs[2]["idx"]):
-        np.testing.assert_array_equal(i, j)                    # (the indices a reader finds in chunk.idx: the timestep's own)
+    for other in (runs[2], runs[3]):
+        for i, j in zip(runs[0]["idx"], other["idx"]):
+            np.testing.assert_array_equal(i, j)                # (the indices a reader finds in chunk.idx: the timestep's own)
     assert not torch.equal(a["theta"], a["theta0"])
     # (b) the chunked path on the same minibatches: positions are stable while the ring only grows (no eviction here)
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     monkeypatch.setenv("NAF_STEP_FUSED", "1")
+    monkeypatch.setenv("NAF_STEP_PIPELINE", "1")
     L2 = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, DEV)
     L2.theta2.copy_(a["theta0"])
     buf = ReplayBuffer(N, B, DEV, 0, state_size=S, action_size=A)
@@ -354,40 +361,50 @@ def test_per_timestep_path_is_the_separate_launches_and_the_chunked_path_bit_for
     assert float(chunk.losses()[-1].item()) == a["loss"]
 
 
-def test_per_timestep_path_is_seven_launches(scratch_cwd):
-    """The update graph of NAFAgent.step() at num_updates = 1: naf_step_prep + the five launches of the row-split chain +
-    naf_adam_polyak_act (profiles/r05_api_path_kernel_stats.csv has the same count from rocprofv3)."""
+def test_per_timestep_path_is_six_or_seven_launches(scratch_cwd, monkeypatch):
+    """The update graph of NAFAgent.step() at num_updates = 1 (profiles/r05_api_path_kernel_stats.csv has the same counts from
+    rocprofv3). Pipelined (default): naf_adam_polyak_act — the append, the waiting gradient's optimizer step, act(), the prefetch —
+    + the five launches of the row-split chain on the prefetched minibatch; the graph that starts a timestep over is naf_step_prep +
+    chain + that. NAF_STEP_PIPELINE=0: naf_step_prep + the chain + naf_adam_polyak_act."""
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
-    agent = NAFAgent(object(), 21, 6, 256, 64, 1000, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
-    _drive(agent, 3, 65, 5, None)
-    ch = agent._chunk
-    assert ch.fused_prep and ch.fused_tail and ch.graph is not None
-    g = ch.graph
-    if hasattr(g, "debug_dump"):
-        pass                                                   # (the node count is not exposed by torch: counted under rocprofv3)
-    calls = []
-    lib = agent.learner.lib
-    names = ["naf_step_prep", "naf_bb_layer1_adam", "naf_bb_linear_stats_adam", "naf_bb_layer2_head", "naf_gemm_bundle",
-             "naf_bb_layer1_bwd_finish", "naf_adam_polyak_act", "naf_replay_add_counted", "naf_replay_sample_indices",
-             "naf_counter_add", "naf_replay_gather_rows", "naf_bb_moments", "naf_adam_polyak_fused", "naf_policy_act",
-             "naf_grad_norm_partials"]
+    chain = ["naf_bb_layer1_adam", "naf_bb_linear_stats_adam", "naf_bb_layer2_head", "naf_gemm_bundle", "naf_bb_layer1_bwd_finish"]
+    names = ["naf_step_prep", "naf_adam_polyak_act"] + chain + [
+        "naf_replay_add_counted", "naf_replay_sample_indices", "naf_counter_add", "naf_replay_gather_rows", "naf_bb_moments",
+        "naf_adam_polyak_fused", "naf_policy_act", "naf_grad_norm_partials"]
+    for pipeline in ("1", "0"):
+        monkeypatch.setenv("NAF_STEP_PIPELINE", pipeline)
+        agent = NAFAgent(object(), 21, 6, 256, 64, 1000, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+        _drive(agent, 3, 65, 5, None)
+        ch = agent._chunk
+        assert ch.fused_prep and ch.fused_tail and ch.graph is not None and ch.pipelined == (pipeline == "1")
+        calls = []
+        lib = agent.learner.lib
 
-    class Spy:
-        def __init__(self, inner):
-            self._inner = inner
+        class Spy:
+            def __init__(self, inner):
+                self._inner = inner
 
-        def __getattr__(self, name):
-            fn = getattr(self._inner, name)
-            if name in names:
-                def wrapped(*a, **k):
-                    calls.append(name)
-                    return fn(*a, **k)
-                return wrapped
-            return fn
-    spy = Spy(lib)
-    agent.learner.lib = agent.learner._f = spy
-    ch.L.lib = spy
-    ch._body()                                                 # one eager pass through exactly what the graph holds
-    torch.cuda.synchronize()
-    agent.learner.lib = agent.learner._f = lib
-    assert calls == names[:7], calls
+            def __getattr__(self, name):
+                fn = getattr(self._inner, name)
+                if name in names:
+                    def wrapped(*a, **k):
+                        calls.append(name)
+                        return fn(*a, **k)
+                    return wrapped
+                return fn
+        spy = Spy(lib)
+        agent.learner.lib = agent.learner._f = spy
+        ch.L.lib = spy
+        torch.cuda.synchronize()
+        ch._body()                                             # one eager pass through exactly what the (slower) graph holds
+        torch.cuda.synchronize()
+        if pipeline == "1":
+            assert calls == ["naf_step_prep"] + chain + ["naf_adam_polyak_act"] + chain, calls
+            del calls[:]
+            ch._body_fast()                                    # (behind _body(): its prefetch holds or not — the launches are the same)
+            torch.cuda.synchronize()
+            assert calls == ["naf_adam_polyak_act"] + chain, calls
+            agent.learner.err_host[2] = 0                      # (an eager pass outside the host's bookkeeping may have counted a mismatch)
+        else:
+            assert calls == ["naf_step_prep"] + chain + ["naf_adam_polyak_act"], calls
+        agent.learner.lib = agent.learner._f = lib
