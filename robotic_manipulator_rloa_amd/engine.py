@@ -160,7 +160,7 @@ class TrainChunk:
         self.graph_fast = None
         self._exec_fast = None
         self._spec_armed = False           # the last launch was one of the pipelined graphs: a verdict on its prefetch will come
-        self._r_gen = self._l_gen = self._r_total = -1
+        self._sig, self._r_total = None, -1
         self.fast_runs = self.slow_runs = 0
         self._seq_np = actor.seq_np if self.fused_tail else None
         self._seq_prev = 0
@@ -424,12 +424,16 @@ class TrainChunk:
         """Pipelined chunk, about to launch: may this timestep run the graph that starts with the append and the waiting gradient?
         Yes if it brings a row, the last launch was one of this chunk's graphs whose prefetch says it holds (pinned words its extra
         workgroup wrote a few microseconds behind the action; _seq_prev is that launch's ordinal: the caller has seen its action),
-        and nobody has touched the ring, the sampler's stream or the learner in between (their call counters). Also does the
-        bookkeeping for the launch that follows."""
+        and nobody has touched the ring, the sampler's stream or the learner in between. Also does the bookkeeping for the launch
+        that follows."""
         r, L = self.replay, self.L
+        # (the call counters, and torch's version counters of the buffers: an in-place write through ANY view of them — the NAF
+        #  modules' load_state_dict, a snapshot's restore — moves those; graph replays and this path's own launches do not.
+        #  What stays invisible is a write through `.data` or a raw pointer: INTEGRATION.md says so.)
+        sig = (r._gen, L._gen, L.theta2._version, L.bn_stats._version, L.adam_m._version, L.adam_v._version, L.step_dev._version,
+               L.grad._version, L.partials._version, r.rows._version, r.meta._version, r._sample_ctr._version)
         ok = False
-        if brings_row and self._spec_armed and r._gen == self._r_gen and L._gen == self._l_gen and \
-                r._total_added == self._r_total + 1 and r._pending == 0:
+        if brings_row and self._spec_armed and sig == self._sig and r._total_added == self._r_total + 1 and r._pending == 0:
             hs, want, n = self._host_spec_np, self._seq_prev, 0
             while hs[0] != want:
                 n += 1
@@ -438,7 +442,7 @@ class TrainChunk:
                     break
             ok = hs[0] == want and hs[1] == 1
         self._spec_armed = True
-        self._r_gen, self._l_gen, self._r_total = r._gen, L._gen, r._total_added
+        self._sig, self._r_total = sig, r._total_added
         if ok:
             self.fast_runs += 1
         else:

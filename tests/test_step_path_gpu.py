@@ -361,6 +361,60 @@ def test_per_timestep_path_is_the_separate_launches_and_the_chunked_path_bit_for
     assert float(chunk.losses()[-1].item()) == a["loss"]
 
 
+
+def test_pipelined_path_survives_api_calls_between_timesteps(scratch_cwd, monkeypatch):
+    """The pipelined per-timestep path keeps a gradient waiting between timesteps (taken on the prefetched minibatch while the
+    host stepped the environment). Anything a user does to the agent in between — memory.sample(), learn() on an explicit
+    minibatch, soft_update(), loading weights, adding a transition by hand, a second step() without an act() — voids it (call
+    counters of the replay buffer and the learner, engine.TrainChunk._holds): the next timestep starts over, and the run equals
+    the twelve-launch loop's bit for bit."""
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    from synth_data import make_transitions
+    S, A, B, N, T = 21, 6, 64, 4000, 120
+    st_, ac, rw, ns, dn = make_transitions(B + T + 40, S, A, seed=5)
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NAF_STEP_FUSED", fused)
+        agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+        state = st_[0].astype(np.float64)
+        acts, extra = [], B + T
+        for t in range(B + T):
+            a = agent.act(state)
+            acts.append(np.array(a, copy=True))
+            nxt = ns[t].astype(np.float64)
+            agent.step(state, a, float(rw[t]), nxt, 0)
+            state = nxt
+            k = t - B
+            if k > 5 and k % 9 == 0:
+                agent.memory.sample()                                        # moves the sampler's stream
+            if k > 5 and k % 13 == 0:
+                agent.learn(agent.memory.sample())                           # an update of the user's own
+            if k > 5 and k % 17 == 0:
+                agent.soft_update(agent.qnetwork_main, agent.qnetwork_target)
+            if k > 5 and k % 23 == 0:
+                agent.memory.add(st_[extra], ac[extra], float(rw[extra]), ns[extra], 0)      # a transition added by hand
+                extra += 1
+            if k > 5 and k % 29 == 0:
+                agent.step(state, a, 0.25, state, 0)                         # a second step() without an act() in between
+            if k == 60:
+                sd = {kk: v.clone() for kk, v in agent.qnetwork_main.state_dict().items()}
+                agent.qnetwork_target.load_state_dict(sd)                    # (weights loaded mid-run)
+        torch.cuda.synchronize()
+        ch, L = agent._chunk, agent.learner
+        assert ch.pipelined == (fused == "1")
+        if ch.pipelined:
+            assert ch.fast_runs >= 10 and ch.slow_runs >= 20, (ch.fast_runs, ch.slow_runs)
+            assert int(L.err_host[2]) == 0                                   # never launched on a prefetch that did not hold
+        runs.append(dict(acts=np.array(acts), theta=L.theta2.clone(), m=L.adam_m.clone(), v=L.adam_v.clone(), bn=L.bn_stats.clone(),
+                         ring=agent.memory.rows.clone(), meta=agent.memory.meta.clone(), step=int(L.step_dev.item()),
+                         loss=agent.last_loss()))
+    a, b = runs
+    assert a["step"] == b["step"] and a["step"] > T
+    np.testing.assert_array_equal(a["acts"], b["acts"])
+    for k in ("theta", "m", "v", "bn", "ring", "meta"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["loss"] == b["loss"]
+
 def test_per_timestep_path_is_six_or_seven_launches(scratch_cwd, monkeypatch):
     """The update graph of NAFAgent.step() at num_updates = 1 (profiles/r05_api_path_kernel_stats.csv has the same counts from
     rocprofv3). Pipelined (default): naf_adam_polyak_act — the append, the waiting gradient's optimizer step, act(), the prefetch —
