@@ -5,6 +5,7 @@ given time before the call (does the runtime's completion handling of the previo
     python benchmarks/launch_call_split.py [batch]
 """
 import os, sys, time, tempfile
+os.environ["NAF_STEP_PIPELINE"] = "0"      # (the seven-launch graph: this script launches the chunk's graph itself, timestep by timestep)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.chdir(tempfile.mkdtemp())
 import logging

@@ -45,16 +45,22 @@ timeline)  # phases inside the kernels, gaps between them (no profiler attached)
   unset NAF_BUILD_DEFINES
   head -30 gpurun_out/r05_timeline_b256.txt ;;
 api)       # the per-timestep path (NAFAgent.act -> env.step -> NAFAgent.step, one host env): launches per timestep under rocprofv3,
-           # host-side breakdown, in-kernel timeline of the seven launches (its own build), launch-latency probe
+           # host-side breakdown, the three forms A/B/C (pipelined | prefetch only | neither) with and without a slower environment,
+           # what the launch call is made of, in-kernel timeline of the pipelined graph (its own build), the two launch probes
   benchmarks/prof_api_path.sh r05 64 > gpurun_out/prof_api_b64.log 2>&1; tail -3 gpurun_out/prof_api_b64.log
   benchmarks/prof_api_path.sh r05_b256 256 > gpurun_out/prof_api_b256.log 2>&1; tail -3 gpurun_out/prof_api_b256.log
   for b in 64 256; do python3 benchmarks/host_api_breakdown.py $b 2>&1 | grep -v amdgpu.ids; done > gpurun_out/r05_api_breakdown.txt
   NAF_STEP_FUSED=0 python3 benchmarks/host_api_breakdown.py 64 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_api_breakdown_unfused.txt
   cat gpurun_out/r05_api_breakdown.txt gpurun_out/r05_api_breakdown_unfused.txt
+  bash benchmarks/ab_prefetch.sh > gpurun_out/r05_ab_pipeline.txt 2>&1; grep "==\|timesteps/s" gpurun_out/r05_ab_pipeline.txt
+  bash benchmarks/ab_prefetch.sh delay > gpurun_out/r05_ab_pipeline_env_delay.txt 2>&1; grep "==\|timesteps/s" gpurun_out/r05_ab_pipeline_env_delay.txt
+  for pf in 1 0; do NAF_STEP_PREFETCH=$pf python3 benchmarks/launch_call_split.py 256 2>&1 | grep -v amdgpu.ids; done > gpurun_out/r05_launch_call_split.txt
   (cd benchmarks/probe && hipcc -O2 --offload-arch=gfx950 -o launch_latency launch_latency.hip 2>/dev/null; ./launch_latency 7 6; ./launch_latency 12 4) > gpurun_out/r05_launch_latency_probe.txt; cat gpurun_out/r05_launch_latency_probe.txt
+  (cd benchmarks/probe && hipcc -O2 --offload-arch=gfx950 -o pipeline_gap pipeline_gap.hip 2>/dev/null; ./pipeline_gap 6 7 5 9; ./pipeline_gap 6 7 5 30; ./pipeline_gap 6 11 5 9) > gpurun_out/r05_pipeline_gap_probe.txt; cat gpurun_out/r05_pipeline_gap_probe.txt
   export NAF_BUILD_DEFINES=-DNAF_TIMELINE
   python3 benchmarks/step_timeline.py 64 300 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_step_timeline_b64.txt
   python3 benchmarks/step_timeline.py 256 300 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_step_timeline_b256.txt
+  NAF_STEP_PIPELINE=0 NAF_STEP_PREFETCH=0 python3 benchmarks/step_timeline.py 64 300 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_step_timeline_b64_seven_launches.txt
   unset NAF_BUILD_DEFINES
   head -16 gpurun_out/r05_step_timeline_b64.txt ;;
 esac
