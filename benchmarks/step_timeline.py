@@ -88,7 +88,9 @@ if PIPELINED:
     print(f"B = {B}, pipelined graph (adam_act: append + the waiting gradient's step + act() + prefetch, then the chain): microseconds "
           f"since adam_act's entry, mean of {REPS} timesteps (first workgroup | last workgroup; 0 = no mark; adam_act first-row "
           f"slots 13 / 14 = the prefetching workgroup's entry / exit)")
-    order = ("adam_act", "bb_layer1", "bb_linear_stats", "bb_layer2_head", "gemm_bundle", "finish")
+    print("step_prep's SECOND row = the prefetching workgroup of adam_act (slots 0 - 6 main phases, 7 - 12 moments, 13 - 15 draw); its first "
+          "row is stale (the last timestep that started over)")
+    order = ("adam_act", "step_prep", "bb_layer1", "bb_linear_stats", "bb_layer2_head", "gemm_bundle", "finish")
 else:
     print(f"B = {B}: microseconds since step_prep's entry, mean of {REPS} timesteps (first workgroup | last workgroup; 0 = no mark)")
     order = ("step_prep", "bb_layer1", "bb_linear_stats", "bb_layer2_head", "gemm_bundle", "finish", "adam_act")

@@ -25,9 +25,10 @@
 #include "../../include/naf_hip.h"
 NAF_TL_DECL(g_tl_sp);
 #ifdef NAF_TIMELINE
-// (the stand-alone launch only: the same bodies inside adam_act_kernel's prefetching workgroup leave no marks)
-#define BM_MARK(slot) do { if (gridDim.x == 1) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot); } while (0)
-#define SB_MARK(slot) do { if (gridDim.x == 1) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot); } while (0)
+// (the stand-alone launch leaves both rows of marks; inside adam_act_kernel the prefetching workgroup is the launch's LAST one and
+//  leaves the second row — benchmarks/step_timeline.py knows which is which)
+#define BM_MARK(slot) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot)
+#define SB_MARK(slot) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, slot)
 #endif
 #include "act_body.h"
 #include "adam_body.h"
@@ -130,7 +131,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
     int* vals = (int*)sp_smem;
     const int tid = threadIdx.x, B = P.B;
     const int rf4 = 1 << P.rf4_shift;
-    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 0);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 0);
 
     // ---- ReplayBuffer.add: 0 or 1 rows, from (pinned host) memory -------------------------------------------------------
     int n = 0;
@@ -235,11 +236,11 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
         __syncthreads();                                // every thread has read {head, size, counter} before thread 0 rewrites them
         store_row_and_counters();
     }
-    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 1);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 1);
 
     // ---- random.sample: the chunked sampler's body on the ring as the append leaves it ---------------------------------------
     replay_sample_body(vals, tid, SP_THREADS, size2, ctr, P.seed, B, P.without_replacement, P.hash_bits);
-    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 2);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 2);
     const uint64_t base = head2 + P.cap - size2;        // physical position of deque element 0 (oldest)
     int mypos[4], myidx[4];
 #pragma unroll
@@ -268,7 +269,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
         }
     }
     __syncthreads();                                    // (!cache: the appended row's store has completed too — a workgroup-scope release)
-    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 3);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 3);
     // the verdict for the host (pinned words, system scope: [1] = does the prefetch hold, then [0] = this launch's ordinal)
     auto tell_host = [&](int valid) {
         if (P.host_spec) {
@@ -312,7 +313,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
         }
     }
 
-    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 4);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 4);
     // ---- the moments of layer 1's inputs: threads 0 .. 511 the states (net 0), 512 .. 1023 the next states (net 1) ------------
     const int net = tid >> 9;
     const int c0 = net ? P.off_s2_4 : 0;
@@ -333,7 +334,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
             return v;
         },
         S[net], tid & (BM_THREADS - 1), P.mom + net * REC, B);
-    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 5);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 5);
     if (cache) {
         // everything this launch leaves in memory, in one go (the moments' records left just above)
         if (!SPEC) store_row_and_counters();
@@ -362,7 +363,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
         }
         tell_host(1);
     }
-    if (!SPEC) NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
+    NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
 }
 
 template <int K4, bool CACHE>

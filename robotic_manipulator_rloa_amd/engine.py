@@ -130,8 +130,6 @@ class TrainChunk:
             self.head_dev = torch.zeros(rf + 4, dtype=torch.float32, device=dev)
             self._head_src, self._head_dst, self._head_bytes = head_row.data_ptr(), self.head_dev.data_ptr(), 4 * (rf + 1)
             self._publish = learner.lib.naf_host_publish
-        # fused tail: the launch writes its ordinal to a pinned host word behind the action (ActPath.seq) — the host learns that
-        # a run() has passed by polling that word instead of synchronising an event / the stream
         # with both fused launches: the last launch of a timestep also draws, gathers and takes the moments of the NEXT timestep's
         # minibatch (one more workgroup, beside its own work and behind the action's announcement to the host: what a timestep draws
         # depends on the row it appends only through the fill level — and through the row itself if the draw picks it, which the
@@ -162,6 +160,8 @@ class TrainChunk:
         self._spec_armed = False           # the last launch was one of the pipelined graphs: a verdict on its prefetch will come
         self._sig, self._r_total = None, -1
         self.fast_runs = self.slow_runs = 0
+        # fused tail: the launch writes its ordinal to a pinned host word behind the action (ActPath.seq) — the host learns that
+        # a run() has passed by polling that word instead of synchronising an event / the stream
         self._seq_np = actor.seq_np if self.fused_tail else None
         self._seq_prev = 0
         self._inflight = False             # a run() whose ordinal the host has not seen yet
