@@ -416,15 +416,17 @@ def test_pipelined_path_survives_api_calls_between_timesteps(scratch_cwd, monkey
     assert a["loss"] == b["loss"]
 
 
-def test_pipelined_path_on_a_ring_that_wraps(scratch_cwd, monkeypatch):
+@pytest.mark.parametrize("S,A,p_mode,action_mode", [(21, 6, "hadamard", "trunc_int"), (23, 7, "matmul", "float"), (10, 5, "matmul", "trunc_int")])
+def test_pipelined_path_on_a_ring_that_wraps(scratch_cwd, monkeypatch, S, A, p_mode, action_mode):
     """600 timesteps on a ring of 300 rows at B = 64: every append evicts the oldest row after the first 300, the prefetch does not
-    hold one time in five (the row to come among the positions drawn) — the pipelined loop equals the twelve-launch loop all the way."""
+    hold one time in five (the row to come among the positions drawn) — the pipelined loop equals the twelve-launch loop all the way;
+    also with the textbook P = L L^T head, float actions, the Panda's and the reference test's shapes."""
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
-    S, A, B, N, T = 21, 6, 64, 300, 600
+    B, N, T = 64, 300, 600
     runs = []
     for fused in ("1", "0"):
         monkeypatch.setenv("NAF_STEP_FUSED", fused)
-        agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+        agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0, p_mode=p_mode, action_mode=action_mode)
         acts = _drive(agent, 33, B, T, None)
         ch, L = agent._chunk, agent.learner
         assert ch.pipelined == (fused == "1")
