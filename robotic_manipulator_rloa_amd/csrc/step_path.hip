@@ -20,6 +20,12 @@
 //                         self-validating (value, epoch) records written and polled with sc1 accesses, the protocol of
 //                         csrc/bn2bwd_fold.h; every poll is bounded by wall clock and a bound that runs out is counted where the
 //                         host sees it and turns the action into NaN (the host raises) — no wave can wait forever.
+//
+// ... and one more workgroup of adam_act_kernel runs step_prep's body for the NEXT timestep (step_prep_body, MODE 1 / 2): what a
+// timestep draws depends on its own transition only through the ring's fill level and — if the draw picks it — the row, so the
+// minibatch can be there before the transition is. With it there, so can the gradient: on one GPU the timestep's graph is
+// adam_act_kernel (append, the waiting gradient's optimizer step, act(), prefetch) followed by the chain for the next update, six
+// launches of which the host waits for the first (engine.TrainChunk).
 #include <string.h>
 #include "common.h"
 #include "../../include/naf_hip.h"

@@ -143,9 +143,12 @@ class NAFAgent:
         """Store the experience and, every update_freq steps once len(memory) > batch_size, run num_updates
         (sample + learn) (naf_algorithm.py:129-156). The updates are one captured graph:
         [append this transition] -> sample num_updates minibatches -> one gather -> num_updates x learn -> [act(next_state)];
-        with one update per timestep (the reference's own loop) it is seven launches: the append, the draw, the gather and the
-        moments in one (naf_step_prep), the five of the row-split chain, the optimizer step and the policy's forward on the next
-        state in one (naf_adam_polyak_act)."""
+        with one update per timestep (the reference's own loop) the append, the draw, the gather and the moments are one launch
+        (naf_step_prep), the optimizer step and the policy's forward on the next state another (naf_adam_polyak_act) around the five
+        of the row-split chain — and on one GPU the graph is PIPELINED (engine.TrainChunk): the launch that ends a timestep also
+        draws the next timestep's minibatch, the chain runs on it while the host steps the environment, and this call's graph
+        starts with the launch that appends the row, applies the gradient that is waiting and acts: six launches, of which act()
+        waits for the first."""
         f = self._fast
         if f is not None and self.memory._pending == 0:
             # every tick updates (update_freq = 1, gate open): the append is the first node of the update's graph, reading
