@@ -79,20 +79,32 @@ class Segment:
         return n
 
 
+NATIVE_LAYER = 256     # the width the fused kernels are built for (rl_framework.py's presets; csrc/big_batch.hip, step_path.hip)
+
+
 class NetLayout:
     """Where each parameter of one NAF network sits inside its flat buffer (units: floats).
     Segments start on 64-float (256-B) boundaries; the gaps and the pad rows/columns of Wh hold zeros, receive
-    zero gradients and therefore stay zero under Adam."""
+    zero gradients and therefore stay zero under Adam.
 
-    def __init__(self, state_size: int, action_size: int, layer_size: int):
+    layer_size below 256 (the reference takes any; its own agent test builds 128): with pad_layer the network is STORED as a
+    256-wide one whose units beyond layer_size have zero weights, zero biases and zero BatchNorm scale / shift — `H` (what every
+    kernel sees) is 256, `H_ref` (what state_dict() shows and load_state_dict() takes) is layer_size. Such a unit's pre-activation is
+    0 for every sample, its normalised value 0, its activation ReLU(0 * 0 + 0) = 0; nothing downstream multiplies it with anything
+    but a zero weight, so every gradient it receives or passes on is 0 and Adam (m = v = 0) leaves it where it is: the padded network
+    computes the narrow one's numbers, term for term, with exact zeros appended to its sums — and runs the kernels the presets run."""
+
+    def __init__(self, state_size: int, action_size: int, layer_size: int, pad_layer: bool = True):
         if not (1 <= action_size <= 16):
             raise ValueError("action_size must be in 1..16 (one sample per 8-lane group in the fused head kernels, per 16-lane "
                              "group in the stand-alone ones)")
-        self.S, self.A, self.H = state_size, action_size, layer_size
+        self.H_ref = int(layer_size)
+        self.S, self.A = state_size, action_size
+        self.H = NATIVE_LAYER if (pad_layer and 0 < layer_size < NATIVE_LAYER) else int(layer_size)
         self.T = action_size * (action_size + 1) // 2
         self.NH = self.A + self.T + 1                  # [mu | l | V]
         self.NHP = _round_up(self.NH, 16)              # heads row stride (ldh): whole 16-wide MFMA tiles
-        self.HP = layer_size + 16                      # activations: H features | 1.0 | 15 zeros (K % 16 == 0)
+        self.HP = self.H + 16                          # activations: H features | 1.0 | 15 zeros (K % 16 == 0)
         self.seg: Dict[str, Segment] = {}
         off = 0
         for name, shape in (("W1", (self.H, self.S)), ("b1", (self.H,)), ("g1", (self.H,)), ("be1", (self.H,)),
@@ -115,20 +127,23 @@ class NetLayout:
 
     def n_ref_params(self) -> int:
         """Number of parameters of the reference module (79,644 at S=21, A=6, H=256)."""
-        return self.H * self.S + self.H * self.H + 6 * self.H + self.NH * (self.H + 1)
+        h = self.H_ref
+        return h * self.S + h * h + 6 * h + self.NH * (h + 1)
 
     # ---- mapping to the reference's state_dict keys (naf_neural_network.py:37-54) -------------------------
     def param_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
-        A, T, H = self.A, self.T, self.H
+        """the reference's tensors, in its shapes: views of the stored ones (of their first layer_size units where the layer is
+        stored padded; the heads' bias column is column H of Wh)"""
+        A, T, H, h = self.A, self.T, self.H, self.H_ref
         Wh = self.view(flat, "Wh")
         return {
-            "input_layer.weight": self.view(flat, "W1"), "input_layer.bias": self.view(flat, "b1"),
-            "bn1.weight": self.view(flat, "g1"), "bn1.bias": self.view(flat, "be1"),
-            "hidden_layer.weight": self.view(flat, "W2"), "hidden_layer.bias": self.view(flat, "b2"),
-            "bn2.weight": self.view(flat, "g2"), "bn2.bias": self.view(flat, "be2"),
-            "action_values.weight": Wh[0:A, 0:H], "action_values.bias": Wh[0:A, H],
-            "value.weight": Wh[A + T:A + T + 1, 0:H], "value.bias": Wh[A + T:A + T + 1, H],
-            "matrix_entries.weight": Wh[A:A + T, 0:H], "matrix_entries.bias": Wh[A:A + T, H],
+            "input_layer.weight": self.view(flat, "W1")[:h], "input_layer.bias": self.view(flat, "b1")[:h],
+            "bn1.weight": self.view(flat, "g1")[:h], "bn1.bias": self.view(flat, "be1")[:h],
+            "hidden_layer.weight": self.view(flat, "W2")[:h, :h], "hidden_layer.bias": self.view(flat, "b2")[:h],
+            "bn2.weight": self.view(flat, "g2")[:h], "bn2.bias": self.view(flat, "be2")[:h],
+            "action_values.weight": Wh[0:A, 0:h], "action_values.bias": Wh[0:A, H],
+            "value.weight": Wh[A + T:A + T + 1, 0:h], "value.bias": Wh[A + T:A + T + 1, H],
+            "matrix_entries.weight": Wh[A:A + T, 0:h], "matrix_entries.bias": Wh[A:A + T, H],
         }
 
 
@@ -144,14 +159,16 @@ class Learner:
     def __init__(self, state_size: int, action_size: int, layer_size: int, batch_size: int, learning_rate: float,
                  tau: float, gamma: float, device: torch.device, p_mode: int = _lib.P_HADAMARD,
                  world_size: int = 1, process_group=None, fuse: Optional[str] = None, _force_allreduce: bool = False,
-                 _fold_norm: bool = True):
+                 _fold_norm: bool = True, pad_layer: bool = True):
         """fuse: "rows" | "columns" | "unfused" | None (= NAF_FUSE or the per-shape default, see below). The underscore
-        arguments are for tests: run the gradient all-reduce at world size 1 / keep the separate grad-norm launch."""
+        arguments are for tests: run the gradient all-reduce at world size 1 / keep the separate grad-norm launch.
+        pad_layer: a layer_size below 256 is stored zero-padded to 256 (NetLayout) and runs the kernels built for that width;
+        False: its own width on the column-tile / unfused chains (tests compare the two)."""
         _lib.require_gpu()
         self.lib = _lib.load()
         self.blas = configure_blas()
         self.dev = torch.device(device)
-        self.lay = NetLayout(state_size, action_size, layer_size)
+        self.lay = NetLayout(state_size, action_size, layer_size, pad_layer=pad_layer)
         self.B = int(batch_size)
         self.lr, self.tau, self.gamma = float(learning_rate), float(tau), float(gamma)
         self.p_mode = int(p_mode)
@@ -577,8 +594,8 @@ class Learner:
         return self.lay.param_views(self.theta2[1])
 
     def bn_views(self, net: int) -> Dict[str, torch.Tensor]:
-        s = self.bn_stats[net]
-        return {"bn1.running_mean": s[0], "bn1.running_var": s[1], "bn2.running_mean": s[2], "bn2.running_var": s[3]}
+        s, h = self.bn_stats[net], self.lay.H_ref
+        return {"bn1.running_mean": s[0][:h], "bn1.running_var": s[1][:h], "bn2.running_mean": s[2][:h], "bn2.running_var": s[3][:h]}
 
     def load_params(self, net: int, sd: Dict[str, torch.Tensor]) -> None:
         self._gen += 1

@@ -103,7 +103,7 @@ class NAF(nn.Module):
 
     def __init__(self, state_size: int, action_size: int, layer_size: int, seed: int, device, *,
                  p_mode="hadamard", _flat: Optional[torch.Tensor] = None, _bn: Optional[torch.Tensor] = None,
-                 _init: bool = True) -> None:
+                 _init: bool = True, pad_layer: bool = True) -> None:
         """
         Args (reference order, naf_neural_network.py:10): state_size, action_size, layer_size, seed, device.
         p_mode: 'hadamard' (reference parity) or 'matmul'.
@@ -118,10 +118,13 @@ class NAF(nn.Module):
         if self.device.type != "cuda":
             raise _lib.NafHipError("NAF runs on the MI355X only (device must be cuda:N); there is no CPU path")
         self.p_mode = _P_MODES[p_mode]
-        self.layout = NetLayout(state_size, action_size, layer_size)
+        # (a layer_size below 256 is stored zero-padded to 256: NetLayout — lay.H is the stored width, lay.H_ref = layer_size)
+        self.layout = NetLayout(state_size, action_size, layer_size, pad_layer=pad_layer)
         lay = self.layout
         self.flat = _flat if _flat is not None else torch.zeros(lay.P, dtype=torch.float32, device=self.device)
-        self.bn_stats = _bn if _bn is not None else torch.zeros(4, layer_size, dtype=torch.float32, device=self.device)
+        self.bn_stats = _bn if _bn is not None else torch.zeros(4, lay.H, dtype=torch.float32, device=self.device)
+        if tuple(self.bn_stats.shape) != (4, lay.H) or self.flat.numel() != lay.P:
+            raise ValueError("NAF: the storage handed in does not have this layout's sizes (pad_layer differs from the owner's?)")
         if _bn is None:
             self.bn_stats[1].fill_(1.0)
             self.bn_stats[3].fill_(1.0)
@@ -139,8 +142,9 @@ class NAF(nn.Module):
         for name in PARAM_ORDER:
             mod, attr = name.split(".")
             setattr(getattr(self, mod), attr, nn.Parameter(views[name], requires_grad=True))
-        self.bn1.running_mean, self.bn1.running_var = self.bn_stats[0], self.bn_stats[1]
-        self.bn2.running_mean, self.bn2.running_var = self.bn_stats[2], self.bn_stats[3]
+        h = lay.H_ref
+        self.bn1.running_mean, self.bn1.running_var = self.bn_stats[0][:h], self.bn_stats[1][:h]
+        self.bn2.running_mean, self.bn2.running_var = self.bn_stats[2][:h], self.bn_stats[3][:h]
         self.bn1.num_batches_tracked = torch.zeros((), dtype=torch.long, device=self.device)
         self.bn2.num_batches_tracked = torch.zeros((), dtype=torch.long, device=self.device)
         self._tracked_base = 0            # batches tracked at load time
@@ -172,8 +176,8 @@ class NAF(nn.Module):
             sd[f"{mod}.bias"] = views[f"{mod}.bias"].detach().clone().contiguous()
             if mod.startswith("bn"):
                 k = 0 if mod == "bn1" else 2
-                sd[f"{mod}.running_mean"] = self.bn_stats[k].clone()
-                sd[f"{mod}.running_var"] = self.bn_stats[k + 1].clone()
+                sd[f"{mod}.running_mean"] = self.bn_stats[k][:self.layout.H_ref].clone()
+                sd[f"{mod}.running_var"] = self.bn_stats[k + 1][:self.layout.H_ref].clone()
                 sd[f"{mod}.num_batches_tracked"] = n.clone()
         return sd
 
@@ -191,7 +195,7 @@ class NAF(nn.Module):
                     v.copy_(src.to(self.device, torch.float32))
             for i, k in enumerate(("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var")):
                 if k in state_dict:
-                    self.bn_stats[i].copy_(torch.as_tensor(state_dict[k]).to(self.device, torch.float32))
+                    self.bn_stats[i][:self.layout.H_ref].copy_(torch.as_tensor(state_dict[k]).to(self.device, torch.float32))
         if "bn1.num_batches_tracked" in state_dict:
             self._tracked_base = int(torch.as_tensor(state_dict["bn1.num_batches_tracked"]).item())
             self._tracked_eager = 0
@@ -242,9 +246,9 @@ class NAF(nn.Module):
         if x.dim() == 1:
             x = x.unsqueeze(0)
         h = _BnReluTrain.apply(x @ self.input_layer.weight.t(), self.input_layer.bias, self.bn1.weight, self.bn1.bias,
-                               self.bn_stats[0], self.bn_stats[1], self.lib)
+                               self.bn1.running_mean, self.bn1.running_var, self.lib)
         h = _BnReluTrain.apply(h @ self.hidden_layer.weight.t(), self.hidden_layer.bias, self.bn2.weight, self.bn2.bias,
-                               self.bn_stats[2], self.bn_stats[3], self.lib)
+                               self.bn2.running_mean, self.bn2.running_var, self.lib)
         self._tracked_eager += 1
         mu_pre = h @ self.action_values.weight.t() + self.action_values.bias
         l_pre = h @ self.matrix_entries.weight.t() + self.matrix_entries.bias

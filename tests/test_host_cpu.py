@@ -86,6 +86,30 @@ def test_reference_init_bit_exact_and_layout_roundtrip():
     assert (wide.T, wide.NH, wide.NHP, wide.row_floats) == (45, 55, 64, 128) and wide.n_ref_params() == 256 * 27 + 256 * 256 + 6 * 256 + 55 * 257
     with pytest.raises(ValueError):
         NetLayout(40, 17, 256)
+    # a layer_size below 256 is STORED zero-padded to 256 (the kernels see H = 256), shown in the reference's shapes (H_ref): the
+    # reference's own agent test builds NAF(10, 5, 128)
+    for h in (128, 64, 200, 4):
+        sd = reference_init_state_dict(10, 5, h, 0)
+        lay = NetLayout(10, 5, h)
+        plain = NetLayout(10, 5, h, pad_layer=False)
+        assert (lay.H, lay.H_ref, lay.HP) == (256, h, 272) and (plain.H, plain.H_ref) == (h, h)
+        assert lay.P == NetLayout(10, 5, 256).P and lay.n_ref_params() == plain.n_ref_params() == sum(v.numel() for k, v in sd.items() if k in PARAM_ORDER)
+        flat = torch.zeros(lay.P)
+        views = lay.param_views(flat)
+        probe = lay.param_views(torch.arange(lay.P, dtype=torch.float32))
+        used = torch.zeros(lay.P, dtype=torch.bool)
+        for k in PARAM_ORDER:
+            assert tuple(views[k].shape) == tuple(plain.param_views(torch.zeros(plain.P))[k].shape) == tuple(sd[k].shape) or \
+                views[k].numel() == sd[k].numel(), k
+            views[k].copy_(sd[k].reshape(views[k].shape))
+            ids = probe[k].reshape(-1).long()
+            assert not used[ids].any(), k
+            used[ids] = True
+        assert (flat[~used] == 0).all() and int(used.sum()) == lay.n_ref_params()
+        # the padded units: rows h.. of W1 / b1 / g1 / be1 / W2 / b2 / g2 / be2, columns h.. of W2, columns h..255 of Wh — never a view's
+        assert not used[lay.seg["g1"].offset + h:lay.seg["g1"].offset + 256].any()
+        assert float(lay.view(flat, "Wh")[:, h:256].abs().max()) == 0.0 and float(lay.view(flat, "W2")[:, h:].abs().max()) == 0.0
+    assert NetLayout(21, 6, 300).H == 300                   # (wider than the native width: as it is)
 
 
 def test_hyperparameter_rules_match_reference_contract():

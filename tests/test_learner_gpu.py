@@ -187,24 +187,36 @@ def _random_init_sd(S, A, H, seed=3):
     return sd
 
 
+@pytest.mark.parametrize("pad", [True, False])
 @pytest.mark.parametrize("p_mode", [0, 1])
 @pytest.mark.parametrize("S,A,H,B", [(10, 5, 128, 64), (21, 6, 128, 256), (21, 6, 512, 64), (21, 6, 512, 300), (21, 6, 128, 1024),
-                                     (23, 7, 64, 100), (21, 6, 320, 48)])
-def test_learn_at_other_layer_sizes_vs_oracle(S, A, H, B, p_mode):
+                                     (23, 7, 64, 100), (21, 6, 320, 48), (21, 6, 200, 256), (21, 6, 4, 32)])
+def test_learn_at_other_layer_sizes_vs_oracle(S, A, H, B, p_mode, pad):
     """layer_size is a hyper-parameter of the reference (rl_framework.py:68-74, `NAF(state, action, layer_size,
-    ...)`), and its own agent test builds NAF(10, 5, 128, ...) (tests/.../test_naf_algorithm.py:74). Every width other than 256
-    runs the column-tile chain (B <= 512, widths it has tiles for) or the unfused chain here: 20 updates against the f32 numpy
-    oracle, as test_learn_vs_oracle_both_modes holds the default width to."""
+    ...)`), and its own agent test builds NAF(10, 5, 128, ...) (tests/.../test_naf_algorithm.py:74). A width below 256 is STORED
+    zero-padded to 256 (NetLayout: the padded units compute exact zeros and receive zero gradients) and runs the row-split chain the
+    presets run; pad_layer = False, and every width above 256, runs the column-tile chain (B <= 512) or the unfused chain: 20
+    updates against the f32 numpy oracle of the NARROW network, as test_learn_vs_oracle_both_modes holds the default width to."""
     import warnings
     from synth_data import make_transitions
+    if H > 256 and pad:
+        pytest.skip("wider than the native width: nothing to pad")
     n_upd = 20
     st, ac, rw, ns, dn = make_transitions(n_upd * B, S, A, seed=21, rare_events=False, structured_reward=True)
     sd = _random_init_sd(S, A, H)
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
-        L = make_learner(S, A, B, sd, sd, H=H, p_mode=p_mode)
-    assert "bb" not in L.fuse and L.chain in ("columns", "unfused")
-    assert bool(caught) == (B > 512)                       # (beyond 512 rows the unfused chain says what it is)
+        L = make_learner(S, A, B, sd, sd, H=H, p_mode=p_mode, pad_layer=pad)
+    assert L.lay.H_ref == H and L.lay.H == (256 if (pad and H < 256) else H)
+    if pad and H < 256:
+        assert L.chain == "rows" and "bb" in L.fuse and not caught
+        # what the padding holds: zeros, before and (below) after the updates
+        for name in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2"):
+            v = L.lay.view(L.theta2[0], name)
+            assert float(v[H:].abs().max()) == 0.0 and (v.dim() == 1 or name == "W1" or float(v[:, H:].abs().max()) == 0.0), name
+    else:
+        assert "bb" not in L.fuse and L.chain in ("columns", "unfused")
+        assert bool(caught) == (B > 512)                   # (beyond 512 rows the unfused chain says what it is)
     Or = O.LearnerOracle(sd, p_mode=p_mode, dtype=np.float32)
     rows = rows_device(L, st, ac, rw, ns, dn)
     lp = torch.zeros(n_upd, L.n_loss_wg, device="cuda")
@@ -220,6 +232,13 @@ def test_learn_at_other_layer_sizes_vs_oracle(S, A, H, B, p_mode):
     cur = current_sd(L, 0)
     for name in ("bn1.running_mean", "bn2.running_var", "hidden_layer.weight", "value.weight"):
         np.testing.assert_allclose(cur[name], Or.main[name], rtol=2e-2, atol=2.5e-3)
+    if pad and H < 256:
+        for net in (0, 1):
+            for buf in (L.theta2[net], L.grad, L.adam_m, L.adam_v):
+                for name in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2"):
+                    v = L.lay.view(buf, name)
+                    assert float(v[H:].abs().max()) == 0.0, (name, net)
+                assert float(L.lay.view(buf, "W2")[:, H:].abs().max()) == 0.0 and float(L.lay.view(buf, "Wh")[:, H:256].abs().max()) == 0.0
 
 
 def test_learn_at_the_reference_agent_tests_shape_g3():
