@@ -395,7 +395,7 @@ def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
                     "the LLC"}
 
 
-def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadamard", fuse=None):
+def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadamard", fuse=None, layer=256):
     """The timed loop of main() at another BASELINE shape on this one GPU (same engines, same update-to-data ratio):
     updates/s of E envs, batch B, ring N."""
     import torch
@@ -405,8 +405,8 @@ def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadama
     from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     S, A = (23, 7) if robot == "panda" else (21, 6)
-    L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, dev, p_mode=_lib.P_HADAMARD if p_mode == "hadamard" else _lib.P_MATMUL, fuse=fuse)
-    sd = reference_init_state_dict(S, A, 256, seed=0)
+    L = Learner(S, A, layer, B, 1e-3, 1e-3, 0.99, dev, p_mode=_lib.P_HADAMARD if p_mode == "hadamard" else _lib.P_MATMUL, fuse=fuse)
+    sd = reference_init_state_dict(S, A, layer, seed=0)
     L.load_params(0, sd)
     L.load_params(1, sd)
     replay = ReplayBuffer(N, B, dev, seed=1000, state_size=S, action_size=A)
@@ -549,6 +549,12 @@ def extras(dev, args):
                 # ... and at configs[4]'s literal shape: 7 x 7 L / P tiles, batch 2048, ring 4e6
                 "configs[4] with P = L L^T (p_mode matmul): panda, batch 2048, ring 4e6":
                     measure_shape(dev, "panda", 2048, 4000000, E, 300, 30, p_mode="matmul"),
+                # layer sizes other than the presets' 256 (the reference takes any; its own agent test builds 128): narrower ones are
+                # stored zero-padded to 256 and run the row-split chain, wider ones the column-tile / unfused chains
+                "layer_size 128 (kuka, batch 256, ring 1e6): stored zero-padded to 256":
+                    measure_shape(dev, "kuka", 256, 1000000, E, 500, 30, layer=128),
+                "layer_size 128, batch 1024 (kuka, ring 1e6)": measure_shape(dev, "kuka", 1024, 1000000, E, 300, 30, layer=128),
+                "layer_size 512 (kuka, batch 256, ring 1e6): column tiles": measure_shape(dev, "kuka", 256, 1000000, E, 300, 30, layer=512),
             }
     finally:
         os.chdir(old)
