@@ -416,20 +416,26 @@ def test_pipelined_path_survives_api_calls_between_timesteps(scratch_cwd, monkey
     assert a["loss"] == b["loss"]
 
 
-@pytest.mark.parametrize("S,A,p_mode,action_mode", [(21, 6, "hadamard", "trunc_int"), (23, 7, "matmul", "float"), (10, 5, "matmul", "trunc_int")])
-def test_pipelined_path_on_a_ring_that_wraps(scratch_cwd, monkeypatch, S, A, p_mode, action_mode):
+@pytest.mark.parametrize("S,A,H,p_mode,action_mode", [(21, 6, 256, "hadamard", "trunc_int"), (23, 7, 256, "matmul", "float"),
+                                                      (10, 5, 128, "matmul", "trunc_int"), (21, 6, 100, "hadamard", "trunc_int")])
+def test_pipelined_path_on_a_ring_that_wraps(scratch_cwd, monkeypatch, S, A, H, p_mode, action_mode):
     """600 timesteps on a ring of 300 rows at B = 64: every append evicts the oldest row after the first 300, the prefetch does not
     hold one time in five (the row to come among the positions drawn) — the pipelined loop equals the twelve-launch loop all the way;
-    also with the textbook P = L L^T head, float actions, the Panda's and the reference test's shapes."""
+    also with the textbook P = L L^T head, float actions, the Panda's shapes, the reference agent test's network NAF(10, 5, 128) and a
+    width of 100 (layers narrower than 256 are stored zero-padded: the same launches; state_dict() in the reference's shapes)."""
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
     B, N, T = 64, 300, 600
     runs = []
     for fused in ("1", "0"):
         monkeypatch.setenv("NAF_STEP_FUSED", fused)
-        agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0, p_mode=p_mode, action_mode=action_mode)
+        agent = NAFAgent(object(), S, A, H, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0, p_mode=p_mode, action_mode=action_mode)
         acts = _drive(agent, 33, B, T, None)
         ch, L = agent._chunk, agent.learner
         assert ch.pipelined == (fused == "1")
+        sd = agent.qnetwork_main.state_dict()
+        assert tuple(sd["hidden_layer.weight"].shape) == (H, H) and tuple(sd["input_layer.weight"].shape) == (H, S) and \
+            tuple(sd["bn2.running_var"].shape) == (H,) and tuple(sd["value.weight"].shape) == (1, H)
+        assert int(sd["bn1.num_batches_tracked"]) == T
         if ch.pipelined:
             assert ch.fast_runs > 350 and ch.slow_runs > 60 and int(L.err_host[2]) == 0, (ch.fast_runs, ch.slow_runs)
         runs.append(dict(acts=acts, theta=L.theta2.clone(), m=L.adam_m.clone(), v=L.adam_v.clone(), bn=L.bn_stats.clone(),
