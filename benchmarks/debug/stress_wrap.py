@@ -1,0 +1,52 @@
+"""Hunting an intermittent mismatch of the per-timestep forms (seen once in tests/test_step_path_gpu.py::...ring_that_wraps[10-5-128-matmul]):
+the wrap scenario, repeated in ONE process, every form against the unfused loop; prints the first timestep whose action differs."""
+import os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+os.chdir(tempfile.mkdtemp())
+import logging
+import numpy as np, torch
+from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+from synth_data import make_transitions
+logging.getLogger('robotic_manipulator_rloa.utils.logger').setLevel(40)
+DEV = torch.device("cuda:0")
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+CASES = [(10, 5, 128, "matmul", "trunc_int"), (21, 6, 256, "hadamard", "trunc_int")]
+B, N, T = 64, 300, 600
+
+
+def drive(agent, S, A, seed):
+    st_, ac, rw, ns, dn = make_transitions(B + T + 1, S, A, seed=seed)
+    acts, state = [], st_[0].astype(np.float64)
+    for t in range(B + T):
+        a = agent.act(state)
+        acts.append(np.array(a, copy=True))
+        nxt = ns[t].astype(np.float64)
+        agent.step(state, a, float(rw[t]), nxt, 0)
+        state = nxt
+    torch.cuda.synchronize()
+    return np.array(acts)
+
+
+def run(S, A, H, pm, am, fused, prefetch, pipeline):
+    os.environ["NAF_STEP_FUSED"], os.environ["NAF_STEP_PREFETCH"], os.environ["NAF_STEP_PIPELINE"] = fused, prefetch, pipeline
+    agent = NAFAgent(object(), S, A, H, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0, p_mode=pm, action_mode=am)
+    acts = drive(agent, S, A, 33)
+    L, ch = agent.learner, agent._chunk
+    return dict(acts=acts, theta=L.theta2.clone(), bn=L.bn_stats.clone(), ring=agent.memory.rows.clone(), step=int(L.step_dev.item()),
+                runs=(getattr(ch, "fast_runs", 0), getattr(ch, "slow_runs", 0)), err=[int(x) for x in L.err_host[:3]])
+
+
+bad = 0
+for rep in range(REPS):
+    for (S, A, H, pm, am) in CASES:
+        ref = run(S, A, H, pm, am, "0", "1", "1")
+        for name, (f, p, q) in (("pipelined", ("1", "1", "1")), ("prefetch", ("1", "1", "0")), ("fused", ("1", "0", "0")), ("unfused again", ("0", "1", "1"))):
+            r = run(S, A, H, pm, am, f, p, q)
+            d = np.where((r["acts"] != ref["acts"]).any(axis=1))[0]
+            if len(d) or not torch.equal(r["theta"], ref["theta"]):
+                bad += 1
+                print(f"rep {rep} case {(S, A, H, pm)} {name}: first differing timestep {d[0] if len(d) else None} of {B + T} ({len(d)} differ), "
+                      f"theta equal {torch.equal(r['theta'], ref['theta'])}, bn equal {torch.equal(r['bn'], ref['bn'])}, ring equal "
+                      f"{torch.equal(r['ring'], ref['ring'])}, steps {r['step']} / {ref['step']}, fast/slow {r['runs']}, err {r['err']}", flush=True)
+    print(f"rep {rep} done, mismatching runs so far: {bad}", flush=True)

@@ -66,7 +66,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 28
+#define NAF_HIP_ABI_VERSION 29
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -516,8 +516,11 @@ int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, 
  *   sync: naf_adam_polyak_act_sync_ints() int32 of device scratch, zero-initialised ONCE by the caller, 16-byte aligned, used by
  *     this entry point only (one launch in flight per buffer);
  *   host_errors (nullable): pinned host word that counts polls whose 2-ms bound ran out (the action is then NaN: an error);
- *   host_seq (nullable): pinned host uint32 that receives the launch's ordinal (1, 2, ...: the number of calls on `sync`) once
- *     the action has been written — a host that polls it needs no stream synchronisation to read the action;
+ *   host_seq (nullable): pinned host uint32 that receives the launch's ordinal (1, 2, ...: the number of calls on `sync`) behind
+ *     the action's words — for readers that synchronise the stream (stores to host memory may pass one another on the way);
+ *   action_rec (nullable): pinned host memory, 48 bytes, 16-byte aligned: three chunks {a[3j], a[3j + 1], a[3j + 2], ordinal}, ONE
+ *     16-byte store each — a host that polls the chunks it needs (j < ceil(A / 3)) until they carry the ordinal it expects reads
+ *     the action without synchronising the stream, whatever order the stores arrive in;
  *   prefetch (nullable, HOST pointer): one more workgroup of the launch draws, gathers and takes the moments of the NEXT
  *     timestep's minibatch — naf_step_prep's arguments of the same names, on the ring as ONE more append will leave it — beside the
  *     launch's own work and behind the action's announcement to the host (what a timestep draws depends on the row it appends only
@@ -528,8 +531,8 @@ int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, 
  *     does when the record holds — reads [src_row | n_word], appends, advances the counters, hands idx_spec to idx_out — and then
  *     prefetches on the ring as it has become. The host launches this form only after it has read `valid` from host_spec; a
  *     record that does not hold here is counted in *pipe_errors (pinned host; the caller raises). host_spec (nullable, pinned host
- *     uint32[2]): [1] = whether the prefetch holds (the row to come was not among the positions drawn), then [0] = the launch's
- *     ordinal (as host_seq). copies: committed working -> public state, see naf_step_copies_t.
+ *     uint32[2], 8-byte aligned, written by ONE 8-byte store): [0] = the launch's ordinal (as host_seq), [1] = whether the prefetch
+ *     holds (the row to come was not among the positions drawn). copies: committed working -> public state, see naf_step_copies_t.
  *   obs_system_scope: obs lies in device memory the host stored into (naf_host_publish): read with system-scope loads. */
 typedef struct naf_step_prefetch {
     naf_replay_t* replay;
@@ -559,8 +562,8 @@ typedef struct naf_act_net {
 int naf_adam_polyak_act_sync_ints(void);
 int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
                         float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode, int32_t* sync,
-                        uint64_t* host_errors, uint32_t* host_seq, const naf_step_prefetch_t* prefetch, int obs_system_scope,
-                        void* stream);
+                        uint64_t* host_errors, uint32_t* host_seq, uint32_t* action_rec, const naf_step_prefetch_t* prefetch,
+                        int obs_system_scope, void* stream);
 
 /* ---- synthetic manipulator environment (stand-in for the PyBullet Environment) ---------------- */
 /* One step of E independent kinematic-chain arms on the device, emitting transition rows

@@ -223,7 +223,7 @@ _PROTOS = {
                        _vp, _u64, _vp, _vp, _f, _i, _i, _i, _vp],
     "naf_step_prep": [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "naf_adam_polyak_act_sync_ints": [],
-    "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "naf_xgmi_chunk_floats": [],
     "naf_xgmi_create": [_i, _i, _sz, C.c_double, C.POINTER(_vp)],
     "naf_xgmi_set_timeout": [_vp, C.c_double],

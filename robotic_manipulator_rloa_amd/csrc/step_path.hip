@@ -278,11 +278,10 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
     NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 3);
     // the verdict for the host (pinned words, system scope: [1] = does the prefetch hold, then [0] = this launch's ordinal)
     auto tell_host = [&](int valid) {
-        if (P.host_spec) {
-            __hip_atomic_store(P.host_spec + 1, (uint32_t)valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(P.host_spec, (uint32_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        // ONE 8-byte store {ordinal, valid}: whole in host memory or not at all (two words could pass one another on the way)
+        if (P.host_spec)
+            __hip_atomic_store((unsigned long long*)P.host_spec, ((unsigned long long)(unsigned)valid << 32) | (unsigned long long)(unsigned)epoch,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     if (SPEC && *sHit) {                                // (uniform) nothing usable: say so and go
         if (tid == 0) {
@@ -390,7 +389,7 @@ static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word
         return NAF_ERR_ARG;
     if ((src_row == nullptr) != (n_word == nullptr) || ((uintptr_t)src_row & 15) != 0 || ((uintptr_t)n_word & 3) != 0) return NAF_ERR_ARG;
     if (((uintptr_t)row_out & 15) != 0 || (row_out && !src_row)) return NAF_ERR_ARG;
-    if (((uintptr_t)spec_rec & 15) != 0 || ((uintptr_t)idx_spec & 3) != 0) return NAF_ERR_ARG;
+    if (((uintptr_t)spec_rec & 15) != 0 || ((uintptr_t)idx_spec & 3) != 0 || ((uintptr_t)host_spec & 7) != 0) return NAF_ERR_ARG;
     if (action_mode != NAF_ACTION_TRUNC_INT && action_mode != NAF_ACTION_FLOAT) return NAF_ERR_ARG;
     if ((out_ld & 3) != 0 || out_ld < naf_round_up(naf_row_off_done(h->S, h->A) + 1, 4) || out_ld > h->row_floats) return NAF_ERR_ARG;
     k4 = (h->S + 3) / 4;
@@ -507,6 +506,7 @@ struct AdamActArgs {
     int wh_wgs;                           // workgroups that step the heads' weights
     uint64_t* host_errors;                // nullable pinned host word: timed-out polls
     uint32_t* host_seq;                   // nullable pinned host word: = the launch's epoch once the action has been written
+    uint32_t* act_rec;                    // nullable pinned host record: 3 x {a[3j], a[3j + 1], a[3j + 2], epoch}, a store each
 };
 
 // one float4 / one float of the flat buffers through the pending update (adam_one: the code every other launch of the step runs);
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
     __shared__ __attribute__((aligned(16))) float sW[64 * ACT_MAX_S + 3 * 64]; // layer-1 workgroups: their 64 rows of W1, b1, g1, be1
     __shared__ float sObs[ACT_MAX_S];
     __shared__ float sHeads[HEAD_MAX_LDH];
+    __shared__ float sActOut[NAF_MAX_A + 1];
     __shared__ float sL[PMODE == NAF_P_MATMUL ? 8 * LT_STRIDE : 1];
     __shared__ int sTimed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -805,17 +806,31 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         }
         __syncthreads();
         AA_TL(3);
-        naf_act_noise_body_z<PMODE>(sHeads, sL, P.action_out, zn, P.noise_scale, 0, tid < 8, P.A, tid);
+        // (the action lands in LDS first: its lanes hand it to memory below, once as plain words and once as a self-validating record)
+        naf_act_noise_body_z<PMODE>(sHeads, sL, sActOut, zn, P.noise_scale, 0, tid < 8, P.A, tid);
+        __syncthreads();
         AA_TL(4);
-        if (tid < 64) {                                     // (the first wave: it holds the lanes that wrote the action)
+        if (tid < 64) {                                     // (the first wave)
+            if (tid < P.A) P.action_out[tid] = sActOut[tid];
+            if (P.act_rec && tid < 3) {
+                // How the HOST learns the action without synchronising the stream: 16-byte chunks {a[3j], a[3j+1], a[3j+2], ordinal},
+                // one store each — a chunk is in host memory whole or not at all, and the host takes the action from the chunks
+                // once every chunk it needs carries this launch's ordinal. (Round 5's first form announced the action by a word of
+                // its own, stored after the action's stores had been acknowledged: writes to host memory may pass one another on
+                // the way — relaxed ordering — and one timestep in 1e4 .. 1e5 read the ordinal before the action had landed.)
+                const float a0 = 3 * tid + 0 < P.A ? sActOut[3 * tid + 0] : 0.f, a1 = 3 * tid + 1 < P.A ? sActOut[3 * tid + 1] : 0.f;
+                const float a2 = 3 * tid + 2 < P.A ? sActOut[3 * tid + 2] : 0.f;
+                const naf_u32x4 rec = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, a2),
+                                       (unsigned)epoch};
+                __builtin_amdgcn_raw_buffer_store_b128(rec, naf_buf(P.act_rec), 16u * (unsigned)tid, 0, 17);
+            }
             if (tid == 0) {
                 if (timed) aa_count_timeout(P);
                 *P.counter_dev = ctr + 1;
                 P.sync[0] = epoch;
             }
             if (P.host_seq) {
-                // the action's stores (to fine-grained host memory: written through) are acknowledged before the word that announces
-                // them leaves — no release fence, which would write back this XCD's whole L2 first
+                // (the launch's ordinal as a word of its own, behind the action's plain words: for readers that synchronise the stream)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (tid == 0) __hip_atomic_store(P.host_seq, (uint32_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -827,8 +842,8 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
 
 extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
                                    float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode,
-                                   int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, const naf_step_prefetch_t* prefetch,
-                                   int obs_system_scope, void* stream) {
+                                   int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, uint32_t* action_rec,
+                                   const naf_step_prefetch_t* prefetch, int obs_system_scope, void* stream) {
     if (!adam || !net || !obs || !action_out || !counter_dev || !sync || ((uintptr_t)sync & 15) != 0) return NAF_ERR_ARG;
     AdamActArgs P;
     memset(&P, 0, sizeof(P));
@@ -866,6 +881,8 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     P.sync = sync;
     P.host_errors = host_errors;
     P.host_seq = host_seq;
+    P.act_rec = action_rec;
+    if (((uintptr_t)action_rec & 15) != 0) return NAF_ERR_ARG;
     P.wh_wgs = (int)(((int64_t)NHP * (HP / 4) + AA_THREADS - 1) / AA_THREADS);
     const int grid = AA_L1_WGS + P.wh_wgs + AA_L2_WGS + 1;
     StepPrepArgs SP;

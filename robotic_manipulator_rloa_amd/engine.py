@@ -160,9 +160,10 @@ class TrainChunk:
         self._spec_armed = False           # the last launch was one of the pipelined graphs: a verdict on its prefetch will come
         self._sig, self._r_total = None, -1
         self.fast_runs = self.slow_runs = 0
-        # fused tail: the launch writes its ordinal to a pinned host word behind the action (ActPath.seq) — the host learns that
-        # a run() has passed by polling that word instead of synchronising an event / the stream
-        self._seq_np = actor.seq_np if self.fused_tail else None
+        # fused tail: the launch hands its action to the host as self-validating 16-byte chunks {three components, ordinal}
+        # (ActPath.act_rec) — the host learns that a run() has passed by polling the chunks' ordinals instead of synchronising an
+        # event / the stream, and takes the action from the chunks (wait_tail). _seq_np = chunk 0's ordinal.
+        self._seq_np = actor.ordinal_np if self.fused_tail else None
         self._seq_prev = 0
         self._inflight = False             # a run() whose ordinal the host has not seen yet
         self._exec = None
@@ -216,7 +217,7 @@ class TrainChunk:
         self.step_work = L.step_dev.clone()
         self.loss_work = torch.zeros_like(self.loss_parts[0])
         self.host_spec = torch.zeros(2, dtype=torch.int32).pin_memory()
-        self._host_spec_np = self.host_spec.numpy()
+        self._host_spec_np = self.host_spec.numpy().view(np.uint64)      # {ordinal, valid}: ONE 8-byte store of the launch, one load here
         bw = self.bn_work.data_ptr()
         self._net_work = _lib.ActNet.from_buffer_copy(a._net)
         self._net_work.running_mean1, self._net_work.running_var1 = bw, bw + 4 * H
@@ -351,12 +352,21 @@ class TrainChunk:
         if not self._inflight:
             return
         sq, prev, n = self._seq_np, self._seq_prev, 0
-        while sq[0] == prev:
+        a = self._tail_actor
+        rec, ords = a.rec_np, a._rec_ords
+        while True:
+            # every chunk the action needs carries the new ordinal (the chunks are stores of their own: they may land in any order)
+            want = sq[0]
+            if want != prev and all(rec[w] == want for w in ords):
+                break
             n += 1
             if n > 4000000:                 # (seconds: something is wrong — let the runtime say what)
                 torch.cuda.current_stream().synchronize()
-                if sq[0] == prev:
+                want = sq[0]
+                if want == prev or not all(rec[w] == want for w in ords):
                     raise _lib.NafHipError("the update graph finished without its tail launch writing an action")
+                break
+        a.actions_np[0, :] = a.rec_f[a._rec_words]
         self._inflight = False
         if self._err_np[2]:
             raise _lib.NafHipError("the pipelined timestep found its prefetched minibatch not to hold although the host had read that "
@@ -434,13 +444,16 @@ class TrainChunk:
                L.grad._version, L.partials._version, r.rows._version, r.meta._version, r._sample_ctr._version)
         ok = False
         if brings_row and self._spec_armed and sig == self._sig and r._total_added == self._r_total + 1 and r._pending == 0:
-            hs, want, n = self._host_spec_np, self._seq_prev, 0
-            while hs[0] != want:
+            hs, want, n = self._host_spec_np, int(self._seq_prev) & 0xFFFFFFFF, 0
+            v = int(hs[0])
+            while (v & 0xFFFFFFFF) != want:
                 n += 1
                 if n > 2000000:                 # (the verdict is a few microseconds behind the action: something is wrong)
                     torch.cuda.current_stream().synchronize()
+                    v = int(hs[0])
                     break
-            ok = hs[0] == want and hs[1] == 1
+                v = int(hs[0])
+            ok = (v & 0xFFFFFFFF) == want and (v >> 32) == 1
         self._spec_armed = True
         self._sig, self._r_total = sig, r._total_added
         if ok:

@@ -18,6 +18,8 @@ Design:
 from __future__ import annotations
 
 import os
+
+import numpy as np
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -939,11 +941,19 @@ class ActPath:
                          [0, H * lay.S, H * lay.S + H, H * lay.S + 2 * H, H * lay.S + 3 * H, H * lay.S + 3 * H + H * H,
                           H * lay.S + 4 * H + H * H, H * lay.S + 5 * H + H * H, H * lay.S + 6 * H + H * H] and
                          lay.P == H * lay.S + 6 * H + H * H + lay.NHP * lay.HP)
-        self.sync = self.seq = self.seq_np = None
+        self.sync = self.seq = self.seq_np = self.ordinal_np = None
         if self.can_ride:
             self.sync = torch.zeros(learner.lib.naf_adam_polyak_act_sync_ints(), dtype=torch.int32, device=dev)
             self.seq = torch.zeros(2, dtype=torch.int32).pin_memory()
             self.seq_np = self.seq.numpy()
+            # the action as the launch hands it to a host that does not synchronise the stream: three 16-byte chunks
+            # {a[3j], a[3j + 1], a[3j + 2], ordinal}, one store each (naf_adam_polyak_act: action_rec); `ordinal_np` = chunk 0's
+            self.act_rec = torch.zeros(16, dtype=torch.int32).pin_memory()
+            self.rec_np = self.act_rec.numpy()
+            self.rec_f = self.rec_np.view(np.float32)
+            self.ordinal_np = self.rec_np[3:4]
+            self._rec_words = [w for w in (0, 1, 2, 4, 5, 6, 8, 9)][:lay.A]
+            self._rec_ords = [4 * j + 3 for j in range((lay.A + 2) // 3)]
             bnp = learner.bn_stats.data_ptr()
             self._net = _lib.ActNet(lay.S, lay.A, H, lay.NHP, lay.HP, *[seg[k].offset for k in
                                     ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "Wh")],
@@ -961,7 +971,7 @@ class ActPath:
         check(L.lib.naf_adam_polyak_act(_lib.C.byref(adam_args if adam_args is not None else L._adam_args),
                                         _lib.C.byref(net if net is not None else self._net), obs_ptr or ptr(self.obs), ptr(self.Gh),
                                         ptr(self.actions), self.seed, ptr(self.counter), float(noise_scale), L.p_mode,
-                                        ptr(self.sync), L.err_host.data_ptr() + 8, ptr(self.seq),
+                                        ptr(self.sync), L.err_host.data_ptr() + 8, ptr(self.seq), ptr(self.act_rec),
                                         _lib.C.byref(prefetch) if prefetch is not None else None, int(bool(obs_system_scope)),
                                         stream_ptr()), "adam_polyak_act")
         return self.actions

@@ -448,6 +448,31 @@ def test_pipelined_path_on_a_ring_that_wraps(scratch_cwd, monkeypatch, S, A, H, 
         assert torch.equal(a[k], b[k]), k
     assert a["loss"] == b["loss"]
 
+
+def test_free_running_loop_never_takes_a_stale_action(scratch_cwd, monkeypatch):
+    """The host learns the graph's action WITHOUT synchronising the stream. Round 5's first form polled an ordinal the launch stored
+    behind the action's words: stores to host memory may pass one another on the way, and on some boxes one timestep in 1e4 read
+    the ordinal before the action had landed — the previous action went into the ring, and the run parted from the twelve-launch
+    loop (58 of 500 runs of 600 timesteps on the box that showed it; benchmarks/debug/stress_variants.py). The action now travels as
+    16-byte chunks that carry the ordinal themselves. 40 free-running runs of the pipelined loop and 20 of the plain fused one
+    against the unfused loop: every action, every parameter."""
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    S, A, B, N, T = 21, 6, 64, 300, 600
+
+    def run(fused, prefetch, pipeline):
+        monkeypatch.setenv("NAF_STEP_FUSED", fused)
+        monkeypatch.setenv("NAF_STEP_PREFETCH", prefetch)
+        monkeypatch.setenv("NAF_STEP_PIPELINE", pipeline)
+        agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+        acts = _drive(agent, 33, B, T, None)
+        return acts, agent.learner.theta2.clone()
+    ref_acts, ref_theta = run("0", "1", "1")
+    for form, n in ((("1", "1", "1"), 40), (("1", "0", "0"), 20)):
+        for rep in range(n):
+            acts, theta = run(*form)
+            d = np.where((acts != ref_acts).any(axis=1))[0]
+            assert len(d) == 0 and torch.equal(theta, ref_theta), (form, rep, int(d[0]) if len(d) else None)
+
 def test_per_timestep_path_is_six_or_seven_launches(scratch_cwd, monkeypatch):
     """The update graph of NAFAgent.step() at num_updates = 1 (profiles/r05_api_path_kernel_stats.csv has the same counts from
     rocprofv3). Pipelined (default): naf_adam_polyak_act — the append, the waiting gradient's optimizer step, act(), the prefetch —
