@@ -133,22 +133,10 @@ __device__ __forceinline__ static void bb_moments_body(Load4 load4, BmShared& S,
             const float* pb = sX + (hrows * half + g) * XS + 16 * tn + r;
             int kend = rows - hrows * half;
             kend = kend < 0 ? 0 : (kend > hrows ? hrows : (kend + 3) & ~3);
-            // eight steps' operands at a time, all requested before the first MFMA: as a plain loop every step was an LDS round trip
-            // in front of a dependent MFMA (94 ns per step: 3.0 of the per-timestep launch's 15 us at B = 256). Steps past `kend`
-            // take zeros (they add +0: the same bits), never the other half's rows.
-            for (int kk = 0; kk < kend; kk += 32) {
-                float av[8], bv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = kk + 4 * j;
-                    const bool on = k < kend;
-                    av[j] = pa[(on ? k : 0) * XS];
-                    bv[j] = pb[(on ? k : 0) * XS];
-                    if (!on) av[j] = bv[j] = 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
-            }
+            // (requesting eight steps' operands ahead of their MFMAs measured SLOWER: 49.7 against 48.7 us per timestep at B = 256,
+            //  A/B/A/B on one box — the compiler's own schedule of this loop already overlaps the LDS reads with the matrix pipe)
+#pragma unroll 4
+            for (int kk = 0; kk < kend; kk += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk * XS], pb[kk * XS], acc, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) dacc[e] += (double)acc[e];
         }
