@@ -455,7 +455,7 @@ def extras(dev, args):
         # configs[0]'s literal shape (B = 64, ring 1e5) and the same loop at configs[1]'s batch (B = 256). Steady state as
         # SURVEY.md section 8(d) defines it: the ring filled to capacity before anything is timed (the sampler's redraw rounds and
         # the gather's locality are then those of a long run, not of its first thousand steps).
-        def api_path(batch, n_api):
+        def api_path(batch, n_api, env_us=0.0):
             env = SyntheticEnvironment(A)
             agent = NAFAgent(env, S, A, 256, batch, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, dev, 0)
             m = agent.memory
@@ -471,7 +471,10 @@ def extras(dev, args):
             def steps(n, state):
                 for _ in range(n):
                     a = agent.act(state)
+                    t_env = time.perf_counter()
                     nxt, r_, d = env.step(a)
+                    while env_us and (time.perf_counter() - t_env) * 1e6 < env_us:      # (a slower environment: busy waiting)
+                        pass
                     agent.step(state, a, r_, nxt, d)
                     state = env.reset(False) if d else nxt
                 return state
@@ -499,6 +502,12 @@ def extras(dev, args):
                                              "(numpy stand-in), B=64, N=1e5 (configs[0] shape), naf_algorithm.py:249-261")
         res["reference_api_path_b256"] = api_path(256, n_api)
         res["reference_api_path_b256"]["what"] = "the same loop at configs[1]'s batch (B=256, N=1e5)"
+        # ... and with an environment that takes 100 us per step (a real simulator takes at least that): what the framework adds to a
+        # timestep once the learn() chain runs while the host steps the environment
+        slow = api_path(256, 2000, env_us=100.0)
+        slow["what"] = "the same loop (B=256) with env.step padded to 100 us by busy waiting"
+        slow["framework_us_per_timestep"] = round(1e6 / slow["value"] - 100.0, 1)
+        res["reference_api_path_b256_env_100us"] = slow
         if not args.no_cpu_baseline:
             from oracle.torch_cpu_port import time_baseline
             cb = time_baseline(S, A, 256, 64, 100000, budget_s=6.0, threads=8)
