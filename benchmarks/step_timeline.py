@@ -85,11 +85,10 @@ for _ in range(REPS):
         acc[k] += np.nan_to_num(v, nan=0.0)
 REPS = max(1, n_used)
 if PIPELINED:
-    print(f"B = {B}, pipelined graph (adam_act: append + the waiting gradient's step + act() + prefetch, then the chain): microseconds "
-          f"since adam_act's entry, mean of {REPS} timesteps (first workgroup | last workgroup; 0 = no mark; adam_act first-row "
-          f"slots 13 / 14 = the prefetching workgroup's entry / exit)")
-    print("step_prep's SECOND row = the prefetching workgroup of adam_act (slots 0 - 6 main phases, 7 - 12 moments, 13 - 15 draw); its first "
-          "row is stale (the last timestep that started over)")
+    print(f"B = {B}, pipelined graph (adam_act: the waiting gradient's step + act() + commit, then the chain) and, beside it on a stream "
+          f"of its own, the prefetch launch (step_prep rows: append + depth-2 prefetch): microseconds since adam_act's entry, mean of "
+          f"{REPS} timesteps (first workgroup | last workgroup; 0 = no mark)")
+    print("step_prep rows (one workgroup: both rows are it): slots 0 - 6 main phases, 7 - 12 moments, 13 - 15 draw")
     order = ("adam_act", "step_prep", "bb_layer1", "bb_linear_stats", "bb_layer2_head", "gemm_bundle", "finish")
 else:
     print(f"B = {B}: microseconds since step_prep's entry, mean of {REPS} timesteps (first workgroup | last workgroup; 0 = no mark)")

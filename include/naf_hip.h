@@ -66,7 +66,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 29
+#define NAF_HIP_ABI_VERSION 30
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -88,6 +88,15 @@ int naf_host_publish(void* dst_device, const void* src_host, size_t bytes);
 /* the same followed by hipGraphLaunch(graph_exec, stream) — one call per timestep of the per-timestep path (bytes == 0: launch
  * only). graph_exec: a hipGraphExec_t (e.g. torch.cuda.CUDAGraph.raw_cuda_graph_exec()). */
 int naf_host_publish_launch(void* dst_device, const void* src_host, size_t bytes, void* graph_exec, void* stream);
+/* A device allocation of the library's own for such hand-overs (plain hipMalloc: CPU-mapped on a large-BAR device whatever the
+ * framework allocator does — torch's expandable segments and memory pools need not be), and the proof that the hand-over works
+ * on this machine: naf_host_store_selftest stores n distinct patterns of 65 words through the path's own memcpy + fence and has a
+ * kernel read each back with the path's own loads (system scope) before the next is stored. Returns the number of patterns that
+ * came back wrong (0: use the hand-over; > 0: do not — the caller falls back to pinned host memory and says so), < 0 on an error.
+ * The hand-over carries NAFAgent.step()'s transition (naf_algorithm.py:129-142) to the graph of the timestep. */
+int naf_host_store_alloc(size_t bytes, void** out_device_ptr);
+int naf_host_store_free(void* device_ptr);
+int naf_host_store_selftest(void* dst_device, int n_patterns, void* stream);
 
 /* ---- replay buffer: HBM ring of transition rows ------------------------------------------ */
 /* replaces ReplayBuffer.__init__ (utils/replay_buffer.py:16-30): deque(maxlen=buffer_size) */
@@ -544,7 +553,8 @@ typedef struct naf_step_prefetch {
     float* mom;
     int B, without_replacement;
     int32_t* spec_rec;         /* NAF_STEP_SPEC_INTS int32 */
-    int mode;                  /* 1: prefetch only; 2: this timestep's append, then the prefetch */
+    int mode;                  /* 1: prefetch only; 2: this timestep's append, then the prefetch (naf_step_prefetch only);
+                                * 0 (naf_adam_polyak_act only): no prefetching workgroup, the launch commits `copies` */
     const float* src_row;      /* mode 2 */
     const int32_t* n_word;     /* mode 2 */
     float* row_out;            /* mode 2, nullable */
@@ -552,7 +562,28 @@ typedef struct naf_step_prefetch {
     uint32_t* host_spec;       /* nullable */
     uint64_t* pipe_errors;     /* nullable */
     naf_step_copies_t copies;
+    /* round 6 (ABI 30) */
+    int depth;                 /* 0 / 1: the NEXT timestep's minibatch; 2: the one behind it (two appends and one draw ahead) */
+    int32_t* spec_rec_in;      /* mode 2: the record / indices of the minibatch THIS timestep consumes; NULL: spec_rec / idx_spec */
+    int32_t* idx_spec_in;
+    uint32_t* pf_seq;          /* device word owned by the prefetching workgroup, zero-initialised by the caller: the ordinal its
+                                * verdicts carry (+ 1 per prefetch); required with host_spec */
 } naf_step_prefetch_t;
+/* The prefetch as a launch of its own (one workgroup; csrc/step_path.hip, step_prefetch_kernel) — what the reference does at
+ * utils/replay_buffer.py:55-65 for a LATER timestep of the loop of naf_algorithm.py:249-261, taken off that loop's critical path.
+ *   mode 1: draw, gather and take the moments of the minibatch `depth` appends ahead of the ring as found; nothing is committed.
+ *   mode 2: first this timestep's part — read [src_row | n_word], check the record spec_rec_in against the ring and the stream
+ *     position found (a mismatch is counted in *pipe_errors), append, advance the counters, hand idx_spec_in to idx_out — then
+ *     prefetch `depth` appends ahead of the ring as that leaves it.
+ *   depth 2: the minibatch is void if EITHER of the two rows to come is among the positions drawn; the record names the state
+ *     the consuming launch must find before its append (one append and one draw further on than the state this launch left).
+ *   The verdict {ordinal, valid} goes to host_spec in ONE 8-byte store behind an agent-scope release of everything the workgroup
+ *   wrote: a host that has read it may launch, on any stream, work that reads the minibatch, the ring or the counters.
+ * naf_step_launch: naf_host_publish (bytes == 0: nothing to publish) + hipGraphLaunch(graph_exec, stream) + naf_step_prefetch(
+ *   prefetch, side_stream) (prefetch == NULL: none) — one timestep of NAFAgent.step() in one trip through the FFI. */
+int naf_step_prefetch(const naf_step_prefetch_t* prefetch, void* stream);
+int naf_step_launch(void* dst_device, const void* src_host, size_t bytes, void* graph_exec, void* stream,
+                    const naf_step_prefetch_t* prefetch, void* side_stream);
 typedef struct naf_act_net {
     int S, A, H, NHP, HP;
     int64_t off_W1, off_b1, off_g1, off_be1, off_W2, off_b2, off_g2, off_be2, off_Wh;

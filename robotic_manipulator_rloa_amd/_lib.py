@@ -223,6 +223,11 @@ _PROTOS = {
                        _vp, _u64, _vp, _vp, _f, _i, _i, _i, _vp],
     "naf_step_prep": [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "naf_adam_polyak_act_sync_ints": [],
+    "naf_host_store_alloc": [_sz, C.POINTER(_vp)],
+    "naf_host_store_free": [_vp],
+    "naf_host_store_selftest": [_vp, _i, _vp],
+    "naf_step_prefetch": [_vp, _vp],
+    "naf_step_launch": [_vp, _vp, _sz, _vp, _vp, _vp, _vp],
     "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "naf_xgmi_chunk_floats": [],
     "naf_xgmi_create": [_i, _i, _sz, C.c_double, C.POINTER(_vp)],
@@ -298,7 +303,8 @@ class StepPrefetch(C.Structure):
                 ("out_rows", C.c_void_p), ("out_ld", C.c_int), ("action_mode", C.c_int), ("mom", C.c_void_p), ("B", C.c_int),
                 ("without_replacement", C.c_int), ("spec_rec", C.c_void_p), ("mode", C.c_int), ("src_row", C.c_void_p),
                 ("n_word", C.c_void_p), ("row_out", C.c_void_p), ("idx_out", C.c_void_p), ("host_spec", C.c_void_p),
-                ("pipe_errors", C.c_void_p), ("copies", StepCopies)]
+                ("pipe_errors", C.c_void_p), ("copies", StepCopies), ("depth", C.c_int), ("spec_rec_in", C.c_void_p),
+                ("idx_spec_in", C.c_void_p), ("pf_seq", C.c_void_p)]
 
 
 class GemmBn2Bwd(C.Structure):

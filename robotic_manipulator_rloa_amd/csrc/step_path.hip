@@ -68,8 +68,12 @@ struct StepPrepArgs {
     float* mom;                // [2][KP + KP * KP]
     int B, without_replacement, hash_bits;
     // the prefetch of the NEXT timestep's minibatch (see step_prep_body): its record and the positions it drew
-    int32_t* spec_rec;         // nullable: SP_REC_INTS ints
-    int32_t* idx_spec;         // nullable [B]
+    int32_t* spec_rec;         // nullable: SP_REC_INTS ints — MODE 0: the record to check; MODE 1 / 2: the record this prefetch LEAVES
+    int32_t* idx_spec;         // nullable [B] — ... and the positions it drew
+    int32_t* spec_rec_in;      // MODE 2: the record / positions of the minibatch THIS timestep consumes (at depth 1 the same buffers
+    int32_t* idx_spec_in;      //         as the ones it leaves; at depth 2 the ones left two launches ago); MODE 0: == spec_rec / idx_spec
+    int depth;                 // MODE 1 / 2: how many appends lie between the ring as found (MODE 2: as left) and the draw: 1 | 2
+    uint32_t* pf_seq;          // nullable device word owned by the prefetching workgroup: the ordinal its verdicts carry
     // the pipelined form (step_prep_body, MODE 2) and the learner's working / public state (`copies`)
     uint32_t* host_spec;       // nullable pinned host words {ordinal, valid}: the prefetch's verdict where the host reads it
     uint64_t* pipe_errors;     // nullable pinned host word: MODE 2 launches whose record did not hold (a host-side logic error)
@@ -117,11 +121,20 @@ __device__ __forceinline__ static float4 sp_trunc(float4 v, int f0, int lo, int 
 //         adam_act_kernel; this workgroup appends the row (its minibatch is in place, and so is the gradient the chain has taken
 //         from it while the host stepped the environment), hands the prefetched indices over, and prefetches again. It checks the
 //         record all the same: a mismatch here is a host-side logic error and is counted where the host raises.
+// DEPTH (P.depth, MODE 1 / 2; round 6): how many appends lie between the ring as the prefetch finds (MODE 2: leaves) it and the draw.
+//   1: the next timestep's minibatch, as above. 2: the one BEHIND it — the ring as two more appends will leave it, the stream
+//   position one draw further on, void if either of the two rows to come is among the positions drawn (2 B / fill). With the
+//   minibatch of timestep t + 1 in place before timestep t's graph starts, that graph's chain does not wait for this workgroup any
+//   more: the depth-2 prefetch is a launch of its OWN (step_prefetch_kernel) on a second stream, beside the graph (a fork and a join
+//   inside a hipGraph cost 30 us on this runtime: benchmarks/probe/graph_branch.hip). Three sets of {minibatch, moments, indices,
+//   record} rotate: the one timestep t consumes (spec_rec_in / idx_spec_in), the one the chain of its graph reads, the one this
+//   launch fills. Ordering across the two streams is by construction: the host launches the graph of timestep t + 1 only after it has
+//   read this launch's verdict, and the verdict is stored behind a release of everything the workgroup wrote.
 // `copies`: up to three word ranges copied at the start (MODE 0: public -> working state of the learner, the reset that discards
 // what a chain run on a prefetch that did not hold has left; MODE 1 / 2: working -> public, the commit of the update the launch's
 // other workgroups apply). 4-byte words, ranges that no other workgroup of the launch writes.
 template <int K4, bool CACHE, int MODE>
-__device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, unsigned char* sp_smem, float4* sNew, int* sHit, int epoch) {
+__device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, unsigned char* sp_smem, float4* sNew, int* sHit) {
     constexpr bool SPEC = MODE != 0;                    // the draw is for the NEXT timestep
     constexpr bool APPEND = MODE != 1;                  // reads [row | count] and appends for THIS timestep
     constexpr int KP = 4 * K4, REC = KP + KP * KP;
@@ -137,6 +150,9 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
     int* vals = (int*)sp_smem;
     const int tid = threadIdx.x, B = P.B;
     const int rf4 = 1 << P.rf4_shift;
+    // the ordinal this workgroup's verdict will carry: a word nobody else writes (round 5 derived it from adam_act_kernel's epoch,
+    // which the launch's last workgroup rewrites without waiting for this one)
+    const unsigned pf_epoch = (SPEC && P.pf_seq) ? *P.pf_seq + 1u : 0u;
     NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 0);
 
     // ---- ReplayBuffer.add: 0 or 1 rows, from (pinned host) memory -------------------------------------------------------
@@ -169,12 +185,12 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
     // the prefetch's record, as the previous timestep's last launch left it (a launch boundary ago: plain loads)
     bool take = false;
     int ispec[4] = {0, 0, 0, 0};                        // (its indices: requested beside the record, whether they will be wanted or not)
-    if (APPEND && P.spec_rec) {
-        if (P.idx_out && P.idx_spec) {
+    if (APPEND && P.spec_rec_in) {
+        if (P.idx_out && P.idx_spec_in) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ispec[k] = P.idx_spec[tid + SP_THREADS * k < B ? tid + SP_THREADS * k : 0];
+            for (int k = 0; k < 4; ++k) ispec[k] = P.idx_spec_in[tid + SP_THREADS * k < B ? tid + SP_THREADS * k : 0];
         }
-        const int4 ra = ((const int4*)P.spec_rec)[0], rb = ((const int4*)P.spec_rec)[1];
+        const int4 ra = ((const int4*)P.spec_rec_in)[0], rb = ((const int4*)P.spec_rec_in)[1];
         const uint64_t r_ctr = (uint64_t)(uint32_t)ra.z | ((uint64_t)(uint32_t)ra.w << 32);
         const uint64_t r_head = (uint64_t)(uint32_t)rb.x | ((uint64_t)(uint32_t)rb.y << 32);
         const uint64_t r_size = (uint64_t)(uint32_t)rb.z | ((uint64_t)(uint32_t)rb.w << 32);
@@ -202,9 +218,9 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
                 P.meta[META_TOTAL] = total + 1ull;
             }
             *P.counter = ctr + 1;
-            if (P.spec_rec) {
-                P.spec_rec[SP_REC_VALID] = 0;                  // (a record serves one timestep)
-                P.spec_rec[take ? SP_REC_TAKEN : SP_REC_DRAWN] += 1;
+            if (P.spec_rec_in) {
+                P.spec_rec_in[SP_REC_VALID] = 0;               // (a record serves one timestep)
+                P.spec_rec_in[take ? SP_REC_TAKEN : SP_REC_DRAWN] += 1;
             }
         }
     };
@@ -214,7 +230,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
             __hip_atomic_fetch_add((unsigned long long*)P.pipe_errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();                                // every thread has read {head, size, counter, record} before thread 0 rewrites them
         store_row_and_counters();
-        if (P.idx_out && P.idx_spec) {
+        if (P.idx_out && P.idx_spec_in) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (tid + SP_THREADS * k < B) P.idx_out[tid + SP_THREADS * k] = ispec[k];
@@ -231,11 +247,21 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
         total += (uint64_t)n;
         ctr += 1;
     }
+    int newpos1 = -1;                                   // (depth 2: the second row that does not exist yet)
+    uint64_t rec_ctr = ctr, rec_head = head, rec_size = size;      // what the launch that CONSUMES the prefetch must find before its append
     if (SPEC) {
         n = 1;                                          // the ring as the next append will leave it
         head2 = head + 1 == P.cap ? 0 : head + 1;
         size2 = size + 1 > P.cap ? P.cap : size + 1;
         newpos = (int)head;
+        if (P.depth == 2) {                             // ... and the one behind it: another timestep's append and draw lie in between
+            rec_ctr = ctr + 1;
+            rec_head = head2;
+            rec_size = size2;
+            newpos1 = (int)head2;
+            head2 = head2 + 1 == P.cap ? 0 : head2 + 1;
+            size2 = size2 + 1 > P.cap ? P.cap : size2 + 1;
+        }
         if (tid == 0) *sHit = 0;                        // (visible behind the draw's barriers)
     }
     if (!SPEC && !cache) {
@@ -245,7 +271,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
     NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 1);
 
     // ---- random.sample: the chunked sampler's body on the ring as the append leaves it ---------------------------------------
-    replay_sample_body(vals, tid, SP_THREADS, size2, ctr, P.seed, B, P.without_replacement, P.hash_bits);
+    replay_sample_body(vals, tid, SP_THREADS, size2, SPEC ? rec_ctr : ctr, P.seed, B, P.without_replacement, P.hash_bits);
     NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 2);
     const uint64_t base = head2 + P.cap - size2;        // physical position of deque element 0 (oldest)
     int mypos[4], myidx[4];
@@ -262,7 +288,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
         pos = pos >= P.cap ? pos - P.cap : pos;
         pos = pos >= P.cap ? pos - P.cap : pos;
         mypos[k] = (int)pos;
-        if (SPEC && t < B && mypos[k] == newpos) *sHit = 1;       // the row that does not exist yet
+        if (SPEC && t < B && (mypos[k] == newpos || mypos[k] == newpos1)) *sHit = 1;       // a row that does not exist yet
     }
     // (sPos is LDS of its own; the draw's table is dead and becomes the moments' staging area behind the barriers below)
     int32_t* const idx_dst = SPEC ? P.idx_spec : P.idx_out;
@@ -276,18 +302,24 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
     }
     __syncthreads();                                    // (!cache: the appended row's store has completed too — a workgroup-scope release)
     NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 3);
-    // the verdict for the host (pinned words, system scope: [1] = does the prefetch hold, then [0] = this launch's ordinal)
+    // the verdict for the host (pinned words, system scope: [1] = does the prefetch hold, [0] = this workgroup's ordinal). Thread 0,
+    // behind a barrier every wave reaches with its stores acknowledged: the host launches work on ANOTHER stream on the strength of
+    // this word (the graph whose chain reads the minibatch; the next prefetch, which reads the ring and the counters), so
+    // everything the workgroup wrote is released to the device first.
     auto tell_host = [&](int valid) {
-        // ONE 8-byte store {ordinal, valid}: whole in host memory or not at all (two words could pass one another on the way)
-        if (P.host_spec)
-            __hip_atomic_store((unsigned long long*)P.host_spec, ((unsigned long long)(unsigned)valid << 32) | (unsigned long long)(unsigned)epoch,
+        if (P.pf_seq) *P.pf_seq = pf_epoch;
+        if (P.host_spec) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // ONE 8-byte store {ordinal, valid}: whole in host memory or not at all (two words could pass one another on the way)
+            __hip_atomic_store((unsigned long long*)P.host_spec, ((unsigned long long)(unsigned)valid << 32) | (unsigned long long)pf_epoch,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     };
     if (SPEC && *sHit) {                                // (uniform) nothing usable: say so and go
-        if (tid == 0) {
-            if (P.spec_rec) P.spec_rec[SP_REC_VALID] = 0;
-            tell_host(0);
-        }
+        if (tid == 0 && P.spec_rec) P.spec_rec[SP_REC_VALID] = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) tell_host(0);
         return;
     }
 
@@ -350,23 +382,27 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
             if (t < B && idx_dst) idx_dst[t] = myidx[k];
         }
     }
-    if (SPEC && tid == 0) {
-        if (P.spec_rec) {
-            // what was assumed: the state this workgroup found (MODE 2: left), which the next timestep's launch must find unchanged
-            // before its append
+    if (SPEC) {
+        if (tid == 0 && P.spec_rec) {
+            // what was assumed: the state the launch that consumes this minibatch must find before its append — at depth 1 the state
+            // this workgroup found (MODE 2: left), at depth 2 that state one append and one draw further on
             int4 ra, rb;
             ra.x = 1;
             ra.y = B;
-            ra.z = (int)(uint32_t)ctr;
-            ra.w = (int)(uint32_t)(ctr >> 32);
-            rb.x = (int)(uint32_t)head;
-            rb.y = (int)(uint32_t)(head >> 32);
-            rb.z = (int)(uint32_t)size;
-            rb.w = (int)(uint32_t)(size >> 32);
+            ra.z = (int)(uint32_t)rec_ctr;
+            ra.w = (int)(uint32_t)(rec_ctr >> 32);
+            rb.x = (int)(uint32_t)rec_head;
+            rb.y = (int)(uint32_t)(rec_head >> 32);
+            rb.z = (int)(uint32_t)rec_size;
+            rb.w = (int)(uint32_t)(rec_size >> 32);
             ((int4*)P.spec_rec)[1] = rb;
             ((int4*)P.spec_rec)[0] = ra;
         }
-        tell_host(1);
+        if (P.host_spec || P.pf_seq) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) tell_host(1);
+        }
     }
     NAF_TL(g_tl_sp, NAF_TL_STEP_PREP, 6);
 }
@@ -376,20 +412,33 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     __shared__ float4 sNew[16];                                        // the appended row (rf4 <= 16 float4)
     __shared__ int sHit;
-    step_prep_body<K4, CACHE, 0>(P, sp_smem, sNew, &sHit, 0);
+    step_prep_body<K4, CACHE, 0>(P, sp_smem, sNew, &sHit);
+}
+
+// The prefetch as a launch of its own (round 6): MODE 1 = the prefetch alone, MODE 2 = the timestep's append, the hand-over of the
+// indices of the minibatch it consumes, and the prefetch on the ring as that leaves it. One workgroup, launched on a stream of its
+// own beside the timestep's graph (naf_step_launch) or inside the graph that starts a timestep over.
+template <int K4, bool CACHE, int MODE>
+__global__ __launch_bounds__(SP_THREADS) void step_prefetch_kernel(const StepPrepArgs P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    __shared__ float4 sNew[16];
+    __shared__ int sHit;
+    step_prep_body<K4, CACHE, MODE>(P, sp_smem, sNew, &sHit);
 }
 
 // arguments of a launch of step_prep_body, checked; lds = its dynamic LDS
 static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed, uint64_t* counter_dev,
                     int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B, int without_replacement,
                     int32_t* spec_rec, int32_t* idx_spec, const naf_step_copies_t* copies, uint32_t* host_spec, uint64_t* pipe_errors,
-                    StepPrepArgs& P, size_t& lds, int& k4) {
+                    int32_t* spec_rec_in, int32_t* idx_spec_in, int depth, uint32_t* pf_seq, StepPrepArgs& P, size_t& lds, int& k4) {
     if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
     if (!counter_dev || !out_rows || !mom || B <= 0 || B > 4096 || (((uintptr_t)out_rows | (uintptr_t)mom) & 15) != 0)
         return NAF_ERR_ARG;
     if ((src_row == nullptr) != (n_word == nullptr) || ((uintptr_t)src_row & 15) != 0 || ((uintptr_t)n_word & 3) != 0) return NAF_ERR_ARG;
     if (((uintptr_t)row_out & 15) != 0 || (row_out && !src_row)) return NAF_ERR_ARG;
     if (((uintptr_t)spec_rec & 15) != 0 || ((uintptr_t)idx_spec & 3) != 0 || ((uintptr_t)host_spec & 7) != 0) return NAF_ERR_ARG;
+    if (((uintptr_t)spec_rec_in & 15) != 0 || ((uintptr_t)idx_spec_in & 3) != 0 || ((uintptr_t)pf_seq & 3) != 0) return NAF_ERR_ARG;
+    if ((depth != 1 && depth != 2) || (host_spec && !pf_seq)) return NAF_ERR_ARG;      // (a verdict carries the ordinal pf_seq counts)
     if (action_mode != NAF_ACTION_TRUNC_INT && action_mode != NAF_ACTION_FLOAT) return NAF_ERR_ARG;
     if ((out_ld & 3) != 0 || out_ld < naf_round_up(naf_row_off_done(h->S, h->A) + 1, 4) || out_ld > h->row_floats) return NAF_ERR_ARG;
     k4 = (h->S + 3) / 4;
@@ -419,6 +468,10 @@ static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word
     P.hash_bits = sample_hash_bits(B);
     P.spec_rec = spec_rec;
     P.idx_spec = idx_spec;
+    P.spec_rec_in = spec_rec_in;
+    P.idx_spec_in = idx_spec_in;
+    P.depth = depth;
+    P.pf_seq = pf_seq;
     P.host_spec = host_spec;
     P.pipe_errors = pipe_errors;
     for (int c = 0; c < 3; ++c) {
@@ -452,7 +505,8 @@ extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_
     int k4 = 0;
     if ((spec_rec == nullptr) != (idx_spec == nullptr) && idx_out) return NAF_ERR_ARG;     // (a record without its indices: only if nobody asks for them)
     const int rc = sp_build(h, src_row, n_word, row_out, seed, counter_dev, idx_out, out_rows, out_ld, action_mode, mom, B,
-                            without_replacement, spec_rec, (int32_t*)idx_spec, copies, nullptr, nullptr, P, lds, k4);
+                            without_replacement, spec_rec, (int32_t*)idx_spec, copies, nullptr, nullptr, spec_rec, (int32_t*)idx_spec, 1,
+                            nullptr, P, lds, k4);
     if (rc != NAF_OK) return rc;
     static int raised_dev[64];                           // per device: the kernels' dynamic-LDS limit raised once
     int dev = 0;
@@ -595,9 +649,12 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
 }
 
 // SPEC: one more workgroup — the launch's last, of SP_THREADS threads like all of them then (the others' upper half leaves at once) —
-// prefetches the next timestep's minibatch (step_prep_body above): 0 = none, 1 / 2 = K <= 24 with / without the rows cached in LDS,
-// 3 / 4 = K <= 32; 5 .. 8 = the same four with this timestep's append in front (MODE 2). It depends on nothing in this launch and
-// nothing in this launch depends on it.
+// prefetches the next timestep's minibatch (step_prep_body above, MODE 1): 0 = none, 1 / 2 = K <= 24 with / without the rows cached
+// in LDS, 3 / 4 = K <= 32. It depends on nothing in this launch and nothing in this launch depends on it. (Round 5's pipelined
+// timestep also ran its append + prefetch here — SPEC 5 .. 8 — and the chain behind the launch waited 4 - 9 us for this one
+// workgroup; since round 6 that is step_prefetch_kernel on a stream of its own, one minibatch further ahead.)
+// SPEC == 0 with SP.cp_n set: the COMMIT of the pipelined timestep (working -> public state of the learner, `copies`) by the launch's
+// last workgroup while it waits for the heads' weights.
 template <int PMODE, int SPEC>
 __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP) {
     if (SPEC) {
@@ -606,8 +663,7 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         __shared__ int sHitS;
         if (blockIdx.x == gridDim.x - 1) {
             NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 13, true, false);
-            step_prep_body<(((SPEC - 1) & 3) < 2 ? 6 : 8), ((SPEC - 1) & 1) == 0, (SPEC <= 4 ? 1 : 2)>(
-                SP, aa_smem, sNewS, &sHitS, (int)((unsigned)P.sync[0] + 1u));
+            step_prep_body<(((SPEC - 1) & 3) < 2 ? 6 : 8), ((SPEC - 1) & 1) == 0, 1>(SP, aa_smem, sNewS, &sHitS);
             NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 14, true, false);
             return;
         }
@@ -755,6 +811,18 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
     {
         const uint64_t ctr = *P.counter_dev;
         const int NH = P.NH;
+        if (!SPEC) {
+            // the pipelined timestep's commit: working -> public copies of what the chain advances besides the gradient (ranges no
+            // workgroup of this launch writes; the chain that overwrites the working copies is the NEXT launch)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned* src = SP.cp_src[c];
+                unsigned* dst = SP.cp_dst[c];
+                const int nw = SP.cp_n[c];
+                if (src && dst)
+                    for (int w = tid; w < nw; w += AA_THREADS) dst[w] = src[w];
+            }
+        }
         // every float4 of Wh has been stepped and written through once its workgroups have arrived
         if (tid == 0) {
             const unsigned want = (unsigned)epoch * (unsigned)wh_wgs;
@@ -887,45 +955,52 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     const int grid = AA_L1_WGS + P.wh_wgs + AA_L2_WGS + 1;
     StepPrepArgs SP;
     memset(&SP, 0, sizeof(SP));
-    if (!prefetch) {
+    if (prefetch && prefetch->mode == 0) {
+        // no prefetching workgroup: the launch's last workgroup commits `copies` (working -> public state of the pipelined timestep)
+        for (int c = 0; c < 3; ++c) {
+            const int nw = prefetch->copies.n_words[c];
+            if (nw <= 0) continue;
+            if (!prefetch->copies.src[c] || !prefetch->copies.dst[c] ||
+                (((uintptr_t)prefetch->copies.src[c] | (uintptr_t)prefetch->copies.dst[c]) & 3) != 0)
+                return NAF_ERR_ARG;
+            SP.cp_src[c] = (const unsigned*)prefetch->copies.src[c];
+            SP.cp_dst[c] = (unsigned*)prefetch->copies.dst[c];
+            SP.cp_n[c] = nw;
+        }
+    }
+    if (!prefetch || prefetch->mode == 0) {
         if (p_mode == NAF_P_HADAMARD) adam_act_kernel<NAF_P_HADAMARD, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
         else adam_act_kernel<NAF_P_MATMUL, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
         NAF_CHECK_LAUNCH();
         return NAF_OK;
     }
-    // with the prefetch of the next timestep's minibatch (step_prep_body<.., SPEC>): the record and the indices are its own, nothing
+    // with the prefetch of the next timestep's minibatch (step_prep_body<.., 1>): the record and the indices are its own, nothing
     // of the ring or the sampler's stream is committed
-    if (!prefetch->spec_rec || !prefetch->idx_spec || (prefetch->mode != 1 && prefetch->mode != 2)) return NAF_ERR_ARG;
-    if (prefetch->mode == 2 && (!prefetch->src_row || !prefetch->n_word)) return NAF_ERR_ARG;
+    if (!prefetch->spec_rec || !prefetch->idx_spec || prefetch->mode != 1) return NAF_ERR_ARG;
     size_t lds = 0;
     int k4 = 0;
-    const bool app = prefetch->mode == 2;
-    const int rc = sp_build(prefetch->replay, app ? prefetch->src_row : nullptr, app ? prefetch->n_word : nullptr,
-                            app ? prefetch->row_out : nullptr, prefetch->seed, prefetch->counter_dev, app ? prefetch->idx_out : nullptr,
+    const int rc = sp_build(prefetch->replay, nullptr, nullptr, nullptr, prefetch->seed, prefetch->counter_dev, nullptr,
                             prefetch->out_rows, prefetch->out_ld, prefetch->action_mode, prefetch->mom, prefetch->B,
                             prefetch->without_replacement, prefetch->spec_rec, prefetch->idx_spec, &prefetch->copies,
-                            prefetch->host_spec, prefetch->pipe_errors, SP, lds, k4);
+                            prefetch->host_spec, prefetch->pipe_errors, nullptr, nullptr, prefetch->depth ? prefetch->depth : 1,
+                            prefetch->pf_seq, SP, lds, k4);
     if (rc != NAF_OK) return rc;
     static int raised_dev[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!raised_dev[dev]) {
-        const void* ks[16] = {
+        const void* ks[8] = {
             (const void*)adam_act_kernel<NAF_P_HADAMARD, 1>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2>,
             (const void*)adam_act_kernel<NAF_P_HADAMARD, 3>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4>,
-            (const void*)adam_act_kernel<NAF_P_HADAMARD, 5>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 6>,
-            (const void*)adam_act_kernel<NAF_P_HADAMARD, 7>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 8>,
             (const void*)adam_act_kernel<NAF_P_MATMUL, 1>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2>,
-            (const void*)adam_act_kernel<NAF_P_MATMUL, 3>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4>,
-            (const void*)adam_act_kernel<NAF_P_MATMUL, 5>, (const void*)adam_act_kernel<NAF_P_MATMUL, 6>,
-            (const void*)adam_act_kernel<NAF_P_MATMUL, 7>, (const void*)adam_act_kernel<NAF_P_MATMUL, 8>};
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 3>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4>};
         for (const void* k : ks) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_DYN_LDS);
             if (e != hipSuccess) return (int)e;
         }
         raised_dev[dev] = 1;
     }
-    const int spec = (k4 <= 6 ? 1 : 3) + (prefetch->B <= SP_CACHE_ROWS ? 0 : 1) + (app ? 4 : 0);
+    const int spec = (k4 <= 6 ? 1 : 3) + (prefetch->B <= SP_CACHE_ROWS ? 0 : 1);
     const hipStream_t st = (hipStream_t)stream;
 #define AA_LAUNCH(PM, SV) adam_act_kernel<PM, SV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP)
 #define AA_LAUNCH_PM(PM)                \
@@ -933,17 +1008,72 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
         case 1: AA_LAUNCH(PM, 1); break; \
         case 2: AA_LAUNCH(PM, 2); break; \
         case 3: AA_LAUNCH(PM, 3); break; \
-        case 4: AA_LAUNCH(PM, 4); break; \
-        case 5: AA_LAUNCH(PM, 5); break; \
-        case 6: AA_LAUNCH(PM, 6); break; \
-        case 7: AA_LAUNCH(PM, 7); break; \
-        default: AA_LAUNCH(PM, 8); break; \
+        default: AA_LAUNCH(PM, 4); break; \
     }
     if (p_mode == NAF_P_HADAMARD) { AA_LAUNCH_PM(NAF_P_HADAMARD) } else { AA_LAUNCH_PM(NAF_P_MATMUL) }
 #undef AA_LAUNCH_PM
 #undef AA_LAUNCH
     NAF_CHECK_LAUNCH();
     return NAF_OK;
+}
+
+// ---- the prefetch as a launch of its own ------------------------------------------------------------------------------------------
+static int spf_launch(const naf_step_prefetch_t* pf, hipStream_t st) {
+    if (!pf || !pf->spec_rec || !pf->idx_spec || (pf->mode != 1 && pf->mode != 2)) return NAF_ERR_ARG;
+    if (pf->mode == 2 && (!pf->src_row || !pf->n_word)) return NAF_ERR_ARG;
+    const bool app = pf->mode == 2;
+    StepPrepArgs SP;
+    memset(&SP, 0, sizeof(SP));
+    size_t lds = 0;
+    int k4 = 0;
+    // (mode 2 consumes the record / indices `spec_rec_in` / `idx_spec_in` name — NULL: the ones it leaves, as at depth 1)
+    int32_t* rec_in = app ? (pf->spec_rec_in ? pf->spec_rec_in : pf->spec_rec) : nullptr;
+    int32_t* idx_in = app ? (pf->idx_spec_in ? pf->idx_spec_in : pf->idx_spec) : nullptr;
+    const int rc = sp_build(pf->replay, app ? pf->src_row : nullptr, app ? pf->n_word : nullptr, app ? pf->row_out : nullptr, pf->seed,
+                            pf->counter_dev, app ? pf->idx_out : nullptr, pf->out_rows, pf->out_ld, pf->action_mode, pf->mom, pf->B,
+                            pf->without_replacement, pf->spec_rec, pf->idx_spec, &pf->copies, pf->host_spec, pf->pipe_errors, rec_in,
+                            idx_in, pf->depth ? pf->depth : 1, pf->pf_seq, SP, lds, k4);
+    if (rc != NAF_OK) return rc;
+    static int raised_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised_dev[dev]) {
+        const void* ks[8] = {(const void*)step_prefetch_kernel<6, true, 1>, (const void*)step_prefetch_kernel<6, false, 1>,
+                             (const void*)step_prefetch_kernel<8, true, 1>, (const void*)step_prefetch_kernel<8, false, 1>,
+                             (const void*)step_prefetch_kernel<6, true, 2>, (const void*)step_prefetch_kernel<6, false, 2>,
+                             (const void*)step_prefetch_kernel<8, true, 2>, (const void*)step_prefetch_kernel<8, false, 2>};
+        for (const void* k : ks) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_DYN_LDS);
+            if (e != hipSuccess) return (int)e;
+        }
+        raised_dev[dev] = 1;
+    }
+    const bool cache = pf->B <= SP_CACHE_ROWS;
+#define SPF(K, C, M) step_prefetch_kernel<K, C, M><<<1, SP_THREADS, lds, st>>>(SP)
+    if (app) {
+        if (k4 <= 6 && cache) SPF(6, true, 2); else if (k4 <= 6) SPF(6, false, 2); else if (cache) SPF(8, true, 2); else SPF(8, false, 2);
+    } else {
+        if (k4 <= 6 && cache) SPF(6, true, 1); else if (k4 <= 6) SPF(6, false, 1); else if (cache) SPF(8, true, 1); else SPF(8, false, 1);
+    }
+#undef SPF
+    NAF_CHECK_LAUNCH();
+    return NAF_OK;
+}
+extern "C" int naf_step_prefetch(const naf_step_prefetch_t* prefetch, void* stream) { return spf_launch(prefetch, (hipStream_t)stream); }
+
+// One timestep of the pipelined path in ONE foreign call: the transition row into device memory (naf_host_publish), the timestep's
+// graph on `stream`, and — prefetch != NULL — the append + depth-2 prefetch on `side_stream`, beside the graph.
+extern "C" int naf_step_launch(void* dst_device, const void* src_host, size_t bytes, void* graph_exec, void* stream,
+                               const naf_step_prefetch_t* prefetch, void* side_stream) {
+    if (!graph_exec) return NAF_ERR_ARG;
+    if (bytes) {
+        if (!dst_device || !src_host) return NAF_ERR_ARG;
+        memcpy(dst_device, src_host, bytes);
+        __builtin_ia32_sfence();
+    }
+    hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return prefetch ? spf_launch(prefetch, (hipStream_t)side_stream) : NAF_OK;
 }
 
 extern "C" int naf_adam_polyak_act_sync_ints(void) { return 16 + 4 * AA_H; }

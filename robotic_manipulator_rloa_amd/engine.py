@@ -1,9 +1,12 @@
 """HIP-graph engines around the Learner: the steady-state loop of NAFAgent.step()/run()
 (reference naf_components/naf_algorithm.py:129-156, :228-270) with zero host<->device synchronisation.
 
-  TrainChunk     : [sample U minibatches] -> [gather U*B rows, one launch] -> U x learn()  as ONE graph.
+  UpdateChunk    : [sample U minibatches] -> [gather U*B rows, one launch] -> U x learn()  as ONE graph (TrainChunk: its old name).
+  TimestepGraph  : one tick of NAFAgent.step(): [append the transition] -> the tick's updates -> [act() on the next state]; with one
+                   update per tick in four forms up to the PIPELINED one (_Pipeline: six launches, the host waits for the first,
+                   the prefetch of a later minibatch on a stream of its own).
   DeviceEnvLoop  : E synthetic arms stepped on the device: act (eval-mode policy + noise) -> env step ->
-                   append E transitions to the HBM ring, as ONE graph; followed by a TrainChunk with
+                   append E transitions to the HBM ring, as ONE graph; followed by an UpdateChunk with
                    U = E * num_updates / update_freq so the reference's update-to-data ratio is kept.
 
 Graph capture goes through torch.cuda.CUDAGraph (= hipGraph on ROCm): the ctypes kernel launches use the
@@ -59,30 +62,16 @@ def _capture(body, snapshot: _StateSnapshot, warmup: int = 2, after_warmup=None)
     return g
 
 
-class TrainChunk:
-    """U consecutive learn() updates on U freshly sampled minibatches."""
+class UpdateChunk:
+    """U consecutive learn() updates on U freshly sampled (or teacher-forced) minibatches, as one graph:
+    [sample U minibatches] -> [gather U*B rows, one launch] -> [moments of all U] -> U x learn(), the optimizer step of update k
+    riding on the first two launches of update k + 1. The many-env loops (DeviceEnvLoop + this), bench.py's headline and the
+    long parity runs use it; the reference's own per-timestep loop is TimestepGraph below."""
 
     def __init__(self, learner: Learner, replay: ReplayBuffer, n_updates: int, teacher_forced: bool = False,
-                 use_graph: bool = True, gather_outside_graph: bool = False, tail=None, tail_state=(), head_row=None):
+                 use_graph: bool = True, gather_outside_graph: bool = False):
         """gather_outside_graph: launch sample+gather eagerly in front of the graph of U updates, so the caller can
-        bracket the gather launch with events (bench.py's live roofline measurement).
-        tail: optional callable enqueued behind the last update, inside the same graph (NAFAgent puts the NEXT timestep's
-        act() there); tail_state: device tensors it changes, so that the capture's warm-up leaves no trace in them.
-        head_row: optional pinned [1, row_floats] tensor: the graph STARTS by appending that one transition to the ring
-        (the append kernel reads pinned host memory itself) — ReplayBuffer.add of the timestep inside the graph of its
-        update instead of a launch, two event calls and a staging switch of its own. The caller fills the row and counts
-        the transition (replay._total_added) before every run(head_rows=1); a run() without a new transition (an idle
-        tick of a data-parallel run(), a timestep whose row went through the staging area) appends nothing: the node
-        reads its row count from a pinned word that run() sets (naf_replay_add_counted)."""
-        self.tail, self._tail_state = tail, tuple(tail_state)
-        self.head_row = head_row
-        self.head_count = torch.zeros(1, dtype=torch.int32).pin_memory() if head_row is not None else None
-        rf = learner.lay.row_floats
-        if head_row is not None and head_row.numel() >= rf + 4:
-            # (a row with room for its count behind it: [row (rf floats) | count (int32) | 0 0 0] — one contiguous piece of host
-            #  memory, so the per-timestep path can hand both to the GPU in one store, see head_dev below)
-            self.head_count = head_row.view(-1)[rf:rf + 1].view(torch.int32)
-        self._ran = None                   # event behind the last run(): the pinned words are free again once it has passed
+        bracket the gather launch with events (bench.py's live roofline measurement)."""
         self.L, self.replay, self.U = learner, replay, int(n_updates)
         self.teacher_forced = teacher_forced
         self.gather_outside_graph = gather_outside_graph
@@ -103,80 +92,6 @@ class TrainChunk:
                         if "bb" in learner.fuse else None)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph
-        # The per-timestep shape (ONE update per chunk on the row-split chain: the reference's own loop, NAFAgent.step with
-        # num_updates = 1) runs two fused launches of csrc/step_path.hip around the chain's five:
-        #   fused_prep: [counted append +] sample + gather + moments in one launch (naf_step_prep) instead of five;
-        #   fused_tail: the update's optimizer step and the tail's act() in one launch (naf_adam_polyak_act) instead of two —
-        #               `tail` must then be the bound `act` of an ActPath that can take the step along (ActPath.can_ride).
-        # NAF_STEP_FUSED=0 keeps the separate launches (A/B measurements; the bit-equality test runs both).
-        fused = os.environ.get("NAF_STEP_FUSED", "1") != "0"
-        self.fused_prep = (fused and self.U == 1 and self.moments is not None and not teacher_forced and not gather_outside_graph)
-        actor = getattr(tail, "__self__", None)
-        self.fused_tail = (fused and isinstance(actor, ActPath) and actor.can_ride and learner.defer_ok)
-        self._tail_actor = actor if self.fused_tail else None
-        # with both: the first launch leaves a device copy of the pinned row, and the last takes the policy's observation from its
-        # next_state columns (the state the loop asks about next IS the transition's next state) — one read of host memory per
-        # timestep instead of two, and none on the last launch's critical path
-        self.row_dev = None
-        if self.fused_prep and self.fused_tail and head_row is not None:
-            self.row_dev = torch.zeros(learner.lay.row_floats, dtype=torch.float32, device=dev)
-            self._obs_ptr = self.row_dev.data_ptr() + 4 * learner.lay.off_s2
-        # fused_prep with a [row | count] head row: the launch reads both from DEVICE memory that the host stores into directly
-        # (naf_host_publish: every device allocation is CPU-mapped here) — its first dependent load is then a local-memory
-        # latency (~0.8 us) instead of a PCIe round trip to pinned host memory (~2.8 us, measured inside the kernel)
-        self.head_dev = None
-        if self.fused_prep and head_row is not None and head_row.numel() >= rf + 4 and os.environ.get("NAF_HOST_STORE", "1") != "0" and \
-                learner.lib.naf_host_store_supported(dev.index or 0) == 1:       # (no large BAR: the kernel reads the pinned row itself)
-            self.head_dev = torch.zeros(rf + 4, dtype=torch.float32, device=dev)
-            self._head_src, self._head_dst, self._head_bytes = head_row.data_ptr(), self.head_dev.data_ptr(), 4 * (rf + 1)
-            self._publish = learner.lib.naf_host_publish
-        # with both fused launches: the last launch of a timestep also draws, gathers and takes the moments of the NEXT timestep's
-        # minibatch (one more workgroup, beside its own work and behind the action's announcement to the host: what a timestep draws
-        # depends on the row it appends only through the fill level — and through the row itself if the draw picks it, which the
-        # record says); the next timestep's first launch then only appends its row (csrc/step_path.hip, step_prep_body).
-        # NAF_STEP_PREFETCH=0: every timestep draws for itself.
-        self.spec_rec = self.idx_spec = self._prefetch = None
-        if self.fused_prep and self.fused_tail and os.environ.get("NAF_STEP_PREFETCH", "1") != "0":
-            self.spec_rec = torch.zeros(12, dtype=torch.int32, device=dev)
-            self.idx_spec = torch.zeros(B, dtype=torch.int32, device=dev)
-            r = replay
-            self._prefetch = _lib.StepPrefetch(r.handle, r.seed, ptr(r._sample_ctr), ptr(self.idx_spec), ptr(self.batch),
-                                               self.batch.shape[-1], r.action_mode, ptr(self.moments), B,
-                                               int(r.without_replacement), ptr(self.spec_rec), 1)
-        # ... and PIPELINED (one GPU, graphs): with the minibatch of timestep t + 1 in place before its transition exists, its whole
-        # learn() chain can run before it too — the gradient depends on the parameters update t leaves and on that minibatch, not
-        # on the new row. A timestep's graph is then [naf_adam_polyak_act: append the row, apply the gradient that is waiting, act(),
-        # prefetch] -> [the chain on the prefetched minibatch], and what the host waits for is the first launch: the chain runs
-        # while it steps the environment. The chain works on copies of the state it advances besides the gradient (BatchNorm
-        # running statistics, step count, loss partials); the first launch of the next graph commits them with the update, so the
-        # learner's public buffers are exactly "after update t" between graphs. If the prefetch does not hold (the host reads the
-        # verdict from pinned memory before it launches) the other graph runs: reset the working copies, draw, chain, and from
-        # there as above. NAF_STEP_PIPELINE=0: the prefetch only. (_init_pipeline, at capture time.)
-        self.pipelined = (self._prefetch is not None and head_row is not None and self.head_dev is not None and use_graph and
-                          learner.world_size == 1 and learner.fold_norm and not learner._force_allreduce and
-                          os.environ.get("NAF_STEP_PIPELINE", "1") != "0")
-        self.graph_fast = None
-        self._exec_fast = None
-        self._spec_armed = False           # the last launch was one of the pipelined graphs: a verdict on its prefetch will come
-        self._sig, self._r_total = None, -1
-        self.fast_runs = self.slow_runs = 0
-        # fused tail: the launch hands its action to the host as self-validating 16-byte chunks {three components, ordinal}
-        # (ActPath.act_rec) — the host learns that a run() has passed by polling the chunks' ordinals instead of synchronising an
-        # event / the stream, and takes the action from the chunks (wait_tail). _seq_np = chunk 0's ordinal.
-        self._seq_np = actor.ordinal_np if self.fused_tail else None
-        self._seq_prev = 0
-        self._inflight = False             # a run() whose ordinal the host has not seen yet
-        self._exec = None
-        self._err_np = learner.err_host.numpy()
-        self._head_count_np = self.head_count.numpy() if self.head_count is not None else None
-
-    def prefetch_stats(self) -> Tuple[int, int]:
-        """(timesteps that took the minibatch the previous timestep's last launch had prefetched, timesteps that drew for
-        themselves) since the chunk was built; (0, 0) without the prefetch. Synchronises."""
-        if self.spec_rec is None:
-            return 0, 0
-        r = self.spec_rec.cpu()
-        return int(r[8]), int(r[9])
 
     def _sample_gather(self) -> None:
         if not self.teacher_forced:
@@ -191,16 +106,180 @@ class TrainChunk:
                 self.empty_events[0].record()
                 self.empty_events[1].record()
 
-    def _updates(self, moments_ready: bool = False) -> None:
+    def _updates(self, moments_ready: bool = False, defer_last: bool = False) -> None:
         if self.moments is not None and not moments_ready:
             self.L.moments(self.batch.view(self.U * self.L.B, -1), self.moments, self.U)
         # a chain of updates: the optimizer step of update k rides on the first two launches of update k + 1 (one launch
-        # less per update, Learner.defer_ok); the last one of the chunk takes its step as a launch of its own, so the
-        # parameter buffers are current whenever anything outside the chunk looks at them
+        # less per update, Learner.defer_ok); the last one of the chunk takes its step as a launch of its own (defer_last: the
+        # caller's next launch carries it), so the parameter buffers are current whenever anything outside the chunk looks
         d = self.L.defer_ok
         for k in range(self.U):
             self.L.learn_rows(self.batch[k], self.loss_parts[k], None if self.moments is None else self.moments[k],
-                              pending=d and k > 0, defer=d and (k < self.U - 1 or self.fused_tail))
+                              pending=d and k > 0, defer=d and (k < self.U - 1 or defer_last))
+
+    def _body(self) -> None:
+        self._sample_gather()
+        self._updates()
+
+    def _snapshot(self, extra=()) -> _StateSnapshot:
+        return _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts) + tuple(extra))
+
+    def capture(self) -> None:
+        self.replay.flush()
+        snap = self._snapshot()
+        if self.gather_outside_graph:
+            self._sample_gather()          # the updates need a valid batch to warm up on
+            self.graph = _capture(self._updates, snap)
+        else:
+            self.graph = _capture(self._body, snap)
+
+    def run(self) -> None:
+        """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first."""
+        self.L.raise_on_device_error()         # pinned host words written by the kernels: costs two loads, never a sync
+        if not self.use_graph:
+            self._body()
+            return
+        if self.graph is None:
+            self.capture()
+        if self.gather_outside_graph:
+            self._sample_gather()
+        self.graph.replay()
+
+    def losses(self) -> torch.Tensor:
+        """[U] MSE losses of the last run (device tensor; summing the per-workgroup parts in index order)."""
+        return self.loss_parts.sum(dim=1)
+
+
+TrainChunk = UpdateChunk                   # (the name rounds 1 - 5 used; tests and benchmarks still say it)
+
+STEP_FORMS = ("separate", "fused", "prefetch", "pipelined")
+
+
+def step_form() -> str:
+    """NAF_STEP_FORM (tests and A/B measurements only): which form of the per-timestep path TimestepGraph builds where the shape
+    allows every one of them — `separate` (twelve launches), `fused` (naf_step_prep + chain + naf_adam_polyak_act), `prefetch`
+    (+ the last launch draws the next minibatch), `pipelined` (default)."""
+    f = os.environ.get("NAF_STEP_FORM", "pipelined")
+    if f not in STEP_FORMS:
+        raise ValueError(f"NAF_STEP_FORM={f!r}: one of {STEP_FORMS}")
+    return f
+
+
+class TimestepGraph(UpdateChunk):
+    """One tick of NAFAgent.step()'s update schedule (naf_algorithm.py:144-156) as one graph:
+    [append this timestep's transition] -> sample U minibatches -> gather -> U x learn() -> [tail: act() on the next state].
+
+    head_row: pinned [1, row_floats (+ 4)] tensor: the graph STARTS by appending that one transition to the ring
+        (ReplayBuffer.add of the timestep inside the graph of its update). The caller fills the row and counts the transition
+        (replay._total_added) before every run(head_rows=1); a run(head_rows=0) (an idle tick of a data-parallel run(), a timestep
+        whose row went through the staging area) appends nothing: the node reads its row count from a word run() sets.
+    tail: callable enqueued behind the last update (NAFAgent puts the NEXT timestep's act() there); tail_state: device tensors it
+        changes, so that the capture's warm-up leaves no trace in them.
+
+    With ONE update per tick on the row-split chain (the reference's own loop) the tick has four forms, each bit-equal to the one
+    before (`form`):
+      separate   counted append, draw, counter, gather, moments, the chain's five, optimizer step, act(): twelve launches
+      fused      naf_step_prep (append + draw + gather + moments) + chain + naf_adam_polyak_act (optimizer step + act()): seven
+      prefetch   ... whose last launch also draws the NEXT tick's minibatch; the next naf_step_prep then only appends
+      pipelined  (one GPU, graphs) the chain of the next update runs BEFORE its transition exists, while the host steps the
+                 environment: _Pipeline below — six launches per tick of which the host waits for the first
+    """
+
+    def __init__(self, learner: Learner, replay: ReplayBuffer, n_updates: int, use_graph: bool = True, tail=None, tail_state=(),
+                 head_row=None):
+        super().__init__(learner, replay, n_updates, use_graph=use_graph)
+        self.tail, self._tail_state = tail, tuple(tail_state)
+        self.head_row = head_row
+        self.head_count = torch.zeros(1, dtype=torch.int32).pin_memory() if head_row is not None else None
+        rf, dev, B = learner.lay.row_floats, learner.dev, learner.B
+        row_with_count = head_row is not None and head_row.numel() >= rf + 4
+        if row_with_count:
+            # [row (rf floats) | count (int32) | 0 0 0] — one contiguous piece of host memory, so the per-timestep path can hand
+            # both to the GPU in one store (head_dev below)
+            self.head_count = head_row.view(-1)[rf:rf + 1].view(torch.int32)
+        self._head_count_np = self.head_count.numpy() if self.head_count is not None else None
+        self._ran = None                   # event behind the last run(): the pinned words are free again once it has passed
+        want = STEP_FORMS.index(step_form())
+        actor = getattr(tail, "__self__", None)
+        can_prep = self.U == 1 and self.moments is not None
+        can_tail = isinstance(actor, ActPath) and actor.can_ride and learner.defer_ok
+        self.fused_prep = want >= 1 and can_prep
+        self.fused_tail = want >= 1 and can_tail
+        self._tail_actor = actor if self.fused_tail else None
+        both = self.fused_prep and self.fused_tail
+        # with both: the first launch leaves a device copy of the pinned row, and the last takes the policy's observation from its
+        # next_state columns (the state the loop asks about next IS the transition's next state) — one read of host memory per
+        # timestep instead of two, and none on the last launch's critical path
+        self.row_dev = None
+        if both and head_row is not None:
+            self.row_dev = torch.zeros(rf, dtype=torch.float32, device=dev)
+            self._obs_ptr = self.row_dev.data_ptr() + 4 * learner.lay.off_s2
+        # fused_prep with a [row | count] head row: the launch reads both from DEVICE memory that the host stores into directly
+        # (HostStoreRow: a library allocation the CPU can reach, proven by a self-test at construction) — its first dependent load
+        # is then a local-memory latency (~0.8 us) instead of a PCIe round trip to pinned host memory (~2.8 us)
+        self.head_dev: Optional[HostStoreRow] = None
+        if self.fused_prep and row_with_count:
+            self.head_dev = HostStoreRow.try_create(learner.lib, dev, head_row, 4 * (rf + 1))
+        # prefetch: the last launch of a tick also draws, gathers and takes the moments of the NEXT tick's minibatch (one more
+        # workgroup, beside its own work and behind the action's announcement: what a tick draws depends on the row it appends only
+        # through the fill level — and through the row itself if the draw picks it, which the record says); the next tick's first
+        # launch then only appends its row (csrc/step_path.hip, step_prep_body)
+        self.spec_rec = self.idx_spec = self._prefetch = None
+        if both and want >= 2:
+            self.spec_rec = torch.zeros(12, dtype=torch.int32, device=dev)
+            self.idx_spec = torch.zeros(B, dtype=torch.int32, device=dev)
+            r = replay
+            self._prefetch = _lib.StepPrefetch(r.handle, r.seed, ptr(r._sample_ctr), ptr(self.idx_spec), ptr(self.batch),
+                                               self.batch.shape[-1], r.action_mode, ptr(self.moments), B,
+                                               int(r.without_replacement), ptr(self.spec_rec), 1)
+        self.pipe: Optional[_Pipeline] = None
+        if (self._prefetch is not None and want >= 3 and self.head_dev is not None and use_graph and learner.world_size == 1 and
+                learner.fold_norm and not learner._force_allreduce):
+            self.pipe = _Pipeline(self)
+        # fused tail: the launch hands its action to the host as self-validating 16-byte chunks {three components, ordinal}
+        # (ActPath.act_rec) — the host learns that a run() has passed by polling the chunks' ordinals instead of synchronising an
+        # event / the stream, and takes the action from the chunks (wait_tail). _seq_np = chunk 0's ordinal.
+        self._seq_np = actor.ordinal_np if self.fused_tail else None
+        self._seq_prev = 0
+        self._inflight = False             # a run() whose ordinal the host has not seen yet
+        self._err_np = learner.err_host.numpy()
+
+    # ---- what tests and the agent ask -----------------------------------------------------------------------------------------
+    @property
+    def pipelined(self) -> bool:
+        return self.pipe is not None
+
+    @property
+    def form(self) -> str:
+        return ("pipelined" if self.pipe is not None else "prefetch" if self._prefetch is not None else
+                "fused" if (self.fused_prep or self.fused_tail) else "separate")
+
+    @property
+    def fast_runs(self) -> int:
+        return self.pipe.fast_runs if self.pipe is not None else 0
+
+    @property
+    def slow_runs(self) -> int:
+        return self.pipe.slow_runs if self.pipe is not None else 0
+
+    def prefetch_stats(self) -> Tuple[int, int]:
+        """(ticks that took a prefetched minibatch, ticks that drew for themselves) since the graph was built; (0, 0) without the
+        prefetch. Synchronises (the pipelined form counts on the host and does not)."""
+        if self.pipe is not None:
+            return self.pipe.fast_runs, self.pipe.slow_runs
+        if self.spec_rec is None:
+            return 0, 0
+        r = self.spec_rec.cpu()
+        return int(r[8]), int(r[9])
+
+    def error_words(self) -> Dict[str, int]:
+        """The path's pinned error counters (never a synchronisation): polls inside naf_adam_polyak_act that ran into their bound,
+        pipelined ticks whose record did not hold on the device, host-side waits for a verdict that had to synchronise."""
+        return {"act_poll_timeouts": int(self._err_np[1]), "pipe_errors": int(self._err_np[2]),
+                "verdict_waits_synchronised": self.pipe.sync_waits if self.pipe is not None else 0}
+
+    # ---- the graph's body ---------------------------------------------------------------------------------------------------------
+    def _finish(self) -> None:
         if self.fused_tail:
             # the last update's clip + Adam + Polyak and the tail's act(): one launch
             self._tail_actor.act_with_optimizer_step(obs_ptr=self._obs_ptr if self.row_dev is not None else None,
@@ -208,131 +287,58 @@ class TrainChunk:
         elif self.tail is not None:
             self.tail()
 
-    def _init_pipeline(self) -> None:
-        """working copies, argument structures and the verdict word of the pipelined graphs (at capture time: the public tensors'
-        addresses are final by then)"""
-        L, r, a = self.L, self.replay, self._tail_actor
-        H, rf, B = L.lay.H, L.lay.row_floats, L.B
-        self.bn_work = L.bn_stats.clone()
-        self.step_work = L.step_dev.clone()
-        self.loss_work = torch.zeros_like(self.loss_parts[0])
-        self.host_spec = torch.zeros(2, dtype=torch.int32).pin_memory()
-        self._host_spec_np = self.host_spec.numpy().view(np.uint64)      # {ordinal, valid}: ONE 8-byte store of the launch, one load here
-        bw = self.bn_work.data_ptr()
-        self._net_work = _lib.ActNet.from_buffer_copy(a._net)
-        self._net_work.running_mean1, self._net_work.running_var1 = bw, bw + 4 * H
-        self._net_work.running_mean2, self._net_work.running_var2 = bw + 8 * H, bw + 12 * H
-        self._adam_work = _lib.AdamArgs.from_buffer_copy(L._adam_args)
-        self._adam_work.step_dev = self.step_work.data_ptr()
-        commit = _lib.StepCopies.of((bw, L.bn_stats.data_ptr(), 8 * H),
-                                    (self.loss_work.data_ptr(), self.loss_parts.data_ptr(), self.loss_work.numel()),
-                                    (self.step_work.data_ptr(), L.step_dev.data_ptr(), 1))
-        self._reset = _lib.StepCopies.of((L.bn_stats.data_ptr(), bw, 8 * H), (L.step_dev.data_ptr(), self.step_work.data_ptr(), 1))
-        rowp = self.head_dev.data_ptr()
-        common = (r.handle, r.seed, ptr(r._sample_ctr), ptr(self.idx_spec), ptr(self.batch), self.batch.shape[-1], r.action_mode,
-                  ptr(self.moments), B, int(r.without_replacement), ptr(self.spec_rec))
-        errp = L.err_host.data_ptr() + 16
-        self._pf_fast = _lib.StepPrefetch(*common, 2, rowp, rowp + 4 * rf, ptr(self.row_dev), ptr(self.idx), ptr(self.host_spec),
-                                          errp, commit)
-        self._pf_slow = _lib.StepPrefetch(*common, 1, None, None, None, None, ptr(self.host_spec), errp, commit)
-
-    def _chain_on_working_state(self) -> None:
-        L = self.L
-        L.bn_live, L.step_live = self.bn_work, self.step_work
-        try:
-            L.learn_rows(self.batch[0], self.loss_work, self.moments[0], pending=False, defer=True)
-        finally:
-            L.bn_live, L.step_live = L.bn_stats, L.step_dev
-
-    def _body_fast(self) -> None:
-        """the prefetch held: append + apply the waiting gradient + act() + prefetch in ONE launch, then the chain for the next
-        update (six launches; the host waits for the first)"""
-        self._tail_actor.act_with_optimizer_step(obs_ptr=self.head_dev.data_ptr() + 4 * self.L.lay.off_s2, prefetch=self._pf_fast,
-                                                 obs_system_scope=True, adam_args=self._adam_work, net=self._net_work)
-        self._chain_on_working_state()
-
-    def _body_slow(self) -> None:
-        """it did not (or nothing was prefetched): reset the working state, draw, chain — and from there as the other graph"""
-        r = self.replay
-        src = self.head_dev.data_ptr()
-        check(self.L.lib.naf_step_prep(r.handle, src, src + 4 * self.L.lay.row_floats, ptr(self.row_dev), r.seed,
-                                       ptr(r._sample_ctr), ptr(self.idx), ptr(self.batch), self.batch.shape[-1], r.action_mode,
-                                       ptr(self.moments), self.L.B, int(r.without_replacement), ptr(self.spec_rec),
-                                       ptr(self.idx_spec), _lib.C.byref(self._reset), stream_ptr()), "naf_step_prep")
-        self._chain_on_working_state()
-        self._tail_actor.act_with_optimizer_step(obs_ptr=self._obs_ptr, prefetch=self._pf_slow, adam_args=self._adam_work,
-                                                 net=self._net_work)
-        self._chain_on_working_state()
-
     def _body(self) -> None:
-        if self.pipelined:
-            self._body_slow()
+        if self.pipe is not None:
+            self.pipe.body_slow()
             return
         if self.fused_prep:
             r = self.replay
             src, cnt = ptr(self.head_row), ptr(self.head_count)
             if self.head_dev is not None:
-                src, cnt = self.head_dev.data_ptr(), self.head_dev.data_ptr() + 4 * self.L.lay.row_floats
+                src, cnt = self.head_dev.ptr, self.head_dev.ptr + 4 * self.L.lay.row_floats
             check(self.L.lib.naf_step_prep(r.handle, src, cnt, ptr(self.row_dev), r.seed,
                                            ptr(r._sample_ctr), ptr(self.idx), ptr(self.batch), self.batch.shape[-1], r.action_mode,
                                            ptr(self.moments), self.L.B, int(r.without_replacement), ptr(self.spec_rec),
                                            ptr(self.idx_spec), None, stream_ptr()), "naf_step_prep")
-            self._updates(moments_ready=True)
-            return
-        if self.head_row is not None:
-            check(self.L.lib.naf_replay_add_counted(self.replay.handle, ptr(self.head_row), ptr(self.head_count), 1, stream_ptr()),
-                  "naf_replay_add_counted")
-        self._sample_gather()
-        self._updates()
+            self._updates(moments_ready=True, defer_last=self.fused_tail)
+        else:
+            if self.head_row is not None:
+                check(self.L.lib.naf_replay_add_counted(self.replay.handle, ptr(self.head_row), ptr(self.head_count), 1, stream_ptr()),
+                      "naf_replay_add_counted")
+            self._sample_gather()
+            self._updates(defer_last=self.fused_tail)
+        self._finish()
 
     def capture(self) -> None:
         self.replay.flush()
-        if self.pipelined:
-            self._init_pipeline()
+        pipe = self.pipe
+        if pipe is not None:
+            pipe.prepare()
         # (the prefetch's record among them: the warm-up's last run leaves a valid one, for a ring that is put back)
-        snap = _StateSnapshot(self.L, self.replay, (self.idx, self.batch, self.loss_parts) + self._tail_state +
-                              ((self.spec_rec,) if self.spec_rec is not None else ()) +
-                              ((self.bn_work, self.step_work, self.loss_work) if self.pipelined else ()))
-        if self.gather_outside_graph:
-            self._sample_gather()          # the updates need a valid batch to warm up on
-            self.graph = _capture(self._updates, snap)
-        elif self.head_row is not None:
-            # the warm-up appends rows to the ring: {head, size} come back with the snapshot, the ring slots it wrote
-            # (live rows, if the ring is full) are saved and put back
-            warmup = 2
-            head = int(self.replay.meta[0].item())
-            pos = (head + torch.arange(warmup, device=self.L.dev)) % self.replay.buffer_size
-            saved = self.replay.rows[pos].clone()
-            count = int(self.head_count[0])
-            self.head_count[0] = 1         # the warm-up runs really append (and are undone)
-            if self.head_dev is not None:
-                self._publish(self._head_dst, self._head_src, self._head_bytes)
-
-            def put_back():
-                self.replay.rows[pos] = saved
-                self.head_count[0] = count
-            self.graph = _capture(self._body, snap, warmup=warmup, after_warmup=put_back)
-            if self.pipelined:
-                # (its kernels are warm — the other graph's are the same but for a template argument of the first — and a run of it
-                #  needs a prefetch that holds: captured without one)
-                self.graph_fast = _capture(self._body_fast, snap, warmup=0)
-                self._spec_armed = False
-        else:
+        snap = self._snapshot(self._tail_state + ((self.spec_rec,) if self.spec_rec is not None else ()) +
+                              (pipe.state() if pipe is not None else ()))
+        if self.head_row is None:
             self.graph = _capture(self._body, snap)
-        self._raw_exec()
+            return
+        # the warm-up appends rows to the ring: {head, size} come back with the snapshot, the ring slots it wrote
+        # (live rows, if the ring is full) are saved and put back
+        warmup = 2
+        head = int(self.replay.meta[0].item())
+        pos = (head + torch.arange(warmup, device=self.L.dev)) % self.replay.buffer_size
+        saved = self.replay.rows[pos].clone()
+        count = int(self.head_count[0])
+        self.head_count[0] = 1             # the warm-up runs really append (and are undone)
+        if self.head_dev is not None:
+            self.head_dev.publish()
 
-    def _raw_exec(self) -> None:
-        """the instantiated graph's handle, for run_row()'s direct launch (None: torch's replay())"""
-        self._exec = None
-        self._launch = self.L.lib.naf_host_publish_launch
-        if self.graph is not None and self.head_dev is not None and hasattr(self.graph, "raw_cuda_graph_exec"):
-            try:
-                self._exec = int(self.graph.raw_cuda_graph_exec())
-                if self.graph_fast is not None:
-                    self._exec_fast = int(self.graph_fast.raw_cuda_graph_exec())
-            except Exception:                      # (a torch build that keeps the handle to itself)
-                self._exec = self._exec_fast = None
+        def put_back():
+            self.replay.rows[pos] = saved
+            self.head_count[0] = count
+        self.graph = _capture(self._body, snap, warmup=warmup, after_warmup=put_back)
+        if pipe is not None:
+            pipe.capture_fast(snap)
 
+    # ---- hand-overs with the host -----------------------------------------------------------------------------------------------
     def wait_pinned_free(self) -> None:
         """Block until the last run() has passed: what it reads from pinned host memory (the head row, its count, a tail's
         observation) may be rewritten afterwards. In NAFAgent.run's loop act() has waited for it already."""
@@ -343,9 +349,9 @@ class TrainChunk:
             self._ran.synchronize()
 
     def wait_tail(self) -> None:
-        """Block until the last run()'s tail has written its action to pinned host memory. Fused tail: a spin on the pinned
-        ordinal the launch writes behind the action (no stream synchronisation: the hipStreamSynchronize round trip was a tenth
-        of a timestep); other tails: the stream."""
+        """Block until the last run()'s tail has written its action to pinned host memory. Fused tail: a spin on the ordinals of
+        the action's chunks (no stream synchronisation: the hipStreamSynchronize round trip was a tenth of a timestep); other
+        tails: the stream."""
         if self._seq_np is None:
             torch.cuda.current_stream().synchronize()
             return
@@ -368,42 +374,43 @@ class TrainChunk:
                 break
         a.actions_np[0, :] = a.rec_f[a._rec_words]
         self._inflight = False
+        first = a.actions_np[0, 0]
+        if first != first:
+            # a NaN action is how the launch says that one of its bounded polls ran out; the counter that says so travels as a
+            # store of its own and may still be on its way: let the stream drain before reading it
+            torch.cuda.synchronize()
         if self._err_np[2]:
             raise _lib.NafHipError("the pipelined timestep found its prefetched minibatch not to hold although the host had read that "
-                                   "it does (engine.TrainChunk._holds): the update is not valid")
+                                   "it does (engine._Pipeline.decide): the update is not valid")
         if self._err_np[1]:
             raise _lib.NafHipError(f"naf_adam_polyak_act: {int(self.L.err_host[1])} polls inside the launch ran into their 2-ms bound "
                                    "(the GPU is over-subscribed or a workgroup died): the action is not valid")
 
     def run(self, head_rows: int = 0) -> None:
-        """Enqueue the chunk (asynchronous). With teacher forcing, fill self.idx first. head_rows (chunks built with
-        head_row): 1 = the pinned row holds a new transition that the chunk's first node appends, 0 = it appends nothing.
-        The caller has waited (wait_pinned_free) before it rewrote the row."""
+        """Enqueue the tick (asynchronous). head_rows (graphs built with head_row): 1 = the pinned row holds a new transition
+        that the graph's first node appends, 0 = it appends nothing. The caller has waited (wait_pinned_free) before it rewrote
+        the row."""
         self.L.raise_on_device_error()         # pinned host words written by the kernels: costs two loads, never a sync
+        if self.use_graph and self.graph is None:
+            self.capture()
         if self.head_row is not None:
-            if self.use_graph and self.graph is None:
-                self.capture()
             # the previous run's append node must have read its count before the word changes (an idle tick right behind a
             # step() would otherwise zero the count of a row the GPU has not appended yet); in run()'s loop act() has waited
             self.wait_pinned_free()
             self.head_count[0] = 1 if head_rows else 0
-        if self.use_graph and self.graph is None:
-            self.capture()
         if self._seq_np is not None:
             if self._inflight:
                 self.wait_tail()               # (its ordinal must be in before the next launch's "before" value is read)
             self._seq_prev = int(self._seq_np[0])
-        if self.head_dev is not None:
-            self._publish(self._head_dst, self._head_src, self._head_bytes)
-        if self.use_graph:
-            if self.gather_outside_graph:
-                self._sample_gather()
-            if self.pipelined and self._holds(bool(head_rows)):
-                self.graph_fast.replay()
-            else:
-                self.graph.replay()
+        if self.pipe is not None:
+            self.pipe.launch(bool(head_rows))
         else:
-            self._body()
+            if self.head_dev is not None:
+                self.head_dev.publish()
+            if self.use_graph:
+                self.graph.replay()
+            else:
+                self._body()
         if self._seq_np is not None:
             self._inflight = True
         elif self.head_row is not None or self.tail is not None:
@@ -416,55 +423,277 @@ class TrainChunk:
         exists, the previous run has passed, the pinned row is filled)."""
         self._head_count_np[0] = 1
         self._seq_prev = int(self._seq_np[0])
-        fast = self.pipelined and self._holds(True)
-        if self._exec is not None:
-            # the row into device memory and the graph's launch in ONE foreign call (torch's replay() is that launch plus
-            # device guards and generator bookkeeping this graph does not need)
-            rc = self._launch(self._head_dst, self._head_src, self._head_bytes, self._exec_fast if fast else self._exec,
-                              torch.cuda.current_stream().cuda_stream)
-            if rc:
-                check(rc, "naf_host_publish_launch")
+        if self.pipe is not None:
+            self.pipe.launch(True)
         else:
             if self.head_dev is not None:
-                self._publish(self._head_dst, self._head_src, self._head_bytes)
-            (self.graph_fast if fast else self.graph).replay()
+                self.head_dev.publish()
+            self.graph.replay()
         self._inflight = True
 
-    def _holds(self, brings_row: bool) -> bool:
-        """Pipelined chunk, about to launch: may this timestep run the graph that starts with the append and the waiting gradient?
-        Yes if it brings a row, the last launch was one of this chunk's graphs whose prefetch says it holds (pinned words its extra
-        workgroup wrote a few microseconds behind the action; _seq_prev is that launch's ordinal: the caller has seen its action),
-        and nobody has touched the ring, the sampler's stream or the learner in between. Also does the bookkeeping for the launch
-        that follows."""
-        r, L = self.replay, self.L
+
+class HostStoreRow:
+    """A few hundred bytes of DEVICE memory the host stores into directly (large BAR): the hand-over of a timestep's
+    [transition row | count] to the graph's first launch without a PCIe read on the launch's critical path (csrc/lib.hip,
+    naf_host_publish; the reading kernels use system-scope loads).
+
+    The memory is the library's own hipMalloc — not the framework allocator's, whose segments need not be CPU-mapped
+    (expandable segments, pools) — and the hand-over is PROVEN at construction: 1000 distinct patterns are stored through the very
+    call the path uses and read back by a kernel with the path's own loads (naf_host_store_selftest). A device without a large BAR,
+    an allocation the CPU cannot reach, or one mismatch -> try_create() returns None with a warning, and the launch reads the
+    pinned row across PCIe instead (NAF_HOST_STORE=0 forces that)."""
+
+    def __init__(self, lib, dev_ptr: int, src: torch.Tensor, n_bytes: int):
+        self.lib, self.ptr, self._src, self.n_bytes = lib, int(dev_ptr), src.data_ptr(), int(n_bytes)
+        self._keep = src
+
+    @classmethod
+    def try_create(cls, lib, device, src: torch.Tensor, n_bytes: int) -> Optional["HostStoreRow"]:
+        if os.environ.get("NAF_HOST_STORE", "1") == "0" or lib.naf_host_store_supported(device.index or 0) != 1:
+            return None
+        p = _lib.C.c_void_p()
+        if lib.naf_host_store_alloc(4 * ((n_bytes + 3) // 4 + 4), _lib.C.byref(p)) != 0 or not p.value:
+            return None
+        bad = lib.naf_host_store_selftest(p.value, 1000, stream_ptr())
+        if bad != 0:
+            import warnings
+            warnings.warn(f"naf_host_store_selftest: {bad} (mismatching patterns, or an error if negative) — the per-timestep path "
+                          "hands its transition row over through pinned host memory instead of device memory", RuntimeWarning)
+            lib.naf_host_store_free(p.value)
+            return None
+        return cls(lib, p.value, src, n_bytes)
+
+    def publish(self) -> None:
+        self.lib.naf_host_publish(self.ptr, self._src, self.n_bytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                torch.cuda.synchronize()
+                self.lib.naf_host_store_free(self.ptr)
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+class _Pipeline:
+    """The pipelined form of TimestepGraph (one GPU). Timestep t's graph is
+        naf_adam_polyak_act  [clip + Adam + Polyak with the gradient that is WAITING (taken from minibatch t while the host stepped
+                              the environment), act(s_t+1), commit working -> public state]      -> the action: what the host waits for
+        the chain's five launches on minibatch t + 1                                             -> the gradient that waits next
+    and BESIDE it, on a stream of its own (round 6; round 5 ran it as the first launch's extra workgroup and the chain waited
+    4 - 9 us for it):
+        step_prefetch_kernel [append row t, hand over minibatch t's indices, draw + gather + moments of minibatch t + 2 on the ring
+                              as two more appends will leave it, verdict -> pinned host word]
+    Three sets of {minibatch, moments, indices, record, verdict} rotate: timestep t consumes set p (`phase`), its chain reads set
+    p + 1, its prefetch fills set p + 2 — which the chain of timestep t - 2's graph read last, and that graph had finished before
+    the host saw the action of timestep t - 1. The host takes this graph iff the tick brings a row, both sets it needs are valid
+    (verdicts: the rows to come were not among the positions drawn) and nothing has touched the ring, the sampler's stream or the
+    learner since the last tick (call counters and torch's version counters). Otherwise the OTHER graph starts the timestep over
+    on the public state: naf_step_prep (reset working <- public, append, draw minibatch t into set 0) + chain + naf_adam_polyak_act
+    (+ depth-1 prefetch of t + 1 into set 1) + depth-2 prefetch of t + 2 into set 2 + chain — and leaves phase 1.
+    Ordering between the two streams is the host's: a launch is only made after every verdict owed by earlier launches has been
+    read, and a verdict is stored behind a release of everything its workgroup wrote."""
+
+    def __init__(self, tg: TimestepGraph):
+        self.tg = tg
+        L, r = tg.L, tg.replay
+        B, dev, brf = L.B, L.dev, L.lay.batch_row_floats
+        # set 0 = the graph's own buffers (what a reader of tg.batch / tg.moments finds after a timestep that started over)
+        self._stores = [tg._batch_store] + [torch.zeros(B * brf + 64, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.batches = [s[:B * brf].view(B, brf) for s in self._stores]
+        self.moments = [tg.moments[0]] + [torch.zeros_like(tg.moments[0]) for _ in range(2)]
+        self.spec_rec = torch.zeros(3, 12, dtype=torch.int32, device=dev)
+        self.idx_spec = torch.zeros(3, B, dtype=torch.int32, device=dev)
+        self.pf_seq = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.host_spec = torch.zeros(3, 2, dtype=torch.int32).pin_memory()
+        self._hs = self.host_spec.numpy().view(np.uint64).reshape(3)       # {ordinal, valid}: ONE 8-byte store of the launch, one load here
+        self.side = torch.cuda.Stream(device=dev)
+        self.phase = 0
+        self.valid = [False, False, False]
+        self.owed: List[Tuple[int, int]] = []      # (set, ordinal) of verdicts launched and not read yet
+        self.n_verdicts = 0                        # host mirror of *pf_seq
+        self.armed = False                         # the last launch was one of this object's graphs
+        self._sig, self._r_total = None, -1
+        self.fast_runs = self.slow_runs = self.sync_waits = 0
+        self.graph_fast: List[Optional[torch.cuda.CUDAGraph]] = [None, None, None]
+        self._exec = self._exec_fast = None
+        r._side_join = self.join                   # (ReplayBuffer's own launches read what the side stream writes)
+
+    def state(self) -> tuple:
+        """device tensors a warm-up run changes"""
+        return (self.spec_rec, self.idx_spec, self.pf_seq, self.bn_work, self.step_work, self.loss_work) + tuple(self._stores[1:])
+
+    def prepare(self) -> None:
+        """working copies and argument structures (at capture time: the public tensors' addresses are final by then)"""
+        tg = self.tg
+        L, r, a = tg.L, tg.replay, tg._tail_actor
+        H, rf, B = L.lay.H, L.lay.row_floats, L.B
+        self.bn_work = L.bn_stats.clone()
+        self.step_work = L.step_dev.clone()
+        self.loss_work = torch.zeros_like(tg.loss_parts[0])
+        bw = self.bn_work.data_ptr()
+        self._net_work = _lib.ActNet.from_buffer_copy(a._net)
+        self._net_work.running_mean1, self._net_work.running_var1 = bw, bw + 4 * H
+        self._net_work.running_mean2, self._net_work.running_var2 = bw + 8 * H, bw + 12 * H
+        self._adam_work = _lib.AdamArgs.from_buffer_copy(L._adam_args)
+        self._adam_work.step_dev = self.step_work.data_ptr()
+        commit = _lib.StepCopies.of((bw, L.bn_stats.data_ptr(), 8 * H),
+                                    (self.loss_work.data_ptr(), tg.loss_parts.data_ptr(), self.loss_work.numel()),
+                                    (self.step_work.data_ptr(), L.step_dev.data_ptr(), 1))
+        self._reset = _lib.StepCopies.of((L.bn_stats.data_ptr(), bw, 8 * H), (L.step_dev.data_ptr(), self.step_work.data_ptr(), 1))
+        rowp = tg.head_dev.ptr
+        errp = L.err_host.data_ptr() + 16
+        seq = self.pf_seq.data_ptr()
+
+        def pf(k, mode, depth, **kw):
+            s = _lib.StepPrefetch(r.handle, r.seed, ptr(r._sample_ctr), self.idx_spec[k].data_ptr(), ptr(self.batches[k]),
+                                  self.batches[k].shape[-1], r.action_mode, ptr(self.moments[k]), B, int(r.without_replacement),
+                                  self.spec_rec[k].data_ptr(), mode)
+            s.host_spec, s.pipe_errors, s.depth, s.pf_seq = self.host_spec[k].data_ptr(), errp, depth, seq
+            for name, v in kw.items():
+                setattr(s, name, v)
+            return s
+        self._pf_commit = _lib.StepPrefetch()                      # mode 0: the first launch of the fast graph commits, nothing else
+        self._pf_commit.copies = commit
+        self._pf_mid = pf(1, 1, 1, copies=commit)                  # started-over graph: the optimizer launch's workgroup, set 1
+        self._pf_far = pf(2, 1, 2)                                 # ... and a launch of its own behind it, set 2
+        # timestep in phase p: consumes set p, fills set p + 2 (a launch of its own on the side stream)
+        self._pf_side = [pf((p + 2) % 3, 2, 2, src_row=rowp, n_word=rowp + 4 * rf, idx_out=ptr(tg.idx),
+                            spec_rec_in=self.spec_rec[p].data_ptr(), idx_spec_in=self.idx_spec[p].data_ptr()) for p in range(3)]
+
+    def _chain(self, k: int) -> None:
+        """learn() on set k with the learner's working state; the optimizer step is left to the next graph's first launch"""
+        L = self.tg.L
+        L.bn_live, L.step_live = self.bn_work, self.step_work
+        try:
+            L.learn_rows(self.batches[k], self.loss_work, self.moments[k], pending=False, defer=True)
+        finally:
+            L.bn_live, L.step_live = L.bn_stats, L.step_dev
+
+    def body_fast(self, p: int) -> None:
+        """phase p, the prefetches held: apply the waiting gradient + act() + commit in ONE launch, then the chain for the next
+        update (six launches; the host waits for the first)"""
+        tg = self.tg
+        tg._tail_actor.act_with_optimizer_step(obs_ptr=tg.head_dev.ptr + 4 * tg.L.lay.off_s2, prefetch=self._pf_commit,
+                                               obs_system_scope=True, adam_args=self._adam_work, net=self._net_work)
+        self._chain((p + 1) % 3)
+
+    def body_slow(self) -> None:
+        """they did not (or nothing was prefetched): reset the working state, draw, chain — and from there as the other graph"""
+        tg = self.tg
+        r, L = tg.replay, tg.L
+        src = tg.head_dev.ptr
+        check(L.lib.naf_step_prep(r.handle, src, src + 4 * L.lay.row_floats, ptr(tg.row_dev), r.seed, ptr(r._sample_ctr), ptr(tg.idx),
+                                  ptr(self.batches[0]), self.batches[0].shape[-1], r.action_mode, ptr(self.moments[0]), L.B,
+                                  int(r.without_replacement), None, None, _lib.C.byref(self._reset), stream_ptr()), "naf_step_prep")
+        self._chain(0)
+        tg._tail_actor.act_with_optimizer_step(obs_ptr=tg._obs_ptr, prefetch=self._pf_mid, adam_args=self._adam_work,
+                                               net=self._net_work)
+        check(L.lib.naf_step_prefetch(_lib.C.byref(self._pf_far), stream_ptr()), "naf_step_prefetch")
+        self._chain(1)
+
+    def capture_fast(self, snap: _StateSnapshot) -> None:
+        """(behind the other graph's capture: its kernels are warm — these are the same but for a template argument of the first —
+        and a run of them needs prefetches that hold: captured without a warm-up)"""
+        tg = self.tg
+        for p in range(3):
+            self.graph_fast[p] = _capture(lambda p=p: self.body_fast(p), snap, warmup=0)
+        torch.cuda.synchronize()
+        self.host_spec.zero_()             # (the warm-up's verdicts: ordinals start over with the restored counter)
+        self.armed, self.owed, self.n_verdicts, self.valid = False, [], 0, [False, False, False]
+        self._exec = self._exec_fast = None
+        self._launch = tg.L.lib.naf_step_launch
+        if hasattr(tg.graph, "raw_cuda_graph_exec"):
+            try:
+                self._exec = int(tg.graph.raw_cuda_graph_exec())
+                self._exec_fast = [int(g.raw_cuda_graph_exec()) for g in self.graph_fast]
+            except Exception:              # (a torch build that keeps the handle to itself)
+                self._exec = self._exec_fast = None
+
+    # ---- per timestep ---------------------------------------------------------------------------------------------------------------
+    def collect(self) -> None:
+        """read every verdict the launches so far owe (a few microseconds behind the action of the launch they rode beside)"""
+        hs = self._hs
+        for k, want in self.owed:
+            n = 0
+            v = int(hs[k])
+            while (v & 0xFFFFFFFF) != want:
+                n += 1
+                if n > 2000000:                 # (something is wrong: let the runtime say what)
+                    torch.cuda.synchronize()
+                    self.sync_waits += 1
+                    v = int(hs[k])
+                    if (v & 0xFFFFFFFF) != want:
+                        raise _lib.NafHipError(f"the prefetch launch of the pipelined timestep never reported (set {k}: ordinal "
+                                               f"{v & 0xFFFFFFFF}, expected {want})")
+                    break
+                v = int(hs[k])
+            self.valid[k] = (v >> 32) == 1
+        self.owed = []
+
+    def join(self) -> None:
+        """the current stream waits for whatever the side stream still runs (ReplayBuffer calls this before it reads or writes the
+        ring from the current stream: a user's memory.sample() between two timesteps)"""
+        if self.owed and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def decide(self, brings_row: bool) -> bool:
+        """About to launch: may this tick run the graph that starts with the waiting gradient? Also the bookkeeping for the
+        launch that follows."""
+        r, L = self.tg.replay, self.tg.L
+        self.collect()                     # (always: the launches that owe them read the row's device copy the caller is about to rewrite)
         # (the call counters, and torch's version counters of the buffers: an in-place write through ANY view of them — the NAF
         #  modules' load_state_dict, a snapshot's restore — moves those; graph replays and this path's own launches do not.
         #  What stays invisible is a write through `.data` or a raw pointer: INTEGRATION.md says so.)
         sig = (r._gen, L._gen, L.theta2._version, L.bn_stats._version, L.adam_m._version, L.adam_v._version, L.step_dev._version,
                L.grad._version, L.partials._version, r.rows._version, r.meta._version, r._sample_ctr._version)
-        ok = False
-        if brings_row and self._spec_armed and sig == self._sig and r._total_added == self._r_total + 1 and r._pending == 0:
-            hs, want, n = self._host_spec_np, int(self._seq_prev) & 0xFFFFFFFF, 0
-            v = int(hs[0])
-            while (v & 0xFFFFFFFF) != want:
-                n += 1
-                if n > 2000000:                 # (the verdict is a few microseconds behind the action: something is wrong)
-                    torch.cuda.current_stream().synchronize()
-                    v = int(hs[0])
-                    break
-                v = int(hs[0])
-            ok = (v & 0xFFFFFFFF) == want and (v >> 32) == 1
-        self._spec_armed = True
+        p = self.phase
+        ok = (brings_row and self.armed and sig == self._sig and r._total_added == self._r_total + 1 and r._pending == 0 and
+              self.valid[p] and self.valid[(p + 1) % 3])
+        self.armed = True
         self._sig, self._r_total = sig, r._total_added
-        if ok:
-            self.fast_runs += 1
-        else:
-            self.slow_runs += 1
         return ok
 
-    def losses(self) -> torch.Tensor:
-        """[U] MSE losses of the last run (device tensor; summing the per-workgroup parts in index order)."""
-        return self.loss_parts.sum(dim=1)
+    def launch(self, brings_row: bool) -> None:
+        tg = self.tg
+        fast = self.decide(brings_row)
+        cur = torch.cuda.current_stream()
+        hd = tg.head_dev
+        if fast:
+            p = self.phase
+            k = (p + 2) % 3
+            if self._exec_fast is not None:
+                # the row into device memory, the graph and the side launch in ONE foreign call
+                rc = self._launch(hd.ptr, hd._src, hd.n_bytes, self._exec_fast[p], cur.cuda_stream, _lib.C.byref(self._pf_side[p]),
+                                  self.side.cuda_stream)
+                if rc:
+                    check(rc, "naf_step_launch")
+            else:
+                hd.publish()
+                self.graph_fast[p].replay()
+                check(tg.L.lib.naf_step_prefetch(_lib.C.byref(self._pf_side[p]), self.side.cuda_stream), "naf_step_prefetch")
+            self.n_verdicts += 1
+            self.owed = [(k, self.n_verdicts & 0xFFFFFFFF)]
+            self.valid[k] = False
+            self.phase = (p + 1) % 3
+            self.fast_runs += 1
+            return
+        # start over, everything on the current stream (the side stream is idle: its verdicts have been read — the wait is for
+        # the order of the memory operations, not for time)
+        cur.wait_stream(self.side)
+        if self._exec is not None:
+            rc = self._launch(hd.ptr, hd._src, hd.n_bytes, self._exec, cur.cuda_stream, None, None)
+            if rc:
+                check(rc, "naf_step_launch")
+        else:
+            hd.publish()
+            tg.graph.replay()
+        self.owed = [(1, (self.n_verdicts + 1) & 0xFFFFFFFF), (2, (self.n_verdicts + 2) & 0xFFFFFFFF)]
+        self.n_verdicts += 2
+        self.valid = [False, False, False]
+        self.phase = 1
+        self.slow_runs += 1
 
 
 # naf_episode_record_t (include/naf_hip.h), 32 bytes

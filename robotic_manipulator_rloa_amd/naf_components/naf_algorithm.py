@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..engine import DeviceEnvLoop, EpisodeLedger, TrainChunk
+from ..engine import DeviceEnvLoop, EpisodeLedger, TimestepGraph, UpdateChunk
 from ..learner import ActPath, Learner
 from ..utils.exceptions import MissingWeightsFile
 from ..utils.logger import get_global_logger
@@ -107,14 +107,14 @@ class NAFAgent:
         self._ahead = None                 # the state the last step()'s graph already ran the policy on (see _update_tick)
         self._fast = None                  # (chunk, pinned row) once every step() is "write the row, replay the graph" (step())
         self.use_graph = use_graph
-        self._chunk: Optional[TrainChunk] = None
+        self._chunk: Optional[TimestepGraph] = None
         self._actor1: Optional[ActPath] = None
         self._act_graph = None
         self._obs_pinned = torch.zeros(1, state_size, dtype=torch.float32).pin_memory()
         self._act_pinned = torch.zeros(1, action_size, dtype=torch.float32).pin_memory()
         self._learn_rows = torch.zeros(batch_size + 1, L.lay.batch_row_floats, dtype=torch.float32, device=self.device)[:batch_size]
         self._learn_loss = torch.zeros(L.n_loss_wg, dtype=torch.float32, device=self.device)
-        # step()'s transition, read by the graph: [row | count (int32, kept by TrainChunk) | pad]
+        # step()'s transition, read by the graph: [row | count (int32, kept by TimestepGraph) | pad]
         self._row_pin = torch.zeros(1, L.lay.row_floats + 4, dtype=torch.float32).pin_memory()
         self._row_np = self._row_pin.numpy()
         self.last_run_stats: Optional[dict] = None    # counters of the most recent run_vectorized / run_host_vectorized
@@ -145,7 +145,7 @@ class NAFAgent:
         [append this transition] -> sample num_updates minibatches -> one gather -> num_updates x learn -> [act(next_state)];
         with one update per timestep (the reference's own loop) the append, the draw, the gather and the moments are one launch
         (naf_step_prep), the optimizer step and the policy's forward on the next state another (naf_adam_polyak_act) around the five
-        of the row-split chain — and on one GPU the graph is PIPELINED (engine.TrainChunk): the launch that ends a timestep also
+        of the row-split chain — and on one GPU the graph is PIPELINED (engine.TimestepGraph / _Pipeline): the launch that ends a timestep also
         draws the next timestep's minibatch, the chain runs on it while the host steps the environment, and this call's graph
         starts with the launch that appends the row, applies the gradient that is waiting and acts: six launches, of which act()
         waits for the first."""
@@ -211,7 +211,7 @@ class NAFAgent:
         gradient all-reduce, so every rank must run the SAME number of ticks and open the gate at the same tick — the
         gate is therefore the tick count (identical on all ranks; equal to len(memory) whenever every tick added a row,
         i.e. always on one GPU), not the local fill level; run() pads episodes that ended early with idle ticks. A rank
-        that falls out of step is caught by the exchange's time-out (TrainChunk.run raises).
+        that falls out of step is caught by the exchange's time-out (TimestepGraph.run raises).
 
         next_state: where run()'s loop will ask act() next. The chunk's graph ends with the policy's forward on it — behind
         the updates, so it has seen them, as the reference's ordering demands (naf_algorithm.py:249-261) — and the next
@@ -233,9 +233,9 @@ class NAFAgent:
                 if head is not None and not row_in_graph:
                     # the tick that builds the graph came through memory.add (the gate was closed before it): build the graph
                     # with the append node, but run THIS tick's updates eagerly — its row is in the ring already
-                    self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=True, tail=tail,
+                    self._chunk = TimestepGraph(self.learner, self.memory, self.num_updates, use_graph=True, tail=tail,
                                              tail_state=(a.counter, a._ticket) if tail else (), head_row=head)
-                    once = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=False, tail=tail)
+                    once = TimestepGraph(self.learner, self.memory, self.num_updates, use_graph=False, tail=tail)
                     if tail is not None and next_state is not None:
                         self._actor1.obs_np[0] = next_state
                         self._ahead = self._actor1.obs_np[0]
@@ -249,7 +249,7 @@ class NAFAgent:
                     self._chunk.idx.copy_(once.idx)                # (... and the minibatch it drew, where a reader looks for it)
                     self._last_loss_from = "chunk"
                     return
-                self._chunk = TrainChunk(self.learner, self.memory, self.num_updates, use_graph=self.use_graph,
+                self._chunk = TimestepGraph(self.learner, self.memory, self.num_updates, use_graph=self.use_graph,
                                          tail=tail, tail_state=(a.counter, a._ticket) if tail else (), head_row=head)
             if self._chunk.tail is not None and next_state is not None:
                 self._chunk.wait_pinned_free()     # (a no-op behind step()'s own wait; idle ticks and staged rows come here)
@@ -451,7 +451,7 @@ class NAFAgent:
         loop = DeviceEnvLoop(self.learner, self.memory, E, seed=self.seed + 104729 * self.rank, max_frames=max_frames,
                              noise_scale=noise_scale, use_graph=self.use_graph, robot=robot, obstacle_jitter=obstacle_jitter,
                              preset=preset, variation=variation, records=True, drain_every=drain_every)
-        chunk = TrainChunk(self.learner, self.memory, U, use_graph=self.use_graph)
+        chunk = UpdateChunk(self.learner, self.memory, U, use_graph=self.use_graph)
         ledger = self._ledger(episodes)
         self.memory.flush()
         logger.info(f'Training started ({E} environments on the device)')
@@ -506,7 +506,7 @@ class NAFAgent:
         U = E * self.num_updates // self.update_freq
         L, lay = self.learner, self.learner.lay
         actor = ActPath(L, E, seed=(self.seed * 40503 + 7 + self.rank) & 0xFFFFFFFFFFFFFFFF)
-        chunk = TrainChunk(L, self.memory, U, use_graph=self.use_graph)
+        chunk = UpdateChunk(L, self.memory, U, use_graph=self.use_graph)
         obs_pin = torch.zeros(E, lay.S, dtype=torch.float32).pin_memory()
         act_pin = torch.zeros(E, lay.A, dtype=torch.float32).pin_memory()
         rows_pin = torch.zeros(E, lay.row_floats, dtype=torch.float32).pin_memory()

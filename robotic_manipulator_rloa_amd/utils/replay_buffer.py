@@ -42,6 +42,8 @@ class ReplayBuffer:
         self._pending = 0
         self._gen = 0              # bumped by everything here that changes the ring or the sampler's stream position (a pipelined
                                    # per-timestep chunk, engine.TrainChunk, trusts its prefetch only while this stands still)
+        self._side_join = None     # set by a pipelined per-timestep graph: makes the current stream wait for the stream its prefetch
+                                   # launches run on — they append to the ring and move the counters (engine._Pipeline.join)
         self.S = self.A = None
         if state_size is not None and action_size is not None:
             self._allocate(int(state_size), int(action_size))
@@ -83,6 +85,10 @@ class ReplayBuffer:
             raise _lib.NafHipError("ReplayBuffer storage is not allocated yet (no transition added)")
         return self._handle
 
+    def _join_side(self) -> None:
+        if self._side_join is not None:
+            self._side_join()
+
     # ---- add ------------------------------------------------------------------------------------------------
     def add(self, state, action, reward: float, next_state, done: int) -> None:
         """Append one experience (replay_buffer.py:32-45). Staged in pinned host memory; reaches the HBM ring at the
@@ -103,6 +109,7 @@ class ReplayBuffer:
             self.flush()
 
     def flush(self) -> None:
+        self._join_side()
         n = self._pending
         if n == 0:
             return
@@ -126,6 +133,7 @@ class ReplayBuffer:
 
     def add_rows_device(self, rows_dev: torch.Tensor, n: int, _count: bool = True) -> None:
         """Append n packed transition rows that already live on the device (vector-env path)."""
+        self._join_side()
         self._gen += 1
         if self._handle is None:
             raise _lib.NafHipError("allocate the ReplayBuffer with state_size/action_size before add_rows_device")
@@ -137,6 +145,7 @@ class ReplayBuffer:
 
     # ---- sample -----------------------------------------------------------------------------------------------
     def sample_indices(self, idx_out: torch.Tensor, n_batches: int = 1) -> None:
+        self._join_side()
         self._gen += 1
         if self.batch_size > 4096:
             # beyond one workgroup's LDS: the duplicate check's table in device memory (csrc/replay.hip, replay_sample_big_kernel)
@@ -157,6 +166,7 @@ class ReplayBuffer:
     def gather_rows(self, idx: torch.Tensor, out_rows: torch.Tensor, n: int) -> None:
         """out_rows[..., ld] (contiguous) receives the leading ld floats of the n indexed rows; ld = out_rows.shape[-1]
         between batch_row_floats (what the learner reads) and row_floats (the whole padded ring row)."""
+        self._join_side()
         if not out_rows.is_contiguous() or out_rows.numel() < int(n) * out_rows.shape[-1]:
             raise ValueError("gather_rows: out_rows must be contiguous and hold n rows")
         check(self.lib.naf_replay_gather_rows(self.handle, ptr(idx), ptr(out_rows), int(n), int(out_rows.shape[-1]),
@@ -166,6 +176,7 @@ class ReplayBuffer:
         """(states, actions, rewards, next_states, dones) with the reference's shapes and dtypes
         (replay_buffer.py:47-67): f32 (B,S), int64 (B,A) truncated, f32 (B,1), f32 (B,S), f32 (B,1).
         idx: optional int32 deque positions (0 = oldest) to take instead of drawing."""
+        self._join_side()
         self.flush()
         B, dev = self.batch_size, self.device
         if idx is None and len(self) < B:
@@ -189,11 +200,13 @@ class ReplayBuffer:
 
     def device_len(self) -> int:
         """Fill level as the device sees it (blocking; __len__ is the host-side count and never synchronises)."""
+        self._join_side()
         out = _lib.C.c_uint64()
         check(self.lib.naf_replay_size(self.handle, _lib.C.byref(out), stream_ptr()), "naf_replay_size")
         return int(out.value)
 
     def bad_index_count(self) -> int:
+        self._join_side()
         return int(self.meta[7].item())
 
     def __len__(self) -> int:
