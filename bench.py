@@ -327,6 +327,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         try:
             out.update(extras(dev, args))
+            out["sanity"]["per_timestep_path"] = out.pop("_api_path_sanity", None)
         except Exception as e:                                   # extra keys never cost the headline line
             out["extras_error"] = f"{type(e).__name__}: {e}"
     if rank == 0:
@@ -489,11 +490,19 @@ def extras(dev, args):
             out = {"value": round(n_api / dt, 1), "unit": "timesteps/s", "timesteps": n_api, "batch": batch, "ring": "1e5 rows, full",
                    "launches_per_timestep": launches, "optimizer_steps": int(agent.learner.step_dev.item())}
             if ch is not None and getattr(ch, "pipelined", False):
-                # the pipelined form: naf_adam_polyak_act (append, the waiting gradient's step, act(), prefetch) + the chain on the
-                # prefetched minibatch = 6 launches; a timestep whose prefetch did not hold starts over with the 12-launch graph
+                # the pipelined form: naf_adam_polyak_act (the waiting gradient's step, act(), commit) + the chain on a minibatch
+                # prefetched two timesteps ago = 6 launches in the graph, and the append + depth-2 prefetch as ONE launch beside
+                # the graph on a stream of its own; a timestep whose prefetches did not hold starts over with the 13-launch graph
                 runs = max(1, ch.fast_runs + ch.slow_runs)
-                out["launches_per_timestep"] = round((6 * ch.fast_runs + 12 * ch.slow_runs) / runs, 2)
+                out["launches_per_timestep"] = round((6 * ch.fast_runs + 13 * ch.slow_runs) / runs, 2)
+                out["launches_beside_the_graph_per_timestep"] = round(ch.fast_runs / runs, 2)
                 out["pipelined"] = {"timesteps_on_the_prefetched_minibatch": ch.fast_runs, "timesteps_that_started_over": ch.slow_runs}
+            if ch is not None and hasattr(ch, "error_words"):
+                # the path's hand-overs fail loudly: polls inside naf_adam_polyak_act that ran into their bound, timesteps whose
+                # record did not hold on the device although the host had read that it does, host-side waits that had to synchronise
+                out["errors"] = ch.error_words()
+                out["host_store_hand_over"] = ("device memory the host stores into (self-test passed)" if ch.head_dev is not None
+                                               else "pinned host memory (no large BAR, NAF_HOST_STORE=0, or the self-test failed)")
             del agent
             return out
         n_api = 3000
@@ -508,6 +517,8 @@ def extras(dev, args):
         slow["what"] = "the same loop (B=256) with env.step padded to 100 us by busy waiting"
         slow["framework_us_per_timestep"] = round(1e6 / slow["value"] - 100.0, 1)
         res["reference_api_path_b256_env_100us"] = slow
+        res["_api_path_sanity"] = {k: {**res[k].get("errors", {}), **res[k].get("pipelined", {})}
+                                   for k in ("reference_api_path", "reference_api_path_b256", "reference_api_path_b256_env_100us")}
         if not args.no_cpu_baseline:
             from oracle.torch_cpu_port import time_baseline
             cb = time_baseline(S, A, 256, 64, 100000, budget_s=6.0, threads=8)

@@ -1,5 +1,5 @@
 """Two agents in lockstep on the same transitions — one through the fused per-timestep launches (form by the environment:
-NAF_STEP_PREFETCH / NAF_STEP_PIPELINE), one through the twelve separate launches — compared after EVERY timestep: which quantity
+NAF_STEP_FORM), one through the twelve separate launches — compared after EVERY timestep: which quantity
 differs first when they part (an intermittent mismatch, ~1e-5 per timestep, seen by tests/test_step_path_gpu.py)?"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,11 +15,11 @@ STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 SYNC = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # compare every SYNC timesteps
 S, A, H, B, N = 21, 6, 256, 64, 300
 CH = 5000
-os.environ["NAF_STEP_FUSED"] = "1"
+FORM = os.environ.get("NAF_STEP_FORM", "pipelined")
 fa = NAFAgent(object(), S, A, H, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
-os.environ["NAF_STEP_FUSED"] = "0"
+os.environ["NAF_STEP_FORM"] = "separate"
 ua = NAFAgent(object(), S, A, H, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
-print(f"fused form: prefetch {os.environ.get('NAF_STEP_PREFETCH', '1')} pipeline {os.environ.get('NAF_STEP_PIPELINE', '1')}; compare every {SYNC}", flush=True)
+print(f"form {FORM} against the separate launches; compare every {SYNC}", flush=True)
 
 
 def state_of(ag):

@@ -17,8 +17,8 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 S, A, CH = 21, 6, 50000
 
 
-def run(fused):
-    os.environ["NAF_STEP_FUSED"] = fused
+def run(form):
+    os.environ["NAF_STEP_FORM"] = form
     agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
     h = hashlib.sha256()
     state, done, t0 = None, 0, time.perf_counter()
@@ -41,12 +41,12 @@ def run(fused):
     out = dict(digest=h.hexdigest(), theta=L.theta2.clone(), m=L.adam_m.clone(), v=L.adam_v.clone(), bn=L.bn_stats.clone(),
                ring=agent.memory.rows.clone(), meta=agent.memory.meta.clone(), step=int(L.step_dev.item()), err=[int(e) for e in L.err_host[:3]],
                runs=(getattr(ch, "fast_runs", 0), getattr(ch, "slow_runs", 0)), us=dt / done * 1e6, finite=bool(torch.isfinite(L.theta2).all()))
-    print(f"NAF_STEP_FUSED={fused}: {done} timesteps, {out['us']:.1f} us each (scripted transitions, no environment), {out['step']} optimizer steps, "
+    print(f"NAF_STEP_FORM={form}: {done} timesteps, {out['us']:.1f} us each (scripted transitions, no environment), {out['step']} optimizer steps, "
           f"pipelined graph / start-over graph {out['runs']}, error words {out['err']}, parameters finite {out['finite']}, actions {out['digest'][:16]}", flush=True)
     return out
 
 
-a, b = run("1"), run("0")
+a, b = run("pipelined"), run("separate")
 same = a["digest"] == b["digest"] and all(torch.equal(a[k], b[k]) for k in ("theta", "m", "v", "bn", "ring", "meta")) and a["step"] == b["step"]
 print(f"B = {B}, ring {N}: every action, theta, theta', m, v, BatchNorm buffers, ring and counters equal: {same}")
 sys.exit(0 if same else 1)

@@ -29,7 +29,8 @@ def drive(agent, S, A, seed):
 
 
 def run(S, A, H, pm, am, fused, prefetch, pipeline):
-    os.environ["NAF_STEP_FUSED"], os.environ["NAF_STEP_PREFETCH"], os.environ["NAF_STEP_PIPELINE"] = fused, prefetch, pipeline
+    os.environ["NAF_STEP_FORM"] = ("separate" if fused == "0" else "fused" if prefetch == "0" else "prefetch" if pipeline == "0" else
+                                   "pipelined")
     agent = NAFAgent(object(), S, A, H, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0, p_mode=pm, action_mode=am)
     acts = drive(agent, S, A, 33)
     L, ch = agent.learner, agent._chunk
