@@ -647,6 +647,9 @@ int naf_xgmi_set_timeout(void* handle, double timeout_s); /* for launches enqueu
 int naf_xgmi_mem_kind(void* handle); /* 2 = uncached, 1 = fine-grained */
 int naf_xgmi_export(void* handle, void* out_handle_bytes);
 int naf_xgmi_connect(void* handle, const void* all_handle_bytes, const int* peer_devices /* nullable, W device indices */);
+/* the same for communicators that live in ONE process (no hipIpc: each rank's slab is the process's own memory) — a rehearsal of
+ * world sizes a one-GPU box cannot host as processes; all_handles[world] = the communicators of ranks 0 .. world - 1. */
+int naf_xgmi_connect_local(void* handle, void* const* all_handles);
 int naf_xgmi_allreduce_sum(void* handle, const float* grad_in, float* grad_out, float* sumsq_partials,
                            int32_t* step_dev, void* stream);
 /* Early push: grad[lo, hi) (multiples of 4, hi <= n_floats) goes to the peers ahead of the all-reduce proper, either from

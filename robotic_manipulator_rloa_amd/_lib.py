@@ -235,6 +235,7 @@ _PROTOS = {
     "naf_xgmi_mem_kind": [_vp],
     "naf_xgmi_export": [_vp, _vp],
     "naf_xgmi_connect": [_vp, _vp, _vp],
+    "naf_xgmi_connect_local": [_vp, _vp],
     "naf_xgmi_allreduce_sum": [_vp, _vp, _vp, _vp, _vp, _vp],
     "naf_xgmi_push_desc": [_vp, _vp],
     "naf_xgmi_push_early": [_vp, _vp, _sz, _sz, _vp],

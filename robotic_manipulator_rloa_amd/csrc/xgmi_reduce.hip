@@ -236,6 +236,22 @@ extern "C" int naf_xgmi_connect(void* handle, const void* all_handle_bytes, cons
     return NAF_OK;
 }
 
+// Communicators of ONE process (a rehearsal of world sizes a one-GPU box cannot host as processes: the pool allows six processes on a
+// card, north_star's world is eight): every rank's slab is this process's own memory — no hipIpc, the same kernels, the same
+// protocol. all_handles[world]: the communicators of ranks 0 .. world - 1, all created with the same (world, n_floats).
+extern "C" int naf_xgmi_connect_local(void* handle, void* const* all_handles) {
+    if (!handle || !all_handles) return NAF_ERR_ARG;
+    XgmiComm* c = xg_comm(handle);
+    for (int p = 0; p < c->world; ++p) {
+        const XgmiComm* o = xg_comm(all_handles[p]);
+        if (!o || o->world != c->world || o->rank != p || o->n != c->n) return NAF_ERR_ARG;
+        if (p == c->rank) continue;
+        c->peers.base[p] = o->local;
+        c->opened[p] = false;              // (nothing to close: not a mapping)
+    }
+    return NAF_OK;
+}
+
 static void xg_fill_desc(const XgmiComm* c, naf_xgmi_push_t* d) {
     for (int p = 0; p < NAF_XGMI_MAX_WORLD; ++p) d->peer_base[p] = c->peers.base[p];
     d->ctrl = c->ctrl;

@@ -161,7 +161,7 @@ class Learner:
     def __init__(self, state_size: int, action_size: int, layer_size: int, batch_size: int, learning_rate: float,
                  tau: float, gamma: float, device: torch.device, p_mode: int = _lib.P_HADAMARD,
                  world_size: int = 1, process_group=None, fuse: Optional[str] = None, _force_allreduce: bool = False,
-                 _fold_norm: bool = True, pad_layer: bool = True):
+                 _fold_norm: bool = True, pad_layer: bool = True, _xgmi=None):
         """fuse: "rows" | "columns" | "unfused" | None (= NAF_FUSE or the per-shape default, see below). The underscore
         arguments are for tests: run the gradient all-reduce at world size 1 / keep the separate grad-norm launch.
         pad_layer: a layer_size below 256 is stored zero-padded to 256 (NetLayout) and runs the kernels built for that width;
@@ -298,9 +298,17 @@ class Learner:
         self.xgmi_merged = False
         self.exchange = "none" if self.world_size == 1 else "rccl"
         self.exchange_autotune = None      # {form: us per update ..., "chosen": form} once autotune_exchange() has run
+        self._exchange_pick = "auto"
         self._push_desc = None
         n_partials_most = max(self.n_partials_fold + 1, self.n_partials_norm, self.n_partials)
-        if self.world_size > 1 and os.environ.get("NAF_XGMI", "1") != "0":
+        if _xgmi is not None:
+            # a communicator handed in (XgmiAllReduce.local_group: the in-process rehearsal of world sizes beyond what a one-GPU
+            # box hosts as processes); the exchange form must then be pinned — nothing here is collective
+            if _xgmi.world != self.world_size or _xgmi.n != P or os.environ.get("NAF_DP_EXCHANGE", "auto") not in ("oneshot", "merged"):
+                raise ValueError("Learner(_xgmi=...): a communicator of this world size and length, NAF_DP_EXCHANGE = oneshot | merged")
+            self.xgmi = _xgmi
+            n_partials_most = max(n_partials_most, self.xgmi.n_partials)
+        elif self.world_size > 1 and os.environ.get("NAF_XGMI", "1") != "0":
             self.xgmi = XgmiAllReduce.try_create(P, dev, self.pg)
             if self.xgmi is not None:
                 n_partials_most = max(n_partials_most, self.xgmi.n_partials)
@@ -450,10 +458,11 @@ class Learner:
         # ---- which form the gradient exchange takes (data parallel) -------------------------------------------------------
         if self.world_size > 1:
             want_x = os.environ.get("NAF_DP_EXCHANGE", "auto").lower()
-            if want_x not in ("auto", "oneshot", "merged", "rccl"):
-                raise ValueError(f"NAF_DP_EXCHANGE = {want_x!r}: one of auto, oneshot, merged, rccl")
+            if want_x not in ("auto", "fastest", "oneshot", "merged", "rccl"):
+                raise ValueError(f"NAF_DP_EXCHANGE = {want_x!r}: one of auto, fastest, oneshot, merged, rccl")
             forms = self.exchange_forms()
-            if want_x == "auto":
+            self._exchange_pick = want_x
+            if want_x in ("auto", "fastest"):
                 self._set_exchange(forms[0])
                 if len(forms) > 1:
                     self.autotune_exchange()
@@ -569,12 +578,24 @@ class Learner:
             del graph
             restore()
             torch.cuda.synchronize(dev)
-        t = torch.tensor([times[f] for f in forms], dtype=torch.float64, device=dev if nccl else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)       # the slowest rank bounds a lock-step update
-        agreed = {f: (round(float(v), 2) if v != float("inf") else None) for f, v in zip(forms, t.tolist())}
+        # ONE reduction carries everything the ranks must agree on before they choose: each form's time (the slowest rank bounds a
+        # lock-step update) AND the count of peer waits that timed out while the forms were being timed — that count is per rank (a
+        # late rank A makes rank B give up while A then finds B's flags in place), and ranks that decided on their own counts would
+        # part: one in an RCCL all-reduce without a partner, the other in peer waits
+        my_timeouts = float(self.xgmi.status()[1]) if self.xgmi is not None else 0.0
+        t = torch.tensor([times[f] for f in forms] + [my_timeouts], dtype=torch.float64, device=dev if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        *tt, timeouts = t.tolist()
+        timeouts = int(timeouts)
+        agreed = {f: (round(float(v), 2) if v != float("inf") else None) for f, v in zip(forms, tt)}
         usable = [f for f in forms if agreed[f] is not None] or forms[:1]
-        best = min(usable, key=lambda f: (agreed[f] if agreed[f] is not None else 0.0, forms.index(f)))
-        timeouts = self.xgmi.status()[1] if self.xgmi is not None else 0
+        # the peer-memory forms sum in RANK order, RCCL in ring order: the same job gives the same bits from launch to launch only
+        # if warm-up noise cannot move it between the two families — `auto` therefore chooses among the rank-ordered forms and
+        # keeps RCCL as the fall-back (none of them usable, or one of them lost a wait while being timed);
+        # NAF_DP_EXCHANGE=fastest lets the clock decide among all of them
+        ordered = [f for f in usable if f != "rccl"]
+        pool = usable if (self._exchange_pick == "fastest" or not ordered) else ordered
+        best = min(pool, key=lambda f: (agreed[f] if agreed[f] is not None else 0.0, forms.index(f)))
         if timeouts and best != "rccl":                      # a peer-memory form that lost a wait while being timed is not trusted
             best = "rccl"
         self._set_exchange(best)

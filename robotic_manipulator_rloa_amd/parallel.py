@@ -156,6 +156,26 @@ class XgmiAllReduce:
             return None
         return comm
 
+    @classmethod
+    def local_group(cls, world: int, n_floats: int, device: torch.device, timeout_s: float = 10.0) -> list:
+        """`world` communicators in THIS process, rank r's slab mapped into the others by plain pointers (naf_xgmi_connect_local):
+        the kernels, the slot / flag protocol and the rank-ordered sum of the multi-GPU path at world sizes a one-GPU box cannot host
+        as processes (six processes per card on this pool; north_star's world is eight). Each rank must launch on a stream of its
+        own — a launch waits for its peers' launches. A rehearsal, never a measurement."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        handles = []
+        with torch.cuda.device(device):
+            for r in range(world):
+                h = C.c_void_p()
+                _lib.check(lib.naf_xgmi_create(r, world, n_floats, float(timeout_s), C.byref(h)), "naf_xgmi_create")
+                handles.append(h)
+            arr = (C.c_void_p * world)(*[h.value for h in handles])
+            for h in handles:
+                _lib.check(lib.naf_xgmi_connect_local(h, arr), "naf_xgmi_connect_local")
+        return [cls(h, lib, n_floats, r, world, device, None) for r, h in enumerate(handles)]
+
     def push_desc(self):
         """naf_xgmi_push_t for kernels that push part of the gradient early (naf_bn_relu_bwd_wgrad_push)."""
         from ._lib import XgmiPushDesc, check

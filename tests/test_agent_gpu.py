@@ -509,6 +509,22 @@ def test_xgmi_try_create_falls_back_on_every_rank_when_one_fails():
     assert "one-shot all-reduce disabled" in r.stderr
 
 
+def test_world_8_rehearsal_in_one_process():
+    """north_star's world size, W = 8, on the one GPU: eight communicators, eight learners, eight streams of ONE process
+    (tests/xgmi_inproc_worker.py; the pool allows six processes on a card, so the ranks cannot be processes as in the W = 2 / 4 tests
+    above). xgmi_allreduce_kernel<8> — seven flags per rank, the rank-ordered sum of eight — bit-exact over 40 rounds with ranges
+    pushed ahead; under `oneshot` and `merged` the gradient that leaves learn_rows() on every rank is the rank-ordered sum of the
+    eight local gradients, and twelve updates leave eight bit-identical replicas with no timed-out wait."""
+    env = dict(os.environ, NAF_ROOT=ROOT, OMP_NUM_THREADS="2", GPU_MAX_HW_QUEUES="32")    # (a rank's launch waits for its peers' launches:
+    #                                                                                  every stream needs a hardware queue of its own)
+    env.pop("NAF_FUSE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "xgmi_inproc_worker.py"), "8"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    if "INPROC_SKIP" in r.stdout:
+        pytest.skip(r.stdout[r.stdout.index("INPROC_SKIP"):][:300])
+    assert r.returncode == 0 and "INPROC_OK world=8;" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def _torchrun(script, world, args=(), extra_env=None, timeout=900, cwd=None):
     import socket
     with socket.socket() as sock:

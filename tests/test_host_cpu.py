@@ -568,6 +568,19 @@ def test_framework_many_env_arguments_without_a_gpu(monkeypatch):
     assert f._env_factory is None
 
 
+def test_engine_classes_stay_small():
+    """engine.TrainChunk was five machines in one class (chunked, teacher-forced, fused, prefetching,
+    pipelined) and the round's three state-handling bugs were all in it. Since round 6: UpdateChunk (chunked / teacher-forced),
+    TimestepGraph (the per-timestep forms), _Pipeline (the pipelined form's sets, verdicts and graphs), HostStoreRow — none above
+    300 lines, and the three A/B switches are ONE (NAF_STEP_FORM, tests only)."""
+    import ast
+    src = open(os.path.join(ROOT, "robotic_manipulator_rloa_amd", "engine.py")).read()
+    sizes = {n.name: n.end_lineno - n.lineno + 1 for n in ast.parse(src).body if isinstance(n, ast.ClassDef)}
+    assert {"UpdateChunk", "TimestepGraph", "_Pipeline", "HostStoreRow", "DeviceEnvLoop", "EpisodeLedger"} <= set(sizes), sizes
+    assert max(sizes.values()) <= 300, sizes
+    assert "NAF_STEP_FUSED" not in src and "NAF_STEP_PREFETCH" not in src and "NAF_STEP_PIPELINE" not in src
+
+
 def test_no_kernel_spills_to_scratch_and_the_switch_list_is_short():
     """nothing in libnaf_hip.so may keep values in scratch memory (private_segment_fixed_size, as hipcc's
     -Rpass-analysis=kernel-resource-usage reports it for every kernel at build time -> csrc/libnaf_hip.so.usage.json), and the
@@ -581,6 +594,16 @@ def test_no_kernel_spills_to_scratch_and_the_switch_list_is_short():
     assert len(usage) >= 60, "resource report looks truncated"
     spilling = {k: v for k, v in usage.items() if v.get("scratch_bytes_per_lane", 0) or v.get("vgpr_spills", 0)}
     assert not spilling, spilling
+    # the kernels a timestep's HOST waits on, and the launches of every update's chain, keep their scalars in
+    # scalar registers — at most 32 SGPRs spilled to VGPR lanes (round 5's adam_act_kernel with the prefetch riding in it: 171 - 196;
+    # since round 6 the pipelined timestep's first launch is the variant without that workgroup: 4 / 12). The prefetch body itself
+    # (step_prep_kernel, step_prefetch_kernel, adam_act_kernel<.., 1..4>: ~200 spilled SGPRs, no scratch) runs beside the graph.
+    hot = {k: v["sgpr_spills"] for k, v in usage.items()
+           if (("adam_act_kernelILi0ELi0E" in k or "adam_act_kernelILi1ELi0E" in k) or
+               any(n in k for n in ("bb_layer1_kernel", "bb_linear_stats", "bb_layer2_head_kernel", "gemm_bundle_kernel",
+                                    "bb_layer1_bwd_finish_kernel", "replay_gather_rows_kernel", "policy_act_kernel",
+                                    "adam_polyak_kernel", "xgmi_allreduce_kernel")))}
+    assert len(hot) >= 20 and max(hot.values()) <= 32, {k: v for k, v in hot.items() if v > 32}
     for need in ("gemm_bundle_kernel", "bb_layer2_head_kernel", "replay_gather_rows_kernel", "naf_head_kernel", "adam_polyak_kernel",
                  "synth_env_step_kernel", "policy_act_kernel", "xgmi_allreduce_kernel"):
         assert any(need in k for k in usage), need
