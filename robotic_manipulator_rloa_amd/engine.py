@@ -233,9 +233,21 @@ class TimestepGraph(UpdateChunk):
                                                self.batch.shape[-1], r.action_mode, ptr(self.moments), B,
                                                int(r.without_replacement), ptr(self.spec_rec), 1)
         self.pipe: Optional[_Pipeline] = None
-        if (self._prefetch is not None and want >= 3 and self.head_dev is not None and use_graph and learner.world_size == 1 and
-                learner.fold_norm and not learner._force_allreduce):
-            self.pipe = _Pipeline(self)
+        pipe_ok = self._prefetch is not None and want >= 3 and self.head_dev is not None and use_graph
+        if learner.world_size == 1:
+            if pipe_ok and learner.fold_norm and not learner._force_allreduce:
+                self.pipe = _Pipeline(self)
+        elif want >= 3 and use_graph and row_with_count and can_prep and can_tail:
+            # Data parallel (round 6): the ranks must run the SAME graph every tick — one learn() chain, one gradient exchange, when
+            # the tick's prefetches hold, two when it starts over — so they vote per tick (parallel.TickAgreement: host to host
+            # through shared memory). Collective: every rank builds this object at the same tick (the gate under data parallel is
+            # the tick count) and on rank-independent conditions; what may differ per rank is agreed before anybody pipelines.
+            from .parallel import TickAgreement, _agree
+            agree = TickAgreement.try_create(learner.pg)
+            if _agree(pipe_ok and agree is not None, dev, learner.pg):
+                self.pipe = _Pipeline(self, agree)
+            elif agree is not None:
+                agree.close()
         # fused tail: the launch hands its action to the host as self-validating 16-byte chunks {three components, ordinal}
         # (ActPath.act_rec) — the host learns that a run() has passed by polling the chunks' ordinals instead of synchronising an
         # event / the stream, and takes the action from the chunks (wait_tail). _seq_np = chunk 0's ordinal.
@@ -495,8 +507,9 @@ class _Pipeline:
     Ordering between the two streams is the host's: a launch is only made after every verdict owed by earlier launches has been
     read, and a verdict is stored behind a release of everything its workgroup wrote."""
 
-    def __init__(self, tg: TimestepGraph):
+    def __init__(self, tg: TimestepGraph, agree=None):
         self.tg = tg
+        self.agree = agree                         # data parallel: the ranks' per-tick vote on which graph runs (parallel.TickAgreement)
         L, r = tg.L, tg.replay
         B, dev, brf = L.B, L.dev, L.lay.batch_row_floats
         # set 0 = the graph's own buffers (what a reader of tg.batch / tg.moments finds after a timestep that started over)
@@ -658,6 +671,8 @@ class _Pipeline:
     def launch(self, brings_row: bool) -> None:
         tg = self.tg
         fast = self.decide(brings_row)
+        if self.agree is not None:
+            fast = self.agree.all_ok(fast)     # (every rank, every tick: an exchange pairs with an exchange)
         cur = torch.cuda.current_stream()
         hd = tg.head_dev
         if fast:

@@ -765,7 +765,7 @@ class Learner:
                 # push + rank-ordered reduce in one launch, which also leaves the sum-of-squares partials and the step count
                 # (merged: the finish launch of the row-split chain has done all of that already)
                 if not (self.xgmi_merged and "bb" in self.fuse):
-                    self._xg.all_reduce(self.grad, self.grad, self.partials, self.step_dev, pushed_lo=self._pushed_lo,
+                    self._xg.all_reduce(self.grad, self.grad, self.partials, self.step_live, pushed_lo=self._pushed_lo,
                                          pushed_also=self._pushed_also)
                 if not defer:
                     self.optimizer_step(norm_ready=True)
@@ -774,7 +774,7 @@ class Learner:
             if defer:
                 # the step rides on the next update; the sum-of-squares partials of the reduced gradient (and the step count) it
                 # reads are left by this launch
-                check(self._f.naf_grad_norm_partials(ptr(self.grad), P, ptr(self.partials), ptr(self.step_dev), st), "grad_norm")
+                check(self._f.naf_grad_norm_partials(ptr(self.grad), P, ptr(self.partials), ptr(self.step_live), st), "grad_norm")
                 return
         if defer:
             return                       # the next learn_rows(pending=True) carries the step

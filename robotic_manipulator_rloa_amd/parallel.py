@@ -82,6 +82,109 @@ def _agree(ok: bool, device: torch.device, group=None) -> bool:
     return bool(t.item() == 1)
 
 
+class TickAgreement:
+    """A per-tick AND over the ranks of one node, host to host, through a page of shared memory — no collective, no GPU.
+
+    The pipelined per-timestep path (engine._Pipeline) keeps a gradient waiting between ticks and has two graphs: one learn() chain
+    — one gradient exchange — when the tick's prefetched minibatches hold, two when the tick starts over. Under data parallel every
+    rank must run the SAME graph (an exchange pairs with an exchange), and whether a rank could take the short one is known on its
+    host only when the tick is there (did the prefetch hold; does the tick bring a row at all, or is it one of run()'s idle ticks):
+    so every rank writes its vote {tick ordinal, ok} into its own cache line of the page and spins until the other W - 1 lines carry
+    the ordinal; all ok -> the short graph everywhere. The ranks are in lock-step anyway (each tick's action waits for the
+    all-reduced gradient): the vote costs a cache line's trip between processes.
+
+    try_create is collective (a name for the page and the hosts' names go through torch.distributed once): None unless every rank
+    runs on the same host and mapped the page."""
+
+    LINE = 8                                   # uint64 words per rank: one 64-byte line
+
+    def __init__(self, shm, rank: int, world: int, timeout_s: float):
+        import numpy as np
+        self._shm, self.rank, self.world, self.timeout_s = shm, int(rank), int(world), float(timeout_s)
+        self.words = np.ndarray((world * self.LINE,), dtype=np.uint64, buffer=shm.buf)
+        self.tick = 0
+        self.waited = 0                        # polls spent waiting for peers (a measure of skew, for the curious)
+
+    @classmethod
+    def try_create(cls, group=None, timeout_s: float = 120.0) -> Optional["TickAgreement"]:
+        import socket
+        from multiprocessing import shared_memory
+        if not dist.is_initialized() or dist.get_world_size(group) < 2:
+            return None
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        shm, name = None, [None]
+        if rank == 0:
+            try:
+                shm = shared_memory.SharedMemory(create=True, size=max(4096, world * cls.LINE * 8))
+                shm.buf[:world * cls.LINE * 8] = bytes(world * cls.LINE * 8)
+                name = [shm.name]
+            except Exception:                  # noqa: BLE001
+                shm = None
+        dist.broadcast_object_list(name, src=src, group=group)
+        ok = name[0] is not None
+        if ok and rank != 0:
+            try:
+                shm = shared_memory.SharedMemory(name=name[0])
+                try:                           # (attaching registers the segment with this process's resource tracker, which would
+                    from multiprocessing import resource_tracker      # try to unlink it again at exit: rank 0 owns the name)
+                    resource_tracker.unregister(shm._name, "shared_memory")
+                except Exception:              # noqa: BLE001
+                    pass
+            except Exception:                  # noqa: BLE001
+                ok = False
+        facts = [None] * world
+        dist.all_gather_object(facts, (socket.gethostname(), ok), group=group)     # (also: every rank has mapped before rank 0 unlinks)
+        ok = all(f[1] for f in facts) and len({f[0] for f in facts}) == 1
+        if rank == 0 and shm is not None:
+            try:
+                shm.unlink()                   # the mappings stay; the name goes (nothing to clean up after a crash)
+            except Exception:                  # noqa: BLE001
+                pass
+        if not ok:
+            if shm is not None:
+                shm.close()
+            return None
+        return cls(shm, rank, world, timeout_s)
+
+    def all_ok(self, ok: bool) -> bool:
+        """This tick's vote; True iff every rank voted ok. Every rank calls it once per tick, in the same order of ticks.
+        Two slots per rank, by the tick's parity: a peer that has read every vote of tick t may be writing its vote for t + 1 while a
+        slower rank still reads the votes of t — into the other slot; it cannot reach t + 2 (the slot of t again) before it has
+        read the slow rank's vote for t + 1, which that rank writes only after it is done with t."""
+        import time
+        self.tick += 1
+        t, w, L = self.tick, self.words, self.LINE
+        s = t & 1
+        w[self.rank * L + s] = (t << 1) | (1 if ok else 0)         # one aligned 8-byte store: whole or not at all
+        result, t0, n = bool(ok), None, 0
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            v = int(w[r * L + s])
+            while (v >> 1) != t:
+                n += 1
+                if n & 0x3FF == 0:
+                    if t0 is None:
+                        t0 = time.perf_counter()
+                    elif time.perf_counter() - t0 > self.timeout_s:
+                        from ._lib import NafHipError
+                        raise NafHipError(f"data parallel: rank {r} did not reach tick {t} of the per-timestep loop within "
+                                          f"{self.timeout_s:.0f} s (rank {self.rank} is waiting for its vote, last seen: tick "
+                                          f"{v >> 1}): the ranks are out of step")
+                v = int(w[r * L + s])
+            result = result and bool(v & 1)
+        self.waited += n
+        return result
+
+    def close(self) -> None:
+        try:
+            self.words = None
+            self._shm.close()
+        except Exception:                      # noqa: BLE001
+            pass
+
+
 class XgmiAllReduce:
     """One-shot sum all-reduce of the flat gradient over peer-mapped device memory (csrc/xgmi_reduce.hip):
     every rank pushes its gradient into a slot on each peer over xGMI and sums the W contributions in rank order.

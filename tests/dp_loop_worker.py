@@ -31,8 +31,9 @@ def main():
     os.makedirs(f"rank{rank}", exist_ok=True)
     os.chdir(f"rank{rank}")                                    # who writes what is visible per rank
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
-    env = ScriptedEnvironment(offset=rank)
-    frames, episodes, B = 8, 14, 8
+    env = ScriptedEnvironment(offset=rank, scale=int(os.environ.get("NAF_TEST_DP_LEN_SCALE", "1")))
+    frames, episodes, B = int(os.environ.get("NAF_TEST_DP_FRAMES", "8")), int(os.environ.get("NAF_TEST_DP_EPISODES", "14")), \
+        int(os.environ.get("NAF_TEST_DP_BATCH", "8"))
     # NAF_XGMI=0 puts the gradient on torch.distributed's all-reduce — gloo in this rehearsal, which (unlike RCCL) cannot be
     # captured into a graph: the same launches run eagerly there
     agent = NAFAgent(env, env.S, env.A, 256, B, 1000, 1e-3, 1e-3, 0.99, 1, 1, 5, dev, 0,
@@ -40,6 +41,21 @@ def main():
     assert agent.world_size == world and agent.rank == rank
     scores = agent.run(frames, episodes, verbose=False)
     torch.cuda.synchronize()
+    # round 6: the PIPELINED per-timestep graph under data parallel (the ranks vote per tick on which graph runs: an idle tick or a
+    # prefetch that did not hold on ANY rank starts the tick over on ALL of them); with the collective through the host (NAF_XGMI=0:
+    # gloo cannot be captured) the launches run eagerly and nothing is pipelined
+    ch = agent._chunk
+    want_pipe = (os.environ.get("NAF_XGMI", "1") != "0" and os.environ.get("NAF_STEP_FORM", "pipelined") == "pipelined" and
+                 B >= 16)                                     # (below 16 rows the column-tile chain runs: no fused launches to pipeline)
+    assert ch.pipelined == want_pipe, (ch.form, want_pipe)
+    if ch.pipelined:
+        runs = [None] * world
+        dist.all_gather_object(runs, (ch.fast_runs, ch.slow_runs))
+        assert len(set(runs)) == 1, f"the ranks ran different graphs: {runs}"
+        assert ch.slow_runs >= episodes and ch.error_words() == {"act_poll_timeouts": 0, "pipe_errors": 0, "verdict_waits_synchronised": 0}
+        min_fast = int(os.environ.get("NAF_TEST_MIN_FAST", "0"))
+        assert ch.fast_runs >= min_fast, (ch.fast_runs, ch.slow_runs)
+        print(f"DP_PIPE rank {rank}: {ch.fast_runs} ticks on the six-launch graph, {ch.slow_runs} started over", flush=True)
 
     # ---- the scores dict is run()'s: {episode: (score, last frame)} of THIS rank's env -----------------------------------
     want_rows = []

@@ -10,8 +10,10 @@ class ScriptedEnvironment:
 
     S, A = 21, 6
 
-    def __init__(self, offset: int = 0):
+    def __init__(self, offset: int = 0, scale: int = 1):
+        """scale: every episode `scale` times as long (L = scale * (3 + (offset + k) % 4))"""
         self.offset = int(offset)
+        self.scale = int(scale)
         self.k = -1
         self.t = 0
         self.observation_space = np.zeros((self.S,))
@@ -28,7 +30,7 @@ class ScriptedEnvironment:
         return self._state()
 
     def length(self, k: int) -> int:
-        return 3 + (self.offset + k) % 4
+        return self.scale * (3 + (self.offset + k) % 4)
 
     def step(self, action):
         self.t += 1
