@@ -127,7 +127,7 @@ int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const uint64_t* co
 /* the same draw for minibatches beyond 4096 (the reference takes any positive batch_size: rl_framework.py:186-189): the duplicate
  * check's table lives in device memory — `scratch`: n_batches * naf_replay_sample_scratch_ints(B) int32, owned by the caller, no
  * initialisation needed — instead of one workgroup's LDS. Same rule, same indices (bit for bit what the LDS form would draw).
- * 1 <= B <= 16384. */
+ * 1 <= B <= 1,048,576 (round 6: the table slot of an element has a word of its own; 16384 before). */
 int naf_replay_sample_scratch_ints(int B);
 int naf_replay_sample_indices_big(naf_replay_t* h, uint64_t seed, const uint64_t* counter_dev, uint64_t counter_off, int32_t* idx,
                                   int B, int n_batches, int without_replacement, int32_t* scratch, void* stream);

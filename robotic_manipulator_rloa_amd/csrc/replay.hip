@@ -226,8 +226,9 @@ extern "C" int naf_replay_sample_indices(naf_replay_t* h, uint64_t seed, const u
 // sample, minibatches beyond 4096: the reference takes any positive batch_size (rl_framework.py:186-189 -> random.sample,
 // utils/replay_buffer.py:55). The draw above lives in one workgroup's LDS (B values + a hash table of >= 4 B ints: 80 KB at
 // B = 4096); beyond that the SAME rule — element t redraws while an earlier element holds its value — runs on a table in device
-// memory: one workgroup per minibatch again, the values in the output array itself, attempts / keys / smallest-holder in a scratch
-// area of naf_replay_sample_scratch_ints(B) ints per minibatch. Table reads go through agent-scope atomic loads (a plain load could
+// memory: one workgroup per minibatch again, the values in the output array itself, attempts / slots / keys / smallest-holder in a
+// scratch area of naf_replay_sample_scratch_ints(B) ints per minibatch (round 6: the slot has a word of its own instead of the
+// attempt word's upper half, which capped the table at 32768 entries and B at 16384 — now B <= NAF_SAMPLE_BIG_MAX = 2^20). Table reads go through agent-scope atomic loads (a plain load could
 // be served by a stale line of this CU's L1 from the round before). Tens of microseconds per round instead of two — at batch
 // sizes whose update takes a millisecond. Same indices as the LDS form would give, bit for bit (oracle.replay_sample_indices).
 // ------------------------------------------------------------------------------------------------
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(1024) void replay_sample_big_kernel(const uint64_t*
     const uint64_t ctr = (counter_dev ? *counter_dev : 0ull) + counter_off + (uint64_t)blockIdx.x;
     int* vals = idx + (int64_t)blockIdx.x * B;
     int* attempt = scratch + (int64_t)blockIdx.x * scratch_stride;       // [B]
-    int* keys = attempt + B;                                             // [M]
+    int* slot = attempt + B;                                             // [B]
+    int* keys = slot + B;                                                // [M]
     int* tmin = keys + (1 << hash_bits);                                 // [M]
     if (size == 0) {
         for (int t = tid; t < B; t += nt) vals[t] = 0;
@@ -286,15 +288,15 @@ __global__ __launch_bounds__(1024) void replay_sample_big_kernel(const uint64_t*
                 h = (h + 1) & (unsigned)(M - 1);
             }
             atomicMin(&tmin[h], t);
-            attempt[t] = (attempt[t] & 0xffff) | ((int)h << 16);         // (slot in the high half: M <= 32768)
+            slot[t] = (int)h;
         }
         __syncthreads();
         int dup_any = 0;
         for (int t = tid; t < B; t += nt) {
             const int a = attempt[t];
-            const unsigned h = (unsigned)a >> 16;
+            const unsigned h = (unsigned)slot[t];
             const bool dup = __hip_atomic_load(&tmin[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t;
-            attempt[t] = (a & 0xffff) | (dup ? (1 << 15) : 0);           // (bit 15: redraw)
+            attempt[t] = (a & 0x7fff) | (dup ? (1 << 15) : 0);           // (bit 15: redraw)
             dup_any |= dup;
         }
         const int any = __syncthreads_or(dup_any);
@@ -311,18 +313,19 @@ __global__ __launch_bounds__(1024) void replay_sample_big_kernel(const uint64_t*
     }
 }
 
+#define NAF_SAMPLE_BIG_MAX (1 << 20)
 extern "C" int naf_replay_sample_scratch_ints(int B) {
-    if (B <= 0 || B > 16384) return NAF_ERR_ARG;
+    if (B <= 0 || B > NAF_SAMPLE_BIG_MAX) return NAF_ERR_ARG;
     int bits = 1;
     while ((1 << bits) < 2 * B) ++bits;
-    return B + 2 * (1 << bits);
+    return 2 * B + 2 * (1 << bits);
 }
 
 extern "C" int naf_replay_sample_indices_big(naf_replay_t* h, uint64_t seed, const uint64_t* counter_dev, uint64_t counter_off,
                                              int32_t* idx, int B, int n_batches, int without_replacement, int32_t* scratch,
                                              void* stream) {
     if (!h || h->magic != NAF_REPLAY_MAGIC) return NAF_ERR_STATE;
-    if (!idx || !scratch || B <= 0 || B > 16384 || n_batches <= 0) return NAF_ERR_ARG;
+    if (!idx || !scratch || B <= 0 || B > NAF_SAMPLE_BIG_MAX || n_batches <= 0) return NAF_ERR_ARG;
     int bits = 1;
     while ((1 << bits) < 2 * B) ++bits;
     replay_sample_big_kernel<<<n_batches, 1024, 0, (hipStream_t)stream>>>(h->meta, seed, counter_dev, counter_off, idx, B,

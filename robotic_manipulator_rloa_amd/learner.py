@@ -199,8 +199,8 @@ class Learner:
         # on the row-split chain, smaller ones on the column-tile chain, other layer / state sizes on the unfused chain (beyond 2048
         # with the streamed BatchNorm kernels of csrc/bn_relu.hip) with a warning that names the row-split chain's range. 4096 is
         # the replay sampler's limit (one workgroup draws a minibatch without replacement in LDS, csrc/replay.hip).
-        if self.B < 1 or self.B > 16384:
-            raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 16384 (the replay sampler's table, csrc/replay.hip)")
+        if self.B < 1 or self.B > (1 << 20):
+            raise ValueError(f"batch_size {self.B}: 1 <= batch_size <= 1,048,576 (the replay sampler's table, csrc/replay.hip)")
         # (round 4: ANY batch size from 16 to 4096 — the last 64-row block of layer 1 / GEMM 2, the last 16-row workgroup of the fused
         #  layer-2 + head launch and the last block of the bundle's dA1 product may be partial: rows past the batch read as zeros, are
         #  never stored and stay out of every statistic and sum. The work buffers hold Bp = the next multiple of 16 rows (of 32 beyond

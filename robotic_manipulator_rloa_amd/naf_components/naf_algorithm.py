@@ -519,6 +519,8 @@ class NAFAgent:
         logger.info(f'Training started ({E} environments in worker processes)')
         t0 = time.time()
         updates, reward_sum, pending_learn, steps = 0, 0.0, False, 0
+        dropped_transitions = dropped_episodes = 0
+        respawns0 = getattr(vec_env, "respawns", 0)
         stream = torch.cuda.current_stream()
         while vector_steps is None or steps < vector_steps:
             obs_np[...] = obs
@@ -538,9 +540,20 @@ class NAFAgent:
             ep_score += rewards                               # score += reward, per env (naf_algorithm.py:264)
             ep_frames += 1
             ended = np.nonzero(vec_env.arr["episode_end"])[0]
-            vec_env.pack_rows(rows_np, lay.off_s2)
-            rows_dev.copy_(rows_pin, non_blocking=True)
-            self.memory.add_rows_device(rows_dev, E)
+            n_rows = vec_env.pack_rows(rows_np, lay.off_s2)
+            if n_rows is None:
+                n_rows = E                                    # (a vector env that predates `valid`: every transition exists)
+            if n_rows < E:
+                # a worker died or hung during this step and was replaced (HostVectorEnv): its envs' transitions do not exist and
+                # their episodes in flight are gone — nothing of them is booked or learned from; the step's updates run all the same
+                lost = list(vec_env.respawned_envs)
+                dropped_transitions += len(lost)
+                dropped_episodes += int((ep_frames[lost] > 0).sum())
+                reward_sum -= float(rewards[lost].sum())
+                ep_score[lost], ep_frames[lost] = 0.0, 0
+            if n_rows:
+                rows_dev[:n_rows].copy_(rows_pin[:n_rows], non_blocking=True)
+                self.memory.add_rows_device(rows_dev, n_rows)
             if len(self.memory) > self.batch_size:
                 if async_policy:
                     pending_learn = True
@@ -569,7 +582,10 @@ class NAFAgent:
             "env_steps": steps * E, "updates": updates, "seconds": dt, "env_steps_per_s": steps * E / dt,
             "mean_reward": reward_sum / max(1, steps * E), "episodes_finished": vec_env.episodes_finished,
             "last_loss": float(chunk.losses()[-1].item()) if updates else None, "scores": scores,
-            "checkpoints": list(ledger.checkpoints)}
+            "checkpoints": list(ledger.checkpoints),
+            # env workers found dead or hung and replaced during the run, and what went with them (never booked, never learned from)
+            "worker_respawns": getattr(vec_env, "respawns", 0) - respawns0, "dropped_transitions": dropped_transitions,
+            "dropped_episodes": dropped_episodes}
         return self.last_run_stats
 
     # ---- evaluation with E environments (rl_framework.py:319-367 re-hosted) -------------------------------------------
@@ -626,6 +642,9 @@ class NAFAgent:
                 actions = actor.act(noise_scale).cpu().numpy()
             _, _, rewards, _, dones, obs = vec_env.step(actions)
             fr += 1
+            lost = list(getattr(vec_env, "respawned_envs", ()))
+            if lost:
+                fr[lost] = 0                                  # (a replaced worker: its envs' episodes in flight start over)
             for e in np.nonzero(vec_env.arr["episode_end"])[0]:
                 ordinal[e] += 1
                 if seen[e] < quota[e]:

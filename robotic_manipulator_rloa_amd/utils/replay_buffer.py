@@ -151,7 +151,7 @@ class ReplayBuffer:
             # beyond one workgroup's LDS: the duplicate check's table in device memory (csrc/replay.hip, replay_sample_big_kernel)
             per = self.lib.naf_replay_sample_scratch_ints(self.batch_size)
             if per < 0:
-                raise ValueError(f"batch_size {self.batch_size}: the replay sampler draws minibatches of at most 16384")
+                raise ValueError(f"batch_size {self.batch_size}: the replay sampler draws minibatches of at most 1,048,576")
             if self._sample_scratch is None or self._sample_scratch.numel() < per * int(n_batches):
                 self._sample_scratch = torch.zeros(per * int(n_batches), dtype=torch.int32, device=self.device)
             check(self.lib.naf_replay_sample_indices_big(self.handle, self.seed, ptr(self._sample_ctr), 0, ptr(idx_out),

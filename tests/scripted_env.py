@@ -51,6 +51,31 @@ class ScriptedEnvironment:
         return score, L
 
 
+class HangingEnvironment(ScriptedEnvironment):
+    """a simulator that hangs: step number `hang_at` (counted over the instance's life) never returns — but only in the first
+    process that builds one with this marker file absent (the replacement must work)"""
+
+    def __init__(self, offset: int = 0, hang_at: int = 4, marker: str = ""):
+        super().__init__(offset)
+        import os
+        self._n, self._hang_at = 0, hang_at
+        self._armed = bool(marker) and not os.path.exists(marker)
+        if self._armed:
+            open(marker, "w").close()
+
+    def step(self, action):
+        self._n += 1
+        if self._armed and self._n == self._hang_at:
+            import time
+            while True:
+                time.sleep(1.0)
+        return super().step(action)
+
+
+def make_hanging(offset: int = 0, hang_at: int = 4, marker: str = ""):
+    return HangingEnvironment(offset, hang_at, marker)
+
+
 _NEXT = [0]
 
 

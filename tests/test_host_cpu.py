@@ -6,6 +6,8 @@ import re
 import subprocess
 import sys
 
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -461,6 +463,53 @@ def test_framework_misc_api_contract(tmp_path, monkeypatch):
 def _make_synth_env():
     from robotic_manipulator_rloa_amd.environment.synthetic import SyntheticEnvironment
     return SyntheticEnvironment(6, initial_positions_variation_range=[0.1] * 6)
+
+
+def test_host_vector_env_replaces_a_dead_and_a_hung_worker(tmp_path):
+    """SURVEY.md section 5's build note ("env worker crash -> respawn & mark transitions invalid"), VERDICT r05 item 6: a worker
+    killed in front of a step (a simulator that segfaults) and a worker whose env.step never returns are both replaced by a fresh
+    process with fresh environments — the step reports their envs' transitions as invalid, pack_rows packs the others only, the
+    next observation of the replaced env is a reset state, every other env is untouched, and the vector env goes on."""
+    import functools
+    from robotic_manipulator_rloa_amd.environment.vector_env import HostVectorEnv
+    from scripted_env import ScriptedEnvironment, make_hanging, make_scripted
+    E, S, A = 4, 21, 6
+    acts = np.zeros((E, A), np.float32)
+    vec = HostVectorEnv(functools.partial(make_scripted, 0), E, S, A, max_frames=50, seed=0)
+    try:
+        obs = vec.reset().copy()
+        assert (obs[:, 1] == 0).all() and (obs[:, 2] == 0).all()         # (offset, k, t) = (0, 0, 0) everywhere
+        for t in range(1, 3):
+            _, _, rw, ns, dn, obs = vec.step(acts)
+            assert (ns[:, 2] == t).all() and vec.arr["valid"].all()
+        vec._fault_at = (vec.steps, 2)                                   # worker 2 (env 2) dies in front of the third step
+        st, _, rw, ns, dn, obs = vec.step(acts)
+        assert list(vec.arr["valid"]) == [1, 1, 0, 1] and vec.respawned_envs == [2] and vec.respawns == 1 and vec.dropped_transitions == 1
+        assert (ns[[0, 1, 3], 2] == 3).all() and (dn[[0, 1, 3]] == 1).all()      # the others: episode 0 ends at its third step
+        assert tuple(obs[2][:3]) == (0, 0, 0) and vec.arr["episode_end"][2] == 0   # env 2: a fresh environment's reset state
+        rows = np.zeros((E, 64), np.float32)
+        assert vec.pack_rows(rows, 28) == 3 and list(rows[:3, 28 + 2]) == [3, 3, 3] and (rows[3] == 0).all()
+        _, _, rw, ns, dn, obs = vec.step(acts)
+        assert vec.arr["valid"].all() and vec.respawned_envs == [] and vec.pack_rows(rows, 28) == E
+        assert tuple(ns[2][:3]) == (0, 0, 1) and tuple(ns[0][:3]) == (0, 1, 1)     # env 2 is one episode behind from here on
+    finally:
+        vec.close()
+    marker = str(tmp_path / "hung_once")
+    vec = HostVectorEnv(functools.partial(make_hanging, 0, 3, marker), 2, S, A, max_frames=50, seed=0, step_timeout_s=1.5)
+    try:
+        vec.reset()
+        acts2 = np.zeros((2, A), np.float32)
+        vec.step(acts2), vec.step(acts2)
+        t0 = time.time()
+        vec.step(acts2)                                                  # the first-built env hangs in its third step
+        assert 1.0 < time.time() - t0 < 30 and vec.respawns == 1 and len(vec.respawned_envs) == 1
+        lost = vec.respawned_envs[0]
+        assert vec.arr["valid"][lost] == 0 and vec.arr["valid"][1 - lost] == 1
+        for _ in range(4):
+            vec.step(acts2)                                              # ... and its replacement does not
+        assert vec.respawns == 1 and vec.arr["valid"].all()
+    finally:
+        vec.close()
 
 
 def test_host_vector_env_workers_match_serial_envs():

@@ -200,12 +200,14 @@ def test_replay_sample_api_contract_matches_reference_golden(lib):
 #  and 3000 are not powers of two)
 # (beyond 4096 the table is in device memory, csrc/replay.hip replay_sample_big_kernel — the same rule, so the same restatement:
 #  (100000, 8192) a few redraws, (30000, 8192) a thousand over several rounds, (20000, 8192) the dense regime's partial
-#  Fisher-Yates, (40000, 5000) not a power of two, (200000, 16384) the largest minibatch)
+#  Fisher-Yates, (40000, 5000) not a power of two, (200000, 16384) round 5's largest minibatch; round 6: the table slot of an element has
+#  a word of its own and the limit is 2^20 — (300000, 20000), (150000, 65536) a few thousand redraws, (100000, 40000) the dense regime)
 @pytest.mark.parametrize("size,B,nb", [(1000, 256, 8), (257, 256, 3), (300, 64, 5), (100000, 2048, 2), (5000, 1024, 2),
                                        (9000, 2048, 3), (20000, 2048, 4), (50000, 4096, 2), (20000, 4096, 3), (9000, 3000, 2),
                                        (700, 100, 6), (200, 48, 9),
                                        (1_000_000, 256, 64),
-                                       (100000, 8192, 2), (30000, 8192, 3), (20000, 8192, 2), (40000, 5000, 2), (200000, 16384, 1)])
+                                       (100000, 8192, 2), (30000, 8192, 3), (20000, 8192, 2), (40000, 5000, 2), (200000, 16384, 1),
+                                       (300000, 20000, 1), (150000, 65536, 1), (100000, 40000, 1)])
 def test_replay_sampler_bit_exact_vs_oracle(lib, size, B, nb):
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     buf = ReplayBuffer(size, B, "cuda", 0x1234ABCD5678, state_size=21, action_size=6)
