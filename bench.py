@@ -526,7 +526,8 @@ def extras(dev, args):
                                                                 "cores": cb["threads"], "env": "none (agent only)"}
         # (i) host vector env: 64 envs in worker processes (PyBullet would need one per process; the light stand-in
         # shares workers), B=256, ring 1e5 pre-filled past the `len > batch` gate by the first vector steps
-        workers = max(1, min(E, (os.cpu_count() or 8) // 2))
+        from robotic_manipulator_rloa_amd.environment.vector_env import usable_cpus
+        workers = max(1, min(E, usable_cpus() // 2))               # (the container's share, not the machine's 256)
         per = (E + workers - 1) // workers
         hv = {}
         for mode in (False, True):

@@ -33,13 +33,31 @@ _CMD_RESET, _CMD_STEP, _CMD_CLOSE = 1, 2, 3
 _LINE = 8                                  # uint64 words per worker: [command ordinal, command, done ordinal, pid, 0 ...]
 
 
-def _attach(name: str, shape, dtype):
-    shm = shared_memory.SharedMemory(name=name)
-    try:                                   # (the trainer owns the segments: this process's resource tracker must not unlink them)
-        from multiprocessing import resource_tracker
-        resource_tracker.unregister(shm._name, "shared_memory")
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the scheduler affinity mask and the cgroup's CPU quota, whichever is smaller —
+    os.cpu_count() counts the machine's (256 on a GPU box whose container gets 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
     except Exception:                      # noqa: BLE001
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except Exception:                  # noqa: BLE001
+            continue
+    return max(1, n)
+
+
+def _attach(name: str, shape, dtype):
+    shm = shared_memory.SharedMemory(name=name)      # (a spawned worker shares the trainer's resource tracker: nothing to unregister)
     return shm, np.ndarray(shape, dtype=dtype, buffer=shm.buf)
 
 
@@ -61,8 +79,10 @@ def _worker(w: int, env_fn, first: int, count: int, names: dict, max_frames: int
             # milliseconds), then sleep in short naps — and leave if the trainer is gone
             t_idle = time.perf_counter()
             while int(ctrl[base]) == seen:
-                if time.perf_counter() - t_idle > spin_s:
-                    time.sleep(0.0002)
+                idle = time.perf_counter() - t_idle
+                if idle > spin_s:
+                    # (more workers than cores: give the core away at once — a yield while a step may still be near, naps after)
+                    time.sleep(0.0 if idle < spin_s + 0.002 else 0.0002)
                     if os.getppid() != parent:
                         return
             seen = int(ctrl[base])
@@ -122,6 +142,8 @@ class HostVectorEnv:
         self.step_timeout_s, self.start_timeout_s, self.spin_s = float(step_timeout_s), float(start_timeout_s), float(spin_ms) * 1e-3
         self._slices = [(first, min(envs_per_worker, self.E - first)) for first in range(0, self.E, envs_per_worker)]
         W = len(self._slices)
+        if W + 1 > usable_cpus():
+            self.spin_s = 0.0              # more workers than cores: a spinning worker would keep a working one off its core
         spec = {"obs": ((self.E, self.S), np.float64), "state": ((self.E, self.S), np.float64),
                 "next_state": ((self.E, self.S), np.float64), "actions": ((self.E, self.A), np.float32),
                 "reward": ((self.E,), np.float64), "done": ((self.E,), np.int64), "episode_end": ((self.E,), np.int64),
@@ -177,6 +199,8 @@ class HostVectorEnv:
                     return int(c[b + 2]) == want
                 if now - t0 > 0.002:
                     time.sleep(0.0002)         # (a long wait — a worker starting up: do not burn a core on it)
+                elif self.spin_s == 0.0:
+                    time.sleep(0.0)            # (more workers than cores: let them run)
         return True
 
     def _replace(self, w: int) -> None:
