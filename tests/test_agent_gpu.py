@@ -539,19 +539,20 @@ def _torchrun(script, world, args=(), extra_env=None, timeout=900, cwd=None):
                           env=env, capture_output=True, text=True, timeout=timeout, cwd=cwd)
 
 
-def test_dp_run_loop_two_ranks_pipelined_timestep(tmp_path):
-    """the PIPELINED timestep under data parallel. Two ranks (cuda:0 shared), NAFAgent.run() with episodes of
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_run_loop_two_ranks_pipelined_timestep(tmp_path, world):
+    """the PIPELINED timestep under data parallel. Two / four ranks (cuda:0 shared), NAFAgent.run() with episodes of
     24 .. 48 steps out of a budget of 48 that end at different frames on the two ranks: the ranks vote per tick (parallel.
     TickAgreement) and run the six-launch graph together whenever every rank's prefetches hold and every rank brings a row, the
     graph that starts over together otherwise (idle ticks at an episode's end, a draw that met a row to come on either rank) —
     both ranks report the same (fast, slow) counts, a hundred and more ticks on the six-launch graph (B = 16 of at most 430 rows, two
     rows to come, two ranks: most prefetches are void on one rank or the other), bit-identical replicas, every
     transition in the ring once and in order, no timed-out wait, no error word."""
-    r = _torchrun(os.path.join(ROOT, "tests", "dp_loop_worker.py"), 2, cwd=str(tmp_path),
+    r = _torchrun(os.path.join(ROOT, "tests", "dp_loop_worker.py"), world, cwd=str(tmp_path),
                   extra_env={"NAF_XGMI": "1", "NAF_TEST_DP_LEN_SCALE": "8", "NAF_TEST_DP_FRAMES": "48", "NAF_TEST_DP_EPISODES": "12",
-                             "NAF_TEST_DP_BATCH": "16", "NAF_TEST_MIN_FAST": "100"})
+                             "NAF_TEST_DP_BATCH": "16", "NAF_TEST_MIN_FAST": "100" if world == 2 else "30"})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
-    assert "DP_LOOP_OK_0;" in r.stdout and "DP_LOOP_OK_1;" in r.stdout and "DP_PIPE rank 0" in r.stdout, r.stdout[-2000:]
+    assert all(f"DP_LOOP_OK_{k};" in r.stdout for k in range(world)) and "DP_PIPE rank 0" in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.parametrize("xgmi", ["1", "0"])

@@ -276,6 +276,48 @@ def test_data_parallel_world2_gloo(tmp_path):
     assert "DP_OK_0;" in r.stdout and "DP_OK_1;" in r.stdout, r.stdout[-2000:]
 
 
+_TICK_WORKER = r'''
+import os, sys, random, time
+sys.path.insert(0, os.environ["NAF_ROOT"])
+import torch.distributed as dist
+from robotic_manipulator_rloa_amd import parallel
+rank, local_rank, world = parallel.init_distributed("gloo")
+ag = parallel.TickAgreement.try_create(None, timeout_s=30.0)
+assert ag is not None and ag.world == world == 3 and ag.rank == rank
+# every rank's votes are known to every rank (seeded by tick and rank): the AND must come out the same everywhere, tick after tick,
+# whatever the ranks' relative speed (rank 1 dawdles at random; rank 2 races ahead)
+n, got = 4000, []
+rnd = random.Random(99)
+for t in range(n):
+    vote = [random.Random(1000 * t + r).random() < 0.8 for r in range(world)]
+    if rank == 1 and rnd.random() < 0.02:
+        time.sleep(0.0005)
+    assert ag.all_ok(vote[rank]) == all(vote), (t, rank)
+ag.close()
+dist.barrier(); dist.destroy_process_group()
+os.write(1, f"TICK_OK_{rank};".encode())
+'''
+
+
+def test_tick_agreement_three_ranks_gloo(tmp_path):
+    """parallel.TickAgreement — the per-tick vote that keeps the ranks of a data-parallel job on the SAME graph of the pipelined
+    per-timestep path (an exchange pairs with an exchange) — at world 3 over gloo on the CPU: 4000 ticks, every rank computes the
+    AND of all votes, with one rank dawdling at random (the two slots per rank, by the tick's parity, are what keeps a fast peer's
+    next vote from overwriting the one a slow rank still has to read)."""
+    import socket
+    script = tmp_path / "tick_worker.py"
+    script.write_text(_TICK_WORKER)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, NAF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert all(f"TICK_OK_{k};" in r.stdout for k in range(3)), r.stdout[-2000:]
+
+
 def test_bench_cli_refuses_to_fake_a_multi_gpu_run():
     """bench.py --gpus N on a host with fewer GPUs: an error, never a silent 1-rank line labelled n_gpus=1 (VERDICT r01);
     a launcher world that disagrees with --gpus: an error too. (No GPU is touched: the checks run before any HIP call.)"""
