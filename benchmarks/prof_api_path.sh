@@ -3,7 +3,7 @@
 # launches a timestep costs and what each takes. Usage (GPU box, repo root): benchmarks/prof_api_path.sh <tag> [batch]
 #   -> gpurun_out/<tag>_api_path_kernel_stats.csv, <tag>_api_path_digest.csv (us and launches per timestep)
 set -e
-tag=${1:-r05}; batch=${2:-64}
+tag=${1:-r06}; batch=${2:-64}
 export TMPDIR=/tmp
 d=/tmp/prof_api_$tag
 rm -rf $d
@@ -18,6 +18,6 @@ python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("gpurun_out/${tag}_api_path_kernel_stats.csv")))
 calls = sum(int(r["Calls"]) for r in rows)
-own = sum(int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("step_prep", "bb_layer1", "bb_linear", "bb_layer2", "gemm_bundle", "adam_act", "policy_act", "replay_", "counter_add", "bb_moments", "adam_polyak")))
+own = sum(int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("step_prep", "step_prefetch", "bb_layer1", "bb_linear", "bb_layer2", "gemm_bundle", "adam_act", "policy_act", "replay_", "counter_add", "bb_moments", "adam_polyak")))
 print(f"launches in the process: {calls} ({own} of the path's own kernels); per timestep ($steps timesteps incl. warm-up): {own / $steps:.2f}")
 PY
