@@ -387,7 +387,7 @@ def bulk_gather_roofline(S, A, ring_rows, n_rows, dev, row_alg, reps=20):
             "infinity_cache_share": round(min(1.0, 256 * 2 ** 20 / (ring_rows * ring.row_floats * 4)), 4), "bad_indices": bad,
             "physical_GBps": round(phys / (ms * 1e-3) / 1e9, 1),
             "note": "HIP events around back-to-back launches on the launching stream; achieved = algorithmic bytes "
-                    "(4*(2S+A+2)*2 + 4 per row: 404 B at S=21/A=6) / average launch time; profiles/r05_ring4e6_kernel_stats.csv / r05_ring16e6_kernel_stats.csv are "
+                    "(4*(2S+A+2)*2 + 4 per row: 404 B at S=21/A=6) / average launch time; profiles/r06_ring4e6_kernel_stats.csv / r06_ring16e6_kernel_stats.csv are "
                     "the rocprofv3 kernel-trace averages of this kernel instance, each ring in a process of its own. A ring row is padded "
                     "200 -> 256 B (two whole 128-B lines per random row) and a gathered row 200 -> 208 B, so the launch moves "
                     "1.16 x its algorithmic bytes; `traffic` is the PMC record of that (FETCH_SIZE x 2 + WRITE_SIZE). NOT an "
