@@ -66,7 +66,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 30
+#define NAF_HIP_ABI_VERSION 31
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -334,7 +334,12 @@ typedef struct naf_bb_stats_once {
     float* records;
     const int* epoch;
     uint64_t* errors;
+    /* round 6 (ABI 31): H = 512 runs TWO workgroups per row block, one per 256-column half; their partial heads meet in `exchange`
+     * (device scratch owned by the caller, 16-byte aligned, zero-initialised: naf_bb_layer2_head_exchange_floats(B, NHP) floats),
+     * as records tagged with *epoch. Required (with records / epoch) at H = 512, ignored at H = 256. */
+    float* exchange;
 } naf_bb_stats_once_t;
+int naf_bb_layer2_head_exchange_floats(int B, int NHP);
 int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
                        int64_t param_net_stride, const float* partials, float* running_mean, float* running_var,
                        int64_t stat_net_stride, float* a2_out, int ldo, float* save_mean, float* save_invstd, const float* Wh,

@@ -206,6 +206,7 @@ _PROTOS = {
                            _f, _f, _vp, _vp],
     "naf_bb_linear_stats_adam": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "naf_bb_layer2_head_rows": [_i],
+    "naf_bb_layer2_head_exchange_floats": [_i, _i],
     "naf_bb_layer2_head": [_vp, _i64, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp,
                            _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "naf_bb_layer1_bwd_kp": [_i],
@@ -317,7 +318,7 @@ class GemmBn2Bwd(C.Structure):
 
 class BbStatsOnce(C.Structure):
     """naf_bb_stats_once_t (include/naf_hip.h)"""
-    _fields_ = [("records", C.c_void_p), ("epoch", C.c_void_p), ("errors", C.c_void_p)]
+    _fields_ = [("records", C.c_void_p), ("epoch", C.c_void_p), ("errors", C.c_void_p), ("exchange", C.c_void_p)]
 
 
 class GemmL1Bwd(C.Structure):

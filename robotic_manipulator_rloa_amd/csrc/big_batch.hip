@@ -903,7 +903,7 @@ __device__ __forceinline__ static void bl_store_chunk(const f32x4 (&va)[8], cons
 // ADAM (the deferred optimizer step, adam_body.h): the one-dimensional grid carries, behind its n_main GEMM workgroups (index =
 // x + gx y of the former 2-D grid, gx = nets B/64), extra workgroups that step floats [0, 4 l1_4) of the flat buffers — the
 // layer-1 segment, which the launch in front of this one read for the last time.
-template <bool ADAM, bool FULL>
+template <bool ADAM, bool FULL, bool KBIG = false>
 __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3))) void bb_linear_stats_kernel(const float* __restrict__ a, int64_t a_net_stride,
                                                                      int lda, const float* __restrict__ W,
                                                                      const float* __restrict__ bias,
@@ -966,9 +966,26 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
     __syncthreads();                                      // first chunk fully consumed
     BL_TL(2);
     bl_store_chunk(va1, vb1, sA, sB, tid);
+    // KBIG (K = 512, round 6: layer sizes up to 512 on this chain; a kernel of its own — as a run-time loop it changed the register
+    // allocation of the K = 256 kernel the presets run): two more chunks per trip through the same two register sets, each chunk's
+    // loads issued before the MFMAs of the chunk in front of it
+    if (KBIG) bl_load_chunk_buf(va, vb, ab, la, lda, wb, lw, K, 2 * BL_KC);
     __syncthreads();
     BL_TL(3);
     bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
+    if (KBIG) for (int k0 = 2 * BL_KC; k0 < K; k0 += 2 * BL_KC) {
+        __syncthreads();                                  // the chunk in LDS fully consumed
+        bl_store_chunk(va, vb, sA, sB, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        bl_load_chunk_buf(va1, vb1, ab, la, lda, wb, lw, K, k0 + BL_KC);
+        __syncthreads();
+        bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
+        __syncthreads();
+        bl_store_chunk(va1, vb1, sA, sB, tid);
+        if (k0 + 2 * BL_KC < K) bl_load_chunk_buf(va, vb, ab, la, lda, wb, lw, K, k0 + 2 * BL_KC);
+        __syncthreads();
+        bl_mfma_chunk(pa0, pa1, pb, c00, c01, c10, c11);
+    }
     BL_TL(4);
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
     float v[2][4];
@@ -1013,7 +1030,7 @@ __global__ __launch_bounds__(BB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 3
 // each spends 2 x 1.2 us in its two MFMA phases — a quarter of the chip busy, latency all the way. Half as wide, twice as
 // many workgroups (wave w = rows 16 w .. +15, one MFMA tile): the MFMA phases halve. The statistics blocks stay 64 rows, so
 // the partials and every consumer are unchanged.
-template <bool ADAM, bool FULL>
+template <bool ADAM, bool FULL, bool KBIG = false>
 __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const float* __restrict__ a, int64_t a_net_stride, int lda,
                                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                                        int64_t param_net_stride, float* __restrict__ z,
@@ -1092,9 +1109,36 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
     for (int i = 0; i < 8; ++i) *(f32x4*)(sa_t + 8 * i * BL_LD) = va1[i];
 #pragma unroll
     for (int i = 0; i < 2; ++i) *(f32x4*)(sb_t + 8 * i * BL_LD) = vb1[i];
+    // K > 256 (round 6): two more chunks per trip, see bb_linear_stats_kernel
+    auto load_chunk = [&](f32x4 (&xa)[8], f32x4 (&xb)[2], int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xa[i] = naf_buf_f4(ab, la, (unsigned)(8 * i * lda + k0) * 4u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xb[i] = naf_buf_f4(wb, lw, (unsigned)(8 * i * K + k0) * 4u);
+    };
+    auto store_chunk = [&](const f32x4 (&xa)[8], const f32x4 (&xb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(f32x4*)(sa_t + 8 * i * BL_LD) = xa[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *(f32x4*)(sb_t + 8 * i * BL_LD) = xb[i];
+    };
+    if (KBIG) load_chunk(va, vb, 2 * BL_KC);
     __syncthreads();
     BL_TL(3);
     mfma_chunk();
+    if (KBIG) for (int k0 = 2 * BL_KC; k0 < K; k0 += 2 * BL_KC) {
+        __syncthreads();                                  // the chunk in LDS fully consumed
+        store_chunk(va, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(va1, vb1, k0 + BL_KC);
+        __syncthreads();
+        mfma_chunk();
+        __syncthreads();
+        store_chunk(va1, vb1);
+        if (k0 + 2 * BL_KC < K) load_chunk(va, vb, k0 + 2 * BL_KC);
+        __syncthreads();
+        mfma_chunk();
+    }
     BL_TL(4);
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg. Z2 out, then the column statistics of the 64-row block: 4 rows in
     // the lane, 4 lane groups, 4 waves through LDS
@@ -1154,7 +1198,14 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
 // FULL: whole 64-row blocks, at most 32 of them (every BASELINE config): the kernel as it was before round 4 took other batch sizes
 // — every row of every workgroup is a sample, the statistics fold has no last-block weights and no two-pass form. The general form
 // is a kernel of its own: inside one kernel its extra paths (never taken at these sizes) cost 0.2 us per update at B = 256.
-template <int PMODE, int NH4, int ROWS, bool FULL>
+// HALVES = 2 (round 6: layer sizes up to 512 — H = 512 columns): TWO workgroups per row block, workgroup 2 i + h owning columns
+// 256 h .. 256 h + 255 of block i. Everything up to the heads GEMM and everything behind the head body is per column (the statistics,
+// x-hat, A2, the Wh tile's columns, dA2, dY2, the block sums): the kernel above on a 256-column slice, reading and writing at a column
+// offset. The heads (and V'(s')) are sums over ALL columns: each sibling takes its half's partial products and hands them to the other
+// as self-validating 16-byte records {v, v, epoch, v} (the protocol of the statistics records: sc1 store, sc1 poll, bounded), both
+// add the two halves and the bias — a + b = b + a: the same bits on both — and run the head body redundantly (sibling 0 writes Q,
+// the loss parts and d_heads). Siblings are neighbours in the grid: a workgroup's sibling is resident or next in line for dispatch.
+template <int PMODE, int NH4, int ROWS, bool FULL, int HALVES = 1>
 __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const float* __restrict__ z, int64_t z_net_stride, int ldz, const float* __restrict__ gamma,
     const float* __restrict__ beta, int64_t param_net_stride, const float2* __restrict__ partials, int NB64,
@@ -1165,8 +1216,9 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     float* __restrict__ loss_partials, float* __restrict__ dy_out, int ldd, float2* __restrict__ partials_bw, int B, int A,
     float momentum, float eps, int xcd_rows, float* stat_rec /* polled while other workgroups of the launch write it: NOT __restrict__ — with it the compiler
     hoisted the poll's load out of its loop (the asm memory clobber does not reach a noalias argument) and the wait never ended */,
-    const int* epoch_p, unsigned long long* errors, int n_fold) {
+    const int* epoch_p, unsigned long long* errors, int n_fold, float* xch) {
     constexpr int NHP = 4 * NH4, H = FK_H;
+    constexpr int Ht = HALVES * FK_H;                      // columns of the layer; this workgroup's are c0 .. c0 + 255
     constexpr int MT = ROWS / 16;                          // 16-row MFMA tiles
     constexpr int RPW = ROWS / 8;                          // rows per wave where a wave owns whole rows
     constexpr int KS = ROWS == 16 ? 4 : 2;                 // K split of the heads GEMM (keeps the 8 waves busy)
@@ -1204,10 +1256,10 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         if (__builtin_expect(rb < n_fold, 0)) {
             asm volatile("" ::"s"(partials), "s"(NB64), "s"(B), "s"(eps), "s"(epoch_p), "s"(stat_rec));   // (one batch of scalar loads)
             if (tid < 32) {
-                const int pair = 32 * rb + tid, net = pair >> 8, col = pair & 255;
+                const int pair = 32 * rb + tid, net = pair / Ht, col = pair % Ht;
                 float mean, var;
-                if (ROWS == 16) bb_fold_stats<FULL>(partials      /* (16 rows per workgroup <=> B <= 2048 <=> at most 32 blocks) */ + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
-                else bb_fold_stats_big(partials + (int64_t)net * NB64 * H, H, NB64, B, col, &mean, &var);
+                if (ROWS == 16) bb_fold_stats<FULL>(partials      /* (16 rows per workgroup <=> B <= 2048 <=> at most 32 blocks) */ + (int64_t)net * NB64 * Ht, Ht, NB64, B, col, &mean, &var);
+                else bb_fold_stats_big(partials + (int64_t)net * NB64 * Ht, Ht, NB64, B, col, &mean, &var);
                 const float invstd = 1.0f / sqrtf(var + eps);
                 const int epoch = *epoch_p;
                 const f32x4 rec = {mean, invstd, __builtin_bit_cast(float, epoch), var};
@@ -1217,7 +1269,10 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         }
         rb -= n_fold;
     }
-    if (ROWS == 16 && (n_main & 15) == 0 && xcd_rows) rb = (rb & 7) * (n_main >> 3) + (rb >> 3);
+    const int half = HALVES == 2 ? (rb & 1) : 0, c0 = FK_H * half;
+    const int n_blocks = HALVES == 2 ? n_main >> 1 : n_main;
+    if (HALVES == 2) rb >>= 1;
+    if (ROWS == 16 && (n_blocks & 15) == 0 && xcd_rows) rb = (rb & 7) * (n_blocks >> 3) + (rb >> 3);
     const int64_t s0 = (int64_t)rb * ROWS;
     const int T = A * (A + 1) / 2, v_col = A + T;
     // every kernel argument this prologue needs, fetched NOW: left to itself the compiler fetches an argument where it is
@@ -1236,7 +1291,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const unsigned l16 = 16u * (unsigned)lane, l8 = 8u * (unsigned)lane, l4 = 4u * (unsigned)lane;
     f32x4 zm[RPW], zt[RPW];
     {
-        const __amdgpu_buffer_rsrc_t zb = naf_buf(z + (s0 + wave_s) * ldz), ztb = naf_buf(z + z_net_stride + (s0 + wave_s) * ldz);
+        const __amdgpu_buffer_rsrc_t zb = naf_buf(z + (s0 + wave_s) * ldz + c0), ztb = naf_buf(z + z_net_stride + (s0 + wave_s) * ldz + c0);
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {                   // one wave per row: 64 lanes x 4 columns; rows wave + 8 i
             zm[i] = naf_buf_f4(zb, l16, (unsigned)(8 * i * ldz) * 4u);
@@ -1246,13 +1301,13 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     constexpr int WPT = NHP * (H / 4) / FK_THREADS;       // float4 of the Wh tile per thread: 2, 4 or 6
     f32x4 wreg[WPT];
     {
-        const __amdgpu_buffer_rsrc_t wb = naf_buf(Wh + (int64_t)wave_s * ldw);
+        const __amdgpu_buffer_rsrc_t wb = naf_buf(Wh + (int64_t)wave_s * ldw + c0);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) wreg[i] = naf_buf_f4(wb, l16, (unsigned)(8 * i * ldw) * 4u);   // row = e >> 6, e = tid + 512 i
     }
-    const float bias_r = tid < NHP ? Wh[(int64_t)tid * ldw + H] : (tid == NHP ? Wh[wh_net_stride + (int64_t)v_col * ldw + H] : 0.f);
+    const float bias_r = tid < NHP ? Wh[(int64_t)tid * ldw + Ht] : (tid == NHP ? Wh[wh_net_stride + (int64_t)v_col * ldw + Ht] : 0.f);
     f32x4 wv_r = {0.f, 0.f, 0.f, 0.f};
-    if (tid < H / 4) wv_r = *(const f32x4*)(Wh + wh_net_stride + (int64_t)v_col * ldw + 4 * tid);
+    if (tid < H / 4) wv_r = *(const f32x4*)(Wh + wh_net_stride + (int64_t)v_col * ldw + c0 + 4 * tid);
     const int s_loc_ = tid >> 3, i_ = tid & 7;
     // rows of this workgroup that exist (the last workgroup of a batch that is not whole 16-row groups holds fewer): the others are
     // not samples — the head body leaves their d_heads zero (so dA2, dY2 and every block sum get nothing from them), their Z2 rows
@@ -1265,11 +1320,11 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         const int net = wave_s >> 2;                       // 512 threads = 2 nets x 256 columns: 4 waves per net
         const int cb = (wave_s & 3) * 64;                  // the wave's 64 columns
         const unsigned col = (unsigned)(cb + lane);
-        const float gm_ = naf_buf_f1(naf_buf(gamma + net * param_net_stride + cb), l4, 0);
-        const float bt_ = naf_buf_f1(naf_buf(beta + net * param_net_stride + cb), l4, 0);
+        const float gm_ = naf_buf_f1(naf_buf(gamma + net * param_net_stride + c0 + cb), l4, 0);
+        const float bt_ = naf_buf_f1(naf_buf(beta + net * param_net_stride + c0 + cb), l4, 0);
         float rm_ = 0.f, rv_ = 0.f;
-        float* rmp = running_mean + net * stat_net_stride;
-        float* rvp = running_var + net * stat_net_stride;
+        float* rmp = running_mean + net * stat_net_stride + c0;
+        float* rvp = running_var + net * stat_net_stride + c0;
         if (rb == 0) {
             rm_ = rmp[col];
             rv_ = rvp[col];
@@ -1278,14 +1333,14 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         f32x4 c;
         // (uniform n_fold) the folded statistics, once their record carries this launch; a thread whose budget runs out — the GPU is
         // shared and this XCD's folding workgroup still queued (bn2bwd_fold.h) — folds its pair itself: same arithmetic, same bits
-        if (n_fold && gemm_bn2bwd_poll_record(naf_buf(stat_rec), net * H + (int)col, *epoch_p, &c)) {
+        if (n_fold && gemm_bn2bwd_poll_record(naf_buf(stat_rec), net * Ht + c0 + (int)col, *epoch_p, &c)) {
             mean = c[0];
             invstd = c[1];
             var = c[3];
         } else {
             if (n_fold && errors) __hip_atomic_fetch_add(errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (ROWS == 16) bb_fold_stats_u<FULL>(naf_buf(partials + (int64_t)net * NB64 * H + cb), l8, 0, H, NB64, B, &mean, &var);
-            else bb_fold_stats_big(partials + (int64_t)net * NB64 * H, H, NB64, B, cb + lane, &mean, &var);
+            if (ROWS == 16) bb_fold_stats_u<FULL>(naf_buf(partials + (int64_t)net * NB64 * Ht + c0 + cb), l8, 0, Ht, NB64, B, &mean, &var);
+            else bb_fold_stats_big(partials + (int64_t)net * NB64 * Ht, Ht, NB64, B, c0 + cb + lane, &mean, &var);
             invstd = 1.0f / sqrtf(var + eps);
         }
         sStat[net][0][col] = mean;
@@ -1296,8 +1351,8 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             const float unbiased = B > 1 ? var * ((float)B / (float)(B - 1)) : var;
             rmp[col] = (1.0f - momentum) * rm_ + momentum * mean;
             rvp[col] = (1.0f - momentum) * rv_ + momentum * unbiased;
-            (save_mean + (int64_t)net * H)[col] = mean;
-            (save_invstd + (int64_t)net * H)[col] = invstd;
+            (save_mean + (int64_t)net * Ht + c0)[col] = mean;
+            (save_invstd + (int64_t)net * Ht + c0)[col] = invstd;
         }
     }
 #pragma unroll
@@ -1327,7 +1382,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             for (int c = 0; c < 4; ++c) y[c] = fmaxf(__builtin_fmaf(xh[c], g0[c], b0[c]), 0.f);
             *(f32x4*)(sXH + row * FK_LD + 4 * lane) = xh;
             if (A2T) *(f32x4*)(sA2 + row * FK_LD + 4 * lane) = y;
-            naf_buf_st_f4(naf_buf(a2_out + (s0 + wave_s) * ldo), l16, (unsigned)(8 * i * ldo) * 4u, y, B >= NAF_WT_MIN_B);
+            naf_buf_st_f4(naf_buf(a2_out + (s0 + wave_s) * ldo + c0), l16, (unsigned)(8 * i * ldo) * 4u, y, B >= NAF_WT_MIN_B);
             const f32x4 xt = (zt[i] - m1) * i1;
             float q = 0.f;
 #pragma unroll
@@ -1339,7 +1394,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
         for (int i = 0; i < RPW; ++i) p[i] = naf_sum64(p[i]);
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) sV[wave + 8 * i] = p[i] + sBias[NHP];
+            for (int i = 0; i < RPW; ++i) sV[wave + 8 * i] = HALVES == 2 ? p[i] : p[i] + sBias[NHP];    // (HALVES: the bias behind the exchange)
         }
     }
     __syncthreads();
@@ -1383,21 +1438,63 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             hsum += sHalf[h * ROWS * NHP + e];
             sHalf[h * ROWS * NHP + e] = 0.f;
         }
-        sHd[e] = hsum + sBias[e % NHP];
+        sHd[e] = HALVES == 2 ? hsum : hsum + sBias[e % NHP];
     }
     __syncthreads();
+    if (HALVES == 2) {
+        // the two column halves' partial heads (ROWS x NHP) and partial V'(s') (ROWS) meet: three values + the launch's number per
+        // 16-byte record, written through; the sibling's polled until they carry this launch's number (bounded: a sibling is a
+        // neighbour in the grid, resident or next in line)
+        constexpr int NV = ROWS * NHP + ROWS, NREC = (NV + 2) / 3;
+        const int epoch = *epoch_p;
+        const __amdgpu_buffer_rsrc_t mine = naf_buf(xch + ((int64_t)rb * 2 + half) * NREC * 4);
+        const __amdgpu_buffer_rsrc_t theirs = naf_buf(xch + ((int64_t)rb * 2 + (1 - half)) * NREC * 4);
+        auto val = [&](int j) { return j < ROWS * NHP ? sHd[j] : (j < NV ? sV[j - ROWS * NHP] : 0.f); };
+        for (int t = tid; t < NREC; t += FK_THREADS) {
+            const f32x4 rec = {val(3 * t), val(3 * t + 1), __builtin_bit_cast(float, epoch), val(3 * t + 2)};
+            naf_buf_st_f4_sc1(mine, 16u * (unsigned)t, 0, rec);
+        }
+        for (int t = tid; t < NREC; t += FK_THREADS) {
+            f32x4 c = naf_buf_f4_sc1(theirs, 16u * (unsigned)t, 0);
+            float tagf = c[2];
+            const long long t0 = wall_clock64();
+            while (__builtin_bit_cast(int, tagf) != epoch) {
+                if (wall_clock64() - t0 > 200000LL) {      // 2 ms: a hang guard, not a schedule — the update is poisoned and counted
+                    if (errors) __hip_atomic_fetch_add(errors, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    c[0] = c[1] = c[3] = __builtin_nanf("");
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                c = naf_buf_f4_sc1(theirs, 16u * (unsigned)t, 0);
+                tagf = c[2];
+            }
+            const float other[3] = {c[0], c[1], c[3]};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int j = 3 * t + q;
+                if (j < ROWS * NHP) sHd[j] = (sHd[j] + other[q]) + sBias[j % NHP];
+                else if (j < NV) sV[j - ROWS * NHP] = (sV[j - ROWS * NHP] + other[q]) + sBias[NHP];
+            }
+        }
+        __syncthreads();
+    }
     FK_TL(4);
     // ---- phase 3: the NAF head on the 32 rows (threads 0..255 carry samples; every thread joins the barriers) --------
-    naf_head_body<PMODE, 2, FK_THREADS>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td, q_out,
-                                        nullptr, loss_partials, B, A, s0, ns_);
+    naf_head_body<PMODE, 2, FK_THREADS>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td,
+                                        half ? nullptr : q_out, nullptr,
+                                        // (the body stores its workgroup's loss part at [blockIdx.x]; with two workgroups per row block
+                                        //  and the folding workgroups in front, the row block's own index keeps it inside the array)
+                                        half ? nullptr : (HALVES == 2 && loss_partials ? loss_partials + (rb - (int)blockIdx.x) : loss_partials),
+                                        B, A, s0, ns_);
     FK_TL(5);
-    if (tid < ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
+    if (!half && tid < ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
     // ---- phase 4: dA2 = d_heads Wh (K = NHP), MT x 16 tiles, 2 MT per wave; ReLU mask, dY2, block sums ------------------
     {
         const int mt = wave_s % MT;
         const float* pa = sDH + (16 * mt + rr) * NHP + 4 * gg;
         const unsigned ldd4 = (unsigned)ldd * 4u;
-        const __amdgpu_buffer_rsrc_t dyb = naf_buf(dy_out + s0 * ldd);
+        const __amdgpu_buffer_rsrc_t dyb = naf_buf(dy_out + s0 * ldd + c0);
         const unsigned ldy = (unsigned)(4 * gg) * ldd4 + 4u * (unsigned)rr;
 #pragma unroll
         for (int j = 0; j < 2 * MT; ++j) {
@@ -1434,7 +1531,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     }
     __syncthreads();
     if (A2T) {
-        const __amdgpu_buffer_rsrc_t dyr = naf_buf(dy_out + s0 * ldd);
+        const __amdgpu_buffer_rsrc_t dyr = naf_buf(dy_out + s0 * ldd + c0);
 #pragma unroll
         for (int i = 0; i < ROWS * (H / 4) / FK_THREADS; ++i) {
             const int e = tid + FK_THREADS * i, row = e >> 6, q = e & 63;
@@ -1448,7 +1545,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
             t.x += sP[MT - 1][tid].x;
             t.y += sP[MT - 1][tid].y;
         }
-        partials_bw[(int64_t)rb * H + tid] = t;
+        partials_bw[(int64_t)rb * Ht + c0 + tid] = t;
     }
     FK_TL(7);
 #undef FK_TL
@@ -1548,7 +1645,7 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
                                         int64_t param_net_stride, float* z, int64_t z_net_stride, int ldz, float* partials, int B,
                                         int N, int K, int nets, const naf_adam_args_t* adam, void* stream) {
     if (!a || !W || !bias || !z || !partials || !bb_shape_ok(B, N) || nets <= 0) return NAF_ERR_ARG;
-    if (K != 2 * BL_KC || lda < K || (lda & 3) || ldz < N) return NAF_ERR_ARG;     // two chunks of 128: the framework's H = 256
+    if (K < 2 * BL_KC || K > 4 * BL_KC || K % (2 * BL_KC) != 0 || lda < K || (lda & 3) || ldz < N) return NAF_ERR_ARG;   // pairs of 128-k chunks: H = 256 | 512
     if ((((uintptr_t)a | (uintptr_t)W) & 15) != 0 || (a_net_stride & 3) != 0 || (param_net_stride & 3) != 0 ||
         ((uintptr_t)partials & 7) != 0)
         return NAF_ERR_ARG;
@@ -1559,13 +1656,18 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
     const int xcd_nets = 1;      // rows by eighths (bb_place_rows)
     const int gx = nets * bb_blocks(B);
     hipStream_t st = (hipStream_t)stream;
-#define BB_LS_(KERNEL, GY, FL)                                                                                              \
+#define BB_LS__(KERNEL, GY, FL, KB)                                                                                         \
     do {                                                                                                                    \
         const int n_main = gx * (GY);                                                                                       \
-        if (adam) KERNEL<true, FL><<<n_main + extra, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, \
+        if (adam) KERNEL<true, FL, KB><<<n_main + extra, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, \
                                                                       z_net_stride, ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4, xcd_nets); \
-        else KERNEL<false, FL><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride, \
+        else KERNEL<false, FL, KB><<<n_main, BB_THREADS, 0, st>>>(a, a_net_stride, lda, W, bias, param_net_stride, z, z_net_stride, \
                                                           ldz, (float2*)partials, B, N, K, gx, n_main, ad, l1_4, xcd_nets);             \
+    } while (0)
+#define BB_LS_(KERNEL, GY, FL)                               \
+    do {                                                     \
+        if (K > 2 * BL_KC) BB_LS__(KERNEL, GY, FL, true);    \
+        else BB_LS__(KERNEL, GY, FL, false);                 \
     } while (0)
 #define BB_LS(KERNEL, GY)                            \
     do {                                             \
@@ -1580,6 +1682,7 @@ extern "C" int naf_bb_linear_stats_adam(const float* a, int64_t a_net_stride, in
     else BB_LS(bb_linear_stats_kernel, N / BL_BN);
 #undef BB_LS
 #undef BB_LS_
+#undef BB_LS__
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }
@@ -1588,6 +1691,13 @@ extern "C" int naf_bb_layer2_head_rows(int B) {
     // (32 rows per workgroup measured slower at every batch size up to 2048: 16.9k -> 17.7k updates/s there with 16. Beyond 2048 it
     //  is 32 all the same: the bundle's BatchNorm-backward fold takes at most 128 blocks of backward partials, bn2bwd_fold.h)
     return B > 32 * BB_ROWS ? 32 : 16;
+}
+
+// the exchange area of the two-halves form (H = 512): per row block and half, ceil((rows NHP + rows) / 3) records of 4 floats
+extern "C" int naf_bb_layer2_head_exchange_floats(int B, int NHP) {
+    if (B <= 0 || NHP <= 0) return NAF_ERR_ARG;
+    const int rows = naf_bb_layer2_head_rows(B);
+    return ((B + rows - 1) / rows) * 2 * ((rows * NHP + rows + 2) / 3) * 4;
 }
 
 extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz, const float* gamma, const float* beta,
@@ -1599,8 +1709,10 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
                                   float eps, const naf_bb_stats_once_t* once, void* stream) {
     if (once && (!once->records || !once->epoch || ((uintptr_t)once->records & 15))) return NAF_ERR_ARG;
     if (!z || !gamma || !beta || !partials || !running_mean || !running_var || !a2_out || !save_mean || !save_invstd || !Wh ||
-        !u || !r || !q_out || !d_heads || !dy_out || !partials_bw || !bb_shape_ok(B, H) || H != FK_H)
+        !u || !r || !q_out || !d_heads || !dy_out || !partials_bw || !bb_shape_ok(B, H) || (H != FK_H && H != 2 * FK_H))
         return NAF_ERR_ARG;
+    const bool two = H == 2 * FK_H;      // two workgroups per row block (HALVES = 2): needs the exchange area and the launch's number
+    if (two && (!once || !once->exchange || ((uintptr_t)once->exchange & 15))) return NAF_ERR_ARG;
     if (A <= 0 || A > NAF_MAX_A || (NHP != 16 && NHP != 32 && NHP != 48) || NHP < A + A * (A + 1) / 2 + 1) return NAF_ERR_ARG;
     if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
     if (ldz < H || (ldz & 3) || ldo < H || (ldo & 3) || ldd < H || ldw <= H || (ldw & 3) || ldu < A || ldr < 1) return NAF_ERR_ARG;
@@ -1612,17 +1724,21 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
     // folded once per launch where a workgroup would pull more than 8 statistics blocks per column (B > 512) — and only there: the
     // readers wait ~2.6 us for the records (updates/s, A/B/A/B on one box: B = 512 30.4k -> 30.2k with it, 1024 25.9k -> 26.3k,
     // 1536 21.0k -> 21.65k, 2048 20.35k -> 20.58k)
-    const int n_fold = (once && bb_blocks(B) > 8) ? 2 * FK_H / 32 : 0;
-    const int blocks = (B + rows - 1) / rows + n_fold;
+    const int n_fold = (once && bb_blocks(B) > 8) ? 2 * H / 32 : 0;
+    const int blocks = (two ? 2 : 1) * ((B + rows - 1) / rows) + n_fold;
+    float* xch = once ? once->exchange : nullptr;
     float* rec = once ? once->records : nullptr;
     const int* epoch_p = once ? once->epoch : nullptr;
     unsigned long long* errors = once ? (unsigned long long*)once->errors : nullptr;
     const int xcd_rows = 1;      // row chunks dealt to the XCD whose dA1 blocks read them (+0.4 - 1 %)
-#define BB_FK_R(PM, NH4V, RW, FL)                                                                                           \
-    bb_layer2_head_kernel<PM, NH4V, RW, FL><<<blocks, FK_THREADS, 0, st>>>(                                                  \
-        z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, bb_blocks(B), running_mean, running_var, \
+#define BB_FK_ARGS z, z_net_stride, ldz, gamma, beta, param_net_stride, (const float2*)partials, bb_blocks(B), running_mean, running_var, \
         stat_net_stride, a2_out, ldo, save_mean, save_invstd, Wh, wh_net_stride, ldw, u, ldu, r, ldr, gamma_td, q_out, d_heads, \
-        loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows, rec, epoch_p, errors, n_fold)
+        loss_partials, dy_out, ldd, (float2*)partials_bw, B, A, momentum, eps, xcd_rows, rec, epoch_p, errors, n_fold, xch
+#define BB_FK_R(PM, NH4V, RW, FL)                                                                                           \
+    do {                                                                                                                    \
+        if (two) bb_layer2_head_kernel<PM, NH4V, RW, FL, 2><<<blocks, FK_THREADS, 0, st>>>(BB_FK_ARGS);                      \
+        else bb_layer2_head_kernel<PM, NH4V, RW, FL, 1><<<blocks, FK_THREADS, 0, st>>>(BB_FK_ARGS);                          \
+    } while (0)
 #define BB_FK(PM, NH4V)                                                          \
     do {                                                                         \
         if (rows == 16 && B % BB_ROWS == 0) BB_FK_R(PM, NH4V, 16, true);          \
@@ -1640,6 +1756,7 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
 #undef BB_FK_NH
 #undef BB_FK
 #undef BB_FK_R
+#undef BB_FK_ARGS
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

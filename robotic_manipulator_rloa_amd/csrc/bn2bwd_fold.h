@@ -122,10 +122,12 @@ __device__ static inline f32x4 gemm_bn2bwd_fold_column(const naf_gemm_bn2bwd_t& 
 // stores have landed, one polling lane, barrier, records: 30.1k | 27.3k | 24.0k on a box ~2 % faster | 16.4k. Every block folding
 // for itself, the form before: 29.9k | 27.2k | not possible | not possible.)
 // the waiting side: constants of the block's columns -> cst (LDS, [4][256]). The caller puts the barrier behind it.
+// kbase (k-contiguous A only): the first of the 256 columns the array holds — 0 but for layer sizes beyond 256 (round 6), where a
+// block walks K = H in 256-column stretches and refills the array at each.
 template <bool AK, int THREADS>
-__device__ static inline void gemm_bn2bwd_wait_constants(const naf_gemm_bn2bwd_t& P, int m0, int tid, float* cst) {
+__device__ static inline void gemm_bn2bwd_wait_constants(const naf_gemm_bn2bwd_t& P, int m0, int tid, float* cst, int kbase = 0) {
     constexpr int NCOL = AK ? 32 : 256;
-    const int col0 = AK ? m0 : 0;
+    const int col0 = AK ? m0 : kbase;
     if (tid < NCOL) {
         const int col = col0 + tid;
         const int epoch = *P.epoch;

@@ -58,9 +58,10 @@ struct GemmBundle {
 // TAIL: some descriptor with an epilogue has rows past the batch in its last row block (a batch that is not whole 32-row blocks):
 // a kernel of its own. The launches of every other batch size run code without a trace of it — as a block-uniform branch inside one
 // kernel the clamps and the mask cost 0.25 us per update at B = 256 (A/B on one box; the blocks' cold straight-line code got longer).
-template <int T, int KC, bool TAIL_ = false>
+template <int T, int KC, bool TAIL_ = false, bool HBIG_ = false>
 struct GB {
     static constexpr bool TAIL = TAIL_;
+    static constexpr bool HBIG = HBIG_;        // layer sizes beyond 256 (round 6): the prologue's column constants refilled per 256 k
     static constexpr int THREADS = T, CHUNK = KC;
     static constexpr int LD = KC + 4;          // [row][k] panels: 16-B aligned rows, b128 fragment reads spread over the banks
     static constexpr int LDK = 36;             // [k][row] panels (k-major operands keep their memory layout): 32 rows + 4 pad
@@ -355,7 +356,7 @@ __device__ static inline void gemm_l1bwd_epilogue(const GemmDesc& D, int bm, int
 //   loads) and in the tail chunk of a K range that is not a multiple of KC (load_panel<true, false>: e = tid + T i, column quad e & 7)
 template <class G, bool AK>
 __device__ __forceinline__ static void gemm_bn2bwd_apply(float4 (&va)[GB_PT], const float4 (&vz)[GB_PT], const float* cst, int tid, int k0) {
-    const int ci = AK ? 4 * (tid & 7) : k0 + 4 * (tid & (G::RK - 1));
+    const int ci = AK ? 4 * (tid & 7) : (G::HBIG ? (k0 & 255) : k0) + 4 * (tid & (G::RK - 1));
     const f32x4 mean = *(const f32x4*)(cst + ci), k1 = *(const f32x4*)(cst + 256 + ci), kc1 = *(const f32x4*)(cst + 512 + ci),
                 q = *(const f32x4*)(cst + 768 + ci);
 #pragma unroll
@@ -448,6 +449,11 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
     for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
         const int kc = (k_hi - k0) < KC ? (k_hi - k0) : KC;
         if (k0 != k_lo) __syncthreads();                  // previous chunk fully consumed
+        if (G::HBIG && !AK && pro && k0 != k_lo && (k0 & 255) == 0) {
+            // (K = H = 512: the next 256 columns' constants; every wave is past the stretch before — the barrier above)
+            gemm_bn2bwd_wait_constants<AK, G::THREADS>(D.pro, m0, tid, sC, k0);
+            __syncthreads();
+        }
         if (pro) gemm_bn2bwd_apply<G, AK>(va, vz, sC, tid, k0);
         if (kc == KC) {
             store_panel<G, AK, true>(sA, va, kc, tid);
@@ -526,14 +532,16 @@ __device__ static inline void gemm_block(const GemmDesc& D, int bm, int bn, int 
 #ifndef GB_WAVES_PER_EU
 #define GB_WAVES_PER_EU 4
 #endif
-#define GB_FOLD_WGS (256 / GB_FOLD_COLS)     // folding workgroups of a launch with a prologue (H = 256)
-// FOLD: the launch has a BatchNorm-backward prologue and its first GB_FOLD_WGS workgroups fold the block sums. A template
+// NFOLD (0 | 256 / GB_FOLD_COLS | 512 / GB_FOLD_COLS): the launch has a BatchNorm-backward prologue and its first NFOLD
+// workgroups fold the block sums — one per 32 columns of the layer (H = 256: 8; H = 512, round 6: 16). A template
 // parameter, not a kernel argument: everything that waits in this launch waits for those workgroups, and as arguments their way to
 // the first load of the partials led through three dependent scalar round trips (n_fold -> fold_desc -> the fields of
 // d[fold_desc].pro, ~0.25 us each in front of a cold scalar cache) plus one more in front of the record store; now it is one batch.
-template <int T, int KC, bool FOLD, bool TAIL = false>
+template <int T, int KC, int NFOLD, bool TAIL = false>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(GB_WAVES_PER_EU, GB_WAVES_PER_EU))) void gemm_bundle_kernel(const GemmBundle bundle) {
-    using G = GB<T, KC, TAIL>;
+    using G = GB<T, KC, TAIL, (NFOLD > 256 / GB_FOLD_COLS)>;
+    constexpr bool FOLD = NFOLD > 0;
+    constexpr int GB_FOLD_WGS = NFOLD;
     __shared__ __attribute__((aligned(16))) float sA[G::PANEL];
     __shared__ __attribute__((aligned(16))) float sB[G::PANEL];
     __shared__ __attribute__((aligned(16))) float sC[4 * 64 * 4];   // the column constants of the prologue, then the K halves' hand-over
@@ -627,7 +635,7 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
         if (s.pro) {
             const naf_gemm_bn2bwd_t& q = *s.pro;
             if (!q.z || !q.partials || !q.gamma || !q.save_mean || !q.save_invstd || !q.d_gamma || !q.d_beta || q.npb < 1 ||
-                q.npb > 128 || !q.cst || !q.epoch || ((uintptr_t)q.cst & 15) || q.B <= 0 || q.H != 256 || (s.M & 15) || (s.N & 31) ||
+                q.npb > 128 || !q.cst || !q.epoch || ((uintptr_t)q.cst & 15) || q.B <= 0 || (q.H != 256 && q.H != 512) || (s.M & 15) || (s.N & 31) ||
                 (s.a_kmajor ? s.M != q.H : s.K != q.H) || ((uintptr_t)q.z & 15) || ((uintptr_t)q.partials & 7))
                 return NAF_ERR_ARG;      // (the A operand's columns are the H features: its M when k-major, its K otherwise)
             d.pro = q;
@@ -657,20 +665,27 @@ extern "C" int naf_gemm_bundle(const naf_gemm_desc_t* descs, int n, void* stream
     // (updates/s, A/B/A/B on one box: B = 1536 20.6k -> 21.0k, B = 2048 20.05k -> 20.35k; B = 1024, 428 blocks: 26.1k -> 25.2k)
     const bool big = tiles + b.n_fold > 512;
     hipStream_t st = (hipStream_t)stream;
-    if (b.n_fold) {
+    if (b.n_fold == 16) {                                 // H = 512 (round 6)
         b.fold_pro = b.d[b.fold_desc].pro;
         if (tail) {
-            if (big) gemm_bundle_kernel<256, 128, true, true><<<tiles + b.n_fold, 256, 0, st>>>(b);
-            else gemm_bundle_kernel<512, 256, true, true><<<tiles + b.n_fold, 512, 0, st>>>(b);
-        } else if (big) gemm_bundle_kernel<256, 128, true><<<tiles + b.n_fold, 256, 0, st>>>(b);
-        else gemm_bundle_kernel<512, 256, true><<<tiles + b.n_fold, 512, 0, st>>>(b);
+            if (big) gemm_bundle_kernel<256, 128, 16, true><<<tiles + b.n_fold, 256, 0, st>>>(b);
+            else gemm_bundle_kernel<512, 256, 16, true><<<tiles + b.n_fold, 512, 0, st>>>(b);
+        } else if (big) gemm_bundle_kernel<256, 128, 16><<<tiles + b.n_fold, 256, 0, st>>>(b);
+        else gemm_bundle_kernel<512, 256, 16><<<tiles + b.n_fold, 512, 0, st>>>(b);
+    } else if (b.n_fold) {
+        b.fold_pro = b.d[b.fold_desc].pro;
+        if (tail) {
+            if (big) gemm_bundle_kernel<256, 128, 8, true><<<tiles + b.n_fold, 256, 0, st>>>(b);
+            else gemm_bundle_kernel<512, 256, 8, true><<<tiles + b.n_fold, 512, 0, st>>>(b);
+        } else if (big) gemm_bundle_kernel<256, 128, 8><<<tiles + b.n_fold, 256, 0, st>>>(b);
+        else gemm_bundle_kernel<512, 256, 8><<<tiles + b.n_fold, 512, 0, st>>>(b);
     } else {
         memset(&b.fold_pro, 0, sizeof(b.fold_pro));
         if (tail) {
-            if (big) gemm_bundle_kernel<256, 128, false, true><<<tiles, 256, 0, st>>>(b);
-            else gemm_bundle_kernel<512, 256, false, true><<<tiles, 512, 0, st>>>(b);
-        } else if (big) gemm_bundle_kernel<256, 128, false><<<tiles, 256, 0, st>>>(b);
-        else gemm_bundle_kernel<512, 256, false><<<tiles, 512, 0, st>>>(b);
+            if (big) gemm_bundle_kernel<256, 128, 0, true><<<tiles, 256, 0, st>>>(b);
+            else gemm_bundle_kernel<512, 256, 0, true><<<tiles, 512, 0, st>>>(b);
+        } else if (big) gemm_bundle_kernel<256, 128, 0><<<tiles, 256, 0, st>>>(b);
+        else gemm_bundle_kernel<512, 256, 0><<<tiles, 512, 0, st>>>(b);
     }
     NAF_CHECK_LAUNCH();
     return NAF_OK;

@@ -102,7 +102,9 @@ class NetLayout:
                              "group in the stand-alone ones)")
         self.H_ref = int(layer_size)
         self.S, self.A = state_size, action_size
-        self.H = NATIVE_LAYER if (pad_layer and 0 < layer_size < NATIVE_LAYER) else int(layer_size)
+        # (round 6: widths in (256, 512) likewise stored as 512 — the row-split chain runs 512 columns as two 256-column halves)
+        self.H = (NATIVE_LAYER if (pad_layer and 0 < layer_size < NATIVE_LAYER) else
+                  2 * NATIVE_LAYER if (pad_layer and NATIVE_LAYER < layer_size < 2 * NATIVE_LAYER) else int(layer_size))
         self.T = action_size * (action_size + 1) // 2
         self.NH = self.A + self.T + 1                  # [mu | l | V]
         self.NHP = _round_up(self.NH, 16)              # heads row stride (ldh): whole 16-wide MFMA tiles
@@ -207,7 +209,7 @@ class Learner:
         #  B = 2048, where the fused layer-2 + head launch runs 32 rows per workgroup),
         #  zero-initialised: the weight-gradient products walk Bp rows as their K dimension, and a row past the batch is a zero in at
         #  least one operand of each — dH and dY2 rows the head body never writes, A1 rows layer 1 never stores.)
-        self.bb_ok = (16 <= self.B <= 4096 and lay0.H == 256 and lay0.S <= 26 and lay0.A <= 8)
+        self.bb_ok = (16 <= self.B <= 4096 and lay0.H in (256, 512) and lay0.S <= 26 and lay0.A <= 8)
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
@@ -443,7 +445,10 @@ class Learner:
             # layer 2's forward statistics folded once per launch too where a workgroup would pull more than 16 blocks of them
             # (B > 1024; the library decides): records of their own, the same launch counter and error word
             self.bb_stat_rec = torch.zeros(2 * H, 4, **f32)
-            self._stats_once_s = _lib.BbStatsOnce(ptr(self.bb_stat_rec), ptr(self.bb_fold_flag), self.err_host.data_ptr())
+            # (H = 512: the fused layer-2 launch runs two workgroups per row block, one per 256-column half; their partial heads meet here)
+            self.bb_exchange = torch.zeros(max(4, self.lib.naf_bb_layer2_head_exchange_floats(B, NHP)), **f32) if H > 256 else None
+            self._stats_once_s = _lib.BbStatsOnce(ptr(self.bb_stat_rec), ptr(self.bb_fold_flag), self.err_host.data_ptr(),
+                                                  ptr(self.bb_exchange))
             self._stats_once = _lib.C.byref(self._stats_once_s)
             # dA1 FIRST: its blocks carry the layer-1 epilogue and run longest; dispatched first, the short weight-gradient
             # blocks fill in behind them instead of the other way round
