@@ -575,7 +575,9 @@ def extras(dev, args):
                 "layer_size 128 (kuka, batch 256, ring 1e6): stored zero-padded to 256":
                     measure_shape(dev, "kuka", 256, 1000000, E, 500, 30, layer=128),
                 "layer_size 128, batch 1024 (kuka, ring 1e6)": measure_shape(dev, "kuka", 1024, 1000000, E, 300, 30, layer=128),
-                "layer_size 512 (kuka, batch 256, ring 1e6): column tiles": measure_shape(dev, "kuka", 256, 1000000, E, 300, 30, layer=512),
+                "layer_size 512 (kuka, batch 256, ring 1e6): the row-split chain on two 256-column halves (round 6; column tiles before)":
+                    measure_shape(dev, "kuka", 256, 1000000, E, 300, 30, layer=512),
+                "layer_size 512, batch 1024 (kuka, ring 1e6)": measure_shape(dev, "kuka", 1024, 1000000, E, 200, 20, layer=512),
             }
     finally:
         os.chdir(old)

@@ -241,7 +241,7 @@ class Learner:
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)
             import warnings
             warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
-                          f"row-split chain): the row-split kernels need 16 <= batch_size <= 4096, layer_size 256 and "
+                          f"row-split chain): the row-split kernels need 16 <= batch_size <= 4096, layer_size <= 512 and "
                           f"state_size <= 26", stacklevel=3)
         # with every gradient element produced by one of our own kernels, those kernels also emit its sum-of-squares partial:
         # the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken on the all-reduced gradient).
