@@ -169,8 +169,9 @@ def test_agent_trains_at_shapes_beyond_the_fused_kernels(scratch_cwd, S, A, B):
 
 @pytest.mark.parametrize("H,B", [(512, 64), (384, 300), (128, 64)])
 def test_agent_trains_at_other_layer_sizes(scratch_cwd, H, B):
-    """layer_size is the user's (rl_framework.py:68-74): wider than 256 runs the column-tile chain and the stand-alone launches of
-    the per-timestep path; narrower is stored zero-padded to 256 and runs the pipelined graphs. Either way NAFAgent.act / step work,
+    """layer_size is the user's (rl_framework.py:68-74): narrower than 256 is stored zero-padded to 256 and runs the pipelined graphs;
+    up to 512 (round 6) runs the row-split chain on two 256-column halves — 384 stored as 512 — with naf_step_prep in front and the
+    optimizer launch + act() behind it (the launch that fuses those two is 256-wide). Either way NAFAgent.act / step work,
     the parameters stay finite, state_dict() has the reference's shapes and loads into a fresh agent that then acts the same."""
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
     from synth_data import make_transitions
@@ -178,7 +179,7 @@ def test_agent_trains_at_other_layer_sizes(scratch_cwd, H, B):
     n = B + 60
     st, ac, rw, ns, dn = make_transitions(n, S, A, seed=17)
     agent = NAFAgent(object(), S, A, H, B, 4 * n, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
-    assert agent.learner.chain == ("rows" if H <= 256 else "columns")
+    assert agent.learner.chain == "rows" and agent.learner.lay.H == (256 if H <= 256 else 512)
     state = st[0].astype(np.float64)
     for t in range(n):
         a = agent.act(state)
@@ -187,7 +188,7 @@ def test_agent_trains_at_other_layer_sizes(scratch_cwd, H, B):
         state = ns[t].astype(np.float64)
     torch.cuda.synchronize()
     assert int(agent.learner.step_dev.item()) == n - B and torch.isfinite(agent.learner.theta2).all() and np.isfinite(agent.last_loss())
-    assert (agent._chunk.pipelined if H <= 256 else not agent._chunk.fused_prep)
+    assert (agent._chunk.pipelined if H <= 256 else (agent._chunk.fused_prep and not agent._chunk.fused_tail))
     sd = agent.qnetwork_main.state_dict()
     assert tuple(sd["hidden_layer.weight"].shape) == (H, H) and tuple(sd["bn1.running_mean"].shape) == (H,) and \
         tuple(sd["action_values.weight"].shape) == (A, H)
@@ -549,8 +550,10 @@ def test_dp_run_loop_two_ranks_pipelined_timestep(tmp_path, world):
     rows to come, two ranks: most prefetches are void on one rank or the other), bit-identical replicas, every
     transition in the ring once and in order, no timed-out wait, no error word."""
     r = _torchrun(os.path.join(ROOT, "tests", "dp_loop_worker.py"), world, cwd=str(tmp_path),
-                  extra_env={"NAF_XGMI": "1", "NAF_TEST_DP_LEN_SCALE": "8", "NAF_TEST_DP_FRAMES": "48", "NAF_TEST_DP_EPISODES": "12",
-                             "NAF_TEST_DP_BATCH": "16", "NAF_TEST_MIN_FAST": "100" if world == 2 else "30"})
+                  # (four ranks share the one GPU here: a tick costs them 70 ms — half the ticks at W = 4)
+                  extra_env={"NAF_XGMI": "1", "NAF_TEST_DP_LEN_SCALE": "8" if world == 2 else "4",
+                             "NAF_TEST_DP_FRAMES": "48" if world == 2 else "24", "NAF_TEST_DP_EPISODES": "12",
+                             "NAF_TEST_DP_BATCH": "16", "NAF_TEST_MIN_FAST": "100" if world == 2 else "10"})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
     assert all(f"DP_LOOP_OK_{k};" in r.stdout for k in range(world)) and "DP_PIPE rank 0" in r.stdout, r.stdout[-2000:]
 

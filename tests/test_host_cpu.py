@@ -111,7 +111,12 @@ def test_reference_init_bit_exact_and_layout_roundtrip():
         # the padded units: rows h.. of W1 / b1 / g1 / be1 / W2 / b2 / g2 / be2, columns h.. of W2, columns h..255 of Wh — never a view's
         assert not used[lay.seg["g1"].offset + h:lay.seg["g1"].offset + 256].any()
         assert float(lay.view(flat, "Wh")[:, h:256].abs().max()) == 0.0 and float(lay.view(flat, "W2")[:, h:].abs().max()) == 0.0
-    assert NetLayout(21, 6, 300).H == 300                   # (wider than the native width: as it is)
+    # (round 6: a width in (256, 512) is stored as 512 the same way — the row-split chain runs 512 columns as two 256-column halves;
+    #  beyond 512, and wherever pad_layer = False, as it is)
+    mid = NetLayout(21, 6, 300)
+    assert (mid.H, mid.H_ref, mid.HP) == (512, 300, 528) and mid.P == NetLayout(21, 6, 512).P and \
+        mid.n_ref_params() == NetLayout(21, 6, 300, pad_layer=False).n_ref_params()
+    assert NetLayout(21, 6, 300, pad_layer=False).H == 300 and NetLayout(21, 6, 512).H == 512 and NetLayout(21, 6, 600).H == 600
 
 
 def test_hyperparameter_rules_match_reference_contract():
