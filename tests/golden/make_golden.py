@@ -344,6 +344,43 @@ def main():
                             ref_updates_per_s=np.array(n_upd / dt), **checks,
                             **flat("main_end", sd_np(agent.qnetwork_main.state_dict())))
 
+    # ---------------- G7: teacher-forced loss curves at batch sizes that are NOT whole 64-row blocks / lie beyond 2048 ------------
+    # (round 6: the partial-block and beyond-2048 variants of the row-split kernels were held to the numpy oracle over thousands of
+    #  updates, computed live in the GPU suite — now to the unmodified reference's learn() itself, as G5 holds the whole-block ones.
+    #  Same rows, positions and initial weights as tests/test_learner_gpu.py::test_long_teacher_forced_run_*: 40000 rows of seed
+    #  2024, batch_indices(seed 99), the constructor's own weights at seed 0 = G3's kuka/main0.)   --only g7
+    if only is not None and "g7" in only:
+        import time
+        S, A, NROWS = 21, 6, 40000
+        st, ac, rw, ns, dn = make_transitions(NROWS, S, A, seed=2024, rare_events=False, structured_reward=True)
+        tst, tac, trw, tns, tdn = (torch.from_numpy(st), torch.from_numpy(ac).long(), torch.from_numpy(rw[:, None]),
+                                   torch.from_numpy(ns), torch.from_numpy(dn[:, None]))
+        out = {}
+        for B, n_upd in ((100, 5000), (1000, 5000), (2560, 600), (4096, 2000)):
+            idx = batch_indices(NROWS, B, n_upd, seed=99)
+            agent = NAFAgent(object(), S, A, 256, B, NROWS, 1e-3, 1e-3, 0.99, 1, 1, 500, cpu, 0)
+            losses = []
+            real_mse = ref_alg.F.mse_loss
+
+            def tap(a_, b_):
+                l_ = real_mse(a_, b_)
+                losses.append(float(l_.detach()))
+                return l_
+            ref_alg.F.mse_loss = tap
+            t0 = time.time()
+            for k in range(n_upd):
+                ii = torch.from_numpy(idx[k].astype(np.int64))
+                agent.learn((tst[ii], tac[ii], trw[ii], tns[ii], tdn[ii]))
+            ref_alg.F.mse_loss = real_mse
+            dt = time.time() - t0
+            sd = agent.qnetwork_main.state_dict()
+            out[f"b{B}/losses"] = np.array(losses, dtype=np.float32)
+            out[f"b{B}/theta_l2"] = np.array(float(sum((v.double() ** 2).sum() for n, v in sd.items()
+                                                       if v.dtype.is_floating_point and 'running' not in n) ** 0.5))
+            out[f"b{B}/dims"] = np.array([S, A, B, NROWS, n_upd])
+            print(f"g7: B = {B}: {n_upd} updates in {dt:.1f}s = {n_upd / dt:.1f} updates/s (reference learn(), CPU)", flush=True)
+        np.savez_compressed(os.path.join(HERE, "g7_curves.npz"), data_seed=np.array(2024), idx_seed=np.array(99), **out)
+
     with open(os.path.join(HERE, "VERSIONS.txt"), "w") as f:
         f.write(f"generated by make_golden.py with torch {meta['torch']}, numpy {meta['numpy']} (CPU)\n")
 

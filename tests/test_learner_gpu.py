@@ -310,26 +310,28 @@ def test_learn_at_the_reference_agent_tests_shape_g3():
     np.testing.assert_allclose(lp.sum(1).cpu().numpy(), g[f"{tag}/losses5"], rtol=5e-3)
 
 
-# (the f32 numpy oracle takes 3 ms per update at B = 100 but 43 ms at B = 1000 and 143 ms at B = 4096 on the GPU box's host: the
-#  default suite runs 5000 / 800 / 520 updates — every case past the 500-update window; round 6 cut the B = 1000 case from 1500 and
-#  moved the beyond-2048 case from B = 4096 x 600 to 2560 x 520 (the same BIG kernels, 0.6 of the oracle's time per update) so that
-#  the whole GPU suite stays near 400 s of the driver's 900-s step — and NAF_LONG_PARITY=1 the full 5000 / 5000 / 2000 at 4096,
-#  whose log is profiles/r05_long_parity.log: max deviation of the moving average 0.44 % / 0.63 % / 0.07 %)
+# Round 6: the reference's OWN loss curves at these batch sizes (tests/golden/g7_curves.npz, make_golden.py --only g7: the unmodified
+# NAFAgent.learn() on the same rows, positions and initial weights — 5000 updates at B = 100 and 1000, 600 at 2560, 2000 at 4096) are
+# what the kernels are held to, as G5 holds the whole-block kernels: a direct pin on the reference instead of on its numpy restatement,
+# and no oracle time in the suite (3 / 43 / 143 ms per update at B = 100 / 1000 / 4096 on the GPU box's host: 150 s of the suite's 450
+# before). NAF_LONG_PARITY=1 runs the f32 oracle beside it over the full lengths (profiles/r05_long_parity.log: 0.44 % / 0.63 % / 0.07 %).
 _LONG = os.environ.get("NAF_LONG_PARITY") == "1"
 
 
-@pytest.mark.parametrize("B,n_upd", [(100, 5000), (1000, 5000 if _LONG else 800), (4096 if _LONG else 2560, 2000 if _LONG else 520)])
-def test_long_teacher_forced_run_on_the_general_kernels_vs_oracle(B, n_upd):
-    """the partial-block (TAIL: B = 100, 1000) and beyond-2048 (BIG: B = 4096) variants of the row-split
-    kernels over thousands of updates, not twenty: teacher-forced minibatches (fixed rows, fixed positions) through gather ->
-    learn as replayed graphs of 100 updates against the f32 numpy oracle fed the same minibatches — first updates one by one, then
-    the 500-update moving average of the loss within 5 % (the criterion G5 holds the whole-block kernels to over 100k updates of
-    the unmodified reference), and the parameter norm at the end."""
+@pytest.mark.parametrize("B,n_upd", [(100, 5000), (1000, 5000), (2560, 600), (4096, 2000)])
+def test_long_teacher_forced_run_on_the_general_kernels_vs_reference(B, n_upd):
+    """VERDICT r04 item 4a / r05 weak spot 1c: the partial-block (TAIL: B = 100, 1000) and beyond-2048 (BIG: B = 2560, 4096) variants
+    of the row-split kernels over thousands of updates, not twenty: teacher-forced minibatches (fixed rows, fixed positions) through
+    gather -> learn as replayed graphs of 100 updates against the UNMODIFIED REFERENCE's losses on the same minibatches (G7) — first
+    updates one by one, then the 500-update moving average of the loss within 5 % (the criterion G5 holds the whole-block kernels
+    to over 100k updates), and the parameter norm at the end."""
     from synth_data import batch_indices, make_transitions
     from robotic_manipulator_rloa_amd.engine import TrainChunk
     from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
     S, A, NROWS, U = 21, 6, 40000, 100
     g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
+    g7 = np.load(os.path.join(GOLDEN, "g7_curves.npz"))
+    assert [int(x) for x in g7[f"b{B}/dims"]] == [S, A, B, NROWS, n_upd]
     sd = load_group(g, "kuka/main0")
     L = make_learner(S, A, B, sd, load_group(g, "kuka/target0"))
     assert "bb" in L.fuse
@@ -345,24 +347,28 @@ def test_long_teacher_forced_run_on_the_general_kernels_vs_oracle(B, n_upd):
         chunk.idx.copy_(idx[c * U:(c + 1) * U])
         chunk.run()
         losses[c * U:(c + 1) * U] = chunk.losses()
-    Or = O.LearnerOracle(sd, dtype=np.float32, target_state_dict=load_group(g, "kuka/target0"))
-    ref = np.empty(n_upd)
-    for k in range(n_upd):
-        i = idx_np[k]
-        ref[k] = Or.learn(st[i], ac[i], rw[i], ns[i], dn[i])
     torch.cuda.synchronize()
     got = losses.cpu().numpy().astype(np.float64)
+    ref = g7[f"b{B}/losses"].astype(np.float64)
     assert np.isfinite(got).all() and buf.bad_index_count() == 0
     np.testing.assert_allclose(got[:20], ref[:20], rtol=2e-4)
     np.testing.assert_allclose(got[:200], ref[:200], rtol=3e-2)
     w = 500
     sm = lambda x: np.convolve(x, np.ones(w) / w, mode="valid")            # noqa: E731
     rel = np.abs(sm(got) - sm(ref)) / sm(ref)
-    print("B = %d: smoothed rel. deviation over %d updates: max %.4f mean %.4f" % (B, n_upd, rel.max(), rel.mean()))
-    assert rel.max() < 0.05, f"smoothed loss curve deviates {rel.max():.3f} from the oracle's"
+    print("B = %d: smoothed rel. deviation from the reference over %d updates: max %.4f mean %.4f" % (B, n_upd, rel.max(), rel.mean()))
+    assert rel.max() < 0.05, f"smoothed loss curve deviates {rel.max():.3f} from the reference's"
     l2 = float(sum((v.double() ** 2).sum() for k, v in L.lay.param_views(L.theta2[0]).items()) ** 0.5)
-    l2_ref = float(np.sqrt(sum((np.asarray(Or.main[k], np.float64) ** 2).sum() for k in O.PARAM_ORDER)))
-    np.testing.assert_allclose(l2, l2_ref, rtol=2e-2)
+    np.testing.assert_allclose(l2, float(g7[f"b{B}/theta_l2"]), rtol=2e-2)
+    if _LONG:
+        Or = O.LearnerOracle(sd, dtype=np.float32, target_state_dict=load_group(g, "kuka/target0"))
+        orc = np.empty(n_upd)
+        for k in range(n_upd):
+            i = idx_np[k]
+            orc[k] = Or.learn(st[i], ac[i], rw[i], ns[i], dn[i])
+        rel_o = np.abs(sm(got) - sm(orc)) / sm(orc)
+        print("B = %d: ... from the f32 oracle: max %.4f" % (B, rel_o.max()))
+        assert rel_o.max() < 0.05
 
 
 def test_learn_bitwise_reproducible_run_to_run():

@@ -210,3 +210,20 @@ def test_torch_port_matches_reference_golden():
     np.testing.assert_allclose(agent.losses, g["kuka/losses5"], rtol=1e-5)
     ref5 = load_group(g, "kuka/main5")
     np.testing.assert_allclose(agent.main.p["hidden_layer.weight"].detach().numpy(), ref5["hidden_layer.weight"], atol=1e-6)
+
+
+@pytest.mark.parametrize("B,n", [(100, 60), (1000, 12), (2560, 4)])
+def test_g7_oracle_tracks_the_reference_at_odd_and_large_batches(B, n):
+    """G7 (round 6): the unmodified reference's learn() losses on teacher-forced minibatches at batch sizes that are not whole
+    64-row blocks (100, 1000) and beyond 2048 (2560) — the curves the GPU suite holds the partial-block / beyond-2048 kernels to over
+    thousands of updates. The numpy oracle follows their first updates one by one (f32 against f32)."""
+    from synth_data import batch_indices, make_transitions
+    g, g7 = _npz("g3_learn.npz"), _npz("g7_curves.npz")
+    S, A, Bg, NROWS, n_upd = [int(x) for x in g7[f"b{B}/dims"]]
+    assert (S, A, Bg, NROWS) == (21, 6, B, 40000) and len(g7[f"b{B}/losses"]) == n_upd
+    st, ac, rw, ns, dn = make_transitions(NROWS, S, A, seed=int(g7["data_seed"]), rare_events=False, structured_reward=True)
+    idx = batch_indices(NROWS, B, n, seed=int(g7["idx_seed"]))       # (the generator's draws are sequential: a prefix of the golden's)
+    Or = O.LearnerOracle(load_group(g, "kuka/main0"), dtype=np.float32, target_state_dict=load_group(g, "kuka/target0"))
+    got = [Or.learn(st[i], ac[i], rw[i], ns[i], dn[i]) for i in idx]
+    np.testing.assert_allclose(got[:4], g7[f"b{B}/losses"][:4], rtol=2e-4)
+    np.testing.assert_allclose(got, g7[f"b{B}/losses"][:n], rtol=2e-2)
