@@ -210,6 +210,25 @@ def main():
         g3_case(10, 5, 64, "h128", False, out, H=128)
         np.savez_compressed(os.path.join(HERE, "g3_learn_h128.npz"), **out)
 
+    # ---------------- G3 at layer sizes beyond 256 (round 6: the row-split chain runs widths up to 512 on two 256-column halves; 384 is
+    # stored zero-padded to 512): NAF(21, 6, 512) at batch 256 and NAF(21, 6, 384) at batch 64. SLIM: the 512 x 512 matrix is kept
+    # as its first 16 rows (main0 / main1 / target1 / grads1) + a (sum, sum of squares) pair per full tensor — the initial weights are
+    # the constructor's at seed 0, which the build reproduces (reference_init_state_dict; the test checks slices and sums).  --only g3wide
+    if only is not None and "g3wide" in only:
+        out = {}
+        for (S, A, B, H, tag) in ((21, 6, 256, 512, "h512"), (21, 6, 64, 384, "h384")):
+            full = {}
+            main0 = g3_case(S, A, B, tag, True, full, H=H)
+            full.update(flat(f"{tag}/main0", main0))
+            for k_, v_ in full.items():
+                v_ = np.asarray(v_)
+                if v_.ndim == 2 and v_.shape[0] == H and v_.shape[1] == H:
+                    out[k_ + "@rows16"] = v_[:16].copy()
+                    out[k_ + "@sums"] = np.array([v_.astype(np.float64).sum(), (v_.astype(np.float64) ** 2).sum()])
+                else:
+                    out[k_] = v_
+        np.savez_compressed(os.path.join(HERE, "g3_learn_wide.npz"), **out)
+
     # ---------------- G3 at the batch sizes of BASELINE configs[3] and [4] (one reference learn() trace each) ---------
     if want("g3big"):
         out = {}

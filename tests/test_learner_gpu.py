@@ -281,6 +281,77 @@ def test_learn_at_other_layer_sizes_vs_oracle(S, A, H, B, p_mode, pad):
                 assert float(L.lay.view(buf, "W2")[:, H:].abs().max()) == 0.0 and float(L.lay.view(buf, "Wh")[:, H:Hs].abs().max()) == 0.0
 
 
+def _wide_golden(tag):
+    """(dims, {group: {name: array}}, q1, losses5, grad_norm1) of a slim G3 golden (tests/golden/g3_learn_wide.npz): the H x H matrix
+    of every group is there as its first 16 rows (`name@rows16`) and its (sum, sum of squares) (`name@sums`)"""
+    g = np.load(os.path.join(GOLDEN, "g3_learn_wide.npz"))
+    groups = {grp: load_group(g, f"{tag}/{grp}") for grp in ("main0", "main1", "target1", "grads1")}
+    return [int(x) for x in g[f"{tag}/dims"]], groups, g[f"{tag}/q1"].ravel(), g[f"{tag}/losses5"], float(g[f"{tag}/grad_norm1"])
+
+
+def _check_against_slim(cur, ref, check, msg):
+    """cur: {name: full array}; ref: a slim group; check(actual, desired, name)"""
+    for name, val in ref.items():
+        if "num_batches" in name or name.endswith("@sums"):
+            continue
+        if name.endswith("@rows16"):
+            base = name[:-len("@rows16")]
+            check(cur[base].reshape(-1, val.shape[1])[:16], val, f"{msg}/{base}[:16]")
+        else:
+            check(cur[name].reshape(val.shape), val, f"{msg}/{name}")
+
+
+@pytest.mark.parametrize("tag", ["h512", "h384"])
+def test_learn_at_wide_layers_vs_reference_golden_g3(tag):
+    """Round 6: layer sizes in (256, 512] on the row-split chain (512 columns as two 256-column halves; 384 stored zero-padded to
+    512) against the UNMODIFIED reference's learn() at NAF(21, 6, 512), batch 256, and NAF(21, 6, 384), batch 64 (slim goldens:
+    make_golden.py --only g3wide) — Q, the gradient norm and every gradient before the clip, parameters and target after one step,
+    BatchNorm buffers, the five losses. The initial weights are the reference constructor's at seed 0, which
+    reference_init_state_dict reproduces bit for bit (checked here against the golden's slices and sums)."""
+    from synth_data import make_transitions
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    (S, A, B, H), grp, q1, losses5, norm = _wide_golden(tag)
+    sd0 = {k: v.numpy() for k, v in reference_init_state_dict(S, A, H, 0).items()}
+    for name, val in grp["main0"].items():
+        if name.endswith("@rows16"):
+            np.testing.assert_array_equal(sd0[name[:-7]][:16], val)
+        elif name.endswith("@sums"):
+            w = sd0[name[:-5]].astype(np.float64)
+            np.testing.assert_allclose([w.sum(), (w ** 2).sum()], val, rtol=1e-12)
+        elif "num_batches" not in name:
+            np.testing.assert_array_equal(sd0[name], val, err_msg=name)
+    st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
+    L = make_learner(S, A, B, sd0, sd0, H=H)
+    assert L.chain == "rows" and L.lay.H == 512 and L.lay.H_ref == H
+    rows = rows_device(L, st, ac, rw, ns, dn)
+    lp = torch.zeros(5, L.n_loss_wg, device="cuda")
+    L.learn_rows(rows[:B], lp[0])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(L.q_out.cpu().numpy(), q1, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(np.sqrt(L.partials[:L.n_partials].sum().item()), norm, rtol=2e-4)
+    gv = {k: v.cpu().numpy() for k, v in L.lay.param_views(L.grad).items()}
+
+    def grad_close(actual, desired, name):
+        if "input_layer.bias" in name or "hidden_layer.bias" in name:
+            return                                         # (rounding-noise gradients in front of a train-mode BatchNorm: DESIGN section 2)
+        np.testing.assert_allclose(actual, desired, rtol=5e-3, atol=1e-5 * norm, err_msg=name)
+    _check_against_slim(gv, grp["grads1"], grad_close, "grads1")
+
+    def stepped_close(actual, desired, name):
+        if "input_layer.bias" in name or "hidden_layer.bias" in name:
+            np.testing.assert_allclose(actual, desired, atol=1.01e-3)
+        elif "running" in name:
+            np.testing.assert_allclose(actual, desired, rtol=1e-4, atol=5e-5, err_msg=name)
+        else:
+            assert_adam_stepped_close(actual, desired, lr=1e-3, msg=name)
+    for which, net in (("main1", 0), ("target1", 1)):
+        _check_against_slim(current_sd(L, net), grp[which], stepped_close, which)
+    for k in range(1, 5):
+        L.learn_rows(rows[k * B:(k + 1) * B], lp[k])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lp.sum(1).cpu().numpy(), losses5, rtol=5e-3)
+
+
 def test_learn_at_the_reference_agent_tests_shape_g3():
     """G3 at NAF(10, 5, 128), batch 64 — the network the reference's own agent test builds (test_naf_algorithm.py:74) — from the
     UNMODIFIED reference's learn() (tests/golden/g3_learn_h128.npz, make_golden.py --only g3h128): Q, y, the five losses, every

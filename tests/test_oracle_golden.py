@@ -227,3 +227,21 @@ def test_g7_oracle_tracks_the_reference_at_odd_and_large_batches(B, n):
     got = [Or.learn(st[i], ac[i], rw[i], ns[i], dn[i]) for i in idx]
     np.testing.assert_allclose(got[:4], g7[f"b{B}/losses"][:4], rtol=2e-4)
     np.testing.assert_allclose(got, g7[f"b{B}/losses"][:n], rtol=2e-2)
+
+
+@pytest.mark.parametrize("tag", ["h512", "h384"])
+def test_g3_wide_layers_oracle(tag):
+    """G3 at layer sizes 512 and 384 (round 6, slim goldens of the unmodified reference: tests/golden/g3_learn_wide.npz): the oracle's
+    Q, gradient norm and five losses — the figures the GPU test of the same name holds the row-split chain's two-halves form to."""
+    from synth_data import make_transitions
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    g = _npz("g3_learn_wide.npz")
+    S, A, B, H = [int(x) for x in g[f"{tag}/dims"]]
+    sd0 = {k: v.numpy() for k, v in reference_init_state_dict(S, A, H, 0).items()}
+    np.testing.assert_array_equal(sd0["hidden_layer.weight"][:16], g[f"{tag}/main0/hidden_layer.weight@rows16"])
+    np.testing.assert_array_equal(sd0["matrix_entries.weight"], g[f"{tag}/main0/matrix_entries.weight"])
+    Or = O.LearnerOracle(sd0, dtype=np.float32)
+    st, ac, rw, ns, dn = make_transitions(5 * B, S, A, seed=7)
+    got = [Or.learn(st[k * B:(k + 1) * B], ac[k * B:(k + 1) * B], rw[k * B:(k + 1) * B], ns[k * B:(k + 1) * B], dn[k * B:(k + 1) * B])
+           for k in range(5)]
+    np.testing.assert_allclose(got, g[f"{tag}/losses5"], rtol=5e-3)
