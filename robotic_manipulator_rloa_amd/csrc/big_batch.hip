@@ -1193,6 +1193,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_linear_stats16_kernel(const flo
 #define FK_THREADS 512
 #define FK_H 256
 #define FK_LD (FK_H + 4)
+#define FK_MAX_A 11              // joints the fused launch takes: NHP = 80 floats of heads at most (the Wh tile: 83 KB of LDS)
 // ROWS = 16 (B <= 1024): twice the workgroups, each phase of this latency chain roughly half as long (rows per wave in the
 // normalise phase, MFMA tiles per wave in the two products); the backward partials are then per 16-row block.
 // FULL: whole 64-row blocks, at most 32 of them (every BASELINE config): the kernel as it was before round 4 took other batch sizes
@@ -1221,8 +1222,18 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     constexpr int Ht = HALVES * FK_H;                      // columns of the layer; this workgroup's are c0 .. c0 + 255
     constexpr int MT = ROWS / 16;                          // 16-row MFMA tiles
     constexpr int RPW = ROWS / 8;                          // rows per wave where a wave owns whole rows
-    constexpr int KS = ROWS == 16 ? 4 : 2;                 // K split of the heads GEMM (keeps the 8 waves busy)
+    // 9 .. 11 joints (round 6; NHP = 64 | 80: [mu | l | V] is 55 | 66 | 78 wide): one sample per 16-LANE group in the head body (G; the
+    // 16 rows of a workgroup are its first 256 threads), a Wh tile of 66 | 83 KB, heads and d_heads rows for 32 lane groups instead of
+    // 64 — 16 rows per workgroup only (B <= 2048): with 32 the tiles would not fit the 160 KB. Everything else — the statistics, the
+    // products' tile loops, the halves' exchange, dA2 — walks NHP as it finds it.
+    constexpr int G = NHP > HEAD_MAX_LDH ? 16 : 8;         // lanes per sample in the head body
+    constexpr int SLOTS = FK_THREADS / G;                  // lane groups (ROWS of them carry samples)
+    // K split of the heads GEMM (keeps the 8 waves busy): MT x NHP/16 tiles x KS ranges over 8 waves
+    constexpr int KS = ROWS == 16 ? (NHP == 64 ? 2 : 4) : 2;
+    constexpr int DH_ROWS = SLOTS > (KS - 1) * ROWS ? SLOTS : (KS - 1) * ROWS;   // sDH also holds the partial tiles of K ranges 1 .. KS - 1
     static_assert(ROWS == 16 || ROWS == 32, "rows per workgroup");
+    static_assert(G == 8 || ROWS == 16, "9 .. 11 joints: 16 rows per workgroup");
+    static_assert(ROWS <= SLOTS && (NHP * (FK_H / 4)) % FK_THREADS == 0, "lane groups / Wh tile per thread");
     // A2 = ReLU(gamma xhat + beta) as a tile of its own when the LDS budget allows (not with the 18 KB L tiles of the matmul
     // mode): the heads GEMM then reads ONE operand row per macro-step instead of xhat + gamma + beta and forms nothing on the
     // VALU inside its MFMA loop — that loop was bound by LDS reads (4 x 16 B per lane per step, 8 waves), 1.7 us for 0.4 us of MFMA
@@ -1230,13 +1241,13 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     __shared__ __attribute__((aligned(16))) float sXH[ROWS * FK_LD];
     __shared__ __attribute__((aligned(16))) float sA2[A2T ? ROWS * FK_LD : 4];
     __shared__ __attribute__((aligned(16))) float sW[NHP * FK_LD];
-    __shared__ __attribute__((aligned(16))) float sHd[(FK_THREADS / 8) * NHP];      // heads rows (32 live)
-    __shared__ __attribute__((aligned(16))) float sDH[(FK_THREADS / 8) * NHP];      // d_heads rows
+    __shared__ __attribute__((aligned(16))) float sHd[SLOTS * NHP];                 // heads rows (ROWS live)
+    __shared__ __attribute__((aligned(16))) float sDH[DH_ROWS * NHP];               // d_heads rows
     __shared__ __attribute__((aligned(16))) float sStat[2][4][H];                   // [net][mean, invstd, gamma, beta]
     __shared__ __attribute__((aligned(16))) float sWv[H];
     __shared__ float sBias[NHP + 1];
     __shared__ float sV[FK_THREADS / 8];
-    __shared__ float sL[PMODE == NAF_P_MATMUL ? (FK_THREADS / 8) * 8 * LT_STRIDE : 1];
+    __shared__ float sL[PMODE == NAF_P_MATMUL ? (G == 8 ? SLOTS : ROWS) * G * (G + 1) : 1];   // (G = 16: the live rows' tiles only, head_body.h)
     __shared__ float sRed[FK_THREADS / 64];
     __shared__ float2 sP[MT][H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1308,7 +1319,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     const float bias_r = tid < NHP ? Wh[(int64_t)tid * ldw + Ht] : (tid == NHP ? Wh[wh_net_stride + (int64_t)v_col * ldw + Ht] : 0.f);
     f32x4 wv_r = {0.f, 0.f, 0.f, 0.f};
     if (tid < H / 4) wv_r = *(const f32x4*)(Wh + wh_net_stride + (int64_t)v_col * ldw + c0 + 4 * tid);
-    const int s_loc_ = tid >> 3, i_ = tid & 7;
+    const int s_loc_ = tid / G, i_ = tid & (G - 1);
     // rows of this workgroup that exist (the last workgroup of a batch that is not whole 16-row groups holds fewer): the others are
     // not samples — the head body leaves their d_heads zero (so dA2, dY2 and every block sum get nothing from them), their Z2 rows
     // are the zeros the buffer was allocated with, and nothing of the minibatch is read for them
@@ -1362,7 +1373,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     }
     if (tid <= NHP) sBias[tid] = bias_r;                   // bias = column H of Wh (the ones column of A2); [NHP] = the target's V bias
     if (tid < H / 4) *(f32x4*)(sWv + 4 * tid) = wv_r;
-    for (int e = tid; e < (FK_THREADS / 8) * NHP; e += FK_THREADS) sDH[e] = 0.f;
+    for (int e = tid; e < DH_ROWS * NHP; e += FK_THREADS) sDH[e] = 0.f;
     __syncthreads();
     FK_TL(1);
     // ---- phase 1: normalise. main net -> xhat (LDS) and A2 (memory); target net -> V'(s') ---------------------------
@@ -1481,7 +1492,7 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     }
     FK_TL(4);
     // ---- phase 3: the NAF head on the 32 rows (threads 0..255 carry samples; every thread joins the barriers) --------
-    naf_head_body<PMODE, 2, FK_THREADS>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td,
+    naf_head_body<PMODE, 2, FK_THREADS, G>(sHd, sDH, sL, sRed, NHP, u_val, r_val, live_ ? sV[s_loc_] : 0.f, 0.f, gamma_td,
                                         half ? nullptr : q_out, nullptr,
                                         // (the body stores its workgroup's loss part at [blockIdx.x]; with two workgroups per row block
                                         //  and the folding workgroups in front, the row block's own index keeps it inside the array)
@@ -1713,7 +1724,9 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
         return NAF_ERR_ARG;
     const bool two = H == 2 * FK_H;      // two workgroups per row block (HALVES = 2): needs the exchange area and the launch's number
     if (two && (!once || !once->exchange || ((uintptr_t)once->exchange & 15))) return NAF_ERR_ARG;
-    if (A <= 0 || A > NAF_MAX_A || (NHP != 16 && NHP != 32 && NHP != 48) || NHP < A + A * (A + 1) / 2 + 1) return NAF_ERR_ARG;
+    // (A <= 8: NHP = 16 | 32 | 48, one sample per 8-lane group; 9 .. 11 joints: NHP = 64 | 80, per 16-lane group, B <= 2048)
+    if (A <= 0 || A > FK_MAX_A || NHP < A + A * (A + 1) / 2 + 1 || NHP != ((A + A * (A + 1) / 2 + 1 + 15) / 16) * 16) return NAF_ERR_ARG;
+    if (A > NAF_MAX_A && naf_bb_layer2_head_rows(B) != 16) return NAF_ERR_ARG;
     if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
     if (ldz < H || (ldz & 3) || ldo < H || (ldo & 3) || ldd < H || ldw <= H || (ldw & 3) || ldu < A || ldr < 1) return NAF_ERR_ARG;
     if ((((uintptr_t)z | (uintptr_t)a2_out | (uintptr_t)Wh | (uintptr_t)d_heads) & 15) != 0 || (z_net_stride & 3) ||
@@ -1745,15 +1758,23 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
         else if (rows == 16) BB_FK_R(PM, NH4V, 16, false);                       \
         else BB_FK_R(PM, NH4V, 32, false);                                       \
     } while (0)
-#define BB_FK_NH(PM)                     \
-    do {                                 \
-        if (NHP == 16) BB_FK(PM, 4);     \
-        else if (NHP == 32) BB_FK(PM, 8); \
-        else BB_FK(PM, 12);              \
+#define BB_FK_WIDE(PM, NH4V)                                       \
+    do {                                                           \
+        if (B % BB_ROWS == 0) BB_FK_R(PM, NH4V, 16, true);         \
+        else BB_FK_R(PM, NH4V, 16, false);                         \
+    } while (0)
+#define BB_FK_NH(PM)                          \
+    do {                                      \
+        if (NHP == 16) BB_FK(PM, 4);          \
+        else if (NHP == 32) BB_FK(PM, 8);     \
+        else if (NHP == 48) BB_FK(PM, 12);    \
+        else if (NHP == 64) BB_FK_WIDE(PM, 16); \
+        else BB_FK_WIDE(PM, 20);              \
     } while (0)
     if (p_mode == NAF_P_HADAMARD) BB_FK_NH(NAF_P_HADAMARD);
     else BB_FK_NH(NAF_P_MATMUL);
 #undef BB_FK_NH
+#undef BB_FK_WIDE
 #undef BB_FK
 #undef BB_FK_R
 #undef BB_FK_ARGS

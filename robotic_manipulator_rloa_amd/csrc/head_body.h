@@ -1,5 +1,5 @@
 // NAF head math shared by naf_head.hip (heads rows staged from memory) and fused_layers.hip (heads rows produced
-// in LDS by an MFMA GEMM). One sample per 8-lane group, lane i owns row i of L. See naf_head.hip for the mapping.
+// in LDS by an MFMA GEMM). One sample per 8-lane group (16-lane group: G below), lane i owns row i of L. See naf_head.hip for the mapping.
 #pragma once
 #include "common.h"
 #include "../../include/naf_hip.h"
@@ -17,30 +17,36 @@ __device__ static inline float group8_sum(float x) {
 
 // sh_in : HEAD_SPB heads rows (stride ldh) already in LDS and visible (caller synchronised)
 // sh_out: HEAD_SPB x ldh floats, zero-filled by the caller when MODE != 0; receives d_heads rows
-// sh_L  : HEAD_SPB*8*LT_STRIDE floats (matmul mode only); sh_red: HEAD_THREADS/64 floats
+// sh_L  : HEAD_SPB*G*(G+1) floats (matmul mode only); sh_red: HEAD_THREADS/64 floats
 // Ends with a __syncthreads() when MODE != 0, after which sh_out is complete. MODE 0 returns early per lane.
 // MODE: 0 = forward only (q, optional mu); 1 = backward given dq; 2 = fused TD target + MSE + backward
-// u_val: this lane's action component (lane i of the sample's 8-lane group, 0 beyond A); r_val / vnext_val / dq_val:
+// u_val: this lane's action component (lane i of the sample's G-lane group, 0 beyond A); r_val / vnext_val / dq_val:
 // the sample's reward, V'(s') and dLoss/dQ, needed on lane 0 of the group only. The caller fetches them BEFORE the
 // barrier that publishes sh_in, so their latency overlaps the staging instead of following it.
-template <int PMODE, int MODE, int NTHREADS = HEAD_THREADS>
+// G: lanes per sample — 8 (A <= 8: every BASELINE config) or 16 (9 .. 16 joints inside the row-split chain's fused layer-2 launch,
+// csrc/big_batch.hip; the arithmetic per sample is the same in the same order, as in naf_head_wide.hip). With G = 16 only the samples
+// that exist (s_loc < ns) touch sh_L: the caller sizes it for its live rows, not for every lane group of the workgroup.
+template <int PMODE, int MODE, int NTHREADS = HEAD_THREADS, int G = 8>
 __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, float* sh_L, float* sh_red, int ldh,
                                             float u_val, float r_val, float vnext_val, float dq_val, float gamma,
                                             float* __restrict__ q_out, float* __restrict__ mu_out,
                                             float* __restrict__ loss_partials, int B, int A, int64_t s0, int ns) {
+    static_assert(G == 8 || G == 16, "lanes per sample");
+    constexpr int LTS = G + 1;    // G x G L tile padded to G + 1 columns: column reads hit distinct banks (LT_STRIDE at G = 8)
     const int T = A * (A + 1) / 2;
     const int tid = threadIdx.x;
-    const int s_loc = tid >> 3;   // sample within the workgroup
-    const int i = tid & 7;        // row of L owned by this lane
+    const int s_loc = tid / G;    // sample within the workgroup
+    const int i = tid & (G - 1);  // row of L owned by this lane
     const int64_t s = s0 + s_loc;
     const bool live = s_loc < ns;
     const bool row_on = live && i < A;
+    const bool lt_on = G == 8 || live;
 
     const float* hrow = sh_in + s_loc * ldh;
     float mu = 0.f, d = 0.f, Vv = 0.f;
-    float t_row[8], L_row[8];
+    float t_row[G], L_row[G];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { t_row[j] = 0.f; L_row[j] = 0.f; }
+    for (int j = 0; j < G; ++j) { t_row[j] = 0.f; L_row[j] = 0.f; }
     float tii = 0.f, Lii = 0.f;   // Hadamard mode: the diagonal entry of this lane's row is all P = L (*) L^T keeps
     if (row_on) {
         mu = tanhf(hrow[i]);
@@ -53,7 +59,7 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
             Lii = expf(tii);
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < G; ++j) {
                 if (j <= i) {
                     float t = tanhf(hrow[rbase + j]);
                     t_row[j] = t;
@@ -73,19 +79,21 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
         Pii = Lii * Lii;
         quad_part = Pii * d * d;
     } else {
-        float* Lt = sh_L + s_loc * 8 * LT_STRIDE;
+        float* Lt = sh_L + s_loc * G * LTS;
+        if (lt_on) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Lt[i * LT_STRIDE + j] = L_row[j];
+            for (int j = 0; j < G; ++j) Lt[i * LTS + j] = L_row[j];
+        }
         __syncthreads();  // reached by every lane: no early exit above
-        const int gb = (tid & 63) & ~7;  // first lane of this sample's group inside the wave
+        const int gb = (tid & 63) & ~(G - 1);  // first lane of this sample's group inside the wave
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < G; ++k) {
             float dk = __shfl(d, gb + k);
-            if (k >= i) w += Lt[k * LT_STRIDE + i] * dk;  // column i of L
+            if (k >= i && lt_on) w += Lt[k * LTS + i] * dk;  // column i of L
         }
         quad_part = w * w;
     }
-    const float quad = group8_sum(quad_part);
+    const float quad = G == 8 ? group8_sum(quad_part) : naf_sum16(quad_part);
     const float Q = Vv - 0.5f * quad;
 
     if (MODE == 0) {
@@ -98,12 +106,12 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     float dq = 0.f;
     float sq_err = 0.f;
     if (MODE == 1) {
-        if (live) dq = __shfl(dq_val, (tid & 63) & ~7);
+        if (live) dq = __shfl(dq_val, (tid & 63) & ~(G - 1));
     } else {
         // lane 0 of the group fetches r and V'(s'); the group shares them by shuffle (uniform control flow)
         float y = 0.f;
         if (live && i == 0) y = r_val + gamma * vnext_val;
-        y = __shfl(y, (tid & 63) & ~7);
+        y = __shfl(y, (tid & 63) & ~(G - 1));
         if (live) {
             float e = Q - y;
             dq = 2.0f * e / (float)B;
@@ -123,11 +131,11 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
             orow[A + i * (i + 1) / 2 + i] = dq * (-(Pii * d * d)) * (1.0f - tii * tii);
         }
     } else {
-        const int gb = (tid & 63) & ~7;
+        const int gb = (tid & 63) & ~(G - 1);
         float Lw = 0.f;
-        float wj[8];
+        float wj[G];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < G; ++j) {
             wj[j] = __shfl(w, gb + j);
             Lw += L_row[j] * wj[j];  // L_row[j] = 0 for j > i
         }
@@ -136,7 +144,7 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
             orow[i] = dq * Lw * (1.0f - mu * mu);
             const int rbase = A + i * (i + 1) / 2;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < G; ++j) {
                 if (j <= i) {
                     float dL = -d * wj[j];
                     float dt = (j == i) ? dL * L_row[j] : dL;
@@ -148,9 +156,9 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     if (live && i == 0) orow[A + T] = dq;  // dQ/dV = 1
 
     if (MODE == 2) {
-        // workgroup sum of squared TD errors, fixed order -> bitwise reproducible
+        // workgroup sum of squared TD errors (one per sample, on lane 0 of its group), fixed order -> bitwise reproducible
         float x = sq_err;
-        x = naf_xor32_add(naf_xor16_add(naf_xor8_add(x)));
+        x = G == 8 ? naf_xor32_add(naf_xor16_add(naf_xor8_add(x))) : naf_xor32_add(naf_xor16_add(x));
         if ((tid & 63) == 0) sh_red[tid >> 6] = x;
     }
     __syncthreads();

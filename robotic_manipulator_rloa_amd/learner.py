@@ -81,6 +81,8 @@ class Segment:
         return n
 
 
+BB_MAX_STATE = 32      # the row-split chain: layer 1's K (csrc/big_batch.hip, BB_MAX_K4)
+BB_MAX_JOINTS = 11     # ... and the fused layer-2 launch's heads tile (FK_MAX_A)
 NATIVE_LAYER = 256     # the width the fused kernels are built for (rl_framework.py's presets; csrc/big_batch.hip, step_path.hip)
 
 
@@ -183,7 +185,8 @@ class Learner:
         #              BatchNorm statistics, GEMM 2 on f32 MFMA, layer 2 + heads + NAF head + first backward stage in one launch
         #              (hk), the backward GEMMs as one launch (gb) that also carries the second stage of layer 2's BatchNorm
         #              backward as its prologue (s2) and the batch pass of layer 1's backward as its epilogue (ep), a finish
-        #              launch — 5 launches per update in a chain of updates. Needs 16 <= B <= 4096 (any size in it), H = 256, S <= 26.
+        #              launch — 5 launches per update in a chain of updates. Needs 16 <= B <= 4096 (any size in it), H = 256 | 512, S <= 32,
+        #              A <= 8 (A <= 11 up to B = 2048).
         #              Default wherever the shape fits (measured at the end of round 3, updates/s, column-tile | row-split: B = 64:
         #              32.3k | 36.0k, 128: 30.7k | 35.4k, 192: 25.8k | 34.0k, 256: 25.7k | 34.7k, 512: 20.3k | 30.9k; until then the
         #              column-tile chain led below B = 256 — 32.5k | 29.3k at 64 in round 2).
@@ -209,7 +212,11 @@ class Learner:
         #  B = 2048, where the fused layer-2 + head launch runs 32 rows per workgroup),
         #  zero-initialised: the weight-gradient products walk Bp rows as their K dimension, and a row past the batch is a zero in at
         #  least one operand of each — dH and dY2 rows the head body never writes, A1 rows layer 1 never stores.)
-        self.bb_ok = (16 <= self.B <= 4096 and lay0.H in (256, 512) and lay0.S <= 26 and lay0.A <= 8)
+        # (round 6, late: state sizes up to 32 — the layer-1 kernels' K — and 9 .. 11 joints: the fused layer-2 launch then holds one
+        #  sample per 16-lane group and a Wh tile of 64 | 80 rows, 16 rows per workgroup only, hence B <= 2048; csrc/big_batch.hip.
+        #  The reference's state is 9 + 2 A floats, environment.py:261: 27 | 29 | 31 at 9 | 10 | 11 joints)
+        self.bb_ok = (16 <= self.B <= 4096 and lay0.H in (256, 512) and lay0.S <= BB_MAX_STATE and
+                      (lay0.A <= 8 or (lay0.A <= BB_MAX_JOINTS and self.B <= 2048)))
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
@@ -218,7 +225,7 @@ class Learner:
         if want == "rows" and not self.bb_ok:
             want = "columns" if self.B <= 512 else "unfused"
         if lay0.A > 8 and want != "rows":
-            want = "unfused"                   # (9 .. 16 joints: the fused kernels hold one sample per 8-lane group)
+            want = "unfused"                   # (9 .. 16 joints: the column-tile kernels hold one sample per 8-lane group)
         if want == "rows":
             self.fuse = {"bb", "gb", "hk", "ep", "s2"}
         elif want == "columns" and self.B <= 512:
@@ -233,16 +240,17 @@ class Learner:
         if (self.B % 16 != 0 and want != "rows") or lay0.H % 16 != 0:
             self.fuse -= {"gb"}                # the MFMA kernels take whole 16 x 16 x 16 steps: M, N, K % 16 == 0
         self.chain = want
-        if lay0.A > 8:
+        if lay0.A > 8 and want != "rows":
             import warnings
-            warnings.warn(f"action_size {lay0.A} runs the unfused chain: the fused kernels take at most 8 joints (every arm the "
-                          f"reference ships: KUKA / xArm 6, Panda 7)", stacklevel=3)
+            warnings.warn(f"action_size {lay0.A} at batch_size {self.B}, state_size {lay0.S} runs the unfused chain: the row-split "
+                          f"chain takes up to {BB_MAX_JOINTS} joints at 16 <= batch_size <= 2048, state_size <= {BB_MAX_STATE} "
+                          f"(every arm the reference ships has 6 or 7: KUKA / xArm, Panda)", stacklevel=3)
         elif self.B > 512 and want != "rows":
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)
             import warnings
             warnings.warn(f"batch_size {self.B} at H = {lay0.H}, S = {lay0.S} runs the unfused chain (about half the updates/s of the "
                           f"row-split chain): the row-split kernels need 16 <= batch_size <= 4096, layer_size <= 512 and "
-                          f"state_size <= 26", stacklevel=3)
+                          f"state_size <= {BB_MAX_STATE}", stacklevel=3)
         # with every gradient element produced by one of our own kernels, those kernels also emit its sum-of-squares partial:
         # the separate grad-norm launch disappears. Data-parallel runs keep it (the norm is taken on the all-reduced gradient).
         self.fold_norm = ({"l1", "b2", "gb"} <= self.fuse or {"bb", "gb"} <= self.fuse) and self.world_size == 1 and \

@@ -229,6 +229,26 @@ def main():
                     out[k_] = v_
         np.savez_compressed(os.path.join(HERE, "g3_learn_wide.npz"), **out)
 
+    # ---------------- G3 at 9 and 11 joints (round 6: the row-split chain's fused layer-2 launch holds one sample per 16-lane group there):
+    # NAF(27, 9, 256) at batch 256 and NAF(31, 11, 256) at batch 64 — the reference's state is 9 + 2 A floats (environment.py:261).
+    # SLIM like g3wide: the 256 x 256 matrix as its first 16 rows + (sum, sum of squares); the initial weights are the constructor's at
+    # seed 0 (reference_init_state_dict reproduces them; the tests check slices and sums).  --only g3joints
+    if only is not None and "g3joints" in only:
+        out = {}
+        for (S, A, B, H, tag) in ((27, 9, 256, 256, "j9"), (31, 11, 64, 256, "j11")):
+            full = {}
+            main0 = g3_case(S, A, B, tag, True, full, H=H)
+            full.update(flat(f"{tag}/main0", main0))
+            full[f"{tag}/dims"] = np.array([S, A, B, H])
+            for k_, v_ in full.items():
+                v_ = np.asarray(v_)
+                if v_.ndim == 2 and v_.shape[0] == H and v_.shape[1] == H:
+                    out[k_ + "@rows16"] = v_[:16].copy()
+                    out[k_ + "@sums"] = np.array([v_.astype(np.float64).sum(), (v_.astype(np.float64) ** 2).sum()])
+                else:
+                    out[k_] = v_
+        np.savez_compressed(os.path.join(HERE, "g3_learn_joints.npz"), **out)
+
     # ---------------- G3 at the batch sizes of BASELINE configs[3] and [4] (one reference learn() trace each) ---------
     if want("g3big"):
         out = {}

@@ -229,13 +229,13 @@ def test_g7_oracle_tracks_the_reference_at_odd_and_large_batches(B, n):
     np.testing.assert_allclose(got, g7[f"b{B}/losses"][:n], rtol=2e-2)
 
 
-@pytest.mark.parametrize("tag", ["h512", "h384"])
+@pytest.mark.parametrize("tag", ["h512", "h384", "j9", "j11"])
 def test_g3_wide_layers_oracle(tag):
     """G3 at layer sizes 512 and 384 (round 6, slim goldens of the unmodified reference: tests/golden/g3_learn_wide.npz): the oracle's
     Q, gradient norm and five losses — the figures the GPU test of the same name holds the row-split chain's two-halves form to."""
     from synth_data import make_transitions
     from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
-    g = _npz("g3_learn_wide.npz")
+    g = _npz("g3_learn_joints.npz" if tag.startswith("j") else "g3_learn_wide.npz")       # (j9 / j11: 9 and 11 joints, H = 256)
     S, A, B, H = [int(x) for x in g[f"{tag}/dims"]]
     sd0 = {k: v.numpy() for k, v in reference_init_state_dict(S, A, H, 0).items()}
     np.testing.assert_array_equal(sd0["hidden_layer.weight"][:16], g[f"{tag}/main0/hidden_layer.weight@rows16"])
