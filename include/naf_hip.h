@@ -182,7 +182,8 @@ int naf_act_noise(const float* heads_pre, int ldh, float* action_out, uint64_t s
  * rows of Wh[.][ldw], whose column H is the bias) for obs[E][ldobs], then naf_act_noise's mu / noise / clamp with the
  * same Philox stream (seed, *counter_dev, state, lane). *counter_dev is advanced by one when the launch is over (by
  * the last workgroup to finish: `ticket` is a zero-initialised uint32 the library uses for that). H must be 256,
- * S <= 32. heads_out (nullable): [E][ldh] pre-activations. One workgroup per state. */
+ * S <= 32, A <= 11 (beyond 8 joints the state's group in the noise body is 16 lanes wide). heads_out (nullable): [E][ldh]
+ * pre-activations. One workgroup per state. */
 int naf_policy_act(const float* obs, int ldobs, int S, const float* W1, const float* b1, const float* g1, const float* be1,
                    const float* W2, const float* b2, const float* g2, const float* be2, const float* Wh, int ldw, int NH,
                    const float* running_mean1, const float* running_var1, const float* running_mean2,
@@ -532,7 +533,7 @@ int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, 
  *   host_errors (nullable): pinned host word that counts polls whose 2-ms bound ran out (the action is then NaN: an error);
  *   host_seq (nullable): pinned host uint32 that receives the launch's ordinal (1, 2, ...: the number of calls on `sync`) behind
  *     the action's words — for readers that synchronise the stream (stores to host memory may pass one another on the way);
- *   action_rec (nullable): pinned host memory, 48 bytes, 16-byte aligned: three chunks {a[3j], a[3j + 1], a[3j + 2], ordinal}, ONE
+ *   action_rec (nullable): pinned host memory, 64 bytes, 16-byte aligned: three (A > 8: four) chunks {a[3j], a[3j + 1], a[3j + 2], ordinal}, ONE
  *     16-byte store each — a host that polls the chunks it needs (j < ceil(A / 3)) until they carry the ordinal it expects reads
  *     the action without synchronising the stream, whatever order the stores arrive in;
  *   prefetch (nullable, HOST pointer): one more workgroup of the launch draws, gathers and takes the moments of the NEXT

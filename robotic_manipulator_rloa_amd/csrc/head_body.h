@@ -169,10 +169,10 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     }
 }
 
-// Exploration noise for ONE sample per 8-lane group (lane i = tid & 7 owns component i): action = clamp(mu +
-// noise_scale * P^{-1/2} z, -1, 1), z ~ N(0, I) from Philox keyed by (ctr, sample, lane, seed). Hadamard: P = diag(L_ii^2),
-// so the covariance inverse(P) is diag(exp(-2 tanh l_ii)); matmul: cov = (L L^T)^-1 = L^-T L^-1, x solves L^T x = z by
-// back substitution over the group. hrow: the sample's heads row (global or LDS); Lt: 8 * LT_STRIDE floats of LDS
+// Exploration noise for ONE sample per G-lane group (lane i = tid & (G - 1) owns component i; G = 8, or 16 for 9 .. 16 joints):
+// action = clamp(mu + noise_scale * P^{-1/2} z, -1, 1), z ~ N(0, I) from Philox keyed by (ctr, sample, lane, seed). Hadamard:
+// P = diag(L_ii^2), so the covariance inverse(P) is diag(exp(-2 tanh l_ii)); matmul: cov = (L L^T)^-1 = L^-T L^-1, x solves
+// L^T x = z by back substitution over the group. hrow: the sample's heads row (global or LDS); Lt: G * (G + 1) floats of LDS
 // (matmul mode). Contains a __syncthreads() in matmul mode: call it from every thread of the workgroup (live = false
 // for lanes without a sample).
 // the draw itself: z ~ N(0, 1) of (seed, stream position, sample, row) by Philox + Box-Muller — it depends on nothing else, so a
@@ -187,15 +187,17 @@ __device__ static inline float naf_act_noise_z(uint64_t seed, uint64_t ctr, int6
     }
     return z;
 }
-template <int PMODE>
+template <int PMODE, int G = 8>
 __device__ static inline void naf_act_noise_body_z(const float* hrow, float* Lt, float* __restrict__ action_out, float z,
                                                    float noise_scale, int64_t s, bool live, int A, int tid) {
-    const int i = tid & 7;
+    static_assert(G == 8 || G == 16, "lanes per sample");
+    constexpr int LTS = G + 1;
+    const int i = tid & (G - 1);
     const bool row_on = live && i < A;
     float mu = 0.f, Lii = 1.f;
-    float L_row[8];
+    float L_row[G];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) L_row[j] = 0.f;
+    for (int j = 0; j < G; ++j) L_row[j] = 0.f;
     if (row_on) {
         mu = tanhf(hrow[i]);
         const int rbase = A + i * (i + 1) / 2;
@@ -203,7 +205,7 @@ __device__ static inline void naf_act_noise_body_z(const float* hrow, float* Lt,
             Lii = expf(tanhf(hrow[rbase + i]));
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < G; ++j) {
                 if (j <= i) {
                     float t = tanhf(hrow[rbase + j]);
                     L_row[j] = (j == i) ? expf(t) : t;
@@ -217,18 +219,18 @@ __device__ static inline void naf_act_noise_body_z(const float* hrow, float* Lt,
     } else {
         if (live) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Lt[i * LT_STRIDE + j] = L_row[j];
+            for (int j = 0; j < G; ++j) Lt[i * LTS + j] = L_row[j];
         }
         __syncthreads();
-        const int gb = (tid & 63) & ~7;
+        const int gb = (tid & 63) & ~(G - 1);
         // solve L^T x = z: x_j = (z_j - sum_{k>j} L_kj x_k) / L_jj, j = A-1 .. 0 (lane j owns x_j)
         float acc = z;
-        for (int k = 7; k >= 0; --k) {
-            float Lkk = Lt[k * LT_STRIDE + k];
+        for (int k = G - 1; k >= 0; --k) {
+            float Lkk = Lt[k * LTS + k];
             float xk_mine = (k < A) ? acc / (Lkk == 0.f ? 1.f : Lkk) : 0.f;
             float xk = __shfl(xk_mine, gb + k);  // lane k's value is the finished x_k
             if (i == k) x = xk;
-            if (i < k) acc -= Lt[k * LT_STRIDE + i] * xk;
+            if (i < k) acc -= Lt[k * LTS + i] * xk;
         }
     }
     if (row_on) {
@@ -237,10 +239,10 @@ __device__ static inline void naf_act_noise_body_z(const float* hrow, float* Lt,
         action_out[s * A + i] = a;
     }
 }
-template <int PMODE>
+template <int PMODE, int G = 8>
 __device__ static inline void naf_act_noise_body(const float* hrow, float* Lt, float* __restrict__ action_out,
                                                  uint64_t seed, uint64_t ctr, float noise_scale, int64_t s, bool live,
                                                  int A, int tid) {
-    const float z = naf_act_noise_z(seed, ctr, s, tid & 7, live && (tid & 7) < A);
-    naf_act_noise_body_z<PMODE>(hrow, Lt, action_out, z, noise_scale, s, live, A, tid);
+    const float z = naf_act_noise_z(seed, ctr, s, tid & (G - 1), live && (tid & (G - 1)) < A);
+    naf_act_noise_body_z<PMODE, G>(hrow, Lt, action_out, z, noise_scale, s, live, A, tid);
 }

@@ -39,7 +39,11 @@ __device__ static inline float pa_fold32(float (&v)[32], int lane, int* row_out)
     return e;
 }
 
-template <int PMODE>
+// G: lanes of the state's group in the noise body — 8, or 16 for 9 .. 11 joints (round 6: NH up to 78 rows of Wh; the heads loop walks
+// NH as it finds it, so the wider kernel differs in its LDS arrays and in the noise body's lane map only)
+#define PA_MAX_NH_WIDE 80
+#define PA_MAX_A_WIDE 11
+template <int PMODE, int G>
 __global__ __launch_bounds__(PA_THREADS) void policy_act_kernel(
     const float* __restrict__ obs, int ldobs, int S, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ g1, const float* __restrict__ be1, const float* __restrict__ W2,
@@ -51,8 +55,8 @@ __global__ __launch_bounds__(PA_THREADS) void policy_act_kernel(
     __shared__ float sObs[PA_MAX_S];
     __shared__ __attribute__((aligned(16))) float sA1[PA_H];
     __shared__ __attribute__((aligned(16))) float sA2[PA_H];
-    __shared__ float sHeads[HEAD_MAX_LDH];
-    __shared__ float sL[PMODE == NAF_P_MATMUL ? 8 * LT_STRIDE : 1];
+    __shared__ float sHeads[G == 8 ? HEAD_MAX_LDH : PA_MAX_NH_WIDE];
+    __shared__ float sL[PMODE == NAF_P_MATMUL ? G * (G + 1) : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t s = blockIdx.x;
     const uint64_t ctr = *counter_dev;                      // advanced by the LAST workgroup to finish, below
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(PA_THREADS) void policy_act_kernel(
     }
     __syncthreads();
 
-    // ---- heads: NH <= 45 rows of Wh[NHP][ldw]; column PA_H of Wh is the bias (the activations' constant-1 column) ------
+    // ---- heads: NH <= 45 (G = 16: 78) rows of Wh[NHP][ldw]; column PA_H of Wh is the bias (the activations' constant-1 column) ------
     {
         const pa_f4 x = *(const pa_f4*)(sA2 + 4 * lane);
         for (int h = wave; h < NH; h += PA_WAVES) {
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(PA_THREADS) void policy_act_kernel(
     }
     __syncthreads();
 
-    // ---- mu, exploration noise, clamp: the first 8 lanes are this state's group ------------------------------------------
-    naf_act_noise_body<PMODE>(sHeads, sL, action_out, seed, ctr, noise_scale, s, tid < 8 && s < E, A, tid);
+    // ---- mu, exploration noise, clamp: the first G lanes are this state's group ------------------------------------------
+    naf_act_noise_body<PMODE, G>(sHeads, sL, action_out, seed, ctr, noise_scale, s, tid < G && s < E, A, tid);
 
     // the noise stream moves on once every workgroup has read the counter: the last one to get here advances it
     if (tid == 0) {
@@ -128,19 +132,23 @@ extern "C" int naf_policy_act(const float* obs, int ldobs, int S, const float* W
     if (!obs || !W1 || !b1 || !g1 || !be1 || !W2 || !b2 || !g2 || !be2 || !Wh || !running_mean1 || !running_var1 ||
         !running_mean2 || !running_var2 || !action_out || !counter_dev || !ticket)
         return NAF_ERR_ARG;
-    if (H != PA_H || S <= 0 || S > PA_MAX_S || ldobs < S || E <= 0 || A <= 0 || A > NAF_MAX_A) return NAF_ERR_ARG;
-    if (NH != A + A * (A + 1) / 2 + 1 || NH > HEAD_MAX_LDH || ldw <= PA_H || (ldw & 3) != 0) return NAF_ERR_ARG;
+    if (H != PA_H || S <= 0 || S > PA_MAX_S || ldobs < S || E <= 0 || A <= 0 || A > PA_MAX_A_WIDE) return NAF_ERR_ARG;
+    if (NH != A + A * (A + 1) / 2 + 1 || NH > (A > NAF_MAX_A ? PA_MAX_NH_WIDE : HEAD_MAX_LDH) || ldw <= PA_H || (ldw & 3) != 0) return NAF_ERR_ARG;
     if ((((uintptr_t)W2 | (uintptr_t)Wh) & 15) != 0 || (heads_out && ldh < NH)) return NAF_ERR_ARG;
     if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (p_mode == NAF_P_HADAMARD)
-        policy_act_kernel<NAF_P_HADAMARD><<<E, PA_THREADS, 0, st>>>(
-            obs, ldobs, S, W1, b1, g1, be1, W2, b2, g2, be2, Wh, ldw, NH, running_mean1, running_var1, running_mean2,
-            running_var2, eps, heads_out, ldh, action_out, seed, counter_dev, ticket, noise_scale, E, A);
-    else
-        policy_act_kernel<NAF_P_MATMUL><<<E, PA_THREADS, 0, st>>>(
-            obs, ldobs, S, W1, b1, g1, be1, W2, b2, g2, be2, Wh, ldw, NH, running_mean1, running_var1, running_mean2,
-            running_var2, eps, heads_out, ldh, action_out, seed, counter_dev, ticket, noise_scale, E, A);
+#define PA_GO(PM, GV)                                                                                                         \
+    policy_act_kernel<PM, GV><<<E, PA_THREADS, 0, st>>>(obs, ldobs, S, W1, b1, g1, be1, W2, b2, g2, be2, Wh, ldw, NH, running_mean1, \
+                                                       running_var1, running_mean2, running_var2, eps, heads_out, ldh, action_out,  \
+                                                       seed, counter_dev, ticket, noise_scale, E, A)
+    if (p_mode == NAF_P_HADAMARD) {
+        if (A > NAF_MAX_A) PA_GO(NAF_P_HADAMARD, 16);
+        else PA_GO(NAF_P_HADAMARD, 8);
+    } else {
+        if (A > NAF_MAX_A) PA_GO(NAF_P_MATMUL, 16);
+        else PA_GO(NAF_P_MATMUL, 8);
+    }
+#undef PA_GO
     NAF_CHECK_LAUNCH();
     return NAF_OK;
 }

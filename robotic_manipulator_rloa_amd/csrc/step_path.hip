@@ -51,6 +51,10 @@ NAF_TL_READER(naf_tl_read_sp, g_tl_sp)
 #define SP_THREADS 1024
 #define SP_RPT 4
 #define SP_CACHE_ROWS 256
+#define SP_CACHE_BYTES 65536   // ... and at most 64 KB of them (ring rows of 128 floats — state sizes beyond 26, 9 .. 11 joints — gather
+                               //     72 .. 88 floats per row: 256 of those would not fit beside the draw's table)
+#define SP_MAX_RF4 32          // a ring row is at most 128 floats here
+static inline bool sp_cached(int B, int out_ld) { return B <= SP_CACHE_ROWS && (size_t)B * out_ld * sizeof(float) <= SP_CACHE_BYTES; }
 
 struct StepPrepArgs {
     float4* ring;
@@ -410,7 +414,7 @@ __device__ __forceinline__ static void step_prep_body(const StepPrepArgs& P, uns
 template <int K4, bool CACHE>
 __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArgs P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
-    __shared__ float4 sNew[16];                                        // the appended row (rf4 <= 16 float4)
+    __shared__ float4 sNew[SP_MAX_RF4];                                // the appended row (rf4 <= 32 float4)
     __shared__ int sHit;
     step_prep_body<K4, CACHE, 0>(P, sp_smem, sNew, &sHit);
 }
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(SP_THREADS) void step_prep_kernel(const StepPrepArg
 template <int K4, bool CACHE, int MODE>
 __global__ __launch_bounds__(SP_THREADS) void step_prefetch_kernel(const StepPrepArgs P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
-    __shared__ float4 sNew[16];
+    __shared__ float4 sNew[SP_MAX_RF4];
     __shared__ int sHit;
     step_prep_body<K4, CACHE, MODE>(P, sp_smem, sNew, &sHit);
 }
@@ -442,7 +446,7 @@ static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word
     if (action_mode != NAF_ACTION_TRUNC_INT && action_mode != NAF_ACTION_FLOAT) return NAF_ERR_ARG;
     if ((out_ld & 3) != 0 || out_ld < naf_round_up(naf_row_off_done(h->S, h->A) + 1, 4) || out_ld > h->row_floats) return NAF_ERR_ARG;
     k4 = (h->S + 3) / 4;
-    if (h->row_floats > 64) return NAF_ERR_ARG;          // (the appended row is held in 16 float4 of LDS)
+    if (h->row_floats > 4 * SP_MAX_RF4) return NAF_ERR_ARG;   // (the appended row is held in 32 float4 of LDS)
     if (k4 > 8 || out_ld != naf_replay_batch_row_floats(h->S, h->A)) return NAF_ERR_ARG;   // (the row the learner's kernels and the moments expect)
     P.ring = (float4*)h->rows;
     P.meta = h->meta;
@@ -491,10 +495,11 @@ static int sp_build(naf_replay_t* h, const float* src_row, const int32_t* n_word
     lds = 2 * sizeof(BmShared);
     if (draw > lds) return NAF_ERR_ARG;                  // (cannot happen for B <= 4096: 81,920 <= 82,176)
     lds += (size_t)naf_round_up(B, 4) * sizeof(int);
-    if (B <= SP_CACHE_ROWS) lds += (size_t)B * out_ld * sizeof(float);       // the minibatch itself (<= 64 KB)
+    if (sp_cached(B, out_ld)) lds += (size_t)B * out_ld * sizeof(float);     // the minibatch itself (<= 64 KB)
     return NAF_OK;
 }
-#define SP_MAX_DYN_LDS (149 * 1024)                      // 82,176 + 1,024 + 65,536 at most; adam_act_kernel's own arrays beside it
+#define SP_MAX_DYN_LDS (146 * 1024)                      // 82,176 + 1,024 + 65,536 = 148,736 at most; adam_act_kernel's own arrays (up to
+                                                         // 11.9 KB with the 16-lane noise body's tile) beside it inside the CU's 160 KB
 
 extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, float* row_out, uint64_t seed,
                              uint64_t* counter_dev, int32_t* idx_out, float* out_rows, int out_ld, int action_mode, float* mom, int B,
@@ -520,7 +525,7 @@ extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_
         }
         raised_dev[dev] = 1;
     }
-    const bool cache = B <= SP_CACHE_ROWS;
+    const bool cache = sp_cached(B, out_ld);
     if (k4 <= 6 && cache) step_prep_kernel<6, true><<<1, SP_THREADS, lds, (hipStream_t)stream>>>(P);
     else if (k4 <= 6) step_prep_kernel<6, false><<<1, SP_THREADS, lds, (hipStream_t)stream>>>(P);
     else if (cache) step_prep_kernel<8, true><<<1, SP_THREADS, lds, (hipStream_t)stream>>>(P);
@@ -655,11 +660,17 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
 // workgroup; since round 6 that is step_prefetch_kernel on a stream of its own, one minibatch further ahead.)
 // SPEC == 0 with SP.cp_n set: the COMMIT of the pipelined timestep (working -> public state of the learner, `copies`) by the launch's
 // last workgroup while it waits for the heads' weights.
-template <int PMODE, int SPEC>
+// G (round 6): lanes of the state's group in the noise body — 8, or 16 for 9 .. 11 joints: up to 78 heads rows over the last workgroup's
+// eight waves (ten per wave instead of six), a fourth 16-byte chunk of the action's record. Kernels of their own: the 8-lane ones keep
+// their registers.
+#define AA_MAX_NH_WIDE 80
+#define AA_MAX_A_WIDE 11
+template <int PMODE, int SPEC, int G = 8>
 __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP) {
+    constexpr int HL = G == 8 ? HEAD_MAX_LDH : AA_MAX_NH_WIDE;
     if (SPEC) {
         extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
-        __shared__ float4 sNewS[16];
+        __shared__ float4 sNewS[SP_MAX_RF4];
         __shared__ int sHitS;
         if (blockIdx.x == gridDim.x - 1) {
             NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 13, true, false);
@@ -674,9 +685,9 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
     __shared__ __attribute__((aligned(16))) float sAct[AA_H];                 // a1 (layer-2 workgroups) / a2 (the last workgroup)
     __shared__ __attribute__((aligned(16))) float sW[64 * ACT_MAX_S + 3 * 64]; // layer-1 workgroups: their 64 rows of W1, b1, g1, be1
     __shared__ float sObs[ACT_MAX_S];
-    __shared__ float sHeads[HEAD_MAX_LDH];
-    __shared__ float sActOut[NAF_MAX_A + 1];
-    __shared__ float sL[PMODE == NAF_P_MATMUL ? 8 * LT_STRIDE : 1];
+    __shared__ float sHeads[HL];
+    __shared__ float sActOut[G == 8 ? NAF_MAX_A + 1 : 12];
+    __shared__ float sL[PMODE == NAF_P_MATMUL ? G * (G + 1) : 1];
     __shared__ int sTimed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x;
@@ -835,10 +846,10 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         __syncthreads();
         AA_TL(1);
         const __amdgpu_buffer_rsrc_t whb = naf_buf(A.theta + P.off_Wh);
-        aa_f4 wh[HEAD_MAX_LDH / 8];
-        float bias[HEAD_MAX_LDH / 8];
+        aa_f4 wh[HL / 8];
+        float bias[HL / 8];
 #pragma unroll
-        for (int k = 0; k < HEAD_MAX_LDH / 8; ++k) {
+        for (int k = 0; k < HL / 8; ++k) {
             const int h = wave + 8 * k;
             const unsigned roff = (unsigned)(h < NH ? h : 0) * (unsigned)P.HP * 4u;
             wh[k] = naf_buf_f4_sc1(whb, 16u * (unsigned)lane, roff);
@@ -846,7 +857,7 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
             bias[k] = bq[0];
         }
         // the standard normal draw of the noise depends on nothing the launch computes: taken while the activations are under way
-        const float zn = naf_act_noise_z(P.seed, ctr, 0, tid & 7, tid < 8 && (tid & 7) < P.A);
+        const float zn = naf_act_noise_z(P.seed, ctr, 0, tid & (G - 1), tid < G && (tid & (G - 1)) < P.A);
         if (wave == 0) {
             bool timed = false;
             const aa_f4 x = aa_poll4(rec2, lane, epoch, &timed);
@@ -857,11 +868,11 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         AA_TL(2);
         const bool timed = sTimed != 0;
         const aa_f4 x = *(const aa_f4*)(sAct + 4 * lane);
-        float ph[HEAD_MAX_LDH / 8];
+        float ph[HL / 8];
 #pragma unroll
-        for (int k = 0; k < HEAD_MAX_LDH / 8; ++k) ph[k] = act_dot4(wh[k], x);
+        for (int k = 0; k < HL / 8; ++k) ph[k] = act_dot4(wh[k], x);
 #pragma unroll
-        for (int k = 0; k < HEAD_MAX_LDH / 8; ++k) {
+        for (int k = 0; k < HL / 8; ++k) {
             const int h = wave + 8 * k;
             if (h < NH) {                                   // (wave-uniform)
                 float p = act_sum64(ph[k]);
@@ -875,12 +886,12 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         __syncthreads();
         AA_TL(3);
         // (the action lands in LDS first: its lanes hand it to memory below, once as plain words and once as a self-validating record)
-        naf_act_noise_body_z<PMODE>(sHeads, sL, sActOut, zn, P.noise_scale, 0, tid < 8, P.A, tid);
+        naf_act_noise_body_z<PMODE, G>(sHeads, sL, sActOut, zn, P.noise_scale, 0, tid < G, P.A, tid);
         __syncthreads();
         AA_TL(4);
         if (tid < 64) {                                     // (the first wave)
             if (tid < P.A) P.action_out[tid] = sActOut[tid];
-            if (P.act_rec && tid < 3) {
+            if (P.act_rec && tid < (G == 8 ? 3 : 4)) {
                 // How the HOST learns the action without synchronising the stream: 16-byte chunks {a[3j], a[3j+1], a[3j+2], ordinal},
                 // one store each — a chunk is in host memory whole or not at all, and the host takes the action from the chunks
                 // once every chunk it needs carries this launch's ordinal. (Round 5's first form announced the action by a word of
@@ -919,9 +930,10 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     P.ad.bc = nullptr;
     const int S = net->S, A = net->A, H = net->H, NHP = net->NHP, HP = net->HP;
     const int NH = A + A * (A + 1) / 2 + 1;
-    if (H != AA_H || S <= 0 || S > ACT_MAX_S || A <= 0 || A > NAF_MAX_A || NH > HEAD_MAX_LDH || NHP < NH ||
-        HP <= H || (HP & 3) != 0 || HP / 4 > AA_THREADS)
+    if (H != AA_H || S <= 0 || S > ACT_MAX_S || A <= 0 || A > AA_MAX_A_WIDE || NH > (A > NAF_MAX_A ? AA_MAX_NH_WIDE : HEAD_MAX_LDH) ||
+        NHP < NH || HP <= H || (HP & 3) != 0 || HP / 4 > AA_THREADS)
         return NAF_ERR_ARG;
+    const bool wide = A > NAF_MAX_A;                     // (one sample per 16-lane group, four chunks in the action's record)
     if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
     // the flat layout this kernel walks: [W1 | b1 | g1 | be1 | W2 | b2 | g2 | be2 | Wh] back to back (offsets in floats, multiples of
     // 4; W1 rows of 64 start on 16-byte boundaries because 64 S floats do), covering the whole buffer — every parameter is stepped
@@ -969,8 +981,13 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
         }
     }
     if (!prefetch || prefetch->mode == 0) {
-        if (p_mode == NAF_P_HADAMARD) adam_act_kernel<NAF_P_HADAMARD, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
-        else adam_act_kernel<NAF_P_MATMUL, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+        if (p_mode == NAF_P_HADAMARD) {
+            if (wide) adam_act_kernel<NAF_P_HADAMARD, 0, 16><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+            else adam_act_kernel<NAF_P_HADAMARD, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+        } else {
+            if (wide) adam_act_kernel<NAF_P_MATMUL, 0, 16><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+            else adam_act_kernel<NAF_P_MATMUL, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+        }
         NAF_CHECK_LAUNCH();
         return NAF_OK;
     }
@@ -989,29 +1006,39 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!raised_dev[dev]) {
-        const void* ks[8] = {
+        const void* ks[16] = {
             (const void*)adam_act_kernel<NAF_P_HADAMARD, 1>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2>,
             (const void*)adam_act_kernel<NAF_P_HADAMARD, 3>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4>,
             (const void*)adam_act_kernel<NAF_P_MATMUL, 1>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2>,
-            (const void*)adam_act_kernel<NAF_P_MATMUL, 3>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4>};
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 3>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 1, 16>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2, 16>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 3, 16>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4, 16>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 1, 16>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2, 16>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 3, 16>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4, 16>};
         for (const void* k : ks) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_DYN_LDS);
             if (e != hipSuccess) return (int)e;
         }
         raised_dev[dev] = 1;
     }
-    const int spec = (k4 <= 6 ? 1 : 3) + (prefetch->B <= SP_CACHE_ROWS ? 0 : 1);
+    const int spec = (k4 <= 6 ? 1 : 3) + (sp_cached(prefetch->B, prefetch->out_ld) ? 0 : 1);
     const hipStream_t st = (hipStream_t)stream;
-#define AA_LAUNCH(PM, SV) adam_act_kernel<PM, SV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP)
-#define AA_LAUNCH_PM(PM)                \
-    switch (spec) {                     \
-        case 1: AA_LAUNCH(PM, 1); break; \
-        case 2: AA_LAUNCH(PM, 2); break; \
-        case 3: AA_LAUNCH(PM, 3); break; \
-        default: AA_LAUNCH(PM, 4); break; \
+#define AA_LAUNCH(PM, SV, GV) adam_act_kernel<PM, SV, GV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP)
+#define AA_LAUNCH_SV(PM, SV)                    \
+    do {                                        \
+        if (wide) AA_LAUNCH(PM, SV, 16);        \
+        else AA_LAUNCH(PM, SV, 8);              \
+    } while (0)
+#define AA_LAUNCH_PM(PM)                    \
+    switch (spec) {                         \
+        case 1: AA_LAUNCH_SV(PM, 1); break; \
+        case 2: AA_LAUNCH_SV(PM, 2); break; \
+        case 3: AA_LAUNCH_SV(PM, 3); break; \
+        default: AA_LAUNCH_SV(PM, 4); break; \
     }
     if (p_mode == NAF_P_HADAMARD) { AA_LAUNCH_PM(NAF_P_HADAMARD) } else { AA_LAUNCH_PM(NAF_P_MATMUL) }
 #undef AA_LAUNCH_PM
+#undef AA_LAUNCH_SV
 #undef AA_LAUNCH
     NAF_CHECK_LAUNCH();
     return NAF_OK;
@@ -1048,7 +1075,7 @@ static int spf_launch(const naf_step_prefetch_t* pf, hipStream_t st) {
         }
         raised_dev[dev] = 1;
     }
-    const bool cache = pf->B <= SP_CACHE_ROWS;
+    const bool cache = sp_cached(pf->B, pf->out_ld);
 #define SPF(K, C, M) step_prefetch_kernel<K, C, M><<<1, SP_THREADS, lds, st>>>(SP)
     if (app) {
         if (k4 <= 6 && cache) SPF(6, true, 2); else if (k4 <= 6) SPF(6, false, 2); else if (cache) SPF(8, true, 2); else SPF(8, false, 2);

@@ -201,8 +201,8 @@ class TimestepGraph(UpdateChunk):
         self._ran = None                   # event behind the last run(): the pinned words are free again once it has passed
         want = STEP_FORMS.index(step_form())
         actor = getattr(tail, "__self__", None)
-        # (naf_step_prep holds the appended row as 16 float4 of LDS: ring rows of 64 floats — state sizes up to 26 at up to 8 joints)
-        can_prep = self.U == 1 and self.moments is not None and learner.lay.row_floats <= 64
+        # (naf_step_prep holds the appended row as 32 float4 of LDS: ring rows of up to 128 floats — every shape the row-split chain takes)
+        can_prep = self.U == 1 and self.moments is not None and learner.lay.row_floats <= 128
         can_tail = isinstance(actor, ActPath) and actor.can_ride and learner.defer_ok
         self.fused_prep = want >= 1 and can_prep
         self.fused_tail = want >= 1 and can_tail

@@ -955,7 +955,8 @@ class ActPath:
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)   # noise stream position (uint64 on device)
         # one launch for the whole act() (csrc/policy_act.hip) when the shapes are the framework's (H = 256, S <= 32);
         # other shapes take the seven-launch path (3 GEMMs, 2 BN kernels, noise, counter)
-        self.fused = lay.H == 256 and lay.S <= 32 and lay.A <= 8
+        # (round 6: up to 11 joints — the state's group in the noise body is then 16 lanes wide)
+        self.fused = lay.H == 256 and lay.S <= 32 and lay.A <= BB_MAX_JOINTS
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_io = bool(host_io) and self.fused
         if self.host_io:
@@ -970,7 +971,7 @@ class ActPath:
         # activations) — NAFAgent.step's graph then ends with one launch instead of two. `seq` (pinned host): the launch's ordinal,
         # written behind the action: a host that polls it reads the action without synchronising the stream.
         seg = lay.seg
-        self.can_ride = (self.fused and E == 1 and learner.defer_ok and lay.NHP <= 64 and
+        self.can_ride = (self.fused and E == 1 and learner.defer_ok and lay.NHP <= 80 and
                          [seg[k].offset for k in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "Wh")] ==
                          [0, H * lay.S, H * lay.S + H, H * lay.S + 2 * H, H * lay.S + 3 * H, H * lay.S + 3 * H + H * H,
                           H * lay.S + 4 * H + H * H, H * lay.S + 5 * H + H * H, H * lay.S + 6 * H + H * H] and
@@ -980,13 +981,13 @@ class ActPath:
             self.sync = torch.zeros(learner.lib.naf_adam_polyak_act_sync_ints(), dtype=torch.int32, device=dev)
             self.seq = torch.zeros(2, dtype=torch.int32).pin_memory()
             self.seq_np = self.seq.numpy()
-            # the action as the launch hands it to a host that does not synchronise the stream: three 16-byte chunks
-            # {a[3j], a[3j + 1], a[3j + 2], ordinal}, one store each (naf_adam_polyak_act: action_rec); `ordinal_np` = chunk 0's
+            # the action as the launch hands it to a host that does not synchronise the stream: three (9 .. 11 joints: four) 16-byte
+            # chunks {a[3j], a[3j + 1], a[3j + 2], ordinal}, one store each (naf_adam_polyak_act: action_rec); `ordinal_np` = chunk 0's
             self.act_rec = torch.zeros(16, dtype=torch.int32).pin_memory()
             self.rec_np = self.act_rec.numpy()
             self.rec_f = self.rec_np.view(np.float32)
             self.ordinal_np = self.rec_np[3:4]
-            self._rec_words = [w for w in (0, 1, 2, 4, 5, 6, 8, 9)][:lay.A]
+            self._rec_words = [w for w in (0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13)][:lay.A]
             self._rec_ords = [4 * j + 3 for j in range((lay.A + 2) // 3)]
             bnp = learner.bn_stats.data_ptr()
             self._net = _lib.ActNet(lay.S, lay.A, H, lay.NHP, lay.HP, *[seg[k].offset for k in

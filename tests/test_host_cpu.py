@@ -700,6 +700,13 @@ def test_no_kernel_spills_to_scratch_and_the_switch_list_is_short():
                                     "bb_layer1_bwd_finish_kernel", "replay_gather_rows_kernel", "policy_act_kernel",
                                     "adam_polyak_kernel", "xgmi_allreduce_kernel")))}
     assert len(hot) >= 20 and max(hot.values()) <= 32, {k: v for k, v in hot.items() if v > 32}
+    # the kernels that take the draw's table / the minibatch as DYNAMIC LDS (csrc/step_path.hip, SP_MAX_DYN_LDS) must fit a CU's 160 KB with
+    # their own arrays beside it: hipFuncSetAttribute refuses the limit otherwise — at run time, on the first per-timestep launch
+    src_sp = open(os.path.join(ROOT, "robotic_manipulator_rloa_amd", "csrc", "step_path.hip")).read()
+    dyn = 1024 * int(re.search(r"#define SP_MAX_DYN_LDS \((\d+) \* 1024\)", src_sp).group(1))
+    taking = {k: v["lds_bytes"] for k, v in usage.items()
+              if "step_prep_kernel" in k or "step_prefetch_kernel" in k or re.search(r"adam_act_kernelILi\dELi[1-4]E", k)}
+    assert len(taking) >= 24 and dyn >= 82176 + 1024 + 65536 and max(taking.values()) + dyn <= 160 * 1024, (dyn, max(taking.values()))
     for need in ("gemm_bundle_kernel", "bb_layer2_head_kernel", "replay_gather_rows_kernel", "naf_head_kernel", "adam_polyak_kernel",
                  "synth_env_step_kernel", "policy_act_kernel", "xgmi_allreduce_kernel"):
         assert any(need in k for k in usage), need

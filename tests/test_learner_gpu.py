@@ -646,7 +646,7 @@ def test_device_env_loop_fills_replay_and_trains():
 
 
 @pytest.mark.parametrize("p_mode", [0, 1])
-@pytest.mark.parametrize("S,A,E", [(21, 6, 1), (21, 6, 64), (23, 7, 5), (32, 8, 33), (11, 1, 300)])
+@pytest.mark.parametrize("S,A,E", [(21, 6, 1), (21, 6, 64), (23, 7, 5), (32, 8, 33), (11, 1, 300), (27, 9, 1), (31, 11, 40)])
 def test_policy_act_one_launch_matches_seven_launch_path(S, A, E, p_mode, monkeypatch):
     """csrc/policy_act.hip (act() for E states in one launch) against the GEMM + BN-eval + noise chain it replaces:
     same heads pre-activations to f32 rounding, same noise stream (same Philox keys), counter advanced by one per call."""

@@ -58,6 +58,10 @@ PREP_CASES = [
     (26, 6, 128, 1000, 600, 1),         # 32-column moments records (K4 = 7 -> 8)
     (21, 6, 4096, 40000, 30000, 1),     # the sampler's largest batch: an 80-KB hash table under the moments' staging area
     (21, 6, 256, 5000, 3000, None),     # no append node at all (schedules other than update_freq = 1)
+    (27, 9, 64, 1000, 500, 1),          # round 6: 9 joints — ring rows of 128 floats, 72 of them gathered, the appended row in 32 float4
+    (31, 11, 256, 5000, 3000, 1),       # 11 joints at B = 256: 80 floats per gathered row, more than the 64 KB the launch keeps in LDS
+    (32, 8, 100, 1000, 700, 1),         # the widest state the layer-1 kernels take, a batch that is not whole blocks
+    (29, 10, 64, 300, 899, 1),          # 10 joints, full ring, head about to wrap
 ]
 
 
@@ -147,7 +151,7 @@ def _two_learners(S, A, B, seed):
 
 
 @pytest.mark.parametrize("p_mode", [0, 1])
-@pytest.mark.parametrize("S,A", [(21, 6), (23, 7), (10, 5), (21, 8)])
+@pytest.mark.parametrize("S,A", [(21, 6), (23, 7), (10, 5), (21, 8), (27, 9), (29, 10), (31, 11), (32, 8), (20, 9)])
 def test_adam_polyak_act_equals_the_two_launches_it_replaces(lib, S, A, p_mode):
     """naf_adam_polyak_act == naf_adam_polyak_fused followed by naf_policy_act: theta, theta', m, v, the heads' pre-activations
     and the (noisy, clamped) action bit for bit, over three consecutive launches (epochs of the records, the noise counter and the
@@ -215,6 +219,8 @@ PREFETCH_CASES = [
     (23, 7, 64, 512, 512, (1, 1, 1, 1, 1, 1)),               # a full ring: every append evicts the oldest row
     (21, 6, 512, 100000, 20000, (1, 1, 1, 1)),               # B > 256: the form that gathers through memory
     (26, 6, 100, 4000, 3990, (1,) * 14),                     # K = 28 (the wide moments record), the ring fills up and wraps
+    (27, 9, 64, 5000, 70, (1, 1, 1, 1, 1, 1, 1, 1)),         # round 6: 9 joints (ring rows of 128 floats), a young ring
+    (31, 11, 256, 100000, 3000, (1, 1, 0, 1, 1, 0, 0, 1)),   # 11 joints, B = 256 (gathered through memory: 80 floats per row), idle ticks
 ]
 
 
@@ -282,6 +288,8 @@ DEPTH2_CASES = [
     (21, 6, 512, 100000, 20000, 8),              # B > 256: the form that gathers through memory
     (26, 6, 100, 4000, 3990, 16),                # K = 28 (the wide moments record), the ring fills up and wraps
     (23, 7, 64, 512, 512, 24),                   # a full ring: every append evicts the oldest row
+    (27, 9, 64, 300, 299, 40),                   # round 6: 9 joints (ring rows of 128 floats), a ring that fills up and wraps
+    (31, 11, 256, 100000, 20000, 8),             # 11 joints at B = 256: gathered through memory
 ]
 
 
@@ -588,7 +596,9 @@ def test_pipelined_path_survives_api_calls_between_timesteps(scratch_cwd, monkey
 
 
 @pytest.mark.parametrize("S,A,H,p_mode,action_mode", [(21, 6, 256, "hadamard", "trunc_int"), (23, 7, 256, "matmul", "float"),
-                                                      (10, 5, 128, "matmul", "trunc_int"), (21, 6, 100, "hadamard", "trunc_int")])
+                                                      (10, 5, 128, "matmul", "trunc_int"), (21, 6, 100, "hadamard", "trunc_int"),
+                                                      (27, 9, 256, "hadamard", "trunc_int"), (31, 11, 256, "matmul", "float"),
+                                                      (32, 8, 256, "hadamard", "trunc_int")])
 def test_pipelined_path_on_a_ring_that_wraps(scratch_cwd, monkeypatch, S, A, H, p_mode, action_mode):
     """600 timesteps on a ring of 300 rows at B = 64: every append evicts the oldest row after the first 300, the prefetch does not
     hold four times in ten (one of the two rows to come among the positions drawn) — the pipelined loop equals the twelve-launch loop all the way;
