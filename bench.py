@@ -433,6 +433,39 @@ def measure_shape(dev, robot, B, N, E, steps, warmup, jitter=0.0, p_mode="hadama
             "timed_seconds": round(dt, 3), "sane": ok, "chain": L.chain, "fused_kernels": ",".join(sorted(L.fuse))}
 
 
+def measure_joints(dev, A, B, N, U, reps, fuse=None):
+    """learn() updates/s of an arm of A joints (state 9 + 2 A floats, environment.py:261) at batch B: chunks of U graph-replayed
+    updates on a ring of N rows — without the device env loop, which models arms of up to 8 joints."""
+    import warnings
+    import torch
+    from robotic_manipulator_rloa_amd.engine import TrainChunk
+    from robotic_manipulator_rloa_amd.learner import Learner
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    from robotic_manipulator_rloa_amd.utils.replay_buffer import ReplayBuffer
+    S = 9 + 2 * A
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, dev, fuse=fuse)
+    sd = reference_init_state_dict(S, A, 256, seed=0)
+    L.load_params(0, sd)
+    L.load_params(1, sd)
+    replay = ReplayBuffer(N, B, dev, seed=1000, state_size=S, action_size=A)
+    replay.add_rows_device(synth_rows(N, S, A, replay.row_floats, replay.off_s2, seed=77, device=dev), N)
+    chunk = TrainChunk(L, replay, U)
+    chunk.capture()
+    for _ in range(5):
+        chunk.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        chunk.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.isfinite(L.theta2).all().item()) and replay.bad_index_count() == 0 and int(L.step_dev.item()) == (reps + 5) * U
+    return {"updates_per_s": round(reps * U / dt, 1), "us_per_update": round(1e6 * dt / (reps * U), 2), "updates": reps * U,
+            "timed_seconds": round(dt, 3), "sane": ok, "chain": L.chain, "state_size": S, "what": "learn() only (no device env loop)"}
+
+
 def extras(dev, args):
     """Measurements outside `value`: (i) the host vector env — E=64 environments in worker
     processes around the GPU learner, synchronous and asynchronous policy; (ii) the reference-API path — one host env,
@@ -578,6 +611,12 @@ def extras(dev, args):
                 "layer_size 512 (kuka, batch 256, ring 1e6): the row-split chain on two 256-column halves (round 6; column tiles before)":
                     measure_shape(dev, "kuka", 256, 1000000, E, 300, 30, layer=512),
                 "layer_size 512, batch 1024 (kuka, ring 1e6)": measure_shape(dev, "kuka", 1024, 1000000, E, 200, 20, layer=512),
+                # arms of more than 8 joints (the reference builds its head for any action size, naf_neural_network.py:53-54): 9 .. 11 run
+                # the row-split chain since round 6 (one sample per 16-lane group in the fused layer-2 launch), 12 .. 16 the unfused chain
+                "9 joints (state 27), batch 256, ring 1e5: the row-split chain (round 6)": measure_joints(dev, 9, 256, 100000, 64, 300),
+                "9 joints, batch 256 on the unfused chain it ran before (fuse = unfused)": measure_joints(dev, 9, 256, 100000, 64, 150, fuse="unfused"),
+                "11 joints (state 31), batch 1024, ring 1e5": measure_joints(dev, 11, 1024, 100000, 64, 200),
+                "12 joints (state 33: beyond layer 1's K = 32), batch 256: unfused": measure_joints(dev, 12, 256, 100000, 64, 150),
             }
     finally:
         os.chdir(old)

@@ -14,8 +14,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Every call only enqueues
  *     work on `stream` and returns; no call synchronises, so all of them are HIP-graph capturable.
  *   - Return value: 0 = NAF_OK, <0 = argument/state error (NAF_ERR_*), >0 = hipError_t.
- *   - A = action size, 1 <= A <= 8 for the fused kernels (every BASELINE config), up to 16 for the replay ring and the stand-alone
- *     head / noise entry points (naf_head_*, naf_act_noise: one sample per 16-lane group beyond 8).  T = A(A+1)/2.  "heads row" = [mu_pre(A) | l_pre(T) | V(1)],
+ *   - A = action size, 1 <= A <= 8 for the fused kernels (every BASELINE config; up to 11 in naf_bb_layer2_head, naf_policy_act,
+ *     naf_adam_polyak_act and the naf_step_* launches: one sample per 16-lane group), up to 64 for the replay ring and the stand-alone
+ *     head / noise entry points (naf_head_*, naf_act_noise: one sample per 16- / 32- / 64-lane group beyond 8 / 16 / 32).  T = A(A+1)/2.  "heads row" = [mu_pre(A) | l_pre(T) | V(1)],
  *     row stride ldh >= A+T+1 floats; l_pre is the row-major lower triangle
  *     (0,0),(1,0),(1,1),(2,0)... exactly as torch.tril_indices orders it
  *     (naf_components/naf_neural_network.py:98-100).

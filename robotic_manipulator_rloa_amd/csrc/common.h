@@ -9,7 +9,7 @@
 // positive return values are hipError_t codes
 
 #define NAF_MAX_A 8            // one sample per 8-lane group: A <= 8 (every fused kernel)
-#define NAF_MAX_A_WIDE 16      // ... per 16-lane group: the stand-alone head kernels and the replay ring take up to 16 joints
+#define NAF_MAX_A_WIDE 64      // ... per 16- / 32- / 64-lane group: the stand-alone head kernels and the replay ring take up to 64 joints
 #define NAF_WAVE 64
 
 #define NAF_CHECK_LAUNCH()                                    \

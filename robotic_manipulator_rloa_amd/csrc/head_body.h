@@ -1,5 +1,5 @@
 // NAF head math shared by naf_head.hip (heads rows staged from memory) and fused_layers.hip (heads rows produced
-// in LDS by an MFMA GEMM). One sample per 8-lane group (16-lane group: G below), lane i owns row i of L. See naf_head.hip for the mapping.
+// in LDS by an MFMA GEMM). One sample per 8-lane group (16-, 32- or 64-lane group: G below), lane i owns row i of L. See naf_head.hip for the mapping.
 #pragma once
 #include "common.h"
 #include "../../include/naf_hip.h"
@@ -14,6 +14,11 @@
 __device__ static inline float group8_sum(float x) {
     return naf_sum8(x);                                  // (DPP: common.h; bitwise the xor tree 1, 2, 4)
 }
+// all-reduce over an aligned group of G lanes (16 | 32 | 64: the wider sample groups of arms with more than 8 joints)
+template <int G>
+__device__ __forceinline__ static float naf_group_sum(float x) {
+    return G == 16 ? naf_sum16(x) : (G == 32 ? naf_xor16_add(naf_sum16(x)) : naf_sum64(x));
+}
 
 // sh_in : HEAD_SPB heads rows (stride ldh) already in LDS and visible (caller synchronised)
 // sh_out: HEAD_SPB x ldh floats, zero-filled by the caller when MODE != 0; receives d_heads rows
@@ -23,15 +28,16 @@ __device__ static inline float group8_sum(float x) {
 // u_val: this lane's action component (lane i of the sample's G-lane group, 0 beyond A); r_val / vnext_val / dq_val:
 // the sample's reward, V'(s') and dLoss/dQ, needed on lane 0 of the group only. The caller fetches them BEFORE the
 // barrier that publishes sh_in, so their latency overlaps the staging instead of following it.
-// G: lanes per sample — 8 (A <= 8: every BASELINE config) or 16 (9 .. 16 joints inside the row-split chain's fused layer-2 launch,
-// csrc/big_batch.hip; the arithmetic per sample is the same in the same order, as in naf_head_wide.hip). With G = 16 only the samples
-// that exist (s_loc < ns) touch sh_L: the caller sizes it for its live rows, not for every lane group of the workgroup.
+// G: lanes per sample — 8 (A <= 8: every BASELINE config), 16 (9 .. 11 joints inside the row-split chain's fused layer-2 launch,
+// csrc/big_batch.hip; the arithmetic per sample is the same in the same order, as in naf_head_wide.hip), 32 | 64 (17 .. 64 joints:
+// naf_head_any_kernel, csrc/naf_head_wide.hip). With G > 8 only the samples that exist (s_loc < ns) touch sh_L: the caller sizes it
+// for its live rows, not for every lane group of the workgroup.
 template <int PMODE, int MODE, int NTHREADS = HEAD_THREADS, int G = 8>
 __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, float* sh_L, float* sh_red, int ldh,
                                             float u_val, float r_val, float vnext_val, float dq_val, float gamma,
                                             float* __restrict__ q_out, float* __restrict__ mu_out,
                                             float* __restrict__ loss_partials, int B, int A, int64_t s0, int ns) {
-    static_assert(G == 8 || G == 16, "lanes per sample");
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per sample");
     constexpr int LTS = G + 1;    // G x G L tile padded to G + 1 columns: column reads hit distinct banks (LT_STRIDE at G = 8)
     const int T = A * (A + 1) / 2;
     const int tid = threadIdx.x;
@@ -93,7 +99,7 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
         }
         quad_part = w * w;
     }
-    const float quad = G == 8 ? group8_sum(quad_part) : naf_sum16(quad_part);
+    const float quad = G == 8 ? group8_sum(quad_part) : naf_group_sum<G>(quad_part);
     const float Q = Vv - 0.5f * quad;
 
     if (MODE == 0) {
@@ -158,7 +164,7 @@ __device__ static inline void naf_head_body(const float* sh_in, float* sh_out, f
     if (MODE == 2) {
         // workgroup sum of squared TD errors (one per sample, on lane 0 of its group), fixed order -> bitwise reproducible
         float x = sq_err;
-        x = G == 8 ? naf_xor32_add(naf_xor16_add(naf_xor8_add(x))) : naf_xor32_add(naf_xor16_add(x));
+        x = G == 8 ? naf_xor32_add(naf_xor16_add(naf_xor8_add(x))) : (G == 16 ? naf_xor32_add(naf_xor16_add(x)) : (G == 32 ? naf_xor32_add(x) : x));
         if ((tid & 63) == 0) sh_red[tid >> 6] = x;
     }
     __syncthreads();
@@ -190,7 +196,7 @@ __device__ static inline float naf_act_noise_z(uint64_t seed, uint64_t ctr, int6
 template <int PMODE, int G = 8>
 __device__ static inline void naf_act_noise_body_z(const float* hrow, float* Lt, float* __restrict__ action_out, float z,
                                                    float noise_scale, int64_t s, bool live, int A, int tid) {
-    static_assert(G == 8 || G == 16, "lanes per sample");
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per sample");
     constexpr int LTS = G + 1;
     const int i = tid & (G - 1);
     const bool row_on = live && i < A;

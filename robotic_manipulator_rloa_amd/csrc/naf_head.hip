@@ -94,18 +94,19 @@ __global__ __launch_bounds__(NH_THREADS) void naf_head_kernel(const float* __res
     }
 }
 
-// 9 <= A <= 16: one sample per 16-lane group (csrc/naf_head_wide.hip)
+// 9 <= A <= 64: one sample per 16- / 32- / 64-lane group (csrc/naf_head_wide.hip)
 int naf_head_wide_launch(int mode, const float* heads, int ldh, const float* u, int ldu, const float* r, int ldr, const float* v_next,
                          int ldv, const float* dq, float gamma, float* q_out, float* mu_out, float* d_heads, float* loss_partials,
                          int B, int A, int p_mode, hipStream_t st);
 int naf_act_noise_wide_launch(const float* heads, int ldh, float* action_out, uint64_t seed, const uint64_t* counter_dev,
                               uint64_t counter_off, float noise_scale, int E, int A, int p_mode, hipStream_t st);
-#define HEAD_WIDE_MAX_LDH 160
+// (heads rows of A + A (A + 1) / 2 + 1 floats rounded up to 16: 160 at 16 joints, 576 at 32, 2160 at 64)
+static int head_wide_max_ldh(int A) { return A <= 16 ? 160 : (A <= 32 ? 576 : 2160); }
 
 static int head_args_ok(const float* heads, int ldh, const float* u, int ldu, int B, int A, int p_mode) {
     if (!heads || !u || B <= 0 || A <= 0 || A > NAF_MAX_A_WIDE) return 0;
     if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return 0;
-    if (ldh < A + A * (A + 1) / 2 + 1 || ldh > (A > NAF_MAX_A ? HEAD_WIDE_MAX_LDH : HEAD_MAX_LDH) || (ldh & 3) != 0) return 0;
+    if (ldh < A + A * (A + 1) / 2 + 1 || ldh > (A > NAF_MAX_A ? head_wide_max_ldh(A) : HEAD_MAX_LDH) || (ldh & 3) != 0) return 0;
     if (((uintptr_t)heads & 15) != 0 || ldu < A) return 0;
     return 1;
 }

@@ -146,11 +146,72 @@ __global__ __launch_bounds__(HW_THREADS) void naf_head_wide_kernel(const float* 
     for (int k = tid; k < ns * ldh; k += HW_THREADS) d_heads[s0 * ldh + k] = sh_out[(k / ldh) * HW_MAX_LDH + k % ldh];
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// 17 <= A <= 64 (round 6: the reference builds its head for ANY action size; beyond 16 joints NetLayout raised): one sample per 32- or
+// 64-lane group through the shared body (head_body.h, G = 32 | 64) — the heads rows (up to 64 + 2080 + 1 = 2145 -> 2160 floats) are
+// staged into LDS, d_heads rows assembled there and stored as whole rows. 256 threads: 8 | 4 samples per workgroup. Not a fast path
+// (nothing about a 40-joint arm is): the same arithmetic, checked against the f64 oracle like the others.
+// ------------------------------------------------------------------------------------------------------------------------------
+#include "head_body.h"
+template <int PMODE, int MODE, int G>
+__global__ __launch_bounds__(HW_THREADS) void naf_head_any_kernel(const float* __restrict__ heads, int ldh,
+                                                                  const float* __restrict__ u, int ldu,
+                                                                  const float* __restrict__ r, int ldr,
+                                                                  const float* __restrict__ v_next, int ldv,
+                                                                  const float* __restrict__ dq_in, float gamma,
+                                                                  float* __restrict__ q_out, float* __restrict__ mu_out,
+                                                                  float* __restrict__ d_heads, float* __restrict__ loss_partials,
+                                                                  int B, int A) {
+    constexpr int SPB = HW_THREADS / G, LDH_MAX = G == 32 ? 576 : 2160;
+    __shared__ __attribute__((aligned(16))) float sh_in[SPB * LDH_MAX];
+    __shared__ __attribute__((aligned(16))) float sh_out[MODE == 0 ? 4 : SPB * LDH_MAX];
+    __shared__ float sh_L[PMODE == NAF_P_MATMUL ? SPB * G * (G + 1) : 1];
+    __shared__ float sh_red[HW_THREADS / 64];
+    const int tid = threadIdx.x, s_loc = tid / G, i = tid & (G - 1);
+    const int64_t s0 = (int64_t)blockIdx.x * SPB;
+    const int ns = (B - s0) < SPB ? (int)(B - s0) : SPB;
+    for (int k = tid; k < ns * ldh; k += HW_THREADS) sh_in[k] = heads[s0 * ldh + k];
+    if (MODE != 0)
+        for (int k = tid; k < SPB * ldh; k += HW_THREADS) sh_out[k] = 0.f;
+    const bool live = s_loc < ns;
+    const int64_t s = s0 + s_loc;
+    const float u_val = (live && i < A) ? u[s * ldu + i] : 0.f;
+    float r_val = 0.f, vn_val = 0.f, dq_val = 0.f;
+    if (live && i == 0) {
+        if (MODE == 2) { r_val = r[s * ldr]; vn_val = v_next[s * ldv]; }
+        if (MODE == 1) dq_val = dq_in[s];
+    }
+    __syncthreads();
+    naf_head_body<PMODE, MODE, HW_THREADS, G>(sh_in, sh_out, sh_L, sh_red, ldh, u_val, r_val, vn_val, dq_val, gamma, q_out, mu_out,
+                                              loss_partials, B, A, s0, ns);
+    if (MODE == 0) return;                                 // (the body returned per lane; nothing to store)
+    for (int k = tid; k < ns * ldh; k += HW_THREADS) d_heads[s0 * ldh + k] = sh_out[k];
+}
+
 // called by the entry points of naf_head.hip for A > 8 (arguments already checked there)
 int naf_head_wide_launch(int mode, const float* heads, int ldh, const float* u, int ldu, const float* r, int ldr, const float* v_next,
                          int ldv, const float* dq, float gamma, float* q_out, float* mu_out, float* d_heads, float* loss_partials,
                          int B, int A, int p_mode, hipStream_t st) {
-    if (A <= 8 || A > HW_G || ldh > HW_MAX_LDH) return NAF_ERR_ARG;
+    if (A > HW_G) {
+        if (A > NAF_MAX_A_WIDE || ldh > (A <= 32 ? 576 : 2160)) return NAF_ERR_ARG;
+        const int g = A <= 32 ? 32 : 64;
+        const int blocks_any = (B + HW_THREADS / g - 1) / (HW_THREADS / g);
+#define HA_GO(PM, MD, GV) naf_head_any_kernel<PM, MD, GV><<<blocks_any, HW_THREADS, 0, st>>>(heads, ldh, u, ldu, r, ldr, v_next, ldv, dq, gamma, \
+                                                                                       q_out, mu_out, d_heads, loss_partials, B, A)
+#define HA_MD(PM, GV)                          \
+    do {                                       \
+        if (mode == 0) HA_GO(PM, 0, GV);       \
+        else if (mode == 1) HA_GO(PM, 1, GV);  \
+        else HA_GO(PM, 2, GV);                 \
+    } while (0)
+        if (p_mode == NAF_P_HADAMARD) { if (g == 32) HA_MD(NAF_P_HADAMARD, 32); else HA_MD(NAF_P_HADAMARD, 64); }
+        else { if (g == 32) HA_MD(NAF_P_MATMUL, 32); else HA_MD(NAF_P_MATMUL, 64); }
+#undef HA_MD
+#undef HA_GO
+        NAF_CHECK_LAUNCH();
+        return NAF_OK;
+    }
+    if (A <= 8 || ldh > HW_MAX_LDH) return NAF_ERR_ARG;
     const int blocks = (B + HW_SPB - 1) / HW_SPB;
 #define HW_GO(PM, MD) naf_head_wide_kernel<PM, MD><<<blocks, HW_THREADS, 0, st>>>(heads, ldh, u, ldu, r, ldr, v_next, ldv, dq, gamma, \
                                                                               q_out, mu_out, d_heads, loss_partials, B, A)
@@ -228,9 +289,37 @@ __global__ __launch_bounds__(HW_THREADS) void naf_act_noise_wide_kernel(const fl
     }
 }
 
+// 17 <= A <= 64: the shared noise body on a 32- / 64-lane group (head_body.h), the heads row read where it lies
+template <int PMODE, int G>
+__global__ __launch_bounds__(HW_THREADS) void naf_act_noise_any_kernel(const float* __restrict__ heads, int ldh,
+                                                                       float* __restrict__ action_out, uint64_t seed,
+                                                                       const uint64_t* __restrict__ counter_dev, uint64_t counter_off,
+                                                                       float noise_scale, int E, int A) {
+    constexpr int SPB = HW_THREADS / G;
+    __shared__ float sh_L[PMODE == NAF_P_MATMUL ? SPB * G * (G + 1) : 1];
+    const int tid = threadIdx.x, s_loc = tid / G;
+    const int64_t s = (int64_t)blockIdx.x * SPB + s_loc;
+    const uint64_t ctr = (counter_dev ? *counter_dev : 0ull) + counter_off;
+    const bool live = s < E;
+    naf_act_noise_body<PMODE, G>(heads + (live ? s : 0) * ldh, sh_L + s_loc * G * (G + 1), action_out, seed, ctr, noise_scale, s, live,
+                                 A, tid);
+}
+
 int naf_act_noise_wide_launch(const float* heads, int ldh, float* action_out, uint64_t seed, const uint64_t* counter_dev,
                               uint64_t counter_off, float noise_scale, int E, int A, int p_mode, hipStream_t st) {
-    if (A <= 8 || A > HW_G) return NAF_ERR_ARG;
+    if (A > HW_G) {
+        if (A > NAF_MAX_A_WIDE) return NAF_ERR_ARG;
+        const int g = A <= 32 ? 32 : 64;
+        const int nb = (E + HW_THREADS / g - 1) / (HW_THREADS / g);
+#define NA_GO(PM, GV) naf_act_noise_any_kernel<PM, GV><<<nb, HW_THREADS, 0, st>>>(heads, ldh, action_out, seed, counter_dev, counter_off, \
+                                                                               noise_scale, E, A)
+        if (p_mode == NAF_P_HADAMARD) { if (g == 32) NA_GO(NAF_P_HADAMARD, 32); else NA_GO(NAF_P_HADAMARD, 64); }
+        else { if (g == 32) NA_GO(NAF_P_MATMUL, 32); else NA_GO(NAF_P_MATMUL, 64); }
+#undef NA_GO
+        NAF_CHECK_LAUNCH();
+        return NAF_OK;
+    }
+    if (A <= 8) return NAF_ERR_ARG;
     const int blocks = (E + HW_SPB - 1) / HW_SPB;
     if (p_mode == NAF_P_HADAMARD)
         naf_act_noise_wide_kernel<NAF_P_HADAMARD><<<blocks, HW_THREADS, 0, st>>>(heads, ldh, action_out, seed, counter_dev, counter_off,

@@ -99,9 +99,9 @@ class NetLayout:
     computes the narrow one's numbers, term for term, with exact zeros appended to its sums — and runs the kernels the presets run."""
 
     def __init__(self, state_size: int, action_size: int, layer_size: int, pad_layer: bool = True):
-        if not (1 <= action_size <= 16):
-            raise ValueError("action_size must be in 1..16 (one sample per 8-lane group in the fused head kernels, per 16-lane "
-                             "group in the stand-alone ones)")
+        if not (1 <= action_size <= 64):
+            raise ValueError("action_size must be in 1..64 (one sample per 8- or 16-lane group in the fused head kernels, per 16-, "
+                             "32- or 64-lane group in the stand-alone ones: a wavefront has 64 lanes)")
         self.H_ref = int(layer_size)
         self.S, self.A = state_size, action_size
         # (round 6: widths in (256, 512) likewise stored as 512 — the row-split chain runs 512 columns as two 256-column halves)
@@ -339,7 +339,8 @@ class Learner:
             ptr(self.step_dev), 1.0 / self.world_size, P, lay.seg["W2"].offset, ptr(self.adam_bc))
         self._gb_wh_blocks = ((NHP + 31) // 32) * ((HP + 31) // 32)
         self._gb_blocks, self._ft_blocks = gb_blocks, ft_blocks
-        self.n_loss_wg = (B + 7) // 8                  # loss partials per update (NAF_HEAD_SPB samples per workgroup)
+        # loss partials per update: one per workgroup of the head launch (8 samples each; 4 beyond 32 joints, csrc/naf_head_wide.hip)
+        self.n_loss_wg = (B + 7) // 8 if lay.A <= 32 else (B + 3) // 4
         # a poll inside a fused launch that gave up on the folded records and folded for itself (csrc/bn2bwd_fold.h) bumps this
         # pinned HOST word; fold_fallbacks reads it without synchronising
         self.err_host = torch.zeros(8, dtype=torch.int64).pin_memory()

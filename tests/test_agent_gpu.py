@@ -138,7 +138,7 @@ def test_step_appends_every_transition_exactly_once(scratch_cwd):
     assert torch.isfinite(agent.learner.theta2).all()
 
 
-@pytest.mark.parametrize("S,A,B", [(27, 9, 64), (33, 12, 64), (21, 6, 5000)])
+@pytest.mark.parametrize("S,A,B", [(27, 9, 64), (33, 12, 64), (49, 20, 64), (21, 6, 5000)])
 def test_agent_trains_at_shapes_beyond_the_fused_kernels(scratch_cwd, S, A, B):
     """the reference takes any positive batch_size (rl_framework.py:186-189) and builds its head for any action
     size (naf_neural_network.py:53-54). A 9-joint arm and a 5000-row minibatch go through NAFAgent.act / step like any other shape

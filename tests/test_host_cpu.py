@@ -83,11 +83,14 @@ def test_reference_init_bit_exact_and_layout_roundtrip():
         assert total == lay.n_ref_params() and (flat[~used] == 0).all()
         assert lay.P % 64 == 0 and lay.NHP % 8 == 0 and all(s.offset % 64 == 0 for s in lay.seg.values())
     assert NetLayout(21, 6, 256).n_ref_params() == 79644 and NetLayout(23, 7, 256).n_ref_params() == 82212
-    # 9 .. 16 joints: a layout like any other (one sample per 16-lane group in the stand-alone head kernels); beyond: refused
+    # 9 .. 64 joints: a layout like any other (one sample per 16- / 32- / 64-lane group in the stand-alone head kernels: a wavefront
+    # has 64 lanes); beyond: refused
     wide = NetLayout(27, 9, 256)
     assert (wide.T, wide.NH, wide.NHP, wide.row_floats) == (45, 55, 64, 128) and wide.n_ref_params() == 256 * 27 + 256 * 256 + 6 * 256 + 55 * 257
+    big = NetLayout(137, 64, 256)
+    assert (big.T, big.NH, big.NHP, big.row_floats) == (2080, 2145, 2160, 512)
     with pytest.raises(ValueError):
-        NetLayout(40, 17, 256)
+        NetLayout(139, 65, 256)
     # a layer_size below 256 is STORED zero-padded to 256 (the kernels see H = 256), shown in the reference's shapes (H_ref): the
     # reference's own agent test builds NAF(10, 5, 128)
     for h in (128, 64, 200, 4):

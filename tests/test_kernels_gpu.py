@@ -276,7 +276,9 @@ def test_head_vs_reference_golden(lib, A, B, tag):
 @pytest.mark.parametrize("mode", [0, 1])
 # (A > 8: one sample per 16-lane group, csrc/naf_head_wide.hip — the reference builds matrix_entries for any action size,
 #  naf_neural_network.py:53-54)
-@pytest.mark.parametrize("A,B", [(6, 256), (7, 2048), (3, 33), (8, 100), (1, 5), (9, 256), (12, 100), (16, 37), (10, 1)])
+#  beyond 16 joints (round 6): per 32- / 64-lane group through the shared body, naf_head_any_kernel)
+@pytest.mark.parametrize("A,B", [(6, 256), (7, 2048), (3, 33), (8, 100), (1, 5), (9, 256), (12, 100), (16, 37), (10, 1),
+                                 (17, 64), (24, 100), (32, 9), (33, 50), (48, 256), (64, 21)])
 def test_head_both_modes_vs_oracle_f64(lib, mode, A, B):
     rng = np.random.default_rng(10 * A + B + mode)
     T = A * (A + 1) // 2
@@ -293,7 +295,7 @@ def test_head_both_modes_vs_oracle_f64(lib, mode, A, B):
     ud, rd, vnd = dev(u), dev(r), dev(vn)
     q = torch.empty(B, device="cuda")
     dh = torch.empty(B, ldh, device="cuda")
-    nwg = (B + 7) // 8
+    nwg = (B + 7) // 8 if A <= 32 else (B + 3) // 4      # (one loss part per workgroup: 8 samples each, 4 beyond 32 joints)
     lp = torch.zeros(nwg, device="cuda")
     assert lib.naf_head_fwd_bwd_mse(h.data_ptr(), ldh, ud.data_ptr(), A, rd.data_ptr(), 1, vnd.data_ptr(), 1, gamma,
                                     q.data_ptr(), dh.data_ptr(), lp.data_ptr(), B, A, mode, st()) == 0
@@ -327,7 +329,8 @@ def test_head_argument_errors(lib):
     h = torch.zeros(4, 32, device="cuda")
     u = torch.zeros(4, 6, device="cuda")
     q = torch.zeros(4, device="cuda")
-    assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 17, 0, st()) == -1  # A > 16
+    assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 65, 0, st()) == -1  # A > 64
+    assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 17, q.data_ptr(), None, 4, 17, 0, st()) == -1  # A = 17 needs ldh >= 171
     assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 9, q.data_ptr(), None, 4, 9, 0, st()) == -1   # A = 9 needs ldh >= 55
     assert lib.naf_head_fwd(h.data_ptr(), 24, u.data_ptr(), 6, q.data_ptr(), None, 4, 6, 0, st()) == -1   # ldh too small
     assert lib.naf_head_fwd(h.data_ptr(), 32, u.data_ptr(), 6, q.data_ptr(), None, 4, 6, 2, st()) == -1   # bad mode
@@ -366,6 +369,32 @@ def test_act_noise_distribution(lib, mode):
     # noise_scale = 1 and big sigma: the clamp holds
     lib.naf_act_noise(h.data_ptr(), 32, acts[0].data_ptr(), 1, None, 0, 50.0, E, A, mode, st())
     assert acts[0].abs().max().item() <= 1.0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("A,E", [(9, 40), (16, 5), (20, 33), (32, 8), (40, 17), (64, 6)])
+def test_act_noise_beyond_8_joints_is_the_oracles_draw(lib, mode, A, E):
+    """naf_act_noise for 9 .. 64 joints (one sample per 16- / 32- / 64-lane group): the action is clamp(mu + s x) with x the solution
+    of P^(1/2) x = z for the z of the oracle's Philox restatement — Hadamard: x_i = z_i / L_ii; matmul: L^T x = z (checked as that
+    identity: back substitution over up to 64 lanes)."""
+    T = A * (A + 1) // 2
+    ldh = (A + T + 1 + 7) // 8 * 8
+    rng = np.random.default_rng(A + E)
+    # (small off-diagonals beyond 16 joints: a random triangular matrix of order 64 with entries of 0.5 is hopelessly ill-conditioned)
+    mu_pre, l_pre = 0.05 * rng.standard_normal((E, A)), (0.5 if A <= 16 else 0.05) * rng.standard_normal((E, T))
+    h = dev(heads_rows(mu_pre, l_pre, np.zeros(E), ldh))
+    act = torch.empty(E, A, device="cuda")
+    ctr = torch.full((1,), 3, dtype=torch.int64, device="cuda")
+    scale = 1e-3                                                  # small: the clamp never bites, x is read back exactly
+    assert lib.naf_act_noise(h.data_ptr(), ldh, act.data_ptr(), 77, ctr.data_ptr(), 2, scale, E, A, mode, st()) == 0
+    torch.cuda.synchronize()
+    f = O.head_forward(mu_pre, l_pre, np.zeros(E), np.zeros((E, A)), mode)
+    z = O.normal_from_philox(77, 5, np.arange(E)[:, None], np.arange(A)[None, :])
+    x = (act.cpu().numpy().astype(np.float64) - np.tanh(mu_pre)) / scale
+    if mode == 0:
+        np.testing.assert_allclose(x, z * O.noise_std_hadamard(l_pre, A), rtol=2e-3, atol=2e-3)
+    else:
+        np.testing.assert_allclose(np.einsum("eji,ej->ei", f["L"], x), z, rtol=5e-3, atol=5e-3 * np.abs(z).max())
 
 
 # ------------------------------------------------------------------------------------------------------------

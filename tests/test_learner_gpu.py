@@ -105,7 +105,7 @@ def test_learn_vs_reference_golden_g3(tag, fused, monkeypatch):
                                    (23, 7, 2047), (26, 8, 77), (21, 6, 1023), (21, 6, 16), (21, 6, 17), (21, 6, 33), (23, 7, 63),
                                    (21, 6, 9), (21, 6, 8192), (27, 9, 256), (30, 12, 64), (45, 16, 48), (27, 9, 5000),
                                    (29, 10, 64), (31, 11, 1024), (27, 9, 100), (31, 11, 2048), (29, 10, 1000), (32, 11, 48),
-                                   (27, 9, 2100), (30, 6, 256)])
+                                   (27, 9, 2100), (30, 6, 256), (43, 17, 64), (73, 32, 100), (137, 64, 32)])
 def test_learn_vs_oracle_both_modes(p_mode, S, A, B, fused, monkeypatch):
     """20 updates against the f32 numpy oracle (Hadamard = reference semantics; matmul = textbook NAF), every chain at
     every shape it admits — including batch sizes that are multiples of 64 but not of 256 (K ranges of the weight
