@@ -10,6 +10,7 @@ from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
 logging.getLogger('robotic_manipulator_rloa.utils.logger').setLevel(40)
 BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 JOINTS = int(sys.argv[2]) if len(sys.argv) > 2 else 6          # (the reference's state: 9 + 2 A floats, environment.py:261)
+LAYER = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 
 
 class ScriptedEnvironment:
@@ -32,7 +33,7 @@ class ScriptedEnvironment:
 
 
 env = SyntheticEnvironment(JOINTS) if JOINTS <= 8 else ScriptedEnvironment(JOINTS)
-agent = NAFAgent(env, 9 + 2 * JOINTS, JOINTS, 256, BATCH, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, torch.device("cuda:0"), 0)
+agent = NAFAgent(env, 9 + 2 * JOINTS, JOINTS, LAYER, BATCH, 100000, 1e-3, 1e-3, 0.99, 1, 1, 500, torch.device("cuda:0"), 0)
 state = env.reset(False)
 
 
@@ -65,6 +66,6 @@ def steps(n):
 steps(max(300, 4 * BATCH + 60))      # (past the dense regime of the sampler: population >= 4 B)
 torch.cuda.synchronize(); t0 = time.time(); steps(3000); torch.cuda.synchronize(); dt = time.time() - t0
 ch = agent._chunk
-print(f"joints {JOINTS} ({type(env).__name__}) batch {BATCH} chain {agent.learner.chain} form "
+print(f"joints {JOINTS} ({type(env).__name__}) layer_size {LAYER} batch {BATCH} chain {agent.learner.chain} form "
       f"{'pipelined' if getattr(ch, 'pipelined', False) else ('fused' if getattr(ch, 'fused_prep', False) or getattr(ch, 'fused_tail', False) else 'separate')}: ", end="")
 print(f"host-API path: {3000/dt:.0f} timesteps/s ({dt/3000*1e6:.0f} us per act+env.step+add+sample+learn), optimizer steps {int(agent.learner.step_dev.item())}")
