@@ -508,7 +508,7 @@ int naf_polyak_update(float* target, const float* main, float tau, float one_min
  *     appends the row, advances the counters, copies idx_spec to idx_out and is done (1 us instead of 10); otherwise — and always
  *     without a record — it does everything itself. The same minibatch, moments and indices either way. The record is cleared. */
 #define NAF_STEP_SPEC_INTS 12 /* [8], [9]: timesteps that took the prefetched minibatch / that drew for themselves */
-/*   copies (nullable, HOST pointer): up to three ranges of 4-byte words (<= 2048 each) copied src -> dst by the launch before anything
+/*   copies (nullable, HOST pointer): up to three ranges of 4-byte words (<= 4096 each) copied src -> dst by the launch before anything
  *     else — the pipelined form of the path keeps a WORKING copy of what a learn() chain changes besides the gradient (BatchNorm
  *     running statistics, optimizer step count, loss partials) next to the public one; a launch that starts a timestep over resets
  *     working from public here, naf_adam_polyak_act commits working to public (its `prefetch->copies`). */

@@ -27,6 +27,10 @@ __device__ __forceinline__ static float act_layer1_row(const float (&w)[ACT_MAX_
 __device__ __forceinline__ static float act_dot4(act_f4 w, act_f4 x) {
     return __builtin_fmaf(w.w, x.w, __builtin_fmaf(w.z, x.z, __builtin_fmaf(w.y, x.y, w.x * x.x)));
 }
+// ... and its share of the second 256 inputs of a 512-wide row (round 6: layer sizes up to 512), continuing the same chain
+__device__ __forceinline__ static float act_dot4_acc(act_f4 w, act_f4 x, float acc) {
+    return __builtin_fmaf(w.w, x.w, __builtin_fmaf(w.z, x.z, __builtin_fmaf(w.y, x.y, __builtin_fmaf(w.x, x.x, acc))));
+}
 // the 64 lanes' shares of ONE row: the xor tree over levels 1, 2, 4, 8, 16, 32 — the tree pa_fold32 (policy_act.hip) walks for 32
 // rows at once — on DPP modifiers and permlane swaps (common.h, naf_sum64: bitwise the xor-tree result), not six ds_bpermute
 // round trips (~100 cycles each: 0.3 us per row, and the heads are four to six rows per wave in a row)

@@ -85,7 +85,7 @@ struct StepPrepArgs {
     unsigned* cp_dst[3];
     int cp_n[3];
 };
-#define SP_COPY_WPT 2          // words per thread and copy: ranges of up to 2048 words
+#define SP_COPY_WPT 4          // words per thread and copy: ranges of up to 4096 words (the BatchNorm statistics of both nets at layer size 512)
 // the prefetch's record: what it assumed — the ring as ONE more append leaves the state it found, the sampler's stream position —
 // and whether the minibatch it left in out_rows / mom / idx_spec can stand for the one the next timestep's launch would draw
 // (+ two counters for the host: timesteps that took the prefetched minibatch / that drew for themselves)
@@ -665,9 +665,15 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
 // their registers.
 #define AA_MAX_NH_WIDE 80
 #define AA_MAX_A_WIDE 11
-template <int PMODE, int SPEC, int G = 8>
+// HV (round 6): the layer size — 256, or 512 (widths in (256, 512] are stored as 512): 16 layer-1 and 64 layer-2 workgroups, a row of
+// W2 / Wh as TWO float4 per lane (inputs 4 l .. 4 l + 3 and 256 + 4 l .. 256 + 4 l + 3, one fmaf chain through both: act_dot4 ->
+// act_dot4_acc, as policy_act_512_kernel), 512 + 512 records.
+template <int PMODE, int SPEC, int G = 8, int HV = AA_H>
 __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP) {
     constexpr int HL = G == 8 ? HEAD_MAX_LDH : AA_MAX_NH_WIDE;
+    constexpr int NQ = HV / 256;                        // float4 per lane of a 256- | 512-wide row
+    constexpr int L1_WGS = HV / AA_L1_ROWS, L2_WGS = HV / 8;
+    static_assert(HV == 256 || HV == 512, "layer size");
     if (SPEC) {
         extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
         __shared__ float4 sNewS[SP_MAX_RF4];
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
     }
 #define AA_TL(slot) NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, slot, blockIdx.x == 0, (int)blockIdx.x == (int)gridDim.x - (SPEC ? 2 : 1))
     __shared__ AdamScalars sSc;
-    __shared__ __attribute__((aligned(16))) float sAct[AA_H];                 // a1 (layer-2 workgroups) / a2 (the last workgroup)
+    __shared__ __attribute__((aligned(16))) float sAct[HV];                   // a1 (layer-2 workgroups) / a2 (the last workgroup)
     __shared__ __attribute__((aligned(16))) float sW[64 * ACT_MAX_S + 3 * 64]; // layer-1 workgroups: their 64 rows of W1, b1, g1, be1
     __shared__ float sObs[ACT_MAX_S];
     __shared__ float sHeads[HL];
@@ -695,13 +701,13 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
     // (only the last workgroup writes the epoch, behind everything it waits for; unsigned arithmetic: it may wrap)
     const int epoch = (int)((unsigned)P.sync[0] + 1u);
     int* rec1 = P.sync + 16;
-    int* rec2 = P.sync + 16 + 2 * AA_H;
+    int* rec2 = P.sync + 16 + 2 * HV;
     if (tid == 0) sTimed = 0;
     const int wh_wgs = P.wh_wgs;                        // workgroups that step Wh: ceil(NHP * HP / 4 / AA_THREADS)
-    const bool tl_l2 = wg == AA_L1_WGS + wh_wgs;        // (timeline: the first layer-2 workgroup leaves slots 8 ...)
+    const bool tl_l2 = wg == L1_WGS + wh_wgs;           // (timeline: the first layer-2 workgroup leaves slots 8 ...)
     AA_TL(0);
 
-    if (wg < AA_L1_WGS) {
+    if (wg < L1_WGS) {
         // ---- layer 1: rows 32 wg .. 32 wg + 31 of W1 and of b1 / g1 / be1 --------------------------------------------------
         constexpr int R = AA_L1_ROWS;
         const int S = P.S, row0 = R * wg;
@@ -755,11 +761,11 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         return;
     }
 
-    if (wg < AA_L1_WGS + wh_wgs) {
+    if (wg < L1_WGS + wh_wgs) {
         // ---- the heads' weights: one float4 per thread, written THROUGH (the last workgroup reads them in this launch), then one
         // arrival per workgroup once the stores have landed. Dispatched ahead of the layer-2 workgroups and depending on nothing:
         // long done when the last workgroup asks.
-        const int64_t i = (int64_t)(wg - AA_L1_WGS) * AA_THREADS + tid, n4 = (int64_t)P.NHP * (P.HP / 4);
+        const int64_t i = (int64_t)(wg - L1_WGS) * AA_THREADS + tid, n4 = (int64_t)P.NHP * (P.HP / 4);
         const bool on = i < n4;
         const int64_t f = P.off_Wh / 4 + (on ? i : 0);
         const AaOld4 o = aa_load4(A, f);
@@ -774,12 +780,14 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         return;
     }
 
-    if (wg < AA_L1_WGS + wh_wgs + AA_L2_WGS) {
-        // ---- layer 2: wave = one row of W2 (64 float4, lane l holds inputs 4 l .. 4 l + 3) --------------------------------------
+    if (wg < L1_WGS + wh_wgs + L2_WGS) {
+        // ---- layer 2: wave = one row of W2 (64 float4 per 256 inputs, lane l holds inputs 4 l .. 4 l + 3 of each) -------------------
         NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 8, tl_l2, false);
-        const int w = wg - AA_L1_WGS - wh_wgs, row = 8 * w + wave;
-        const int64_t fW2 = P.off_W2 / 4 + 64 * (int64_t)row + lane;
-        const AaOld4 o2 = aa_load4(A, fW2);
+        const int w = wg - L1_WGS - wh_wgs, row = 8 * w + wave;
+        const int64_t fW2 = P.off_W2 / 4 + (HV / 4) * (int64_t)row + lane;
+        AaOld4 o2[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) o2[q] = aa_load4(A, fW2 + 64 * q);
         AaOld1 ob = {}, og = {}, obe = {};
         if (lane == 0) {
             ob = aa_load1(A, P.off_b2 + row);
@@ -792,7 +800,9 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         __syncthreads();
         NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 9, tl_l2, false);
         const AdamScalars sc = sSc;
-        const aa_f4 w2 = aa_apply4(A, sc, o2, fW2, false);
+        aa_f4 w2[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) w2[q] = aa_apply4(A, sc, o2[q], fW2 + 64 * q, false);
         float b2 = 0.f, g2 = 0.f, be2 = 0.f;
         if (lane == 0) {
             b2 = aa_apply1(A, sc, ob, P.off_b2 + row);
@@ -803,15 +813,18 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         // layer 1's activations: polled by the first wave, shared through LDS
         if (wave == 0) {
             bool timed = false;
-            const aa_f4 x = aa_poll4(rec1, lane, epoch, &timed);
-            *(aa_f4*)(sAct + 4 * lane) = x;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const aa_f4 x = aa_poll4(rec1, lane + 64 * q, epoch, &timed);
+                *(aa_f4*)(sAct + 256 * q + 4 * lane) = x;
+            }
             if (timed) sTimed = 1;
         }
         __syncthreads();
         NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 11, tl_l2, false);
         if (sTimed && tid == 0) aa_count_timeout(P);
-        const aa_f4 x = *(const aa_f4*)(sAct + 4 * lane);
-        float p = act_dot4(w2, x);
+        float p = act_dot4(w2[0], *(const aa_f4*)(sAct + 4 * lane));
+        if (NQ == 2) p = act_dot4_acc(w2[NQ - 1], *(const aa_f4*)(sAct + 256 + 4 * lane), p);
         p = act_sum64(p);
         if (lane == 0) aa_publish(rec2, row, act_bn_relu(p + b2, rm, rv, g2, be2, P.eps), epoch);
         NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, 12, tl_l2, false);
@@ -846,22 +859,26 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         __syncthreads();
         AA_TL(1);
         const __amdgpu_buffer_rsrc_t whb = naf_buf(A.theta + P.off_Wh);
-        aa_f4 wh[HL / 8];
+        aa_f4 wh[HL / 8][NQ];
         float bias[HL / 8];
 #pragma unroll
         for (int k = 0; k < HL / 8; ++k) {
             const int h = wave + 8 * k;
             const unsigned roff = (unsigned)(h < NH ? h : 0) * (unsigned)P.HP * 4u;
-            wh[k] = naf_buf_f4_sc1(whb, 16u * (unsigned)lane, roff);
-            const naf_f32x4 bq = naf_buf_f4_sc1(whb, 16u * (unsigned)(AA_H / 4), roff);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) wh[k][q] = naf_buf_f4_sc1(whb, 16u * (unsigned)lane + 1024u * (unsigned)q, roff);
+            const naf_f32x4 bq = naf_buf_f4_sc1(whb, 16u * (unsigned)(HV / 4), roff);
             bias[k] = bq[0];
         }
         // the standard normal draw of the noise depends on nothing the launch computes: taken while the activations are under way
         const float zn = naf_act_noise_z(P.seed, ctr, 0, tid & (G - 1), tid < G && (tid & (G - 1)) < P.A);
         if (wave == 0) {
             bool timed = false;
-            const aa_f4 x = aa_poll4(rec2, lane, epoch, &timed);
-            *(aa_f4*)(sAct + 4 * lane) = x;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const aa_f4 x = aa_poll4(rec2, lane + 64 * q, epoch, &timed);
+                *(aa_f4*)(sAct + 256 * q + 4 * lane) = x;
+            }
             if (timed) sTimed = 1;
         }
         __syncthreads();
@@ -870,7 +887,10 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         const aa_f4 x = *(const aa_f4*)(sAct + 4 * lane);
         float ph[HL / 8];
 #pragma unroll
-        for (int k = 0; k < HL / 8; ++k) ph[k] = act_dot4(wh[k], x);
+        for (int k = 0; k < HL / 8; ++k) {
+            ph[k] = act_dot4(wh[k][0], x);
+            if (NQ == 2) ph[k] = act_dot4_acc(wh[k][NQ - 1], *(const aa_f4*)(sAct + 256 + 4 * lane), ph[k]);
+        }
 #pragma unroll
         for (int k = 0; k < HL / 8; ++k) {
             const int h = wave + 8 * k;
@@ -930,7 +950,7 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     P.ad.bc = nullptr;
     const int S = net->S, A = net->A, H = net->H, NHP = net->NHP, HP = net->HP;
     const int NH = A + A * (A + 1) / 2 + 1;
-    if (H != AA_H || S <= 0 || S > ACT_MAX_S || A <= 0 || A > AA_MAX_A_WIDE || NH > (A > NAF_MAX_A ? AA_MAX_NH_WIDE : HEAD_MAX_LDH) ||
+    if ((H != AA_H && H != 2 * AA_H) || S <= 0 || S > ACT_MAX_S || A <= 0 || A > AA_MAX_A_WIDE || NH > (A > NAF_MAX_A ? AA_MAX_NH_WIDE : HEAD_MAX_LDH) ||
         NHP < NH || HP <= H || (HP & 3) != 0 || HP / 4 > AA_THREADS)
         return NAF_ERR_ARG;
     const bool wide = A > NAF_MAX_A;                     // (one sample per 16-lane group, four chunks in the action's record)
@@ -964,7 +984,8 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     P.act_rec = action_rec;
     if (((uintptr_t)action_rec & 15) != 0) return NAF_ERR_ARG;
     P.wh_wgs = (int)(((int64_t)NHP * (HP / 4) + AA_THREADS - 1) / AA_THREADS);
-    const int grid = AA_L1_WGS + P.wh_wgs + AA_L2_WGS + 1;
+    const bool h512 = H == 2 * AA_H;
+    const int grid = H / AA_L1_ROWS + P.wh_wgs + H / 8 + 1;
     StepPrepArgs SP;
     memset(&SP, 0, sizeof(SP));
     if (prefetch && prefetch->mode == 0) {
@@ -981,13 +1002,21 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
         }
     }
     if (!prefetch || prefetch->mode == 0) {
+#define AA_GO0(PM, GV, HVV) adam_act_kernel<PM, 0, GV, HVV><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP)
+#define AA_GO0_H(PM, GV)                    \
+    do {                                    \
+        if (h512) AA_GO0(PM, GV, 512);      \
+        else AA_GO0(PM, GV, 256);           \
+    } while (0)
         if (p_mode == NAF_P_HADAMARD) {
-            if (wide) adam_act_kernel<NAF_P_HADAMARD, 0, 16><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
-            else adam_act_kernel<NAF_P_HADAMARD, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+            if (wide) AA_GO0_H(NAF_P_HADAMARD, 16);
+            else AA_GO0_H(NAF_P_HADAMARD, 8);
         } else {
-            if (wide) adam_act_kernel<NAF_P_MATMUL, 0, 16><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
-            else adam_act_kernel<NAF_P_MATMUL, 0><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP);
+            if (wide) AA_GO0_H(NAF_P_MATMUL, 16);
+            else AA_GO0_H(NAF_P_MATMUL, 8);
         }
+#undef AA_GO0_H
+#undef AA_GO0
         NAF_CHECK_LAUNCH();
         return NAF_OK;
     }
@@ -1006,7 +1035,7 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!raised_dev[dev]) {
-        const void* ks[16] = {
+        const void* ks[32] = {
             (const void*)adam_act_kernel<NAF_P_HADAMARD, 1>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2>,
             (const void*)adam_act_kernel<NAF_P_HADAMARD, 3>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4>,
             (const void*)adam_act_kernel<NAF_P_MATMUL, 1>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2>,
@@ -1014,7 +1043,15 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
             (const void*)adam_act_kernel<NAF_P_HADAMARD, 1, 16>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2, 16>,
             (const void*)adam_act_kernel<NAF_P_HADAMARD, 3, 16>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4, 16>,
             (const void*)adam_act_kernel<NAF_P_MATMUL, 1, 16>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2, 16>,
-            (const void*)adam_act_kernel<NAF_P_MATMUL, 3, 16>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4, 16>};
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 3, 16>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4, 16>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 1, 8, 512>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2, 8, 512>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 3, 8, 512>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4, 8, 512>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 1, 8, 512>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2, 8, 512>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 3, 8, 512>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4, 8, 512>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 1, 16, 512>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 2, 16, 512>,
+            (const void*)adam_act_kernel<NAF_P_HADAMARD, 3, 16, 512>, (const void*)adam_act_kernel<NAF_P_HADAMARD, 4, 16, 512>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 1, 16, 512>, (const void*)adam_act_kernel<NAF_P_MATMUL, 2, 16, 512>,
+            (const void*)adam_act_kernel<NAF_P_MATMUL, 3, 16, 512>, (const void*)adam_act_kernel<NAF_P_MATMUL, 4, 16, 512>};
         for (const void* k : ks) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_DYN_LDS);
             if (e != hipSuccess) return (int)e;
@@ -1023,11 +1060,13 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     }
     const int spec = (k4 <= 6 ? 1 : 3) + (sp_cached(prefetch->B, prefetch->out_ld) ? 0 : 1);
     const hipStream_t st = (hipStream_t)stream;
-#define AA_LAUNCH(PM, SV, GV) adam_act_kernel<PM, SV, GV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP)
-#define AA_LAUNCH_SV(PM, SV)                    \
-    do {                                        \
-        if (wide) AA_LAUNCH(PM, SV, 16);        \
-        else AA_LAUNCH(PM, SV, 8);              \
+#define AA_LAUNCH(PM, SV, GV, HVV) adam_act_kernel<PM, SV, GV, HVV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP)
+#define AA_LAUNCH_SV(PM, SV)                              \
+    do {                                                  \
+        if (wide && h512) AA_LAUNCH(PM, SV, 16, 512);     \
+        else if (wide) AA_LAUNCH(PM, SV, 16, 256);        \
+        else if (h512) AA_LAUNCH(PM, SV, 8, 512);         \
+        else AA_LAUNCH(PM, SV, 8, 256);                   \
     } while (0)
 #define AA_LAUNCH_PM(PM)                    \
     switch (spec) {                         \
@@ -1103,4 +1142,4 @@ extern "C" int naf_step_launch(void* dst_device, const void* src_host, size_t by
     return prefetch ? spf_launch(prefetch, (hipStream_t)side_stream) : NAF_OK;
 }
 
-extern "C" int naf_adam_polyak_act_sync_ints(void) { return 16 + 4 * AA_H; }
+extern "C" int naf_adam_polyak_act_sync_ints(void) { return 16 + 4 * 2 * AA_H; }     // (room for the 512-wide launch's records)

@@ -957,7 +957,8 @@ class ActPath:
         # one launch for the whole act() (csrc/policy_act.hip) when the shapes are the framework's (H = 256, S <= 32);
         # other shapes take the seven-launch path (3 GEMMs, 2 BN kernels, noise, counter)
         # (round 6: up to 11 joints — the state's group in the noise body is then 16 lanes wide)
-        self.fused = lay.H == 256 and lay.S <= 32 and lay.A <= BB_MAX_JOINTS
+        #  and layer sizes up to 512 — stored as 512: policy_act_512_kernel)
+        self.fused = lay.H in (256, 512) and lay.S <= 32 and lay.A <= BB_MAX_JOINTS
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_io = bool(host_io) and self.fused
         if self.host_io:

@@ -646,8 +646,9 @@ def test_device_env_loop_fills_replay_and_trains():
 
 
 @pytest.mark.parametrize("p_mode", [0, 1])
-@pytest.mark.parametrize("S,A,E", [(21, 6, 1), (21, 6, 64), (23, 7, 5), (32, 8, 33), (11, 1, 300), (27, 9, 1), (31, 11, 40)])
-def test_policy_act_one_launch_matches_seven_launch_path(S, A, E, p_mode, monkeypatch):
+@pytest.mark.parametrize("S,A,E,H", [(21, 6, 1, 256), (21, 6, 64, 256), (23, 7, 5, 256), (32, 8, 33, 256), (11, 1, 300, 256), (27, 9, 1, 256),
+                                     (31, 11, 40, 256), (21, 6, 1, 512), (23, 7, 70, 512), (27, 9, 3, 384)])
+def test_policy_act_one_launch_matches_seven_launch_path(S, A, E, H, p_mode, monkeypatch):
     """csrc/policy_act.hip (act() for E states in one launch) against the GEMM + BN-eval + noise chain it replaces:
     same heads pre-activations to f32 rounding, same noise stream (same Philox keys), counter advanced by one per call."""
     from robotic_manipulator_rloa_amd.learner import ActPath
@@ -655,22 +656,22 @@ def test_policy_act_one_launch_matches_seven_launch_path(S, A, E, p_mode, monkey
     g = np.load(os.path.join(GOLDEN, "g3_learn.npz"))
     import torch.nn as nn
     T = A * (A + 1) // 2
-    lin = {"input_layer": nn.Linear(S, 256), "hidden_layer": nn.Linear(256, 256), "action_values": nn.Linear(256, A),
-           "value": nn.Linear(256, 1), "matrix_entries": nn.Linear(256, T)}
+    lin = {"input_layer": nn.Linear(S, H), "hidden_layer": nn.Linear(H, H), "action_values": nn.Linear(H, A),
+           "value": nn.Linear(H, 1), "matrix_entries": nn.Linear(H, T)}
     sd = {}
     for k, l in lin.items():
         sd[f"{k}.weight"], sd[f"{k}.bias"] = l.weight.detach().numpy(), l.bias.detach().numpy()
     rng = np.random.default_rng(5)
     for b in ("bn1", "bn2"):
-        sd[f"{b}.weight"], sd[f"{b}.bias"] = rng.uniform(0.5, 1.5, 256).astype(np.float32), rng.normal(0, 0.2, 256).astype(np.float32)
-        sd[f"{b}.running_mean"] = rng.normal(0, 0.3, 256).astype(np.float32)
-        sd[f"{b}.running_var"] = rng.uniform(0.5, 2.0, 256).astype(np.float32)
-    L = make_learner(S, A, 64, sd, sd, p_mode=p_mode)
+        sd[f"{b}.weight"], sd[f"{b}.bias"] = rng.uniform(0.5, 1.5, H).astype(np.float32), rng.normal(0, 0.2, H).astype(np.float32)
+        sd[f"{b}.running_mean"] = rng.normal(0, 0.3, H).astype(np.float32)
+        sd[f"{b}.running_var"] = rng.uniform(0.5, 2.0, H).astype(np.float32)
+    L = make_learner(S, A, 64, sd, sd, H=H, p_mode=p_mode)      # (H = 512 | 384, round 6: stored as 512 — policy_act_512_kernel)
     obs = torch.randn(E, S, device="cuda")
     outs = []
     for fused in ("0", "1"):
         act = ActPath(L, E, seed=1234)
-        assert act.fused                      # H = 256, S <= 32: one launch
+        assert act.fused                      # H <= 512, S <= 32: one launch
         act.fused = fused == "1"              # the seven-launch path other shapes take
         act.obs.copy_(obs)
         a1 = act.act(1.0).clone()

@@ -133,32 +133,34 @@ def test_step_prep_refuses_bad_arguments(lib):
     torch.cuda.synchronize()
 
 
-def _two_learners(S, A, B, seed):
+def _two_learners(S, A, B, seed, H=256):
     from robotic_manipulator_rloa_amd.learner import Learner
     Ls = []
     for _ in range(2):
-        L = Learner(S, A, 256, B, 1e-3, 1e-3, 0.99, DEV)
+        L = Learner(S, A, H, B, 1e-3, 1e-3, 0.99, DEV)
         g = torch.Generator(device="cuda").manual_seed(seed)
         L.theta2.copy_(0.1 * torch.randn(L.theta2.shape, generator=g, device="cuda"))
         L.grad.copy_(0.05 * torch.randn(L.grad.shape, generator=g, device="cuda"))
         L.adam_m.copy_(0.01 * torch.randn(L.grad.shape, generator=g, device="cuda"))
         L.adam_v.copy_(1e-4 * torch.rand(L.grad.shape, generator=g, device="cuda"))
-        L.bn_stats[:, 0::2].copy_(0.3 * torch.randn(2, 2, 256, generator=g, device="cuda"))
-        L.bn_stats[:, 1::2].copy_(0.5 + torch.rand(2, 2, 256, generator=g, device="cuda"))
+        L.bn_stats[:, 0::2].copy_(0.3 * torch.randn(2, 2, L.lay.H, generator=g, device="cuda"))
+        L.bn_stats[:, 1::2].copy_(0.5 + torch.rand(2, 2, L.lay.H, generator=g, device="cuda"))
         L.step_dev.fill_(7)
         Ls.append(L)
     return Ls
 
 
 @pytest.mark.parametrize("p_mode", [0, 1])
-@pytest.mark.parametrize("S,A", [(21, 6), (23, 7), (10, 5), (21, 8), (27, 9), (29, 10), (31, 11), (32, 8), (20, 9)])
-def test_adam_polyak_act_equals_the_two_launches_it_replaces(lib, S, A, p_mode):
+@pytest.mark.parametrize("S,A,H", [(21, 6, 256), (23, 7, 256), (10, 5, 256), (21, 8, 256), (27, 9, 256), (29, 10, 256), (31, 11, 256),
+                                   (32, 8, 256), (20, 9, 256), (21, 6, 512), (23, 7, 512), (27, 9, 512), (31, 11, 512)])
+def test_adam_polyak_act_equals_the_two_launches_it_replaces(lib, S, A, H, p_mode):
     """naf_adam_polyak_act == naf_adam_polyak_fused followed by naf_policy_act: theta, theta', m, v, the heads' pre-activations
     and the (noisy, clamped) action bit for bit, over three consecutive launches (epochs of the records, the noise counter and the
-    pinned ordinal move on); A = 8 takes two rows of Wh per layer-2 workgroup."""
+    pinned ordinal move on); A = 8 takes two rows of Wh per layer-2 workgroup. H = 512 (round 6): 16 + 64 layer workgroups, rows as
+    two float4 per lane — against policy_act_512_kernel."""
     from robotic_manipulator_rloa_amd import _lib
     from robotic_manipulator_rloa_amd.learner import ActPath
-    La, Lb = _two_learners(S, A, 64, seed=3)
+    La, Lb = _two_learners(S, A, 64, seed=3, H=H)
     La.p_mode = Lb.p_mode = p_mode
     acts = [ActPath(La, 1, seed=99, host_io=True), ActPath(Lb, 1, seed=99, host_io=True)]
     assert acts[1].can_ride
@@ -188,7 +190,7 @@ def test_adam_polyak_act_equals_the_two_launches_it_replaces(lib, S, A, p_mode):
         for L in (La, Lb):
             L.grad.mul_(-0.7)
     # the new parameters differ from the old ones (the step did run)
-    assert not torch.equal(La.theta2[0], _two_learners(S, A, 64, seed=3)[0].theta2[0])
+    assert not torch.equal(La.theta2[0], _two_learners(S, A, 64, seed=3, H=H)[0].theta2[0])
 
 
 def test_adam_polyak_act_skips_a_poisoned_update_and_still_acts(lib):
@@ -598,7 +600,8 @@ def test_pipelined_path_survives_api_calls_between_timesteps(scratch_cwd, monkey
 @pytest.mark.parametrize("S,A,H,p_mode,action_mode", [(21, 6, 256, "hadamard", "trunc_int"), (23, 7, 256, "matmul", "float"),
                                                       (10, 5, 128, "matmul", "trunc_int"), (21, 6, 100, "hadamard", "trunc_int"),
                                                       (27, 9, 256, "hadamard", "trunc_int"), (31, 11, 256, "matmul", "float"),
-                                                      (32, 8, 256, "hadamard", "trunc_int")])
+                                                      (32, 8, 256, "hadamard", "trunc_int"), (21, 6, 512, "hadamard", "trunc_int"),
+                                                      (23, 7, 384, "matmul", "float"), (27, 9, 512, "hadamard", "trunc_int")])
 def test_pipelined_path_on_a_ring_that_wraps(scratch_cwd, monkeypatch, S, A, H, p_mode, action_mode):
     """600 timesteps on a ring of 300 rows at B = 64: every append evicts the oldest row after the first 300, the prefetch does not
     hold four times in ten (one of the two rows to come among the positions drawn) — the pipelined loop equals the twelve-launch loop all the way;
