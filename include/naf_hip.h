@@ -182,7 +182,7 @@ int naf_act_noise(const float* heads_pre, int ldh, float* action_out, uint64_t s
  * eval-mode forward of the main net (Linear -> BatchNorm with running statistics -> ReLU, twice; the NH = A+T+1 head
  * rows of Wh[.][ldw], whose column H is the bias) for obs[E][ldobs], then naf_act_noise's mu / noise / clamp with the
  * same Philox stream (seed, *counter_dev, state, lane). *counter_dev is advanced by one when the launch is over (by
- * the last workgroup to finish: `ticket` is a zero-initialised uint32 the library uses for that). H must be 256,
+ * the last workgroup to finish: `ticket` is a zero-initialised uint32 the library uses for that). H must be 256 or 512,
  * S <= 32, A <= 11 (beyond 8 joints the state's group in the noise body is 16 lanes wide). heads_out (nullable): [E][ldh]
  * pre-activations. One workgroup per state. */
 int naf_policy_act(const float* obs, int ldobs, int S, const float* W1, const float* b1, const float* g1, const float* be1,
@@ -526,7 +526,7 @@ int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_t* n_word, 
  * activations, which cross workgroups as (value, epoch) records. Same parameters, Adam state and target as naf_adam_polyak_fused
  * leaves them, same action as naf_policy_act computes from them (bit for bit, both: tests/test_kernels_gpu.py).
  *   adam: as naf_bb_layer1_adam's (l1_floats and bc are ignored); the flat buffers must be exactly
- *     [W1 (H x S) | b1 | g1 | be1 | W2 (H x H) | b2 | g2 | be2 | Wh (NHP x HP)] at the offsets `net` names (floats), H = 256;
+ *     [W1 (H x S) | b1 | g1 | be1 | W2 (H x H) | b2 | g2 | be2 | Wh (NHP x HP)] at the offsets `net` names (floats), H = 256 | 512;
  *   obs [S] and action_out [A] may be pinned host memory; heads_out (nullable) [A + T + 1] pre-activations;
  *   seed / counter_dev / noise_scale / p_mode: naf_policy_act's noise stream (*counter_dev advanced by one);
  *   sync: naf_adam_polyak_act_sync_ints() int32 of device scratch, zero-initialised ONCE by the caller, 16-byte aligned, used by
