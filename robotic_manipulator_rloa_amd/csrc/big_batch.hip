@@ -1232,12 +1232,13 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     constexpr int KS = ROWS == 16 ? (NHP == 64 ? 2 : 4) : 2;
     constexpr int DH_ROWS = SLOTS > (KS - 1) * ROWS ? SLOTS : (KS - 1) * ROWS;   // sDH also holds the partial tiles of K ranges 1 .. KS - 1
     static_assert(ROWS == 16 || ROWS == 32, "rows per workgroup");
-    static_assert(G == 8 || ROWS == 16, "9 .. 11 joints: 16 rows per workgroup");
+    static_assert(G == 8 || ROWS == 16 || PMODE != NAF_P_MATMUL, "9 .. 11 joints, 32 rows per workgroup: the Hadamard head only (no room for the L tiles)");
     static_assert(ROWS <= SLOTS && (NHP * (FK_H / 4)) % FK_THREADS == 0, "lane groups / Wh tile per thread");
     // A2 = ReLU(gamma xhat + beta) as a tile of its own when the LDS budget allows (not with the 18 KB L tiles of the matmul
     // mode): the heads GEMM then reads ONE operand row per macro-step instead of xhat + gamma + beta and forms nothing on the
     // VALU inside its MFMA loop — that loop was bound by LDS reads (4 x 16 B per lane per step, 8 waves), 1.7 us for 0.4 us of MFMA
-    constexpr bool A2T = PMODE != NAF_P_MATMUL;
+    // (9 .. 11 joints at 32 rows per workgroup — B > 2048 —: the 66 | 83 KB heads tile leaves no room for it either)
+    constexpr bool A2T = PMODE != NAF_P_MATMUL && !(G == 16 && ROWS == 32);
     __shared__ __attribute__((aligned(16))) float sXH[ROWS * FK_LD];
     __shared__ __attribute__((aligned(16))) float sA2[A2T ? ROWS * FK_LD : 4];
     __shared__ __attribute__((aligned(16))) float sW[NHP * FK_LD];
@@ -1499,7 +1500,11 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
                                         half ? nullptr : (HALVES == 2 && loss_partials ? loss_partials + (rb - (int)blockIdx.x) : loss_partials),
                                         B, A, s0, ns_);
     FK_TL(5);
-    if (!half && tid < ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
+    if (ROWS * NH4 <= FK_THREADS) {
+        if (!half && tid < ROWS * NH4) ((float4*)(d_heads + s0 * NHP))[tid] = ((const float4*)sDH)[tid];
+    } else if (!half) {                                    // (32 rows of 80 floats: 640 float4 for 512 threads)
+        for (int e = tid; e < ROWS * NH4; e += FK_THREADS) ((float4*)(d_heads + s0 * NHP))[e] = ((const float4*)sDH)[e];
+    }
     // ---- phase 4: dA2 = d_heads Wh (K = NHP), MT x 16 tiles, 2 MT per wave; ReLU mask, dY2, block sums ------------------
     {
         const int mt = wave_s % MT;
@@ -1724,9 +1729,10 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
         return NAF_ERR_ARG;
     const bool two = H == 2 * FK_H;      // two workgroups per row block (HALVES = 2): needs the exchange area and the launch's number
     if (two && (!once || !once->exchange || ((uintptr_t)once->exchange & 15))) return NAF_ERR_ARG;
-    // (A <= 8: NHP = 16 | 32 | 48, one sample per 8-lane group; 9 .. 11 joints: NHP = 64 | 80, per 16-lane group, B <= 2048)
+    // (A <= 8: NHP = 16 | 32 | 48, one sample per 8-lane group; 9 .. 11 joints: NHP = 64 | 80, per 16-lane group — beyond B = 2048, where
+    //  a workgroup takes 32 rows, with the Hadamard head only: the matmul mode's L tiles do not fit beside the heads tile)
     if (A <= 0 || A > FK_MAX_A || NHP < A + A * (A + 1) / 2 + 1 || NHP != ((A + A * (A + 1) / 2 + 1 + 15) / 16) * 16) return NAF_ERR_ARG;
-    if (A > NAF_MAX_A && naf_bb_layer2_head_rows(B) != 16) return NAF_ERR_ARG;
+    if (A > NAF_MAX_A && naf_bb_layer2_head_rows(B) != 16 && p_mode != NAF_P_HADAMARD) return NAF_ERR_ARG;
     if (p_mode != NAF_P_HADAMARD && p_mode != NAF_P_MATMUL) return NAF_ERR_ARG;
     if (ldz < H || (ldz & 3) || ldo < H || (ldo & 3) || ldd < H || ldw <= H || (ldw & 3) || ldu < A || ldr < 1) return NAF_ERR_ARG;
     if ((((uintptr_t)z | (uintptr_t)a2_out | (uintptr_t)Wh | (uintptr_t)d_heads) & 15) != 0 || (z_net_stride & 3) ||
@@ -1758,10 +1764,11 @@ extern "C" int naf_bb_layer2_head(const float* z, int64_t z_net_stride, int ldz,
         else if (rows == 16) BB_FK_R(PM, NH4V, 16, false);                       \
         else BB_FK_R(PM, NH4V, 32, false);                                       \
     } while (0)
-#define BB_FK_WIDE(PM, NH4V)                                       \
-    do {                                                           \
-        if (B % BB_ROWS == 0) BB_FK_R(PM, NH4V, 16, true);         \
-        else BB_FK_R(PM, NH4V, 16, false);                         \
+#define BB_FK_WIDE(PM, NH4V)                                                \
+    do {                                                                    \
+        if (rows == 16 && B % BB_ROWS == 0) BB_FK_R(PM, NH4V, 16, true);    \
+        else if (rows == 16) BB_FK_R(PM, NH4V, 16, false);                  \
+        else if ((PM) == NAF_P_HADAMARD) BB_FK_R(NAF_P_HADAMARD, NH4V, 32, false); \
     } while (0)
 #define BB_FK_NH(PM)                          \
     do {                                      \

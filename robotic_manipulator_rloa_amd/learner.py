@@ -215,8 +215,9 @@ class Learner:
         # (round 6, late: state sizes up to 32 — the layer-1 kernels' K — and 9 .. 11 joints: the fused layer-2 launch then holds one
         #  sample per 16-lane group and a Wh tile of 64 | 80 rows, 16 rows per workgroup only, hence B <= 2048; csrc/big_batch.hip.
         #  The reference's state is 9 + 2 A floats, environment.py:261: 27 | 29 | 31 at 9 | 10 | 11 joints)
+        #  (beyond 2048 — 32 rows per workgroup — with the reference's Hadamard head only: the matmul mode's L tiles do not fit there)
         self.bb_ok = (16 <= self.B <= 4096 and lay0.H in (256, 512) and lay0.S <= BB_MAX_STATE and
-                      (lay0.A <= 8 or (lay0.A <= BB_MAX_JOINTS and self.B <= 2048)))
+                      (lay0.A <= 8 or (lay0.A <= BB_MAX_JOINTS and (self.B <= 2048 or self.p_mode == _lib.P_HADAMARD))))
         want = (fuse or os.environ.get("NAF_FUSE", "default")).lower()
         if want not in ("default", "rows", "columns", "unfused"):
             raise ValueError(f"NAF_FUSE / fuse = {want!r}: one of default, rows, columns, unfused")
@@ -243,7 +244,7 @@ class Learner:
         if lay0.A > 8 and want != "rows":
             import warnings
             warnings.warn(f"action_size {lay0.A} at batch_size {self.B}, state_size {lay0.S} runs the unfused chain: the row-split "
-                          f"chain takes up to {BB_MAX_JOINTS} joints at 16 <= batch_size <= 2048, state_size <= {BB_MAX_STATE} "
+                          f"chain takes up to {BB_MAX_JOINTS} joints at 16 <= batch_size <= 4096 (2048 with p_mode matmul), state_size <= {BB_MAX_STATE} "
                           f"(every arm the reference ships has 6 or 7: KUKA / xArm, Panda)", stacklevel=3)
         elif self.B > 512 and want != "rows":
             # (a performance cliff, not an error: say so once, with the sizes that avoid it)

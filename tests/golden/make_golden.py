@@ -420,6 +420,43 @@ def main():
             print(f"g7: B = {B}: {n_upd} updates in {dt:.1f}s = {n_upd / dt:.1f} updates/s (reference learn(), CPU)", flush=True)
         np.savez_compressed(os.path.join(HERE, "g7_curves.npz"), data_seed=np.array(2024), idx_seed=np.array(99), **out)
 
+    # ---------------- G8: teacher-forced loss curves at 9 and 11 joints and at layer size 512 (round 6: the shapes whose fused kernels are
+    # new this round — one sample per 16-lane group in the fused layer-2 launch, two 256-column halves — held to the unmodified
+    # reference's learn() over thousands of updates as G5 / G7 hold the others). Rows of seed 2024, batch_indices(seed 99), the
+    # constructor's own weights at seed 0 (reference_init_state_dict reproduces them).   --only g8
+    if only is not None and "g8" in only:
+        import time
+        NROWS = 40000
+        out = {}
+        for tag, S, A, H, B, n_upd in (("j9", 27, 9, 256, 256, 3000), ("j11", 31, 11, 256, 1000, 2000), ("h512", 21, 6, 512, 256, 2000),
+                                       ("j10big", 29, 10, 256, 2560, 600)):
+            st, ac, rw, ns, dn = make_transitions(NROWS, S, A, seed=2024, rare_events=False, structured_reward=True)
+            tst, tac, trw, tns, tdn = (torch.from_numpy(st), torch.from_numpy(ac).long(), torch.from_numpy(rw[:, None]),
+                                       torch.from_numpy(ns), torch.from_numpy(dn[:, None]))
+            idx = batch_indices(NROWS, B, n_upd, seed=99)
+            agent = NAFAgent(object(), S, A, H, B, NROWS, 1e-3, 1e-3, 0.99, 1, 1, 500, cpu, 0)
+            losses = []
+            real_mse = ref_alg.F.mse_loss
+
+            def tap(a_, b_):
+                l_ = real_mse(a_, b_)
+                losses.append(float(l_.detach()))
+                return l_
+            ref_alg.F.mse_loss = tap
+            t0 = time.time()
+            for k in range(n_upd):
+                ii = torch.from_numpy(idx[k].astype(np.int64))
+                agent.learn((tst[ii], tac[ii], trw[ii], tns[ii], tdn[ii]))
+            ref_alg.F.mse_loss = real_mse
+            dt = time.time() - t0
+            sd = agent.qnetwork_main.state_dict()
+            out[f"{tag}/losses"] = np.array(losses, dtype=np.float32)
+            out[f"{tag}/theta_l2"] = np.array(float(sum((v.double() ** 2).sum() for n, v in sd.items()
+                                                        if v.dtype.is_floating_point and 'running' not in n) ** 0.5))
+            out[f"{tag}/dims"] = np.array([S, A, H, B, NROWS, n_upd])
+            print(f"g8: {tag}: {n_upd} updates in {dt:.1f}s = {n_upd / dt:.1f} updates/s (reference learn(), CPU)", flush=True)
+        np.savez_compressed(os.path.join(HERE, "g8_curves.npz"), data_seed=np.array(2024), idx_seed=np.array(99), **out)
+
     with open(os.path.join(HERE, "VERSIONS.txt"), "w") as f:
         f.write(f"generated by make_golden.py with torch {meta['torch']}, numpy {meta['numpy']} (CPU)\n")
 

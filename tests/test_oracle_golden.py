@@ -229,6 +229,25 @@ def test_g7_oracle_tracks_the_reference_at_odd_and_large_batches(B, n):
     np.testing.assert_allclose(got, g7[f"b{B}/losses"][:n], rtol=2e-2)
 
 
+@pytest.mark.parametrize("tag,n", [("j9", 30), ("j11", 10), ("h512", 10), ("j10big", 3)])
+def test_g8_oracle_tracks_the_reference_at_more_joints_and_wider_layers(tag, n):
+    """G8 (round 6): the unmodified reference's learn() losses on teacher-forced minibatches at 9 / 11 / 10 joints (B = 256 / 1000 / 2560)
+    and at layer size 512 — the curves the GPU suite holds the 16-lane fused layer-2 launch and the two-halves form to over thousands
+    of updates. The numpy oracle follows their first updates one by one."""
+    from synth_data import batch_indices, make_transitions
+    from robotic_manipulator_rloa_amd.naf_components.naf_neural_network import reference_init_state_dict
+    g8 = _npz("g8_curves.npz")
+    S, A, H, B, NROWS, n_upd = [int(x) for x in g8[f"{tag}/dims"]]
+    assert len(g8[f"{tag}/losses"]) == n_upd
+    st, ac, rw, ns, dn = make_transitions(NROWS, S, A, seed=int(g8["data_seed"]), rare_events=False, structured_reward=True)
+    idx = batch_indices(NROWS, B, n, seed=int(g8["idx_seed"]))
+    sd0 = {k: v.numpy() for k, v in reference_init_state_dict(S, A, H, 0).items()}
+    Or = O.LearnerOracle(sd0, dtype=np.float32)
+    got = [Or.learn(st[i], ac[i], rw[i], ns[i], dn[i]) for i in idx]
+    np.testing.assert_allclose(got[:3], g8[f"{tag}/losses"][:3], rtol=2e-4)
+    np.testing.assert_allclose(got, g8[f"{tag}/losses"][:n], rtol=2e-2)
+
+
 @pytest.mark.parametrize("tag", ["h512", "h384", "j9", "j11"])
 def test_g3_wide_layers_oracle(tag):
     """G3 at layer sizes 512 and 384 (round 6, slim goldens of the unmodified reference: tests/golden/g3_learn_wide.npz): the oracle's
