@@ -1,6 +1,6 @@
 """A long free-running run of the per-timestep loop in its shipped form (pipelined) and through the twelve separate launches, on the
 same scripted transitions: the SHA-256 of every action taken, the final parameters, optimizer state, BatchNorm buffers and ring
-must be equal.   python benchmarks/debug/soak.py [timesteps] [batch] [ring]"""
+must be equal.   python benchmarks/debug/soak.py [timesteps] [batch] [ring] [joints] [layer_size]   (state = 9 + 2 joints)"""
 import hashlib, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -14,12 +14,14 @@ DEV = torch.device("cuda:0")
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
-S, A, CH = 21, 6, 50000
+A = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+H = int(sys.argv[5]) if len(sys.argv) > 5 else 256
+S, CH = 9 + 2 * A, 50000
 
 
 def run(form):
     os.environ["NAF_STEP_FORM"] = form
-    agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+    agent = NAFAgent(object(), S, A, H, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
     h = hashlib.sha256()
     state, done, t0 = None, 0, time.perf_counter()
     while done < STEPS:
@@ -48,5 +50,5 @@ def run(form):
 
 a, b = run("pipelined"), run("separate")
 same = a["digest"] == b["digest"] and all(torch.equal(a[k], b[k]) for k in ("theta", "m", "v", "bn", "ring", "meta")) and a["step"] == b["step"]
-print(f"B = {B}, ring {N}: every action, theta, theta', m, v, BatchNorm buffers, ring and counters equal: {same}")
+print(f"{A} joints, layer size {H}, B = {B}, ring {N}: every action, theta, theta', m, v, BatchNorm buffers, ring and counters equal: {same}")
 sys.exit(0 if same else 1)
