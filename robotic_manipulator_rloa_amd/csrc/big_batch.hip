@@ -1224,8 +1224,9 @@ __global__ __launch_bounds__(FK_THREADS) void bb_layer2_head_kernel(
     constexpr int RPW = ROWS / 8;                          // rows per wave where a wave owns whole rows
     // 9 .. 11 joints (round 6; NHP = 64 | 80: [mu | l | V] is 55 | 66 | 78 wide): one sample per 16-LANE group in the head body (G; the
     // 16 rows of a workgroup are its first 256 threads), a Wh tile of 66 | 83 KB, heads and d_heads rows for 32 lane groups instead of
-    // 64 — 16 rows per workgroup only (B <= 2048): with 32 the tiles would not fit the 160 KB. Everything else — the statistics, the
-    // products' tile loops, the halves' exchange, dA2 — walks NHP as it finds it.
+    // 64. At 16 rows per workgroup (B <= 2048) that is 128 | 154 KB of the CU's 160; at 32 rows (beyond) the A2 tile goes (A2T below: the
+    // heads product forms A2 from x-hat as it reads, as the matmul mode always does) and the matmul mode's L tiles (35 KB) do not fit: the
+    // Hadamard head only. Everything else — the statistics, the products' tile loops, the halves' exchange, dA2 — walks NHP as it finds it.
     constexpr int G = NHP > HEAD_MAX_LDH ? 16 : 8;         // lanes per sample in the head body
     constexpr int SLOTS = FK_THREADS / G;                  // lane groups (ROWS of them carry samples)
     // K split of the heads GEMM (keeps the 8 waves busy): MT x NHP/16 tiles x KS ranges over 8 waves
