@@ -1,6 +1,6 @@
 """A long free-running run of the per-timestep loop in its shipped form (pipelined) and through the twelve separate launches, on the
 same scripted transitions: the SHA-256 of every action taken, the final parameters, optimizer state, BatchNorm buffers and ring
-must be equal.   python benchmarks/debug/soak.py [timesteps] [batch] [ring] [joints] [layer_size]   (state = 9 + 2 joints)"""
+must be equal.   python benchmarks/debug/soak.py [timesteps] [batch] [ring] [joints] [layer_size] [state_size]   (state = 9 + 2 joints unless given)"""
 import hashlib, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -16,7 +16,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 A = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 H = int(sys.argv[5]) if len(sys.argv) > 5 else 256
-S, CH = 9 + 2 * A, 50000
+S = int(sys.argv[6]) if len(sys.argv) > 6 else 9 + 2 * A          # (a state size other than the reference's 9 + 2 joints)
+CH = min(50000, STEPS)
 
 
 def run(form):
@@ -50,5 +51,5 @@ def run(form):
 
 a, b = run("pipelined"), run("separate")
 same = a["digest"] == b["digest"] and all(torch.equal(a[k], b[k]) for k in ("theta", "m", "v", "bn", "ring", "meta")) and a["step"] == b["step"]
-print(f"{A} joints, layer size {H}, B = {B}, ring {N}: every action, theta, theta', m, v, BatchNorm buffers, ring and counters equal: {same}")
+print(f"{A} joints, state {S}, layer size {H}, B = {B}, ring {N}: every action, theta, theta', m, v, BatchNorm buffers, ring and counters equal: {same}")
 sys.exit(0 if same else 1)
