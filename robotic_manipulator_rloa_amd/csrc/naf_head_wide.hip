@@ -6,8 +6,10 @@
 // The heads rows (up to 16 + 136 + 1 = 153 -> 160 floats) are read where they lie; d_heads rows are assembled in LDS and leave as
 // whole rows. Replaces naf_neural_network.py:81-115 (+ autograd) and naf_algorithm.py:199-208 for those action sizes; reached
 // through the entry points of naf_head.hip (naf_head_fwd / _bwd / _fwd_bwd_mse, naf_act_noise), which dispatch on A.
+// 17 <= A <= 64 (second half of the file): one sample per 32- / 64-lane group through the shared body of head_body.h.
 #include "common.h"
 #include "../../include/naf_hip.h"
+#include "head_body.h"
 
 #define HW_G 16                  // lanes per sample
 #define HW_THREADS 256
@@ -152,7 +154,6 @@ __global__ __launch_bounds__(HW_THREADS) void naf_head_wide_kernel(const float* 
 // staged into LDS, d_heads rows assembled there and stored as whole rows. 256 threads: 8 | 4 samples per workgroup. Not a fast path
 // (nothing about a 40-joint arm is): the same arithmetic, checked against the f64 oracle like the others.
 // ------------------------------------------------------------------------------------------------------------------------------
-#include "head_body.h"
 template <int PMODE, int MODE, int G>
 __global__ __launch_bounds__(HW_THREADS) void naf_head_any_kernel(const float* __restrict__ heads, int ldh,
                                                                   const float* __restrict__ u, int ldu,
