@@ -62,7 +62,8 @@ for _ in range(4 * B + 60):
     step()
 ch = agent._chunk
 PIPELINED = bool(getattr(ch, "pipelined", False))
-KIDS = {"bb_layer1": 0, "bb_linear_stats": 1, "bb_layer2_head": 2, "gemm_bundle": 4, "finish": 5, "step_prep": 7, "adam_act": 8}
+KIDS = {"bb_layer1": 0, "bb_linear_stats": 1, "bb_layer2_head": 2, "gemm_bundle": 4, "finish": 5, "step_prep": 7, "adam_act": 8,
+        "l1_riders": 2048}      # (layer 1 riding on adam_act: slots 0 - 6 as bb_layer1's, 13 = entry, 14 = the step's flags seen)
 acc = {k: np.zeros((2, 16)) for k in KIDS}
 out = (C.c_longlong * 32)()
 n_used = 0
@@ -89,7 +90,7 @@ if PIPELINED:
           f"of its own, the prefetch launch (step_prep rows: append + depth-2 prefetch): microseconds since adam_act's entry, mean of "
           f"{REPS} timesteps (first workgroup | last workgroup; 0 = no mark)")
     print("step_prep rows (one workgroup: both rows are it): slots 0 - 6 main phases, 7 - 12 moments, 13 - 15 draw")
-    order = ("adam_act", "step_prep", "bb_layer1", "bb_linear_stats", "bb_layer2_head", "gemm_bundle", "finish")
+    order = ("adam_act", "l1_riders", "step_prep", "bb_layer1", "bb_linear_stats", "bb_layer2_head", "gemm_bundle", "finish")
 else:
     print(f"B = {B}: microseconds since step_prep's entry, mean of {REPS} timesteps (first workgroup | last workgroup; 0 = no mark)")
     order = ("step_prep", "bb_layer1", "bb_linear_stats", "bb_layer2_head", "gemm_bundle", "finish", "adam_act")

@@ -67,7 +67,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 32
+#define NAF_HIP_ABI_VERSION 33
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -602,6 +602,35 @@ int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, c
                         float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode, int32_t* sync,
                         uint64_t* host_errors, uint32_t* host_seq, uint32_t* action_rec, const naf_step_prefetch_t* prefetch,
                         int obs_system_scope, void* stream);
+/* naf_adam_polyak_act_layer1 (round 6): the same launch with LAYER 1 of the NEXT update's chain riding on it — what naf_bb_layer1_adam
+ * does as a launch of its own (both networks' Linear 1 + BatchNorm(train) + ReLU from the minibatch's moments record,
+ * naf_neural_network.py:76), in B/64 x H/64 x 2 extra workgroups that start once the launch's optimizer step has written the layer-1
+ * segment of both networks and the commit (`prefetch->copies`, mode 0) has copied the working BatchNorm statistics they advance.
+ * The chain behind this launch then starts at GEMM 2 (naf_bb_linear_stats_adam with adam = NULL): it no longer waits for the act()
+ * tail of this launch nor for one launch boundary — 40 -> 35 us per timestep of the reference's loop at B = 64. The same body, the same
+ * bits as the launch of its own (csrc/layer1_body.h). `layer1`: the arguments of naf_bb_layer1_adam of the same names (nets must be
+ * 2; W / bias / gamma / beta: the MAIN network's, the target's param_net_stride floats behind — the buffers this launch steps);
+ * `prefetch`: NULL or mode 0 (the commit only). Everything else as naf_adam_polyak_act. */
+typedef struct {
+    const float* x;              /* the minibatch rows: net 0 reads `state`, net 1 `next_state` x_net_stride floats further on */
+    int64_t x_net_stride;
+    int ldx, K;
+    const float *W, *bias, *gamma, *beta;
+    int64_t param_net_stride;
+    const float* mom;            /* [2][naf_bb_moments_floats(K)] */
+    float *running_mean, *running_var;
+    int64_t stat_net_stride;
+    float* out;                  /* A1 [2][..][ldo] */
+    int64_t out_net_stride;
+    int ldo;
+    float *save_mean, *save_invstd, *wc_out, *xhat_out;
+    int B, H, nets;
+    float momentum, eps;
+} naf_bb_layer1_t;
+int naf_adam_polyak_act_layer1(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
+                               float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode, int32_t* sync,
+                               uint64_t* host_errors, uint32_t* host_seq, uint32_t* action_rec, const naf_step_prefetch_t* prefetch,
+                               int obs_system_scope, const naf_bb_layer1_t* layer1, void* stream);
 
 /* ---- synthetic manipulator environment (stand-in for the PyBullet Environment) ---------------- */
 /* One step of E independent kinematic-chain arms on the device, emitting transition rows

@@ -230,6 +230,7 @@ _PROTOS = {
     "naf_step_prefetch": [_vp, _vp],
     "naf_step_launch": [_vp, _vp, _sz, _vp, _vp, _vp, _vp],
     "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "naf_adam_polyak_act_layer1": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "naf_xgmi_chunk_floats": [],
     "naf_xgmi_create": [_i, _i, _sz, C.c_double, C.POINTER(_vp)],
     "naf_xgmi_set_timeout": [_vp, C.c_double],
@@ -285,6 +286,16 @@ class ActNet(C.Structure):
                 ("off_b2", C.c_int64), ("off_g2", C.c_int64), ("off_be2", C.c_int64), ("off_Wh", C.c_int64),
                 ("running_mean1", C.c_void_p), ("running_var1", C.c_void_p), ("running_mean2", C.c_void_p),
                 ("running_var2", C.c_void_p), ("eps", C.c_float)]
+
+
+class BbLayer1(C.Structure):
+    """naf_bb_layer1_t (include/naf_hip.h): layer 1 of the next update's chain riding on naf_adam_polyak_act_layer1"""
+    _fields_ = [("x", C.c_void_p), ("x_net_stride", C.c_int64), ("ldx", C.c_int), ("K", C.c_int), ("W", C.c_void_p),
+                ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("param_net_stride", C.c_int64),
+                ("mom", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("stat_net_stride", C.c_int64),
+                ("out", C.c_void_p), ("out_net_stride", C.c_int64), ("ldo", C.c_int), ("save_mean", C.c_void_p),
+                ("save_invstd", C.c_void_p), ("wc_out", C.c_void_p), ("xhat_out", C.c_void_p), ("B", C.c_int), ("H", C.c_int),
+                ("nets", C.c_int), ("momentum", C.c_float), ("eps", C.c_float)]
 
 
 class StepCopies(C.Structure):

@@ -14,6 +14,7 @@ int naf_tl_read_sp(int kid, long long* out);
 extern "C" int naf_timeline_read(int kernel_id, long long* out) {
     if (!out || kernel_id < 0 || (kernel_id >= NAF_TL_KERNELS && kernel_id < 1024)) return NAF_ERR_ARG;
     if (hipDeviceSynchronize() != hipSuccess) return NAF_ERR_STATE;
+    if (kernel_id >= 2048) return naf_tl_read_sp(kernel_id - 2048, out);               // (layer 1 riding on adam_act_kernel: its marks, 2048 + NAF_TL_BB_LAYER1)
     if (kernel_id >= 1024) return naf_tl_read_gb_wg(16 * (kernel_id - 1024), out);   // gemm_bundle, entry / exit per workgroup
     if (kernel_id == NAF_TL_GEMM_BUNDLE) return naf_tl_read_gb(kernel_id, out);
     if (kernel_id == NAF_TL_ADAM) return naf_tl_read_opt(kernel_id, out);

@@ -39,6 +39,12 @@ NAF_TL_DECL(g_tl_sp);
 #include "act_body.h"
 #include "adam_body.h"
 #include "head_body.h"
+#ifdef NAF_TIMELINE
+// (layer 1 riding on adam_act_kernel leaves its marks in this file's table, row NAF_TL_BB_LAYER1: naf_timeline_read(2048 + 0))
+#define BB_L1_TL(slot, is_first, is_last) NAF_TL_FL(g_tl_sp, NAF_TL_BB_LAYER1, slot, is_first, is_last)
+#define BB_L1_TL_T(slot, is_first, is_last, thread) NAF_TL_FL_T(g_tl_sp, NAF_TL_BB_LAYER1, slot, is_first, is_last, thread)
+#endif
+#include "layer1_body.h"      // bb_layer1_impl: layer 1 of the row-split chain, riding on adam_act_kernel (round 6)
 #include "moments_body.h"
 #include "replay_dev.h"
 #include "sample_body.h"
@@ -542,6 +548,7 @@ extern "C" int naf_step_prep(naf_replay_t* h, const float* src_row, const int32_
 #define AA_L1_WGS 8                       // layer-1 workgroups: 32 rows of W1 each (one float4 of the slice per thread)
 #define AA_L1_ROWS (AA_H / AA_L1_WGS)
 #define AA_L2_WGS 32                      // layer-2 workgroups: 8 rows of W2 each (one wave per row)
+#define AA_SYNC_RIDE (16 + 4 * 2 * AA_H)  // ints: the riders' words (naf_adam_polyak_act_layer1) lie behind the widest launch's records
 #define AA_POLL_TICKS 200000LL            // 2 ms at 100 MHz: a hang guard, not a schedule (records arrive within ~2 us)
 
 typedef float aa_f4 __attribute__((ext_vector_type(4)));
@@ -568,6 +575,30 @@ struct AdamActArgs {
     uint32_t* act_rec;                    // nullable pinned host record: 3 x {a[3j], a[3j + 1], a[3j + 2], epoch}, a store each
 };
 
+// Layer 1 of the NEXT update's chain riding on this launch (round 6; naf_adam_polyak_act_layer1): the arguments of bb_layer1_kernel
+// (csrc/big_batch.hip, csrc/layer1_body.h). The chain's first launch needs the parameters this launch's optimizer step leaves and
+// nothing else of it — as a launch of its own behind adam_act it also waited for the act() tail (heads, noise, the action: 4 of the
+// launch's 7.6 us) and for a launch boundary. Here n_main extra workgroups run its body once the layer-1 workgroups have stepped
+// their slices (their arrivals) and the last workgroup has committed the working BatchNorm statistics they advance; the last
+// workgroup holds the launch's ordinal back until they are done (three words of `sync` behind the records, a line each).
+struct L1RideArgs {
+    const float* x;
+    int64_t x_net_stride;
+    int ldx, K;
+    const float *W, *bias, *gamma, *beta;
+    int64_t param_net_stride;
+    const float* mom;
+    float *running_mean, *running_var;
+    int64_t stat_net_stride;
+    float* out;
+    int64_t out_net_stride;
+    int ldo;
+    float *save_mean, *save_invstd, *wc_out, *xhat_out;
+    int B, H;
+    float momentum, eps;
+    int n_main, xcd_rows;
+};
+
 // one float4 / one float of the flat buffers through the pending update (adam_one: the code every other launch of the step runs);
 // loads and arithmetic are separate so that a workgroup has every operand in flight before it derives the step's scalars
 struct AaOld4 {
@@ -582,7 +613,27 @@ __device__ __forceinline__ static AaOld4 aa_load4(const AdamArgs& A, int64_t f4)
     o.tg = ((float4*)(A.target ? A.target : A.theta))[f4];
     return o;
 }
-__device__ __forceinline__ static aa_f4 aa_apply4(const AdamArgs& A, const AdamScalars& sc, AaOld4 o, int64_t f4, bool through) {
+// (the same in two halves — the new values now, their stores later: the layer-1 workgroups of a launch whose riders read the OLD
+//  values of the same addresses, adam_act_kernel<.., L1K4 != 0>)
+__device__ __forceinline__ static void aa_step4(const AdamArgs& A, const AdamScalars& sc, AaOld4& o) {
+    if (!sc.skip) {
+        const bool ht = A.target != nullptr;
+        adam_one(o.th.x, o.gr.x, o.mm.x, o.vv.x, o.tg.x, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(o.th.y, o.gr.y, o.mm.y, o.vv.y, o.tg.y, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(o.th.z, o.gr.z, o.mm.z, o.vv.z, o.tg.z, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+        adam_one(o.th.w, o.gr.w, o.mm.w, o.vv.w, o.tg.w, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
+    }
+}
+__device__ __forceinline__ static void aa_store4(const AdamArgs& A, const AdamScalars& sc, const AaOld4& o, int64_t f4) {
+    if (!sc.skip) {
+        ((float4*)A.theta)[f4] = o.th;
+        ((float4*)A.m)[f4] = o.mm;
+        ((float4*)A.v)[f4] = o.vv;
+        if (A.target != nullptr) ((float4*)A.target)[f4] = o.tg;
+    }
+}
+__device__ __forceinline__ static aa_f4 aa_apply4(const AdamArgs& A, const AdamScalars& sc, AaOld4 o, int64_t f4, bool through,
+                                                  bool through_target = false) {
     if (!sc.skip) {
         const bool ht = A.target != nullptr;
         adam_one(o.th.x, o.gr.x, o.mm.x, o.vv.x, o.tg.x, ht, sc, A.beta1, A.beta2, A.eps, A.tau, A.one_minus_tau);
@@ -594,7 +645,8 @@ __device__ __forceinline__ static aa_f4 aa_apply4(const AdamArgs& A, const AdamS
         else ((float4*)A.theta)[f4] = o.th;
         ((float4*)A.m)[f4] = o.mm;
         ((float4*)A.v)[f4] = o.vv;
-        if (ht) ((float4*)A.target)[f4] = o.tg;
+        if (ht && through_target) naf_buf_st_f4_sc1(naf_buf(A.target), off, 0, (naf_f32x4){o.tg.x, o.tg.y, o.tg.z, o.tg.w});
+        else if (ht) ((float4*)A.target)[f4] = o.tg;
     }
     return (aa_f4){o.th.x, o.th.y, o.th.z, o.th.w};
 }
@@ -668,8 +720,11 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
 // HV (round 6): the layer size — 256, or 512 (widths in (256, 512] are stored as 512): 16 layer-1 and 64 layer-2 workgroups, a row of
 // W2 / Wh as TWO float4 per lane (inputs 4 l .. 4 l + 3 and 256 + 4 l .. 256 + 4 l + 3, one fmaf chain through both: act_dot4 ->
 // act_dot4_acc, as policy_act_512_kernel), 512 + 512 records.
-template <int PMODE, int SPEC, int G = 8, int HV = AA_H>
-__global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP) {
+// L1K4 (round 6): 6 | 8 = the next update's layer 1 rides on this launch (L1RideArgs; K4 = 6 | 8 float4 of state, L1FULL: whole 64-row
+// blocks): L1.n_main more workgroups behind the last one. 0: no riders, the kernel as it was.
+template <int PMODE, int SPEC, int G = 8, int HV = AA_H, int L1K4 = 0, bool L1FULL = true>
+__global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP, const L1RideArgs L1) {
+    static_assert(L1K4 == 0 || SPEC == 0, "layer 1 rides on the launch without the prefetching workgroup");
     constexpr int HL = G == 8 ? HEAD_MAX_LDH : AA_MAX_NH_WIDE;
     constexpr int NQ = HV / 256;                        // float4 per lane of a 256- | 512-wide row
     constexpr int L1_WGS = HV / AA_L1_ROWS, L2_WGS = HV / 8;
@@ -686,7 +741,7 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         }
         if (threadIdx.x >= AA_THREADS) return;          // (whole waves: the barriers below count the waves that are left)
     }
-#define AA_TL(slot) NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, slot, blockIdx.x == 0, (int)blockIdx.x == (int)gridDim.x - (SPEC ? 2 : 1))
+#define AA_TL(slot) NAF_TL_FL(g_tl_sp, NAF_TL_ADAM_ACT, slot, blockIdx.x == 0, (int)blockIdx.x == (int)gridDim.x - (SPEC ? 2 : 1) - (L1K4 ? L1.n_main : 0))
     __shared__ AdamScalars sSc;
     __shared__ __attribute__((aligned(16))) float sAct[HV];                   // a1 (layer-2 workgroups) / a2 (the last workgroup)
     __shared__ __attribute__((aligned(16))) float sW[64 * ACT_MAX_S + 3 * 64]; // layer-1 workgroups: their 64 rows of W1, b1, g1, be1
@@ -702,6 +757,23 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
     const int epoch = (int)((unsigned)P.sync[0] + 1u);
     int* rec1 = P.sync + 16;
     int* rec2 = P.sync + 16 + 2 * HV;
+    // the riders' three words, each on a 128-byte line of its own BEHIND the records (polled with atomics by every rider: on the line
+    // of the launch's counters they delayed the first records of layer 1 by 0.85 us — the action's critical path)
+    int* const l1_arrived = P.sync + AA_SYNC_RIDE;          // layer-1 workgroups that have stepped their slice
+    int* const l1_done = P.sync + AA_SYNC_RIDE + 32;        // riders that are through
+    int* const l1_commit = P.sync + AA_SYNC_RIDE + 64;      // = the launch's ordinal once the commit has been copied
+    int* const l1_loaded = P.sync + AA_SYNC_RIDE + 96;      // riders that have consumed the old layer-1 parameters they read
+    // Nobody waits for the launch's end: every party that uses these words — the riders, the layer-1 workgroups, the last workgroup —
+    // counts itself out in `l1_done`, and the LAST one out clears the words and moves the launch's ordinal (one that starts late must
+    // still read the old one; a wait for the riders in the last workgroup cost the launch 2 us: a flag takes that long to cross the chip)
+    auto ride_out = [&]() {
+        if (__hip_atomic_fetch_add(l1_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L1.n_main + L1_WGS) {
+            __hip_atomic_store(l1_arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(l1_loaded, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(l1_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            P.sync[0] = epoch;
+        }
+    };
     if (tid == 0) sTimed = 0;
     const int wh_wgs = P.wh_wgs;                        // workgroups that step Wh: ceil(NHP * HP / 4 / AA_THREADS)
     const bool tl_l2 = wg == L1_WGS + wh_wgs;           // (timeline: the first layer-2 workgroup leaves slots 8 ...)
@@ -739,11 +811,25 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         const float rm = P.rm1[row0 + (tid & (R - 1))], rv = P.rv1[row0 + (tid & (R - 1))];
         const AdamPrefetch pf = adam_prefetch(A, tid);
         adam_derive(A, pf, &sSc, tid);
+        if constexpr (L1K4 != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (rm / rv above have been READ)
         __syncthreads();
+        if constexpr (L1K4 != 0) {
+            // the riders overwrite the running statistics this workgroup has just read — once every one of the launch's layer-1
+            // workgroups has said so (raised here, early: a flag takes 1.5 - 2 us to cross the chip, and the riders get to their
+            // statistics 4 us into the launch)
+            if (tid == 0) __hip_atomic_fetch_add(l1_arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         AA_TL(1);
         const AdamScalars sc = sSc;
+        AaOld4 on = o;                                      // (L1K4: the stepped values, stored at the end)
         if (tid < items) {
-            const aa_f4 nv = aa_apply4(A, sc, o, f4, false);
+            aa_f4 nv;
+            if constexpr (L1K4 != 0) {
+                aa_step4(A, sc, on);
+                nv = (aa_f4){on.th.x, on.th.y, on.th.z, on.th.w};
+            } else {
+                nv = aa_apply4(A, sc, o, f4, false);
+            }
             *(aa_f4*)(sW + lds) = nv;
         }
         __syncthreads();
@@ -758,6 +844,24 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
             aa_publish(rec1, row, a1, epoch);
         }
         AA_TL(3);
+        if constexpr (L1K4 != 0) {
+            // The riders evaluate this slice themselves, from its OLD values, gradient and optimizer state — so the stepped values go
+            // to memory only once every rider has consumed what it reads (they have, microseconds ago: their loads are the first
+            // thing they do; act() above ran on the copies in LDS). Bounded like every wait here.
+            if (tid == 0) {
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(l1_loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < L1.n_main) {
+                    if (wall_clock64() - t0 > AA_POLL_TICKS) { sTimed = 1; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+            if (tid < items) aa_store4(A, sc, on, f4);
+            if (tid == 0) {
+                if (sTimed) aa_count_timeout(P);
+                ride_out();
+            }
+        }
         return;
     }
 
@@ -831,6 +935,61 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         return;
     }
 
+    if constexpr (L1K4 != 0) {
+        const int last_wg = L1_WGS + wh_wgs + L2_WGS;
+        if (wg > last_wg) {
+            // ---- layer 1 of the next update's chain (csrc/layer1_body.h), in its ADAM form: the workgroup evaluates the layer-1
+            // parameters it reads AS THIS LAUNCH'S STEP WILL LEAVE THEM (the form the chunked chain runs when the previous update's
+            // step rides on it: same gradient, same norm partials, same step count — the same bits the layer-1 workgroups above
+            // write), so it depends on nothing in this launch and starts with it. Its one hazard is the running statistics of
+            // layer 1, which the workgroups above READ (act() is eval-mode BatchNorm) and the commit copies: the lanes that write
+            // them wait for both first (the hook; both have long happened by then).
+            __shared__ BbL1Shared<L1K4, true> sL1;
+            NAF_TL_FL(g_tl_sp, NAF_TL_BB_LAYER1, 13, wg == last_wg + 1, wg == last_wg + L1.n_main);
+            struct Guard {
+                const int *arrived, *commit;
+                int want_arrived, want_commit;
+                int* timed;
+                int* loaded;
+                __device__ __forceinline__ void parameters_loaded() const {
+                    __hip_atomic_fetch_add(loaded, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __device__ __forceinline__ void before_running_stats() const {
+                    // ONE lane of each wave that gets here polls, the others take its word: with all 64 column lanes of 8 riders
+                    // polling, the two lines were so busy that the layer-1 workgroups' arrivals took 3 us to land
+                    const int lane_ = (int)(threadIdx.x & 63);
+                    const bool leader = __builtin_amdgcn_readfirstlane(lane_) == lane_;
+                    const long long t0 = wall_clock64();
+                    for (;;) {
+                        int a = 0, c = 0;
+                        if (leader) {
+                            a = __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            c = __hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        a = __builtin_amdgcn_readfirstlane(a);
+                        c = __builtin_amdgcn_readfirstlane(c);
+                        if (a >= want_arrived && c == want_commit) break;
+                        if (wall_clock64() - t0 > AA_POLL_TICKS) { *timed = 1; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            };
+            const Guard guard = {l1_arrived, l1_commit, L1_WGS, epoch, &sTimed, l1_loaded};
+            bb_layer1_impl<L1K4, true, L1FULL, Guard>(sL1, wg - last_wg - 1, L1.x, L1.x_net_stride, L1.ldx, L1.K, L1.W, L1.bias, L1.gamma,
+                                                      L1.beta, L1.param_net_stride, L1.mom, L1.running_mean, L1.running_var,
+                                                      L1.stat_net_stride, L1.out, L1.out_net_stride, L1.ldo, L1.save_mean, L1.save_invstd,
+                                                      L1.wc_out, L1.B, L1.H, L1.momentum, L1.eps, L1.n_main, A, 0, 0, 0, L1.xcd_rows,
+                                                      L1.xhat_out, guard);
+            NAF_TL_FL(g_tl_sp, NAF_TL_BB_LAYER1, 14, wg == last_wg + 1, wg == last_wg + L1.n_main);
+            __syncthreads();
+            if (tid == 0) {
+                if (sTimed) aa_count_timeout(P);            // (counted where the host raises: the chain's result is not valid)
+                ride_out();
+            }
+            return;
+        }
+    }
+
     // ---- the last workgroup: heads, exploration noise, clamp ----------------------------------------------------------------------
     {
         const uint64_t ctr = *P.counter_dev;
@@ -846,6 +1005,14 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
                 if (src && dst)
                     for (int w = tid; w < nw; w += AA_THREADS) dst[w] = src[w];
             }
+        }
+        if constexpr (L1K4 != 0) {
+            // the riders advance the working BatchNorm statistics the commit above has just copied: they wait for this word (a barrier
+            // of its own: behind the poll below it kept them waiting until the heads' weights had arrived, 4 us into the launch).
+            // What they must not overtake is the copy's READS of the working statistics: done once its stores have been issued — no
+            // release (nobody in this launch reads the public copy).
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(l1_commit, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // every float4 of Wh has been stepped and written through once its workgroups have arrived
         if (tid == 0) {
@@ -926,7 +1093,8 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
             if (tid == 0) {
                 if (timed) aa_count_timeout(P);
                 *P.counter_dev = ctr + 1;
-                P.sync[0] = epoch;
+                if constexpr (L1K4 != 0) ride_out();        // (the last party out moves the ordinal)
+                else P.sync[0] = epoch;
             }
             if (P.host_seq) {
                 // (the launch's ordinal as a word of its own, behind the action's plain words: for readers that synchronise the stream)
@@ -939,11 +1107,37 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
 #undef AA_TL
 }
 
-extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
-                                   float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode,
-                                   int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, uint32_t* action_rec,
-                                   const naf_step_prefetch_t* prefetch, int obs_system_scope, void* stream) {
+static int aa_launch(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
+                     float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode,
+                     int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, uint32_t* action_rec,
+                     const naf_step_prefetch_t* prefetch, int obs_system_scope, const naf_bb_layer1_t* l1, void* stream) {
     if (!adam || !net || !obs || !action_out || !counter_dev || !sync || ((uintptr_t)sync & 15) != 0) return NAF_ERR_ARG;
+    L1RideArgs L1;
+    memset(&L1, 0, sizeof(L1));
+    int l1k4 = 0;
+    bool l1full = true;
+    if (l1) {
+        // (the checks of naf_bb_layer1_adam, csrc/big_batch.hip: the same body runs)
+        if (prefetch && prefetch->mode != 0) return NAF_ERR_ARG;      // (the launch without the prefetching workgroup only)
+        if (!l1->x || !l1->W || !l1->bias || !l1->mom || !l1->gamma || !l1->beta || !l1->running_mean || !l1->running_var || !l1->out ||
+            !l1->save_mean || !l1->save_invstd || l1->B < 16 || l1->B > 4096 || l1->H < BB_COLS || (l1->H % BB_COLS) != 0 || l1->nets != 2 ||
+            l1->K <= 0 || l1->K > 4 * BB_MAX_K4 || l1->ldo < l1->H || (l1->ldo & 3))
+            return NAF_ERR_ARG;
+        const int k4 = (l1->K + 3) / 4, k4d = k4 <= 6 ? 6 : 8;
+        if (((uintptr_t)l1->x & 15) != 0 || (l1->ldx & 3) != 0 || l1->ldx < 4 * k4d || (l1->x_net_stride & 3) != 0) return NAF_ERR_ARG;
+        if ((((uintptr_t)l1->bias | (uintptr_t)l1->out | (uintptr_t)l1->mom | (uintptr_t)l1->W) & 15) != 0 || (l1->param_net_stride & 3) != 0 ||
+            (l1->out_net_stride & 3) != 0 || (l1->xhat_out && ((uintptr_t)l1->xhat_out & 15)))
+            return NAF_ERR_ARG;
+        L1.x = l1->x; L1.x_net_stride = l1->x_net_stride; L1.ldx = l1->ldx; L1.K = l1->K; L1.W = l1->W; L1.bias = l1->bias;
+        L1.gamma = l1->gamma; L1.beta = l1->beta; L1.param_net_stride = l1->param_net_stride; L1.mom = l1->mom;
+        L1.running_mean = l1->running_mean; L1.running_var = l1->running_var; L1.stat_net_stride = l1->stat_net_stride; L1.out = l1->out;
+        L1.out_net_stride = l1->out_net_stride; L1.ldo = l1->ldo; L1.save_mean = l1->save_mean; L1.save_invstd = l1->save_invstd;
+        L1.wc_out = l1->wc_out; L1.xhat_out = l1->xhat_out; L1.B = l1->B; L1.H = l1->H; L1.momentum = l1->momentum; L1.eps = l1->eps;
+        L1.n_main = ((l1->B + BB_ROWS - 1) / BB_ROWS) * (l1->H / BB_COLS) * l1->nets;
+        L1.xcd_rows = 1;
+        l1k4 = k4d;
+        l1full = l1->B % BB_ROWS == 0;
+    }
     AdamActArgs P;
     memset(&P, 0, sizeof(P));
     if (!adam_args_from(*adam, P.ad)) return NAF_ERR_ARG;
@@ -1002,11 +1196,19 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
         }
     }
     if (!prefetch || prefetch->mode == 0) {
-#define AA_GO0(PM, GV, HVV) adam_act_kernel<PM, 0, GV, HVV><<<grid, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP)
+#define AA_GO0(PM, GV, HVV, LK, LF) adam_act_kernel<PM, 0, GV, HVV, LK, LF><<<grid + L1.n_main, AA_THREADS, 0, (hipStream_t)stream>>>(P, SP, L1)
+#define AA_GO0_L(PM, GV, HVV)                                 \
+    do {                                                      \
+        if (l1k4 == 0) AA_GO0(PM, GV, HVV, 0, true);          \
+        else if (l1k4 == 6 && l1full) AA_GO0(PM, GV, HVV, 6, true);  \
+        else if (l1k4 == 6) AA_GO0(PM, GV, HVV, 6, false);    \
+        else if (l1full) AA_GO0(PM, GV, HVV, 8, true);        \
+        else AA_GO0(PM, GV, HVV, 8, false);                   \
+    } while (0)
 #define AA_GO0_H(PM, GV)                    \
     do {                                    \
-        if (h512) AA_GO0(PM, GV, 512);      \
-        else AA_GO0(PM, GV, 256);           \
+        if (h512) AA_GO0_L(PM, GV, 512);    \
+        else AA_GO0_L(PM, GV, 256);         \
     } while (0)
         if (p_mode == NAF_P_HADAMARD) {
             if (wide) AA_GO0_H(NAF_P_HADAMARD, 16);
@@ -1016,6 +1218,7 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
             else AA_GO0_H(NAF_P_MATMUL, 8);
         }
 #undef AA_GO0_H
+#undef AA_GO0_L
 #undef AA_GO0
         NAF_CHECK_LAUNCH();
         return NAF_OK;
@@ -1060,7 +1263,7 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
     }
     const int spec = (k4 <= 6 ? 1 : 3) + (sp_cached(prefetch->B, prefetch->out_ld) ? 0 : 1);
     const hipStream_t st = (hipStream_t)stream;
-#define AA_LAUNCH(PM, SV, GV, HVV) adam_act_kernel<PM, SV, GV, HVV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP)
+#define AA_LAUNCH(PM, SV, GV, HVV) adam_act_kernel<PM, SV, GV, HVV><<<grid + 1, SP_THREADS, lds, st>>>(P, SP, L1)
 #define AA_LAUNCH_SV(PM, SV)                              \
     do {                                                  \
         if (wide && h512) AA_LAUNCH(PM, SV, 16, 512);     \
@@ -1081,6 +1284,23 @@ extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_ne
 #undef AA_LAUNCH
     NAF_CHECK_LAUNCH();
     return NAF_OK;
+}
+
+extern "C" int naf_adam_polyak_act(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
+                                   float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode,
+                                   int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, uint32_t* action_rec,
+                                   const naf_step_prefetch_t* prefetch, int obs_system_scope, void* stream) {
+    return aa_launch(adam, net, obs, heads_out, action_out, seed, counter_dev, noise_scale, p_mode, sync, host_errors, host_seq, action_rec,
+                     prefetch, obs_system_scope, nullptr, stream);
+}
+extern "C" int naf_adam_polyak_act_layer1(const naf_adam_args_t* adam, const naf_act_net_t* net, const float* obs, float* heads_out,
+                                          float* action_out, uint64_t seed, uint64_t* counter_dev, float noise_scale, int p_mode,
+                                          int32_t* sync, uint64_t* host_errors, uint32_t* host_seq, uint32_t* action_rec,
+                                          const naf_step_prefetch_t* prefetch, int obs_system_scope, const naf_bb_layer1_t* layer1,
+                                          void* stream) {
+    if (!layer1) return NAF_ERR_ARG;
+    return aa_launch(adam, net, obs, heads_out, action_out, seed, counter_dev, noise_scale, p_mode, sync, host_errors, host_seq, action_rec,
+                     prefetch, obs_system_scope, layer1, stream);
 }
 
 // ---- the prefetch as a launch of its own ------------------------------------------------------------------------------------------
@@ -1142,4 +1362,4 @@ extern "C" int naf_step_launch(void* dst_device, const void* src_host, size_t by
     return prefetch ? spf_launch(prefetch, (hipStream_t)side_stream) : NAF_OK;
 }
 
-extern "C" int naf_adam_polyak_act_sync_ints(void) { return 16 + 4 * 2 * AA_H; }     // (room for the 512-wide launch's records)
+extern "C" int naf_adam_polyak_act_sync_ints(void) { return AA_SYNC_RIDE + 128; }     // (the 512-wide launch's records, the riders' words)

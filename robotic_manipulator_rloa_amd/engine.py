@@ -533,6 +533,8 @@ class _Pipeline:
         self.graph_fast: List[Optional[torch.cuda.CUDAGraph]] = [None, None, None]
         self._exec = self._exec_fast = None
         r._side_join = self.join                   # (ReplayBuffer's own launches read what the side stream writes)
+        self.l1_ride = os.environ.get("NAF_STEP_L1_RIDE", "1") != "0"      # (tests / A-B only: layer 1 as a launch of its own)
+        self._l1_args = [None, None, None]
 
     def state(self) -> tuple:
         """device tensors a warm-up run changes"""
@@ -576,12 +578,13 @@ class _Pipeline:
         self._pf_side = [pf((p + 2) % 3, 2, 2, src_row=rowp, n_word=rowp + 4 * rf, idx_out=ptr(tg.idx),
                             spec_rec_in=self.spec_rec[p].data_ptr(), idx_spec_in=self.idx_spec[p].data_ptr()) for p in range(3)]
 
-    def _chain(self, k: int) -> None:
-        """learn() on set k with the learner's working state; the optimizer step is left to the next graph's first launch"""
+    def _chain(self, k: int, l1_done: bool = False) -> None:
+        """learn() on set k with the learner's working state; the optimizer step is left to the next graph's first launch.
+        l1_done: the chain's first launch (layer 1) rode on the launch in front (body_fast)."""
         L = self.tg.L
         L.bn_live, L.step_live = self.bn_work, self.step_work
         try:
-            L.learn_rows(self.batches[k], self.loss_work, self.moments[k], pending=False, defer=True)
+            L.learn_rows(self.batches[k], self.loss_work, self.moments[k], pending=False, defer=True, l1_done=l1_done)
         finally:
             L.bn_live, L.step_live = L.bn_stats, L.step_dev
 
@@ -589,9 +592,19 @@ class _Pipeline:
         """phase p, the prefetches held: apply the waiting gradient + act() + commit in ONE launch, then the chain for the next
         update (six launches; the host waits for the first)"""
         tg = self.tg
+        k = (p + 1) % 3
+        # (round 6: layer 1 of the chain rides on the first launch — extra workgroups behind its optimizer step — so the chain proper
+        #  starts at GEMM 2 without waiting for the act() tail or a launch boundary; NAF_STEP_L1_RIDE=0: as a launch of its own)
+        l1 = None
+        if self.l1_ride:
+            tg.L.bn_live = self.bn_work
+            try:
+                l1 = self._l1_args[k] = tg.L.layer1_args(self.batches[k], self.moments[k])      # (kept alive: the capture reads it now)
+            finally:
+                tg.L.bn_live = tg.L.bn_stats
         tg._tail_actor.act_with_optimizer_step(obs_ptr=tg.head_dev.ptr + 4 * tg.L.lay.off_s2, prefetch=self._pf_commit,
-                                               obs_system_scope=True, adam_args=self._adam_work, net=self._net_work)
-        self._chain((p + 1) % 3)
+                                               obs_system_scope=True, adam_args=self._adam_work, net=self._net_work, layer1=l1)
+        self._chain(k, l1_done=l1 is not None)
 
     def body_slow(self) -> None:
         """they did not (or nothing was prefetched): reset the working state, draw, chain — and from there as the other graph"""

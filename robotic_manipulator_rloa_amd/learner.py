@@ -680,8 +680,20 @@ class Learner:
         check(self._f.naf_bb_moments(rows.data_ptr(), self.B * ld, lay.off_s2, ld, lay.S, ptr(out), self.B, int(n_batches), 2,
                                      stream_ptr()), "bb_moments")
 
+    def layer1_args(self, rows: torch.Tensor, moments: torch.Tensor) -> "_lib.BbLayer1":
+        """The arguments of the row-split chain's first launch (layer 1 of both networks from the minibatch's moments record) as a
+        structure: naf_adam_polyak_act_layer1 runs that launch's body in extra workgroups of the per-timestep path's first launch
+        (csrc/step_path.hip), and learn_rows(..., l1_done=True) then starts the chain at GEMM 2. Reads the working BatchNorm
+        statistics (bn_live) as they are set when it is called."""
+        lay, H, P = self.lay, self.lay.H, self.lay.P
+        seg, t2p, bnp = lay.seg, self.theta2.data_ptr(), self.bn_live.data_ptr()
+        return _lib.BbLayer1(rows.data_ptr(), lay.off_s2, rows.stride(0), lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                             t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
+                             ptr(self.A1), self.Bp * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc),
+                             ptr(self.XH1), self.B, H, 2, BN_MOMENTUM, BN_EPS)
+
     def forward_train(self, rows: torch.Tensor, heads_gemm: bool = True, moments: Optional[torch.Tensor] = None,
-                      adam_pending: bool = False) -> None:
+                      adam_pending: bool = False, l1_done: bool = False) -> None:
         """Both networks' training-mode forward up to the second hidden activation A2 (and, with heads_gemm, the
         heads pre-activations Gh). Main net sees `state`, target net sees `next_state` (naf_algorithm.py:194-202);
         both use batch statistics and both update their running statistics (the reference never calls .eval() on the
@@ -704,11 +716,16 @@ class Learner:
             # the first step everything behind the layer-1 segment while its own workgroups evaluate the layer-1
             # parameters as the step will leave them, extra workgroups of the second step the layer-1 segment)
             adam = _lib.C.byref(self._adam_args) if adam_pending else None
-            check(self._f.naf_bb_layer1_adam(
-                rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
-                t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
-                ptr(self.A1), self.Bp * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), ptr(self.XH1), B, H, 2,
-                BN_MOMENTUM, BN_EPS, adam, st), "bb_layer1")
+            if l1_done:
+                # (layer 1 of this minibatch rode on the per-timestep path's first launch, naf_adam_polyak_act_layer1: layer1_args)
+                if adam_pending:
+                    raise ValueError("forward_train: l1_done with a pending optimizer step (that step rides on layer 1's launch)")
+            else:
+                check(self._f.naf_bb_layer1_adam(
+                    rows.data_ptr(), lay.off_s2, ld, lay.S, t2p + 4 * seg["W1"].offset, t2p + 4 * seg["b1"].offset,
+                    t2p + 4 * seg["g1"].offset, t2p + 4 * seg["be1"].offset, P, ptr(moments), bnp, bnp + 4 * H, 4 * H,
+                    ptr(self.A1), self.Bp * H, H, ptr(self.save_mean[0]), ptr(self.save_invstd[0]), ptr(self.bb_wc), ptr(self.XH1), B, H,
+                    2, BN_MOMENTUM, BN_EPS, adam, st), "bb_layer1")
             # GEMM 2 of both nets on f32 MFMA, bias added, statistics partials from the epilogue
             check(self._f.naf_bb_linear_stats_adam(ptr(self.A1), self.Bp * H, H, t2p + 4 * seg["W2"].offset,
                                                    t2p + 4 * seg["b2"].offset, P, ptr(self.G2), self.Bp * H, H, ptr(self.bb_st2), B, H,
@@ -744,7 +761,7 @@ class Learner:
             torch.bmm(self.A2, self.WhT2, out=self.Gh)
 
     def learn_rows(self, rows: torch.Tensor, loss_partials: Optional[torch.Tensor] = None,
-                   moments: Optional[torch.Tensor] = None, pending: bool = False, defer: bool = False) -> None:
+                   moments: Optional[torch.Tensor] = None, pending: bool = False, defer: bool = False, l1_done: bool = False) -> None:
         """Enqueue one full NAFAgent.learn() (naf_algorithm.py:180-215) + soft_update (:217-226) on the minibatch
         `rows` [B, ld] in the transition-row layout, ld = rows.stride(0) >= lay.batch_row_floats (actions already
         truncated by the gather if the reference's `.long()` is mimicked).
@@ -754,7 +771,9 @@ class Learner:
         defer / pending (only where self.defer_ok; a chain of updates, engine.TrainChunk): defer = leave this update's
         optimizer step (clip + Adam + Polyak) to the NEXT learn_rows call, which must then say pending = True and whose
         first two launches carry it — one launch less per update. Between the two calls the parameter buffers still hold
-        the values from before this update; the chain ends with a call that does not defer."""
+        the values from before this update; the chain ends with a call that does not defer.
+        l1_done (row-split chain): layer 1 of this minibatch has run already — in the extra workgroups of the per-timestep path's
+        first launch (layer1_args, naf_adam_polyak_act_layer1) — and the chain starts at GEMM 2."""
         self._gen += 1
         if (pending or defer) and not self.defer_ok:
             raise ValueError("learn_rows: a deferred optimizer step needs the row-split chain with the gradient norm left by the "
@@ -769,8 +788,10 @@ class Learner:
         if rows.shape[0] != B or rows.stride(1) != 1 or ld < lay.batch_row_floats or ld % 4 or rp % 16:
             raise ValueError(f"learn_rows: need [B={B}, >={lay.batch_row_floats}] f32 rows, 16-B aligned, row stride % 4 == 0")
         lp = ptr(loss_partials) if loss_partials is not None else None
+        if l1_done and ("bb" not in self.fuse or pending or moments is None):
+            raise ValueError("learn_rows: l1_done needs the row-split chain, the minibatch's moments and no pending optimizer step")
         if "bb" in self.fuse:
-            self._learn_rows_split(rows, lp, moments, pending)
+            self._learn_rows_split(rows, lp, moments, pending, l1_done)
         else:
             self._learn_rows_tiles(rows, lp)
         if self.world_size > 1 or self._force_allreduce:
@@ -795,7 +816,7 @@ class Learner:
             return                       # the next learn_rows(pending=True) carries the step
         self.optimizer_step(norm_ready=self.fold_norm)
 
-    def _learn_rows_split(self, rows: torch.Tensor, lp, moments, pending: bool) -> None:
+    def _learn_rows_split(self, rows: torch.Tensor, lp, moments, pending: bool, l1_done: bool = False) -> None:
         """The row-split chain (csrc/big_batch.hip + gemm_bundle.hip): layer 1 | GEMM 2 | layer 2 + heads + head + first
         backward stage | backward GEMM bundle with its prologue and epilogue | finish."""
         lay, B, st = self.lay, self.B, stream_ptr()
@@ -804,7 +825,7 @@ class Learner:
         t2p, gp, bnp = self.theta2.data_ptr(), self.grad.data_ptr(), self.bn_live.data_ptr()
         rp, ld = rows.data_ptr(), rows.stride(0)
         self._pushed_lo = self._pushed_also = None
-        self.forward_train(rows, moments=moments, adam_pending=pending)
+        self.forward_train(rows, moments=moments, adam_pending=pending, l1_done=l1_done)
         # BN2 + ReLU + heads (MFMA) + NAF head + dA2 (MFMA) + ReLU mask + backward block sums: one launch
         check(f.naf_bb_layer2_head(
             ptr(self.G2), self.Bp * H, H, t2p + 4 * seg["g2"].offset, t2p + 4 * seg["be2"].offset, P, ptr(self.bb_st2),
@@ -998,14 +1019,24 @@ class ActPath:
                                     bnp, bnp + 4 * H, bnp + 8 * H, bnp + 12 * H, BN_EPS)
 
     def act_with_optimizer_step(self, noise_scale: float = 1.0, obs_ptr: Optional[int] = None, prefetch=None,
-                                obs_system_scope: bool = False, adam_args=None, net=None) -> torch.Tensor:
+                                obs_system_scope: bool = False, adam_args=None, net=None, layer1=None) -> torch.Tensor:
         """The pending optimizer step of the learner (a learn_rows(defer=True) in front) and act() on the parameters it leaves, in
         one launch. Same parameters as Learner.optimizer_step() and the same action as act() behind it, bit for bit.
         obs_ptr: where the observation lies instead of self.obs (device-visible, S floats). prefetch: a _lib.StepPrefetch — one
         more workgroup of the launch draws the NEXT timestep's minibatch (engine.TrainChunk). obs_system_scope: the observation
         lies in device memory the host stores into. adam_args / net: the structures to pass instead of the learner's / this path's
-        own (the pipelined chunk's: optimizer step count and BatchNorm statistics of its working state)."""
+        own (the pipelined chunk's: optimizer step count and BatchNorm statistics of its working state). layer1: a _lib.BbLayer1
+        (Learner.layer1_args) — layer 1 of the NEXT update's chain rides on the launch (naf_adam_polyak_act_layer1); the caller then
+        runs that chain with learn_rows(..., l1_done=True)."""
         L = self.L
+        if layer1 is not None:
+            check(L.lib.naf_adam_polyak_act_layer1(
+                _lib.C.byref(adam_args if adam_args is not None else L._adam_args), _lib.C.byref(net if net is not None else self._net),
+                obs_ptr or ptr(self.obs), ptr(self.Gh), ptr(self.actions), self.seed, ptr(self.counter), float(noise_scale), L.p_mode,
+                ptr(self.sync), L.err_host.data_ptr() + 8, ptr(self.seq), ptr(self.act_rec),
+                _lib.C.byref(prefetch) if prefetch is not None else None, int(bool(obs_system_scope)), _lib.C.byref(layer1),
+                stream_ptr()), "adam_polyak_act_layer1")
+            return self.actions
         check(L.lib.naf_adam_polyak_act(_lib.C.byref(adam_args if adam_args is not None else L._adam_args),
                                         _lib.C.byref(net if net is not None else self._net), obs_ptr or ptr(self.obs), ptr(self.Gh),
                                         ptr(self.actions), self.seed, ptr(self.counter), float(noise_scale), L.p_mode,

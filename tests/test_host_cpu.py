@@ -723,7 +723,8 @@ def test_no_kernel_spills_to_scratch_and_the_switch_list_is_short():
                 src = open(os.path.join(dirpath, f)).read()
                 names |= set(re.findall(r'(?:environ\.get\(|getenv\(|environ\[|NAF_ENV_INT\()\s*["\'](NAF_[A-Z0-9_]+)["\']', src))
     documented = {"NAF_FUSE", "NAF_DEFER_ADAM", "NAF_XGMI", "NAF_XGMI_FREE_SLAB", "NAF_BLAS_DEFAULT", "NAF_BLAS_TUNING_FILE",
-                  "NAF_BUILD_DEFINES", "NAF_LOG_FILE", "NAF_DP_SHARE_GPU", "NAF_DP_EXCHANGE", "NAF_STEP_FORM", "NAF_HOST_STORE"}
+                  "NAF_BUILD_DEFINES", "NAF_LOG_FILE", "NAF_DP_SHARE_GPU", "NAF_DP_EXCHANGE", "NAF_STEP_FORM", "NAF_HOST_STORE",
+                  "NAF_STEP_L1_RIDE"}
     assert names <= documented, names - documented
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     for n in names:

@@ -686,23 +686,25 @@ def test_free_running_soak_200k_timesteps_equals_the_twelve_launch_loop(scratch_
     assert fast + slow in (T - B - 1, T - B) and fast > 0.98 * (T - B), (fast, slow)    # (2 B / N = 0.6 % of the prefetches void)
 
 
-def test_per_timestep_path_is_six_or_seven_launches(scratch_cwd, monkeypatch):
+def test_per_timestep_path_is_five_to_seven_launches(scratch_cwd, monkeypatch):
     """The update graph of NAFAgent.step() at num_updates = 1 (profiles/r06_api_path_kernel_stats.csv has the same counts from
-    rocprofv3). Pipelined (default): naf_adam_polyak_act — the waiting gradient's optimizer step, act(), the commit — + the five
-    launches of the row-split chain on a minibatch prefetched two timesteps ago: six launches in the graph, and naf_step_prefetch
+    rocprofv3). Pipelined (default): naf_adam_polyak_act_layer1 — the waiting gradient's optimizer step, act(), the commit, AND layer 1
+    of the chain in extra workgroups behind the step — + the other four launches of the row-split chain on a minibatch prefetched two
+    timesteps ago: five launches in the graph (six with NAF_STEP_L1_RIDE=0: layer 1 as a launch of its own), and naf_step_prefetch
     (the append + the prefetch of the minibatch two timesteps ahead) beside it on a stream of its own. The graph that starts a
     timestep over is naf_step_prep + chain + naf_adam_polyak_act (with the depth-1 prefetch) + naf_step_prefetch (depth 2) + chain. NAF_STEP_FORM=prefetch: naf_step_prep + the chain + naf_adam_polyak_act."""
     from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
     chain = ["naf_bb_layer1_adam", "naf_bb_linear_stats_adam", "naf_bb_layer2_head", "naf_gemm_bundle", "naf_bb_layer1_bwd_finish"]
-    names = ["naf_step_prep", "naf_adam_polyak_act", "naf_step_prefetch"] + chain + [
+    names = ["naf_step_prep", "naf_adam_polyak_act", "naf_adam_polyak_act_layer1", "naf_step_prefetch"] + chain + [
         "naf_replay_add_counted", "naf_replay_sample_indices", "naf_counter_add", "naf_replay_gather_rows", "naf_bb_moments",
         "naf_adam_polyak_fused", "naf_policy_act", "naf_grad_norm_partials"]
-    for pipeline in ("1", "0"):
-        monkeypatch.setenv("NAF_STEP_FORM", "pipelined" if pipeline == "1" else "prefetch")
+    for pipeline in ("1", "1-no-ride", "0"):
+        monkeypatch.setenv("NAF_STEP_FORM", "pipelined" if pipeline != "0" else "prefetch")
+        monkeypatch.setenv("NAF_STEP_L1_RIDE", "0" if pipeline == "1-no-ride" else "1")
         agent = NAFAgent(object(), 21, 6, 256, 64, 1000, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
         _drive(agent, 3, 65, 5, None)
         ch = agent._chunk
-        assert ch.fused_prep and ch.fused_tail and ch.graph is not None and ch.pipelined == (pipeline == "1")
+        assert ch.fused_prep and ch.fused_tail and ch.graph is not None and ch.pipelined == (pipeline != "0")
         calls = []
         lib = agent.learner.lib
 
@@ -724,12 +726,12 @@ def test_per_timestep_path_is_six_or_seven_launches(scratch_cwd, monkeypatch):
         torch.cuda.synchronize()
         ch._body()                                             # one eager pass through exactly what the (slower) graph holds
         torch.cuda.synchronize()
-        if pipeline == "1":
+        if pipeline != "0":
             assert calls == ["naf_step_prep"] + chain + ["naf_adam_polyak_act", "naf_step_prefetch"] + chain, calls
             del calls[:]
             ch.pipe.body_fast(1)                               # (the graph of a timestep in phase 1: what _body() leaves)
             torch.cuda.synchronize()
-            assert calls == ["naf_adam_polyak_act"] + chain, calls
+            assert calls == (["naf_adam_polyak_act_layer1"] + chain[1:] if pipeline == "1" else ["naf_adam_polyak_act"] + chain), calls
             agent.learner.err_host[2] = 0                      # (an eager pass outside the host's bookkeeping may have counted a mismatch)
         else:
             assert calls == ["naf_step_prep"] + chain + ["naf_adam_polyak_act"], calls
