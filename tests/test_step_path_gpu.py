@@ -193,6 +193,64 @@ def test_adam_polyak_act_equals_the_two_launches_it_replaces(lib, S, A, H, p_mod
     assert not torch.equal(La.theta2[0], _two_learners(S, A, 64, seed=3, H=H)[0].theta2[0])
 
 
+@pytest.mark.parametrize("p_mode", [0, 1])
+@pytest.mark.parametrize("S,A,H,B", [(21, 6, 256, 64), (21, 6, 256, 256), (23, 7, 256, 100), (27, 9, 256, 64), (21, 6, 512, 256),
+                                     (31, 11, 384, 1000), (32, 8, 256, 2048)])
+def test_adam_polyak_act_layer1_equals_the_three_launches_it_replaces(lib, S, A, H, B, p_mode):
+    """naf_adam_polyak_act_layer1 (end of round 6: layer 1 of the next update's chain riding on the per-timestep path's first launch, in
+    workgroups that evaluate the layer-1 parameters as the launch's own step will leave them) == naf_adam_polyak_fused +
+    naf_policy_act + naf_bb_layer1_adam as launches of their own: parameters, optimizer state, target, the action, and everything
+    layer 1 leaves — A1 of both networks, x-hat, the saved statistics, w_c C, the running statistics — bit for bit, three launches
+    in a row; whole and partial 64-row blocks, both state widths (K4 = 6 | 8), 9 / 11 joints, layer sizes 512 / 384."""
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.learner import ActPath, BN_EPS, BN_MOMENTUM
+    La, Lb = _two_learners(S, A, B, seed=5, H=H)
+    La.p_mode = Lb.p_mode = p_mode
+    acts = [ActPath(La, 1, seed=7, host_io=True), ActPath(Lb, 1, seed=7, host_io=True)]
+    assert acts[1].can_ride
+    g = torch.Generator(device="cuda").manual_seed(11)
+    brf = La.lay.batch_row_floats
+    rng = np.random.default_rng(1)
+    for rep in range(3):
+        rows = torch.randn(B + 1, brf, generator=g, device="cuda")[:B]
+        obs = rng.standard_normal(S).astype(np.float32)
+        outs = []
+        for which, (L, act) in enumerate(zip((La, Lb), acts)):
+            _lib.check(lib.naf_grad_norm_partials(L.grad.data_ptr(), L.lay.P, L.partials.data_ptr(), L.step_dev.data_ptr(), st()), "norm")
+            L._adam_args.n_partials = L.n_partials_norm
+            mom = torch.zeros(2, L.mom_floats, device="cuda")
+            L.moments(rows, mom)
+            act.obs_np[0] = obs
+            l1 = L.layer1_args(rows, mom)
+            if which == 0:
+                _lib.check(lib.naf_adam_polyak_fused(
+                    L.theta2[0].data_ptr(), L.grad.data_ptr(), L.adam_m.data_ptr(), L.adam_v.data_ptr(), L.theta2[1].data_ptr(),
+                    L.partials.data_ptr(), L.n_partials_norm, 1.0, L.lr, 0.9, 0.999, 1e-8, L.tau, float(1.0 - L.tau),
+                    L.step_dev.data_ptr(), 1.0, L.lay.P, st()), "adam")
+                act.act(1.0)
+                _lib.check(lib.naf_bb_layer1_adam(l1.x, l1.x_net_stride, l1.ldx, l1.K, l1.W, l1.bias, l1.gamma, l1.beta, l1.param_net_stride,
+                                                  l1.mom, l1.running_mean, l1.running_var, l1.stat_net_stride, l1.out, l1.out_net_stride,
+                                                  l1.ldo, l1.save_mean, l1.save_invstd, l1.wc_out, l1.xhat_out, l1.B, l1.H, 2, BN_MOMENTUM,
+                                                  BN_EPS, None, st()), "layer1")
+            else:
+                act.act_with_optimizer_step(1.0, layer1=l1)
+            torch.cuda.synchronize()
+            assert act.act_timeouts == 0
+            outs.append(dict(theta=L.theta2.clone(), m=L.adam_m.clone(), v=L.adam_v.clone(), A1=L.A1[:, :B].clone(),
+                             xh=None if L.XH1 is None else L.XH1[:B].clone(), sm=L.save_mean[0].clone(), si=L.save_invstd[0].clone(),
+                             wc=L.bb_wc.clone(), bn=L.bn_stats.clone(), act=act.actions_np.copy(), gh=act.Gh[0, :L.lay.NH].clone()))
+        a, b = outs
+        for k in a:
+            if a[k] is None:
+                continue
+            if isinstance(a[k], np.ndarray):
+                np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} (launch {rep})")
+            else:
+                assert torch.equal(a[k], b[k]), (k, rep)
+        for L in (La, Lb):
+            L.grad.mul_(-0.7)
+
+
 def test_adam_polyak_act_skips_a_poisoned_update_and_still_acts(lib):
     """A -inf norm partial (a timed-out gradient exchange under data parallel, csrc/xgmi_reduce.hip) makes the optimizer leave
     every buffer alone; the action is then the policy's on the OLD parameters — as naf_adam_polyak_fused + naf_policy_act."""
