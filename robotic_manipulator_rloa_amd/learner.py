@@ -1033,7 +1033,10 @@ class ActPath:
             check(L.lib.naf_adam_polyak_act_layer1(
                 _lib.C.byref(adam_args if adam_args is not None else L._adam_args), _lib.C.byref(net if net is not None else self._net),
                 obs_ptr or ptr(self.obs), ptr(self.Gh), ptr(self.actions), self.seed, ptr(self.counter), float(noise_scale), L.p_mode,
-                ptr(self.sync), L.err_host.data_ptr() + 8, ptr(self.seq), ptr(self.act_rec),
+                # (no `host_seq` word here: the pipelined timestep's host takes the action from the self-validating chunks of act_rec
+                #  alone, and the launch's last workgroup would wait a microsecond for the action's stores to cross PCIe before it
+                #  stores that word — at the very end of the kernel the chain is queued behind)
+                ptr(self.sync), L.err_host.data_ptr() + 8, None, ptr(self.act_rec),
                 _lib.C.byref(prefetch) if prefetch is not None else None, int(bool(obs_system_scope)), _lib.C.byref(layer1),
                 stream_ptr()), "adam_polyak_act_layer1")
             return self.actions
