@@ -523,11 +523,13 @@ def extras(dev, args):
             out = {"value": round(n_api / dt, 1), "unit": "timesteps/s", "timesteps": n_api, "batch": batch, "ring": "1e5 rows, full",
                    "launches_per_timestep": launches, "optimizer_steps": int(agent.learner.step_dev.item())}
             if ch is not None and getattr(ch, "pipelined", False):
-                # the pipelined form: naf_adam_polyak_act (the waiting gradient's step, act(), commit) + the chain on a minibatch
-                # prefetched two timesteps ago = 6 launches in the graph, and the append + depth-2 prefetch as ONE launch beside
-                # the graph on a stream of its own; a timestep whose prefetches did not hold starts over with the 13-launch graph
+                # the pipelined form: naf_adam_polyak_act_layer1 (the waiting gradient's step, act(), commit, and layer 1 of the chain in
+                # extra workgroups) + the other four launches of the chain on a minibatch prefetched two timesteps ago = 5 launches
+                # in the graph (6 with NAF_STEP_L1_RIDE=0), and the append + depth-2 prefetch as ONE launch beside the graph on a
+                # stream of its own; a timestep whose prefetches did not hold starts over with the 13-launch graph
                 runs = max(1, ch.fast_runs + ch.slow_runs)
-                out["launches_per_timestep"] = round((6 * ch.fast_runs + 13 * ch.slow_runs) / runs, 2)
+                in_graph = 5 if getattr(ch.pipe, "l1_ride", False) else 6
+                out["launches_per_timestep"] = round((in_graph * ch.fast_runs + 13 * ch.slow_runs) / runs, 2)
                 out["launches_beside_the_graph_per_timestep"] = round(ch.fast_runs / runs, 2)
                 out["pipelined"] = {"timesteps_on_the_prefetched_minibatch": ch.fast_runs, "timesteps_that_started_over": ch.slow_runs}
             if ch is not None and hasattr(ch, "error_words"):
