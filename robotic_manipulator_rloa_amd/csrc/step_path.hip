@@ -578,9 +578,15 @@ struct AdamActArgs {
 // Layer 1 of the NEXT update's chain riding on this launch (round 6; naf_adam_polyak_act_layer1): the arguments of bb_layer1_kernel
 // (csrc/big_batch.hip, csrc/layer1_body.h). The chain's first launch needs the parameters this launch's optimizer step leaves and
 // nothing else of it — as a launch of its own behind adam_act it also waited for the act() tail (heads, noise, the action: 4 of the
-// launch's 7.6 us) and for a launch boundary. Here n_main extra workgroups run its body once the layer-1 workgroups have stepped
-// their slices (their arrivals) and the last workgroup has committed the working BatchNorm statistics they advance; the last
-// workgroup holds the launch's ordinal back until they are done (three words of `sync` behind the records, a line each).
+// launch's 7.6 us) and for a launch boundary. Here n_main extra workgroups run its body IN ITS ADAM FORM: they evaluate the layer-1
+// parameters they read as this launch's step will leave them (the form the chunked chain runs when the previous update's step rides
+// on layer 1: the same bits the layer-1 workgroups of this launch write), so they start with the launch and wait for nothing it
+// computes. Two orderings, both off the critical path: the launch's layer-1 workgroups store their stepped slices only once every
+// rider has consumed the old values (`l1_loaded`), and the riders' statistics lanes overwrite the running statistics only once this
+// launch's readers of them — the layer-1 workgroups, the commit — are through (`l1_arrived`, `l1_commit`); the last party out
+// (`l1_done`) clears the words and moves the launch's ordinal. Four words of `sync` behind the records, a cache line each.
+// (Riders BEHIND the step — a flag, then the stand-alone form — were built first and gained a third of this: a flag between XCDs is
+// 1.5 - 2 us under this launch's traffic; NOTEBOOK section 11.16.)
 struct L1RideArgs {
     const float* x;
     int64_t x_net_stride;
@@ -720,8 +726,9 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
 // HV (round 6): the layer size — 256, or 512 (widths in (256, 512] are stored as 512): 16 layer-1 and 64 layer-2 workgroups, a row of
 // W2 / Wh as TWO float4 per lane (inputs 4 l .. 4 l + 3 and 256 + 4 l .. 256 + 4 l + 3, one fmaf chain through both: act_dot4 ->
 // act_dot4_acc, as policy_act_512_kernel), 512 + 512 records.
-// L1K4 (round 6): 6 | 8 = the next update's layer 1 rides on this launch (L1RideArgs; K4 = 6 | 8 float4 of state, L1FULL: whole 64-row
-// blocks): L1.n_main more workgroups behind the last one. 0: no riders, the kernel as it was.
+// L1K4 (round 6): 6 | 8 = the next update's layer 1 rides on this launch (L1RideArgs above; K4 = 6 | 8 float4 of state, L1FULL: whole
+// 64-row blocks): L1.n_main more workgroups behind the last one, 512 threads each (bb_layer1_impl<.., ADAM = true, ..>). 0: no riders,
+// the kernel as it was.
 template <int PMODE, int SPEC, int G = 8, int HV = AA_H, int L1K4 = 0, bool L1FULL = true>
 __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP, const L1RideArgs L1) {
     static_assert(L1K4 == 0 || SPEC == 0, "layer 1 rides on the launch without the prefetching workgroup");
