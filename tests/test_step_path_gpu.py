@@ -271,6 +271,44 @@ def test_adam_polyak_act_skips_a_poisoned_update_and_still_acts(lib):
     np.testing.assert_array_equal(acts[0].actions_np, acts[1].actions_np)
 
 
+def test_adam_polyak_act_layer1_skips_a_poisoned_update_like_the_launches_it_replaces(lib):
+    """The same with layer 1 riding (naf_adam_polyak_act_layer1): a -inf norm partial leaves every parameter alone in the launch's
+    own workgroups AND in the riders' evaluation of the layer-1 parameters — A1, the statistics and the action are those of the
+    separate launches on the OLD parameters."""
+    from robotic_manipulator_rloa_amd import _lib
+    from robotic_manipulator_rloa_amd.learner import ActPath, BN_EPS, BN_MOMENTUM
+    B = 128
+    La, Lb = _two_learners(21, 6, B, seed=4)
+    before = La.theta2.clone()
+    acts = [ActPath(La, 1, seed=5, host_io=True), ActPath(Lb, 1, seed=5, host_io=True)]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rows = torch.randn(B + 1, La.lay.batch_row_floats, generator=g, device="cuda")[:B]
+    obs = np.linspace(-1, 1, 21).astype(np.float32)
+    outs = []
+    for which, (L, act) in enumerate(zip((La, Lb), acts)):
+        L.partials.fill_(1.0)
+        L.partials[3] = float("-inf")
+        mom = torch.zeros(2, L.mom_floats, device="cuda")
+        L.moments(rows, mom)
+        act.obs_np[0] = obs
+        l1 = L.layer1_args(rows, mom)
+        if which == 0:
+            L.optimizer_step(norm_ready=True)
+            act.act(1.0)
+            _lib.check(lib.naf_bb_layer1_adam(l1.x, l1.x_net_stride, l1.ldx, l1.K, l1.W, l1.bias, l1.gamma, l1.beta, l1.param_net_stride,
+                                              l1.mom, l1.running_mean, l1.running_var, l1.stat_net_stride, l1.out, l1.out_net_stride,
+                                              l1.ldo, l1.save_mean, l1.save_invstd, l1.wc_out, l1.xhat_out, l1.B, l1.H, 2, BN_MOMENTUM,
+                                              BN_EPS, None, st()), "layer1")
+        else:
+            act.act_with_optimizer_step(1.0, layer1=l1)
+        torch.cuda.synchronize()
+        outs.append((L.theta2.clone(), L.adam_m.clone(), L.A1[:, :B].clone(), L.bn_stats.clone(), L.save_invstd[0].clone(), act.actions_np.copy()))
+    assert torch.equal(outs[0][0], before) and torch.equal(outs[1][0], before)
+    for x, y in zip(outs[0][:-1], outs[1][:-1]):
+        assert torch.equal(x, y)
+    np.testing.assert_array_equal(outs[0][-1], outs[1][-1])
+
+
 PREFETCH_CASES = [
     # S, A, B, capacity, rows in the ring, counts of the timesteps (1 = brings a row, 0 = an idle tick)
     (21, 6, 64, 100000, 50000, (1, 1, 1, 1, 1, 1)),         # the steady state: the new row is hardly ever drawn
