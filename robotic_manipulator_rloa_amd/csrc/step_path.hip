@@ -1135,6 +1135,16 @@ static int aa_launch(const naf_adam_args_t* adam, const naf_act_net_t* net, cons
         if ((((uintptr_t)l1->bias | (uintptr_t)l1->out | (uintptr_t)l1->mom | (uintptr_t)l1->W) & 15) != 0 || (l1->param_net_stride & 3) != 0 ||
             (l1->out_net_stride & 3) != 0 || (l1->xhat_out && ((uintptr_t)l1->xhat_out & 15)))
             return NAF_ERR_ARG;
+        {
+            // (the riders evaluate these parameters through the pending step: they must be the main network's, inside the flat buffer
+            //  this launch steps, the target's param_net_stride floats behind — what naf_bb_layer1_adam asks of a riding step)
+            const float* lo = adam->theta;
+            const float* hi = adam->theta + adam->n;
+            if ((((uintptr_t)l1->gamma | (uintptr_t)l1->beta) & 15) != 0) return NAF_ERR_ARG;
+            if (l1->W < lo || l1->W + (int64_t)l1->H * l1->K > hi || l1->bias < lo || l1->bias + l1->H > hi || l1->gamma < lo ||
+                l1->gamma + l1->H > hi || l1->beta < lo || l1->beta + l1->H > hi || adam->theta_target != adam->theta + l1->param_net_stride)
+                return NAF_ERR_ARG;
+        }
         L1.x = l1->x; L1.x_net_stride = l1->x_net_stride; L1.ldx = l1->ldx; L1.K = l1->K; L1.W = l1->W; L1.bias = l1->bias;
         L1.gamma = l1->gamma; L1.beta = l1->beta; L1.param_net_stride = l1->param_net_stride; L1.mom = l1->mom;
         L1.running_mean = l1->running_mean; L1.running_var = l1->running_var; L1.stat_net_stride = l1->stat_net_stride; L1.out = l1->out;
