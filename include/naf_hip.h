@@ -67,7 +67,7 @@ typedef struct {
 /* ---- library ------------------------------------------------------------------------------ */
 /* Bumped whenever a signature or a struct in this header changes; the ctypes host compares the library's answer with
  * the value in this header and refuses a mismatch (a stale .so would otherwise be called with wrong argument lists). */
-#define NAF_HIP_ABI_VERSION 33
+#define NAF_HIP_ABI_VERSION 34
 int naf_hip_abi_version(void);
 /* "gfx950" — the only architecture this library carries code objects for */
 const char* naf_hip_arch(void);
@@ -587,10 +587,12 @@ typedef struct naf_step_prefetch {
  *   The verdict {ordinal, valid} goes to host_spec in ONE 8-byte store behind an agent-scope release of everything the workgroup
  *   wrote: a host that has read it may launch, on any stream, work that reads the minibatch, the ring or the counters.
  * naf_step_launch: naf_host_publish (bytes == 0: nothing to publish) + hipGraphLaunch(graph_exec, stream) + naf_step_prefetch(
- *   prefetch, side_stream) (prefetch == NULL: none) — one timestep of NAFAgent.step() in one trip through the FFI. */
+ *   prefetch, side_stream) (prefetch == NULL: none) — one timestep of NAFAgent.step() in one trip through the FFI.
+ *   prefetch_first != 0: the prefetch is launched BEFORE the graph (neither reads what the other writes): its verdict reaches the
+ *   host 8 us sooner — the time hipGraphLaunch keeps the calling thread — and the action as much later. */
 int naf_step_prefetch(const naf_step_prefetch_t* prefetch, void* stream);
 int naf_step_launch(void* dst_device, const void* src_host, size_t bytes, void* graph_exec, void* stream,
-                    const naf_step_prefetch_t* prefetch, void* side_stream);
+                    const naf_step_prefetch_t* prefetch, void* side_stream, int prefetch_first);
 typedef struct naf_act_net {
     int S, A, H, NHP, HP;
     int64_t off_W1, off_b1, off_g1, off_be1, off_W2, off_b2, off_g2, off_be2, off_Wh;

@@ -228,7 +228,7 @@ _PROTOS = {
     "naf_host_store_free": [_vp],
     "naf_host_store_selftest": [_vp, _i, _vp],
     "naf_step_prefetch": [_vp, _vp],
-    "naf_step_launch": [_vp, _vp, _sz, _vp, _vp, _vp, _vp],
+    "naf_step_launch": [_vp, _vp, _sz, _vp, _vp, _vp, _vp, C.c_int],
     "naf_adam_polyak_act": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "naf_adam_polyak_act_layer1": [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "naf_xgmi_chunk_floats": [],

@@ -729,6 +729,9 @@ __device__ static inline void aa_count_timeout(const AdamActArgs& P) {
 // L1K4 (round 6): 6 | 8 = the next update's layer 1 rides on this launch (L1RideArgs above; K4 = 6 | 8 float4 of state, L1FULL: whole
 // 64-row blocks): L1.n_main more workgroups behind the last one, 512 threads each (bb_layer1_impl<.., ADAM = true, ..>). 0: no riders,
 // the kernel as it was.
+#ifndef AA_EARLY_RIDE_OUT
+#define AA_EARLY_RIDE_OUT 1               // (0: the last workgroup counts itself out at its end, as the riders' first form did — A/B)
+#endif
 template <int PMODE, int SPEC, int G = 8, int HV = AA_H, int L1K4 = 0, bool L1FULL = true>
 __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kernel(const AdamActArgs P, const StepPrepArgs SP, const L1RideArgs L1) {
     static_assert(L1K4 == 0 || SPEC == 0, "layer 1 rides on the launch without the prefetching workgroup");
@@ -773,14 +776,18 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
     // Nobody waits for the launch's end: every party that uses these words — the riders, the layer-1 workgroups, the last workgroup —
     // counts itself out in `l1_done`, and the LAST one out clears the words and moves the launch's ordinal (one that starts late must
     // still read the old one; a wait for the riders in the last workgroup cost the launch 2 us: a flag takes that long to cross the chip)
-    auto ride_out = [&]() {
-        if (__hip_atomic_fetch_add(l1_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L1.n_main + L1_WGS) {
+    // (in two halves: the count comes back across the chip, 1.2 us — a party with work left issues it BEHIND ITS LAST USE of the words and
+    //  looks at the answer when it leaves)
+    auto ride_out_begin = [&]() { return __hip_atomic_fetch_add(l1_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ride_out_end = [&](int before) {
+        if (before == L1.n_main + L1_WGS) {
             __hip_atomic_store(l1_arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(l1_loaded, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(l1_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             P.sync[0] = epoch;
         }
     };
+    auto ride_out = [&]() { ride_out_end(ride_out_begin()); };
     if (tid == 0) sTimed = 0;
     const int wh_wgs = P.wh_wgs;                        // workgroups that step Wh: ceil(NHP * HP / 4 / AA_THREADS)
     const bool tl_l2 = wg == L1_WGS + wh_wgs;           // (timeline: the first layer-2 workgroup leaves slots 8 ...)
@@ -1057,6 +1064,14 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
         }
         __syncthreads();
         AA_TL(2);
+        // The last workgroup counts itself out of the riders' words HERE: every workgroup of the launch has started (the records
+        // above are the layer-2 workgroups', the arrivals the heads' weights'), so the launch's ordinal may move, and this workgroup
+        // does not touch the words again. The answer is read at the very end — waited for there, the count's way across the chip was
+        // the launch's last 1.2 us (r06_step_timeline_b256: action stored at 8.6 us, end at 9.85).
+        int rode = 0;
+        if constexpr (L1K4 != 0 && AA_EARLY_RIDE_OUT != 0) {
+            if (tid == 0) rode = ride_out_begin();
+        }
         const bool timed = sTimed != 0;
         const aa_f4 x = *(const aa_f4*)(sAct + 4 * lane);
         float ph[HL / 8];
@@ -1100,7 +1115,7 @@ __global__ __launch_bounds__(SPEC ? SP_THREADS : AA_THREADS) void adam_act_kerne
             if (tid == 0) {
                 if (timed) aa_count_timeout(P);
                 *P.counter_dev = ctr + 1;
-                if constexpr (L1K4 != 0) ride_out();        // (the last party out moves the ordinal)
+                if constexpr (L1K4 != 0) ride_out_end(AA_EARLY_RIDE_OUT != 0 ? rode : ride_out_begin());    // (the last party out moves the ordinal)
                 else P.sync[0] = epoch;
             }
             if (P.host_seq) {
@@ -1367,16 +1382,25 @@ extern "C" int naf_step_prefetch(const naf_step_prefetch_t* prefetch, void* stre
 // One timestep of the pipelined path in ONE foreign call: the transition row into device memory (naf_host_publish), the timestep's
 // graph on `stream`, and — prefetch != NULL — the append + depth-2 prefetch on `side_stream`, beside the graph.
 extern "C" int naf_step_launch(void* dst_device, const void* src_host, size_t bytes, void* graph_exec, void* stream,
-                               const naf_step_prefetch_t* prefetch, void* side_stream) {
+                               const naf_step_prefetch_t* prefetch, void* side_stream, int prefetch_first) {
     if (!graph_exec) return NAF_ERR_ARG;
     if (bytes) {
         if (!dst_device || !src_host) return NAF_ERR_ARG;
         memcpy(dst_device, src_host, bytes);
         __builtin_ia32_sfence();
     }
+    // Which of the two launches goes first is free (neither reads what the other writes: engine._Pipeline's docstring) and decides what
+    // the host gets sooner: hipGraphLaunch keeps this thread 8 us, so the launch behind it starts 8 us late. The graph first: the
+    // action. The prefetch first: its verdict, which the host must have read before the NEXT call — the caller asks for that when it
+    // had to wait for the last one (see _Pipeline.collect: the loop has a second stable state in which every tick waits for a
+    // verdict that left 8 us late because the tick before did)
+    if (prefetch && prefetch_first) {
+        const int rc = spf_launch(prefetch, (hipStream_t)side_stream);
+        if (rc != NAF_OK) return rc;
+    }
     hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    return prefetch ? spf_launch(prefetch, (hipStream_t)side_stream) : NAF_OK;
+    return prefetch && !prefetch_first ? spf_launch(prefetch, (hipStream_t)side_stream) : NAF_OK;
 }
 
 extern "C" int naf_adam_polyak_act_sync_ints(void) { return AA_SYNC_RIDE + 128; }     // (the 512-wide launch's records, the riders' words)

@@ -534,6 +534,13 @@ class _Pipeline:
         self._exec = self._exec_fast = None
         r._side_join = self.join                   # (ReplayBuffer's own launches read what the side stream writes)
         self.l1_ride = os.environ.get("NAF_STEP_L1_RIDE", "1") != "0"      # (tests / A-B only: layer 1 as a launch of its own)
+        # The loop host -> launch -> action -> env.step -> verdict -> launch has TWO stable states at B = 256, where the side launch
+        # runs 17 us: one in which the verdict is in when the host asks (35 us per timestep), and one in which every tick waits 10 us
+        # for a verdict that left late because the tick before waited too (43 us; a host hiccup is enough to fall into it, and whole
+        # processes stayed in it: benchmarks/debug/api_step_histogram.py). A tick that had to wait launches the prefetch BEFORE the
+        # graph (naf_step_launch, prefetch_first): its verdict leaves 8 us sooner, the host gets ahead again.
+        self.waited = False                        # the last collect() found a verdict missing
+        self.side_first_runs = 0
         self._l1_args = [None, None, None]
 
     def state(self) -> tuple:
@@ -642,9 +649,11 @@ class _Pipeline:
     def collect(self) -> None:
         """read every verdict the launches so far owe (a few microseconds behind the action of the launch they rode beside)"""
         hs = self._hs
+        self.waited = False
         for k, want in self.owed:
             n = 0
             v = int(hs[k])
+            self.waited = self.waited or (v & 0xFFFFFFFF) != want
             while (v & 0xFFFFFFFF) != want:
                 n += 1
                 if n > 2000000:                 # (something is wrong: let the runtime say what)
@@ -695,7 +704,8 @@ class _Pipeline:
             if self._exec_fast is not None:
                 # the row into device memory, the graph and the side launch in ONE foreign call
                 rc = self._launch(hd.ptr, hd._src, hd.n_bytes, self._exec_fast[p], cur.cuda_stream, _lib.C.byref(self._pf_side[p]),
-                                  self.side.cuda_stream)
+                                  self.side.cuda_stream, 1 if self.waited else 0)
+                self.side_first_runs += self.waited
                 if rc:
                     check(rc, "naf_step_launch")
             else:
@@ -712,7 +722,7 @@ class _Pipeline:
         # the order of the memory operations, not for time)
         cur.wait_stream(self.side)
         if self._exec is not None:
-            rc = self._launch(hd.ptr, hd._src, hd.n_bytes, self._exec, cur.cuda_stream, None, None)
+            rc = self._launch(hd.ptr, hd._src, hd.n_bytes, self._exec, cur.cuda_stream, None, None, 0)
             if rc:
                 check(rc, "naf_step_launch")
         else:
