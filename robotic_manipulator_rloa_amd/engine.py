@@ -705,13 +705,16 @@ class _Pipeline:
                 # the row into device memory, the graph and the side launch in ONE foreign call
                 rc = self._launch(hd.ptr, hd._src, hd.n_bytes, self._exec_fast[p], cur.cuda_stream, _lib.C.byref(self._pf_side[p]),
                                   self.side.cuda_stream, 1 if self.waited else 0)
-                self.side_first_runs += self.waited
                 if rc:
                     check(rc, "naf_step_launch")
             else:
                 hd.publish()
+                if self.waited:
+                    check(tg.L.lib.naf_step_prefetch(_lib.C.byref(self._pf_side[p]), self.side.cuda_stream), "naf_step_prefetch")
                 self.graph_fast[p].replay()
-                check(tg.L.lib.naf_step_prefetch(_lib.C.byref(self._pf_side[p]), self.side.cuda_stream), "naf_step_prefetch")
+                if not self.waited:
+                    check(tg.L.lib.naf_step_prefetch(_lib.C.byref(self._pf_side[p]), self.side.cuda_stream), "naf_step_prefetch")
+            self.side_first_runs += self.waited
             self.n_verdicts += 1
             self.owed = [(k, self.n_verdicts & 0xFFFFFFFF)]
             self.valid[k] = False

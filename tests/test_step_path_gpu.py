@@ -564,6 +564,51 @@ def test_per_timestep_path_is_the_separate_launches_and_the_chunked_path_bit_for
 
 
 
+@pytest.mark.parametrize("B", [64, 256])
+def test_pipelined_path_is_the_same_bits_whichever_of_its_two_launches_goes_first(scratch_cwd, monkeypatch, B):
+    """naf_step_launch(..., prefetch_first): a tick whose verdict the host had to wait for launches the prefetch BEFORE the graph
+    (engine._Pipeline.waited; DESIGN 4d, "two stable states"). Which ticks do depends on timing — here both orders are forced for a
+    whole run each and held against the twelve-launch loop: every action, the parameters, Adam's state, the BatchNorm buffers, the ring."""
+    from robotic_manipulator_rloa_amd import engine
+    from robotic_manipulator_rloa_amd.naf_components.naf_algorithm import NAFAgent
+    S, A, N, T = 21, 6, 20000, 400
+    inner = engine._Pipeline.collect
+    runs = []
+    for form, first in (("pipelined", True), ("pipelined", False), ("separate", None)):
+        monkeypatch.setenv("NAF_STEP_FORM", form)
+        if first is not None:
+            def collect(self, _first=first):
+                inner(self)
+                self.waited = _first
+            monkeypatch.setattr(engine._Pipeline, "collect", collect)
+        agent = NAFAgent(object(), S, A, 256, B, N, 1e-3, 1e-3, 0.99, 1, 1, 500, DEV, 0)
+        # (a ring of 6000 rows before the first timestep: the prefetches hold in all but a few percent of the ticks)
+        rng = np.random.default_rng(5)
+        m = agent.memory
+        r = np.zeros((6000, m.row_floats), np.float32)
+        r[:, :S] = rng.standard_normal((6000, S))
+        r[:, S:S + A] = rng.uniform(-1, 1, (6000, A))
+        r[:, S + A] = -rng.random(6000)
+        r[:, m.off_s2:m.off_s2 + S] = r[:, :S]
+        m.add_rows_device(torch.from_numpy(r).to(DEV), 6000)
+        acts = _drive(agent, 33, 0, T, None)
+        ch = agent._chunk
+        if first is not None:
+            assert ch.pipelined and ch.fast_runs >= T * 3 // 4, (ch.fast_runs, ch.slow_runs)
+            assert ch.pipe.side_first_runs == (ch.fast_runs if first else 0), (ch.pipe.side_first_runs, ch.fast_runs)
+            assert not any(ch.error_words().values()), ch.error_words()
+        L = agent.learner
+        runs.append(dict(acts=acts, theta=L.theta2.clone(), m=L.adam_m.clone(), v=L.adam_v.clone(), bn=L.bn_stats.clone(),
+                         ring=agent.memory.rows.clone(), meta=agent.memory.meta.clone(), step=int(L.step_dev.item()), loss=agent.last_loss()))
+    a = runs[2]
+    for b in runs[:2]:
+        assert a["step"] == b["step"] == T
+        np.testing.assert_array_equal(a["acts"], b["acts"])
+        for k in ("theta", "m", "v", "bn", "ring", "meta"):
+            assert torch.equal(a[k], b[k]), k
+        assert a["loss"] == b["loss"] and torch.isfinite(b["theta"]).all()
+
+
 @pytest.mark.parametrize("tag", ["kuka64", "kuka"])
 def test_agent_step_on_the_reference_goldens_minibatches(scratch_cwd, monkeypatch, tag):
     """A direct pin of the per-timestep path on the unmodified reference's learn() (G3: Q, 14 gradients' norm, parameters and
