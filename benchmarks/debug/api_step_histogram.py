@@ -25,6 +25,7 @@ m.add_rows_device(torch.from_numpy(r).cuda(), 100000)
 state = env.reset(False)
 # ORDER=auto (the product: the prefetch goes first on a tick whose verdict the host had to wait for) | graph | prefetch (always that one first)
 ORDER = os.environ.get("ORDER", "auto")
+ENV_US = float(os.environ.get("ENV_US", "0"))
 def force_order():
     pipe = getattr(agent._chunk, "pipe", None)
     if pipe is None or ORDER == "auto":
@@ -44,6 +45,8 @@ def steps(n, rec):
         a = agent.act(state)
         t1 = pc()
         nxt, rw, d = env.step(a)
+        while ENV_US and (pc() - t1) * 1e6 < ENV_US:      # (a slower environment: busy waiting, as bench.py's env_100us leg)
+            pass
         t2 = pc()
         agent.step(state, a, rw, nxt, d)
         state = env.reset(False) if d else nxt
