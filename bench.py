@@ -531,7 +531,10 @@ def extras(dev, args):
                 in_graph = 5 if getattr(ch.pipe, "l1_ride", False) else 6
                 out["launches_per_timestep"] = round((in_graph * ch.fast_runs + 13 * ch.slow_runs) / runs, 2)
                 out["launches_beside_the_graph_per_timestep"] = round(ch.fast_runs / runs, 2)
-                out["pipelined"] = {"timesteps_on_the_prefetched_minibatch": ch.fast_runs, "timesteps_that_started_over": ch.slow_runs}
+                out["pipelined"] = {"timesteps_on_the_prefetched_minibatch": ch.fast_runs, "timesteps_that_started_over": ch.slow_runs,
+                                    # (ticks whose prefetch was launched BEFORE the graph because the host had waited for the last
+                                    #  verdict: DESIGN 4d, "two stable states")
+                                    "timesteps_with_the_prefetch_launched_first": getattr(ch.pipe, "side_first_runs", 0)}
             if ch is not None and hasattr(ch, "error_words"):
                 # the path's hand-overs fail loudly: polls inside naf_adam_polyak_act that ran into their bound, timesteps whose
                 # record did not hold on the device although the host had read that it does, host-side waits that had to synchronise
