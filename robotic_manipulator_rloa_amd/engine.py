@@ -523,6 +523,8 @@ class _Pipeline:
         self.host_spec = torch.zeros(3, 2, dtype=torch.int32).pin_memory()
         self._hs = self.host_spec.numpy().view(np.uint64).reshape(3)       # {ordinal, valid}: ONE 8-byte store of the launch, one load here
         self.side = torch.cuda.Stream(device=dev)
+        self._side_raw = self.side.cuda_stream
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         self.phase = 0
         self.valid = [False, False, False]
         self.owed: List[Tuple[int, int]] = []      # (set, ordinal) of verdicts launched and not read yet
@@ -696,24 +698,25 @@ class _Pipeline:
         fast = self.decide(brings_row)
         if self.agree is not None:
             fast = self.agree.all_ok(fast)     # (every rank, every tick: an exchange pairs with an exchange)
-        cur = torch.cuda.current_stream()
         hd = tg.head_dev
         if fast:
             p = self.phase
             k = (p + 2) % 3
             if self._exec_fast is not None:
                 # the row into device memory, the graph and the side launch in ONE foreign call
-                rc = self._launch(hd.ptr, hd._src, hd.n_bytes, self._exec_fast[p], cur.cuda_stream, _lib.C.byref(self._pf_side[p]),
-                                  self.side.cuda_stream, 1 if self.waited else 0)
+                # (the current stream as its raw handle: torch.cuda.current_stream() is 2.6 us of Python per timestep — it asks for the
+                #  device count on its way — in a loop whose host side and GPU side are 35 and 35.5 us: benchmarks/debug/torch_call_costs.py)
+                rc = self._launch(hd.ptr, hd._src, hd.n_bytes, self._exec_fast[p], torch._C._cuda_getCurrentRawStream(self._dev_index),
+                                  _lib.C.byref(self._pf_side[p]), self._side_raw, 1 if self.waited else 0)
                 if rc:
                     check(rc, "naf_step_launch")
             else:
                 hd.publish()
                 if self.waited:
-                    check(tg.L.lib.naf_step_prefetch(_lib.C.byref(self._pf_side[p]), self.side.cuda_stream), "naf_step_prefetch")
+                    check(tg.L.lib.naf_step_prefetch(_lib.C.byref(self._pf_side[p]), self._side_raw), "naf_step_prefetch")
                 self.graph_fast[p].replay()
                 if not self.waited:
-                    check(tg.L.lib.naf_step_prefetch(_lib.C.byref(self._pf_side[p]), self.side.cuda_stream), "naf_step_prefetch")
+                    check(tg.L.lib.naf_step_prefetch(_lib.C.byref(self._pf_side[p]), self._side_raw), "naf_step_prefetch")
             self.side_first_runs += self.waited
             self.n_verdicts += 1
             self.owed = [(k, self.n_verdicts & 0xFFFFFFFF)]
@@ -721,6 +724,7 @@ class _Pipeline:
             self.phase = (p + 1) % 3
             self.fast_runs += 1
             return
+        cur = torch.cuda.current_stream()
         # start over, everything on the current stream (the side stream is idle: its verdicts have been read — the wait is for
         # the order of the memory operations, not for time)
         cur.wait_stream(self.side)
