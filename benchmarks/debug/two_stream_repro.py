@@ -1,3 +1,5 @@
+"""Needs benchmarks/probe/two_streams_product.patch applied (NAF_STEP_TWO_STREAMS=1: the graphs of consecutive timesteps on two alternating
+streams; NOTEBOOK section 11.20): three agents in a row, both launch orders, the streams' handles and the order words printed."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
